@@ -1,0 +1,283 @@
+// libbbdecode.so -- C ABI over the gfx950 kernels.  See include/bbdecode.h.
+// Single translation unit: the kernel headers share the __device__ level
+// tables defined in bb_common.h.
+#include "bb_common.h"
+#include "k_scan.h"
+#include "k_flat.h"
+
+#include <atomic>
+#include <mutex>
+#include <string.h>
+
+namespace {
+
+thread_local int t_last_hip = 0;
+
+inline int hip_fail(hipError_t e) { t_last_hip = (int)e; return BB_EIO; }
+#define BB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_); } while (0)
+
+// ---- level tables ---------------------------------------------------------
+float h_levels[3][4][256];
+std::once_flag h_levels_once;
+
+void fill_host_levels()
+{
+    memset(h_levels, 0, sizeof(h_levels));
+    // base/encoding.py:14  OPTIMAL_2BIT_HIGH = 3.316505 -> float32
+    const volatile float hi = 3.316505f;
+    // VDIF, offset binary (base/encoding.py:52-56; vdif/payload.py:53-63)
+    h_levels[BB_CODER_VDIF][0][0] = -1.0f; h_levels[BB_CODER_VDIF][0][1] = 1.0f;
+    h_levels[BB_CODER_VDIF][1][0] = -hi;   h_levels[BB_CODER_VDIF][1][1] = -1.0f;
+    h_levels[BB_CODER_VDIF][1][2] = 1.0f;  h_levels[BB_CODER_VDIF][1][3] = hi;
+    const volatile float four_bit_1_sigma = 2.95f;       // base/encoding.py:46
+    for (int n = 0; n < 16; ++n) {
+        volatile float x = (float)n;
+        x = x - 8.0f;
+        x = x / four_bit_1_sigma;                         // true IEEE division
+        h_levels[BB_CODER_VDIF][2][n] = x;
+    }
+    const volatile float eight_bit_1_sigma = 35.5f;      // base/encoding.py:48
+    for (int n = 0; n < 256; ++n) {                       // base/encoding.py:141-143
+        volatile float x = (float)n;
+        x = x - 127.5f;
+        x = x / eight_bit_1_sigma;
+        h_levels[BB_CODER_VDIF][3][n] = x;
+    }
+    // Mark 5B, sign/magnitude (mark5b/payload.py:60-66)
+    h_levels[BB_CODER_MARK5B][0][0] = 1.0f; h_levels[BB_CODER_MARK5B][0][1] = -1.0f;
+    h_levels[BB_CODER_MARK5B][1][0] = -hi;  h_levels[BB_CODER_MARK5B][1][1] = 1.0f;
+    h_levels[BB_CODER_MARK5B][1][2] = -1.0f; h_levels[BB_CODER_MARK5B][1][3] = hi;
+    // two's complement integers (gsb/payload.py:24-42; dada/payload.py:13-14)
+    for (int n = 0; n < 16; ++n)  h_levels[BB_CODER_INT][2][n] = (float)(n < 8 ? n : n - 16);
+    for (int n = 0; n < 256; ++n) h_levels[BB_CODER_INT][3][n] = (float)(int8_t)(uint8_t)n;
+}
+
+inline int log2_bps(int bps)
+{
+    switch (bps) { case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3; default: return -1; }
+}
+
+bool coder_supported(int coder, int bps)
+{
+    if (log2_bps(bps) < 0) return false;
+    switch (coder) {
+        case BB_CODER_VDIF:   return true;
+        case BB_CODER_MARK5B: return bps == 1 || bps == 2;
+        case BB_CODER_INT:    return bps == 4 || bps == 8;
+        default: return false;
+    }
+}
+
+std::atomic<uint64_t> g_dev_inited{0};
+std::mutex g_init_mutex;
+
+int ensure_init()
+{
+    int dev = 0;
+    BB_HIP(hipGetDevice(&dev));
+    if (dev < 64 && (g_dev_inited.load(std::memory_order_acquire) >> dev) & 1) return BB_OK;
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    std::call_once(h_levels_once, fill_host_levels);
+    BB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_levels), h_levels, sizeof(h_levels)));
+    if (dev < 64) g_dev_inited.fetch_or(1ull << dev, std::memory_order_release);
+    return BB_OK;
+}
+
+int device_levels(int coder, int lb, const float **p)
+{
+    float *base = nullptr;
+    BB_HIP(hipGetSymbolAddress((void **)&base, HIP_SYMBOL(g_levels)));
+    *p = base + ((size_t)coder * 4 + lb) * 256;
+    return BB_OK;
+}
+
+// ---- tuning ----------------------------------------------------------------
+std::atomic<int> g_tune_variant{0};
+std::atomic<int> g_tune_nt{1};
+std::atomic<int> g_tune_blocks{0};
+
+template <int BPS, int LV>
+void launch_flat(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+#define BB_L(OM, NT) hipLaunchKernelGGL((k_decode_flat<BPS, LV, OM, NT>), grid, dim3(BB_BLOCK), 0, st, a)
+    if (om == BB_OUT_FLAT)       { if (nt) BB_L(BB_OUT_FLAT, true);    else BB_L(BB_OUT_FLAT, false); }
+    else if (om == BB_OUT_ROWS4) { if (nt) BB_L(BB_OUT_ROWS4, true);   else BB_L(BB_OUT_ROWS4, false); }
+    else                         { if (nt) BB_L(BB_OUT_SCATTER, true); else BB_L(BB_OUT_SCATTER, false); }
+#undef BB_L
+}
+
+} // namespace
+
+extern "C" {
+
+int bb_abi_version(void) { return BB_ABI_VERSION; }
+
+const char *bb_strerror(int code)
+{
+    switch (code) {
+        case BB_OK:      return "success";
+        case BB_EIO:     return "HIP runtime call failed";
+        case BB_EINVAL:  return "invalid argument";
+        case BB_ERANGE:  return "buffer too small or index out of range";
+        case BB_ENOTSUP: return "unsupported coder / bits per sample / mode";
+        default:         return "unknown error";
+    }
+}
+
+int bb_last_hip_error(void) { return t_last_hip; }
+
+int bb_init(void) { return ensure_init(); }
+
+int bb_get_levels(int coder, int bps, float *h_out, size_t n)
+{
+    if (!h_out) return BB_EINVAL;
+    if (!coder_supported(coder, bps)) return BB_ENOTSUP;
+    if (n < ((size_t)1 << bps)) return BB_ERANGE;
+    std::call_once(h_levels_once, fill_host_levels);
+    memcpy(h_out, h_levels[coder][log2_bps(bps)], sizeof(float) << bps);
+    return BB_OK;
+}
+
+int bb_tune(int knob, int value)
+{
+    switch (knob) {
+        case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
+        case BB_TUNE_NT_STORES:    g_tune_nt = value;      return BB_OK;
+        case BB_TUNE_BLOCKS:       g_tune_blocks = value;  return BB_OK;
+        default: return BB_EINVAL;
+    }
+}
+
+int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
+                 bb_frame_rec *d_recs, size_t nframes, void *stream)
+{
+    if (!d_buf || !p || !d_recs) return BB_EINVAL;
+    if (p->header_nbytes != 32 && p->header_nbytes != 16) return BB_EINVAL;
+    if (p->frame_nbytes < p->header_nbytes || (p->frame_nbytes & 7)) return BB_EINVAL;
+    if ((p->first_offset & 3) || ((uintptr_t)d_buf & 3)) return BB_EINVAL;
+    if (nframes == 0) return BB_OK;
+    const uint64_t threads = (uint64_t)nframes * 8;
+    const uint64_t blocks = (threads + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 0x7fffffffull) return BB_ERANGE;
+    hipLaunchKernelGGL(k_vdif_scan, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_mark5b_scan(const void *d_buf, size_t nbytes, const bb_mark5b_scan_params *p,
+                   bb_frame_rec *d_recs, size_t nframes, void *stream)
+{
+    if (!d_buf || !p || !d_recs) return BB_EINVAL;
+    if ((p->first_offset & 3) || ((uintptr_t)d_buf & 3)) return BB_EINVAL;
+    if (nframes == 0) return BB_OK;
+    const uint64_t blocks = ((uint64_t)nframes + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
+    if (blocks > 0x7fffffffull) return BB_ERANGE;
+    hipLaunchKernelGGL(k_mark5b_scan, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_build_index(const bb_frame_rec *d_recs, size_t nrecs,
+                   const int16_t *d_thread_slot, int nslot,
+                   int64_t *d_src, size_t nframes_out, void *stream)
+{
+    if (!d_src || nslot < 1 || (nrecs && !d_recs)) return BB_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (nframes_out)
+        BB_HIP(hipMemsetAsync(d_src, 0xff, nframes_out * (size_t)nslot * sizeof(int64_t), st));
+    if (nrecs == 0) return BB_OK;
+    const uint64_t blocks = ((uint64_t)nrecs + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 0x7fffffffull) return BB_ERANGE;
+    hipLaunchKernelGGL(k_build_index, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, st,
+                       d_recs, (uint64_t)nrecs, d_thread_slot, nslot, d_src, (uint64_t)nframes_out);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
+                     const int64_t *d_src, size_t nframes,
+                     const bb_decode_params *p,
+                     float *d_out, size_t out_elems, void *stream)
+{
+    if (!p) return BB_EINVAL;
+    if (!coder_supported(p->coder, p->bps)) return BB_ENOTSUP;
+    if (!d_buf || !d_out) return BB_EINVAL;
+    if (p->nslot < 1 || p->chunk < 1) return BB_EINVAL;
+    if (p->payload_nbytes == 0 || (p->payload_nbytes & 3)) return BB_EINVAL;
+    if (((uintptr_t)d_buf & 3) || ((uintptr_t)d_out & 15)) return BB_EINVAL;
+    const uint64_t E = p->payload_nbytes * 8 / (uint64_t)p->bps;
+    const uint64_t nfs = (uint64_t)nframes * (uint64_t)p->nslot;
+    uint32_t lchunk = 0;
+    int om = BB_OUT_FLAT;
+    if (p->nslot > 1) {
+        if (p->chunk & (p->chunk - 1)) return BB_ENOTSUP;   // VDIF nchan is 2^k
+        while ((1u << lchunk) < (uint32_t)p->chunk) ++lchunk;
+        if (E % (uint64_t)p->chunk) return BB_EINVAL;
+        om = (p->chunk % 4 == 0) ? BB_OUT_ROWS4 : BB_OUT_SCATTER;
+    }
+    if (out_elems < nfs * E) return BB_ERANGE;
+    if (!d_src) {
+        if ((p->src0 & 3) || (p->src_stride & 3) || p->src0 < 0 || p->src_stride < 0) return BB_EINVAL;
+        if (nfs && (uint64_t)p->src0 + (nfs - 1) * (uint64_t)p->src_stride + p->payload_nbytes > buf_nbytes)
+            return BB_ERANGE;
+    }
+    if (nfs == 0) return BB_OK;
+    int rc = ensure_init();
+    if (rc) return rc;
+
+    const int lb = log2_bps(p->bps);
+    bb_flat_args a;
+    a.buf = (const uint8_t *)d_buf;
+    a.src = d_src;
+    a.out = d_out;
+    rc = device_levels(p->coder, lb, &a.tab);
+    if (rc) return rc;
+    a.nfs = nfs;
+    a.ndw = p->payload_nbytes / 4;
+    const uint64_t ntiles = (a.ndw + 63) / 64;
+    a.nseg = (ntiles + BB_SEG_TILES - 1) / BB_SEG_TILES;
+    a.src0 = p->src0;
+    a.src_stride = p->src_stride;
+    a.nslot = (uint32_t)p->nslot;
+    a.chunk = (uint32_t)p->chunk;
+    a.lchunk = lchunk;
+    a.fill_re = p->fill_re;
+    a.fill_im = p->fill_im;
+    a.complex_data = p->complex_data;
+
+    const uint64_t nwork = nfs * a.nseg;
+    uint64_t blocks = nwork;
+    const int tb = g_tune_blocks.load();
+    if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
+    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+    const dim3 grid((unsigned)blocks);
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = g_tune_nt.load() != 0;
+
+    if (g_tune_variant.load() == 1 && p->bps == 2 && om == BB_OUT_FLAT) {
+        uint64_t b2 = nfs;
+        if (tb > 0 && b2 > (uint64_t)tb) b2 = (uint64_t)tb;
+        if (b2 > 0x7fffffffull) b2 = 0x7fffffffull;
+        if (nt) hipLaunchKernelGGL(k_decode_flat2_bytes<true>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
+        else    hipLaunchKernelGGL(k_decode_flat2_bytes<false>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
+
+    switch (p->bps) {
+        case 1: launch_flat<1, BB_LV_REG>(om, nt, grid, st, a); break;
+        case 2: launch_flat<2, BB_LV_REG>(om, nt, grid, st, a); break;
+        case 4: launch_flat<4, BB_LV_LDS>(om, nt, grid, st, a); break;
+        case 8:
+            if (p->coder == BB_CODER_INT) launch_flat<8, BB_LV_INT8>(om, nt, grid, st, a);
+            else                          launch_flat<8, BB_LV_LDS>(om, nt, grid, st, a);
+            break;
+        default: return BB_ENOTSUP;
+    }
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,216 @@
+// Flat LUT decode: packed 1/2/4/8-bit codes -> float32, whole frames.
+//
+// Replaces (reference, path:line): lut.take(words.view(u1), axis=0)
+// (vdif/payload.py:69-103, mark5b/payload.py:78-94), decode_8bit
+// (base/encoding.py:131-144), int8.astype(f32) (dada/payload.py:13-14,
+// gsb/payload.py:39-42), the sign-extending nibble split of
+// gsb/payload.py:24-36, PayloadBase._decode (base/payload.py:314-330), the
+// frameset thread interleave (vdif/frame.py:402-434) and the invalid-frame
+// fill (base/frame.py:191-199).
+//
+// Shape (gfx950): one workgroup (4 waves) per frame-slot segment.  A wave
+// reads a 256-byte tile with one coalesced dword-per-lane load, then emits
+// 8/bps store passes.  In every pass lane l writes the float4 holding
+// elements [256p + 4l, 256p + 4l + 4) of the tile, so each store instruction
+// covers 1 KiB of contiguous output (8 full 128-byte lines).  The packed bits
+// a lane needs sit in another lane's dword; they are fetched with one
+// ds_bpermute (__shfl) per pass -- no LDS allocation, no barrier.
+#pragma once
+#include "bb_common.h"
+
+enum { BB_OUT_FLAT = 0,     // nslot == 1: frame output is contiguous
+       BB_OUT_ROWS4 = 1,    // nslot > 1, chunk % 4 == 0: float4 stays in a row chunk
+       BB_OUT_SCATTER = 2 };// nslot > 1, chunk < 4: scalar stores (correctness path)
+
+enum { BB_LV_REG = 0,       // 2 or 4 levels held in registers (bps 1, 2)
+       BB_LV_LDS = 1,       // 16 / 256 entry table in LDS (bps 4; VDIF bps 8)
+       BB_LV_INT8 = 2 };    // int8 -> f32 conversion (no table)
+
+#define BB_SEG_TILES 32     // tiles (of 256 input bytes) per workgroup work item
+#define BB_FLAT_UNROLL 4
+
+struct bb_flat_args {
+    const uint8_t *buf;
+    const int64_t *src;     // [nfs] payload offsets, -1 = fill; may be null
+    float         *out;
+    const float   *tab;     // g_levels[coder][log2 bps]
+    uint64_t nfs;           // nframes * nslot
+    uint64_t ndw;           // payload dwords per frame-slot
+    uint64_t nseg;          // work items per frame-slot
+    int64_t  src0, src_stride;
+    uint32_t nslot, chunk, lchunk;
+    float    fill_re, fill_im;
+    int32_t  complex_data;
+};
+
+template <int BPS, int LV>
+struct bb_levels {
+    float t0, t1, t2, t3;
+    const float *lds;
+    __device__ __forceinline__ float get(uint32_t code) const {
+        if (LV == BB_LV_REG) {
+            if (BPS == 1) return code ? t1 : t0;
+            const float lo = (code & 1) ? t1 : t0;
+            const float hi = (code & 1) ? t3 : t2;
+            return (code & 2) ? hi : lo;
+        } else if (LV == BB_LV_LDS) {
+            return lds[code];
+        } else {
+            return (float)(int)(int8_t)code;
+        }
+    }
+};
+
+template <int BPS, int LV, int OM, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_flat(bb_flat_args a)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr int EPT = 2048 / BPS;         // elements per 256-byte tile
+    constexpr int PASSES = 8 / BPS;         // store passes per tile
+    constexpr uint32_t CMASK = NCODE - 1;
+    __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
+
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
+        __syncthreads();
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+
+    const int lane = bb_lane();
+    const int wave = bb_wave();
+    const uint64_t E = a.ndw * (32 / BPS);          // elements per frame-slot
+    const uint64_t ntiles = (a.ndw + 63) / 64;
+    const uint64_t nwork = a.nfs * a.nseg;
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+    // lane-constant shuffle geometry
+    const int src_lane0 = (lane * BPS) >> 3;
+    const int shift = (4 * lane * BPS) & 31;
+
+    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+        uint64_t fs, seg;
+        if (a.nseg == 1) { fs = work; seg = 0; }
+        else { fs = work / a.nseg; seg = work - fs * a.nseg; }
+        const int64_t so = a.src ? a.src[fs] : a.src0 + (int64_t)fs * a.src_stride;
+        const bool valid = so >= 0;
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(a.buf + (valid ? so : 0));
+
+        float *obase;           // FLAT: start of this frame-slot's output
+        uint64_t rowbase = 0, slot = 0;
+        if (OM == BB_OUT_FLAT) {
+            obase = a.out + fs * E;
+        } else {
+            const uint64_t f = fs / a.nslot;
+            slot = fs - f * a.nslot;
+            rowbase = f * (E >> a.lchunk);
+            obase = a.out;
+        }
+
+        const uint64_t tile_begin = seg * BB_SEG_TILES;
+        const uint64_t tile_end = (tile_begin + BB_SEG_TILES < ntiles)
+                                  ? tile_begin + BB_SEG_TILES : ntiles;
+        for (uint64_t t = tile_begin + wave; t < tile_end;
+             t += BB_WAVES_PER_BLOCK * BB_FLAT_UNROLL) {
+            uint32_t w[BB_FLAT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BB_FLAT_UNROLL; ++u) {
+                const uint64_t tile = t + (uint64_t)u * BB_WAVES_PER_BLOCK;
+                const uint64_t dw = tile * 64 + lane;
+                w[u] = (valid && tile < tile_end && dw < a.ndw) ? in[dw] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < BB_FLAT_UNROLL; ++u) {
+                const uint64_t tile = t + (uint64_t)u * BB_WAVES_PER_BLOCK;
+                if (tile >= tile_end) break;            // wave-uniform
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    uint32_t bits;
+                    if (BPS == 8) bits = w[u];
+                    else bits = (uint32_t)__shfl((int)w[u], p * 8 * BPS + src_lane0) >> shift;
+                    const uint64_t e0 = tile * EPT + 256 * p + 4 * lane;
+                    if (e0 >= E) continue;
+                    bb_f4 v;
+                    if (valid) {
+                        v.x = lv.get(bits & CMASK);
+                        v.y = lv.get((bits >> BPS) & CMASK);
+                        v.z = lv.get((bits >> (2 * BPS)) & CMASK);
+                        v.w = lv.get((bits >> (3 * BPS)) & CMASK);
+                    } else {
+                        v = fillv;
+                    }
+                    if (OM == BB_OUT_FLAT) {
+                        bb_store4<NT>(obase + e0, v);
+                    } else if (OM == BB_OUT_ROWS4) {
+                        const uint64_t row = e0 >> a.lchunk;
+                        const uint64_t within = e0 & (a.chunk - 1);
+                        bb_store4<NT>(obase + ((((rowbase + row) * a.nslot + slot) << a.lchunk) + within), v);
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint64_t e = e0 + j;
+                            const uint64_t row = e >> a.lchunk;
+                            const uint64_t within = e & (a.chunk - 1);
+                            bb_store1<NT>(obase + ((((rowbase + row) * a.nslot + slot) << a.lchunk) + within), vv[j]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Experimental twin of the 2-bit flat kernel: every lane loads its own byte
+// (64-byte wave loads) instead of shuffling a dword; kept for A/B timing only.
+template <bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_flat2_bytes(bb_flat_args a)
+{
+    const float t0 = a.tab[0], t1 = a.tab[1], t2 = a.tab[2], t3 = a.tab[3];
+    const int lane = bb_lane();
+    const int wave = bb_wave();
+    const uint64_t nbytes = a.ndw * 4;
+    const uint64_t E = nbytes * 4;
+    const uint64_t nunits = (nbytes + 63) / 64;     // 64 input bytes -> 1 KiB
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+    for (uint64_t fs = blockIdx.x; fs < a.nfs; fs += gridDim.x) {
+        const int64_t so = a.src ? a.src[fs] : a.src0 + (int64_t)fs * a.src_stride;
+        const bool valid = so >= 0;
+        const uint8_t *in = a.buf + (valid ? so : 0);
+        float *obase = a.out + fs * E;
+        for (uint64_t u0 = wave; u0 < nunits; u0 += BB_WAVES_PER_BLOCK * 8) {
+            uint32_t b[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint64_t i = (u0 + (uint64_t)k * BB_WAVES_PER_BLOCK) * 64 + lane;
+                b[k] = (valid && i < nbytes) ? in[i] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint64_t i = (u0 + (uint64_t)k * BB_WAVES_PER_BLOCK) * 64 + lane;
+                if (i >= nbytes) continue;
+                bb_f4 v;
+                if (valid) {
+                    float r[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t c = (b[k] >> (2 * j)) & 3;
+                        const float lo = (c & 1) ? t1 : t0;
+                        const float hi = (c & 1) ? t3 : t2;
+                        r[j] = (c & 2) ? hi : lo;
+                    }
+                    v = bb_f4{r[0], r[1], r[2], r[3]};
+                } else v = fillv;
+                bb_store4<NT>(obase + i * 4, v);
+            }
+        }
+    }
+}

@@ -1,0 +1,205 @@
+/*
+ * bbdecode.h -- C ABI of libbbdecode.so: MI355X (gfx950) frame-index scan and
+ * packed-sample decode for radio-baseband formats (VDIF, Mark 5B, Mark 4,
+ * GUPPI, DADA, GSB).
+ *
+ * This is the drop-in boundary for the hot path of mhvk/baseband
+ * (open().read() -> Payload.fromfile -> Payload.data).  Every entry point
+ * cites the reference interface (path:line relative to the reference tree)
+ * it replaces.  The reference is pure Python; the seam a maintainer would bind
+ * is PayloadBase._decoders (base/payload.py:50,314-315) plus the per-frame
+ * header reads of the stream readers (base/base.py:919-1125).  See
+ * INTEGRATION.md for the ctypes stub.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all `d_*` pointers are DEVICE pointers
+ *    (hipMalloc'ed or equivalent); `stream` is a hipStream_t passed as void*
+ *    (NULL = the default stream).
+ *  - every function is stream-ordered and asynchronous w.r.t. the host, never
+ *    allocates and never synchronises (graph-capturable), and keeps no
+ *    mutable state except the constant level tables uploaded once per device
+ *    by bb_init().
+ *  - return value 0 = success, negative errno-style code otherwise.  No
+ *    exceptions cross the ABI.  The Python host maps BB_ENOTSUP to KeyError
+ *    (the reference surfaces an unknown coder as KeyError from the _decoders
+ *    dict, base/payload.py:314-315).
+ *  - decoded output is float32; complex64 is (re, im) interleaved float32.
+ */
+#ifndef BBDECODE_H
+#define BBDECODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BB_ABI_VERSION 1
+
+/* error codes (negative errno values) */
+#define BB_OK        0
+#define BB_EIO      (-5)   /* a HIP runtime call failed (see bb_last_hip_error) */
+#define BB_EINVAL   (-22)  /* bad argument (size, alignment, null pointer) */
+#define BB_ERANGE   (-34)  /* output buffer too small / index out of range */
+#define BB_ENOTSUP  (-95)  /* unsupported coder / bps / mode (-> KeyError) */
+
+/*
+ * Sample coders.  A coder plus bits-per-sample selects the code -> float32
+ * level table.
+ *   BB_CODER_VDIF    offset binary, LSB-first fields
+ *                    (vdif/payload.py:25-103; base/encoding.py:52-56,131-144)
+ *                    bps 1: {-1,+1}; 2: {-Hi,-1,+1,+Hi}; 4: (n-8)/2.95;
+ *                    8: (n-127.5)/35.5   (true float32 division)
+ *   BB_CODER_MARK5B  sign/magnitude (mark5b/payload.py:27-94); also VDIF
+ *                    EDV 0xab (vdif/payload.py:151-154)
+ *                    bps 1: bit ? -1 : +1; 2: field f -> {-Hi,+1,-1,+Hi}[f]
+ *   BB_CODER_INT     two's complement integers cast to float32
+ *                    bps 8: int8 (dada/payload.py:13-14, guppi/payload.py:13-14,
+ *                    gsb/payload.py:39-42); bps 4: sign-extended nibbles, low
+ *                    nibble first (gsb/payload.py:24-36)
+ */
+enum bb_coder {
+    BB_CODER_VDIF   = 0,
+    BB_CODER_MARK5B = 1,
+    BB_CODER_INT    = 2
+};
+
+/* flags in bb_frame_rec.flags */
+#define BB_FRAME_OK       0x0001u  /* header matches the stream invariants */
+#define BB_FRAME_INVALID  0x0002u  /* frame carries invalid data -> fill_value */
+
+/*
+ * One record per frame found by a header scan, in file order.
+ * Replaces the (header, file offset) pairs the reference keeps implicitly
+ * while walking a file (vdif/frame.py:176-243, base/base.py:1083-1125).
+ */
+typedef struct bb_frame_rec {
+    int64_t  payload_offset;  /* byte offset of the payload in the scanned buffer */
+    int32_t  time_index;      /* frame(set) index relative to header0
+                                 (vdif/base.py:386-390; mark5b/base.py:206-213) */
+    int16_t  thread_id;       /* VDIF thread_id; 0 for other formats */
+    uint16_t flags;           /* BB_FRAME_* */
+} bb_frame_rec;
+
+/* ---- library ---------------------------------------------------------- */
+
+int         bb_abi_version(void);
+const char *bb_strerror(int code);
+/* hipError_t of the last failing HIP call on this host thread (0 if none) */
+int         bb_last_hip_error(void);
+/* Upload the constant level tables to the current device.  Called lazily by
+ * every launch entry point; exported so hosts can front-load it.  Fails with
+ * BB_EIO when no usable gfx950 device/code object is present: there is no
+ * CPU fallback in this library. */
+int         bb_init(void);
+/* Copy the 2^bps-entry code -> level table of (coder, bps) to host memory
+ * (what vdif/payload.py:25-63 and mark5b/payload.py:27-72 tabulate per byte). */
+int         bb_get_levels(int coder, int bps, float *h_levels, size_t n);
+
+/* ---- frame index: header scan ------------------------------------------ */
+
+/*
+ * VDIF header scan: VDIFHeader.fromfile + verify + _get_index for every frame
+ * of a fixed-stride file image (vdif/header.py:158-186,569-589;
+ * vdif/base.py:386-390), and the stream-invariant match of
+ * base/header.py:588-638 used by locate_frames (base/base.py:181-335).
+ * Frame k is expected at first_offset + k*frame_nbytes.
+ */
+typedef struct bb_vdif_scan_params {
+    uint64_t first_offset;    /* byte offset of the first header */
+    uint32_t frame_nbytes;    /* header + payload */
+    uint32_t header_nbytes;   /* 32, or 16 for legacy headers */
+    uint32_t pattern[8];      /* header0 words */
+    uint32_t mask[8];         /* 1-bits = stream-invariant header bits */
+    int32_t  ref_seconds;     /* header0['seconds'] */
+    int32_t  ref_frame_nr;    /* header0['frame_nr'] */
+    int32_t  frame_rate;      /* frames per second per thread (integer Hz) */
+    int32_t  reserved;
+} bb_vdif_scan_params;
+
+int bb_vdif_scan(const void *d_buf, size_t nbytes,
+                 const bb_vdif_scan_params *params,
+                 bb_frame_rec *d_recs, size_t nframes, void *stream);
+
+/*
+ * Mark 5B header scan (mark5b/header.py:60-68,91-97; mark5b/base.py:206-213):
+ * sync word 0xABADDEED, frame_nr, BCD seconds; fixed 10016-byte frames.  The
+ * invalid-frame test (payload == 0x11223344 everywhere,
+ * mark5b/frame.py:62-70) is folded into the same pass.
+ */
+typedef struct bb_mark5b_scan_params {
+    uint64_t first_offset;
+    int32_t  ref_seconds;     /* header0 BCD jday*86400+seconds, decoded */
+    int32_t  ref_frame_nr;
+    int32_t  frame_rate;
+    int32_t  reserved;
+} bb_mark5b_scan_params;
+
+int bb_mark5b_scan(const void *d_buf, size_t nbytes,
+                   const bb_mark5b_scan_params *params,
+                   bb_frame_rec *d_recs, size_t nframes, void *stream);
+
+/*
+ * Turn scan records into the dense, output-ordered source table the decode
+ * kernels consume: d_src[time_index*nslot + slot] = payload offset, or -1 for
+ * frames that are missing or flagged invalid (they decode to fill_value:
+ * base/frame.py:191-199, vdif/frame.py:79-90).  d_thread_slot maps a VDIF
+ * thread_id (0..1023) to its output slot or -1 (thread not selected:
+ * vdif/base.py:464-490); NULL means "slot 0 for every frame".
+ * Replaces VDIFFrameSet.fromfile's gather-by-thread (vdif/frame.py:176-243)
+ * and RawOffsets (base/offsets.py).
+ */
+int bb_build_index(const bb_frame_rec *d_recs, size_t nrecs,
+                   const int16_t *d_thread_slot, int nslot,
+                   int64_t *d_src, size_t nframes_out, void *stream);
+
+/* ---- packed-sample decode ---------------------------------------------- */
+
+/*
+ * Flat LUT decode of whole frames (V1-V3, V8, V10, M5-1, S1, D1 of
+ * SURVEY.md section 8a): replaces lut.take(words.view(u1), axis=0)
+ * (vdif/payload.py:69-103, mark5b/payload.py:78-94), decode_8bit
+ * (base/encoding.py:131-144), int8 astype (dada/payload.py:13-14),
+ * PayloadBase._decode/.view/.reshape (base/payload.py:314-330), the frameset
+ * thread interleave (vdif/frame.py:402-434) and the invalid -> fill_value
+ * branch (base/frame.py:191-199).
+ *
+ * For output frame f and slot s the payload at d_buf + d_src[f*nslot+s]
+ * (payload_nbytes bytes) is expanded to E = payload_nbytes*8/bps float32
+ * values v[e]; value e lands at
+ *     d_out[((f*R + e/chunk)*nslot + s)*chunk + e%chunk],  R = E/chunk
+ * i.e. rows of `chunk` values (chunk = nchan * (2 if complex)) interleaved
+ * over nslot threads.  A source of -1 writes fill (re, im alternating when
+ * `complex_data`).  With d_src == NULL frames are taken at
+ * src0 + (f*nslot + s)*src_stride (fixed-stride file, all valid).
+ */
+typedef struct bb_decode_params {
+    int32_t  coder;            /* enum bb_coder */
+    int32_t  bps;              /* 1, 2, 4, 8 */
+    int32_t  chunk;            /* float32 values per (sample, slot) */
+    int32_t  nslot;            /* threads interleaved in one output row */
+    uint64_t payload_nbytes;   /* per frame and slot */
+    int64_t  src0;             /* used when d_src == NULL */
+    int64_t  src_stride;       /* used when d_src == NULL */
+    int32_t  complex_data;     /* selects (fill_re, fill_im) vs fill_re only */
+    float    fill_re;
+    float    fill_im;
+    int32_t  reserved;
+} bb_decode_params;
+
+int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
+                     const int64_t *d_src, size_t nframes,
+                     const bb_decode_params *params,
+                     float *d_out, size_t out_elems, void *stream);
+
+/* ---- tuning knobs (performance experiments; results never change) ------ */
+#define BB_TUNE_FLAT_VARIANT   0   /* kernel variant of the flat decode */
+#define BB_TUNE_NT_STORES      1   /* 1 = non-temporal stores */
+#define BB_TUNE_BLOCKS         2   /* 0 = one workgroup per frame-slot; >0 = persistent grid */
+int bb_tune(int knob, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBDECODE_H */

@@ -1,0 +1,149 @@
+// kbench: standalone timing harness for libbbdecode kernels (developer tool).
+// Times the flat decode on a synthetic fixed-stride VDIF-like file image
+// (cfg2 geometry: 32-byte header + 8000-byte 2-bit payload) for each tuning
+// combination, next to plain fill / copy kernels that bound what the HBM
+// system delivers.  Usage: kbench [input MiB] [reps] [bps]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <vector>
+#include <algorithm>
+#include "bbdecode.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_rand(uint32_t *p, size_t n, uint32_t seed)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t x = (uint32_t)i * 2654435761u + seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = x;
+    }
+}
+
+template <bool NT>
+__global__ void k_fill(f4 *p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    f4 v = {1.f, 2.f, 3.f, 4.f};
+    for (; i < n; i += stride) {
+        if (NT) __builtin_nontemporal_store(v, &p[i]); else p[i] = v;
+    }
+}
+
+__global__ void k_copy(const f4 *s, f4 *d, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) d[i] = s[i];
+}
+
+static double time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
+
+int main(int argc, char **argv)
+{
+    size_t in_mib = argc > 1 ? strtoull(argv[1], 0, 10) : 2048;
+    int reps = argc > 2 ? atoi(argv[2]) : 5;
+    int bps = argc > 3 ? atoi(argv[3]) : 2;
+    const size_t frame = 8032, payload = 8000, hdr = 32;
+    size_t nframes = (in_mib << 20) / frame;
+    size_t in_bytes = nframes * frame;
+    size_t E = payload * 8 / bps;
+    size_t out_elems = nframes * E;
+    printf("kbench: %zu frames, in %.3f GiB, out %.3f GiB, bps %d\n", nframes,
+           in_bytes / 1073741824.0, out_elems * 4 / 1073741824.0, bps);
+
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s, %d CUs, %.1f GiB\n", prop.name, prop.multiProcessorCount, prop.totalGlobalMem / 1073741824.0);
+
+    uint8_t *d_in; float *d_out;
+    CK(hipMalloc(&d_in, in_bytes + 256));
+    CK(hipMalloc(&d_out, out_elems * 4));
+    hipLaunchKernelGGL(k_rand, dim3(4096), dim3(256), 0, 0, (uint32_t *)d_in, in_bytes / 4, 12345u);
+    CK(hipDeviceSynchronize());
+
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double alg_bytes = (double)in_bytes + (double)out_elems * 4;
+
+    // bounds: fill and copy
+    for (int nt = 0; nt < 2; ++nt) {
+        std::vector<double> t;
+        for (int r = 0; r < reps + 1; ++r) {
+            CK(hipEventRecord(e0));
+            if (nt) hipLaunchKernelGGL(k_fill<true>, dim3(256 * 8), dim3(256), 0, 0, (f4 *)d_out, out_elems / 4);
+            else    hipLaunchKernelGGL(k_fill<false>, dim3(256 * 8), dim3(256), 0, 0, (f4 *)d_out, out_elems / 4);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            if (r) t.push_back(time_ms(e0, e1));
+        }
+        std::sort(t.begin(), t.end());
+        printf("fill nt=%d: median %.3f ms  %.1f GB/s\n", nt, t[t.size() / 2], out_elems * 4 / t[t.size() / 2] / 1e6);
+    }
+    {
+        std::vector<double> t;
+        size_t n = out_elems / 8;   // copy first half into second half
+        for (int r = 0; r < reps + 1; ++r) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, 0, (const f4 *)d_out, (f4 *)d_out + n, n);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            if (r) t.push_back(time_ms(e0, e1));
+        }
+        std::sort(t.begin(), t.end());
+        printf("copy: median %.3f ms  %.1f GB/s (read+write)\n", t[t.size() / 2], n * 32.0 / t[t.size() / 2] / 1e6);
+    }
+
+    bb_decode_params p = {};
+    p.coder = BB_CODER_VDIF; p.bps = bps; p.chunk = 1; p.nslot = 1;
+    p.payload_nbytes = payload; p.src0 = hdr; p.src_stride = frame;
+    p.complex_data = 0; p.fill_re = 0.f; p.fill_im = 0.f;
+
+    const int blocks_opts[] = {0, 2048, 4096, 8192};
+    for (int variant = 0; variant < 2; ++variant)
+    for (int nt = 0; nt < 2; ++nt)
+    for (int bi = 0; bi < 4; ++bi) {
+        if (variant == 1 && bps != 2) continue;
+        bb_tune(BB_TUNE_FLAT_VARIANT, variant);
+        bb_tune(BB_TUNE_NT_STORES, nt);
+        bb_tune(BB_TUNE_BLOCKS, blocks_opts[bi]);
+        std::vector<double> t;
+        for (int r = 0; r < reps + 1; ++r) {
+            CK(hipEventRecord(e0));
+            int rc = bb_decode_frames(d_in, in_bytes, nullptr, nframes, &p, d_out, out_elems, nullptr);
+            if (rc) { fprintf(stderr, "bb_decode_frames rc=%d (%s) hip=%d\n", rc, bb_strerror(rc), bb_last_hip_error()); return 1; }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            if (r) t.push_back(time_ms(e0, e1));
+        }
+        std::sort(t.begin(), t.end());
+        double med = t[t.size() / 2];
+        printf("decode variant=%d nt=%d blocks=%d: median %.3f ms (min %.3f)  %.1f GB/s alg  %.1f Msamples/s  frac8TB=%.3f\n",
+               variant, nt, blocks_opts[bi], med, t[0], alg_bytes / med / 1e6, out_elems / med / 1e3,
+               alg_bytes / med / 1e6 / 8000.0);
+    }
+
+    // spot check (2-bit VDIF only): first and last frame against a host LUT
+    if (bps == 2) {
+        bb_tune(BB_TUNE_FLAT_VARIANT, 0); bb_tune(BB_TUNE_NT_STORES, 0); bb_tune(BB_TUNE_BLOCKS, 0);
+        bb_decode_frames(d_in, in_bytes, nullptr, nframes, &p, d_out, out_elems, nullptr);
+        CK(hipDeviceSynchronize());
+        float lv[4]; bb_get_levels(BB_CODER_VDIF, 2, lv, 4);
+        size_t bad = 0;
+        const size_t fr[3] = {0, nframes / 2, nframes - 1};
+        std::vector<uint8_t> hb(payload); std::vector<float> ho(E);
+        for (int k = 0; k < 3; ++k) {
+            size_t f = fr[k];
+            CK(hipMemcpy(hb.data(), d_in + f * frame + hdr, payload, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(ho.data(), d_out + f * E, E * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < payload; ++i)
+                for (int j = 0; j < 4; ++j)
+                    if (ho[i * 4 + j] != lv[(hb[i] >> (2 * j)) & 3]) ++bad;
+        }
+        printf("spot check: %zu mismatches\n", bad);
+    }
+    return 0;
+}
