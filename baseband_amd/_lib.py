@@ -1,0 +1,115 @@
+"""ctypes binding of libbbdecode.so (the C ABI declared in include/bbdecode.h).
+
+The library is the only compute path of this package: if it cannot be loaded
+the import fails loudly -- there is no NumPy/PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbbdecode.so')
+
+BB_OK = 0
+BB_EIO = -5
+BB_EINVAL = -22
+BB_ERANGE = -34
+BB_ENOTSUP = -95
+
+CODER_VDIF = 0
+CODER_MARK5B = 1
+CODER_INT = 2
+
+FRAME_OK = 0x1
+FRAME_INVALID = 0x2
+
+TUNE_FLAT_VARIANT = 0
+TUNE_NT_STORES = 1
+TUNE_BLOCKS = 2
+
+
+class BBError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("{}: {} (code {}, hip error {})".format(
+            where, lib.bb_strerror(code).decode(), code, lib.bb_last_hip_error()))
+
+
+class FrameRec(C.Structure):
+    _fields_ = [('payload_offset', C.c_int64), ('time_index', C.c_int32),
+                ('thread_id', C.c_int16), ('flags', C.c_uint16)]
+
+
+class VDIFScanParams(C.Structure):
+    _fields_ = [('first_offset', C.c_uint64), ('frame_nbytes', C.c_uint32),
+                ('header_nbytes', C.c_uint32), ('pattern', C.c_uint32 * 8),
+                ('mask', C.c_uint32 * 8), ('ref_seconds', C.c_int32),
+                ('ref_frame_nr', C.c_int32), ('frame_rate', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class Mark5BScanParams(C.Structure):
+    _fields_ = [('first_offset', C.c_uint64), ('ref_seconds', C.c_int32),
+                ('ref_frame_nr', C.c_int32), ('frame_rate', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class DecodeParams(C.Structure):
+    _fields_ = [('coder', C.c_int32), ('bps', C.c_int32), ('chunk', C.c_int32),
+                ('nslot', C.c_int32), ('payload_nbytes', C.c_uint64),
+                ('src0', C.c_int64), ('src_stride', C.c_int64),
+                ('complex_data', C.c_int32), ('fill_re', C.c_float),
+                ('fill_im', C.c_float), ('reserved', C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "baseband_amd: {} not found. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C baseband_amd/csrc` (needs hipcc, gfx950). There is no "
+            "CPU fallback.".format(LIB_PATH))
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp = C.c_void_p
+_sz = C.c_size_t
+
+# (name, restype, argtypes) -- must list every symbol of include/bbdecode.h
+SIGNATURES = [
+    ('bb_abi_version', C.c_int, []),
+    ('bb_strerror', C.c_char_p, [C.c_int]),
+    ('bb_last_hip_error', C.c_int, []),
+    ('bb_init', C.c_int, []),
+    ('bb_get_levels', C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _sz]),
+    ('bb_vdif_scan', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp]),
+    ('bb_mark5b_scan', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp]),
+    ('bb_build_index', C.c_int, [_vp, _sz, _vp, C.c_int, _vp, _sz, _vp]),
+    ('bb_decode_frames', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, _sz, _vp]),
+    ('bb_tune', C.c_int, [C.c_int, C.c_int]),
+]
+
+for _name, _res, _args in SIGNATURES:
+    _f = getattr(lib, _name)
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(code, where):
+    if code != BB_OK:
+        if code == BB_ENOTSUP:
+            # the reference surfaces an unknown coder as KeyError from the
+            # _decoders dict (base/payload.py:314-315)
+            raise KeyError("{}: unsupported coder / bits per sample".format(where))
+        raise BBError(code, where)
+
+
+def get_levels(coder, bps):
+    """Host copy of the code -> level table the kernels use."""
+    import numpy as np
+    n = 1 << bps
+    out = np.empty(n, dtype=np.float32)
+    check(lib.bb_get_levels(coder, bps, out.ctypes.data_as(C.POINTER(C.c_float)), n),
+          'bb_get_levels')
+    return out

@@ -1,0 +1,344 @@
+"""File and stream reader bases.
+
+Host-side mirror of the reference's ``FileBase``/``VLBIFileReaderBase``
+(base/base.py:54-406) and ``StreamReaderBase``/``VLBIStreamReaderBase``
+(base/base.py:602-1227).  The public surface is the same -- ``read(count,
+out)``, ``seek``, ``tell``, ``shape/size/ndim/dtype/sample_shape``,
+``start_time/stop_time/time``, ``squeeze/subset/fill_value/verify``, context
+manager, ``close`` -- but ``read`` does not loop over frames in Python
+(base/base.py:957-967).  It maps the requested sample range to a range of
+frame sets, streams the corresponding bytes to HBM in large windows
+(`staging.WindowPipeline`), and per window launches header scan ->
+index build -> decode.  The result is a device tensor.
+"""
+import io
+import operator
+import warnings
+
+import numpy as np
+import torch
+
+from .. import kernels
+from ..staging import host_image, WindowPipeline
+
+__all__ = ['FileBase', 'VLBIFileReaderBase', 'GPUStreamReaderBase',
+           'HeaderNotFoundError']
+
+
+class HeaderNotFoundError(LookupError):
+    pass
+
+
+class FileBase:
+    """Thin wrapper around a binary filehandle (base/base.py:54-151)."""
+
+    def __init__(self, fh_raw):
+        self.fh_raw = fh_raw
+
+    def __getattr__(self, attr):
+        if attr == 'fh_raw':
+            raise AttributeError(attr)
+        return getattr(self.fh_raw, attr)
+
+    class _TemporaryOffset:
+        def __init__(self, fh, offset, whence):
+            self.fh, self.offset, self.whence = fh, offset, whence
+
+        def __enter__(self):
+            self.old = self.fh.tell()
+            if self.offset is not None:
+                self.fh.seek(self.offset, self.whence)
+            return self.fh
+
+        def __exit__(self, *exc):
+            self.fh.seek(self.old)
+
+    def temporary_offset(self, offset=None, whence=0):
+        return self._TemporaryOffset(self, offset, whence)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.close()
+
+    def close(self):
+        self.fh_raw.close()
+
+    def __repr__(self):
+        return "{0}(fh_raw={1})".format(self.__class__.__name__, self.fh_raw)
+
+
+class VLBIFileReaderBase(FileBase):
+    """Adds header walking helpers shared by fixed-frame formats."""
+
+    def image(self):
+        """uint8 view of the whole file (memory mapped when possible)."""
+        if getattr(self, '_image', None) is None:
+            self._image = host_image(self.fh_raw)
+        return self._image
+
+
+def _apply_squeeze(shape):
+    return tuple(s for s in shape if s > 1)
+
+
+class GPUStreamReaderBase:
+    """Sample-stream view of a file whose frames decode on the GPU.
+
+    Subclasses set up the geometry (`_setup`) and implement
+    ``_scan_window(dbuf, nframes, first_set)`` -> scan records and
+    ``_decode_window(dbuf, src, nsets, out_flat)``.
+    """
+    # window of file bytes staged per pipeline step
+    window_bytes = 64 << 20
+
+    def __init__(self, fh_raw, header0, *, sample_rate, samples_per_frame,
+                 unsliced_shape, bps, complex_data, squeeze=True, subset=(),
+                 fill_value=0., verify=True):
+        self.fh_raw = fh_raw
+        self._header0 = header0
+        self._sample_rate = sample_rate
+        self.samples_per_frame = samples_per_frame
+        self._unsliced_shape = tuple(unsliced_shape)
+        self._decode_shape = tuple(unsliced_shape)
+        self.bps = bps
+        self.complex_data = complex_data
+        self._squeeze = bool(squeeze)
+        self._subset = (() if subset is None
+                        else subset if isinstance(subset, tuple) else (subset,))
+        self._fill_value = float(fill_value)
+        self.verify = verify
+        self.offset = 0
+        self._pipeline = None
+        self._pending_checks = []
+        self._closed = False
+
+    # -- simple attributes
+    @property
+    def header0(self):
+        return self._header0
+
+    @property
+    def squeeze(self):
+        return self._squeeze
+
+    @property
+    def subset(self):
+        return self._subset
+
+    @property
+    def fill_value(self):
+        return self._fill_value
+
+    @property
+    def verify(self):
+        return self._verify
+
+    @verify.setter
+    def verify(self, verify):
+        self._verify = bool(verify) if verify != 'fix' else verify
+
+    @property
+    def sample_rate(self):
+        """Complete samples per second (Hz, float)."""
+        return self._sample_rate
+
+    @property
+    def closed(self):
+        return self._closed
+
+    def close(self):
+        self._closed = True
+        if self._pipeline is not None:
+            self._pipeline.drain()
+        self.fh_raw.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- shapes
+    def _squeeze_and_subset(self, data):
+        """Remove unit dimensions, then apply `subset`
+        (base/base.py:706-717)."""
+        if self.squeeze:
+            data = data.reshape(data.shape[:1] + _apply_squeeze(data.shape[1:]))
+        if self.subset:
+            data = data[(slice(None),) + self._torch_subset()]
+        return data
+
+    def _torch_subset(self):
+        out = []
+        for s in self.subset:
+            if isinstance(s, (list, np.ndarray)):
+                s = torch.as_tensor(np.asarray(s), device='cuda')
+            out.append(s)
+        return tuple(out)
+
+    @property
+    def sample_shape(self):
+        shape = self._unsliced_shape
+        if self.squeeze:
+            shape = _apply_squeeze(shape)
+        if self.subset:
+            shape = np.empty((1,) + tuple(shape), dtype=bool)[
+                (slice(None),) + self.subset].shape[1:]
+        return tuple(shape)
+
+    @property
+    def shape(self):
+        return (self._nsample,) + self.sample_shape
+
+    @property
+    def size(self):
+        prod = 1
+        for dim in self.shape:
+            prod *= dim
+        return prod
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(np.complex64 if self.complex_data else np.float32)
+
+    # -- times (numpy datetime64[ns]; see DESIGN.md on astropy)
+    @property
+    def start_time(self):
+        return self._start_time
+
+    @property
+    def stop_time(self):
+        return self._time_at(self._nsample)
+
+    @property
+    def time(self):
+        return self._time_at(self.offset)
+
+    def _time_at(self, offset):
+        ns = int(round(offset * 1e9 / self.sample_rate))
+        return self._start_time + np.timedelta64(ns, 'ns')
+
+    def tell(self, unit=None):
+        """Current sample offset; ``unit='time'`` gives the time
+        (base/base.py:552-576)."""
+        if unit is None:
+            return self.offset
+        if unit == 'time':
+            return self.time
+        if unit == 's':
+            return self.offset / self.sample_rate
+        raise ValueError("unit should be None, 'time' or 's'")
+
+    def seek(self, offset, whence=0):
+        """Move the sample pointer (base/base.py:876-917).  `offset` may be an
+        integer sample count, a ``numpy.timedelta64`` or a ``numpy.datetime64``."""
+        try:
+            offset = operator.index(offset)
+        except Exception:
+            if isinstance(offset, np.datetime64):
+                offset = offset - self.start_time
+                whence = 0
+            if isinstance(offset, np.timedelta64):
+                ns = offset / np.timedelta64(1, 'ns')
+                offset = int(round(ns * self.sample_rate / 1e9))
+            else:
+                offset = int(round(float(offset) * self.sample_rate))
+        if whence == 0 or whence == 'start':
+            self.offset = offset
+        elif whence == 1 or whence == 'current':
+            self.offset += offset
+        elif whence == 2 or whence == 'end':
+            self.offset = self.shape[0] + offset
+        else:
+            raise ValueError("invalid 'whence'; should be 0 or 'start', 1 or "
+                             "'current', or 2 or 'end'.")
+        return self.offset
+
+    # -- the hot path
+    def read(self, count=None, out=None):
+        """Read and decode `count` complete samples -> device tensor of shape
+        ``(count,) + sample_shape`` (base/base.py:919-969)."""
+        if self.closed:
+            raise ValueError("I/O operation on closed stream.")
+        samples_left = self.shape[0] - self.offset
+        if out is None:
+            if count is None or count < 0:
+                count = max(0, samples_left)
+        else:
+            assert tuple(out.shape[1:]) == self.sample_shape, (
+                "'out' must have trailing shape {}".format(self.sample_shape))
+            count = out.shape[0]
+        if count > samples_left:
+            raise EOFError("cannot read from beyond end of input.")
+
+        spf = self.samples_per_frame
+        first, off0 = divmod(self.offset, spf)
+        last = -(-(self.offset + count) // spf) if count else first
+        data = self._read_sets(first, last)             # (nsets*spf, *unsliced)
+        data = data[off0:off0 + count]
+        data = self._squeeze_and_subset(data)
+        self.offset += count
+        self._resolve_checks()
+        if out is None:
+            return data
+        if isinstance(out, torch.Tensor):
+            out.copy_(data)
+        else:
+            out[...] = data.cpu().numpy()
+        return out
+
+    def _read_sets(self, first, last):
+        """Decode frame sets [first, last) -> tensor (nsets*spf, *unsliced)."""
+        kernels.require_gpu()
+        nsets = last - first
+        spf = self.samples_per_frame
+        ncomp = 2 if self.complex_data else 1
+        row = int(np.prod(self._decode_shape)) * ncomp
+        flat = torch.empty(nsets * spf * row, dtype=torch.float32, device='cuda')
+        if nsets:
+            set_nbytes = self._set_nbytes
+            image = self._image()
+            per_win = max(1, self.window_bytes // set_nbytes)
+            if self._pipeline is None:
+                self._pipeline = WindowPipeline(image, per_win * set_nbytes)
+            ranges, spans = [], []
+            for s in range(first, last, per_win):
+                e = min(last, s + per_win)
+                lo = self._file_offset0 + s * set_nbytes
+                hi = min(self._file_offset0 + e * set_nbytes, len(image))
+                ranges.append((lo, hi))
+                spans.append((s, e))
+
+            def process(dbuf, i):
+                s, e = spans[i]
+                o = flat[(s - first) * spf * row:(e - first) * spf * row]
+                self._process_window(dbuf, s, e, o)
+
+            self._pipeline.run(ranges, process)
+        if self.complex_data:
+            flat = torch.view_as_complex(flat.view(-1, 2))
+        return flat.reshape((nsets * spf,) + tuple(self._decode_shape))
+
+    def _resolve_checks(self):
+        """Look at the verification counters the windows left on the device
+        (one host sync per read, none when verify is False)."""
+        checks, self._pending_checks = self._pending_checks, []
+        if not self.verify or not checks:
+            return
+        nbad = int(torch.stack(checks).sum().item())
+        if nbad:
+            msg = ("{} frame header(s) failed verification (bad sync/invariants "
+                   "or unexpected time index)".format(nbad))
+            if self.verify == 'fix':
+                warnings.warn(msg + "; affected samples were set to fill_value.")
+            else:
+                raise ValueError("wrong frame number. " + msg)
+
+    def __getstate__(self):
+        raise TypeError("pickling of GPU stream readers is not supported yet")

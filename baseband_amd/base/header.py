@@ -1,0 +1,143 @@
+"""Bit-field headers: a compact table-driven equivalent of the reference's
+``HeaderParser``/``VLBIHeaderBase`` (base/header.py:35-87,250-667).
+
+A header class lists its fields as ``name -> (word, bit, nbits[, default])``;
+``header['name']`` extracts ``(words[word] >> bit) & (2**nbits - 1)`` (bool
+for single bits, two words for nbits == 64), which is exactly what the
+reference's generated parsers do.
+"""
+import struct
+
+import numpy as np
+
+four_word_struct = struct.Struct('<4I')
+eight_word_struct = struct.Struct('<8I')
+
+
+class BitFieldHeader:
+    """Header made of 32-bit little-endian words with named bit fields."""
+
+    _fields = {}            # name -> (word, bit, nbits, default)
+    _struct = None
+    _invariants = set()
+    _stream_invariants = set()
+
+    def __init__(self, words=None, verify=True, **kwargs):
+        if words is None:
+            self.words = [0] * (self._struct.size // 4)
+            self._mutable = True
+        else:
+            self.words = tuple(int(w) for w in words)
+            self._mutable = False
+        if verify:
+            self.verify()
+
+    # -- dict-like access
+    def keys(self):
+        return self._fields.keys()
+
+    def __contains__(self, key):
+        return key in self._fields
+
+    def __getitem__(self, key):
+        try:
+            word, bit, nbits = self._fields[key][:3]
+        except KeyError:
+            raise KeyError("{0} header does not contain {1}"
+                           .format(self.__class__.__name__, key))
+        if nbits == 64:
+            return self.words[word] + (self.words[word + 1] << 32)
+        v = (self.words[word] >> bit) & ((1 << nbits) - 1)
+        return bool(v) if nbits == 1 else v
+
+    def __setitem__(self, key, value):
+        if not self._mutable:
+            raise TypeError("header is immutable; use .copy() to get a "
+                            "mutable one.")
+        word, bit, nbits = self._fields[key][:3]
+        default = self._fields[key][3] if len(self._fields[key]) > 3 else None
+        mask = (1 << nbits) - 1
+        if value is None:
+            if default is None:
+                raise ValueError("no default value so cannot set to 'None'.")
+            value = default
+        elif value is True:
+            value = mask                 # all bits: used for invariant masks
+        else:
+            value = int(value)
+            if value & mask != value:
+                raise ValueError("{0} cannot be represented with {1} bits"
+                                 .format(value, nbits))
+        if nbits == 64:
+            self.words[word] = value & 0xffffffff
+            self.words[word + 1] = value >> 32
+        else:
+            w = self.words[word]
+            self.words[word] = (w & ~(mask << bit) & 0xffffffff) | (value << bit)
+
+    def copy(self):
+        new = self.__class__.__new__(self.__class__)
+        new.__dict__.update(self.__dict__)
+        new.words = list(self.words)
+        new._mutable = True
+        return new
+
+    @property
+    def mutable(self):
+        return self._mutable
+
+    @mutable.setter
+    def mutable(self, mutable):
+        self.words = (list if mutable else tuple)(self.words)
+        self._mutable = bool(mutable)
+
+    @property
+    def nbytes(self):
+        return self._struct.size
+
+    def tofile(self, fh):
+        return fh.write(self._struct.pack(*self.words))
+
+    def verify(self):
+        pass
+
+    def invariants(self):
+        """Keys whose bits are the same for all headers of this stream."""
+        return self._stream_invariants
+
+    def invariant_pattern(self, invariants=None):
+        """(pattern words, mask words): bits shared by all headers of the
+        stream (base/header.py:588-638)."""
+        if invariants is None:
+            invariants = self.invariants()
+        if not invariants:
+            raise ValueError("cannot create an invariant_mask without "
+                             "some invariants")
+        mask = [0] * len(self.words)
+        for key in invariants:
+            word, bit, nbits = self._fields[key][:3]
+            if nbits == 64:
+                mask[word] = mask[word + 1] = 0xffffffff
+            else:
+                mask[word] |= ((1 << nbits) - 1) << bit
+        return list(self.words), mask
+
+    def __eq__(self, other):
+        return (type(self) is type(other)
+                and list(self.words) == list(other.words))
+
+    def __repr__(self):
+        name = self.__class__.__name__
+        return ("<{0} {1}>".format(name, (",\n  " + len(name) * " ").join(
+            ["{0}: {1}".format(k, self[k]) for k in self.keys()])))
+
+
+def strided_header_words(buf, frame_nbytes, nwords, offset=0):
+    """(nframes, nwords) uint32 view of the headers of a fixed-stride file
+    image held in a uint8 NumPy array or memmap (no copy).  Only frames whose
+    header lies completely inside the buffer are included."""
+    buf = np.asarray(buf)[offset:]
+    nframes = (len(buf) - 4 * nwords) // frame_nbytes + 1 if len(buf) >= 4 * nwords else 0
+    u4 = np.frombuffer(buf, dtype='<u4', count=len(buf) // 4)
+    return np.lib.stride_tricks.as_strided(
+        u4, shape=(nframes, nwords), strides=(frame_nbytes, 4), writeable=False)

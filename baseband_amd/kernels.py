@@ -1,0 +1,130 @@
+"""Thin Python wrappers over the C ABI: torch tensors in, torch tensors out.
+
+PyTorch is used only as the device allocator / stream provider; every
+computation is a libbbdecode kernel launched on torch's current HIP stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "baseband_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() "
+            "is False and there is no CPU decode path in this package.")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def init():
+    require_gpu()
+    check(lib.bb_init(), 'bb_init')
+
+
+def to_device_bytes(raw, device=None):
+    """Host bytes-like / ndarray -> 1-D uint8 device tensor (simple upload;
+    the chunked pinned pipeline lives in `staging`)."""
+    require_gpu()
+    if isinstance(raw, torch.Tensor):
+        t = raw if raw.dtype == torch.uint8 else raw.view(torch.uint8)
+        return t.reshape(-1).to(device or 'cuda')
+    a = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) \
+        else np.ascontiguousarray(raw).view(np.uint8).reshape(-1)
+    return torch.from_numpy(np.array(a, copy=True)).to(device or 'cuda')
+
+
+def vdif_scan(dbuf, nframes, frame_nbytes, header_nbytes, pattern, mask,
+              ref_seconds, ref_frame_nr, frame_rate, first_offset=0):
+    """-> int32 tensor (nframes, 4): payload offset lo/hi, time_index,
+    thread_id | flags << 16 (the 16-byte bb_frame_rec)."""
+    p = _lib.VDIFScanParams()
+    p.first_offset = first_offset
+    p.frame_nbytes = frame_nbytes
+    p.header_nbytes = header_nbytes
+    for i in range(8):
+        p.pattern[i] = int(pattern[i]) if i < len(pattern) else 0
+        p.mask[i] = int(mask[i]) if i < len(mask) else 0
+    p.ref_seconds = ref_seconds
+    p.ref_frame_nr = ref_frame_nr
+    p.frame_rate = frame_rate
+    recs = torch.empty((nframes, 4), dtype=torch.int32, device=dbuf.device)
+    check(lib.bb_vdif_scan(_ptr(dbuf), dbuf.numel(), C.byref(p), _ptr(recs),
+                           nframes, _stream()), 'bb_vdif_scan')
+    return recs
+
+
+def mark5b_scan(dbuf, nframes, ref_seconds, ref_frame_nr, frame_rate,
+                first_offset=0):
+    p = _lib.Mark5BScanParams()
+    p.first_offset = first_offset
+    p.ref_seconds = ref_seconds
+    p.ref_frame_nr = ref_frame_nr
+    p.frame_rate = frame_rate
+    recs = torch.empty((nframes, 4), dtype=torch.int32, device=dbuf.device)
+    check(lib.bb_mark5b_scan(_ptr(dbuf), dbuf.numel(), C.byref(p), _ptr(recs),
+                             nframes, _stream()), 'bb_mark5b_scan')
+    return recs
+
+
+def recs_fields(recs):
+    """Split scan records (device int32 (n,4)) into named host arrays."""
+    r = recs.cpu().numpy()
+    off = r[:, :2].copy().view(np.int64)[:, 0]
+    tidx = r[:, 2]
+    thread = (r[:, 3] & 0xffff).astype(np.int16)
+    flags = ((r[:, 3] >> 16) & 0xffff).astype(np.uint16)
+    return dict(payload_offset=off, time_index=tidx, thread_id=thread, flags=flags)
+
+
+def thread_slot_map(thread_ids, device):
+    m = np.full(1024, -1, dtype=np.int16)
+    for s, t in enumerate(thread_ids):
+        m[int(t)] = s
+    return torch.from_numpy(m).to(device)
+
+
+def build_index(recs, nframes_out, nslot=1, thread_slot=None):
+    src = torch.empty(nframes_out * nslot, dtype=torch.int64, device=recs.device)
+    check(lib.bb_build_index(_ptr(recs), recs.shape[0], _ptr(thread_slot), nslot,
+                             _ptr(src), nframes_out, _stream()), 'bb_build_index')
+    return src
+
+
+def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
+                  src=None, src0=0, src_stride=0, complex_data=False,
+                  fill_value=0., out=None):
+    """Decode `nframes` frame(set)s to a flat float32 device tensor."""
+    p = _lib.DecodeParams()
+    p.coder = coder
+    p.bps = bps
+    p.chunk = chunk
+    p.nslot = nslot
+    p.payload_nbytes = payload_nbytes
+    p.src0 = src0
+    p.src_stride = src_stride
+    p.complex_data = int(bool(complex_data))
+    fv = complex(fill_value)
+    p.fill_re = fv.real
+    p.fill_im = fv.imag
+    nelem = nframes * nslot * (payload_nbytes * 8 // bps) if bps in (1, 2, 4, 8) else 0
+    if out is None:
+        out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
+    check(lib.bb_decode_frames(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
+                               C.byref(p), _ptr(out), out.numel(), _stream()),
+          'bb_decode_frames')
+    return out
+
+
+def tune(knob, value):
+    check(lib.bb_tune(knob, value), 'bb_tune')

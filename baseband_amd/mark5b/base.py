@@ -1,0 +1,188 @@
+"""Mark 5B file and stream readers, and ``open``.
+
+Mirrors ``Mark5BFileReader`` (mark5b/base.py:25-155) and
+``Mark5BStreamReader`` (mark5b/base.py:228-301).  Per staged window the
+stream reader launches ``bb_mark5b_scan`` (sync word, BCD time -> frame
+index, fill-pattern validity) -> ``bb_build_index`` -> ``bb_decode_frames``.
+"""
+import io
+import operator
+
+import numpy as np
+import torch
+
+from .. import _lib, kernels
+from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
+                         HeaderNotFoundError)
+from ..base.header import strided_header_words
+from .header import Mark5BHeader, crc16_mark5b
+from .frame import Mark5BFrame
+
+__all__ = ['Mark5BFileReader', 'Mark5BStreamReader', 'open']
+
+FRAME_NBYTES = 10016
+SYNC = 0xABADDEED
+
+
+class Mark5BFileReader(VLBIFileReaderBase):
+    def __init__(self, fh_raw, kday=None, ref_time=None, nchan=None, bps=2):
+        self.kday = operator.index(kday) if kday is not None else None
+        self.ref_time = ref_time
+        self.nchan = operator.index(nchan) if nchan is not None else None
+        self.bps = operator.index(bps)
+        super().__init__(fh_raw)
+
+    def read_header(self):
+        return Mark5BHeader.fromfile(self.fh_raw, kday=self.kday,
+                                     ref_time=self.ref_time)
+
+    def read_frame(self, verify=True):
+        if self.nchan is None:
+            raise TypeError("In order to read frames, the file handle should "
+                            "be initialized with nchan set.")
+        return Mark5BFrame.fromfile(self.fh_raw, kday=self.kday,
+                                    ref_time=self.ref_time,
+                                    sample_shape=(self.nchan,), bps=self.bps,
+                                    verify=verify)
+
+    def find_header(self, maximum=2 * FRAME_NBYTES):
+        """Locate the first frame at or after the current position: a sync
+        word with another one a frame later and a correct time-code CRC
+        (mark5b/base.py:136-155)."""
+        image = self.image()
+        pos = self.fh_raw.tell()
+        stop = min(len(image) - 16, pos + maximum)
+        sync = np.frombuffer(np.array([SYNC], '<u4').tobytes(), np.uint8)
+        for o in range(pos, max(stop, pos) + 1):
+            if not np.array_equal(image[o:o + 4], sync):
+                continue
+            nxt = o + FRAME_NBYTES
+            if nxt + 4 <= len(image) and not np.array_equal(image[nxt:nxt + 4], sync):
+                continue
+            words = image[o:o + 16].view('<u4')
+            try:
+                header = Mark5BHeader(words, kday=self.kday,
+                                      ref_time=self.ref_time)
+                header.jday, header.seconds
+            except Exception:
+                continue
+            if crc16_mark5b(words) == header['crc']:
+                self.fh_raw.seek(o)
+                return header
+        raise HeaderNotFoundError('could not locate a a nearby frame.')
+
+    def get_frame_rate(self):
+        """Largest frame number within the first second plus one
+        (base/base.py:371-406), else the inverse of the time step between the
+        first two headers (mark5b/base.py:99-124)."""
+        with self.temporary_offset(0):
+            header0 = self.find_header()
+            offset0 = self.fh_raw.tell()
+        hw = strided_header_words(self.image(), FRAME_NBYTES, 4, offset=offset0)
+        frame_nr = hw[:, 1] & 0x7fff
+        differ = np.nonzero(frame_nr != frame_nr[0])[0]
+        if len(differ):
+            i = differ[0]
+            wrap = np.nonzero(frame_nr[i:] == 0)[0]
+            if len(wrap):
+                j = i + wrap[0]
+                return int(max(frame_nr[0], frame_nr[i:j].max() if j > i else 0)) + 1
+        if len(hw) > 1:
+            h1 = Mark5BHeader(hw[1], kday=self.kday, ref_time=self.ref_time)
+            tdelta = h1.fraction - header0.fraction
+            if tdelta != 0.:
+                return int(round(1. / tdelta))
+        raise EOFError("file contains less than one second of data and the "
+                       "first two headers do not give a time step.")
+
+
+class Mark5BStreamReader(GPUStreamReaderBase):
+    """Mark 5B stream -> device tensor (nsample, nchan)."""
+
+    def __init__(self, fh_raw, sample_rate=None, kday=None, ref_time=None,
+                 nchan=None, bps=2, squeeze=True, subset=(), fill_value=0.,
+                 verify='fix'):
+        if nchan is None:
+            raise TypeError("Mark 5B stream reader requires nchan to be "
+                            "explicity passed in.")
+        if kday is None and ref_time is None:
+            raise TypeError("Mark 5B stream reader requires either kday or "
+                            "ref_time to be passed in.")
+        fh_raw = Mark5BFileReader(fh_raw, nchan=nchan, bps=bps,
+                                  ref_time=ref_time, kday=kday)
+        header0 = fh_raw.find_header()
+        offset0 = fh_raw.tell()
+        spf = header0.payload_nbytes * 8 // bps // nchan
+        if sample_rate is None:
+            sample_rate = fh_raw.get_frame_rate() * spf
+        super().__init__(
+            fh_raw, header0, sample_rate=float(sample_rate),
+            samples_per_frame=spf, unsliced_shape=(nchan,), bps=bps,
+            complex_data=False, squeeze=squeeze, subset=subset,
+            fill_value=fill_value, verify=verify)
+        self._frame_rate = int(round(self.sample_rate / spf))
+        self._set_nbytes = FRAME_NBYTES
+        self._file_offset0 = offset0
+        self._start_time = header0.get_time(frame_rate=self._frame_rate)
+        self._ref_seconds = header0.jday * 86400 + header0.seconds
+        last = self._last_header()
+        self._nsample = (self._get_index(last) + 1) * spf
+
+    def _image(self):
+        return self.fh_raw.image()
+
+    def _get_index(self, header):
+        """mark5b/base.py:206-213."""
+        return int(round(self._frame_rate
+                         * (header.seconds - self.header0.seconds
+                            + 86400 * (header.kday - self.header0.kday
+                                       + header.jday - self.header0.jday))
+                         + header['frame_nr'] - self.header0['frame_nr']))
+
+    def _last_header(self):
+        image = self._image()
+        nfull = (len(image) - self._file_offset0) // FRAME_NBYTES
+        hw = strided_header_words(image, FRAME_NBYTES, 4,
+                                  offset=self._file_offset0)
+        for k in range(min(nfull, len(hw)) - 1, max(-1, nfull - 3), -1):
+            if int(hw[k][0]) != SYNC:
+                continue
+            header = Mark5BHeader(hw[k], verify=False)
+            header.infer_kday(self.start_time)
+            return header
+        raise HeaderNotFoundError("corrupt VLBI frame? No frame in last {0} "
+                                  "bytes.".format(2 * FRAME_NBYTES))
+
+    def _process_window(self, dbuf, first, last, out_flat):
+        n = last - first
+        nframes = min(n, dbuf.numel() // FRAME_NBYTES)
+        recs = kernels.mark5b_scan(dbuf, nframes, self._ref_seconds,
+                                   self.header0['frame_nr'] + first,
+                                   self._frame_rate)
+        src = kernels.build_index(recs, n, 1, None)
+        kernels.decode_frames(
+            dbuf, n, 10000, _lib.CODER_MARK5B, self.bps,
+            chunk=self._unsliced_shape[0], nslot=1, src=src,
+            fill_value=self.fill_value, out=out_flat)
+        if self.verify:
+            ok = (recs[:, 3] >> 16) & _lib.FRAME_OK
+            expect = torch.arange(nframes, device=recs.device, dtype=torch.int32)
+            bad = ((ok == 0) | (recs[:, 2] != expect)).sum() + (n - nframes)
+            self._pending_checks.append(bad)
+
+
+def open(name, mode='rs', **kwargs):
+    """``'rb'`` -> `Mark5BFileReader`, ``'rs'`` -> `Mark5BStreamReader`
+    (mark5b/base.py:356-428)."""
+    if mode not in ('rb', 'rs'):
+        raise ValueError("only reading modes 'rb' and 'rs' are supported "
+                         "(got {!r}).".format(mode))
+    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
+    try:
+        if mode == 'rb':
+            return Mark5BFileReader(fh, **kwargs)
+        return Mark5BStreamReader(fh, **kwargs)
+    except Exception:
+        if fh is not name:
+            fh.close()
+        raise

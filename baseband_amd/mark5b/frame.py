@@ -1,0 +1,31 @@
+"""Mark 5B frames: header + payload, invalid when the payload is the
+0x11223344 fill pattern everywhere (mark5b/frame.py:21-70)."""
+from ..base.frame import FrameBase
+from .header import Mark5BHeader
+from .payload import Mark5BPayload
+
+__all__ = ['Mark5BFrame']
+
+
+class Mark5BFrame(FrameBase):
+    _header_class = Mark5BHeader
+    _payload_class = Mark5BPayload
+    _fill_pattern = 0x11223344
+
+    def __init__(self, header, payload, valid=None, verify=True):
+        if valid is None:
+            # usually valid, so look at the first few words first
+            w = payload.words
+            valid = bool(w[0] != self._fill_pattern
+                         or w[1] != self._fill_pattern
+                         or w[2] != self._fill_pattern
+                         or (w[3:] != self._fill_pattern).any())
+        super().__init__(header, payload, valid, verify)
+
+    @classmethod
+    def fromfile(cls, fh, *, kday=None, ref_time=None, sample_shape=(1,),
+                 bps=2, valid=None, verify=True):
+        header = Mark5BHeader.fromfile(fh, kday=kday, ref_time=ref_time,
+                                       verify=verify)
+        payload = Mark5BPayload.fromfile(fh, sample_shape=sample_shape, bps=bps)
+        return cls(header, payload, valid, verify)

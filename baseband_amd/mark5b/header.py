@@ -1,0 +1,185 @@
+"""Mark 5B headers (host side): four words, BCD time stamp, fixed 10016-byte
+frames (mark5b/header.py:60-68,91-97,177-185,235-262).  Times are
+``numpy.datetime64[ns]``; ``kday`` resolves the modulo-1000 day count."""
+import numpy as np
+
+from ..base.header import BitFieldHeader, four_word_struct
+
+__all__ = ['Mark5BHeader', 'bcd_decode', 'bcd_encode', 'crc16_mark5b']
+
+_MJD_UNIX = 40587          # MJD of 1970-01-01
+
+
+def bcd_decode(value):
+    """Binary-coded decimal -> int; ValueError on a non-decimal nibble
+    (base/utils.py:18-40)."""
+    result, factor = 0, 1
+    while value > 0:
+        value, digit = divmod(value, 16)
+        if digit > 9:
+            raise ValueError("invalid BCD encoded value {0}={1}."
+                             .format(value, hex(value)))
+        result += digit * factor
+        factor *= 10
+    return result
+
+
+def bcd_encode(value):
+    result, shift = 0, 0
+    value = int(value)
+    while value > 0:
+        value, digit = divmod(value, 10)
+        result += digit << shift
+        shift += 4
+    return result
+
+
+def crc16_mark5b(words):
+    """CRC-16-IBM, x^16 + x^15 + x^2 + 1 = 0x18005 (mark5b/header.py:20-31,154-160)
+    over the 48 time-stamp bits: bcd_jday/bcd_seconds word and bcd_fraction."""
+    stream = (int(words[2]) << 16) | (int(words[3]) >> 16)
+    nbits, poly, ncrc = 48, 0x18005, 16
+    value = stream << ncrc
+    for i in range(nbits - 1, -1, -1):
+        if value & (1 << (i + ncrc)):
+            value ^= poly << i
+    return value & 0xffff
+
+
+class Mark5BHeader(BitFieldHeader):
+    _fields = {
+        'sync_pattern': (0, 0, 32, 0xABADDEED),
+        'user': (1, 16, 16),
+        'internal_tvg': (1, 15, 1),
+        'frame_nr': (1, 0, 15),
+        'bcd_jday': (2, 20, 12),
+        'bcd_seconds': (2, 0, 20),
+        'bcd_fraction': (3, 16, 16),
+        'crc': (3, 0, 16),
+    }
+    _struct = four_word_struct
+    _stream_invariants = {'sync_pattern', 'user'}
+    payload_nbytes = 10000
+    frame_nbytes = 10016
+    complex_data = False
+    kday = None
+
+    def __init__(self, words=None, kday=None, ref_time=None, verify=True):
+        if kday is not None:
+            self.kday = kday
+        super().__init__(words, verify=verify)
+        if kday is None and ref_time is not None:
+            self.infer_kday(ref_time)
+
+    @classmethod
+    def fromfile(cls, fh, kday=None, ref_time=None, verify=True):
+        s = fh.read(16)
+        if len(s) != 16:
+            raise EOFError
+        return cls(four_word_struct.unpack(s), kday=kday, ref_time=ref_time,
+                   verify=verify)
+
+    @classmethod
+    def fromvalues(cls, *, time=None, frame_rate=None, verify=True, **kwargs):
+        self = cls(None, verify=False)
+        self['sync_pattern'] = None
+        for key in [k for k in kwargs if k in cls._fields]:
+            self[key] = kwargs.pop(key)
+        for key in ('kday', 'jday', 'seconds', 'fraction'):
+            if key in kwargs:
+                setattr(self, key, kwargs.pop(key))
+        if kwargs:
+            raise KeyError("unknown header keywords: {}".format(sorted(kwargs)))
+        if time is not None:
+            self.set_time(time, frame_rate)
+        self['crc'] = crc16_mark5b(self.words)
+        if verify:
+            self.verify()
+        return self
+
+    def verify(self):
+        assert len(self.words) == 4
+        assert self['sync_pattern'] == 0xABADDEED
+        assert self.kday is None or (33000 < self.kday < 400000)
+        if self.kday is not None:
+            assert self.kday % 1000 == 0, "kday must be thousands of MJD."
+
+    def copy(self):
+        new = super().copy()
+        new.kday = self.kday
+        return new
+
+    def infer_kday(self, ref_time):
+        """Thousands of MJD such that the time is within 500 days of ref_time
+        (mark5b/header.py:160-175)."""
+        ref_mjd = (np.datetime64(ref_time, 'ns') - np.datetime64('1970-01-01', 'ns')
+                   ) / np.timedelta64(1, 'D') + _MJD_UNIX
+        self.kday = int(np.around(ref_mjd - self.jday, decimals=-3))
+
+    @property
+    def jday(self):
+        return bcd_decode(self['bcd_jday'])
+
+    @jday.setter
+    def jday(self, jday):
+        self['bcd_jday'] = bcd_encode(jday)
+
+    @property
+    def seconds(self):
+        return bcd_decode(self['bcd_seconds'])
+
+    @seconds.setter
+    def seconds(self, seconds):
+        self['bcd_seconds'] = bcd_encode(seconds)
+
+    @property
+    def fraction(self):
+        """Fractional second, 'unrounded' from the 0.1 ms stamp
+        (mark5b/header.py:206-225)."""
+        ns = bcd_decode(self['bcd_fraction']) * 100000
+        return (156250 * ((ns + 156249) // 156250)) / 1e9
+
+    @fraction.setter
+    def fraction(self, fraction):
+        ns = np.around(fraction * 1.e9)
+        self['bcd_fraction'] = bcd_encode(int(ns / 100000))
+
+    def get_time(self, frame_rate=None):
+        frame_nr = self['frame_nr']
+        if frame_nr == 0:
+            fraction = 0.
+        elif frame_rate is None:
+            fraction = self.fraction
+            if fraction == 0.:
+                raise ValueError('header does not provide correct fractional '
+                                 'second (it is zero for non-zero frame '
+                                 'number). Please pass in a frame_rate.')
+        else:
+            fraction = frame_nr / float(frame_rate)
+        days = self.kday + self.jday - _MJD_UNIX
+        return (np.datetime64('1970-01-01', 'ns') + np.timedelta64(days, 'D')
+                + np.timedelta64(self.seconds, 's')
+                + np.timedelta64(int(round(fraction * 1e9)), 'ns'))
+
+    def set_time(self, time, frame_rate=None):
+        time = np.datetime64(time, 'ns')
+        dt = int((time - np.datetime64('1970-01-01', 'ns')) / np.timedelta64(1, 'ns'))
+        days, ns = divmod(dt, 86400 * 1000000000)
+        mjd = days + _MJD_UNIX
+        self.kday = (mjd // 1000) * 1000
+        self.jday = mjd - self.kday
+        int_sec, ns = divmod(ns, 1000000000)
+        frame_nr, frac = 0, 0.
+        if ns:
+            if frame_rate is None:
+                raise ValueError("cannot calculate frame rate. Pass it "
+                                 "in explicitly.")
+            frame_nr = int(round(ns * float(frame_rate) / 1e9))
+            frac = frame_nr / float(frame_rate)
+            if abs(frac - 1.) < 1e-9:
+                int_sec, frame_nr, frac = int_sec + 1, 0, 0.
+        self.seconds = int_sec
+        self.fraction = frac
+        self['frame_nr'] = frame_nr
+
+    time = property(get_time, set_time)

@@ -1,0 +1,109 @@
+"""Synthetic file images (host side) for tests, smoke and bench.
+
+The reference's writers cannot travel to the GPU box, so inputs are made
+here.  Header words are built with this package's header classes; the byte
+layout is checked byte-for-byte against files written by the reference's own
+writers (tests/golden/synth/*.bin, see tests/test_host_logic.py).
+"""
+import numpy as np
+
+from .vdif.header import VDIFHeader
+from .base import encoding as enc
+
+
+def vdif_frame_headers(header0, nsets, thread_ids, frame_rate,
+                       thread_order=None):
+    """(nsets * nthread, nwords) uint32 header words for consecutive frame
+    sets starting at header0's time; threads are stored in `thread_order`
+    (positions into thread_ids) within each set."""
+    nthread = len(thread_ids)
+    order = list(range(nthread)) if thread_order is None else list(thread_order)
+    nwords = header0.nbytes // 4
+    words = np.empty((nsets, nthread, nwords), dtype=np.uint32)
+    words[...] = np.array(header0.words, dtype=np.uint32)
+    idx = np.arange(nsets, dtype=np.int64) + header0['frame_nr']
+    seconds = header0['seconds'] + idx // frame_rate
+    frame_nr = idx % frame_rate
+    words[:, :, 0] = ((words[:, :, 0] & np.uint32(0xc0000000))
+                      | seconds[:, None].astype(np.uint32))
+    words[:, :, 1] = ((words[:, :, 1] & np.uint32(0xff000000))
+                      | frame_nr[:, None].astype(np.uint32))
+    tids = np.array([thread_ids[p] for p in order], dtype=np.uint32)
+    words[:, :, 3] = ((words[:, :, 3] & np.uint32(0xfc00ffff))
+                      | (tids[None, :] << np.uint32(16)))
+    if header0.edv == 0xab:
+        words[:, :, 5] = ((words[:, :, 5] & np.uint32(0xffff8000))
+                          | frame_nr[:, None].astype(np.uint32))
+    return words.reshape(nsets * nthread, nwords)
+
+
+def vdif_file_image(payloads, header0, thread_ids=(0,), frame_rate=100,
+                    thread_order=None, invalid=()):
+    """Assemble a VDIF file image.
+
+    payloads : uint8 array (nsets, nthread, payload_nbytes) in thread_ids order
+    invalid  : iterable of (set, thread position) whose invalid_data bit is set
+    Returns a 1-D uint8 array.
+    """
+    payloads = np.asarray(payloads, dtype=np.uint8)
+    nsets, nthread, pn = payloads.shape
+    assert nthread == len(thread_ids) and pn == header0.payload_nbytes
+    order = list(range(nthread)) if thread_order is None else list(thread_order)
+    hw = vdif_frame_headers(header0, nsets, thread_ids, frame_rate, order)
+    hn = header0.nbytes
+    out = np.empty((nsets, nthread, hn + pn), dtype=np.uint8)
+    out[:, :, :hn] = hw.view(np.uint8).reshape(nsets, nthread, hn)
+    out[:, :, hn:] = payloads[:, order, :]
+    for s, p in invalid:
+        out[s, order.index(p), 3] |= 0x80
+    return out.reshape(-1)
+
+
+def encode_vdif_stream(data, header0, frame_rate, thread_ids=None,
+                       thread_order=None):
+    """Encode (nsample, nthread, nchan) data as a complete VDIF file image
+    (what the reference's stream writer would produce)."""
+    data = np.asarray(data)
+    nsample, nthread, nchan = data.shape
+    spf = header0.samples_per_frame
+    assert nsample % spf == 0
+    nsets = nsample // spf
+    if thread_ids is None:
+        thread_ids = list(range(nthread))
+    comp = enc.components(np.ascontiguousarray(
+        data.reshape(nsets, spf, nthread, nchan).transpose(0, 2, 1, 3)))
+    bps = header0.bps
+    if header0.edv == 0xab:
+        from .mark5b.payload import encode_mark5b
+        packed = encode_mark5b(comp, bps)
+    else:
+        codes = {1: enc.codes_1bit, 2: enc.codes_2bit, 4: enc.codes_4bit,
+                 8: enc.codes_8bit}[bps](comp)
+        packed = enc.pack_codes(codes, bps)
+    payloads = packed.reshape(nsets, nthread, -1)
+    return vdif_file_image(payloads, header0, thread_ids, frame_rate,
+                           thread_order)
+
+
+def random_vdif(seed, nsets, *, nthread=1, nchan=1, bps=2, complex_data=False,
+                edv=0, payload_nbytes=8000, frame_rate=1000, station='AA',
+                time='2020-01-01T00:00:00', thread_order=None, invalid=()):
+    """Seeded random VDIF file image (uniform random payload bytes: every
+    code equally likely) plus its header0."""
+    kw = dict(bps=bps, nchan=nchan, complex_data=complex_data,
+              station=station, time=np.datetime64(time), frame_rate=frame_rate)
+    if edv == 3:
+        kw['frame_length'] = 629
+    else:
+        kw['payload_nbytes'] = payload_nbytes
+    if edv in (1, 3):
+        vpw = 32 // bps // (2 if complex_data else 1)
+        spf = (kw.get('payload_nbytes', 5000)) // 4 * vpw // nchan
+        kw['sample_rate'] = spf * frame_rate
+    header0 = VDIFHeader.fromvalues(edv=edv, **kw)
+    rng = np.random.default_rng(seed)
+    payloads = rng.integers(0, 256, size=(nsets, nthread, header0.payload_nbytes),
+                            dtype=np.uint8)
+    image = vdif_file_image(payloads, header0, list(range(nthread)), frame_rate,
+                            thread_order, invalid)
+    return image, header0

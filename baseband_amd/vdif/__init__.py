@@ -1,0 +1,8 @@
+"""VDIF format: GPU-decoded reader with the reference's call shapes."""
+from .header import VDIFHeader
+from .payload import VDIFPayload
+from .frame import VDIFFrame, VDIFFrameSet
+from .base import VDIFFileReader, VDIFStreamReader, open
+
+__all__ = ['VDIFHeader', 'VDIFPayload', 'VDIFFrame', 'VDIFFrameSet',
+           'VDIFFileReader', 'VDIFStreamReader', 'open']

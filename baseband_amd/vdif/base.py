@@ -1,0 +1,231 @@
+"""VDIF file and stream readers, and ``open``.
+
+Mirrors ``VDIFFileReader`` (vdif/base.py:70-298), ``VDIFStreamReader``
+(vdif/base.py:413-755) and ``open`` (vdif/base.py:810-884) for the reading
+modes ``'rb'`` and ``'rs'``.  The stream reader's per-frame-set Python loop
+(base/base.py:957-967 -> vdif/frame.py:176-243,402-434) is replaced per staged
+window by three launches: ``bb_vdif_scan`` -> ``bb_build_index`` ->
+``bb_decode_frames``.
+"""
+import io
+
+import numpy as np
+import torch
+
+from .. import _lib, kernels
+from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
+                         HeaderNotFoundError)
+from ..base.header import strided_header_words
+from .header import VDIFHeader
+from .frame import VDIFFrame, VDIFFrameSet
+
+__all__ = ['VDIFFileReader', 'VDIFStreamReader', 'open']
+
+
+class VDIFFileReader(VLBIFileReaderBase):
+    """Simple reader for VDIF files: headers, frames, frame sets."""
+
+    def read_header(self, edv=None, verify=True):
+        return VDIFHeader.fromfile(self.fh_raw, edv=edv, verify=verify)
+
+    def read_frame(self, edv=None, verify=True):
+        return VDIFFrame.fromfile(self.fh_raw, edv=edv, verify=verify)
+
+    def read_frameset(self, thread_ids=None, edv=None, verify=True):
+        return VDIFFrameSet.fromfile(self.fh_raw, thread_ids, edv=edv,
+                                     verify=verify)
+
+    def _header_table(self, header0, offset=0):
+        """(nframes, nwords) view of all headers at the fixed frame stride."""
+        return strided_header_words(self.image(), header0.frame_nbytes,
+                                    header0.nbytes // 4, offset=offset)
+
+    def get_frame_rate(self):
+        """Frames per second: largest frame number seen within the first
+        second, plus one (base/base.py:371-406); falls back to the EDV 1/3
+        header sample rate (vdif/base.py:150-170)."""
+        with self.temporary_offset(0):
+            header0 = self.read_header()
+        hw = self._header_table(header0)
+        frame_nr = hw[:, 1] & 0xffffff
+        # skip the first frame number, then walk until the count wraps to 0
+        differ = np.nonzero(frame_nr != frame_nr[0])[0]
+        if len(differ):
+            i = differ[0]
+            wrap = np.nonzero(frame_nr[i:] == 0)[0]
+            if len(wrap):
+                j = i + wrap[0]
+                return int(max(frame_nr[0], frame_nr[i:j].max() if j > i else 0)) + 1
+        rate = header0.frame_rate
+        if rate is None:
+            raise EOFError("file contains less than one second of data and "
+                           "the header does not provide a sample rate.")
+        return int(round(rate))
+
+    def get_thread_ids(self, check=2):
+        """Sorted thread ids: frame sets are scanned until the set of ids
+        stops growing for `check` sets (vdif/base.py:172-215)."""
+        pos = self.fh_raw.tell()
+        with self.temporary_offset():
+            header0 = self.read_header()
+        hw = self._header_table(header0, offset=pos)
+        frame_nrs = hw[:, 1] & 0xffffff
+        threads = (hw[:, 3] >> 16) & 0x3ff
+        seen, n_check, k, n = set(), 1, 0, len(hw)
+        while n_check > 0:
+            if k >= n:
+                # very short files (like the samples) are let through
+                if len(self.image()) - pos > check * len(seen) * header0.frame_nbytes:
+                    raise EOFError
+                break
+            fnr, n0 = frame_nrs[k], len(seen)
+            while k < n and frame_nrs[k] == fnr:
+                seen.add(int(threads[k]))
+                k += 1
+            n_check = check if len(seen) > n0 else n_check - 1
+        return sorted(seen)
+
+
+class VDIFStreamReader(GPUStreamReaderBase):
+    """VDIF stream -> device tensor of shape (nsample, nthread, nchan)
+    (squeezed / subset as requested).
+
+    Parameters are those of the reference reader (vdif/base.py:413-440);
+    ``sample_rate`` is a plain number in Hz.
+    """
+
+    def __init__(self, fh_raw, sample_rate=None, squeeze=True, subset=(),
+                 fill_value=0., verify='fix'):
+        fh_raw = VDIFFileReader(fh_raw)
+        header0 = fh_raw.read_header()
+        fh_raw.seek(0)
+        thread_ids = fh_raw.get_thread_ids()
+        nthread = len(thread_ids)
+        self._file_threads = thread_ids
+        if sample_rate is None:
+            sample_rate = header0.sample_rate
+            if sample_rate is None:
+                sample_rate = fh_raw.get_frame_rate() * header0.samples_per_frame
+        sample_rate = float(sample_rate)
+        super().__init__(
+            fh_raw, header0, sample_rate=sample_rate,
+            samples_per_frame=header0.samples_per_frame,
+            unsliced_shape=(nthread, header0.nchan), bps=header0.bps,
+            complex_data=header0.complex_data, squeeze=squeeze, subset=subset,
+            fill_value=fill_value, verify=verify)
+        self._frame_rate = int(round(sample_rate / self.samples_per_frame))
+        self._frame_nbytes = header0.frame_nbytes
+        self._set_nbytes = header0.frame_nbytes * nthread
+        self._file_offset0 = 0
+        # thread part of the subset is applied while reading
+        # (vdif/base.py:464-490)
+        if self.subset and (nthread > 1 or not self.squeeze):
+            sel = np.array(thread_ids)[self.subset[0]]
+            self._thread_ids = np.atleast_1d(sel.squeeze()).tolist()
+            if sel.shape == ():
+                new_subset0 = () if self.squeeze else (0,)
+            elif len(self._thread_ids) == 1 and self.squeeze:
+                new_subset0 = (np.newaxis,)
+            else:
+                new_subset0 = (slice(None),)
+            self._frameset_subset = new_subset0 + self.subset[1:]
+        else:
+            self._frameset_subset = self.subset
+            self._thread_ids = thread_ids
+        self._decode_shape = (len(self._thread_ids), header0.nchan)
+        self._thread_slot = None
+        self._pattern, self._mask = header0.invariant_pattern()
+        self._start_time = header0.get_time(frame_rate=self._frame_rate)
+        self._coder = (_lib.CODER_MARK5B if header0.edv == 0xab
+                       else _lib.CODER_VDIF)
+        last = self._last_header()
+        self._nsample = (self._get_index(last) + 1) * self.samples_per_frame
+
+    def _image(self):
+        return self.fh_raw.image()
+
+    def _get_index(self, header):
+        """Frame-set index relative to header0 (vdif/base.py:386-390)."""
+        return int((header['seconds'] - self.header0['seconds'])
+                   * self._frame_rate
+                   + header['frame_nr'] - self.header0['frame_nr'])
+
+    def _last_header(self):
+        """Last header of header0's thread, searching backwards from the end
+        of the file (vdif/base.py:492-517)."""
+        hw = self.fh_raw._header_table(self.header0)
+        nfull = len(self._image()) // self._frame_nbytes
+        look = 2 * len(self._file_threads) + 1
+        for k in range(min(nfull, len(hw)) - 1, max(-1, nfull - 1 - look), -1):
+            words = hw[k]
+            if ((int(words[3]) >> 16) & 0x3ff) != self.header0['thread_id']:
+                continue
+            if any(((int(w) ^ p) & m) for w, p, m in
+                   zip(words, self._pattern, self._mask)):
+                continue
+            return VDIFHeader(words, edv=self.header0.edv, verify=False)
+        raise HeaderNotFoundError(
+            "corrupt VDIF? No thread_id={0} frame in last {1} bytes."
+            .format(self.header0['thread_id'], look * self._frame_nbytes))
+
+    def _squeeze_and_subset(self, data):
+        # threads were already selected on read (vdif/base.py:519-528)
+        if self.squeeze:
+            data = data.reshape(data.shape[:1]
+                                + tuple(sh for sh in data.shape[1:] if sh > 1))
+        if self._frameset_subset:
+            sub = tuple(torch.as_tensor(np.asarray(s), device=data.device)
+                        if isinstance(s, (list, np.ndarray)) else s
+                        for s in self._frameset_subset)
+            data = data[(slice(None),) + sub]
+        return data
+
+    def _process_window(self, dbuf, first_set, last_set, out_flat):
+        """scan -> index -> decode for frame sets [first_set, last_set)."""
+        h0 = self.header0
+        nsets = last_set - first_set
+        nthread_file = len(self._file_threads)
+        nframes = min(nsets * nthread_file, dbuf.numel() // self._frame_nbytes)
+        recs = kernels.vdif_scan(
+            dbuf, nframes, self._frame_nbytes, h0.nbytes, self._pattern,
+            self._mask, h0['seconds'], h0['frame_nr'] + first_set,
+            self._frame_rate)
+        if self._thread_slot is None:
+            self._thread_slot = kernels.thread_slot_map(self._thread_ids,
+                                                        dbuf.device)
+        nslot = len(self._thread_ids)
+        src = kernels.build_index(recs, nsets, nslot, self._thread_slot)
+        chunk = h0.nchan * (2 if self.complex_data else 1)
+        kernels.decode_frames(
+            dbuf, nsets, h0.payload_nbytes, self._coder, self.bps,
+            chunk=chunk, nslot=nslot, src=src, complex_data=self.complex_data,
+            fill_value=self.fill_value, out=out_flat)
+        if self.verify:
+            meta = recs[:, 3]
+            ok = (meta >> 16) & _lib.FRAME_OK
+            expect = torch.arange(nframes, device=recs.device,
+                                  dtype=torch.int32) // nthread_file
+            bad = ((ok == 0) | (recs[:, 2] != expect)).sum()
+            if nframes < nsets * nthread_file:
+                bad = bad + (nsets * nthread_file - nframes)
+            self._pending_checks.append(bad)
+
+
+def open(name, mode='rs', **kwargs):
+    """Open a VDIF file for reading: ``'rb'`` gives a `VDIFFileReader`,
+    ``'rs'`` a `VDIFStreamReader` (vdif/base.py:810-884).  Writing modes are
+    outside the decode hot path; use ``baseband_amd.synth`` to make files."""
+    if mode not in ('rb', 'rs'):
+        raise ValueError("only reading modes 'rb' and 'rs' are supported "
+                         "(got {!r}).".format(mode))
+    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
+    if mode == 'rb':
+        if kwargs:
+            raise TypeError("got unexpected arguments {}".format(kwargs.keys()))
+        return VDIFFileReader(fh)
+    try:
+        return VDIFStreamReader(fh, **kwargs)
+    except Exception:
+        if fh is not name:
+            fh.close()
+        raise

@@ -1,0 +1,216 @@
+"""VDIF frames and frame sets.
+
+Mirrors ``VDIFFrame`` (vdif/frame.py:21-128) and ``VDIFFrameSet``
+(vdif/frame.py:131-512).  A frame set gathers the frames of all threads of
+one time step; its ``data`` is ``(nsample, nthread, nchan)``.  Instead of
+decoding each thread and copying it into a strided column
+(vdif/frame.py:402-434), the set uploads the payloads once and runs a single
+``bb_decode_frames`` launch with ``nslot = nthread`` that writes the
+interleaved layout directly; invalid frames are handed over as source -1 and
+come back as ``fill_value``.
+"""
+import numpy as np
+import torch
+
+from .. import kernels
+from ..base.frame import FrameBase
+from .header import VDIFHeader
+from .payload import VDIFPayload
+
+__all__ = ['VDIFFrame', 'VDIFFrameSet']
+
+
+class VDIFFrame(FrameBase):
+    _header_class = VDIFHeader
+    _payload_class = VDIFPayload
+
+    def __init__(self, header, payload, valid=None, verify=True):
+        self.header = header
+        self.payload = payload
+        if valid is not None:
+            self.valid = valid
+        if verify:
+            self.verify()
+
+    @property
+    def valid(self):
+        """Valid unless the header's invalid_data bit is set
+        (vdif/frame.py:79-90)."""
+        return not self.header['invalid_data']
+
+    @valid.setter
+    def valid(self, valid):
+        if bool(valid) == self.header['invalid_data']:
+            if not self.header.mutable:
+                self.header = self.header.copy()
+            self.header['invalid_data'] = not valid
+
+    def verify(self):
+        super().verify()
+        assert self.header.payload_nbytes == self.payload.nbytes
+        assert self.payload.sample_shape == (self.header.nchan,)
+
+    @classmethod
+    def fromfile(cls, fh, edv=None, verify=True):
+        header = VDIFHeader.fromfile(fh, edv, verify)
+        payload = VDIFPayload.fromfile(fh, header=header)
+        return cls(header, payload, verify=verify)
+
+    @classmethod
+    def fromdata(cls, data, header=None, verify=True, **kwargs):
+        if header is None:
+            header = VDIFHeader.fromvalues(verify=verify, **kwargs)
+        payload = VDIFPayload.fromdata(data, header=header)
+        return cls(header, payload, verify=verify)
+
+
+class VDIFFrameSet:
+    def __init__(self, frames, header0=None):
+        self.frames = frames
+        self.header0 = frames[0].header if header0 is None else header0
+        self._fill_value = 0.
+
+    @classmethod
+    def fromfile(cls, fh, thread_ids=None, edv=None, verify=True):
+        """Read frames until the frame number changes or a thread repeats
+        (vdif/frame.py:176-243)."""
+        header0 = VDIFHeader.fromfile(fh, edv, verify)
+        edv = header0.edv
+        frame_nr = header0['frame_nr']
+        frames = {}
+        header = header0
+        while True:
+            thread_id = header['thread_id']
+            if header['frame_nr'] != frame_nr or thread_id in frames:
+                fh.seek(-header.nbytes, 1)
+                break
+            if thread_ids is None or thread_id in thread_ids:
+                payload = VDIFPayload.fromfile(fh, header=header)
+                frames[thread_id] = VDIFFrame(header, payload, verify=False)
+            else:
+                fh.seek(header.payload_nbytes, 1)
+            try:
+                header = VDIFHeader.fromfile(fh, edv, verify)
+            except (EOFError, AssertionError):
+                if thread_ids is None or len(frames) == len(thread_ids):
+                    break
+                raise
+        if thread_ids and len(frames) < len(thread_ids):
+            raise OSError("could not find all requested frames.")
+        if thread_ids is None:
+            thread_ids = sorted(frames.keys())
+        return cls([frames[tid] for tid in thread_ids], header0)
+
+    def tofile(self, fh):
+        for frame in self.frames:
+            frame.tofile(fh)
+
+    @classmethod
+    def fromdata(cls, data, headers=None, verify=True, **kwargs):
+        """Encode (samples_per_frame, nthread, nchan) data as one frame per
+        thread (vdif/frame.py:250-311)."""
+        if isinstance(data, torch.Tensor):
+            data = data.cpu().numpy()
+        nthread = data.shape[1]
+        if headers is None:
+            kwargs.setdefault('thread_id', 0)
+            headers = VDIFHeader.fromvalues(
+                complex_data=(data.dtype.kind == 'c'), verify=verify, **kwargs)
+        if isinstance(headers, VDIFHeader):
+            header0 = headers
+            headers = []
+            for t in range(nthread):
+                h = header0.copy()
+                h['thread_id'] = header0['thread_id'] + t
+                headers.append(h)
+        frames = [VDIFFrame.fromdata(data[:, i], h, verify=verify)
+                  for i, h in enumerate(headers)]
+        return cls(frames)
+
+    # -- properties
+    @property
+    def sample_shape(self):
+        return (len(self.frames),) + tuple(self.frames[0].sample_shape)
+
+    def __len__(self):
+        return len(self.frames[0])
+
+    @property
+    def shape(self):
+        return (len(self),) + self.sample_shape
+
+    @property
+    def dtype(self):
+        return self.frames[0].dtype
+
+    @property
+    def nbytes(self):
+        return len(self.frames) * self.frames[0].nbytes
+
+    @property
+    def size(self):
+        size = 1
+        for dim in self.shape:
+            size *= dim
+        return size
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def valid(self):
+        return any(f.valid for f in self.frames)
+
+    @property
+    def fill_value(self):
+        return self._fill_value
+
+    @fill_value.setter
+    def fill_value(self, fill_value):
+        self._fill_value = fill_value
+        for f in self.frames:
+            f.fill_value = fill_value
+
+    def keys(self):
+        return self.header0.keys()
+
+    def __getattr__(self, attr):
+        if attr in ('frames', 'header0'):
+            raise AttributeError(attr)
+        return getattr(self.header0, attr)
+
+    def _decode_all(self):
+        """All threads in one launch -> (nsample, nthread, nchan) tensor."""
+        f0 = self.frames[0]
+        pl = f0.payload
+        nthread = len(self.frames)
+        nbytes = pl.nbytes
+        staged = np.empty(nthread * nbytes, dtype=np.uint8)
+        src = np.empty(nthread, dtype=np.int64)
+        for i, f in enumerate(self.frames):
+            staged[i * nbytes:(i + 1) * nbytes] = f.payload.words.view(np.uint8)
+            src[i] = i * nbytes if f.valid else -1
+        dbuf = kernels.to_device_bytes(staged)
+        dsrc = torch.from_numpy(src).to(dbuf.device)
+        chunk = f0.header.nchan * (2 if pl.complex_data else 1)
+        flat = kernels.decode_frames(
+            dbuf, 1, nbytes, pl._coder_id, pl.bps, chunk=chunk, nslot=nthread,
+            src=dsrc, complex_data=pl.complex_data, fill_value=self.fill_value)
+        if pl.complex_data:
+            flat = torch.view_as_complex(flat.view(-1, 2))
+        nsample = len(pl)
+        full = flat.reshape(-1, nthread, f0.header.nchan)
+        return full[:nsample]
+
+    def __getitem__(self, item=()):
+        if isinstance(item, str):
+            if item == 'thread_id':
+                return np.array([f.header[item] for f in self.frames])
+            if item != 'invalid_data':
+                return self.header0[item]
+            values = np.array([f.header[item] for f in self.frames])
+            return values[0] if len(np.unique(values)) == 1 else values
+        return self._decode_all()[item]
+
+    data = property(__getitem__, doc="Decoded frame set (device tensor).")

@@ -1,0 +1,345 @@
+"""VDIF headers (host side).
+
+Field layout and derived sizes follow the reference's VDIF header classes
+(vdif/header.py:529-542 legacy/base words, :557-559 EDV, :595-598 sample-rate
+words, :697-706 EDV 3, :763-771 EDV 2, :787-793 Mark5B-over-VDIF) and the VDIF
+1.1.1 specification.  Times are ``numpy.datetime64[ns]`` UTC labels (with a
+small built-in leap-second table) instead of astropy ``Time``.
+"""
+import numpy as np
+
+from ..base.header import (BitFieldHeader, four_word_struct,
+                           eight_word_struct)
+
+__all__ = ['VDIFHeader', 'ref_epoch_time']
+
+_LEGACY_FIELDS = {
+    'invalid_data': (0, 31, 1, False),
+    'legacy_mode': (0, 30, 1, True),
+    'seconds': (0, 0, 30),
+    '_1_30_2': (1, 30, 2, 0x0),
+    'ref_epoch': (1, 24, 6),
+    'frame_nr': (1, 0, 24, 0x0),
+    'vdif_version': (2, 29, 3, 0x1),
+    'lg2_nchan': (2, 24, 5),
+    'frame_length': (2, 0, 24, 0x80),
+    'complex_data': (3, 31, 1),
+    'bits_per_sample': (3, 26, 5),
+    'thread_id': (3, 16, 10, 0x0),
+    'station_id': (3, 0, 16),
+}
+_BASE_FIELDS = dict(_LEGACY_FIELDS, legacy_mode=(0, 30, 1, False),
+                    edv=(4, 24, 8))
+_SAMPLE_RATE_FIELDS = dict(_BASE_FIELDS,
+                           sampling_unit=(4, 23, 1),
+                           sampling_rate=(4, 0, 23),
+                           sync_pattern=(5, 0, 32, 0xACABFEED))
+_EDV_FIELDS = {
+    False: _LEGACY_FIELDS,
+    0: _BASE_FIELDS,
+    1: dict(_SAMPLE_RATE_FIELDS, das_id=(6, 0, 64, 0x0)),
+    2: dict(_BASE_FIELDS, complex_data=(3, 31, 1, 0x0),
+            bits_per_sample=(3, 26, 5, 0x1), pol=(4, 0, 1),
+            BL_quadrant=(4, 1, 2), BL_correlator=(4, 3, 1),
+            sync_pattern=(4, 4, 20, 0xa5ea5), PIC_status=(5, 0, 32),
+            PSN=(6, 0, 64)),
+    3: dict(_SAMPLE_RATE_FIELDS, frame_length=(2, 0, 24, 629),
+            loif_tuning=(6, 0, 32, 0x0), _7_28_4=(7, 28, 4, 0x0),
+            dbe_unit=(7, 24, 4, 0x0), if_nr=(7, 20, 4, 0x0),
+            subband=(7, 17, 3, 0x0), sideband=(7, 16, 1, False),
+            major_rev=(7, 12, 4, 0x0), minor_rev=(7, 8, 4, 0x0),
+            personality=(7, 0, 8)),
+    0xab: dict(_BASE_FIELDS, frame_length=(2, 0, 24, 1254),
+               sync_pattern=(4, 0, 32, 0xABADDEED), user=(5, 16, 16),
+               internal_tvg=(5, 15, 1), mark5b_frame_nr=(5, 0, 15),
+               bcd_jday=(6, 20, 12), bcd_seconds=(6, 0, 20),
+               bcd_fraction=(7, 16, 16), crc=(7, 0, 16)),
+}
+_STREAM_INV_COMMON = {'legacy_mode', 'vdif_version', 'lg2_nchan',
+                      'frame_length', 'complex_data', 'bits_per_sample',
+                      'station_id'}
+_STREAM_INVARIANTS = {
+    False: _STREAM_INV_COMMON,
+    0: _STREAM_INV_COMMON | {'edv'},
+    1: _STREAM_INV_COMMON | {'edv', 'sync_pattern', 'sampling_unit',
+                             'sampling_rate'},
+    2: _STREAM_INV_COMMON | {'edv', 'sync_pattern'},
+    3: _STREAM_INV_COMMON | {'edv', 'sync_pattern', 'sampling_unit',
+                             'sampling_rate', 'major_rev', 'minor_rev',
+                             'personality'},
+    0xab: _STREAM_INV_COMMON | {'edv', 'sync_pattern'},
+}
+
+
+def ref_epoch_time(ref_epoch):
+    """Start of VDIF reference epoch: 2000-01-01 plus 6 months per step
+    (vdif/header.py:28-32)."""
+    year = 2000 + ref_epoch // 2
+    month = 1 if ref_epoch % 2 == 0 else 7
+    return np.datetime64('{:04d}-{:02d}-01T00:00:00'.format(year, month), 'ns')
+
+
+# UTC instants just after a leap second was inserted (since the first VDIF
+# reference epoch, 2000-01-01).  The reference adds the header's elapsed
+# seconds to the epoch on the TAI scale (astropy Time + TimeDelta), so a leap
+# second between epoch and frame time shifts the UTC label by one second.
+_LEAP_INSTANTS = np.array(['2006-01-01', '2009-01-01', '2012-07-01',
+                           '2015-07-01', '2017-01-01'], dtype='datetime64[ns]')
+
+
+def _leaps_between(t0, t1):
+    return int(np.count_nonzero((_LEAP_INSTANTS > t0) & (_LEAP_INSTANTS <= t1)))
+
+
+def ref_epoch_for(time):
+    """Latest reference epoch not after `time` (vdif/header.py:393-397)."""
+    time = np.datetime64(time, 'ns')
+    ym = time.astype('datetime64[M]').astype(int)       # months since 1970-01
+    months = ym - (2000 - 1970) * 12
+    return int(months // 6)
+
+
+class VDIFHeader(BitFieldHeader):
+    """VDIF header for any supported Extended Data Version.
+
+    ``VDIFHeader(words)`` picks the field table from the words themselves
+    (legacy bit, EDV byte), as the reference's ``VDIFHeader.__new__`` does
+    (vdif/header.py:124-143).  Unknown EDVs get the base (EDV-agnostic) table.
+    """
+
+    def __init__(self, words=None, edv=None, verify=True, **kwargs):
+        if edv is None and words is not None:
+            edv = False if (int(words[0]) >> 30) & 1 else (int(words[4]) >> 24) & 0xff
+        self._edv = edv
+        self._fields = _EDV_FIELDS.get(edv, _BASE_FIELDS)
+        self._stream_invariants = _STREAM_INVARIANTS.get(
+            edv, _STREAM_INV_COMMON | {'edv'})
+        self._struct = four_word_struct if edv is False else eight_word_struct
+        if words is not None and edv is False:
+            words = words[:4]
+        super().__init__(words, verify=verify)
+
+    @classmethod
+    def fromfile(cls, fh, edv=None, verify=True):
+        """Read a header; legacy headers rewind the 16 surplus bytes
+        (vdif/header.py:158-186)."""
+        s = fh.read(32)
+        if len(s) != 32:
+            raise EOFError
+        self = cls(eight_word_struct.unpack(s), edv, verify=False)
+        if self.edv is False:
+            fh.seek(-16, 1)
+        if verify:
+            self.verify()
+        return self
+
+    @classmethod
+    def fromvalues(cls, edv=False, *, verify=True, **kwargs):
+        """Build a header from field values and/or derived properties
+        (``bps, nchan, complex_data, samples_per_frame | frame_nbytes |
+        frame_length, station, time + frame_rate, sample_rate``)."""
+        self = cls(None, edv=edv, verify=False)
+        for key, spec in self._fields.items():
+            if len(spec) > 3 and spec[3] is not None:
+                self[key] = spec[3]
+        self['legacy_mode'] = edv is False
+        if edv is not False:
+            self['edv'] = edv
+        props = ('bps', 'complex_data', 'nchan', 'frame_nbytes',
+                 'payload_nbytes', 'samples_per_frame', 'station',
+                 'sample_rate')
+        time = kwargs.pop('time', None)
+        frame_rate = kwargs.pop('frame_rate', None)
+        for key in [k for k in kwargs if k in self._fields]:
+            self[key] = kwargs.pop(key)
+        for key in props:
+            if key in kwargs:
+                setattr(self, key, kwargs.pop(key))
+        if kwargs:
+            raise KeyError("unknown header keywords: {}".format(sorted(kwargs)))
+        if time is not None:
+            self.set_time(time, frame_rate=frame_rate)
+        if verify:
+            self.verify()
+        return self
+
+    def verify(self):
+        """Basic integrity checks (vdif/header.py:550-553,569-577,587-589,
+        735-737,815-826 minus the time cross-check)."""
+        if self.edv is False:
+            assert self['legacy_mode']
+            assert len(self.words) == 4
+            assert self['frame_length'] >= 2
+            return
+        assert not self['legacy_mode']
+        assert self.edv == self['edv']
+        assert len(self.words) == 8
+        assert self['frame_length'] >= 4
+        if 'sync_pattern' in self._fields:
+            assert self['sync_pattern'] == self._fields['sync_pattern'][3]
+        if self.edv == 0:
+            assert all(w == 0 for w in self.words[4:])
+        elif self.edv == 3:
+            assert self['frame_length'] in (129, 629)
+        elif self.edv == 0xab:
+            assert self['frame_length'] == 1254
+            assert self['frame_nr'] == self['mark5b_frame_nr']
+            assert not self['complex_data']
+
+    def same_stream(self, other):
+        return all(self[key] == other[key] for key in self.invariants())
+
+    # -- derived properties (vdif/header.py:283-364)
+    @property
+    def edv(self):
+        return self._edv
+
+    @property
+    def frame_nbytes(self):
+        return self['frame_length'] * 8
+
+    @frame_nbytes.setter
+    def frame_nbytes(self, nbytes):
+        assert nbytes % 8 == 0
+        self['frame_length'] = int(nbytes) // 8
+
+    @property
+    def payload_nbytes(self):
+        return self.frame_nbytes - self.nbytes
+
+    @payload_nbytes.setter
+    def payload_nbytes(self, nbytes):
+        self.frame_nbytes = nbytes + self.nbytes
+
+    @property
+    def bps(self):
+        return self['bits_per_sample'] + 1
+
+    @bps.setter
+    def bps(self, bps):
+        self['bits_per_sample'] = int(bps) - 1
+
+    @property
+    def complex_data(self):
+        return self['complex_data']
+
+    @complex_data.setter
+    def complex_data(self, complex_data):
+        self['complex_data'] = bool(complex_data)
+
+    @property
+    def nchan(self):
+        return 2 ** self['lg2_nchan']
+
+    @nchan.setter
+    def nchan(self, nchan):
+        if nchan <= 0 or (nchan & (nchan - 1)) != 0:
+            raise ValueError("channel numbers have to be powers of two.")
+        self['lg2_nchan'] = int(nchan).bit_length() - 1
+
+    @property
+    def sample_shape(self):
+        return (self.nchan,)
+
+    @property
+    def samples_per_frame(self):
+        # values are not split over word boundaries (vdif/header.py:359-364)
+        values_per_word = 32 // self.bps // (2 if self['complex_data'] else 1)
+        return self.payload_nbytes // 4 * values_per_word // self.nchan
+
+    @samples_per_frame.setter
+    def samples_per_frame(self, samples_per_frame):
+        values_per_long = 2 * (32 // self.bps // (2 if self['complex_data'] else 1))
+        longs = (samples_per_frame * self.nchan - 1) // values_per_long + 1
+        self.payload_nbytes = int(8 * longs)
+        if self.samples_per_frame != samples_per_frame:
+            raise ValueError("header cannot store {} samples per frame. "
+                             "Nearest is {}.".format(samples_per_frame,
+                                                     self.samples_per_frame))
+
+    @property
+    def station(self):
+        msb = self['station_id'] >> 8
+        if 48 <= msb < 128:
+            return chr(msb) + chr(self['station_id'] & 0xff)
+        return self['station_id']
+
+    @station.setter
+    def station(self, station):
+        try:
+            station_id = (ord(station[0]) << 8) + ord(station[1])
+        except TypeError:
+            station_id = station
+        self['station_id'] = int(station_id)
+
+    @property
+    def sample_rate(self):
+        """Complete samples per second in Hz for EDV 1 and 3
+        (vdif/header.py:610-619); None if the header does not carry it."""
+        if 'sampling_rate' not in self._fields or self['sampling_rate'] == 0:
+            return None
+        return (self['sampling_rate'] * (1 if self['complex_data'] else 2)
+                * (1000000 if self['sampling_unit'] else 1000))
+
+    @sample_rate.setter
+    def sample_rate(self, sample_rate):
+        if 'sampling_rate' not in self._fields:
+            return
+        rate = int(round(float(sample_rate)))
+        rate //= (1 if self['complex_data'] else 2)
+        if rate % 1000000 == 0:
+            self['sampling_unit'] = True
+            self['sampling_rate'] = rate // 1000000
+        else:
+            assert rate % 1000 == 0
+            self['sampling_unit'] = False
+            self['sampling_rate'] = rate // 1000
+
+    @property
+    def frame_rate(self):
+        sr = self.sample_rate
+        return None if sr is None else sr / self.samples_per_frame
+
+    @property
+    def ref_time(self):
+        return ref_epoch_time(self['ref_epoch'])
+
+    def get_time(self, frame_rate=None):
+        """ref_epoch + seconds + frame_nr / frame_rate as datetime64[ns]."""
+        frame_nr = self['frame_nr']
+        ns = 0
+        if frame_nr:
+            if frame_rate is None:
+                frame_rate = self.frame_rate
+            if frame_rate is None:
+                raise ValueError("this header does not provide a frame "
+                                 "rate. Pass it in explicitly.")
+            ns = int(round(frame_nr * 1e9 / float(frame_rate)))
+        ref = self.ref_time
+        utc = ref + np.timedelta64(self['seconds'], 's')
+        utc = utc - np.timedelta64(_leaps_between(ref, utc), 's')
+        return utc + np.timedelta64(ns, 'ns')
+
+    def set_time(self, time, frame_rate=None):
+        time = np.datetime64(time, 'ns')
+        self['ref_epoch'] = ref_epoch_for(time)
+        dt = int((time - self.ref_time) / np.timedelta64(1, 'ns'))
+        seconds, ns = divmod(dt, 1000000000)
+        seconds += _leaps_between(self.ref_time, time)
+        frame_nr = 0
+        if ns:
+            if frame_rate is None:
+                frame_rate = self.frame_rate
+            if frame_rate is None:
+                raise ValueError("this header does not provide a frame "
+                                 "rate. Pass it in explicitly.")
+            frame_nr = int(round(ns * float(frame_rate) / 1e9))
+            if frame_nr >= int(round(float(frame_rate))):
+                frame_nr = 0
+                seconds += 1
+        self['seconds'] = seconds
+        self['frame_nr'] = frame_nr
+        if self.edv == 0xab:
+            self['mark5b_frame_nr'] = frame_nr
+
+    time = property(get_time, set_time)

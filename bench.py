@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decoded Msamples/s + achieved HBM GB/s, VDIF 2-bit.
+
+One step = one pass of the hot path (header scan -> index build -> packed
+sample decode) over one synthetic file image that is already resident in HBM:
+BASELINE.json configs[1], "synthetic 8 GiB single-thread VDIF, 2-bit real,
+1 channel, EDV 0" (8032-byte frames, 32000 samples per frame).  With N > 1
+GPUs every rank decodes its own time slab of the same size (weak scaling, no
+data-path collective: frames are independent).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events
+around the dominant kernel (k_decode_flat) on the launching stream;
+`cpu_baseline` times the NumPy restatement of the reference's per-frame read
+loop (oracle/, "port") on one host core over a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X spec peak (MI355X_MICROARCH.md)
+FRAME_NBYTES = 8032
+HEADER_NBYTES = 32
+PAYLOAD_NBYTES = 8000
+SPF = 32000                     # samples per frame (2-bit, real, 1 channel)
+FRAME_RATE = 1000               # frames per second -> 32 MHz sample rate
+
+
+def make_file_image_on_device(nframes, seed, first_frame, device):
+    """cfg2 file image born in HBM: uniform random payload bytes + EDV-0
+    headers (seconds / frame_nr incrementing).  Same header words as
+    baseband_amd.synth / the reference writer would produce."""
+    from baseband_amd.vdif.header import VDIFHeader
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    words_per_frame = FRAME_NBYTES // 4
+    img = torch.empty(nframes * words_per_frame, dtype=torch.int32, device=device)
+    step = 1 << 28
+    for lo in range(0, img.numel(), step):          # bounded temporaries
+        hi = min(img.numel(), lo + step)
+        img[lo:hi] = torch.randint(-2 ** 31, 2 ** 31 - 1, (hi - lo,), generator=g,
+                                   device=device, dtype=torch.int64).to(torch.int32)
+    h0 = VDIFHeader.fromvalues(edv=0, bps=2, nchan=1, complex_data=False,
+                               payload_nbytes=PAYLOAD_NBYTES, station='AA',
+                               time=np.datetime64('2020-01-01T00:00:00'))
+    w = [int(x) for x in h0.words]
+    v = img.view(nframes, words_per_frame)
+    idx = torch.arange(first_frame, first_frame + nframes, device=device, dtype=torch.int64)
+    v[:, 0] = (w[0] + idx // FRAME_RATE).to(torch.int32)
+    v[:, 1] = ((w[1] & 0xff000000) + idx % FRAME_RATE).to(torch.int32)
+
+    def s32(x):
+        return x - (1 << 32) if x >= (1 << 31) else x
+    v[:, 2] = s32(w[2])
+    v[:, 3] = s32(w[3])
+    v[:, 4:8] = 0
+    return img.view(torch.uint8), h0
+
+
+def cpu_baseline(target_seconds=12.0):
+    """Reference-as-written loop (NumPy port, 1 core) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import bb_oracle_np as orc
+    from baseband_amd import synth
+    nframes = 4000
+    image, _ = synth.random_vdif(12345, nframes, payload_nbytes=PAYLOAD_NBYTES,
+                                 frame_rate=FRAME_RATE)
+    orc.vdif_read(image, frame_rate=FRAME_RATE)           # warm (LUT, page faults)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        orc.vdif_read(image, frame_rate=FRAME_RATE)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or reps >= 64:
+            break
+    msps = reps * nframes * SPF / dt / 1e6
+    return {"value": round(msps, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "{} x {} frames of the same cfg2 layout ({:.1f} MiB each), "
+                      "oracle/bb_oracle_np.vdif_read (per-frame NumPy LUT take loop)"
+                      .format(reps, nframes, image.size / 2 ** 20),
+            "host": "{} logical cores; numpy {}".format(os.cpu_count(), np.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--gib', type=float, default=8.0, help="file image size per GPU")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback).")
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from baseband_amd import kernels, _lib
+    from baseband_amd.parallel import frame_slab
+    kernels.init()
+
+    nframes = int(args.gib * 2 ** 30) // FRAME_NBYTES
+    # time-slab sharding: rank r owns frames [r*nframes, (r+1)*nframes)
+    first_frame, _ = frame_slab(nframes * world, rank, world)
+    image, h0 = make_file_image_on_device(nframes, 12345 + rank, first_frame, device)
+    pattern, mask = h0.invariant_pattern()
+    out = torch.empty(nframes * SPF, dtype=torch.float32, device=device)
+    bytes_in = nframes * FRAME_NBYTES
+    bytes_out = nframes * SPF * 4
+    alg_bytes = bytes_in + bytes_out
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def step(k=None):
+        recs = kernels.vdif_scan(image, nframes, FRAME_NBYTES, HEADER_NBYTES, pattern,
+                                 mask, h0['seconds'], h0['frame_nr'] + first_frame,
+                                 FRAME_RATE)
+        src = kernels.build_index(recs, nframes, 1, None)
+        if k is not None:
+            ev[k][0].record()
+        kernels.decode_frames(image, nframes, PAYLOAD_NBYTES, _lib.CODER_VDIF, 2,
+                              src=src, out=out)
+        if k is not None:
+            ev[k][1].record()
+        return recs, src
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # parity spot check against the oracle (outside the timed region)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import bb_oracle_np as orc
+    ok = True
+    for f in (0, nframes // 3, nframes - 1):
+        raw = image[f * FRAME_NBYTES + HEADER_NBYTES:(f + 1) * FRAME_NBYTES].cpu().numpy()
+        got = out[f * SPF:(f + 1) * SPF].cpu().numpy()
+        ok &= bool(np.array_equal(got.view(np.uint32),
+                                  orc.decode_flat(raw, 'vdif', 2).view(np.uint32)))
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg = sum(kern_ms) / len(kern_ms)
+    achieved = alg_bytes / (kern_avg * 1e-3) / 1e9
+    total_samples = nframes * SPF * world * args.steps
+    value = total_samples / elapsed / 1e6
+
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f)
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "decoded Msamples/s, VDIF 2-bit 1-thread (scan + index + decode, input resident in HBM)",
+        "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "cfg2: synthetic {:.3f} GiB per GPU single-thread VDIF, "
+                               "2-bit real, 1 channel, EDV 0, 8032-byte frames"
+                               .format(bytes_in / 2 ** 30),
+                   "frames_per_gpu": nframes, "bytes_in_per_gpu": bytes_in,
+                   "bytes_out_per_gpu": bytes_out,
+                   "output": "full-size float32 tensor kept in HBM (no slab recycling)",
+                   "sharding": "time slabs, one per rank, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "k_decode_flat<2,REG,FLAT,NT>",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "kernel_ms_avg": round(kern_avg, 4),
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "traffic": traffic},
+        "parity_spot_check": ok,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

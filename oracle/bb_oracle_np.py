@@ -1,0 +1,355 @@
+"""CPU oracle (NumPy) for the baseband decode hot path -- TEST INFRASTRUCTURE.
+
+This module is a from-scratch NumPy restatement of the algorithms of the
+reference package mhvk/baseband (pure Python/NumPy, GPLv3) for the path
+``open().read() -> Payload.fromfile -> Payload.data``.  It is the checker the
+HIP kernels are compared against; it is never imported by the product package
+``baseband_amd`` (only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` use it).
+
+Parity status: PINNED.  ``oracle/gen_golden.py`` imports the real reference in
+the development container and (a) checks every function below against it on
+seeded inputs and on the reference's own sample files, (b) writes the golden
+vectors under ``tests/golden/`` that ``tests/test_oracle_*.py`` re-check
+everywhere.  Rows without a reference counterpart (Mark 4 "longitudinal
+parity", DADA NBIT=32) are not implemented here.
+
+Every function cites the reference lines it follows (paths relative to the
+reference tree).
+"""
+import numpy as np
+
+# --------------------------------------------------------------------------
+# Levels (base/encoding.py:14,46-56)
+# --------------------------------------------------------------------------
+OPTIMAL_2BIT_HIGH = 3.316505
+TWO_BIT_1_SIGMA = 2.174564
+FOUR_BIT_1_SIGMA = 2.95
+EIGHT_BIT_1_SIGMA = 71.0 / 2.
+
+LEVELS_1 = np.array([-1.0, 1.0], dtype=np.float32)
+LEVELS_2 = np.array([-OPTIMAL_2BIT_HIGH, -1.0, 1.0, OPTIMAL_2BIT_HIGH],
+                    dtype=np.float32)
+# float32 division, not a reciprocal multiply (base/encoding.py:56)
+LEVELS_4 = ((np.arange(16, dtype=np.float32) - np.float32(8.))
+            / np.float32(FOUR_BIT_1_SIGMA)).astype(np.float32)
+
+
+def levels_8bit_vdif():
+    """256-entry table of base/encoding.py:131-144 (subtract, then divide)."""
+    b = np.arange(256, dtype=np.uint8).astype(np.float32)
+    b -= np.float32(127.5)
+    b /= np.float32(EIGHT_BIT_1_SIGMA)
+    return b
+
+
+def code_levels(coder, bps):
+    """Code -> float32 level table, 2**bps entries.
+
+    coder 'vdif'   : offset binary (vdif/payload.py:53-63)
+    coder 'mark5b' : sign/magnitude, field f = s + 2 m, level index 2 s + m
+                     (mark5b/payload.py:60-66); 1 bit: set -> -1
+    coder 'int'    : two's complement (gsb/payload.py:24-42, dada/payload.py:13-14)
+    """
+    if coder == 'vdif':
+        return {1: LEVELS_1, 2: LEVELS_2, 4: LEVELS_4,
+                8: levels_8bit_vdif()}[bps]
+    if coder == 'mark5b':
+        if bps == 1:
+            return LEVELS_1[[1, 0]]
+        if bps == 2:
+            f = np.arange(4)
+            return LEVELS_2[2 * (f & 1) + (f >> 1)]
+        raise KeyError(bps)
+    if coder == 'int':
+        if bps == 4:
+            n = np.arange(16)
+            return np.where(n < 8, n, n - 16).astype(np.float32)
+        if bps == 8:
+            return np.arange(256, dtype=np.uint8).view(np.int8).astype(np.float32)
+        raise KeyError(bps)
+    raise KeyError(coder)
+
+
+def byte_lut(coder, bps):
+    """256 x (8/bps) table: byte value -> samples in time order (LSB first).
+
+    Same construction as vdif/payload.py:53-63 / mark5b/payload.py:60-72.
+    """
+    lev = code_levels(coder, bps)
+    b = np.arange(256)[:, np.newaxis]
+    i = np.arange(0, 8, bps)
+    return lev[(b >> i) & ((1 << bps) - 1)]
+
+
+_LUT_CACHE = {}
+
+
+def decode_flat(raw, coder, bps):
+    """Flat decode of payload bytes: lut.take(words.view(u1), axis=0).
+
+    vdif/payload.py:69-103, mark5b/payload.py:78-94, base/encoding.py:131-144,
+    gsb/payload.py:24-42, dada/payload.py:13-14.  Returns 1-D float32.
+    """
+    b = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) \
+        else raw.view(np.uint8).ravel()
+    if bps == 8 and coder == 'int':
+        return b.view(np.int8).astype(np.float32)
+    key = (coder, bps)
+    if key not in _LUT_CACHE:
+        _LUT_CACHE[key] = byte_lut(coder, bps)
+    return _LUT_CACHE[key].take(b, axis=0).ravel()
+
+
+def payload_data(raw, coder, bps, sample_shape, complex_data):
+    """PayloadBase._decode + __getitem__(()) (base/payload.py:314-330)."""
+    flat = decode_flat(raw, coder, bps)
+    if complex_data:
+        flat = flat.view(np.complex64)
+    return flat.reshape((-1,) + tuple(sample_shape))
+
+
+# --------------------------------------------------------------------------
+# VDIF headers (vdif/header.py:529-542,557-559,595-598; base/header.py:35-87)
+# --------------------------------------------------------------------------
+def vdif_header_fields(w):
+    """Extract the fields of an 8-word (or 4-word legacy) VDIF header."""
+    w = [int(x) for x in w]
+    h = dict(
+        invalid_data=bool(w[0] >> 31 & 1),
+        legacy_mode=bool(w[0] >> 30 & 1),
+        seconds=w[0] & 0x3fffffff,
+        ref_epoch=w[1] >> 24 & 0x3f,
+        frame_nr=w[1] & 0xffffff,
+        vdif_version=w[2] >> 29 & 0x7,
+        lg2_nchan=w[2] >> 24 & 0x1f,
+        frame_length=w[2] & 0xffffff,
+        complex_data=bool(w[3] >> 31 & 1),
+        bits_per_sample=w[3] >> 26 & 0x1f,
+        thread_id=w[3] >> 16 & 0x3ff,
+        station_id=w[3] & 0xffff)
+    h['edv'] = False if h['legacy_mode'] else (w[4] >> 24 & 0xff)
+    h['header_nbytes'] = 16 if h['legacy_mode'] else 32
+    h['frame_nbytes'] = h['frame_length'] * 8          # vdif/header.py:293-296
+    h['payload_nbytes'] = h['frame_nbytes'] - h['header_nbytes']
+    h['bps'] = h['bits_per_sample'] + 1                # :313-315
+    h['nchan'] = 2 ** h['lg2_nchan']                   # :336-338
+    # vdif/header.py:359-364
+    vpw = 32 // h['bps'] // (2 if h['complex_data'] else 1)
+    h['samples_per_frame'] = h['payload_nbytes'] // 4 * vpw // h['nchan']
+    if h['edv'] in (1, 3):                             # :595-598, :610-619
+        h['sampling_unit'] = bool(w[4] >> 23 & 1)
+        h['sampling_rate'] = w[4] & 0x7fffff
+        h['sync_pattern'] = w[5]
+    return h
+
+
+def vdif_verify(h, w):
+    """VDIFBaseHeader.verify and subclasses (vdif/header.py:550-589,735-737)."""
+    if h['legacy_mode']:
+        assert h['frame_length'] >= 2
+        return
+    assert h['frame_length'] >= 4
+    if h['edv'] == 0:
+        assert all(int(x) == 0 for x in w[4:8])
+    if h['edv'] in (1, 3):
+        assert h['sync_pattern'] == 0xACABFEED
+    if h['edv'] == 3:
+        assert h['frame_length'] in (129, 629)
+
+
+def vdif_stream_mask(edv):
+    """Stream-invariant mask words (base/header.py:588-638 with the keys of
+    vdif/header.py:109-111,560-566,603-605,727-732)."""
+    m = [0] * 8
+    m[0] |= 1 << 30                     # legacy_mode
+    m[2] |= 0x7 << 29                   # vdif_version
+    m[2] |= 0x1f << 24                  # lg2_nchan
+    m[2] |= 0xffffff                    # frame_length
+    m[3] |= 1 << 31                     # complex_data
+    m[3] |= 0x1f << 26                  # bits_per_sample
+    m[3] |= 0xffff                      # station_id
+    if edv is False:
+        return m[:4]
+    m[4] |= 0xff << 24                  # edv
+    if edv in (1, 3):
+        m[4] |= 1 << 23                 # sampling_unit
+        m[4] |= 0x7fffff                # sampling_rate
+        m[5] |= 0xffffffff              # sync_pattern
+    if edv == 3:
+        m[7] |= 0xf << 12               # major_rev
+        m[7] |= 0xf << 8                # minor_rev
+        m[7] |= 0xff                    # personality
+    if edv == 2:
+        m[4] |= 0xfffff << 4            # sync_pattern (4, 4, 20)
+    if edv == 0xab:
+        m[2] |= 0xffffff                # frame_length
+        m[4] |= 0xffffffff              # Mark 5B sync word lives in word 4
+    return m
+
+
+def vdif_frame_rate(headers):
+    """Frames per second from the frame numbers seen in one second
+    (base/base.py:371-406): max frame_nr + 1 where the count wraps."""
+    h0 = headers[0]
+    mx = 0
+    for h in headers:
+        if h['seconds'] != h0['seconds'] and h['frame_nr'] == 0 and mx > 0:
+            break
+        mx = max(mx, h['frame_nr'])
+    return mx + 1
+
+
+def vdif_sample_rate_from_header(h):
+    """EDV 1/3 sample rate in Hz (vdif/header.py:610-619); None otherwise."""
+    if h['edv'] in (1, 3) and h.get('sampling_rate', 0):
+        return (h['sampling_rate'] * (1 if h['complex_data'] else 2)
+                * (1000000 if h['sampling_unit'] else 1000))
+    return None
+
+
+def vdif_read(raw, frame_rate=None, fill_value=0., thread_ids=None,
+              coder=None):
+    """Reference-as-written VDIF stream decode of a clean file image.
+
+    Follows VDIFStreamReader.__init__ / get_thread_ids (vdif/base.py:172-215,
+    441-457), StreamReaderBase.read (base/base.py:919-969), the frameset
+    gather (vdif/frame.py:176-243,402-434), the validity fill
+    (base/frame.py:191-199) and the LUT decode, one Python iteration per
+    frameset -- this loop IS the reference algorithm and is what the CPU
+    baseline times.
+
+    Returns (out, info) with out of shape (nsample, nthread, nchan).
+    """
+    buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    w0 = buf[:32].view('<u4')
+    h0 = vdif_header_fields(w0)
+    vdif_verify(h0, w0)
+    fn, hn, pn = h0['frame_nbytes'], h0['header_nbytes'], h0['payload_nbytes']
+    nframes_file = len(buf) // fn
+    # thread census over leading framesets (vdif/base.py:172-215)
+    hdr_words = np.lib.stride_tricks.as_strided(
+        buf[:nframes_file * fn].view('<u4'), shape=(nframes_file, hn // 4),
+        strides=(fn, 4))
+    all_threads = (hdr_words[:, 3] >> 16) & 0x3ff
+    frame_nrs = hdr_words[:, 1] & 0xffffff
+    seconds = hdr_words[:, 0] & 0x3fffffff
+    seen, n_check, k = set(), 1, 0
+    while n_check > 0 and k < nframes_file:
+        fnr, n0 = frame_nrs[k], len(seen)
+        while k < nframes_file and frame_nrs[k] == fnr:
+            seen.add(int(all_threads[k]))
+            k += 1
+        n_check = 2 if len(seen) > n0 else n_check - 1
+    file_threads = sorted(seen)
+    nthread_file = len(file_threads)
+    if thread_ids is None:
+        thread_ids = file_threads
+    slot = {t: i for i, t in enumerate(thread_ids)}
+    if frame_rate is None:
+        sr = vdif_sample_rate_from_header(h0)
+        if sr is not None:
+            frame_rate = int(round(sr / h0['samples_per_frame']))
+        else:
+            same = seconds == seconds[0]
+            frame_rate = int(frame_nrs[same].max()) + 1
+    if coder is None:
+        coder = 'mark5b' if h0['edv'] == 0xab else 'vdif'
+    bps, nchan, cplx = h0['bps'], h0['nchan'], h0['complex_data']
+    spf = h0['samples_per_frame']
+    # last header of header0's thread (vdif/base.py:492-517)
+    same_thread = np.nonzero(all_threads == h0['thread_id'])[0]
+    last = same_thread[-1]
+    idx_last = int((int(seconds[last]) - h0['seconds']) * frame_rate
+                   + int(frame_nrs[last]) - h0['frame_nr'])
+    nset = idx_last + 1
+    dtype = np.complex64 if cplx else np.float32
+    out = np.empty((nset * spf, len(thread_ids), nchan), dtype=dtype)
+    set_nbytes = fn * nthread_file
+    lut = byte_lut(coder, bps) if not (coder == 'int' and bps == 8) else None
+    for i in range(nset):                      # base/base.py:957-967
+        base = i * set_nbytes
+        for k in range(nthread_file):          # vdif/frame.py:190-226
+            o = base + k * fn
+            w = buf[o:o + hn].view('<u4')
+            tid = int(w[3] >> 16) & 0x3ff
+            if tid not in slot:
+                continue
+            idx = int((int(w[0] & 0x3fffffff) - h0['seconds']) * frame_rate
+                      + int(w[1] & 0xffffff) - h0['frame_nr'])
+            assert idx == i, "wrong frame number"      # base/base.py:1108-1110
+            if w[0] >> 31:                     # base/frame.py:191-199
+                out[i * spf:(i + 1) * spf, slot[tid]] = fill_value
+                continue
+            words = buf[o + hn:o + fn]
+            d = lut.take(words, axis=0).ravel()          # vdif/payload.py:83-86
+            if cplx:
+                d = d.view(np.complex64)
+            out[i * spf:(i + 1) * spf, slot[tid]] = d.reshape(-1, nchan)[:spf]
+    info = dict(header0=h0, thread_ids=list(thread_ids), frame_rate=frame_rate,
+                samples_per_frame=spf, nframesets=nset)
+    return out, info
+
+
+# --------------------------------------------------------------------------
+# Mark 5B (mark5b/header.py:60-68,177-185; frame.py:62-70; base.py:206-213)
+# --------------------------------------------------------------------------
+MARK5B_SYNC = 0xABADDEED
+MARK5B_FRAME_NBYTES = 10016
+MARK5B_PAYLOAD_NBYTES = 10000
+MARK5B_FILL = 0x11223344
+
+
+def bcd_decode(v, ndigit):
+    """base/utils.py:18-40 restricted to ndigit digits."""
+    r, m = 0, 1
+    for i in range(ndigit):
+        d = (v >> (4 * i)) & 0xf
+        if d > 9:
+            raise ValueError("invalid BCD encoded value")
+        r += d * m
+        m *= 10
+    return r
+
+
+def mark5b_header_fields(w):
+    w = [int(x) for x in w]
+    return dict(sync_pattern=w[0], user=w[1] >> 16 & 0xffff,
+                internal_tvg=bool(w[1] >> 15 & 1), frame_nr=w[1] & 0x7fff,
+                bcd_jday=w[2] >> 20 & 0xfff, bcd_seconds=w[2] & 0xfffff,
+                bcd_fraction=w[3] >> 16 & 0xffff, crc=w[3] & 0xffff,
+                jday=bcd_decode(w[2] >> 20 & 0xfff, 3),
+                seconds=bcd_decode(w[2] & 0xfffff, 5))
+
+
+def mark5b_read(raw, nchan, bps=2, frame_rate=None, fill_value=0.):
+    """Reference-as-written Mark 5B decode of a clean file image
+    (mark5b/base.py:228-301; mark5b/frame.py:62-70; payload.py:78-94)."""
+    buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    fn = MARK5B_FRAME_NBYTES
+    nframes = len(buf) // fn
+    h0 = mark5b_header_fields(buf[:16].view('<u4'))
+    assert h0['sync_pattern'] == MARK5B_SYNC
+    hdrs = np.lib.stride_tricks.as_strided(
+        buf[:nframes * fn].view('<u4'), shape=(nframes, 4), strides=(fn, 4))
+    if frame_rate is None:
+        same = hdrs[:, 2] == hdrs[0, 2]
+        frame_rate = int((hdrs[same, 1] & 0x7fff).max()) + 1
+    spf = MARK5B_PAYLOAD_NBYTES * 8 // bps // nchan
+    hl = mark5b_header_fields(hdrs[nframes - 1])
+    idx_last = ((hl['jday'] - h0['jday']) * 86400 + hl['seconds'] - h0['seconds']) \
+        * frame_rate + hl['frame_nr'] - h0['frame_nr']
+    nfr = idx_last + 1
+    out = np.empty((nfr * spf, nchan), dtype=np.float32)
+    lut = byte_lut('mark5b', bps)
+    for i in range(nfr):
+        o = i * fn
+        w = buf[o:o + 16].view('<u4')
+        assert w[0] == MARK5B_SYNC
+        words = buf[o + 16:o + fn]
+        if np.all(words.view('<u4') == MARK5B_FILL):     # mark5b/frame.py:62-70
+            out[i * spf:(i + 1) * spf] = fill_value
+            continue
+        out[i * spf:(i + 1) * spf] = lut.take(words, axis=0).reshape(-1, nchan)
+    return out, dict(header0=h0, frame_rate=frame_rate, samples_per_frame=spf,
+                     nframes=nfr)

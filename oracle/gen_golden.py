@@ -1,0 +1,360 @@
+"""Generate golden vectors from the REAL reference (development container only).
+
+Run with the interpreter that can import the reference (astropy present):
+
+    /opt/conda/bin/python3.9 -W ignore oracle/gen_golden.py
+
+It imports mhvk/baseband from /root/reference (read-only), and
+  1. dumps the reference's level / look-up tables as uint32 bit patterns,
+  2. copies the reference's small sample DATA files (recordings, not code) to
+     tests/golden/samples/ and stores what the reference decodes from them,
+  3. writes small seeded synthetic files with the reference's own writers and
+     stores file bytes + reference-decoded output,
+  4. checks oracle/bb_oracle_np.py against the reference on all of the above
+     (asserts; this is the "oracle pinned" step).
+Only data (inputs and expected outputs) is written; no reference source text.
+"""
+import os
+import sys
+import io
+import json
+import hashlib
+import shutil
+import tempfile
+
+import numpy as np
+
+np.asscalar = getattr(np, 'asscalar', lambda a: a.item())
+np.alen = getattr(np, 'alen', len)
+sys.path.insert(0, '/root/reference')
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import astropy.units as u                       # noqa: E402
+from astropy.time import Time                   # noqa: E402
+import baseband                                 # noqa: E402
+from baseband import vdif, mark5b, mark4, dada, guppi, gsb   # noqa: E402
+from baseband.data import (                     # noqa: E402
+    SAMPLE_VDIF, SAMPLE_MWA_VDIF, SAMPLE_AROCHIME_VDIF, SAMPLE_BPS1_VDIF,
+    SAMPLE_MARK5B, SAMPLE_MARK4, SAMPLE_MARK4_32TRACK,
+    SAMPLE_MARK4_32TRACK_FANOUT2, SAMPLE_MARK4_16TRACK,
+    SAMPLE_MARK4_64TRACK_FANOUT2_FT, SAMPLE_DADA, SAMPLE_MEERKAT_DADA,
+    SAMPLE_MKBF_DADA, SAMPLE_PUPPI, SAMPLE_GSB_RAWDUMP,
+    SAMPLE_GSB_RAWDUMP_HEADER, SAMPLE_GSB_PHASED, SAMPLE_GSB_PHASED_HEADER)
+import bb_oracle_np as orc                      # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+SAMPLES = os.path.join(GOLD, 'samples')
+EXPECT = os.path.join(GOLD, 'expected')
+SYNTH = os.path.join(GOLD, 'synth')
+for d in (GOLD, SAMPLES, EXPECT, SYNTH):
+    os.makedirs(d, exist_ok=True)
+
+manifest = {'reference': 'mhvk/baseband @ 2025-08-08 (/root/reference)',
+            'numpy': np.__version__, 'cases': {}}
+
+
+class KeepBytesIO(io.BytesIO):
+    """BytesIO whose content survives the close() done by stream writers."""
+    final = None
+
+    def close(self):
+        self.final = self.getvalue()
+        super().close()
+
+    def value(self):
+        return self.final if self.closed else self.getvalue()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def save_expected(name, data, **extra):
+    data = np.ascontiguousarray(data)
+    np.savez_compressed(os.path.join(EXPECT, name + '.npz'), data=data)
+    entry = dict(shape=list(data.shape), dtype=str(data.dtype), sha256=sha(data))
+    entry.update(extra)
+    manifest['cases'][name] = entry
+    return entry
+
+
+def copy_sample(path, sub=''):
+    dst = os.path.join(SAMPLES, sub, os.path.basename(path))
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    shutil.copyfile(path, dst)
+    os.chmod(dst, 0o644)
+    return os.path.relpath(dst, GOLD)
+
+
+# ---------------------------------------------------------------- 1. levels
+def gen_levels():
+    from baseband.base import encoding
+    from baseband.vdif import payload as vp
+    from baseband.mark5b import payload as m5p
+    from baseband.mark4 import payload as m4p
+    from baseband.gsb import payload as gp
+    allb = np.arange(256, dtype=np.uint8)
+    lv = {
+        'decoder_levels_1': bits(encoding.decoder_levels[1]).tolist(),
+        'decoder_levels_2': bits(encoding.decoder_levels[2]).tolist(),
+        'decoder_levels_4': bits(encoding.decoder_levels[4]).tolist(),
+        'decode_8bit': bits(encoding.decode_8bit(allb)).tolist(),
+        'vdif_lut1bit': bits(vp.lut1bit).tolist(),
+        'vdif_lut2bit': bits(vp.lut2bit).tolist(),
+        'vdif_lut4bit': bits(vp.lut4bit).tolist(),
+        'mark5b_lut1bit': bits(m5p.lut1bit).tolist(),
+        'mark5b_lut2bit': bits(m5p.lut2bit).tolist(),
+        'mark4_lut1bit': bits(m4p.lut1bit).tolist(),
+        'mark4_lut2bit1': bits(m4p.lut2bit1).tolist(),
+        'mark4_lut2bit2': bits(m4p.lut2bit2).tolist(),
+        'mark4_lut2bit3': bits(m4p.lut2bit3).tolist(),
+        'gsb_decode_4bit': bits(gp.decode_4bit(allb.view(np.int8))
+                                .reshape(256, 2)).tolist(),
+        'gsb_decode_8bit': bits(gp.decode_8bit(allb.view(np.int8))).tolist(),
+    }
+    with open(os.path.join(GOLD, 'levels.json'), 'w') as f:
+        json.dump(lv, f)
+    # pin the oracle
+    assert np.array_equal(bits(orc.byte_lut('vdif', 1)), bits(vp.lut1bit))
+    assert np.array_equal(bits(orc.byte_lut('vdif', 2)), bits(vp.lut2bit))
+    assert np.array_equal(bits(orc.byte_lut('vdif', 4)), bits(vp.lut4bit))
+    assert np.array_equal(bits(orc.code_levels('vdif', 8)),
+                          bits(encoding.decode_8bit(allb)))
+    assert np.array_equal(bits(orc.byte_lut('mark5b', 1)), bits(m5p.lut1bit))
+    assert np.array_equal(bits(orc.byte_lut('mark5b', 2)), bits(m5p.lut2bit))
+    assert np.array_equal(bits(orc.byte_lut('int', 4)),
+                          bits(gp.decode_4bit(allb.view(np.int8)).reshape(256, 2)))
+    assert np.array_equal(bits(orc.decode_flat(allb, 'int', 8)),
+                          bits(gp.decode_8bit(allb.view(np.int8))))
+    print('levels: oracle == reference')
+
+
+# ------------------------------------------------------- 2. sample files
+def gen_vdif_samples():
+    cases = [
+        ('sample_vdif', SAMPLE_VDIF, {}),
+        ('sample_mwa_vdif', SAMPLE_MWA_VDIF, dict(sample_rate=1.28 * u.MHz)),
+        ('sample_arochime_vdif', SAMPLE_AROCHIME_VDIF,
+         dict(sample_rate=800 / 2048 * u.MHz)),
+        ('sample_bps1_vdif', SAMPLE_BPS1_VDIF, dict(sample_rate=8 * u.MHz)),
+    ]
+    for name, path, kw in cases:
+        rel = copy_sample(path)
+        with vdif.open(path, 'rs', squeeze=False, **kw) as fh:
+            data = fh.read()
+            h0 = fh.header0
+            info = dict(
+                file=rel, kwargs={k: float(v.to_value(u.Hz)) for k, v in kw.items()},
+                header0_words=[int(w) for w in h0.words],
+                samples_per_frame=int(fh.samples_per_frame),
+                sample_rate_hz=float(fh.sample_rate.to_value(u.Hz)),
+                bps=int(fh.bps), complex_data=bool(fh.complex_data),
+                thread_ids=[int(t) for t in fh._thread_ids],
+                start_time=fh.start_time.isot, stop_time=fh.stop_time.isot,
+                edv=(int(h0.edv) if h0.edv is not False else False))
+        with vdif.open(path, 'rb') as fb:
+            fb.seek(0)
+            order = []
+            while True:
+                try:
+                    h = fb.read_header()
+                except EOFError:
+                    break
+                order.append([int(h['thread_id']), int(h['frame_nr']),
+                              int(h['seconds']), bool(h['invalid_data'])])
+                fb.seek(h.payload_nbytes, 1)
+            pat, mask = h0.invariant_pattern()
+            info['frame_order'] = order
+            info['stream_mask'] = [int(m) for m in mask]
+        save_expected(name, data, **info)
+        # pin the oracle's reference-as-written loop
+        raw = np.fromfile(path, dtype=np.uint8)
+        fr = int(round(info['sample_rate_hz'] / info['samples_per_frame']))
+        out, oinfo = orc.vdif_read(raw, frame_rate=fr)
+        assert out.dtype == data.dtype and out.shape == data.shape, (name, out.shape, data.shape)
+        assert np.array_equal(out.view(np.uint32), data.view(np.uint32)), name
+        assert oinfo['thread_ids'] == info['thread_ids']
+        m = orc.vdif_stream_mask(info['edv'])
+        assert m == info['stream_mask'], (name, m, info['stream_mask'])
+        print('vdif sample', name, data.shape, data.dtype, 'oracle == reference')
+
+
+def gen_mark5b_sample():
+    rel = copy_sample(SAMPLE_MARK5B)
+    with mark5b.open(SAMPLE_MARK5B, 'rs', sample_rate=32 * u.MHz, kday=56000,
+                     nchan=8, bps=2, squeeze=False) as fh:
+        data = fh.read()
+        info = dict(file=rel, nchan=8, bps=2, sample_rate_hz=32e6, kday=56000,
+                    header0_words=[int(w) for w in fh.header0.words],
+                    samples_per_frame=int(fh.samples_per_frame),
+                    start_time=fh.start_time.isot, stop_time=fh.stop_time.isot)
+    save_expected('sample_m5b', data, **info)
+    raw = np.fromfile(SAMPLE_MARK5B, dtype=np.uint8)
+    out, _ = orc.mark5b_read(raw, nchan=8, bps=2, frame_rate=6400)
+    assert np.array_equal(out.view(np.uint32), data.view(np.uint32))
+    print('mark5b sample', data.shape, 'oracle == reference')
+
+
+# --------------------------------------------------- 3. synthetic (VDIF)
+def write_synth(name, blob, data, **info):
+    with open(os.path.join(SYNTH, name + '.bin'), 'wb') as f:
+        f.write(blob)
+    info['file'] = os.path.join('synth', name + '.bin')
+    info['file_sha256'] = hashlib.sha256(blob).hexdigest()
+    save_expected(name, data, **info)
+
+
+def levels_for(bps):
+    from baseband.base import encoding
+    if bps == 8:
+        return encoding.decode_8bit(np.arange(256, dtype=np.uint8))
+    return encoding.decoder_levels[bps]
+
+
+def gen_vdif_synth():
+    t0 = Time('2020-01-01T00:00:00', precision=9)
+    cases = [
+        # name, nthread, nchan, bps, complex, edv, samples_per_frame, nframes, seed
+        ('vdif_cfg2_small', 1, 1, 2, False, 0, 32000, 12, 12345),
+        ('vdif_cfg3_small', 8, 16, 2, True, 0, 1000, 4, 7),
+        ('vdif_bps1_c4', 1, 4, 1, False, 0, 8000, 4, 21),
+        ('vdif_bps4_cplx_t2', 2, 2, 4, True, 1, 500, 5, 22),
+        ('vdif_bps8_real_c2', 1, 2, 8, False, 1, 1000, 4, 23),
+        ('vdif_bps8_cplx_t4', 4, 1, 8, True, 0, 256, 6, 24),
+        ('vdif_bps2_t8_c1', 8, 1, 2, False, 3, 20000, 2, 25),
+        ('vdif_legacy_bps2', 2, 4, 2, False, False, 2000, 4, 26),
+        ('vdif_bps4_t2_c1', 2, 1, 4, False, 0, 64, 8, 27),
+    ]
+    for (name, nthread, nchan, bps, cplx, edv, spf, nframes, seed) in cases:
+        rng = np.random.default_rng(seed)
+        lev = levels_for(bps)
+        shape = (spf * nframes, nthread, nchan)
+        data = lev[rng.integers(0, len(lev), size=shape + ((2,) if cplx else ()))]
+        data = data.astype(np.float32)
+        if cplx:
+            data = data.view(np.complex64)[..., 0]
+        sample_rate = spf * 100 * u.Hz          # 100 frames per second
+        bio = KeepBytesIO()
+        kw = dict(sample_rate=sample_rate, samples_per_frame=spf,
+                  nthread=nthread, nchan=nchan, complex_data=cplx, bps=bps,
+                  edv=edv, station='AA', time=t0)
+        if edv == 3:
+            kw.pop('samples_per_frame')
+            kw['frame_length'] = 629
+        with vdif.open(bio, 'ws', squeeze=False, **kw) as fw:
+            fw.write(data)
+        blob = bio.value()
+        # shuffle thread order on disk within each frameset (order is "not mandated")
+        if nthread > 1:
+            with vdif.open(io.BytesIO(blob), 'rb') as fb:
+                fn = fb.read_header().frame_nbytes
+            frames = [blob[i:i + fn] for i in range(0, len(blob), fn)]
+            perm = list(range(1, nthread, 2)) + list(range(0, nthread, 2))
+            out = []
+            for s in range(0, len(frames), nthread):
+                out += [frames[s + p] for p in perm]
+            blob = b''.join(out)
+        with vdif.open(io.BytesIO(blob), 'rs', squeeze=False,
+                       sample_rate=sample_rate) as fr:
+            back = fr.read()
+            h0w = [int(w) for w in fr.header0.words]
+            thread_ids = [int(t) for t in fr._thread_ids]
+        assert np.array_equal(back.view(np.uint32), data.view(np.uint32)), name
+        write_synth(name, blob, back, nthread=nthread, nchan=nchan, bps=bps,
+                    complex_data=cplx, edv=edv, samples_per_frame=spf,
+                    nframes=nframes, seed=seed, frame_rate=100,
+                    header0_words=h0w, thread_ids=thread_ids)
+        out, _ = orc.vdif_read(np.frombuffer(blob, np.uint8), frame_rate=100)
+        assert np.array_equal(out.view(np.uint32), back.view(np.uint32)), name
+        print('vdif synth', name, back.shape, back.dtype, 'oracle == reference')
+
+
+def gen_vdif_invalid():
+    """Frames flagged invalid_data decode to fill_value (base/frame.py:191-199)."""
+    t0 = Time('2020-01-01T00:00:00', precision=9)
+    rng = np.random.default_rng(31)
+    nthread, nchan, spf, nframes = 2, 4, 400, 6
+    lev = levels_for(2)
+    data = lev[rng.integers(0, 4, size=(spf * nframes, nthread, nchan))].astype(np.float32)
+    bio = KeepBytesIO()
+    with vdif.open(bio, 'ws', squeeze=False, sample_rate=spf * 100 * u.Hz,
+                   samples_per_frame=spf, nthread=nthread, nchan=nchan,
+                   bps=2, edv=0, station='AA', time=t0) as fw:
+        fw.write(data)
+    blob = bytearray(bio.value())
+    fn = 32 + spf * nchan * 2 // 8
+    bad = [(1, 0), (3, 1), (4, 0), (4, 1)]           # (frameset, thread position)
+    for fs_, th in bad:
+        o = (fs_ * nthread + th) * fn
+        blob[o + 3] |= 0x80                          # invalid_data bit (w0.31)
+    blob = bytes(blob)
+    for fill in (0.0, -999.0):
+        with vdif.open(io.BytesIO(blob), 'rs', squeeze=False,
+                       sample_rate=spf * 100 * u.Hz, fill_value=fill) as fr:
+            back = fr.read()
+        nm = 'vdif_invalid_fill%s' % ('0' if fill == 0 else 'm999')
+        write_synth(nm, blob, back, nthread=nthread, nchan=nchan, bps=2,
+                    complex_data=False, edv=0, samples_per_frame=spf,
+                    nframes=nframes, frame_rate=100, fill_value=fill,
+                    invalid=[list(b) for b in bad])
+        out, _ = orc.vdif_read(np.frombuffer(blob, np.uint8), frame_rate=100,
+                               fill_value=fill)
+        assert np.array_equal(out.view(np.uint32), back.view(np.uint32))
+    print('vdif invalid: oracle == reference')
+
+
+def gen_mark5b_synth():
+    t0 = Time('2014-06-13T05:30:01', precision=9)
+    for name, nchan, bps, nframes, seed in (('m5b_c16_b2', 16, 2, 5, 4),
+                                           ('m5b_c8_b1', 8, 1, 3, 41),
+                                           ('m5b_c4_b2', 4, 2, 4, 42)):
+        rng = np.random.default_rng(seed)
+        spf = 10000 * 8 // bps // nchan
+        lev = levels_for(bps)
+        data = lev[rng.integers(0, len(lev), size=(spf * nframes, nchan))].astype(np.float32)
+        bio = KeepBytesIO()
+        sample_rate = spf * 400 * u.Hz
+        with mark5b.open(bio, 'ws', sample_rate=sample_rate, nchan=nchan, bps=bps,
+                         time=t0, squeeze=False) as fw:
+            fw.write(data)
+        blob = bytearray(bio.value())
+        invalid = []
+        if name == 'm5b_c16_b2':
+            # frame 2 replaced by the fill pattern -> invalid (mark5b/frame.py:62-70)
+            o = 2 * 10016 + 16
+            blob[o:o + 10000] = np.full(2500, 0x11223344, '<u4').tobytes()
+            invalid = [2]
+        blob = bytes(blob)
+        with mark5b.open(io.BytesIO(blob), 'rs', sample_rate=sample_rate, kday=56000,
+                         nchan=nchan, bps=bps, squeeze=False) as fr:
+            back = fr.read()
+            h0w = [int(w) for w in fr.header0.words]
+        write_synth(name, blob, back, nchan=nchan, bps=bps, nframes=nframes,
+                    frame_rate=400, samples_per_frame=spf, seed=seed,
+                    kday=56000, header0_words=h0w, invalid=invalid)
+        out, _ = orc.mark5b_read(np.frombuffer(blob, np.uint8), nchan=nchan,
+                                 bps=bps, frame_rate=400)
+        assert np.array_equal(out.view(np.uint32), back.view(np.uint32)), name
+        print('mark5b synth', name, back.shape, 'oracle == reference')
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['all']
+    steps = [('levels', gen_levels), ('vdif_samples', gen_vdif_samples),
+             ('mark5b_sample', gen_mark5b_sample), ('vdif_synth', gen_vdif_synth),
+             ('vdif_invalid', gen_vdif_invalid), ('mark5b_synth', gen_mark5b_synth)]
+    mpath = os.path.join(GOLD, 'manifest.json')
+    if os.path.exists(mpath) and which != ['all']:
+        with open(mpath) as f:
+            manifest = json.load(f)
+    for nm, fn in steps:
+        if 'all' in which or nm in which:
+            fn()
+    with open(mpath, 'w') as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print('wrote', mpath, len(manifest['cases']), 'cases')

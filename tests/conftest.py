@@ -1,0 +1,66 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        "markers", "gpu: test needs a real MI355X (run with -m gpu)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="needs a GPU (torch.cuda.is_available() is False)")
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def manifest():
+    with open(os.path.join(GOLD, 'manifest.json')) as f:
+        return json.load(f)['cases']
+
+
+@pytest.fixture(scope='session')
+def levels_json():
+    with open(os.path.join(GOLD, 'levels.json')) as f:
+        return {k: np.array(v, dtype=np.uint32) for k, v in json.load(f).items()}
+
+
+def golden_path(rel):
+    return os.path.join(GOLD, rel)
+
+
+def load_expected(name):
+    return np.load(os.path.join(GOLD, 'expected', name + '.npz'))['data']
+
+
+def load_file(rel):
+    return np.fromfile(os.path.join(GOLD, rel), dtype=np.uint8)
+
+
+def bits_equal(a, b):
+    """Bit-exact comparison of float32/complex64 arrays."""
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    return (a.shape == b.shape and a.dtype == b.dtype
+            and np.array_equal(a.view(np.uint32), b.view(np.uint32)))

@@ -1,0 +1,216 @@
+"""Host-side logic (no GPU): headers, thread census, geometry, slicing
+arithmetic, and the synthetic-file packers (byte-identical to files written
+by the reference's own writers)."""
+import io
+
+import numpy as np
+import pytest
+
+from conftest import golden_path, load_expected, load_file
+
+from baseband_amd import vdif, mark5b, synth
+from baseband_amd.vdif.header import VDIFHeader, ref_epoch_time
+from baseband_amd.vdif.payload import VDIFPayload
+from baseband_amd.mark5b.header import Mark5BHeader, crc16_mark5b
+from baseband_amd.mark5b.payload import encode_mark5b
+from baseband_amd.base import encoding as enc
+
+
+def test_vdif_header_fields_sample(manifest):
+    case = manifest['sample_vdif']
+    h = VDIFHeader(case['header0_words'])
+    # sample.vdif facts (vdif/tests/test_vdif.py:44-80)
+    assert h.edv == 3 and h.frame_nbytes == 5032 and h.payload_nbytes == 5000
+    assert h.bps == 2 and h.nchan == 1 and not h.complex_data
+    assert h.samples_per_frame == 20000 == case['samples_per_frame']
+    assert h['thread_id'] == 1 and h['frame_nr'] == 0
+    assert h.sample_rate == case['sample_rate_hz']
+    assert str(h.get_time()).startswith(case['start_time'][:19])
+    pattern, mask = h.invariant_pattern()
+    assert mask == case['stream_mask']
+    assert h.same_stream(h)
+    with pytest.raises(TypeError):
+        h['frame_nr'] = 3                 # immutable when read from words
+    h2 = h.copy()
+    h2['frame_nr'] = 3
+    assert h2['frame_nr'] == 3 and h['frame_nr'] == 0
+
+
+@pytest.mark.parametrize('name', ['sample_vdif', 'sample_mwa_vdif',
+                                  'sample_arochime_vdif', 'sample_bps1_vdif'])
+def test_vdif_stream_geometry(manifest, name):
+    case = manifest[name]
+    kw = {}
+    if case['kwargs']:
+        kw['sample_rate'] = case['kwargs']['sample_rate']
+    with vdif.open(golden_path(case['file']), 'rs', squeeze=False, **kw) as fh:
+        assert fh.shape == tuple(case['shape'])
+        assert fh.dtype == np.dtype(case['dtype'])
+        assert fh.samples_per_frame == case['samples_per_frame']
+        assert fh._thread_ids == case['thread_ids']
+        assert fh.bps == case['bps'] and fh.complex_data == case['complex_data']
+        assert abs(fh.sample_rate - case['sample_rate_hz']) < 1e-6
+        assert str(fh.start_time)[:23] == case['start_time'][:23]
+        assert str(fh.stop_time)[:23] == case['stop_time'][:23]
+        assert fh.tell() == 0
+        assert fh.seek(5) == 5 and fh.seek(-2, 2) == fh.shape[0] - 2
+        assert fh.seek(3, 'current') == fh.shape[0] + 1
+        with pytest.raises(ValueError):
+            fh.seek(0, 7)
+
+
+def test_vdif_squeeze_subset_shapes(manifest):
+    """Shapes for the squeeze/subset matrix (vdif/tests/test_vdif.py:1072-1149)."""
+    f = golden_path(manifest['sample_vdif']['file'])
+    with vdif.open(f, 'rs') as fh:
+        assert fh.sample_shape == (8,) and fh.shape == (40000, 8)
+    with vdif.open(f, 'rs', squeeze=False) as fh:
+        assert fh.sample_shape == (8, 1)
+    with vdif.open(f, 'rs', subset=[1, 3]) as fh:
+        assert fh.sample_shape == (2,) and fh._thread_ids == [1, 3]
+    with vdif.open(f, 'rs', subset=2) as fh:
+        assert fh.sample_shape == () and fh._thread_ids == [2]
+    with vdif.open(f, 'rs', squeeze=False, subset=(slice(1, 7, 2), 0)) as fh:
+        assert fh.sample_shape == (3,) and fh._thread_ids == [1, 3, 5]
+
+
+def test_vdif_file_reader_headers(manifest):
+    case = manifest['sample_vdif']
+    with vdif.open(golden_path(case['file']), 'rb') as fb:
+        assert fb.get_thread_ids() == list(range(8))
+        order = []
+        for _ in range(16):
+            h = fb.read_header()
+            order.append([h['thread_id'], h['frame_nr'], h['seconds'], h['invalid_data']])
+            fb.seek(h.payload_nbytes, 1)
+        assert order == case['frame_order']
+        with pytest.raises(EOFError):
+            fb.read_header()
+        assert fb.get_frame_rate() == 1600            # from the EDV 3 header
+
+
+def test_vdif_legacy_header(manifest):
+    case = manifest['vdif_legacy_bps2']
+    with vdif.open(golden_path(case['file']), 'rb') as fb:
+        h = fb.read_header()
+        assert h.edv is False and h.nbytes == 16 and fb.tell() == 16
+        assert list(h.words) == case['header0_words']
+        assert h.payload_nbytes == h.frame_nbytes - 16
+
+
+def test_item_to_slices_matches_bruteforce():
+    """_item_to_slices picks the minimal word range (base/payload.py:226-312)."""
+    for bps, nchan, cplx in ((2, 1, False), (2, 4, False), (4, 2, True),
+                             (8, 2, True), (1, 8, False), (8, 16, True)):
+        words = np.zeros(64, '<u4')
+        pl = VDIFPayload(words, sample_shape=(nchan,), bps=bps, complex_data=cplx)
+        n = len(pl)
+        bpfs = bps * nchan * (2 if cplx else 1)
+        assert n == 64 * 32 // bpfs
+        for item in (0, 1, n - 1, -1, slice(3, 9), slice(None), slice(1, None, 3),
+                     slice(5, 6), (slice(2, 20), 0), slice(0, n), slice(n // 2, n)):
+            ws, ds = pl._item_to_slices(item)
+            w0, w1, _ = ws.indices(64)
+            first = item[0] if isinstance(item, tuple) else item
+            if isinstance(first, slice):
+                start, stop, step = first.indices(n)
+            else:
+                start = first % n
+                stop = start + 1
+            # every requested sample's bits lie inside the word range
+            assert w0 * 32 <= start * bpfs and stop * bpfs <= w1 * 32
+            if (stop - start) != n:
+                # minimal: cannot drop a word on either side
+                assert (w0 + 1) * 32 > start * bpfs and (w1 - 1) * 32 < stop * bpfs
+    with pytest.raises(IndexError):
+        pl[len(pl)]
+    with pytest.raises(TypeError):
+        pl['a']
+
+
+def test_payload_constructor_errors():
+    with pytest.raises(ValueError):
+        VDIFPayload(np.zeros(8, '<u2'), bps=2)            # wrong word dtype
+    h = VDIFHeader.fromvalues(edv=0, bps=2, nchan=1, payload_nbytes=64,
+                              station='AA', time=np.datetime64('2020-01-01'))
+    with pytest.raises(ValueError):
+        VDIFPayload(np.zeros(8, '<u4'), header=h)         # wrong size
+    with pytest.raises(EOFError):
+        VDIFPayload.fromfile(io.BytesIO(b'\0' * 10), header=h)
+    with pytest.raises(ValueError):
+        VDIFPayload(np.zeros(8, '<u4'), sample_shape=(2,), bps=3)
+
+
+SYNTH_VDIF = ['vdif_cfg2_small', 'vdif_cfg3_small', 'vdif_bps1_c4',
+              'vdif_bps4_cplx_t2', 'vdif_bps8_real_c2', 'vdif_bps8_cplx_t4',
+              'vdif_bps2_t8_c1', 'vdif_legacy_bps2', 'vdif_bps4_t2_c1']
+
+
+@pytest.mark.parametrize('name', SYNTH_VDIF)
+def test_vdif_packer_is_byte_identical_to_reference_writer(manifest, name):
+    case = manifest[name]
+    blob = load_file(case['file'])
+    data = load_expected(name)
+    header0 = VDIFHeader(case['header0_words']).copy()
+    # header0 on disk belongs to the first stored thread; rebuild thread 0's
+    header0['thread_id'] = 0
+    nthread = case['nthread']
+    order = (list(range(1, nthread, 2)) + list(range(0, nthread, 2))
+             if nthread > 1 else None)
+    image = synth.encode_vdif_stream(data, header0, case['frame_rate'],
+                                     thread_order=order)
+    assert image.tobytes() == blob.tobytes()
+
+
+def test_vdif_fromvalues_roundtrip(manifest):
+    case = manifest['vdif_cfg2_small']
+    h = VDIFHeader.fromvalues(edv=0, bps=2, nchan=1, complex_data=False,
+                              samples_per_frame=32000, station='AA',
+                              time=np.datetime64('2020-01-01T00:00:00'))
+    assert list(h.words) == case['header0_words']
+    assert h.frame_nbytes == 8032
+    case = manifest['vdif_bps4_cplx_t2']
+    h = VDIFHeader.fromvalues(edv=1, bps=4, nchan=2, complex_data=True,
+                              samples_per_frame=500, station='AA',
+                              sample_rate=50000,
+                              time=np.datetime64('2020-01-01T00:00:00'))
+    w = list(h.words)
+    w[3] |= case['header0_words'][3] & (0x3ff << 16)      # thread id on disk
+    assert w == case['header0_words']
+    assert ref_epoch_time(40) == np.datetime64('2020-01-01')
+    with pytest.raises(ValueError):
+        VDIFHeader.fromvalues(edv=0, bps=2, nchan=3, payload_nbytes=64)
+
+
+def test_encoders_thresholds():
+    lev = np.array([-3.316505, -1., 1., 3.316505], np.float32)
+    assert enc.codes_2bit(lev).tolist() == [0, 1, 2, 3]
+    assert enc.codes_2bit(np.array([-2.2, -2.1, -0.1, 0.1, 2.1, 2.2])).tolist() == [0, 1, 1, 2, 2, 3]
+    assert enc.codes_1bit(np.array([-1., 1., 0.])).tolist() == [0, 1, 1]
+    l4 = (np.arange(16, dtype=np.float32) - 8) / np.float32(2.95)
+    assert enc.codes_4bit(l4).tolist() == list(range(16))
+    l8 = (np.arange(256, dtype=np.float32) - np.float32(127.5)) / np.float32(35.5)
+    assert enc.codes_8bit(l8).tolist() == list(range(256))
+    assert enc.pack_codes([1, 1, 2, 2], 2).tolist() == [0b10100101]
+    assert encode_mark5b(lev, 2).tolist() == [0b11011000]
+
+
+def test_mark5b_header_and_geometry(manifest):
+    case = manifest['sample_m5b']
+    h = Mark5BHeader(case['header0_words'], kday=56000)
+    assert h.jday == 821 and h.seconds == 19801 and h['frame_nr'] == 0
+    assert crc16_mark5b(h.words) == h['crc']
+    assert str(h.get_time()).startswith('2014-06-13T05:30:01')
+    with mark5b.open(golden_path(case['file']), 'rs', sample_rate=32e6,
+                     kday=56000, nchan=8, bps=2) as fh:
+        assert fh.shape == tuple(case['shape'])
+        assert fh.samples_per_frame == 5000
+        assert str(fh.start_time)[:23] == case['start_time'][:23]
+        assert str(fh.stop_time)[:23] == case['stop_time'][:23]
+    with pytest.raises(TypeError):
+        mark5b.open(golden_path(case['file']), 'rs', kday=56000)
+    with pytest.raises(TypeError):
+        mark5b.open(golden_path(case['file']), 'rs', nchan=8)
+    h2 = Mark5BHeader.fromvalues(time=np.datetime64('2014-06-13T05:30:01'),
+                                 user=h['user'])
+    assert list(h2.words) == list(h.words)

@@ -1,0 +1,184 @@
+"""Raw C-ABI kernels against the CPU oracle (bit-exact), on the GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bb_oracle_np as orc
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+CODERS = {'vdif': 0, 'mark5b': 1, 'int': 2}
+COMBOS = [('vdif', 1), ('vdif', 2), ('vdif', 4), ('vdif', 8),
+          ('mark5b', 1), ('mark5b', 2), ('int', 4), ('int', 8)]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+@pytest.mark.parametrize('coder,bps', COMBOS)
+@pytest.mark.parametrize('nbytes', [8, 256, 1000, 8000, 8192 + 24, 70000])
+def test_flat_decode_single_payload(coder, bps, nbytes):
+    from baseband_amd import kernels
+    rng = np.random.default_rng(bps * 1000 + nbytes)
+    raw = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    dbuf = kernels.to_device_bytes(raw)
+    out = kernels.decode_frames(dbuf, 1, nbytes, CODERS[coder], bps)
+    exp = orc.decode_flat(raw, coder, bps)
+    assert bits_equal(out.cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize('coder,bps', COMBOS)
+def test_all_byte_values(coder, bps):
+    """Every byte value through the kernel == the reference LUT row."""
+    from baseband_amd import kernels
+    raw = np.repeat(np.arange(256, dtype=np.uint8), 4)       # dword multiples
+    out = kernels.decode_frames(kernels.to_device_bytes(raw), 1, raw.size,
+                                CODERS[coder], bps).cpu().numpy()
+    assert bits_equal(out, orc.decode_flat(raw, coder, bps))
+
+
+@pytest.mark.parametrize('bps,chunk,nslot', [(2, 1, 8), (2, 2, 4), (2, 32, 8),
+                                             (4, 4, 2), (8, 2, 4), (1, 16, 3),
+                                             (2, 4, 5), (8, 1, 2), (4, 1, 2)])
+def test_multislot_interleave_and_fill(bps, chunk, nslot):
+    """Frame-set layout (vdif/frame.py:402-434) with missing/invalid frames."""
+    torch = _torch()
+    from baseband_amd import kernels
+    nframes, pn = 7, 640
+    rng = np.random.default_rng(bps * 100 + chunk * 10 + nslot)
+    raw = rng.integers(0, 256, nframes * nslot * pn, dtype=np.uint8)
+    # shuffled placement of payloads in the buffer + some missing
+    perm = rng.permutation(nframes * nslot)
+    src = (perm * pn).astype(np.int64)
+    missing = rng.choice(nframes * nslot, size=5, replace=False)
+    src[missing] = -1
+    cplx = chunk % 2 == 0
+    fill = -7.5
+    out = kernels.decode_frames(
+        kernels.to_device_bytes(raw), nframes, pn, 0, bps, chunk=chunk,
+        nslot=nslot, src=torch.from_numpy(src).cuda(), complex_data=cplx,
+        fill_value=fill).cpu().numpy()
+    E = pn * 8 // bps
+    R = E // chunk
+    exp = np.empty((nframes, R, nslot, chunk), np.float32)
+    fillrow = np.tile(np.array([fill, 0.], np.float32), chunk // 2) if cplx \
+        else np.full(chunk, fill, np.float32)
+    for f in range(nframes):
+        for s in range(nslot):
+            o = src[f * nslot + s]
+            if o < 0:
+                exp[f, :, s, :] = fillrow
+            else:
+                exp[f, :, s, :] = orc.decode_flat(raw[o:o + pn], 'vdif', bps).reshape(R, chunk)
+    assert bits_equal(out, exp.reshape(-1))
+
+
+def test_fixed_stride_without_index():
+    from baseband_amd import kernels
+    rng = np.random.default_rng(5)
+    frame, hdr, pn, n = 8032, 32, 8000, 33
+    raw = rng.integers(0, 256, frame * n, dtype=np.uint8)
+    out = kernels.decode_frames(kernels.to_device_bytes(raw), n, pn, 0, 2,
+                                src0=hdr, src_stride=frame).cpu().numpy()
+    exp = np.concatenate([orc.decode_flat(raw[i * frame + hdr:(i + 1) * frame], 'vdif', 2)
+                          for i in range(n)])
+    assert bits_equal(out, exp)
+
+
+def test_tuning_variants_agree():
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(9)
+    raw = rng.integers(0, 256, 8032 * 64, dtype=np.uint8)
+    dbuf = kernels.to_device_bytes(raw)
+    ref = None
+    try:
+        for variant in (0, 1):
+            for nt in (0, 1):
+                for blocks in (0, 7, 2048):
+                    kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+                    kernels.tune(_lib.TUNE_NT_STORES, nt)
+                    kernels.tune(_lib.TUNE_BLOCKS, blocks)
+                    out = kernels.decode_frames(dbuf, 64, 8000, 0, 2, src0=32,
+                                                src_stride=8032).cpu().numpy()
+                    if ref is None:
+                        ref = out
+                    assert bits_equal(out, ref)
+    finally:
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 0)
+        kernels.tune(_lib.TUNE_NT_STORES, 1)
+        kernels.tune(_lib.TUNE_BLOCKS, 0)
+
+
+def test_abi_argument_errors():
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    dbuf = torch.zeros(1024, dtype=torch.uint8, device='cuda')
+    with pytest.raises(KeyError):                       # unsupported coder/bps
+        kernels.decode_frames(dbuf, 1, 64, _lib.CODER_MARK5B, 4)
+    with pytest.raises(KeyError):
+        kernels.decode_frames(dbuf, 1, 64, _lib.CODER_VDIF, 3)
+    with pytest.raises(_lib.BBError) as e:              # payload not dword multiple
+        kernels.decode_frames(dbuf, 1, 62, 0, 2)
+    assert e.value.code == _lib.BB_EINVAL
+    with pytest.raises(_lib.BBError) as e:              # output too small
+        kernels.decode_frames(dbuf, 1, 64, 0, 2,
+                              out=torch.empty(16, dtype=torch.float32, device='cuda'))
+    assert e.value.code == _lib.BB_ERANGE
+    with pytest.raises(_lib.BBError) as e:              # source range outside buffer
+        kernels.decode_frames(dbuf, 4, 512, 0, 2, src0=0, src_stride=512)
+    assert e.value.code == _lib.BB_ERANGE
+    with pytest.raises(KeyError):                       # nslot > 1 needs 2^k chunk
+        kernels.decode_frames(dbuf, 1, 96, 0, 2, chunk=3, nslot=2,
+                              src=torch.zeros(2, dtype=torch.int64, device='cuda'))
+    # empty input is fine
+    out = kernels.decode_frames(dbuf, 0, 64, 0, 2)
+    assert out.numel() == 0
+
+
+def test_vdif_scan_and_index():
+    torch = _torch()
+    from baseband_amd import kernels, synth, _lib
+    image, h0 = synth.random_vdif(3, 9, nthread=4, nchan=2, bps=2,
+                                  payload_nbytes=64, frame_rate=4,
+                                  thread_order=[2, 0, 3, 1],
+                                  invalid=[(1, 2), (5, 0)])
+    image = image.copy()
+    fn = h0.frame_nbytes
+    image[7 * fn + 8] ^= 0xff            # corrupt frame_length of file frame 7
+    pattern, mask = h0.invariant_pattern()
+    dbuf = kernels.to_device_bytes(image)
+    recs = kernels.vdif_scan(dbuf, 36, fn, 32, pattern, mask, h0['seconds'],
+                             h0['frame_nr'], 4)
+    f = kernels.recs_fields(recs)
+    k = np.arange(36)
+    assert np.array_equal(f['payload_offset'], k * fn + 32)
+    exp_ok = np.ones(36, bool)
+    exp_ok[7] = False
+    assert np.array_equal((f['flags'] & _lib.FRAME_OK) != 0, exp_ok)
+    assert np.array_equal(f['thread_id'], np.tile([2, 0, 3, 1], 9))
+    good = exp_ok
+    assert np.array_equal(f['time_index'][good], (k // 4)[good])
+    inv = np.zeros(36, bool)
+    inv[1 * 4 + 0] = True                # thread 2 is stored first
+    inv[5 * 4 + 1] = True                # thread 0 second
+    assert np.array_equal((f['flags'] & _lib.FRAME_INVALID) != 0, inv)
+    # dense index for threads (3, 0) only
+    slot = kernels.thread_slot_map([3, 0], dbuf.device)
+    src = kernels.build_index(recs, 9, 2, slot).cpu().numpy().reshape(9, 2)
+    exp = np.empty((9, 2), np.int64)
+    for s in range(9):
+        exp[s, 0] = (s * 4 + 2) * fn + 32        # thread 3 sits at position 2
+        exp[s, 1] = (s * 4 + 1) * fn + 32        # thread 0 at position 1
+    exp[5, 1] = -1          # thread 0 flagged invalid in set 5
+    # (set 1, thread 2) is invalid and file frame 7 (thread 1) is corrupt, but
+    # neither thread is selected
+    assert np.array_equal(src, exp)
+    # with all threads selected the corrupt frame is simply absent (-1)
+    slot = kernels.thread_slot_map([0, 1, 2, 3], dbuf.device)
+    src = kernels.build_index(recs, 9, 4, slot).cpu().numpy().reshape(9, 4)
+    assert src[1, 1] == -1 and src[1, 2] == -1 and src[5, 0] == -1
+    assert np.count_nonzero(src < 0) == 3

@@ -1,0 +1,90 @@
+"""The CPU oracle against the golden vectors captured from the reference
+(oracle/gen_golden.py) -- runs without a GPU and without the reference."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import bb_oracle_np as orc
+from conftest import load_expected, load_file, bits_equal
+
+
+def test_level_tables(levels_json):
+    lj = levels_json
+    assert np.array_equal(orc.LEVELS_1.view(np.uint32), lj['decoder_levels_1'])
+    assert np.array_equal(orc.LEVELS_2.view(np.uint32), lj['decoder_levels_2'])
+    assert np.array_equal(orc.LEVELS_4.view(np.uint32), lj['decoder_levels_4'])
+    assert np.array_equal(orc.code_levels('vdif', 8).view(np.uint32), lj['decode_8bit'])
+    for bps, key in ((1, 'vdif_lut1bit'), (2, 'vdif_lut2bit'), (4, 'vdif_lut4bit')):
+        assert np.array_equal(orc.byte_lut('vdif', bps).view(np.uint32), lj[key])
+    for bps, key in ((1, 'mark5b_lut1bit'), (2, 'mark5b_lut2bit')):
+        assert np.array_equal(orc.byte_lut('mark5b', bps).view(np.uint32), lj[key])
+    assert np.array_equal(orc.byte_lut('int', 4).view(np.uint32), lj['gsb_decode_4bit'])
+    assert np.array_equal(orc.code_levels('int', 8).view(np.uint32), lj['gsb_decode_8bit'])
+
+
+def test_known_answers_from_reference_tests():
+    """Literal known answers quoted in the reference's test-suite
+    (vdif/tests/test_vdif.py:323-336, vdif/payload.py:50-51)."""
+    lut2 = orc.byte_lut('vdif', 2)
+    assert np.all(lut2[0b10100101] == [-1., -1., 1., 1.])
+    assert np.all(lut2[0x55] == -1.) and np.all(lut2[0xaa] == 1.)
+    assert np.all(orc.byte_lut('vdif', 4)[0x88] == 0.)
+    # first payload bytes of sample.vdif frame 0: 2a 0a 7c ...
+    # (vdif/tests/test_vdif.py:21-25,381-382)
+    d = orc.decode_flat(bytes([0x2a, 0x0a, 0x7c]), 'vdif', 2)
+    assert d.astype(int).tolist() == [1, 1, 1, -3, 1, 1, -3, -3, -3, 3, 3, -1]
+    # reciprocal multiplication is NOT bit-identical
+    x = np.arange(256, dtype=np.float32)
+    wrong = (x - np.float32(127.5)) * np.float32(1 / 35.5)
+    assert np.count_nonzero(wrong != orc.code_levels('vdif', 8)) > 0
+
+
+VDIF_CASES = ['sample_vdif', 'sample_mwa_vdif', 'sample_arochime_vdif',
+              'sample_bps1_vdif', 'vdif_cfg2_small', 'vdif_cfg3_small',
+              'vdif_bps1_c4', 'vdif_bps4_cplx_t2', 'vdif_bps8_real_c2',
+              'vdif_bps8_cplx_t4', 'vdif_bps2_t8_c1', 'vdif_legacy_bps2',
+              'vdif_bps4_t2_c1', 'vdif_invalid_fill0', 'vdif_invalid_fillm999']
+
+
+@pytest.mark.parametrize('name', VDIF_CASES)
+def test_vdif_oracle_matches_reference(manifest, name):
+    case = manifest[name]
+    raw = load_file(case['file'])
+    if 'frame_rate' in case:
+        fr = case['frame_rate']
+    else:
+        fr = int(round(case['sample_rate_hz'] / case['samples_per_frame']))
+    out, info = orc.vdif_read(raw, frame_rate=fr,
+                              fill_value=case.get('fill_value', 0.))
+    exp = load_expected(name)
+    assert bits_equal(out, exp)
+    assert hashlib.sha256(out.tobytes()).hexdigest() == case['sha256']
+    if 'thread_ids' in case:
+        assert info['thread_ids'] == case['thread_ids']
+
+
+def test_sample_vdif_literals(manifest):
+    """vdif/tests/test_vdif.py:546-552,930-931: thread 0 and 3 first values."""
+    exp = load_expected('sample_vdif')
+    assert exp[:12, 0, 0].astype(int).tolist() == [-1, -1, 3, -1, 1, -1, 3, -1, 1, 3, -1, 1]
+    assert exp[:12, 3, 0].astype(int).tolist() == [-1, 1, -1, 1, -3, -1, 3, -1, 3, -3, 1, 3]
+    order = manifest['sample_vdif']['frame_order']
+    assert [o[0] for o in order[:8]] == [1, 3, 5, 7, 0, 2, 4, 6]
+
+
+@pytest.mark.parametrize('name', ['sample_m5b', 'm5b_c16_b2', 'm5b_c8_b1', 'm5b_c4_b2'])
+def test_mark5b_oracle_matches_reference(manifest, name):
+    case = manifest[name]
+    raw = load_file(case['file'])
+    fr = case.get('frame_rate',
+                  int(round(case.get('sample_rate_hz', 0) / case['samples_per_frame'])))
+    out, _ = orc.mark5b_read(raw, nchan=case['nchan'], bps=case['bps'], frame_rate=fr)
+    assert bits_equal(out, load_expected(name))
+    assert hashlib.sha256(out.tobytes()).hexdigest() == case['sha256']
+
+
+def test_stream_masks(manifest):
+    for name in ('sample_vdif', 'sample_mwa_vdif', 'sample_arochime_vdif', 'sample_bps1_vdif'):
+        case = manifest[name]
+        assert orc.vdif_stream_mask(case['edv']) == case['stream_mask']
