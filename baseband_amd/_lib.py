@@ -6,6 +6,12 @@ the import fails loudly -- there is no NumPy/PyTorch fallback.
 import ctypes as C
 import os
 
+# PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  Import it
+# BEFORE loading libbbdecode.so so that the dynamic loader resolves our HIP
+# dependency (same SONAME) to the runtime torch already initialised: two HIP
+# runtimes in one process do not see each other's devices, streams or memory.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libbbdecode.so')
 

@@ -203,6 +203,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
 {
     if (!p) return BB_EINVAL;
     if (!coder_supported(p->coder, p->bps)) return BB_ENOTSUP;
+    if (nframes == 0) return BB_OK;
     if (!d_buf || !d_out) return BB_EINVAL;
     if (p->nslot < 1 || p->chunk < 1) return BB_EINVAL;
     if (p->payload_nbytes == 0 || (p->payload_nbytes & 3)) return BB_EINVAL;

@@ -34,8 +34,9 @@ _SAMPLE_RATE_FIELDS = dict(_BASE_FIELDS,
                            sampling_unit=(4, 23, 1),
                            sampling_rate=(4, 0, 23),
                            sync_pattern=(5, 0, 32, 0xACABFEED))
+# legacy headers are keyed -1: False and 0 are the same dict key
 _EDV_FIELDS = {
-    False: _LEGACY_FIELDS,
+    -1: _LEGACY_FIELDS,
     0: _BASE_FIELDS,
     1: dict(_SAMPLE_RATE_FIELDS, das_id=(6, 0, 64, 0x0)),
     2: dict(_BASE_FIELDS, complex_data=(3, 31, 1, 0x0),
@@ -59,7 +60,7 @@ _STREAM_INV_COMMON = {'legacy_mode', 'vdif_version', 'lg2_nchan',
                       'frame_length', 'complex_data', 'bits_per_sample',
                       'station_id'}
 _STREAM_INVARIANTS = {
-    False: _STREAM_INV_COMMON,
+    -1: _STREAM_INV_COMMON,
     0: _STREAM_INV_COMMON | {'edv'},
     1: _STREAM_INV_COMMON | {'edv', 'sync_pattern', 'sampling_unit',
                              'sampling_rate'},
@@ -111,9 +112,10 @@ class VDIFHeader(BitFieldHeader):
         if edv is None and words is not None:
             edv = False if (int(words[0]) >> 30) & 1 else (int(words[4]) >> 24) & 0xff
         self._edv = edv
-        self._fields = _EDV_FIELDS.get(edv, _BASE_FIELDS)
+        key = -1 if edv is False else edv
+        self._fields = _EDV_FIELDS.get(key, _BASE_FIELDS)
         self._stream_invariants = _STREAM_INVARIANTS.get(
-            edv, _STREAM_INV_COMMON | {'edv'})
+            key, _STREAM_INV_COMMON | {'edv'})
         self._struct = four_word_struct if edv is False else eight_word_struct
         if words is not None and edv is False:
             words = words[:4]
