@@ -176,14 +176,18 @@ def main():
     total_samples = nframes * SPF * world * args.steps
     value = total_samples / elapsed / 1e6
 
-    traffic = None
+    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE, separate runs of this same command; tools/summarize_prof.py).
+    # Only meaningful for the default 8 GiB workload the counters were taken on.
+    traffic, traffic_detail = None, None
     tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and abs(args.gib - 8.0) < 1e-9:
         try:
             with open(tpath) as f:
-                traffic = json.load(f)
+                traffic_detail = json.load(f)
+            traffic = traffic_detail["hbm_bytes_per_launch"]
         except Exception:
-            traffic = None
+            traffic, traffic_detail = None, None
 
     line = {
         "metric": "decoded Msamples/s, VDIF 2-bit 1-thread (scan + index + decode, input resident in HBM)",
@@ -204,7 +208,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "kernel_ms_avg": round(kern_avg, 4),
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "traffic": traffic},
+                     "traffic": traffic, "traffic_detail": traffic_detail},
         "parity_spot_check": ok,
     }
     if rank == 0:
