@@ -67,6 +67,20 @@ class DecodeParams(C.Structure):
                 ('fill_im', C.c_float), ('reserved', C.c_int32)]
 
 
+class Mark4ScanParams(C.Structure):
+    _fields_ = [('first_offset', C.c_uint64), ('ntrack', C.c_int32),
+                ('ref_year', C.c_int32), ('ref_qms', C.c_int64),
+                ('frame_qms', C.c_int32), ('reserved', C.c_int32)]
+
+
+class Mark4DecodeParams(C.Structure):
+    _fields_ = [('ntrack', C.c_int32), ('reserved', C.c_int32),
+                ('nwords', C.c_uint64), ('fill_words', C.c_uint64),
+                ('src0', C.c_int64), ('src_stride', C.c_int64),
+                ('sign_bit', C.c_uint8 * 32), ('mag_bit', C.c_uint8 * 32),
+                ('fill', C.c_float), ('reserved2', C.c_int32)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -93,6 +107,8 @@ SIGNATURES = [
     ('bb_mark5b_scan', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp]),
     ('bb_build_index', C.c_int, [_vp, _sz, _vp, C.c_int, _vp, _sz, _vp]),
     ('bb_decode_frames', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, _sz, _vp]),
+    ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),
+    ('bb_decode_mark4', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(Mark4DecodeParams), _vp, _sz, _vp]),
     ('bb_tune', C.c_int, [C.c_int, C.c_int]),
 ]
 

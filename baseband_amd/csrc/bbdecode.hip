@@ -4,6 +4,7 @@
 #include "bb_common.h"
 #include "k_scan.h"
 #include "k_flat.h"
+#include "k_mark4.h"
 
 #include <atomic>
 #include <mutex>
@@ -277,6 +278,89 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             break;
         default: return BB_ENOTSUP;
     }
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_mark4_scan(const void *d_buf, size_t nbytes, const bb_mark4_scan_params *p,
+                  bb_frame_rec *d_recs, size_t nframes, void *stream)
+{
+    if (!d_buf || !p || !d_recs) return BB_EINVAL;
+    if (p->ntrack != 16 && p->ntrack != 32 && p->ntrack != 64) return BB_ENOTSUP;
+    if ((p->first_offset & (p->ntrack / 8 - 1)) || ((uintptr_t)d_buf & 7)) return BB_EINVAL;
+    if (p->frame_qms < 0) return BB_EINVAL;
+    if (nframes == 0) return BB_OK;
+    const uint64_t blocks = ((uint64_t)nframes + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
+    if (blocks > 0x7fffffffull) return BB_ERANGE;
+    const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *b = (const uint8_t *)d_buf;
+    switch (p->ntrack) {
+        case 16: hipLaunchKernelGGL(k_mark4_scan<16>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes); break;
+        case 32: hipLaunchKernelGGL(k_mark4_scan<32>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes); break;
+        default: hipLaunchKernelGGL(k_mark4_scan<64>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes); break;
+    }
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
+                    const int64_t *d_src, size_t nframes,
+                    const bb_mark4_decode_params *p,
+                    float *d_out, size_t out_elems, void *stream)
+{
+    if (!p) return BB_EINVAL;
+    if (p->ntrack != 16 && p->ntrack != 32 && p->ntrack != 64) return BB_ENOTSUP;
+    if (nframes == 0) return BB_OK;
+    if (!d_buf || !d_out) return BB_EINVAL;
+    if (p->nwords == 0 || p->fill_words > p->nwords) return BB_EINVAL;
+    if (((uintptr_t)d_buf & 7) || ((uintptr_t)d_out & 15)) return BB_EINVAL;
+    const int opw = p->ntrack / 2;
+    const uint64_t wbytes = (uint64_t)p->ntrack / 8;
+    for (int j = 0; j < opw; ++j)
+        if (p->sign_bit[j] >= p->ntrack || p->mag_bit[j] >= p->ntrack) return BB_EINVAL;
+    const uint64_t E = p->nwords * (uint64_t)opw;
+    if (out_elems < (uint64_t)nframes * E) return BB_ERANGE;
+    if (!d_src) {
+        if (p->src0 < 0 || p->src_stride < 0 || (p->src0 % (int64_t)wbytes) || (p->src_stride % (int64_t)wbytes))
+            return BB_EINVAL;
+        if ((uint64_t)p->src0 + ((uint64_t)nframes - 1) * (uint64_t)p->src_stride + p->nwords * wbytes > buf_nbytes)
+            return BB_ERANGE;
+    }
+    int rc = ensure_init();
+    if (rc) return rc;
+    bb_m4_args a;
+    a.buf = (const uint8_t *)d_buf;
+    a.src = d_src;
+    a.out = d_out;
+    a.nframes = nframes;
+    a.nwords = p->nwords;
+    a.fill_words = p->fill_words;
+    const uint64_t ntiles = (p->nwords + 63) / 64;
+    a.nseg = (ntiles + BB_M4_SEG_TILES - 1) / BB_M4_SEG_TILES;
+    a.src0 = p->src0;
+    a.src_stride = p->src_stride;
+    memset(a.sign_bit, 0, sizeof(a.sign_bit));
+    memset(a.mag_bit, 0, sizeof(a.mag_bit));
+    memcpy(a.sign_bit, p->sign_bit, opw);
+    memcpy(a.mag_bit, p->mag_bit, opw);
+    a.fill = p->fill;
+    a.hi = h_levels[BB_CODER_VDIF][1][3];
+    uint64_t blocks = (uint64_t)nframes * a.nseg;
+    const int tb = g_tune_blocks.load();
+    if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
+    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+    const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = g_tune_nt.load() != 0;
+#define BB_M4(N) do { if (nt) hipLaunchKernelGGL((k_decode_mark4<N, true>), grid, block, 0, st, a); \
+                      else    hipLaunchKernelGGL((k_decode_mark4<N, false>), grid, block, 0, st, a); } while (0)
+    switch (p->ntrack) {
+        case 16: BB_M4(16); break;
+        case 32: BB_M4(32); break;
+        default: BB_M4(64); break;
+    }
+#undef BB_M4
     BB_HIP(hipGetLastError());
     return BB_OK;
 }

@@ -1,0 +1,195 @@
+// Mark 4: embedded-header scan and track-demultiplexing decode.
+//
+// A Mark 4 frame is 20000 "stream words" of ntrack bits (ntrack = 16/32/64);
+// bit k of every word belongs to tape track k.  The first 160 words carry the
+// per-track headers (bit k of word j = header bit j of track k, MSB first:
+// mark4/header.py:47-64), the rest the samples: each word holds `fanout`
+// consecutive samples of `nchan` channels as (sign, magnitude) bit pairs on
+// track positions given by the track-assignment tables (mark4/header.py:306-
+// 328) -- i.e. the output of one word is fanout*nchan = ntrack/2 contiguous
+// float32 values.
+//
+// Replaces (reference, path:line): Mark4Header.fromfile + stream2words
+// (mark4/header.py:425-454,47-64), the sync search pattern
+// (mark4/header.py:345-373), frame validity from the error flags
+// (mark4/frame.py:78-87), the five decoders reorder32/64/64_Ft + lut2bit{1,3}
+// + transposes (mark4/payload.py:48-69,122-288), and the header-overwrite
+// fill of Mark4Frame.__getitem__ (mark4/frame.py:185-189,248-258).
+#pragma once
+#include "bb_common.h"
+
+template <int NTRACK> struct bb_m4_word;
+template <> struct bb_m4_word<16> { typedef uint16_t type; };
+template <> struct bb_m4_word<32> { typedef uint32_t type; };
+template <> struct bb_m4_word<64> { typedef uint64_t type; };
+
+__device__ __forceinline__ uint32_t bb_bcd(uint32_t v, int ndigit, bool *ok)
+{
+    uint32_t r = 0, m = 1;
+    for (int i = 0; i < ndigit; ++i) {
+        const uint32_t d = (v >> (4 * i)) & 0xf;
+        if (d > 9) *ok = false;
+        r += d * m;
+        m *= 10;
+    }
+    return r;
+}
+
+// One wave per frame.  Lane i looks at stream words 32+i (flags, sync) and
+// 96+i (time code); three ballots give validity, sync and the 64 time-code
+// bits of track 0.
+template <int NTRACK>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_mark4_scan(const uint8_t *buf, uint64_t nbytes, bb_mark4_scan_params p,
+                  bb_frame_rec *recs, uint64_t nframes)
+{
+    typedef typename bb_m4_word<NTRACK>::type word_t;
+    const uint64_t frame = (uint64_t)blockIdx.x * BB_WAVES_PER_BLOCK + bb_wave();
+    if (frame >= nframes) return;                       // wave-uniform
+    const int lane = bb_lane();
+    const uint64_t frame_nbytes = (uint64_t)NTRACK * 2500;
+    const uint64_t off = p.first_offset + frame * frame_nbytes;
+    const bool whole = off + frame_nbytes <= nbytes;
+    const word_t *fw = reinterpret_cast<const word_t *>(buf + off);
+    word_t a = 0, b = 0;
+    if (whole) { a = fw[32 + lane]; b = fw[96 + lane]; }
+    const word_t ones = (word_t)~(word_t)0;
+    // error flags: header word 1 bits 15..12 -> stream words 48..51
+    const bool err = lane >= 16 && lane < 20 && a != 0;
+    // sync: stream word 63 all zero, words 64..95 all ones
+    const bool syn = lane < 31 ? true : (lane == 31 ? a == 0 : a == ones);
+    const unsigned long long errs = __ballot(err);
+    const unsigned long long syns = __ballot(syn);
+    const unsigned long long tb = __ballot((b & 1) != 0);
+    if (lane == 0) {
+        const uint32_t w3 = __brev((uint32_t)(tb & 0xffffffffull));
+        const uint32_t w4 = __brev((uint32_t)(tb >> 32));
+        bool ok = whole && syns == ~0ull;
+        const uint32_t uyear = (w3 >> 28) & 0xf;
+        const uint32_t day = bb_bcd((w3 >> 16) & 0xfff, 3, &ok);
+        const uint32_t hour = bb_bcd((w3 >> 8) & 0xff, 2, &ok);
+        const uint32_t minute = bb_bcd(w3 & 0xff, 2, &ok);
+        const uint32_t sec = bb_bcd((w4 >> 24) & 0xff, 2, &ok);
+        const uint32_t ms = bb_bcd((w4 >> 12) & 0xfff, 3, &ok);
+        // last ms digit d encodes d*1.25 ms (mark4/header.py:198-214)
+        int64_t q = (((int64_t)(day * 24 + hour) * 60 + minute) * 60 + sec) * 4000
+                    + 4 * ms + ms % 5;
+        const int y = p.ref_year;
+        if (uyear == (uint32_t)((y + 1) % 10) && uyear != (uint32_t)(y % 10)) {
+            const int leap = (y % 4 == 0 && (y % 100 != 0 || y % 400 == 0)) ? 1 : 0;
+            q += (int64_t)(365 + leap) * 86400 * 4000;
+        } else if (uyear != (uint32_t)(y % 10)) {
+            ok = false;
+        }
+        int64_t tidx;
+        if (p.frame_qms > 0) {
+            const int64_t dq = q - p.ref_qms;
+            tidx = (dq >= 0 ? dq + p.frame_qms / 2 : dq - p.frame_qms / 2) / p.frame_qms;
+            if (tidx * p.frame_qms != dq) ok = false;   // not on the frame grid
+        } else {
+            tidx = (int64_t)frame;
+        }
+        if (tidx > 0x7fffffffll) tidx = 0x7fffffffll;
+        if (tidx < -0x7fffffffll) tidx = -0x7fffffffll;
+        bb_frame_rec r;
+        r.payload_offset = (int64_t)off;                // frame start: decode skips the header words
+        r.time_index = (int32_t)tidx;
+        r.thread_id = 0;
+        r.flags = (uint16_t)((ok ? BB_FRAME_OK : 0u) | (errs ? BB_FRAME_INVALID : 0u));
+        *reinterpret_cast<bb_u4 *>(&recs[frame]) = *reinterpret_cast<const bb_u4 *>(&r);
+    }
+}
+
+struct bb_m4_args {
+    const uint8_t *buf;
+    const int64_t *src;
+    float         *out;
+    uint64_t nframes;
+    uint64_t nwords;        // stream words per frame (20000) or per payload
+    uint64_t fill_words;    // leading words that decode to fill (160 / 0)
+    uint64_t nseg;
+    int64_t  src0, src_stride;
+    uint32_t sign_bit[8];   // 32 x uint8: output j -> bit position of its sign
+    uint32_t mag_bit[8];    //                       ... of its magnitude
+    float    fill, hi;
+};
+
+#define BB_M4_SEG_TILES 32
+
+// Lane l of a wave owns outputs [4*(l % LPW), +4) of word (l / LPW) of the
+// current pass, LPW = NTRACK/8 lanes per word, so a store instruction covers
+// 64/LPW consecutive words = 1 KiB of contiguous output.  Words are loaded
+// once per 64-word tile (one coalesced load) and handed around with shuffles.
+template <int NTRACK, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_mark4(bb_m4_args a)
+{
+    typedef typename bb_m4_word<NTRACK>::type word_t;
+    constexpr int LPW = NTRACK / 8;         // lanes per word
+    constexpr int WPP = 64 / LPW;           // words per store pass
+    constexpr int OPW = NTRACK / 2;         // outputs per word
+    const int lane = bb_lane();
+    const int wave = bb_wave();
+    const int sub = lane % LPW;
+    const int wsel = lane / LPW;
+    // per-lane bit positions of its four outputs (uniform selects, once)
+    uint32_t spack = 0, mpack = 0;
+#pragma unroll
+    for (int k = 0; k < LPW; ++k)
+        if (sub == k) { spack = a.sign_bit[k]; mpack = a.mag_bit[k]; }
+    const float hi = a.hi;
+    const bb_f4 fillv = {a.fill, a.fill, a.fill, a.fill};
+    const uint64_t E = a.nwords * OPW;
+    const uint64_t ntiles = (a.nwords + 63) / 64;
+    const uint64_t nwork = a.nframes * a.nseg;
+
+    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+        uint64_t f, seg;
+        if (a.nseg == 1) { f = work; seg = 0; }
+        else { f = work / a.nseg; seg = work - f * a.nseg; }
+        const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
+        const bool valid = so >= 0;
+        const word_t *in = reinterpret_cast<const word_t *>(a.buf + (valid ? so : 0));
+        float *obase = a.out + f * E;
+        const uint64_t tile_begin = seg * BB_M4_SEG_TILES;
+        const uint64_t tile_end = (tile_begin + BB_M4_SEG_TILES < ntiles)
+                                  ? tile_begin + BB_M4_SEG_TILES : ntiles;
+        for (uint64_t tile = tile_begin + wave; tile < tile_end; tile += BB_WAVES_PER_BLOCK) {
+            const uint64_t wi = tile * 64 + lane;
+            const word_t w = (valid && wi < a.nwords && wi >= a.fill_words) ? in[wi] : (word_t)0;
+#pragma unroll
+            for (int p = 0; p < LPW; ++p) {
+                const int srcl = p * WPP + wsel;
+                uint64_t x;
+                if (NTRACK == 64) {
+                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)((uint64_t)w & 0xffffffffull), srcl);
+                    const uint32_t hi32 = (uint32_t)__shfl((int)(uint32_t)((uint64_t)w >> 32), srcl);
+                    x = ((uint64_t)hi32 << 32) | lo;
+                } else {
+                    x = (uint32_t)__shfl((int)(uint32_t)w, srcl);
+                }
+                const uint64_t widx = tile * 64 + srcl;
+                if (widx >= a.nwords) continue;
+                bb_f4 v;
+                if (!valid || widx < a.fill_words) {
+                    v = fillv;
+                } else {
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t sb = (spack >> (8 * k)) & 0xff;
+                        const uint32_t mb = (mpack >> (8 * k)) & 0xff;
+                        const bool s = (x >> sb) & 1;
+                        const bool m = (x >> mb) & 1;
+                        // sign set = positive; magnitude set = high level
+                        // (mark4/payload.py:93-115: index 2*s + m into
+                        // {-Hi, -1, +1, +Hi})
+                        r[k] = (s == m) ? (s ? hi : -hi) : (s ? 1.0f : -1.0f);
+                    }
+                    v = bb_f4{r[0], r[1], r[2], r[3]};
+                }
+                bb_store4<NT>(obase + widx * OPW + 4 * sub, v);
+            }
+        }
+    }
+}

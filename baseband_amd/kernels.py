@@ -126,5 +126,42 @@ def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
     return out
 
 
+def mark4_scan(dbuf, nframes, ntrack, ref_year, ref_qms, frame_qms,
+               first_offset=0):
+    p = _lib.Mark4ScanParams()
+    p.first_offset = first_offset
+    p.ntrack = ntrack
+    p.ref_year = ref_year
+    p.ref_qms = ref_qms
+    p.frame_qms = frame_qms
+    recs = torch.empty((nframes, 4), dtype=torch.int32, device=dbuf.device)
+    check(lib.bb_mark4_scan(_ptr(dbuf), dbuf.numel(), C.byref(p), _ptr(recs),
+                            nframes, _stream()), 'bb_mark4_scan')
+    return recs
+
+
+def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
+                 src=None, src0=0, src_stride=0, fill_value=0., out=None):
+    """Track-demultiplex `nframes` units of `nwords` stream words each ->
+    flat float32 device tensor of nframes * nwords * ntrack/2 values."""
+    p = _lib.Mark4DecodeParams()
+    p.ntrack = ntrack
+    p.nwords = nwords
+    p.fill_words = fill_words
+    p.src0 = src0
+    p.src_stride = src_stride
+    for j, (s, m) in enumerate(zip(sign_bit, mag_bit)):
+        p.sign_bit[j] = s
+        p.mag_bit[j] = m
+    p.fill = float(fill_value)
+    if out is None:
+        out = torch.empty(nframes * nwords * (ntrack // 2), dtype=torch.float32,
+                          device=dbuf.device)
+    check(lib.bb_decode_mark4(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
+                              C.byref(p), _ptr(out), out.numel(), _stream()),
+          'bb_decode_mark4')
+    return out
+
+
 def tune(knob, value):
     check(lib.bb_tune(knob, value), 'bb_tune')

@@ -1,0 +1,8 @@
+"""Mark 4 format: GPU-decoded reader with the reference's call shapes."""
+from .header import Mark4Header
+from .payload import Mark4Payload
+from .frame import Mark4Frame
+from .base import Mark4FileReader, Mark4StreamReader, open
+
+__all__ = ['Mark4Header', 'Mark4Payload', 'Mark4Frame', 'Mark4FileReader',
+           'Mark4StreamReader', 'open']

@@ -1,0 +1,214 @@
+"""Mark 4 file and stream readers, and ``open``.
+
+Mirrors ``Mark4FileReader`` (mark4/base.py:28-207) and ``Mark4StreamReader``
+(mark4/base.py:233-312).  Per staged window the stream reader launches
+``bb_mark4_scan`` (sync, error flags, BCD time -> frame index) ->
+``bb_build_index`` -> ``bb_decode_mark4`` (track demultiplexing + header
+fill).
+"""
+import io
+import operator
+
+import numpy as np
+import torch
+
+from .. import _lib, kernels
+from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
+                         HeaderNotFoundError)
+from .header import Mark4Header, MARK4_DTYPES, stream2words
+from .payload import Mark4Payload
+from .frame import Mark4Frame
+from ._bitmaps import BITMAPS
+
+__all__ = ['Mark4FileReader', 'Mark4StreamReader', 'open']
+
+
+class Mark4FileReader(VLBIFileReaderBase):
+    def __init__(self, fh_raw, ntrack=None, decade=None, ref_time=None):
+        self.ntrack = operator.index(ntrack) if ntrack is not None else None
+        self.decade = operator.index(decade) if decade is not None else None
+        self.ref_time = ref_time
+        super().__init__(fh_raw)
+
+    def read_header(self):
+        return Mark4Header.fromfile(self.fh_raw, ntrack=self.ntrack,
+                                    decade=self.decade, ref_time=self.ref_time)
+
+    def read_frame(self, verify=True):
+        return Mark4Frame.fromfile(self.fh_raw, self.ntrack,
+                                   decade=self.decade, ref_time=self.ref_time,
+                                   verify=verify)
+
+    def _sync_at(self, image, o, ntrack):
+        """Sync pattern at frame offset o: stream word 63 zero, words 64-95
+        all ones (mark4/header.py:345-373)."""
+        dt = np.dtype(MARK4_DTYPES[ntrack])
+        isz = dt.itemsize
+        if o < 0 or o + 96 * isz > len(image):
+            return False
+        w = np.frombuffer(image[o + 63 * isz:o + 96 * isz].tobytes(), dtype=dt)
+        return bool(w[0] == 0 and np.all(w[1:] == np.iinfo(dt).max))
+
+    def locate_frames(self, maximum=None, forward=True, check=1):
+        """Offsets of frames near the current position, nearest first: a sync
+        pattern with another one `check` frames away when that lies inside
+        the file (mark4/base.py:110-166, base/base.py:181-335)."""
+        ntrack = self.ntrack
+        if ntrack is None:
+            with self.temporary_offset(0):
+                ntrack = self.determine_ntrack(maximum=maximum)
+        fn = ntrack * 2500
+        isz = ntrack // 8
+        image = self.image()
+        pos = self.fh_raw.tell()
+        if maximum is None:
+            maximum = 2 * fn
+        # all-ones run detection on the byte image, then confirm per candidate
+        lo = max(0, pos - (0 if forward else maximum))
+        hi = min(len(image), pos + (maximum if forward else 0) + 96 * isz)
+        seg = np.asarray(image[lo:hi])
+        ones = seg == 0xff
+        run = 32 * isz
+        if len(seg) < run + 64 * isz:
+            return []
+        c = np.concatenate([[0], np.cumsum(ones)])
+        full = np.nonzero(c[run:] - c[:-run] == run)[0]      # start of all-ones runs
+        cands = full + lo - 64 * isz
+        out = []
+        checks = (check,) if isinstance(check, int) else tuple(check)
+        for o in cands:
+            o = int(o)
+            if o < lo or o > (pos + maximum if forward else pos):
+                continue
+            if not self._sync_at(image, o, ntrack):
+                continue
+            if all(self._sync_at(image, o + k * fn, ntrack)
+                   or o + k * fn < 0 or o + k * fn + 96 * isz > len(image)
+                   for k in checks):
+                out.append(o)
+        out.sort(key=lambda o: abs(o - pos))
+        return out
+
+    def find_header(self, forward=True, maximum=None):
+        locations = self.locate_frames(forward=forward, maximum=maximum)
+        if not locations:
+            raise HeaderNotFoundError('could not locate a a nearby frame.')
+        self.fh_raw.seek(locations[0])
+        with self.temporary_offset():
+            return self.read_header()
+
+    def determine_ntrack(self, maximum=None):
+        """Try 16, 32 and 64 tracks (mark4/base.py:168-207)."""
+        old_ntrack = self.ntrack
+        for ntrack in (16, 32, 64):
+            self.ntrack = ntrack
+            with self.temporary_offset():
+                offsets = self.locate_frames(maximum=maximum)
+            if offsets:
+                self.fh_raw.seek(offsets[0])
+                return ntrack
+        self.ntrack = old_ntrack
+        raise HeaderNotFoundError("cannot determine ntrack automatically. "
+                                  "(tried 16, 32, 64). Try passing in an "
+                                  "explicit value.")
+
+    def get_frame_rate(self):
+        """From the time step between the first two frames
+        (mark4/base.py:87-108)."""
+        with self.temporary_offset(0):
+            header0 = self.find_header()
+            self.fh_raw.seek(header0.frame_nbytes, 1)
+            header1 = self.read_header()
+        tdelta = (header1.fraction[0] - header0.fraction[0]) % 1.
+        return float(np.round(1. / tdelta))
+
+
+class Mark4StreamReader(GPUStreamReaderBase):
+    """Mark 4 stream -> device tensor (nsample, nchan)."""
+
+    def __init__(self, fh_raw, sample_rate=None, ntrack=None, decade=None,
+                 ref_time=None, squeeze=True, subset=(), fill_value=0.,
+                 verify='fix'):
+        if decade is None and ref_time is None:
+            raise TypeError("Mark 4 stream reader requires either decade or "
+                            "ref_time to be passed in.")
+        fh_raw = Mark4FileReader(fh_raw, ntrack=ntrack, decade=decade,
+                                 ref_time=ref_time)
+        header0 = fh_raw.find_header()
+        offset0 = fh_raw.tell()
+        if sample_rate is None:
+            sample_rate = fh_raw.get_frame_rate() * header0.samples_per_frame
+        super().__init__(
+            fh_raw, header0, sample_rate=float(sample_rate),
+            samples_per_frame=header0.samples_per_frame,
+            unsliced_shape=(header0.nchan,), bps=header0.bps,
+            complex_data=False, squeeze=squeeze, subset=subset,
+            fill_value=fill_value, verify=verify)
+        self._ntrack = header0.ntrack
+        self._set_nbytes = header0.frame_nbytes
+        self._file_offset0 = offset0
+        frame_rate = self.sample_rate / self.samples_per_frame
+        self._frame_qms = int(round(4000. / frame_rate))
+        self._coder = (header0.nchan, header0.magnitude_signature() or header0.bps,
+                       header0.fanout)
+        self._start_time = header0.get_time()
+        self._ref_qms = header0.time_quarter_ms()
+        last = self._last_header()
+        dq = last.time_quarter_ms() - self._ref_qms
+        if last.year != header0.year:
+            y = header0.year
+            leap = (y % 4 == 0 and (y % 100 != 0 or y % 400 == 0))
+            dq += (365 + leap) * 86400 * 4000
+        self._nsample = (int(round(dq / self._frame_qms)) + 1) * self.samples_per_frame
+
+    def _image(self):
+        return self.fh_raw.image()
+
+    def _last_header(self):
+        image = self._image()
+        fn = self._set_nbytes
+        nfull = (len(image) - self._file_offset0) // fn
+        for k in range(nfull - 1, max(-1, nfull - 3), -1):
+            o = self._file_offset0 + k * fn
+            if self.fh_raw._sync_at(image, o, self._ntrack):
+                dt = np.dtype(MARK4_DTYPES[self._ntrack])
+                stream = np.frombuffer(image[o:o + 160 * dt.itemsize].tobytes(), dtype=dt)
+                header = Mark4Header(stream2words(stream), verify=False)
+                header.infer_decade(self.start_time)
+                return header
+        raise HeaderNotFoundError("corrupt VLBI frame? No frame in last {0} "
+                                  "bytes.".format(2 * fn))
+
+    def _process_window(self, dbuf, first, last, out_flat):
+        maps = BITMAPS[self._coder]          # KeyError: unsupported Mark 4 mode
+        n = last - first
+        nframes = min(n, dbuf.numel() // self._set_nbytes)
+        recs = kernels.mark4_scan(
+            dbuf, nframes, self._ntrack, self.header0.year,
+            self._ref_qms + first * self._frame_qms, self._frame_qms)
+        src = kernels.build_index(recs, n, 1, None)
+        kernels.decode_mark4(
+            dbuf, n, self._ntrack, 20000, maps['sign_bit'], maps['mag_bit'],
+            fill_words=160, src=src, fill_value=self.fill_value, out=out_flat)
+        if self.verify:
+            ok = (recs[:, 3] >> 16) & _lib.FRAME_OK
+            expect = torch.arange(nframes, device=recs.device, dtype=torch.int32)
+            bad = ((ok == 0) | (recs[:, 2] != expect)).sum() + (n - nframes)
+            self._pending_checks.append(bad)
+
+
+def open(name, mode='rs', **kwargs):
+    """``'rb'`` -> `Mark4FileReader`, ``'rs'`` -> `Mark4StreamReader`
+    (mark4/base.py:337-430)."""
+    if mode not in ('rb', 'rs'):
+        raise ValueError("only reading modes 'rb' and 'rs' are supported "
+                         "(got {!r}).".format(mode))
+    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
+    try:
+        if mode == 'rb':
+            return Mark4FileReader(fh, **kwargs)
+        return Mark4StreamReader(fh, **kwargs)
+    except Exception:
+        if fh is not name:
+            fh.close()
+        raise

@@ -1,0 +1,438 @@
+"""Mark 4 headers (host side).
+
+A Mark 4 header is 160 bits per tape track, stored bit-interleaved across the
+first 160 stream words of a frame.  This mirrors ``Mark4Header``
+(mark4/header.py:268-700): ``words`` is a ``(5, ntrack)`` uint32 array (one
+column per track), fields come back as per-track arrays, and the derived
+quantities (``fanout, bps, nchan, samples_per_frame, frame_nbytes, ...``)
+follow mark4/header.py:540-650.  Times are ``numpy.datetime64[ns]``.
+"""
+import numpy as np
+
+__all__ = ['Mark4Header', 'stream2words', 'words2stream', 'MARK4_DTYPES',
+           'PAYLOAD_NBITS']
+
+MARK4_DTYPES = {8: '<u1', 16: '<u2', 32: '<u4', 64: '<u8'}
+PAYLOAD_NBITS = 20000
+
+_FIELDS = {
+    'bcd_headstack1': (0, 0, 16, 0x3344),
+    'bcd_headstack2': (0, 16, 16, 0x1122),
+    'headstack_id': (1, 30, 2),
+    'bcd_track_id': (1, 24, 6),
+    'fan_out': (1, 22, 2),
+    'magnitude_bit': (1, 21, 1),
+    'lsb_output': (1, 20, 1),
+    'converter_id': (1, 16, 4),
+    'time_sync_error': (1, 15, 1, False),
+    'internal_clock_error': (1, 14, 1, False),
+    'processor_time_out_error': (1, 13, 1, False),
+    'communication_error': (1, 12, 1, False),
+    '_1_11_1': (1, 11, 1, False),
+    '_1_10_1': (1, 10, 1, False),
+    'track_roll_enabled': (1, 9, 1, False),
+    'sequence_suspended': (1, 8, 1, False),
+    'system_id': (1, 0, 8),
+    '_1_0_1_sync': (1, 0, 1, 0),
+    'sync_pattern': (2, 0, 32, 0xffffffff),
+    'bcd_unit_year': (3, 28, 4),
+    'bcd_day': (3, 16, 12),
+    'bcd_hour': (3, 8, 8),
+    'bcd_minute': (3, 0, 8),
+    'bcd_second': (4, 24, 8),
+    'bcd_fraction': (4, 12, 12),
+    'crc': (4, 0, 12),
+}
+
+# Track assignments (tables 10-14 of Mark 4 memo 230.3), minus 2 so tracks
+# start at 0; shape (fanout, nchan, bps) for 32 tracks
+# (mark4/header.py:306-328).
+_TRACK_ASSIGNMENTS = {
+    (2, 4): np.array([[2, 10, 3, 11, 18, 26, 19, 27],
+                      [4, 12, 5, 13, 20, 28, 21, 29],
+                      [6, 14, 7, 15, 22, 30, 23, 31],
+                      [8, 16, 9, 17, 24, 32, 25, 33]]).reshape(4, 4, 2) - 2,
+    (1, 4): np.array([[2, 3, 10, 11, 18, 19, 26, 27],
+                      [4, 5, 12, 13, 20, 21, 28, 29],
+                      [6, 7, 14, 15, 22, 23, 30, 31],
+                      [8, 9, 16, 17, 24, 25, 32, 33]]).reshape(4, 8, 1) - 2,
+    (2, 2): np.array([[2, 6, 3, 7, 10, 14, 11, 15, 18, 22, 19, 23, 26, 30, 27, 31],
+                      [4, 8, 5, 9, 12, 16, 13, 17, 20, 24, 21, 25, 28, 32, 29, 33]]
+                     ).reshape(2, 8, 2) - 2,
+    (1, 2): np.array([[2, 3, 6, 7, 10, 11, 14, 15, 18, 19, 22, 23, 26, 27, 30, 31],
+                      [4, 5, 8, 9, 12, 13, 16, 17, 20, 21, 24, 25, 28, 29, 32, 33]]
+                     ).reshape(2, 16, 1) - 2,
+    (2, 1): np.array([[2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32,
+                       3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33]]
+                     ).reshape(1, 16, 2) - 2,
+}
+
+
+def stream2words(stream, track=None):
+    """Stream words (one bit per track) -> uint32 header words per track:
+    bit `track` of stream word 32 j + i lands in bit 31 - i of word j
+    (mark4/header.py:47-64)."""
+    stream = np.asarray(stream)
+    if track is None:
+        track = np.arange(stream.dtype.itemsize * 8, dtype=stream.dtype)
+    bits = ((stream.reshape(-1, 32, 1) >> track) & 1).astype(np.uint32)
+    bits <<= np.arange(31, -1, -1, dtype=np.uint32).reshape(-1, 1)
+    return np.bitwise_or.reduce(bits, axis=1)
+
+
+def words2stream(words):
+    """Inverse of `stream2words` (mark4/header.py:67-87)."""
+    words = np.asarray(words, dtype=np.uint32)
+    ntrack = words.shape[1]
+    dtype = np.dtype(MARK4_DTYPES[ntrack])
+    bit = np.arange(31, -1, -1, dtype=np.uint32).reshape(-1, 1)
+    sel = ((words[:, np.newaxis, :] >> bit) & 1).astype(dtype)
+    sel <<= np.arange(ntrack, dtype=dtype)
+    return np.bitwise_or.reduce(sel, axis=2).astype(dtype).ravel()
+
+
+def _bcd_decode_array(value):
+    value = np.asarray(value).astype(np.int64)
+    result = np.zeros_like(value)
+    factor = 1
+    v = value.copy()
+    while np.any(v > 0):
+        digit = v & 0xf
+        if np.any(digit > 9):
+            raise ValueError("invalid BCD encoded value")
+        result += digit * factor
+        factor *= 10
+        v >>= 4
+    return result
+
+
+def _bcd_encode(value):
+    result, shift, value = 0, 0, int(value)
+    while value > 0:
+        value, digit = divmod(value, 10)
+        result += digit << shift
+        shift += 4
+    return result
+
+
+def crc12_stream(stream):
+    """CRC-12 (x^12 + x^11 + x^3 + x^2 + x + 1 = 0x180f, mark4/header.py:34-43)
+    of a bit stream given as stream words (all tracks at once,
+    base/utils.py:200-248)."""
+    pol = [int(b) for b in '{:b}'.format(0x180f)]
+    stream = np.concatenate([stream, np.zeros(12, stream.dtype)])
+    ones = np.iinfo(stream.dtype).max
+    pol_arr = np.array([ones if b else 0 for b in pol], dtype=stream.dtype)
+    for i in range(len(stream) - 12):
+        stream[i:i + 13] ^= stream[i] & pol_arr
+    return stream[-12:]
+
+
+class Mark4Header:
+    """Decoder of a Mark 4 header containing all tracks."""
+
+    decade = None
+
+    def __init__(self, words, ntrack=None, decade=None, ref_time=None,
+                 verify=True):
+        if words is None:
+            words = np.zeros((5, ntrack), dtype=np.uint32)
+            verify = False
+            self._mutable = True
+        else:
+            words = np.asarray(words, dtype=np.uint32)
+            self._mutable = False
+        self.words = words
+        if decade is not None:
+            self.decade = decade
+        if verify:
+            self.verify()
+        if decade is None and ref_time is not None:
+            self.infer_decade(ref_time)
+
+    # -- field access
+    def keys(self):
+        return _FIELDS.keys()
+
+    def __getitem__(self, key):
+        try:
+            word, bit, nbits = _FIELDS[key][:3]
+        except KeyError:
+            raise KeyError("Mark4Header header does not contain {0}".format(key))
+        v = (self.words[word] >> np.uint32(bit)) & np.uint32((1 << nbits) - 1)
+        return v.astype(bool) if nbits == 1 else v
+
+    def __setitem__(self, key, value):
+        if not self._mutable:
+            raise TypeError("header is immutable; use .copy() to get a "
+                            "mutable one.")
+        word, bit, nbits = _FIELDS[key][:3]
+        mask = np.uint32(((1 << nbits) - 1) << bit)
+        value = np.asarray(value).astype(np.uint32)
+        self.words[word] = (self.words[word] & ~mask) | ((value << np.uint32(bit)) & mask)
+
+    def copy(self):
+        new = Mark4Header(self.words.copy(), decade=self.decade, verify=False)
+        new._mutable = True
+        return new
+
+    @property
+    def mutable(self):
+        return self._mutable
+
+    @mutable.setter
+    def mutable(self, mutable):
+        self._mutable = bool(mutable)
+
+    def verify(self):
+        """mark4/header.py:171-179,334-339."""
+        assert self.words.shape[0] == 5
+        assert np.all(self['sync_pattern'] == 0xffffffff)
+        assert np.all((self['bcd_fraction'] & 0xf) % 5 != 4)
+        if self.decade is not None:
+            assert (1950 < self.decade < 3000)
+            assert self.decade % 10 == 0, "decade must end in zero"
+        assert set(self['fan_out'].tolist()) == set(range(self.fanout))
+        assert (len(set(zip(self['converter_id'].tolist(),
+                            self['lsb_output'].tolist()))) == self.nchan)
+
+    @classmethod
+    def fromfile(cls, fh, ntrack, decade=None, ref_time=None, verify=True):
+        """Read the 160 stream words and transpose them into per-track header
+        words (mark4/header.py:425-454)."""
+        dtype = np.dtype(MARK4_DTYPES[ntrack])
+        header_nbytes = ntrack * 160 // 8
+        s = fh.read(header_nbytes)
+        if len(s) != header_nbytes:
+            raise EOFError("could not read full Mark 4 Header.")
+        words = stream2words(np.frombuffer(s, dtype=dtype))
+        return cls(words, decade=decade, ref_time=ref_time, verify=verify)
+
+    def tofile(self, fh):
+        fh.write(words2stream(self.words).tobytes())
+
+    @classmethod
+    def fromvalues(cls, ntrack, *, time, bps=2, fanout=4, nsb=1,
+                   system_id=0, verify=True):
+        """Header with the standard track layout for (ntrack, bps, fanout)
+        at `time`, the way the reference's writer fills it
+        (mark4/header.py:456-507,565-700).  Used to synthesise files."""
+        self = cls(None, ntrack=ntrack)
+        self['bcd_headstack1'] = 0x3344
+        self['bcd_headstack2'] = 0x1122
+        self['sync_pattern'] = 0xffffffff
+        self['system_id'] = system_id
+        if ntrack == 64:
+            self['headstack_id'] = np.repeat(np.arange(2), 32)
+            track_id = np.tile(np.arange(2, 34), 2)
+        elif ntrack == 32:
+            track_id = np.arange(2, 34)
+        else:
+            track_id = np.arange(2, 34, 2)
+        self['bcd_track_id'] = np.array([_bcd_encode(t) for t in track_id])
+        self.fanout = fanout
+        self.bps = bps
+        self.nsb = nsb
+        self.set_time(time)
+        self.update_crc()
+        if verify:
+            self.verify()
+        return self
+
+    def update_crc(self):
+        stream = words2stream(self.words)
+        stream[-12:] = crc12_stream(stream[:-12].copy())
+        self.words = stream2words(stream)
+
+    # -- geometry (mark4/header.py:540-650)
+    @property
+    def ntrack(self):
+        return self.words.shape[1]
+
+    @property
+    def stream_dtype(self):
+        return np.dtype(MARK4_DTYPES[self.ntrack])
+
+    @property
+    def nbytes(self):
+        return self.ntrack * 160 // 8
+
+    @property
+    def frame_nbytes(self):
+        return self.ntrack * PAYLOAD_NBITS // 8
+
+    @property
+    def payload_nbytes(self):
+        return self.frame_nbytes - self.nbytes
+
+    @property
+    def fanout(self):
+        return int(np.max(self['fan_out']) + 1)
+
+    @fanout.setter
+    def fanout(self, fanout):
+        if fanout not in (1, 2, 4):
+            raise ValueError("Mark 4 data only supports fanout=1, 2, or 4, "
+                             "not {0}.".format(fanout))
+        if self.ntrack == 16:
+            self['fan_out'] = np.tile(np.arange(fanout), self.ntrack // fanout)
+        else:
+            self['fan_out'] = np.tile(np.repeat(np.arange(fanout), 2),
+                                      self.ntrack // 2 // fanout)
+
+    @property
+    def samples_per_frame(self):
+        return self.frame_nbytes * 8 // (self.ntrack // self.fanout)
+
+    @property
+    def bps(self):
+        return 2 if self['magnitude_bit'].any() else 1
+
+    @bps.setter
+    def bps(self, bps):
+        if bps == 1:
+            self['magnitude_bit'] = np.zeros(self.ntrack, bool)
+        elif bps == 2:
+            ta = self._track_assignment(self.ntrack, bps, self.fanout)
+            magnitude_bit = np.empty(self.ntrack, dtype=bool)
+            magnitude_bit[ta] = [False, True]
+            self['magnitude_bit'] = magnitude_bit
+        else:
+            raise ValueError("Mark 4 data can only have bps=1 or 2, "
+                             "not {0}".format(bps))
+
+    complex_data = False
+
+    @property
+    def nchan(self):
+        return self.ntrack // (self.fanout * self.bps)
+
+    @property
+    def sample_shape(self):
+        return (self.nchan,)
+
+    @property
+    def nsb(self):
+        sb = self['lsb_output']
+        return 1 if (sb == sb[0]).all() else 2
+
+    @nsb.setter
+    def nsb(self, nsb):
+        """Side bands and default converter ids (mark4/header.py:654-677,
+        690-730)."""
+        if nsb == 1:
+            self['lsb_output'] = np.ones(self.ntrack, bool)
+        elif nsb == 2:
+            self['lsb_output'] = np.tile([False, True], self.ntrack // 2)
+        else:
+            raise ValueError("number of sidebands can only be 1 or 2.")
+        nconverter = self.ntrack // (self.fanout * self.bps * self.nsb)
+        converters = np.arange(nconverter)
+        if nconverter > 2:
+            converters = converters.reshape(-1, 2, 2).transpose(0, 2, 1).ravel()
+        ta = self.track_assignment
+        ta_ch = ta[0, :, 0]
+        nchan = len(ta_ch)
+        sb = self['lsb_output'][ta_ch]
+        if len(converters) == nchan // 2:
+            c = np.empty(nchan, dtype=int)
+            c[sb] = converters
+            c[~sb] = converters
+            converters = c
+        converter_id = np.empty(self.ntrack, dtype=int)
+        converter_id[ta] = np.asarray(converters)[:, np.newaxis]
+        self['converter_id'] = converter_id
+
+    @classmethod
+    def _track_assignment(cls, ntrack, bps, fanout):
+        try:
+            ta = _TRACK_ASSIGNMENTS[(bps, fanout)]
+        except KeyError:
+            raise ValueError("Mark 4 reader does not support bps={0}, "
+                             "fanout={1}".format(bps, fanout))
+        if ntrack == 64:
+            return np.concatenate((ta, ta + 32), axis=1)
+        if ntrack == 32:
+            return ta
+        if ntrack == 16:
+            return ta[:, ::2, :] // 2
+        raise ValueError("have Mark 4 track assignments only for "
+                         "ntrack=32 or 64, not {0}".format(ntrack))
+
+    @property
+    def track_assignment(self):
+        return self._track_assignment(self.ntrack, self.bps, self.fanout)
+
+    def magnitude_signature(self):
+        """None for the standard sign/magnitude placement, else the packed
+        magnitude bits used as decoder key (mark4/payload.py:346-357)."""
+        magnitude_bit = self['magnitude_bit']
+        if self.bps == 1 or np.all(magnitude_bit[self.track_assignment]
+                                   == [False, True]):
+            return None
+        return int(np.packbits(magnitude_bit).view(self.stream_dtype).item())
+
+    # -- time (mark4/header.py:181-262)
+    def infer_decade(self, ref_time):
+        year = np.datetime64(ref_time, 'ns').astype('datetime64[Y]').astype(int) + 1970
+        frac = ((np.datetime64(ref_time, 'ns') - np.datetime64(str(year), 'ns'))
+                / np.timedelta64(365, 'D'))
+        self.decade = int(np.around(year + frac - int(self['bcd_unit_year'][0]),
+                                    decimals=-1))
+
+    @property
+    def fraction(self):
+        ms = _bcd_decode_array(self['bcd_fraction'])
+        return (ms + (ms % 5) * 0.25) / 1000.
+
+    def time_quarter_ms(self, track=0):
+        """Time of `track` in units of 0.25 ms since the start of its year
+        (what the scan kernel works in)."""
+        day = int(_bcd_decode_array(self['bcd_day'][track]))
+        hour = int(_bcd_decode_array(self['bcd_hour'][track]))
+        minute = int(_bcd_decode_array(self['bcd_minute'][track]))
+        second = int(_bcd_decode_array(self['bcd_second'][track]))
+        ms = int(_bcd_decode_array(self['bcd_fraction'][track]))
+        return (((day * 24 + hour) * 60 + minute) * 60 + second) * 4000 + 4 * ms + ms % 5
+
+    @property
+    def year(self):
+        return self.decade + int(self['bcd_unit_year'][0])
+
+    def get_time(self):
+        q = self.time_quarter_ms()
+        return (np.datetime64('{:04d}-01-01'.format(self.year), 'ns')
+                + np.timedelta64(q * 250000 - 86400 * 10 ** 9, 'ns'))
+
+    def set_time(self, time):
+        time = np.datetime64(time, 'ns')
+        year = int(time.astype('datetime64[Y]').astype(int)) + 1970
+        ns = int((time - np.datetime64('{:04d}-01-01'.format(year), 'ns'))
+                 / np.timedelta64(1, 'ns'))
+        ms_total, rem = divmod(ns, 1000000)
+        frac_ms = ms_total % 1000 + rem / 1e6
+        if abs(frac_ms / 1.25 - round(frac_ms / 1.25)) > 1e-6:
+            raise ValueError("{0} ms is not a multiple of 1.25 ms".format(frac_ms))
+        sec_total = ms_total // 1000
+        day, sec_of_day = divmod(sec_total, 86400)
+        hour, rest = divmod(sec_of_day, 3600)
+        minute, second = divmod(rest, 60)
+        self.decade = year // 10 * 10
+        n = self.ntrack
+        self['bcd_unit_year'] = np.full(n, year % 10)
+        self['bcd_day'] = np.full(n, _bcd_encode(day + 1))
+        self['bcd_hour'] = np.full(n, _bcd_encode(hour))
+        self['bcd_minute'] = np.full(n, _bcd_encode(minute))
+        self['bcd_second'] = np.full(n, _bcd_encode(second))
+        self['bcd_fraction'] = np.full(n, _bcd_encode(int(np.floor(frac_ms + 1e-6))))
+
+    time = property(get_time, set_time)
+
+    def __eq__(self, other):
+        return (type(self) is type(other)
+                and np.array_equal(self.words, other.words))
+
+    def __repr__(self):
+        return "<Mark4Header ntrack={} fanout={} bps={} nchan={} time={}>".format(
+            self.ntrack, self.fanout, self.bps, self.nchan,
+            self.get_time() if self.decade is not None else '?')

@@ -107,3 +107,61 @@ def random_vdif(seed, nsets, *, nthread=1, nchan=1, bps=2, complex_data=False,
     image = vdif_file_image(payloads, header0, list(range(nthread)), frame_rate,
                             thread_order, invalid)
     return image, header0
+
+
+# ---------------------------------------------------------------- Mark 4
+def mark4_frame_headers(header0, nframes, frame_rate):
+    """Stream-word headers (nframes, 160) for consecutive frames starting at
+    header0's time; CRC recomputed per frame like the reference's writer."""
+    from .mark4.header import words2stream
+    out = np.empty((nframes, 160), dtype=header0.stream_dtype)
+    t0 = header0.get_time()
+    for i in range(nframes):
+        h = header0.copy()
+        ns = int(round(i * 1e9 / frame_rate))
+        h.set_time(t0 + np.timedelta64(ns, 'ns'))
+        h.update_crc()
+        out[i] = words2stream(h.words)
+    return out
+
+
+def encode_mark4_stream(data, header0, frame_rate):
+    """(nsample, nchan) data -> Mark 4 file image: each frame's first
+    160*fanout samples are dropped (overwritten by the header), as the
+    reference's writer does (mark4/frame.py:139-141)."""
+    from .mark4.payload import encode_mark4
+    data = np.asarray(data)
+    spf = header0.samples_per_frame
+    nframes = data.shape[0] // spf
+    assert nframes * spf == data.shape[0]
+    nfill = 160 * header0.fanout
+    hdr = mark4_frame_headers(header0, nframes, frame_rate)
+    frames = np.empty((nframes, 20000), dtype=header0.stream_dtype)
+    frames[:, :160] = hdr
+    for i in range(nframes):
+        frames[i, 160:] = encode_mark4(data[i * spf + nfill:(i + 1) * spf], header0)
+    return frames.reshape(-1).view(np.uint8)
+
+
+def random_mark4(seed, nframes, *, ntrack=64, fanout=4, frame_rate=400,
+                 time='2015-03-02T04:05:06.25', invalid=(), lead_bytes=0):
+    """Seeded random Mark 4 file image (uniform random payload bits) plus its
+    header0.  `invalid` lists frames that get an error flag on one track;
+    `lead_bytes` random bytes (without a sync pattern) precede the first
+    frame, as in real recordings."""
+    from .mark4.header import Mark4Header
+    header0 = Mark4Header.fromvalues(ntrack, time=np.datetime64(time), bps=2,
+                                     fanout=fanout)
+    rng = np.random.default_rng(seed)
+    dt = header0.stream_dtype
+    frames = rng.integers(0, 256, size=(nframes, 20000 * dt.itemsize),
+                          dtype=np.uint8).view(dt)
+    frames = frames.copy()
+    frames[:, :160] = mark4_frame_headers(header0, nframes, frame_rate)
+    for f in invalid:
+        frames[f, 51] |= dt.type(1 << (f % ntrack))     # communication_error bit
+    image = frames.reshape(-1).view(np.uint8)
+    if lead_bytes:
+        lead = rng.integers(0, 255, size=lead_bytes, dtype=np.uint8)  # never 0xff
+        image = np.concatenate([lead, image])
+    return image, header0

@@ -193,6 +193,64 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
                      const bb_decode_params *params,
                      float *d_out, size_t out_elems, void *stream);
 
+/* ---- Mark 4 ------------------------------------------------------------ */
+
+/*
+ * Mark 4 header scan (M4-2 of SURVEY.md section 8a): for every
+ * ntrack*2500-byte frame at first_offset + k*frame_nbytes, test the sync
+ * pattern (stream word 63 all zero, words 64-95 all ones:
+ * mark4/header.py:345-373, mark4/base.py:110-166), read the four error flags
+ * of all tracks (any set -> BB_FRAME_INVALID: mark4/frame.py:78-87) and the
+ * BCD time code of track 0 (mark4/header.py:134-141,198-241) to form the
+ * frame index.  Times are handled in quarter-milliseconds since the start of
+ * `ref_year`; `frame_qms` is the frame duration (5 .. 640).
+ * bb_frame_rec.payload_offset is the FRAME start (bb_decode_mark4 skips the
+ * 160 header words itself).
+ */
+typedef struct bb_mark4_scan_params {
+    uint64_t first_offset;
+    int32_t  ntrack;          /* 16, 32 or 64 */
+    int32_t  ref_year;        /* full year of header0 */
+    int64_t  ref_qms;         /* header0 time, quarter-ms since start of ref_year */
+    int32_t  frame_qms;       /* frame duration in quarter-ms; 0: index = position */
+    int32_t  reserved;
+} bb_mark4_scan_params;
+
+int bb_mark4_scan(const void *d_buf, size_t nbytes,
+                  const bb_mark4_scan_params *params,
+                  bb_frame_rec *d_recs, size_t nframes, void *stream);
+
+/*
+ * Mark 4 track-demultiplexing decode (M4-1, M4-2): replaces the five
+ * decoders decode_{2chan_2bit_fanout4, 4chan_2bit_fanout4, 8chan_2bit_fanout2,
+ * 8chan_2bit_fanout4, 16chan_2bit_fanout2_ft} (mark4/payload.py:122-288) and
+ * the header-overwrite fill of Mark4Frame (mark4/frame.py:185-189,248-258).
+ * Every stream word of `ntrack` bits yields ntrack/2 float32 values: output j
+ * (= fanout sample t * nchan + channel c) takes its sign from bit sign_bit[j]
+ * and its magnitude from bit mag_bit[j] of the word; value = {-Hi,-1,+1,+Hi}
+ * [2*sign + magnitude].  The maps are data (tests/golden/mark4_bitmaps.json
+ * holds the ones of the reference's five decoders).  Unit f is read at
+ * d_src[f] (or src0 + f*src_stride); its first `fill_words` words and whole
+ * units with source -1 are written as `fill`.
+ */
+typedef struct bb_mark4_decode_params {
+    int32_t  ntrack;          /* 16, 32 or 64 */
+    int32_t  reserved;
+    uint64_t nwords;          /* stream words per unit: 20000 (frame) or payload size */
+    uint64_t fill_words;      /* 160 for frames, 0 for bare payloads */
+    int64_t  src0;
+    int64_t  src_stride;
+    uint8_t  sign_bit[32];
+    uint8_t  mag_bit[32];
+    float    fill;
+    int32_t  reserved2;
+} bb_mark4_decode_params;
+
+int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
+                    const int64_t *d_src, size_t nframes,
+                    const bb_mark4_decode_params *params,
+                    float *d_out, size_t out_elems, void *stream);
+
 /* ---- tuning knobs (performance experiments; results never change) ------ */
 #define BB_TUNE_FLAT_VARIANT   0   /* kernel variant of the flat decode */
 #define BB_TUNE_NT_STORES      1   /* 1 = non-temporal stores */

@@ -353,3 +353,223 @@ def mark5b_read(raw, nchan, bps=2, frame_rate=None, fill_value=0.):
         out[i * spf:(i + 1) * spf] = lut.take(words, axis=0).reshape(-1, nchan)
     return out, dict(header0=h0, frame_rate=frame_rate, samples_per_frame=spf,
                      nframes=nfr)
+
+
+# --------------------------------------------------------------------------
+# Mark 4 (mark4/header.py:26-64,107-143,306-328,540-650; payload.py:48-342;
+#         frame.py:78-97,148-263)
+# --------------------------------------------------------------------------
+MARK4_DTYPES = {8: '<u1', 16: '<u2', 32: '<u4', 64: '<u8'}
+MARK4_FT_SIGNATURE = 0xf0faf050f0faf05
+
+
+def mark4_stream2words(stream, track=None):
+    """Track transpose: bit `track` of stream word 32 j + i becomes bit
+    31 - i of header word j (mark4/header.py:47-64)."""
+    stream = np.asarray(stream)
+    if track is None:
+        track = np.arange(stream.dtype.itemsize * 8, dtype=stream.dtype)
+    sel = ((stream.reshape(-1, 32, 1) >> track) & 1).astype(np.uint32)
+    sel <<= np.arange(31, -1, -1, dtype=np.uint32).reshape(-1, 1)
+    return np.bitwise_or.reduce(sel, axis=1)
+
+
+def mark4_header_fields(words):
+    """Per-track fields of a (5, ntrack) header word array
+    (mark4/header.py:107-143)."""
+    w = np.asarray(words, dtype=np.uint32)
+    f = dict(
+        fan_out=(w[1] >> 22) & 0x3, magnitude_bit=((w[1] >> 21) & 1).astype(bool),
+        lsb_output=((w[1] >> 20) & 1).astype(bool), converter_id=(w[1] >> 16) & 0xf,
+        time_sync_error=((w[1] >> 15) & 1).astype(bool),
+        internal_clock_error=((w[1] >> 14) & 1).astype(bool),
+        processor_time_out_error=((w[1] >> 13) & 1).astype(bool),
+        communication_error=((w[1] >> 12) & 1).astype(bool),
+        system_id=w[1] & 0xff, sync_pattern=w[2],
+        bcd_unit_year=(w[3] >> 28) & 0xf, bcd_day=(w[3] >> 16) & 0xfff,
+        bcd_hour=(w[3] >> 8) & 0xff, bcd_minute=w[3] & 0xff,
+        bcd_second=(w[4] >> 24) & 0xff, bcd_fraction=(w[4] >> 12) & 0xfff,
+        crc=w[4] & 0xfff)
+    ntrack = w.shape[1]
+    f['ntrack'] = ntrack
+    f['fanout'] = int(f['fan_out'].max()) + 1                  # :565-571
+    f['bps'] = 2 if f['magnitude_bit'].any() else 1             # :611-617
+    f['nchan'] = ntrack // (f['fanout'] * f['bps'])             # :636-641
+    f['frame_nbytes'] = ntrack * 2500                           # :550-553
+    f['header_nbytes'] = ntrack * 20                            # :545-548
+    f['samples_per_frame'] = 20000 * f['fanout']                # :584-592
+    f['valid'] = not np.any(f['time_sync_error'] | f['internal_clock_error']
+                            | f['processor_time_out_error']
+                            | f['communication_error'])         # frame.py:78-87
+    return f
+
+
+def mark4_time_quarter_ms(f, track=0):
+    """Header time of one track in units of 0.25 ms since the start of the
+    (unit) year: day, hour, minute, second BCD + millisecond BCD whose last
+    digit d encodes d*1.25 ms (mark4/header.py:198-214,223-241)."""
+    day = bcd_decode(int(f['bcd_day'][track]), 3)
+    hour = bcd_decode(int(f['bcd_hour'][track]), 2)
+    minute = bcd_decode(int(f['bcd_minute'][track]), 2)
+    sec = bcd_decode(int(f['bcd_second'][track]), 2)
+    ms = bcd_decode(int(f['bcd_fraction'][track]), 3)
+    q = 4 * ms + ms % 5
+    return (((day * 24 + hour) * 60 + minute) * 60 + sec) * 4000 + q
+
+
+def _m4_reorder32(x):
+    """mark4/payload.py:48-52."""
+    x = x.astype(np.uint32)
+    return ((x & np.uint32(0xAA55AA55)) | ((x & np.uint32(0x55005500)) >> np.uint32(7))
+            | ((x & np.uint32(0x00AA00AA)) << np.uint32(7)))
+
+
+def _m4_reorder64(x):
+    """mark4/payload.py:56-60."""
+    x = x.astype(np.uint64)
+    return ((x & np.uint64(0xAA55AA55AA55AA55))
+            | ((x & np.uint64(0x5500550055005500)) >> np.uint64(7))
+            | ((x & np.uint64(0x00AA00AA00AA00AA)) << np.uint64(7)))
+
+
+def _m4_reorder64_ft(x):
+    """mark4/payload.py:62-69."""
+    x = x.astype(np.uint64)
+    return ((x & np.uint64(0xFFFFFAAFFFFFFAAF))
+            | ((x & np.uint64(0x0000050000000500)) >> np.uint64(4))
+            | ((x & np.uint64(0x0000005000000050)) << np.uint64(4)))
+
+
+def _m4_luts():
+    """mark4/payload.py:88-115: byte -> 4 samples for the three sign/mag
+    placements."""
+    b = np.arange(256)[:, np.newaxis]
+    i = np.arange(4)
+    out = []
+    for s, m in ((i * 2, i * 2 + 1), (i + (i // 2) * 2, i + (i // 2) * 2 + 2),
+                 (i, i + 4)):
+        out.append(LEVELS_2[2 * (b >> s & 1) + (b >> m & 1)])
+    return out
+
+
+_M4_LUT1, _M4_LUT2, _M4_LUT3 = _m4_luts()
+
+
+def mark4_decode(words, nchan, fanout, magnitude_signature=None):
+    """The five registered Mark 4 decoders (mark4/payload.py:122-288,333-342).
+    `words` has the stream dtype of its track count."""
+    words = np.ascontiguousarray(words)
+    key = (nchan, magnitude_signature if magnitude_signature is not None else 2, fanout)
+    if key == (2, 2, 4):                       # 16 tracks
+        fr = words.view(np.uint8).reshape(-1, 2)
+        return _M4_LUT3.take(fr, axis=0).transpose(1, 0, 2).reshape(2, -1).T
+    if key == (4, 2, 4):                       # 32 tracks
+        fr = _m4_reorder32(words.view('<u4')).view(np.uint8).reshape(-1, 4)
+        fr = fr.take(np.array([0, 2, 1, 3]), axis=1)
+        return _M4_LUT1.take(fr.T, axis=0).reshape(4, -1).T
+    if key == (8, 2, 2):                       # 32 tracks
+        fr = words.view(np.uint8).reshape(-1, 4)
+        return (_M4_LUT3.take(fr, axis=0).reshape(-1, 4, 2, 2)
+                .transpose(3, 1, 0, 2).reshape(8, -1).T)
+    if key == (8, 2, 4):                       # 64 tracks
+        fr = _m4_reorder64(words.view('<u8')).view(np.uint8).reshape(-1, 8)
+        fr = fr.take(np.array([0, 2, 1, 3, 4, 6, 5, 7]), axis=1)
+        return _M4_LUT1.take(fr.T, axis=0).reshape(8, -1).T
+    if key == (16, MARK4_FT_SIGNATURE, 2):     # 64 tracks, Fortaleza
+        fr = _m4_reorder64_ft(words.view('<u8')).view(np.uint8).reshape(-1, 8)
+        return (_M4_LUT3.take(fr, axis=0).reshape(-1, 2, 4, 2, 2)
+                .transpose(1, 4, 2, 0, 3).reshape(16, -1).T)
+    raise KeyError(key)
+
+
+# Track assignments, tables 10-14 of the Mark 4 memo 230.3, as tabulated in
+# mark4/header.py:306-328; shape (fanout, nchan, bps) for 32 tracks.
+_M4_TA = {
+    (2, 4): np.array([[2, 10, 3, 11, 18, 26, 19, 27], [4, 12, 5, 13, 20, 28, 21, 29],
+                      [6, 14, 7, 15, 22, 30, 23, 31], [8, 16, 9, 17, 24, 32, 25, 33]]
+                     ).reshape(4, 4, 2) - 2,
+    (2, 2): np.array([[2, 6, 3, 7, 10, 14, 11, 15, 18, 22, 19, 23, 26, 30, 27, 31],
+                      [4, 8, 5, 9, 12, 16, 13, 17, 20, 24, 21, 25, 28, 32, 29, 33]]
+                     ).reshape(2, 8, 2) - 2,
+    (2, 1): np.array([[2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32,
+                       3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33]]
+                     ).reshape(1, 16, 2) - 2,
+}
+
+
+def mark4_track_assignment(ntrack, bps, fanout):
+    """mark4/header.py:381-399."""
+    ta = _M4_TA[(bps, fanout)]
+    if ntrack == 64:
+        return np.concatenate((ta, ta + 32), axis=1)
+    if ntrack == 32:
+        return ta
+    if ntrack == 16:
+        return ta[:, ::2, :] // 2
+    raise ValueError(ntrack)
+
+
+def mark4_magnitude_signature(f):
+    """None for the standard sign/magnitude placement, else the packed
+    magnitude bits (mark4/payload.py:346-357)."""
+    if f['bps'] == 1:
+        return None
+    ta = mark4_track_assignment(f['ntrack'], f['bps'], f['fanout'])
+    if np.all(f['magnitude_bit'][ta] == [False, True]):
+        return None
+    return int(np.packbits(f['magnitude_bit']).view(MARK4_DTYPES[f['ntrack']]).item())
+
+
+def mark4_locate_first_frame(buf, ntrack):
+    """First byte offset at which the sync pattern (32 all-ones stream words
+    preceded by one all-zero stream word, starting 63 words into the header)
+    is found with another one a frame later (mark4/base.py:110-166;
+    mark4/header.py:345-373)."""
+    dt = np.dtype(MARK4_DTYPES[ntrack])
+    isz = dt.itemsize
+    fn = ntrack * 2500
+    ones = np.iinfo(dt).max
+    limit = min(len(buf) - fn - 160 * isz, 2 * fn)
+
+    def sync_at(o):
+        w = np.frombuffer(buf[o + 63 * isz:o + 96 * isz].tobytes(), dtype=dt)
+        return w[0] == 0 and np.all(w[1:] == ones)
+    for o in range(0, max(limit, 0) + 1):
+        if sync_at(o) and (o + fn + 96 * isz > len(buf) or sync_at(o + fn)):
+            return o
+    raise LookupError("no Mark 4 frame found")
+
+
+def mark4_read(raw, ntrack, frame_rate=None, fill_value=0.):
+    """Reference-as-written Mark 4 decode of a clean file image: first 160
+    stream words of every frame are the headers and decode to fill_value
+    (mark4/frame.py:185-189,248-258); error flags make the frame invalid."""
+    buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    dt = np.dtype(MARK4_DTYPES[ntrack])
+    fn = ntrack * 2500
+    off0 = mark4_locate_first_frame(buf, ntrack)
+    nframes = (len(buf) - off0) // fn
+    out = None
+    info = {}
+    t0 = None
+    for i in range(nframes):
+        frame = np.frombuffer(buf[off0 + i * fn:off0 + (i + 1) * fn].tobytes(), dtype=dt)
+        f = mark4_header_fields(mark4_stream2words(frame[:160]))
+        if i == 0:
+            sig = mark4_magnitude_signature(f)
+            spf = f['samples_per_frame']
+            out = np.empty((nframes * spf, f['nchan']), np.float32)
+            info = dict(header0=f, samples_per_frame=spf, offset0=off0,
+                        signature=sig, nframes=nframes)
+            t0 = mark4_time_quarter_ms(f)
+        if frame_rate is not None:
+            dq = mark4_time_quarter_ms(f) - t0
+            assert dq * frame_rate == i * 4000, "wrong frame number"
+        rows = out[i * spf:(i + 1) * spf]
+        nfill = 160 * f['fanout']
+        rows[:nfill] = fill_value
+        if f['valid']:
+            rows[nfill:] = mark4_decode(frame[160:], f['nchan'], f['fanout'], sig)
+        else:
+            rows[nfill:] = fill_value
+    return out, info

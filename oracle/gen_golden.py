@@ -343,11 +343,115 @@ def gen_mark5b_synth():
         print('mark5b synth', name, back.shape, 'oracle == reference')
 
 
+def gen_mark4_bitmaps():
+    """Bit -> (sign|magnitude, fanout sample, channel) maps of the five
+    registered decoders, found by pushing single-bit words through the
+    REFERENCE decoders (facts about the format, stored as data)."""
+    from baseband.mark4 import payload as m4p
+    maps = {}
+    hi = np.float32(3.316505)
+    for key, dec in m4p.Mark4Payload._decoders.items():
+        nchan, sig, fanout = key
+        ntrack = nchan * 2 * fanout
+        dt = np.dtype(orc.MARK4_DTYPES[ntrack])
+        zero = dec(np.zeros(1, dt))                 # all bits 0 -> all -Hi
+        assert np.all(zero == -hi)
+        sbit = -np.ones((fanout, nchan), int)
+        mbit = -np.ones((fanout, nchan), int)
+        for b in range(ntrack):
+            out = dec(np.array([1 << b], dtype=dt))  # (fanout, nchan)
+            t, c = np.nonzero(out != -hi)
+            assert len(t) == 1
+            if out[t[0], c[0]] == np.float32(1.):    # sign set, magnitude 0 -> +1
+                sbit[t[0], c[0]] = b
+            else:                                    # magnitude only -> -1
+                assert out[t[0], c[0]] == np.float32(-1.)
+                mbit[t[0], c[0]] = b
+        assert sbit.min() >= 0 and mbit.min() >= 0
+        name = '%d_%s_%d' % (nchan, 'ft' if sig != 2 else '2', fanout)
+        maps[name] = dict(nchan=nchan, fanout=fanout, ntrack=ntrack,
+                          signature=(None if sig == 2 else int(sig)),
+                          sign_bit=sbit.ravel().tolist(), mag_bit=mbit.ravel().tolist())
+        # pin the oracle's restatement of the decoders on random words
+        rng = np.random.default_rng(ntrack + fanout)
+        w = rng.integers(0, 2 ** 63, 4096, dtype=np.uint64).astype(dt) if ntrack == 64 \
+            else rng.integers(0, 2 ** ntrack, 4096, dtype=np.uint64).astype(dt)
+        assert np.array_equal(orc.mark4_decode(w, nchan, fanout, None if sig == 2 else sig),
+                              dec(w))
+    with open(os.path.join(GOLD, 'mark4_bitmaps.json'), 'w') as f:
+        json.dump(maps, f, indent=1, sort_keys=True)
+    print('mark4 bitmaps:', sorted(maps), 'oracle decoders == reference')
+
+
+def gen_mark4_samples():
+    cases = [('sample_m4', SAMPLE_MARK4, 64, 32e6), ('sample_32track_m4', SAMPLE_MARK4_32TRACK, 32, None),
+             ('sample_32track_fanout2_m4', SAMPLE_MARK4_32TRACK_FANOUT2, 32, None),
+             ('sample_16track_m4', SAMPLE_MARK4_16TRACK, 16, None),
+             ('sample_64track_fanout2_ft_m4', SAMPLE_MARK4_64TRACK_FANOUT2_FT, 64, None)]
+    for name, path, ntrack, sr in cases:
+        rel = copy_sample(path)
+        with mark4.open(path, 'rs', ntrack=ntrack, decade=2010, squeeze=False) as fh:
+            data = fh.read()
+            h0 = fh.header0
+            info = dict(file=rel, ntrack=ntrack, decade=2010,
+                        sample_rate_hz=float(fh.sample_rate.to_value(u.Hz)),
+                        samples_per_frame=int(fh.samples_per_frame),
+                        fanout=int(h0.fanout), nchan=int(h0.nchan), bps=int(h0.bps),
+                        offset0=int(fh._raw_offsets[0]),
+                        header0_words=np.asarray(h0.words).tolist(),
+                        start_time=fh.start_time.isot, stop_time=fh.stop_time.isot)
+        save_expected(name, data, **info)
+        raw = np.fromfile(path, dtype=np.uint8)
+        fr = info['sample_rate_hz'] / info['samples_per_frame']
+        out, oinfo = orc.mark4_read(raw, ntrack, frame_rate=int(round(fr)))
+        assert oinfo['offset0'] == info['offset0'], (oinfo['offset0'], info['offset0'])
+        assert np.array_equal(out.view(np.uint32), data.view(np.uint32)), name
+        print('mark4 sample', name, data.shape, 'offset0', info['offset0'], 'oracle == reference')
+
+
+def gen_mark4_synth():
+    t0 = Time('2015-03-02T04:05:06.25', precision=9)
+    for name, ntrack, fanout, nchan, nframes, seed in (
+            ('m4_t64_f4', 64, 4, 8, 3, 5), ('m4_t32_f4', 32, 4, 4, 3, 51),
+            ('m4_t32_f2', 32, 2, 8, 4, 52), ('m4_t16_f4', 16, 4, 2, 3, 53)):
+        rng = np.random.default_rng(seed)
+        spf = 20000 * fanout
+        lev = levels_for(2)
+        data = lev[rng.integers(0, 4, size=(spf * nframes, nchan))].astype(np.float32)
+        sample_rate = spf * 80 * u.Hz          # 12.5 ms frames
+        bio = KeepBytesIO()
+        with mark4.open(bio, 'ws', sample_rate=sample_rate, time=t0, ntrack=ntrack,
+                        bps=2, fanout=fanout, squeeze=False) as fw:
+            fw.write(data)
+        blob = bytearray(bio.value())
+        invalid = []
+        if name == 'm4_t64_f4':
+            # set communication_error (header word 1 bit 12) on track 5 of frame 1:
+            # stream word 32 + (31 - 12) = 51, bit 5
+            o = 1 * ntrack * 2500 + 51 * 8
+            blob[o] |= 1 << 5
+            invalid = [1]
+        blob = bytes(blob)
+        with mark4.open(io.BytesIO(blob), 'rs', ntrack=ntrack, decade=2010,
+                        sample_rate=sample_rate, squeeze=False, verify=False) as fr:
+            back = fr.read()
+            h0w = np.asarray(fr.header0.words).tolist()
+        write_synth(name, blob, back, ntrack=ntrack, fanout=fanout, nchan=nchan,
+                    bps=2, nframes=nframes, frame_rate=80, samples_per_frame=spf,
+                    seed=seed, decade=2010, header0_words=h0w, invalid=invalid,
+                    start_time=t0.isot)
+        out, _ = orc.mark4_read(np.frombuffer(blob, np.uint8), ntrack, frame_rate=80)
+        assert np.array_equal(out.view(np.uint32), back.view(np.uint32)), name
+        print('mark4 synth', name, back.shape, 'oracle == reference')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
     steps = [('levels', gen_levels), ('vdif_samples', gen_vdif_samples),
              ('mark5b_sample', gen_mark5b_sample), ('vdif_synth', gen_vdif_synth),
-             ('vdif_invalid', gen_vdif_invalid), ('mark5b_synth', gen_mark5b_synth)]
+             ('vdif_invalid', gen_vdif_invalid), ('mark5b_synth', gen_mark5b_synth),
+             ('mark4_bitmaps', gen_mark4_bitmaps), ('mark4_samples', gen_mark4_samples),
+             ('mark4_synth', gen_mark4_synth)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

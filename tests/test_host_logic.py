@@ -214,3 +214,88 @@ def test_mark5b_header_and_geometry(manifest):
     h2 = Mark5BHeader.fromvalues(time=np.datetime64('2014-06-13T05:30:01'),
                                  user=h['user'])
     assert list(h2.words) == list(h.words)
+
+
+# ------------------------------------------------------------------ Mark 4
+M4_SAMPLES = ['sample_m4', 'sample_32track_m4', 'sample_32track_fanout2_m4',
+              'sample_16track_m4', 'sample_64track_fanout2_ft_m4']
+
+
+@pytest.mark.parametrize('name', M4_SAMPLES + ['m4_t64_f4', 'm4_t32_f2'])
+def test_mark4_stream_geometry(manifest, name):
+    from baseband_amd import mark4
+    case = manifest[name]
+    kw = {}
+    if 'frame_rate' in case:
+        kw['sample_rate'] = case['frame_rate'] * case['samples_per_frame']
+    with mark4.open(golden_path(case['file']), 'rs', ntrack=case['ntrack'],
+                    decade=2010, **kw) as fh:
+        assert fh.shape == tuple(case['shape'])
+        assert fh._file_offset0 == case.get('offset0', 0)
+        assert fh.samples_per_frame == case['samples_per_frame']
+        if 'sample_rate_hz' in case:
+            assert fh.sample_rate == case['sample_rate_hz']
+        assert str(fh.start_time)[:23] == case['start_time'][:23]
+        h = fh.header0
+        assert np.array_equal(h.words, np.array(case['header0_words'], np.uint32))
+        assert (h.fanout, h.nchan, h.bps) == (case['fanout'], case['nchan'], case['bps'])
+    with pytest.raises(TypeError):
+        mark4.open(golden_path(case['file']), 'rs', ntrack=case['ntrack'])
+
+
+def test_mark4_ntrack_detection_and_header(manifest):
+    from baseband_amd import mark4
+    from baseband_amd.mark4.header import Mark4Header, stream2words, words2stream
+    for name in M4_SAMPLES:
+        case = manifest[name]
+        with mark4.open(golden_path(case['file']), 'rb') as fb:
+            assert fb.determine_ntrack() == case['ntrack']
+            assert fb.tell() == case['offset0']
+            fb.decade = 2010
+            h = fb.read_header()
+            assert fb.tell() == case['offset0'] + h.nbytes
+            assert h.frame_nbytes == case['ntrack'] * 2500
+            assert h.payload_nbytes == h.frame_nbytes - case['ntrack'] * 20
+            assert np.array_equal(words2stream(h.words),
+                                  np.frombuffer(load_file(case['file'])[case['offset0']:case['offset0'] + h.nbytes].tobytes(),
+                                                dtype=h.stream_dtype))
+    # the Fortaleza file has a non-standard magnitude-bit layout
+    case = manifest['sample_64track_fanout2_ft_m4']
+    h = Mark4Header(np.array(case['header0_words'], np.uint32), decade=2010)
+    assert h.magnitude_signature() == 0xf0faf050f0faf05
+    case = manifest['sample_m4']
+    h = Mark4Header(np.array(case['header0_words'], np.uint32), decade=2010)
+    assert h.magnitude_signature() is None
+    with pytest.raises(TypeError):
+        h['fan_out'] = 0
+
+
+@pytest.mark.parametrize('name', ['m4_t64_f4', 'm4_t32_f4', 'm4_t32_f2', 'm4_t16_f4'])
+def test_mark4_packer_is_byte_identical_to_reference_writer(manifest, name):
+    from baseband_amd.mark4.header import Mark4Header
+    case = manifest[name]
+    blob = load_file(case['file'])
+    data = load_expected(name)
+    h0 = Mark4Header.fromvalues(case['ntrack'], time=np.datetime64(case['start_time']),
+                                bps=2, fanout=case['fanout'])
+    assert np.array_equal(h0.words, np.array(case['header0_words'], np.uint32))
+    image = synth.encode_mark4_stream(data, h0, case['frame_rate'])
+    fn = case['ntrack'] * 2500
+    for f in range(case['nframes']):
+        if f in case['invalid']:
+            continue          # the fixture's error-flag frame decodes to fill
+        assert image[f * fn:(f + 1) * fn].tobytes() == blob[f * fn:(f + 1) * fn].tobytes(), f
+
+
+def test_mark4_bitmaps_module_matches_golden():
+    import json
+    from baseband_amd.mark4._bitmaps import BITMAPS, FT_SIGNATURE
+    with open(golden_path('mark4_bitmaps.json')) as f:
+        gold = json.load(f)
+    assert len(BITMAPS) == len(gold) == 5
+    for e in gold.values():
+        key = (e['nchan'], e['signature'] or 2, e['fanout'])
+        assert BITMAPS[key]['sign_bit'] == e['sign_bit']
+        assert BITMAPS[key]['mag_bit'] == e['mag_bit']
+        assert BITMAPS[key]['ntrack'] == e['ntrack']
+    assert (16, FT_SIGNATURE, 2) in BITMAPS

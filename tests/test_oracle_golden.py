@@ -88,3 +88,54 @@ def test_stream_masks(manifest):
     for name in ('sample_vdif', 'sample_mwa_vdif', 'sample_arochime_vdif', 'sample_bps1_vdif'):
         case = manifest[name]
         assert orc.vdif_stream_mask(case['edv']) == case['stream_mask']
+
+
+M4_CASES = ['sample_m4', 'sample_32track_m4', 'sample_32track_fanout2_m4',
+            'sample_16track_m4', 'sample_64track_fanout2_ft_m4',
+            'm4_t64_f4', 'm4_t32_f4', 'm4_t32_f2', 'm4_t16_f4']
+
+
+@pytest.mark.parametrize('name', M4_CASES)
+def test_mark4_oracle_matches_reference(manifest, name):
+    case = manifest[name]
+    raw = load_file(case['file'])
+    out, info = orc.mark4_read(raw, case['ntrack'])
+    assert bits_equal(out, load_expected(name))
+    assert hashlib.sha256(out.tobytes()).hexdigest() == case['sha256']
+    assert info['offset0'] == case.get('offset0', 0)
+
+
+def test_mark4_known_answers(manifest):
+    """mark4/tests/test_mark4.py:304-308 (reorder64 of 738811025863578102) and
+    :324-327,449-453 (first payload rows of sample.m4; 640 fill rows)."""
+    x = np.array([738811025863578102], dtype=np.uint64)
+    assert orc._m4_reorder64(x).view(np.uint8).tolist() == [118, 209, 53, 244, 148, 217, 64, 10]
+    halves = x.view(np.uint32)
+    assert np.array_equal(orc._m4_reorder32(halves).view(np.uint8),
+                          orc._m4_reorder64(x).view(np.uint8))
+    exp = load_expected('sample_m4')
+    assert np.all(exp[:640] == 0.)
+    assert exp[640:642].astype(int).tolist() == [[-1, 1, 1, -3, -3, -3, 1, -1],
+                                                 [1, 1, -3, 1, 1, -3, -1, -1]]
+
+
+def test_mark4_bitmaps_reproduce_decoders():
+    """The (sign, magnitude) bit maps are equivalent to the reference's
+    reorder + LUT + transpose decoders on random words."""
+    import json
+    from conftest import golden_path
+    with open(golden_path('mark4_bitmaps.json')) as f:
+        maps = json.load(f)
+    assert len(maps) == 5
+    for name, e in maps.items():
+        nt, nchan, fanout = e['ntrack'], e['nchan'], e['fanout']
+        dt = np.dtype(orc.MARK4_DTYPES[nt])
+        rng = np.random.default_rng(nt + fanout)
+        w = rng.integers(0, 256, size=(2000, dt.itemsize), dtype=np.uint8).view(dt).ravel()
+        ref = orc.mark4_decode(w, nchan, fanout, e['signature'])
+        s = np.array(e['sign_bit'], dtype=np.uint64)
+        m = np.array(e['mag_bit'], dtype=np.uint64)
+        w64 = w.astype(np.uint64)[:, None]
+        idx = 2 * ((w64 >> s) & np.uint64(1)) + ((w64 >> m) & np.uint64(1))
+        got = orc.LEVELS_2[idx.astype(int)].reshape(-1, nchan)
+        assert bits_equal(np.ascontiguousarray(got), np.ascontiguousarray(ref)), name
