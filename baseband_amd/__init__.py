@@ -6,11 +6,11 @@ packed-sample decode running as hand-written HIP kernels (libbbdecode.so,
 gfx950) behind a C ABI.  Decoded samples are device tensors.
 """
 from . import _lib          # noqa: F401  (fails loudly if the library is missing)
-from . import vdif, mark5b, mark4
+from . import vdif, mark5b, mark4, guppi, dada, gsb
 
 __version__ = '0.1.0'
 
-FORMATS = ('vdif', 'mark5b', 'mark4')
+FORMATS = ('vdif', 'mark5b', 'mark4', 'guppi', 'dada', 'gsb')
 
 
 def open(name, mode='rs', format=None, **kwargs):

@@ -81,6 +81,19 @@ class Mark4DecodeParams(C.Structure):
                 ('fill', C.c_float), ('reserved2', C.c_int32)]
 
 
+class TiledParams(C.Structure):
+    _fields_ = [('layout', C.c_int32), ('npol', C.c_int32), ('nchan', C.c_int32),
+                ('reserved', C.c_int32), ('ntime', C.c_uint64),
+                ('t_lo', C.c_uint64), ('t_hi', C.c_uint64),
+                ('src0', C.c_int64), ('src_stride', C.c_int64),
+                ('fill_re', C.c_float), ('fill_im', C.c_float)]
+
+
+LAYOUT_GUPPI_CF = 0
+LAYOUT_MKBF = 1
+LAYOUT_GUPPI_TF = 2
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -109,6 +122,7 @@ SIGNATURES = [
     ('bb_decode_frames', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, _sz, _vp]),
     ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),
     ('bb_decode_mark4', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(Mark4DecodeParams), _vp, _sz, _vp]),
+    ('bb_decode_i8_tiled', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(TiledParams), _vp, _sz, _vp]),
     ('bb_tune', C.c_int, [C.c_int, C.c_int]),
 ]
 

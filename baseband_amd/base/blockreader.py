@@ -1,0 +1,97 @@
+"""Stream reader for byte-aligned block formats (GUPPI, DADA).
+
+These formats have few, large frames (tens of MiB) with ASCII headers, so
+there is no device-side header scan: the host walks the headers and the read
+is cut into pieces ``(frame, first row, last row)`` exactly as the reference's
+loop would take them (base/base.py:957-967 with the per-format ``_get_frame``
+rules).  Runs of frames with the same row range are staged frame-by-frame
+through the pinned pipeline and decoded by one kernel launch per window.
+"""
+import numpy as np
+import torch
+
+from .. import kernels
+from ..staging import WindowPipeline
+from .base import GPUStreamReaderBase
+
+
+class BlockStreamReader(GPUStreamReaderBase):
+    # subclasses set: _frame_nbytes, _header_nbytes, _file_offset0, _nframes
+    def _pieces(self, offset, count):
+        """[(frame, row_lo, row_hi), ...] covering `count` samples from
+        sample `offset`."""
+        raise NotImplementedError
+
+    def _decode_window(self, dbuf, nframes, row_lo, row_hi, out_flat,
+                       payload_offset, frame_stride, first_frame):
+        raise NotImplementedError
+
+    def _frame_span(self, frame):
+        """(byte offset of the frame in the file, number of bytes to stage)."""
+        return (self._file_offset0 + frame * self._frame_nbytes,
+                self._frame_nbytes)
+
+    def read(self, count=None, out=None):
+        if self.closed:
+            raise ValueError("I/O operation on closed stream.")
+        samples_left = self.shape[0] - self.offset
+        if out is None:
+            if count is None or count < 0:
+                count = max(0, samples_left)
+        else:
+            assert tuple(out.shape[1:]) == self.sample_shape, (
+                "'out' must have trailing shape {}".format(self.sample_shape))
+            count = out.shape[0]
+        if count > samples_left:
+            raise EOFError("cannot read from beyond end of input.")
+        kernels.require_gpu()
+        ncomp = 2 if self.complex_data else 1
+        row = int(np.prod(self._decode_shape)) * ncomp
+        flat = torch.empty(count * row, dtype=torch.float32, device='cuda')
+        pieces = self._pieces(self.offset, count)
+        image = self._image()
+        # merge consecutive frames that use the same row range into runs
+        runs = []
+        for f, a, b in pieces:
+            if runs and runs[-1][1] == f and runs[-1][2:] == (a, b):
+                runs[-1][1] = f + 1
+            else:
+                runs.append([f, f + 1, a, b])
+        done = 0
+        for f0, f1, a, b in runs:
+            off0, nbytes = self._frame_span(f0)
+            per_win = max(1, self.window_bytes // self._frame_nbytes)
+            cap = max(per_win * self._frame_nbytes, nbytes)
+            if self._pipeline is None or self._pipeline.cap < cap:
+                self._pipeline = WindowPipeline(image, cap)
+            ranges, spans = [], []
+            for s in range(f0, f1, per_win):
+                e = min(f1, s + per_win)
+                lo = self._frame_span(s)[0]
+                last_lo, last_n = self._frame_span(e - 1)
+                ranges.append((lo, min(last_lo + last_n, len(image))))
+                spans.append((s, e))
+            base = done
+
+            def process(dbuf, i, base=base, a=a, b=b, f0=f0):
+                s, e = spans[i]
+                o = flat[(base + (s - f0) * (b - a)) * row:
+                         (base + (e - f0) * (b - a)) * row]
+                self._decode_window(dbuf, e - s, a, b, o, self._header_nbytes,
+                                    self._frame_nbytes, s)
+
+            self._pipeline.run(ranges, process)
+            done += (f1 - f0) * (b - a)
+        assert done == count
+        if self.complex_data:
+            flat = torch.view_as_complex(flat.view(-1, 2))
+        data = flat.reshape((count,) + tuple(self._decode_shape))
+        data = self._squeeze_and_subset(data)
+        self.offset += count
+        if out is None:
+            return data
+        if isinstance(out, torch.Tensor):
+            out.copy_(data)
+        else:
+            out[...] = data.cpu().numpy()
+        return out

@@ -5,6 +5,7 @@
 #include "k_scan.h"
 #include "k_flat.h"
 #include "k_mark4.h"
+#include "k_tiled.h"
 
 #include <atomic>
 #include <mutex>
@@ -361,6 +362,82 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
         default: BB_M4(64); break;
     }
 #undef BB_M4
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
+                       const int64_t *d_src, size_t nframes,
+                       const bb_tiled_params *p,
+                       float *d_out, size_t out_elems, void *stream)
+{
+    if (!p) return BB_EINVAL;
+    if (p->layout < 0 || p->layout > 2) return BB_ENOTSUP;
+    if (p->npol < 1 || p->nchan < 1 || p->t_hi > p->ntime || p->t_lo > p->t_hi) return BB_EINVAL;
+    if (p->layout == BB_LAYOUT_MKBF && (p->ntime % 256)) return BB_EINVAL;
+    const uint64_t rows = p->t_hi - p->t_lo;
+    if (nframes == 0 || rows == 0) return BB_OK;
+    if (!d_buf || !d_out) return BB_EINVAL;
+    if (((uintptr_t)d_buf & 1) || ((uintptr_t)d_out & 15)) return BB_EINVAL;
+    const uint64_t rowlen = (uint64_t)p->npol * p->nchan * 2;
+    if (out_elems < (uint64_t)nframes * rows * rowlen) return BB_ERANGE;
+    const uint64_t payload = p->ntime * (uint64_t)p->npol * p->nchan * 2;
+    if (!d_src) {
+        if (p->src0 < 0 || p->src_stride < 0 || (p->src0 & 1) || (p->src_stride & 1)) return BB_EINVAL;
+        if ((uint64_t)p->src0 + ((uint64_t)nframes - 1) * (uint64_t)p->src_stride + payload > buf_nbytes)
+            return BB_ERANGE;
+    }
+    bb_tiled_args a;
+    a.buf = (const uint8_t *)d_buf;
+    a.src = d_src;
+    a.out = d_out;
+    a.nframes = nframes;
+    a.t_lo = p->t_lo;
+    a.t_hi = p->t_hi;
+    a.src0 = p->src0;
+    a.src_stride = p->src_stride;
+    a.npol = (uint32_t)p->npol;
+    a.nchan = (uint32_t)p->nchan;
+    a.fill_re = p->fill_re;
+    a.fill_im = p->fill_im;
+    const uint64_t T = p->ntime, np_ = (uint64_t)p->npol, nc = (uint64_t)p->nchan;
+    switch (p->layout) {
+        case BB_LAYOUT_GUPPI_CF: a.tb = T ? T : 1; a.sh = 0; a.st = np_; a.sp = 1; a.sc = T * np_; break;
+        case BB_LAYOUT_MKBF:     a.tb = 256; a.sh = np_ * nc * 256; a.st = 1; a.sp = nc * 256; a.sc = 256; break;
+        default:                 a.tb = T ? T : 1; a.sh = 0; a.st = nc * np_; a.sp = 1; a.sc = np_; break;
+    }
+    // tile: up to 64 channels (even count so float4 pieces pair up), and as
+    // many times as keep the tile near 8192 elements (16 KiB in, 64 KiB out)
+    uint32_t tc = (uint32_t)(nc < 64 ? nc : 64);
+    if (tc > 1 && (tc & 1)) tc += 1;
+    uint32_t tt = 8192u / (uint32_t)(np_ * tc);
+    if (tt < 1) tt = 1;
+    if (tt > 1024) tt = 1024;
+    if (p->layout == BB_LAYOUT_MKBF) { if (tt > 256) tt = 256; while (256 % tt) --tt; }
+    if ((uint64_t)tt > rows) tt = (uint32_t)rows;
+    a.tt = tt;
+    a.tc = tc;
+    const uint64_t ntt = (rows + tt - 1) / tt, nct = (nc + tc - 1) / tc;
+    if (ntt > 0xffffffffull || nct > 0xffffffffull) return BB_ERANGE;
+    a.ntt = (uint32_t)ntt;
+    a.nct = (uint32_t)nct;
+    const size_t lds = (size_t)tt * np_ * (tc + 2) * sizeof(uint16_t);
+    if (lds > 64 * 1024) return BB_ENOTSUP;
+    uint64_t blocks = (uint64_t)nframes * ntt * nct;
+    const int tb = g_tune_blocks.load();
+    if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
+    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+    const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = g_tune_nt.load() != 0;
+#define BB_TL(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_tiled<L, true>), grid, block, lds, st, a); \
+                      else    hipLaunchKernelGGL((k_decode_i8_tiled<L, false>), grid, block, lds, st, a); } while (0)
+    switch (p->layout) {
+        case BB_LAYOUT_GUPPI_CF: BB_TL(0); break;
+        case BB_LAYOUT_MKBF:     BB_TL(1); break;
+        default:                 BB_TL(2); break;
+    }
+#undef BB_TL
     BB_HIP(hipGetLastError());
     return BB_OK;
 }

@@ -1,0 +1,123 @@
+// int8 (re, im) pairs -> complex64 with an axis permutation, through LDS.
+//
+// Replaces (reference, path:line): GUPPIPayload._decode, channels-first
+//   words.reshape(nchan, -1)... .T.reshape(-1, npol, nchan)   (guppi/payload.py:90-96)
+// and time-first .reshape(-1, nchan, npol).transpose(0, 2, 1)  (guppi/payload.py:97-102),
+// MKBFPayload's np.moveaxis(words["heaps"], -1, 1)             (dada/payload.py:76-79),
+// plus the int8 -> float32 casts (guppi/payload.py:13-14, dada/payload.py:13-14).
+//
+// Output is always (time, pol, chan) complex64.  The input address of element
+// (t, p, c), in 2-byte elements, is
+//     (t / tb) * sh + (t % tb) * st + p * sp + c * sc
+//   layout 0  GUPPI channels-first (chan, time, pol):  st = npol, sp = 1, sc = T*npol
+//   layout 1  MKBF heaps (heap, pol, chan, 256):       tb = 256, sh = npol*nchan*256,
+//                                                       st = 1, sp = nchan*256, sc = 256
+//   layout 2  GUPPI time-first (time, chan, pol):      st = nchan*npol, sp = 1, sc = npol
+//
+// A workgroup moves a tile of tt times x tc channels x all pols.  Phase 1
+// walks the tile in INPUT order (lanes along the contiguous input axis:
+// 128-byte wave loads) and drops each 2-byte element into LDS at its OUTPUT
+// position [t][p][c]; the row pitch tc+2 elements (odd number of dwords) keeps
+// the strided writes off the same bank.  Phase 2 reads LDS linearly: a lane
+// takes one dword (two elements) and stores one float4, so output rows are
+// written in contiguous 16-byte pieces (512 B per 64-channel row).
+#pragma once
+#include "bb_common.h"
+
+struct bb_tiled_args {
+    const uint8_t *buf;
+    const int64_t *src;
+    float         *out;
+    uint64_t nframes;
+    uint64_t t_lo, t_hi;        // local time range decoded from every frame
+    uint64_t tb, sh, st, sp, sc;
+    int64_t  src0, src_stride;
+    uint32_t npol, nchan;
+    uint32_t tt, tc;            // tile: times, channels (tc even or == 1)
+    uint32_t ntt, nct;          // tiles per frame along time / channel
+    float    fill_re, fill_im;
+};
+
+template <int LAYOUT, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_i8_tiled(bb_tiled_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_tile[];
+    const uint32_t tcp = a.tc + 2;                      // padded row pitch (elements)
+    const uint32_t npol = a.npol, tc = a.tc, tt = a.tt;
+    const uint64_t rows_out = a.t_hi - a.t_lo;          // output rows per frame
+    const uint64_t rowlen = (uint64_t)npol * a.nchan * 2;   // floats per output time
+    const uint64_t nwork = a.nframes * a.ntt * a.nct;
+    const uint32_t tile_elems = tt * npol * tc;
+
+    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const uint64_t f = work / ((uint64_t)a.ntt * a.nct);
+        const uint32_t rem = (uint32_t)(work - f * a.ntt * a.nct);
+        const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
+        const uint64_t t0 = a.t_lo + (uint64_t)ti * tt;
+        const uint32_t nt_tile = (uint32_t)((a.t_hi - t0 < tt) ? a.t_hi - t0 : tt);
+        const uint32_t c0 = ci * tc;
+        const uint32_t nc_tile = (a.nchan - c0 < tc) ? a.nchan - c0 : tc;
+        const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
+        const bool valid = so >= 0;
+        const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
+
+        if (valid) {
+            // phase 1: input order -> LDS at output position
+            for (uint32_t i = threadIdx.x; i < tile_elems; i += BB_BLOCK) {
+                uint32_t tl, p, c;
+                if (LAYOUT == 0) {              // (c, t, p)
+                    c = i / (tt * npol);
+                    const uint32_t r = i - c * tt * npol;
+                    tl = r / npol; p = r - tl * npol;
+                } else if (LAYOUT == 1) {       // (p, c, t)
+                    p = i / (tc * tt);
+                    const uint32_t r = i - p * tc * tt;
+                    c = r / tt; tl = r - c * tt;
+                } else {                        // (t, c, p)
+                    tl = i / (tc * npol);
+                    const uint32_t r = i - tl * tc * npol;
+                    c = r / npol; p = r - c * npol;
+                }
+                if (tl < nt_tile && c < nc_tile) {
+                    const uint64_t t = t0 + tl;
+                    const uint64_t off = (t / a.tb) * a.sh + (t % a.tb) * a.st
+                                         + (uint64_t)p * a.sp + (uint64_t)(c0 + c) * a.sc;
+                    s_tile[(tl * npol + p) * tcp + c] = in[off];
+                }
+            }
+        }
+        __syncthreads();
+        // phase 2: LDS rows -> global, one dword (2 elements) -> one float4
+        const uint32_t pairs = (tc + 1) / 2;
+        const uint32_t nrows = nt_tile * npol;
+        float *obase = a.out + (f * rows_out + (t0 - a.t_lo)) * rowlen + (uint64_t)c0 * 2;
+        for (uint32_t j = threadIdx.x; j < nrows * pairs; j += BB_BLOCK) {
+            const uint32_t row = j / pairs;
+            const uint32_t c = (j - row * pairs) * 2;
+            if (c >= nc_tile) continue;
+            float *o = obase + (uint64_t)row * a.nchan * 2 + (uint64_t)c * 2;
+            float v0, v1, v2 = 0.f, v3 = 0.f;
+            const bool two = c + 1 < nc_tile;
+            if (valid) {
+                const uint32_t e0 = s_tile[row * tcp + c];
+                v0 = (float)(int)(int8_t)(e0 & 0xff);
+                v1 = (float)(int)(int8_t)(e0 >> 8);
+                if (two) {
+                    const uint32_t e1 = s_tile[row * tcp + c + 1];
+                    v2 = (float)(int)(int8_t)(e1 & 0xff);
+                    v3 = (float)(int)(int8_t)(e1 >> 8);
+                }
+            } else {
+                v0 = v2 = a.fill_re; v1 = v3 = a.fill_im;
+            }
+            if (two && (((uintptr_t)o & 15) == 0)) {
+                bb_store4<NT>(o, bb_f4{v0, v1, v2, v3});
+            } else {
+                bb_store1<NT>(o, v0); bb_store1<NT>(o + 1, v1);
+                if (two) { bb_store1<NT>(o + 2, v2); bb_store1<NT>(o + 3, v3); }
+            }
+        }
+        __syncthreads();
+    }
+}

@@ -1,0 +1,126 @@
+"""DADA file and stream readers, and ``open`` (dada/base.py:99-330)."""
+import io
+from math import gcd
+
+import numpy as np
+import torch
+
+from .. import _lib, kernels
+from ..base.base import VLBIFileReaderBase
+from ..base.blockreader import BlockStreamReader
+from .header import DADAHeader
+from .payload import DADAPayload, decode_i8_rows
+from .frame import DADAFrame
+
+__all__ = ['DADAFileReader', 'DADAStreamReader', 'open']
+
+
+class DADAFileReader(VLBIFileReaderBase):
+    def read_header(self):
+        return DADAHeader.fromfile(self.fh_raw)
+
+    def read_frame(self, memmap=True, verify=True):
+        return DADAFrame.fromfile(self.fh_raw, memmap=memmap, verify=verify)
+
+    def get_frame_rate(self):
+        with self.temporary_offset(0):
+            header = self.read_header()
+        return header.sample_rate / header.samples_per_frame
+
+
+class DADAStreamReader(BlockStreamReader):
+    """DADA stream -> device tensor (nsample, npol, nchan)."""
+
+    def __init__(self, fh_raw, squeeze=True, subset=(), verify=True):
+        fh_raw = DADAFileReader(fh_raw)
+        header0 = fh_raw.read_header()
+        super().__init__(
+            fh_raw, header0, sample_rate=header0.sample_rate,
+            samples_per_frame=header0.samples_per_frame,
+            unsliced_shape=header0.sample_shape, bps=header0.bps,
+            complex_data=header0.complex_data, squeeze=squeeze, subset=subset,
+            fill_value=0., verify=verify)
+        self._header_nbytes = header0.nbytes
+        self._frame_nbytes = header0.frame_nbytes
+        self._file_offset0 = 0
+        self._mkbf = header0.get('INSTRUMENT') == 'MKBF'
+        size = len(self._image())
+        # a truncated last frame counts down to whole payload blocks
+        # (dada/base.py:251-306)
+        nframes, partial = divmod(size, self._frame_nbytes)
+        self._row_nbytes = header0._sample_nbits // 8
+        self._last_rows = self.samples_per_frame
+        if partial > self._header_nbytes:
+            nframes += 1
+            block = 4 * self._row_nbytes // gcd(4, self._row_nbytes)
+            self._last_rows = ((partial - self._header_nbytes) // block * block
+                               // self._row_nbytes)
+            if nframes == 1:
+                self.samples_per_frame = self._last_rows
+        elif nframes == 0:
+            raise EOFError('file (of {0} bytes) appears to end without'
+                           'any payload.'.format(partial))
+        self._nframes = nframes
+        self._nsample = (nframes - 1) * header0.samples_per_frame + self._last_rows
+        self._spf0 = header0.samples_per_frame
+        self._start_time = header0.time
+
+    def _image(self):
+        return self.fh_raw.image()
+
+    def _frame_span(self, frame):
+        lo = frame * self._frame_nbytes
+        return lo, min(self._frame_nbytes, len(self._image()) - lo)
+
+    def _pieces(self, offset, count):
+        spf = self._spf0
+        pieces, done = [], 0
+        while done < count:
+            index, so = divmod(offset + done, spf)
+            rows = self._last_rows if index == self._nframes - 1 else spf
+            n = min(count - done, rows - so)
+            pieces.append((index, so, so + n))
+            done += n
+        return pieces
+
+    def _decode_window(self, dbuf, nframes, a, b, out_flat, payload_offset,
+                       frame_stride, first_frame):
+        if self.bps != 8:
+            raise KeyError(self.bps)
+        npol, nchan = self._unsliced_shape
+        if self._mkbf:
+            # a truncated last frame only holds `_last_rows` samples (whole heaps)
+            n_full = nframes
+            row = (b - a) * npol * nchan * 2
+            if first_frame + nframes == self._nframes and self._last_rows < self._spf0:
+                n_full -= 1
+                kernels.decode_i8_tiled(
+                    dbuf, 1, _lib.LAYOUT_MKBF, npol, nchan,
+                    self._last_rows // 256 * 256, a, b,
+                    src0=payload_offset + n_full * frame_stride,
+                    out=out_flat[n_full * row:])
+            if n_full:
+                kernels.decode_i8_tiled(dbuf, n_full, _lib.LAYOUT_MKBF, npol, nchan,
+                                        self._spf0, a, b, src0=payload_offset,
+                                        src_stride=frame_stride,
+                                        out=out_flat[:n_full * row])
+            return
+        n = (b - a) * self._row_nbytes
+        for i in range(nframes):
+            out_flat[i * n:(i + 1) * n] = decode_i8_rows(
+                dbuf, payload_offset + i * frame_stride, self._row_nbytes, a, b)
+
+
+def open(name, mode='rs', **kwargs):
+    if mode not in ('rb', 'rs'):
+        raise ValueError("only reading modes 'rb' and 'rs' are supported "
+                         "(got {!r}).".format(mode))
+    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
+    try:
+        if mode == 'rb':
+            return DADAFileReader(fh, **kwargs)
+        return DADAStreamReader(fh, **kwargs)
+    except Exception:
+        if fh is not name:
+            fh.close()
+        raise

@@ -1,0 +1,122 @@
+"""DADA payloads: int8 -> float32/complex64 on the GPU
+(dada/payload.py:21-89).  Standard payloads are already stored
+(time, pol, chan[, re/im]) and use the flat cast of ``bb_decode_frames``;
+MeerKAT beamformer (MKBF) heaps go through ``bb_decode_i8_tiled``."""
+import operator
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from .. import _lib, kernels
+from ..base.payload import PayloadBase
+
+__all__ = ['DADAPayload', 'MKBFPayload', 'decode_i8_rows']
+
+
+def decode_i8_rows(dbuf, byte0, row_nbytes, start, stop):
+    """Flat int8 -> float32 of rows [start, stop) (row = one complete sample)
+    located at byte0 in dbuf; handles starts/ends that are not dword aligned
+    by decoding the enclosing aligned range."""
+    b0 = byte0 + start * row_nbytes
+    b1 = byte0 + stop * row_nbytes
+    if b1 == b0:
+        return torch.empty(0, dtype=torch.float32, device=dbuf.device)
+    lo = b0 - b0 % 4
+    hi = -(-b1 // 4) * 4
+    if hi > dbuf.numel():
+        dbuf = torch.nn.functional.pad(dbuf, (0, hi - dbuf.numel()))
+    flat = kernels.decode_frames(dbuf, 1, hi - lo, _lib.CODER_INT, 8, src0=lo)
+    return flat[b0 - lo:b1 - lo]
+
+
+class DADAPayload(PayloadBase):
+    _memmap = True
+    _dtype_word = np.dtype('<u4')
+    _coder_id = _lib.CODER_INT
+    _sample_shape_maker = namedtuple('SampleShape', 'npol, nchan')
+
+    def __new__(cls, words, *, header=None, **kwargs):
+        if header is not None and header.get("INSTRUMENT") == "MKBF":
+            cls = MKBFPayload
+        return super().__new__(cls)
+
+    def __init__(self, words, *, header=None, sample_shape=(), bps=8,
+                 complex_data=False):
+        if words.dtype != self._dtype_word:
+            words = np.asarray(words).view(np.uint8)
+            self._dtype_word = words.dtype
+        super().__init__(words, header=header, sample_shape=sample_shape,
+                         bps=bps, complex_data=complex_data)
+
+    def _rows(self, start, stop):
+        if self.bps != 8:
+            raise KeyError(self.bps)
+        npol, nchan = self.sample_shape
+        row = npol * nchan * (2 if self.complex_data else 1)
+        flat = decode_i8_rows(self._device_words(), 0, row, start, stop)
+        if self.complex_data:
+            flat = torch.view_as_complex(flat.reshape(-1, 2))
+        return flat.reshape(stop - start, npol, nchan)
+
+    def __getitem__(self, item=()):
+        if isinstance(item, tuple):
+            sample_index = item[1:]
+            first = item[0] if item else slice(None)
+        else:
+            sample_index, first = (), item
+        nsample = len(self)
+        if isinstance(first, slice):
+            start, stop, step = first.indices(nsample)
+            assert step > 0, "cannot deal with negative steps yet."
+            data = self._rows(start, max(stop, start))[::step]
+            if sample_index:
+                data = data[(slice(None),) + sample_index]
+        else:
+            try:
+                first = operator.index(first)
+            except Exception:
+                raise TypeError("{0} object can only be indexed or sliced."
+                                .format(type(self)))
+            if first < 0:
+                first += nsample
+            if not (0 <= first < nsample):
+                raise IndexError("{0} index out of range.".format(type(self)))
+            data = self._rows(first, first + 1)[0]
+            if sample_index:
+                data = data[sample_index]
+        return data
+
+    data = property(__getitem__, doc="Full decoded payload (device tensor).")
+
+    @classmethod
+    def fromdata(cls, data, header=None, bps=8):
+        if isinstance(data, torch.Tensor):
+            data = data.cpu().numpy()
+        data = np.asarray(data)
+        if data.dtype.kind == 'c':
+            comp = np.ascontiguousarray(data.astype(np.complex64)).view(np.float32)
+        else:
+            comp = data.astype(np.float32)
+        b = np.clip(np.rint(comp), -128, 127).astype(np.int8)
+        if header is not None and header.get("INSTRUMENT") == "MKBF":
+            npol, nchan = header.sample_shape
+            b = np.moveaxis(b.reshape(-1, 256, npol, nchan, 2), 1, 3)
+        words = np.ascontiguousarray(b).reshape(-1).view(np.uint8)
+        if header is not None:
+            return cls(words, header=header)
+        return cls(words, sample_shape=data.shape[1:], bps=bps,
+                   complex_data=data.dtype.kind == 'c')
+
+
+class MKBFPayload(DADAPayload):
+    """Heaps of 256 samples stored (heap, pol, chan, 256, re/im)
+    (dada/payload.py:54-89)."""
+
+    def _rows(self, start, stop):
+        if self.bps != 8 or not self.complex_data:
+            raise KeyError(self.bps)
+        npol, nchan = self.sample_shape
+        flat = kernels.decode_i8_tiled(self._device_words(), 1, _lib.LAYOUT_MKBF,
+                                       npol, nchan, len(self), start, stop)
+        return torch.view_as_complex(flat.view(-1, 2)).reshape(stop - start, npol, nchan)

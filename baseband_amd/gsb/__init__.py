@@ -1,0 +1,7 @@
+"""GMRT GSB format: GPU-decoded reader with the reference's call shapes."""
+from .header import GSBHeader
+from .payload import GSBPayload
+from .frame import GSBFrame
+from .base import GSBStreamReader, open
+
+__all__ = ['GSBHeader', 'GSBPayload', 'GSBFrame', 'GSBStreamReader', 'open']

@@ -1,0 +1,107 @@
+"""GUPPI file and stream readers, and ``open`` (guppi/base.py:27-278)."""
+import io
+
+import numpy as np
+import torch
+
+from .. import _lib, kernels
+from ..base.base import VLBIFileReaderBase
+from ..base.blockreader import BlockStreamReader
+from .header import GUPPIHeader
+from .payload import GUPPIPayload
+from .frame import GUPPIFrame
+
+__all__ = ['GUPPIFileReader', 'GUPPIStreamReader', 'open']
+
+
+class GUPPIFileReader(VLBIFileReaderBase):
+    def read_header(self):
+        return GUPPIHeader.fromfile(self.fh_raw)
+
+    def read_frame(self, memmap=True, verify=True):
+        return GUPPIFrame.fromfile(self.fh_raw, memmap=memmap, verify=verify)
+
+    def get_frame_rate(self):
+        with self.temporary_offset(0):
+            header = self.read_header()
+        return header.sample_rate / (header.samples_per_frame - header.overlap)
+
+
+class GUPPIStreamReader(BlockStreamReader):
+    """GUPPI stream -> device tensor (nsample, npol, nchan)."""
+
+    def __init__(self, fh_raw, squeeze=True, subset=(), verify=True):
+        fh_raw = GUPPIFileReader(fh_raw)
+        header0 = fh_raw.read_header()
+        super().__init__(
+            fh_raw, header0, sample_rate=header0.sample_rate,
+            samples_per_frame=header0.samples_per_frame - header0.overlap,
+            unsliced_shape=header0.sample_shape, bps=header0.bps,
+            complex_data=header0.complex_data, squeeze=squeeze, subset=subset,
+            fill_value=0., verify=verify)
+        self._header_nbytes = header0.nbytes
+        self._frame_nbytes = header0.frame_nbytes
+        self._file_offset0 = 0
+        self._nframes = len(self._image()) // self._frame_nbytes
+        self._spf_full = header0.samples_per_frame
+        self._overlap = header0.overlap
+        self._nsample = self._nframes * self.samples_per_frame + self._overlap
+        self._start_time = header0.time
+
+    def _image(self):
+        return self.fh_raw.image()
+
+    def _pieces(self, offset, count):
+        """The reference loop: the frame a read starts in is taken up to its
+        END (overlap tail included); following frames are entered at their
+        sample OVERLAP (base/base.py:957-967; guppi/base.py:270-278)."""
+        keep, spf = self.samples_per_frame, self._spf_full
+        normal_end = self._nsample - self._overlap
+        pieces, done = [], 0
+        while done < count:
+            o = offset + done
+            if normal_end <= o < self._nsample:
+                index, so = divmod(normal_end - 1, keep)
+                so += 1 + o - normal_end
+            else:
+                index, so = divmod(o, keep)
+            n = min(count - done, spf - so)
+            pieces.append((index, so, so + n))
+            done += n
+        return pieces
+
+    def _decode_window(self, dbuf, nframes, a, b, out_flat, payload_offset,
+                       frame_stride, first_frame):
+        h = self.header0
+        if self.bps != 8:
+            raise KeyError(self.bps)
+        if not self.complex_data:
+            npol = h.npol
+            for i in range(nframes):
+                src = payload_offset + i * frame_stride
+                b0, b1 = a * npol, b * npol
+                lo, hi = b0 - b0 % 4, -(-b1 // 4) * 4
+                tmp = kernels.decode_frames(dbuf, 1, hi - lo, _lib.CODER_INT, 8,
+                                            src0=src + lo)
+                n = (b - a) * npol
+                out_flat[i * n:(i + 1) * n] = tmp[b0 - lo:b1 - lo]
+            return
+        layout = _lib.LAYOUT_GUPPI_CF if h.channels_first else _lib.LAYOUT_GUPPI_TF
+        kernels.decode_i8_tiled(dbuf, nframes, layout, h.npol, h.nchan,
+                                self._spf_full, a, b, src0=payload_offset,
+                                src_stride=frame_stride, out=out_flat)
+
+
+def open(name, mode='rs', **kwargs):
+    if mode not in ('rb', 'rs'):
+        raise ValueError("only reading modes 'rb' and 'rs' are supported "
+                         "(got {!r}).".format(mode))
+    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
+    try:
+        if mode == 'rb':
+            return GUPPIFileReader(fh, **kwargs)
+        return GUPPIStreamReader(fh, **kwargs)
+    except Exception:
+        if fh is not name:
+            fh.close()
+        raise

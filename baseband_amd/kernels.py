@@ -163,5 +163,30 @@ def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
     return out
 
 
+def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
+                    src=None, src0=0, src_stride=0, fill_value=0., out=None):
+    """int8 (re, im) -> complex64 with the (time, pol, chan) permutation of
+    `layout`; rows [t_lo, t_hi) of every frame -> flat float32 tensor."""
+    p = _lib.TiledParams()
+    p.layout = layout
+    p.npol = npol
+    p.nchan = nchan
+    p.ntime = ntime
+    p.t_lo = t_lo
+    p.t_hi = t_hi
+    p.src0 = src0
+    p.src_stride = src_stride
+    fv = complex(fill_value)
+    p.fill_re = fv.real
+    p.fill_im = fv.imag
+    nelem = nframes * (t_hi - t_lo) * npol * nchan * 2
+    if out is None:
+        out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
+    check(lib.bb_decode_i8_tiled(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
+                                 C.byref(p), _ptr(out), out.numel(), _stream()),
+          'bb_decode_i8_tiled')
+    return out
+
+
 def tune(knob, value):
     check(lib.bb_tune(knob, value), 'bb_tune')

@@ -251,6 +251,47 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
                     const bb_mark4_decode_params *params,
                     float *d_out, size_t out_elems, void *stream);
 
+/* ---- byte-aligned formats with an axis permutation --------------------- */
+
+/*
+ * int8 (re, im) -> complex64 decode with the axis permutation of
+ *   BB_LAYOUT_GUPPI_CF  GUPPI channels-first payloads, (chan, time, pol) ->
+ *                       (time, pol, chan)            (guppi/payload.py:90-96)
+ *   BB_LAYOUT_MKBF      MeerKAT beamformer DADA heaps, (heap, pol, chan, 256)
+ *                       -> (heap*256, pol, chan)     (dada/payload.py:54-89)
+ *   BB_LAYOUT_GUPPI_TF  GUPPI time-first ('SIMPLE') payloads, (time, chan, pol)
+ *                       -> (time, pol, chan)         (guppi/payload.py:97-102)
+ * (G1 and D1 of SURVEY.md section 8a).  From every frame only times
+ * [t_lo, t_hi) are decoded -- this is how the GUPPI OVERLAP is dropped
+ * (guppi/base.py:203-225) and how partial reads avoid touching whole blocks.
+ * Output: frame f, time t, pol p, chan c at
+ *   d_out[(((f*(t_hi-t_lo) + t-t_lo)*npol + p)*nchan + c)*2 + {0,1}].
+ * Real-valued byte data needs no permutation and goes through
+ * bb_decode_frames(BB_CODER_INT, 8).
+ */
+enum bb_layout {
+    BB_LAYOUT_GUPPI_CF = 0,
+    BB_LAYOUT_MKBF     = 1,
+    BB_LAYOUT_GUPPI_TF = 2
+};
+
+typedef struct bb_tiled_params {
+    int32_t  layout;          /* enum bb_layout */
+    int32_t  npol;
+    int32_t  nchan;
+    int32_t  reserved;
+    uint64_t ntime;           /* complete samples stored per frame */
+    uint64_t t_lo, t_hi;      /* local sample range to decode, t_hi <= ntime */
+    int64_t  src0;            /* payload offsets when d_src == NULL */
+    int64_t  src_stride;
+    float    fill_re, fill_im;
+} bb_tiled_params;
+
+int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
+                       const int64_t *d_src, size_t nframes,
+                       const bb_tiled_params *params,
+                       float *d_out, size_t out_elems, void *stream);
+
 /* ---- tuning knobs (performance experiments; results never change) ------ */
 #define BB_TUNE_FLAT_VARIANT   0   /* kernel variant of the flat decode */
 #define BB_TUNE_NT_STORES      1   /* 1 = non-temporal stores */

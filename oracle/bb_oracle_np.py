@@ -573,3 +573,212 @@ def mark4_read(raw, ntrack, frame_rate=None, fill_value=0.):
         else:
             rows[nfill:] = fill_value
     return out, info
+
+
+# --------------------------------------------------------------------------
+# GUPPI (guppi/header.py:105-143,216-352; payload.py:13-14,52-110;
+#        base.py:196-225,270-278)
+# --------------------------------------------------------------------------
+def _fits_value(text):
+    text = text.split('/')[0].strip() if not text.strip().startswith("'") else text.strip()
+    if text.startswith("'"):
+        return text[1:text.index("'", 1)].rstrip()
+    if text in ('T', 'F'):
+        return text == 'T'
+    try:
+        return int(text)
+    except ValueError:
+        try:
+            return float(text)
+        except ValueError:
+            return text
+
+
+def guppi_parse_header(buf, offset=0):
+    """80-character cards up to END (guppi/header.py:105-143); returns
+    (dict, header_nbytes) with DIRECTIO padding to 512 (guppi/header.py:216-224)."""
+    cards, pos = {}, offset
+    ncards = 0
+    while True:
+        line = bytes(buf[pos:pos + 80]).decode('ascii')
+        if line == '':
+            raise EOFError
+        pos += 80
+        ncards += 1
+        if line[:3] == 'END':
+            break
+        if line[8] == '=':
+            cards[line[:8].strip()] = _fits_value(line[9:])
+    nbytes = ncards * 80
+    if int(cards.get('DIRECTIO', 0)) and nbytes % 512:
+        nbytes += 512 - nbytes % 512
+    return cards, nbytes
+
+
+def guppi_geometry(h):
+    nchan = int(h['OBSNCHAN'])
+    cplx = nchan != 1                                   # guppi/header.py:254-256
+    npol = int(h['NPOL']) // (2 if cplx else 1)         # :259-261
+    bps = int(h['NBITS'])
+    bpcs = nchan * int(h['NPOL']) * bps                 # :287-289
+    spf = int(h['BLOCSIZE']) * 8 // bpcs                # :326-328
+    return dict(nchan=nchan, complex_data=cplx, npol=npol, bps=bps,
+                samples_per_frame=spf, overlap=int(h.get('OVERLAP', 0)),
+                channels_first=h.get('PKTFMT', '1SFA') != 'SIMPLE',
+                payload_nbytes=int(h['BLOCSIZE']))
+
+
+def guppi_payload_data(words, g):
+    """Whole-payload decode (guppi/payload.py:90-102): int8 -> float32 ->
+    complex, then (chan, time, pol) or (time, chan, pol) -> (time, pol, chan)."""
+    d = np.asarray(words).view(np.int8).astype(np.float32)
+    if g['complex_data']:
+        d = d.view(np.complex64)
+    if g['channels_first']:
+        return d.reshape(g['nchan'], -1).T.reshape(-1, g['npol'], g['nchan'])
+    return d.reshape(-1, g['nchan'], g['npol']).transpose(0, 2, 1)
+
+
+def guppi_read(raw, offset=0, count=None):
+    """Reference-as-written GUPPI stream read of `count` samples from sample
+    `offset` (guppi/base.py:203-206,270-278 + the loop of base/base.py:957-967).
+
+    The stream advances by spf - OVERLAP samples per frame, but each loop
+    iteration takes everything up to the END of the frame it is in (overlap
+    tail included), so inside one read() the overlap samples come from the
+    earlier frame and the next frame is entered at its sample OVERLAP."""
+    buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    h0, hn = guppi_parse_header(buf)
+    g = guppi_geometry(h0)
+    fn = hn + g['payload_nbytes']
+    nframes = len(buf) // fn
+    spf = g['samples_per_frame']
+    keep = spf - g['overlap']
+    nsample = nframes * keep + g['overlap']
+    if count is None:
+        count = nsample - offset
+    assert offset + count <= nsample
+    normal_end = nsample - g['overlap']
+    parts, done = [], 0
+    cache = {}
+    while done < count:
+        o = offset + done
+        if normal_end <= o < nsample:                   # guppi/base.py:270-278
+            index, so = divmod(normal_end - 1, keep)
+            so += 1 + o - normal_end
+        else:
+            index, so = divmod(o, keep)
+        if index not in cache:
+            fo = index * fn
+            _, hni = guppi_parse_header(buf, fo)
+            cache = {index: guppi_payload_data(
+                buf[fo + hni:fo + hni + g['payload_nbytes']], g)}
+        n = min(count - done, spf - so)
+        parts.append(cache[index][so:so + n])
+        done += n
+    shape = (0, g['npol'], g['nchan'])
+    out = (np.ascontiguousarray(np.concatenate(parts)) if parts
+           else np.empty(shape, np.complex64 if g['complex_data'] else np.float32))
+    return out, dict(header0=h0, header_nbytes=hn, frame_nbytes=fn,
+                     nframes=nframes, nsample=nsample, **g)
+
+
+# --------------------------------------------------------------------------
+# DADA (dada/header.py:117-136,161-200,289-382; payload.py:13-14,54-89;
+#       base.py:251-330)
+# --------------------------------------------------------------------------
+def dada_parse_header(buf, offset=0):
+    """ASCII 'KEY VALUE' lines; default size 4096, HDR_SIZE overrides."""
+    hdr_size, pos, h = 4096, offset, {}
+    text = bytes(buf[offset:offset + 65536])
+    lines = []
+    rel = 0
+    while rel < hdr_size and text[rel:rel + 1] != b'\x00':
+        end = text.index(b'\n', rel) + 1
+        line = text[rel:end].decode('ascii')
+        rel = end
+        if line[0] == '#' and 'end of header' in line:
+            break
+        if line.startswith('HDR_SIZE'):
+            hdr_size = int(line.split()[1])
+        lines.append(line)
+    for line in lines:
+        split = line.strip().split('#')[0].strip().split()
+        if len(split) < 2:
+            continue
+        key, value = split[0], split[1]
+        if key in ('FILE_SIZE', 'FILE_NUMBER', 'HDR_SIZE', 'OBS_OFFSET',
+                   'OBS_OVERLAP', 'NBIT', 'NDIM', 'NPOL', 'NCHAN',
+                   'RESOLUTION', 'DSB'):
+            value = int(value)
+        elif key in ('FREQ', 'BW', 'TSAMP'):
+            value = float(value)
+        h[key] = value
+    h.setdefault('HDR_SIZE', hdr_size)
+    return h
+
+
+def dada_payload_data(words, h):
+    """int8 -> float32 (-> complex); MKBF heaps (heap, pol, chan, 256) ->
+    (heap*256, pol, chan) (dada/payload.py:76-79)."""
+    npol, nchan, ndim = h['NPOL'], h['NCHAN'], h['NDIM']
+    d = np.asarray(words).view(np.int8)
+    if h.get('INSTRUMENT') == 'MKBF':
+        d = np.moveaxis(d.reshape(-1, npol, nchan, 256, ndim), 3, 1)
+    d = np.ascontiguousarray(d).astype(np.float32)
+    if ndim == 2:
+        d = d.view(np.complex64)
+    return d.reshape(-1, npol, nchan)
+
+
+def dada_read(raw):
+    """Frames of HDR_SIZE + FILE_SIZE bytes; a truncated last frame is cut
+    to whole payload blocks (dada/base.py:251-306)."""
+    buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    h0 = dada_parse_header(buf)
+    hn, pn = h0['HDR_SIZE'], h0['FILE_SIZE']
+    fn = hn + pn
+    nframes, partial = divmod(len(buf), fn)
+    sample_nbytes = h0['NBIT'] * h0['NDIM'] * h0['NPOL'] * h0['NCHAN'] // 8
+    block = np.lcm(4, sample_nbytes)
+    parts = []
+    for i in range(nframes):
+        parts.append(dada_payload_data(buf[i * fn + hn:(i + 1) * fn], h0))
+    if partial > hn:
+        n = (partial - hn) // block * block
+        o = nframes * fn + hn
+        parts.append(dada_payload_data(buf[o:o + n], h0))
+    out = np.ascontiguousarray(np.concatenate(parts))
+    return out, dict(header0=h0, nframes=len(parts))
+
+
+# --------------------------------------------------------------------------
+# GSB (gsb/payload.py:24-42,88-131; gsb/base.py:146-201,373-387)
+# --------------------------------------------------------------------------
+def gsb_read_rawdump(raw, nframes, payload_nbytes, bps=4, nchan=1):
+    """Headerless blocks; 4-bit signed nibbles, low nibble first."""
+    buf = np.frombuffer(raw, dtype=np.uint8) if not isinstance(raw, np.ndarray) else raw
+    out = [decode_flat(buf[i * payload_nbytes:(i + 1) * payload_nbytes], 'int', bps)
+           .reshape(-1, nchan) for i in range(nframes)]
+    return np.concatenate(out)
+
+
+def gsb_read_phased(files, nframes, payload_nbytes, nchan=512, bps=8,
+                    complex_data=True):
+    """`files[p][f]`: F consecutive-in-time parts for each polarisation p;
+    a frame is (F, n, P, sample_nbytes) words (gsb/payload.py:115-131)."""
+    P, F = len(files), len(files[0])
+    sample_nbytes = bps * nchan * (2 if complex_data else 1) // 8
+    n = payload_nbytes // sample_nbytes
+    out = []
+    for i in range(nframes):
+        words = np.empty((F, n, P, sample_nbytes), np.uint8)
+        for p in range(P):
+            for f in range(F):
+                b = np.asarray(files[p][f])[i * payload_nbytes:(i + 1) * payload_nbytes]
+                words[f, :, p, :] = b.reshape(-1, sample_nbytes)
+        d = decode_flat(words.ravel(), 'int', bps)
+        if complex_data:
+            d = d.view(np.complex64)
+        out.append(d.reshape(-1, P, nchan))
+    return np.concatenate(out)

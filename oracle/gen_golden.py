@@ -445,13 +445,190 @@ def gen_mark4_synth():
         print('mark4 synth', name, back.shape, 'oracle == reference')
 
 
+def gen_guppi():
+    rel = copy_sample(SAMPLE_PUPPI)
+    raw = np.fromfile(SAMPLE_PUPPI, dtype=np.uint8)
+    with guppi.open(SAMPLE_PUPPI, 'rs', squeeze=False) as fh:
+        data = fh.read()
+        info = dict(file=rel, samples_per_frame=int(fh.samples_per_frame),
+                    overlap=int(fh.header0.overlap),
+                    sample_rate_hz=float(fh.sample_rate.to_value(u.Hz)),
+                    start_time=fh.start_time.isot, stop_time=fh.stop_time.isot,
+                    header_nbytes=int(fh.header0.nbytes),
+                    payload_nbytes=int(fh.header0.payload_nbytes),
+                    channels_first=bool(fh.header0.channels_first))
+        reads = []
+        for off, cnt in ((0, 100), (900, 200), (960, 64), (1000, 1000), (3000, 904),
+                         (3840, 64), (3850, 10), (1919, 3)):
+            fh.seek(off)
+            reads.append([off, cnt, sha(fh.read(cnt))])
+        info['reads'] = reads
+    save_expected('sample_puppi', data, **info)
+    out, _ = orc.guppi_read(raw)
+    assert np.array_equal(out.view(np.uint32), data.view(np.uint32))
+    for off, cnt, digest in reads:
+        o, _ = orc.guppi_read(raw, off, cnt)
+        assert sha(o) == digest, (off, cnt)
+    print('guppi sample', data.shape, 'oracle == reference (incl. partial reads)')
+
+    t0 = Time('2018-01-01T00:00:00', precision=9)
+    for name, nchan, npol, spf, overlap, nframes, cf, seed in (
+            ('guppi_cf_c64_ov0', 64, 2, 512, 0, 3, True, 61),
+            ('guppi_cf_c64_ov32', 64, 2, 512, 32, 3, True, 62),
+            ('guppi_tf_c8_ov16', 8, 2, 256, 16, 4, False, 63),
+            ('guppi_cf_c6_p1', 6, 1, 128, 8, 3, True, 64),
+            ('guppi_real_c1', 1, 2, 1024, 0, 2, True, 65)):
+        rng = np.random.default_rng(seed)
+        cplx = nchan != 1
+        n = (spf - overlap) * nframes + overlap
+        shape = (n, npol, nchan)
+        if cplx:
+            data = (rng.integers(-128, 128, size=shape) + 1j * rng.integers(-128, 128, size=shape)).astype(np.complex64)
+        else:
+            data = rng.integers(-128, 128, size=shape).astype(np.float32)
+        tmpf = os.path.join(tempfile.mkdtemp(), 'f.raw')
+        # the stream writer refuses OVERLAP != 0, so write frame by frame:
+        # frame i holds stream samples [i*keep, i*keep + spf)
+        keep = spf - overlap
+        bpcs = nchan * npol * (2 if cplx else 1)          # bytes per complete sample
+        header0 = guppi.GUPPIHeader.fromvalues(
+            time=t0, sample_rate=1 * u.MHz, samples_per_frame=spf, overlap=overlap,
+            npol=npol, nchan=nchan, pktsize=keep * bpcs // 4, bps=8,
+            pktfmt=('1SFA' if cf else 'SIMPLE'))
+        assert header0.channels_first == cf
+        ppf = (header0.payload_nbytes - overlap * bpcs) // header0['PKTSIZE']
+        with guppi.open(tmpf, 'wb') as fw:
+            for i in range(nframes):
+                h = header0.copy()
+                h.update(pktidx=header0['PKTIDX'] + i * ppf)
+                fw.write_frame(data[i * keep:i * keep + spf], h)
+        with open(tmpf, 'rb') as ftmp:
+            blob = ftmp.read()
+        with guppi.open(tmpf, 'rs', squeeze=False) as fr:
+            back = fr.read()
+            reads = []
+            for off, cnt in ((0, 10), (spf - overlap - 3, 2 * spf), (spf - overlap, overlap + 5),
+                             (n - overlap - 2, overlap + 2), (n - 1, 1)):
+                cnt = min(cnt, n - off)
+                fr.seek(off)
+                reads.append([off, cnt, sha(fr.read(cnt))])
+            hn = int(fr.header0.nbytes)
+        assert np.array_equal(back.view(np.uint32), data.view(np.uint32)), name
+        write_synth(name, blob, back, nchan=nchan, npol=npol, samples_per_frame=spf - overlap,
+                    overlap=overlap, nframes=nframes, channels_first=cf, seed=seed,
+                    header_nbytes=hn, reads=reads)
+        out, _ = orc.guppi_read(np.frombuffer(blob, np.uint8))
+        assert np.array_equal(out.view(np.uint32), back.view(np.uint32)), name
+        for off, cnt, digest in reads:
+            o, _ = orc.guppi_read(np.frombuffer(blob, np.uint8), off, cnt)
+            assert sha(o) == digest, (name, off, cnt)
+        print('guppi synth', name, back.shape, back.dtype, 'oracle == reference')
+
+
+def gen_dada():
+    for name, path in (('sample_dada', SAMPLE_DADA), ('sample_meerkat_dada', SAMPLE_MEERKAT_DADA),
+                       ('sample_mkbf_dada', SAMPLE_MKBF_DADA)):
+        rel = copy_sample(path)
+        with dada.open(path, 'rs', squeeze=False) as fh:
+            data = fh.read()
+            info = dict(file=rel, samples_per_frame=int(fh.samples_per_frame),
+                        sample_rate_hz=float(fh.sample_rate.to_value(u.Hz)),
+                        start_time=fh.start_time.isot, stop_time=fh.stop_time.isot,
+                        header_nbytes=int(fh.header0.nbytes))
+            reads = []
+            n = data.shape[0]
+            for off, cnt in ((0, 3), (1, 250), (255, 2), (n - 7, 7), (n // 2 + 1, 300)):
+                cnt = min(cnt, n - off)
+                fh.seek(off)
+                reads.append([off, cnt, sha(fh.read(cnt))])
+            info['reads'] = reads
+        save_expected(name, data, **info)
+        out, _ = orc.dada_read(np.fromfile(path, dtype=np.uint8))
+        assert np.array_equal(out.view(np.uint32), data.view(np.uint32)), name
+        for off, cnt, digest in reads:
+            assert sha(out[off:off + cnt]) == digest
+        print('dada sample', name, data.shape, data.dtype, 'oracle == reference')
+    # synthetic: several frames in one file, last one truncated
+    t0 = Time('2018-01-01T00:00:00', precision=9)
+    for name, npol, nchan, cplx, spf, nframes, cut, seed in (
+            ('dada_p2_c4_cplx', 2, 4, True, 1000, 3, 1234, 71),
+            ('dada_p1_c1_real', 1, 1, False, 4096, 2, 0, 72),
+            ('dada_p2_c3_real', 2, 3, False, 500, 3, 77, 73)):
+        rng = np.random.default_rng(seed)
+        shape = (spf * nframes, npol, nchan)
+        if cplx:
+            data = (rng.integers(-128, 128, size=shape) + 1j * rng.integers(-128, 128, size=shape)).astype(np.complex64)
+        else:
+            data = rng.integers(-128, 128, size=shape).astype(np.float32)
+        tmpf = os.path.join(tempfile.mkdtemp(), 'f.dada')
+        header0 = dada.DADAHeader.fromvalues(
+            time=t0, sample_rate=1 * u.MHz, samples_per_frame=spf, npol=npol,
+            nchan=nchan, bps=8, complex_data=cplx)
+        with dada.open(tmpf, 'wb') as fw:
+            for i in range(nframes):
+                h = header0.copy()
+                h.update(offset=i * spf / (1 * u.MHz))
+                fw.write_frame(data[i * spf:(i + 1) * spf], h)
+        with open(tmpf, 'rb') as ftmp:
+            blob = ftmp.read()
+        if cut:
+            blob = blob[:-cut]
+        tmpf = os.path.join(tempfile.mkdtemp(), 'all.dada')
+        with open(tmpf, 'wb') as ftmp:
+            ftmp.write(blob)
+        with dada.open(tmpf, 'rs', squeeze=False) as fr:
+            back = fr.read()
+        assert np.array_equal(back.view(np.uint32), data[:back.shape[0]].view(np.uint32)), name
+        write_synth(name, blob, back, npol=npol, nchan=nchan, complex_data=cplx,
+                    samples_per_frame=spf, nframes=nframes, cut=cut, seed=seed)
+        out, _ = orc.dada_read(np.frombuffer(blob, np.uint8))
+        assert np.array_equal(out.view(np.uint32), back.view(np.uint32)), name
+        print('dada synth', name, back.shape, back.dtype, 'oracle == reference')
+
+
+def gen_gsb():
+    rel_ts = copy_sample(SAMPLE_GSB_RAWDUMP_HEADER, 'gsb')
+    rel = copy_sample(SAMPLE_GSB_RAWDUMP, 'gsb')
+    with gsb.open(SAMPLE_GSB_RAWDUMP_HEADER, 'rs', raw=SAMPLE_GSB_RAWDUMP,
+                  samples_per_frame=8192, squeeze=False) as fh:
+        data = fh.read()
+        info = dict(file=rel, timestamp=rel_ts, samples_per_frame=8192,
+                    payload_nbytes=int(fh.payload_nbytes), bps=int(fh.bps),
+                    sample_rate_hz=float(fh.sample_rate.to_value(u.Hz)),
+                    start_time=fh.start_time.isot, stop_time=fh.stop_time.isot)
+    save_expected('sample_gsb_rawdump', data, **info)
+    out = orc.gsb_read_rawdump(np.fromfile(SAMPLE_GSB_RAWDUMP, np.uint8), 10, info['payload_nbytes'])
+    assert np.array_equal(out.view(np.uint32), data.view(np.uint32))
+    print('gsb rawdump', data.shape, 'oracle == reference')
+    rel_ts = copy_sample(SAMPLE_GSB_PHASED_HEADER, 'gsb')
+    rels = [[copy_sample(f, 'gsb') for f in pol] for pol in SAMPLE_GSB_PHASED]
+    with gsb.open(SAMPLE_GSB_PHASED_HEADER, 'rs', raw=SAMPLE_GSB_PHASED,
+                  samples_per_frame=8, squeeze=False) as fh:
+        data = fh.read()
+        info = dict(files=rels, timestamp=rel_ts, samples_per_frame=8,
+                    payload_nbytes=int(fh.payload_nbytes), bps=int(fh.bps), nchan=512,
+                    sample_rate_hz=float(fh.sample_rate.to_value(u.Hz)),
+                    start_time=fh.start_time.isot, stop_time=fh.stop_time.isot)
+        reads = []
+        for off, cnt in ((0, 5), (3, 9), (7, 2), (70, 10), (37, 1)):
+            fh.seek(off)
+            reads.append([off, cnt, sha(fh.read(cnt))])
+        info['reads'] = reads
+    save_expected('sample_gsb_phased', data, **info)
+    files = [[np.fromfile(f, np.uint8) for f in pol] for pol in SAMPLE_GSB_PHASED]
+    out = orc.gsb_read_phased(files, 10, info['payload_nbytes'])
+    assert np.array_equal(out.view(np.uint32), data.view(np.uint32))
+    print('gsb phased', data.shape, 'oracle == reference')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
     steps = [('levels', gen_levels), ('vdif_samples', gen_vdif_samples),
              ('mark5b_sample', gen_mark5b_sample), ('vdif_synth', gen_vdif_synth),
              ('vdif_invalid', gen_vdif_invalid), ('mark5b_synth', gen_mark5b_synth),
              ('mark4_bitmaps', gen_mark4_bitmaps), ('mark4_samples', gen_mark4_samples),
-             ('mark4_synth', gen_mark4_synth)]
+             ('mark4_synth', gen_mark4_synth), ('guppi', gen_guppi), ('dada', gen_dada),
+             ('gsb', gen_gsb)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

@@ -1,0 +1,193 @@
+"""GUPPI, DADA (incl. MKBF) and GSB through the drop-in API on the GPU,
+bit-exact vs the reference's outputs."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import bb_oracle_np as orc
+from conftest import golden_path, load_expected, load_file, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+GUPPI_CASES = ['sample_puppi', 'guppi_cf_c64_ov0', 'guppi_cf_c64_ov32',
+               'guppi_tf_c8_ov16', 'guppi_cf_c6_p1', 'guppi_real_c1']
+DADA_CASES = ['sample_dada', 'sample_meerkat_dada', 'sample_mkbf_dada',
+              'dada_p2_c4_cplx', 'dada_p1_c1_real', 'dada_p2_c3_real']
+
+
+def _sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize('name', GUPPI_CASES)
+def test_guppi_stream(manifest, name):
+    from baseband_amd import guppi
+    case = manifest[name]
+    exp = load_expected(name)
+    with guppi.open(golden_path(case['file']), 'rs', squeeze=False) as fh:
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        for off, cnt, digest in case['reads']:      # overlap rules of the reference loop
+            fh.seek(off)
+            assert _sha(fh.read(cnt)) == digest, (off, cnt)
+        fh.seek(0)
+        with pytest.raises(EOFError):
+            fh.read(exp.shape[0] + 1)
+    with guppi.open(golden_path(case['file']), 'rs') as fh:
+        got = fh.read(7).cpu().numpy()
+        want = exp[:7].reshape((7,) + tuple(s for s in exp.shape[1:] if s > 1))
+        assert bits_equal(got, np.ascontiguousarray(want))
+
+
+def test_guppi_known_answers_and_subset(manifest):
+    """guppi/tests/test_guppi.py:236-249,504-510."""
+    from baseband_amd import guppi
+    exp = load_expected('sample_puppi')
+    with guppi.open(golden_path('samples/sample_puppi.raw'), 'rs', subset=(0, [1, 3])) as fh:
+        assert fh.sample_shape == (2,)
+        got = fh.read(3).cpu().numpy()
+    assert bits_equal(got, np.ascontiguousarray(exp[:3, 0][:, [1, 3]]))
+    assert exp[0, 0, 0] == -7 + 12j
+
+
+@pytest.mark.parametrize('name', ['sample_puppi', 'guppi_tf_c8_ov16', 'guppi_cf_c6_p1', 'guppi_real_c1'])
+@pytest.mark.parametrize('item', [(), 0, -1, slice(3, 17), slice(5, None, 4),
+                                  (slice(2, 9), 0), (4, slice(None), 0)])
+def test_guppi_payload_items(manifest, name, item):
+    from baseband_amd import guppi
+    case = manifest[name]
+    raw = load_file(case['file'])
+    h, hn = orc.guppi_parse_header(raw)
+    g = orc.guppi_geometry(h)
+    full = orc.guppi_payload_data(raw[hn:hn + g['payload_nbytes']], g)
+    with guppi.open(golden_path(case['file']), 'rb') as fb:
+        frame = fb.read_frame()
+    assert frame.shape == full.shape
+    got = frame.payload[item].cpu().numpy()
+    want = full[item]
+    assert got.shape == np.shape(want)
+    assert bits_equal(np.ascontiguousarray(got).reshape(-1), np.ascontiguousarray(want).reshape(-1))
+    if item == ():
+        assert bits_equal(frame.data.cpu().numpy(), np.ascontiguousarray(full))
+
+
+def test_tiled_kernel_raw_layouts():
+    """bb_decode_i8_tiled vs NumPy transposes for all three layouts, odd
+    channel counts, partial time ranges and several frames."""
+    import torch
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(3)
+    for layout, npol, nchan, T in ((0, 2, 64, 300), (0, 1, 5, 77), (0, 2, 200, 40),
+                                   (1, 2, 32, 512), (1, 1, 3, 256), (2, 2, 8, 100),
+                                   (2, 4, 7, 33), (0, 2, 1, 50)):
+        nfr = 3
+        pn = T * npol * nchan * 2
+        raw = rng.integers(0, 256, size=(nfr, pn + 16), dtype=np.uint8)
+        b = raw[:, 16:].view(np.int8)
+        if layout == 0:
+            ref = b.reshape(nfr, nchan, T, npol, 2).transpose(0, 2, 3, 1, 4)
+        elif layout == 1:
+            ref = b.reshape(nfr, T // 256, npol, nchan, 256, 2).transpose(0, 1, 4, 2, 3, 5) \
+                .reshape(nfr, T, npol, nchan, 2)
+        else:
+            ref = b.reshape(nfr, T, nchan, npol, 2).transpose(0, 1, 3, 2, 4)
+        ref = np.ascontiguousarray(ref).astype(np.float32)
+        dbuf = kernels.to_device_bytes(raw.reshape(-1))
+        for lo, hi in ((0, T), (3, T - 5), (T // 2, T // 2 + 1)):
+            out = kernels.decode_i8_tiled(dbuf, nfr, layout, npol, nchan, T, lo, hi,
+                                          src0=16, src_stride=pn + 16).cpu().numpy()
+            want = ref[:, lo:hi].reshape(-1)
+            assert bits_equal(out, np.ascontiguousarray(want)), (layout, npol, nchan, T, lo, hi)
+    # missing frame -> fill
+    src = torch.tensor([16, -1], dtype=torch.int64, device='cuda')
+    out = kernels.decode_i8_tiled(dbuf, 2, 0, 2, 1, 50, 0, 50, src=src,
+                                  fill_value=3 - 4j).cpu().numpy().reshape(2, -1, 2)
+    assert np.all(out[1] == np.array([3., -4.], np.float32))
+
+
+@pytest.mark.parametrize('name', DADA_CASES)
+def test_dada_stream(manifest, name):
+    from baseband_amd import dada
+    case = manifest[name]
+    exp = load_expected(name)
+    with dada.open(golden_path(case['file']), 'rs', squeeze=False) as fh:
+        assert fh.shape == exp.shape
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        n = exp.shape[0]
+        for off, cnt in ((0, 3), (1, 250), (255, 2), (n - 7, 7), (n // 2 + 1, min(300, n - n // 2 - 1))):
+            cnt = min(cnt, n - off)
+            fh.seek(off)
+            assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(exp[off:off + cnt])), (off, cnt)
+        for off, cnt, digest in case.get('reads', []):
+            fh.seek(off)
+            assert _sha(fh.read(cnt)) == digest
+
+
+def test_dada_known_answers_and_frame(manifest):
+    """dada/tests/test_dada.py:180-183 (first rows), :828-841 (MKBF layout)."""
+    from baseband_amd import dada
+    exp = load_expected('sample_dada')
+    with dada.open(golden_path('samples/sample.dada'), 'rb') as fb:
+        frame = fb.read_frame()
+        assert frame.shape == (16000, 2, 1)
+        assert bits_equal(frame[:3].cpu().numpy(), np.ascontiguousarray(exp[:3]))
+        assert bits_equal(frame.payload[100:110, 1].cpu().numpy(), np.ascontiguousarray(exp[100:110, 1]))
+        assert bits_equal(frame.data.cpu().numpy(), exp)
+    expm = load_expected('sample_mkbf_dada')
+    # the sample is cut short of the header's FILE_SIZE: build the payload
+    # from the bytes that are there (one heap of 256 samples)
+    from baseband_amd.dada import DADAHeader, DADAPayload
+    with open(golden_path('samples/sample_mkbf.dada'), 'rb') as f:
+        header = DADAHeader.fromfile(f)
+        words = np.frombuffer(f.read(), np.uint8)
+    h = header.copy()
+    h.payload_nbytes = len(words)
+    pl = DADAPayload(words.view('<u4'), header=h)
+    assert type(pl).__name__ == 'MKBFPayload' and pl.shape == (256, 2, 1024)
+    assert bits_equal(pl[5:200:3, 1, 10:20].cpu().numpy(),
+                      np.ascontiguousarray(expm[5:200:3, 1, 10:20]))
+    with dada.open(golden_path('samples/sample_mkbf.dada'), 'rs', subset=(1, slice(100, 104))) as fh:
+        fh.seek(250)
+        assert bits_equal(fh.read(6).cpu().numpy(), np.ascontiguousarray(expm[250:256, 1, 100:104]))
+
+
+def test_gsb_streams(manifest):
+    from baseband_amd import gsb
+    case = manifest['sample_gsb_rawdump']
+    exp = load_expected('sample_gsb_rawdump')
+    with gsb.open(golden_path(case['timestamp']), 'rs', raw=golden_path(case['file']),
+                  samples_per_frame=8192, squeeze=False) as fh:
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        fh.seek(8190)
+        assert bits_equal(fh.read(5).cpu().numpy(), exp[8190:8195])
+    # gsb/tests/test_gsb.py:257-259: first values of the rawdump sample
+    case = manifest['sample_gsb_phased']
+    exp = load_expected('sample_gsb_phased')
+    raw = [[golden_path(f) for f in pol] for pol in case['files']]
+    with gsb.open(golden_path(case['timestamp']), 'rs', raw=raw, samples_per_frame=8,
+                  squeeze=False) as fh:
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        for off, cnt, digest in case['reads']:
+            fh.seek(off)
+            assert _sha(fh.read(cnt)) == digest
+    with gsb.open(golden_path(case['timestamp']), 'rs', raw=raw, samples_per_frame=8,
+                  subset=(1, slice(10, 20))) as fh:
+        assert bits_equal(fh.read(9).cpu().numpy(), np.ascontiguousarray(exp[:9, 1, 10:20]))
+
+
+def test_gsb_payload_fromfile(manifest):
+    from baseband_amd.gsb import GSBPayload
+    case = manifest['sample_gsb_phased']
+    exp = load_expected('sample_gsb_phased')
+    fhs = [[open(golden_path(f), 'rb') for f in pol] for pol in case['files']]
+    pl = GSBPayload.fromfile(fhs, payload_nbytes=4096, sample_shape=(2, 512), bps=8,
+                             complex_data=True)
+    assert pl.shape == (8, 2, 512)
+    assert bits_equal(pl.data.cpu().numpy(), exp[:8])
+    assert bits_equal(pl[3:6, 1].cpu().numpy(), np.ascontiguousarray(exp[3:6, 1]))
+    for pol in fhs:
+        for f in pol:
+            f.close()
+    with open(golden_path(manifest['sample_gsb_rawdump']['file']), 'rb') as f:
+        pl = GSBPayload.fromfile(f, payload_nbytes=4096, sample_shape=(1,), bps=4)
+    assert bits_equal(pl.data.cpu().numpy(), load_expected('sample_gsb_rawdump')[:8192])

@@ -299,3 +299,68 @@ def test_mark4_bitmaps_module_matches_golden():
         assert BITMAPS[key]['mag_bit'] == e['mag_bit']
         assert BITMAPS[key]['ntrack'] == e['ntrack']
     assert (16, FT_SIGNATURE, 2) in BITMAPS
+
+
+# ------------------------------------------------- GUPPI / DADA / GSB hosts
+def test_guppi_geometry_and_pieces(manifest):
+    from baseband_amd import guppi
+    case = manifest['sample_puppi']
+    with guppi.open(golden_path(case['file']), 'rs', squeeze=False) as fh:
+        assert fh.shape == tuple(case['shape'])
+        assert fh.samples_per_frame == case['samples_per_frame'] == 960
+        assert fh.header0.overlap == 64 and fh.header0.channels_first
+        assert fh.header0.nbytes == case['header_nbytes']
+        assert fh.sample_rate == case['sample_rate_hz']
+        assert str(fh.start_time)[:23] == case['start_time'][:23]
+        assert str(fh.stop_time)[:23] == case['stop_time'][:23]
+        # frame entered first is read to its end, later ones from OVERLAP on
+        assert fh._pieces(0, 3904) == [(0, 0, 1024), (1, 64, 1024), (2, 64, 1024), (3, 64, 1024)]
+        assert fh._pieces(960, 64) == [(1, 0, 64)]
+        assert fh._pieces(3850, 10) == [(3, 970, 980)]
+        assert fh._pieces(900, 200) == [(0, 900, 1024), (1, 64, 140)]
+    for name in ('guppi_cf_c64_ov32', 'guppi_tf_c8_ov16', 'guppi_real_c1'):
+        case = manifest[name]
+        with guppi.open(golden_path(case['file']), 'rs', squeeze=False) as fh:
+            assert fh.shape == tuple(case['shape'])
+            assert fh.header0.nbytes == case['header_nbytes']
+            assert fh.header0.channels_first == case['channels_first']
+
+
+def test_dada_geometry(manifest):
+    from baseband_amd import dada
+    for name in ('sample_dada', 'sample_meerkat_dada', 'sample_mkbf_dada',
+                 'dada_p2_c4_cplx', 'dada_p1_c1_real', 'dada_p2_c3_real'):
+        case = manifest[name]
+        with dada.open(golden_path(case['file']), 'rs', squeeze=False) as fh:
+            assert fh.shape == tuple(case['shape'])
+            assert fh.dtype == np.dtype(case['dtype'])
+            if 'sample_rate_hz' in case:
+                assert abs(fh.sample_rate - case['sample_rate_hz']) < 1e-6 * case['sample_rate_hz']
+                t = np.datetime64(case['start_time'], 'ns')
+                assert abs((fh.start_time - t) / np.timedelta64(1, 'us')) < 1000   # isot string has ms precision
+    case = manifest['dada_p2_c4_cplx']
+    with dada.open(golden_path(case['file']), 'rs') as fh:
+        assert fh._nframes == 3 and fh._last_rows == case['shape'][0] - 2000
+        assert fh._pieces(990, 1020) == [(0, 990, 1000), (1, 0, 1000), (2, 0, 10)]
+
+
+def test_gsb_geometry(manifest):
+    from baseband_amd import gsb
+    case = manifest['sample_gsb_rawdump']
+    with gsb.open(golden_path(case['timestamp']), 'rs', raw=golden_path(case['file']),
+                  samples_per_frame=8192, squeeze=False) as fh:
+        assert fh.shape == tuple(case['shape'])
+        assert fh.payload_nbytes == case['payload_nbytes'] and fh.bps == 4
+        assert str(fh.start_time) == case['start_time']
+        assert str(fh.stop_time) == case['stop_time']
+        assert fh.sample_rate == case['sample_rate_hz']
+    case = manifest['sample_gsb_phased']
+    raw = [[golden_path(f) for f in pol] for pol in case['files']]
+    with gsb.open(golden_path(case['timestamp']), 'rs', raw=raw,
+                  samples_per_frame=8, squeeze=False) as fh:
+        assert fh.shape == tuple(case['shape']) and fh.complex_data and fh.bps == 8
+        assert str(fh.start_time) == case['start_time']
+        assert str(fh.stop_time) == case['stop_time']
+    with pytest.raises(ValueError):
+        gsb.open(golden_path(case['timestamp']), 'rs', raw=raw, samples_per_frame=8,
+                 payload_nbytes=999)
