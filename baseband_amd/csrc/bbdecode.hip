@@ -94,9 +94,19 @@ int device_levels(int coder, int lb, const float **p)
 }
 
 // ---- tuning ----------------------------------------------------------------
-std::atomic<int> g_tune_variant{0};
+std::atomic<int> g_tune_variant{2};   // 2 = persistent pipelined kernel
 std::atomic<int> g_tune_nt{1};
 std::atomic<int> g_tune_blocks{0};
+
+template <int BPS, int LV>
+void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+#define BB_L(OM, NT) hipLaunchKernelGGL((k_decode_flat_pipe<BPS, LV, OM, NT>), grid, dim3(BB_BLOCK), 0, st, a)
+    if (om == BB_OUT_FLAT)       { if (nt) BB_L(BB_OUT_FLAT, true);    else BB_L(BB_OUT_FLAT, false); }
+    else if (om == BB_OUT_ROWS4) { if (nt) BB_L(BB_OUT_ROWS4, true);   else BB_L(BB_OUT_ROWS4, false); }
+    else                         { if (nt) BB_L(BB_OUT_SCATTER, true); else BB_L(BB_OUT_SCATTER, false); }
+#undef BB_L
+}
 
 template <int BPS, int LV>
 void launch_flat(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
@@ -265,6 +275,25 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         if (b2 > 0x7fffffffull) b2 = 0x7fffffffull;
         if (nt) hipLaunchKernelGGL(k_decode_flat2_bytes<true>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
         else    hipLaunchKernelGGL(k_decode_flat2_bytes<false>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
+
+    if (g_tune_variant.load() == 2) {
+        // persistent pipelined form: default grid = 8 workgroups per CU
+        uint64_t b2 = nwork;
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : 4096;
+        if (b2 > cap) b2 = cap;
+        const dim3 g2((unsigned)b2);
+        switch (p->bps) {
+            case 1: launch_flat_pipe<1, BB_LV_REG>(om, nt, g2, st, a); break;
+            case 2: launch_flat_pipe<2, BB_LV_REG>(om, nt, g2, st, a); break;
+            case 4: launch_flat_pipe<4, BB_LV_LDS>(om, nt, g2, st, a); break;
+            default:
+                if (p->coder == BB_CODER_INT) launch_flat_pipe<8, BB_LV_INT8>(om, nt, g2, st, a);
+                else                          launch_flat_pipe<8, BB_LV_LDS>(om, nt, g2, st, a);
+                break;
+        }
         BB_HIP(hipGetLastError());
         return BB_OK;
     }

@@ -166,6 +166,124 @@ void k_decode_flat(bb_flat_args a)
     }
 }
 
+// Persistent, software-pipelined form of k_decode_flat: a fixed grid of
+// workgroups walks the work items; before a workgroup emits the stores of its
+// current item it has already issued the loads of its next one (register
+// double buffer, 8 dwords per lane each), so the HBM read latency -- several
+// microseconds while the write queues are saturated -- overlaps the store
+// phase instead of preceding it.  Each wave owns 8 consecutive tiles, i.e. a
+// contiguous 32 KiB run of the output.
+template <int BPS, int LV, int OM, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_flat_pipe(bb_flat_args a)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr int EPT = 2048 / BPS;
+    constexpr int PASSES = 8 / BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    constexpr int TPW = BB_SEG_TILES / BB_WAVES_PER_BLOCK;      // tiles per wave: 8
+    __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
+
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
+        __syncthreads();
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    const int lane = bb_lane();
+    const int wave = bb_wave();
+    const uint64_t E = a.ndw * (32 / BPS);
+    const uint64_t nwork = a.nfs * a.nseg;
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+    const int src_lane0 = (lane * BPS) >> 3;
+    const int shift = (4 * lane * BPS) & 31;
+
+    uint32_t cur[TPW], nxt[TPW];
+    bool cur_valid = false, nxt_valid = false;
+
+    auto issue = [&](uint64_t work, uint32_t (&w)[TPW], bool &valid) {
+        uint64_t fs, seg;
+        if (a.nseg == 1) { fs = work; seg = 0; }
+        else { fs = work / a.nseg; seg = work - fs * a.nseg; }
+        const int64_t so = a.src ? a.src[fs] : a.src0 + (int64_t)fs * a.src_stride;
+        valid = so >= 0;
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(a.buf + (valid ? so : 0));
+        const uint64_t tile0 = seg * BB_SEG_TILES + (uint64_t)wave * TPW;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint64_t dw = (tile0 + u) * 64 + lane;
+            w[u] = (valid && dw < a.ndw) ? in[dw] : 0u;
+        }
+    };
+
+    uint64_t work = blockIdx.x;
+    if (work < nwork) issue(work, cur, cur_valid);
+    for (; work < nwork; work += gridDim.x) {
+        const uint64_t next = work + gridDim.x;
+        if (next < nwork) issue(next, nxt, nxt_valid);
+
+        uint64_t fs, seg;
+        if (a.nseg == 1) { fs = work; seg = 0; }
+        else { fs = work / a.nseg; seg = work - fs * a.nseg; }
+        float *obase;
+        uint64_t rowbase = 0, slot = 0;
+        if (OM == BB_OUT_FLAT) {
+            obase = a.out + fs * E;
+        } else {
+            const uint64_t f = fs / a.nslot;
+            slot = fs - f * a.nslot;
+            rowbase = f * (E >> a.lchunk);
+            obase = a.out;
+        }
+        const uint64_t tile0 = seg * BB_SEG_TILES + (uint64_t)wave * TPW;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint64_t tile = tile0 + u;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                uint32_t bits;
+                if (BPS == 8) bits = cur[u];
+                else bits = (uint32_t)__shfl((int)cur[u], p * 8 * BPS + src_lane0) >> shift;
+                const uint64_t e0 = tile * EPT + 256 * p + 4 * lane;
+                if (e0 >= E) continue;
+                bb_f4 v;
+                if (cur_valid) {
+                    v.x = lv.get(bits & CMASK);
+                    v.y = lv.get((bits >> BPS) & CMASK);
+                    v.z = lv.get((bits >> (2 * BPS)) & CMASK);
+                    v.w = lv.get((bits >> (3 * BPS)) & CMASK);
+                } else {
+                    v = fillv;
+                }
+                if (OM == BB_OUT_FLAT) {
+                    bb_store4<NT>(obase + e0, v);
+                } else if (OM == BB_OUT_ROWS4) {
+                    const uint64_t row = e0 >> a.lchunk;
+                    const uint64_t within = e0 & (a.chunk - 1);
+                    bb_store4<NT>(obase + ((((rowbase + row) * a.nslot + slot) << a.lchunk) + within), v);
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint64_t e = e0 + j;
+                        const uint64_t row = e >> a.lchunk;
+                        const uint64_t within = e & (a.chunk - 1);
+                        bb_store1<NT>(obase + ((((rowbase + row) * a.nslot + slot) << a.lchunk) + within), vv[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) cur[u] = nxt[u];
+        cur_valid = nxt_valid;
+    }
+}
+
 // Experimental twin of the 2-bit flat kernel: every lane loads its own byte
 // (64-byte wave loads) instead of shuffling a dword; kept for A/B timing only.
 template <bool NT>

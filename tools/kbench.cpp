@@ -45,6 +45,41 @@ __global__ void k_copy(const f4 *s, f4 *d, size_t n)
     for (; i < n; i += stride) d[i] = s[i];
 }
 
+// Fill patterns that mimic the decode kernel's store order, to separate "what
+// the write pattern costs" from "what the decode adds".
+//  mode 0: one workgroup per 128000-byte region, waves interleaved per 4 KiB
+//          (the decode kernel's order); mode 1: each wave owns a contiguous
+//          quarter of the region; mode 2: as 0 plus the 8000-byte input read.
+template <int MODE, bool NT>
+__global__ __launch_bounds__(256)
+void k_fill_regions(f4 *out, const uint32_t *in, size_t nregions)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t R4 = 8000;                 // float4 per region (128000 B)
+    f4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t r = blockIdx.x; r < nregions; r += gridDim.x) {
+        f4 *o = out + r * R4;
+        if (MODE == 1) {
+            for (size_t i = wave * 2000 + lane; i < (size_t)(wave + 1) * 2000; i += 64) {
+                if (NT) __builtin_nontemporal_store(v, &o[i]); else o[i] = v;
+            }
+        } else {
+            uint32_t acc = 0;
+            for (int t = wave; t < 32; t += 4) {            // 32 tiles of 256 float4
+                if (MODE == 2) {
+                    size_t dw = (size_t)t * 64 + lane;
+                    if (dw < 2000) acc = in[r * 2008 + 8 + dw];
+                    v.x = (float)(acc & 3);
+                }
+                for (int p = 0; p < 4; ++p) {
+                    size_t i = (size_t)t * 256 + p * 64 + lane;
+                    if (i < R4) { if (NT) __builtin_nontemporal_store(v, &o[i]); else o[i] = v; }
+                }
+            }
+        }
+    }
+}
+
 static double time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 int main(int argc, char **argv)
@@ -98,16 +133,33 @@ int main(int argc, char **argv)
         printf("copy: median %.3f ms  %.1f GB/s (read+write)\n", t[t.size() / 2], n * 32.0 / t[t.size() / 2] / 1e6);
     }
 
+    for (int mode = 0; mode < 3; ++mode) {
+        std::vector<double> t;
+        for (int r = 0; r < reps + 1; ++r) {
+            CK(hipEventRecord(e0));
+            dim3 g((unsigned)nframes), b(256);
+            if (mode == 0) hipLaunchKernelGGL((k_fill_regions<0, true>), g, b, 0, 0, (f4 *)d_out, (const uint32_t *)d_in, nframes);
+            if (mode == 1) hipLaunchKernelGGL((k_fill_regions<1, true>), g, b, 0, 0, (f4 *)d_out, (const uint32_t *)d_in, nframes);
+            if (mode == 2) hipLaunchKernelGGL((k_fill_regions<2, true>), g, b, 0, 0, (f4 *)d_out, (const uint32_t *)d_in, nframes);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            if (r) t.push_back(time_ms(e0, e1));
+        }
+        std::sort(t.begin(), t.end());
+        double bytes = (double)out_elems * 4 + (mode == 2 ? (double)in_bytes : 0.0);
+        printf("fill_regions mode=%d nt=1: median %.3f ms  %.1f GB/s\n", mode, t[t.size() / 2], bytes / t[t.size() / 2] / 1e6);
+    }
+
     bb_decode_params p = {};
     p.coder = BB_CODER_VDIF; p.bps = bps; p.chunk = 1; p.nslot = 1;
     p.payload_nbytes = payload; p.src0 = hdr; p.src_stride = frame;
     p.complex_data = 0; p.fill_re = 0.f; p.fill_im = 0.f;
 
-    const int blocks_opts[] = {0, 2048, 4096, 8192};
-    for (int variant = 0; variant < 2; ++variant)
+    const int blocks_opts[] = {0, 2048, 8192, 16384};
+    for (int variant = 0; variant < 3; ++variant)
     for (int nt = 0; nt < 2; ++nt)
     for (int bi = 0; bi < 4; ++bi) {
         if (variant == 1 && bps != 2) continue;
+        if (variant != 2 && (nt == 0 || bi > 1)) continue;      // keep the sweep short
         bb_tune(BB_TUNE_FLAT_VARIANT, variant);
         bb_tune(BB_TUNE_NT_STORES, nt);
         bb_tune(BB_TUNE_BLOCKS, blocks_opts[bi]);
