@@ -4,6 +4,7 @@
 #include "bb_common.h"
 #include "k_scan.h"
 #include "k_flat.h"
+#include "k_gather.h"
 #include "k_mark4.h"
 #include "k_tiled.h"
 
@@ -97,6 +98,13 @@ int device_levels(int coder, int lb, const float **p)
 std::atomic<int> g_tune_variant{2};   // 2 = persistent pipelined kernel
 std::atomic<int> g_tune_nt{1};
 std::atomic<int> g_tune_blocks{0};
+
+template <int BPS, int LV>
+void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
+{
+    if (nt) hipLaunchKernelGGL((k_decode_gather<BPS, LV, true>), grid, dim3(BB_BLOCK), lds, st, a);
+    else    hipLaunchKernelGGL((k_decode_gather<BPS, LV, false>), grid, dim3(BB_BLOCK), lds, st, a);
+}
 
 template <int BPS, int LV>
 void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
@@ -251,6 +259,11 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     a.ndw = p->payload_nbytes / 4;
     const uint64_t ntiles = (a.ndw + 63) / 64;
     a.nseg = (ntiles + BB_SEG_TILES - 1) / BB_SEG_TILES;
+    // split a frame-slot's tiles evenly over its work items and a work item's
+    // tiles evenly over the four waves (a 10000-byte Mark 5B payload is 40
+    // tiles: 2 items x 20 tiles x 5 per wave, not 32 + 8)
+    a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
+    a.tpw = (a.seg_tiles + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
     a.src0 = p->src0;
     a.src_stride = p->src_stride;
     a.nslot = (uint32_t)p->nslot;
@@ -275,6 +288,38 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         if (b2 > 0x7fffffffull) b2 = 0x7fffffffull;
         if (nt) hipLaunchKernelGGL(k_decode_flat2_bytes<true>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
         else    hipLaunchKernelGGL(k_decode_flat2_bytes<false>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
+
+    if (om == BB_OUT_SCATTER && d_src && g_tune_variant.load() != 0
+        && (size_t)p->nslot * 260 + 1024 + 64 <= 48 * 1024) {
+        // narrow chunks: assemble output rows in LDS (k_gather.h)
+        bb_gather_args ga;
+        ga.buf = a.buf; ga.src = d_src; ga.out = d_out; ga.tab = a.tab;
+        ga.nframes = nframes; ga.ndw = a.ndw;
+        ga.nslot = a.nslot; ga.chunk = a.chunk; ga.lchunk = a.lchunk;
+        uint32_t gt = (uint32_t)(16384 / ((size_t)p->nslot * 256));
+        if (gt < 1) gt = 1;
+        if (gt > 32) gt = 32;
+        if ((uint64_t)gt > ntiles) gt = (uint32_t)ntiles;
+        ga.gtiles = gt;
+        ga.ngroup = (uint32_t)((ntiles + gt - 1) / gt);
+        ga.fill_re = a.fill_re; ga.fill_im = a.fill_im; ga.complex_data = a.complex_data;
+        const size_t lds = ((size_t)p->nslot * (gt * 64 + 1) + p->nslot) * 4 + 1024;
+        uint64_t gb = (uint64_t)nframes * ga.ngroup;
+        if (tb > 0 && gb > (uint64_t)tb) gb = (uint64_t)tb;
+        if (gb > 0x7fffffffull) gb = 0x7fffffffull;
+        const dim3 gg((unsigned)gb);
+        switch (p->bps) {
+            case 1: launch_gather<1, BB_LV_REG>(nt, gg, lds, st, ga); break;
+            case 2: launch_gather<2, BB_LV_REG>(nt, gg, lds, st, ga); break;
+            case 4: launch_gather<4, BB_LV_LDS>(nt, gg, lds, st, ga); break;
+            default:
+                if (p->coder == BB_CODER_INT) launch_gather<8, BB_LV_INT8>(nt, gg, lds, st, ga);
+                else                          launch_gather<8, BB_LV_LDS>(nt, gg, lds, st, ga);
+                break;
+        }
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
@@ -368,6 +413,8 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
     a.fill_words = p->fill_words;
     const uint64_t ntiles = (p->nwords + 63) / 64;
     a.nseg = (ntiles + BB_M4_SEG_TILES - 1) / BB_M4_SEG_TILES;
+    a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
+    a.tpw = (a.seg_tiles + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
     a.src0 = p->src0;
     a.src_stride = p->src_stride;
     memset(a.sign_bit, 0, sizeof(a.sign_bit));
@@ -378,8 +425,8 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
     a.hi = h_levels[BB_CODER_VDIF][1][3];
     uint64_t blocks = (uint64_t)nframes * a.nseg;
     const int tb = g_tune_blocks.load();
-    if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
-    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+    const uint64_t cap = tb > 0 ? (uint64_t)tb : 4096;      // persistent grid
+    if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     const bool nt = g_tune_nt.load() != 0;
@@ -446,11 +493,14 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     if ((uint64_t)tt > rows) tt = (uint32_t)rows;
     a.tt = tt;
     a.tc = tc;
+    uint32_t pitch_dw = ((tc + 1) / 2) + 1;             // dwords per LDS row
+    if ((pitch_dw & 1) == 0) pitch_dw += 1;             // odd: strided writes hit distinct banks
+    a.tcp = 2 * pitch_dw;
     const uint64_t ntt = (rows + tt - 1) / tt, nct = (nc + tc - 1) / tc;
     if (ntt > 0xffffffffull || nct > 0xffffffffull) return BB_ERANGE;
     a.ntt = (uint32_t)ntt;
     a.nct = (uint32_t)nct;
-    const size_t lds = (size_t)tt * np_ * (tc + 2) * sizeof(uint16_t);
+    const size_t lds = (size_t)tt * np_ * a.tcp * sizeof(uint16_t);
     if (lds > 64 * 1024) return BB_ENOTSUP;
     uint64_t blocks = (uint64_t)nframes * ntt * nct;
     const int tb = g_tune_blocks.load();

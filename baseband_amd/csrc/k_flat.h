@@ -37,6 +37,8 @@ struct bb_flat_args {
     uint64_t nfs;           // nframes * nslot
     uint64_t ndw;           // payload dwords per frame-slot
     uint64_t nseg;          // work items per frame-slot
+    uint32_t seg_tiles;     // tiles per work item (<= BB_SEG_TILES), evenly split
+    uint32_t tpw;           // tiles per wave within a work item (<= 8)
     int64_t  src0, src_stride;
     uint32_t nslot, chunk, lchunk;
     float    fill_re, fill_im;
@@ -112,9 +114,9 @@ void k_decode_flat(bb_flat_args a)
             obase = a.out;
         }
 
-        const uint64_t tile_begin = seg * BB_SEG_TILES;
-        const uint64_t tile_end = (tile_begin + BB_SEG_TILES < ntiles)
-                                  ? tile_begin + BB_SEG_TILES : ntiles;
+        const uint64_t tile_begin = seg * a.seg_tiles;
+        const uint64_t tile_end = (tile_begin + a.seg_tiles < ntiles)
+                                  ? tile_begin + a.seg_tiles : ntiles;
         for (uint64_t t = tile_begin + wave; t < tile_end;
              t += BB_WAVES_PER_BLOCK * BB_FLAT_UNROLL) {
             uint32_t w[BB_FLAT_UNROLL];
@@ -213,11 +215,13 @@ void k_decode_flat_pipe(bb_flat_args a)
         const int64_t so = a.src ? a.src[fs] : a.src0 + (int64_t)fs * a.src_stride;
         valid = so >= 0;
         const uint32_t *in = reinterpret_cast<const uint32_t *>(a.buf + (valid ? so : 0));
-        const uint64_t tile0 = seg * BB_SEG_TILES + (uint64_t)wave * TPW;
+        const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
+        const uint64_t dw_end = (seg + 1) * a.seg_tiles * 64 < a.ndw
+                                ? (seg + 1) * a.seg_tiles * 64 : a.ndw;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const uint64_t dw = (tile0 + u) * 64 + lane;
-            w[u] = (valid && dw < a.ndw) ? in[dw] : 0u;
+            w[u] = (valid && u < (int)a.tpw && dw < dw_end) ? in[dw] : 0u;
         }
     };
 
@@ -240,9 +244,12 @@ void k_decode_flat_pipe(bb_flat_args a)
             rowbase = f * (E >> a.lchunk);
             obase = a.out;
         }
-        const uint64_t tile0 = seg * BB_SEG_TILES + (uint64_t)wave * TPW;
+        const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
+        const uint64_t seg_e_end = (seg + 1) * a.seg_tiles * EPT < E
+                                   ? (seg + 1) * a.seg_tiles * EPT : E;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
+            if (u >= (int)a.tpw) break;                 // wave-uniform
             const uint64_t tile = tile0 + u;
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
@@ -250,7 +257,7 @@ void k_decode_flat_pipe(bb_flat_args a)
                 if (BPS == 8) bits = cur[u];
                 else bits = (uint32_t)__shfl((int)cur[u], p * 8 * BPS + src_lane0) >> shift;
                 const uint64_t e0 = tile * EPT + 256 * p + 4 * lane;
-                if (e0 >= E) continue;
+                if (e0 >= seg_e_end) continue;
                 bb_f4 v;
                 if (cur_valid) {
                     v.x = lv.get(bits & CMASK);

@@ -1,0 +1,102 @@
+// Thread interleave for narrow samples: frame sets whose per-thread chunk is
+// smaller than one float4 (nchan * ncomp = 1 or 2, e.g. the 8-thread,
+// 1-channel layout of sample.vdif).
+//
+// Replaces (reference, path:line) the same expressions as k_decode_flat plus
+// the strided per-thread copies of VDIFFrameSet.__getitem__
+// (vdif/frame.py:427-434): there every thread's (nsample, nchan) block is
+// written into column t of a (nsample, nthread, nchan) array; here the output
+// rows are assembled on chip so that HBM only sees contiguous 16-byte stores.
+//
+// A workgroup stages G tiles (256 bytes each) of the SAME position from every
+// thread slot's payload in LDS (coalesced dword loads), then walks the
+// contiguous output region those tiles map to: lane -> float4 -> four
+// (row, slot) pairs -> one LDS byte read + bit-field extract each.
+#pragma once
+#include "bb_common.h"
+#include "k_flat.h"
+
+struct bb_gather_args {
+    const uint8_t *buf;
+    const int64_t *src;     // [nframes * nslot], -1 = fill; never null here
+    float         *out;
+    const float   *tab;
+    uint64_t nframes;
+    uint64_t ndw;           // payload dwords per slot
+    uint32_t nslot, chunk, lchunk;
+    uint32_t gtiles;        // tiles per slot staged per work item
+    uint32_t ngroup;        // work items per frame set
+    float    fill_re, fill_im;
+    int32_t  complex_data;
+};
+
+template <int BPS, int LV, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_gather(bb_gather_args a)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    // layout: [nslot][pitch] dwords of raw payload, then nslot validity words,
+    // then the level table
+    const uint32_t pitch = a.gtiles * 64 + 1;           // +1 dword: bank skew
+    uint32_t *s_raw = s_mem;
+    uint32_t *s_valid = s_mem + (size_t)a.nslot * pitch;
+    float *s_tab = reinterpret_cast<float *>(s_valid + a.nslot);
+
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    const uint64_t E = a.ndw * (32 / BPS);              // elements per slot
+    const uint64_t R = E >> a.lchunk;                   // rows per frame set
+    const uint32_t rowlen = a.nslot << a.lchunk;        // floats per output row
+    const uint64_t nwork = a.nframes * a.ngroup;
+    const uint32_t gdw = a.gtiles * 64;                 // dwords staged per slot
+
+    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const uint64_t f = work / a.ngroup;
+        const uint32_t g = (uint32_t)(work - f * a.ngroup);
+        const uint64_t dw0 = (uint64_t)g * gdw;         // first dword of the group
+        // phase 1: stage the group's dwords of every slot
+        for (uint32_t i = threadIdx.x; i < a.nslot * gdw; i += BB_BLOCK) {
+            const uint32_t s = i / gdw, d = i - s * gdw;
+            const int64_t so = a.src[f * a.nslot + s];
+            uint32_t w = 0;
+            if (so >= 0 && dw0 + d < a.ndw)
+                w = reinterpret_cast<const uint32_t *>(a.buf + so)[dw0 + d];
+            s_raw[s * pitch + d] = w;
+            if (d == 0) s_valid[s] = so >= 0 ? 1u : 0u;
+        }
+        __syncthreads();
+        // phase 2: contiguous output region of this group
+        const uint64_t e_lo = dw0 * (32 / BPS);
+        const uint64_t e_hi = (e_lo + (uint64_t)gdw * (32 / BPS) < E) ? e_lo + (uint64_t)gdw * (32 / BPS) : E;
+        const uint32_t nrow = (uint32_t)((e_hi - e_lo) >> a.lchunk);
+        const uint32_t nfloat = nrow * rowlen;          // multiple of 4
+        float *obase = a.out + (f * R + (e_lo >> a.lchunk)) * rowlen;
+        const uint8_t *rawb = reinterpret_cast<const uint8_t *>(s_raw);
+        for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
+            uint32_t row = q / rowlen;
+            uint32_t rem = q - row * rowlen;
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t s = rem >> a.lchunk;
+                const uint32_t within = rem & (a.chunk - 1);
+                const uint32_t bit = ((row << a.lchunk) + within) * BPS;
+                const uint32_t byte = rawb[(size_t)s * pitch * 4 + (bit >> 3)];
+                const uint32_t code = (byte >> (bit & 7)) & CMASK;
+                const float fillj = (a.complex_data && (within & 1)) ? a.fill_im : a.fill_re;
+                r[j] = s_valid[s] ? lv.get(code) : fillj;
+                if (++rem == rowlen) { rem = 0; ++row; }
+            }
+            bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
+        }
+        __syncthreads();
+    }
+}

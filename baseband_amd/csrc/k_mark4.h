@@ -108,6 +108,7 @@ struct bb_m4_args {
     uint64_t nwords;        // stream words per frame (20000) or per payload
     uint64_t fill_words;    // leading words that decode to fill (160 / 0)
     uint64_t nseg;
+    uint32_t seg_tiles, tpw;
     int64_t  src0, src_stride;
     uint32_t sign_bit[8];   // 32 x uint8: output j -> bit position of its sign
     uint32_t mag_bit[8];    //                       ... of its magnitude
@@ -115,11 +116,15 @@ struct bb_m4_args {
 };
 
 #define BB_M4_SEG_TILES 32
+#define BB_M4_TPW (BB_M4_SEG_TILES / BB_WAVES_PER_BLOCK)
 
 // Lane l of a wave owns outputs [4*(l % LPW), +4) of word (l / LPW) of the
 // current pass, LPW = NTRACK/8 lanes per word, so a store instruction covers
 // 64/LPW consecutive words = 1 KiB of contiguous output.  Words are loaded
 // once per 64-word tile (one coalesced load) and handed around with shuffles.
+// Persistent and software pipelined like k_decode_flat_pipe: the loads of the
+// next work item (8 tiles per wave) are in flight while the current one is
+// being stored.
 template <int NTRACK, bool NT>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_decode_mark4(bb_m4_args a)
@@ -128,6 +133,7 @@ void k_decode_mark4(bb_m4_args a)
     constexpr int LPW = NTRACK / 8;         // lanes per word
     constexpr int WPP = 64 / LPW;           // words per store pass
     constexpr int OPW = NTRACK / 2;         // outputs per word
+    constexpr int TPW = BB_M4_TPW;
     const int lane = bb_lane();
     const int wave = bb_wave();
     const int sub = lane % LPW;
@@ -140,23 +146,45 @@ void k_decode_mark4(bb_m4_args a)
     const float hi = a.hi;
     const bb_f4 fillv = {a.fill, a.fill, a.fill, a.fill};
     const uint64_t E = a.nwords * OPW;
-    const uint64_t ntiles = (a.nwords + 63) / 64;
     const uint64_t nwork = a.nframes * a.nseg;
 
-    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+    word_t cur[TPW], nxt[TPW];
+    bool cur_valid = false, nxt_valid = false;
+
+    auto issue = [&](uint64_t work, word_t (&w)[TPW], bool &valid) {
         uint64_t f, seg;
         if (a.nseg == 1) { f = work; seg = 0; }
         else { f = work / a.nseg; seg = work - f * a.nseg; }
         const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
-        const bool valid = so >= 0;
+        valid = so >= 0;
         const word_t *in = reinterpret_cast<const word_t *>(a.buf + (valid ? so : 0));
+        const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
+        const uint64_t w_end = (seg + 1) * a.seg_tiles * 64 < a.nwords
+                               ? (seg + 1) * a.seg_tiles * 64 : a.nwords;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint64_t wi = (tile0 + u) * 64 + lane;
+            w[u] = (valid && u < (int)a.tpw && wi < w_end && wi >= a.fill_words) ? in[wi] : (word_t)0;
+        }
+    };
+
+    uint64_t work = blockIdx.x;
+    if (work < nwork) issue(work, cur, cur_valid);
+    for (; work < nwork; work += gridDim.x) {
+        const uint64_t next = work + gridDim.x;
+        if (next < nwork) issue(next, nxt, nxt_valid);
+        uint64_t f, seg;
+        if (a.nseg == 1) { f = work; seg = 0; }
+        else { f = work / a.nseg; seg = work - f * a.nseg; }
         float *obase = a.out + f * E;
-        const uint64_t tile_begin = seg * BB_M4_SEG_TILES;
-        const uint64_t tile_end = (tile_begin + BB_M4_SEG_TILES < ntiles)
-                                  ? tile_begin + BB_M4_SEG_TILES : ntiles;
-        for (uint64_t tile = tile_begin + wave; tile < tile_end; tile += BB_WAVES_PER_BLOCK) {
-            const uint64_t wi = tile * 64 + lane;
-            const word_t w = (valid && wi < a.nwords && wi >= a.fill_words) ? in[wi] : (word_t)0;
+        const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
+        const uint64_t w_end = (seg + 1) * a.seg_tiles * 64 < a.nwords
+                               ? (seg + 1) * a.seg_tiles * 64 : a.nwords;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            if (u >= (int)a.tpw) break;                 // wave-uniform
+            const uint64_t tile = tile0 + u;
+            const word_t w = cur[u];
 #pragma unroll
             for (int p = 0; p < LPW; ++p) {
                 const int srcl = p * WPP + wsel;
@@ -169,9 +197,9 @@ void k_decode_mark4(bb_m4_args a)
                     x = (uint32_t)__shfl((int)(uint32_t)w, srcl);
                 }
                 const uint64_t widx = tile * 64 + srcl;
-                if (widx >= a.nwords) continue;
+                if (widx >= w_end) continue;
                 bb_f4 v;
-                if (!valid || widx < a.fill_words) {
+                if (!cur_valid || widx < a.fill_words) {
                     v = fillv;
                 } else {
                     float r[4];
@@ -191,5 +219,8 @@ void k_decode_mark4(bb_m4_args a)
                 bb_store4<NT>(obase + widx * OPW + 4 * sub, v);
             }
         }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) cur[u] = nxt[u];
+        cur_valid = nxt_valid;
     }
 }

@@ -17,7 +17,7 @@
 // A workgroup moves a tile of tt times x tc channels x all pols.  Phase 1
 // walks the tile in INPUT order (lanes along the contiguous input axis:
 // 128-byte wave loads) and drops each 2-byte element into LDS at its OUTPUT
-// position [t][p][c]; the row pitch tc+2 elements (odd number of dwords) keeps
+// position [t][p][c]; the row pitch (tc rounded up to an odd number of dwords) keeps
 // the strided writes off the same bank.  Phase 2 reads LDS linearly: a lane
 // takes one dword (two elements) and stores one float4, so output rows are
 // written in contiguous 16-byte pieces (512 B per 64-channel row).
@@ -33,7 +33,8 @@ struct bb_tiled_args {
     uint64_t tb, sh, st, sp, sc;
     int64_t  src0, src_stride;
     uint32_t npol, nchan;
-    uint32_t tt, tc;            // tile: times, channels (tc even or == 1)
+    uint32_t tt, tc;            // tile: times, channels
+    uint32_t tcp;               // LDS row pitch in elements: even, odd number of dwords
     uint32_t ntt, nct;          // tiles per frame along time / channel
     float    fill_re, fill_im;
 };
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(BB_BLOCK)
 void k_decode_i8_tiled(bb_tiled_args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_tile[];
-    const uint32_t tcp = a.tc + 2;                      // padded row pitch (elements)
+    const uint32_t tcp = a.tcp;                         // padded row pitch (elements)
     const uint32_t npol = a.npol, tc = a.tc, tt = a.tt;
     const uint64_t rows_out = a.t_hi - a.t_lo;          // output rows per frame
     const uint64_t rowlen = (uint64_t)npol * a.nchan * 2;   // floats per output time
@@ -63,27 +64,69 @@ void k_decode_i8_tiled(bb_tiled_args a)
         const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
 
         if (valid) {
-            // phase 1: input order -> LDS at output position
-            for (uint32_t i = threadIdx.x; i < tile_elems; i += BB_BLOCK) {
-                uint32_t tl, p, c;
-                if (LAYOUT == 0) {              // (c, t, p)
-                    c = i / (tt * npol);
-                    const uint32_t r = i - c * tt * npol;
-                    tl = r / npol; p = r - tl * npol;
-                } else if (LAYOUT == 1) {       // (p, c, t)
-                    p = i / (tc * tt);
-                    const uint32_t r = i - p * tc * tt;
-                    c = r / tt; tl = r - c * tt;
-                } else {                        // (t, c, p)
-                    tl = i / (tc * npol);
-                    const uint32_t r = i - tl * tc * npol;
-                    c = r / npol; p = r - c * npol;
+            // phase 1: input order -> LDS at output position [t][p][c]
+            const int lane = bb_lane(), wave = bb_wave();
+            if (LAYOUT == 0) {
+                // (c, t, p): within a channel the (t, p) run is contiguous and
+                // its index IS the LDS row.  One wave per channel, lanes along
+                // the run, two elements (one dword) per lane when aligned.
+                const uint32_t run = nt_tile * npol;
+                for (uint32_t c = wave; c < nc_tile; c += BB_WAVES_PER_BLOCK) {
+                    const uint64_t off = (uint64_t)(c0 + c) * a.sc + t0 * npol;
+                    const uint16_t *row = in + off;
+                    if (((uintptr_t)row & 3) == 0) {
+                        for (uint32_t i = lane * 2; i < run; i += 128) {
+                            if (i + 1 < run) {
+                                const uint32_t w = *reinterpret_cast<const uint32_t *>(row + i);
+                                s_tile[i * tcp + c] = (uint16_t)(w & 0xffff);
+                                s_tile[(i + 1) * tcp + c] = (uint16_t)(w >> 16);
+                            } else {
+                                s_tile[i * tcp + c] = row[i];
+                            }
+                        }
+                    } else {
+                        for (uint32_t i = lane; i < run; i += 64) s_tile[i * tcp + c] = row[i];
+                    }
                 }
-                if (tl < nt_tile && c < nc_tile) {
-                    const uint64_t t = t0 + tl;
-                    const uint64_t off = (t / a.tb) * a.sh + (t % a.tb) * a.st
-                                         + (uint64_t)p * a.sp + (uint64_t)(c0 + c) * a.sc;
-                    s_tile[(tl * npol + p) * tcp + c] = in[off];
+            } else if (LAYOUT == 1 && (t0 % a.tb) + nt_tile <= a.tb) {
+                // (heap, p, c, t): a (p, c) pair has contiguous times inside a heap
+                const uint64_t hbase = (t0 / a.tb) * a.sh + (t0 % a.tb) * a.st;
+                for (uint32_t pc = wave; pc < npol * nc_tile; pc += BB_WAVES_PER_BLOCK) {
+                    const uint32_t p = pc / nc_tile, c = pc - p * nc_tile;
+                    const uint16_t *row = in + hbase + (uint64_t)p * a.sp + (uint64_t)(c0 + c) * a.sc;
+                    if (((uintptr_t)row & 3) == 0) {
+                        for (uint32_t tl = lane * 2; tl < nt_tile; tl += 128) {
+                            if (tl + 1 < nt_tile) {
+                                const uint32_t w = *reinterpret_cast<const uint32_t *>(row + tl);
+                                s_tile[(tl * npol + p) * tcp + c] = (uint16_t)(w & 0xffff);
+                                s_tile[((tl + 1) * npol + p) * tcp + c] = (uint16_t)(w >> 16);
+                            } else {
+                                s_tile[(tl * npol + p) * tcp + c] = row[tl];
+                            }
+                        }
+                    } else {
+                        for (uint32_t tl = lane; tl < nt_tile; tl += 64)
+                            s_tile[(tl * npol + p) * tcp + c] = row[tl];
+                    }
+                }
+            } else {
+                for (uint32_t i = threadIdx.x; i < tile_elems; i += BB_BLOCK) {
+                    uint32_t tl, p, c;
+                    if (LAYOUT == 1) {              // (p, c, t), tile crosses a heap
+                        p = i / (tc * tt);
+                        const uint32_t r = i - p * tc * tt;
+                        c = r / tt; tl = r - c * tt;
+                    } else {                        // (t, c, p)
+                        tl = i / (tc * npol);
+                        const uint32_t r = i - tl * tc * npol;
+                        c = r / npol; p = r - c * npol;
+                    }
+                    if (tl < nt_tile && c < nc_tile) {
+                        const uint64_t t = t0 + tl;
+                        const uint64_t off = (t / a.tb) * a.sh + (t % a.tb) * a.st
+                                             + (uint64_t)p * a.sp + (uint64_t)(c0 + c) * a.sc;
+                        s_tile[(tl * npol + p) * tcp + c] = in[off];
+                    }
                 }
             }
         }
@@ -100,14 +143,12 @@ void k_decode_i8_tiled(bb_tiled_args a)
             float v0, v1, v2 = 0.f, v3 = 0.f;
             const bool two = c + 1 < nc_tile;
             if (valid) {
-                const uint32_t e0 = s_tile[row * tcp + c];
-                v0 = (float)(int)(int8_t)(e0 & 0xff);
-                v1 = (float)(int)(int8_t)(e0 >> 8);
-                if (two) {
-                    const uint32_t e1 = s_tile[row * tcp + c + 1];
-                    v2 = (float)(int)(int8_t)(e1 & 0xff);
-                    v3 = (float)(int)(int8_t)(e1 >> 8);
-                }
+                // tcp and c are even: the two elements form one aligned dword
+                const uint32_t e = *reinterpret_cast<const uint32_t *>(&s_tile[row * tcp + c]);
+                v0 = (float)(int)(int8_t)(e & 0xff);
+                v1 = (float)(int)(int8_t)((e >> 8) & 0xff);
+                v2 = (float)(int)(int8_t)((e >> 16) & 0xff);
+                v3 = (float)(int)(int8_t)(e >> 24);
             } else {
                 v0 = v2 = a.fill_re; v1 = v3 = a.fill_im;
             }

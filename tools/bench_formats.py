@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Kernel-level roofline numbers for the non-headline configurations
+(BASELINE.json configs 0, 2, 3, 4): decode kernels on synthetic payload bytes
+resident in HBM, timed with HIP events.  Writes one JSON line per case.
+
+usage: python tools/bench_formats.py [GiB of input per case, default 1]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from baseband_amd import kernels, _lib          # noqa: E402
+from baseband_amd.mark4._bitmaps import BITMAPS  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timeit(fn, reps=7):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts))
+
+
+def report(name, ms, bytes_in, bytes_out, nvalues, **extra):
+    gbs = (bytes_in + bytes_out) / ms / 1e6
+    line = dict(case=name, ms=round(ms, 4), algorithmic_GBps=round(gbs, 1),
+                frac_of_8TBps=round(gbs / PEAK, 4),
+                Mvalues_per_s=round(nvalues / ms / 1e3, 1),
+                bytes_in=bytes_in, bytes_out=bytes_out, **extra)
+    print(json.dumps(line), flush=True)
+
+
+def main():
+    gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    nbytes = int(gib * 2 ** 30)
+    dev = torch.device('cuda')
+    kernels.init()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    buf = torch.randint(0, 2 ** 31 - 1, (nbytes // 4 + 1024,), generator=g, device=dev,
+                        dtype=torch.int64).to(torch.int32).view(torch.uint8)
+
+    # cfg0-like: sample.vdif structure, 8 threads x 1 channel, 2-bit real, 5032-byte frames
+    fn_, pn, nth = 5032, 5000, 8
+    nsets = nbytes // (fn_ * nth)
+    src = (torch.arange(nsets * nth, device=dev, dtype=torch.int64) * fn_ + 32)
+    out = torch.empty(nsets * nth * pn * 4, dtype=torch.float32, device=dev)
+    ms = timeit(lambda: kernels.decode_frames(buf, nsets, pn, 0, 2, chunk=1, nslot=nth, src=src, out=out))
+    report('cfg0 VDIF 8 threads x 1 ch 2-bit real (LDS thread interleave, k_decode_gather)',
+           ms, nsets * nth * fn_, out.numel() * 4, out.numel(), nsets=nsets)
+    del out
+
+    # cfg2: 8 threads, 16 channels, 2-bit complex, 8032-byte frames (thread order shuffled)
+    fn_, pn, nth = 8032, 8000, 8
+    nsets = nbytes // (fn_ * nth)
+    perm = torch.tensor([4, 0, 5, 1, 6, 2, 7, 3], device=dev)       # slot -> position on disk
+    pos = torch.arange(nsets, device=dev, dtype=torch.int64)[:, None] * nth + perm[None, :]
+    src = (pos * fn_ + 32).reshape(-1).contiguous()
+    out = torch.empty(nsets * nth * pn * 4, dtype=torch.float32, device=dev)
+    ms = timeit(lambda: kernels.decode_frames(buf, nsets, pn, 0, 2, chunk=32, nslot=nth, src=src,
+                                              complex_data=True, out=out))
+    report('cfg2 VDIF 8 threads x 16 ch 2-bit complex (k_decode_flat_pipe ROWS4)',
+           ms, nsets * nth * fn_, out.numel() * 4, out.numel() // 2, nsets=nsets)
+    del out
+
+    # cfg3a: Mark 5B 16 ch 2-bit
+    nfr = nbytes // 10016
+    out = torch.empty(nfr * 40000, dtype=torch.float32, device=dev)
+    ms = timeit(lambda: kernels.decode_frames(buf, nfr, 10000, _lib.CODER_MARK5B, 2, chunk=16,
+                                              src0=16, src_stride=10016, out=out))
+    report('cfg3a Mark5B 16 ch 2-bit (k_decode_flat_pipe)', ms, nfr * 10016, out.numel() * 4,
+           out.numel(), nframes=nfr)
+    del out
+
+    # cfg3b: Mark 4 64 tracks fanout 4
+    m = BITMAPS[(8, 2, 4)]
+    nfr = nbytes // 160000
+    out = torch.empty(nfr * 20000 * 32, dtype=torch.float32, device=dev)
+    ms = timeit(lambda: kernels.decode_mark4(buf, nfr, 64, 20000, m['sign_bit'], m['mag_bit'],
+                                             fill_words=160, src0=0, src_stride=160000, out=out))
+    report('cfg3b Mark4 64 tracks fanout 4 (k_decode_mark4)', ms, nfr * 160000, out.numel() * 4,
+           out.numel(), nframes=nfr)
+    del out
+
+    # cfg4a: GUPPI 8-bit, 2 pol complex, 64 channels, channels-first, 128 MiB blocks
+    npol, nchan = 2, 64
+    blk = 128 << 20
+    T = blk // (npol * nchan * 2)
+    nfr = max(1, nbytes // blk)
+    out = torch.empty(nfr * T * npol * nchan * 2, dtype=torch.float32, device=dev)
+    for ov in (0, 512):
+        ms = timeit(lambda: kernels.decode_i8_tiled(buf, nfr, _lib.LAYOUT_GUPPI_CF, npol, nchan, T, 0,
+                                                    T - ov, src0=0, src_stride=blk,
+                                                    out=out[:nfr * (T - ov) * npol * nchan * 2]))
+        nb = nfr * (T - ov) * npol * nchan * 2
+        report('cfg4a GUPPI 8-bit 2 pol 64 ch channels-first overlap %d (k_decode_i8_tiled)' % ov,
+               ms, nb, nb * 4, nb // 2, nframes=nfr)
+    del out
+
+    # cfg4b: DADA 8-bit, 2 pol complex, 1 channel (flat cast)
+    nb = nbytes // 4 * 4
+    out = torch.empty(nb, dtype=torch.float32, device=dev)
+    ms = timeit(lambda: kernels.decode_frames(buf, 1, nb, _lib.CODER_INT, 8, src0=0, out=out))
+    report('cfg4b DADA 8-bit 2 pol complex (k_decode_flat_pipe INT8)', ms, nb, nb * 4, nb // 2)
+
+
+if __name__ == '__main__':
+    main()
