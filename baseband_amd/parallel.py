@@ -58,3 +58,35 @@ def local_index(src, lo_set, hi_set, nslot, payload_nbytes, align=8):
     byte_hi = int(vals.max().item()) + int(payload_nbytes)
     local = torch.where(valid, part - byte_lo, part)
     return local, byte_lo, byte_hi
+
+
+def sharded_vdif_read(reader, rank=None, world=None, src=None, group=None):
+    """Decode this rank's time slab of a (multi-thread) VDIF stream.
+
+    The scanning rank (0) builds the dense frame index with the GPU header
+    scan and broadcasts it (ONE collective); every rank then stages only the
+    file bytes its slab needs and decodes them into its own HBM.  Returns
+    ``(data, (first_sample, last_sample))`` with ``data`` of shape
+    ``(nsample_slab, nthread, nchan)`` before squeeze/subset of channels.
+    `rank`/`world`/`src` can be given explicitly to run without
+    torch.distributed (tests, single process)."""
+    import torch.distributed as dist
+    use_dist = rank is None and dist.is_available() and dist.is_initialized()
+    if rank is None:
+        rank = dist.get_rank(group) if use_dist else 0
+        world = dist.get_world_size(group) if use_dist else 1
+    spf = reader.samples_per_frame
+    nsets = reader.shape[0] // spf
+    nslot = len(reader._thread_ids)
+    if src is None:
+        if rank == 0:
+            src = reader.build_index()
+        if use_dist and world > 1:
+            src = broadcast_frame_index(src, nsets * nslot, src_rank=0,
+                                        device=torch.device('cuda', torch.cuda.current_device()),
+                                        group=group)
+    lo, hi = frame_slab(nsets, rank, world)
+    local, byte_lo, byte_hi = local_index(src, lo, hi, nslot,
+                                          reader.header0.payload_nbytes)
+    data = reader.decode_with_index(local, byte_lo, byte_hi, hi - lo)
+    return data, (lo * spf, hi * spf)

@@ -9,6 +9,7 @@ Ordering is by events only; nothing blocks the device.
 """
 import mmap
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -32,6 +33,29 @@ def host_image(fh):
     data = fh.read()
     fh.seek(pos)
     return np.frombuffer(data, dtype=np.uint8)
+
+
+_COPY_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+_copy_pool = None
+
+
+def _parallel_copy(dst, src):
+    """dst[:] = src with several threads (NumPy releases the GIL while
+    copying): one core moves ~10 GB/s from the page cache, the host link
+    wants ~50 GB/s."""
+    global _copy_pool
+    n = len(src)
+    if n < (8 << 20) or _COPY_THREADS == 1:
+        dst[:n] = src
+        return
+    if _copy_pool is None:
+        _copy_pool = ThreadPoolExecutor(_COPY_THREADS)
+    step = -(-n // _COPY_THREADS)
+    step += -step % 4096
+    futs = [_copy_pool.submit(np.copyto, dst[o:min(n, o + step)], src[o:min(n, o + step)])
+            for o in range(0, n, step)]
+    for f in futs:
+        f.result()
 
 
 class WindowPipeline:
@@ -67,7 +91,7 @@ class WindowPipeline:
             if self._done[b] is not None:
                 self._done[b].synchronize()          # buffer b free again
             pinned, dev = self._buffers(b)
-            pinned.numpy()[:n] = self.image[lo:hi]   # page cache -> pinned (CPU)
+            _parallel_copy(pinned.numpy(), self.image[lo:hi])   # page cache -> pinned (CPU)
             with torch.cuda.stream(self._copy_stream):
                 dev[:n].copy_(pinned[:n], non_blocking=True)
                 copied = torch.cuda.Event()

@@ -211,6 +211,64 @@ class VDIFStreamReader(GPUStreamReaderBase):
             self._pending_checks.append(bad)
 
 
+    # -- frame index as a first-class object (multi-GPU sharding, parallel.py)
+    def build_index(self, first=0, last=None):
+        """Dense device index of frame sets [first, last): int64 payload
+        offsets INTO THE FILE for every (frame set, selected thread), -1 where
+        a frame is missing/invalid.  Streams the headers' windows through HBM
+        and runs bb_vdif_scan + bb_build_index on each."""
+        from ..staging import WindowPipeline
+        h0 = self.header0
+        nsets_total = self._nsample // self.samples_per_frame
+        last = nsets_total if last is None else last
+        nslot = len(self._thread_ids)
+        nthread_file = len(self._file_threads)
+        src = torch.full(((last - first) * nslot,), -1, dtype=torch.int64, device='cuda')
+        if self._thread_slot is None:
+            self._thread_slot = kernels.thread_slot_map(self._thread_ids, src.device)
+        image = self._image()
+        per_win = max(1, self.window_bytes // self._set_nbytes)
+        pipe = WindowPipeline(image, per_win * self._set_nbytes)
+        ranges, spans = [], []
+        for s in range(first, last, per_win):
+            e = min(last, s + per_win)
+            ranges.append((s * self._set_nbytes, min(e * self._set_nbytes, len(image))))
+            spans.append((s, e))
+
+        def process(dbuf, i):
+            s, e = spans[i]
+            nframes = min((e - s) * nthread_file, dbuf.numel() // self._frame_nbytes)
+            recs = kernels.vdif_scan(dbuf, nframes, self._frame_nbytes, h0.nbytes,
+                                     self._pattern, self._mask, h0['seconds'],
+                                     h0['frame_nr'] + s, self._frame_rate)
+            part = kernels.build_index(recs, e - s, nslot, self._thread_slot)
+            part = torch.where(part >= 0, part + ranges[i][0], part)
+            src[(s - first) * nslot:(e - first) * nslot] = part
+
+        pipe.run(ranges, process)
+        pipe.drain()
+        return src
+
+    def decode_with_index(self, src, byte_lo, byte_hi, nsets):
+        """Decode `nsets` frame sets given a dense index whose offsets are
+        relative to file bytes [byte_lo, byte_hi) (see parallel.local_index)."""
+        h0 = self.header0
+        nslot = len(self._thread_ids)
+        dbuf = kernels.to_device_bytes(np.asarray(self._image()[byte_lo:byte_hi]))
+        if dbuf.numel() % 4:
+            dbuf = torch.nn.functional.pad(dbuf, (0, 4 - dbuf.numel() % 4))
+        chunk = h0.nchan * (2 if self.complex_data else 1)
+        if dbuf.numel() == 0:
+            dbuf = torch.zeros(4, dtype=torch.uint8, device='cuda')
+        flat = kernels.decode_frames(
+            dbuf, nsets, h0.payload_nbytes, self._coder, self.bps, chunk=chunk,
+            nslot=nslot, src=src.to(dbuf.device), complex_data=self.complex_data,
+            fill_value=self.fill_value)
+        if self.complex_data:
+            flat = torch.view_as_complex(flat.view(-1, 2))
+        return flat.reshape((nsets * self.samples_per_frame, nslot, h0.nchan))
+
+
 def open(name, mode='rs', **kwargs):
     """Open a VDIF file for reading: ``'rb'`` gives a `VDIFFileReader`,
     ``'rs'`` a `VDIFStreamReader` (vdif/base.py:810-884).  Writing modes are
