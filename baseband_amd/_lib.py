@@ -31,6 +31,7 @@ FRAME_INVALID = 0x2
 TUNE_FLAT_VARIANT = 0
 TUNE_NT_STORES = 1
 TUNE_BLOCKS = 2
+TUNE_NT_LOADS = 3
 
 
 class BBError(RuntimeError):

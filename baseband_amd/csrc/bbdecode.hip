@@ -98,6 +98,7 @@ int device_levels(int coder, int lb, const float **p)
 std::atomic<int> g_tune_variant{2};   // 2 = persistent pipelined kernel
 std::atomic<int> g_tune_nt{1};
 std::atomic<int> g_tune_blocks{0};
+std::atomic<int> g_tune_nt_loads{0};
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
@@ -164,6 +165,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
         case BB_TUNE_NT_STORES:    g_tune_nt = value;      return BB_OK;
         case BB_TUNE_BLOCKS:       g_tune_blocks = value;  return BB_OK;
+        case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
         default: return BB_EINVAL;
     }
 }
@@ -272,6 +274,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     a.fill_re = p->fill_re;
     a.fill_im = p->fill_im;
     a.complex_data = p->complex_data;
+    a.nt_loads = g_tune_nt_loads.load();
 
     const uint64_t nwork = nfs * a.nseg;
     uint64_t blocks = nwork;

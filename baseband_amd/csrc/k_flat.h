@@ -43,6 +43,7 @@ struct bb_flat_args {
     uint32_t nslot, chunk, lchunk;
     float    fill_re, fill_im;
     int32_t  complex_data;
+    int32_t  nt_loads;      // experiment: non-temporal input loads
 };
 
 template <int BPS, int LV>
@@ -221,7 +222,8 @@ void k_decode_flat_pipe(bb_flat_args a)
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
             const uint64_t dw = (tile0 + u) * 64 + lane;
-            w[u] = (valid && u < (int)a.tpw && dw < dw_end) ? in[dw] : 0u;
+            w[u] = (valid && u < (int)a.tpw && dw < dw_end)
+                   ? (a.nt_loads ? __builtin_nontemporal_load(&in[dw]) : in[dw]) : 0u;
         }
     };
 

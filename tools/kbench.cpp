@@ -178,6 +178,22 @@ int main(int argc, char **argv)
                alg_bytes / med / 1e6 / 8000.0);
     }
 
+    for (int ntl = 0; ntl < 2; ++ntl) {
+        bb_tune(BB_TUNE_FLAT_VARIANT, 2); bb_tune(BB_TUNE_NT_STORES, 1); bb_tune(BB_TUNE_BLOCKS, 0);
+        bb_tune(BB_TUNE_NT_LOADS, ntl);
+        std::vector<double> t;
+        for (int r = 0; r < reps + 1; ++r) {
+            CK(hipEventRecord(e0));
+            bb_decode_frames(d_in, in_bytes, nullptr, nframes, &p, d_out, out_elems, nullptr);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            if (r) t.push_back(time_ms(e0, e1));
+        }
+        std::sort(t.begin(), t.end());
+        printf("decode pipe nt_loads=%d: median %.3f ms  %.1f GB/s alg  frac8TB=%.3f\n", ntl,
+               t[t.size() / 2], alg_bytes / t[t.size() / 2] / 1e6, alg_bytes / t[t.size() / 2] / 1e6 / 8000.0);
+    }
+    bb_tune(BB_TUNE_NT_LOADS, 0);
+
     // spot check (2-bit VDIF only): first and last frame against a host LUT
     if (bps == 2) {
         bb_tune(BB_TUNE_FLAT_VARIANT, 0); bb_tune(BB_TUNE_NT_STORES, 0); bb_tune(BB_TUNE_BLOCKS, 0);
