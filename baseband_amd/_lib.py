@@ -118,6 +118,8 @@ SIGNATURES = [
     ('bb_init', C.c_int, []),
     ('bb_get_levels', C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _sz]),
     ('bb_vdif_scan', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp]),
+    ('bb_vdif_locate', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
+    ('bb_vdif_scan_at', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_mark5b_scan', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp]),
     ('bb_build_index', C.c_int, [_vp, _sz, _vp, C.c_int, _vp, _sz, _vp]),
     ('bb_decode_frames', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, _sz, _vp]),

@@ -277,14 +277,24 @@ class GPUStreamReaderBase:
         if count > samples_left:
             raise EOFError("cannot read from beyond end of input.")
 
+        if self._pending_warning:
+            warnings.warn(self._pending_warning)
+            self._pending_warning = None
         spf = self.samples_per_frame
         first, off0 = divmod(self.offset, spf)
         last = -(-(self.offset + count) // spf) if count else first
         data = self._read_sets(first, last)             # (nsets*spf, *unsliced)
+        if not self._resolve_checks():
+            # verify='fix': frames are missing or out of place.  Build the
+            # corruption-tolerant index (byte-granular header search) and
+            # decode again through it.
+            self._relocate()
+            if self.offset + count > self.shape[0]:
+                raise EOFError("cannot read from beyond end of input.")
+            data = self._read_sets(first, last)
         data = data[off0:off0 + count]
         data = self._squeeze_and_subset(data)
         self.offset += count
-        self._resolve_checks()
         if out is None:
             return data
         if isinstance(out, torch.Tensor):
@@ -327,18 +337,31 @@ class GPUStreamReaderBase:
 
     def _resolve_checks(self):
         """Look at the verification counters the windows left on the device
-        (one host sync per read, none when verify is False)."""
+        (one host sync per read, none when verify is False).  Returns False
+        when verify='fix' found a problem that `_relocate` can repair."""
         checks, self._pending_checks = self._pending_checks, []
         if not self.verify or not checks:
-            return
+            return True
         nbad = int(torch.stack(checks).sum().item())
         if nbad:
-            msg = ("{} frame header(s) failed verification (bad sync/invariants "
-                   "or unexpected time index)".format(nbad))
+            msg = ("problem loading frame: {} frame header(s) failed verification "
+                   "(bad sync/invariants or unexpected time index)".format(nbad))
             if self.verify == 'fix':
+                if self._can_relocate and not self._relocated:
+                    warnings.warn(msg + "; searching for frames byte by byte, "
+                                  "missing ones are set to fill_value.")
+                    return False
                 warnings.warn(msg + "; affected samples were set to fill_value.")
             else:
                 raise ValueError("wrong frame number. " + msg)
+        return True
+
+    _can_relocate = False
+    _relocated = False
+    _pending_warning = None
+
+    def _relocate(self):
+        raise NotImplementedError
 
     def __getstate__(self):
         raise TypeError("pickling of GPU stream readers is not supported yet")

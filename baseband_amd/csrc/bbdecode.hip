@@ -187,6 +187,37 @@ int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
     return BB_OK;
 }
 
+int bb_vdif_locate(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
+                   int64_t *d_offsets, size_t cap, unsigned long long *d_count, void *stream)
+{
+    if (!d_buf || !p || !d_offsets || !d_count) return BB_EINVAL;
+    if (p->header_nbytes != 32 && p->header_nbytes != 16) return BB_EINVAL;
+    if (p->frame_nbytes < p->header_nbytes) return BB_EINVAL;
+    if ((uintptr_t)d_buf & 3) return BB_EINVAL;
+    if (nbytes < p->frame_nbytes) return BB_OK;
+    uint64_t blocks = (nbytes + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_vdif_locate, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_offsets, (uint64_t)cap, d_count);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_vdif_scan_at(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
+                    const int64_t *d_offsets, size_t nframes, bb_frame_rec *d_recs, void *stream)
+{
+    if (!d_buf || !p || !d_offsets || !d_recs) return BB_EINVAL;
+    if (p->header_nbytes != 32 && p->header_nbytes != 16) return BB_EINVAL;
+    if ((uintptr_t)d_buf & 3) return BB_EINVAL;
+    if (nframes == 0) return BB_OK;
+    const uint64_t blocks = ((uint64_t)nframes + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 0x7fffffffull) return BB_ERANGE;
+    hipLaunchKernelGGL(k_vdif_scan_at, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_offsets, d_recs, (uint64_t)nframes);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
 int bb_mark5b_scan(const void *d_buf, size_t nbytes, const bb_mark5b_scan_params *p,
                    bb_frame_rec *d_recs, size_t nframes, void *stream)
 {

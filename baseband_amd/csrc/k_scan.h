@@ -66,6 +66,94 @@ void k_vdif_scan(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
     }
 }
 
+// Unaligned little-endian dword at byte position pos, assembled from the two
+// aligned dwords around it (positions found by the byte-granular locate
+// kernel need not be aligned once bytes went missing from a file).
+__device__ __forceinline__ uint32_t bb_load_u32_any(const uint8_t *buf, uint64_t nbytes, uint64_t pos)
+{
+    const uint64_t a = pos & ~3ull;
+    const uint32_t sh = (uint32_t)(pos & 3) * 8;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(buf + a);
+    const uint32_t lo = (a + 4 <= nbytes) ? w[0] : 0u;
+    if (sh == 0) return lo;
+    const uint32_t hi = (a + 8 <= nbytes) ? w[1] : 0u;
+    return (lo >> sh) | (hi << (32 - sh));
+}
+
+__device__ __forceinline__ bool bb_vdif_header_at(const uint8_t *buf, uint64_t nbytes,
+                                                  const bb_vdif_scan_params &p, uint64_t pos)
+{
+    const int nwords = (int)(p.header_nbytes >> 2);
+    if (pos + p.header_nbytes > nbytes) return false;
+    // most selective word first (word 2: version, lg2_nchan, frame_length)
+    if (((bb_load_u32_any(buf, nbytes, pos + 8) ^ p.pattern[2]) & p.mask[2]) != 0) return false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (k == 2 || k >= nwords || p.mask[k] == 0) continue;
+        if (((bb_load_u32_any(buf, nbytes, pos + 4 * k) ^ p.pattern[k]) & p.mask[k]) != 0) return false;
+    }
+    return true;
+}
+
+// Byte-granular search for frame headers: position pos is reported when the
+// stream-invariant pattern matches there, the whole frame fits in the buffer,
+// and another header sits exactly one frame later (or two, when the next
+// header is damaged in place; for the last frame in the buffer: one earlier) -- the `check` logic of locate_frames
+// (base/base.py:181-335) as used by VDIF's _bad_frame recovery
+// (vdif/base.py:536-755).  Matches are appended unordered.
+__global__ __launch_bounds__(BB_BLOCK)
+void k_vdif_locate(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
+                   int64_t *out, uint64_t cap, unsigned long long *count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
+    for (uint64_t pos = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+         pos + p.frame_nbytes <= nbytes; pos += stride) {
+        if (!bb_vdif_header_at(buf, nbytes, p, pos)) continue;
+        const uint64_t next = pos + p.frame_nbytes;
+        bool ok;
+        if (next + p.header_nbytes <= nbytes) {
+            ok = bb_vdif_header_at(buf, nbytes, p, next);
+            // the following header may be damaged in place (no bytes lost):
+            // then the one after it is still where the stride says
+            if (!ok && next + p.frame_nbytes + p.header_nbytes <= nbytes)
+                ok = bb_vdif_header_at(buf, nbytes, p, next + p.frame_nbytes);
+        } else {
+            ok = pos < p.frame_nbytes || bb_vdif_header_at(buf, nbytes, p, pos - p.frame_nbytes);
+        }
+        if (!ok) continue;
+        const unsigned long long i = atomicAdd(count, 1ull);
+        if (i < cap) out[i] = (int64_t)pos;
+    }
+}
+
+// Header scan at explicit (possibly unaligned) frame offsets: same record as
+// k_vdif_scan, one lane per frame.
+__global__ __launch_bounds__(BB_BLOCK)
+void k_vdif_scan_at(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
+                    const int64_t *offsets, bb_frame_rec *recs, uint64_t nframes)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (i >= nframes) return;
+    const uint64_t off = (uint64_t)offsets[i];
+    const bool ok = bb_vdif_header_at(buf, nbytes, p, off) && off + p.frame_nbytes <= nbytes;
+    const uint32_t w0 = bb_load_u32_any(buf, nbytes, off);
+    const uint32_t w1 = bb_load_u32_any(buf, nbytes, off + 4);
+    const uint32_t w3 = bb_load_u32_any(buf, nbytes, off + 12);
+    const int32_t seconds = (int32_t)(w0 & 0x3fffffffu);
+    const int32_t frame_nr = (int32_t)(w1 & 0x00ffffffu);
+    int64_t tidx = p.frame_rate > 0
+        ? (int64_t)(seconds - p.ref_seconds) * p.frame_rate + (frame_nr - p.ref_frame_nr)
+        : (int64_t)i;
+    if (tidx > 0x7fffffffll) tidx = 0x7fffffffll;
+    if (tidx < -0x7fffffffll) tidx = -0x7fffffffll;
+    bb_frame_rec r;
+    r.payload_offset = (int64_t)(off + p.header_nbytes);
+    r.time_index = (int32_t)tidx;
+    r.thread_id = (int16_t)((w3 >> 16) & 0x3ffu);
+    r.flags = (uint16_t)((ok ? BB_FRAME_OK : 0u) | ((w0 >> 31) ? BB_FRAME_INVALID : 0u));
+    *reinterpret_cast<bb_u4 *>(&recs[i]) = *reinterpret_cast<const bb_u4 *>(&r);
+}
+
 __device__ __forceinline__ int bb_bcd_decode(uint32_t v, int ndigit)
 {
     int r = 0, m = 1;

@@ -64,6 +64,45 @@ def vdif_scan(dbuf, nframes, frame_nbytes, header_nbytes, pattern, mask,
     return recs
 
 
+def _vdif_params(frame_nbytes, header_nbytes, pattern, mask, ref_seconds,
+                 ref_frame_nr, frame_rate, first_offset=0):
+    p = _lib.VDIFScanParams()
+    p.first_offset = first_offset
+    p.frame_nbytes = frame_nbytes
+    p.header_nbytes = header_nbytes
+    for i in range(8):
+        p.pattern[i] = int(pattern[i]) if i < len(pattern) else 0
+        p.mask[i] = int(mask[i]) if i < len(mask) else 0
+    p.ref_seconds = ref_seconds
+    p.ref_frame_nr = ref_frame_nr
+    p.frame_rate = frame_rate
+    return p
+
+
+def vdif_locate(dbuf, nbytes, frame_nbytes, header_nbytes, pattern, mask):
+    """Byte-granular header search -> sorted int64 device tensor of frame
+    offsets (corruption-tolerant discovery)."""
+    p = _vdif_params(frame_nbytes, header_nbytes, pattern, mask, 0, 0, 0)
+    cap = nbytes // frame_nbytes + 16
+    offs = torch.empty(cap, dtype=torch.int64, device=dbuf.device)
+    count = torch.zeros(1, dtype=torch.int64, device=dbuf.device)
+    check(lib.bb_vdif_locate(_ptr(dbuf), nbytes, C.byref(p), _ptr(offs), cap,
+                             _ptr(count), _stream()), 'bb_vdif_locate')
+    n = min(int(count.item()), cap)
+    return torch.sort(offs[:n]).values
+
+
+def vdif_scan_at(dbuf, nbytes, offsets, frame_nbytes, header_nbytes, pattern,
+                 mask, ref_seconds, ref_frame_nr, frame_rate):
+    p = _vdif_params(frame_nbytes, header_nbytes, pattern, mask, ref_seconds,
+                     ref_frame_nr, frame_rate)
+    n = offsets.numel()
+    recs = torch.empty((n, 4), dtype=torch.int32, device=dbuf.device)
+    check(lib.bb_vdif_scan_at(_ptr(dbuf), nbytes, C.byref(p), _ptr(offsets), n,
+                              _ptr(recs), _stream()), 'bb_vdif_scan_at')
+    return recs
+
+
 def mark5b_scan(dbuf, nframes, ref_seconds, ref_frame_nr, frame_rate,
                 first_offset=0):
     p = _lib.Mark5BScanParams()

@@ -106,3 +106,33 @@ class WindowPipeline:
         for ev in self._done:
             if ev is not None:
                 ev.synchronize()
+
+
+def upload(image, device='cuda', chunk_bytes=64 << 20):
+    """Whole host image -> one device tensor (with 256 bytes of slack), moved
+    in pinned chunks on a side stream while the next chunk is being copied by
+    the CPU.  Used when a file is kept resident in HBM."""
+    device = torch.device(device)
+    n = len(image)
+    dev = torch.empty(n + 256, dtype=torch.uint8, device=device)
+    dev[n:] = 0
+    stream = torch.cuda.Stream(device=device)
+    pinned = [torch.empty(min(chunk_bytes, max(n, 1)), dtype=torch.uint8, pin_memory=True)
+              for _ in range(2)]
+    events = [None, None]
+    for i, lo in enumerate(range(0, n, chunk_bytes)):
+        hi = min(n, lo + chunk_bytes)
+        b = i % 2
+        if events[b] is not None:
+            events[b].synchronize()
+        _parallel_copy(pinned[b].numpy(), image[lo:hi])
+        with torch.cuda.stream(stream):
+            dev[lo:hi].copy_(pinned[b][:hi - lo], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        events[b] = ev
+    torch.cuda.current_stream(device).wait_stream(stream)
+    for ev in events:
+        if ev is not None:
+            ev.synchronize()
+    return dev

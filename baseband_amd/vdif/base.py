@@ -138,11 +138,70 @@ class VDIFStreamReader(GPUStreamReaderBase):
         self._start_time = header0.get_time(frame_rate=self._frame_rate)
         self._coder = (_lib.CODER_MARK5B if header0.edv == 0xab
                        else _lib.CODER_VDIF)
-        last = self._last_header()
-        self._nsample = (self._get_index(last) + 1) * self.samples_per_frame
+        self._resident = None
+        try:
+            last = self._last_header()
+            self._nsample = (self._get_index(last) + 1) * self.samples_per_frame
+        except HeaderNotFoundError:
+            if self.verify != 'fix':
+                raise
+            self._nsample = 0
+            self._relocate()            # bytes are missing: find frames by search
+            self._pending_warning = (
+                "problem loading frame: no header at the expected end of the "
+                "file; frames were located by a byte-by-byte search and "
+                "missing ones are set to fill_value.")
+
+    _can_relocate = True
 
     def _image(self):
         return self.fh_raw.image()
+
+    def _relocate(self):
+        """Corruption-tolerant index: keep the file resident in
+        HBM, find every intact frame with the byte-granular header search
+        (bb_vdif_locate: pattern + a header one frame later), scan those
+        headers and place the frames by (time index, thread).  Frames that
+        are missing or damaged simply have no entry and decode to fill_value
+        -- what the reference's _bad_frame achieves frame set by frame set
+        (vdif/base.py:536-755)."""
+        from ..staging import upload
+        kernels.require_gpu()
+        h0 = self.header0
+        image = self._image()
+        dev = upload(image)
+        n = len(image)
+        offs = kernels.vdif_locate(dev, n, self._frame_nbytes, h0.nbytes,
+                                   self._pattern, self._mask)
+        recs = kernels.vdif_scan_at(dev, n, offs, self._frame_nbytes, h0.nbytes,
+                                    self._pattern, self._mask, h0['seconds'],
+                                    h0['frame_nr'], self._frame_rate)
+        if self._thread_slot is None:
+            self._thread_slot = kernels.thread_slot_map(self._thread_ids, dev.device)
+        ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
+        same = (recs[:, 3] & 0xffff) == h0['thread_id']
+        sel = recs[:, 2][ok & same]
+        nsets = int(sel.max().item()) + 1 if sel.numel() else 0
+        src = kernels.build_index(recs, nsets, len(self._thread_ids), self._thread_slot)
+        self._resident = (dev, src)
+        self._nsample = nsets * self.samples_per_frame
+        self._relocated = True
+
+    def _read_sets(self, first, last):
+        if self._resident is None:
+            return super()._read_sets(first, last)
+        dev, src = self._resident
+        h0 = self.header0
+        nslot = len(self._thread_ids)
+        nsets = last - first
+        chunk = h0.nchan * (2 if self.complex_data else 1)
+        flat = kernels.decode_frames(
+            dev, nsets, h0.payload_nbytes, self._coder, self.bps, chunk=chunk,
+            nslot=nslot, src=src[first * nslot:last * nslot].contiguous(),
+            complex_data=self.complex_data, fill_value=self.fill_value)
+        if self.complex_data:
+            flat = torch.view_as_complex(flat.view(-1, 2))
+        return flat.reshape((nsets * self.samples_per_frame,) + tuple(self._decode_shape))
 
     def _get_index(self, header):
         """Frame-set index relative to header0 (vdif/base.py:386-390)."""
@@ -164,6 +223,29 @@ class VDIFStreamReader(GPUStreamReaderBase):
                    zip(words, self._pattern, self._mask)):
                 continue
             return VDIFHeader(words, edv=self.header0.edv, verify=False)
+        # the fixed-stride positions hold no header (bytes went missing
+        # somewhere): search the tail byte by byte, like locate_frames going
+        # backwards (base/base.py:181-335; vdif/base.py:492-517)
+        image = self._image()
+        n = len(image)
+        lo = max(0, n - look * self._frame_nbytes)
+        tail = np.asarray(image[lo:n])
+        if len(tail) >= self.header0.nbytes:
+            win = np.lib.stride_tricks.sliding_window_view(tail, 4)
+            w2 = np.ascontiguousarray(win[8:]).view('<u4')[:, 0]      # word 2 at p + 8
+            cand = np.nonzero(((w2 ^ np.uint32(self._pattern[2]))
+                               & np.uint32(self._mask[2])) == 0)[0]
+            nw = self.header0.nbytes // 4
+            for p in cand[::-1]:
+                if lo + p + self._frame_nbytes > n:
+                    continue                    # incomplete frame
+                words = np.frombuffer(tail[p:p + 4 * nw].tobytes(), '<u4')
+                if any(((int(w) ^ pt) & m) for w, pt, m in
+                       zip(words, self._pattern, self._mask)):
+                    continue
+                if ((int(words[3]) >> 16) & 0x3ff) != self.header0['thread_id']:
+                    continue
+                return VDIFHeader(words, edv=self.header0.edv, verify=False)
         raise HeaderNotFoundError(
             "corrupt VDIF? No thread_id={0} frame in last {1} bytes."
             .format(self.header0['thread_id'], look * self._frame_nbytes))

@@ -123,6 +123,27 @@ int bb_vdif_scan(const void *d_buf, size_t nbytes,
                  bb_frame_rec *d_recs, size_t nframes, void *stream);
 
 /*
+ * Corruption-tolerant frame discovery: byte-granular
+ * search for VDIF headers -- the masked-pattern search of
+ * VLBIFileReaderBase.locate_frames (base/base.py:181-335) that the reference's
+ * _bad_frame recovery relies on (vdif/base.py:536-755).  A position is reported
+ * when the stream-invariant pattern matches, the complete frame fits, and
+ * another header lies exactly one frame later (for the last frame: earlier).
+ * Offsets are appended UNORDERED to d_offsets (capacity `cap`); *d_count
+ * (device, caller-zeroed) receives the total number found.  bb_vdif_scan_at()
+ * then produces the usual records for explicit, possibly unaligned offsets.
+ */
+int bb_vdif_locate(const void *d_buf, size_t nbytes,
+                   const bb_vdif_scan_params *params,
+                   int64_t *d_offsets, size_t cap,
+                   unsigned long long *d_count, void *stream);
+
+int bb_vdif_scan_at(const void *d_buf, size_t nbytes,
+                    const bb_vdif_scan_params *params,
+                    const int64_t *d_offsets, size_t nframes,
+                    bb_frame_rec *d_recs, void *stream);
+
+/*
  * Mark 5B header scan (mark5b/header.py:60-68,91-97; mark5b/base.py:206-213):
  * sync word 0xABADDEED, frame_nr, BCD seconds; fixed 10016-byte frames.  The
  * invalid-frame test (payload == 0x11223344 everywhere,

@@ -621,6 +621,77 @@ def gen_gsb():
     print('gsb phased', data.shape, 'oracle == reference')
 
 
+def gen_vdif_corrupt():
+    """File-surgery cases of the reference's own corrupt-file tests
+    (vdif/tests/test_corrupt_files.py:13-156): a tripled sample.vdif with
+    whole frames or byte ranges removed, read by the reference with
+    verify='fix'.  Stored: the intact base file once, and per case the removed
+    byte range(s), the sha256 of what the reference returns and which frames
+    came back as fill."""
+    import warnings
+    with vdif.open(SAMPLE_VDIF, 'rs') as fs:
+        bio = KeepBytesIO()
+        with vdif.open(bio, 'ws', header0=fs.header0, nthread=8) as fw:
+            data = fs.read()
+            for i in range(3):
+                fw.write(data)
+    base = bio.value()
+    full = np.concatenate([data, data, data]).reshape(-1, 8, 1)
+    write_synth('vdif_triple', base, full, nthread=8, nchan=1, bps=2,
+                complex_data=False, edv=3, samples_per_frame=20000, nframes=6,
+                frame_rate=1600)
+    fn = 5032
+    cases = []
+    frames = [36, (46, 48), [30, 45], (8, 16), 0, (4, 12)]
+    for m in frames:
+        if isinstance(m, tuple):
+            idx = list(range(*m))
+        elif isinstance(m, list):
+            idx = m
+        else:
+            idx = [m]
+        cases.append(dict(kind='frames', frames=idx,
+                          remove=[[i * fn, (i + 1) * fn] for i in idx]))
+    for lo, hi in ((fn * 26, fn * 26 + 1), (fn * 26 + 50, fn * 26 + 60),
+                   (fn * 27 + 50, fn * 29 + 700), (fn * 31 + 10, fn * 31 + 20),
+                   (fn * 32, fn * 32 + 10), (fn * 48 - 1, fn * 48)):
+        cases.append(dict(kind='bytes', remove=[[lo, hi]]))
+    # headers damaged in place (no bytes lost): sync pattern / frame length
+    cases.append(dict(kind='overwrite', remove=[], flip=[fn * 27 + 21]))
+    cases.append(dict(kind='overwrite', remove=[], flip=[fn * 12 + 22]))
+    cases.append(dict(kind='overwrite', remove=[], flip=[fn * 29 + 20, fn * 30 + 23]))
+    arr = np.frombuffer(base, np.uint8)
+    for c in cases:
+        keep = np.ones(len(arr), bool)
+        for lo, hi in c['remove']:
+            keep[lo:hi] = False
+        work = arr.copy()
+        for pos in c.get('flip', []):
+            work[pos] ^= 0x55
+        blob = work[keep].tobytes()
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                with vdif.open(io.BytesIO(blob), 'rs', squeeze=False) as fr:
+                    got = fr.read()
+        except Exception as exc:
+            print('reference cannot read case', c, '->', type(exc).__name__)
+            c['reference_fails'] = type(exc).__name__
+            continue
+        c['shape'] = list(got.shape)
+        c['sha256'] = sha(got)
+        # which (frame set, thread) blocks came back as zeros
+        byframe = got.reshape(-1, 20000, 8).transpose(0, 2, 1).reshape(-1, 20000)
+        ref = full[:got.shape[0]].reshape(-1, 20000, 8).transpose(0, 2, 1).reshape(-1, 20000)
+        bad = [int(i) for i in range(len(byframe)) if not np.array_equal(byframe[i], ref[i])]
+        assert all(np.all(byframe[i] == 0) for i in bad)
+        c['zeroed'] = bad           # index = frame set * 8 + thread
+    cases = [c for c in cases if 'reference_fails' not in c]
+    with open(os.path.join(GOLD, 'vdif_corrupt_cases.json'), 'w') as f:
+        json.dump(cases, f, indent=1)
+    print('vdif corrupt:', len(cases), 'cases;', [c['zeroed'] for c in cases])
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
     steps = [('levels', gen_levels), ('vdif_samples', gen_vdif_samples),
@@ -628,7 +699,7 @@ if __name__ == '__main__':
              ('vdif_invalid', gen_vdif_invalid), ('mark5b_synth', gen_mark5b_synth),
              ('mark4_bitmaps', gen_mark4_bitmaps), ('mark4_samples', gen_mark4_samples),
              ('mark4_synth', gen_mark4_synth), ('guppi', gen_guppi), ('dada', gen_dada),
-             ('gsb', gen_gsb)]
+             ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:
