@@ -79,6 +79,17 @@ class VLBIFileReaderBase(FileBase):
         return self._image
 
 
+def _reopen(cls, name, kwargs, offset):
+    fh = io.open(name, 'rb')
+    try:
+        self = cls(fh, **kwargs)
+    except Exception:
+        fh.close()
+        raise
+    self.offset = offset
+    return self
+
+
 def _apply_squeeze(shape):
     return tuple(s for s in shape if s > 1)
 
@@ -363,5 +374,13 @@ class GPUStreamReaderBase:
     def _relocate(self):
         raise NotImplementedError
 
-    def __getstate__(self):
-        raise TypeError("pickling of GPU stream readers is not supported yet")
+    # -- pickling: reopen by file name at the saved offset
+    # (base/base.py:123-151,1020-1032); device buffers are re-creatable
+    def __reduce__(self):
+        init = getattr(self, '_init_args', None)
+        name = getattr(getattr(self.fh_raw, 'fh_raw', None), 'name', None)
+        if init is None or not isinstance(name, str):
+            raise TypeError("can only pickle readers opened from a named file")
+        if self.closed:
+            raise TypeError("cannot pickle a closed stream reader")
+        return (_reopen, (type(self), name, init, self.offset))

@@ -119,7 +119,9 @@ def open(name, mode='rs', **kwargs):
     try:
         if mode == 'rb':
             return DADAFileReader(fh, **kwargs)
-        return DADAStreamReader(fh, **kwargs)
+        reader = DADAStreamReader(fh, **kwargs)
+        reader._init_args = dict(kwargs)
+        return reader
     except Exception:
         if fh is not name:
             fh.close()

@@ -100,7 +100,9 @@ def open(name, mode='rs', **kwargs):
     try:
         if mode == 'rb':
             return GUPPIFileReader(fh, **kwargs)
-        return GUPPIStreamReader(fh, **kwargs)
+        reader = GUPPIStreamReader(fh, **kwargs)
+        reader._init_args = dict(kwargs)
+        return reader
     except Exception:
         if fh is not name:
             fh.close()

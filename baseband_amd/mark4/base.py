@@ -207,7 +207,9 @@ def open(name, mode='rs', **kwargs):
     try:
         if mode == 'rb':
             return Mark4FileReader(fh, **kwargs)
-        return Mark4StreamReader(fh, **kwargs)
+        reader = Mark4StreamReader(fh, **kwargs)
+        reader._init_args = dict(kwargs)
+        return reader
     except Exception:
         if fh is not name:
             fh.close()

@@ -181,7 +181,9 @@ def open(name, mode='rs', **kwargs):
     try:
         if mode == 'rb':
             return Mark5BFileReader(fh, **kwargs)
-        return Mark5BStreamReader(fh, **kwargs)
+        reader = Mark5BStreamReader(fh, **kwargs)
+        reader._init_args = dict(kwargs)
+        return reader
     except Exception:
         if fh is not name:
             fh.close()

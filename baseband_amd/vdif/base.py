@@ -364,7 +364,9 @@ def open(name, mode='rs', **kwargs):
             raise TypeError("got unexpected arguments {}".format(kwargs.keys()))
         return VDIFFileReader(fh)
     try:
-        return VDIFStreamReader(fh, **kwargs)
+        reader = VDIFStreamReader(fh, **kwargs)
+        reader._init_args = dict(kwargs)
+        return reader
     except Exception:
         if fh is not name:
             fh.close()

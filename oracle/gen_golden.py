@@ -621,6 +621,41 @@ def gen_gsb():
     print('gsb phased', data.shape, 'oracle == reference')
 
 
+def gen_vdif_edv_ab():
+    """Mark 5B frames wrapped in VDIF (EDV 0xab, vdif/payload.py:151-154):
+    the four frames of sample.m5b converted with the reference's
+    VDIFFrame.from_mark5b_frame and read back as a VDIF stream."""
+    bio = KeepBytesIO()
+    with mark5b.open(SAMPLE_MARK5B, 'rb', kday=56000, nchan=8, bps=2) as fh:
+        fh.find_header()
+        for i in range(4):
+            m5f = fh.read_frame()
+            vdif.VDIFFrame.from_mark5b_frame(m5f).tofile(bio)
+    blob = bio.getvalue()
+    # the reference cannot open such a file as a STREAM (its invariant_pattern
+    # trips over the fixed complex_data of VDIFMark5BHeader), so the pin is at
+    # frame level: VDIFFrame.fromfile(...).data for every frame
+    parts = []
+    with vdif.open(io.BytesIO(blob), 'rb') as fb:
+        for i in range(4):
+            fr = fb.read_frame()
+            assert fr.header.edv == 0xab
+            if i == 0:
+                h0w = [int(w) for w in fr.header.words]
+            parts.append(fr.data)
+    back = np.concatenate(parts)[:, np.newaxis, :]
+    info = dict(nthread=1, nchan=8, bps=2, complex_data=False, edv=0xab,
+                samples_per_frame=5000, nframes=4, frame_rate=6400,
+                header0_words=h0w, thread_ids=[0], frame_level_only=True)
+    write_synth('vdif_edv_ab', blob, back, **info)
+    with mark5b.open(SAMPLE_MARK5B, 'rs', sample_rate=32 * u.MHz, kday=56000, nchan=8,
+                     bps=2) as f5:
+        assert np.array_equal(f5.read(), back[:, 0])
+    out, _ = orc.vdif_read(np.frombuffer(blob, np.uint8), frame_rate=6400)
+    assert np.array_equal(out.view(np.uint32), back.view(np.uint32))
+    print('vdif edv 0xab', back.shape, 'oracle == reference')
+
+
 def gen_vdif_corrupt():
     """File-surgery cases of the reference's own corrupt-file tests
     (vdif/tests/test_corrupt_files.py:13-156): a tripled sample.vdif with
@@ -699,7 +734,8 @@ if __name__ == '__main__':
              ('vdif_invalid', gen_vdif_invalid), ('mark5b_synth', gen_mark5b_synth),
              ('mark4_bitmaps', gen_mark4_bitmaps), ('mark4_samples', gen_mark4_samples),
              ('mark4_synth', gen_mark4_synth), ('guppi', gen_guppi), ('dada', gen_dada),
-             ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt)]
+             ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt),
+             ('vdif_edv_ab', gen_vdif_edv_ab)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

@@ -44,7 +44,8 @@ VDIF_CASES = ['sample_vdif', 'sample_mwa_vdif', 'sample_arochime_vdif',
               'sample_bps1_vdif', 'vdif_cfg2_small', 'vdif_cfg3_small',
               'vdif_bps1_c4', 'vdif_bps4_cplx_t2', 'vdif_bps8_real_c2',
               'vdif_bps8_cplx_t4', 'vdif_bps2_t8_c1', 'vdif_legacy_bps2',
-              'vdif_bps4_t2_c1', 'vdif_invalid_fill0', 'vdif_invalid_fillm999']
+              'vdif_bps4_t2_c1', 'vdif_invalid_fill0', 'vdif_invalid_fillm999',
+              'vdif_edv_ab', 'vdif_triple']
 
 
 @pytest.mark.parametrize('name', VDIF_CASES)

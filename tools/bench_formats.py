@@ -53,6 +53,14 @@ def main():
     buf = torch.randint(0, 2 ** 31 - 1, (nbytes // 4 + 1024,), generator=g, device=dev,
                         dtype=torch.int64).to(torch.int32).view(torch.uint8)
 
+    # cfg1 at this size, for comparison with the other cases
+    nfr = nbytes // 8032
+    out = torch.empty(nfr * 32000, dtype=torch.float32, device=dev)
+    ms = timeit(lambda: kernels.decode_frames(buf, nfr, 8000, 0, 2, src0=32, src_stride=8032, out=out))
+    report('cfg1 VDIF 1 thread x 1 ch 2-bit real (k_decode_flat_pipe)', ms, nfr * 8032,
+           out.numel() * 4, out.numel(), nframes=nfr)
+    del out
+
     # cfg0-like: sample.vdif structure, 8 threads x 1 channel, 2-bit real, 5032-byte frames
     fn_, pn, nth = 5032, 5000, 8
     nsets = nbytes // (fn_ * nth)
