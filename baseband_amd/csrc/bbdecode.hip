@@ -95,7 +95,7 @@ int device_levels(int coder, int lb, const float **p)
 }
 
 // ---- tuning ----------------------------------------------------------------
-std::atomic<int> g_tune_variant{2};   // 2 = persistent pipelined kernel
+std::atomic<int> g_tune_variant{3};   // 3 = persistent pipelined kernel, 2 waves x long runs
 std::atomic<int> g_tune_nt{1};
 std::atomic<int> g_tune_blocks{0};
 std::atomic<int> g_tune_nt_loads{0};
@@ -107,10 +107,10 @@ void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gath
     else    hipLaunchKernelGGL((k_decode_gather<BPS, LV, false>), grid, dim3(BB_BLOCK), lds, st, a);
 }
 
-template <int BPS, int LV>
+template <int BPS, int LV, int NW, int TPW>
 void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
-#define BB_L(OM, NT) hipLaunchKernelGGL((k_decode_flat_pipe<BPS, LV, OM, NT>), grid, dim3(BB_BLOCK), 0, st, a)
+#define BB_L(OM, NT) hipLaunchKernelGGL((k_decode_flat_pipe<BPS, LV, OM, NT, NW, TPW>), grid, dim3(NW * BB_WAVE), 0, st, a)
     if (om == BB_OUT_FLAT)       { if (nt) BB_L(BB_OUT_FLAT, true);    else BB_L(BB_OUT_FLAT, false); }
     else if (om == BB_OUT_ROWS4) { if (nt) BB_L(BB_OUT_ROWS4, true);   else BB_L(BB_OUT_ROWS4, false); }
     else                         { if (nt) BB_L(BB_OUT_SCATTER, true); else BB_L(BB_OUT_SCATTER, false); }
@@ -326,7 +326,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         return BB_OK;
     }
 
-    if (om == BB_OUT_SCATTER && d_src && g_tune_variant.load() != 0
+    if (om == BB_OUT_SCATTER && d_src && g_tune_variant.load() >= 2
         && (size_t)p->nslot * 260 + 1024 + 64 <= 48 * 1024) {
         // narrow chunks: assemble output rows in LDS (k_gather.h)
         bb_gather_args ga;
@@ -358,20 +358,42 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         return BB_OK;
     }
 
-    if (g_tune_variant.load() == 2) {
-        // persistent pipelined form: default grid = 8 workgroups per CU
-        uint64_t b2 = nwork;
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : 4096;
+    if (g_tune_variant.load() >= 2) {
+        // persistent pipelined form.  Geometry (waves per workgroup x tiles
+        // per wave) is chosen so that a wave writes a long contiguous run:
+        // 2 waves x 16 tiles (64 KiB per wave at 2 bits).  Variant 2 keeps the
+        // 4 x 8 geometry; 2 x 32 tiles was tried for 8-bit data and lost 27 %.
+        const bool wide = g_tune_variant.load() >= 3;
+        const int nw = wide ? 2 : 4;
+        const int tpw_max = wide ? 16 : 8;
+        const uint64_t seg_max = (uint64_t)nw * tpw_max;
+        a.nseg = (ntiles + seg_max - 1) / seg_max;
+        a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
+        a.tpw = (a.seg_tiles + nw - 1) / nw;
+        uint64_t b2 = nfs * a.nseg;
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : (uint64_t)(wide ? 16384 : 4096);
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
-        switch (p->bps) {
-            case 1: launch_flat_pipe<1, BB_LV_REG>(om, nt, g2, st, a); break;
-            case 2: launch_flat_pipe<2, BB_LV_REG>(om, nt, g2, st, a); break;
-            case 4: launch_flat_pipe<4, BB_LV_LDS>(om, nt, g2, st, a); break;
-            default:
-                if (p->coder == BB_CODER_INT) launch_flat_pipe<8, BB_LV_INT8>(om, nt, g2, st, a);
-                else                          launch_flat_pipe<8, BB_LV_LDS>(om, nt, g2, st, a);
-                break;
+        if (!wide) {
+            switch (p->bps) {
+                case 1: launch_flat_pipe<1, BB_LV_REG, 4, 8>(om, nt, g2, st, a); break;
+                case 2: launch_flat_pipe<2, BB_LV_REG, 4, 8>(om, nt, g2, st, a); break;
+                case 4: launch_flat_pipe<4, BB_LV_LDS, 4, 8>(om, nt, g2, st, a); break;
+                default:
+                    if (p->coder == BB_CODER_INT) launch_flat_pipe<8, BB_LV_INT8, 4, 8>(om, nt, g2, st, a);
+                    else                          launch_flat_pipe<8, BB_LV_LDS, 4, 8>(om, nt, g2, st, a);
+                    break;
+            }
+        } else {
+            switch (p->bps) {
+                case 1: launch_flat_pipe<1, BB_LV_REG, 2, 16>(om, nt, g2, st, a); break;
+                case 2: launch_flat_pipe<2, BB_LV_REG, 2, 16>(om, nt, g2, st, a); break;
+                case 4: launch_flat_pipe<4, BB_LV_LDS, 2, 16>(om, nt, g2, st, a); break;
+                default:
+                    if (p->coder == BB_CODER_INT) launch_flat_pipe<8, BB_LV_INT8, 2, 16>(om, nt, g2, st, a);
+                    else                          launch_flat_pipe<8, BB_LV_LDS, 2, 16>(om, nt, g2, st, a);
+                    break;
+            }
         }
         BB_HIP(hipGetLastError());
         return BB_OK;

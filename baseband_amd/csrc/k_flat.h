@@ -176,21 +176,22 @@ void k_decode_flat(bb_flat_args a)
 // microseconds while the write queues are saturated -- overlaps the store
 // phase instead of preceding it.  Each wave owns 8 consecutive tiles, i.e. a
 // contiguous 32 KiB run of the output.
-template <int BPS, int LV, int OM, bool NT>
-__global__ __launch_bounds__(BB_BLOCK)
+template <int BPS, int LV, int OM, bool NT, int NW, int TPW>
+__global__ __launch_bounds__(NW * BB_WAVE)
 void k_decode_flat_pipe(bb_flat_args a)
 {
     constexpr int NCODE = 1 << BPS;
     constexpr int EPT = 2048 / BPS;
     constexpr int PASSES = 8 / BPS;
     constexpr uint32_t CMASK = NCODE - 1;
-    constexpr int TPW = BB_SEG_TILES / BB_WAVES_PER_BLOCK;      // tiles per wave: 8
+    // NW waves per workgroup, TPW tiles per wave: a work item is at most
+    // NW * TPW tiles; every wave owns a contiguous run of TPW tiles.
     __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
 
     bb_levels<BPS, LV> lv;
     lv.lds = s_tab;
     if (LV == BB_LV_LDS) {
-        for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
+        for (int i = threadIdx.x; i < NCODE; i += NW * BB_WAVE) s_tab[i] = a.tab[i];
         __syncthreads();
     } else if (LV == BB_LV_REG) {
         lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
@@ -251,15 +252,17 @@ void k_decode_flat_pipe(bb_flat_args a)
                                    ? (seg + 1) * a.seg_tiles * EPT : E;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
-            if (u >= (int)a.tpw) break;                 // wave-uniform
+            // (no early exit: the loop must unroll completely so that cur[]
+            // stays in registers; tiles beyond tpw fail the range test below)
             const uint64_t tile = tile0 + u;
+            const bool live = u < (int)a.tpw;           // wave-uniform
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
                 uint32_t bits;
                 if (BPS == 8) bits = cur[u];
                 else bits = (uint32_t)__shfl((int)cur[u], p * 8 * BPS + src_lane0) >> shift;
                 const uint64_t e0 = tile * EPT + 256 * p + 4 * lane;
-                if (e0 >= seg_e_end) continue;
+                if (!live || e0 >= seg_e_end) continue;
                 bb_f4 v;
                 if (cur_valid) {
                     v.x = lv.get(bits & CMASK);

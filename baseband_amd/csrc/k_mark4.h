@@ -182,8 +182,8 @@ void k_decode_mark4(bb_m4_args a)
                                ? (seg + 1) * a.seg_tiles * 64 : a.nwords;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
-            if (u >= (int)a.tpw) break;                 // wave-uniform
             const uint64_t tile = tile0 + u;
+            const bool live = u < (int)a.tpw;           // wave-uniform; no break: keep cur[] in registers
             const word_t w = cur[u];
 #pragma unroll
             for (int p = 0; p < LPW; ++p) {
@@ -197,7 +197,7 @@ void k_decode_mark4(bb_m4_args a)
                     x = (uint32_t)__shfl((int)(uint32_t)w, srcl);
                 }
                 const uint64_t widx = tile * 64 + srcl;
-                if (widx >= w_end) continue;
+                if (!live || widx >= w_end) continue;
                 bb_f4 v;
                 if (!cur_valid || widx < a.fill_words) {
                     v = fillv;

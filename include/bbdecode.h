@@ -314,7 +314,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
                        float *d_out, size_t out_elems, void *stream);
 
 /* ---- tuning knobs (performance experiments; results never change) ------ */
-#define BB_TUNE_FLAT_VARIANT   0   /* 0 = workgroup per frame, 1 = byte loads (2-bit), 2 = persistent pipelined (default) */
+#define BB_TUNE_FLAT_VARIANT   0   /* 0 = workgroup per frame, 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16/32 tiles (default) */
 #define BB_TUNE_NT_STORES      1   /* 1 = non-temporal stores */
 #define BB_TUNE_BLOCKS         2   /* 0 = default grid; >0 = number of workgroups */
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */

@@ -96,7 +96,7 @@ def test_tuning_variants_agree():
     dbuf = kernels.to_device_bytes(raw)
     ref = None
     try:
-        for variant in (0, 1, 2):
+        for variant in (0, 1, 2, 3):
             for nt in (0, 1):
                 for blocks in (0, 7, 2048):
                     kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
@@ -108,7 +108,7 @@ def test_tuning_variants_agree():
                         ref = out
                     assert bits_equal(out, ref)
     finally:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, 2)
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 3)
         kernels.tune(_lib.TUNE_NT_STORES, 1)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
 

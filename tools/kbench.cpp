@@ -178,9 +178,11 @@ int main(int argc, char **argv)
                alg_bytes / med / 1e6 / 8000.0);
     }
 
-    for (int ntl = 0; ntl < 2; ++ntl) {
-        bb_tune(BB_TUNE_FLAT_VARIANT, 2); bb_tune(BB_TUNE_NT_STORES, 1); bb_tune(BB_TUNE_BLOCKS, 0);
-        bb_tune(BB_TUNE_NT_LOADS, ntl);
+    for (int ntl = 0; ntl < 6; ++ntl) {
+        const int var_[6] = {2, 3, 3, 3, 2, 3}; const int blk_[6] = {0, 0, 8192, 32768, 8192, 0};
+        bb_tune(BB_TUNE_FLAT_VARIANT, var_[ntl]); bb_tune(BB_TUNE_NT_STORES, 1);
+        bb_tune(BB_TUNE_BLOCKS, blk_[ntl]);
+        bb_tune(BB_TUNE_NT_LOADS, 0);
         std::vector<double> t;
         for (int r = 0; r < reps + 1; ++r) {
             CK(hipEventRecord(e0));
@@ -189,7 +191,7 @@ int main(int argc, char **argv)
             if (r) t.push_back(time_ms(e0, e1));
         }
         std::sort(t.begin(), t.end());
-        printf("decode pipe nt_loads=%d: median %.3f ms  %.1f GB/s alg  frac8TB=%.3f\n", ntl,
+        printf("decode pipe exp=%d (0: 4 waves; 1,2: 2 waves/item default,16384 blocks; 3,4,5: 1 wave/item default,32768,8192 blocks): median %.3f ms  %.1f GB/s alg  frac8TB=%.3f\n", ntl,
                t[t.size() / 2], alg_bytes / t[t.size() / 2] / 1e6, alg_bytes / t[t.size() / 2] / 1e6 / 8000.0);
     }
     bb_tune(BB_TUNE_NT_LOADS, 0);
