@@ -118,6 +118,15 @@ void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_
 }
 
 template <int BPS, int LV>
+void launch_rows_pipe(bool nt, int nw, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+#define BB_R(NW) do { if (nt) hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, true, NW, 8>), grid, dim3(NW * BB_WAVE), 0, st, a); \
+                      else    hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, false, NW, 8>), grid, dim3(NW * BB_WAVE), 0, st, a); } while (0)
+    if (nw == 8) BB_R(8); else if (nw == 4) BB_R(4); else BB_R(2);
+#undef BB_R
+}
+
+template <int BPS, int LV>
 void launch_flat(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
 #define BB_L(OM, NT) hipLaunchKernelGGL((k_decode_flat<BPS, LV, OM, NT>), grid, dim3(BB_BLOCK), 0, st, a)
@@ -340,6 +349,11 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         ga.gtiles = gt;
         ga.ngroup = (uint32_t)((ntiles + gt - 1) / gt);
         ga.fill_re = a.fill_re; ga.fill_im = a.fill_im; ga.complex_data = a.complex_data;
+        {
+            const uint32_t rl = (uint32_t)p->nslot * (uint32_t)p->chunk;
+            ga.lrow = -1;
+            if ((rl & (rl - 1)) == 0) { ga.lrow = 0; while ((1u << ga.lrow) < rl) ++ga.lrow; }
+        }
         const size_t lds = ((size_t)p->nslot * (gt * 64 + 1) + p->nslot) * 4 + 1024;
         uint64_t gb = (uint64_t)nframes * ga.ngroup;
         if (tb > 0 && gb > (uint64_t)tb) gb = (uint64_t)tb;
@@ -352,6 +366,32 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             default:
                 if (p->coder == BB_CODER_INT) launch_gather<8, BB_LV_INT8>(nt, gg, lds, st, ga);
                 else                          launch_gather<8, BB_LV_LDS>(nt, gg, lds, st, ga);
+                break;
+        }
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
+
+    if (om == BB_OUT_ROWS4 && g_tune_variant.load() >= 3) {
+        // thread interleave with wide chunks: one wave per thread slot, all
+        // waves on the same 8 tiles (k_decode_rows_pipe)
+        const int nw = p->nslot >= 8 ? 8 : (p->nslot >= 4 ? 4 : 2);
+        const uint64_t seg_max = 8;
+        a.nseg = (ntiles + seg_max - 1) / seg_max;
+        a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
+        a.tpw = a.seg_tiles;
+        const uint64_t sgroups = ((uint64_t)p->nslot + nw - 1) / nw;
+        uint64_t b2 = (uint64_t)nframes * a.nseg * sgroups;
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : (uint64_t)(16384 / nw);
+        if (b2 > cap) b2 = cap;
+        const dim3 g2((unsigned)b2);
+        switch (p->bps) {
+            case 1: launch_rows_pipe<1, BB_LV_REG>(nt, nw, g2, st, a); break;
+            case 2: launch_rows_pipe<2, BB_LV_REG>(nt, nw, g2, st, a); break;
+            case 4: launch_rows_pipe<4, BB_LV_LDS>(nt, nw, g2, st, a); break;
+            default:
+                if (p->coder == BB_CODER_INT) launch_rows_pipe<8, BB_LV_INT8>(nt, nw, g2, st, a);
+                else                          launch_rows_pipe<8, BB_LV_LDS>(nt, nw, g2, st, a);
                 break;
         }
         BB_HIP(hipGetLastError());

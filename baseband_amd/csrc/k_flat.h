@@ -296,6 +296,111 @@ void k_decode_flat_pipe(bb_flat_args a)
     }
 }
 
+// Thread-interleaved output with chunks of >= 4 floats (e.g. 8 threads x 16
+// complex channels: 128-byte chunks in 1 KiB rows).  One wave per thread
+// slot; all waves of a workgroup walk the SAME tiles of their payloads, so
+// the rows of the output region are completed by the workgroup within a few
+// microseconds instead of being visited by eight workgroups at different
+// times.  Persistent and software pipelined like k_decode_flat_pipe.
+template <int BPS, int LV, bool NT, int NW, int TPW>
+__global__ __launch_bounds__(NW * BB_WAVE)
+void k_decode_rows_pipe(bb_flat_args a)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr int EPT = 2048 / BPS;
+    constexpr int PASSES = 8 / BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += NW * BB_WAVE) s_tab[i] = a.tab[i];
+        __syncthreads();
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    const int lane = bb_lane();
+    const int wave = bb_wave();
+    const uint64_t E = a.ndw * (32 / BPS);
+    const uint64_t R = E >> a.lchunk;
+    const uint64_t nframes = a.nfs / a.nslot;
+    const uint32_t sgroups = (a.nslot + NW - 1) / NW;       // slot groups of NW waves
+    const uint64_t nwork = nframes * a.nseg * sgroups;
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+    const int src_lane0 = (lane * BPS) >> 3;
+    const int shift = (4 * lane * BPS) & 31;
+
+    uint32_t cur[TPW], nxt[TPW];
+    bool cur_valid = false, nxt_valid = false;
+
+    // work -> (frame set, segment, slot group); slot = group * NW + wave
+    auto split = [&](uint64_t work, uint64_t &f, uint64_t &seg, uint32_t &slot) {
+        const uint64_t per_f = a.nseg * sgroups;
+        f = work / per_f;
+        const uint64_t r = work - f * per_f;
+        seg = r / sgroups;
+        slot = (uint32_t)(r - seg * sgroups) * NW + wave;
+    };
+    auto issue = [&](uint64_t work, uint32_t (&w)[TPW], bool &valid) {
+        uint64_t f, seg; uint32_t slot;
+        split(work, f, seg, slot);
+        int64_t so = -1;
+        if (slot < a.nslot)
+            so = a.src ? a.src[f * a.nslot + slot]
+                       : a.src0 + (int64_t)(f * a.nslot + slot) * a.src_stride;
+        valid = so >= 0;
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(a.buf + (valid ? so : 0));
+        const uint64_t tile0 = seg * a.seg_tiles;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint64_t dw = (tile0 + u) * 64 + lane;
+            w[u] = (valid && u < (int)a.seg_tiles && dw < a.ndw) ? in[dw] : 0u;
+        }
+    };
+
+    uint64_t work = blockIdx.x;
+    if (work < nwork) issue(work, cur, cur_valid);
+    for (; work < nwork; work += gridDim.x) {
+        const uint64_t next = work + gridDim.x;
+        if (next < nwork) issue(next, nxt, nxt_valid);
+        uint64_t f, seg; uint32_t slot;
+        split(work, f, seg, slot);
+        const uint64_t tile0 = seg * a.seg_tiles;
+        const uint64_t rowbase = f * R;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint64_t tile = tile0 + u;
+            const bool live = u < (int)a.seg_tiles && slot < a.nslot;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                uint32_t bits;
+                if (BPS == 8) bits = cur[u];
+                else bits = (uint32_t)__shfl((int)cur[u], p * 8 * BPS + src_lane0) >> shift;
+                const uint64_t e0 = tile * EPT + 256 * p + 4 * lane;
+                if (!live || e0 >= E) continue;
+                bb_f4 v;
+                if (cur_valid) {
+                    v.x = lv.get(bits & CMASK);
+                    v.y = lv.get((bits >> BPS) & CMASK);
+                    v.z = lv.get((bits >> (2 * BPS)) & CMASK);
+                    v.w = lv.get((bits >> (3 * BPS)) & CMASK);
+                } else {
+                    v = fillv;
+                }
+                const uint64_t row = e0 >> a.lchunk;
+                const uint64_t within = e0 & (a.chunk - 1);
+                bb_store4<NT>(a.out + ((((rowbase + row) * a.nslot + slot) << a.lchunk) + within), v);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) cur[u] = nxt[u];
+        cur_valid = nxt_valid;
+    }
+}
+
 // Experimental twin of the 2-bit flat kernel: every lane loads its own byte
 // (64-byte wave loads) instead of shuffling a dword; kept for A/B timing only.
 template <bool NT>

@@ -28,6 +28,7 @@ struct bb_gather_args {
     uint32_t ngroup;        // work items per frame set
     float    fill_re, fill_im;
     int32_t  complex_data;
+    int32_t  lrow;          // log2(nslot * chunk) when that is a power of two, else -1
 };
 
 template <int BPS, int LV, bool NT>
@@ -62,15 +63,14 @@ void k_decode_gather(bb_gather_args a)
         const uint64_t f = work / a.ngroup;
         const uint32_t g = (uint32_t)(work - f * a.ngroup);
         const uint64_t dw0 = (uint64_t)g * gdw;         // first dword of the group
-        // phase 1: stage the group's dwords of every slot
-        for (uint32_t i = threadIdx.x; i < a.nslot * gdw; i += BB_BLOCK) {
-            const uint32_t s = i / gdw, d = i - s * gdw;
+        // phase 1: stage the group's dwords of every slot (one wave per
+        // slot at a time: coalesced 256-byte loads, no index arithmetic)
+        for (uint32_t s = bb_wave(); s < a.nslot; s += BB_WAVES_PER_BLOCK) {
             const int64_t so = a.src[f * a.nslot + s];
-            uint32_t w = 0;
-            if (so >= 0 && dw0 + d < a.ndw)
-                w = reinterpret_cast<const uint32_t *>(a.buf + so)[dw0 + d];
-            s_raw[s * pitch + d] = w;
-            if (d == 0) s_valid[s] = so >= 0 ? 1u : 0u;
+            const uint32_t *in = reinterpret_cast<const uint32_t *>(a.buf + (so >= 0 ? so : 0));
+            for (uint32_t d = bb_lane(); d < gdw; d += BB_WAVE)
+                s_raw[s * pitch + d] = (so >= 0 && dw0 + d < a.ndw) ? in[dw0 + d] : 0u;
+            if (bb_lane() == 0) s_valid[s] = so >= 0 ? 1u : 0u;
         }
         __syncthreads();
         // phase 2: contiguous output region of this group
@@ -81,8 +81,9 @@ void k_decode_gather(bb_gather_args a)
         float *obase = a.out + (f * R + (e_lo >> a.lchunk)) * rowlen;
         const uint8_t *rawb = reinterpret_cast<const uint8_t *>(s_raw);
         for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
-            uint32_t row = q / rowlen;
-            uint32_t rem = q - row * rowlen;
+            uint32_t row, rem;
+            if (a.lrow >= 0) { row = q >> a.lrow; rem = q & (rowlen - 1); }   // power-of-two rows
+            else             { row = q / rowlen;  rem = q - row * rowlen; }
             float r[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -80,7 +80,13 @@ def main():
     out = torch.empty(nsets * nth * pn * 4, dtype=torch.float32, device=dev)
     ms = timeit(lambda: kernels.decode_frames(buf, nsets, pn, 0, 2, chunk=32, nslot=nth, src=src,
                                               complex_data=True, out=out))
-    report('cfg2 VDIF 8 threads x 16 ch 2-bit complex (k_decode_flat_pipe ROWS4)',
+    report('cfg2 VDIF 8 threads x 16 ch 2-bit complex (k_decode_rows_pipe)',
+           ms, nsets * nth * fn_, out.numel() * 4, out.numel() // 2, nsets=nsets)
+    kernels.tune(_lib.TUNE_FLAT_VARIANT, 2)
+    ms = timeit(lambda: kernels.decode_frames(buf, nsets, pn, 0, 2, chunk=32, nslot=nth, src=src,
+                                              complex_data=True, out=out))
+    kernels.tune(_lib.TUNE_FLAT_VARIANT, 3)
+    report('cfg2 same, previous kernel (k_decode_flat_pipe ROWS4, one workgroup per thread)',
            ms, nsets * nth * fn_, out.numel() * 4, out.numel() // 2, nsets=nsets)
     del out
 
