@@ -32,6 +32,7 @@ TUNE_FLAT_VARIANT = 0
 TUNE_NT_STORES = 1
 TUNE_BLOCKS = 2
 TUNE_NT_LOADS = 3
+TUNE_TILE_ELEMS = 4
 
 
 class BBError(RuntimeError):

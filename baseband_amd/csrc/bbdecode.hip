@@ -99,6 +99,7 @@ std::atomic<int> g_tune_variant{3};   // 3 = persistent pipelined kernel, 2 wave
 std::atomic<int> g_tune_nt{1};
 std::atomic<int> g_tune_blocks{0};
 std::atomic<int> g_tune_nt_loads{0};
+std::atomic<int> g_tune_tile_elems{8192};
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
@@ -175,6 +176,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_NT_STORES:    g_tune_nt = value;      return BB_OK;
         case BB_TUNE_BLOCKS:       g_tune_blocks = value;  return BB_OK;
         case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
+        case BB_TUNE_TILE_ELEMS:   g_tune_tile_elems = value > 0 ? value : 8192; return BB_OK;
         default: return BB_EINVAL;
     }
 }
@@ -582,7 +584,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     // many times as keep the tile near 8192 elements (16 KiB in, 64 KiB out)
     uint32_t tc = (uint32_t)(nc < 64 ? nc : 64);
     if (tc > 1 && (tc & 1)) tc += 1;
-    uint32_t tt = 8192u / (uint32_t)(np_ * tc);
+    uint32_t tt = (uint32_t)g_tune_tile_elems.load() / (uint32_t)(np_ * tc);
     if (tt < 1) tt = 1;
     if (tt > 1024) tt = 1024;
     if (p->layout == BB_LAYOUT_MKBF) { if (tt > 256) tt = 256; while (256 % tt) --tt; }

@@ -318,6 +318,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
 #define BB_TUNE_NT_STORES      1   /* 1 = non-temporal stores */
 #define BB_TUNE_BLOCKS         2   /* 0 = default grid; >0 = number of workgroups */
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */
+#define BB_TUNE_TILE_ELEMS     4   /* elements per tile of bb_decode_i8_tiled (default 8192) */
 int bb_tune(int knob, int value);
 
 #ifdef __cplusplus

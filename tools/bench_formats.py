@@ -129,6 +129,10 @@ def main():
     out = torch.empty(nb, dtype=torch.float32, device=dev)
     ms = timeit(lambda: kernels.decode_frames(buf, 1, nb, _lib.CODER_INT, 8, src0=0, out=out))
     report('cfg4b DADA 8-bit 2 pol complex (k_decode_flat_pipe INT8)', ms, nb, nb * 4, nb // 2)
+    # yardstick: the same 1 B -> 4 B cast done by the framework's elementwise kernel
+    i8 = buf[:nb].view(torch.int8)
+    ms = timeit(lambda: torch.Tensor.copy_(out, i8))
+    report('yardstick: torch int8 -> float32 elementwise copy_ (not part of the product)', ms, nb, nb * 4, nb // 2)
 
 
 if __name__ == '__main__':
