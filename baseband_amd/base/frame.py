@@ -1,43 +1,42 @@
-"""Frame = header + payload, with the validity -> fill_value rule.
+"""A frame couples one header with one payload.
 
-Mirror of the reference's ``FrameBase`` (base/frame.py:14-241): a frame acts
-as a dict of header keys, indexes/slices like its payload, and returns
-``fill_value`` everywhere when it is not valid (base/frame.py:191-199).
-Decoded data are device tensors.
+Same call shapes as the reference's ``FrameBase`` (base/frame.py:14-241):
+``fromfile``/``tofile``, dict-style access to header fields, array-style access
+to decoded samples, ``valid`` and ``fill_value``.  The one rule that matters on
+the decode path is the validity rule: an invalid frame reads as ``fill_value``
+everywhere, without touching its payload (base/frame.py:191-199).  Samples come
+back as device tensors.
 """
 import numpy as np
 import torch
 
 
+def _delegate(owner, name, doc=None):
+    """Read-only attribute forwarded to ``self.<owner>.<name>``."""
+    return property(lambda self: getattr(getattr(self, owner), name), doc=doc)
+
+
 class FrameBase:
     _header_class = None
     _payload_class = None
-    _fill_value = 0.
+    _fill_value = 0.        # class defaults; instances override on assignment
     _valid = True
 
     def __init__(self, header, payload, valid=None, verify=True):
-        self.header = header
-        self.payload = payload
+        self.header, self.payload = header, payload
         if valid is not None:
             self.valid = valid
         if verify:
             self.verify()
 
     def verify(self):
+        """Header and payload have the right types and agree on the size."""
         assert isinstance(self.header, self._header_class)
         assert isinstance(self.payload, self._payload_class)
-        payload_nbytes = getattr(self.header, 'payload_nbytes', None)
-        if payload_nbytes is not None:
-            assert self.payload.nbytes == payload_nbytes
+        expected = getattr(self.header, 'payload_nbytes', None)
+        assert expected is None or expected == self.payload.nbytes
 
-    @property
-    def valid(self):
-        return self._valid
-
-    @valid.setter
-    def valid(self, valid):
-        self._valid = bool(valid)
-
+    # -- construction / serialisation
     @classmethod
     def fromfile(cls, fh, memmap=None, valid=None, verify=True, **kwargs):
         header = cls._header_class.fromfile(fh, verify=verify)
@@ -46,12 +45,37 @@ class FrameBase:
         return cls(header, payload, valid=valid, verify=verify)
 
     def tofile(self, fh):
-        self.header.tofile(fh)
-        self.payload.tofile(fh)
+        for part in (self.header, self.payload):
+            part.tofile(fh)
 
-    @property
-    def sample_shape(self):
-        return self.payload.sample_shape
+    # -- validity and fill
+    def _get_valid(self):
+        return self._valid
+
+    def _set_valid(self, valid):
+        self._valid = bool(valid)
+
+    valid = property(lambda self: self._get_valid(),
+                     lambda self, v: self._set_valid(v),
+                     doc="Whether the frame holds usable data.")
+
+    def _get_fill(self):
+        return self._fill_value
+
+    def _set_fill(self, value):
+        self._fill_value = value
+
+    fill_value = property(lambda self: self._get_fill(),
+                          lambda self, v: self._set_fill(v),
+                          doc="Value returned for invalid data (default 0).")
+
+    def _fill(self, shape):
+        kind = torch.complex64 if self.dtype.kind == 'c' else torch.float32
+        return torch.full(tuple(shape), self.fill_value, dtype=kind, device='cuda')
+
+    # -- array-like view of the decoded samples
+    sample_shape = _delegate('payload', 'sample_shape')
+    dtype = _delegate('payload', 'dtype')
 
     def __len__(self):
         return len(self.payload)
@@ -62,64 +86,59 @@ class FrameBase:
 
     @property
     def size(self):
-        size = 1
-        for dim in self.shape:
-            size *= dim
-        return size
+        return int(np.prod(self.shape, dtype=np.int64))
 
-    @property
-    def ndim(self):
-        return len(self.shape)
-
-    @property
-    def dtype(self):
-        return self.payload.dtype
-
-    @property
-    def nbytes(self):
-        return self.header.nbytes + self.payload.nbytes
-
-    @property
-    def fill_value(self):
-        return self._fill_value
-
-    @fill_value.setter
-    def fill_value(self, fill_value):
-        self._fill_value = fill_value
-
-    def _fill(self, shape):
-        tdtype = torch.complex64 if self.dtype.kind == 'c' else torch.float32
-        return torch.full(tuple(shape), self.fill_value, dtype=tdtype,
-                          device='cuda')
+    ndim = property(lambda self: len(self.shape))
+    nbytes = property(lambda self: self.header.nbytes + self.payload.nbytes)
 
     def __getitem__(self, item=()):
-        if isinstance(item, str):
-            return self.header.__getitem__(item)
+        if isinstance(item, str):               # header field
+            return self.header[item]
         if self.valid:
             return self.payload[item]
-        # shape of the item without decoding anything
-        probe = np.empty(self.shape, dtype=bool)[item]
-        return self._fill(probe.shape)
+        # invalid: only the SHAPE of the answer depends on the item
+        return self._fill(np.empty(self.shape, dtype=bool)[item].shape)
 
     data = property(__getitem__, doc="Full decoded frame (device tensor).")
 
+    # -- header passthrough
     def keys(self):
         return self.header.keys()
 
     def __contains__(self, key):
-        return key in self.header.keys()
+        return key in self.keys()
 
     def __getattr__(self, attr):
-        if attr in ('header', 'payload'):
+        # anything the frame does not define itself (time, bps, ...) is looked
+        # up on the header; guard against recursion before __init__ ran
+        if attr in ('header', 'payload') or attr.startswith('__'):
             raise AttributeError(attr)
         try:
             return getattr(self.header, attr)
         except AttributeError:
             raise AttributeError("{} object has no attribute {}"
-                                 .format(type(self).__name__, attr))
+                                 .format(type(self).__name__, attr)) from None
 
     def __eq__(self, other):
-        return (type(self) is type(other)
-                and self.valid == other.valid
-                and self.header == other.header
-                and self.payload == other.payload)
+        return (type(other) is type(self)
+                and (self.valid, self.header, self.payload)
+                == (other.valid, other.header, other.payload))
+
+    __hash__ = None
+
+
+def block_frame_class(name, header_class, payload_class, doc):
+    """Frame type for block formats whose frames are always valid and whose
+    payloads are memory mapped (GUPPI, DADA): header + payload, nothing else."""
+
+    def fromfile(cls, fh, memmap=True, verify=True):
+        header = header_class.fromfile(fh, verify=verify)
+        return cls(header, payload_class.fromfile(fh, header=header, memmap=memmap),
+                   verify=verify)
+
+    def fromdata(cls, data, header, verify=True):
+        return cls(header, payload_class.fromdata(data, header=header), verify=verify)
+
+    return type(name, (FrameBase,), dict(
+        __doc__=doc, _header_class=header_class, _payload_class=payload_class,
+        fromfile=classmethod(fromfile), fromdata=classmethod(fromdata)))

@@ -1,16 +1,16 @@
 """Payload container: encoded words on the host, decode on the GPU.
 
-Host-side mirror of the reference's ``PayloadBase`` (base/payload.py:18-360):
-same constructor, ``fromfile``/``fromdata`` class methods, ``nbytes, shape,
-size, ndim, dtype, sample_shape, data`` properties, ``__len__``,
-``__getitem__`` and ``__array__``.  The difference is where ``_decode`` runs:
-the words are uploaded once and expanded by the libbbdecode flat kernel
-(bb_decode_frames), and ``data`` / ``__getitem__`` return device tensors
-(torch, float32 or complex64).  ``__array__`` performs the device-to-host
-copy for NumPy consumers.
+Keeps the public surface of the reference's ``PayloadBase``
+(base/payload.py:18-360) -- constructor arguments, ``fromfile``/``fromdata``,
+``nbytes, shape, size, ndim, dtype, sample_shape, data``, ``len()``, item
+access and ``__array__`` -- but is organised around one primitive: *decode
+the smallest run of whole words that covers samples [start, stop)*.  The run
+is expanded by the libbbdecode flat kernel (``bb_decode_frames``) from a copy
+of the words that is uploaded to HBM once; everything that comes back is a
+device tensor (float32 or complex64).  ``__array__`` is the only place where
+samples travel back to the host.
 """
 import operator
-from functools import reduce
 
 import numpy as np
 import torch
@@ -18,231 +18,207 @@ import torch
 from .. import kernels
 
 
+def _resolve_index(index, length, who):
+    """Normalise an int or slice over `length` samples.
+
+    Returns (start, stop, step, scalar).  Only forward steps are supported,
+    like in the reference (base/payload.py:262-264)."""
+    if isinstance(index, slice):
+        start, stop, step = index.indices(length)
+        assert step > 0, "cannot deal with negative steps yet."
+        return start, max(stop, start), step, False
+    try:
+        i = operator.index(index)
+    except Exception:
+        raise TypeError("{0} object can only be indexed or sliced.".format(who))
+    if i < 0:
+        i += length
+    if i < 0 or i >= length:
+        raise IndexError("{0} index out of range.".format(who))
+    return i, i + 1, 1, True
+
+
 class PayloadBase:
-    # Possible fixed payload size in bytes.
-    _nbytes = None
-    _memmap = False
-    _dtype_word = np.dtype('<u4')
-    # ABI coder id (include/bbdecode.h enum bb_coder); set by subclasses.
-    _coder_id = None
-    # bits per sample the coder supports; anything else -> KeyError on decode,
-    # like a missing key in the reference's _decoders dict.
-    _sample_shape_maker = None
+    # subclass knobs -------------------------------------------------------
+    _nbytes = None                      # fixed payload size, if the format has one
+    _memmap = False                     # map rather than read in fromfile
+    _dtype_word = np.dtype('<u4')       # dtype the encoded words must have
+    _coder_id = None                    # enum bb_coder handed to the kernels
+    _sample_shape_maker = None          # namedtuple factory for sample_shape
 
     def __init__(self, words, *, header=None, sample_shape=(), bps=2,
                  complex_data=False):
         if header is not None:
-            sample_shape = header.sample_shape
-            bps = header.bps
+            sample_shape, bps = header.sample_shape, header.bps
             complex_data = header.complex_data
-            if self._nbytes is None:
-                self._nbytes = header.payload_nbytes
-            elif self._nbytes != header.payload_nbytes:
+            expected = header.payload_nbytes
+            if self._nbytes is not None and self._nbytes != expected:
                 raise ValueError("header payload size should be {0}"
                                  .format(self._nbytes))
-        self.words = words
-        if self._sample_shape_maker is not None:
-            self.sample_shape = self._sample_shape_maker(*sample_shape)
-        else:
-            self.sample_shape = tuple(sample_shape)
-        self._sample_size = reduce(operator.mul, sample_shape, 1)
-        self.bps = bps
-        self.complex_data = complex_data
-        self._bpfs = bps * (2 if complex_data else 1) * self._sample_size
-        self._coder = bps
-        self._dwords = None
-        if self._nbytes is not None and self._nbytes != words.nbytes:
-            raise ValueError("encoded data should have length {0}"
-                             .format(self._nbytes))
+            self._nbytes = expected
         if words.dtype != self._dtype_word:
             raise ValueError("encoded data should have dtype {0}"
                              .format(self._dtype_word))
+        if self._nbytes not in (None, words.nbytes):
+            raise ValueError("encoded data should have length {0}"
+                             .format(self._nbytes))
+        maker = self._sample_shape_maker
+        self.sample_shape = maker(*sample_shape) if maker else tuple(sample_shape)
+        self.words, self.bps, self.complex_data = words, bps, complex_data
+        self._sample_size = int(np.prod(sample_shape, dtype=np.int64)) if len(sample_shape) else 1
+        # bits per complete sample; subclasses may adjust (VDIF 3-bit etc.)
+        self._bpfs = bps * (2 if complex_data else 1) * self._sample_size
+        self._coder = bps               # key of the reference's _decoders dict
+        self._dwords = None             # device copy of the words (lazy)
+
+    # construction -----------------------------------------------------------
+    @staticmethod
+    def _read_words(fh, nbytes, dtype, memmap):
+        if not memmap:
+            raw = fh.read(nbytes)
+            if len(raw) < nbytes:
+                raise EOFError("could not read full payload.")
+            return np.frombuffer(raw, dtype=dtype)
+        count = nbytes // dtype.itemsize
+        if hasattr(fh, 'memmap'):
+            return fh.memmap(dtype=dtype, shape=(count,))
+        start = fh.tell()
+        words = np.memmap(fh, mode=fh.mode.replace('b', ''), dtype=dtype,
+                          offset=start, shape=(count,))
+        fh.seek(start + words.nbytes)
+        return words
 
     @classmethod
     def fromfile(cls, fh, header=None, *, payload_nbytes=None, dtype=None,
                  memmap=None, **kwargs):
-        """Read payload words from a filehandle (base/payload.py:84-139)."""
+        """Take ``payload_nbytes`` (from the header, the argument, or the
+        class) bytes from `fh` as payload words (base/payload.py:84-139)."""
         if header is not None:
-            payload_nbytes = header.payload_nbytes
             kwargs['header'] = header
-        elif payload_nbytes is None:
+            payload_nbytes = header.payload_nbytes
+        if payload_nbytes is None:
             payload_nbytes = cls._nbytes
-            if payload_nbytes is None:
-                raise ValueError(
-                    "payload_nbytes or header should be passed in "
-                    "if no default payload size is defined on the class.")
-        if dtype is None:
-            dtype = cls._dtype_word
-        if memmap is None:
-            memmap = cls._memmap
-        if memmap:
-            shape = (payload_nbytes // dtype.itemsize,)
-            if hasattr(fh, 'memmap'):
-                words = fh.memmap(dtype=dtype, shape=shape)
-            else:
-                mode = fh.mode.replace('b', '')
-                offset = fh.tell()
-                words = np.memmap(fh, mode=mode, dtype=dtype, offset=offset,
-                                  shape=shape)
-                fh.seek(offset + words.nbytes)
-        else:
-            s = fh.read(payload_nbytes)
-            if len(s) < payload_nbytes:
-                raise EOFError("could not read full payload.")
-            words = np.frombuffer(s, dtype=dtype)
+        if payload_nbytes is None:
+            raise ValueError(
+                "payload_nbytes or header should be passed in "
+                "if no default payload size is defined on the class.")
+        words = cls._read_words(fh, payload_nbytes,
+                                cls._dtype_word if dtype is None else dtype,
+                                cls._memmap if memmap is None else memmap)
         return cls(words, **kwargs)
-
-    def tofile(self, fh):
-        return fh.write(self.words.tobytes())
 
     @classmethod
     def fromdata(cls, data, header=None, bps=2, **kwargs):
-        """Encode data as a payload (host side; used to synthesise inputs)."""
+        """Encode samples on the host (only used to synthesise inputs)."""
         if isinstance(data, torch.Tensor):
             data = data.cpu().numpy()
-        sample_shape = data.shape[1:]
-        complex_data = data.dtype.kind == 'c'
-        if header:
-            bps = header.bps
-            if tuple(header.sample_shape) != tuple(sample_shape):
-                raise ValueError(
-                    f"header is for sample_shape={header.sample_shape} "
-                    f"but data has {sample_shape}")
-            if header.complex_data != complex_data:
-                raise ValueError("header is for {0} data but data are {1}"
-                                 .format(*(('complex' if c else 'real') for c
-                                           in (header.complex_data,
-                                               complex_data))))
-            base_kwargs = {"header": header}
-        else:
-            base_kwargs = {"bps": bps, "sample_shape": sample_shape,
-                           "complex_data": complex_data}
-        words = cls._encode_data(data, bps, **kwargs)
-        return cls(words, **base_kwargs)
+        is_complex = data.dtype.kind == 'c'
+        if header is None:
+            words = cls._encode_data(data, bps, **kwargs)
+            return cls(words, bps=bps, sample_shape=data.shape[1:],
+                       complex_data=is_complex)
+        if tuple(header.sample_shape) != tuple(data.shape[1:]):
+            raise ValueError(
+                f"header is for sample_shape={header.sample_shape} "
+                f"but data has {data.shape[1:]}")
+        if bool(header.complex_data) != is_complex:
+            kinds = ['complex' if c else 'real'
+                     for c in (header.complex_data, is_complex)]
+            raise ValueError("header is for {0} data but data are {1}".format(*kinds))
+        return cls(cls._encode_data(data, header.bps, **kwargs), header=header)
 
     @classmethod
     def _encode_data(cls, data, bps, **kwargs):
         raise ValueError(f"{cls.__name__} cannot encode data")
 
-    # ----- array-like properties (base/payload.py:190-224)
-    def __array__(self, dtype=None, copy=None):
-        a = self.data.cpu().numpy()
-        return a if dtype is None or dtype == a.dtype else a.astype(dtype)
+    def tofile(self, fh):
+        return fh.write(self.words.tobytes())
 
-    @property
-    def nbytes(self):
-        return self.words.nbytes
+    # geometry -----------------------------------------------------------------
+    nbytes = property(lambda self: self.words.nbytes,
+                      doc="Size of the payload in bytes.")
+    shape = property(lambda self: (len(self),) + tuple(self.sample_shape),
+                     doc="Shape of the decoded data.")
+    size = property(lambda self: len(self) * self._sample_size,
+                    doc="Number of component samples in the decoded data.")
+    ndim = property(lambda self: 1 + len(self.sample_shape))
+    dtype = property(lambda self: np.dtype('c8' if self.complex_data else 'f4'),
+                     doc="NumPy dtype the decoded data corresponds to.")
 
     def __len__(self):
-        return self.words.nbytes * 8 // self._bpfs
+        return 8 * self.words.nbytes // self._bpfs
 
-    @property
-    def shape(self):
-        return (len(self),) + tuple(self.sample_shape)
+    # item access ----------------------------------------------------------------
+    def _covering_words(self, start, stop):
+        """Smallest [w0, w1) word range holding samples [start, stop) and the
+        number of decoded samples that precede `start` in it.  Samples either
+        tile words or words tile samples (base/payload.py:283-310)."""
+        bpw, bpfs = 8 * self.words.itemsize, self._bpfs
+        if bpfs % bpw and bpw % bpfs:
+            raise TypeError("do not know how to extract data when full "
+                            "samples have {0} bits and words have {1} bits"
+                            .format(bpfs, bpw))
+        w0 = start * bpfs // bpw
+        w1 = -(-stop * bpfs // bpw)
+        return w0, w1, start - w0 * bpw // bpfs
 
-    @property
-    def size(self):
-        return len(self) * self._sample_size
-
-    @property
-    def ndim(self):
-        return 1 + len(self.sample_shape)
-
-    @property
-    def dtype(self):
-        return np.dtype(np.complex64 if self.complex_data else np.float32)
-
-    # ----- item -> minimal word range + residual slice (base/payload.py:226-312)
     def _item_to_slices(self, item):
+        """(word slice, data index) pair: decoding ``words[word slice]`` and
+        applying ``data index`` gives ``item``.  Same contract as the
+        reference's helper of this name (base/payload.py:226-312)."""
+        rest = ()
         if isinstance(item, tuple):
-            sample_index = item[1:]
-            item = item[0] if item else slice(None)
-        else:
-            sample_index = ()
-        nsample = len(self)
-        is_slice = isinstance(item, slice)
-        if is_slice:
-            start, stop, step = item.indices(nsample)
-            assert step > 0, "cannot deal with negative steps yet."
-            n = stop - start
-            if step == 1:
-                step = None
-        else:
-            try:
-                item = operator.index(item)
-            except Exception:
-                raise TypeError("{0} object can only be indexed or sliced."
-                                .format(type(self)))
-            if item < 0:
-                item += nsample
-            if not (0 <= item < nsample):
-                raise IndexError("{0} index out of range.".format(type(self)))
-            start, stop, step, n = item, item + 1, 1, 1
+            item, rest = (item[0], item[1:]) if item else (slice(None), ())
+        start, stop, step, scalar = _resolve_index(item, len(self),
+                                                   type(self))
+        if stop - start == len(self) and not scalar:
+            return slice(None), (slice(None, None, None if step == 1 else step),) + rest
+        w0, w1, lead = self._covering_words(start, stop)
+        if scalar:
+            return slice(w0, w1), (lead,) + rest
+        tail_open = (stop * self._bpfs) % (8 * self.words.itemsize) == 0
+        index = slice(lead or None, None if tail_open else lead + stop - start,
+                      None if step == 1 else step)
+        return slice(w0, w1), (index,) + rest
 
-        if n == nsample:
-            words_slice = slice(None)
-            data_slice = slice(None, None, step) if is_slice else 0
-        else:
-            bpw = 8 * self.words.itemsize
-            bpfs = self._bpfs
-            if bpfs % bpw == 0:
-                wpfs = bpfs // bpw
-                words_slice = slice(start * wpfs, stop * wpfs)
-                data_slice = slice(None, None, step) if is_slice else 0
-            elif bpw % bpfs == 0:
-                fspw = bpw // bpfs
-                w_start, o_start = divmod(start, fspw)
-                w_stop, o_stop = divmod(stop, fspw)
-                words_slice = slice(w_start, w_stop + 1 if o_stop else w_stop)
-                data_slice = slice(o_start if o_start else None,
-                                   o_start + n if o_stop else None,
-                                   step) if is_slice else o_start
-            else:
-                raise TypeError("do not know how to extract data when full "
-                                "samples have {0} bits and words have {1} bits"
-                                .format(bpfs, bpw))
-        return words_slice, (data_slice,) + sample_index
-
-    # ----- GPU decode
     def _device_words(self):
-        """Payload bytes in HBM (uploaded once per payload)."""
         if self._dwords is None:
             self._dwords = kernels.to_device_bytes(self.words)
         return self._dwords
 
     def _decode(self, byte_start, byte_stop):
-        """Decode words[byte_start:byte_stop] -> flat float32 device tensor.
-        The seam the reference calls ``self._decoders[self._coder](words)``
-        (base/payload.py:314-315)."""
+        """Flat float32 device tensor for payload bytes [byte_start,
+        byte_stop): the seam where the reference calls
+        ``self._decoders[self._coder](words)`` (base/payload.py:314-315)."""
         if self._coder_id is None:
             raise KeyError(self._coder)
-        nbytes = byte_stop - byte_start
-        if nbytes == 0:
+        if byte_stop == byte_start:
             return torch.empty(0, dtype=torch.float32, device='cuda')
-        return kernels.decode_frames(
-            self._device_words(), 1, nbytes, self._coder_id, self.bps,
-            src0=byte_start, src_stride=0)
+        return kernels.decode_frames(self._device_words(), 1,
+                                     byte_stop - byte_start, self._coder_id,
+                                     self.bps, src0=byte_start)
 
     def _as_dtype(self, flat):
-        if self.complex_data:
-            flat = torch.view_as_complex(flat.view(-1, 2))
-        return flat
+        return torch.view_as_complex(flat.view(-1, 2)) if self.complex_data else flat
 
     def __getitem__(self, item=()):
-        words_slice, data_slice = self._item_to_slices(item)
-        isz = self.words.itemsize
-        w0, w1, _ = words_slice.indices(len(self.words))
-        flat = self._decode(w0 * isz, w1 * isz)
-        return self._as_dtype(flat).reshape(-1, *self.sample_shape)[data_slice]
+        word_slice, index = self._item_to_slices(item)
+        w0, w1, _ = word_slice.indices(len(self.words))
+        size = self.words.itemsize
+        block = self._as_dtype(self._decode(w0 * size, w1 * size))
+        return block.reshape(-1, *self.sample_shape)[index]
 
     data = property(__getitem__, doc="Full decoded payload (device tensor).")
 
-    def __eq__(self, other):
-        return (type(self) is type(other)
-                and self.shape == other.shape
-                and self.dtype == other.dtype
-                and (self.words is other.words
-                     or np.all(self.words == other.words)))
+    def __array__(self, dtype=None, copy=None):
+        host = self.data.cpu().numpy()
+        return host if dtype in (None, host.dtype) else host.astype(dtype)
 
-    def __ne__(self, other):
-        return not self.__eq__(other)
+    def __eq__(self, other):
+        if type(other) is not type(self):
+            return False
+        same_meta = (self.shape, self.dtype) == (other.shape, other.dtype)
+        return same_meta and (self.words is other.words
+                              or bool(np.all(self.words == other.words)))
+
+    __hash__ = None

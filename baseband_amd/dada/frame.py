@@ -1,22 +1,11 @@
-"""DADA frames (dada/frame.py): header + payload, always valid."""
-from ..base.frame import FrameBase
+"""DADA frames (dada/frame.py in the reference): one 4096-byte ASCII header
+plus one int8 payload; always valid."""
+from ..base.frame import block_frame_class
 from .header import DADAHeader
 from .payload import DADAPayload
 
 __all__ = ['DADAFrame']
 
-
-class DADAFrame(FrameBase):
-    _header_class = DADAHeader
-    _payload_class = DADAPayload
-
-    @classmethod
-    def fromfile(cls, fh, memmap=True, verify=True):
-        header = DADAHeader.fromfile(fh, verify=verify)
-        payload = DADAPayload.fromfile(fh, header=header, memmap=memmap)
-        return cls(header, payload, verify=verify)
-
-    @classmethod
-    def fromdata(cls, data, header, verify=True):
-        payload = DADAPayload.fromdata(data, header=header)
-        return cls(header, payload, verify=verify)
+DADAFrame = block_frame_class(
+    'DADAFrame', DADAHeader, DADAPayload,
+    "DADA frame: ASCII header + int8 payload (MKBF heaps when INSTRUMENT says so).")

@@ -1,22 +1,11 @@
-"""GUPPI frames (guppi/frame.py): header + payload, always valid."""
-from ..base.frame import FrameBase
+"""GUPPI frames (guppi/frame.py in the reference): one ASCII-card header plus
+one int8 payload block; always valid."""
+from ..base.frame import block_frame_class
 from .header import GUPPIHeader
 from .payload import GUPPIPayload
 
 __all__ = ['GUPPIFrame']
 
-
-class GUPPIFrame(FrameBase):
-    _header_class = GUPPIHeader
-    _payload_class = GUPPIPayload
-
-    @classmethod
-    def fromfile(cls, fh, memmap=True, verify=True):
-        header = GUPPIHeader.fromfile(fh, verify=verify)
-        payload = GUPPIPayload.fromfile(fh, header=header, memmap=memmap)
-        return cls(header, payload, verify=verify)
-
-    @classmethod
-    def fromdata(cls, data, header, verify=True):
-        payload = GUPPIPayload.fromdata(data, header=header)
-        return cls(header, payload, verify=verify)
+GUPPIFrame = block_frame_class(
+    'GUPPIFrame', GUPPIHeader, GUPPIPayload,
+    "GUPPI frame: header cards + (channels-first or time-first) int8 block.")
