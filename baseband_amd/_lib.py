@@ -127,6 +127,8 @@ SIGNATURES = [
     ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),
     ('bb_decode_mark4', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(Mark4DecodeParams), _vp, _sz, _vp]),
     ('bb_decode_i8_tiled', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(TiledParams), _vp, _sz, _vp]),
+    ('bb_encode_flat', C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
+    ('bb_encode_mark4', C.c_int, [_vp, _sz, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _vp, _sz, _vp]),
     ('bb_tune', C.c_int, [C.c_int, C.c_int]),
 ]
 

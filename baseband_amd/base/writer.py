@@ -1,0 +1,110 @@
+"""Stream writer base: samples in (device tensors or arrays), frames out.
+
+Write-side twin of `GPUStreamReaderBase` with the
+call shape of the reference's ``StreamWriterBase`` (base/base.py:1230-1342):
+``write(data, valid=True)`` buffers until whole frames are available, the
+samples of the complete frames are packed by the GPU encoders
+(``bb_encode_flat`` / ``bb_encode_mark4``), and the host only glues headers
+and payload bytes together.  ``close()`` pads a partial last frame with zeros
+and marks it invalid, with the reference's warning.
+"""
+import warnings
+
+import numpy as np
+import torch
+
+
+class GPUStreamWriterBase:
+    def __init__(self, fh_raw, header0, *, sample_rate, samples_per_frame,
+                 unsliced_shape, bps, complex_data, squeeze=True):
+        self.fh_raw = fh_raw
+        self.header0 = header0
+        self.sample_rate = float(sample_rate)
+        self.samples_per_frame = samples_per_frame
+        self._unsliced_shape = tuple(unsliced_shape)
+        self.bps = bps
+        self.complex_data = complex_data
+        self.squeeze = bool(squeeze)
+        self.offset = 0                     # samples accepted so far
+        self._nframes_written = 0
+        self._pending = []                  # list of (tensor, valid)
+        self._npending = 0
+        self._closed = False
+
+    @property
+    def sample_shape(self):
+        if self.squeeze:
+            return tuple(d for d in self._unsliced_shape if d > 1)
+        return self._unsliced_shape
+
+    @property
+    def start_time(self):
+        return self._start_time
+
+    def tell(self, unit=None):
+        if unit is None:
+            return self.offset
+        ns = int(round(self.offset * 1e9 / self.sample_rate))
+        if unit == 'time':
+            return self._start_time + np.timedelta64(ns, 'ns')
+        raise ValueError("unit should be None or 'time'")
+
+    def write(self, data, valid=True):
+        """Accept `data` of shape ``(n,) + sample_shape`` (NumPy array or torch
+        tensor on any device)."""
+        if self._closed:
+            raise ValueError("I/O operation on closed stream.")
+        if not isinstance(data, torch.Tensor):
+            data = torch.from_numpy(np.ascontiguousarray(data))
+        assert tuple(data.shape[1:]) == self.sample_shape, (
+            "'data' should have trailing shape {}".format(self.sample_shape))
+        want = torch.complex64 if self.complex_data else torch.float32
+        data = data.to(device='cuda', dtype=want).reshape(
+            (data.shape[0],) + self._unsliced_shape)
+        self._pending.append((data, bool(valid)))
+        self._npending += data.shape[0]
+        self.offset += data.shape[0]
+        spf = self.samples_per_frame
+        nfull = self._npending // spf
+        if nfull:
+            block = torch.cat([d for d, _ in self._pending]) if len(self._pending) > 1 \
+                else self._pending[0][0]
+            # validity per frame: a frame is valid only if all of its pieces were
+            edges = np.cumsum([0] + [d.shape[0] for d, _ in self._pending])
+            flags = np.ones(nfull, bool)
+            for (lo, hi), (_, ok) in zip(zip(edges[:-1], edges[1:]), self._pending):
+                if not ok and hi > lo:
+                    flags[lo // spf:min(nfull, -(-hi // spf))] = False
+            self._write_frames(block[:nfull * spf], flags)
+            self._nframes_written += nfull
+            rest = block[nfull * spf:]
+            tail_ok = self._pending[-1][1]
+            self._pending = [(rest, tail_ok)] if rest.shape[0] else []
+            self._npending = rest.shape[0]
+
+    def _write_frames(self, data, valid):
+        raise NotImplementedError
+
+    def close(self):
+        if self._closed:
+            return
+        extra = self._npending
+        if extra:
+            warnings.warn("closing with partial buffer remaining.  "
+                          "Writing padded frame, marked as invalid.")
+            pad = torch.zeros((self.samples_per_frame - extra,) + self._unsliced_shape,
+                              dtype=self._pending[0][0].dtype, device='cuda')
+            self._pending.append((pad, False))
+            self._npending += pad.shape[0]
+            block = torch.cat([d for d, _ in self._pending])
+            self._write_frames(block, np.zeros(1, bool))
+            self._nframes_written += 1
+            self._pending, self._npending = [], 0
+        self._closed = True
+        self.fh_raw.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

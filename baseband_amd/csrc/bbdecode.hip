@@ -7,6 +7,7 @@
 #include "k_gather.h"
 #include "k_mark4.h"
 #include "k_tiled.h"
+#include "k_encode.h"
 
 #include <atomic>
 #include <mutex>
@@ -615,6 +616,69 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
         default:                 BB_TL(2); break;
     }
 #undef BB_TL
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
+                   void *d_out, size_t out_nbytes, void *stream)
+{
+    if (!coder_supported(coder, bps)) return BB_ENOTSUP;
+    if (nelem == 0) return BB_OK;
+    if (!d_in || !d_out) return BB_EINVAL;
+    if ((nelem & 3) || ((nelem * (size_t)bps) & 7)) return BB_EINVAL;
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 3)) return BB_EINVAL;
+    if (out_nbytes < nelem * (size_t)bps / 8) return BB_ERANGE;
+    const uint64_t nquad = nelem / 4;
+    uint64_t blocks = (nquad + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *o = (uint8_t *)d_out;
+#define BB_E(C, B) hipLaunchKernelGGL((k_encode_flat<C, B>), grid, block, 0, st, d_in, nquad, o)
+    if (coder == BB_CODER_VDIF) {
+        switch (bps) { case 1: BB_E(BB_CODER_VDIF, 1); break; case 2: BB_E(BB_CODER_VDIF, 2); break;
+                       case 4: BB_E(BB_CODER_VDIF, 4); break; default: BB_E(BB_CODER_VDIF, 8); break; }
+    } else if (coder == BB_CODER_MARK5B) {
+        if (bps == 1) BB_E(BB_CODER_MARK5B, 1); else BB_E(BB_CODER_MARK5B, 2);
+    } else {
+        if (bps == 4) BB_E(BB_CODER_INT, 4); else BB_E(BB_CODER_INT, 8);
+    }
+#undef BB_E
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
+                    const uint8_t sign_bit[32], const uint8_t mag_bit[32],
+                    void *d_out, size_t out_nbytes, void *stream)
+{
+    if (ntrack != 16 && ntrack != 32 && ntrack != 64) return BB_ENOTSUP;
+    if (nwords == 0) return BB_OK;
+    if (!d_in || !d_out || !sign_bit || !mag_bit) return BB_EINVAL;
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 7)) return BB_EINVAL;
+    if (out_nbytes < nwords * (size_t)(ntrack / 8)) return BB_ERANGE;
+    const int opw = ntrack / 2;
+    for (int j = 0; j < opw; ++j)
+        if (sign_bit[j] >= ntrack || mag_bit[j] >= ntrack) return BB_EINVAL;
+    bb_m4enc_args a;
+    a.in = d_in;
+    a.out = (uint8_t *)d_out;
+    a.nwords = nwords;
+    memset(a.sign_bit, 0, sizeof(a.sign_bit));
+    memset(a.mag_bit, 0, sizeof(a.mag_bit));
+    memcpy(a.sign_bit, sign_bit, opw);
+    memcpy(a.mag_bit, mag_bit, opw);
+    const uint64_t nquad = (uint64_t)nwords * (ntrack / 8);
+    uint64_t blocks = (nquad + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    switch (ntrack) {
+        case 16: hipLaunchKernelGGL(k_encode_mark4<16>, grid, block, 0, st, a); break;
+        case 32: hipLaunchKernelGGL(k_encode_mark4<32>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(k_encode_mark4<64>, grid, block, 0, st, a); break;
+    }
     BB_HIP(hipGetLastError());
     return BB_OK;
 }

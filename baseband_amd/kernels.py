@@ -227,5 +227,32 @@ def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
     return out
 
 
+def encode_flat(values, coder, bps):
+    """float32 (or complex64) device tensor -> packed uint8 device tensor."""
+    require_gpu()
+    if values.is_complex():
+        values = torch.view_as_real(values)
+    values = values.to(torch.float32).contiguous().reshape(-1)
+    nbytes = values.numel() * bps // 8 if bps in (1, 2, 4, 8) else 0
+    out = torch.empty(nbytes, dtype=torch.uint8, device=values.device)
+    check(lib.bb_encode_flat(_ptr(values), values.numel(), coder, bps, _ptr(out),
+                             out.numel(), _stream()), 'bb_encode_flat')
+    return out
+
+
+def encode_mark4(values, ntrack, sign_bit, mag_bit):
+    """(nsample, nchan) float32 device tensor -> stream words as uint8."""
+    require_gpu()
+    values = values.to(torch.float32).contiguous().reshape(-1)
+    opw = ntrack // 2
+    nwords = values.numel() // opw
+    sb = (C.c_uint8 * 32)(*sign_bit)
+    mb = (C.c_uint8 * 32)(*mag_bit)
+    out = torch.empty(nwords * (ntrack // 8), dtype=torch.uint8, device=values.device)
+    check(lib.bb_encode_mark4(_ptr(values), nwords, ntrack, sb, mb, _ptr(out),
+                              out.numel(), _stream()), 'bb_encode_mark4')
+    return out
+
+
 def tune(knob, value):
     check(lib.bb_tune(knob, value), 'bb_tune')

@@ -19,8 +19,9 @@ from .header import Mark4Header, MARK4_DTYPES, stream2words
 from .payload import Mark4Payload
 from .frame import Mark4Frame
 from ._bitmaps import BITMAPS
+from ..base.writer import GPUStreamWriterBase
 
-__all__ = ['Mark4FileReader', 'Mark4StreamReader', 'open']
+__all__ = ['Mark4FileReader', 'Mark4StreamReader', 'Mark4StreamWriter', 'open']
 
 
 class Mark4FileReader(VLBIFileReaderBase):
@@ -197,11 +198,58 @@ class Mark4StreamReader(GPUStreamReaderBase):
             self._pending_checks.append(bad)
 
 
+class Mark4StreamWriter(GPUStreamWriterBase):
+    """Mark 4 stream writer (mark4/base.py:315-334): (n, nchan) samples are
+    track-multiplexed on the GPU; the first 160*fanout samples of every frame
+    are dropped because the headers occupy their place on tape."""
+
+    def __init__(self, fh_raw, header0=None, sample_rate=None, squeeze=True,
+                 time=None, ntrack=64, bps=2, fanout=4):
+        if header0 is None:
+            header0 = Mark4Header.fromvalues(ntrack, time=time, bps=bps, fanout=fanout)
+        if sample_rate is None:
+            raise ValueError("Mark 4 stream writer needs a sample_rate.")
+        super().__init__(fh_raw, header0, sample_rate=sample_rate,
+                         samples_per_frame=header0.samples_per_frame,
+                         unsliced_shape=(header0.nchan,), bps=header0.bps,
+                         complex_data=False, squeeze=squeeze)
+        self._frame_rate = self.sample_rate / self.samples_per_frame
+        self._start_time = header0.get_time()
+        self._coder = (header0.nchan, header0.magnitude_signature() or header0.bps,
+                       header0.fanout)
+
+    def _write_frames(self, data, valid):
+        from .. import synth
+        from .header import words2stream
+        h0 = self.header0
+        maps = BITMAPS[self._coder]
+        spf = self.samples_per_frame
+        nfr = data.shape[0] // spf
+        nfill = 160 * h0.fanout
+        body = data.reshape(nfr, spf, h0.nchan)[:, nfill:].contiguous()
+        words = kernels.encode_mark4(body, h0.ntrack, maps['sign_bit'], maps['mag_bit'])
+        words = words.cpu().numpy().view(h0.stream_dtype).reshape(nfr, 20000 - 160)
+        frames = np.empty((nfr, 20000), dtype=h0.stream_dtype)
+        frames[:, 160:] = words
+        for i in range(nfr):
+            h = h0.copy()
+            ns = int(round((self._nframes_written + i) * 1e9 / self._frame_rate))
+            h.set_time(self._start_time + np.timedelta64(ns, 'ns'))
+            if not valid[i]:
+                h['communication_error'] = np.ones(h0.ntrack, bool)
+            h.update_crc()
+            frames[i, :160] = words2stream(h.words)
+        self.fh_raw.write(frames.tobytes())
+
+
 def open(name, mode='rs', **kwargs):
-    """``'rb'`` -> `Mark4FileReader`, ``'rs'`` -> `Mark4StreamReader`
-    (mark4/base.py:337-430)."""
+    """``'rb'`` -> `Mark4FileReader`, ``'rs'`` -> `Mark4StreamReader`,
+    ``'ws'`` -> `Mark4StreamWriter` (mark4/base.py:337-430)."""
+    if mode == 'ws':
+        fh = name if hasattr(name, 'write') else io.open(name, 'wb')
+        return Mark4StreamWriter(fh, **kwargs)
     if mode not in ('rb', 'rs'):
-        raise ValueError("only reading modes 'rb' and 'rs' are supported "
+        raise ValueError("supported modes are 'rb', 'rs' and 'ws' "
                          "(got {!r}).".format(mode))
     fh = name if hasattr(name, 'read') else io.open(name, 'rb')
     try:

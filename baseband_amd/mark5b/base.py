@@ -17,8 +17,9 @@ from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
 from ..base.header import strided_header_words
 from .header import Mark5BHeader, crc16_mark5b
 from .frame import Mark5BFrame
+from ..base.writer import GPUStreamWriterBase
 
-__all__ = ['Mark5BFileReader', 'Mark5BStreamReader', 'open']
+__all__ = ['Mark5BFileReader', 'Mark5BStreamReader', 'Mark5BStreamWriter', 'open']
 
 FRAME_NBYTES = 10016
 SYNC = 0xABADDEED
@@ -171,11 +172,53 @@ class Mark5BStreamReader(GPUStreamReaderBase):
             self._pending_checks.append(bad)
 
 
+class Mark5BStreamWriter(GPUStreamWriterBase):
+    """Mark 5B stream writer (mark5b/base.py:304-353): (n, nchan) samples are
+    packed on the GPU into 10000-byte payloads; every frame gets a header with
+    the BCD time code and its CRC."""
+
+    def __init__(self, fh_raw, header0=None, sample_rate=None, nchan=1, bps=2,
+                 squeeze=True, time=None, **kwargs):
+        if sample_rate is None:
+            raise ValueError("Mark 5B stream writer needs a sample_rate.")
+        spf = 10000 * 8 // bps // nchan
+        frame_rate = float(sample_rate) / spf
+        if header0 is None:
+            header0 = Mark5BHeader.fromvalues(time=time, frame_rate=frame_rate, **kwargs)
+        super().__init__(fh_raw, header0, sample_rate=sample_rate, samples_per_frame=spf,
+                         unsliced_shape=(nchan,), bps=bps, complex_data=False,
+                         squeeze=squeeze)
+        self._frame_rate = frame_rate
+        self._start_time = header0.get_time(frame_rate=frame_rate)
+
+    def _write_frames(self, data, valid):
+        nfr = data.shape[0] // self.samples_per_frame
+        packed = kernels.encode_flat(data, _lib.CODER_MARK5B, self.bps).cpu().numpy()
+        packed = packed.reshape(nfr, 10000)
+        out = np.empty((nfr, FRAME_NBYTES), np.uint8)
+        for i in range(nfr):
+            k = self._nframes_written + i
+            ns = int(round(k * 1e9 / self._frame_rate))
+            h = Mark5BHeader.fromvalues(time=self._start_time + np.timedelta64(ns, 'ns'),
+                                        frame_rate=self._frame_rate,
+                                        user=self.header0['user'],
+                                        internal_tvg=self.header0['internal_tvg'])
+            out[i, :16] = np.array(h.words, '<u4').view(np.uint8)
+            if valid[i]:
+                out[i, 16:] = packed[i]
+            else:                       # invalid frames carry the fill pattern
+                out[i, 16:] = np.full(2500, 0x11223344, '<u4').view(np.uint8)
+        self.fh_raw.write(out.tobytes())
+
+
 def open(name, mode='rs', **kwargs):
-    """``'rb'`` -> `Mark5BFileReader`, ``'rs'`` -> `Mark5BStreamReader`
-    (mark5b/base.py:356-428)."""
+    """``'rb'`` -> `Mark5BFileReader`, ``'rs'`` -> `Mark5BStreamReader`,
+    ``'ws'`` -> `Mark5BStreamWriter` (mark5b/base.py:356-428)."""
+    if mode == 'ws':
+        fh = name if hasattr(name, 'write') else io.open(name, 'wb')
+        return Mark5BStreamWriter(fh, **kwargs)
     if mode not in ('rb', 'rs'):
-        raise ValueError("only reading modes 'rb' and 'rs' are supported "
+        raise ValueError("supported modes are 'rb', 'rs' and 'ws' "
                          "(got {!r}).".format(mode))
     fh = name if hasattr(name, 'read') else io.open(name, 'rb')
     try:

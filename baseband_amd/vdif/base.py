@@ -15,11 +15,12 @@ import torch
 from .. import _lib, kernels
 from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
+from ..base.writer import GPUStreamWriterBase
 from ..base.header import strided_header_words
 from .header import VDIFHeader
 from .frame import VDIFFrame, VDIFFrameSet
 
-__all__ = ['VDIFFileReader', 'VDIFStreamReader', 'open']
+__all__ = ['VDIFFileReader', 'VDIFStreamReader', 'VDIFStreamWriter', 'open']
 
 
 class VDIFFileReader(VLBIFileReaderBase):
@@ -351,12 +352,67 @@ class VDIFStreamReader(GPUStreamReaderBase):
         return flat.reshape((nsets * self.samples_per_frame, nslot, h0.nchan))
 
 
+class VDIFStreamWriter(GPUStreamWriterBase):
+    """VDIF stream writer (vdif/base.py:756-807): samples of shape
+    ``(n, nthread, nchan)`` are packed on the GPU; one frame per thread and
+    time step is written, threads in increasing thread_id order."""
+
+    def __init__(self, fh_raw, header0=None, sample_rate=None, nthread=1,
+                 squeeze=True, **kwargs):
+        if header0 is None:
+            kwargs.setdefault('edv', False)
+            if sample_rate is not None and kwargs['edv'] in (1, 3):
+                kwargs.setdefault('sample_rate', sample_rate)
+            time = kwargs.pop('time', None)
+            header0 = VDIFHeader.fromvalues(verify=False, **kwargs)
+            if sample_rate is None:
+                sample_rate = header0.sample_rate
+            if time is not None and sample_rate is not None:
+                header0.set_time(time, frame_rate=sample_rate / header0.samples_per_frame)
+            header0.verify()
+        if sample_rate is None:
+            sample_rate = header0.sample_rate
+        if sample_rate is None:
+            raise ValueError("the sample rate must be passed either "
+                             "explicitly, or through the header if it "
+                             "can be stored there.")
+        super().__init__(fh_raw, header0, sample_rate=sample_rate,
+                         samples_per_frame=header0.samples_per_frame,
+                         unsliced_shape=(nthread, header0.nchan),
+                         bps=header0.bps, complex_data=header0.complex_data,
+                         squeeze=squeeze)
+        self._frame_rate = int(round(self.sample_rate / self.samples_per_frame))
+        self._start_time = header0.get_time(frame_rate=self._frame_rate)
+        self._coder = (_lib.CODER_MARK5B if header0.edv == 0xab else _lib.CODER_VDIF)
+
+    def _write_frames(self, data, valid):
+        from .. import synth
+        nthread, nchan = self._unsliced_shape
+        spf = self.samples_per_frame
+        nsets = data.shape[0] // spf
+        # (set, sample, thread, chan) -> (set, thread, sample, chan): payload order
+        block = data.reshape(nsets, spf, nthread, nchan).permute(0, 2, 1, 3).contiguous()
+        packed = kernels.encode_flat(block, self._coder, self.bps).cpu().numpy()
+        payloads = packed.reshape(nsets, nthread, self.header0.payload_nbytes)
+        h = self.header0.copy()
+        idx = self.header0['frame_nr'] + self._nframes_written
+        h['seconds'] = self.header0['seconds'] + idx // self._frame_rate
+        h['frame_nr'] = idx % self._frame_rate
+        base_tid = self.header0['thread_id']
+        invalid = [(s, t) for s in np.nonzero(~np.asarray(valid))[0] for t in range(nthread)]
+        image = synth.vdif_file_image(payloads, h, [base_tid + t for t in range(nthread)],
+                                      self._frame_rate, invalid=invalid)
+        self.fh_raw.write(image.tobytes())
+
+
 def open(name, mode='rs', **kwargs):
-    """Open a VDIF file for reading: ``'rb'`` gives a `VDIFFileReader`,
-    ``'rs'`` a `VDIFStreamReader` (vdif/base.py:810-884).  Writing modes are
-    outside the decode hot path; use ``baseband_amd.synth`` to make files."""
+    """``'rb'`` gives a `VDIFFileReader`, ``'rs'`` a `VDIFStreamReader`,
+    ``'ws'`` a `VDIFStreamWriter` (vdif/base.py:810-884)."""
+    if mode == 'ws':
+        fh = name if hasattr(name, 'write') else io.open(name, 'wb')
+        return VDIFStreamWriter(fh, **kwargs)
     if mode not in ('rb', 'rs'):
-        raise ValueError("only reading modes 'rb' and 'rs' are supported "
+        raise ValueError("supported modes are 'rb', 'rs' and 'ws' "
                          "(got {!r}).".format(mode))
     fh = name if hasattr(name, 'read') else io.open(name, 'rb')
     if mode == 'rb':

@@ -313,6 +313,30 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
                        const bb_tiled_params *params,
                        float *d_out, size_t out_elems, void *stream);
 
+/* ---- encoders (write side) ----------------------------------------------- */
+
+/*
+ * float32 samples -> packed codes, the inverse of bb_decode_frames for one
+ * contiguous run.  Thresholds and rounding follow
+ * the reference encoders operation by operation: encode_1bit_base /
+ * encode_2bit_base (incl. NumPy's floor_divide) / encode_4bit_base /
+ * encode_8bit (base/encoding.py:63-158; vdif/payload.py:77-114), Mark 5B
+ * sign/magnitude ordering (mark5b/payload.py:84-106), integer formats
+ * (gsb/payload.py:44-52, dada/payload.py:17-18).  Complex data are passed as
+ * interleaved (re, im) float32.  nelem must be a multiple of 4 and of 8/bps.
+ */
+int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
+                   void *d_out, size_t out_nbytes, void *stream);
+
+/*
+ * Mark 4 track multiplexing (mark4/payload.py:138-300): nwords stream words
+ * from nwords * ntrack/2 float32 values laid out (sample, channel); the bit
+ * maps are those of bb_decode_mark4.
+ */
+int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
+                    const uint8_t sign_bit[32], const uint8_t mag_bit[32],
+                    void *d_out, size_t out_nbytes, void *stream);
+
 /* ---- tuning knobs (performance experiments; results never change) ------ */
 #define BB_TUNE_FLAT_VARIANT   0   /* 0 = workgroup per frame, 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16/32 tiles (default) */
 #define BB_TUNE_NT_STORES      1   /* 1 = non-temporal stores */

@@ -782,3 +782,45 @@ def gsb_read_phased(files, nframes, payload_nbytes, nchan=512, bps=8,
             d = d.view(np.complex64)
         out.append(d.reshape(-1, P, nchan))
     return np.concatenate(out)
+
+
+# --------------------------------------------------------------------------
+# Encoders: base/encoding.py:63-158, vdif/payload.py:77-114,
+# mark5b/payload.py:78-106, gsb/payload.py:44-52, dada/payload.py:17-18,
+# mark4/payload.py:138-300.  float32 in, packed codes out.
+# --------------------------------------------------------------------------
+def encode_codes(values, coder, bps):
+    """Un-packed integer codes for float32 `values` (flat)."""
+    v = np.asarray(values, dtype=np.float32)
+    if coder in ('vdif', 'mark5b'):
+        if bps == 1:
+            if coder == 'vdif':                          # encode_1bit_base
+                return (v >= np.float32(0.)).astype(np.uint8)
+            return np.signbit(v).astype(np.uint8)        # mark5b/payload.py:84-87
+        if bps == 2:                                     # encode_2bit_base
+            w = np.clip(v, -1.5 * TWO_BIT_1_SIGMA, 1.5 * TWO_BIT_1_SIGMA)
+            w = w + np.float32(2 * TWO_BIT_1_SIGMA)
+            c = np.floor_divide(w, np.float32(TWO_BIT_1_SIGMA)).astype(np.uint8)
+            if coder == 'mark5b':
+                c = np.array([0, 2, 1, 3], np.uint8)[c]
+            return c
+        if coder == 'vdif' and bps == 4:                 # encode_4bit_base
+            w = v * np.float32(FOUR_BIT_1_SIGMA)
+            w = w + np.float32(8.5)
+            return np.clip(w, 0., 15.).astype(np.uint8)
+        if coder == 'vdif' and bps == 8:                 # encode_8bit
+            return np.clip(np.rint(v * np.float32(EIGHT_BIT_1_SIGMA) + np.float32(127.5)),
+                           0, 255).astype(np.uint8)
+    if coder == 'int':
+        if bps == 8:
+            return np.clip(np.rint(v), -128, 127).astype(np.int8).view(np.uint8)
+        if bps == 4:
+            return (np.clip(np.around(v), -8, 7).astype(np.int8) & 0xf).astype(np.uint8)
+    raise KeyError((coder, bps))
+
+
+def encode_flat(values, coder, bps):
+    """Packed bytes, first sample in the least significant bits."""
+    c = encode_codes(values, coder, bps).reshape(-1, 8 // bps).astype(np.uint8)
+    shifts = (np.arange(8 // bps) * bps).astype(np.uint8)
+    return np.bitwise_or.reduce(c << shifts, axis=-1).astype(np.uint8)

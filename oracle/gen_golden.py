@@ -656,6 +656,49 @@ def gen_vdif_edv_ab():
     print('vdif edv 0xab', back.shape, 'oracle == reference')
 
 
+def gen_encode():
+    """Reference ENCODERS on continuous float32 inputs (values near and far
+    from the decision thresholds).  Stored: the inputs and the packed words."""
+    from baseband.vdif import payload as vp
+    from baseband.mark5b import payload as m5p
+    from baseband.gsb import payload as gp
+    from baseband.dada import payload as dp
+    from baseband.base import encoding as enc
+    rng = np.random.default_rng(2024)
+    x = (rng.standard_normal(8192) * 2.2).astype(np.float32)
+    # exact thresholds, levels, halves, extremes, signed zeros
+    special = np.array([0., -0., 2.174564, -2.174564, 4.349128, -4.349128, 3.261846,
+                        -3.261846, 1e9, -1e9, 0.5, -0.5, 1.5, 2.5, -1.5, -2.5, 127.5,
+                        -128.5, 126.5, 3.316505, -3.316505, 1., -1., 0.16949153,
+                        -0.16949153, 7.5 / 2.95, -7.5 / 2.95, 2.5423729, 1e-30, -1e-30,
+                        0.014084507, -0.014084507], dtype=np.float32)
+    x[:len(special)] = special
+    thr = np.float32(2.174564)
+    x[64:96] = np.nextafter(thr, np.float32(10)) * np.array([1, -1] * 16, np.float32)
+    x[96:128] = np.nextafter(thr, np.float32(-10)) * np.array([1, -1] * 16, np.float32)
+    out = {'input': x}
+    for name, fn, shape in (('vdif1', vp.encode_1bit, None), ('vdif2', vp.encode_2bit, None),
+                            ('vdif4', vp.encode_4bit, None), ('vdif8', enc.encode_8bit, None),
+                            ('mark5b1', m5p.encode_1bit, None), ('mark5b2', m5p.encode_2bit, None),
+                            ('int4', gp.encode_4bit, None), ('int8', dp.encode_8bit, None)):
+        out[name] = np.ascontiguousarray(fn(x.copy())).view(np.uint8).ravel()
+    for coder, bps, key in (('vdif', 1, 'vdif1'), ('vdif', 2, 'vdif2'), ('vdif', 4, 'vdif4'),
+                            ('vdif', 8, 'vdif8'), ('mark5b', 1, 'mark5b1'), ('mark5b', 2, 'mark5b2'),
+                            ('int', 4, 'int4'), ('int', 8, 'int8')):
+        got = orc.encode_flat(x, coder, bps) if bps < 8 else orc.encode_codes(x, coder, bps)
+        assert np.array_equal(got, out[key]), key
+    # Mark 4: the five modes, from (nsample, nchan) data
+    from baseband.mark4 import payload as m4p
+    for key, encfn in m4p.Mark4Payload._encoders.items():
+        nchan, sig, fanout = key
+        data = x[:nchan * fanout * (8192 // (nchan * fanout))].reshape(-1, nchan)
+        w = encfn(data.copy())
+        out['mark4_%d_%s_%d' % (nchan, 'ft' if sig != 2 else '2', fanout)] = \
+            np.ascontiguousarray(w).view(np.uint8).ravel()
+    np.savez_compressed(os.path.join(GOLD, 'encode_cases.npz'), **out)
+    print('encode: oracle == reference for', sorted(k for k in out if k != 'input'))
+
+
 def gen_vdif_corrupt():
     """File-surgery cases of the reference's own corrupt-file tests
     (vdif/tests/test_corrupt_files.py:13-156): a tripled sample.vdif with
@@ -735,7 +778,7 @@ if __name__ == '__main__':
              ('mark4_bitmaps', gen_mark4_bitmaps), ('mark4_samples', gen_mark4_samples),
              ('mark4_synth', gen_mark4_synth), ('guppi', gen_guppi), ('dada', gen_dada),
              ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt),
-             ('vdif_edv_ab', gen_vdif_edv_ab)]
+             ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

@@ -1,0 +1,188 @@
+"""GPU encoders (float32 -> packed codes) against the reference encoders'
+outputs (tests/golden/encode_cases.npz) and the oracle."""
+import json
+
+import numpy as np
+import pytest
+
+import bb_oracle_np as orc
+from conftest import golden_path, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+CODERS = {'vdif': 0, 'mark5b': 1, 'int': 2}
+CASES = [('vdif', 1, 'vdif1'), ('vdif', 2, 'vdif2'), ('vdif', 4, 'vdif4'), ('vdif', 8, 'vdif8'),
+         ('mark5b', 1, 'mark5b1'), ('mark5b', 2, 'mark5b2'), ('int', 4, 'int4'), ('int', 8, 'int8')]
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return np.load(golden_path('encode_cases.npz'))
+
+
+@pytest.mark.parametrize('coder,bps,key', CASES)
+def test_flat_encoders_match_reference(gold, coder, bps, key):
+    import torch
+    from baseband_amd import kernels
+    x = torch.from_numpy(gold['input']).cuda()
+    got = kernels.encode_flat(x, CODERS[coder], bps).cpu().numpy()
+    assert np.array_equal(got, gold[key])
+
+
+@pytest.mark.parametrize('coder,bps,key', CASES)
+def test_flat_encoders_large_random_vs_oracle(coder, bps, key):
+    import torch
+    from baseband_amd import kernels
+    rng = np.random.default_rng(bps * 7 + len(coder))
+    scale = {1: 1.0, 2: 2.2, 4: 1.4, 8: 1.3}[bps] * (30. if coder == 'int' and bps == 8 else 1.)
+    x = (rng.standard_normal(1 << 20) * scale).astype(np.float32)
+    got = kernels.encode_flat(torch.from_numpy(x).cuda(), CODERS[coder], bps).cpu().numpy()
+    want = orc.encode_flat(x, coder, bps) if bps < 8 else orc.encode_codes(x, coder, bps)
+    assert np.array_equal(got, want)
+    # decode(encode(x)) == nearest level, and re-encoding is idempotent
+    dec = kernels.decode_frames(torch.from_numpy(want).cuda(), 1, want.size, CODERS[coder], bps)
+    again = kernels.encode_flat(dec, CODERS[coder], bps).cpu().numpy()
+    assert np.array_equal(again, want)
+
+
+def test_complex_and_errors():
+    import torch
+    from baseband_amd import kernels, _lib
+    z = torch.tensor([1 - 3j, 0.5 + 9j, -0.1 - 0.2j, 2.2 + 2.1j], dtype=torch.complex64, device='cuda')
+    got = kernels.encode_flat(z, 0, 2).cpu().numpy()
+    want = orc.encode_flat(np.array([1, -3, .5, 9, -.1, -.2, 2.2, 2.1], np.float32), 'vdif', 2)
+    assert np.array_equal(got, want)
+    with pytest.raises(KeyError):
+        kernels.encode_flat(torch.zeros(8, device='cuda'), _lib.CODER_MARK5B, 4)
+    with pytest.raises(_lib.BBError):
+        kernels.encode_flat(torch.zeros(6, device='cuda'), 0, 2)       # not a multiple of 4
+
+
+def test_mark4_encoders_match_reference(gold):
+    import torch
+    from baseband_amd import kernels
+    with open(golden_path('mark4_bitmaps.json')) as f:
+        maps = json.load(f)
+    x = gold['input']
+    for name, e in maps.items():
+        nchan, fanout, nt = e['nchan'], e['fanout'], e['ntrack']
+        n = nchan * fanout * (8192 // (nchan * fanout))
+        data = torch.from_numpy(x[:n].reshape(-1, nchan).copy()).cuda()
+        got = kernels.encode_mark4(data, nt, e['sign_bit'], e['mag_bit']).cpu().numpy()
+        assert np.array_equal(got, gold['mark4_' + name]), name
+        # and back
+        dbuf = torch.from_numpy(np.concatenate([got, np.zeros(8, np.uint8)])).cuda()
+        dec = kernels.decode_mark4(dbuf, 1, nt, got.size // (nt // 8), e['sign_bit'], e['mag_bit'])
+        lev = orc.LEVELS_2[orc.encode_codes(x[:n], 'vdif', 2)]
+        assert bits_equal(dec.cpu().numpy(), lev)
+
+
+VDIF_WRITE_CASES = ['vdif_cfg2_small', 'vdif_cfg3_small', 'vdif_bps1_c4', 'vdif_bps4_cplx_t2',
+                    'vdif_bps8_real_c2', 'vdif_bps8_cplx_t4', 'vdif_bps2_t8_c1',
+                    'vdif_legacy_bps2', 'vdif_bps4_t2_c1']
+
+
+@pytest.mark.parametrize('name', VDIF_WRITE_CASES)
+def test_vdif_stream_writer_is_byte_identical_to_reference(manifest, name):
+    """open(..., 'ws').write(data) produces the file the reference's stream
+    writer produced for the same data (tests/golden/synth/*.bin)."""
+    import io
+    import torch
+    from conftest import load_expected, load_file
+    from baseband_amd import vdif
+    case = manifest[name]
+    data = load_expected(name)
+    blob = load_file(case['file'])
+    kw = dict(edv=case['edv'], bps=case['bps'], nchan=case['nchan'],
+              complex_data=case['complex_data'], station='AA',
+              time=np.datetime64('2020-01-01T00:00:00'))
+    if case['edv'] == 3:
+        kw['frame_length'] = 629
+    else:
+        kw['samples_per_frame'] = case['samples_per_frame']
+    out = io.BytesIO()
+    out.close = lambda: None                     # keep the buffer readable
+    fw = vdif.open(out, 'ws', sample_rate=case['frame_rate'] * case['samples_per_frame'],
+                   nthread=case['nthread'], squeeze=False, **kw)
+    # feed it in uneven pieces, from the host and from the device
+    n = data.shape[0]
+    cuts = [0, 7, n // 3 + 1, n // 2, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        piece = data[a:b]
+        fw.write(torch.from_numpy(piece).cuda() if a % 2 else piece)
+    assert fw.tell() == n
+    fw.close()
+    mine = np.frombuffer(out.getvalue(), np.uint8)
+    nth = case['nthread']
+    if nth > 1:                                  # the fixture stores threads as 1,3,..,0,2,..
+        fn = len(blob) // (case['nframes'] * nth)
+        perm = list(range(1, nth, 2)) + list(range(0, nth, 2))
+        mine = mine.reshape(case['nframes'], nth, fn)[:, perm].reshape(-1)
+    assert mine.tobytes() == blob.tobytes()
+
+
+def test_vdif_writer_partial_last_frame_and_roundtrip(manifest, tmp_path):
+    from baseband_amd import vdif
+    rng = np.random.default_rng(5)
+    lev = orc.LEVELS_2
+    data = lev[rng.integers(0, 4, size=(2500, 2, 4))].astype(np.float32)
+    p = str(tmp_path / 'w.vdif')
+    with pytest.warns(UserWarning, match='partial buffer'):
+        with vdif.open(p, 'ws', sample_rate=100000., nthread=2, edv=0, bps=2, nchan=4,
+                       samples_per_frame=1000, station='ab',
+                       time=np.datetime64('2021-03-04T05:06:07')) as fw:
+            fw.write(data[:1234])
+            fw.write(data[1234:], valid=True)
+    with vdif.open(p, 'rs', sample_rate=100000., squeeze=False, verify=False) as fr:
+        assert fr.shape == (3000, 2, 4)
+        assert str(fr.start_time).startswith('2021-03-04T05:06:07')
+        back = fr.read().cpu().numpy()
+    assert bits_equal(back[:2000], data[:2000])
+    assert np.all(back[2000:] == 0.)             # padded frame is flagged invalid -> fill
+
+
+@pytest.mark.parametrize('name', ['m5b_c16_b2', 'm5b_c8_b1', 'm5b_c4_b2'])
+def test_mark5b_stream_writer_is_byte_identical_to_reference(manifest, name):
+    import io
+    from conftest import load_expected, load_file
+    from baseband_amd import mark5b
+    case = manifest[name]
+    data = load_expected(name)
+    blob = load_file(case['file'])
+    out = io.BytesIO()
+    out.close = lambda: None
+    with mark5b.open(out, 'ws', sample_rate=case['frame_rate'] * case['samples_per_frame'],
+                     nchan=case['nchan'], bps=case['bps'],
+                     time=np.datetime64('2014-06-13T05:30:01')) as fw:
+        fw.write(data)
+    mine = np.frombuffer(out.getvalue(), np.uint8).reshape(-1, 10016)
+    ref = blob.reshape(-1, 10016)
+    for f in range(case['nframes']):
+        if f in case['invalid']:
+            assert mine[f, :16].tobytes() == ref[f, :16].tobytes()   # payload was replaced in the fixture
+        else:
+            assert mine[f].tobytes() == ref[f].tobytes(), f
+
+
+@pytest.mark.parametrize('name', ['m4_t64_f4', 'm4_t32_f4', 'm4_t32_f2', 'm4_t16_f4'])
+def test_mark4_stream_writer_is_byte_identical_to_reference(manifest, name):
+    import io
+    from conftest import load_expected, load_file
+    from baseband_amd import mark4
+    case = manifest[name]
+    data = load_expected(name)
+    blob = load_file(case['file'])
+    out = io.BytesIO()
+    out.close = lambda: None
+    with mark4.open(out, 'ws', sample_rate=case['frame_rate'] * case['samples_per_frame'],
+                    ntrack=case['ntrack'], fanout=case['fanout'], bps=2,
+                    time=np.datetime64(case['start_time'])) as fw:
+        fw.write(data[:1000])
+        fw.write(data[1000:])
+    fn = case['ntrack'] * 2500
+    mine = np.frombuffer(out.getvalue(), np.uint8)
+    assert len(mine) == len(blob)
+    for f in range(case['nframes']):
+        if f in case['invalid']:
+            continue            # the fixture's error-flag frame decoded to fill
+        assert mine[f * fn:(f + 1) * fn].tobytes() == blob[f * fn:(f + 1) * fn].tobytes(), f

@@ -129,6 +129,18 @@ def main():
     out = torch.empty(nb, dtype=torch.float32, device=dev)
     ms = timeit(lambda: kernels.decode_frames(buf, 1, nb, _lib.CODER_INT, 8, src0=0, out=out))
     report('cfg4b DADA 8-bit 2 pol complex (k_decode_flat_pipe INT8)', ms, nb, nb * 4, nb // 2)
+    # write side: 2-bit VDIF encode of 8 GiB worth of payload (read-amplified twin of cfg1)
+    del out
+    nfl = (nbytes // 8000) * 32000
+    x = torch.empty(nfl, dtype=torch.float32, device=dev)
+    x.normal_(0., 2.2, generator=g)
+    ms = timeit(lambda: kernels.encode_flat(x, 0, 2))
+    report('encode: float32 -> 2-bit VDIF codes (k_encode_flat)', ms, nfl * 4, nfl // 4, nfl)
+    m = BITMAPS[(8, 2, 4)]
+    ms = timeit(lambda: kernels.encode_mark4(x, 64, m['sign_bit'], m['mag_bit']))
+    report('encode: float32 -> Mark 4 64-track words (k_encode_mark4)', ms, nfl * 4, nfl // 4, nfl)
+    del x
+    out = torch.empty(nb, dtype=torch.float32, device=dev)
     # yardstick: the same 1 B -> 4 B cast done by the framework's elementwise kernel
     i8 = buf[:nb].view(torch.int8)
     ms = timeit(lambda: torch.Tensor.copy_(out, i8))
