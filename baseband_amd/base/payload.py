@@ -109,13 +109,17 @@ class PayloadBase:
 
     @classmethod
     def fromdata(cls, data, header=None, bps=2, **kwargs):
-        """Encode samples on the host (only used to synthesise inputs)."""
-        if isinstance(data, torch.Tensor):
-            data = data.cpu().numpy()
-        is_complex = data.dtype.kind == 'c'
+        """Encode samples as a payload.  Device tensors are packed by the GPU
+        encoders (bb_encode_flat), host arrays by the NumPy twins in
+        `base.encoding` (both bit-identical to the reference encoders)."""
+        on_gpu = isinstance(data, torch.Tensor) and data.is_cuda
+        if isinstance(data, torch.Tensor) and not on_gpu:
+            data = data.numpy()
+        is_complex = data.is_complex() if on_gpu else data.dtype.kind == 'c'
+        encode = cls._encode_device if on_gpu else cls._encode_data
         if header is None:
-            words = cls._encode_data(data, bps, **kwargs)
-            return cls(words, bps=bps, sample_shape=data.shape[1:],
+            words = encode(data, bps, **kwargs)
+            return cls(words, bps=bps, sample_shape=tuple(data.shape[1:]),
                        complex_data=is_complex)
         if tuple(header.sample_shape) != tuple(data.shape[1:]):
             raise ValueError(
@@ -125,11 +129,21 @@ class PayloadBase:
             kinds = ['complex' if c else 'real'
                      for c in (header.complex_data, is_complex)]
             raise ValueError("header is for {0} data but data are {1}".format(*kinds))
-        return cls(cls._encode_data(data, header.bps, **kwargs), header=header)
+        return cls(encode(data, header.bps, **kwargs), header=header)
 
     @classmethod
     def _encode_data(cls, data, bps, **kwargs):
         raise ValueError(f"{cls.__name__} cannot encode data")
+
+    @classmethod
+    def _encode_device(cls, data, bps, coder_id=None, **kwargs):
+        """Pack a device tensor with the GPU encoder of this payload's coder."""
+        coder_id = cls._coder_id if coder_id is None else coder_id
+        try:
+            packed = kernels.encode_flat(data, coder_id, bps)
+        except KeyError:
+            raise ValueError(f"{cls.__name__} cannot encode data with {bps} bits") from None
+        return packed.cpu().numpy().view(cls._dtype_word)
 
     def tofile(self, fh):
         return fh.write(self.words.tobytes())

@@ -14,6 +14,27 @@ import numpy as np
 import torch
 
 
+class LazyWriteFile:
+    """File that is created (truncated) only when the first bytes are written
+    or on close, so that a writer whose arguments turn out to be invalid never
+    clobbers an existing file."""
+
+    def __init__(self, name):
+        self.name = name
+        self._fh = None
+
+    def _open(self):
+        if self._fh is None:
+            self._fh = open(self.name, 'wb')
+        return self._fh
+
+    def write(self, data):
+        return self._open().write(data)
+
+    def close(self):
+        self._open().close()
+
+
 class GPUStreamWriterBase:
     def __init__(self, fh_raw, header0, *, sample_rate, samples_per_frame,
                  unsliced_shape, bps, complex_data, squeeze=True):

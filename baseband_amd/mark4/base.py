@@ -19,7 +19,7 @@ from .header import Mark4Header, MARK4_DTYPES, stream2words
 from .payload import Mark4Payload
 from .frame import Mark4Frame
 from ._bitmaps import BITMAPS
-from ..base.writer import GPUStreamWriterBase
+from ..base.writer import GPUStreamWriterBase, LazyWriteFile
 
 __all__ = ['Mark4FileReader', 'Mark4StreamReader', 'Mark4StreamWriter', 'open']
 
@@ -246,7 +246,7 @@ def open(name, mode='rs', **kwargs):
     """``'rb'`` -> `Mark4FileReader`, ``'rs'`` -> `Mark4StreamReader`,
     ``'ws'`` -> `Mark4StreamWriter` (mark4/base.py:337-430)."""
     if mode == 'ws':
-        fh = name if hasattr(name, 'write') else io.open(name, 'wb')
+        fh = name if hasattr(name, 'write') else LazyWriteFile(name)
         return Mark4StreamWriter(fh, **kwargs)
     if mode not in ('rb', 'rs'):
         raise ValueError("supported modes are 'rb', 'rs' and 'ws' "

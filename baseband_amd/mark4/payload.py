@@ -66,14 +66,21 @@ class Mark4Payload(PayloadBase):
     @classmethod
     def fromdata(cls, data, header):
         """Encode (nsample, nchan) data with the header's track layout."""
-        if isinstance(data, torch.Tensor):
-            data = data.cpu().numpy()
-        if data.dtype.kind == 'c':
+        on_gpu = isinstance(data, torch.Tensor) and data.is_cuda
+        if isinstance(data, torch.Tensor) and not on_gpu:
+            data = data.numpy()
+        if (data.is_complex() if on_gpu else data.dtype.kind == 'c'):
             raise ValueError("Mark4 format does not support complex data.")
-        if header.sample_shape != data.shape[1:]:
+        if tuple(header.sample_shape) != tuple(data.shape[1:]):
             raise ValueError("header is for {0} channels but data has {1}"
                              .format(header.nchan, data.shape[-1]))
-        words = encode_mark4(data, header)
+        if on_gpu:
+            key = (header.nchan, header.magnitude_signature() or header.bps, header.fanout)
+            maps = BITMAPS[key]
+            words = kernels.encode_mark4(data, header.ntrack, maps['sign_bit'],
+                                         maps['mag_bit']).cpu().numpy().view(header.stream_dtype)
+        else:
+            words = encode_mark4(data, header)
         return cls(words, header)
 
 

@@ -17,7 +17,7 @@ from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
 from ..base.header import strided_header_words
 from .header import Mark5BHeader, crc16_mark5b
 from .frame import Mark5BFrame
-from ..base.writer import GPUStreamWriterBase
+from ..base.writer import GPUStreamWriterBase, LazyWriteFile
 
 __all__ = ['Mark5BFileReader', 'Mark5BStreamReader', 'Mark5BStreamWriter', 'open']
 
@@ -215,7 +215,7 @@ def open(name, mode='rs', **kwargs):
     """``'rb'`` -> `Mark5BFileReader`, ``'rs'`` -> `Mark5BStreamReader`,
     ``'ws'`` -> `Mark5BStreamWriter` (mark5b/base.py:356-428)."""
     if mode == 'ws':
-        fh = name if hasattr(name, 'write') else io.open(name, 'wb')
+        fh = name if hasattr(name, 'write') else LazyWriteFile(name)
         return Mark5BStreamWriter(fh, **kwargs)
     if mode not in ('rb', 'rs'):
         raise ValueError("supported modes are 'rb', 'rs' and 'ws' "

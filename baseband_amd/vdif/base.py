@@ -15,7 +15,7 @@ import torch
 from .. import _lib, kernels
 from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
-from ..base.writer import GPUStreamWriterBase
+from ..base.writer import GPUStreamWriterBase, LazyWriteFile
 from ..base.header import strided_header_words
 from .header import VDIFHeader
 from .frame import VDIFFrame, VDIFFrameSet
@@ -409,7 +409,7 @@ def open(name, mode='rs', **kwargs):
     """``'rb'`` gives a `VDIFFileReader`, ``'rs'`` a `VDIFStreamReader`,
     ``'ws'`` a `VDIFStreamWriter` (vdif/base.py:810-884)."""
     if mode == 'ws':
-        fh = name if hasattr(name, 'write') else io.open(name, 'wb')
+        fh = name if hasattr(name, 'write') else LazyWriteFile(name)
         return VDIFStreamWriter(fh, **kwargs)
     if mode not in ('rb', 'rs'):
         raise ValueError("supported modes are 'rb', 'rs' and 'ws' "

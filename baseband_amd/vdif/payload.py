@@ -59,12 +59,19 @@ class VDIFPayload(PayloadBase):
         return enc.pack_codes(codes, bps).view('<u4')
 
     @classmethod
+    def _encode_device(cls, data, bps, edv=None, **kwargs):
+        coder = _lib.CODER_MARK5B if edv == 0xab else _lib.CODER_VDIF
+        return super()._encode_device(data, bps, coder_id=coder)
+
+    @classmethod
     def fromdata(cls, data, header=None, bps=2, edv=None):
         if header is not None:
             edv = header.edv
         if edv == 0xab:
+            import torch
             bps = bps if header is None else header.bps
-            words = cls._encode_data(data, bps, edv=edv)
-            return cls(words, header, sample_shape=data.shape[1:], bps=bps,
+            on_gpu = isinstance(data, torch.Tensor) and data.is_cuda
+            words = (cls._encode_device if on_gpu else cls._encode_data)(data, bps, edv=edv)
+            return cls(words, header, sample_shape=tuple(data.shape[1:]), bps=bps,
                        complex_data=False)
         return super().fromdata(data, header=header, bps=bps)

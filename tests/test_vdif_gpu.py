@@ -236,7 +236,14 @@ def test_top_level_open(manifest):
     with pytest.raises(ValueError):
         baseband_amd.open(golden_path('samples/sample.vdif'), 'rs')
     with pytest.raises(ValueError):
-        baseband_amd.vdif.open(golden_path('samples/sample.vdif'), 'ws')
+        baseband_amd.vdif.open(golden_path('samples/sample.vdif'), 'xs')
+    # an invalid writer call must not touch an existing file
+    import os
+    size = os.path.getsize(golden_path('samples/sample.vdif'))
+    with pytest.raises(ValueError):
+        baseband_amd.vdif.open(golden_path('samples/sample.vdif'), 'ws', edv=0, bps=2,
+                               nchan=1, samples_per_frame=32000)        # no sample rate
+    assert os.path.getsize(golden_path('samples/sample.vdif')) == size
 
 
 @pytest.mark.parametrize('cfg', [
