@@ -33,6 +33,7 @@ TUNE_NT_STORES = 1
 TUNE_BLOCKS = 2
 TUNE_NT_LOADS = 3
 TUNE_TILE_ELEMS = 4
+TUNE_ENCODE_DIRECT = 5
 
 
 class BBError(RuntimeError):
@@ -118,6 +119,7 @@ SIGNATURES = [
     ('bb_last_hip_error', C.c_int, []),
     ('bb_init', C.c_int, []),
     ('bb_get_levels', C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _sz]),
+    ('bb_get_encode_thresholds', C.c_int, [C.POINTER(C.c_float)]),
     ('bb_vdif_scan', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp]),
     ('bb_vdif_locate', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_vdif_scan_at', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
@@ -154,4 +156,13 @@ def get_levels(coder, bps):
     out = np.empty(n, dtype=np.float32)
     check(lib.bb_get_levels(coder, bps, out.ctypes.data_as(C.POINTER(C.c_float)), n),
           'bb_get_levels')
+    return out
+
+
+def encode_thresholds():
+    """float32[3]: inputs at which the 2-bit encoder steps to code 1, 2, 3."""
+    import numpy as np
+    out = np.empty(3, np.float32)
+    check(lib.bb_get_encode_thresholds(out.ctypes.data_as(C.POINTER(C.c_float))),
+          'bb_get_encode_thresholds')
     return out

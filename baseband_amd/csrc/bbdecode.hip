@@ -22,11 +22,41 @@ inline int hip_fail(hipError_t e) { t_last_hip = (int)e; return BB_EIO; }
 
 // ---- level tables ---------------------------------------------------------
 float h_levels[3][4][256];
+float h_enc2_thr[3];
 std::once_flag h_levels_once;
+
+// floats in increasing order <-> uint32 keys in increasing order
+inline uint32_t float_key(float f)
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float key_float(uint32_t k)
+{
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f; memcpy(&f, &u, 4);
+    return f;
+}
+
+// Smallest float at which the reference 2-bit encoder reaches each code
+// (the encoder is a monotone step function; see k_encode.h).
+void fill_encode_thresholds()
+{
+    const uint32_t kmin = float_key(-3.4028234663852886e38f), kmax = float_key(3.4028234663852886e38f);
+    for (uint32_t code = 1; code <= 3; ++code) {
+        uint32_t lo = kmin, hi = kmax;            // code(lo) < code <= code(hi)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (bb_encode2_reference(key_float(mid)) >= code) hi = mid; else lo = mid;
+        }
+        h_enc2_thr[code - 1] = key_float(hi);
+    }
+}
 
 void fill_host_levels()
 {
     memset(h_levels, 0, sizeof(h_levels));
+    fill_encode_thresholds();
     // base/encoding.py:14  OPTIMAL_2BIT_HIGH = 3.316505 -> float32
     const volatile float hi = 3.316505f;
     // VDIF, offset binary (base/encoding.py:52-56; vdif/payload.py:53-63)
@@ -83,6 +113,7 @@ int ensure_init()
     std::lock_guard<std::mutex> lock(g_init_mutex);
     std::call_once(h_levels_once, fill_host_levels);
     BB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_levels), h_levels, sizeof(h_levels)));
+    BB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_enc2_thr), h_enc2_thr, sizeof(h_enc2_thr)));
     if (dev < 64) g_dev_inited.fetch_or(1ull << dev, std::memory_order_release);
     return BB_OK;
 }
@@ -101,6 +132,7 @@ std::atomic<int> g_tune_nt{1};
 std::atomic<int> g_tune_blocks{0};
 std::atomic<int> g_tune_nt_loads{0};
 std::atomic<int> g_tune_tile_elems{8192};
+std::atomic<int> g_tune_encode_direct{0};
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
@@ -170,6 +202,14 @@ int bb_get_levels(int coder, int bps, float *h_out, size_t n)
     return BB_OK;
 }
 
+int bb_get_encode_thresholds(float h_thr[3])
+{
+    if (!h_thr) return BB_EINVAL;
+    std::call_once(h_levels_once, fill_host_levels);
+    memcpy(h_thr, h_enc2_thr, sizeof(h_enc2_thr));
+    return BB_OK;
+}
+
 int bb_tune(int knob, int value)
 {
     switch (knob) {
@@ -178,6 +218,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_BLOCKS:       g_tune_blocks = value;  return BB_OK;
         case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
         case BB_TUNE_TILE_ELEMS:   g_tune_tile_elems = value > 0 ? value : 8192; return BB_OK;
+        case BB_TUNE_ENCODE_DIRECT: g_tune_encode_direct = value; return BB_OK;
         default: return BB_EINVAL;
     }
 }
@@ -629,13 +670,17 @@ int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
     if ((nelem & 3) || ((nelem * (size_t)bps) & 7)) return BB_EINVAL;
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 3)) return BB_EINVAL;
     if (out_nbytes < nelem * (size_t)bps / 8) return BB_ERANGE;
+    { const int rc_ = ensure_init(); if (rc_) return rc_; }
     const uint64_t nquad = nelem / 4;
-    uint64_t blocks = (nquad + BB_BLOCK - 1) / BB_BLOCK;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    uint64_t blocks = (nquad / 256 + 3) / 4;              // one 256-quad run per wave
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks == 0) blocks = 1;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     uint8_t *o = (uint8_t *)d_out;
-#define BB_E(C, B) hipLaunchKernelGGL((k_encode_flat<C, B>), grid, block, 0, st, d_in, nquad, o)
+    const bool direct = g_tune_encode_direct.load() != 0;
+#define BB_E(C, B) do { if (direct && (B) == 2) hipLaunchKernelGGL((k_encode_flat<C, B, true>), grid, block, 0, st, d_in, nquad, o); \
+                        else hipLaunchKernelGGL((k_encode_flat<C, B, false>), grid, block, 0, st, d_in, nquad, o); } while (0)
     if (coder == BB_CODER_VDIF) {
         switch (bps) { case 1: BB_E(BB_CODER_VDIF, 1); break; case 2: BB_E(BB_CODER_VDIF, 2); break;
                        case 4: BB_E(BB_CODER_VDIF, 4); break; default: BB_E(BB_CODER_VDIF, 8); break; }
@@ -674,11 +719,16 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
     if (blocks > 256 * 32) blocks = 256 * 32;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;
+    { const int rc_ = ensure_init(); if (rc_) return rc_; }
+    const bool direct = g_tune_encode_direct.load() != 0;
+#define BB_M4E(N) do { if (direct) hipLaunchKernelGGL((k_encode_mark4<N, true>), grid, block, 0, st, a); \
+                       else hipLaunchKernelGGL((k_encode_mark4<N, false>), grid, block, 0, st, a); } while (0)
     switch (ntrack) {
-        case 16: hipLaunchKernelGGL(k_encode_mark4<16>, grid, block, 0, st, a); break;
-        case 32: hipLaunchKernelGGL(k_encode_mark4<32>, grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL(k_encode_mark4<64>, grid, block, 0, st, a); break;
+        case 16: BB_M4E(16); break;
+        case 32: BB_M4E(32); break;
+        default: BB_M4E(64); break;
     }
+#undef BB_M4E
     BB_HIP(hipGetLastError());
     return BB_OK;
 }

@@ -14,7 +14,7 @@
 
 // numpy.floor_divide for float32 (npy_divmodf): fmod-based, so that quotients
 // that round up to an integer in a plain division are still floored correctly.
-__device__ __forceinline__ float bb_np_floor_divide(float a, float b)
+__host__ __device__ __forceinline__ float bb_np_floor_divide_hd(float a, float b)
 {
     float mod = fmodf(a, b);
     float div = (a - mod) / b;
@@ -29,19 +29,39 @@ __device__ __forceinline__ float bb_np_floor_divide(float a, float b)
     return copysignf(0.0f, a / b);
 }
 
-template <int CODER, int BPS>
+// The 2-bit code is a monotone step function of the input, so it is fully
+// described by the three smallest floats at which it reaches 1, 2 and 3.
+// bb_init() finds them by bisection over the float32 bit patterns with the
+// exact reference arithmetic (bb_encode2_reference below, compiled for the
+// host), so the default path is three compares per sample.  DIRECT evaluates
+// the reference arithmetic on the device instead (BB_TUNE_ENCODE_DIRECT; the
+// GPU tests check both paths against each other over all 2^32 inputs).
+__device__ float g_enc2_thr[3];
+
+__host__ __device__ __forceinline__ float bb_np_floor_divide_hd(float a, float b);
+
+__host__ __device__ inline uint32_t bb_encode2_reference(float x)
+{
+    // base/encoding.py:77-102: clip to +-1.5 sigma, add 2 sigma, floor_divide by sigma
+    const float sigma = 2.174564f;
+    const float lo = (float)(-1.5 * 2.174564), hi = (float)(1.5 * 2.174564);
+    float w = x < lo ? lo : x;              // np.clip = minimum(maximum(x, lo), hi)
+    w = w > hi ? hi : w;
+    w = w + (float)(2 * 2.174564);
+    return (uint32_t)(int)bb_np_floor_divide_hd(w, sigma);
+}
+
+template <int CODER, int BPS, bool DIRECT = false>
 __device__ __forceinline__ uint32_t bb_encode_one(float x)
 {
     if (BPS == 1) {
         if (CODER == BB_CODER_VDIF) return x >= 0.0f ? 1u : 0u;          // base/encoding.py:63-74
         return (__float_as_uint(x) >> 31);                                // np.signbit (mark5b)
     } else if (BPS == 2) {
-        // base/encoding.py:77-102: clip to +-1.5 sigma, add 2 sigma, floor_divide by sigma
-        const float sigma = 2.174564f;
-        const float lo = (float)(-1.5 * 2.174564), hi = (float)(1.5 * 2.174564);
-        float w = fminf(fmaxf(x, lo), hi);
-        w = w + (float)(2 * 2.174564);
-        const uint32_t c = (uint32_t)(int)bb_np_floor_divide(w, sigma);
+        uint32_t c;
+        if (DIRECT) c = bb_encode2_reference(x);
+        else c = (uint32_t)(x >= g_enc2_thr[0]) + (uint32_t)(x >= g_enc2_thr[1])
+               + (uint32_t)(x >= g_enc2_thr[2]);
         if (CODER == BB_CODER_MARK5B) return ((c & 1u) << 1) | (c >> 1);  // reorder [0, 2, 1, 3]
         return c;
     } else if (BPS == 4) {
@@ -66,22 +86,67 @@ __device__ __forceinline__ uint32_t bb_encode_one(float x)
     }
 }
 
-// One float4 (16 coalesced bytes) per lane -> 4*BPS bits of output.
-template <int CODER, int BPS>
+template <int CODER, int BPS, bool DIRECT>
+__device__ __forceinline__ uint32_t bb_encode_quad(const bb_f4 v)
+{
+    return bb_encode_one<CODER, BPS, DIRECT>(v.x)
+         | (bb_encode_one<CODER, BPS, DIRECT>(v.y) << BPS)
+         | (bb_encode_one<CODER, BPS, DIRECT>(v.z) << (2 * BPS))
+         | (bb_encode_one<CODER, BPS, DIRECT>(v.w) << (3 * BPS));
+}
+
+// Quad q (4 floats = 16 input bytes) -> 4*BPS bits of output.  A wave takes
+// runs of 256 quads (4 KiB in): four coalesced float4 loads per lane are in
+// flight before the first compare; for 2-bit data the four result bytes of a
+// lane are transposed across the wave (ds_bpermute) so that the run leaves as
+// ONE coalesced 256-byte store.  Quads past the last whole run go through the
+// per-quad tail at the end.
+template <int CODER, int BPS, bool DIRECT>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
-    const uint64_t nquad_pad = (nquad + 63) & ~63ull;           // keep waves whole for the shuffle
-    for (uint64_t q = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x; q < nquad_pad; q += stride) {
-        uint32_t bits = 0;
-        if (q < nquad) {
-            const bb_f4 v = __builtin_nontemporal_load(reinterpret_cast<const bb_f4 *>(in) + q);
-            bits = bb_encode_one<CODER, BPS>(v.x)
-                 | (bb_encode_one<CODER, BPS>(v.y) << BPS)
-                 | (bb_encode_one<CODER, BPS>(v.z) << (2 * BPS))
-                 | (bb_encode_one<CODER, BPS>(v.w) << (3 * BPS));
+    const int lane = bb_lane();
+    const bb_f4 *in4 = reinterpret_cast<const bb_f4 *>(in);
+    const uint64_t nrun = nquad >> 8;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x) >> 6;
+    const uint64_t nwave = ((uint64_t)gridDim.x * BB_BLOCK) >> 6;
+    for (uint64_t r = wave0; r < nrun; r += nwave) {
+        const uint64_t q0 = (r << 8) + lane;
+        bb_f4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(in4 + q0 + 64 * j);
+        uint32_t bits[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bits[j] = bb_encode_quad<CODER, BPS, DIRECT>(v[j]);
+        if (BPS == 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) reinterpret_cast<uint32_t *>(out)[q0 + 64 * j] = bits[j];
+        } else if (BPS == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) reinterpret_cast<uint16_t *>(out)[q0 + 64 * j] = (uint16_t)bits[j];
+        } else if (BPS == 2) {
+            // byte of (load j, lane l) sits at run offset 64 j + l; output dword d
+            // = bytes of load d/16, lanes 4 (d%16) .. +3
+            const uint32_t mine = bits[0] | (bits[1] << 8) | (bits[2] << 16) | (bits[3] << 24);
+            const int sel = 8 * (lane >> 4), src = 4 * (lane & 15);
+            uint32_t word = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                word |= (((uint32_t)__shfl((int)mine, src + k) >> sel) & 0xffu) << (8 * k);
+            reinterpret_cast<uint32_t *>(out)[(r << 6) + lane] = word;
+        } else {
+            // nibble per quad: even lane = low nibble of the byte
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)bits[j], 1);
+                if (!(lane & 1)) out[(q0 + 64 * j) >> 1] = (uint8_t)(bits[j] | (other << 4));
+            }
         }
+    }
+    // tail: fewer than 256 quads, first workgroup only (whole waves for the shuffle)
+    if (blockIdx.x == 0) {
+        const uint64_t q = (nrun << 8) + threadIdx.x;
+        const uint32_t bits = q < nquad ? bb_encode_quad<CODER, BPS, DIRECT>(in4[q]) : 0u;
         if (BPS == 8) {
             if (q < nquad) reinterpret_cast<uint32_t *>(out)[q] = bits;
         } else if (BPS == 4) {
@@ -89,7 +154,6 @@ void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out)
         } else if (BPS == 2) {
             if (q < nquad) out[q] = (uint8_t)bits;
         } else {
-            // two lanes make one byte: even lane = low nibble
             const uint32_t other = (uint32_t)__shfl_xor((int)bits, 1);
             if (!(q & 1) && q < nquad) out[q >> 1] = (uint8_t)(bits | (other << 4));
         }
@@ -108,7 +172,7 @@ struct bb_m4enc_args {
 // (sample, channel) values to 2-bit codes (sign = code >> 1, magnitude =
 // code & 1), scatters them to their track bits, and the partial words are
 // OR-reduced with xor shuffles.
-template <int NTRACK>
+template <int NTRACK, bool DIRECT>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_encode_mark4(bb_m4enc_args a)
 {
@@ -130,7 +194,7 @@ void k_encode_mark4(bb_m4enc_args a)
             const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t c = bb_encode_one<BB_CODER_VDIF, 2>(vv[k]);
+                const uint32_t c = bb_encode_one<BB_CODER_VDIF, 2, DIRECT>(vv[k]);
                 part |= (uint64_t)(c >> 1) << ((spack >> (8 * k)) & 0xff);
                 part |= (uint64_t)(c & 1u) << ((mpack >> (8 * k)) & 0xff);
             }

@@ -96,6 +96,10 @@ int         bb_init(void);
 /* Copy the 2^bps-entry code -> level table of (coder, bps) to host memory
  * (what vdif/payload.py:25-63 and mark5b/payload.py:27-72 tabulate per byte). */
 int         bb_get_levels(int coder, int bps, float *h_levels, size_t n);
+/* The three float32 inputs at which the 2-bit encoder (encode_2bit_base,
+ * base/encoding.py:77-102) steps to code 1, 2, 3: code(x) = #{k : x >= thr[k]}.
+ * Found on the host by bisection over the reference arithmetic. */
+int         bb_get_encode_thresholds(float h_thr[3]);
 
 /* ---- frame index: header scan ------------------------------------------ */
 
@@ -343,6 +347,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_BLOCKS         2   /* 0 = default grid; >0 = number of workgroups */
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */
 #define BB_TUNE_TILE_ELEMS     4   /* elements per tile of bb_decode_i8_tiled (default 8192) */
+#define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
 int bb_tune(int knob, int value);
 
 #ifdef __cplusplus

@@ -67,3 +67,26 @@ def test_error_codes():
     with pytest.raises(_lib.BBError):
         _lib.check(_lib.BB_EINVAL, 'x')
     assert _lib.lib.bb_strerror(_lib.BB_ERANGE).decode().startswith('buffer')
+
+
+def test_encode_thresholds_equal_the_oracle_steps():
+    """The library derives the 2-bit encoder's three step positions on the host;
+    they must be the exact floats at which the NumPy restatement of
+    encode_2bit_base (base/encoding.py:77-102) changes code."""
+    import bb_oracle_np as orc
+    from baseband_amd import _lib
+    thr = _lib.encode_thresholds()
+    assert thr.dtype == np.float32 and thr.shape == (3,)
+    for k, t in enumerate(thr):
+        below = np.nextafter(t, np.float32(-np.inf))
+        codes = orc.encode_codes(np.array([below, t], np.float32), 'vdif', 2)
+        assert list(codes) == [k, k + 1]
+    # not the naive multiples of sigma: x + 2 sigma rounds for tiny negative x
+    assert thr[1] < 0 and thr[1] == np.float32(-2.3841858e-07)
+    # the step description reproduces the oracle on a dense sweep around each step
+    for t in thr:
+        u = np.arange(-20000, 20000, dtype=np.int64) + int(np.float32(t).view(np.int32))
+        x = u.astype(np.int32).view(np.float32)
+        want = orc.encode_codes(x, 'vdif', 2)
+        got = (x[:, None] >= thr[None, :]).sum(1)
+        assert np.array_equal(got, want)

@@ -45,6 +45,64 @@ def test_flat_encoders_large_random_vs_oracle(coder, bps, key):
     assert np.array_equal(again, want)
 
 
+def test_two_bit_threshold_encoder_equals_direct_arithmetic_for_every_float():
+    """Default 2-bit path (three compares against host-bisected thresholds) vs
+    the per-sample clip/add/floor_divide arithmetic, over all 2^32 float32 bit
+    patterns except NaNs (whose integer cast numpy leaves undefined)."""
+    import torch
+    from baseband_amd import kernels, _lib
+    chunk = 1 << 28
+    try:
+        for start in range(0, 1 << 32, chunk):
+            bits = torch.arange(start, start + chunk, dtype=torch.int64, device='cuda')
+            x = (bits - ((bits >> 31) << 32)).to(torch.int32).view(torch.float32)
+            x = torch.where(torch.isnan(x), torch.zeros_like(x), x)
+            del bits
+            kernels.tune(_lib.TUNE_ENCODE_DIRECT, 0)
+            fast = kernels.encode_flat(x, 0, 2)
+            fast5 = kernels.encode_flat(x, 1, 2)
+            kernels.tune(_lib.TUNE_ENCODE_DIRECT, 1)
+            direct = kernels.encode_flat(x, 0, 2)
+            direct5 = kernels.encode_flat(x, 1, 2)
+            assert torch.equal(fast, direct) and torch.equal(fast5, direct5)
+            del x, fast, direct, fast5, direct5
+    finally:
+        kernels.tune(_lib.TUNE_ENCODE_DIRECT, 0)
+
+
+@pytest.mark.parametrize('direct', [0, 1])
+def test_two_bit_encoder_near_steps_vs_oracle(direct):
+    import torch
+    from baseband_amd import kernels, _lib
+    thr = _lib.encode_thresholds()
+    xs = []
+    for t in list(thr) + [np.float32(-3.261846), np.float32(3.261846), np.float32(0)]:
+        u = np.arange(-4096, 4096, dtype=np.int64) + int(np.float32(t).view(np.int32))
+        xs.append(u.astype(np.int32).view(np.float32))
+    xs.append(np.array([np.inf, -np.inf, 1e38, -1e38, 1e-45, -1e-45, -0.0, 0.0], np.float32))
+    x = np.concatenate(xs)
+    x = x[:x.size // 256 * 256 + 4 * 7]       # whole runs plus a ragged tail of 7 quads
+    try:
+        kernels.tune(_lib.TUNE_ENCODE_DIRECT, direct)
+        for coder in ('vdif', 'mark5b'):
+            got = kernels.encode_flat(torch.from_numpy(x).cuda(), CODERS[coder], 2).cpu().numpy()
+            assert np.array_equal(got, orc.encode_flat(x, coder, 2))
+    finally:
+        kernels.tune(_lib.TUNE_ENCODE_DIRECT, 0)
+
+
+@pytest.mark.parametrize('coder,bps,key', CASES)
+@pytest.mark.parametrize('n', [4 * 8, 4 * 255, 4 * 256, 4 * 257 + 8, 4 * 1024 * 3 + 16])
+def test_flat_encoders_run_and_tail_sizes(coder, bps, key, n):
+    import torch
+    from baseband_amd import kernels
+    n = n // (32 // bps) * (32 // bps) if bps < 8 else n
+    x = (np.random.default_rng(n + bps).standard_normal(n) * 2.5).astype(np.float32)
+    got = kernels.encode_flat(torch.from_numpy(x).cuda(), CODERS[coder], bps).cpu().numpy()
+    want = orc.encode_flat(x, coder, bps) if bps < 8 else orc.encode_codes(x, coder, bps)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+
+
 def test_complex_and_errors():
     import torch
     from baseband_amd import kernels, _lib
