@@ -79,17 +79,6 @@ class VLBIFileReaderBase(FileBase):
         return self._image
 
 
-def _reopen(cls, name, kwargs, offset):
-    fh = io.open(name, 'rb')
-    try:
-        self = cls(fh, **kwargs)
-    except Exception:
-        fh.close()
-        raise
-    self.offset = offset
-    return self
-
-
 def _apply_squeeze(shape):
     return tuple(s for s in shape if s > 1)
 
@@ -377,10 +366,10 @@ class GPUStreamReaderBase:
     # -- pickling: reopen by file name at the saved offset
     # (base/base.py:123-151,1020-1032); device buffers are re-creatable
     def __reduce__(self):
-        init = getattr(self, '_init_args', None)
-        name = getattr(getattr(self.fh_raw, 'fh_raw', None), 'name', None)
-        if init is None or not isinstance(name, str):
-            raise TypeError("can only pickle readers opened from a named file")
+        recipe = getattr(self, '_pickle_recipe', None)
+        if recipe is None:
+            raise TypeError("can only pickle readers opened from named files")
         if self.closed:
             raise TypeError("cannot pickle a closed stream reader")
-        return (_reopen, (type(self), name, init, self.offset))
+        reopen, opener, source, init_args = recipe
+        return (reopen, (opener, source, init_args, self.offset))

@@ -136,6 +136,8 @@ def strided_header_words(buf, frame_nbytes, nwords, offset=0):
     """(nframes, nwords) uint32 view of the headers of a fixed-stride file
     image held in a uint8 NumPy array or memmap (no copy).  Only frames whose
     header lies completely inside the buffer are included."""
+    if hasattr(buf, 'header_words'):         # helpers.sequentialfile.SequenceImage
+        return buf.header_words(frame_nbytes, nwords, offset)
     buf = np.asarray(buf)[offset:]
     nframes = (len(buf) - 4 * nwords) // frame_nbytes + 1 if len(buf) >= 4 * nwords else 0
     u4 = np.frombuffer(buf, dtype='<u4', count=len(buf) // 4)

@@ -1,0 +1,151 @@
+"""One ``open()`` for every format: resolves what `name` is (file handle, file
+name, list of names, or a ``{file_nr}`` template), opens it -- a sequence goes
+through `helpers.sequentialfile` -- and hands the handle to the format's file
+or stream class.  Same call shapes as the reference's ``FileOpener``
+(base/base.py:1650-1837): modes ``'rb'``, ``'rs'``, ``'ws'`` (``'r'``/``'w'``
+mean the stream modes), ``file_size=`` for written sequences, template fields
+filled from ``header0`` or the header keywords.
+"""
+import io
+import os
+
+from ..helpers import sequentialfile as sf
+from .writer import LazyWriteFile
+
+__all__ = ['FormatOpener', 'source_kind']
+
+
+def source_kind(name):
+    """'fh', 'name', 'sequence' or 'template' (base/base.py:1694-1741)."""
+    if isinstance(name, str):
+        return 'template' if ('{' in name and '}' in name) else 'name'
+    if isinstance(name, os.PathLike):
+        return 'name'
+    if hasattr(name, 'read') or hasattr(name, 'write'):
+        return 'fh'
+    if hasattr(name, '__getitem__') or hasattr(name, '__iter__'):
+        return 'sequence'
+    raise ValueError("name '{}' not understood.".format(name))
+
+
+def _reopen_stream(opener, source, kwargs, offset):
+    """Unpickling: open again from the recorded source and go to `offset`."""
+    reader = opener(source, 'rs', **kwargs)
+    reader.offset = offset
+    return reader
+
+
+class FormatOpener:
+    """``open`` function of one format.
+
+    Parameters
+    ----------
+    fmt : str
+        Format name, for messages.
+    classes : dict
+        ``{'rb': FileReader, 'rs': StreamReader, 'ws': StreamWriter}``
+        (whichever exist).
+    sequencer : class
+        `FileNameSequencer` flavour used for templates.
+    default_file_size : callable, optional
+        ``f(header0) -> int`` -- file size used for written sequences when
+        the caller gives none (DADA, GUPPI: one frame per file).
+    """
+    def __init__(self, fmt, classes, sequencer=sf.FileNameSequencer,
+                 default_file_size=None):
+        self.fmt, self.classes = fmt, dict(classes)
+        self.sequencer = sequencer
+        self.default_file_size = default_file_size
+
+    def __reduce__(self):
+        # the opener of a format is a module-level singleton named `open`
+        return (_module_opener, (self.classes[next(iter(self.classes))].__module__,))
+
+    def normalize_mode(self, mode):
+        for candidate in (mode, mode[::-1], mode + 's' if mode in ('r', 'w') else None):
+            if candidate in self.classes:
+                return candidate
+        raise ValueError("invalid mode: {} ({} supports {}).".format(
+            mode, self.fmt, sorted(self.classes)))
+
+    # -- templates
+    def _sequencer_for(self, template, mode, kwargs):
+        """Template -> file-name sequencer.  Fields are filled from ``header0``
+        (if given) and the keywords; when reading, keywords the template used
+        are removed so that they do not reach the reader class."""
+        values = {}
+        header0 = kwargs.get('header0')
+        if header0 is not None:
+            values.update({k: header0[k] for k in header0.keys()})
+        values.update(kwargs)
+        values = _CaseBlind(values)
+        fns = self.sequencer(template, values)
+        if mode[0] == 'r':
+            for key in values.consulted.intersection(kwargs):
+                kwargs.pop(key)
+        return fns
+
+    # -- handles
+    def _handle(self, name, mode, kwargs):
+        kind = source_kind(name)
+        if kind == 'fh':
+            return name, None
+        if kind == 'template':
+            name, kind = self._sequencer_for(name, mode, kwargs), 'sequence'
+        if mode[0] == 'r':
+            if kind == 'sequence':
+                return sf.open(name, 'rb'), name
+            return io.open(name, 'rb'), os.fspath(name)
+        if kind == 'sequence':
+            if mode == 'wb':
+                raise ValueError("{} does not support writing to a sequence or "
+                                 "template in binary mode.".format(self.fmt))
+            return sf.open(name, 'w+b', file_size=kwargs.pop('file_size', None)), name
+        return LazyWriteFile(name), os.fspath(name)
+
+    def __call__(self, name, mode='rs', **kwargs):
+        mode = self.normalize_mode(mode)
+        if (mode == 'ws' and self.default_file_size is not None
+                and source_kind(name) in ('sequence', 'template')
+                and 'file_size' not in kwargs and kwargs.get('header0') is not None):
+            kwargs['file_size'] = self.default_file_size(kwargs['header0'])
+        fh, source = self._handle(name, mode, kwargs)
+        init_args = dict(kwargs)
+        try:
+            opened = self.classes[mode](fh, **kwargs)
+        except Exception:
+            if fh is not name:
+                try:
+                    getattr(fh, 'discard', fh.close)()
+                except Exception:
+                    pass
+            raise
+        if mode == 'rs' and source is not None:
+            # what GPUStreamReaderBase.__reduce__ needs to come back after pickling
+            opened._pickle_recipe = (_reopen_stream, self, source, init_args)
+        return opened
+
+
+class _CaseBlind(dict):
+    """Header values looked up by a template field, ignoring case; remembers
+    which of its keys were consulted."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.consulted = set()
+
+    def __getitem__(self, key):
+        for k in self:
+            if k == key or (isinstance(k, str) and k.lower() == key.lower()):
+                self.consulted.add(k)
+                return super().__getitem__(k)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return any(k == key or (isinstance(k, str) and k.lower() == key.lower())
+                   for k in self)
+
+
+def _module_opener(module_name):
+    import importlib
+    return importlib.import_module(module_name).open

@@ -34,6 +34,11 @@ class LazyWriteFile:
     def close(self):
         self._open().close()
 
+    def discard(self):
+        """Give up without creating the file (the writer never came to be)."""
+        if self._fh is not None:
+            self._fh.close()
+
 
 class GPUStreamWriterBase:
     def __init__(self, fh_raw, header0, *, sample_rate, samples_per_frame,

@@ -2,7 +2,7 @@
 from .header import DADAHeader
 from .payload import DADAPayload, MKBFPayload
 from .frame import DADAFrame
-from .base import DADAFileReader, DADAStreamReader, open
+from .base import DADAFileReader, DADAStreamReader, DADAFileNameSequencer, open
 
-__all__ = ['DADAHeader', 'DADAPayload', 'MKBFPayload', 'DADAFrame',
+__all__ = ['DADAFileNameSequencer', 'DADAHeader', 'DADAPayload', 'MKBFPayload', 'DADAFrame',
            'DADAFileReader', 'DADAStreamReader', 'open']

@@ -8,11 +8,33 @@ import torch
 from .. import _lib, kernels
 from ..base.base import VLBIFileReaderBase
 from ..base.blockreader import BlockStreamReader
+from ..base.opener import FormatOpener
+from ..helpers.sequentialfile import UpperCaseSequencer
 from .header import DADAHeader
 from .payload import DADAPayload, decode_i8_rows
 from .frame import DADAFrame
 
-__all__ = ['DADAFileReader', 'DADAStreamReader', 'open']
+__all__ = ['DADAFileNameSequencer', 'DADAFileReader', 'DADAStreamReader', 'open']
+
+
+class DADAFileNameSequencer(UpperCaseSequencer):
+    """DADA file names from a template (dada/base.py:27-96): fields match the
+    header keys ignoring case, and ``{obs_offset}`` advances by the header's
+    ``FILE_SIZE`` for every file.
+
+    >>> DADAFileNameSequencer('{date}_{file_nr:03d}.dada', {'DATE': "2018-01-01"})[10]
+    '2018-01-01_010.dada'
+    """
+
+    def __init__(self, template, header={}):
+        super().__init__(template, header)
+        self._step = header['FILE_SIZE'] if 'OBS_OFFSET' in self.items else 0
+
+    def _values(self, file_nr):
+        values = super()._values(file_nr)
+        if self._step:
+            values['OBS_OFFSET'] = self.items['OBS_OFFSET'] + file_nr * self._step
+        return values
 
 
 class DADAFileReader(VLBIFileReaderBase):
@@ -111,18 +133,8 @@ class DADAStreamReader(BlockStreamReader):
                 dbuf, payload_offset + i * frame_stride, self._row_nbytes, a, b)
 
 
-def open(name, mode='rs', **kwargs):
-    if mode not in ('rb', 'rs'):
-        raise ValueError("only reading modes 'rb' and 'rs' are supported "
-                         "(got {!r}).".format(mode))
-    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
-    try:
-        if mode == 'rb':
-            return DADAFileReader(fh, **kwargs)
-        reader = DADAStreamReader(fh, **kwargs)
-        reader._init_args = dict(kwargs)
-        return reader
-    except Exception:
-        if fh is not name:
-            fh.close()
-        raise
+open = FormatOpener('DADA', {'rb': DADAFileReader, 'rs': DADAStreamReader},
+                    sequencer=DADAFileNameSequencer)
+open.__doc__ = """Open DADA file(s) for reading (dada/base.py:366-470): names, handles,
+lists of names, or a template such as
+``'{utc_start}_{obs_offset:016d}.000000.dada'``."""

@@ -2,7 +2,7 @@
 from .header import GUPPIHeader
 from .payload import GUPPIPayload
 from .frame import GUPPIFrame
-from .base import GUPPIFileReader, GUPPIStreamReader, open
+from .base import GUPPIFileReader, GUPPIStreamReader, GUPPIFileNameSequencer, open
 
-__all__ = ['GUPPIHeader', 'GUPPIPayload', 'GUPPIFrame', 'GUPPIFileReader',
+__all__ = ['GUPPIFileNameSequencer', 'GUPPIHeader', 'GUPPIPayload', 'GUPPIFrame', 'GUPPIFileReader',
            'GUPPIStreamReader', 'open']

@@ -7,11 +7,17 @@ import torch
 from .. import _lib, kernels
 from ..base.base import VLBIFileReaderBase
 from ..base.blockreader import BlockStreamReader
+from ..base.opener import FormatOpener
+from ..helpers.sequentialfile import UpperCaseSequencer
 from .header import GUPPIHeader
 from .payload import GUPPIPayload
 from .frame import GUPPIFrame
 
-__all__ = ['GUPPIFileReader', 'GUPPIStreamReader', 'open']
+__all__ = ['GUPPIFileNameSequencer', 'GUPPIFileReader', 'GUPPIStreamReader', 'open']
+
+# template fields are matched to the (upper-case) header keys ignoring case
+# (guppi/base.py:23-85)
+GUPPIFileNameSequencer = UpperCaseSequencer
 
 
 class GUPPIFileReader(VLBIFileReaderBase):
@@ -92,18 +98,8 @@ class GUPPIStreamReader(BlockStreamReader):
                                 src_stride=frame_stride, out=out_flat)
 
 
-def open(name, mode='rs', **kwargs):
-    if mode not in ('rb', 'rs'):
-        raise ValueError("only reading modes 'rb' and 'rs' are supported "
-                         "(got {!r}).".format(mode))
-    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
-    try:
-        if mode == 'rb':
-            return GUPPIFileReader(fh, **kwargs)
-        reader = GUPPIStreamReader(fh, **kwargs)
-        reader._init_args = dict(kwargs)
-        return reader
-    except Exception:
-        if fh is not name:
-            fh.close()
-        raise
+open = FormatOpener('GUPPI', {'rb': GUPPIFileReader, 'rs': GUPPIStreamReader},
+                    sequencer=GUPPIFileNameSequencer)
+open.__doc__ = """Open GUPPI raw file(s) for reading (guppi/base.py:305-396): names,
+handles, lists of names, or a template such as
+``'puppi_{stt_imjd}_{src_name}_{scannum}.{file_nr:04d}.raw'``."""

@@ -1,0 +1,483 @@
+"""Several files addressed as one contiguous byte stream.
+
+Observations are recorded as long runs of files; the reader has to treat them
+as one stream.  This module gives the same public surface as the reference's
+``baseband.helpers.sequentialfile`` (helpers/sequentialfile.py:17-425:
+`FileNameSequencer`, `SequentialFileReader`, `SequentialFileWriter`, `open`)
+but is organised for the GPU staging path:
+
+* the reader keeps a table of cumulative file sizes, filled by ``stat`` (no
+  file is opened just to learn its size);
+* `SequentialFileReader.host_image()` returns a `SequenceImage`: every file
+  memory-mapped once, addressable by *global* byte offset, which
+  `staging.WindowPipeline` / `staging.upload` copy piecewise into pinned
+  buffers -- so frame windows that straddle a file boundary go to HBM without
+  an intermediate concatenation.
+"""
+import bisect
+import io
+import mmap
+import os
+import string
+
+import numpy as np
+
+__all__ = ['FileNameSequencer', 'SequenceImage', 'SequentialFileReader',
+           'SequentialFileWriter', 'open']
+
+
+class FileNameSequencer:
+    """List-like source of file names made from a template.
+
+    ``template.format(**items, file_nr=i)`` with the items taken from `header`
+    (helpers/sequentialfile.py:17-87).  ``len()`` counts how many consecutive
+    names, starting at 0, exist on disk.
+
+    >>> FileNameSequencer('a{file_nr:03d}.vdif')[10]
+    'a010.vdif'
+    """
+    _counter_keys = ('file_nr',)
+
+    def __init__(self, template, header={}):
+        self.template = self._normalize(template)
+        self.items = {}
+        for _, field, _, _ in string.Formatter().parse(self.template):
+            if field and field not in self._counter_keys:
+                self.items[field] = header[field]
+
+    @staticmethod
+    def _normalize(template):
+        return template
+
+    def _values(self, file_nr):
+        """Mapping used to format name number `file_nr`."""
+        values = dict(self.items)
+        values.update((key, file_nr) for key in self._counter_keys)
+        return values
+
+    def __getitem__(self, file_nr):
+        if file_nr < 0:
+            file_nr += len(self)
+            if file_nr < 0:
+                raise IndexError('file number out of range.')
+        return self.template.format(**self._values(file_nr))
+
+    def __len__(self):
+        n = 0
+        while os.path.isfile(self[n]):
+            n += 1
+        return n
+
+    def __repr__(self):
+        return "{}({!r})".format(type(self).__name__, self.template)
+
+
+class UpperCaseSequencer(FileNameSequencer):
+    """Sequencer for formats whose header keys are upper case (DADA, GUPPI):
+    template fields are case-insensitive (dada/base.py:71-96,
+    guppi/base.py:62-85)."""
+    _counter_keys = ('FILE_NR', 'FRAME_NR')
+
+    @staticmethod
+    def _normalize(template):
+        out = []
+        for text, field, spec, conv in string.Formatter().parse(template):
+            out.append(text.replace('{', '{{').replace('}', '}}'))
+            if field is not None:
+                out.append('{' + field.upper() + ('!' + conv if conv else '')
+                           + (':' + spec if spec else '') + '}')
+        return ''.join(out)
+
+
+def _as_name(entry):
+    return os.fspath(entry) if isinstance(entry, (str, os.PathLike)) else None
+
+
+class SequenceImage:
+    """Read-only global byte addressing over memory-mapped files.
+
+    Behaves like the uint8 array `staging.host_image` returns for one file:
+    ``len()``, slicing (a view when the slice lies in one file, a gathered
+    copy otherwise) -- plus `pieces`, which the staging code uses to copy a
+    range file by file, and `header_words`, the strided header gather."""
+
+    def __init__(self, names):
+        self._maps, starts, total = [], [0], 0
+        for name in names:
+            size = os.path.getsize(name)
+            if size:
+                with io.open(name, 'rb') as f:
+                    mm = mmap.mmap(f.fileno(), size, access=mmap.ACCESS_READ)
+                self._maps.append(np.frombuffer(mm, dtype=np.uint8))
+            else:
+                self._maps.append(np.empty(0, np.uint8))
+            total += size
+            starts.append(total)
+        self._starts = starts
+        self.dtype = np.dtype(np.uint8)
+
+    def __len__(self):
+        return self._starts[-1]
+
+    shape = property(lambda self: (len(self),))
+
+    def pieces(self, lo, hi):
+        """Array views that together hold bytes [lo, hi)."""
+        lo, hi = max(0, lo), min(hi, len(self))
+        out = []
+        k = max(0, bisect.bisect_right(self._starts, lo) - 1)
+        while lo < hi and k < len(self._maps):
+            base, end = self._starts[k], self._starts[k + 1]
+            stop = min(hi, end)
+            if stop > lo:
+                out.append(self._maps[k][lo - base:stop - base])
+                lo = stop
+            k += 1
+        return out
+
+    def __getitem__(self, item):
+        if not isinstance(item, slice):
+            i = item + len(self) if item < 0 else item
+            got = self.pieces(i, i + 1)
+            if not got:
+                raise IndexError(item)
+            return got[0][0]
+        lo, hi, step = item.indices(len(self))
+        if step != 1:
+            raise IndexError("only contiguous slices of a file sequence")
+        got = self.pieces(lo, hi)
+        if len(got) == 1:
+            return got[0]
+        return np.concatenate(got) if got else np.empty(0, np.uint8)
+
+    def __array__(self, dtype=None, copy=None):
+        whole = self[:]
+        return whole if dtype in (None, whole.dtype) else whole.astype(dtype)
+
+    def header_words(self, frame_nbytes, nwords, offset=0):
+        """(nframes, nwords) little-endian uint32 header words of frames that
+        start every `frame_nbytes` bytes from `offset`; frames whose header is
+        cut off by the end of the sequence are left out."""
+        n = len(self) - offset
+        nframes = (n - 4 * nwords) // frame_nbytes + 1 if n >= 4 * nwords else 0
+        out = np.empty((nframes, nwords), '<u4')
+        hb = 4 * nwords
+        for k, m in enumerate(self._maps):
+            base, end = self._starts[k], self._starts[k + 1]
+            # frames whose header lies wholly inside file k
+            first = max(0, -(-(base - offset) // frame_nbytes))
+            last = min(nframes, (end - hb - offset) // frame_nbytes + 1) if end - hb >= offset else 0
+            if last > first:
+                o = offset + first * frame_nbytes - base
+                span = m[o:o + (last - first - 1) * frame_nbytes + hb]
+                rows = np.lib.stride_tricks.as_strided(
+                    span, shape=(last - first, hb), strides=(frame_nbytes, 1), writeable=False)
+                out[first:last] = np.ascontiguousarray(rows).view('<u4')
+            # a header straddling the end of file k
+            f = (end - offset) // frame_nbytes if end > offset else -1
+            if 0 <= f < nframes:
+                o = offset + f * frame_nbytes
+                if o < end < o + hb:
+                    out[f] = self[o:o + hb].view('<u4')
+        return out
+
+
+class _SequentialBase:
+    """Position bookkeeping shared by reader and writer."""
+
+    def __init__(self, files, mode, opener):
+        self.files = files
+        self.mode = mode
+        self.opener = io.open if opener is None else opener
+        self._starts = [0]              # cumulative sizes of the files known so far
+        self.fh = None
+        self.file_nr = None
+        self._closed = False
+
+    closed = property(lambda self: self._closed)
+
+    def _switch(self, file_nr):
+        if file_nr == self.file_nr:
+            return
+        try:
+            name = self.files[file_nr]
+        except IndexError:
+            raise OSError('ran out of files.') from None
+        fh = name if hasattr(name, 'seek') else self.opener(name, mode=self.mode)
+        if self.fh is not None:
+            self.fh.close()
+        self.fh, self.file_nr = fh, file_nr
+
+    def __getattr__(self, attr):
+        # anything else (name, readline, ...) comes from the file that is open
+        if attr.startswith('_') or attr in ('fh', 'files'):
+            raise AttributeError(attr)
+        return getattr(self.fh, attr)
+
+    def close(self):
+        if self.fh is not None:
+            self.fh.close()
+        self._closed = True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __repr__(self):
+        current = None if self.file_nr is None else self.files[self.file_nr]
+        return ("{}(files={}, mode='{}')\n# At offset: {}; open file: {!r}."
+                .format(type(self).__name__, self.files, self.mode,
+                        None if self.closed else self.tell(), current))
+
+
+class SequentialFileReader(_SequentialBase):
+    """Read several files as if they were one (helpers/sequentialfile.py:
+    199-322).  `files` is a list/tuple of names, or anything indexable by file
+    number that raises `IndexError` past the end (e.g. `FileNameSequencer`)."""
+
+    def __init__(self, files, mode='rb', opener=None):
+        super().__init__(files, mode, opener)
+        self._complete = False          # True once the size table covers all files
+        self._pos = 0
+        self._switch(0)
+        self._know(1)
+
+    # -- size table
+    def _size_of(self, file_nr):
+        """Size of file `file_nr`, or None when there is no such file."""
+        try:
+            entry = self.files[file_nr]
+        except IndexError:
+            return None
+        name = _as_name(entry)
+        if name is not None and self.opener is io.open:
+            return os.path.getsize(name) if os.path.isfile(name) else None
+        if file_nr == self.file_nr:
+            fh, close = self.fh, False
+        else:
+            try:
+                fh, close = (entry, False) if hasattr(entry, 'seek') else (
+                    self.opener(entry, mode=self.mode), True)
+            except Exception:
+                return None
+        here = fh.tell()
+        size = fh.seek(0, 2)
+        fh.seek(here)
+        if close:
+            fh.close()
+        return size
+
+    def _know(self, nfiles=None):
+        """Extend the size table to `nfiles` files (all of them if None)."""
+        while not self._complete and (nfiles is None or len(self._starts) - 1 < nfiles):
+            size = self._size_of(len(self._starts) - 1)
+            if size is None:
+                self._complete = True
+            else:
+                self._starts.append(self._starts[-1] + size)
+
+    def _locate(self, offset):
+        """(file number, offset inside it) for a global offset; positions at or
+        past the end map to the end of the last file."""
+        while not self._complete and offset >= self._starts[-1]:
+            self._know(len(self._starts))
+        k = bisect.bisect_right(self._starts, offset) - 1
+        k = min(k, len(self._starts) - 2)
+        return k, offset - self._starts[k]
+
+    @property
+    def file_size(self):
+        """Size of the file that is currently open."""
+        return self._size_of(self.file_nr)
+
+    @property
+    def size(self):
+        """Size of all files together."""
+        self._know()
+        return self._starts[-1]
+
+    # -- file interface
+    def tell(self):
+        return self._pos
+
+    def seek(self, offset, whence=0):
+        if self.closed:
+            raise ValueError('seek of closed file.')
+        if whence == 1:
+            offset += self._pos
+        elif whence == 2:
+            offset += self.size
+        elif whence != 0:
+            raise ValueError("invalid 'whence'; should be 0, 1, or 2.")
+        if offset < 0:
+            raise OSError('invalid offset')
+        self._pos = offset
+        return offset
+
+    def _sync(self):
+        """Open the file holding the current position and move there."""
+        k, inner = self._locate(self._pos)
+        self._switch(k)
+        self.fh.seek(inner)
+
+    def read(self, count=None):
+        if self.closed:
+            raise ValueError('read of closed file.')
+        if count is None or count < 0:
+            count = max(self.size - self._pos, 0)
+        chunks = []
+        while count > 0:
+            self._sync()
+            got = self.fh.read(count)
+            if not got:
+                break
+            chunks.append(got)
+            self._pos += len(got)
+            count -= len(got)
+        return chunks[0] if len(chunks) == 1 else b''.join(chunks)
+
+    def readinto(self, buffer):
+        view = memoryview(buffer).cast('B')
+        data = self.read(len(view))
+        view[:len(data)] = data
+        return len(data)
+
+    def readable(self):
+        return True
+
+    def seekable(self):
+        return True
+
+    def readline(self, *args):
+        """One line of the file holding the current position (lines do not
+        continue across files)."""
+        self._sync()
+        line = self.fh.readline(*args)
+        self._pos += len(line)
+        return line
+
+    def memmap(self, dtype=np.uint8, mode=None, offset=None, shape=None, order='C'):
+        """Map part of ONE underlying file, starting at `offset` (default: the
+        current position); the position moves past the mapped bytes."""
+        if self.closed:
+            raise ValueError('memmap of closed file.')
+        dtype = np.dtype(dtype)
+        if offset is not None:
+            self.seek(offset)
+        k, inner = self._locate(self._pos)
+        if inner == self._starts[k + 1] - self._starts[k] and self._pos < self.size:
+            k, inner = k + 1, 0
+        if shape is None:
+            count = self.size - self._pos
+            if count % dtype.itemsize:
+                raise ValueError("size of available data is not a "
+                                 "multiple of the data-type size.")
+            shape = (count // dtype.itemsize,)
+        elif not isinstance(shape, tuple):
+            shape = (shape,)
+        count = dtype.itemsize * int(np.prod(shape, dtype=np.int64))
+        if inner + count > self._starts[k + 1] - self._starts[k]:
+            raise ValueError('mmap length exceeds individual file size')
+        self._switch(k)
+        mm = np.memmap(self.fh, dtype, (mode or self.mode).replace('b', ''), inner, shape, order)
+        self._pos += count
+        return mm
+
+    def host_image(self):
+        """`SequenceImage` over all files (named files only)."""
+        self._know()
+        names = [_as_name(self.files[k]) for k in range(len(self._starts) - 1)]
+        if any(n is None for n in names) or self.opener is not io.open:
+            return np.frombuffer(self._read_all(), dtype=np.uint8)
+        return SequenceImage(names)
+
+    def _read_all(self):
+        here = self._pos
+        self.seek(0)
+        data = self.read()
+        self.seek(here)
+        return data
+
+    # -- pickling: names and position travel, open files do not
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        fh = state.pop('fh')
+        if not isinstance(fh, io.IOBase):
+            state['fh'] = fh            # a custom object has to pickle itself
+        state['file_nr'] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__.setdefault('fh', None)
+        if not self._closed and self.fh is None:
+            self._sync()
+
+
+class SequentialFileWriter(_SequentialBase):
+    """Write a byte stream into files of at most `file_size` bytes each
+    (helpers/sequentialfile.py:325-378).  Not seekable."""
+
+    def __init__(self, files, mode='w+b', file_size=None, opener=None):
+        super().__init__(files, mode, opener)
+        self.file_size = file_size
+        self._switch(0)
+
+    def tell(self):
+        return self._starts[self.file_nr] + self.fh.tell()
+
+    def _advance(self):
+        self._starts.append(self._starts[-1] + self.fh.tell())
+        self._switch(self.file_nr + 1)
+
+    def write(self, data):
+        if self.closed:
+            raise ValueError('write to closed file.')
+        data = memoryview(data).cast('B')
+        written = 0
+        while self.file_size is not None and len(data) - written > self.file_size - self.fh.tell():
+            room = self.file_size - self.fh.tell()
+            self.fh.write(data[written:written + room])
+            written += room
+            self._advance()
+        self.fh.write(data[written:])
+        return len(data)
+
+    def writable(self):
+        return True
+
+    def memmap(self, dtype=np.uint8, mode=None, offset=None, shape=None, order='C'):
+        """Writable map of the next bytes of the current file (moving to the
+        next file when the current one is full)."""
+        if shape is None:
+            raise ValueError('cannot make writable memmap without shape.')
+        if self.closed:
+            raise ValueError('memmap of closed file.')
+        if offset is not None and offset != self.tell():
+            raise OSError('a sequential writer cannot seek.')
+        dtype = np.dtype(dtype)
+        shape = shape if isinstance(shape, tuple) else (shape,)
+        count = dtype.itemsize * int(np.prod(shape, dtype=np.int64))
+        if self.file_size is not None:
+            if self.fh.tell() == self.file_size:
+                self._advance()
+            if self.fh.tell() + count > self.file_size:
+                raise ValueError('mmap length exceeds individual file size')
+        inner = self.fh.tell()
+        mm = np.memmap(self.fh, dtype, (mode or self.mode).replace('b', ''), inner, shape, order)
+        self.fh.seek(inner + count)
+        return mm
+
+
+def open(files, mode='rb', file_size=None, opener=None):
+    """Reader (``'r'`` in mode) or writer (``'w'``) over a file sequence
+    (helpers/sequentialfile.py:381-425)."""
+    if 'r' in mode:
+        if file_size is not None:
+            raise TypeError("cannot pass in 'file_size' for reading.")
+        return SequentialFileReader(files, mode, opener=opener)
+    if 'w' in mode:
+        return SequentialFileWriter(files, mode, file_size=file_size, opener=opener)
+    raise ValueError("invalid mode '{0}'".format(mode))

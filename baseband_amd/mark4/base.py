@@ -19,7 +19,8 @@ from .header import Mark4Header, MARK4_DTYPES, stream2words
 from .payload import Mark4Payload
 from .frame import Mark4Frame
 from ._bitmaps import BITMAPS
-from ..base.writer import GPUStreamWriterBase, LazyWriteFile
+from ..base.writer import GPUStreamWriterBase
+from ..base.opener import FormatOpener
 
 __all__ = ['Mark4FileReader', 'Mark4StreamReader', 'Mark4StreamWriter', 'open']
 
@@ -242,23 +243,8 @@ class Mark4StreamWriter(GPUStreamWriterBase):
         self.fh_raw.write(frames.tobytes())
 
 
-def open(name, mode='rs', **kwargs):
-    """``'rb'`` -> `Mark4FileReader`, ``'rs'`` -> `Mark4StreamReader`,
-    ``'ws'`` -> `Mark4StreamWriter` (mark4/base.py:337-430)."""
-    if mode == 'ws':
-        fh = name if hasattr(name, 'write') else LazyWriteFile(name)
-        return Mark4StreamWriter(fh, **kwargs)
-    if mode not in ('rb', 'rs'):
-        raise ValueError("supported modes are 'rb', 'rs' and 'ws' "
-                         "(got {!r}).".format(mode))
-    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
-    try:
-        if mode == 'rb':
-            return Mark4FileReader(fh, **kwargs)
-        reader = Mark4StreamReader(fh, **kwargs)
-        reader._init_args = dict(kwargs)
-        return reader
-    except Exception:
-        if fh is not name:
-            fh.close()
-        raise
+open = FormatOpener('Mark4', {'rb': Mark4FileReader, 'rs': Mark4StreamReader,
+                              'ws': Mark4StreamWriter})
+open.__doc__ = """Open Mark 4 file(s): ``'rb'`` -> `Mark4FileReader`, ``'rs'`` ->
+`Mark4StreamReader`, ``'ws'`` -> `Mark4StreamWriter` (mark4/base.py:337-430);
+names, handles, lists of names and ``{file_nr}`` templates are accepted."""

@@ -17,7 +17,8 @@ from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
 from ..base.header import strided_header_words
 from .header import Mark5BHeader, crc16_mark5b
 from .frame import Mark5BFrame
-from ..base.writer import GPUStreamWriterBase, LazyWriteFile
+from ..base.writer import GPUStreamWriterBase
+from ..base.opener import FormatOpener
 
 __all__ = ['Mark5BFileReader', 'Mark5BStreamReader', 'Mark5BStreamWriter', 'open']
 
@@ -211,23 +212,8 @@ class Mark5BStreamWriter(GPUStreamWriterBase):
         self.fh_raw.write(out.tobytes())
 
 
-def open(name, mode='rs', **kwargs):
-    """``'rb'`` -> `Mark5BFileReader`, ``'rs'`` -> `Mark5BStreamReader`,
-    ``'ws'`` -> `Mark5BStreamWriter` (mark5b/base.py:356-428)."""
-    if mode == 'ws':
-        fh = name if hasattr(name, 'write') else LazyWriteFile(name)
-        return Mark5BStreamWriter(fh, **kwargs)
-    if mode not in ('rb', 'rs'):
-        raise ValueError("supported modes are 'rb', 'rs' and 'ws' "
-                         "(got {!r}).".format(mode))
-    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
-    try:
-        if mode == 'rb':
-            return Mark5BFileReader(fh, **kwargs)
-        reader = Mark5BStreamReader(fh, **kwargs)
-        reader._init_args = dict(kwargs)
-        return reader
-    except Exception:
-        if fh is not name:
-            fh.close()
-        raise
+open = FormatOpener('Mark5B', {'rb': Mark5BFileReader, 'rs': Mark5BStreamReader,
+                               'ws': Mark5BStreamWriter})
+open.__doc__ = """Open Mark 5B file(s): ``'rb'`` -> `Mark5BFileReader`, ``'rs'`` ->
+`Mark5BStreamReader`, ``'ws'`` -> `Mark5BStreamWriter` (mark5b/base.py:356-428);
+names, handles, lists of names and ``{file_nr}`` templates are accepted."""

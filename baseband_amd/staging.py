@@ -18,6 +18,8 @@ import torch
 def host_image(fh):
     """uint8 view of a whole file: memory-mapped for real files, a byte copy
     for in-memory streams.  The file position is left unchanged."""
+    if hasattr(fh, 'host_image'):            # helpers.sequentialfile reader
+        return fh.host_image()
     try:
         fileno = fh.fileno()
     except Exception:
@@ -58,6 +60,18 @@ def _parallel_copy(dst, src):
         f.result()
 
 
+def _stage(dst, image, lo, hi):
+    """dst[:hi-lo] = image[lo:hi]; a file sequence is copied file by file,
+    straight from each mapping."""
+    if not hasattr(image, 'pieces'):
+        _parallel_copy(dst, image[lo:hi])
+        return
+    o = 0
+    for part in image.pieces(lo, hi):
+        _parallel_copy(dst[o:o + len(part)], part)
+        o += len(part)
+
+
 class WindowPipeline:
     """Stream byte windows of a host image through pinned buffers to HBM and
     call ``process(dev_bytes, index)`` for each on the compute stream."""
@@ -91,7 +105,7 @@ class WindowPipeline:
             if self._done[b] is not None:
                 self._done[b].synchronize()          # buffer b free again
             pinned, dev = self._buffers(b)
-            _parallel_copy(pinned.numpy(), self.image[lo:hi])   # page cache -> pinned (CPU)
+            _stage(pinned.numpy(), self.image, lo, hi)           # page cache -> pinned (CPU)
             with torch.cuda.stream(self._copy_stream):
                 dev[:n].copy_(pinned[:n], non_blocking=True)
                 copied = torch.cuda.Event()
@@ -125,7 +139,7 @@ def upload(image, device='cuda', chunk_bytes=64 << 20):
         b = i % 2
         if events[b] is not None:
             events[b].synchronize()
-        _parallel_copy(pinned[b].numpy(), image[lo:hi])
+        _stage(pinned[b].numpy(), image, lo, hi)
         with torch.cuda.stream(stream):
             dev[lo:hi].copy_(pinned[b][:hi - lo], non_blocking=True)
             ev = torch.cuda.Event()

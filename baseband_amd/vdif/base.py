@@ -15,7 +15,8 @@ import torch
 from .. import _lib, kernels
 from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
-from ..base.writer import GPUStreamWriterBase, LazyWriteFile
+from ..base.writer import GPUStreamWriterBase
+from ..base.opener import FormatOpener
 from ..base.header import strided_header_words
 from .header import VDIFHeader
 from .frame import VDIFFrame, VDIFFrameSet
@@ -398,32 +399,16 @@ class VDIFStreamWriter(GPUStreamWriterBase):
         idx = self.header0['frame_nr'] + self._nframes_written
         h['seconds'] = self.header0['seconds'] + idx // self._frame_rate
         h['frame_nr'] = idx % self._frame_rate
-        base_tid = self.header0['thread_id']
         invalid = [(s, t) for s in np.nonzero(~np.asarray(valid))[0] for t in range(nthread)]
-        image = synth.vdif_file_image(payloads, h, [base_tid + t for t in range(nthread)],
+        # thread ids are 0..n-1 whatever header0 holds (vdif/frame.py:277-285)
+        image = synth.vdif_file_image(payloads, h, list(range(nthread)),
                                       self._frame_rate, invalid=invalid)
         self.fh_raw.write(image.tobytes())
 
 
-def open(name, mode='rs', **kwargs):
-    """``'rb'`` gives a `VDIFFileReader`, ``'rs'`` a `VDIFStreamReader`,
-    ``'ws'`` a `VDIFStreamWriter` (vdif/base.py:810-884)."""
-    if mode == 'ws':
-        fh = name if hasattr(name, 'write') else LazyWriteFile(name)
-        return VDIFStreamWriter(fh, **kwargs)
-    if mode not in ('rb', 'rs'):
-        raise ValueError("supported modes are 'rb', 'rs' and 'ws' "
-                         "(got {!r}).".format(mode))
-    fh = name if hasattr(name, 'read') else io.open(name, 'rb')
-    if mode == 'rb':
-        if kwargs:
-            raise TypeError("got unexpected arguments {}".format(kwargs.keys()))
-        return VDIFFileReader(fh)
-    try:
-        reader = VDIFStreamReader(fh, **kwargs)
-        reader._init_args = dict(kwargs)
-        return reader
-    except Exception:
-        if fh is not name:
-            fh.close()
-        raise
+open = FormatOpener('VDIF', {'rb': VDIFFileReader, 'rs': VDIFStreamReader,
+                             'ws': VDIFStreamWriter})
+open.__doc__ = """Open VDIF file(s): ``'rb'`` gives a `VDIFFileReader`, ``'rs'`` a
+`VDIFStreamReader`, ``'ws'`` a `VDIFStreamWriter` (vdif/base.py:810-884).
+`name` may be a file name, a file handle, a list of names or a ``{file_nr}``
+template; with ``'ws'`` and ``file_size=`` a sequence of files is written."""

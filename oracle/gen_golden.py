@@ -770,6 +770,98 @@ def gen_vdif_corrupt():
     print('vdif corrupt:', len(cases), 'cases;', [c['zeroed'] for c in cases])
 
 
+def gen_sequence():
+    """Multi-file sequences through the reference (helpers/sequentialfile.py,
+    baseband/tests/test_sequential_baseband.py): template names, byte-level
+    reads across file boundaries, stream reads of a split file, and the files
+    a sequence writer produces.  Stored as names / sizes / hashes."""
+    from baseband.helpers import sequentialfile as sf
+    out = {}
+    with vdif.open(SAMPLE_VDIF, 'rb') as fh:
+        vh = vdif.VDIFHeader.fromfile(fh)
+    with open(SAMPLE_DADA, 'rb') as fh:
+        dh = dada.DADAHeader.fromfile(fh)
+    with open(SAMPLE_PUPPI, 'rb') as fh:
+        gh = guppi.GUPPIHeader.fromfile(fh)
+    out['names'] = {
+        'plain': [sf.FileNameSequencer('a{file_nr:03d}.vdif')[10], 'a{file_nr:03d}.vdif'],
+        'vdif_header': [sf.FileNameSequencer('obs.edv{edv:d}.{file_nr:05d}.vdif', vh)[10],
+                        'obs.edv{edv:d}.{file_nr:05d}.vdif'],
+        'dada': [[dada.DADAFileNameSequencer('{utc_start}.{obs_offset:016d}.000000.dada', dh)[i]
+                  for i in (0, 1, 10)], '{utc_start}.{obs_offset:016d}.000000.dada'],
+        'dada_date': [dada.DADAFileNameSequencer('{date}_{file_nr:03d}.dada',
+                                                 {'DATE': "2018-01-01"})[10],
+                      '{date}_{file_nr:03d}.dada'],
+        'guppi': [guppi.GUPPIFileNameSequencer(
+            'puppi_{stt_imjd}_{src_name}_{scannum}.{file_nr:04d}.raw', gh)[3],
+            'puppi_{stt_imjd}_{src_name}_{scannum}.{file_nr:04d}.raw'],
+    }
+    tmp = tempfile.mkdtemp()
+    # byte-level reads over three files of unequal size
+    blob = open(SAMPLE_VDIF, 'rb').read()
+    cuts = [0, 10000, 40001, len(blob)]
+    names = []
+    for i in range(3):
+        names.append(os.path.join(tmp, 'part%d.vdif' % i))
+        with open(names[-1], 'wb') as f:
+            f.write(blob[cuts[i]:cuts[i + 1]])
+    reads = []
+    with sf.open(names, 'rb') as fh:
+        size = fh.size
+        for off, cnt in ((0, 100), (9990, 20), (9990, 40000), (40001, 10), (80000, 1000), (5, None)):
+            fh.seek(off)
+            d = fh.read(cnt) if cnt is not None else fh.read()
+            reads.append(dict(offset=off, count=cnt, nbytes=len(d), tell=fh.tell(),
+                              sha256=hashlib.sha256(d).hexdigest()))
+    out['byte_reads'] = dict(cuts=cuts, size=size, reads=reads)
+    with vdif.open(names, 'rs') as fs, vdif.open(SAMPLE_VDIF, 'rs') as f1:
+        a = fs.read()
+        assert np.array_equal(a, f1.read())
+        fs.seek(19990)
+        part = fs.read(30)
+        out['vdif_split_stream'] = dict(shape=list(a.shape), sha256=sha(a),
+                                        seek=19990, count=30, part_sha256=sha(part))
+    # sequence writer: sample.vdif data into files of two frame sets each (x2 the data)
+    with vdif.open(SAMPLE_VDIF, 'rs') as f1:
+        data = f1.read()
+        header0 = f1.header0
+    template = os.path.join(tmp, 'w{file_nr:02d}.vdif')
+    with vdif.open(template, 'ws', header0=header0, nthread=8, file_size=8 * 5032) as fw:
+        fw.write(data)
+        fw.write(data)
+    written = sorted(f for f in os.listdir(tmp) if f.startswith('w'))
+    out['vdif_sequence_write'] = dict(
+        file_size=8 * 5032, files=written,
+        sizes=[os.path.getsize(os.path.join(tmp, f)) for f in written],
+        sha256=[hashlib.sha256(open(os.path.join(tmp, f), 'rb').read()).hexdigest()
+                for f in written])
+    with vdif.open(template, 'rs') as fr:
+        back = fr.read()
+    assert np.array_equal(back, np.concatenate([data, data]))
+    # DADA: one frame per file (template with obs_offset), read back as a stream
+    with dada.open(SAMPLE_DADA, 'rs') as f1:
+        ddata = f1.read()
+        dheader = f1.header0
+    dtemplate = os.path.join(tmp, '{utc_start}.{obs_offset:016d}.000000.dada')
+    with dada.open(dtemplate, 'ws', header0=dheader) as fw:
+        fw.write(ddata)
+        fw.write(ddata)
+    dfiles = sorted(f for f in os.listdir(tmp) if f.endswith('.dada'))
+    with dada.open(dtemplate, 'rs', UTC_START=dheader['UTC_START'],
+                   OBS_OFFSET=dheader['OBS_OFFSET'], FILE_SIZE=dheader['FILE_SIZE']) as fr:
+        dback = fr.read()
+    out['dada_sequence'] = dict(files=dfiles,
+                                sizes=[os.path.getsize(os.path.join(tmp, f)) for f in dfiles],
+                                sha256=[hashlib.sha256(open(os.path.join(tmp, f), 'rb').read()).hexdigest()
+                                        for f in dfiles],
+                                shape=list(dback.shape), data_sha256=sha(dback))
+    assert np.array_equal(dback, np.concatenate([ddata, ddata]))
+    shutil.rmtree(tmp)
+    with open(os.path.join(GOLD, 'sequence_cases.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('sequence:', out['names'], out['vdif_sequence_write']['sizes'], out['dada_sequence']['files'])
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
     steps = [('levels', gen_levels), ('vdif_samples', gen_vdif_samples),
@@ -778,7 +870,8 @@ if __name__ == '__main__':
              ('mark4_bitmaps', gen_mark4_bitmaps), ('mark4_samples', gen_mark4_samples),
              ('mark4_synth', gen_mark4_synth), ('guppi', gen_guppi), ('dada', gen_dada),
              ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt),
-             ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode)]
+             ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
+             ('sequence', gen_sequence)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:
