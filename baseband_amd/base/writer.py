@@ -134,3 +134,38 @@ class GPUStreamWriterBase:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class BlockStreamWriter(GPUStreamWriterBase):
+    """Writer for block formats (DADA, GUPPI): every frame is an ASCII header
+    followed by int8 samples in the format's storage order.  Samples are
+    rounded, clipped and packed on the GPU (``bb_encode_flat``, integer
+    coder); subclasses give the per-frame header (`_frame_header`) and the
+    storage order (`_storage_order`).
+
+    Replaces the memory-mapped frame filling of the reference's writers
+    (dada/base.py:333-362, guppi/base.py:281-310, base/base.py:1276-1342); a
+    partial last frame is padded with zeros at close, as there."""
+
+    def _frame_header(self, index):
+        raise NotImplementedError
+
+    def _storage_order(self, block):
+        """(nframes, samples_per_frame, *sample_shape[, 2]) float32 tensor ->
+        same values in on-disk order."""
+        return block
+
+    def _write_frames(self, data, valid):
+        from .. import kernels, _lib
+        spf = self.samples_per_frame
+        nframes = data.shape[0] // spf
+        if data.is_complex():
+            data = torch.view_as_real(data)
+        block = self._storage_order(data.reshape((nframes, spf) + tuple(data.shape[1:])))
+        packed = kernels.encode_flat(block, _lib.CODER_INT, self.bps).cpu().numpy()
+        payloads = packed.reshape(nframes, -1)
+        for k in range(nframes):
+            header = self._frame_header(self._nframes_written + k)
+            assert header.payload_nbytes == payloads.shape[1]
+            header.tofile(self.fh_raw)
+            self.fh_raw.write(payloads[k].data)

@@ -9,12 +9,14 @@ from .. import _lib, kernels
 from ..base.base import VLBIFileReaderBase
 from ..base.blockreader import BlockStreamReader
 from ..base.opener import FormatOpener
+from ..base.writer import BlockStreamWriter
 from ..helpers.sequentialfile import UpperCaseSequencer
 from .header import DADAHeader
 from .payload import DADAPayload, decode_i8_rows
 from .frame import DADAFrame
 
-__all__ = ['DADAFileNameSequencer', 'DADAFileReader', 'DADAStreamReader', 'open']
+__all__ = ['DADAFileNameSequencer', 'DADAFileReader', 'DADAStreamReader',
+           'DADAStreamWriter', 'open']
 
 
 class DADAFileNameSequencer(UpperCaseSequencer):
@@ -133,8 +135,47 @@ class DADAStreamReader(BlockStreamReader):
                 dbuf, payload_offset + i * frame_stride, self._row_nbytes, a, b)
 
 
-open = FormatOpener('DADA', {'rb': DADAFileReader, 'rs': DADAStreamReader},
-                    sequencer=DADAFileNameSequencer)
-open.__doc__ = """Open DADA file(s) for reading (dada/base.py:366-470): names, handles,
-lists of names, or a template such as
-``'{utc_start}_{obs_offset:016d}.000000.dada'``."""
+class DADAStreamWriter(BlockStreamWriter):
+    """DADA stream writer (dada/base.py:333-362): ``header0`` describes the
+    first frame; frame k gets ``OBS_OFFSET = header0's + k * payload_nbytes``
+    (dada/base.py:222-225).  Without ``header0`` the keywords make one."""
+
+    def __init__(self, fh_raw, header0=None, squeeze=True, **kwargs):
+        if header0 is None:
+            header0 = DADAHeader.fromvalues(**kwargs)
+        elif kwargs:
+            raise TypeError("got unexpected arguments {}".format(sorted(kwargs)))
+        assert header0.get('OBS_OVERLAP', 0) == 0
+        if header0.bps != 8:
+            raise ValueError("DADAPayload cannot encode data with {} bits".format(header0.bps))
+        super().__init__(fh_raw, header0, sample_rate=header0.sample_rate,
+                         samples_per_frame=header0.samples_per_frame,
+                         unsliced_shape=header0.sample_shape, bps=header0.bps,
+                         complex_data=header0.complex_data, squeeze=squeeze)
+        self._start_time = header0.time
+
+    def _frame_header(self, index):
+        header = self.header0.copy()
+        header['OBS_OFFSET'] = self.header0['OBS_OFFSET'] + index * self.header0.payload_nbytes
+        return header
+
+
+class _DADAOpener(FormatOpener):
+    def _sequencer_for(self, template, mode, kwargs):
+        fns = super()._sequencer_for(template, mode, kwargs)
+        if mode[0] == 'r' and 'obs_offset' in template.lower():
+            # the step of {obs_offset} is the size found in the first file
+            # (dada/base.py:366-377)
+            with io.open(fns[0], 'rb') as fh:
+                fns = self.sequencer(template, DADAHeader.fromfile(fh))
+        return fns
+
+
+open = _DADAOpener('DADA', {'rb': DADAFileReader, 'rs': DADAStreamReader,
+                            'ws': DADAStreamWriter},
+                   sequencer=DADAFileNameSequencer,
+                   default_file_size=lambda header0: header0.frame_nbytes)
+open.__doc__ = """Open DADA file(s) (dada/base.py:366-470): ``'rb'``, ``'rs'`` or ``'ws'``;
+names, handles, lists of names, or a template such as
+``'{utc_start}_{obs_offset:016d}.000000.dada'``.  A written sequence gets one
+frame per file unless ``file_size`` says otherwise."""

@@ -8,12 +8,14 @@ from .. import _lib, kernels
 from ..base.base import VLBIFileReaderBase
 from ..base.blockreader import BlockStreamReader
 from ..base.opener import FormatOpener
+from ..base.writer import BlockStreamWriter
 from ..helpers.sequentialfile import UpperCaseSequencer
 from .header import GUPPIHeader
 from .payload import GUPPIPayload
 from .frame import GUPPIFrame
 
-__all__ = ['GUPPIFileNameSequencer', 'GUPPIFileReader', 'GUPPIStreamReader', 'open']
+__all__ = ['GUPPIFileNameSequencer', 'GUPPIFileReader', 'GUPPIStreamReader',
+           'GUPPIStreamWriter', 'open']
 
 # template fields are matched to the (upper-case) header keys ignoring case
 # (guppi/base.py:23-85)
@@ -98,8 +100,53 @@ class GUPPIStreamReader(BlockStreamReader):
                                 src_stride=frame_stride, out=out_flat)
 
 
-open = FormatOpener('GUPPI', {'rb': GUPPIFileReader, 'rs': GUPPIStreamReader},
+class GUPPIStreamWriter(BlockStreamWriter):
+    """GUPPI stream writer (guppi/base.py:281-310): no overlap; frame k gets
+    ``PKTIDX = header0's + k * packets per frame`` (guppi/base.py:209-225)."""
+
+    def __init__(self, fh_raw, header0=None, squeeze=True, **kwargs):
+        if header0 is None:
+            header0 = GUPPIHeader.fromvalues(**kwargs)
+        elif kwargs:
+            raise TypeError("got unexpected arguments {}".format(sorted(kwargs)))
+        assert header0.get('OVERLAP', 0) == 0, "overlap must be 0 when writing GUPPI files."
+        if header0.bps != 8:
+            raise ValueError("GUPPIPayload cannot encode data with {} bits".format(header0.bps))
+        super().__init__(fh_raw, header0, sample_rate=header0.sample_rate,
+                         samples_per_frame=header0.samples_per_frame,
+                         unsliced_shape=header0.sample_shape, bps=header0.bps,
+                         complex_data=header0.complex_data, squeeze=squeeze)
+        self._start_time = header0.time
+        self._packets_per_frame = header0.payload_nbytes // header0['PKTSIZE']
+
+    def _frame_header(self, index):
+        header = self.header0.copy()
+        header['PKTIDX'] = self.header0['PKTIDX'] + index * self._packets_per_frame
+        return header
+
+    def _storage_order(self, block):
+        # (frame, time, pol, chan[, re/im]) -> (frame, chan, time, pol[, re/im]) or
+        # (frame, time, chan, pol[, re/im]) (guppi/payload.py:90-102 inverted)
+        if self.header0.channels_first:
+            return block.movedim(3, 1)
+        return block.transpose(2, 3)
+
+
+class _GUPPIOpener(FormatOpener):
+    def __call__(self, name, mode='rs', **kwargs):
+        per_file = kwargs.pop('frames_per_file', 128)
+        if (self.normalize_mode(mode) == 'ws' and kwargs.get('header0') is not None
+                and 'file_size' not in kwargs):
+            from ..base.opener import source_kind
+            if source_kind(name) in ('sequence', 'template'):
+                kwargs['file_size'] = per_file * kwargs['header0'].frame_nbytes
+        return super().__call__(name, mode, **kwargs)
+
+
+open = _GUPPIOpener('GUPPI', {'rb': GUPPIFileReader, 'rs': GUPPIStreamReader,
+                              'ws': GUPPIStreamWriter},
                     sequencer=GUPPIFileNameSequencer)
-open.__doc__ = """Open GUPPI raw file(s) for reading (guppi/base.py:305-396): names,
-handles, lists of names, or a template such as
-``'puppi_{stt_imjd}_{src_name}_{scannum}.{file_nr:04d}.raw'``."""
+open.__doc__ = """Open GUPPI raw file(s) (guppi/base.py:305-396): ``'rb'``, ``'rs'`` or
+``'ws'``; names, handles, lists of names, or a template such as
+``'puppi_{stt_imjd}_{src_name}_{scannum}.{file_nr:04d}.raw'``.  A written
+sequence gets ``frames_per_file`` (default 128) frames per file."""

@@ -11,45 +11,84 @@ __all__ = ['GUPPIHeader']
 _MJD_UNIX = 40587
 
 
-def _parse_value(text):
-    text = text.strip()
+def _parse_card(body):
+    """(value, comment) from the part of a card after ``KEY     =``."""
+    text = body.strip()
     if text.startswith("'"):
-        end = text.index("'", 1)
-        return text[1:end].rstrip()
-    text = text.split('/')[0].strip()
-    if text in ('T', 'F'):
-        return text == 'T'
-    try:
-        return int(text)
-    except ValueError:
-        try:
-            return float(text)
-        except ValueError:
-            return text
+        end = 1
+        while True:                             # '' inside a string is a quote
+            end = text.index("'", end)
+            if text[end:end + 2] == "''":
+                end += 2
+                continue
+            break
+        value = text[1:end].replace("''", "'").rstrip()
+        rest = text[end + 1:]
+    else:
+        raw, _, rest = text.partition('/')
+        raw = raw.strip()
+        rest = '/' + rest if _ else ''
+        if raw in ('T', 'F'):
+            value = raw == 'T'
+        else:
+            try:
+                value = int(raw)
+            except ValueError:
+                try:
+                    value = float(raw.replace('D', 'E'))
+                except ValueError:
+                    value = raw
+    comment = rest.partition('/')[2].strip() or None
+    return value, comment
 
 
-def _format_card(key, value):
-    if isinstance(value, bool):
+def _format_float(value):
+    """FITS card text of a float as astropy (<= 5.2) writes it: 16 significant
+    digits, always a '.' or an exponent, exponent at least two digits."""
+    text = '{:.16G}'.format(value)
+    if '.' not in text and 'E' not in text:
+        text += '.0'
+    elif 'E' in text:
+        mantissa, exponent = text.split('E')
+        sign = exponent[0] if exponent[0] in '+-' else ''
+        text = '{}E{}{:02d}'.format(mantissa, sign, int(exponent.lstrip('+-')))
+    return text
+
+
+def _format_card(key, value, comment=None):
+    if isinstance(value, (bool, np.bool_)):
         v = '{:>20}'.format('T' if value else 'F')
     elif isinstance(value, str):
-        v = "'{:<8}'".format(value)
-    elif isinstance(value, float):
-        v = '{:>20}'.format(repr(value).upper() if 'e' in repr(value) else repr(value))
+        v = '{:20}'.format("'{:8}'".format(value.replace("'", "''")))
+    elif isinstance(value, (float, np.floating)):
+        v = '{:>20}'.format(_format_float(float(value)))
     else:
         v = '{:>20}'.format(value)
-    return '{:<8}= {}'.format(key, v).ljust(80)[:80]
+    card = '{:<8}= {}'.format(key, v)
+    if comment:
+        card += ' / ' + comment
+    return card.ljust(80)[:80]
 
 
 class GUPPIHeader(dict):
     """Dictionary of header cards with the reference's derived properties."""
 
-    _defaults = [('BACKEND', 'GUPPI'), ('BLOCSIZE', 0), ('PKTIDX', 0),
+    # guppi/header.py:56-67
+    _defaults = [('BACKEND', 'GUPPI'), ('BLOCSIZE', 0), ('STT_OFFS', 0), ('PKTIDX', 0),
                  ('OVERLAP', 0), ('SRC_NAME', 'unset'), ('TELESCOP', 'unset'),
                  ('PKTFMT', '1SFA'), ('PKTSIZE', 8192), ('NBITS', 8),
                  ('NPOL', 1), ('OBSNCHAN', 1)]
+    # property-like keywords, applied after plain keys, in this order
+    # (guppi/header.py:50-53)
+    _properties = ('payload_nbytes', 'frame_nbytes', 'bps', 'nchan', 'npol',
+                   'sample_shape', 'sample_rate', 'sideband', 'overlap',
+                   'samples_per_frame', 'offset', 'start_time', 'time')
 
     def __init__(self, *args, verify=True, mutable=True, **kwargs):
         super().__init__(*args, **kwargs)
+        self.comments = {}
+        self._layout = None         # card order of a header read from file,
+        #                             with cards that are not KEY = value kept verbatim
         self.mutable = mutable
         if len(self) and verify:
             self.verify()
@@ -59,22 +98,27 @@ class GUPPIHeader(dict):
 
     @classmethod
     def fromfile(cls, fh, verify=True):
+        """80-character cards up to END (guppi/header.py:105-143)."""
         start = fh.tell()
-        cards = {}
-        ncards = 0
+        cards, comments, layout = {}, {}, []
         while True:
             line = fh.read(80).decode('ascii')
             if line == '':
                 raise EOFError
-            ncards += 1
             if line[:3] == 'END':
                 break
             if len(line) > 8 and line[8] == '=':
-                cards[line[:8].strip()] = _parse_value(line[9:])
-            elif line[8:9] not in ('=', ' '):
+                key = line[:8].strip()
+                cards[key], comment = _parse_card(line[9:])
+                if comment:
+                    comments[key] = comment
+                layout.append((key, None))
+            elif line[8:9] == ' ':
+                layout.append((None, line))         # HIERARCH, COMMENT, blank ...
+            else:
                 break
         self = cls(cards, verify=False, mutable=True)
-        self._ncards = ncards
+        self.comments, self._layout = comments, layout
         self.mutable = False
         fh.seek(start + self.nbytes)
         if verify:
@@ -83,24 +127,37 @@ class GUPPIHeader(dict):
 
     @classmethod
     def fromvalues(cls, **kwargs):
+        """Header from defaults + keywords; keywords named after properties
+        are applied last, in `_properties` order (guppi/header.py:170-214)."""
         self = cls(cls._defaults, verify=False)
-        props = ('bps', 'nchan', 'npol', 'payload_nbytes', 'channels_first',
-                 'overlap', 'samples_per_frame', 'sample_rate', 'start_time')
-        extras = [(k, kwargs.pop(k)) for k in props if k in kwargs]
-        for key, value in kwargs.items():
-            self[key.upper()] = value
-        for key, value in extras:
-            setattr(self, key, value)
+        self.update(**kwargs)
         return self
 
+    def update(self, *, verify=True, **kwargs):
+        extras = [(k, kwargs.pop(k)) for k in self._properties if k in kwargs]
+        for key, value in kwargs.items():
+            self[key] = value
+        for key, value in extras:
+            setattr(self, key, value)
+        if verify:
+            self.verify()
+
+    def _cards(self):
+        layout = self._layout if self._layout is not None else []
+        placed = {key for key, _ in layout if key is not None}
+        layout = list(layout) + [(key, None) for key in self if key not in placed]
+        return [text if key is None else _format_card(key, self[key], self.comments.get(key))
+                for key, text in layout if key is None or key in self]
+
     def tofile(self, fh):
-        out = ''.join(_format_card(k, v) for k, v in self.items()) + 'END'.ljust(80)
-        out = out.encode('ascii')
+        out = (''.join(self._cards()) + 'END'.ljust(80)).encode('ascii')
         out += (self.nbytes - len(out)) * b'\x00'
         return fh.write(out)
 
     def copy(self):
         new = GUPPIHeader(self, verify=False, mutable=True)
+        new.comments = dict(self.comments)
+        new._layout = None if self._layout is None else list(self._layout)
         return new
 
     def __setitem__(self, key, value):
@@ -113,8 +170,7 @@ class GUPPIHeader(dict):
     @property
     def nbytes(self):
         # cards without '=' (HIERARCH, COMMENT, ...) still occupy 80 bytes
-        ncards = getattr(self, '_ncards', None)
-        nbytes = (len(self) + 1) * 80 if ncards is None else ncards * 80
+        nbytes = (len(self._cards()) + 1) * 80
         if int(self.get('DIRECTIO', '0')) and nbytes % 512:
             nbytes += 512 - nbytes % 512
         return nbytes
@@ -130,6 +186,10 @@ class GUPPIHeader(dict):
     @property
     def frame_nbytes(self):
         return self.nbytes + self.payload_nbytes
+
+    @frame_nbytes.setter
+    def frame_nbytes(self, frame_nbytes):
+        self.payload_nbytes = frame_nbytes - self.nbytes
 
     @property
     def bps(self):
@@ -174,7 +234,19 @@ class GUPPIHeader(dict):
 
     @sample_rate.setter
     def sample_rate(self, sample_rate):
-        self['TBIN'] = 1. / abs(float(sample_rate))
+        # TBIN in s; OBSBW in MHz (guppi/header.py:303-308)
+        sample_rate = float(sample_rate)
+        self['TBIN'] = 1. / abs(sample_rate)
+        self['OBSBW'] = (sample_rate / 1e6 * int(self['OBSNCHAN'])
+                         / (1 if self.complex_data else 2))
+
+    @property
+    def sideband(self):
+        return float(self['OBSBW']) > 0
+
+    @sideband.setter
+    def sideband(self, sideband):
+        self['OBSBW'] = (1 if sideband else -1) * abs(self['OBSBW'])
 
     @property
     def channels_first(self):
@@ -190,7 +262,13 @@ class GUPPIHeader(dict):
 
     @samples_per_frame.setter
     def samples_per_frame(self, samples_per_frame):
+        old = self.payload_nbytes
         self.payload_nbytes = (samples_per_frame * self._bpcs + 7) // 8
+        if self.samples_per_frame != samples_per_frame:
+            nearest = self.samples_per_frame
+            self.payload_nbytes = old
+            raise ValueError("header cannot store {} samples per frame. "
+                             "Nearest is {}.".format(samples_per_frame, nearest))
 
     @property
     def overlap(self):
@@ -206,6 +284,13 @@ class GUPPIHeader(dict):
         return ((int(self['PKTIDX']) * int(self['PKTSIZE']) * 8 // self._bpcs)
                 * float(self['TBIN']))
 
+    @offset.setter
+    def offset(self, offset):
+        """`offset` in seconds (float) or a numpy timedelta64."""
+        if isinstance(offset, np.timedelta64):
+            offset = offset.astype('timedelta64[ns]').astype(np.int64) * 1e-9
+        self['PKTIDX'] = int(round(offset / float(self['TBIN']) * ((self._bpcs + 7) // 8)))
+
     @property
     def start_time(self):
         day = np.datetime64('1970-01-01', 'ns') + np.timedelta64(
@@ -215,14 +300,22 @@ class GUPPIHeader(dict):
 
     @start_time.setter
     def start_time(self, start_time):
+        """STT_IMJD (int), STT_SMJD and STT_OFFS (floats: whole and fractional
+        seconds of the day, guppi/header.py:392-400)."""
         t = np.datetime64(start_time, 'ns')
-        days = (t - np.datetime64('1970-01-01', 'ns')) // np.timedelta64(1, 'D')
-        rem = t - (np.datetime64('1970-01-01', 'ns') + np.timedelta64(int(days), 'D'))
-        sec = rem / np.timedelta64(1, 's')
-        self['STT_IMJD'] = int(days) + _MJD_UNIX
-        self['STT_SMJD'] = int(sec)
-        self['STT_OFFS'] = float(sec - int(sec))
+        day = t.astype('datetime64[D]')
+        seconds = int((t - day).astype(np.int64)) / 1e9
+        self['STT_IMJD'] = int(day.astype(np.int64)) + _MJD_UNIX
+        self['STT_SMJD'], self['STT_OFFS'] = divmod(seconds, 1)
 
     @property
     def time(self):
         return self.start_time + np.timedelta64(int(round(self.offset * 1e9)), 'ns')
+
+    @time.setter
+    def time(self, time):
+        time = np.datetime64(time, 'ns')
+        if 'STT_IMJD' not in self:
+            self.start_time = time - np.timedelta64(int(round(self.offset * 1e9)), 'ns')
+        else:
+            self.offset = time - self.start_time

@@ -862,6 +862,68 @@ def gen_sequence():
     print('sequence:', out['names'], out['vdif_sequence_write']['sizes'], out['dada_sequence']['files'])
 
 
+def gen_block_writers():
+    """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
+    guppi/base.py:281-310) on seeded non-integer data (exercises the round +
+    clip of the int8 encoders), including a padded partial last frame.  Stored:
+    the input samples and the bytes of the file the reference wrote."""
+    import warnings
+    out = {}
+    tmp = tempfile.mkdtemp()
+    t0 = Time('2019-03-01T12:00:00', precision=9)
+    rng = np.random.default_rng(2024)
+
+    def rnd(shape, cplx):
+        x = rng.standard_normal(shape) * 60.
+        if cplx:
+            x = x + 1j * rng.standard_normal(shape) * 60.
+        return x.astype(np.complex64 if cplx else np.float32)
+
+    # DADA: 2 pol, 1 channel, complex; 3.4 frames of 500 samples
+    h = dada.DADAHeader.fromvalues(time=t0, sample_rate=16 * u.MHz, samples_per_frame=500,
+                                   bps=8, complex_data=True, npol=2, nchan=1,
+                                   telescope='TEST', instrument='bbamd')
+    data = rnd((1700, 2), True)
+    f = os.path.join(tmp, 'w.dada')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with dada.open(f, 'ws', header0=h) as fw:
+            fw.write(data[:123])
+            fw.write(data[123:])
+    out['dada_in'] = data
+    out['dada_file'] = np.fromfile(f, np.uint8)
+    with dada.open(f, 'rs') as fr:
+        out['dada_back'] = fr.read()
+    # DADA real, 4 channels
+    h = dada.DADAHeader.fromvalues(time=t0, sample_rate=1 * u.MHz, samples_per_frame=256,
+                                   bps=8, complex_data=False, npol=1, nchan=4)
+    data = rnd((512, 4), False)
+    f = os.path.join(tmp, 'r.dada')
+    with dada.open(f, 'ws', header0=h) as fw:
+        fw.write(data)
+    out['dada_real_in'] = data
+    out['dada_real_file'] = np.fromfile(f, np.uint8)
+    # GUPPI channels-first and time-first, overlap 0
+    for key, cf, nchan, npol, spf, n in (('guppi_cf', True, 8, 2, 128, 3 * 128),
+                                         ('guppi_tf', False, 4, 2, 64, 2 * 64 + 20)):
+        bpcs = nchan * npol * 2
+        h = guppi.GUPPIHeader.fromvalues(time=t0, sample_rate=1 * u.MHz, samples_per_frame=spf,
+                                         overlap=0, npol=npol, nchan=nchan, pktsize=spf * bpcs // 4,
+                                         bps=8, pktfmt=('1SFA' if cf else 'SIMPLE'))
+        data = rnd((n, npol, nchan), True)
+        f = os.path.join(tmp, key + '.raw')
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            with guppi.open(f, 'ws', header0=h) as fw:
+                fw.write(data[:50])
+                fw.write(data[50:])
+        out[key + '_in'] = data
+        out[key + '_file'] = np.fromfile(f, np.uint8)
+    shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(GOLD, 'block_writer_cases.npz'), **out)
+    print('block writers:', {k: v.shape for k, v in out.items()})
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['all']
     steps = [('levels', gen_levels), ('vdif_samples', gen_vdif_samples),
@@ -871,7 +933,7 @@ if __name__ == '__main__':
              ('mark4_synth', gen_mark4_synth), ('guppi', gen_guppi), ('dada', gen_dada),
              ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt),
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
-             ('sequence', gen_sequence)]
+             ('sequence', gen_sequence), ('block_writers', gen_block_writers)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:
