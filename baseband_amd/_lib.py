@@ -124,9 +124,13 @@ SIGNATURES = [
     ('bb_vdif_locate', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_vdif_scan_at', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_mark5b_scan', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp]),
+    ('bb_mark5b_locate', C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    ('bb_mark5b_scan_at', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp, _vp]),
     ('bb_build_index', C.c_int, [_vp, _sz, _vp, C.c_int, _vp, _sz, _vp]),
     ('bb_decode_frames', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, _sz, _vp]),
     ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),
+    ('bb_mark4_locate', C.c_int, [_vp, _sz, C.c_int, _vp, _sz, _vp, _vp]),
+    ('bb_mark4_scan_at', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp, _vp]),
     ('bb_decode_mark4', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(Mark4DecodeParams), _vp, _sz, _vp]),
     ('bb_decode_i8_tiled', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(TiledParams), _vp, _sz, _vp]),
     ('bb_encode_flat', C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),

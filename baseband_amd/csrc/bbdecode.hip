@@ -271,16 +271,45 @@ int bb_vdif_scan_at(const void *d_buf, size_t nbytes, const bb_vdif_scan_params 
     return BB_OK;
 }
 
-int bb_mark5b_scan(const void *d_buf, size_t nbytes, const bb_mark5b_scan_params *p,
-                   bb_frame_rec *d_recs, size_t nframes, void *stream)
+static int mark5b_scan_impl(const void *d_buf, size_t nbytes, const bb_mark5b_scan_params *p,
+                            const int64_t *d_offsets, bb_frame_rec *d_recs, size_t nframes,
+                            void *stream)
 {
     if (!d_buf || !p || !d_recs) return BB_EINVAL;
-    if ((p->first_offset & 3) || ((uintptr_t)d_buf & 3)) return BB_EINVAL;
+    if ((!d_offsets && (p->first_offset & 3)) || ((uintptr_t)d_buf & 3)) return BB_EINVAL;
     if (nframes == 0) return BB_OK;
     const uint64_t blocks = ((uint64_t)nframes + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
     if (blocks > 0x7fffffffull) return BB_ERANGE;
     hipLaunchKernelGGL(k_mark5b_scan, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
-                       (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes);
+                       (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_offsets, d_recs,
+                       (uint64_t)nframes);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_mark5b_scan(const void *d_buf, size_t nbytes, const bb_mark5b_scan_params *p,
+                   bb_frame_rec *d_recs, size_t nframes, void *stream)
+{
+    return mark5b_scan_impl(d_buf, nbytes, p, nullptr, d_recs, nframes, stream);
+}
+
+int bb_mark5b_scan_at(const void *d_buf, size_t nbytes, const bb_mark5b_scan_params *p,
+                      const int64_t *d_offsets, size_t nframes, bb_frame_rec *d_recs, void *stream)
+{
+    if (!d_offsets && nframes) return BB_EINVAL;
+    return mark5b_scan_impl(d_buf, nbytes, p, d_offsets, d_recs, nframes, stream);
+}
+
+int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets, size_t cap,
+                     unsigned long long *d_count, void *stream)
+{
+    if (!d_buf || !d_offsets || !d_count) return BB_EINVAL;
+    if ((uintptr_t)d_buf & 3) return BB_EINVAL;
+    if (nbytes < BB_M5B_FRAME) return BB_OK;
+    uint64_t blocks = (nbytes + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_mark5b_locate, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_buf, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }
@@ -497,12 +526,13 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     return BB_OK;
 }
 
-int bb_mark4_scan(const void *d_buf, size_t nbytes, const bb_mark4_scan_params *p,
-                  bb_frame_rec *d_recs, size_t nframes, void *stream)
+static int mark4_scan_impl(const void *d_buf, size_t nbytes, const bb_mark4_scan_params *p,
+                           const int64_t *d_offsets, bb_frame_rec *d_recs, size_t nframes,
+                           void *stream)
 {
     if (!d_buf || !p || !d_recs) return BB_EINVAL;
     if (p->ntrack != 16 && p->ntrack != 32 && p->ntrack != 64) return BB_ENOTSUP;
-    if ((p->first_offset & (p->ntrack / 8 - 1)) || ((uintptr_t)d_buf & 7)) return BB_EINVAL;
+    if ((!d_offsets && (p->first_offset & (p->ntrack / 8 - 1))) || ((uintptr_t)d_buf & 7)) return BB_EINVAL;
     if (p->frame_qms < 0) return BB_EINVAL;
     if (nframes == 0) return BB_OK;
     const uint64_t blocks = ((uint64_t)nframes + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
@@ -511,9 +541,42 @@ int bb_mark4_scan(const void *d_buf, size_t nbytes, const bb_mark4_scan_params *
     hipStream_t st = (hipStream_t)stream;
     const uint8_t *b = (const uint8_t *)d_buf;
     switch (p->ntrack) {
-        case 16: hipLaunchKernelGGL(k_mark4_scan<16>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes); break;
-        case 32: hipLaunchKernelGGL(k_mark4_scan<32>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes); break;
-        default: hipLaunchKernelGGL(k_mark4_scan<64>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes); break;
+        case 16: hipLaunchKernelGGL(k_mark4_scan<16>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_offsets, d_recs, (uint64_t)nframes); break;
+        case 32: hipLaunchKernelGGL(k_mark4_scan<32>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_offsets, d_recs, (uint64_t)nframes); break;
+        default: hipLaunchKernelGGL(k_mark4_scan<64>, grid, block, 0, st, b, (uint64_t)nbytes, *p, d_offsets, d_recs, (uint64_t)nframes); break;
+    }
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_mark4_scan(const void *d_buf, size_t nbytes, const bb_mark4_scan_params *p,
+                  bb_frame_rec *d_recs, size_t nframes, void *stream)
+{
+    return mark4_scan_impl(d_buf, nbytes, p, nullptr, d_recs, nframes, stream);
+}
+
+int bb_mark4_scan_at(const void *d_buf, size_t nbytes, const bb_mark4_scan_params *p,
+                     const int64_t *d_offsets, size_t nframes, bb_frame_rec *d_recs, void *stream)
+{
+    if (!d_offsets && nframes) return BB_EINVAL;
+    return mark4_scan_impl(d_buf, nbytes, p, d_offsets, d_recs, nframes, stream);
+}
+
+int bb_mark4_locate(const void *d_buf, size_t nbytes, int ntrack, int64_t *d_offsets, size_t cap,
+                    unsigned long long *d_count, void *stream)
+{
+    if (!d_buf || !d_offsets || !d_count) return BB_EINVAL;
+    if (ntrack != 16 && ntrack != 32 && ntrack != 64) return BB_ENOTSUP;
+    if (nbytes < (size_t)ntrack * 2500) return BB_OK;
+    uint64_t blocks = (nbytes + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *b = (const uint8_t *)d_buf;
+    switch (ntrack) {
+        case 16: hipLaunchKernelGGL(k_mark4_locate<16>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count); break;
+        case 32: hipLaunchKernelGGL(k_mark4_locate<32>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count); break;
+        default: hipLaunchKernelGGL(k_mark4_locate<64>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count); break;
     }
     BB_HIP(hipGetLastError());
     return BB_OK;

@@ -38,21 +38,74 @@ __device__ __forceinline__ uint32_t bb_bcd(uint32_t v, int ndigit, bool *ok)
 // One wave per frame.  Lane i looks at stream words 32+i (flags, sync) and
 // 96+i (time code); three ballots give validity, sync and the 64 time-code
 // bits of track 0.
+// Stream word at any byte position (frames found by bb_mark4_locate need not
+// be word aligned): assembled from bytes, header reads only.
+template <int NTRACK>
+__device__ __forceinline__ typename bb_m4_word<NTRACK>::type
+bb_m4_load_any(const uint8_t *buf, uint64_t pos)
+{
+    typedef typename bb_m4_word<NTRACK>::type word_t;
+    if ((pos & (sizeof(word_t) - 1)) == 0)
+        return *reinterpret_cast<const word_t *>(buf + pos);
+    word_t w = 0;
+#pragma unroll
+    for (int k = 0; k < (int)sizeof(word_t); ++k) w |= (word_t)buf[pos + k] << (8 * k);
+    return w;
+}
+
+// Byte-granular Mark 4 frame search: position p holds a frame
+// when stream word 63 is all zero and words 64..95 are all ones (the sync
+// pattern of every track plus the zero bit before it: mark4/header.py:345-373),
+// the whole frame fits, and -- if its pattern still fits in the buffer -- the
+// frame one later shows the same: locate_frames with check=1
+// (mark4/base.py:110-166, base/base.py:181-335).  One lane per position; the
+// first byte (0xff) rejects nearly all of them.
+template <int NTRACK>
+__device__ __forceinline__ bool bb_m4_sync_at(const uint8_t *buf, uint64_t pos)
+{
+    constexpr int ISZ = NTRACK / 8;
+    const uint8_t *q = buf + pos + 63 * ISZ;
+    if (q[ISZ] != 0xffu) return false;
+#pragma unroll
+    for (int k = 0; k < ISZ; ++k) if (q[k] != 0) return false;
+    for (int k = 1; k < 32 * ISZ; ++k) if (q[ISZ + k] != 0xffu) return false;
+    return true;
+}
+
+template <int NTRACK>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_mark4_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t cap,
+                    unsigned long long *count)
+{
+    constexpr uint64_t FN = (uint64_t)NTRACK * 2500, PAT_END = 96 * (NTRACK / 8);
+    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
+    for (uint64_t pos = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+         pos + FN <= nbytes; pos += stride) {
+        if (!bb_m4_sync_at<NTRACK>(buf, pos)) continue;
+        if (pos + FN + PAT_END <= nbytes && !bb_m4_sync_at<NTRACK>(buf, pos + FN)) continue;
+        const unsigned long long i = atomicAdd(count, 1ull);
+        if (i < cap) out[i] = (int64_t)pos;
+    }
+}
+
 template <int NTRACK>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_mark4_scan(const uint8_t *buf, uint64_t nbytes, bb_mark4_scan_params p,
-                  bb_frame_rec *recs, uint64_t nframes)
+                  const int64_t *offsets, bb_frame_rec *recs, uint64_t nframes)
 {
     typedef typename bb_m4_word<NTRACK>::type word_t;
     const uint64_t frame = (uint64_t)blockIdx.x * BB_WAVES_PER_BLOCK + bb_wave();
     if (frame >= nframes) return;                       // wave-uniform
     const int lane = bb_lane();
     const uint64_t frame_nbytes = (uint64_t)NTRACK * 2500;
-    const uint64_t off = p.first_offset + frame * frame_nbytes;
+    // fixed stride, or explicit (possibly odd) offsets from bb_mark4_locate
+    const uint64_t off = offsets ? (uint64_t)offsets[frame] : p.first_offset + frame * frame_nbytes;
     const bool whole = off + frame_nbytes <= nbytes;
-    const word_t *fw = reinterpret_cast<const word_t *>(buf + off);
     word_t a = 0, b = 0;
-    if (whole) { a = fw[32 + lane]; b = fw[96 + lane]; }
+    if (whole) {
+        a = bb_m4_load_any<NTRACK>(buf, off + (uint64_t)(32 + lane) * sizeof(word_t));
+        b = bb_m4_load_any<NTRACK>(buf, off + (uint64_t)(96 + lane) * sizeof(word_t));
+    }
     const word_t ones = (word_t)~(word_t)0;
     // error flags: header word 1 bits 15..12 -> stream words 48..51
     const bool err = lane >= 16 && lane < 20 && a != 0;

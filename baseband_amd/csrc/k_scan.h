@@ -169,16 +169,18 @@ __device__ __forceinline__ int bb_bcd_decode(uint32_t v, int ndigit)
 #define BB_M5B_PAYLOAD_WORDS 2500u
 __global__ __launch_bounds__(BB_BLOCK)
 void k_mark5b_scan(const uint8_t *buf, uint64_t nbytes, bb_mark5b_scan_params p,
-                   bb_frame_rec *recs, uint64_t nframes)
+                   const int64_t *offsets, bb_frame_rec *recs, uint64_t nframes)
 {
     const uint64_t frame = (uint64_t)blockIdx.x * BB_WAVES_PER_BLOCK + bb_wave();
     if (frame >= nframes) return;                       // wave-uniform
     const int lane = bb_lane();
-    const uint64_t off = p.first_offset + frame * (uint64_t)BB_M5B_FRAME;
+    // fixed stride, or explicit (possibly odd) offsets from bb_mark5b_locate
+    const uint64_t off = offsets ? (uint64_t)offsets[frame]
+                                 : p.first_offset + frame * (uint64_t)BB_M5B_FRAME;
     const bool whole = off + BB_M5B_FRAME <= nbytes;
     const uint32_t *fw = reinterpret_cast<const uint32_t *>(buf + off);
     uint32_t w = 0;
-    if (whole && lane < 4) w = fw[lane];
+    if (whole && lane < 4) w = bb_load_u32_any(buf, nbytes, off + 4 * lane);
     const uint32_t w0 = (uint32_t)__shfl((int)w, 0);
     const uint32_t w1 = (uint32_t)__shfl((int)w, 1);
     const uint32_t w2 = (uint32_t)__shfl((int)w, 2);
@@ -213,6 +215,47 @@ void k_mark5b_scan(const uint8_t *buf, uint64_t nbytes, bb_mark5b_scan_params p,
         r.thread_id = 0;
         r.flags = (uint16_t)((sync_ok ? BB_FRAME_OK : 0u) | (all_fill ? BB_FRAME_INVALID : 0u));
         *reinterpret_cast<bb_u4 *>(&recs[frame]) = *reinterpret_cast<const bb_u4 *>(&r);
+    }
+}
+
+// CRC-16 (x^16 + x^15 + x^2 + 1) of the 48 time-code bits of header words 2
+// and 3, compared with the 16 bits stored below them (mark5b/header.py:28-31,
+// used by find_header: mark5b/base.py:136-155).
+__device__ __forceinline__ bool bb_mark5b_crc_ok(uint32_t w2, uint32_t w3)
+{
+    const uint64_t stream = ((uint64_t)w2 << 32) | w3;  // 48 data bits, then 16 CRC bits
+    uint32_t reg = 0;
+#pragma unroll 8
+    for (int i = 63; i >= 16; --i) {
+        const uint32_t bit = (uint32_t)(stream >> i) & 1u;
+        const uint32_t top = (reg >> 15) & 1u;
+        reg = (reg << 1) & 0xffffu;
+        if (top ^ bit) reg ^= 0x8005u;
+    }
+    return reg == (uint32_t)(w3 & 0xffffu);
+}
+
+// Byte-granular Mark 5B frame search: position p holds a frame
+// when the sync word sits at p, the whole frame fits in the buffer, the time
+// code passes its CRC, and -- if four more bytes fit there -- another sync word
+// sits exactly one frame later: locate_frames with check=1 plus the CRC gate
+// of Mark5BFileReader.find_header (base/base.py:181-335, mark5b/base.py:136-155),
+// which is what the reference's _bad_frame recovery accepts
+// (base/base.py:1127-1219).  Matches are appended unordered.
+__global__ __launch_bounds__(BB_BLOCK)
+void k_mark5b_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t cap,
+                     unsigned long long *count)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
+    for (uint64_t pos = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+         pos + BB_M5B_FRAME <= nbytes; pos += stride) {
+        if (bb_load_u32_any(buf, nbytes, pos) != 0xABADDEEDu) continue;
+        const uint64_t next = pos + BB_M5B_FRAME;
+        if (next + 4 <= nbytes && bb_load_u32_any(buf, nbytes, next) != 0xABADDEEDu) continue;
+        if (!bb_mark5b_crc_ok(bb_load_u32_any(buf, nbytes, pos + 8),
+                              bb_load_u32_any(buf, nbytes, pos + 12))) continue;
+        const unsigned long long i = atomicAdd(count, 1ull);
+        if (i < cap) out[i] = (int64_t)pos;
     }
 }
 

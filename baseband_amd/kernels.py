@@ -116,6 +116,51 @@ def mark5b_scan(dbuf, nframes, ref_seconds, ref_frame_nr, frame_rate,
     return recs
 
 
+def _collect_offsets(launch, dbuf, cap, where):
+    offs = torch.empty(cap, dtype=torch.int64, device=dbuf.device)
+    count = torch.zeros(1, dtype=torch.int64, device=dbuf.device)
+    check(launch(_ptr(offs), cap, _ptr(count)), where)
+    n = min(int(count.item()), cap)
+    return torch.sort(offs[:n]).values
+
+
+def mark5b_locate(dbuf, nbytes):
+    """Byte-granular Mark 5B frame search -> sorted int64 device offsets."""
+    return _collect_offsets(
+        lambda offs, cap, count: lib.bb_mark5b_locate(_ptr(dbuf), nbytes, offs, cap, count, _stream()),
+        dbuf, nbytes // 10016 + 16, 'bb_mark5b_locate')
+
+
+def mark5b_scan_at(dbuf, nbytes, offsets, ref_seconds, ref_frame_nr, frame_rate):
+    p = _lib.Mark5BScanParams()
+    p.first_offset, p.ref_seconds = 0, ref_seconds
+    p.ref_frame_nr, p.frame_rate = ref_frame_nr, frame_rate
+    n = offsets.numel()
+    recs = torch.empty((n, 4), dtype=torch.int32, device=dbuf.device)
+    check(lib.bb_mark5b_scan_at(_ptr(dbuf), nbytes, C.byref(p), _ptr(offsets), n,
+                                _ptr(recs), _stream()), 'bb_mark5b_scan_at')
+    return recs
+
+
+def mark4_locate(dbuf, nbytes, ntrack):
+    """Byte-granular Mark 4 frame search -> sorted int64 device offsets."""
+    return _collect_offsets(
+        lambda offs, cap, count: lib.bb_mark4_locate(_ptr(dbuf), nbytes, ntrack, offs, cap, count,
+                                                     _stream()),
+        dbuf, nbytes // (ntrack * 2500) + 16, 'bb_mark4_locate')
+
+
+def mark4_scan_at(dbuf, nbytes, offsets, ntrack, ref_year, ref_qms, frame_qms):
+    p = _lib.Mark4ScanParams()
+    p.first_offset, p.ntrack, p.ref_year = 0, ntrack, ref_year
+    p.ref_qms, p.frame_qms = ref_qms, frame_qms
+    n = offsets.numel()
+    recs = torch.empty((n, 4), dtype=torch.int32, device=dbuf.device)
+    check(lib.bb_mark4_scan_at(_ptr(dbuf), nbytes, C.byref(p), _ptr(offsets), n,
+                               _ptr(recs), _stream()), 'bb_mark4_scan_at')
+    return recs
+
+
 def recs_fields(recs):
     """Split scan records (device int32 (n,4)) into named host arrays."""
     r = recs.cpu().numpy()

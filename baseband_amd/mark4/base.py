@@ -82,6 +82,8 @@ class Mark4FileReader(VLBIFileReaderBase):
             o = int(o)
             if o < lo or o > (pos + maximum if forward else pos):
                 continue
+            if o + fn > len(image):              # the frame has to fit completely
+                continue
             if not self._sync_at(image, o, ntrack):
                 continue
             if all(self._sync_at(image, o + k * fn, ntrack)
@@ -91,8 +93,8 @@ class Mark4FileReader(VLBIFileReaderBase):
         out.sort(key=lambda o: abs(o - pos))
         return out
 
-    def find_header(self, forward=True, maximum=None):
-        locations = self.locate_frames(forward=forward, maximum=maximum)
+    def find_header(self, forward=True, maximum=None, check=1):
+        locations = self.locate_frames(forward=forward, maximum=maximum, check=check)
         if not locations:
             raise HeaderNotFoundError('could not locate a a nearby frame.')
         self.fh_raw.seek(locations[0])
@@ -167,19 +169,60 @@ class Mark4StreamReader(GPUStreamReaderBase):
         return self.fh_raw.image()
 
     def _last_header(self):
-        image = self._image()
+        """Last frame of the file: searched backwards from one frame before
+        the end, with a sync pattern required one frame earlier and (if inside
+        the file) one later (base/base.py:1066-1077; mark4/base.py:307-314)."""
         fn = self._set_nbytes
-        nfull = (len(image) - self._file_offset0) // fn
-        for k in range(nfull - 1, max(-1, nfull - 3), -1):
-            o = self._file_offset0 + k * fn
-            if self.fh_raw._sync_at(image, o, self._ntrack):
-                dt = np.dtype(MARK4_DTYPES[self._ntrack])
-                stream = np.frombuffer(image[o:o + 160 * dt.itemsize].tobytes(), dtype=dt)
-                header = Mark4Header(stream2words(stream), verify=False)
-                header.infer_decade(self.start_time)
-                return header
-        raise HeaderNotFoundError("corrupt VLBI frame? No frame in last {0} "
-                                  "bytes.".format(2 * fn))
+        size = len(self._image())
+        with self.fh_raw.temporary_offset(max(0, size - fn)):
+            try:
+                header = self.fh_raw.find_header(forward=False, maximum=2 * fn - 1,
+                                                 check=(-1, 1))
+            except HeaderNotFoundError as exc:
+                exc.args += ("corrupt VLBI frame? No frame in last {0} bytes."
+                             .format(2 * fn),)
+                raise
+        header.infer_decade(self.start_time)
+        return header
+
+    # -- corruption-tolerant index (SURVEY 8f N1)
+    _can_relocate = True
+    _resident = None
+
+    def _relocate(self):
+        """Frames are missing or out of place: keep the file in HBM, find every
+        intact frame byte by byte (bb_mark4_locate), read those headers
+        (bb_mark4_scan_at) and place the frames by their time index; frames
+        without an entry decode to fill_value -- the outcome of the
+        reference's _bad_frame recovery (base/base.py:1127-1219).  A frame
+        that shows up more than once is 'excess data', which the reference
+        refuses as well."""
+        from ..staging import upload
+        kernels.require_gpu()
+        image = self._image()
+        dev, n = upload(image), len(image)
+        offs = kernels.mark4_locate(dev, n, self._ntrack)
+        recs = kernels.mark4_scan_at(dev, n, offs, self._ntrack, self.header0.year,
+                                     self._ref_qms, self._frame_qms)
+        ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
+        index = recs[:, 2][ok]
+        if index.numel() != torch.unique(index).numel():
+            raise AssertionError("problem loading frame: there appears to be excess data "
+                                 "(a frame time occurs more than once).")
+        nsets = self._nsample // self.samples_per_frame
+        self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
+        self._relocated = True
+
+    def _read_sets(self, first, last):
+        if self._resident is None:
+            return super()._read_sets(first, last)
+        dev, src = self._resident
+        maps = BITMAPS[self._coder]
+        flat = kernels.decode_mark4(
+            dev, last - first, self._ntrack, 20000, maps['sign_bit'], maps['mag_bit'],
+            fill_words=160, src=src[first:last].contiguous(), fill_value=self.fill_value)
+        return flat.reshape(((last - first) * self.samples_per_frame,)
+                            + tuple(self._decode_shape))
 
     def _process_window(self, dbuf, first, last, out_flat):
         maps = BITMAPS[self._coder]          # KeyError: unsupported Mark 4 mode

@@ -47,30 +47,55 @@ class Mark5BFileReader(VLBIFileReaderBase):
                                     sample_shape=(self.nchan,), bps=self.bps,
                                     verify=verify)
 
-    def find_header(self, maximum=2 * FRAME_NBYTES):
-        """Locate the first frame at or after the current position: a sync
-        word with another one a frame later and a correct time-code CRC
-        (mark5b/base.py:136-155)."""
+    def locate_frames(self, lo, hi, check=(1,)):
+        """Offsets p in [lo, hi] that hold a frame: sync word at p, the whole
+        frame fits in the file, a correct time-code CRC, and a sync word
+        `check` frames away wherever that still lies inside the file --
+        locate_frames + the CRC gate of find_header (base/base.py:181-335,
+        mark5b/base.py:136-155).  Ascending."""
         image = self.image()
+        n = len(image)
+        lo, hi = max(0, lo), min(hi, n - FRAME_NBYTES)
+        if hi < lo:
+            return []
+        seg = np.asarray(image[lo:hi + 4])
+        sync = np.array([SYNC], '<u4').view(np.uint8)
+        hit = seg[:hi - lo + 1] == sync[0]
+        for k in (1, 2, 3):
+            hit &= seg[k:k + hi - lo + 1] == sync[k]
+
+        def sync_at(q):
+            return bytes(image[q:q + 4]) == sync.tobytes()
+
+        found = []
+        for p in (np.flatnonzero(hit) + lo).tolist():
+            if any(0 <= p + c * FRAME_NBYTES and p + c * FRAME_NBYTES + 4 <= n
+                   and not sync_at(p + c * FRAME_NBYTES) for c in check):
+                continue
+            words = np.frombuffer(bytes(image[p:p + 16]), '<u4')
+            if crc16_mark5b(words) != (int(words[3]) & 0xffff):
+                continue
+            found.append(p)
+        return found
+
+    def _header_at(self, offset):
+        words = np.frombuffer(bytes(self.image()[offset:offset + 16]), '<u4')
+        return Mark5BHeader(words, kday=self.kday, ref_time=self.ref_time)
+
+    def find_header(self, maximum=2 * FRAME_NBYTES, forward=True, check=(1,)):
+        """Nearest frame at or after (before, with ``forward=False``) the
+        current position; the file pointer is left at its start."""
         pos = self.fh_raw.tell()
-        stop = min(len(image) - 16, pos + maximum)
-        sync = np.frombuffer(np.array([SYNC], '<u4').tobytes(), np.uint8)
-        for o in range(pos, max(stop, pos) + 1):
-            if not np.array_equal(image[o:o + 4], sync):
-                continue
-            nxt = o + FRAME_NBYTES
-            if nxt + 4 <= len(image) and not np.array_equal(image[nxt:nxt + 4], sync):
-                continue
-            words = image[o:o + 16].view('<u4')
+        found = (self.locate_frames(pos, pos + maximum, check) if forward
+                 else self.locate_frames(pos - maximum, pos, check)[::-1])
+        for offset in found:
             try:
-                header = Mark5BHeader(words, kday=self.kday,
-                                      ref_time=self.ref_time)
+                header = self._header_at(offset)
                 header.jday, header.seconds
             except Exception:
                 continue
-            if crc16_mark5b(words) == header['crc']:
-                self.fh_raw.seek(o)
-                return header
+            self.fh_raw.seek(offset)
+            return header
         raise HeaderNotFoundError('could not locate a a nearby frame.')
 
     def get_frame_rate(self):
@@ -142,18 +167,52 @@ class Mark5BStreamReader(GPUStreamReaderBase):
                          + header['frame_nr'] - self.header0['frame_nr']))
 
     def _last_header(self):
+        """Last frame of the file: searched backwards from one frame before
+        the end, with a sync word required one frame earlier and (if inside
+        the file) one later (base/base.py:1066-1077)."""
+        size = len(self._image())
+        with self.fh_raw.temporary_offset(max(0, size - FRAME_NBYTES)):
+            try:
+                header = self.fh_raw.find_header(maximum=2 * FRAME_NBYTES - 1,
+                                                 forward=False, check=(-1, 1))
+            except HeaderNotFoundError as exc:
+                exc.args += ("corrupt VLBI frame? No frame in last {0} bytes."
+                             .format(2 * FRAME_NBYTES),)
+                raise
+        header.infer_kday(self.start_time)
+        return header
+
+    # -- corruption-tolerant index (SURVEY 8f N1)
+    _can_relocate = True
+    _resident = None
+
+    def _relocate(self):
+        """Frames are missing or out of place: keep the file in HBM, find every
+        intact frame byte by byte (bb_mark5b_locate), read those headers
+        (bb_mark5b_scan_at) and place the frames by their time index; frames
+        without an entry decode to fill_value.  Same outcome as the
+        reference's frame-by-frame _bad_frame recovery (base/base.py:1127-1219)."""
+        from ..staging import upload
+        kernels.require_gpu()
         image = self._image()
-        nfull = (len(image) - self._file_offset0) // FRAME_NBYTES
-        hw = strided_header_words(image, FRAME_NBYTES, 4,
-                                  offset=self._file_offset0)
-        for k in range(min(nfull, len(hw)) - 1, max(-1, nfull - 3), -1):
-            if int(hw[k][0]) != SYNC:
-                continue
-            header = Mark5BHeader(hw[k], verify=False)
-            header.infer_kday(self.start_time)
-            return header
-        raise HeaderNotFoundError("corrupt VLBI frame? No frame in last {0} "
-                                  "bytes.".format(2 * FRAME_NBYTES))
+        dev, n = upload(image), len(image)
+        offs = kernels.mark5b_locate(dev, n)
+        recs = kernels.mark5b_scan_at(dev, n, offs, self._ref_seconds,
+                                      self.header0['frame_nr'], self._frame_rate)
+        nsets = self._nsample // self.samples_per_frame
+        self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
+        self._relocated = True
+
+    def _read_sets(self, first, last):
+        if self._resident is None:
+            return super()._read_sets(first, last)
+        dev, src = self._resident
+        flat = kernels.decode_frames(
+            dev, last - first, 10000, _lib.CODER_MARK5B, self.bps,
+            chunk=self._unsliced_shape[0], nslot=1,
+            src=src[first:last].contiguous(), fill_value=self.fill_value)
+        return flat.reshape(((last - first) * self.samples_per_frame,)
+                            + tuple(self._decode_shape))
 
     def _process_window(self, dbuf, first, last, out_flat):
         n = last - first

@@ -166,6 +166,26 @@ int bb_mark5b_scan(const void *d_buf, size_t nbytes,
                    bb_frame_rec *d_recs, size_t nframes, void *stream);
 
 /*
+ * Corruption-tolerant Mark 5B indexing (reference:
+ * VLBIStreamReaderBase._bad_frame, base/base.py:1127-1219, with
+ * Mark5BFileReader.find_header, mark5b/base.py:136-155, and locate_frames,
+ * base/base.py:181-335).  bb_mark5b_locate tests EVERY byte offset: a frame
+ * starts at p when the sync word 0xABADDEED sits there, the 10016-byte frame
+ * fits in the buffer, the BCD time code passes its CRC-16, and -- when four
+ * bytes still fit there -- another sync word sits one frame later (check=1).
+ * Offsets are appended unordered to d_offsets (at most `cap`; *d_count, which
+ * the caller zeroes, receives the number found).  bb_mark5b_scan_at is
+ * bb_mark5b_scan for frames at explicit, possibly odd, offsets
+ * (params->first_offset is ignored).
+ */
+int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets,
+                     size_t cap, unsigned long long *d_count, void *stream);
+int bb_mark5b_scan_at(const void *d_buf, size_t nbytes,
+                      const bb_mark5b_scan_params *params,
+                      const int64_t *d_offsets, size_t nframes,
+                      bb_frame_rec *d_recs, void *stream);
+
+/*
  * Turn scan records into the dense, output-ordered source table the decode
  * kernels consume: d_src[time_index*nslot + slot] = payload offset, or -1 for
  * frames that are missing or flagged invalid (they decode to fill_value:
@@ -244,6 +264,24 @@ typedef struct bb_mark4_scan_params {
 int bb_mark4_scan(const void *d_buf, size_t nbytes,
                   const bb_mark4_scan_params *params,
                   bb_frame_rec *d_recs, size_t nframes, void *stream);
+
+/*
+ * Corruption-tolerant Mark 4 indexing (reference: _bad_frame,
+ * base/base.py:1127-1219, with Mark4FileReader.locate_frames,
+ * mark4/base.py:110-166).  bb_mark4_locate tests EVERY byte offset: a frame
+ * starts at p when stream word 63 is zero and words 64..95 are all ones, the
+ * ntrack*2500-byte frame fits in the buffer, and -- when its pattern still
+ * fits -- the frame one later shows the same pattern (check=1).  Output as
+ * for bb_mark5b_locate.  bb_mark4_scan_at is bb_mark4_scan for frames at
+ * explicit offsets (need not be word aligned; params->first_offset ignored).
+ */
+int bb_mark4_locate(const void *d_buf, size_t nbytes, int ntrack,
+                    int64_t *d_offsets, size_t cap,
+                    unsigned long long *d_count, void *stream);
+int bb_mark4_scan_at(const void *d_buf, size_t nbytes,
+                     const bb_mark4_scan_params *params,
+                     const int64_t *d_offsets, size_t nframes,
+                     bb_frame_rec *d_recs, void *stream);
 
 /*
  * Mark 4 track-demultiplexing decode (M4-1, M4-2): replaces the five

@@ -862,6 +862,111 @@ def gen_sequence():
     print('sequence:', out['names'], out['vdif_sequence_write']['sizes'], out['dada_sequence']['files'])
 
 
+def gen_fixed_corrupt():
+    """File-surgery cases of the reference's Mark 5B and Mark 4 corrupt-file
+    tests (mark5b/tests/test_corrupt_files.py, mark4/tests/test_corrupt_files.py)
+    read by the reference with verify='fix'.  Stored: the intact base files
+    (compressed) and per case the removed byte range / replacement, the shape
+    and sha256 of what the reference returns, and which frames came back as
+    fill."""
+    import warnings
+    arrays, cases = {}, {}
+
+    def run(opener, blob, kwargs, spf):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            with opener(io.BytesIO(blob), 'rs', **kwargs) as fr:
+                n = fr.shape[0]
+                data = fr.read()
+        return data
+
+    def record(lst, kind, blob, base_data, opener, kwargs, spf, **info):
+        c = dict(kind=kind, **info)
+        try:
+            got = run(opener, blob, kwargs, spf)
+        except Exception as exc:
+            c['error'] = type(exc).__name__
+            c['message'] = str(exc)[:200]
+            lst.append(c)
+            return
+        c['shape'] = list(got.shape)
+        c['sha256'] = sha(got)
+        byframe = got.reshape(-1, spf * got.shape[-1])
+        c['zeroed'] = [int(i) for i in range(len(byframe)) if not byframe[i].any()]
+        lst.append(c)
+
+    # ---- Mark 5B, sample file + 4 invalid frames (test_bad_bytes)
+    sample = open(SAMPLE_MARK5B, 'rb').read()
+    kw = dict(sample_rate=32 * u.MHz, kday=56000, nchan=8, bps=2)
+    with mark5b.open(SAMPLE_MARK5B, 'rs', **kw) as fs:
+        frame_rate = fs._frame_rate
+        start_time = fs.start_time
+        fs.read()
+        frame3 = fs._frame
+    tail = io.BytesIO()
+    for i in range(4, 8):
+        header = frame3.header.copy()
+        header.set_time(start_time + i / frame_rate, frame_rate=frame_rate)
+        header.update()
+        frame3.__class__(header, frame3.payload, valid=False).tofile(tail)
+    arrays['m5b_sample_tail'] = np.frombuffer(tail.getvalue(), np.uint8)
+    lst = cases['m5b_sample'] = []
+    kwj = dict(sample_rate=32e6, kday=56000, nchan=8, bps=2)
+    for (lo, hi), rep in (((20032, 20033), b''), ((20096, 20100), b''), ((12000, 22000), b''),
+                          ((30060, 30070), b''), ((40063, 40064), b''),
+                          ((20032, 20033), b'\xff'), ((20032, 20036), b'\xff'),
+                          ((20040, 20041), b'\xff')):
+        blob = sample[:lo] + rep + sample[hi:] + tail.getvalue()
+        record(lst, 'bytes', blob, None, mark5b.open, kw, 5000, remove=[lo, hi], replace=rep.hex())
+    # ---- Mark 5B fake file (TestCorruptFile)
+    time = Time('2010-11-12T13:14:15')
+    header0 = mark5b.Mark5BHeader.fromvalues(time=time)
+    data = np.repeat([[-1, 1], [-3, 3]], 10000, axis=0)
+    bio = KeepBytesIO()
+    with mark5b.open(bio, 'ws', header0=header0, sample_rate=100 * u.kHz, nchan=2) as fw:
+        for _ in range(16):
+            fw.write(data)
+    fake = bio.value()
+    arrays['m5b_fake'] = np.frombuffer(fake, np.uint8)
+    kw = dict(nchan=2, sample_rate=100 * u.kHz, ref_time=time)
+    lst = cases['m5b_fake'] = []
+    fn = 10016
+    todo = [((f0 * fn, f1 * fn), 'frames') for f0, f1 in ((1, 2), (3, 4), (5, 6), (7, 10))]
+    todo += [((0, 8), 'start'), ((0, 9000), 'start'), ((0, 10012), 'start'), ((8, 10016), 'start')]
+    todo += [((15 * fn + a, 15 * fn + b), 'end') for a, b in
+             ((0, 10016), (0, 16), (8, 16), (0, 1), (10, 11), (15, 16), (20, 21), (10015, 10016))]
+    todo += [((10016, 20032), 'middle'), ((20000, 20501), 'middle'), ((20032, 20048), 'middle')]
+    for (lo, hi), kind in todo:
+        record(lst, kind, fake[:lo] + fake[hi:], None, mark5b.open, kw, 20000, remove=[lo, hi], replace='')
+    # ---- Mark 4 fake file
+    header0 = mark4.Mark4Header.fromvalues(time=time, ntrack=16, nchan=2, fanout=4)
+    data = np.zeros((2 * header0.frame_nbytes, 2))
+    data.reshape(-1, 4, 2)[160:] = [[-1, 1], [-3, 3], [1, -1], [3, -3]]
+    bio = KeepBytesIO()
+    with mark4.open(bio, 'ws', header0=header0, sample_rate=100 * u.kHz) as fw:
+        for _ in range(8):
+            fw.write(data)
+    fake = bio.value()
+    arrays['m4_fake'] = np.frombuffer(fake, np.uint8)
+    kw = dict(sample_rate=100 * u.kHz, ref_time=time)
+    lst = cases['m4_fake'] = []
+    fn = 40000
+    todo = [((f0 * fn, f1 * fn), 'frames') for f0, f1 in ((1, 2), (3, 4), (3, 5))]
+    todo += [((7 * fn + a, 7 * fn + b), 'end') for a, b in
+             ((0, 40000), (0, 320), (8, 16), (0, 1), (10, 11), (319, 320), (400, 401), (39999, 40000))]
+    todo += [((40000, 80000), 'middle'), ((78000, 82000), 'middle'), ((80010, 80100), 'middle')]
+    for (lo, hi), kind in todo:
+        record(lst, kind, fake[:lo] + fake[hi:], None, mark4.open, kw, 80000, remove=[lo, hi], replace='')
+    # duplicated data: 'excess data' error in the reference
+    record(lst, 'duplicate', fake[:100000] + fake[40000:], None, mark4.open, kw, 80000,
+           remove=[100000, 40000], replace='')
+    np.savez_compressed(os.path.join(GOLD, 'fixed_corrupt_files.npz'), **arrays)
+    with open(os.path.join(GOLD, 'fixed_corrupt_cases.json'), 'w') as f:
+        json.dump(cases, f, indent=1)
+    for k, lst in cases.items():
+        print(k, [(c['kind'], c.get('shape', c.get('error')), c.get('zeroed')) for c in lst])
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -933,7 +1038,8 @@ if __name__ == '__main__':
              ('mark4_synth', gen_mark4_synth), ('guppi', gen_guppi), ('dada', gen_dada),
              ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt),
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
-             ('sequence', gen_sequence), ('block_writers', gen_block_writers)]
+             ('sequence', gen_sequence), ('block_writers', gen_block_writers),
+             ('fixed_corrupt', gen_fixed_corrupt)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

@@ -97,3 +97,98 @@ def test_adjacent_damaged_headers(tmp_path):
         want[s * 20000:(s + 1) * 20000, t] = 0.
     assert bits_equal(got, want)
     assert set(case['zeroed']) == {28, 29, 30, 31}      # what the reference returns
+
+
+# ---- Mark 5B and Mark 4 (mark5b/tests/test_corrupt_files.py,
+# ---- mark4/tests/test_corrupt_files.py), reference outputs as digests -------
+with open(golden_path('fixed_corrupt_cases.json')) as _f:
+    FIXED = json.load(_f)
+_FIXED_FILES = np.load(golden_path('fixed_corrupt_files.npz'))
+
+
+def _fixed_blob(group, case):
+    if group == 'm5b_sample':
+        base = load_file('samples/sample.m5b').tobytes()
+        tail = _FIXED_FILES['m5b_sample_tail'].tobytes()
+    else:
+        base, tail = _FIXED_FILES[group].tobytes(), b''
+    lo, hi = case['remove']
+    if case['kind'] == 'duplicate':
+        return base[:lo] + base[hi:]
+    return base[:lo] + bytes.fromhex(case['replace']) + base[hi:] + tail
+
+
+def _fixed_open(group, blob, tmp_path, **extra):
+    from baseband_amd import mark5b, mark4
+    p = tmp_path / (group + '.bin')
+    p.write_bytes(blob)
+    t0 = np.datetime64('2010-11-12T13:14:15')
+    if group == 'm5b_sample':
+        return mark5b.open(str(p), 'rs', sample_rate=32e6, kday=56000, nchan=8, bps=2, **extra)
+    if group == 'm5b_fake':
+        return mark5b.open(str(p), 'rs', nchan=2, sample_rate=100e3, ref_time=t0, **extra)
+    return mark4.open(str(p), 'rs', sample_rate=100e3, ref_time=t0, **extra)
+
+
+_FIXED_PARAMS = [(g, i) for g in ('m5b_sample', 'm5b_fake', 'm4_fake') for i in range(len(FIXED[g]))]
+
+
+@pytest.mark.parametrize('group,i', _FIXED_PARAMS,
+                         ids=['%s-%s%d' % (g, FIXED[g][i]['kind'], i) for g, i in _FIXED_PARAMS])
+def test_mark5b_mark4_file_surgery(group, i, tmp_path):
+    case = FIXED[group][i]
+    blob = _fixed_blob(group, case)
+    if 'error' in case:                      # duplicated data: refused, as in the reference
+        with _fixed_open(group, blob, tmp_path) as fh:
+            with pytest.raises(Exception, match='excess data'):
+                with warnings.catch_warnings():
+                    warnings.simplefilter('ignore')
+                    fh.read()
+        return
+    spf = {'m5b_sample': 5000, 'm5b_fake': 20000, 'm4_fake': 80000}[group]
+    with _fixed_open(group, blob, tmp_path) as fh:
+        assert list(fh.shape) == case['shape']            # size from the last good header
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter('always')
+            got = fh.read().cpu().numpy()
+    assert list(got.shape) == case['shape']
+    assert hashlib.sha256(got.tobytes()).hexdigest() == case['sha256']
+    byframe = got.reshape(-1, spf * got.shape[-1])
+    assert [k for k in range(len(byframe)) if not byframe[k].any()] == case['zeroed']
+    interior = [k for k in case['zeroed'] if not (group == 'm5b_sample' and k >= 4)]
+    if interior:
+        assert any('problem loading frame' in str(w.message) for w in wlist)
+        with _fixed_open(group, blob, tmp_path, verify=True) as fh:
+            with pytest.raises(ValueError):
+                fh.read()
+    else:
+        assert not wlist
+
+
+def test_mark5b_locate_kernel(tmp_path):
+    """bb_mark5b_locate: sync + CRC + next sync, at odd offsets too."""
+    from baseband_amd import kernels
+    base = load_file('samples/sample.m5b')
+    # one byte of frame 2's payload removed, time code of frame 3 damaged in place
+    blob = np.concatenate([base[:20100], base[20101:]])
+    blob[30047 + 9] ^= 0xff
+    dbuf = kernels.to_device_bytes(np.concatenate([blob, np.zeros(8, np.uint8)]))
+    offs = kernels.mark5b_locate(dbuf, len(blob)).cpu().numpy().tolist()
+    # frame 1 is followed by frame 2 in place; frame 2's successor is one byte early;
+    # frame 3 (at 30047) fails its CRC
+    assert offs == [0, 10016]
+    import torch
+    at = torch.tensor([0, 10016, 20032, 30047], dtype=torch.int64, device='cuda')
+    recs = kernels.recs_fields(kernels.mark5b_scan_at(dbuf, len(blob), at, 0, 0, 0))
+    assert recs['payload_offset'].tolist() == [16, 10032, 20048, 30063]
+
+
+def test_mark4_locate_kernel():
+    from baseband_amd import kernels
+    base = _FIXED_FILES['m4_fake']
+    blob = np.concatenate([base[:80010], base[80100:]])          # 90 bytes of header 2 gone
+    dbuf = kernels.to_device_bytes(np.concatenate([blob, np.zeros(8, np.uint8)]))
+    offs = kernels.mark4_locate(dbuf, len(blob), 16).cpu().numpy().tolist()
+    # frame 1 has no successor in place; frame 2 lost bytes 10..100 of its header but
+    # its sync pattern (bytes 126..191) survives 90 bytes early, like all later frames
+    assert offs == [0] + [k * 40000 - 90 for k in range(2, 8)]
