@@ -78,6 +78,26 @@ class VLBIFileReaderBase(FileBase):
             self._image = host_image(self.fh_raw)
         return self._image
 
+    # name used in `info.format`; constructor arguments a reader may lack
+    _format = None
+
+    def _info_needs(self):
+        return {}
+
+    def _info_extras(self, header0, offset0):
+        return {}
+
+    @property
+    def info(self):
+        """`FileReaderInfo` snapshot (base/file_info.py:282-415)."""
+        from .info import FileReaderInfo
+        cached = self.__dict__.get('_info')
+        if cached is None:
+            cached = self.__dict__['_info'] = FileReaderInfo(
+                self, self._format or type(self).__name__.replace('FileReader', '').lower(),
+                self._info_needs())
+        return cached
+
 
 def _apply_squeeze(shape):
     return tuple(s for s in shape if s > 1)
@@ -147,6 +167,16 @@ class GPUStreamReaderBase:
     @property
     def closed(self):
         return self._closed
+
+    @property
+    def info(self):
+        """`StreamReaderInfo` snapshot, renewed when `verify` changes or the
+        stream is closed (base/file_info.py:417-571)."""
+        from .info import StreamReaderInfo
+        cached = self.__dict__.get('_info')
+        if cached is None or cached.verify != self.verify or cached.closed != self.closed:
+            cached = self.__dict__['_info'] = StreamReaderInfo(self)
+        return cached
 
     def close(self):
         self._closed = True
@@ -316,12 +346,16 @@ class GPUStreamReaderBase:
             image = self._image()
             per_win = max(1, self.window_bytes // set_nbytes)
             if self._pipeline is None:
-                self._pipeline = WindowPipeline(image, per_win * set_nbytes)
+                self._pipeline = WindowPipeline(image, (per_win + 1) * set_nbytes)
             ranges, spans = [], []
             for s in range(first, last, per_win):
                 e = min(last, s + per_win)
                 lo = self._file_offset0 + s * set_nbytes
-                hi = min(self._file_offset0 + e * set_nbytes, len(image))
+                # when verifying, the frame set after the last one requested
+                # travels along: a frame only counts as good if the header
+                # behind it is in place too (base/base.py:1083-1125)
+                look = 1 if (self.verify and e == last) else 0
+                hi = min(self._file_offset0 + (e + look) * set_nbytes, len(image))
                 ranges.append((lo, hi))
                 spans.append((s, e))
 

@@ -40,6 +40,8 @@ class DADAFileNameSequencer(UpperCaseSequencer):
 
 
 class DADAFileReader(VLBIFileReaderBase):
+    _format = 'dada'
+
     def read_header(self):
         return DADAHeader.fromfile(self.fh_raw)
 

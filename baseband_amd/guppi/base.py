@@ -23,6 +23,11 @@ GUPPIFileNameSequencer = UpperCaseSequencer
 
 
 class GUPPIFileReader(VLBIFileReaderBase):
+    _format = 'guppi'
+
+    def _info_extras(self, header0, offset0):
+        return {'pktfmt': header0['PKTFMT'], 'overlap': header0.overlap}
+
     def read_header(self):
         return GUPPIHeader.fromfile(self.fh_raw)
 

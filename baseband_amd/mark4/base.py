@@ -26,6 +26,22 @@ __all__ = ['Mark4FileReader', 'Mark4StreamReader', 'Mark4StreamWriter', 'open']
 
 
 class Mark4FileReader(VLBIFileReaderBase):
+    _format = 'mark4'
+
+    def _info_needs(self):
+        if self.decade is None and self.ref_time is None:
+            return {'decade': "needed to infer full times.",
+                    'ref_time': "needed to infer full times."}
+        return {}
+
+    def _info_extras(self, header0, offset0):
+        return {'ntrack': header0.ntrack, 'offset0': offset0}
+
+    def _info_number_of_frames(self, header0, offset0):
+        with self.temporary_offset(-header0.frame_nbytes, 2):
+            self.find_header(forward=False)
+            return (self.fh_raw.tell() - offset0) / header0.frame_nbytes + 1
+
     def __init__(self, fh_raw, ntrack=None, decade=None, ref_time=None):
         self.ntrack = operator.index(ntrack) if ntrack is not None else None
         self.decade = operator.index(decade) if decade is not None else None
@@ -227,7 +243,8 @@ class Mark4StreamReader(GPUStreamReaderBase):
     def _process_window(self, dbuf, first, last, out_flat):
         maps = BITMAPS[self._coder]          # KeyError: unsupported Mark 4 mode
         n = last - first
-        nframes = min(n, dbuf.numel() // self._set_nbytes)
+        # one header beyond the request is checked too when it was staged
+        nframes = min(n + (1 if self.verify else 0), dbuf.numel() // self._set_nbytes)
         recs = kernels.mark4_scan(
             dbuf, nframes, self._ntrack, self.header0.year,
             self._ref_qms + first * self._frame_qms, self._frame_qms)
@@ -238,7 +255,10 @@ class Mark4StreamReader(GPUStreamReaderBase):
         if self.verify:
             ok = (recs[:, 3] >> 16) & _lib.FRAME_OK
             expect = torch.arange(nframes, device=recs.device, dtype=torch.int32)
-            bad = ((ok == 0) | (recs[:, 2] != expect)).sum() + (n - nframes)
+            wrong = recs[:, 2] != expect
+            if nframes > n:                 # the look-ahead header only has to be a header
+                wrong[n:] = False
+            bad = ((ok == 0) | wrong).sum() + max(0, n - nframes)
             self._pending_checks.append(bad)
 
 

@@ -26,6 +26,17 @@ __all__ = ['VDIFFileReader', 'VDIFStreamReader', 'VDIFStreamWriter', 'open']
 
 class VDIFFileReader(VLBIFileReaderBase):
     """Simple reader for VDIF files: headers, frames, frame sets."""
+    _format = 'vdif'
+
+    def _info_extras(self, header0, offset0):
+        """edv, thread ids and number of frame sets (vdif/file_info.py:10-50)."""
+        with self.temporary_offset(0):
+            thread_ids = self.get_thread_ids()
+        nframes = len(self.image()) / header0.frame_nbytes
+        nsets = nframes / len(thread_ids)
+        return {'edv': header0.edv, 'thread_ids': thread_ids,
+                'number_of_framesets': int(nsets) if nsets % 1 == 0 else None,
+                '_sample_shape': (len(thread_ids), header0.nchan)}
 
     def read_header(self, edv=None, verify=True):
         return VDIFHeader.fromfile(self.fh_raw, edv=edv, verify=verify)

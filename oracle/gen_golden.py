@@ -967,6 +967,67 @@ def gen_fixed_corrupt():
         print(k, [(c['kind'], c.get('shape', c.get('error')), c.get('zeroed')) for c in lst])
 
 
+def gen_info():
+    """``info`` of the reference for every sample file, as plain JSON values
+    (base/file_info.py; */file_info.py)."""
+    def plain(v):
+        if isinstance(v, Time):
+            return v.isot
+        if isinstance(v, u.Quantity):
+            return float(v.to_value(u.Hz))
+        if isinstance(v, dict):
+            return {k: plain(x) for k, x in v.items()}
+        if isinstance(v, (tuple, list)):
+            return [plain(x) for x in v]
+        if isinstance(v, (np.integer, np.bool_)):
+            return v.item()
+        if isinstance(v, Exception):
+            return repr(v)
+        return v
+
+    out = {}
+    todo = [('sample_vdif', vdif, SAMPLE_VDIF, {}), ('sample_mwa_vdif', vdif, SAMPLE_MWA_VDIF, {}),
+            ('sample_arochime_vdif', vdif, SAMPLE_AROCHIME_VDIF, {}),
+            ('sample_bps1_vdif', vdif, SAMPLE_BPS1_VDIF, {}),
+            ('sample_m5b_bare', mark5b, SAMPLE_MARK5B, {}),
+            ('sample_m5b', mark5b, SAMPLE_MARK5B, dict(kday=56000, nchan=8)),
+            ('sample_m4_bare', mark4, SAMPLE_MARK4, {}),
+            ('sample_m4', mark4, SAMPLE_MARK4, dict(ntrack=64, decade=2010)),
+            ('sample_m4_32', mark4, SAMPLE_MARK4_32TRACK, dict(ntrack=32, decade=2010)),
+            ('sample_dada', dada, SAMPLE_DADA, {}), ('sample_puppi', guppi, SAMPLE_PUPPI, {})]
+    for key, mod, path, kw in todo:
+        with mod.open(path, 'rb', **kw) as fh:
+            d = plain(fh.info())
+        d.pop('file_info', None)
+        entry = dict(file=os.path.basename(path), kwargs={k: v for k, v in kw.items()}, file_info=d)
+        if not d.get('missing'):
+            skw = dict(kw)
+            if mod is mark5b:
+                skw['sample_rate'] = 32 * u.MHz
+            if mod is mark4:
+                skw['sample_rate'] = 32 * u.MHz
+            if 'mwa' in key:
+                skw['sample_rate'] = 1.28 * u.MHz
+            if 'arochime' in key:
+                skw['sample_rate'] = 800. / 1024. / 2. * u.MHz
+            if 'bps1' in key:
+                skw['sample_rate'] = 8 * u.MHz
+            try:
+                with mod.open(path, 'rs', **skw) as fs:
+                    sd = plain(fs.info())
+            except Exception as exc:
+                print('no stream info for', key, repr(exc)[:80])
+                out[key] = entry
+                continue
+            sd.pop('file_info', None)
+            entry['stream_info'] = sd
+        out[key] = entry
+    with open(os.path.join(GOLD, 'info_cases.json'), 'w') as f:
+        json.dump(out, f, indent=1, default=str)
+    for k, v in out.items():
+        print(k, v['file_info'])
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1039,7 +1100,7 @@ if __name__ == '__main__':
              ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt),
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
-             ('fixed_corrupt', gen_fixed_corrupt)]
+             ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

@@ -1,0 +1,118 @@
+"""``fh.info`` against the reference's info on the sample files
+(tests/golden/info_cases.json, oracle/gen_golden.py `info`) and the
+readability checks its corrupt-file tests make."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden_path
+
+pytestmark = pytest.mark.gpu
+
+with open(golden_path('info_cases.json')) as _f:
+    INFO = json.load(_f)
+
+MODULE = {'vdif': 'vdif', 'm5b': 'mark5b', 'm4': 'mark4', 'dada': 'dada', 'puppi': 'guppi'}
+STREAM_RATE = {'sample_m5b': 32e6, 'sample_m4': 32e6, 'sample_m4_32': 32e6,
+               'sample_mwa_vdif': 1.28e6, 'sample_arochime_vdif': 800e6 / 1024. / 2.,
+               'sample_bps1_vdif': 8e6}
+
+
+def _module(key):
+    import importlib
+    name = next(v for k, v in MODULE.items() if k in key)
+    return importlib.import_module('baseband_amd.' + name)
+
+
+def _same(mine, ref, key):
+    if key == 'start_time' or key == 'stop_time':
+        return np.datetime64(mine, 'ns') == np.datetime64(ref, 'ns')
+    if isinstance(ref, float):
+        return abs(mine - ref) <= 1e-9 * abs(ref)
+    if isinstance(ref, list):
+        return list(mine) == ref
+    return mine == ref
+
+
+@pytest.mark.parametrize('key', sorted(INFO))
+def test_file_info_matches_reference(key):
+    case = INFO[key]
+    mod = _module(key)
+    ref = case['file_info']
+    with mod.open(golden_path('samples/' + case['file']), 'rb', **case['kwargs']) as fh:
+        info = fh.info
+        mine = info()
+    for name, value in ref.items():
+        if name in ('errors', 'warnings'):
+            assert set(mine.get(name, {})) == set(value), name
+        elif name == 'missing':
+            assert mine['missing'] == value
+        else:
+            assert name in mine, name
+            assert _same(mine[name], value, name), (name, mine[name], value)
+    assert set(mine) - {'errors', 'warnings'} == set(ref) - {'errors', 'warnings'}
+    assert bool(info) and 'information' in repr(info)
+
+
+@pytest.mark.parametrize('key', sorted(k for k in INFO if 'stream_info' in INFO[k]))
+def test_stream_info_matches_reference(key):
+    case = INFO[key]
+    mod = _module(key)
+    ref = case['stream_info']
+    kwargs = dict(case['kwargs'])
+    if key in STREAM_RATE:
+        kwargs['sample_rate'] = STREAM_RATE[key]
+    with mod.open(golden_path('samples/' + case['file']), 'rs', **kwargs) as fh:
+        mine = fh.info()
+        assert fh.info.readable and fh.info.checks['continuous'] == 'no obvious gaps'
+        assert fh.tell() == 0
+    for name, value in ref.items():
+        if name in ('errors', 'warnings'):
+            continue
+        assert name in mine, name
+        if name == 'verify':
+            assert str(mine[name]) == str(value)
+        else:
+            assert _same(mine[name], value, name), (name, mine[name], value)
+    assert not fh.info.readable                      # closed stream
+
+
+def test_info_of_corrupt_streams(tmp_path):
+    """The readability checks of the reference's corrupt-file tests
+    (mark5b/tests/test_corrupt_files.py:100-140,
+    mark4/tests/test_corrupt_files.py:56-80)."""
+    from baseband_amd import mark5b, mark4
+    with open(golden_path('fixed_corrupt_cases.json')) as f:
+        fixed = json.load(f)
+    files = np.load(golden_path('fixed_corrupt_files.npz'))
+    sample = open(golden_path('samples/sample.m5b'), 'rb').read()
+    tail = files['m5b_sample_tail'].tobytes()
+    # first byte of header 2 missing -> frames 1, 2 bad: trouble starts at frame 1
+    for (lo, hi), bad_start in (((20032, 20033), 1), ((20096, 20100), 2), ((30060, 30070), 3)):
+        p = tmp_path / 'c.m5b'
+        p.write_bytes(sample[:lo] + sample[hi:] + tail)
+        with mark5b.open(str(p), 'rs', nchan=8, bps=2, kday=56000, verify=True) as fv:
+            info = fv.info
+            assert not info.readable and not info.checks['continuous']
+            msg = 'While reading at {}'.format(bad_start * fv.samples_per_frame)
+            assert msg in str(info.errors['continuous'])
+            fv.verify = 'fix'
+            info = fv.info
+            assert info.readable and 'fixable' in info.checks['continuous']
+            assert msg in info.warnings['continuous']
+            assert 'problem loading' in info.warnings['continuous']
+            assert fv.tell() == 0
+    fake = files['m4_fake'].tobytes()
+    t0 = np.datetime64('2010-11-12T13:14:15')
+    for (lo, hi), bad_start in (((40000, 80000), 1), ((120000, 200000), 3), ((78000, 82000), 1)):
+        p = tmp_path / 'c.m4'
+        p.write_bytes(fake[:lo] + fake[hi:])
+        with mark4.open(str(p), 'rs', verify=True, sample_rate=100e3, ref_time=t0) as fv:
+            assert not fv.info.readable and not fv.info.checks['continuous']
+            msg = 'While reading at {}'.format(bad_start * fv.samples_per_frame)
+            assert msg in str(fv.info.errors['continuous'])
+        with mark4.open(str(p), 'rs', verify='fix', sample_rate=100e3, ref_time=t0) as ff:
+            assert ff.info.readable and 'fixable' in ff.info.checks['continuous']
+            assert msg in ff.info.warnings['continuous']
+            assert 'problem loading frame' in ff.info.warnings['continuous']
