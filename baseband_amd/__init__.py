@@ -10,17 +10,6 @@ from . import vdif, mark5b, mark4, guppi, dada, gsb
 
 __version__ = '0.1.0'
 
-FORMATS = ('vdif', 'mark5b', 'mark4', 'guppi', 'dada', 'gsb')
+from .io import FORMATS, file_info, open   # noqa: E402,F401
 
-
-def open(name, mode='rs', format=None, **kwargs):
-    """``baseband.open`` look-alike (io/__init__.py:178-231): dispatch to the
-    opener of `format` (required: there is no format auto-detection here)."""
-    if format is None:
-        raise ValueError("pass format=... (one of {}); format auto-detection "
-                         "is outside the decode hot path".format(FORMATS))
-    try:
-        module = globals()[format]
-    except KeyError:
-        raise ValueError("unknown format {!r}".format(format)) from None
-    return module.open(name, mode, **kwargs)
+__all__ = ['FORMATS', 'file_info', 'open', 'vdif', 'mark5b', 'mark4', 'guppi', 'dada', 'gsb']

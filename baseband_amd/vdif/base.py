@@ -48,6 +48,27 @@ class VDIFFileReader(VLBIFileReaderBase):
         return VDIFFrameSet.fromfile(self.fh_raw, thread_ids, edv=edv,
                                      verify=verify)
 
+    def find_header(self):
+        """Header at the current position, accepted only when a header with the
+        same stream invariants sits one frame later (if the file is that
+        long): almost any bytes parse as a VDIF header, so this is the sanity
+        check format detection needs (vdif/file_info.py:24-30)."""
+        pos = self.fh_raw.tell()
+        with self.temporary_offset():
+            header = self.read_header()
+        pattern, mask = header.invariant_pattern()
+        image = self.image()
+        nxt = pos + header.frame_nbytes
+        if header.frame_nbytes < header.nbytes + 4:
+            raise HeaderNotFoundError('could not locate a a nearby frame.')
+        if nxt + header.nbytes <= len(image):
+            words = np.frombuffer(bytes(image[nxt:nxt + header.nbytes]), '<u4')
+            if any((int(w) ^ int(p)) & int(m) for w, p, m in zip(words, pattern, mask)):
+                raise HeaderNotFoundError('could not locate a a nearby frame.')
+        elif nxt != len(image):
+            raise HeaderNotFoundError('could not locate a a nearby frame.')
+        return header
+
     def _header_table(self, header0, offset=0):
         """(nframes, nwords) view of all headers at the fixed frame stride."""
         return strided_header_words(self.image(), header0.frame_nbytes,

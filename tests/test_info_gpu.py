@@ -116,3 +116,53 @@ def test_info_of_corrupt_streams(tmp_path):
             assert ff.info.readable and 'fixable' in ff.info.checks['continuous']
             assert msg in ff.info.warnings['continuous']
             assert 'problem loading frame' in ff.info.warnings['continuous']
+
+
+# ---- format auto-detection (io/__init__.py:99-231) -------------------------
+DETECT = [('samples/sample.vdif', 'vdif', {}), ('samples/sample_mwa.vdif', 'vdif', dict(sample_rate=1.28e6)),
+          ('samples/sample_arochime.vdif', 'vdif', dict(sample_rate=390625.)),
+          ('samples/sample_bps1.vdif', 'vdif', dict(sample_rate=8e6)),
+          ('samples/sample.m5b', 'mark5b', dict(nchan=8, kday=56000)),
+          ('samples/sample.m4', 'mark4', dict(decade=2010)),
+          ('samples/sample_32track.m4', 'mark4', dict(ref_time=np.datetime64('2015-01-01'))),
+          ('samples/sample_16track.m4', 'mark4', dict(decade=2010)),
+          ('samples/sample.dada', 'dada', {}), ('samples/sample_puppi.raw', 'guppi', {})]
+
+
+@pytest.mark.parametrize('path,fmt,kwargs', DETECT)
+def test_format_is_detected_and_file_opens(path, fmt, kwargs):
+    import importlib
+    import baseband_amd
+    info = baseband_amd.file_info(golden_path(path), **kwargs)
+    assert info and info.format == fmt and info.readable
+    assert info.used_kwargs == {k: v for k, v in kwargs.items()}
+    with baseband_amd.open(golden_path(path), 'rs', **kwargs) as fh, \
+            importlib.import_module('baseband_amd.' + fmt).open(golden_path(path), 'rs', **kwargs) as f1:
+        assert type(fh) is type(f1) and fh.shape == f1.shape
+        assert bool((fh.read() == f1.read()).all())
+    with baseband_amd.open(golden_path(path), 'rb', **kwargs) as fb:
+        assert type(fb).__name__.lower().startswith(fmt)
+
+
+def test_detection_reports_missing_and_inconsistent_arguments(tmp_path):
+    import baseband_amd
+    info = baseband_amd.file_info(golden_path('samples/sample.m5b'))
+    assert info.format == 'mark5b' and set(info.missing) == {'nchan', 'kday', 'ref_time'}
+    with pytest.raises(TypeError, match='missing required arguments'):
+        baseband_amd.open(golden_path('samples/sample.m5b'), 'rs')
+    # arguments the format does not take are classified against the file
+    info = baseband_amd.file_info(golden_path('samples/sample.vdif'), nchan=8,
+                                  ref_time=np.datetime64('2014-01-01'), kday=56000, decade=2010)
+    assert info.format == 'vdif' and not info.inconsistent_kwargs
+    assert set(info.consistent_kwargs) == {'nchan', 'ref_time', 'kday', 'decade'}
+    info = baseband_amd.file_info(golden_path('samples/sample.vdif'), nchan=4, decade=2000)
+    assert set(info.inconsistent_kwargs) == {'nchan', 'decade'}
+    with pytest.raises(ValueError, match='inconsistent'):
+        baseband_amd.open(golden_path('samples/sample.vdif'), 'rs', nchan=4)
+    junk = tmp_path / 'junk.bin'
+    junk.write_bytes(np.random.default_rng(1).integers(0, 256, 100000, dtype=np.uint8).tobytes())
+    assert not baseband_amd.file_info(str(junk))
+    with pytest.raises(ValueError, match='could not be auto-determined'):
+        baseband_amd.open(str(junk), 'rs')
+    with pytest.raises(ValueError):
+        baseband_amd.open(str(junk), 'ws', sample_rate=1e6)

@@ -233,8 +233,10 @@ def test_top_level_open(manifest):
     import baseband_amd
     with baseband_amd.open(golden_path('samples/sample.vdif'), 'rs', format='vdif') as fh:
         assert fh.shape == (40000, 8)
+    with baseband_amd.open(golden_path('samples/sample.vdif'), 'rs') as fh:    # auto-detected
+        assert fh.shape == (40000, 8)
     with pytest.raises(ValueError):
-        baseband_amd.open(golden_path('samples/sample.vdif'), 'rs')
+        baseband_amd.open(golden_path('samples/sample.vdif'), 'rs', format='nonsense')
     with pytest.raises(ValueError):
         baseband_amd.vdif.open(golden_path('samples/sample.vdif'), 'xs')
     # an invalid writer call must not touch an existing file
