@@ -109,16 +109,13 @@ class PayloadBase:
 
     @classmethod
     def fromdata(cls, data, header=None, bps=2, **kwargs):
-        """Encode samples as a payload.  Device tensors are packed by the GPU
-        encoders (bb_encode_flat), host arrays by the NumPy twins in
-        `base.encoding` (both bit-identical to the reference encoders)."""
-        on_gpu = isinstance(data, torch.Tensor) and data.is_cuda
-        if isinstance(data, torch.Tensor) and not on_gpu:
-            data = data.numpy()
-        is_complex = data.is_complex() if on_gpu else data.dtype.kind == 'c'
-        encode = cls._encode_device if on_gpu else cls._encode_data
+        """Encode samples as a payload on the GPU (bb_encode_flat; bit-identical
+        to the reference encoders, base/payload.py:141-188).  Host arrays are
+        uploaded first: there is no CPU encoder on this path."""
+        data = kernels.as_device_samples(data)
+        is_complex = data.is_complex()
         if header is None:
-            words = encode(data, bps, **kwargs)
+            words = cls._encode_device(data, bps, **kwargs)
             return cls(words, bps=bps, sample_shape=tuple(data.shape[1:]),
                        complex_data=is_complex)
         if tuple(header.sample_shape) != tuple(data.shape[1:]):
@@ -129,11 +126,7 @@ class PayloadBase:
             kinds = ['complex' if c else 'real'
                      for c in (header.complex_data, is_complex)]
             raise ValueError("header is for {0} data but data are {1}".format(*kinds))
-        return cls(encode(data, header.bps, **kwargs), header=header)
-
-    @classmethod
-    def _encode_data(cls, data, bps, **kwargs):
-        raise ValueError(f"{cls.__name__} cannot encode data")
+        return cls(cls._encode_device(data, header.bps, **kwargs), header=header)
 
     @classmethod
     def _encode_device(cls, data, bps, coder_id=None, **kwargs):

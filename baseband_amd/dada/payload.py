@@ -91,22 +91,21 @@ class DADAPayload(PayloadBase):
 
     @classmethod
     def fromdata(cls, data, header=None, bps=8):
-        if isinstance(data, torch.Tensor):
-            data = data.cpu().numpy()
-        data = np.asarray(data)
-        if data.dtype.kind == 'c':
-            comp = np.ascontiguousarray(data.astype(np.complex64)).view(np.float32)
-        else:
-            comp = data.astype(np.float32)
-        b = np.clip(np.rint(comp), -128, 127).astype(np.int8)
+        """(nsample, npol, nchan) samples -> int8 words (dada/payload.py:17-18,
+        80-89), rounded, clipped and packed by the GPU int8 encoder; MKBF
+        headers get the (heap, pol, chan, 256, re/im) heap order."""
+        data = kernels.as_device_samples(data)
+        if (bps if header is None else header.bps) != 8:
+            raise ValueError(f"{cls.__name__} cannot encode data with {bps} bits")
+        comp = torch.view_as_real(data) if data.is_complex() else data
         if header is not None and header.get("INSTRUMENT") == "MKBF":
             npol, nchan = header.sample_shape
-            b = np.moveaxis(b.reshape(-1, 256, npol, nchan, 2), 1, 3)
-        words = np.ascontiguousarray(b).reshape(-1).view(np.uint8)
+            comp = comp.reshape(-1, 256, npol, nchan, 2).movedim(1, 3)
+        words = kernels.encode_flat(comp, _lib.CODER_INT, 8).cpu().numpy()
         if header is not None:
             return cls(words, header=header)
-        return cls(words, sample_shape=data.shape[1:], bps=bps,
-                   complex_data=data.dtype.kind == 'c')
+        return cls(words, sample_shape=tuple(data.shape[1:]), bps=bps,
+                   complex_data=data.is_complex())
 
 
 class MKBFPayload(DADAPayload):

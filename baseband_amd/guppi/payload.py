@@ -27,16 +27,22 @@ class GUPPIPayload(PayloadBase):
 
     @classmethod
     def fromdata(cls, data, header=None, bps=8, channels_first=True):
-        if isinstance(data, torch.Tensor):
-            data = data.cpu().numpy()
+        """(nsample, npol, nchan) samples -> int8 words in the on-disk order
+        (guppi/payload.py:64-84): rounded, clipped and packed by the GPU int8
+        encoder after the storage-order permutation."""
+        data = kernels.as_device_samples(data)
         if header is not None:
             bps, channels_first = header.bps, header.channels_first
-        words = encode_guppi(data, channels_first)
+        if bps != 8:
+            raise ValueError(f"{cls.__name__} cannot encode data with {bps} bits")
+        comp = torch.view_as_real(data) if data.is_complex() else data.unsqueeze(-1)
+        # (time, pol, chan, comp) -> (chan, time, pol, comp) or (time, chan, pol, comp)
+        comp = comp.permute(2, 0, 1, 3) if channels_first else comp.permute(0, 2, 1, 3)
+        words = kernels.encode_flat(comp, _lib.CODER_INT, 8).cpu().numpy().view(np.int8)
         if header is not None:
             return cls(words, header=header)
-        return cls(words, sample_shape=data.shape[1:], bps=bps,
-                   complex_data=data.dtype.kind == 'c',
-                   channels_first=channels_first)
+        return cls(words, sample_shape=tuple(data.shape[1:]), bps=bps,
+                   complex_data=data.is_complex(), channels_first=channels_first)
 
     def _decode_rows(self, start, stop):
         """Rows [start, stop) -> (n, npol, nchan) device tensor."""
@@ -92,19 +98,3 @@ class GUPPIPayload(PayloadBase):
         return data
 
     data = property(__getitem__, doc="Full decoded payload (device tensor).")
-
-
-def encode_guppi(data, channels_first=True):
-    """(nsample, npol, nchan) -> int8 words in the on-disk order
-    (guppi/payload.py:112-133 inverse of _decode)."""
-    data = np.asarray(data)
-    if data.dtype.kind == 'c':
-        comp = np.ascontiguousarray(data.astype(np.complex64)).view(np.float32).reshape(data.shape + (2,))
-    else:
-        comp = data.astype(np.float32)[..., np.newaxis]
-    b = np.clip(np.rint(comp), -128, 127).astype(np.int8)
-    if channels_first:
-        b = b.transpose(2, 0, 1, 3)         # (nchan, nsample, npol, ncomp)
-    else:
-        b = b.transpose(0, 2, 1, 3)         # (nsample, nchan, npol, ncomp)
-    return np.ascontiguousarray(b).reshape(-1)

@@ -272,6 +272,16 @@ def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
     return out
 
 
+def as_device_samples(data):
+    """Samples to encode -> float32 / complex64 tensor on the GPU (NumPy
+    arrays and host tensors are uploaded)."""
+    require_gpu()
+    if not isinstance(data, torch.Tensor):
+        data = torch.from_numpy(np.ascontiguousarray(data))
+    want = torch.complex64 if data.is_complex() else torch.float32
+    return data.to(device='cuda', dtype=want)
+
+
 def encode_flat(values, coder, bps):
     """float32 (or complex64) device tensor -> packed uint8 device tensor."""
     require_gpu()

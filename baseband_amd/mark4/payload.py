@@ -13,7 +13,6 @@ import torch
 
 from .. import kernels
 from ..base.payload import PayloadBase
-from ..base import encoding as enc
 from .header import MARK4_DTYPES
 from ._bitmaps import BITMAPS
 
@@ -65,39 +64,15 @@ class Mark4Payload(PayloadBase):
 
     @classmethod
     def fromdata(cls, data, header):
-        """Encode (nsample, nchan) data with the header's track layout."""
-        on_gpu = isinstance(data, torch.Tensor) and data.is_cuda
-        if isinstance(data, torch.Tensor) and not on_gpu:
-            data = data.numpy()
-        if (data.is_complex() if on_gpu else data.dtype.kind == 'c'):
+        """Encode (nsample, nchan) data with the header's track layout on the
+        GPU (bb_encode_mark4; mark4/payload.py:138-300)."""
+        data = kernels.as_device_samples(data)
+        if data.is_complex():
             raise ValueError("Mark4 format does not support complex data.")
         if tuple(header.sample_shape) != tuple(data.shape[1:]):
             raise ValueError("header is for {0} channels but data has {1}"
                              .format(header.nchan, data.shape[-1]))
-        if on_gpu:
-            key = (header.nchan, header.magnitude_signature() or header.bps, header.fanout)
-            maps = BITMAPS[key]
-            words = kernels.encode_mark4(data, header.ntrack, maps['sign_bit'],
-                                         maps['mag_bit']).cpu().numpy().view(header.stream_dtype)
-        else:
-            words = encode_mark4(data, header)
-        return cls(words, header)
-
-
-def encode_mark4(data, header):
-    """float data (nsample, nchan) -> stream words, inverse of the bit maps:
-    2-bit code = 2*sign + magnitude with levels {-Hi,-1,+1,+Hi}."""
-    key = (header.nchan, header.magnitude_signature() or header.bps, header.fanout)
-    maps = BITMAPS[key]
-    ntrack = maps['ntrack']
-    dtype = np.dtype(MARK4_DTYPES[ntrack])
-    codes = enc.codes_2bit(np.asarray(data, dtype=np.float32))
-    opw = ntrack // 2
-    codes = codes.reshape(-1, opw).astype(np.uint64)
-    sign = (codes >> np.uint64(1)) & np.uint64(1)
-    mag = codes & np.uint64(1)
-    words = np.zeros(codes.shape[0], dtype=np.uint64)
-    for j in range(opw):
-        words |= sign[:, j] << np.uint64(maps['sign_bit'][j])
-        words |= mag[:, j] << np.uint64(maps['mag_bit'][j])
-    return words.astype(dtype)
+        key = (header.nchan, header.magnitude_signature() or header.bps, header.fanout)
+        maps = BITMAPS[key]
+        words = kernels.encode_mark4(data, header.ntrack, maps['sign_bit'], maps['mag_bit'])
+        return cls(words.cpu().numpy().view(header.stream_dtype), header)

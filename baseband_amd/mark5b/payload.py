@@ -6,21 +6,8 @@ import numpy as np
 
 from .. import _lib
 from ..base.payload import PayloadBase
-from ..base import encoding as enc
 
-__all__ = ['Mark5BPayload', 'encode_mark5b']
-
-
-def encode_mark5b(comp, bps):
-    """float32 components -> packed bytes.  2-bit codes are re-ordered so
-    that the sign sits on the even and the magnitude on the odd bit stream
-    (mark5b/payload.py:97-106); 1 bit stores the sign bit."""
-    if bps == 1:
-        return enc.pack_codes(np.signbit(np.asarray(comp)).astype(np.uint8), 1)
-    if bps == 2:
-        reorder = np.array([0, 2, 1, 3], dtype=np.uint8)
-        return enc.pack_codes(reorder[enc.codes_2bit(comp)], 2)
-    raise ValueError(f"Mark5BPayload cannot encode data with {bps} bits")
+__all__ = ['Mark5BPayload']
 
 
 class Mark5BPayload(PayloadBase):
@@ -41,12 +28,11 @@ class Mark5BPayload(PayloadBase):
         return super()._decode(byte_start, byte_stop)
 
     @classmethod
-    def _encode_data(cls, data, bps, **kwargs):
-        return encode_mark5b(enc.components(data), bps).view('<u4')
-
-    @classmethod
     def fromdata(cls, data, header=None, bps=2):
-        if data.dtype.kind == 'c':
+        """Pack (nsample, nchan) samples on the GPU (Mark 5B coder)."""
+        from .. import kernels
+        data = kernels.as_device_samples(data)
+        if data.is_complex():
             raise ValueError("Mark5B format does not support complex data.")
-        words = cls._encode_data(np.asarray(data), bps)
-        return cls(words, sample_shape=data.shape[1:], bps=bps)
+        words = cls._encode_device(data, bps)
+        return cls(words, sample_shape=tuple(data.shape[1:]), bps=bps)

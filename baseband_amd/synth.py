@@ -8,7 +8,7 @@ writers (tests/golden/synth/*.bin, see tests/test_host_logic.py).
 import numpy as np
 
 from .vdif.header import VDIFHeader
-from .base import encoding as enc
+from . import synth_codes as enc
 
 
 def vdif_frame_headers(header0, nsets, thread_ids, frame_rate,
@@ -74,8 +74,7 @@ def encode_vdif_stream(data, header0, frame_rate, thread_ids=None,
         data.reshape(nsets, spf, nthread, nchan).transpose(0, 2, 1, 3)))
     bps = header0.bps
     if header0.edv == 0xab:
-        from .mark5b.payload import encode_mark5b
-        packed = encode_mark5b(comp, bps)
+        packed = enc.encode_mark5b(comp, bps)
     else:
         codes = {1: enc.codes_1bit, 2: enc.codes_2bit, 4: enc.codes_4bit,
                  8: enc.codes_8bit}[bps](comp)
@@ -129,7 +128,7 @@ def encode_mark4_stream(data, header0, frame_rate):
     """(nsample, nchan) data -> Mark 4 file image: each frame's first
     160*fanout samples are dropped (overwritten by the header), as the
     reference's writer does (mark4/frame.py:139-141)."""
-    from .mark4.payload import encode_mark4
+    encode_mark4 = enc.encode_mark4
     data = np.asarray(data)
     spf = header0.samples_per_frame
     nframes = data.shape[0] // spf

@@ -109,13 +109,13 @@ class VDIFFrameSet:
     def fromdata(cls, data, headers=None, verify=True, **kwargs):
         """Encode (samples_per_frame, nthread, nchan) data as one frame per
         thread (vdif/frame.py:250-311)."""
-        if isinstance(data, torch.Tensor):
-            data = data.cpu().numpy()
+        from .. import kernels
+        data = kernels.as_device_samples(data)          # threads are encoded on the GPU
         nthread = data.shape[1]
         if headers is None:
             kwargs.setdefault('thread_id', 0)
             headers = VDIFHeader.fromvalues(
-                complex_data=(data.dtype.kind == 'c'), verify=verify, **kwargs)
+                complex_data=data.is_complex(), verify=verify, **kwargs)
         if isinstance(headers, VDIFHeader):
             header0 = headers
             headers = []

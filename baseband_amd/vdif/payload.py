@@ -11,7 +11,6 @@ import numpy as np
 
 from .. import _lib
 from ..base.payload import PayloadBase
-from ..base import encoding as enc
 
 __all__ = ['VDIFPayload']
 
@@ -46,19 +45,6 @@ class VDIFPayload(PayloadBase):
         return super()._decode(byte_start, byte_stop)
 
     @classmethod
-    def _encode_data(cls, data, bps, edv=None, **kwargs):
-        comp = enc.components(data)
-        if edv == 0xab:
-            from ..mark5b.payload import encode_mark5b
-            return encode_mark5b(comp, bps).view('<u4')
-        try:
-            codes = {1: enc.codes_1bit, 2: enc.codes_2bit, 4: enc.codes_4bit,
-                     8: enc.codes_8bit}[bps](comp)
-        except KeyError:
-            raise ValueError(f"{cls.__name__} cannot encode data with {bps} bits") from None
-        return enc.pack_codes(codes, bps).view('<u4')
-
-    @classmethod
     def _encode_device(cls, data, bps, edv=None, **kwargs):
         coder = _lib.CODER_MARK5B if edv == 0xab else _lib.CODER_VDIF
         return super()._encode_device(data, bps, coder_id=coder)
@@ -67,11 +53,11 @@ class VDIFPayload(PayloadBase):
     def fromdata(cls, data, header=None, bps=2, edv=None):
         if header is not None:
             edv = header.edv
-        if edv == 0xab:
-            import torch
+        if edv == 0xab:                                     # Mark 5B payload in a VDIF frame
+            from .. import kernels
+            data = kernels.as_device_samples(data)
             bps = bps if header is None else header.bps
-            on_gpu = isinstance(data, torch.Tensor) and data.is_cuda
-            words = (cls._encode_device if on_gpu else cls._encode_data)(data, bps, edv=edv)
+            words = cls._encode_device(data, bps, edv=edv)
             return cls(words, header, sample_shape=tuple(data.shape[1:]), bps=bps,
                        complex_data=False)
         return super().fromdata(data, header=header, bps=bps)

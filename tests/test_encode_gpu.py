@@ -247,8 +247,9 @@ def test_mark4_stream_writer_is_byte_identical_to_reference(manifest, name):
 
 
 def test_payload_fromdata_on_device_roundtrip(manifest):
-    """Payload.fromdata with device tensors uses the GPU encoders; words are
-    identical to the host (NumPy) encoders and decode back to the data."""
+    """Payload.fromdata packs on the GPU whether the samples come as device
+    tensors or as host arrays (uploaded first); the words equal what the
+    input-synthesis encoders of synth_codes produce and decode back to the data."""
     import torch
     from conftest import load_expected
     from baseband_amd.vdif import VDIFPayload, VDIFHeader
@@ -258,6 +259,9 @@ def test_payload_fromdata_on_device_roundtrip(manifest):
     dev = VDIFPayload.fromdata(torch.from_numpy(data).cuda(), header=h)
     host = VDIFPayload.fromdata(data, header=h)
     assert dev == host and np.array_equal(dev.words, host.words)
+    from baseband_amd import synth_codes
+    want = synth_codes.pack_codes(synth_codes.codes_2bit(synth_codes.components(data)), 2)
+    assert np.array_equal(dev.words.view(np.uint8), want)
     assert bits_equal(dev.data.cpu().numpy(), data)
     pl = VDIFPayload.fromdata(torch.from_numpy(data.real.copy()).cuda(), bps=4)
     assert pl.shape == (1000, 16) and pl.bps == 4
@@ -268,7 +272,18 @@ def test_payload_fromdata_on_device_roundtrip(manifest):
     pd = Mark4Payload.fromdata(torch.from_numpy(body).cuda(), h4)
     ph = Mark4Payload.fromdata(body, h4)
     assert np.array_equal(pd.words, ph.words)
+    assert np.array_equal(pd.words, synth_codes.encode_mark4(body, h4))
     assert bits_equal(pd.data.cpu().numpy(), body)
+    # the block formats too: GUPPI storage orders, DADA / MKBF
+    from baseband_amd.guppi import GUPPIPayload
+    from baseband_amd.dada import DADAPayload
+    rng = np.random.default_rng(8)
+    z = (rng.integers(-128, 128, (64, 2, 4)) + 1j * rng.integers(-128, 128, (64, 2, 4))).astype(np.complex64)
+    for cf in (True, False):
+        gp = GUPPIPayload.fromdata(z, bps=8, channels_first=cf)
+        assert gp.words.dtype == np.int8 and bits_equal(gp.data.cpu().numpy(), z)
+    dp = DADAPayload.fromdata(z[:, :, :1] + np.complex64(0.3 - 0.3j), bps=8)   # rounds back
+    assert bits_equal(dp.data.cpu().numpy(), z[:, :, :1])
     with pytest.raises(ValueError):
         VDIFPayload.fromdata(torch.zeros(8, 1, device='cuda'), bps=3)
 

@@ -12,8 +12,8 @@ from baseband_amd import vdif, mark5b, synth
 from baseband_amd.vdif.header import VDIFHeader, ref_epoch_time
 from baseband_amd.vdif.payload import VDIFPayload
 from baseband_amd.mark5b.header import Mark5BHeader, crc16_mark5b
-from baseband_amd.mark5b.payload import encode_mark5b
-from baseband_amd.base import encoding as enc
+from baseband_amd.synth_codes import encode_mark5b
+from baseband_amd import synth_codes as enc
 
 
 def test_vdif_header_fields_sample(manifest):
