@@ -2,7 +2,7 @@
 from .header import DADAHeader
 from .payload import DADAPayload, MKBFPayload
 from .frame import DADAFrame
-from .base import DADAFileReader, DADAStreamReader, DADAStreamWriter, DADAFileNameSequencer, open
+from .base import DADAFileWriter, DADAFileReader, DADAStreamReader, DADAStreamWriter, DADAFileNameSequencer, open
 
-__all__ = ['DADAStreamWriter', 'DADAFileNameSequencer', 'DADAHeader', 'DADAPayload', 'MKBFPayload', 'DADAFrame',
+__all__ = ['DADAFileWriter', 'DADAStreamWriter', 'DADAFileNameSequencer', 'DADAHeader', 'DADAPayload', 'MKBFPayload', 'DADAFrame',
            'DADAFileReader', 'DADAStreamReader', 'open']

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from .. import _lib, kernels
-from ..base.base import VLBIFileReaderBase
+from ..base.base import FileBase, VLBIFileReaderBase
 from ..base.blockreader import BlockStreamReader
 from ..base.opener import FormatOpener
 from ..base.writer import BlockStreamWriter
@@ -16,7 +16,7 @@ from .payload import DADAPayload, decode_i8_rows
 from .frame import DADAFrame
 
 __all__ = ['DADAFileNameSequencer', 'DADAFileReader', 'DADAStreamReader',
-           'DADAStreamWriter', 'open']
+           'DADAStreamWriter', 'open', 'DADAFileWriter']
 
 
 class DADAFileNameSequencer(UpperCaseSequencer):
@@ -52,6 +52,17 @@ class DADAFileReader(VLBIFileReaderBase):
         with self.temporary_offset(0):
             header = self.read_header()
         return header.sample_rate / header.samples_per_frame
+
+
+class DADAFileWriter(FileBase):
+    """Frame-level writer (dada/base.py): header + payload packed on the GPU."""
+
+    def write_frame(self, data, header=None, **kwargs):
+        if not isinstance(data, DADAFrame):
+            if header is None:
+                header = DADAHeader.fromvalues(**kwargs)
+            data = DADAFrame.fromdata(data, header)
+        return data.tofile(self.fh_raw)
 
 
 class DADAStreamReader(BlockStreamReader):
@@ -173,7 +184,8 @@ class _DADAOpener(FormatOpener):
         return fns
 
 
-open = _DADAOpener('DADA', {'rb': DADAFileReader, 'rs': DADAStreamReader,
+open = _DADAOpener('DADA', {'rb': DADAFileReader, 'wb': DADAFileWriter,
+                            'rs': DADAStreamReader,
                             'ws': DADAStreamWriter},
                    sequencer=DADAFileNameSequencer,
                    default_file_size=lambda header0: header0.frame_nbytes)

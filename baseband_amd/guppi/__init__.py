@@ -2,7 +2,7 @@
 from .header import GUPPIHeader
 from .payload import GUPPIPayload
 from .frame import GUPPIFrame
-from .base import GUPPIFileReader, GUPPIStreamReader, GUPPIStreamWriter, GUPPIFileNameSequencer, open
+from .base import GUPPIFileWriter, GUPPIFileReader, GUPPIStreamReader, GUPPIStreamWriter, GUPPIFileNameSequencer, open
 
-__all__ = ['GUPPIStreamWriter', 'GUPPIFileNameSequencer', 'GUPPIHeader', 'GUPPIPayload', 'GUPPIFrame', 'GUPPIFileReader',
+__all__ = ['GUPPIFileWriter', 'GUPPIStreamWriter', 'GUPPIFileNameSequencer', 'GUPPIHeader', 'GUPPIPayload', 'GUPPIFrame', 'GUPPIFileReader',
            'GUPPIStreamReader', 'open']

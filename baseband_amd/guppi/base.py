@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from .. import _lib, kernels
-from ..base.base import VLBIFileReaderBase
+from ..base.base import FileBase, VLBIFileReaderBase
 from ..base.blockreader import BlockStreamReader
 from ..base.opener import FormatOpener
 from ..base.writer import BlockStreamWriter
@@ -15,7 +15,7 @@ from .payload import GUPPIPayload
 from .frame import GUPPIFrame
 
 __all__ = ['GUPPIFileNameSequencer', 'GUPPIFileReader', 'GUPPIStreamReader',
-           'GUPPIStreamWriter', 'open']
+           'GUPPIStreamWriter', 'open', 'GUPPIFileWriter']
 
 # template fields are matched to the (upper-case) header keys ignoring case
 # (guppi/base.py:23-85)
@@ -38,6 +38,17 @@ class GUPPIFileReader(VLBIFileReaderBase):
         with self.temporary_offset(0):
             header = self.read_header()
         return header.sample_rate / (header.samples_per_frame - header.overlap)
+
+
+class GUPPIFileWriter(FileBase):
+    """Frame-level writer (guppi/base.py): header + payload packed on the GPU."""
+
+    def write_frame(self, data, header=None, **kwargs):
+        if not isinstance(data, GUPPIFrame):
+            if header is None:
+                header = GUPPIHeader.fromvalues(**kwargs)
+            data = GUPPIFrame.fromdata(data, header)
+        return data.tofile(self.fh_raw)
 
 
 class GUPPIStreamReader(BlockStreamReader):
@@ -148,7 +159,8 @@ class _GUPPIOpener(FormatOpener):
         return super().__call__(name, mode, **kwargs)
 
 
-open = _GUPPIOpener('GUPPI', {'rb': GUPPIFileReader, 'rs': GUPPIStreamReader,
+open = _GUPPIOpener('GUPPI', {'rb': GUPPIFileReader, 'wb': GUPPIFileWriter,
+                            'rs': GUPPIStreamReader,
                               'ws': GUPPIStreamWriter},
                     sequencer=GUPPIFileNameSequencer)
 open.__doc__ = """Open GUPPI raw file(s) (guppi/base.py:305-396): ``'rb'``, ``'rs'`` or

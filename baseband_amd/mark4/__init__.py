@@ -2,7 +2,7 @@
 from .header import Mark4Header
 from .payload import Mark4Payload
 from .frame import Mark4Frame
-from .base import Mark4FileReader, Mark4StreamReader, open
+from .base import Mark4StreamWriter, Mark4FileWriter, Mark4FileReader, Mark4StreamReader, open
 
-__all__ = ['Mark4Header', 'Mark4Payload', 'Mark4Frame', 'Mark4FileReader',
+__all__ = ['Mark4StreamWriter', 'Mark4FileWriter', 'Mark4Header', 'Mark4Payload', 'Mark4Frame', 'Mark4FileReader',
            'Mark4StreamReader', 'open']

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import _lib, kernels
-from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
+from ..base.base import (FileBase, VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
 from .header import Mark4Header, MARK4_DTYPES, stream2words
 from .payload import Mark4Payload
@@ -22,7 +22,7 @@ from ._bitmaps import BITMAPS
 from ..base.writer import GPUStreamWriterBase
 from ..base.opener import FormatOpener
 
-__all__ = ['Mark4FileReader', 'Mark4StreamReader', 'Mark4StreamWriter', 'open']
+__all__ = ['Mark4FileReader', 'Mark4StreamReader', 'Mark4StreamWriter', 'open', 'Mark4FileWriter']
 
 
 class Mark4FileReader(VLBIFileReaderBase):
@@ -141,6 +141,17 @@ class Mark4FileReader(VLBIFileReaderBase):
             header1 = self.read_header()
         tdelta = (header1.fraction[0] - header0.fraction[0]) % 1.
         return float(np.round(1. / tdelta))
+
+
+class Mark4FileWriter(FileBase):
+    """Frame-level writer (mark4/base.py:210-232)."""
+
+    def write_frame(self, data, header=None, **kwargs):
+        if not isinstance(data, Mark4Frame):
+            if header is None:
+                header = Mark4Header.fromvalues(**kwargs)
+            data = Mark4Frame.fromdata(data, header)
+        return data.tofile(self.fh_raw)
 
 
 class Mark4StreamReader(GPUStreamReaderBase):
@@ -306,7 +317,8 @@ class Mark4StreamWriter(GPUStreamWriterBase):
         self.fh_raw.write(frames.tobytes())
 
 
-open = FormatOpener('Mark4', {'rb': Mark4FileReader, 'rs': Mark4StreamReader,
+open = FormatOpener('Mark4', {'rb': Mark4FileReader, 'wb': Mark4FileWriter,
+                              'rs': Mark4StreamReader,
                               'ws': Mark4StreamWriter})
 open.__doc__ = """Open Mark 4 file(s): ``'rb'`` -> `Mark4FileReader`, ``'rs'`` ->
 `Mark4StreamReader`, ``'ws'`` -> `Mark4StreamWriter` (mark4/base.py:337-430);

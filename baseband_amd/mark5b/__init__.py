@@ -2,7 +2,7 @@
 from .header import Mark5BHeader
 from .payload import Mark5BPayload
 from .frame import Mark5BFrame
-from .base import Mark5BFileReader, Mark5BStreamReader, open
+from .base import Mark5BStreamWriter, Mark5BFileWriter, Mark5BFileReader, Mark5BStreamReader, open
 
-__all__ = ['Mark5BHeader', 'Mark5BPayload', 'Mark5BFrame',
+__all__ = ['Mark5BStreamWriter', 'Mark5BFileWriter', 'Mark5BHeader', 'Mark5BPayload', 'Mark5BFrame',
            'Mark5BFileReader', 'Mark5BStreamReader', 'open']

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .. import _lib, kernels
-from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
+from ..base.base import (FileBase, VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
 from ..base.header import strided_header_words
 from .header import Mark5BHeader, crc16_mark5b
@@ -20,7 +20,8 @@ from .frame import Mark5BFrame
 from ..base.writer import GPUStreamWriterBase
 from ..base.opener import FormatOpener
 
-__all__ = ['Mark5BFileReader', 'Mark5BStreamReader', 'Mark5BStreamWriter', 'open']
+__all__ = ['Mark5BFileReader', 'Mark5BFileWriter', 'Mark5BStreamReader',
+           'Mark5BStreamWriter', 'open']
 
 FRAME_NBYTES = 10016
 SYNC = 0xABADDEED
@@ -134,6 +135,15 @@ class Mark5BFileReader(VLBIFileReaderBase):
                 return int(round(1. / tdelta))
         raise EOFError("file contains less than one second of data and the "
                        "first two headers do not give a time step.")
+
+
+class Mark5BFileWriter(FileBase):
+    """Frame-level writer (mark5b/base.py:158-186)."""
+
+    def write_frame(self, data, header=None, bps=2, valid=True, **kwargs):
+        if not isinstance(data, Mark5BFrame):
+            data = Mark5BFrame.fromdata(data, header, bps=bps, valid=valid, **kwargs)
+        return data.tofile(self.fh_raw)
 
 
 class Mark5BStreamReader(GPUStreamReaderBase):
@@ -288,7 +298,8 @@ class Mark5BStreamWriter(GPUStreamWriterBase):
         self.fh_raw.write(out.tobytes())
 
 
-open = FormatOpener('Mark5B', {'rb': Mark5BFileReader, 'rs': Mark5BStreamReader,
+open = FormatOpener('Mark5B', {'rb': Mark5BFileReader, 'wb': Mark5BFileWriter,
+                               'rs': Mark5BStreamReader,
                                'ws': Mark5BStreamWriter})
 open.__doc__ = """Open Mark 5B file(s): ``'rb'`` -> `Mark5BFileReader`, ``'rs'`` ->
 `Mark5BStreamReader`, ``'ws'`` -> `Mark5BStreamWriter` (mark5b/base.py:356-428);

@@ -29,3 +29,20 @@ class Mark5BFrame(FrameBase):
                                        verify=verify)
         payload = Mark5BPayload.fromfile(fh, sample_shape=sample_shape, bps=bps)
         return cls(header, payload, valid, verify)
+
+    @classmethod
+    def fromdata(cls, data, header=None, bps=2, valid=True, verify=True, **kwargs):
+        """Frame from (nsample, nchan) samples, packed on the GPU; without a
+        header the keywords make one (mark5b/frame.py:102-124)."""
+        if header is None:
+            header = Mark5BHeader.fromvalues(verify=verify, **kwargs)
+        return cls(header, Mark5BPayload.fromdata(data, bps=bps), valid=valid, verify=verify)
+
+    def tofile(self, fh):
+        """Header, then the payload -- or the fill pattern when the frame is
+        not valid (mark5b/frame.py:126-133)."""
+        import numpy as np
+        self.header.tofile(fh)
+        if self.valid:
+            return self.payload.tofile(fh)
+        return fh.write(np.full_like(self.payload.words, self._fill_pattern).tobytes())

@@ -2,7 +2,7 @@
 from .header import VDIFHeader
 from .payload import VDIFPayload
 from .frame import VDIFFrame, VDIFFrameSet
-from .base import VDIFFileReader, VDIFStreamReader, open
+from .base import VDIFStreamWriter, VDIFFileWriter, VDIFFileReader, VDIFStreamReader, open
 
-__all__ = ['VDIFHeader', 'VDIFPayload', 'VDIFFrame', 'VDIFFrameSet',
+__all__ = ['VDIFStreamWriter', 'VDIFFileWriter', 'VDIFHeader', 'VDIFPayload', 'VDIFFrame', 'VDIFFrameSet',
            'VDIFFileReader', 'VDIFStreamReader', 'open']

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .. import _lib, kernels
-from ..base.base import (VLBIFileReaderBase, GPUStreamReaderBase,
+from ..base.base import (FileBase, VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
 from ..base.writer import GPUStreamWriterBase
 from ..base.opener import FormatOpener
@@ -21,7 +21,8 @@ from ..base.header import strided_header_words
 from .header import VDIFHeader
 from .frame import VDIFFrame, VDIFFrameSet
 
-__all__ = ['VDIFFileReader', 'VDIFStreamReader', 'VDIFStreamWriter', 'open']
+__all__ = ['VDIFFileReader', 'VDIFFileWriter', 'VDIFStreamReader', 'VDIFStreamWriter',
+           'open']
 
 
 class VDIFFileReader(VLBIFileReaderBase):
@@ -118,6 +119,21 @@ class VDIFFileReader(VLBIFileReaderBase):
                 k += 1
             n_check = check if len(seen) > n0 else n_check - 1
         return sorted(seen)
+
+
+class VDIFFileWriter(FileBase):
+    """Frame-level writer (vdif/base.py:318-363): samples are packed on the
+    GPU by ``VDIFFrame.fromdata`` / ``VDIFFrameSet.fromdata``."""
+
+    def write_frame(self, data, header=None, **kwargs):
+        if not isinstance(data, VDIFFrame):
+            data = VDIFFrame.fromdata(data, header, **kwargs)
+        return data.tofile(self.fh_raw)
+
+    def write_frameset(self, data, header=None, **kwargs):
+        if not isinstance(data, VDIFFrameSet):
+            data = VDIFFrameSet.fromdata(data, header, **kwargs)
+        return data.tofile(self.fh_raw)
 
 
 class VDIFStreamReader(GPUStreamReaderBase):
@@ -438,7 +454,7 @@ class VDIFStreamWriter(GPUStreamWriterBase):
         self.fh_raw.write(image.tobytes())
 
 
-open = FormatOpener('VDIF', {'rb': VDIFFileReader, 'rs': VDIFStreamReader,
+open = FormatOpener('VDIF', {'rb': VDIFFileReader, 'wb': VDIFFileWriter, 'rs': VDIFStreamReader,
                              'ws': VDIFStreamWriter})
 open.__doc__ = """Open VDIF file(s): ``'rb'`` gives a `VDIFFileReader`, ``'rs'`` a
 `VDIFStreamReader`, ``'ws'`` a `VDIFStreamWriter` (vdif/base.py:810-884).
