@@ -127,6 +127,9 @@ class GPUStreamWriterBase:
             self._nframes_written += 1
             self._pending, self._npending = [], 0
         self._closed = True
+        self._close_files()
+
+    def _close_files(self):
         self.fh_raw.close()
 
     def __enter__(self):

@@ -2,6 +2,7 @@
 from .header import GSBHeader
 from .payload import GSBPayload
 from .frame import GSBFrame
-from .base import GSBStreamReader, open
+from .base import GSBStreamReader, GSBStreamWriter, open
 
-__all__ = ['GSBHeader', 'GSBPayload', 'GSBFrame', 'GSBStreamReader', 'open']
+__all__ = ['GSBHeader', 'GSBPayload', 'GSBFrame', 'GSBStreamReader',
+           'GSBStreamWriter', 'open']

@@ -15,12 +15,13 @@ import torch
 
 from .. import _lib, kernels
 from ..base.base import GPUStreamReaderBase
+from ..base.writer import GPUStreamWriterBase, LazyWriteFile
 from ..staging import host_image
 from .header import GSBHeader
 from .payload import GSBPayload
 from .frame import GSBFrame
 
-__all__ = ['GSBStreamReader', 'open']
+__all__ = ['GSBStreamReader', 'GSBStreamWriter', 'open']
 
 DEFAULT_FRAME_RATE = 1e8 / 6 / 2 ** 22          # Hz (gsb/base.py:170)
 
@@ -139,18 +140,134 @@ class GSBStreamReader(GPUStreamReaderBase):
                             + tuple(self._unsliced_shape))
 
 
+class GSBStreamWriter(GPUStreamWriterBase):
+    """GSB stream writer (gsb/base.py:388-457): one timestamp line per frame
+    to `fh_ts`; samples are rounded / clipped / packed on the GPU (signed
+    4-bit nibbles for rawdump, int8 pairs for phased) and written to one raw
+    file (rawdump) or to ``fh_raw[pol][part]`` (phased: parts are consecutive
+    in time).  Arguments and defaults as for the reader."""
+
+    def __init__(self, fh_ts, fh_raw, header0=None, sample_rate=None,
+                 samples_per_frame=None, payload_nbytes=None, nchan=None, bps=None,
+                 complex_data=None, squeeze=True, mode=None, **kwargs):
+        if header0 is None:
+            header0 = GSBHeader.fromvalues(mode, **kwargs)
+        elif kwargs:
+            raise TypeError("got unexpected arguments {}".format(sorted(kwargs)))
+        self.fh_ts = fh_ts
+        rawdump = header0.mode == 'rawdump'
+        if isinstance(fh_raw, (tuple, list)):
+            assert not rawdump
+            for pair in fh_raw:
+                assert isinstance(pair, (tuple, list)) and len(pair) == len(fh_raw[0])
+        elif not rawdump:
+            fh_raw = ((fh_raw,),)
+        complex_data = (not rawdump) if complex_data is None else complex_data
+        bps = bps if bps is not None else (4 if rawdump else 8)
+        nchan = nchan if nchan is not None else (1 if rawdump else 512)
+        bpfs = bps * nchan * (2 if complex_data else 1)
+        nfiles = 1 if rawdump else len(fh_raw[0])
+        if payload_nbytes is None:
+            if samples_per_frame is not None:
+                payload_nbytes = samples_per_frame * bpfs // (8 * nfiles)
+            elif sample_rate is None:
+                payload_nbytes = 2 ** 22
+            else:
+                payload_nbytes = int(round(sample_rate / DEFAULT_FRAME_RATE * bpfs / 8 / nfiles))
+        if samples_per_frame is None:
+            samples_per_frame = payload_nbytes * 8 // bpfs * nfiles
+        elif samples_per_frame != payload_nbytes * nfiles * 8 / bpfs:
+            raise ValueError('inconsistent samples_per_frame, bps, '
+                             'complex_data, and payload_nbytes')
+        if sample_rate is None:
+            sample_rate = samples_per_frame * DEFAULT_FRAME_RATE
+        shape = (nchan,) if rawdump else (len(fh_raw), nchan)
+        super().__init__(fh_raw, header0, sample_rate=float(sample_rate),
+                         samples_per_frame=samples_per_frame, unsliced_shape=shape,
+                         bps=bps, complex_data=complex_data, squeeze=squeeze)
+        self._payload_nbytes, self._rawdump, self._nfiles = payload_nbytes, rawdump, nfiles
+        self._start_time = header0.time
+
+    payload_nbytes = property(lambda self: self._payload_nbytes)
+
+    def _frame_header(self, index):
+        """Timestamp of frame `index` (gsb/base.py:220-229): times advance by
+        the frame duration, the sequence number by one, the memory block
+        cycles modulo 8."""
+        h0 = self.header0
+        step = np.timedelta64(int(round(index * self.samples_per_frame * 1e9 / self.sample_rate)), 'ns')
+        if self._rawdump:
+            return GSBHeader.fromvalues('rawdump', time=h0.time + step)
+        return GSBHeader.fromvalues('phased', gps_time=h0.gps_time + step,
+                                    pc_time=h0.pc_time + step,
+                                    seq_nr=h0['seq_nr'] + index,
+                                    mem_block=(h0['mem_block'] + index) % 8)
+
+    def _write_frames(self, data, valid):
+        spf = self.samples_per_frame
+        nframes = data.shape[0] // spf
+        if data.is_complex():
+            data = torch.view_as_real(data)
+        if self._rawdump:
+            packed = kernels.encode_flat(data, _lib.CODER_INT, self.bps).cpu().numpy()
+            self.fh_raw.write(packed.data)
+        else:
+            npol, F = len(self.fh_raw), self._nfiles
+            # (frame, part, time in part, pol, ...) -> (pol, part, frame, time, ...)
+            block = data.reshape((nframes, F, spf // F, npol) + tuple(data.shape[2:]))
+            block = block.permute(3, 1, 0, 2, *range(4, block.dim()))
+            packed = kernels.encode_flat(block, _lib.CODER_INT, self.bps).cpu().numpy()
+            packed = packed.reshape(npol, F, nframes * self._payload_nbytes)
+            for p in range(npol):
+                for f in range(F):
+                    self.fh_raw[p][f].write(packed[p, f].data)
+        for k in range(nframes):
+            self._frame_header(self._nframes_written + k).tofile(self.fh_ts)
+
+    def flush(self):
+        self.fh_ts.flush()
+        for fh in ([self.fh_raw] if self._rawdump else [f for pair in self.fh_raw for f in pair]):
+            fh.flush()
+
+    def _close_files(self):
+        self.fh_ts.close()
+        for fh in ([self.fh_raw] if self._rawdump else [f for pair in self.fh_raw for f in pair]):
+            fh.close()
+
+
 def open(name, mode='rs', **kwargs):
-    """Open a GSB timestamp file plus ``raw=`` data file(s) for stream
-    reading (gsb/base.py:470-560)."""
-    if mode != 'rs':
-        raise ValueError("only stream reading mode 'rs' is supported "
+    """Open a GSB timestamp file plus ``raw=`` data file(s) for stream reading
+    (``'rs'``) or writing (``'ws'``) (gsb/base.py:460-560).  ``raw`` is one
+    file for rawdump, a (nested) tuple ``((polL1, polL2), (polR1, polR2))``
+    for phased data; ``header_mode`` overrides the mode inferred from it."""
+    if mode not in ('rs', 'ws'):
+        raise ValueError("only stream modes 'rs' and 'ws' are supported "
                          "(got {!r}).".format(mode))
-    raw = kwargs.pop('raw')
-    fh_ts = name if hasattr(name, 'read') else io.open(name, 'r')
-    if isinstance(raw, (tuple, list)):
-        fh_raw = tuple(tuple(f if hasattr(f, 'read') else io.open(f, 'rb')
-                             for f in (pair if isinstance(pair, (tuple, list)) else (pair,)))
-                       for pair in raw)
+    raw = kwargs.pop('raw', None)
+    if raw is None:
+        raise TypeError("stream missing required argument 'raw'.")
+    stream_mode = kwargs.pop('header_mode',
+                             'phased' if isinstance(raw, (tuple, list)) else 'rawdump')
+    rw = mode[0]
+    attr = 'read' if rw == 'r' else 'write'
+
+    def handle(f, text=False):
+        if hasattr(f, attr):
+            return f
+        return io.open(f, rw + ('' if text else 'b')) if rw == 'r' else (
+            io.open(f, 'w') if text else LazyWriteFile(f))
+
+    fh_ts = handle(name, text=True)
+    if stream_mode == 'rawdump':
+        fh_raw = handle(raw)
     else:
-        fh_raw = raw if hasattr(raw, 'read') else io.open(raw, 'rb')
-    return GSBStreamReader(fh_ts, fh_raw, **kwargs)
+        if not isinstance(raw, (tuple, list)):
+            raw = ((raw,),)
+        elif not isinstance(raw[0], (tuple, list)):
+            raw = (raw,)
+        fh_raw = tuple(tuple(handle(f) for f in pair) for pair in raw)
+    if rw == 'r':
+        return GSBStreamReader(fh_ts, fh_raw, **kwargs)
+    if 'header0' not in kwargs:
+        kwargs['mode'] = stream_mode
+    return GSBStreamWriter(fh_ts, fh_raw, **kwargs)

@@ -18,8 +18,44 @@ def _parse_time(items):
     return base + np.timedelta64(ns, 'ns') - _IST
 
 
+def _format_time(time, precision):
+    """UTC ``datetime64`` -> the seven items ``YYYY MM DD HH MM SS 0.fff...``
+    in IST, rounded to `precision` decimals (gsb/header.py:19-68)."""
+    t = np.datetime64(time, 'ns') + _IST
+    unit = 10 ** (9 - precision)
+    ticks = (int(t.astype(np.int64)) + unit // 2) // unit        # nearest tick
+    sec, frac = divmod(ticks, 10 ** precision)
+    text = str(np.datetime64(sec, 's'))                          # YYYY-MM-DDTHH:MM:SS
+    items = text[:10].split('-') + text[11:].split(':')
+    return items + ['0.{:0{}d}'.format(frac, precision)]
+
+
 class GSBHeader:
     """Header = the whitespace-separated items of one timestamp line."""
+    _gps_precision, _pc_precision = 9, 6
+
+    @classmethod
+    def fromvalues(cls, mode=None, *, time=None, gps_time=None, pc_time=None,
+                   seq_nr=0, mem_block=0, **ignored):
+        """Header for `time` (UTC): rawdump = the GPS time; phased = PC time,
+        GPS time, sequence number and memory block (gsb/header.py:200-318)."""
+        if mode is None:
+            mode = 'phased' if (pc_time is not None or seq_nr or mem_block) else 'rawdump'
+        gps_time = time if gps_time is None else gps_time
+        if gps_time is None:
+            raise TypeError("a GSB header needs a time.")
+        words = _format_time(gps_time, cls._gps_precision)
+        if mode == 'phased':
+            pc = _format_time(gps_time if pc_time is None else pc_time, cls._pc_precision)
+            words = pc + words + [str(int(seq_nr)), str(int(mem_block))]
+        return GSBHeader(words)
+
+    def tofile(self, fh):
+        line = ' '.join(self.words) + '\n'
+        return fh.write(line if 'b' not in getattr(fh, 'mode', 't') else line.encode('ascii'))
+
+    def keys(self):
+        return ('pc', 'gps', 'seq_nr', 'mem_block') if self.mode == 'phased' else ('gps',)
 
     def __new__(cls, words=None, mode=None, **kwargs):
         if cls is GSBHeader and words is not None:
@@ -58,7 +94,12 @@ class GSBRawdumpHeader(GSBHeader):
     def pc_time(self):
         return _parse_time(self.words[:7])
 
-    time = pc_time
+    time = gps_time = pc_time
+
+    def __getitem__(self, key):
+        if key == 'gps':
+            return ' '.join(self.words[:7])
+        raise KeyError(key)
 
 
 class GSBPhasedHeader(GSBHeader):
@@ -72,6 +113,10 @@ class GSBPhasedHeader(GSBHeader):
             return int(self.words[14])
         if key == 'mem_block':
             return int(self.words[15])
+        if key == 'pc':
+            return ' '.join(self.words[:7])
+        if key == 'gps':
+            return ' '.join(self.words[7:14])
         raise KeyError(key)
 
     @property

@@ -1028,6 +1028,62 @@ def gen_info():
         print(k, v['file_info'])
 
 
+def gen_gsb_writer():
+    """GSB stream writer of the reference (gsb/base.py:388-447) re-writing the
+    two sample observations: the timestamp text and the raw bytes it produces."""
+    out = {}
+    tmp = tempfile.mkdtemp()
+    with gsb.open(SAMPLE_GSB_RAWDUMP_HEADER, 'rs', raw=SAMPLE_GSB_RAWDUMP,
+                  samples_per_frame=8192) as fr:
+        data = fr.read()
+        ts, raw = os.path.join(tmp, 'r.timestamp'), os.path.join(tmp, 'r.dat')
+        with gsb.open(ts, 'ws', raw=raw, header0=fr.header0, sample_rate=fr.sample_rate,
+                      samples_per_frame=8192) as fw:
+            fw.write(data)
+    out['rawdump_ts'] = np.frombuffer(open(ts, 'rb').read(), np.uint8)
+    out['rawdump_raw'] = np.fromfile(raw, np.uint8)
+    assert np.array_equal(out['rawdump_raw'], np.fromfile(SAMPLE_GSB_RAWDUMP, np.uint8))
+    with gsb.open(SAMPLE_GSB_PHASED_HEADER, 'rs', raw=SAMPLE_GSB_PHASED,
+                  samples_per_frame=8) as fr:
+        data = fr.read()
+        ts = os.path.join(tmp, 'p.timestamp')
+        raws = [[os.path.join(tmp, 'p%d%d.dat' % (p, f)) for f in range(2)] for p in range(2)]
+        with gsb.open(ts, 'ws', raw=raws, sample_rate=fr.sample_rate, samples_per_frame=8,
+                      **fr.header0) as fw:
+            fw.write(data)
+    out['phased_ts'] = np.frombuffer(open(ts, 'rb').read(), np.uint8)
+    for p in range(2):
+        for f in range(2):
+            out['phased_raw%d%d' % (p, f)] = np.fromfile(raws[p][f], np.uint8)
+            assert np.array_equal(out['phased_raw%d%d' % (p, f)],
+                                  np.fromfile(SAMPLE_GSB_PHASED[p][f], np.uint8))
+    # non-integer samples, one pol / one file phased, 4-bit rawdump clipping
+    t0 = Time('2015-06-01T01:02:03.251658240', precision=9)
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal(3 * 64) * 5).astype(np.float32)
+    ts, raw = os.path.join(tmp, 'r2.timestamp'), os.path.join(tmp, 'r2.dat')
+    with gsb.open(ts, 'ws', raw=raw, time=t0, samples_per_frame=64, sample_rate=1 * u.kHz) as fw:
+        fw.write(x)
+    out['raw2_in'] = x
+    out['raw2_ts'] = np.frombuffer(open(ts, 'rb').read(), np.uint8)
+    out['raw2_raw'] = np.fromfile(raw, np.uint8)
+    z = (rng.standard_normal((40, 4)) * 60 + 1j * rng.standard_normal((40, 4)) * 60).astype(np.complex64)
+    ts, raw = os.path.join(tmp, 'p2.timestamp'), os.path.join(tmp, 'p2.dat')
+    with gsb.open(ts, 'ws', raw=raw, header_mode='phased', time=t0, seq_nr=9998, mem_block=6,
+                  samples_per_frame=8, nchan=4, sample_rate=2 * u.kHz) as fw:
+        fw.write(z)
+    out['ph2_in'] = z
+    out['ph2_ts'] = np.frombuffer(open(ts, 'rb').read(), np.uint8)
+    out['ph2_raw'] = np.fromfile(raw, np.uint8)
+    shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(GOLD, 'gsb_writer_cases.npz'), **out)
+    print('gsb writer:', {k: v.shape for k, v in out.items()})
+    print(out['rawdump_ts'].tobytes().decode()[:200])
+    print(out['phased_ts'].tobytes().decode()[:300])
+    print(out['ph2_ts'].tobytes().decode())
+    print(out['raw2_ts'].tobytes().decode())
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1100,7 +1156,7 @@ if __name__ == '__main__':
              ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt),
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
-             ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info)]
+             ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

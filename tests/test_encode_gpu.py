@@ -441,3 +441,70 @@ def test_vdif_write_frameset(manifest, tmp_path):
         assert f1.shape == f2.shape == (1536, 4, 1) and bool((f1.read() == f2.read()).all())
     with vdif.open(out, 'rb') as fr:
         assert [fr.read_frame().header['thread_id'] for _ in range(8)] == [0, 1, 2, 3] * 2
+
+
+# ---- GSB stream writer --------------------------------------------------------
+@pytest.fixture(scope='module')
+def gsb_gold():
+    return np.load(golden_path('gsb_writer_cases.npz'))
+
+
+def test_gsb_writer_rewrites_the_sample_observations(gsb_gold, tmp_path):
+    """Reading the two sample observations and writing them again gives the
+    timestamp text and raw bytes the reference's writer gives
+    (oracle/gen_golden.py `gsb_writer`)."""
+    from baseband_amd import gsb
+    d = golden_path('samples/gsb/')
+    ts, raw = str(tmp_path / 'r.timestamp'), str(tmp_path / 'r.dat')
+    with gsb.open(d + 'sample_gsb_rawdump.timestamp', 'rs', raw=d + 'sample_gsb_rawdump.dat',
+                  samples_per_frame=8192) as fr:
+        data = fr.read()
+        with gsb.open(ts, 'ws', raw=raw, header0=fr.header0, sample_rate=fr.sample_rate,
+                      samples_per_frame=8192) as fw:
+            fw.write(data[:10000])
+            fw.write(data[10000:])
+            assert fw.tell() == data.shape[0]
+    assert open(ts, 'rb').read() == gsb_gold['rawdump_ts'].tobytes()
+    assert open(raw, 'rb').read() == gsb_gold['rawdump_raw'].tobytes()
+    names = [[d + 'sample_gsb_phased.Pol-%s%d.dat' % (pol, part) for part in (1, 2)] for pol in 'LR']
+    import os
+    if not os.path.exists(names[0][0]):
+        names = [[d + f for f in sorted(os.listdir(d)) if 'phased' in f and f.endswith('.dat')][i:i + 2]
+                 for i in (0, 2)]
+    ts = str(tmp_path / 'p.timestamp')
+    raws = [[str(tmp_path / ('p%d%d.dat' % (p, f))) for f in range(2)] for p in range(2)]
+    with gsb.open(d + 'sample_gsb_phased.timestamp', 'rs', raw=names, samples_per_frame=8) as fr:
+        data = fr.read()
+        with gsb.open(ts, 'ws', raw=raws, header0=fr.header0, sample_rate=fr.sample_rate,
+                      samples_per_frame=8) as fw:
+            fw.write(data)
+    assert open(ts, 'rb').read() == gsb_gold['phased_ts'].tobytes()
+    for p in range(2):
+        for f in range(2):
+            assert open(raws[p][f], 'rb').read() == gsb_gold['phased_raw%d%d' % (p, f)].tobytes()
+    with gsb.open(ts, 'rs', raw=raws, samples_per_frame=8) as fb:
+        assert bool((fb.read() == data).all())
+
+
+def test_gsb_writer_from_keywords(gsb_gold, tmp_path):
+    """Headers from keywords, non-integer samples (4-bit clipping, int8
+    rounding), sequence numbers growing a digit, memory block modulo 8."""
+    from baseband_amd import gsb
+    t0 = np.datetime64('2015-06-01T01:02:03.251658240')
+    ts, raw = str(tmp_path / 'r2.timestamp'), str(tmp_path / 'r2.dat')
+    with gsb.open(ts, 'ws', raw=raw, time=t0, samples_per_frame=64, sample_rate=1e3) as fw:
+        assert fw.header0.mode == 'rawdump' and fw.bps == 4 and fw.sample_shape == ()
+        fw.write(gsb_gold['raw2_in'])
+    assert open(ts, 'rb').read() == gsb_gold['raw2_ts'].tobytes()
+    assert open(raw, 'rb').read() == gsb_gold['raw2_raw'].tobytes()
+    ts, raw = str(tmp_path / 'p2.timestamp'), str(tmp_path / 'p2.dat')
+    with gsb.open(ts, 'ws', raw=raw, header_mode='phased', time=t0, seq_nr=9998, mem_block=6,
+                  samples_per_frame=8, nchan=4, sample_rate=2e3) as fw:
+        assert fw.header0.mode == 'phased' and fw.bps == 8 and fw.complex_data
+        fw.write(gsb_gold['ph2_in'])
+    assert open(ts, 'rb').read() == gsb_gold['ph2_ts'].tobytes()
+    assert open(raw, 'rb').read() == gsb_gold['ph2_raw'].tobytes()
+    with pytest.raises(TypeError):
+        gsb.open(ts, 'ws', time=t0)                              # no raw
+    with pytest.raises(ValueError):
+        gsb.open(ts, 'wb', raw=raw)
