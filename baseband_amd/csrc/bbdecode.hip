@@ -152,6 +152,13 @@ void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_
 }
 
 template <int BPS, int LV>
+void launch_flat_span(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+    if (nt) hipLaunchKernelGGL((k_decode_flat_span<BPS, LV, true, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    else    hipLaunchKernelGGL((k_decode_flat_span<BPS, LV, false, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+}
+
+template <int BPS, int LV>
 void launch_rows_pipe(bool nt, int nw, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
 #define BB_R(NW) do { if (nt) hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, true, NW, 8>), grid, dim3(NW * BB_WAVE), 0, st, a); \
@@ -465,6 +472,27 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             default:
                 if (p->coder == BB_CODER_INT) launch_rows_pipe<8, BB_LV_INT8>(nt, nw, g2, st, a);
                 else                          launch_rows_pipe<8, BB_LV_LDS>(nt, nw, g2, st, a);
+                break;
+        }
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
+
+    if (om == BB_OUT_FLAT && g_tune_variant.load() >= 4 && a.ndw >= 64 * 16) {
+        // contiguous output: cut the work in output space (k_decode_flat_span),
+        // 2 waves x 16 tiles per item whatever the frame size
+        const uint64_t tiles_all = (nfs * a.ndw + 63) / 64;
+        uint64_t b2 = (tiles_all + 31) / 32;
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : 16384ull;
+        if (b2 > cap) b2 = cap;
+        const dim3 g2((unsigned)b2);
+        switch (p->bps) {
+            case 1: launch_flat_span<1, BB_LV_REG>(nt, g2, st, a); break;
+            case 2: launch_flat_span<2, BB_LV_REG>(nt, g2, st, a); break;
+            case 4: launch_flat_span<4, BB_LV_LDS>(nt, g2, st, a); break;
+            default:
+                if (p->coder == BB_CODER_INT) launch_flat_span<8, BB_LV_INT8>(nt, g2, st, a);
+                else                          launch_flat_span<8, BB_LV_LDS>(nt, g2, st, a);
                 break;
         }
         BB_HIP(hipGetLastError());

@@ -296,6 +296,117 @@ void k_decode_flat_pipe(bb_flat_args a)
     }
 }
 
+// Frame-agnostic form of k_decode_flat_pipe for contiguous output (nslot == 1):
+// the work is cut in OUTPUT space.  All payload dwords of the launch form one
+// stream D = 0 .. nfs*ndw-1 (frame = D / ndw); a wave owns TPW consecutive
+// 64-dword tiles of that stream, i.e. a run of the output that starts on a
+// multiple of its own length (64 KiB for 2-bit data) no matter where frame
+// boundaries fall.  With the per-frame split an 8000-byte payload is 31.25
+// tiles: runs of 64 and 61 KiB at 1 KiB-aligned positions, which costs about
+// 2.5 % of the HBM write rate against aligned runs
+// (profiles/r01e_exp_frame_size.log).  Payloads are at least one run long
+// (host side checks ndw >= 64 * TPW), so a run touches at most two frames, A
+// and B: their payload offsets are wave-uniform, and a lane only decides on
+// which side of the boundary its dword lies.  Frames without an entry (-1)
+// decode to fill.
+template <int BPS, int LV, bool NT, int NW, int TPW>
+__global__ __launch_bounds__(NW * BB_WAVE)
+void k_decode_flat_span(bb_flat_args a)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr int EPT = 2048 / BPS;
+    constexpr int PASSES = 8 / BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
+
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += NW * BB_WAVE) s_tab[i] = a.tab[i];
+        __syncthreads();
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    const int lane = bb_lane();
+    const int wave = __builtin_amdgcn_readfirstlane(bb_wave());
+    const uint64_t W = a.ndw;                       // payload dwords per frame (>= 64 * TPW)
+    const uint64_t dtot = a.nfs * W;
+    const uint64_t etot = dtot * (32 / BPS);
+    const uint64_t ntile = (dtot + 63) / 64;
+    const uint64_t nwork = (ntile + NW * TPW - 1) / (NW * TPW);
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+    const int src_lane0 = (lane * BPS) >> 3;
+    const int shift = (4 * lane * BPS) & 31;
+
+    auto offset_of = [&](uint64_t frame) -> int64_t {
+        if (frame >= a.nfs) return -1;
+        return a.src ? a.src[frame] : a.src0 + (int64_t)frame * a.src_stride;
+    };
+
+    struct span { uint64_t boundary; bool okA, okB; };   // wave-uniform
+    uint32_t cur[TPW], nxt[TPW];
+    span cs = {0, false, false}, ns = {0, false, false};
+
+    auto issue = [&](uint64_t work, uint32_t (&w)[TPW], span &sp) {
+        const uint64_t dstart = ((work * NW + wave) * TPW) * 64;      // uniform
+        const uint64_t frameA = dstart / W;
+        const int64_t soA = offset_of(frameA), soB = offset_of(frameA + 1);
+        sp.boundary = (frameA + 1) * W;
+        sp.okA = soA >= 0;
+        sp.okB = soB >= 0;
+        // dword pointers such that ptr[D] is stream dword D on either side
+        const uint32_t *pa = reinterpret_cast<const uint32_t *>(a.buf + (sp.okA ? soA : 0)) - frameA * W;
+        const uint32_t *pb = reinterpret_cast<const uint32_t *>(a.buf + (sp.okB ? soB : 0)) - sp.boundary;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint64_t d = dstart + 64ull * u + lane;
+            const bool inA = d < sp.boundary;
+            const bool ok = d < dtot && (inA ? sp.okA : sp.okB);
+            const uint32_t *q = (inA ? pa : pb) + d;
+            w[u] = ok ? (a.nt_loads ? __builtin_nontemporal_load(q) : *q) : 0u;
+        }
+    };
+
+    uint64_t work = blockIdx.x;
+    if (work < nwork) issue(work, cur, cs);
+    for (; work < nwork; work += gridDim.x) {
+        const uint64_t next = work + gridDim.x;
+        if (next < nwork) issue(next, nxt, ns);
+
+        const uint64_t tile0 = (work * NW + wave) * TPW;
+        const bool holes = !(cs.okA && cs.okB);                 // uniform, rare
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint64_t tile = tile0 + u;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int owner = p * 8 * BPS + src_lane0;      // lane whose dword holds my bits
+                uint32_t bits;
+                if (BPS == 8) bits = cur[u];
+                else bits = (uint32_t)__shfl((int)cur[u], owner) >> shift;
+                const uint64_t e0 = tile * EPT + 256 * p + 4 * lane;
+                if (e0 >= etot) continue;
+                bb_f4 v;
+                v.x = lv.get(bits & CMASK);
+                v.y = lv.get((bits >> BPS) & CMASK);
+                v.z = lv.get((bits >> (2 * BPS)) & CMASK);
+                v.w = lv.get((bits >> (3 * BPS)) & CMASK);
+                if (holes) {
+                    const uint64_t d = tile * 64 + (BPS == 8 ? lane : owner);
+                    if (!(d < cs.boundary ? cs.okA : cs.okB)) v = fillv;
+                }
+                bb_store4<NT>(a.out + e0, v);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) cur[u] = nxt[u];
+        cs = ns;
+    }
+}
+
 // Thread-interleaved output with chunks of >= 4 floats (e.g. 8 threads x 16
 // complex channels: 128-byte chunks in 1 KiB rows).  One wave per thread
 // slot; all waves of a workgroup walk the SAME tiles of their payloads, so

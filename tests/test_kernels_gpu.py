@@ -96,7 +96,7 @@ def test_tuning_variants_agree():
     dbuf = kernels.to_device_bytes(raw)
     ref = None
     try:
-        for variant in (0, 1, 2, 3):
+        for variant in (0, 1, 2, 3, 4):
             for nt in (0, 1):
                 for blocks in (0, 7, 2048):
                     kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
@@ -111,6 +111,50 @@ def test_tuning_variants_agree():
         kernels.tune(_lib.TUNE_FLAT_VARIANT, 3)
         kernels.tune(_lib.TUNE_NT_STORES, 1)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
+
+
+@pytest.mark.parametrize('coder,bps', [(0, 1), (0, 2), (0, 4), (0, 8), (1, 1), (1, 2), (2, 4), (2, 8)])
+@pytest.mark.parametrize('pn', [256, 260, 1000, 8000, 10000, 16384])
+def test_output_space_kernel_matches_per_frame_kernel(coder, bps, pn):
+    """k_decode_flat_span (work cut in output space, tiles may straddle frames)
+    against the per-frame kernel and the oracle: shuffled payload positions,
+    missing frames at the start / middle / end, fixed stride, complex fill."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(pn + bps + 10 * coder)
+    nframes = 37
+    stride = pn + 32
+    raw = rng.integers(0, 256, stride * (nframes + 3), dtype=np.uint8)
+    dbuf = kernels.to_device_bytes(raw)
+    order = rng.permutation(nframes + 3)[:nframes]
+    src = (order * stride + 32).astype(np.int64)
+    src[[0, 5, 6, 20, nframes - 1]] = -1
+    name = {0: 'vdif', 1: 'mark5b', 2: 'int'}[coder]
+    got = {}
+    try:
+        for variant in (3, 4):
+            kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+            for blocks in (0, 3):
+                kernels.tune(_lib.TUNE_BLOCKS, blocks)
+                a = kernels.decode_frames(dbuf, nframes, pn, coder, bps,
+                                          src=torch.from_numpy(src).cuda(), fill_value=-2.5)
+                b = kernels.decode_frames(dbuf, nframes, pn, coder, bps, src0=32, src_stride=stride)
+                c = kernels.decode_frames(dbuf, nframes, pn, coder, bps, complex_data=True,
+                                          src=torch.from_numpy(src).cuda(), fill_value=1 - 3j)
+                got[variant, blocks] = [x.cpu().numpy() for x in (a, b, c)]
+    finally:
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 3)
+        kernels.tune(_lib.TUNE_BLOCKS, 0)
+    E = pn * 8 // bps
+    want = np.empty((nframes, E), np.float32)
+    for f, o in enumerate(src):
+        want[f] = -2.5 if o < 0 else orc.decode_flat(raw[o:o + pn], name, bps)
+    for key, (a, b, c) in got.items():
+        assert bits_equal(a, want.reshape(-1)), key
+        assert bits_equal(b, got[3, 0][1]), key
+        assert bits_equal(c, got[3, 0][2]), key
+    cplx = got[4, 0][2].reshape(nframes, E // 2, 2)
+    assert np.all(cplx[0] == np.array([1., -3.], np.float32))
 
 
 def test_abi_argument_errors():
