@@ -127,7 +127,7 @@ int device_levels(int coder, int lb, const float **p)
 }
 
 // ---- tuning ----------------------------------------------------------------
-std::atomic<int> g_tune_variant{3};   // 3 = persistent pipelined kernel, 2 waves x long runs
+std::atomic<int> g_tune_variant{5};   // 5 = persistent pipelined kernel, 2 waves x long runs, aligned block loads
 std::atomic<int> g_tune_nt{1};
 std::atomic<int> g_tune_blocks{0};
 std::atomic<int> g_tune_nt_loads{0};
@@ -152,6 +152,13 @@ void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_
 }
 
 template <int BPS, int LV>
+void launch_flat_aln(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+    if (nt) hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, true, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    else    hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, false, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+}
+
+template <int BPS, int LV>
 void launch_flat_span(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
     if (nt) hipLaunchKernelGGL((k_decode_flat_span<BPS, LV, true, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
@@ -159,12 +166,14 @@ void launch_flat_span(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 }
 
 template <int BPS, int LV>
-void launch_rows_pipe(bool nt, int nw, dim3 grid, hipStream_t st, const bb_flat_args &a)
+void launch_rows_pipe(bool nt, bool aln, int nw, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
-#define BB_R(NW) do { if (nt) hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, true, NW, 8>), grid, dim3(NW * BB_WAVE), 0, st, a); \
-                      else    hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, false, NW, 8>), grid, dim3(NW * BB_WAVE), 0, st, a); } while (0)
+#define BB_R2(NW, NT, ALN) hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, NT, NW, 8, ALN>), grid, dim3(NW * BB_WAVE), 0, st, a)
+#define BB_R(NW) do { if (aln) { if (nt) BB_R2(NW, true, true); else BB_R2(NW, false, true); } \
+                      else     { if (nt) BB_R2(NW, true, false); else BB_R2(NW, false, false); } } while (0)
     if (nw == 8) BB_R(8); else if (nw == 4) BB_R(4); else BB_R(2);
 #undef BB_R
+#undef BB_R2
 }
 
 template <int BPS, int LV>
@@ -456,6 +465,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // thread interleave with wide chunks: one wave per thread slot, all
         // waves on the same 8 tiles (k_decode_rows_pipe)
         const int nw = p->nslot >= 8 ? 8 : (p->nslot >= 4 ? 4 : 2);
+        const bool aln = g_tune_variant.load() >= 5 && ((uintptr_t)d_buf & 255) == 0;
         const uint64_t seg_max = 8;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
@@ -466,19 +476,19 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
         switch (p->bps) {
-            case 1: launch_rows_pipe<1, BB_LV_REG>(nt, nw, g2, st, a); break;
-            case 2: launch_rows_pipe<2, BB_LV_REG>(nt, nw, g2, st, a); break;
-            case 4: launch_rows_pipe<4, BB_LV_LDS>(nt, nw, g2, st, a); break;
+            case 1: launch_rows_pipe<1, BB_LV_REG>(nt, aln, nw, g2, st, a); break;
+            case 2: launch_rows_pipe<2, BB_LV_REG>(nt, aln, nw, g2, st, a); break;
+            case 4: launch_rows_pipe<4, BB_LV_LDS>(nt, aln, nw, g2, st, a); break;
             default:
-                if (p->coder == BB_CODER_INT) launch_rows_pipe<8, BB_LV_INT8>(nt, nw, g2, st, a);
-                else                          launch_rows_pipe<8, BB_LV_LDS>(nt, nw, g2, st, a);
+                if (p->coder == BB_CODER_INT) launch_rows_pipe<8, BB_LV_INT8>(nt, aln, nw, g2, st, a);
+                else                          launch_rows_pipe<8, BB_LV_LDS>(nt, aln, nw, g2, st, a);
                 break;
         }
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
 
-    if (om == BB_OUT_FLAT && g_tune_variant.load() >= 4 && a.ndw >= 64 * 16) {
+    if (om == BB_OUT_FLAT && g_tune_variant.load() == 4 && a.ndw >= 64 * 16) {
         // contiguous output: cut the work in output space (k_decode_flat_span),
         // 2 waves x 16 tiles per item whatever the frame size
         const uint64_t tiles_all = (nfs * a.ndw + 63) / 64;
@@ -523,6 +533,17 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
                 default:
                     if (p->coder == BB_CODER_INT) launch_flat_pipe<8, BB_LV_INT8, 4, 8>(om, nt, g2, st, a);
                     else                          launch_flat_pipe<8, BB_LV_LDS, 4, 8>(om, nt, g2, st, a);
+                    break;
+            }
+        } else if (om == BB_OUT_FLAT && g_tune_variant.load() == 5 && ((uintptr_t)d_buf & 255) == 0) {
+            // aligned 256-byte block loads (k_decode_flat_aln)
+            switch (p->bps) {
+                case 1: launch_flat_aln<1, BB_LV_REG>(nt, g2, st, a); break;
+                case 2: launch_flat_aln<2, BB_LV_REG>(nt, g2, st, a); break;
+                case 4: launch_flat_aln<4, BB_LV_LDS>(nt, g2, st, a); break;
+                default:
+                    if (p->coder == BB_CODER_INT) launch_flat_aln<8, BB_LV_INT8>(nt, g2, st, a);
+                    else                          launch_flat_aln<8, BB_LV_LDS>(nt, g2, st, a);
                     break;
             }
         } else {

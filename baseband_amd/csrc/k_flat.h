@@ -296,6 +296,119 @@ void k_decode_flat_pipe(bb_flat_args a)
     }
 }
 
+// k_decode_flat_pipe for contiguous output with 256-byte ALIGNED tile loads.
+// A payload starts wherever its header ends (VDIF: 32 bytes into an 8032-byte
+// frame), so the dword-per-lane tile loads of k_decode_flat_pipe straddle
+// three 128-byte lines instead of covering two.  Here a wave loads the TPW+1
+// aligned 256-byte blocks that cover its tiles; the misalignment s (dwords,
+// wave-uniform per frame) is folded into the lane index of the bit hand-out:
+// payload dword o of tile u is lane (o+s)&63 of block u or u+1.
+template <int BPS, int LV, bool NT, int NW, int TPW>
+__global__ __launch_bounds__(NW * BB_WAVE)
+void k_decode_flat_aln(bb_flat_args a)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr int EPT = 2048 / BPS;
+    constexpr int PASSES = 8 / BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
+
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += NW * BB_WAVE) s_tab[i] = a.tab[i];
+        __syncthreads();
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    const int lane = bb_lane();
+    const int wave = __builtin_amdgcn_readfirstlane(bb_wave());
+    const uint64_t E = a.ndw * (32 / BPS);
+    const uint64_t nwork = a.nfs * a.nseg;
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+    const int src_lane0 = (lane * BPS) >> 3;
+    const int shift = (4 * lane * BPS) & 31;
+
+    uint32_t cur[TPW + 1], nxt[TPW + 1];
+    bool cur_valid = false, nxt_valid = false;
+    uint32_t cur_s = 0, nxt_s = 0;
+
+    auto issue = [&](uint64_t work, uint32_t (&w)[TPW + 1], bool &valid, uint32_t &s) {
+        uint64_t fs, seg;
+        if (a.nseg == 1) { fs = work; seg = 0; }
+        else { fs = work / a.nseg; seg = work - fs * a.nseg; }
+        const int64_t so = a.src ? a.src[fs] : a.src0 + (int64_t)fs * a.src_stride;
+        valid = so >= 0;
+        // absolute dword index of the payload start in the buffer; its low six
+        // bits are the misalignment against 256-byte blocks
+        // payloads found by the byte-granular search may start at odd bytes:
+        // those keep plain (hardware-unaligned) loads, s = 0
+        const uint64_t b0 = valid ? (uint64_t)so : 0;
+        s = (b0 & 3) ? 0u : (uint32_t)((b0 >> 2) & 63);
+        const uint32_t *blk = reinterpret_cast<const uint32_t *>(a.buf + b0) - s;
+        const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
+        const uint64_t dw_end = (seg + 1) * a.seg_tiles * 64 < a.ndw
+                                ? (seg + 1) * a.seg_tiles * 64 : a.ndw;
+#pragma unroll
+        for (int u = 0; u <= TPW; ++u) {
+            // block dword j holds payload dword j - s
+            const uint64_t j = (tile0 + u) * 64 + lane;
+            const bool want = valid && u <= (int)a.tpw && j >= s && j - s < dw_end;
+            w[u] = want ? (a.nt_loads ? __builtin_nontemporal_load(&blk[j]) : blk[j]) : 0u;
+        }
+    };
+
+    uint64_t work = blockIdx.x;
+    if (work < nwork) issue(work, cur, cur_valid, cur_s);
+    for (; work < nwork; work += gridDim.x) {
+        const uint64_t next = work + gridDim.x;
+        if (next < nwork) issue(next, nxt, nxt_valid, nxt_s);
+
+        uint64_t fs, seg;
+        if (a.nseg == 1) { fs = work; seg = 0; }
+        else { fs = work / a.nseg; seg = work - fs * a.nseg; }
+        float *obase = a.out + fs * E;
+        const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
+        const uint64_t seg_e_end = (seg + 1) * a.seg_tiles * EPT < E
+                                   ? (seg + 1) * a.seg_tiles * EPT : E;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint64_t tile = tile0 + u;
+            const bool live = u < (int)a.tpw;           // wave-uniform
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const uint32_t idx = (uint32_t)(BPS == 8 ? lane : p * 8 * BPS + src_lane0) + cur_s;
+                const uint32_t lo = (uint32_t)__shfl((int)cur[u], (int)(idx & 63));
+                uint32_t bits = lo;
+                if (cur_s) {                            // uniform: aligned frames need one shuffle
+                    const uint32_t hi = (uint32_t)__shfl((int)cur[u + 1], (int)(idx & 63));
+                    bits = idx >= 64 ? hi : lo;
+                }
+                bits >>= (BPS == 8 ? 0 : shift);
+                const uint64_t e0 = tile * EPT + 256 * p + 4 * lane;
+                if (!live || e0 >= seg_e_end) continue;
+                bb_f4 v;
+                if (cur_valid) {
+                    v.x = lv.get(bits & CMASK);
+                    v.y = lv.get((bits >> BPS) & CMASK);
+                    v.z = lv.get((bits >> (2 * BPS)) & CMASK);
+                    v.w = lv.get((bits >> (3 * BPS)) & CMASK);
+                } else {
+                    v = fillv;
+                }
+                bb_store4<NT>(obase + e0, v);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u <= TPW; ++u) cur[u] = nxt[u];
+        cur_valid = nxt_valid;
+        cur_s = nxt_s;
+    }
+}
+
 // Frame-agnostic form of k_decode_flat_pipe for contiguous output (nslot == 1):
 // the work is cut in OUTPUT space.  All payload dwords of the launch form one
 // stream D = 0 .. nfs*ndw-1 (frame = D / ndw); a wave owns TPW consecutive
@@ -413,7 +526,9 @@ void k_decode_flat_span(bb_flat_args a)
 // the rows of the output region are completed by the workgroup within a few
 // microseconds instead of being visited by eight workgroups at different
 // times.  Persistent and software pipelined like k_decode_flat_pipe.
-template <int BPS, int LV, bool NT, int NW, int TPW>
+// ALN: 256-byte aligned block loads with the misalignment folded into the
+// bit hand-out, as in k_decode_flat_aln (every wave has its own payload offset).
+template <int BPS, int LV, bool NT, int NW, int TPW, bool ALN>
 __global__ __launch_bounds__(NW * BB_WAVE)
 void k_decode_rows_pipe(bb_flat_args a)
 {
@@ -444,8 +559,10 @@ void k_decode_rows_pipe(bb_flat_args a)
     const int src_lane0 = (lane * BPS) >> 3;
     const int shift = (4 * lane * BPS) & 31;
 
-    uint32_t cur[TPW], nxt[TPW];
+    constexpr int NR = TPW + (ALN ? 1 : 0);
+    uint32_t cur[NR], nxt[NR];
     bool cur_valid = false, nxt_valid = false;
+    uint32_t cur_s = 0, nxt_s = 0;
 
     // work -> (frame set, segment, slot group); slot = group * NW + wave
     auto split = [&](uint64_t work, uint64_t &f, uint64_t &seg, uint32_t &slot) {
@@ -455,7 +572,7 @@ void k_decode_rows_pipe(bb_flat_args a)
         seg = r / sgroups;
         slot = (uint32_t)(r - seg * sgroups) * NW + wave;
     };
-    auto issue = [&](uint64_t work, uint32_t (&w)[TPW], bool &valid) {
+    auto issue = [&](uint64_t work, uint32_t (&w)[NR], bool &valid, uint32_t &s) {
         uint64_t f, seg; uint32_t slot;
         split(work, f, seg, slot);
         int64_t so = -1;
@@ -463,20 +580,32 @@ void k_decode_rows_pipe(bb_flat_args a)
             so = a.src ? a.src[f * a.nslot + slot]
                        : a.src0 + (int64_t)(f * a.nslot + slot) * a.src_stride;
         valid = so >= 0;
-        const uint32_t *in = reinterpret_cast<const uint32_t *>(a.buf + (valid ? so : 0));
         const uint64_t tile0 = seg * a.seg_tiles;
+        if (ALN) {
+            const uint64_t b0 = valid ? (uint64_t)so : 0;           // odd byte offsets: s = 0
+            s = (b0 & 3) ? 0u : (uint32_t)((b0 >> 2) & 63);
+            const uint32_t *blk = reinterpret_cast<const uint32_t *>(a.buf + b0) - s;
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            const uint64_t dw = (tile0 + u) * 64 + lane;
-            w[u] = (valid && u < (int)a.seg_tiles && dw < a.ndw) ? in[dw] : 0u;
+            for (int u = 0; u < NR; ++u) {
+                const uint64_t j = (tile0 + u) * 64 + lane;     // block dword j = payload dword j - s
+                w[u] = (valid && u <= (int)a.seg_tiles && j >= s && j - s < a.ndw) ? blk[j] : 0u;
+            }
+        } else {
+            s = 0;
+            const uint32_t *in = reinterpret_cast<const uint32_t *>(a.buf + (valid ? so : 0));
+#pragma unroll
+            for (int u = 0; u < TPW; ++u) {
+                const uint64_t dw = (tile0 + u) * 64 + lane;
+                w[u] = (valid && u < (int)a.seg_tiles && dw < a.ndw) ? in[dw] : 0u;
+            }
         }
     };
 
     uint64_t work = blockIdx.x;
-    if (work < nwork) issue(work, cur, cur_valid);
+    if (work < nwork) issue(work, cur, cur_valid, cur_s);
     for (; work < nwork; work += gridDim.x) {
         const uint64_t next = work + gridDim.x;
-        if (next < nwork) issue(next, nxt, nxt_valid);
+        if (next < nwork) issue(next, nxt, nxt_valid, nxt_s);
         uint64_t f, seg; uint32_t slot;
         split(work, f, seg, slot);
         const uint64_t tile0 = seg * a.seg_tiles;
@@ -488,8 +617,19 @@ void k_decode_rows_pipe(bb_flat_args a)
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
                 uint32_t bits;
-                if (BPS == 8) bits = cur[u];
-                else bits = (uint32_t)__shfl((int)cur[u], p * 8 * BPS + src_lane0) >> shift;
+                if (ALN) {
+                    const uint32_t idx = (uint32_t)(BPS == 8 ? lane : p * 8 * BPS + src_lane0) + cur_s;
+                    bits = (uint32_t)__shfl((int)cur[u], (int)(idx & 63));
+                    if (cur_s) {                        // wave-uniform
+                        const uint32_t hi = (uint32_t)__shfl((int)cur[u + (ALN ? 1 : 0)], (int)(idx & 63));
+                        if (idx >= 64) bits = hi;
+                    }
+                    bits >>= (BPS == 8 ? 0 : shift);
+                } else if (BPS == 8) {
+                    bits = cur[u];
+                } else {
+                    bits = (uint32_t)__shfl((int)cur[u], p * 8 * BPS + src_lane0) >> shift;
+                }
                 const uint64_t e0 = tile * EPT + 256 * p + 4 * lane;
                 if (!live || e0 >= E) continue;
                 bb_f4 v;
@@ -507,8 +647,9 @@ void k_decode_rows_pipe(bb_flat_args a)
             }
         }
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < NR; ++u) cur[u] = nxt[u];
         cur_valid = nxt_valid;
+        cur_s = nxt_s;
     }
 }
 

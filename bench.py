@@ -203,7 +203,7 @@ def main():
                    "bytes_out_per_gpu": bytes_out,
                    "output": "full-size float32 tensor kept in HBM (no slab recycling)",
                    "sharding": "time slabs, one per rank, no collective"},
-        "roofline": {"bound": "hbm", "kernel": "k_decode_flat_pipe<2, 0, 0, true, 2, 16>",
+        "roofline": {"bound": "hbm", "kernel": "k_decode_flat_aln<2, 0, true, 2, 16>",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "kernel_ms_avg": round(kern_avg, 4),

@@ -96,7 +96,7 @@ def test_tuning_variants_agree():
     dbuf = kernels.to_device_bytes(raw)
     ref = None
     try:
-        for variant in (0, 1, 2, 3, 4):
+        for variant in (0, 1, 2, 3, 4, 5):
             for nt in (0, 1):
                 for blocks in (0, 7, 2048):
                     kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
@@ -108,7 +108,7 @@ def test_tuning_variants_agree():
                         ref = out
                     assert bits_equal(out, ref)
     finally:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, 3)
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
         kernels.tune(_lib.TUNE_NT_STORES, 1)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
 
@@ -124,15 +124,17 @@ def test_output_space_kernel_matches_per_frame_kernel(coder, bps, pn):
     rng = np.random.default_rng(pn + bps + 10 * coder)
     nframes = 37
     stride = pn + 32
-    raw = rng.integers(0, 256, stride * (nframes + 3), dtype=np.uint8)
+    raw = rng.integers(0, 256, stride * (nframes + 3) + 16, dtype=np.uint8)
     dbuf = kernels.to_device_bytes(raw)
     order = rng.permutation(nframes + 3)[:nframes]
     src = (order * stride + 32).astype(np.int64)
+    src[3] += 1                                             # odd byte offsets (repaired files)
+    src[9] += 2
     src[[0, 5, 6, 20, nframes - 1]] = -1
     name = {0: 'vdif', 1: 'mark5b', 2: 'int'}[coder]
     got = {}
     try:
-        for variant in (3, 4):
+        for variant in (3, 4, 5):
             kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
             for blocks in (0, 3):
                 kernels.tune(_lib.TUNE_BLOCKS, blocks)
@@ -143,7 +145,7 @@ def test_output_space_kernel_matches_per_frame_kernel(coder, bps, pn):
                                           src=torch.from_numpy(src).cuda(), fill_value=1 - 3j)
                 got[variant, blocks] = [x.cpu().numpy() for x in (a, b, c)]
     finally:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, 3)
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
     E = pn * 8 // bps
     want = np.empty((nframes, E), np.float32)
@@ -155,6 +157,47 @@ def test_output_space_kernel_matches_per_frame_kernel(coder, bps, pn):
         assert bits_equal(c, got[3, 0][2]), key
     cplx = got[4, 0][2].reshape(nframes, E // 2, 2)
     assert np.all(cplx[0] == np.array([1., -3.], np.float32))
+
+
+@pytest.mark.parametrize('bps,coder', [(1, 0), (2, 0), (4, 0), (8, 0), (8, 2)])
+@pytest.mark.parametrize('nslot,chunk,cplx', [(8, 32, True), (4, 8, False), (2, 4, False), (3, 16, True)])
+def test_thread_interleave_aligned_loads_agree(bps, coder, nslot, chunk, cplx):
+    """k_decode_rows_pipe with aligned block loads (default) against the plain
+    loads of variant 3 and the oracle; payloads at odd multiples of 4 bytes."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(bps * 100 + nslot)
+    pn, nframes = 4000, 11
+    stride = pn + 36
+    raw = rng.integers(0, 256, stride * (nframes * nslot + 2) + 300, dtype=np.uint8)
+    dbuf = kernels.to_device_bytes(raw)
+    order = rng.permutation(nframes * nslot + 2)[:nframes * nslot]
+    src = (order * stride + 36 + 4 * (order % 7)).astype(np.int64)
+    src[3] += 1                                             # odd byte offsets (repaired files)
+    src[7] += 3
+    src[[1, nslot, nframes * nslot - 1]] = -1
+    outs = {}
+    try:
+        for variant in (3, 5):
+            kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+            outs[variant] = kernels.decode_frames(
+                dbuf, nframes, pn, coder, bps, chunk=chunk, nslot=nslot,
+                src=torch.from_numpy(src).cuda(), complex_data=cplx,
+                fill_value=(2 - 1j) if cplx else 9.).cpu().numpy()
+    finally:
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
+    assert bits_equal(outs[3], outs[5])
+    E = pn * 8 // bps
+    R = E // chunk
+    name = {0: 'vdif', 2: 'int'}[coder]
+    got = outs[5].reshape(nframes, R, nslot, chunk)
+    fillrow = np.tile(np.array([2., -1.], np.float32), chunk // 2) if cplx else np.full(chunk, 9., np.float32)
+    for f in range(nframes):
+        for sl in range(nslot):
+            o = src[f * nslot + sl]
+            want = np.tile(fillrow, (R, 1)) if o < 0 else \
+                orc.decode_flat(raw[o:o + pn], name, bps).reshape(R, chunk)
+            assert bits_equal(got[f, :, sl, :], want), (f, sl)
 
 
 def test_abi_argument_errors():

@@ -85,7 +85,7 @@ def main():
     kernels.tune(_lib.TUNE_FLAT_VARIANT, 2)
     ms = timeit(lambda: kernels.decode_frames(buf, nsets, pn, 0, 2, chunk=32, nslot=nth, src=src,
                                               complex_data=True, out=out))
-    kernels.tune(_lib.TUNE_FLAT_VARIANT, 3)
+    kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
     report('cfg2 same, previous kernel (k_decode_flat_pipe ROWS4, one workgroup per thread)',
            ms, nsets * nth * fn_, out.numel() * 4, out.numel() // 2, nsets=nsets)
     del out

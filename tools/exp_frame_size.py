@@ -15,12 +15,15 @@ from tools.bench_formats import timeit          # noqa: E402
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
 nbytes = int(gib * 2 ** 30)
 kernels.init()
-variant = int(os.environ.get('BB_VARIANT', '3'))
-kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+variants = [int(v) for v in os.environ.get('BB_VARIANT', '3').split(',')]
 buf = torch.randint(0, 256, (nbytes + 4096,), dtype=torch.uint8, device='cuda')
 out = torch.empty(nbytes * 4, dtype=torch.float32, device='cuda')
-for payload, header in ((8000, 32), (8000, 0), (8192, 0), (16384, 0), (65536, 0), (160000, 0),
-                        (1 << 20, 0), (1 << 24, 0), (nbytes, 0)):
+cases = ((8000, 32), (8000, 0), (8192, 0), (16384, 0), (65536, 0), (160000, 0),
+         (1 << 20, 0), (1 << 24, 0), (nbytes, 0))
+if os.environ.get('BB_CASES') == 'short':
+    cases = ((8000, 32), (8000, 0), (8192, 0), (10000, 16))
+for payload, header, variant in [(p, h, v) for p, h in cases for v in variants]:
+    kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
     stride = payload + header
     nfr = nbytes // stride
     o = out[:nfr * payload * 4]
