@@ -425,7 +425,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     }
 
     if (om == BB_OUT_SCATTER && d_src && g_tune_variant.load() >= 2
-        && (size_t)p->nslot * 260 + 1024 + 64 <= 48 * 1024) {
+        && (size_t)p->nslot * 528 + 1024 + 64 <= 48 * 1024) {
         // narrow chunks: assemble output rows in LDS (k_gather.h)
         bb_gather_args ga;
         ga.buf = a.buf; ga.src = d_src; ga.out = d_out; ga.tab = a.tab;
@@ -443,7 +443,8 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             ga.lrow = -1;
             if ((rl & (rl - 1)) == 0) { ga.lrow = 0; while ((1u << ga.lrow) < rl) ++ga.lrow; }
         }
-        const size_t lds = ((size_t)p->nslot * (gt * 64 + 1) + p->nslot) * 4 + 1024;
+        ga.aligned = (g_tune_variant.load() >= 5 && ((uintptr_t)d_buf & 255) == 0) ? 1 : 0;
+        const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024;
         uint64_t gb = (uint64_t)nframes * ga.ngroup;
         if (tb > 0 && gb > (uint64_t)tb) gb = (uint64_t)tb;
         if (gb > 0x7fffffffull) gb = 0x7fffffffull;

@@ -29,6 +29,7 @@ struct bb_gather_args {
     float    fill_re, fill_im;
     int32_t  complex_data;
     int32_t  lrow;          // log2(nslot * chunk) when that is a power of two, else -1
+    int32_t  aligned;       // buf is 256-byte aligned: use aligned block loads
 };
 
 template <int BPS, int LV, bool NT>
@@ -38,12 +39,15 @@ void k_decode_gather(bb_gather_args a)
     constexpr int NCODE = 1 << BPS;
     constexpr uint32_t CMASK = NCODE - 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
-    // layout: [nslot][pitch] dwords of raw payload, then nslot validity words,
-    // then the level table
-    const uint32_t pitch = a.gtiles * 64 + 1;           // +1 dword: bank skew
+    // layout: [nslot][pitch] dwords of raw payload (one 256-byte block more
+    // than the group needs: loads are whole aligned blocks, see
+    // k_decode_flat_aln), then per slot a validity word and the byte offset of
+    // the group's first payload dword inside its row, then the level table
+    const uint32_t pitch = a.gtiles * 64 + 64 + 1;      // +1 dword: bank skew
     uint32_t *s_raw = s_mem;
     uint32_t *s_valid = s_mem + (size_t)a.nslot * pitch;
-    float *s_tab = reinterpret_cast<float *>(s_valid + a.nslot);
+    uint32_t *s_base = s_valid + a.nslot;
+    float *s_tab = reinterpret_cast<float *>(s_base + a.nslot + 1);
 
     bb_levels<BPS, LV> lv;
     lv.lds = s_tab;
@@ -65,14 +69,27 @@ void k_decode_gather(bb_gather_args a)
         const uint64_t dw0 = (uint64_t)g * gdw;         // first dword of the group
         // phase 1: stage the group's dwords of every slot (one wave per
         // slot at a time: coalesced 256-byte loads, no index arithmetic)
+        if (threadIdx.x == 0) s_base[a.nslot] = 0;      // count of missing slots
+        __syncthreads();
         for (uint32_t s = bb_wave(); s < a.nslot; s += BB_WAVES_PER_BLOCK) {
             const int64_t so = a.src[f * a.nslot + s];
-            const uint32_t *in = reinterpret_cast<const uint32_t *>(a.buf + (so >= 0 ? so : 0));
-            for (uint32_t d = bb_lane(); d < gdw; d += BB_WAVE)
-                s_raw[s * pitch + d] = (so >= 0 && dw0 + d < a.ndw) ? in[dw0 + d] : 0u;
-            if (bb_lane() == 0) s_valid[s] = so >= 0 ? 1u : 0u;
+            const uint64_t b0 = so >= 0 ? (uint64_t)so : 0;
+            // misalignment of the payload against 256-byte blocks, in dwords
+            // (payloads at odd byte offsets keep plain loads: sh = 0)
+            const uint32_t sh = (a.aligned && !(b0 & 3)) ? (uint32_t)((b0 >> 2) & 63) : 0u;
+            const uint32_t *blk = reinterpret_cast<const uint32_t *>(a.buf + b0) - sh;
+            for (uint32_t j = bb_lane(); j < gdw + 64; j += BB_WAVE) {
+                const uint64_t q = dw0 + j;             // block dword q = payload dword q - sh
+                s_raw[s * pitch + j] = (so >= 0 && q >= sh && q - sh < a.ndw) ? blk[q] : 0u;
+            }
+            if (bb_lane() == 0) {
+                s_valid[s] = so >= 0 ? 1u : 0u;
+                s_base[s] = (s * pitch + sh) * 4;
+                if (so < 0) atomicAdd(&s_base[a.nslot], 1u);
+            }
         }
         __syncthreads();
+        const bool holes = s_base[a.nslot] != 0;        // uniform
         // phase 2: contiguous output region of this group
         const uint64_t e_lo = dw0 * (32 / BPS);
         const uint64_t e_hi = (e_lo + (uint64_t)gdw * (32 / BPS) < E) ? e_lo + (uint64_t)gdw * (32 / BPS) : E;
@@ -90,10 +107,11 @@ void k_decode_gather(bb_gather_args a)
                 const uint32_t s = rem >> a.lchunk;
                 const uint32_t within = rem & (a.chunk - 1);
                 const uint32_t bit = ((row << a.lchunk) + within) * BPS;
-                const uint32_t byte = rawb[(size_t)s * pitch * 4 + (bit >> 3)];
+                const uint32_t byte = rawb[s_base[s] + (bit >> 3)];
                 const uint32_t code = (byte >> (bit & 7)) & CMASK;
-                const float fillj = (a.complex_data && (within & 1)) ? a.fill_im : a.fill_re;
-                r[j] = s_valid[s] ? lv.get(code) : fillj;
+                r[j] = lv.get(code);
+                if (holes && !s_valid[s])
+                    r[j] = (a.complex_data && (within & 1)) ? a.fill_im : a.fill_re;
                 if (++rem == rowlen) { rem = 0; ++row; }
             }
             bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
@@ -101,3 +119,4 @@ void k_decode_gather(bb_gather_args a)
         __syncthreads();
     }
 }
+
