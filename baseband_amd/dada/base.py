@@ -122,7 +122,7 @@ class DADAStreamReader(BlockStreamReader):
 
     def _decode_window(self, dbuf, nframes, a, b, out_flat, payload_offset,
                        frame_stride, first_frame):
-        if self.bps != 8:
+        if self.bps not in (8, 32) or (self._mkbf and self.bps != 8):
             raise KeyError(self.bps)
         npol, nchan = self._unsliced_shape
         if self._mkbf:
@@ -141,6 +141,15 @@ class DADAStreamReader(BlockStreamReader):
                                         self._spf0, a, b, src0=payload_offset,
                                         src_stride=frame_stride,
                                         out=out_flat[:n_full * row])
+            return
+        if self.bps == 32:
+            # EXTENSION (no counterpart in the reference, which knows NBIT 8
+            # only: dada/payload.py:40-41): float32 samples are passed through
+            # as they are -- a device-to-device copy, byte-identical to the file
+            nb = (b - a) * self._row_nbytes
+            for i in range(nframes):
+                lo = payload_offset + i * frame_stride + a * self._row_nbytes
+                out_flat[i * nb // 4:(i + 1) * nb // 4] = dbuf[lo:lo + nb].view(torch.float32)
             return
         n = (b - a) * self._row_nbytes
         for i in range(nframes):

@@ -50,11 +50,15 @@ class DADAPayload(PayloadBase):
                          bps=bps, complex_data=complex_data)
 
     def _rows(self, start, stop):
-        if self.bps != 8:
+        if self.bps not in (8, 32):
             raise KeyError(self.bps)
         npol, nchan = self.sample_shape
         row = npol * nchan * (2 if self.complex_data else 1)
-        flat = decode_i8_rows(self._device_words(), 0, row, start, stop)
+        if self.bps == 32:
+            # EXTENSION: NBIT 32 = float32 passthrough (not in the reference)
+            flat = self._device_words()[start * row * 4:stop * row * 4].view(torch.float32).clone()
+        else:
+            flat = decode_i8_rows(self._device_words(), 0, row, start, stop)
         if self.complex_data:
             flat = torch.view_as_complex(flat.reshape(-1, 2))
         return flat.reshape(stop - start, npol, nchan)

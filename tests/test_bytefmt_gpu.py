@@ -191,3 +191,38 @@ def test_gsb_payload_fromfile(manifest):
     with open(golden_path(manifest['sample_gsb_rawdump']['file']), 'rb') as f:
         pl = GSBPayload.fromfile(f, payload_nbytes=4096, sample_shape=(1,), bps=4)
     assert bits_equal(pl.data.cpu().numpy(), load_expected('sample_gsb_rawdump')[:8192])
+
+
+def test_dada_float32_passthrough_extension(tmp_path):
+    """NBIT 32 (BASELINE config 4; NOT in the reference, which raises KeyError(32)):
+    float32 samples come back byte-identical to the file, through the stream
+    reader (whole file, windows, partial reads) and the payload."""
+    import io
+    from baseband_amd import dada
+    rng = np.random.default_rng(32)
+    spf, npol, nchan, nframes = 1000, 2, 3, 5
+    h = dada.DADAHeader.fromvalues(time=np.datetime64('2020-02-02T02:02:02'), sample_rate=1e6,
+                                   bps=32, complex_data=True, npol=npol, nchan=nchan,
+                                   samples_per_frame=spf)
+    assert h.payload_nbytes == spf * npol * nchan * 8
+    data = (rng.standard_normal((nframes * spf, npol, nchan))
+            + 1j * rng.standard_normal((nframes * spf, npol, nchan))).astype(np.complex64)
+    data.view(np.uint32)[7] = 0x7fc01234                  # a NaN payload must survive bit for bit
+    p = tmp_path / 'f32.dada'
+    with open(str(p), 'wb') as fw:
+        for k in range(nframes):
+            hk = h.copy()
+            hk['OBS_OFFSET'] = k * h.payload_nbytes
+            hk.tofile(fw)
+            fw.write(data[k * spf:(k + 1) * spf].tobytes())
+    with dada.open(str(p), 'rs') as fh:
+        assert fh.bps == 32 and fh.shape == (nframes * spf, npol, nchan)
+        got = fh.read().cpu().numpy()
+        assert bits_equal(got, data)
+        fh.window_bytes = 30000                            # several windows per read
+        fh.seek(777)
+        assert bits_equal(fh.read(3000).cpu().numpy(), data[777:3777])
+    with dada.open(str(p), 'rb') as fb:
+        frame = fb.read_frame()
+        assert bits_equal(frame[10:20].cpu().numpy(), data[10:20])
+        assert bits_equal(frame.data.cpu().numpy(), data[:spf])
