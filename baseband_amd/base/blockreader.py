@@ -53,7 +53,7 @@ class BlockStreamReader(GPUStreamReaderBase):
         # merge consecutive frames that use the same row range into runs
         runs = []
         for f, a, b in pieces:
-            if runs and runs[-1][1] == f and runs[-1][2:] == (a, b):
+            if runs and runs[-1][1] == f and tuple(runs[-1][2:]) == (a, b):
                 runs[-1][1] = f + 1
             else:
                 runs.append([f, f + 1, a, b])

@@ -85,6 +85,7 @@ class WindowPipeline:
         self._dev = [None] * nbuf
         self._done = [None] * nbuf
         self._copy_stream = None
+        self._count = 0
 
     def _buffers(self, b):
         if self._pinned[b] is None:
@@ -101,7 +102,8 @@ class WindowPipeline:
             n = hi - lo
             if n > self.cap:
                 raise ValueError("window larger than staging buffer")
-            b = i % self.nbuf
+            b = self._count % self.nbuf         # rotation continues across run() calls
+            self._count += 1
             if self._done[b] is not None:
                 self._done[b].synchronize()          # buffer b free again
             pinned, dev = self._buffers(b)
