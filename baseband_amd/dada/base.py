@@ -152,6 +152,13 @@ class DADAStreamReader(BlockStreamReader):
                 out_flat[i * nb // 4:(i + 1) * nb // 4] = dbuf[lo:lo + nb].view(torch.float32)
             return
         n = (b - a) * self._row_nbytes
+        lo = payload_offset + a * self._row_nbytes
+        if n % 4 == 0 and lo % 4 == 0 and frame_stride % 4 == 0:
+            # rows [a, b) of every frame in ONE launch: the frames are `nframes`
+            # payloads of n bytes at a fixed stride
+            kernels.decode_frames(dbuf, nframes, n, _lib.CODER_INT, 8, src0=lo,
+                                  src_stride=frame_stride, out=out_flat)
+            return
         for i in range(nframes):
             out_flat[i * n:(i + 1) * n] = decode_i8_rows(
                 dbuf, payload_offset + i * frame_stride, self._row_nbytes, a, b)
