@@ -313,7 +313,10 @@ class GPUStreamReaderBase:
         spf = self.samples_per_frame
         first, off0 = divmod(self.offset, spf)
         last = -(-(self.offset + count) // spf) if count else first
-        data = self._read_sets(first, last)             # (nsets*spf, *unsliced)
+        # a frame-aligned request into a suitable device tensor is decoded in
+        # place: no second pass over the 16x larger output
+        into = self._direct_target(out, off0, count, (last - first) * spf)
+        data = self._read_sets(first, last, into)       # (nsets*spf, *unsliced)
         if not self._resolve_checks():
             # verify='fix': frames are missing or out of place.  Build the
             # corruption-tolerant index (byte-granular header search) and
@@ -321,10 +324,12 @@ class GPUStreamReaderBase:
             self._relocate()
             if self.offset + count > self.shape[0]:
                 raise EOFError("cannot read from beyond end of input.")
-            data = self._read_sets(first, last)
+            data = self._read_sets(first, last, into)
+        self.offset += count
+        if into is not None:
+            return out
         data = data[off0:off0 + count]
         data = self._squeeze_and_subset(data)
-        self.offset += count
         if out is None:
             return data
         if isinstance(out, torch.Tensor):
@@ -333,14 +338,29 @@ class GPUStreamReaderBase:
             out[...] = data.cpu().numpy()
         return out
 
-    def _read_sets(self, first, last):
-        """Decode frame sets [first, last) -> tensor (nsets*spf, *unsliced)."""
+    def _direct_target(self, out, off0, count, nrows):
+        """Flat float32 view of `out` when the decode may write straight into
+        it: a contiguous device tensor of the stream's dtype covering whole
+        frame sets, and no subset (squeezing only drops unit dimensions)."""
+        if (not isinstance(out, torch.Tensor) or not out.is_cuda or off0 or count != nrows
+                or count == 0 or not out.is_contiguous() or self.subset
+                or getattr(self, '_frameset_subset', None)
+                or tuple(self._decode_shape) != tuple(self._unsliced_shape)
+                or out.dtype != (torch.complex64 if self.complex_data else torch.float32)):
+            return None
+        flat = torch.view_as_real(out) if self.complex_data else out
+        return flat.reshape(-1)
+
+    def _read_sets(self, first, last, into=None):
+        """Decode frame sets [first, last) -> tensor (nsets*spf, *unsliced);
+        `into` is an optional flat float32 device tensor to decode into."""
         kernels.require_gpu()
         nsets = last - first
         spf = self.samples_per_frame
         ncomp = 2 if self.complex_data else 1
         row = int(np.prod(self._decode_shape)) * ncomp
-        flat = torch.empty(nsets * spf * row, dtype=torch.float32, device='cuda')
+        flat = into if into is not None else torch.empty(
+            nsets * spf * row, dtype=torch.float32, device='cuda')
         if nsets:
             set_nbytes = self._set_nbytes
             image = self._image()

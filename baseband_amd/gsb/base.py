@@ -107,7 +107,7 @@ class GSBStreamReader(GPUStreamReaderBase):
                 for fh in pair:
                     fh.close()
 
-    def _read_sets(self, first, last):
+    def _read_sets(self, first, last, into=None):
         kernels.require_gpu()
         nsets = last - first
         pn = self._payload_nbytes
@@ -123,7 +123,7 @@ class GSBStreamReader(GPUStreamReaderBase):
         chunk = nchan * (2 if self.complex_data else 1)
         if self._rawdump:
             flat = kernels.decode_frames(dbuf, nsets, pn, _lib.CODER_INT, self.bps,
-                                         chunk=chunk, src0=0, src_stride=pn)
+                                         chunk=chunk, src0=0, src_stride=pn, out=into)
         else:
             # output frame (k, part f), slot = polarisation p
             k = np.arange(nsets)[:, None, None]
@@ -133,7 +133,7 @@ class GSBStreamReader(GPUStreamReaderBase):
             dsrc = torch.from_numpy(np.ascontiguousarray(src.reshape(-1)).astype(np.int64)).to(dbuf.device)
             flat = kernels.decode_frames(dbuf, nsets * F, pn, _lib.CODER_INT,
                                          self.bps, chunk=chunk, nslot=npol,
-                                         src=dsrc, complex_data=self.complex_data)
+                                         src=dsrc, complex_data=self.complex_data, out=into)
         if self.complex_data:
             flat = torch.view_as_complex(flat.view(-1, 2))
         return flat.reshape((nsets * self.samples_per_frame,)

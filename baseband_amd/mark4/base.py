@@ -240,14 +240,15 @@ class Mark4StreamReader(GPUStreamReaderBase):
         self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
         self._relocated = True
 
-    def _read_sets(self, first, last):
+    def _read_sets(self, first, last, into=None):
         if self._resident is None:
-            return super()._read_sets(first, last)
+            return super()._read_sets(first, last, into)
         dev, src = self._resident
         maps = BITMAPS[self._coder]
         flat = kernels.decode_mark4(
             dev, last - first, self._ntrack, 20000, maps['sign_bit'], maps['mag_bit'],
-            fill_words=160, src=src[first:last].contiguous(), fill_value=self.fill_value)
+            fill_words=160, src=src[first:last].contiguous(), fill_value=self.fill_value,
+            out=into)
         return flat.reshape(((last - first) * self.samples_per_frame,)
                             + tuple(self._decode_shape))
 

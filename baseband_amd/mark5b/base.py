@@ -226,14 +226,14 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
         self._relocated = True
 
-    def _read_sets(self, first, last):
+    def _read_sets(self, first, last, into=None):
         if self._resident is None:
-            return super()._read_sets(first, last)
+            return super()._read_sets(first, last, into)
         dev, src = self._resident
         flat = kernels.decode_frames(
             dev, last - first, 10000, _lib.CODER_MARK5B, self.bps,
             chunk=self._unsliced_shape[0], nslot=1,
-            src=src[first:last].contiguous(), fill_value=self.fill_value)
+            src=src[first:last].contiguous(), fill_value=self.fill_value, out=into)
         return flat.reshape(((last - first) * self.samples_per_frame,)
                             + tuple(self._decode_shape))
 

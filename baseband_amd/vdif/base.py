@@ -237,9 +237,9 @@ class VDIFStreamReader(GPUStreamReaderBase):
         self._nsample = nsets * self.samples_per_frame
         self._relocated = True
 
-    def _read_sets(self, first, last):
+    def _read_sets(self, first, last, into=None):
         if self._resident is None:
-            return super()._read_sets(first, last)
+            return super()._read_sets(first, last, into)
         dev, src = self._resident
         h0 = self.header0
         nslot = len(self._thread_ids)
@@ -248,7 +248,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
         flat = kernels.decode_frames(
             dev, nsets, h0.payload_nbytes, self._coder, self.bps, chunk=chunk,
             nslot=nslot, src=src[first * nslot:last * nslot].contiguous(),
-            complex_data=self.complex_data, fill_value=self.fill_value)
+            complex_data=self.complex_data, fill_value=self.fill_value, out=into)
         if self.complex_data:
             flat = torch.view_as_complex(flat.view(-1, 2))
         return flat.reshape((nsets * self.samples_per_frame,) + tuple(self._decode_shape))

@@ -320,3 +320,45 @@ def test_reader_pickle_roundtrip(manifest):
     with pytest.raises(TypeError):
         import io
         pickle.dumps(vdif.open(io.BytesIO(load_file(manifest['sample_vdif']['file']).tobytes()), 'rs'))
+
+
+def test_read_into_device_tensor_is_decoded_in_place(manifest):
+    """read(out=<device tensor>) on a frame-aligned request decodes straight
+    into `out` (no second pass over the output); unaligned requests, subsets
+    and host arrays go through a temporary.  Results are the same."""
+    import torch
+    from baseband_amd import vdif, kernels
+    exp = load_expected('sample_vdif')[:, :, 0]
+    calls = []
+    orig = kernels.decode_frames
+
+    def spy(*a, **k):
+        calls.append(k.get('out'))
+        return orig(*a, **k)
+    kernels.decode_frames = spy
+    try:
+        with vdif.open(golden_path('samples/sample.vdif'), 'rs') as fh:
+            out = torch.full((40000, 8), -1., dtype=torch.float32, device='cuda')
+            assert fh.read(out=out) is out and fh.tell() == 40000
+            assert calls[-1] is not None and calls[-1].data_ptr() == out.data_ptr()
+            assert bits_equal(out.cpu().numpy(), exp)
+            fh.seek(20000)
+            half = torch.empty((20000, 8), dtype=torch.float32, device='cuda')
+            fh.read(out=half)
+            assert calls[-1].data_ptr() == half.data_ptr()
+            assert bits_equal(half.cpu().numpy(), exp[20000:])
+            fh.seek(5)                                   # not frame aligned: temporary
+            part = torch.empty((100, 8), dtype=torch.float32, device='cuda')
+            fh.read(out=part)
+            assert calls[-1] is None or calls[-1].data_ptr() != part.data_ptr()
+            assert bits_equal(part.cpu().numpy(), exp[5:105])
+            fh.seek(0)
+            host = np.empty((20000, 8), np.float32)      # host array: copied back
+            fh.read(out=host)
+            assert bits_equal(host, exp[:20000])
+        with vdif.open(golden_path('samples/sample.vdif'), 'rs', subset=[1, 3]) as fh:
+            sub = torch.empty((20000, 2), dtype=torch.float32, device='cuda')
+            fh.read(out=sub)
+            assert bits_equal(sub.cpu().numpy(), exp[:20000][:, [1, 3]])
+    finally:
+        kernels.decode_frames = orig
