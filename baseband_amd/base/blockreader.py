@@ -47,7 +47,15 @@ class BlockStreamReader(GPUStreamReaderBase):
         kernels.require_gpu()
         ncomp = 2 if self.complex_data else 1
         row = int(np.prod(self._decode_shape)) * ncomp
-        flat = torch.empty(count * row, dtype=torch.float32, device='cuda')
+        # pieces land exactly where they belong, so a suitable `out` tensor is
+        # decoded into directly
+        direct = (isinstance(out, torch.Tensor) and out.is_cuda and out.is_contiguous()
+                  and count > 0 and not self.subset
+                  and out.dtype == (torch.complex64 if self.complex_data else torch.float32))
+        if direct:
+            flat = (torch.view_as_real(out) if self.complex_data else out).reshape(-1)
+        else:
+            flat = torch.empty(count * row, dtype=torch.float32, device='cuda')
         pieces = self._pieces(self.offset, count)
         image = self._image()
         # merge consecutive frames that use the same row range into runs
@@ -83,6 +91,9 @@ class BlockStreamReader(GPUStreamReaderBase):
             self._pipeline.run(ranges, process)
             done += (f1 - f0) * (b - a)
         assert done == count
+        if direct:
+            self.offset += count
+            return out
         if self.complex_data:
             flat = torch.view_as_complex(flat.view(-1, 2))
         data = flat.reshape((count,) + tuple(self._decode_shape))
