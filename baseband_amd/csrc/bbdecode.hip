@@ -330,6 +330,19 @@ int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets, size_
     return BB_OK;
 }
 
+int bb_verify_records(const bb_frame_rec *d_recs, size_t nrecs, int32_t first_index,
+                      uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad, void *stream)
+{
+    if (!d_nbad || (nrecs && !d_recs) || recs_per_index == 0) return BB_EINVAL;
+    if (nrecs == 0) return BB_OK;
+    const uint64_t blocks = ((uint64_t)nrecs + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 0x7fffffffull) return BB_ERANGE;
+    hipLaunchKernelGGL(k_verify_records, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
+                       d_recs, (uint64_t)nrecs, first_index, recs_per_index, (uint64_t)nstrict, d_nbad);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
 int bb_build_index(const bb_frame_rec *d_recs, size_t nrecs,
                    const int16_t *d_thread_slot, int nslot,
                    int64_t *d_src, size_t nframes_out, void *stream)

@@ -259,6 +259,28 @@ void k_mark5b_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t
     }
 }
 
+// Verification of a window's scan records in one launch: counts the records
+// that are not BB_FRAME_OK, or -- for the first `nstrict` of them -- whose time
+// index is not first_index + i / recs_per_index (frames out of place).  The
+// records after `nstrict` are the look-ahead header behind the request: it only
+// has to be a header (base/base.py:1083-1125).  The count is ADDED to *nbad.
+__global__ __launch_bounds__(BB_BLOCK)
+void k_verify_records(const bb_frame_rec *recs, uint64_t nrecs, int32_t first_index,
+                      uint32_t recs_per_index, uint64_t nstrict, uint32_t *nbad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+    bool bad = false;
+    if (i < nrecs) {
+        const bb_u4 raw = *reinterpret_cast<const bb_u4 *>(&recs[i]);
+        bb_frame_rec r;
+        *reinterpret_cast<bb_u4 *>(&r) = raw;
+        bad = !(r.flags & BB_FRAME_OK)
+              || (i < nstrict && r.time_index != first_index + (int32_t)(i / recs_per_index));
+    }
+    const unsigned long long m = __ballot(bad);
+    if (bb_lane() == 0 && m) atomicAdd(nbad, (uint32_t)__popcll(m));
+}
+
 // Scatter scan records into the dense output-ordered source table (which the
 // caller's launch wrapper pre-fills with -1).
 __global__ __launch_bounds__(BB_BLOCK)

@@ -161,6 +161,13 @@ def mark4_scan_at(dbuf, nbytes, offsets, ntrack, ref_year, ref_qms, frame_qms):
     return recs
 
 
+def verify_records(recs, nrecs, first_index, recs_per_index, nstrict, nbad):
+    """Add to the device counter `nbad` (int32[1]) the number of records that
+    fail verification (see bb_verify_records)."""
+    check(lib.bb_verify_records(_ptr(recs), nrecs, first_index, recs_per_index, nstrict,
+                                _ptr(nbad), _stream()), 'bb_verify_records')
+
+
 def recs_fields(recs):
     """Split scan records (device int32 (n,4)) into named host arrays."""
     r = recs.cpu().numpy()

@@ -250,13 +250,8 @@ class Mark5BStreamReader(GPUStreamReaderBase):
             chunk=self._unsliced_shape[0], nslot=1, src=src,
             fill_value=self.fill_value, out=out_flat)
         if self.verify:
-            ok = (recs[:, 3] >> 16) & _lib.FRAME_OK
-            expect = torch.arange(nframes, device=recs.device, dtype=torch.int32)
-            wrong = recs[:, 2] != expect
-            if nframes > n:                 # the look-ahead header only has to be a header
-                wrong[n:] = False
-            bad = ((ok == 0) | wrong).sum() + max(0, n - nframes)
-            self._pending_checks.append(bad)
+            # the look-ahead header (record n) only has to be a header
+            self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))
 
 
 class Mark5BStreamWriter(GPUStreamWriterBase):

@@ -333,14 +333,8 @@ class VDIFStreamReader(GPUStreamReaderBase):
             chunk=chunk, nslot=nslot, src=src, complex_data=self.complex_data,
             fill_value=self.fill_value, out=out_flat)
         if self.verify:
-            meta = recs[:, 3]
-            ok = (meta >> 16) & _lib.FRAME_OK
-            expect = torch.arange(nframes, device=recs.device,
-                                  dtype=torch.int32) // nthread_file
-            bad = ((ok == 0) | (recs[:, 2] != expect)).sum()
-            if nframes < nsets * nthread_file:
-                bad = bad + (nsets * nthread_file - nframes)
-            self._pending_checks.append(bad)
+            self._check_window(recs, nframes, nthread_file, nframes,
+                               missing=nsets * nthread_file - nframes)
 
 
     # -- frame index as a first-class object (multi-GPU sharding, parallel.py)

@@ -195,6 +195,18 @@ int bb_mark5b_scan_at(const void *d_buf, size_t nbytes,
  * Replaces VDIFFrameSet.fromfile's gather-by-thread (vdif/frame.py:176-243)
  * and RawOffsets (base/offsets.py).
  */
+/*
+ * Verification of scan records (verify=True / 'fix': the checks the reference
+ * makes frame by frame in VLBIStreamReaderBase._read_frame, base/base.py:
+ * 1083-1125 -- header valid, frame index as expected, and a readable header
+ * behind the frame).  Adds to *d_nbad the number of records that are not
+ * BB_FRAME_OK or, among the first `nstrict`, whose time_index differs from
+ * first_index + i / recs_per_index (recs_per_index = threads per frame set).
+ */
+int bb_verify_records(const bb_frame_rec *d_recs, size_t nrecs,
+                      int32_t first_index, uint32_t recs_per_index,
+                      size_t nstrict, uint32_t *d_nbad, void *stream);
+
 int bb_build_index(const bb_frame_rec *d_recs, size_t nrecs,
                    const int16_t *d_thread_slot, int nslot,
                    int64_t *d_src, size_t nframes_out, void *stream);
