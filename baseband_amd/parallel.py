@@ -90,3 +90,27 @@ def sharded_vdif_read(reader, rank=None, world=None, src=None, group=None):
                                           reader.header0.payload_nbytes)
     data = reader.decode_with_index(local, byte_lo, byte_hi, hi - lo)
     return data, (lo * spf, hi * spf)
+
+
+def sharded_read(reader, rank=None, world=None, group=None):
+    """This rank's time slab of ANY stream reader (VDIF, Mark 5B, Mark 4,
+    GUPPI, DADA, GSB): frames are independent, so rank r simply seeks to the
+    start of its slab of frames and reads it through the normal pipeline into
+    its own HBM -- no collective at all.  Returns
+    ``(data, (first_sample, last_sample))``; the slabs of all ranks tile the
+    stream.  (GUPPI files with OVERLAP: a slab starts with its first frame's
+    own leading samples, exactly like a seek + read at that offset in the
+    reference.)  Use `sharded_vdif_read` when the scan of a multi-thread VDIF file
+    should be done once and its index broadcast instead."""
+    import torch.distributed as dist
+    if rank is None:
+        use_dist = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if use_dist else 0
+        world = dist.get_world_size(group) if use_dist else 1
+    spf = reader.samples_per_frame
+    nsample = reader.shape[0]
+    nframes = -(-nsample // spf)
+    lo, hi = frame_slab(nframes, rank, world)
+    first, last = min(lo * spf, nsample), min(hi * spf, nsample)
+    reader.seek(first)
+    return reader.read(last - first), (first, last)
