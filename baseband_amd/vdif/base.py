@@ -228,6 +228,26 @@ class VDIFStreamReader(GPUStreamReaderBase):
                                     h0['frame_nr'], self._frame_rate)
         if self._thread_slot is None:
             self._thread_slot = kernels.thread_slot_map(self._thread_ids, dev.device)
+        # The reference assembles a frame set frame by frame and, when a frame
+        # cannot be read, looks for the next header no further than two frames
+        # on; if there is none it gives up on the REST of that set
+        # (vdif/base.py:655-690).  Same here: a hole of more than three frame
+        # lengths between two located frames of one set drops the later ones.
+        if offs.numel() > 1:
+            t = recs[:, 2]
+            same_set = t[1:] == t[:-1]
+            hole = (offs[1:] - offs[:-1]) > 3 * self._frame_nbytes + h0.nbytes - 1
+            brk = torch.zeros_like(t)
+            brk[1:] = (hole & same_set).to(t.dtype)
+            if bool(brk.any()):
+                c = torch.cumsum(brk, 0)
+                start = torch.zeros_like(t, dtype=torch.bool)
+                start[0] = True
+                start[1:] = ~same_set
+                idx = torch.arange(t.numel(), device=t.device)
+                first = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
+                lost = (c - c[first]) > 0
+                recs[:, 3] = torch.where(lost, recs[:, 3] & ~(_lib.FRAME_OK << 16), recs[:, 3])
         ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
         same = (recs[:, 3] & 0xffff) == h0['thread_id']
         sel = recs[:, 2][ok & same]

@@ -34,15 +34,7 @@ def test_intact_triple_file():
             assert bits_equal(fh.read().cpu().numpy(), load_expected('vdif_triple'))
 
 
-# Two adjacent headers damaged in place: the reference's heuristic recovery
-# also drops the intact frame after them (28-31); the index-based recovery
-# here keeps it (28-30).  Documented difference.
-KNOWN_DIFFERENT = [i for i, c in enumerate(CASES)
-                   if c['kind'] == 'overwrite' and len(c.get('flip', [])) > 1]
-
-
-@pytest.mark.parametrize('case', [c for i, c in enumerate(CASES) if i not in KNOWN_DIFFERENT],
-                         ids=[c['kind'] + str(i) for i, c in enumerate(CASES) if i not in KNOWN_DIFFERENT])
+@pytest.mark.parametrize('case', CASES, ids=[c['kind'] + str(i) for i, c in enumerate(CASES)])
 def test_missing_frames_and_bytes(case, tmp_path):
     from baseband_amd import vdif
     blob = _corrupt(case)
@@ -80,23 +72,25 @@ def test_locate_kernel_offsets(tmp_path):
     assert offs.tolist() == want
 
 
-def test_adjacent_damaged_headers(tmp_path):
-    """Both damaged frames and the one before them read as fill; every other
-    frame is recovered."""
+def test_adjacent_damaged_headers_drop_the_rest_of_the_set(tmp_path):
+    """Two adjacent headers damaged in place: like the reference, which finds no
+    header within two frames of the failure and gives up on the frame set
+    (vdif/base.py:655-690), the frame before them, the two damaged ones AND the
+    intact one after them (the last of that set) read as fill."""
     from baseband_amd import vdif
-    case = CASES[KNOWN_DIFFERENT[0]]
+    case = next(c for c in CASES if c['kind'] == 'overwrite' and len(c.get('flip', [])) > 1)
     p = tmp_path / 'corrupt.vdif'
     p.write_bytes(_corrupt(case).tobytes())
     full = load_expected('vdif_triple')
     with vdif.open(str(p), 'rs', squeeze=False) as fh:
         with pytest.warns(UserWarning, match='problem loading frame'):
             got = fh.read().cpu().numpy()
+    assert case['zeroed'] == [28, 29, 30, 31]
     want = full.copy()
-    for idx in (28, 29, 30):
+    for idx in case['zeroed']:
         s, t = divmod(idx, 8)
         want[s * 20000:(s + 1) * 20000, t] = 0.
     assert bits_equal(got, want)
-    assert set(case['zeroed']) == {28, 29, 30, 31}      # what the reference returns
 
 
 # ---- Mark 5B and Mark 4 (mark5b/tests/test_corrupt_files.py,
