@@ -1084,6 +1084,87 @@ def gen_gsb_writer():
     print(out['raw2_ts'].tobytes().decode())
 
 
+def gen_stream_fuzz():
+    """Random stream-API calls through the reference: for every sample file a
+    set of (squeeze, subset) openings and (seek, read) sequences; stored are
+    shapes and digests of what comes back (base/base.py:706-717,876-969)."""
+    rng = np.random.default_rng(20261002)
+    files = [
+        ('vdif', 'samples/sample.vdif', SAMPLE_VDIF, {}, (8, 1)),
+        ('vdif', 'samples/sample_arochime.vdif', SAMPLE_AROCHIME_VDIF,
+         dict(sample_rate=800. / 1024. / 2. * u.MHz), (2, 1024)),
+        ('vdif', 'samples/sample_mwa.vdif', SAMPLE_MWA_VDIF, dict(sample_rate=1.28 * u.MHz), (1, 2)),
+        ('mark5b', 'samples/sample.m5b', SAMPLE_MARK5B,
+         dict(kday=56000, nchan=8, sample_rate=32 * u.MHz), (8,)),
+        ('mark4', 'samples/sample.m4', SAMPLE_MARK4, dict(ntrack=64, decade=2010, sample_rate=32 * u.MHz), (8,)),
+        ('mark4', 'samples/sample_32track_fanout2.m4', SAMPLE_MARK4_32TRACK_FANOUT2,
+         dict(ntrack=32, decade=2010), (8,)),
+        ('dada', 'samples/sample.dada', SAMPLE_DADA, {}, (2, 1)),
+        ('guppi', 'samples/sample_puppi.raw', SAMPLE_PUPPI, {}, (2, 4)),
+    ]
+    mods = dict(vdif=vdif, mark5b=mark5b, mark4=mark4, dada=dada, guppi=guppi)
+
+    def pick(n):
+        kind = rng.integers(0, 4)
+        if n == 1 or kind == 0:
+            return None                                  # no selection on this axis
+        if kind == 1:
+            return int(rng.integers(0, n))
+        if kind == 2:
+            a = int(rng.integers(0, n - 1))
+            b = int(rng.integers(a + 1, n + 1))
+            return ['slice', a, b, int(rng.integers(1, 3))]
+        k = int(rng.integers(1, min(n, 4) + 1))
+        return [int(v) for v in rng.choice(n, size=k, replace=False)]
+
+    def decode(x):
+        return slice(x[1], x[2], x[3]) if isinstance(x, list) and x and x[0] == 'slice' else x
+
+    out = []
+    for fmt, rel, path, kw, shape in files:
+        for trial in range(6):
+            squeeze = bool(rng.integers(0, 2))
+            eff = tuple(d for d in shape if d > 1) if squeeze else shape
+            sub = []
+            for n in eff:
+                sub.append(pick(n))
+            while sub and sub[-1] is None:
+                sub.pop()
+            if any(v is None for v in sub):              # only trailing axes may be left out
+                sub = [v if v is not None else ['slice', 0, n, 1] for v, n in zip(sub, eff)]
+            # two list selections are broadcast together by numpy; keep at most one
+            seen_list = False
+            for i, v in enumerate(sub):
+                if isinstance(v, list) and v and v[0] != 'slice':
+                    if seen_list:
+                        sub[i] = int(v[0])
+                    seen_list = True
+            subset = tuple(decode(v) for v in sub)
+            kwargs = dict(kw, squeeze=squeeze, subset=subset)
+            try:
+                with mods[fmt].open(path, 'rs', **kwargs) as fh:
+                    n = fh.shape[0]
+                    ops = []
+                    for _ in range(4):
+                        off = int(rng.integers(0, n))
+                        cnt = int(rng.integers(1, min(n - off, 30000) + 1))
+                        fh.seek(off)
+                        d = fh.read(cnt)
+                        ops.append(dict(seek=off, count=cnt, shape=list(d.shape), sha256=sha(d),
+                                        tell=int(fh.tell())))
+                    case = dict(fmt=fmt, file=rel, squeeze=squeeze, subset=sub,
+                                shape=list(fh.shape), sample_shape=list(fh.sample_shape), ops=ops)
+            except Exception as exc:
+                case = dict(fmt=fmt, file=rel, squeeze=squeeze, subset=sub,
+                            error=type(exc).__name__)
+            out.append(case)
+    with open(os.path.join(GOLD, 'stream_fuzz_cases.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('stream fuzz:', len(out), 'cases;', sum('error' in c for c in out), 'raise in the reference')
+    for c in out[:8]:
+        print(c['fmt'], c['squeeze'], c['subset'], c.get('shape'), c.get('error'))
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1156,7 +1237,8 @@ if __name__ == '__main__':
              ('gsb', gen_gsb), ('vdif_corrupt', gen_vdif_corrupt),
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
-             ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer)]
+             ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer),
+             ('stream_fuzz', gen_stream_fuzz)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:
