@@ -1165,6 +1165,81 @@ def gen_stream_fuzz():
         print(c['fmt'], c['squeeze'], c['subset'], c.get('shape'), c.get('error'))
 
 
+def gen_item_fuzz():
+    """Random item access on payloads / frames / frame sets of the sample files
+    through the reference (base/payload.py:226-330, base/frame.py:191-199,
+    vdif/frame.py:402-434, mark4/frame.py:152-263, guppi/payload.py:104-133)."""
+    rng = np.random.default_rng(424242)
+
+    def rand_index(n):
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            return int(rng.integers(-n, n))
+        if kind == 1:
+            return ['slice', None, None, None]
+        a = int(rng.integers(0, n))
+        b = int(rng.integers(a, n + 1))
+        step = None if kind < 4 else int(rng.integers(2, 6))
+        return ['slice', a, b, step]
+
+    def rand_sub(n):
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            return int(rng.integers(0, n))
+        a = int(rng.integers(0, n))
+        b = int(rng.integers(a + 1, n + 1))
+        return ['slice', a, b, None]
+
+    def dec(x):
+        return slice(x[1], x[2], x[3]) if isinstance(x, list) else x
+
+    objs = []
+    with vdif.open(SAMPLE_VDIF, 'rb') as fh:
+        fr = fh.read_frame()
+        objs.append(('vdif_frame', 'samples/sample.vdif', fr))
+        objs.append(('vdif_payload', 'samples/sample.vdif', fr.payload))
+        fh.seek(0)
+        objs.append(('vdif_frameset', 'samples/sample.vdif', fh.read_frameset()))
+    with vdif.open(SAMPLE_AROCHIME_VDIF, 'rb') as fh:
+        objs.append(('vdif_frame', 'samples/sample_arochime.vdif', fh.read_frame()))
+    with vdif.open(SAMPLE_MWA_VDIF, 'rb') as fh:
+        objs.append(('vdif_payload', 'samples/sample_mwa.vdif', fh.read_frame().payload))
+    with mark5b.open(SAMPLE_MARK5B, 'rb', kday=56000, nchan=8) as fh:
+        objs.append(('mark5b_frame', 'samples/sample.m5b', fh.read_frame()))
+    with mark4.open(SAMPLE_MARK4, 'rb', ntrack=64, decade=2010) as fh:
+        fh.find_header()
+        objs.append(('mark4_frame', 'samples/sample.m4', fh.read_frame()))
+    with dada.open(SAMPLE_DADA, 'rb') as fh:
+        objs.append(('dada_frame', 'samples/sample.dada', fh.read_frame()))
+    with guppi.open(SAMPLE_PUPPI, 'rb') as fh:
+        fr = fh.read_frame(memmap=False)
+        objs.append(('guppi_frame', 'samples/sample_puppi.raw', fr))
+        objs.append(('guppi_payload', 'samples/sample_puppi.raw', fr.payload))
+    out = []
+    for kind, rel, obj in objs:
+        shape = obj.shape
+        items = []
+        for _ in range(12):
+            item = [rand_index(shape[0])]
+            for n in shape[1:]:
+                if rng.integers(0, 2):
+                    item.append(rand_sub(n))
+                else:
+                    break
+            key = tuple(dec(v) for v in item)
+            key = key[0] if len(key) == 1 and rng.integers(0, 2) else key
+            try:
+                d = np.asarray(obj[key])
+                items.append(dict(item=item, bare=not isinstance(key, tuple), shape=list(d.shape),
+                                  dtype=str(d.dtype), sha256=sha(np.ascontiguousarray(d))))
+            except Exception as exc:
+                items.append(dict(item=item, bare=not isinstance(key, tuple), error=type(exc).__name__))
+        out.append(dict(kind=kind, file=rel, shape=list(shape), items=items))
+    with open(os.path.join(GOLD, 'item_fuzz_cases.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('item fuzz:', [(c['kind'], c['shape'], sum('error' in i for i in c['items'])) for c in out])
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1238,7 +1313,7 @@ if __name__ == '__main__':
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
              ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer),
-             ('stream_fuzz', gen_stream_fuzz)]
+             ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

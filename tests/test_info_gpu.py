@@ -202,3 +202,53 @@ def test_stream_calls_match_reference(i):
             d = fh.read(op['count']).cpu().numpy()
             assert list(d.shape) == op['shape'] and fh.tell() == op['tell']
             assert hashlib.sha256(np.ascontiguousarray(d).tobytes()).hexdigest() == op['sha256']
+
+
+# ---- item access fuzz (payload / frame / frame set) ---------------------------
+with open(golden_path('item_fuzz_cases.json')) as _f:
+    ITEMS = json.load(_f)
+
+
+def _open_object(kind, path):
+    from baseband_amd import vdif, mark5b, mark4, dada, guppi
+    if kind.startswith('vdif'):
+        with vdif.open(path, 'rb') as fh:
+            if kind == 'vdif_frameset':
+                return fh.read_frameset()
+            fr = fh.read_frame()
+            return fr.payload if kind == 'vdif_payload' else fr
+    if kind == 'mark5b_frame':
+        with mark5b.open(path, 'rb', kday=56000, nchan=8) as fh:
+            return fh.read_frame()
+    if kind == 'mark4_frame':
+        with mark4.open(path, 'rb', ntrack=64, decade=2010) as fh:
+            fh.find_header()
+            return fh.read_frame()
+    if kind == 'dada_frame':
+        with dada.open(path, 'rb') as fh:
+            return fh.read_frame(memmap=False)
+    with guppi.open(path, 'rb') as fh:
+        fr = fh.read_frame(memmap=False)
+        return fr.payload if kind == 'guppi_payload' else fr
+
+
+@pytest.mark.parametrize('k', range(len(ITEMS)), ids=['%s-%d' % (c['kind'], k) for k, c in enumerate(ITEMS)])
+def test_item_access_matches_reference(k):
+    """obj[item] for random items (negative ints, open / stepped slices, channel
+    and thread sub-indices): shape, dtype and digest as in the reference."""
+    import hashlib
+    case = ITEMS[k]
+    obj = _open_object(case['kind'], golden_path(case['file']))
+    assert list(obj.shape) == case['shape']
+    for it in case['items']:
+        key = tuple(slice(v[1], v[2], v[3]) if isinstance(v, list) else v for v in it['item'])
+        key = key[0] if it['bare'] else key
+        if 'error' in it:
+            with pytest.raises(Exception):
+                obj[key]
+            continue
+        got = obj[key]
+        d = got.cpu().numpy() if hasattr(got, 'cpu') else np.asarray(got)
+        assert list(d.shape) == it['shape'], (it['item'], d.shape)
+        assert str(d.dtype) == it['dtype']
+        assert hashlib.sha256(np.ascontiguousarray(d).tobytes()).hexdigest() == it['sha256'], it['item']
