@@ -57,9 +57,20 @@ def main():
     nfr = nbytes // 8032
     out = torch.empty(nfr * 32000, dtype=torch.float32, device=dev)
     ms = timeit(lambda: kernels.decode_frames(buf, nfr, 8000, 0, 2, src0=32, src_stride=8032, out=out))
-    report('cfg1 VDIF 1 thread x 1 ch 2-bit real (k_decode_flat_pipe)', ms, nfr * 8032,
+    report('cfg1 VDIF 1 thread x 1 ch 2-bit real (k_decode_flat_aln)', ms, nfr * 8032,
            out.numel() * 4, out.numel(), nframes=nfr)
-    del out
+    # the same through the dense index, and with 1 % of the frames invalid
+    # (index entry -1 -> fill): SURVEY section 8d asks that the fill path cost nothing
+    src = torch.arange(nfr, device=dev, dtype=torch.int64) * 8032 + 32
+    ms = timeit(lambda: kernels.decode_frames(buf, nfr, 8000, 0, 2, src=src, out=out))
+    report('cfg1 through the index, all frames valid', ms, nfr * 8032, out.numel() * 4,
+           out.numel(), nframes=nfr)
+    bad = torch.rand(nfr, generator=g, device=dev) < 0.01
+    src1 = torch.where(bad, torch.full_like(src, -1), src)
+    ms = timeit(lambda: kernels.decode_frames(buf, nfr, 8000, 0, 2, src=src1, out=out))
+    report('cfg1 through the index, 1 % invalid frames (fill)', ms, nfr * 8032, out.numel() * 4,
+           out.numel(), nframes=nfr, invalid=int(bad.sum().item()))
+    del out, src, src1
 
     # cfg0-like: sample.vdif structure, 8 threads x 1 channel, 2-bit real, 5032-byte frames
     fn_, pn, nth = 5032, 5000, 8
