@@ -799,7 +799,9 @@ int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
     { const int rc_ = ensure_init(); if (rc_) return rc_; }
     const uint64_t nquad = nelem / 4;
     uint64_t blocks = (nquad / 256 + 3) / 4;              // one 256-quad run per wave
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    const int tbe = g_tune_blocks.load();
+    const uint64_t ecap = tbe > 0 ? (uint64_t)tbe : 256 * 16;
+    if (blocks > ecap) blocks = ecap;
     if (blocks == 0) blocks = 1;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;
