@@ -34,6 +34,7 @@ TUNE_BLOCKS = 2
 TUNE_NT_LOADS = 3
 TUNE_TILE_ELEMS = 4
 TUNE_ENCODE_DIRECT = 5
+TUNE_GATHER_BYTES = 6
 
 
 class BBError(RuntimeError):

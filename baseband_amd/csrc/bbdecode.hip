@@ -126,6 +126,14 @@ int device_levels(int coder, int lb, const float **p)
     return BB_OK;
 }
 
+// Persistent grids: measured optimum for all decode kernels is about 10^5
+// workgroups (profiles/r01f_exp_grid.log: flat 6.22 -> 6.41 TB/s, thread
+// interleave 5.84 -> 6.39, Mark 4 6.26 -> 6.37 against 4-16 thousand; one
+// workgroup per work item is 10-15 % slower).  Far more workgroups than the
+// ~4000 resident ones lets the dispatcher even out the tail, while each still
+// walks several items with its loads one item ahead.
+#define BB_GRID_CAP 131072ull
+
 // ---- tuning ----------------------------------------------------------------
 std::atomic<int> g_tune_variant{5};   // 5 = persistent pipelined kernel, 2 waves x long runs, aligned block loads
 std::atomic<int> g_tune_nt{1};
@@ -133,6 +141,7 @@ std::atomic<int> g_tune_blocks{0};
 std::atomic<int> g_tune_nt_loads{0};
 std::atomic<int> g_tune_tile_elems{8192};
 std::atomic<int> g_tune_encode_direct{0};
+std::atomic<int> g_tune_gather_bytes{8192};
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
@@ -235,6 +244,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
         case BB_TUNE_TILE_ELEMS:   g_tune_tile_elems = value > 0 ? value : 8192; return BB_OK;
         case BB_TUNE_ENCODE_DIRECT: g_tune_encode_direct = value; return BB_OK;
+        case BB_TUNE_GATHER_BYTES: g_tune_gather_bytes = value > 0 ? value : 8192; return BB_OK;
         default: return BB_EINVAL;
     }
 }
@@ -444,7 +454,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         ga.buf = a.buf; ga.src = d_src; ga.out = d_out; ga.tab = a.tab;
         ga.nframes = nframes; ga.ndw = a.ndw;
         ga.nslot = a.nslot; ga.chunk = a.chunk; ga.lchunk = a.lchunk;
-        uint32_t gt = (uint32_t)(16384 / ((size_t)p->nslot * 256));
+        uint32_t gt = (uint32_t)((size_t)g_tune_gather_bytes.load() / ((size_t)p->nslot * 256));
         if (gt < 1) gt = 1;
         if (gt > 32) gt = 32;
         if ((uint64_t)gt > ntiles) gt = (uint32_t)ntiles;
@@ -458,8 +468,12 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         }
         ga.aligned = (g_tune_variant.load() >= 5 && ((uintptr_t)d_buf & 255) == 0) ? 1 : 0;
         const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024;
+        // persistent grid: a workgroup walks about five work items (8 KiB of
+        // payload each); one workgroup per item costs 15 %, a few thousand
+        // long-running ones 5-10 % (profiles/r01f_exp_gather*.log)
         uint64_t gb = (uint64_t)nframes * ga.ngroup;
-        if (tb > 0 && gb > (uint64_t)tb) gb = (uint64_t)tb;
+        const uint64_t gcap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
+        if (gb > gcap) gb = gcap;
         if (gb > 0x7fffffffull) gb = 0x7fffffffull;
         const dim3 gg((unsigned)gb);
         switch (p->bps) {
@@ -486,7 +500,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.tpw = a.seg_tiles;
         const uint64_t sgroups = ((uint64_t)p->nslot + nw - 1) / nw;
         uint64_t b2 = (uint64_t)nframes * a.nseg * sgroups;
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : (uint64_t)(16384 / nw);
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
         switch (p->bps) {
@@ -507,7 +521,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // 2 waves x 16 tiles per item whatever the frame size
         const uint64_t tiles_all = (nfs * a.ndw + 63) / 64;
         uint64_t b2 = (tiles_all + 31) / 32;
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : 16384ull;
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
         switch (p->bps) {
@@ -536,7 +550,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
         a.tpw = (a.seg_tiles + nw - 1) / nw;
         uint64_t b2 = nfs * a.nseg;
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : (uint64_t)(wide ? 16384 : 4096);
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : (uint64_t)(wide ? BB_GRID_CAP : 4096);
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
         if (!wide) {
@@ -691,7 +705,7 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
     a.hi = h_levels[BB_CODER_VDIF][1][3];
     uint64_t blocks = (uint64_t)nframes * a.nseg;
     const int tb = g_tune_blocks.load();
-    const uint64_t cap = tb > 0 ? (uint64_t)tb : 4096;      // persistent grid
+    const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;      // persistent grid
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;
