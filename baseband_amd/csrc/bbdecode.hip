@@ -813,8 +813,11 @@ int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
     { const int rc_ = ensure_init(); if (rc_) return rc_; }
     const uint64_t nquad = nelem / 4;
     uint64_t blocks = (nquad / 256 + 3) / 4;              // one 256-quad run per wave
+    // one run per wave and as many workgroups as that takes: the encoder is a
+    // streaming read without a software pipeline, the dispatcher overlaps it
+    // best (profiles/r01g_exp_encode_grid.log: 4.7 -> 5.6 TB/s against 4096)
     const int tbe = g_tune_blocks.load();
-    const uint64_t ecap = tbe > 0 ? (uint64_t)tbe : 256 * 16;
+    const uint64_t ecap = tbe > 0 ? (uint64_t)tbe : 0x7fffffffull;
     if (blocks > ecap) blocks = ecap;
     if (blocks == 0) blocks = 1;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
@@ -857,8 +860,12 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
     memcpy(a.sign_bit, sign_bit, opw);
     memcpy(a.mag_bit, mag_bit, opw);
     const uint64_t nquad = (uint64_t)nwords * (ntrack / 8);
-    uint64_t blocks = (nquad + BB_BLOCK - 1) / BB_BLOCK;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    // four quads per lane (measured optimum, profiles/r01g_exp_encode_grid.log)
+    uint64_t blocks = (nquad + 4 * BB_BLOCK - 1) / (4 * BB_BLOCK);
+    const int tbm = g_tune_blocks.load();
+    const uint64_t mcap = tbm > 0 ? (uint64_t)tbm : 0x7fffffffull;
+    if (blocks > mcap) blocks = mcap;
+    if (blocks == 0) blocks = 1;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     { const int rc_ = ensure_init(); if (rc_) return rc_; }
