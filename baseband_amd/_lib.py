@@ -35,6 +35,7 @@ TUNE_NT_LOADS = 3
 TUNE_TILE_ELEMS = 4
 TUNE_ENCODE_DIRECT = 5
 TUNE_GATHER_BYTES = 6
+TUNE_TILES_PER_WAVE = 7
 
 
 class BBError(RuntimeError):

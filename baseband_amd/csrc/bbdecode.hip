@@ -142,6 +142,7 @@ std::atomic<int> g_tune_nt_loads{0};
 std::atomic<int> g_tune_tile_elems{8192};
 std::atomic<int> g_tune_encode_direct{0};
 std::atomic<int> g_tune_gather_bytes{8192};
+std::atomic<int> g_tune_tpw{12};
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
@@ -244,6 +245,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
         case BB_TUNE_TILE_ELEMS:   g_tune_tile_elems = value > 0 ? value : 8192; return BB_OK;
         case BB_TUNE_ENCODE_DIRECT: g_tune_encode_direct = value; return BB_OK;
+        case BB_TUNE_TILES_PER_WAVE: g_tune_tpw = (value >= 1 && value <= 16) ? value : 12; return BB_OK;
         case BB_TUNE_GATHER_BYTES: g_tune_gather_bytes = value > 0 ? value : 8192; return BB_OK;
         default: return BB_EINVAL;
     }
@@ -540,11 +542,13 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     if (g_tune_variant.load() >= 2) {
         // persistent pipelined form.  Geometry (waves per workgroup x tiles
         // per wave) is chosen so that a wave writes a long contiguous run:
-        // 2 waves x 16 tiles (64 KiB per wave at 2 bits).  Variant 2 keeps the
+        // 2 waves x up to 12 tiles (an 8000-byte payload becomes two items of
+        // 2 x 8 tiles = 32 KiB runs; with the large grid that beats 2 x 16 by
+        // 1.5 %, profiles/r01g_exp_tpw.log).  Variant 2 keeps the
         // 4 x 8 geometry; 2 x 32 tiles was tried for 8-bit data and lost 27 %.
         const bool wide = g_tune_variant.load() >= 3;
         const int nw = wide ? 2 : 4;
-        const int tpw_max = wide ? 16 : 8;
+        const int tpw_max = wide ? g_tune_tpw.load() : 8;
         const uint64_t seg_max = (uint64_t)nw * tpw_max;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
