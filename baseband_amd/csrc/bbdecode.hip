@@ -496,7 +496,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // waves on the same 8 tiles (k_decode_rows_pipe)
         const int nw = p->nslot >= 8 ? 8 : (p->nslot >= 4 ? 4 : 2);
         const bool aln = g_tune_variant.load() >= 5 && ((uintptr_t)d_buf & 255) == 0;
-        const uint64_t seg_max = 8;
+        const uint64_t seg_max = g_tune_tpw.load() < 8 ? (uint64_t)g_tune_tpw.load() : 8;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
         a.tpw = a.seg_tiles;
