@@ -38,6 +38,22 @@ __global__ void k_fill(f4 *p, size_t n)
     }
 }
 
+// Fill in "runs": a wave owns run r = wave + k * nwaves of RUN_KIB KiB and
+// writes it 1 KiB per store instruction; threads per workgroup = blockDim.
+template <int RUN_KIB>
+__global__ void k_fill_runs(f4 *p, size_t nrun)
+{
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwave = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const f4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t r = wave; r < nrun; r += nwave) {
+        f4 *q = p + r * (RUN_KIB * 64) + lane;
+#pragma unroll 8
+        for (int k = 0; k < RUN_KIB; ++k) __builtin_nontemporal_store(v, q + 64 * k);
+    }
+}
+
 __global__ void k_copy(const f4 *s, f4 *d, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,6 +123,49 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const double alg_bytes = (double)in_bytes + (double)out_elems * 4;
 
+    // the fill bound against the grid size (grid-stride float4 fill, nt stores)
+    for (unsigned gridsz : {2048u, 8192u, 32768u, 131072u, 524288u, 2097152u}) {
+        std::vector<double> t;
+        for (int r = 0; r < reps + 1; ++r) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_fill<true>, dim3(gridsz), dim3(256), 0, 0, (f4 *)d_out, out_elems / 4);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            if (r) t.push_back(time_ms(e0, e1));
+        }
+        std::sort(t.begin(), t.end());
+        printf("fill nt=1 grid=%u: median %.3f ms  %.1f GB/s\n", gridsz, t[t.size() / 2],
+               out_elems * 4 / t[t.size() / 2] / 1e6);
+    }
+    // fill by runs: run length x threads per workgroup x grid
+    if (getenv("KB_RUNS")) {
+        for (int run_kib : {1, 4, 16, 32, 64}) {
+            for (int threads : {64, 128, 256}) {
+                for (unsigned gridsz : {4096u, 32768u, 131072u, 524288u, 2097152u, 0u}) {
+                    const size_t nrun = out_elems * 4 / ((size_t)run_kib * 1024);
+                    size_t need = (nrun * 64 + threads - 1) / threads;
+                    unsigned g = gridsz ? gridsz : (unsigned)std::min<size_t>(need, 0x7fffffff);
+                    if (gridsz && (size_t)gridsz > need) continue;
+                    std::vector<double> t;
+                    for (int r = 0; r < 4; ++r) {
+                        CK(hipEventRecord(e0));
+                        switch (run_kib) {
+                            case 1:  hipLaunchKernelGGL(k_fill_runs<1>, dim3(g), dim3(threads), 0, 0, (f4 *)d_out, nrun); break;
+                            case 4:  hipLaunchKernelGGL(k_fill_runs<4>, dim3(g), dim3(threads), 0, 0, (f4 *)d_out, nrun); break;
+                            case 16: hipLaunchKernelGGL(k_fill_runs<16>, dim3(g), dim3(threads), 0, 0, (f4 *)d_out, nrun); break;
+                            case 32: hipLaunchKernelGGL(k_fill_runs<32>, dim3(g), dim3(threads), 0, 0, (f4 *)d_out, nrun); break;
+                            default: hipLaunchKernelGGL(k_fill_runs<64>, dim3(g), dim3(threads), 0, 0, (f4 *)d_out, nrun); break;
+                        }
+                        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                        if (r) t.push_back(time_ms(e0, e1));
+                    }
+                    std::sort(t.begin(), t.end());
+                    printf("fill_runs run=%dKiB threads=%d grid=%u%s: %.3f ms  %.1f GB/s\n", run_kib, threads, g,
+                           gridsz ? "" : " (one run per wave)", t[t.size() / 2], out_elems * 4 / t[t.size() / 2] / 1e6);
+                }
+            }
+        }
+        return 0;
+    }
     // bounds: fill and copy
     for (int nt = 0; nt < 2; ++nt) {
         std::vector<double> t;
