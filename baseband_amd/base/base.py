@@ -78,6 +78,113 @@ class VLBIFileReaderBase(FileBase):
             self._image = host_image(self.fh_raw)
         return self._image
 
+    # -- masked byte-pattern search (base/base.py:181-368)
+    @staticmethod
+    def _as_bytes(value):
+        """Pattern or mask given as header words, bytes, an int or ints
+        (unsigned 32-bit, little endian), or a uint8 array -> uint8 array."""
+        if isinstance(value, (bytes, bytearray)):
+            return np.frombuffer(bytes(value), np.uint8)
+        arr = np.asanyarray(value)
+        if arr.dtype == np.uint8:
+            return np.ascontiguousarray(arr).reshape(-1)
+        return np.atleast_1d(arr).astype('<u4').view(np.uint8)
+
+    def locate_frames(self, pattern, *, mask=None, frame_nbytes=None, offset=0,
+                      forward=True, maximum=None, check=1):
+        """Frame starts near the current position, nearest first, at which the
+        (masked) byte `pattern` sits `offset` bytes into the frame, whose frame
+        fits in the file, and for which the pattern is also found `check` frames
+        away wherever that position can be looked at.
+
+        Same arguments and results as the reference's
+        ``VLBIFileReaderBase.locate_frames`` (base/base.py:181-335): `pattern`
+        may be a header (its invariant pattern and frame size are used), bytes,
+        a uint8 / masked array, an int or ints (32-bit little-endian words);
+        `maximum` defaults to two frames (minus one byte), or 10^6 bytes when no
+        frame size is known.  The search is a vectorised compare over the
+        memory-mapped file, leading byte first.
+        """
+        if hasattr(pattern, 'invariant_pattern'):
+            if frame_nbytes is None:
+                frame_nbytes = pattern.frame_nbytes
+            pattern, mask = pattern.invariant_pattern()
+        if isinstance(pattern, np.ma.MaskedArray):
+            if mask is None:
+                mask = np.where(np.ma.getmaskarray(pattern), 0, 0xff).astype(np.uint8)
+            pattern = pattern.filled(0)
+        pat = self._as_bytes(pattern)
+        msk = None
+        if mask is not None:
+            msk = self._as_bytes(mask)
+            used = np.nonzero(msk)[0]
+            span = slice(used[0], used[-1] + 1)
+            pat, msk = pat[span], msk[span]
+            offset += span.start
+        if maximum is None:
+            maximum = (2 * frame_nbytes if frame_nbytes else 1000000) - 1
+        if check is None or frame_nbytes is None:
+            checks = np.zeros(0, dtype=np.int64)
+        else:
+            checks = np.atleast_1d(check).astype(np.int64) * frame_nbytes
+        check_min = min(int(checks.min()) if checks.size else 0, 0)
+        check_max = max(int(checks.max()) if checks.size else 0, 0)
+        need = frame_nbytes if frame_nbytes is not None else offset + pat.size
+
+        image = self.image()
+        here = self.fh_raw.tell()
+        seek_start = here if forward else here - maximum
+        # bytes that may be looked at: from the earliest check position to the
+        # end of the last candidate frame and its latest check pattern
+        start = max(seek_start + offset + check_min, 0)
+        stop = min(max(seek_start + maximum + 1 + check_max + need, start), len(image))
+        size = min(maximum + 1 + check_max - check_min, stop - start - pat.size)
+        if size <= 0:
+            return []
+        data = np.asarray(image[start:start + size + pat.size])
+
+        def matches_at(lo, hi):
+            """Pattern positions (in `data`) within [lo, hi): first byte, then the rest."""
+            first = data[lo:hi]
+            hit = (first == pat[0]) if msk is None else (((first ^ pat[0]) & msk[0]) == 0)
+            idx = np.nonzero(hit)[0] + lo
+            for k in range(1, pat.size):
+                if idx.size == 0:
+                    break
+                col = data[idx + k]
+                ok = (col == pat[k]) if msk is None else (((col ^ pat[k]) & msk[k]) == 0)
+                idx = idx[ok]
+            return idx
+
+        found = matches_at(0, size) + (start - offset)        # frame starts
+        found_set = set(found.tolist())
+        loc_lo = max(seek_start, 0)
+        loc_hi = min(seek_start + maximum + 1, stop - need + 1)
+        check_lo, check_hi = start, stop - offset - pat.size
+        out = [int(loc) for loc in found.tolist()
+               if loc_lo <= loc < loc_hi
+               and all((int(loc + c) in found_set) for c in checks.tolist()
+                       if check_lo <= loc + c < check_hi)]
+        return out if forward else out[::-1]
+
+    def find_header(self, *args, **kwargs):
+        """Nearest header from the current position (arguments as for
+        `locate_frames`); the file pointer is left at its start
+        (base/base.py:337-368)."""
+        for location in self.locate_frames(*args, **kwargs):
+            with self.temporary_offset(location):
+                try:
+                    header = self.read_header()
+                except Exception:
+                    continue
+            if self._accept_header(header):
+                self.fh_raw.seek(location)
+                return header
+        raise HeaderNotFoundError('could not locate a a nearby frame.')
+
+    def _accept_header(self, header):
+        return True
+
     # name used in `info.format`; constructor arguments a reader may lack
     _format = None
 

@@ -114,8 +114,8 @@ class FileReaderInfo(_Snapshot):
         self.readable = bool(self.checks) and all(bool(v) for v in self.checks.values())
 
     def _first_header(self, reader):
-        if hasattr(reader, 'find_header'):
-            header = reader.find_header()
+        if getattr(reader, '_info_find_kwargs', None) is not None:
+            header = reader.find_header(**reader._info_find_kwargs)
             self._offset0 = reader.tell()
             return header
         return reader.read_header()
@@ -148,8 +148,8 @@ class FileReaderInfo(_Snapshot):
         if 'nchan' in self.missing:
             return
         try:
-            if hasattr(reader, 'find_header'):
-                reader.find_header()
+            if getattr(reader, '_info_find_kwargs', None) is not None:
+                reader.find_header(**reader._info_find_kwargs)
             frame = reader.read_frame()
             frame[0]
             self.checks['decodable'] = True

@@ -27,6 +27,7 @@ __all__ = ['Mark4FileReader', 'Mark4StreamReader', 'Mark4StreamWriter', 'open', 
 
 class Mark4FileReader(VLBIFileReaderBase):
     _format = 'mark4'
+    _info_find_kwargs = {}                  # the first frame may start anywhere
 
     def _info_needs(self):
         if self.decade is None and self.ref_time is None:
@@ -67,55 +68,30 @@ class Mark4FileReader(VLBIFileReaderBase):
         w = np.frombuffer(image[o + 63 * isz:o + 96 * isz].tobytes(), dtype=dt)
         return bool(w[0] == 0 and np.all(w[1:] == np.iinfo(dt).max))
 
-    def locate_frames(self, maximum=None, forward=True, check=1):
-        """Offsets of frames near the current position, nearest first: a sync
-        pattern with another one `check` frames away when that lies inside
-        the file (mark4/base.py:110-166, base/base.py:181-335)."""
+    def locate_frames(self, pattern=None, *, mask=None, frame_nbytes=None, offset=0,
+                      forward=True, maximum=None, check=1):
+        """As `VLBIFileReaderBase.locate_frames`; by default the Mark 4 sync
+        pattern of all tracks plus the zero bit before it, for the reader's
+        `ntrack` (found with `determine_ntrack` if not known): stream word 63
+        zero, words 64-95 all ones (mark4/base.py:110-166)."""
         ntrack = self.ntrack
-        if ntrack is None:
-            with self.temporary_offset(0):
-                ntrack = self.determine_ntrack(maximum=maximum)
-        fn = ntrack * 2500
-        isz = ntrack // 8
-        image = self.image()
-        pos = self.fh_raw.tell()
-        if maximum is None:
-            maximum = 2 * fn
-        # all-ones run detection on the byte image, then confirm per candidate
-        lo = max(0, pos - (0 if forward else maximum))
-        hi = min(len(image), pos + (maximum if forward else 0) + 96 * isz)
-        seg = np.asarray(image[lo:hi])
-        ones = seg == 0xff
-        run = 32 * isz
-        if len(seg) < run + 64 * isz:
-            return []
-        c = np.concatenate([[0], np.cumsum(ones)])
-        full = np.nonzero(c[run:] - c[:-run] == run)[0]      # start of all-ones runs
-        cands = full + lo - 64 * isz
-        out = []
-        checks = (check,) if isinstance(check, int) else tuple(check)
-        for o in cands:
-            o = int(o)
-            if o < lo or o > (pos + maximum if forward else pos):
-                continue
-            if o + fn > len(image):              # the frame has to fit completely
-                continue
-            if not self._sync_at(image, o, ntrack):
-                continue
-            if all(self._sync_at(image, o + k * fn, ntrack)
-                   or o + k * fn < 0 or o + k * fn + 96 * isz > len(image)
-                   for k in checks):
-                out.append(o)
-        out.sort(key=lambda o: abs(o - pos))
-        return out
-
-    def find_header(self, forward=True, maximum=None, check=1):
-        locations = self.locate_frames(forward=forward, maximum=maximum, check=check)
-        if not locations:
-            raise HeaderNotFoundError('could not locate a a nearby frame.')
-        self.fh_raw.seek(locations[0])
-        with self.temporary_offset():
-            return self.read_header()
+        if frame_nbytes is None:
+            if ntrack is None:
+                with self.temporary_offset(0):
+                    ntrack = self.determine_ntrack(maximum=maximum)
+            frame_nbytes = ntrack * 2500
+        else:
+            ntrack, resid = divmod(frame_nbytes, 2500)
+            if resid:
+                raise ValueError('frame_nbytes must be a multiple of '
+                                 '2500 bytes for Mark 4 data.')
+        if pattern is None:
+            isz = ntrack // 8
+            pattern = np.concatenate([np.zeros(isz, np.uint8), np.full(32 * isz, 0xff, np.uint8)])
+            offset = offset + 63 * isz
+        return super().locate_frames(pattern, mask=mask, frame_nbytes=frame_nbytes,
+                                     offset=offset, forward=forward, maximum=maximum,
+                                     check=check)
 
     def determine_ntrack(self, maximum=None):
         """Try 16, 32 and 64 tracks (mark4/base.py:168-207)."""

@@ -29,6 +29,7 @@ SYNC = 0xABADDEED
 
 class Mark5BFileReader(VLBIFileReaderBase):
     _format = 'mark5b'
+    _info_find_kwargs = {}                  # the first frame may start anywhere
 
     def _info_needs(self):
         needs = {}
@@ -61,56 +62,17 @@ class Mark5BFileReader(VLBIFileReaderBase):
                                     sample_shape=(self.nchan,), bps=self.bps,
                                     verify=verify)
 
-    def locate_frames(self, lo, hi, check=(1,)):
-        """Offsets p in [lo, hi] that hold a frame: sync word at p, the whole
-        frame fits in the file, a correct time-code CRC, and a sync word
-        `check` frames away wherever that still lies inside the file --
-        locate_frames + the CRC gate of find_header (base/base.py:181-335,
-        mark5b/base.py:136-155).  Ascending."""
-        image = self.image()
-        n = len(image)
-        lo, hi = max(0, lo), min(hi, n - FRAME_NBYTES)
-        if hi < lo:
-            return []
-        seg = np.asarray(image[lo:hi + 4])
-        sync = np.array([SYNC], '<u4').view(np.uint8)
-        hit = seg[:hi - lo + 1] == sync[0]
-        for k in (1, 2, 3):
-            hit &= seg[k:k + hi - lo + 1] == sync[k]
+    def locate_frames(self, pattern=None, **kwargs):
+        """As `VLBIFileReaderBase.locate_frames`, with the Mark 5B sync word and
+        frame size by default (mark5b/base.py:126-134)."""
+        if pattern is None:
+            pattern = np.array([SYNC], '<u4').view(np.uint8)
+            kwargs.setdefault('frame_nbytes', FRAME_NBYTES)
+        return super().locate_frames(pattern, **kwargs)
 
-        def sync_at(q):
-            return bytes(image[q:q + 4]) == sync.tobytes()
-
-        found = []
-        for p in (np.flatnonzero(hit) + lo).tolist():
-            if any(0 <= p + c * FRAME_NBYTES and p + c * FRAME_NBYTES + 4 <= n
-                   and not sync_at(p + c * FRAME_NBYTES) for c in check):
-                continue
-            words = np.frombuffer(bytes(image[p:p + 16]), '<u4')
-            if crc16_mark5b(words) != (int(words[3]) & 0xffff):
-                continue
-            found.append(p)
-        return found
-
-    def _header_at(self, offset):
-        words = np.frombuffer(bytes(self.image()[offset:offset + 16]), '<u4')
-        return Mark5BHeader(words, kday=self.kday, ref_time=self.ref_time)
-
-    def find_header(self, maximum=2 * FRAME_NBYTES, forward=True, check=(1,)):
-        """Nearest frame at or after (before, with ``forward=False``) the
-        current position; the file pointer is left at its start."""
-        pos = self.fh_raw.tell()
-        found = (self.locate_frames(pos, pos + maximum, check) if forward
-                 else self.locate_frames(pos - maximum, pos, check)[::-1])
-        for offset in found:
-            try:
-                header = self._header_at(offset)
-                header.jday, header.seconds
-            except Exception:
-                continue
-            self.fh_raw.seek(offset)
-            return header
-        raise HeaderNotFoundError('could not locate a a nearby frame.')
+    def _accept_header(self, header):
+        """find_header also wants a correct time-code CRC (mark5b/base.py:136-155)."""
+        return crc16_mark5b(header.words) == header['crc']
 
     def get_frame_rate(self):
         """Largest frame number within the first second plus one
@@ -196,8 +158,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         size = len(self._image())
         with self.fh_raw.temporary_offset(max(0, size - FRAME_NBYTES)):
             try:
-                header = self.fh_raw.find_header(maximum=2 * FRAME_NBYTES - 1,
-                                                 forward=False, check=(-1, 1))
+                header = self.fh_raw.find_header(forward=False, check=(-1, 1))
             except HeaderNotFoundError as exc:
                 exc.args += ("corrupt VLBI frame? No frame in last {0} bytes."
                              .format(2 * FRAME_NBYTES),)

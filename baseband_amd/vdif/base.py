@@ -28,6 +28,7 @@ __all__ = ['VDIFFileReader', 'VDIFFileWriter', 'VDIFStreamReader', 'VDIFStreamWr
 class VDIFFileReader(VLBIFileReaderBase):
     """Simple reader for VDIF files: headers, frames, frame sets."""
     _format = 'vdif'
+    _info_find_kwargs = {'maximum': 0}      # only at the start (vdif/file_info.py:24-30)
 
     def _info_extras(self, header0, offset0):
         """edv, thread ids and number of frame sets (vdif/file_info.py:10-50)."""
@@ -49,26 +50,44 @@ class VDIFFileReader(VLBIFileReaderBase):
         return VDIFFrameSet.fromfile(self.fh_raw, thread_ids, edv=edv,
                                      verify=verify)
 
-    def find_header(self):
-        """Header at the current position, accepted only when a header with the
-        same stream invariants sits one frame later (if the file is that
-        long): almost any bytes parse as a VDIF header, so this is the sanity
-        check format detection needs (vdif/file_info.py:24-30)."""
-        pos = self.fh_raw.tell()
-        with self.temporary_offset():
-            header = self.read_header()
-        pattern, mask = header.invariant_pattern()
-        image = self.image()
-        nxt = pos + header.frame_nbytes
-        if header.frame_nbytes < header.nbytes + 4:
-            raise HeaderNotFoundError('could not locate a a nearby frame.')
-        if nxt + header.nbytes <= len(image):
-            words = np.frombuffer(bytes(image[nxt:nxt + header.nbytes]), '<u4')
-            if any((int(w) ^ int(p)) & int(m) for w, p, m in zip(words, pattern, mask)):
+    def find_header(self, pattern=None, *, edv=None, mask=None, frame_nbytes=None,
+                    offset=0, forward=True, maximum=None, check=1):
+        """Nearest header from the current position (vdif/base.py:216-316).
+
+        With a `pattern` (normally a header of the stream: its invariant bits
+        and frame size are used) this is a masked byte search
+        (`locate_frames`).  Without one, a header is read at every position --
+        almost any bytes parse as a VDIF header -- and accepted when the same
+        stream invariants are found `check` frames away."""
+        if pattern is not None:
+            locations = self.locate_frames(pattern, mask=mask, frame_nbytes=frame_nbytes,
+                                           offset=offset, forward=forward, maximum=maximum,
+                                           check=check)
+            if not locations:
                 raise HeaderNotFoundError('could not locate a a nearby frame.')
-        elif nxt != len(image):
-            raise HeaderNotFoundError('could not locate a a nearby frame.')
-        return header
+            self.fh_raw.seek(locations[0])
+            with self.temporary_offset():
+                return self.read_header(edv=getattr(pattern, 'edv', None))
+        if maximum is None:
+            maximum = 10000 if frame_nbytes is None else 2 * frame_nbytes
+        here = self.fh_raw.tell()
+        positions = (range(here, here + maximum + 1) if forward
+                     else range(here, max(here - maximum - 1, -1), -1))
+        for pos in positions:
+            self.fh_raw.seek(pos)
+            try:
+                header = self.read_header(edv=edv)
+            except Exception:
+                continue
+            if frame_nbytes is not None and frame_nbytes != header.frame_nbytes:
+                continue
+            self.fh_raw.seek(pos)
+            try:
+                return self.find_header(header, maximum=0, check=check)
+            except Exception:
+                continue
+        self.fh_raw.seek(here)
+        raise HeaderNotFoundError("could not locate a nearby header.")
 
     def _header_table(self, header0, offset=0):
         """(nframes, nwords) view of all headers at the fixed frame stride."""

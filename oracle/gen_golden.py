@@ -1240,6 +1240,76 @@ def gen_item_fuzz():
     print('item fuzz:', [(c['kind'], c['shape'], sum('error' in i for i in c['items'])) for c in out])
 
 
+def gen_locate():
+    """locate_frames / find_header of the reference (base/base.py:181-368,
+    vdif/base.py:216-316, mark5b/base.py:126-155, mark4/base.py:110-166) at the
+    positions its own tests probe plus random ones; stored: the calls and the
+    returned locations / header offsets."""
+    rng = np.random.default_rng(99)
+    out = {}
+
+    def probe(fh, n, header0, calls, kwlist):
+        for kw in kwlist:
+            for pos in [0, 10, 16, n - 20, n] + [int(v) for v in rng.integers(0, n, 12)]:
+                fh.seek(pos)
+                args = (header0,) if header0 is not None else ()
+                try:
+                    loc = fh.locate_frames(*args, **kw)
+                except Exception as exc:
+                    loc = type(exc).__name__
+                fh.seek(pos)
+                try:
+                    fh.find_header(*args, **{k: v for k, v in kw.items()})
+                    found = fh.tell()
+                except Exception as exc:
+                    found = type(exc).__name__
+                calls.append(dict(pos=pos, kwargs={k: (list(v) if isinstance(v, tuple) else v)
+                                                   for k, v in kw.items()},
+                                  locations=loc, found=found))
+
+    kws = [dict(), dict(forward=False), dict(check=(-1, 1)), dict(forward=False, check=(-1, 1)),
+           dict(maximum=20000), dict(forward=False, maximum=30000, check=(1, 2)), dict(check=None),
+           dict(maximum=0)]
+    with vdif.open(SAMPLE_VDIF, 'rb') as fh:
+        header0 = vdif.VDIFHeader.fromfile(fh)
+        n = fh.seek(0, 2)
+        calls = []
+        probe(fh, n, header0, calls, kws)
+        # explicit pattern / mask / offset forms (vdif/tests/test_vdif.py:694-727)
+        extra = []
+        fh.seek(0)
+        extra.append(dict(pos=0, form='sync', locations=fh.locate_frames(pattern=header0['sync_pattern'], offset=20)))
+        fh.seek(0, 2)
+        extra.append(dict(pos=n, form='sync_back',
+                          locations=fh.locate_frames(pattern=header0['sync_pattern'], offset=20, forward=False)))
+        fh.seek(10)
+        mask = [0, 0, 0xffffffff, 0xfc00ffff, 0xffffffff, 0, 0, 0]
+        extra.append(dict(pos=10, form='words_mask',
+                          locations=fh.locate_frames(pattern=header0.words, mask=mask, frame_nbytes=5032)))
+        out['vdif'] = dict(file='samples/sample.vdif', calls=calls, extra=extra)
+    blob = open(SAMPLE_VDIF, 'rb').read()
+    gap = blob[:5100] + blob[10000:]
+    with vdif.open(io.BytesIO(gap), 'rb') as fh:
+        calls = []
+        probe(fh, len(gap), header0, calls, kws[:4])
+        out['vdif_gap'] = dict(file='samples/sample.vdif', cut=[5100, 10000], calls=calls)
+    with mark5b.open(SAMPLE_MARK5B, 'rb', kday=56000, nchan=8) as fh:
+        n = fh.seek(0, 2)
+        calls = []
+        probe(fh, n, None, calls, kws)
+        out['mark5b'] = dict(file='samples/sample.m5b', calls=calls)
+    with mark4.open(SAMPLE_MARK4, 'rb', ntrack=64, decade=2010) as fh:
+        n = fh.seek(0, 2)
+        calls = []
+        probe(fh, n, None, calls, [dict(), dict(forward=False), dict(check=(-1, 1)), dict(maximum=400000),
+                                   dict(forward=False, maximum=400000), dict(check=None)])
+        out['mark4'] = dict(file='samples/sample.m4', calls=calls)
+    with open(os.path.join(GOLD, 'locate_cases.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('locate:', {k: len(v['calls']) for k, v in out.items()})
+    print(out['vdif']['extra'])
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1313,7 +1383,7 @@ if __name__ == '__main__':
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
              ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer),
-             ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz)]
+             ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz), ('locate', gen_locate)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

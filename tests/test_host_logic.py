@@ -424,3 +424,64 @@ def test_block_headers_serialize_like_the_reference():
     src = open(golden_path('samples/sample_puppi.raw'), 'rb').read()
     hs = GUPPIHeader.fromfile(io.BytesIO(src))
     assert image(hs) == src[:hs.nbytes] and image(hs.copy()) == src[:hs.nbytes]
+
+
+def test_locate_frames_and_find_header_match_reference():
+    """locate_frames / find_header (base/base.py:181-368 and the VDIF, Mark 5B,
+    Mark 4 overrides) at fixed and random positions, forward / backward, with
+    check tuples, maxima and explicit patterns: locations as the reference
+    returns them (tests/golden/locate_cases.json, oracle/gen_golden.py `locate`)."""
+    import io
+    import json
+    from baseband_amd import vdif, mark5b, mark4
+    from baseband_amd.base.base import HeaderNotFoundError
+    with open(golden_path('locate_cases.json')) as f:
+        gold = json.load(f)
+
+    def run(fh, calls, header0):
+        args = (header0,) if header0 is not None else ()
+        for c in calls:
+            kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in c['kwargs'].items()}
+            fh.seek(c['pos'])
+            assert fh.locate_frames(*args, **kw) == c['locations'], (c['pos'], kw)
+            fh.seek(c['pos'])
+            try:
+                fh.find_header(*args, **kw)
+                found = fh.tell()
+            except HeaderNotFoundError:
+                found = 'HeaderNotFoundError'
+            assert found == c['found'], (c['pos'], kw)
+
+    path = golden_path('samples/sample.vdif')
+    with vdif.open(path, 'rb') as fh:
+        header0 = fh.read_header()
+        run(fh, gold['vdif']['calls'], header0)
+        mask = [0, 0, 0xffffffff, 0xfc00ffff, 0xffffffff, 0, 0, 0]
+        for e in gold['vdif']['extra']:
+            fh.seek(e['pos'])
+            got = {'sync': lambda: fh.locate_frames(pattern=header0['sync_pattern'], offset=20),
+                   'sync_back': lambda: fh.locate_frames(pattern=header0['sync_pattern'], offset=20,
+                                                         forward=False),
+                   'words_mask': lambda: fh.locate_frames(pattern=header0.words, mask=mask,
+                                                          frame_nbytes=5032)}[e['form']]()
+            assert got == e['locations']
+        # masked-array pattern (vdif/tests/test_vdif.py:706-713)
+        fh.seek(0, 2)
+        pat = np.ma.MaskedArray(np.array(header0.words[3:6], '<u4').view('u1'),
+                                [False, False, True, True] + [False] * 8)
+        assert fh.locate_frames(pattern=pat, offset=12, forward=False) == [x * 5032 for x in range(15, -1, -1)]
+        # no pattern: headers are tried position by position (vdif/base.py:283-316)
+        fh.seek(5000)
+        assert fh.find_header(frame_nbytes=5032, forward=True)['frame_nr'] == 0 and fh.tell() == 5032
+        fh.seek(16)
+        assert fh.find_header(frame_nbytes=5032, forward=False) == header0 and fh.tell() == 0
+    blob = open(path, 'rb').read()
+    lo, hi = gold['vdif_gap']['cut']
+    with vdif.open(io.BytesIO(blob[:lo] + blob[hi:]), 'rb') as fh:
+        run(fh, gold['vdif_gap']['calls'], header0)
+    with mark5b.open(golden_path('samples/sample.m5b'), 'rb', kday=56000, nchan=8) as fh:
+        run(fh, gold['mark5b']['calls'], None)
+    with mark4.open(golden_path('samples/sample.m4'), 'rb', ntrack=64, decade=2010) as fh:
+        run(fh, gold['mark4']['calls'], None)
+    with mark4.open(golden_path('samples/sample.m4'), 'rb', decade=2010) as fh:     # ntrack found
+        assert fh.locate_frames()[0] == 2696 and fh.ntrack == 64
