@@ -342,6 +342,14 @@ class VDIFHeader(BitFieldHeader):
         self['seconds'] = seconds
         self['frame_nr'] = frame_nr
         if self.edv == 0xab:
+            # the Mark 5B half of the header (words 4-7 = Mark 5B words 0-3)
+            # carries its own BCD time code and CRC (vdif/header.py:784-797,880-882)
+            from ..mark5b.header import Mark5BHeader
+            m5 = Mark5BHeader.fromvalues(time=time, frame_rate=frame_rate)
+            words = list(self.words)
+            # (the reference leaves the CRC field of this embedded copy at zero)
+            words[6], words[7] = int(m5.words[2]), int(m5.words[3]) & 0xffff0000
+            self.words = words
             self['mark5b_frame_nr'] = frame_nr
 
     time = property(get_time, set_time)

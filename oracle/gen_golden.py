@@ -1310,6 +1310,84 @@ def gen_locate():
     print(out['vdif']['extra'])
 
 
+def gen_header_fuzz():
+    """Headers built from keywords by the reference (vdif/header.py:188-290,
+    mark5b/header.py:120-176, mark4/header.py:456-538): words and derived
+    properties for seeded random keyword sets."""
+    rng = np.random.default_rng(5150)
+    out = dict(vdif=[], mark5b=[], mark4=[])
+    t_lo = Time('2001-01-01T00:00:00').unix
+    for i in range(60):
+        edv = [False, 0, 1, 2, 3, 0xab][i % 6]
+        bps = int(rng.choice([1, 2, 4, 8])) if edv != 0xab else int(rng.choice([1, 2]))
+        cplx = bool(rng.integers(0, 2)) if edv not in (0xab,) else False
+        nchan = int(2 ** rng.integers(0, 6))
+        kw = dict(bps=bps, complex_data=cplx, nchan=nchan, thread_id=int(rng.integers(0, 1024)),
+                  station=(int(rng.integers(0, 65536)) if rng.integers(0, 2) else
+                           ''.join(chr(int(c)) for c in rng.integers(65, 91, 2))),
+                  invalid_data=bool(rng.integers(0, 2)))
+        if edv == 3:
+            pass                                   # fixed frame length
+        elif edv == 0xab:
+            kw['frame_length'] = 1254
+        else:
+            kw['payload_nbytes'] = int(rng.integers(1, 1000)) * 8
+        frame_rate = int(rng.choice([100, 1000, 1600, 6400, 25600]))
+        tsec = float(rng.integers(int(t_lo), int(t_lo) + 20 * 365 * 86400))
+        nfr = int(rng.integers(0, frame_rate))
+        time = Time(tsec, format='unix', precision=9) + nfr / frame_rate * u.s
+        kw['time'] = time
+        if edv in (1, 3):
+            h0 = vdif.VDIFHeader.fromvalues(edv=edv, **{k: v for k, v in kw.items() if k != 'time'})
+            kw['sample_rate'] = frame_rate * h0.samples_per_frame * u.Hz
+        else:
+            kw['frame_rate'] = frame_rate * u.Hz
+        if edv == 2:
+            kw.pop('complex_data')
+        try:
+            h = vdif.VDIFHeader.fromvalues(edv=edv, **kw)
+        except Exception as exc:
+            continue
+        rec = {k: (v if not isinstance(v, (Time, u.Quantity)) else None) for k, v in kw.items()}
+        rec.pop('time')
+        rec.pop('sample_rate', None)
+        rec.pop('frame_rate', None)
+        out['vdif'].append(dict(
+            edv=(-1 if edv is False else edv), kwargs=rec, time_unix_ns=int(round(tsec)) * 10**9 + round(nfr * 10**9 / frame_rate),
+            frame_rate=frame_rate, words=[int(w) for w in h.words], nbytes=int(h.nbytes),
+            frame_nbytes=int(h.frame_nbytes), payload_nbytes=int(h.payload_nbytes), bps=int(h.bps),
+            nchan=int(h.nchan), samples_per_frame=int(h.samples_per_frame),
+            complex_data=bool(h.complex_data), station=h.station if isinstance(h.station, str) else int(h.station),
+            sample_rate=(float(h.sample_rate.to_value(u.Hz)) if edv in (1, 3) else None)))
+    for i in range(25):
+        frame_rate = int(rng.choice([400, 1600, 6400, 25600]))
+        tsec = float(rng.integers(int(t_lo), int(t_lo) + 20 * 365 * 86400))
+        nfr = int(rng.integers(0, frame_rate))
+        time = Time(tsec, format='unix', precision=9) + nfr / frame_rate * u.s
+        user = int(rng.integers(0, 65536))
+        h = mark5b.Mark5BHeader.fromvalues(time=time, frame_rate=frame_rate * u.Hz, user=user,
+                                           internal_tvg=bool(i % 2))
+        out['mark5b'].append(dict(time_unix_ns=int(round(tsec)) * 10**9 + round(nfr * 10**9 / frame_rate),
+                                  frame_rate=frame_rate, user=user, internal_tvg=bool(i % 2),
+                                  words=[int(w) for w in h.words], kday=int(h.kday), jday=int(h.jday),
+                                  seconds=int(h.seconds), frame_nr=int(h['frame_nr'])))
+    for i in range(25):
+        ntrack, fanout = [(64, 4), (64, 2), (32, 4), (32, 2), (16, 4)][i % 5]
+        tsec = float(rng.integers(int(Time('2010-01-01').unix), int(Time('2019-12-30').unix)))
+        ms = int(rng.integers(0, 800)) * 1.25
+        time = Time(tsec, format='unix', precision=9) + ms * u.ms
+        try:
+            h = mark4.Mark4Header.fromvalues(ntrack=ntrack, time=time, bps=2, fanout=fanout, nsb=1)
+        except Exception as exc:
+            continue
+        out['mark4'].append(dict(ntrack=ntrack, fanout=fanout, time_unix_ns=int(round(tsec)) * 10**9 + int(round(ms * 1e6)),
+                                 words=np.asarray(h.words).astype(np.uint64).tolist(), nchan=int(h.nchan),
+                                 samples_per_frame=int(h.samples_per_frame), time_isot=h.time.isot))
+    with open(os.path.join(GOLD, 'header_fuzz_cases.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('header fuzz:', {k: len(v) for k, v in out.items()})
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1383,7 +1461,7 @@ if __name__ == '__main__':
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
              ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer),
-             ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz), ('locate', gen_locate)]
+             ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz), ('locate', gen_locate), ('header_fuzz', gen_header_fuzz)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:
