@@ -1101,8 +1101,12 @@ def gen_stream_fuzz():
          dict(ntrack=32, decade=2010), (8,)),
         ('dada', 'samples/sample.dada', SAMPLE_DADA, {}, (2, 1)),
         ('guppi', 'samples/sample_puppi.raw', SAMPLE_PUPPI, {}, (2, 4)),
+        ('gsb', 'samples/gsb/sample_gsb_rawdump.timestamp', SAMPLE_GSB_RAWDUMP_HEADER,
+         dict(raw=SAMPLE_GSB_RAWDUMP, samples_per_frame=8192), (1,)),
+        ('gsb', 'samples/gsb/sample_gsb_phased.timestamp', SAMPLE_GSB_PHASED_HEADER,
+         dict(raw=SAMPLE_GSB_PHASED, samples_per_frame=8), (2, 512)),
     ]
-    mods = dict(vdif=vdif, mark5b=mark5b, mark4=mark4, dada=dada, guppi=guppi)
+    mods = dict(vdif=vdif, mark5b=mark5b, mark4=mark4, dada=dada, guppi=guppi, gsb=gsb)
 
     def pick(n):
         kind = rng.integers(0, 4)

@@ -190,6 +190,13 @@ def test_stream_calls_match_reference(i):
     subset = tuple(slice(v[1], v[2], v[3]) if isinstance(v, list) and v and v[0] == 'slice' else v
                    for v in case['subset'])
     kwargs = dict(FUZZ_KW.get(case['file'], {}), squeeze=case['squeeze'], subset=subset)
+    if case['fmt'] == 'gsb':
+        d = golden_path('samples/gsb/')
+        if 'rawdump' in case['file']:
+            kwargs.update(raw=d + 'sample_gsb_rawdump.dat', samples_per_frame=8192)
+        else:
+            kwargs.update(raw=[[d + 'sample_gsb_phased.Pol-%s%d.dat' % (p, k) for k in (1, 2)] for p in 'LR'],
+                          samples_per_frame=8)
     if 'error' in case:
         with pytest.raises(Exception):
             with mod.open(golden_path(case['file']), 'rs', **kwargs) as fh:
