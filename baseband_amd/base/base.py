@@ -578,3 +578,7 @@ class GPUStreamReaderBase:
             raise TypeError("cannot pickle a closed stream reader")
         reopen, opener, source, init_args = recipe
         return (reopen, (opener, source, init_args, self.offset))
+
+
+# the reference's names for these roles (base/base.py)
+StreamReaderBase = VLBIStreamReaderBase = GPUStreamReaderBase

@@ -6,3 +6,13 @@ from .base import DADAFileWriter, DADAFileReader, DADAStreamReader, DADAStreamWr
 
 __all__ = ['DADAFileWriter', 'DADAStreamWriter', 'DADAFileNameSequencer', 'DADAHeader', 'DADAPayload', 'MKBFPayload', 'DADAFrame',
            'DADAFileReader', 'DADAStreamReader', 'open']
+
+
+def info(name, **kwargs):
+    """Information on a dada file: format, rates, shapes, readability
+    (the reference's ``dada.info``; base/base.py:1440-1550)."""
+    from ..io import _format_info
+    return _format_info('dada', name, dict(kwargs))
+
+
+__all__ += ['info']

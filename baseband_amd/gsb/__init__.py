@@ -6,3 +6,13 @@ from .base import GSBStreamReader, GSBStreamWriter, open
 
 __all__ = ['GSBHeader', 'GSBPayload', 'GSBFrame', 'GSBStreamReader',
            'GSBStreamWriter', 'open']
+
+
+def info(name, **kwargs):
+    """Information on a gsb file: format, rates, shapes, readability
+    (the reference's ``gsb.info``; base/base.py:1440-1550)."""
+    from ..io import _format_info
+    return _format_info('gsb', name, dict(kwargs))
+
+
+__all__ += ['info']

@@ -22,7 +22,7 @@ import string
 
 import numpy as np
 
-__all__ = ['FileNameSequencer', 'SequenceImage', 'SequentialFileReader',
+__all__ = ['FileNameSequencer', 'SequenceImage', 'SequentialFileBase', 'SequentialFileReader',
            'SequentialFileWriter', 'open']
 
 
@@ -230,6 +230,9 @@ class _SequentialBase:
         return ("{}(files={}, mode='{}')\n# At offset: {}; open file: {!r}."
                 .format(type(self).__name__, self.files, self.mode,
                         None if self.closed else self.tell(), current))
+
+
+SequentialFileBase = _SequentialBase      # the reference's name for the shared base
 
 
 class SequentialFileReader(_SequentialBase):

@@ -6,3 +6,13 @@ from .base import Mark5BStreamWriter, Mark5BFileWriter, Mark5BFileReader, Mark5B
 
 __all__ = ['Mark5BStreamWriter', 'Mark5BFileWriter', 'Mark5BHeader', 'Mark5BPayload', 'Mark5BFrame',
            'Mark5BFileReader', 'Mark5BStreamReader', 'open']
+
+
+def info(name, **kwargs):
+    """Information on a mark5b file: format, rates, shapes, readability
+    (the reference's ``mark5b.info``; base/base.py:1440-1550)."""
+    from ..io import _format_info
+    return _format_info('mark5b', name, dict(kwargs))
+
+
+__all__ += ['info']

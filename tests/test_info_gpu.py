@@ -259,3 +259,16 @@ def test_item_access_matches_reference(k):
         assert list(d.shape) == it['shape'], (it['item'], d.shape)
         assert str(d.dtype) == it['dtype']
         assert hashlib.sha256(np.ascontiguousarray(d).tobytes()).hexdigest() == it['sha256'], it['item']
+
+
+def test_module_level_info_functions():
+    """``<format>.info(name, **kwargs)`` as in the reference."""
+    from baseband_amd import vdif, mark5b, dada
+    i = vdif.info(golden_path('samples/sample.vdif'))
+    assert i and i.format == 'vdif' and i.readable and tuple(i.shape) == (40000, 8)
+    assert not vdif.info(golden_path('samples/sample.m5b'))
+    i = mark5b.info(golden_path('samples/sample.m5b'))
+    assert i.format == 'mark5b' and set(i.missing) == {'nchan', 'kday', 'ref_time'}
+    i = mark5b.info(golden_path('samples/sample.m5b'), nchan=8, kday=56000)
+    assert i.readable and i.used_kwargs == dict(nchan=8, kday=56000)
+    assert dada.info(golden_path('samples/sample.dada')).format == 'dada'
