@@ -75,6 +75,40 @@ class BitFieldHeader:
             w = self.words[word]
             self.words[word] = (w & ~(mask << bit) & 0xffffffff) | (value << bit)
 
+    # property-like keywords `update` knows, applied in this order after the
+    # plain header keys (base/header.py:420-450)
+    _properties = ()
+
+    @classmethod
+    def fromkeys(cls, *args, verify=True, **kwargs):
+        """Header from explicit values for header KEYS only (no derived
+        properties, no defaults for missing keys: base/header.py:396-418)."""
+        self = cls(None, *args, verify=False)
+        missing = [k for k in self.keys() if k not in kwargs]
+        if missing or len(kwargs) != len(list(self.keys())):
+            raise KeyError("need keyword arguments for all keys in header "
+                           "(missing or extra: {})".format(
+                               sorted(set(missing) | (set(kwargs) - set(self.keys())))))
+        for key, value in kwargs.items():
+            self[key] = value
+        if verify:
+            self.verify()
+        return self
+
+    def update(self, *, verify=True, **kwargs):
+        """Set header keys first, then derived properties in `_properties`
+        order; anything left over draws a warning (base/header.py:420-450)."""
+        import warnings
+        for key in [k for k in kwargs if k in self.keys()]:
+            self[key] = kwargs.pop(key)
+        for key in self._properties:
+            if key in kwargs:
+                setattr(self, key, kwargs.pop(key))
+        if kwargs:
+            warnings.warn("some keywords unused in header update: {0}".format(kwargs))
+        if verify:
+            self.verify()
+
     def copy(self):
         new = self.__class__.__new__(self.__class__)
         new.__dict__.update(self.__dict__)

@@ -143,6 +143,20 @@ class DADAHeader(dict):
                              "{0}".format(self.nbytes))
         return fh.write(out + (self.nbytes - len(out)) * b'\x00')
 
+    def move_to_end(self, key, last=True):
+        """Move `key` to the end (or the start) of the header lines."""
+        value = self.pop(key)
+        if last:
+            self[key] = value
+        else:
+            rest = list(self.items())
+            self.clear()
+            self[key] = value
+            for k, v in rest:
+                self[k] = v
+        if self._layout is not None:
+            self._layout = None
+
     def copy(self):
         new = DADAHeader(self, verify=False, mutable=True)
         new.comments = dict(self.comments)

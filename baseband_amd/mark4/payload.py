@@ -20,6 +20,7 @@ __all__ = ['Mark4Payload']
 
 
 class Mark4Payload(PayloadBase):
+    complex_data = False                # the format has real samples only
     _dtype_word = None
     _sample_shape_maker = namedtuple('SampleShape', 'nchan')
 

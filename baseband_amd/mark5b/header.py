@@ -97,6 +97,16 @@ class Mark5BHeader(BitFieldHeader):
             self.verify()
         return self
 
+    def update(self, *, time=None, frame_rate=None, crc=None, verify=True, **kwargs):
+        """As the base `update`; `time` is applied last and the CRC of the time
+        code is recalculated unless one is given (mark5b/header.py:127-165)."""
+        super().update(verify=False, **kwargs)
+        if time is not None:
+            self.set_time(time, frame_rate)
+        self['crc'] = crc16_mark5b(self.words) if crc is None else crc
+        if verify:
+            self.verify()
+
     def verify(self):
         assert len(self.words) == 4
         assert self['sync_pattern'] == 0xABADDEED

@@ -11,6 +11,7 @@ __all__ = ['Mark5BPayload']
 
 
 class Mark5BPayload(PayloadBase):
+    complex_data = False                # the format has real samples only
     _nbytes = 10000
     _coder_id = _lib.CODER_MARK5B
     _sample_shape_maker = namedtuple('SampleShape', 'nchan')

@@ -64,6 +64,20 @@ class VDIFFrame(FrameBase):
         return cls(header, payload, verify=verify)
 
 
+def _from_mark5b_frame(cls, mark5b_frame, verify=True, **kwargs):
+    """VDIF frame (EDV 0xab) around a Mark 5B frame: same payload words, the
+    header converted (vdif/frame.py:104-128)."""
+    m5_payload = mark5b_frame.payload
+    header = VDIFHeader.from_mark5b_header(mark5b_frame.header, bps=m5_payload.bps,
+                                           nchan=m5_payload.sample_shape[0],
+                                           invalid_data=not mark5b_frame.valid, **kwargs)
+    payload = VDIFPayload(m5_payload.words, header)
+    return cls(header, payload, verify=verify)
+
+
+VDIFFrame.from_mark5b_frame = classmethod(_from_mark5b_frame)
+
+
 class VDIFFrameSet:
     def __init__(self, frames, header0=None):
         self.frames = frames

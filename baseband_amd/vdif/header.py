@@ -165,6 +165,57 @@ class VDIFHeader(BitFieldHeader):
             self.verify()
         return self
 
+    _properties = ('frame_nbytes', 'payload_nbytes', 'bps', 'complex_data', 'nchan',
+                   'samples_per_frame', 'station', 'sample_rate')
+
+    @classmethod
+    def fromkeys(cls, edv=None, *, verify=True, **kwargs):
+        """Header from values for all of its keys; the EDV is taken from the
+        ``edv`` / ``legacy_mode`` keys unless given (vdif/header.py:141-186)."""
+        if edv is None or kwargs.get('legacy_mode'):
+            edv = False if kwargs.get('legacy_mode') else kwargs.get('edv', False)
+        self = cls(None, edv=edv, verify=False)
+        if edv is not False:
+            kwargs.setdefault('edv', edv)       # `edv=` doubles as the value of that key
+        if set(kwargs) != set(self.keys()):
+            raise KeyError("need keyword arguments for all keys in header: "
+                           "{}".format(sorted(set(self.keys()) ^ set(kwargs))))
+        for key, value in kwargs.items():
+            self[key] = value
+        if verify:
+            self.verify()
+        return self
+
+    def update(self, *, time=None, frame_rate=None, verify=True, **kwargs):
+        """As the base `update`; `time` (with `frame_rate` for non-integer
+        seconds) is applied last (vdif/header.py:188-236)."""
+        super().update(verify=False, **kwargs)
+        if time is not None:
+            self.set_time(time, frame_rate=frame_rate)
+        if verify:
+            self.verify()
+
+    @classmethod
+    def from_mark5b_header(cls, mark5b_header, bps, nchan, **kwargs):
+        """EDV 0xab header wrapping a Mark 5B header: whole seconds from the
+        Mark 5B time code, frame number and fractional-second digits copied
+        (vdif/header.py:238-285)."""
+        assert 'time' not in kwargs, "Time is inferred from Mark 5B Header."
+        for key in mark5b_header.keys():
+            kwargs['mark5b_frame_nr' if key == 'frame_nr' else key] = mark5b_header[key]
+        kwargs.pop('sync_pattern', None)
+        day = (np.datetime64('1858-11-17', 'ns')
+               + np.timedelta64(mark5b_header.kday + mark5b_header.jday, 'D'))
+        time_frame0 = day + np.timedelta64(mark5b_header.seconds, 's')
+        fraction, crc = kwargs.pop('bcd_fraction'), kwargs.pop('crc')
+        self = cls.fromvalues(edv=0xab, bps=bps, nchan=nchan, complex_data=False,
+                              time=time_frame0, **kwargs)
+        self['frame_nr'] = mark5b_header['frame_nr']
+        self['mark5b_frame_nr'] = mark5b_header['frame_nr']
+        self['bcd_fraction'] = fraction
+        self['crc'] = crc
+        return self
+
     def verify(self):
         """Basic integrity checks (vdif/header.py:550-553,569-577,587-589,
         735-737,815-826 minus the time cross-check)."""

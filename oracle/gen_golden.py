@@ -1387,6 +1387,24 @@ def gen_header_fuzz():
         out['mark4'].append(dict(ntrack=ntrack, fanout=fanout, time_unix_ns=int(round(tsec)) * 10**9 + int(round(ms * 1e6)),
                                  words=np.asarray(h.words).astype(np.uint64).tolist(), nchan=int(h.nchan),
                                  samples_per_frame=int(h.samples_per_frame), time_isot=h.time.isot))
+    # Mark 5B frames wrapped as VDIF EDV 0xab (vdif/frame.py:104-128), and update()
+    out['mark5b_to_vdif'] = []
+    with mark5b.open(SAMPLE_MARK5B, 'rb', kday=56000, nchan=8) as fh:
+        for k in range(4):
+            m5 = fh.read_frame()
+            vf = vdif.VDIFFrame.from_mark5b_frame(m5)
+            b = io.BytesIO()
+            vf.tofile(b)
+            out['mark5b_to_vdif'].append(dict(words=[int(w) for w in vf.header.words],
+                                              frame_sha256=hashlib.sha256(b.getvalue()).hexdigest(),
+                                              valid=bool(vf.valid)))
+    h = vdif.VDIFHeader.fromvalues(edv=1, bps=2, nchan=4, complex_data=True, payload_nbytes=4000,
+                                   station='Ab', time=Time('2015-06-07T08:09:10'), sample_rate=16 * u.MHz)
+    h.update(thread_id=7, bps=4, nchan=2, time=Time('2015-06-07T08:09:11.25'), frame_rate=8000 * u.Hz)
+    out['vdif_update'] = [int(w) for w in h.words]
+    m = mark5b.Mark5BHeader.fromvalues(time=Time('2015-06-07T08:09:10'), user=5)
+    m.update(user=77, time=Time('2015-06-07T08:09:10.5'), frame_rate=6400 * u.Hz)
+    out['mark5b_update'] = [int(w) for w in m.words]
     with open(os.path.join(GOLD, 'header_fuzz_cases.json'), 'w') as f:
         json.dump(out, f, indent=0)
     print('header fuzz:', {k: len(v) for k, v in out.items()})
