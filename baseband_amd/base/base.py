@@ -274,6 +274,10 @@ class GPUStreamReaderBase:
     def closed(self):
         return self._closed
 
+    def readable(self):
+        """Whether the stream can be read and decoded (base/base.py:1012-1018)."""
+        return bool(self.info.readable)
+
     @property
     def info(self):
         """`StreamReaderInfo` snapshot, renewed when `verify` changes or the

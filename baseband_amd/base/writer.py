@@ -67,6 +67,11 @@ class GPUStreamWriterBase:
     def start_time(self):
         return self._start_time
 
+    @property
+    def time(self):
+        """Time of the next sample to be written."""
+        return self.tell('time')
+
     def tell(self, unit=None):
         if unit is None:
             return self.offset

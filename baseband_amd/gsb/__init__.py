@@ -2,10 +2,11 @@
 from .header import GSBHeader
 from .payload import GSBPayload
 from .frame import GSBFrame
-from .base import GSBStreamReader, GSBStreamWriter, open
+from .base import (GSBTimeStampIO, GSBFileReader, GSBFileWriter, GSBStreamReader,
+                   GSBStreamWriter, open)
 
 __all__ = ['GSBHeader', 'GSBPayload', 'GSBFrame', 'GSBStreamReader',
-           'GSBStreamWriter', 'open']
+           'GSBStreamWriter', 'GSBTimeStampIO', 'GSBFileReader', 'GSBFileWriter', 'open']
 
 
 def info(name, **kwargs):

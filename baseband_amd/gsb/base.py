@@ -14,16 +14,59 @@ import numpy as np
 import torch
 
 from .. import _lib, kernels
-from ..base.base import GPUStreamReaderBase
+from ..base.base import FileBase, GPUStreamReaderBase
 from ..base.writer import GPUStreamWriterBase, LazyWriteFile
 from ..staging import host_image
 from .header import GSBHeader
 from .payload import GSBPayload
 from .frame import GSBFrame
 
-__all__ = ['GSBStreamReader', 'GSBStreamWriter', 'open']
+__all__ = ['GSBTimeStampIO', 'GSBFileReader', 'GSBFileWriter', 'GSBStreamReader',
+           'GSBStreamWriter', 'open']
 
 DEFAULT_FRAME_RATE = 1e8 / 6 / 2 ** 22          # Hz (gsb/base.py:170)
+
+
+class GSBTimeStampIO(FileBase):
+    """Timestamp (text) file: one header line per frame (gsb/base.py:23-75)."""
+
+    def read_timestamp(self):
+        return GSBHeader.fromfile(self.fh_raw)
+
+    def write_timestamp(self, header=None, **kwargs):
+        if header is None:
+            header = GSBHeader.fromvalues(**kwargs)
+        return header.tofile(self.fh_raw)
+
+    def get_frame_rate(self):
+        """From the first two timestamps (Hz)."""
+        with self.temporary_offset(0):
+            t0 = self.read_timestamp().time
+            t1 = self.read_timestamp().time
+        return 1e9 / float((t1 - t0) / np.timedelta64(1, 'ns'))
+
+
+class GSBFileReader(FileBase):
+    """Raw data file: fixed-size payload blocks (gsb/base.py:78-121)."""
+
+    def __init__(self, fh_raw, payload_nbytes, nchan=1, bps=4, complex_data=False):
+        self.payload_nbytes, self.nchan = payload_nbytes, nchan
+        self.bps, self.complex_data = bps, complex_data
+        super().__init__(fh_raw)
+
+    def read_payload(self):
+        return GSBPayload.fromfile(self.fh_raw, payload_nbytes=self.payload_nbytes,
+                                   sample_shape=(self.nchan,), bps=self.bps,
+                                   complex_data=self.complex_data)
+
+
+class GSBFileWriter(FileBase):
+    """Raw data file writer (gsb/base.py:124-143): payloads packed on the GPU."""
+
+    def write_payload(self, data, bps=4):
+        if not isinstance(data, GSBPayload):
+            data = GSBPayload.fromdata(data, bps=bps)
+        return data.tofile(self.fh_raw)
 
 
 class GSBStreamReader(GPUStreamReaderBase):
@@ -240,8 +283,15 @@ def open(name, mode='rs', **kwargs):
     (``'rs'``) or writing (``'ws'``) (gsb/base.py:460-560).  ``raw`` is one
     file for rawdump, a (nested) tuple ``((polL1, polL2), (polR1, polR2))``
     for phased data; ``header_mode`` overrides the mode inferred from it."""
+    if mode in ('rt', 'wt'):
+        fh = name if hasattr(name, 'read') or hasattr(name, 'write') else io.open(name, mode[0])
+        return GSBTimeStampIO(fh, **kwargs)
+    if mode == 'rb':
+        return GSBFileReader(name if hasattr(name, 'read') else io.open(name, 'rb'), **kwargs)
+    if mode == 'wb':
+        return GSBFileWriter(name if hasattr(name, 'write') else LazyWriteFile(name), **kwargs)
     if mode not in ('rs', 'ws'):
-        raise ValueError("only stream modes 'rs' and 'ws' are supported "
+        raise ValueError("supported modes are 'rt', 'wt', 'rb', 'wb', 'rs' and 'ws' "
                          "(got {!r}).".format(mode))
     raw = kwargs.pop('raw', None)
     if raw is None:

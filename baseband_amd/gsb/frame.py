@@ -18,3 +18,21 @@ class GSBFrame(FrameBase):
                                       sample_shape=sample_shape, bps=bps,
                                       complex_data=complex_data)
         return cls(header, payload, valid=valid, verify=verify)
+
+    @classmethod
+    def fromdata(cls, data, header=None, *, bps=4, valid=True, verify=True, **kwargs):
+        """Frame from samples (packed on the GPU) and a timestamp header; without
+        a header the keywords make one (gsb/frame.py:113-136)."""
+        if header is None:
+            header = GSBHeader.fromvalues(**kwargs)
+        return cls(header, GSBPayload.fromdata(data, bps=bps), valid=valid, verify=verify)
+
+    def tofile(self, fh_ts, fh_raw):
+        """Timestamp line to `fh_ts`, payload to the raw file(s): one handle for
+        rawdump, ``((L1, L2), (R1, R2))`` for phased data (gsb/frame.py:99-111)."""
+        self.header.tofile(fh_ts)
+        self.payload.tofile(fh_raw)
+
+    @property
+    def nbytes(self):
+        return self.payload.nbytes

@@ -62,3 +62,16 @@ class GSBPayload(PayloadBase):
                 words[f, :, p, :] = part.reshape(-1, sample_nbytes)
         return cls(words.ravel(), sample_shape=sample_shape, bps=bps,
                    complex_data=complex_data)
+
+    def tofile(self, fh):
+        """Write the words to one raw file, or split a phased payload over
+        ``fh[pol][part]``: parts are consecutive in time, polarisations
+        interleaved per sample (gsb/payload.py:133-144)."""
+        if hasattr(fh, 'write'):
+            return fh.write(self.words.tobytes())
+        npol = len(fh)
+        assert npol == self.sample_shape[0]
+        words = self.words.reshape(len(fh[0]), -1, npol, self._bpfs // npol // 8)
+        for fh_set, pol in zip(fh, words.transpose(2, 0, 1, 3)):
+            for fh1, part in zip(fh_set, pol):
+                fh1.write(np.ascontiguousarray(part).tobytes())

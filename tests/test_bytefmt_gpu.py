@@ -253,3 +253,41 @@ def test_block_readers_decode_into_out_tensor(manifest):
         out = torch.zeros(fh.shape, dtype=torch.complex64, device='cuda')
         fh.read(out=out)
         assert bits_equal(out.cpu().numpy(), exp.reshape(out.shape))
+
+
+def test_gsb_file_level_classes(tmp_path):
+    """GSBTimeStampIO / GSBFileReader / GSBFileWriter / GSBFrame.fromdata+tofile
+    (gsb/base.py:23-143, gsb/frame.py:99-136) on the sample observations."""
+    from baseband_amd import gsb
+    d = golden_path('samples/gsb/')
+    with gsb.open(d + 'sample_gsb_rawdump.timestamp', 'rt') as ft:
+        h0 = ft.read_timestamp()
+        assert h0.mode == 'rawdump' and abs(ft.get_frame_rate() - 1e8 / 6 / 2 ** 22) < 1e-6 * 4
+    exp = load_expected('sample_gsb_rawdump')
+    with gsb.open(d + 'sample_gsb_rawdump.dat', 'rb', payload_nbytes=4096, nchan=1, bps=4) as fr:
+        p0 = fr.read_payload()
+        assert p0.shape == (8192, 1) and bits_equal(p0.data.cpu().numpy(), exp[:8192].reshape(8192, 1))
+        p1 = fr.read_payload()
+    # write the two payloads and their timestamps again, frame by frame
+    ts, raw = str(tmp_path / 'c.timestamp'), str(tmp_path / 'c.dat')
+    with gsb.open(ts, 'wt') as fts, gsb.open(raw, 'wb') as fw:
+        fts.write_timestamp(h0)
+        fw.write_payload(p0.data, bps=4)
+        frame = gsb.GSBFrame.fromdata(p1.data, h0, bps=4)
+        frame.tofile(fts, fw)
+    assert open(raw, 'rb').read() == open(d + 'sample_gsb_rawdump.dat', 'rb').read()[:8192]
+    assert open(ts).read().splitlines() == [' '.join(h0.words)] * 2
+    # phased payload split over ((L1, L2), (R1, R2))
+    names = [[d + 'sample_gsb_phased.Pol-%s%d.dat' % (p, k) for k in (1, 2)] for p in 'LR']
+    with gsb.open(d + 'sample_gsb_phased.timestamp', 'rs', raw=names, samples_per_frame=8) as fs:
+        data = fs.read(8)
+        hp = fs.header0
+    frame = gsb.GSBFrame.fromdata(data, hp, bps=8)
+    outs = [[open(str(tmp_path / ('q%d%d.dat' % (p, k))), 'wb') for k in range(2)] for p in range(2)]
+    with open(str(tmp_path / 'q.timestamp'), 'w') as fts:
+        frame.tofile(fts, outs)
+    for p in range(2):
+        for k in range(2):
+            outs[p][k].close()
+            n = 8 // 2 * 512 * 2
+            assert open(str(tmp_path / ('q%d%d.dat' % (p, k))), 'rb').read() == open(names[p][k], 'rb').read()[:n]
