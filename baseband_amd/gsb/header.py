@@ -57,6 +57,61 @@ class GSBHeader:
     def keys(self):
         return ('pc', 'gps', 'seq_nr', 'mem_block') if self.mode == 'phased' else ('gps',)
 
+    mutable = True
+
+    def verify(self):
+        pass
+
+    def copy(self):
+        return GSBHeader(list(self.words))
+
+    @classmethod
+    def fromkeys(cls, mode=None, **kwargs):
+        """Header from the raw keys: ``gps`` (and ``pc``, ``seq_nr``,
+        ``mem_block`` for phased data), times as their seven-item strings
+        (gsb/header.py:231-238)."""
+        if mode is None:
+            mode = 'phased' if set(kwargs) & {'pc', 'seq_nr', 'mem_block'} else 'rawdump'
+        words = kwargs['gps'].split()
+        if mode == 'phased':
+            words = (kwargs['pc'].split() + words
+                     + [str(int(kwargs.get('seq_nr', 0))), str(int(kwargs.get('mem_block', 0)))])
+        return GSBHeader(words)
+
+    def update(self, *, verify=True, **kwargs):
+        """New times / counters; keyword names as for `fromvalues`."""
+        current = dict(gps_time=self.time)
+        if self.mode == 'phased':
+            current.update(pc_time=self.pc_time, seq_nr=self['seq_nr'], mem_block=self['mem_block'])
+        if 'time' in kwargs:
+            t = kwargs.pop('time')
+            kwargs.setdefault('gps_time', t)
+            if self.mode == 'phased':
+                kwargs.setdefault('pc_time', t)
+        current.update(kwargs)
+        self.words = GSBHeader.fromvalues(self.mode, **current).words
+
+    def seek_offset(self, n, nbytes=None):
+        """Bytes to move a file pointer `n` timestamp lines on: rawdump lines
+        all have one length; phased lines grow with the digits of the
+        sequence number (gsb/header.py:240-262,319-357)."""
+        if nbytes is None:
+            nbytes = self.nbytes
+        guess = n * nbytes
+        if self.mode != 'phased':
+            return guess
+        seq = self['seq_nr']
+        ndseq, target = len(str(seq)), seq + n
+        ndtarg = len(str(target))
+        while ndseq != ndtarg:
+            if n > 0:
+                guess += target - int('1' + ndseq * '0')
+                ndseq += 1
+            else:
+                guess += int('1' + (ndseq - 1) * '0') - target
+                ndseq -= 1
+        return guess
+
     def __new__(cls, words=None, mode=None, **kwargs):
         if cls is GSBHeader and words is not None:
             cls = GSBRawdumpHeader if len(words) == 7 else GSBPhasedHeader

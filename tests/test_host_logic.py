@@ -562,3 +562,26 @@ def test_header_update_and_mark5b_wrapping_match_reference():
                                                invalid_data=not m5.valid)
             assert [int(w) for w in vh.words] == want['words']
             assert vh.edv == 0xab and vh['frame_nr'] == m5.header['frame_nr']
+
+
+def test_gsb_header_helpers():
+    """seek_offset over lines whose length grows with the sequence number
+    (gsb/header.py:319-357), copy / update / fromkeys."""
+    from baseband_amd.gsb import GSBHeader
+    t0 = np.datetime64('2015-06-01T01:02:03.251658240')
+    lines = []
+    for k in range(6):
+        hk = GSBHeader.fromvalues('phased', time=t0 + np.timedelta64(4000000 * k, 'ns'),
+                                  seq_nr=9998 + k, mem_block=(6 + k) % 8)
+        lines.append(' '.join(hk.words) + '\n')
+    pos = np.concatenate([[0], np.cumsum([len(ln) for ln in lines])])
+    h0, h5 = GSBHeader(lines[0].split()), GSBHeader(lines[5].split())
+    assert [h0.seek_offset(n) for n in range(6)] == pos[:6].tolist()
+    assert [h5.seek_offset(-n) for n in range(6)] == (pos[5 - np.arange(6)] - pos[5]).tolist()
+    raw = GSBHeader.fromvalues(time=t0)
+    assert raw.mode == 'rawdump' and raw.seek_offset(7) == 7 * raw.nbytes
+    c = h0.copy()
+    c.update(seq_nr=12, time=t0 + np.timedelta64(1, 's'))
+    assert c['seq_nr'] == 12 and c.time == t0 + np.timedelta64(1, 's') and c != h0
+    assert GSBHeader.fromkeys(**{k: h0[k] for k in h0.keys()}) == h0
+    assert GSBHeader.fromkeys(gps=raw['gps']) == raw
