@@ -168,7 +168,13 @@ class Mark4Header:
                             "mutable one.")
         word, bit, nbits = _FIELDS[key][:3]
         mask = np.uint32(((1 << nbits) - 1) << bit)
-        value = np.asarray(value).astype(np.uint32)
+        if value is True:
+            value = (1 << nbits) - 1                 # all bits, for masks
+        value = np.asarray(value)
+        if np.any(value.astype(np.int64) & ((1 << nbits) - 1) != value):
+            raise ValueError("{0} cannot be represented with {1} bits"
+                             .format(value, nbits))
+        value = value.astype(np.uint32)
         self.words[word] = (self.words[word] & ~mask) | ((value << np.uint32(bit)) & mask)
 
     def copy(self):
@@ -211,33 +217,132 @@ class Mark4Header:
     def tofile(self, fh):
         fh.write(words2stream(self.words).tobytes())
 
+    _properties = ('decade', 'track_id', 'fraction', 'time', 'fanout',
+                   'samples_per_frame', 'bps', 'complex_data', 'nchan',
+                   'sample_shape', 'nsb', 'converters')
+    _invariants = {'sync_pattern', '_1_0_1_sync'}
+    _stream_invariants = _invariants | {'bcd_headstack1', 'bcd_headstack2',
+                                        'track_roll_enabled',
+                                        'sequence_suspended', 'system_id'}
+
     @classmethod
-    def fromvalues(cls, ntrack, *, time, bps=2, fanout=4, nsb=1,
-                   system_id=0, verify=True):
-        """Header with the standard track layout for (ntrack, bps, fanout)
-        at `time`, the way the reference's writer fills it
-        (mark4/header.py:456-507,565-700).  Used to synthesise files."""
-        self = cls(None, ntrack=ntrack)
-        self['bcd_headstack1'] = 0x3344
-        self['bcd_headstack2'] = 0x1122
-        self['sync_pattern'] = 0xffffffff
-        self['system_id'] = system_id
+    def fromvalues(cls, ntrack, decade=None, ref_time=None, **kwargs):
+        """Header from keys and properties (mark4/header.py:460-507):
+        defaults for headstack and track ids follow from ``ntrack``, one
+        sideband unless converters or sidebands are given; ``time``, ``bps``
+        and ``fanout`` make it complete.  The CRC is recalculated."""
         if ntrack == 64:
-            self['headstack_id'] = np.repeat(np.arange(2), 32)
-            track_id = np.tile(np.arange(2, 34), 2)
+            kwargs.setdefault('headstack_id', np.repeat(np.arange(2), 32))
+            kwargs.setdefault('track_id', np.tile(np.arange(2, 34), 2))
         elif ntrack == 32:
-            track_id = np.arange(2, 34)
-        else:
-            track_id = np.arange(2, 34, 2)
-        self['bcd_track_id'] = np.array([_bcd_encode(t) for t in track_id])
-        self.fanout = fanout
-        self.bps = bps
-        self.nsb = nsb
-        self.set_time(time)
-        self.update_crc()
+            kwargs.setdefault('headstack_id', np.zeros(32, dtype=int))
+            kwargs.setdefault('track_id', np.arange(2, 34))
+        elif ntrack == 16:
+            kwargs.setdefault('headstack_id', np.zeros(16, dtype=int))
+            kwargs.setdefault('track_id', np.arange(2, 34, 2))
+        if not any(key in kwargs for key in ('lsb_output', 'converter_id',
+                                             'converter')):
+            kwargs.setdefault('nsb', 1)
+        self = cls(None, ntrack=ntrack, decade=decade)
+        for key, field in _FIELDS.items():
+            if len(field) > 3 and not key.startswith('_1_0_1'):
+                self[key] = field[3]
+        verify = kwargs.pop('verify', True)
+        self.update(verify=False, **kwargs)
+        if self.decade is None and ref_time is not None:
+            self.infer_decade(ref_time)
         if verify:
             self.verify()
         return self
+
+    @classmethod
+    def fromkeys(cls, ntrack, decade=None, ref_time=None, verify=True, **kwargs):
+        """Header from a complete set of key values, i.e.,
+        ``Mark4Header.fromkeys(h.ntrack, h.decade, **h) == h``
+        (base/header.py:695-723)."""
+        missing = [key for key in _FIELDS if key not in kwargs]
+        if missing:
+            raise KeyError("missing key(s) {} for Mark4Header".format(missing))
+        self = cls(None, ntrack=ntrack, decade=decade)
+        for key in _FIELDS:
+            self[key] = kwargs.pop(key)
+        if kwargs:
+            raise KeyError("Mark4Header header does not contain {0}"
+                           .format(sorted(kwargs)))
+        if decade is None and ref_time is not None:
+            self.infer_decade(ref_time)
+        if verify:
+            self.verify()
+        return self
+
+    def update(self, crc=None, verify=True, **kwargs):
+        """Set keys first, then properties in class order, and recalculate
+        the CRC unless one is passed in (mark4/header.py:509-533,
+        base/header.py:753-787)."""
+        if not self._mutable:
+            raise TypeError("header is immutable; use .copy() to get a "
+                            "mutable one.")
+        if crc is not None:
+            kwargs['crc'] = crc
+        for key in [k for k in kwargs if k in _FIELDS]:
+            self[key] = kwargs.pop(key)
+        for name in self._properties:
+            if name in kwargs:
+                setattr(self, name, kwargs.pop(name))
+        if kwargs:
+            import warnings
+            warnings.warn("some keywords unused in header update: {0}"
+                          .format(kwargs))
+        if crc is None:
+            self.update_crc()
+        if verify:
+            self.verify()
+
+    def invariants(self):
+        """Keys of parts shared by the headers of one stream
+        (mark4/header.py:144-154); the class-level set is ``_invariants``."""
+        return self._stream_invariants
+
+    def invariant_pattern(self, invariants=None, ntrack=None):
+        """(pattern, mask) as stream words (mark4/header.py:345-373): on an
+        instance from its own words and the stream invariants."""
+        if invariants is None:
+            invariants = self.invariants()
+        if not invariants:
+            raise ValueError("cannot create an invariant_mask without "
+                             "some invariants")
+        mask = type(self)(None, ntrack=self.ntrack)
+        for key in invariants:
+            mask[key] = True
+        return words2stream(self.words), words2stream(mask.words)
+
+    @classmethod
+    def class_invariant_pattern(cls, ntrack, invariants=None):
+        """The reference's ``Mark4Header.invariant_pattern(ntrack=...)`` called
+        on the class: defaults of the type invariants (the sync pattern plus
+        the always-zero lowest bit of 'system_id')."""
+        self = cls(None, ntrack=ntrack)
+        if invariants is None:
+            invariants = cls._invariants
+        for key in invariants:
+            if len(_FIELDS[key]) < 4:
+                raise ValueError('can only set as invariant a header '
+                                 'part that has a default.')
+            self[key] = _FIELDS[key][3]
+        return self.invariant_pattern(invariants)
+
+    def __len__(self):
+        return self.ntrack
+
+    @property
+    def track_id(self):
+        """Track identifiers decoded from 'bcd_track_id' (mark4/header.py:191-198)."""
+        return _bcd_decode_array(self['bcd_track_id'])
+
+    @track_id.setter
+    def track_id(self, track_id):
+        self['bcd_track_id'] = np.array(
+            [_bcd_encode(t) for t in np.broadcast_to(track_id, (self.ntrack,))])
 
     def update_crc(self):
         stream = words2stream(self.words)
@@ -284,6 +389,19 @@ class Mark4Header:
     def samples_per_frame(self):
         return self.frame_nbytes * 8 // (self.ntrack // self.fanout)
 
+    @samples_per_frame.setter
+    def samples_per_frame(self, samples_per_frame):
+        fanout, extra = divmod(samples_per_frame * self.ntrack,
+                               8 * self.frame_nbytes)
+        if extra or fanout not in (1, 2, 4):
+            raise ValueError(
+                "header cannot store {} samples per frame. "
+                "Should be one of {}."
+                .format(samples_per_frame,
+                        ', '.join([str(f * 8 * self.frame_nbytes)
+                                   for f in (1, 2, 4)])))
+        self.fanout = int(fanout)
+
     @property
     def bps(self):
         return 2 if self['magnitude_bit'].any() else 1
@@ -301,15 +419,30 @@ class Mark4Header:
             raise ValueError("Mark 4 data can only have bps=1 or 2, "
                              "not {0}".format(bps))
 
-    complex_data = False
+    @property
+    def complex_data(self):
+        return False
+
+    @complex_data.setter
+    def complex_data(self, complex_data):
+        if complex_data:
+            raise ValueError("Mark 4 data are always real.")
 
     @property
     def nchan(self):
         return self.ntrack // (self.fanout * self.bps)
 
+    @nchan.setter
+    def nchan(self, nchan):
+        self.bps = self.ntrack // (self.fanout * nchan)
+
     @property
     def sample_shape(self):
         return (self.nchan,)
+
+    @sample_shape.setter
+    def sample_shape(self, sample_shape):
+        self.nchan, = sample_shape
 
     @property
     def nsb(self):
@@ -323,6 +456,12 @@ class Mark4Header:
         if nsb == 1:
             self['lsb_output'] = np.ones(self.ntrack, bool)
         elif nsb == 2:
+            # the reference alternates sidebands over 16 track pairs, i.e.
+            # 32 tracks only (mark4/header.py:671-676); a 64-track header is
+            # two such headstacks
+            if self.ntrack not in (32, 64):
+                raise ValueError("two sidebands can only be set for 32 or "
+                                 "64 tracks.")
             self['lsb_output'] = np.tile([False, True], self.ntrack // 2)
         else:
             raise ValueError("number of sidebands can only be 1 or 2.")
@@ -330,17 +469,48 @@ class Mark4Header:
         converters = np.arange(nconverter)
         if nconverter > 2:
             converters = converters.reshape(-1, 2, 2).transpose(0, 2, 1).ravel()
+        self.converters = converters
+
+    @property
+    def converters(self):
+        """Converter id and sideband of every channel as a structured array
+        with 'converter' and 'lsb' entries (mark4/header.py:690-739).  Can be
+        set with such an array, a dict, or just the converter ids (sidebands
+        as they are; with two sidebands half the number of ids suffices)."""
+        ta_ch = self.track_assignment[0, :, 0]
+        converters = np.empty(len(ta_ch), [("converter", int), ("lsb", bool)])
+        converters['converter'] = self['converter_id'][ta_ch]
+        converters['lsb'] = self['lsb_output'][ta_ch]
+        return converters
+
+    @converters.setter
+    def converters(self, converters):
         ta = self.track_assignment
         ta_ch = ta[0, :, 0]
         nchan = len(ta_ch)
-        sb = self['lsb_output'][ta_ch]
-        if len(converters) == nchan // 2:
-            c = np.empty(nchan, dtype=int)
-            c[sb] = converters
-            c[~sb] = converters
-            converters = c
+        msg = ('Mark 4 file with bps={0}, fanout={1} '
+               'needs to define {2} converters')
+        try:
+            converter = converters['converter']
+        except (KeyError, ValueError, IndexError, TypeError):
+            converter = np.array(converters)
+            sb = self['lsb_output'][ta_ch]
+            if self.nsb == 2 and len(converter) == nchan // 2:
+                c = np.empty(nchan, dtype=int)
+                c[sb] = c[~sb] = converter
+                converter = c
+            if len(converter) != nchan:
+                raise ValueError(msg.format(self.bps, self.fanout, nchan))
+        else:
+            converter = np.asarray(converter)
+            sb = np.array(converters['lsb'])
+            if len(converter) != nchan:
+                raise ValueError(msg.format(self.bps, self.fanout, nchan))
+            lsb_output = np.empty(self.ntrack, bool)
+            lsb_output[ta] = sb[:, np.newaxis]
+            self['lsb_output'] = lsb_output
         converter_id = np.empty(self.ntrack, dtype=int)
-        converter_id[ta] = np.asarray(converters)[:, np.newaxis]
+        converter_id[ta] = converter[:, np.newaxis]
         self['converter_id'] = converter_id
 
     @classmethod
@@ -384,6 +554,16 @@ class Mark4Header:
     def fraction(self):
         ms = _bcd_decode_array(self['bcd_fraction'])
         return (ms + (ms % 5) * 0.25) / 1000.
+
+    @fraction.setter
+    def fraction(self, fraction):
+        """Fractional seconds, a multiple of 1.25 ms, stored truncated to ms
+        (mark4/header.py:214-221)."""
+        ms = np.asarray(fraction) * 1000.
+        if np.any(np.abs((ms / 1.25) - np.around(ms / 1.25)) > 1e-6):
+            raise ValueError("{0} ms is not a multiple of 1.25 ms".format(ms))
+        ms = np.broadcast_to(np.floor(ms + 1e-6).astype(int), (self.ntrack,))
+        self['bcd_fraction'] = np.array([_bcd_encode(m) for m in ms])
 
     def time_quarter_ms(self, track=0):
         """Time of `track` in units of 0.25 ms since the start of its year

@@ -1410,6 +1410,82 @@ def gen_header_fuzz():
     print('header fuzz:', {k: len(v) for k, v in out.items()})
 
 
+def gen_mark4_header():
+    """Mark 4 header construction by the reference (mark4/header.py:345-373,
+    456-533, 558-739): words for keyword combinations (bps/nchan,
+    fanout/samples_per_frame, nsb, converters), update(), fromkeys() and the
+    class / stream invariant patterns."""
+    out = dict(fromvalues=[], update=[], patterns=[])
+    time = Time('2014-06-15T12:34:56.0125', precision=9)
+    tns = 1402835696 * 10**9 + 12500000
+    assert abs(time.unix - tns / 1e9) < 1e-6
+    combos = []
+    for ntrack in (16, 32, 64):
+        for fanout in (1, 2, 4):
+            for bps in (1, 2):
+                for nsb in (1, 2):
+                    combos.append(dict(ntrack=ntrack, fanout=fanout, bps=bps, nsb=nsb))
+    combos += [dict(ntrack=64, fanout=4, nchan=8), dict(ntrack=32, samples_per_frame=80000, bps=2),
+               dict(ntrack=32, samples_per_frame=40000, nchan=16, system_id=108),
+               dict(ntrack=64, fanout=4, bps=2, nsb=2, converters=[3, 1, 2, 0]),
+               dict(ntrack=64, fanout=4, bps=2, nsb=1, converters=[7, 6, 5, 4, 3, 2, 1, 0]),
+               dict(ntrack=32, fanout=2, bps=2,
+                    converters=dict(converter=[0, 1, 2, 3, 4, 5, 6, 7],
+                                    lsb=[True, False, True, False, False, True, False, True])),
+               dict(ntrack=64, fanout=4, bps=2, nsb=1, converters=[1, 2, 3]),
+               dict(ntrack=32, fanout=3, bps=2), dict(ntrack=32, fanout=4, bps=3),
+               dict(ntrack=32, samples_per_frame=12345, bps=2),
+               dict(ntrack=64, fanout=4, bps=2, track_id=np.arange(64).tolist()),
+               dict(ntrack=64, fanout=4, bps=2, nosuchkey=1)]
+    for kw in combos:
+        rec = dict(kwargs=kw)
+        kw = {k: (np.array(v) if isinstance(v, list) else v) for k, v in kw.items()}
+        if isinstance(kw.get('converters'), dict):
+            kw['converters'] = {k: np.array(v) for k, v in kw['converters'].items()}
+        try:
+            h = mark4.Mark4Header.fromvalues(time=time, **kw)
+        except Exception as exc:
+            rec['error'] = type(exc).__name__
+        else:
+            rec.update(words=np.asarray(h.words).astype(np.uint64).tolist(),
+                       nchan=int(h.nchan), bps=int(h.bps), fanout=int(h.fanout), nsb=int(h.nsb),
+                       samples_per_frame=int(h.samples_per_frame),
+                       track_id=np.asarray(h.track_id).tolist(),
+                       converter=h.converters['converter'].tolist(),
+                       lsb=h.converters['lsb'].tolist(), decade=int(h.decade),
+                       fraction=float(np.asarray(h.fraction).ravel()[0]))
+            k = mark4.Mark4Header.fromkeys(h.ntrack, h.decade, **h)
+            assert k == h
+        out['fromvalues'].append(rec)
+    h = mark4.Mark4Header.fromvalues(ntrack=32, time=time, bps=2, fanout=4)
+    for kw in (dict(system_id=12), dict(bps=1), dict(nsb=2), dict(fanout=2, bps=2, nsb=1),
+               dict(time_ns=tns + 3 * 10**9 + 250 * 10**6), dict(crc=0x123, verify=False),
+               dict(fraction=0.99875), dict(nchan=16), dict(bcd_day=0x123, nsb=2, fanout=1)):
+        m = h.copy()
+        kk = dict(kw)
+        if 'time_ns' in kk:
+            kk['time'] = time + (kk.pop('time_ns') - tns) / 1e9 * u.s
+        try:
+            m.update(**kk)
+        except Exception as exc:
+            out['update'].append(dict(kwargs=kw, error=type(exc).__name__))
+        else:
+            out['update'].append(dict(kwargs=kw, words=np.asarray(m.words).astype(np.uint64).tolist()))
+    for ntrack in (16, 32, 64):
+        pat, mask = mark4.Mark4Header.invariant_pattern(ntrack=ntrack)
+        hh = mark4.Mark4Header.fromvalues(ntrack=ntrack, time=time, bps=2, fanout=4, system_id=108)
+        ipat, imask = hh.invariant_pattern()
+        out['patterns'].append(dict(ntrack=ntrack, pattern=np.asarray(pat).astype(np.uint64).tolist(),
+                                    mask=np.asarray(mask).astype(np.uint64).tolist(),
+                                    stream_pattern=np.asarray(ipat).astype(np.uint64).tolist(),
+                                    stream_mask=np.asarray(imask).astype(np.uint64).tolist()))
+    out['time_unix_ns'] = tns
+    with open(os.path.join(GOLD, 'mark4_header_cases.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('mark4 header:', {k: (len(v) if isinstance(v, list) else v) for k, v in out.items()},
+          'errors', sum('error' in r for r in out['fromvalues']))
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1483,7 +1559,8 @@ if __name__ == '__main__':
              ('vdif_edv_ab', gen_vdif_edv_ab), ('encode', gen_encode),
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
              ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer),
-             ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz), ('locate', gen_locate), ('header_fuzz', gen_header_fuzz)]
+             ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz), ('locate', gen_locate), ('header_fuzz', gen_header_fuzz),
+             ('mark4_header', gen_mark4_header)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:
