@@ -659,3 +659,21 @@ def test_mark4_header_construction_matches_reference():
         ipat, imask = hh.invariant_pattern()
         assert ipat.tolist() == rec['stream_pattern'] and imask.tolist() == rec['stream_mask']
         assert len(hh) == ntrack
+
+
+def test_plugin_entry_points_name_format_modules():
+    """pyproject.toml registers the format packages in the reference's
+    ``baseband.io`` entry-point group; each must be a module exposing ``open``
+    and ``info`` (io/__init__.py:43-91,162-175 of the reference)."""
+    import importlib
+    import os
+    import tomli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'pyproject.toml'), 'rb') as f:
+        meta = tomli.load(f)
+    entries = meta['project']['entry-points']['baseband.io']
+    assert set(entries) == {f + '_hip' for f in ('vdif', 'mark5b', 'mark4', 'guppi', 'dada', 'gsb')}
+    for name, target in entries.items():
+        assert ':' not in target                   # a module entry = a format
+        mod = importlib.import_module(target)
+        assert callable(mod.open) and callable(mod.info)
