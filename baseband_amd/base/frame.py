@@ -99,6 +99,13 @@ class FrameBase:
         # invalid: only the SHAPE of the answer depends on the item
         return self._fill(np.empty(self.shape, dtype=bool)[item].shape)
 
+    def __setitem__(self, item, value):
+        """Header key -> header; samples -> payload (base/frame.py:203-207)."""
+        if isinstance(item, str):
+            self.header[item] = value
+        else:
+            self.payload[item] = value
+
     data = property(__getitem__, doc="Full decoded frame (device tensor).")
 
     # -- header passthrough

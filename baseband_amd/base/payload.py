@@ -38,6 +38,44 @@ def _resolve_index(index, length, who):
     return i, i + 1, 1, True
 
 
+class RowSetMixin:
+    """``payload[item] = data`` for payloads that decode by rows of complete
+    samples (GUPPI, DADA): rows [lo, hi) that cover the item -- whole
+    `_row_granule` blocks -- are decoded on the GPU, updated, packed again by
+    the GPU encoder and stored with ``_store_rows`` (guppi/payload.py:112-140,
+    base/payload.py:332-347)."""
+    _row_granule = 1
+
+    def __setitem__(self, item, data):
+        if isinstance(item, tuple):
+            sample_index = item[1:]
+            first = item[0] if item else slice(None)
+        else:
+            sample_index, first = (), item
+        start, stop, step, scalar = _resolve_index(first, len(self), type(self))
+        if stop == start:
+            return
+        g = self._row_granule
+        lo, hi = start // g * g, min(-(-stop // g) * g, len(self))
+        if not isinstance(data, torch.Tensor):
+            data = torch.from_numpy(np.ascontiguousarray(data))
+        data = data.to('cuda')
+        want = torch.complex64 if self.complex_data else torch.float32
+        if (not scalar and step == 1 and not sample_index and (lo, hi) == (start, stop)
+                and tuple(data.shape) == (stop - start,) + tuple(self.sample_shape)):
+            block = data.to(want)               # whole rows: nothing to keep
+        else:
+            self._dwords = None                 # the words may have changed
+            block = self[lo:hi].clone()
+            if scalar:
+                index = (start - lo,) + sample_index
+            else:
+                index = (slice(start - lo, stop - lo, step),) + sample_index
+            block[index] = data.to(want)
+        self._store_rows(lo, hi, block)
+        self._dwords = None
+
+
 class PayloadBase:
     # subclass knobs -------------------------------------------------------
     _nbytes = None                      # fixed payload size, if the format has one
@@ -214,6 +252,50 @@ class PayloadBase:
         size = self.words.itemsize
         block = self._as_dtype(self._decode(w0 * size, w1 * size))
         return block.reshape(-1, *self.sample_shape)[index]
+
+    def _encode(self, data):
+        """Device samples ``(n,) + sample_shape`` -> packed words (host
+        array): the seam where the reference calls
+        ``self._encoders[self._coder](data)`` (base/payload.py:317-325)."""
+        if self._coder_id is None:
+            raise ValueError("{} cannot encode data with {} bits"
+                             .format(type(self).__name__, self.bps))
+        try:
+            packed = kernels.encode_flat(data, self._coder_id, self.bps)
+        except KeyError:
+            raise ValueError("{} cannot encode data with {} bits"
+                             .format(type(self).__name__, self.bps)) from None
+        return packed.cpu().numpy().view(self._dtype_word)
+
+    def _fresh_block(self, w0, w1):
+        """Decoded copy of words [w0, w1) as (n,) + sample_shape, taken from
+        the host words as they are now."""
+        self._dwords = None
+        size = self.words.itemsize
+        block = self._as_dtype(self._decode(w0 * size, w1 * size))
+        return block.reshape(-1, *self.sample_shape).clone()
+
+    def __setitem__(self, item, data):
+        """Replace samples: the covering words are decoded on the GPU, the
+        new values inserted, and the block packed again by the GPU encoder
+        (base/payload.py:332-347).  The words must be writable (made by
+        ``fromdata`` or memory-mapped for writing)."""
+        word_slice, index = self._item_to_slices(item)
+        w0, w1, _ = word_slice.indices(len(self.words))
+        if not isinstance(data, torch.Tensor):
+            data = torch.from_numpy(np.ascontiguousarray(data))
+        data = data.to('cuda')
+        ns = len(self.sample_shape)
+        whole = (index == (slice(None),) and data.ndim > ns
+                 and tuple(data.shape[data.ndim - ns:]) == tuple(self.sample_shape)
+                 and data.is_complex() == self.complex_data)
+        if not whole:
+            block = self._fresh_block(w0, w1)
+            block[index] = data.to(block.dtype)
+            data = block
+        encoded = self._encode(kernels.as_device_samples(data))
+        self.words[w0:w1] = encoded.reshape(-1)
+        self._dwords = None
 
     data = property(__getitem__, doc="Full decoded payload (device tensor).")
 

@@ -23,13 +23,44 @@ class LazyWriteFile:
         self.name = name
         self._fh = None
 
+    mode = 'rb+'                        # what io.open(name, 'w+b') reports
+
     def _open(self):
         if self._fh is None:
-            self._fh = open(self.name, 'wb')
+            self._fh = open(self.name, 'w+b')
         return self._fh
 
     def write(self, data):
         return self._open().write(data)
+
+    def tell(self):
+        return self._fh.tell() if self._fh is not None else 0
+
+    def seek(self, offset, whence=0):
+        return self._open().seek(offset, whence)
+
+    def read(self, count=-1):
+        return self._open().read(count)
+
+    def flush(self):
+        if self._fh is not None:
+            self._fh.flush()
+
+    @property
+    def closed(self):
+        return self._fh is not None and self._fh.closed
+
+    def memmap(self, dtype=np.uint8, mode=None, offset=None, shape=None, order='C'):
+        """Writable map of the next bytes (the file grows to hold them), as
+        ``numpy.memmap`` on a file opened 'w+b' gives the reference's
+        ``memmap_frame`` (dada/base.py:185-208)."""
+        if shape is None:
+            raise ValueError('cannot make writable memmap without shape.')
+        fh = self._open()
+        start = fh.tell() if offset is None else offset
+        mm = np.memmap(fh, dtype, mode or 'r+', start, shape, order)
+        fh.seek(start + mm.nbytes)
+        return mm
 
     def close(self):
         self._open().close()

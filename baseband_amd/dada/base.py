@@ -64,6 +64,16 @@ class DADAFileWriter(FileBase):
             data = DADAFrame.fromdata(data, header)
         return data.tofile(self.fh_raw)
 
+    def memmap_frame(self, header=None, **kwargs):
+        """Write the header now and map the payload, so that the frame can be
+        filled in pieces by setting slices of it (dada/base.py `memmap_frame`);
+        every piece is packed by the GPU encoder."""
+        if header is None:
+            header = DADAHeader.fromvalues(**kwargs)
+        header.tofile(self.fh_raw)
+        payload = DADAPayload.fromfile(self.fh_raw, memmap=True, header=header)
+        return DADAFrame(header, payload)
+
 
 class DADAStreamReader(BlockStreamReader):
     """DADA stream -> device tensor (nsample, npol, nchan)."""

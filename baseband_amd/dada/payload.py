@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from .. import _lib, kernels
-from ..base.payload import PayloadBase
+from ..base.payload import PayloadBase, RowSetMixin
 
 __all__ = ['DADAPayload', 'MKBFPayload', 'decode_i8_rows']
 
@@ -30,7 +30,7 @@ def decode_i8_rows(dbuf, byte0, row_nbytes, start, stop):
     return flat[b0 - lo:b1 - lo]
 
 
-class DADAPayload(PayloadBase):
+class DADAPayload(RowSetMixin, PayloadBase):
     _memmap = True
     _dtype_word = np.dtype('<u4')
     _coder_id = _lib.CODER_INT
@@ -93,6 +93,13 @@ class DADAPayload(PayloadBase):
 
     data = property(__getitem__, doc="Full decoded payload (device tensor).")
 
+    def _store_rows(self, lo, hi, block):
+        if self.bps != 8:
+            raise ValueError(f"{type(self).__name__} cannot encode data with {self.bps} bits")
+        comp = torch.view_as_real(block) if block.is_complex() else block
+        enc = kernels.encode_flat(comp, _lib.CODER_INT, 8).cpu().numpy().view(np.int8)
+        self.words.view(np.int8).reshape(len(self), -1)[lo:hi] = enc.reshape(hi - lo, -1)
+
     @classmethod
     def fromdata(cls, data, header=None, bps=8):
         """(nsample, npol, nchan) samples -> int8 words (dada/payload.py:17-18,
@@ -115,6 +122,15 @@ class DADAPayload(PayloadBase):
 class MKBFPayload(DADAPayload):
     """Heaps of 256 samples stored (heap, pol, chan, 256, re/im)
     (dada/payload.py:54-89)."""
+
+    _row_granule = 256
+
+    def _store_rows(self, lo, hi, block):
+        npol, nchan = self.sample_shape
+        comp = torch.view_as_real(block).reshape(-1, 256, npol, nchan, 2).movedim(1, 3)
+        enc = kernels.encode_flat(comp, _lib.CODER_INT, 8).cpu().numpy().view(np.int8)
+        self.words.view(np.int8).reshape(len(self) // 256, -1)[lo // 256:hi // 256] = (
+            enc.reshape((hi - lo) // 256, -1))
 
     def _rows(self, start, stop):
         if self.bps != 8 or not self.complex_data:

@@ -50,6 +50,16 @@ class GUPPIFileWriter(FileBase):
             data = GUPPIFrame.fromdata(data, header)
         return data.tofile(self.fh_raw)
 
+    def memmap_frame(self, header=None, **kwargs):
+        """Write the header now and map the payload, so that the frame can be
+        filled in pieces by setting slices of it (guppi/base.py `memmap_frame`);
+        every piece is packed by the GPU encoder."""
+        if header is None:
+            header = GUPPIHeader.fromvalues(**kwargs)
+        header.tofile(self.fh_raw)
+        payload = GUPPIPayload.fromfile(self.fh_raw, memmap=True, header=header)
+        return GUPPIFrame(header, payload)
+
 
 class GUPPIStreamReader(BlockStreamReader):
     """GUPPI stream -> device tensor (nsample, npol, nchan)."""

@@ -7,12 +7,12 @@ import numpy as np
 import torch
 
 from .. import _lib, kernels
-from ..base.payload import PayloadBase
+from ..base.payload import PayloadBase, RowSetMixin
 
 __all__ = ['GUPPIPayload']
 
 
-class GUPPIPayload(PayloadBase):
+class GUPPIPayload(RowSetMixin, PayloadBase):
     _dtype_word = np.dtype('int8')
     _memmap = True
     _coder_id = _lib.CODER_INT
@@ -96,5 +96,20 @@ class GUPPIPayload(PayloadBase):
             data = data[(Ellipsis,) + sample_index] if not isinstance(first, slice) \
                 else data[(slice(None),) + sample_index]
         return data
+
+    def _store_rows(self, lo, hi, block):
+        """Pack rows [lo, hi) given as (n, npol, nchan) and put them at their
+        place in the on-disk order."""
+        npol, nchan = self.sample_shape
+        comp = torch.view_as_real(block) if block.is_complex() else block.unsqueeze(-1)
+        ncomp = comp.shape[-1]
+        comp = comp.permute(2, 0, 1, 3) if self.channels_first else comp.permute(0, 2, 1, 3)
+        enc = kernels.encode_flat(comp, _lib.CODER_INT, 8).cpu().numpy().view(np.int8)
+        words = self.words.view(np.int8)
+        if self.channels_first:
+            words.reshape(nchan, len(self), npol * ncomp)[:, lo:hi] = enc.reshape(
+                nchan, hi - lo, npol * ncomp)
+        else:
+            words.reshape(len(self), -1)[lo:hi] = enc.reshape(hi - lo, -1)
 
     data = property(__getitem__, doc="Full decoded payload (device tensor).")

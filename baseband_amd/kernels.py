@@ -296,10 +296,17 @@ def encode_flat(values, coder, bps):
         values = torch.view_as_real(values)
     values = values.to(torch.float32).contiguous().reshape(-1)
     nbytes = values.numel() * bps // 8 if bps in (1, 2, 4, 8) else 0
-    out = torch.empty(nbytes, dtype=torch.uint8, device=values.device)
+    # the kernel packs quads of samples into whole bytes: a shorter tail (item
+    # assignment of a few samples) is padded here and cut off the output
+    unit = max(4, 8 // bps) if bps in (1, 2, 4, 8) else 4
+    short = -values.numel() % unit
+    if short and (values.numel() * bps) % 8 == 0:       # whole bytes only
+        values = torch.nn.functional.pad(values, (0, short))
+    out = torch.empty(values.numel() * bps // 8 if bps in (1, 2, 4, 8) else 0,
+                      dtype=torch.uint8, device=values.device)
     check(lib.bb_encode_flat(_ptr(values), values.numel(), coder, bps, _ptr(out),
                              out.numel(), _stream()), 'bb_encode_flat')
-    return out
+    return out[:nbytes]
 
 
 def encode_mark4(values, ntrack, sign_bit, mag_bit):

@@ -110,4 +110,19 @@ class Mark4Frame(FrameBase):
             data = data[(Ellipsis,) + sample_index]
         return data
 
+    def __setitem__(self, item, value):
+        """Header key -> header; samples -> payload, ignoring whatever falls
+        in the part overwritten by the header (mark4/frame.py:265-295).  The
+        frame is updated as a whole on the GPU and its payload packed again."""
+        if isinstance(item, str):
+            return self.header.__setitem__(item, value)
+        nfill = len(self) - len(self.payload)
+        if not isinstance(value, torch.Tensor):
+            value = torch.from_numpy(np.ascontiguousarray(value))
+        assert value.ndim <= 2
+        full = torch.cat([self._fill((nfill,) + tuple(self.sample_shape)),
+                          self.payload.data])
+        full[item] = value.to(device=full.device, dtype=full.dtype)
+        self.payload[:] = full[nfill:]
+
     data = property(__getitem__, doc="Full decoded frame (device tensor).")

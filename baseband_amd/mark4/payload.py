@@ -63,6 +63,11 @@ class Mark4Payload(PayloadBase):
             self._device_words(), 1, self.ntrack, nwords, maps['sign_bit'],
             maps['mag_bit'], src0=byte_start)
 
+    def _encode(self, data):
+        maps = BITMAPS[self._coder]
+        words = kernels.encode_mark4(data, self.ntrack, maps['sign_bit'], maps['mag_bit'])
+        return words.cpu().numpy().view(self._dtype_word)
+
     @classmethod
     def fromdata(cls, data, header):
         """Encode (nsample, nchan) data with the header's track layout on the

@@ -227,4 +227,38 @@ class VDIFFrameSet:
             return values[0] if len(np.unique(values)) == 1 else values
         return self._decode_all()[item]
 
+    def __setitem__(self, item, data):
+        """Header keys for all frames, or samples in the (nsample, nthread,
+        nchan) view of the set (vdif/frame.py:436-486): the touched threads'
+        payloads are packed again by the GPU encoder."""
+        if isinstance(item, str):
+            if isinstance(data, (int, np.integer)):
+                data = [int(data)] * len(self.frames)
+                len_unique = 1
+            elif (isinstance(data, (tuple, list))
+                  and all(isinstance(d, (int, np.integer)) for d in data)):
+                len_unique = len(set(data))
+            else:
+                raise ValueError("header items can only be set to integers.")
+            if item == 'thread_id':
+                if len_unique != len(self.frames):
+                    raise ValueError("all thread ids should be unique.")
+            elif (item != 'invalid_data' and len_unique > 1
+                  and item in ('invalid_data', 'legacy_mode', 'seconds', '_1_30_2',
+                               'ref_epoch', 'frame_nr', 'vdif_version', 'lg2_nchan',
+                               'frame_length', 'complex_data', 'bits_per_sample',
+                               'thread_id', 'station_id')):
+                raise ValueError("base header keys should be identical.")
+            for f, value in zip(self.frames, data):
+                f.header[item] = value
+            return
+        full = self._decode_all().clone()
+        if not isinstance(data, torch.Tensor):
+            data = torch.from_numpy(np.ascontiguousarray(data))
+        touched = torch.zeros(full.shape, dtype=torch.bool, device=full.device)
+        touched[item] = True
+        full[item] = data.to(device=full.device, dtype=full.dtype)
+        for t in torch.nonzero(touched.any(0).any(-1)).flatten().tolist():
+            self.frames[t].payload[:] = full[:, t]
+
     data = property(__getitem__, doc="Decoded frame set (device tensor).")

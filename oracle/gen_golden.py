@@ -1486,6 +1486,105 @@ def gen_mark4_header():
           'errors', sum('error' in r for r in out['fromvalues']))
 
 
+def gen_setitem():
+    """``obj[item] = values`` on payloads, frames and frame sets through the
+    reference (base/payload.py:332-347, base/frame.py:203-207,
+    mark4/frame.py:265-295, vdif/frame.py:436-486, guppi/payload.py:112-140):
+    initial words, the assignments (items + values) and the words afterwards."""
+    rng = np.random.default_rng(20240611)
+    arrays, meta = {}, []
+
+    def dec(x):
+        return slice(x[1], x[2], x[3]) if isinstance(x, list) else x
+
+    def values(shape, cplx, scale):
+        v = rng.normal(0., scale, size=shape)
+        if cplx:
+            v = v + 1j * rng.normal(0., scale, size=shape)
+            return v.astype('c8')
+        return v.astype('f4')
+
+    def run(name, obj, words_of, ops, cplx, scale, recipe):
+        arrays[name + '_words0'] = np.concatenate([np.asarray(w).view(np.uint8).ravel() for w in words_of(obj)])
+        recs = []
+        for j, item in enumerate(ops):
+            key = tuple(dec(v) for v in item)
+            key = key[0] if len(key) == 1 else key
+            shape = np.empty(obj.shape, bool)[key].shape
+            v = values(shape, cplx, scale)
+            arrays['{}_v{}'.format(name, j)] = v
+            try:
+                obj[key] = v
+                recs.append(dict(item=item))
+            except Exception as exc:
+                recs.append(dict(item=item, error=type(exc).__name__))
+        arrays[name + '_words1'] = np.concatenate([np.asarray(w).view(np.uint8).ravel() for w in words_of(obj)])
+        meta.append(dict(name=name, recipe=recipe, shape=list(obj.shape), ops=recs))
+
+    S = lambda a, b, c=None: ['slice', a, b, c]
+    # VDIF payloads
+    for name, bps, cplx, nchan, n in (('vdif_p2r4', 2, False, 4, 64), ('vdif_p4c2', 4, True, 2, 48),
+                                      ('vdif_p1r1', 1, False, 1, 256), ('vdif_p8r16', 8, False, 16, 20)):
+        d = values((n, nchan), cplx, 2. if bps < 8 else 30.)
+        pl = vdif.VDIFPayload.fromdata(d, bps=bps)
+        pl.words = pl.words.copy()
+        run(name, pl, lambda o: [o.words],
+            [[3], [S(5, 17)], [S(2, 40, 3), min(1, nchan - 1)], [S(None, None)], [-1, S(0, 1)], [S(7, 8)]],
+            cplx, 2. if bps < 8 else 30., dict(kind='vdif_payload', bps=bps, complex_data=cplx, nchan=nchan))
+    # Mark 5B payload (fixed 10000 bytes): 8 channels, 2 bit -> 5000 samples
+    d = values((5000, 8), False, 2.)
+    pl = mark5b.Mark5BPayload.fromdata(d, bps=2)
+    pl.words = pl.words.copy()
+    run('mark5b_p2', pl, lambda o: [o.words], [[11], [S(100, 228)], [S(3, 999, 7), S(2, 5)], [S(4990, None)]],
+        False, 2., dict(kind='mark5b_payload', bps=2, nchan=8))
+    # Mark 4 frame: assignments reaching into the part under the header
+    time = Time('2014-06-15T12:34:56.0125', precision=9)
+    h4 = mark4.Mark4Header.fromvalues(ntrack=32, time=time, bps=2, fanout=4)
+    d = values((h4.samples_per_frame, h4.nchan), False, 2.)
+    fr = mark4.Mark4Frame.fromdata(d, h4)
+    fr.payload.words = fr.payload.words.copy()
+    run('mark4_f32', fr, lambda o: [o.payload.words],
+        [[S(0, 700)], [650, 1], [S(10000, 10100, 7)], [S(630, 650), S(1, 3)], [S(100, 200)], [79999]],
+        False, 2., dict(kind='mark4_frame', ntrack=32, fanout=4, bps=2,
+                        time_unix_ns=1402835696 * 10**9 + 12500000))
+    # DADA payloads (standard and MKBF heaps)
+    d = values((64, 2, 4), True, 30.)
+    hd = dada.DADAHeader.fromvalues(time=Time('2013-07-02T01:39:20'), samples_per_frame=64,
+                                    sample_rate=16 * u.MHz, bps=8, complex_data=True, sample_shape=(2, 4))
+    pl = dada.DADAPayload.fromdata(d, header=hd)
+    pl.words = pl.words.copy()
+    run('dada_c', pl, lambda o: [o.words], [[3], [S(5, 17)], [S(2, 40, 3), 1], [S(8, 12), S(None, None), 2], [S(None, None)]],
+        True, 30., dict(kind='dada_payload', sample_shape=[2, 4], complex_data=True))
+    # GUPPI payloads: channels first and time first
+    for name, cf in (('guppi_cf', True), ('guppi_tf', False)):
+        d = values((96, 2, 4), True, 30.)
+        pl = guppi.GUPPIPayload.fromdata(d, bps=8, channels_first=cf)
+        pl.words = pl.words.copy()
+        run(name, pl, lambda o: [o.words], [[3], [S(5, 17)], [S(2, 40, 3), 1], [S(8, 12), S(None, None), 2], [S(90, None)]],
+            True, 30., dict(kind='guppi_payload', sample_shape=[2, 4], channels_first=cf))
+    # GSB rawdump 4 bit and phased-like 8 bit single stream
+    d = values((128, 1), False, 3.)
+    pl = gsb.GSBPayload.fromdata(d, bps=4)
+    pl.words = pl.words.copy()
+    run('gsb_r4', pl, lambda o: [o.words], [[3], [S(5, 17)], [S(2, 40, 3)], [S(100, None)]], False, 3.,
+        dict(kind='gsb_payload', bps=4, complex_data=False, sample_shape=[1]))
+    # VDIF frame set: 4 threads, 2 channels, 2 bit real
+    d = values((32, 4, 2), False, 2.)
+    h0 = vdif.VDIFHeader.fromvalues(edv=0, time=Time('2015-06-07T08:09:10'), nchan=2, bps=2,
+                                    complex_data=False, thread_id=0, samples_per_frame=32, station='AA')
+    fs = vdif.VDIFFrameSet.fromdata(d, h0)
+    for f in fs.frames:
+        f.payload.words = f.payload.words.copy()
+    run('vdif_fs', fs, lambda o: [f.payload.words for f in o.frames],
+        [[S(3, 9), 1], [S(None, None), 2, 1], [5], [S(0, 32, 5), S(1, 3), 0], [7, 3, 1], [S(None, None)]],
+        False, 2., dict(kind='vdif_frameset', nthread=4, nchan=2, bps=2, samples_per_frame=32,
+                        words=[int(w) for w in h0.words]))
+    np.savez_compressed(os.path.join(GOLD, 'setitem_cases.npz'), **arrays)
+    with open(os.path.join(GOLD, 'setitem_cases.json'), 'w') as f:
+        json.dump(meta, f, indent=0)
+    print('setitem:', [(m['name'], sum('error' in o for o in m['ops'])) for m in meta])
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1560,7 +1659,7 @@ if __name__ == '__main__':
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
              ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer),
              ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz), ('locate', gen_locate), ('header_fuzz', gen_header_fuzz),
-             ('mark4_header', gen_mark4_header)]
+             ('mark4_header', gen_mark4_header), ('setitem', gen_setitem)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

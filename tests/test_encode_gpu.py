@@ -113,7 +113,10 @@ def test_complex_and_errors():
     with pytest.raises(KeyError):
         kernels.encode_flat(torch.zeros(8, device='cuda'), _lib.CODER_MARK5B, 4)
     with pytest.raises(_lib.BBError):
-        kernels.encode_flat(torch.zeros(6, device='cuda'), 0, 2)       # not a multiple of 4
+        kernels.encode_flat(torch.zeros(6, device='cuda'), 0, 2)       # not whole bytes
+    # whole bytes that are not whole quads are padded on the host side
+    got = kernels.encode_flat(torch.tensor([1., -3.], device='cuda'), _lib.CODER_INT, 4).cpu().numpy()
+    assert got.tolist() == [0xd1]
 
 
 def test_mark4_encoders_match_reference(gold):
@@ -506,5 +509,5 @@ def test_gsb_writer_from_keywords(gsb_gold, tmp_path):
     assert open(raw, 'rb').read() == gsb_gold['ph2_raw'].tobytes()
     with pytest.raises(TypeError):
         gsb.open(ts, 'ws', time=t0)                              # no raw
-    with pytest.raises(ValueError):
-        gsb.open(ts, 'wb', raw=raw)
+    with pytest.raises(TypeError):
+        gsb.open(ts, 'wb', raw=raw)                              # raw is for streams
