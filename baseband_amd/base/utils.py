@@ -1,0 +1,135 @@
+"""Small host-side helpers with the names of the reference's
+``baseband.base.utils`` (base/utils.py:13-250): least common multiple, binary
+coded decimals, byte patterns and the two kinds of cyclic redundancy checks
+(per value: Mark 5B headers; per bit stream: Mark 4 headers).  Headers are
+host metadata -- the bulk checks of every frame in a file run in the scan
+kernels (``bb_mark5b_locate`` checks the CRC-16 of each candidate header on
+the GPU); these serve header construction and single-header verification."""
+import operator
+from math import gcd
+
+import numpy as np
+
+__all__ = ['lcm', 'bcd_decode', 'bcd_encode', 'byte_array', 'CRC', 'CRCStack']
+
+
+def lcm(a, b):
+    """Least common multiple of a and b."""
+    return abs(a * b) // gcd(a, b)
+
+
+def _digits(value, base):
+    n = value.dtype.itemsize * 2
+    place = np.arange(n)
+    if base == 16:
+        return (value[..., np.newaxis] >> (4 * place).astype(value.dtype)) & 0xf
+    return (value[..., np.newaxis] // (10 ** place).astype(value.dtype)) % 10
+
+
+def bcd_decode(value):
+    """Binary coded decimal -> integer, e.g. 0x1234 -> 1234; arrays of integers
+    element by element.  A nibble above 9 is a ValueError (base/utils.py:18-34)."""
+    try:
+        return int('{:x}'.format(operator.index(value)))
+    except TypeError as exc:
+        if getattr(getattr(value, 'dtype', None), 'kind', '') not in 'iu' or \
+                getattr(value, 'dtype', None) is None:
+            raise exc
+    digits = _digits(value, 16)
+    if digits.size and digits.max() > 9:
+        bad = value[(digits > 9).any(-1)].ravel()[0]
+        raise ValueError("invalid BCD encoded value {0}={1}.".format(bad, hex(bad)))
+    place = np.arange(digits.shape[-1])
+    return (digits.astype(np.int64) * 10 ** place).sum(-1)
+
+
+def bcd_encode(value):
+    """Integer -> binary coded decimal, e.g. 1234 -> 0x1234 (base/utils.py:37-49)."""
+    try:
+        return int('{:d}'.format(operator.index(value)), base=16)
+    except TypeError as exc:
+        if getattr(getattr(value, 'dtype', None), 'kind', '') not in 'iu' or \
+                getattr(value, 'dtype', None) is None:
+            raise exc
+    digits = _digits(value, 10).astype(np.int64)
+    place = np.arange(digits.shape[-1])
+    return (digits << (4 * place)).sum(-1)
+
+
+def byte_array(pattern):
+    """Pattern -> array of bytes: arrays and ``bytes`` are viewed, (iterables
+    of) unsigned 32-bit integers are stored little-endian (base/utils.py:52-76)."""
+    if isinstance(pattern, (np.ndarray, bytes)):
+        return np.atleast_1d(pattern).view('u1')
+    pattern = np.array(pattern, ndmin=1)
+    if (pattern.dtype.kind not in 'uif' or pattern.min() < 0
+            or pattern.max() >= 1 << 32):
+        raise ValueError('values have to fit in 32 bit unsigned int.')
+    return pattern.astype('<u4').view('u1')
+
+
+class CRC:
+    """Cyclic redundancy check with the given binary-encoded divisor, e.g.
+    0x18005 (x^16 + x^15 + x^2 + 1) for Mark 5B headers.  Calling the instance
+    gives the CRC of an integer (of any length) or of every element of an
+    array; ``check`` tells whether a value that ends in its CRC is consistent
+    (base/utils.py:93-197)."""
+
+    def __init__(self, polynomial):
+        self.polynomial = operator.index(polynomial)
+
+    def __len__(self):
+        return self.polynomial.bit_length() - 1
+
+    def __call__(self, stream):
+        return self._remainder(stream, extend=True)
+
+    def check(self, stream):
+        return self._remainder(stream, extend=False) == 0
+
+    def _remainder(self, stream, extend):
+        try:
+            value = operator.index(stream)
+        except TypeError:
+            return self._remainder_array(stream, extend)
+        if extend:
+            value <<= len(self)
+        width = self.polynomial.bit_length()
+        while value.bit_length() >= width:
+            value ^= self.polynomial << (value.bit_length() - width)
+        return value
+
+    def _remainder_array(self, array, extend):
+        array = np.array(array, copy=True, dtype='u8')
+        if extend:
+            array <<= np.uint64(len(self))
+        width = self.polynomial.bit_length()
+        top = int(array.max()).bit_length() if array.size else 0
+        while top >= width:
+            # divide at bit `top` wherever it is set
+            hit = (array >> np.uint64(top - 1)) & np.uint64(1)
+            array ^= hit * np.uint64(self.polynomial << (top - width))
+            top -= 1
+        return array
+
+
+class CRCStack(CRC):
+    """CRC over bit streams stacked in the bits of unsigned integers (or a
+    single stream of bool): element i of the array holds bit i of every
+    stream, as the tracks of a Mark 4 header do (base/utils.py:200-248)."""
+
+    def check(self, stream):
+        return np.all(self._remainder(stream, extend=False) == 0)
+
+    def _remainder(self, stream, extend):
+        ncrc = len(self)
+        stream = np.asarray(stream)
+        if extend:
+            stream = np.hstack((stream, np.zeros(ncrc, stream.dtype)))
+        else:
+            stream = stream.copy()
+        taps = np.array([-int(bit) for bit in '{:b}'.format(self.polynomial)],
+                        dtype='i1').astype(stream.dtype)
+        for i in range(len(stream) - ncrc):
+            stream[i:i + ncrc + 1] ^= stream[i] & taps
+        return stream[-ncrc:]

@@ -1585,6 +1585,37 @@ def gen_setitem():
     print('setitem:', [(m['name'], sum('error' in o for o in m['ops'])) for m in meta])
 
 
+def gen_utils():
+    """Known answers of the reference's helpers (base/utils.py:13-250): BCD,
+    CRC per value (Mark 5B polynomial and a short one), CRC over stacked bit
+    streams (Mark 4 polynomial), byte patterns."""
+    from baseband.base.utils import bcd_decode, bcd_encode, CRC, CRCStack, byte_array, lcm
+    rng = np.random.default_rng(99)
+    out = {}
+    vals = [int(v) for v in rng.integers(0, 10**8, 20)]
+    out['bcd'] = [[v, int(bcd_encode(v))] for v in vals]
+    arr = rng.integers(0, 10**8, 16).astype(np.uint32)
+    out['bcd_array'] = [arr.tolist(), np.asarray(bcd_encode(arr)).tolist()]
+    out['crc'] = []
+    for pol in (0x18005, 0x180f, 0x13):
+        c = CRC(pol)
+        ints = [int(v) for v in rng.integers(0, 2**48, 10)] + [0, 1, 2**80 + 12345]
+        out['crc'].append(dict(polynomial=pol, length=len(c), values=[[str(v), int(c(v))] for v in ints],
+                               array=[[int(v) for v in ints[:10]],
+                                      np.asarray(c(np.array(ints[:10], dtype='u8'))).tolist()]))
+    cs = CRCStack(0x180f)
+    stream = rng.integers(0, 2**32, 148).astype(np.uint32)
+    bits = rng.integers(0, 2, 60).astype(bool)
+    out['crcstack'] = dict(stream=stream.tolist(), crc=np.asarray(cs(stream)).tolist(),
+                           bits=bits.astype(int).tolist(), bits_crc=np.asarray(cs(bits)).astype(int).tolist())
+    out['byte_array'] = [[[0xabaddeed], byte_array(0xabaddeed).tolist()],
+                         [[1, 2**32 - 1], byte_array([1, 2**32 - 1]).tolist()]]
+    out['lcm'] = [[4, 6, int(lcm(4, 6))], [21, 6, int(lcm(21, 6))]]
+    with open(os.path.join(GOLD, 'utils_cases.json'), 'w') as f:
+        json.dump(out, f)
+    print('utils:', {k: len(v) for k, v in out.items()})
+
+
 def gen_block_writers():
     """DADA / GUPPI stream writers of the reference (dada/base.py:333-362,
     guppi/base.py:281-310) on seeded non-integer data (exercises the round +
@@ -1659,7 +1690,7 @@ if __name__ == '__main__':
              ('sequence', gen_sequence), ('block_writers', gen_block_writers),
              ('fixed_corrupt', gen_fixed_corrupt), ('info', gen_info), ('gsb_writer', gen_gsb_writer),
              ('stream_fuzz', gen_stream_fuzz), ('item_fuzz', gen_item_fuzz), ('locate', gen_locate), ('header_fuzz', gen_header_fuzz),
-             ('mark4_header', gen_mark4_header), ('setitem', gen_setitem)]
+             ('mark4_header', gen_mark4_header), ('setitem', gen_setitem), ('utils', gen_utils)]
     mpath = os.path.join(GOLD, 'manifest.json')
     if os.path.exists(mpath) and which != ['all']:
         with open(mpath) as f:

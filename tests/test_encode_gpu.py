@@ -511,3 +511,31 @@ def test_gsb_writer_from_keywords(gsb_gold, tmp_path):
         gsb.open(ts, 'ws', time=t0)                              # no raw
     with pytest.raises(TypeError):
         gsb.open(ts, 'wb', raw=raw)                              # raw is for streams
+
+
+def test_base_encoding_module_matches_oracle_and_library_tables(gold):
+    """``baseband_amd.base.encoding`` (the names of base/encoding.py:12-160):
+    level tables are the library's and equal the reference's; the unpacked
+    coders and the 8-bit decoder equal the oracle for odd-sized inputs."""
+    import torch
+    from baseband_amd.base import encoding as enc
+    for bps in (1, 2, 4):
+        assert bits_equal(enc.decoder_levels[bps], orc.code_levels('vdif', bps))
+    with pytest.raises(KeyError):
+        enc.decoder_levels[3]
+    assert (enc.OPTIMAL_2BIT_HIGH, enc.TWO_BIT_1_SIGMA, enc.FOUR_BIT_1_SIGMA,
+            enc.EIGHT_BIT_1_SIGMA) == (3.316505, 2.174564, 2.95, 35.5)
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((37, 3)) * 2.5).astype(np.float32)       # 111 samples: ragged
+    for bps, fn in ((1, enc.encode_1bit_base), (2, enc.encode_2bit_base),
+                    (4, enc.encode_4bit_base), (8, enc.encode_8bit)):
+        scale = 30. if bps == 8 else 1.
+        got = fn(x[:36] * np.float32(scale))
+        want = orc.encode_codes((x[:36] * np.float32(scale)).ravel(), 'vdif', bps).reshape(36, 3)
+        assert got.shape == (36, 3) and got.dtype == torch.uint8
+        assert np.array_equal(got.cpu().numpy(), want), bps
+    words = rng.integers(0, 256, 1003, dtype=np.uint8)
+    out = enc.decode_8bit(words)
+    assert bits_equal(out.cpu().numpy(), orc.code_levels('vdif', 8)[words])
+    out2 = enc.decode_8bit(torch.from_numpy(words).cuda())
+    assert bool((out2 == out).all())

@@ -677,3 +677,44 @@ def test_plugin_entry_points_name_format_modules():
         assert ':' not in target                   # a module entry = a format
         mod = importlib.import_module(target)
         assert callable(mod.open) and callable(mod.info)
+
+
+def test_utils_match_reference_known_answers():
+    """base.utils helpers against the reference's answers
+    (tests/golden/utils_cases.json, oracle/gen_golden.py `utils`;
+    base/utils.py:13-250)."""
+    import json
+    from baseband_amd.base.utils import bcd_decode, bcd_encode, CRC, CRCStack, byte_array, lcm
+    with open(golden_path('utils_cases.json')) as f:
+        g = json.load(f)
+    for v, enc in g['bcd']:
+        assert bcd_encode(v) == enc and bcd_decode(enc) == v
+    arr, enc = (np.array(a, dtype=np.uint32) for a in g['bcd_array'])
+    assert np.array_equal(bcd_encode(arr), enc) and np.array_equal(bcd_decode(enc), arr)
+    with pytest.raises(ValueError):
+        bcd_decode(np.array([0x1a], dtype=np.uint32))
+    with pytest.raises(ValueError):
+        bcd_decode(0x1a)
+    for rec in g['crc']:
+        c = CRC(rec['polynomial'])
+        assert len(c) == rec['length']
+        for v, want in rec['values']:
+            v = int(v)
+            assert c(v) == want and c.check((v << len(c)) | want)
+            assert not c.check(((v << len(c)) | want) ^ 1)
+        vals, want = rec['array']
+        assert np.array_equal(c(np.array(vals, dtype='u8')), np.array(want, dtype='u8'))
+        assert np.all(c.check((np.array(vals, dtype='u8') << np.uint64(len(c)))
+                              | np.array(want, dtype='u8')))       # 48 + 16 bits fit
+    cs = CRCStack(0x180f)
+    stream = np.array(g['crcstack']['stream'], dtype=np.uint32)
+    crc = cs(stream)
+    assert crc.tolist() == g['crcstack']['crc'] and cs.check(np.hstack([stream, crc]))
+    bits = np.array(g['crcstack']['bits'], dtype=bool)
+    assert cs(bits).astype(int).tolist() == g['crcstack']['bits_crc']
+    for pattern, want in g['byte_array']:
+        assert byte_array(pattern if len(pattern) > 1 else pattern[0]).tolist() == want
+    with pytest.raises(ValueError):
+        byte_array(-1)
+    for a, b, want in g['lcm']:
+        assert lcm(a, b) == want
