@@ -36,6 +36,7 @@ TUNE_TILE_ELEMS = 4
 TUNE_ENCODE_DIRECT = 5
 TUNE_GATHER_BYTES = 6
 TUNE_TILES_PER_WAVE = 7
+TUNE_TILES_PER_WAVE_8BIT = 8
 
 
 class BBError(RuntimeError):

@@ -143,6 +143,7 @@ std::atomic<int> g_tune_tile_elems{8192};
 std::atomic<int> g_tune_encode_direct{0};
 std::atomic<int> g_tune_gather_bytes{8192};
 std::atomic<int> g_tune_tpw{12};
+std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
@@ -166,6 +167,15 @@ void launch_flat_aln(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
     if (nt) hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, true, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
     else    hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, false, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+}
+
+// 8-bit data: one dword is only four samples, so a wave needs 32 tiles for a
+// 32 KiB output run (k_decode_flat_aln<.., 2, 32>)
+template <int BPS, int LV>
+void launch_flat_aln32(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+    if (nt) hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, true, 2, 32>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    else    hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, false, 2, 32>), grid, dim3(2 * BB_WAVE), 0, st, a);
 }
 
 template <int BPS, int LV>
@@ -246,6 +256,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_TILE_ELEMS:   g_tune_tile_elems = value > 0 ? value : 8192; return BB_OK;
         case BB_TUNE_ENCODE_DIRECT: g_tune_encode_direct = value; return BB_OK;
         case BB_TUNE_TILES_PER_WAVE: g_tune_tpw = (value >= 1 && value <= 16) ? value : 12; return BB_OK;
+        case BB_TUNE_TILES_PER_WAVE_8BIT: g_tune_tpw8 = (value >= 1 && value <= 32) ? value : 12; return BB_OK;
         case BB_TUNE_GATHER_BYTES: g_tune_gather_bytes = value > 0 ? value : 8192; return BB_OK;
         default: return BB_EINVAL;
     }
@@ -439,7 +450,18 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     hipStream_t st = (hipStream_t)stream;
     const bool nt = g_tune_nt.load() != 0;
 
-    if (g_tune_variant.load() == 1 && p->bps == 2 && om == BB_OUT_FLAT) {
+    // Kernel choice.  The default (5) is the persistent pipelined family with
+    // aligned block loads -- except for 8-bit samples with contiguous output:
+    // they read 20 % of their traffic instead of 6 %, and the plain
+    // one-workgroup-per-32-tiles kernel with an uncapped grid is 3-6 % faster
+    // there for every payload size tried (profiles/r01i_exp_int8_v0.log:
+    // 5.34-5.37 -> 5.55-5.67 TB/s int8, 5.10-5.37 -> 5.44-5.58 VDIF 8-bit).
+    // BB_TUNE_TILES_PER_WAVE_8BIT > 16 selects the long pipelined form again.
+    int variant = g_tune_variant.load();
+    if (variant == 5 && p->bps == 8 && om == BB_OUT_FLAT && g_tune_tpw8.load() <= 16)
+        variant = 0;
+
+    if (variant == 1 && p->bps == 2 && om == BB_OUT_FLAT) {
         uint64_t b2 = nfs;
         if (tb > 0 && b2 > (uint64_t)tb) b2 = (uint64_t)tb;
         if (b2 > 0x7fffffffull) b2 = 0x7fffffffull;
@@ -449,7 +471,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         return BB_OK;
     }
 
-    if (om == BB_OUT_SCATTER && d_src && g_tune_variant.load() >= 2
+    if (om == BB_OUT_SCATTER && d_src && variant >= 2
         && (size_t)p->nslot * 528 + 1024 + 64 <= 48 * 1024) {
         // narrow chunks: assemble output rows in LDS (k_gather.h)
         bb_gather_args ga;
@@ -468,7 +490,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             ga.lrow = -1;
             if ((rl & (rl - 1)) == 0) { ga.lrow = 0; while ((1u << ga.lrow) < rl) ++ga.lrow; }
         }
-        ga.aligned = (g_tune_variant.load() >= 5 && ((uintptr_t)d_buf & 255) == 0) ? 1 : 0;
+        ga.aligned = (variant >= 5 && ((uintptr_t)d_buf & 255) == 0) ? 1 : 0;
         const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024;
         // persistent grid: a workgroup walks about five work items (8 KiB of
         // payload each); one workgroup per item costs 15 %, a few thousand
@@ -491,11 +513,11 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         return BB_OK;
     }
 
-    if (om == BB_OUT_ROWS4 && g_tune_variant.load() >= 3) {
+    if (om == BB_OUT_ROWS4 && variant >= 3) {
         // thread interleave with wide chunks: one wave per thread slot, all
         // waves on the same 8 tiles (k_decode_rows_pipe)
         const int nw = p->nslot >= 8 ? 8 : (p->nslot >= 4 ? 4 : 2);
-        const bool aln = g_tune_variant.load() >= 5 && ((uintptr_t)d_buf & 255) == 0;
+        const bool aln = variant >= 5 && ((uintptr_t)d_buf & 255) == 0;
         const uint64_t seg_max = g_tune_tpw.load() < 8 ? (uint64_t)g_tune_tpw.load() : 8;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
@@ -518,7 +540,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         return BB_OK;
     }
 
-    if (om == BB_OUT_FLAT && g_tune_variant.load() == 4 && a.ndw >= 64 * 16) {
+    if (om == BB_OUT_FLAT && variant == 4 && a.ndw >= 64 * 16) {
         // contiguous output: cut the work in output space (k_decode_flat_span),
         // 2 waves x 16 tiles per item whatever the frame size
         const uint64_t tiles_all = (nfs * a.ndw + 63) / 64;
@@ -539,16 +561,20 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         return BB_OK;
     }
 
-    if (g_tune_variant.load() >= 2) {
+    if (variant >= 2) {
         // persistent pipelined form.  Geometry (waves per workgroup x tiles
         // per wave) is chosen so that a wave writes a long contiguous run:
         // 2 waves x up to 12 tiles (an 8000-byte payload becomes two items of
         // 2 x 8 tiles = 32 KiB runs; with the large grid that beats 2 x 16 by
         // 1.5 %, profiles/r01g_exp_tpw.log).  Variant 2 keeps the
         // 4 x 8 geometry; 2 x 32 tiles was tried for 8-bit data and lost 27 %.
-        const bool wide = g_tune_variant.load() >= 3;
+        const bool wide = variant >= 3;
         const int nw = wide ? 2 : 4;
-        const int tpw_max = wide ? g_tune_tpw.load() : 8;
+        const bool aln = wide && om == BB_OUT_FLAT && variant == 5
+                         && ((uintptr_t)d_buf & 255) == 0;
+        const int tpw8 = g_tune_tpw8.load();
+        const bool long8 = aln && p->bps == 8 && tpw8 > 16;
+        const int tpw_max = long8 ? (tpw8 > 32 ? 32 : tpw8) : wide ? g_tune_tpw.load() : 8;
         const uint64_t seg_max = (uint64_t)nw * tpw_max;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
@@ -567,7 +593,10 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
                     else                          launch_flat_pipe<8, BB_LV_LDS, 4, 8>(om, nt, g2, st, a);
                     break;
             }
-        } else if (om == BB_OUT_FLAT && g_tune_variant.load() == 5 && ((uintptr_t)d_buf & 255) == 0) {
+        } else if (long8) {
+            if (p->coder == BB_CODER_INT) launch_flat_aln32<8, BB_LV_INT8>(nt, g2, st, a);
+            else                          launch_flat_aln32<8, BB_LV_LDS>(nt, g2, st, a);
+        } else if (aln) {
             // aligned 256-byte block loads (k_decode_flat_aln)
             switch (p->bps) {
                 case 1: launch_flat_aln<1, BB_LV_REG>(nt, g2, st, a); break;

@@ -398,6 +398,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */
 #define BB_TUNE_TILE_ELEMS     4   /* elements per tile of bb_decode_i8_tiled (default 8192) */
 #define BB_TUNE_GATHER_BYTES   6   /* payload bytes of all thread slots staged in LDS per work item of k_decode_gather (default 8192) */
+#define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* the same bound for 8-bit data in the aligned flat kernel (1..32; above 16 selects the 32-tile instantiation) */
 #define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */
 #define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
 int bb_tune(int knob, int value);
