@@ -37,6 +37,7 @@ TUNE_ENCODE_DIRECT = 5
 TUNE_GATHER_BYTES = 6
 TUNE_TILES_PER_WAVE = 7
 TUNE_TILES_PER_WAVE_8BIT = 8
+TUNE_LDS_PAD = 9
 
 
 class BBError(RuntimeError):
@@ -123,6 +124,7 @@ SIGNATURES = [
     ('bb_init', C.c_int, []),
     ('bb_get_levels', C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _sz]),
     ('bb_get_encode_thresholds', C.c_int, [C.POINTER(C.c_float)]),
+    ('bb_debug_trace', C.c_int, [_vp]),
     ('bb_vdif_scan', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp]),
     ('bb_vdif_locate', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_vdif_scan_at', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),

@@ -143,6 +143,8 @@ std::atomic<int> g_tune_tile_elems{8192};
 std::atomic<int> g_tune_encode_direct{0};
 std::atomic<int> g_tune_gather_bytes{8192};
 std::atomic<int> g_tune_tpw{12};
+std::atomic<uint64_t *> g_trace{nullptr};
+std::atomic<int> g_tune_lds_pad{0};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
 
 template <int BPS, int LV>
@@ -165,8 +167,10 @@ void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_
 template <int BPS, int LV>
 void launch_flat_aln(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
-    if (nt) hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, true, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
-    else    hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, false, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    // experiment knob: unused dynamic LDS caps the workgroups per CU (160 KiB / pad)
+    const size_t pad = (size_t)g_tune_lds_pad.load();
+    if (nt) hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, true, 2, 16>), grid, dim3(2 * BB_WAVE), pad, st, a);
+    else    hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, false, 2, 16>), grid, dim3(2 * BB_WAVE), pad, st, a);
 }
 
 // 8-bit data: one dword is only four samples, so a wave needs 32 tiles for a
@@ -258,8 +262,15 @@ int bb_tune(int knob, int value)
         case BB_TUNE_TILES_PER_WAVE: g_tune_tpw = (value >= 1 && value <= 16) ? value : 12; return BB_OK;
         case BB_TUNE_TILES_PER_WAVE_8BIT: g_tune_tpw8 = (value >= 1 && value <= 32) ? value : 12; return BB_OK;
         case BB_TUNE_GATHER_BYTES: g_tune_gather_bytes = value > 0 ? value : 8192; return BB_OK;
+        case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         default: return BB_EINVAL;
     }
+}
+
+int bb_debug_trace(uint64_t *d_times)
+{
+    g_trace = d_times;
+    return BB_OK;
 }
 
 int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
@@ -440,6 +451,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     a.fill_im = p->fill_im;
     a.complex_data = p->complex_data;
     a.nt_loads = g_tune_nt_loads.load();
+    a.trace = g_trace.load();
 
     const uint64_t nwork = nfs * a.nseg;
     uint64_t blocks = nwork;

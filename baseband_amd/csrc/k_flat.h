@@ -44,6 +44,7 @@ struct bb_flat_args {
     float    fill_re, fill_im;
     int32_t  complex_data;
     int32_t  nt_loads;      // experiment: non-temporal input loads
+    uint64_t *trace;        // experiment: completion time (wall_clock64) per work item, or null
 };
 
 template <int BPS, int LV>
@@ -166,6 +167,7 @@ void k_decode_flat(bb_flat_args a)
                 }
             }
         }
+        if (a.trace && threadIdx.x == 0) a.trace[work] = wall_clock64();
     }
 }
 
@@ -362,6 +364,7 @@ void k_decode_flat_aln(bb_flat_args a)
     };
 
     uint64_t work = blockIdx.x;
+    if (a.trace && threadIdx.x == 0) a.trace[nwork + blockIdx.x] = wall_clock64();   // workgroup start
     if (work < nwork) issue(work, cur, cur_valid, cur_s);
     for (; work < nwork; work += gridDim.x) {
         const uint64_t next = work + gridDim.x;
@@ -402,6 +405,7 @@ void k_decode_flat_aln(bb_flat_args a)
                 bb_store4<NT>(obase + e0, v);
             }
         }
+        if (a.trace && threadIdx.x == 0) a.trace[work] = wall_clock64();
 #pragma unroll
         for (int u = 0; u <= TPW; ++u) cur[u] = nxt[u];
         cur_valid = nxt_valid;

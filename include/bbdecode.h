@@ -398,10 +398,19 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */
 #define BB_TUNE_TILE_ELEMS     4   /* elements per tile of bb_decode_i8_tiled (default 8192) */
 #define BB_TUNE_GATHER_BYTES   6   /* payload bytes of all thread slots staged in LDS per work item of k_decode_gather (default 8192) */
+#define BB_TUNE_LDS_PAD 9             /* experiment: bytes of unused dynamic LDS per workgroup of the aligned flat kernel (caps workgroups per CU); 0 = none (default) */
 #define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* the same bound for 8-bit data in the aligned flat kernel (1..32; above 16 selects the 32-tile instantiation) */
 #define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */
 #define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
 int bb_tune(int knob, int value);
+
+/* Measurement aid: when d_times is not NULL, the contiguous-output flat decode
+ * kernels store the device wall clock (100 MHz ticks) at which each work item
+ * was completed into d_times[item] (the caller sizes it for the launch: frames
+ * x work items per frame, plus one slot per workgroup of the launch behind
+ * them, where the aligned kernel stores its start time).  NULL switches it off (default).  Not for
+ * production use: one extra 8-byte store per 32-64 KiB of output. */
+int bb_debug_trace(uint64_t *d_times);
 
 #ifdef __cplusplus
 }
