@@ -586,3 +586,11 @@ class GPUStreamReaderBase:
 
 # the reference's names for these roles (base/base.py)
 StreamReaderBase = VLBIStreamReaderBase = GPUStreamReaderBase
+
+from .writer import GPUStreamWriterBase          # noqa: E402  (no import cycle: writer is self-contained)
+from .opener import FormatOpener                 # noqa: E402
+
+StreamWriterBase = VLBIStreamWriterBase = GPUStreamWriterBase
+FileOpener = FormatOpener
+__all__ += ['StreamReaderBase', 'VLBIStreamReaderBase', 'StreamWriterBase',
+            'VLBIStreamWriterBase', 'FileOpener']

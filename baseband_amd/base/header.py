@@ -177,3 +177,7 @@ def strided_header_words(buf, frame_nbytes, nwords, offset=0):
     u4 = np.frombuffer(buf, dtype='<u4', count=len(buf) // 4)
     return np.lib.stride_tricks.as_strided(
         u4, shape=(nframes, nwords), strides=(frame_nbytes, 4), writeable=False)
+
+
+# the reference's names for this role (base/header.py:488-800)
+ParsedHeaderBase = VLBIHeaderBase = BitFieldHeader
