@@ -38,6 +38,8 @@ TUNE_GATHER_BYTES = 6
 TUNE_TILES_PER_WAVE = 7
 TUNE_TILES_PER_WAVE_8BIT = 8
 TUNE_LDS_PAD = 9
+TUNE_TILED_STAGE = 10
+TUNE_MKBF_CHANNELS = 11
 
 
 class BBError(RuntimeError):

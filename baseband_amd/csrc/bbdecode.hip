@@ -144,7 +144,9 @@ std::atomic<int> g_tune_encode_direct{0};
 std::atomic<int> g_tune_gather_bytes{8192};
 std::atomic<int> g_tune_tpw{12};
 std::atomic<uint64_t *> g_trace{nullptr};
-std::atomic<int> g_tune_lds_pad{0};   // bb_debug_trace
+std::atomic<int> g_tune_lds_pad{0};
+std::atomic<int> g_tune_tiled_stage{1};
+std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
 
 template <int BPS, int LV>
@@ -262,6 +264,8 @@ int bb_tune(int knob, int value)
         case BB_TUNE_TILES_PER_WAVE: g_tune_tpw = (value >= 1 && value <= 16) ? value : 12; return BB_OK;
         case BB_TUNE_TILES_PER_WAVE_8BIT: g_tune_tpw8 = (value >= 1 && value <= 32) ? value : 12; return BB_OK;
         case BB_TUNE_GATHER_BYTES: g_tune_gather_bytes = value > 0 ? value : 8192; return BB_OK;
+        case BB_TUNE_TILED_STAGE: g_tune_tiled_stage = value; return BB_OK;
+        case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         default: return BB_EINVAL;
     }
@@ -811,21 +815,39 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     // many times as keep the tile near 8192 elements (16 KiB in, 64 KiB out)
     uint32_t tc = (uint32_t)(nc < 64 ? nc : 64);
     if (tc > 1 && (tc & 1)) tc += 1;
-    uint32_t tt = (uint32_t)g_tune_tile_elems.load() / (uint32_t)(np_ * tc);
+    // MKBF and GUPPI time-first stage the tile in input order and permute on
+    // the LDS read side (k_decode_i8_stage); BB_TUNE_TILED_STAGE 0 = old kernel
+    const bool stage = p->layout != BB_LAYOUT_GUPPI_CF && g_tune_tiled_stage.load() != 0;
+    uint32_t tile_elems = (uint32_t)g_tune_tile_elems.load();
+    // MKBF: 32 channels x 128 times keeps the input runs at 256 bytes and the
+    // tile at 16 KiB of LDS (more workgroups per CU overlap load and store phases)
+    if (stage && p->layout == BB_LAYOUT_MKBF && tc > (uint32_t)g_tune_mkbf_tc.load())
+        tc = (uint32_t)g_tune_mkbf_tc.load();
+    uint32_t tt = tile_elems / (uint32_t)(np_ * tc);
     if (tt < 1) tt = 1;
     if (tt > 1024) tt = 1024;
     if (p->layout == BB_LAYOUT_MKBF) { if (tt > 256) tt = 256; while (256 % tt) --tt; }
     if ((uint64_t)tt > rows) tt = (uint32_t)rows;
     a.tt = tt;
     a.tc = tc;
-    uint32_t pitch_dw = ((tc + 1) / 2) + 1;             // dwords per LDS row
-    if ((pitch_dw & 1) == 0) pitch_dw += 1;             // odd: strided writes hit distinct banks
-    a.tcp = 2 * pitch_dw;
+    size_t lds;
+    if (stage) {
+        // LDS row = one input run: tt times (MKBF) or tc * npol elements (time-first)
+        const uint32_t run = p->layout == BB_LAYOUT_MKBF ? tt : tc * (uint32_t)np_;
+        uint32_t pitch_dw = (run + 1) / 2;
+        if ((pitch_dw & 1) == 0) pitch_dw += 1;         // odd number of dwords
+        a.tcp = 2 * pitch_dw;
+        lds = (size_t)(p->layout == BB_LAYOUT_MKBF ? np_ * tc : tt) * a.tcp * sizeof(uint16_t);
+    } else {
+        uint32_t pitch_dw = ((tc + 1) / 2) + 1;         // dwords per LDS row
+        if ((pitch_dw & 1) == 0) pitch_dw += 1;         // odd: strided writes hit distinct banks
+        a.tcp = 2 * pitch_dw;
+        lds = (size_t)tt * np_ * a.tcp * sizeof(uint16_t);
+    }
     const uint64_t ntt = (rows + tt - 1) / tt, nct = (nc + tc - 1) / tc;
     if (ntt > 0xffffffffull || nct > 0xffffffffull) return BB_ERANGE;
     a.ntt = (uint32_t)ntt;
     a.nct = (uint32_t)nct;
-    const size_t lds = (size_t)tt * np_ * a.tcp * sizeof(uint16_t);
     if (lds > 64 * 1024) return BB_ENOTSUP;
     uint64_t blocks = (uint64_t)nframes * ntt * nct;
     const int tb = g_tune_blocks.load();
@@ -836,11 +858,14 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     const bool nt = g_tune_nt.load() != 0;
 #define BB_TL(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_tiled<L, true>), grid, block, lds, st, a); \
                       else    hipLaunchKernelGGL((k_decode_i8_tiled<L, false>), grid, block, lds, st, a); } while (0)
+#define BB_TS(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_stage<L, true>), grid, block, lds, st, a); \
+                      else    hipLaunchKernelGGL((k_decode_i8_stage<L, false>), grid, block, lds, st, a); } while (0)
     switch (p->layout) {
         case BB_LAYOUT_GUPPI_CF: BB_TL(0); break;
-        case BB_LAYOUT_MKBF:     BB_TL(1); break;
-        default:                 BB_TL(2); break;
+        case BB_LAYOUT_MKBF:     if (stage) BB_TS(1); else BB_TL(1); break;
+        default:                 if (stage) BB_TS(2); else BB_TL(2); break;
     }
+#undef BB_TS
 #undef BB_TL
     BB_HIP(hipGetLastError());
     return BB_OK;

@@ -162,3 +162,107 @@ void k_decode_i8_tiled(bb_tiled_args a)
         __syncthreads();
     }
 }
+
+
+// Layouts whose INPUT rows are long but whose output position is strided
+// (MKBF heaps: a (pol, chan) pair holds 256 consecutive times; GUPPI time-first:
+// one time holds all (chan, pol)): stage the tile in input order -- coalesced
+// dword loads, conflict-free dword LDS writes -- and do the permutation on the
+// LDS READ side, where every lane picks the two 2-byte elements of its float4.
+// The row pitch is an odd number of dwords.  (k_decode_i8_tiled, which places
+// elements at their output position with 2-byte LDS writes and, for these two
+// layouts, read 2-byte pieces from global memory, reached 3.1-3.7 TB/s here;
+// profiles/r01i_exp_tiled.log.)
+//   LAYOUT 1  MKBF: LDS row = (p, c), tt times long       (a.tcp = pitch in elements)
+//   LAYOUT 2  GUPPI time-first: LDS row = one time, tc * npol elements
+template <int LAYOUT, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_i8_stage(bb_tiled_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_tile[];
+    uint32_t *s32 = reinterpret_cast<uint32_t *>(s_tile);
+    const uint32_t npol = a.npol, tc = a.tc, tt = a.tt, pe = a.tcp;
+    const uint64_t rows_out = a.t_hi - a.t_lo;
+    const uint64_t rowlen = (uint64_t)npol * a.nchan * 2;
+    const uint64_t nwork = a.nframes * a.ntt * a.nct;
+    const int lane = bb_lane(), wave = bb_wave();
+
+    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const uint64_t f = work / ((uint64_t)a.ntt * a.nct);
+        const uint32_t rem = (uint32_t)(work - f * a.ntt * a.nct);
+        const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
+        const uint64_t t0 = a.t_lo + (uint64_t)ti * tt;
+        const uint32_t nt_tile = (uint32_t)((a.t_hi - t0 < tt) ? a.t_hi - t0 : tt);
+        const uint32_t c0 = ci * tc;
+        const uint32_t nc_tile = (a.nchan - c0 < tc) ? a.nchan - c0 : tc;
+        const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
+        const bool valid = so >= 0;
+        const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
+
+        if (valid) {
+            const uint32_t nrows_in = LAYOUT == 2 ? nt_tile : npol * nc_tile;
+            const uint32_t run = LAYOUT == 2 ? nc_tile * npol : nt_tile;
+            for (uint32_t r = wave; r < nrows_in; r += BB_WAVES_PER_BLOCK) {
+                if (LAYOUT == 2) {
+                    const uint16_t *row = in + ((t0 + r) * a.nchan + c0) * npol;
+                    if (((uintptr_t)row & 3) == 0) {
+                        for (uint32_t i = lane * 2; i < run; i += 128) {
+                            if (i + 1 < run) s32[(r * pe + i) >> 1] = *reinterpret_cast<const uint32_t *>(row + i);
+                            else             s_tile[r * pe + i] = row[i];
+                        }
+                    } else {
+                        for (uint32_t i = lane; i < run; i += 64) s_tile[r * pe + i] = row[i];
+                    }
+                } else {
+                    const uint32_t p = r / nc_tile, c = r - p * nc_tile;
+                    const uint16_t *rowbase = in + (uint64_t)p * a.sp + (uint64_t)(c0 + c) * a.sc;
+                    // heaps hold 256 times (a.tb == 256): shifts, not divisions
+                    for (uint32_t i = lane * 2; i < run; i += 128) {
+                        const uint64_t t = t0 + i;
+                        const uint16_t *ptr = rowbase + (t >> 8) * a.sh + (t & 255);
+                        if (i + 1 < run && (t & 255) != 255 && ((uintptr_t)ptr & 3) == 0) {
+                            s32[(r * pe + i) >> 1] = *reinterpret_cast<const uint32_t *>(ptr);
+                        } else {
+                            s_tile[r * pe + i] = ptr[0];
+                            if (i + 1 < run) {
+                                const uint64_t t1 = t + 1;
+                                s_tile[r * pe + i + 1] = rowbase[(t1 >> 8) * a.sh + (t1 & 255)];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t pairs = (tc + 1) / 2;
+        const uint32_t nrows = nt_tile * npol;
+        float *obase = a.out + (f * rows_out + (t0 - a.t_lo)) * rowlen + (uint64_t)c0 * 2;
+        for (uint32_t j = threadIdx.x; j < nrows * pairs; j += BB_BLOCK) {
+            const uint32_t row = j / pairs;
+            const uint32_t c = (j - row * pairs) * 2;
+            if (c >= nc_tile) continue;
+            float *o = obase + (uint64_t)row * a.nchan * 2 + (uint64_t)c * 2;
+            const bool two = c + 1 < nc_tile;
+            float v0, v1, v2 = 0.f, v3 = 0.f;
+            if (valid) {
+                const uint32_t tl = row / npol, p = row - tl * npol;
+                const uint32_t i0 = LAYOUT == 2 ? tl * pe + c * npol + p : (p * nc_tile + c) * pe + tl;
+                const uint32_t e0 = s_tile[i0];
+                const uint32_t e1 = two ? s_tile[i0 + (LAYOUT == 2 ? npol : pe)] : 0u;
+                v0 = (float)(int)(int8_t)(e0 & 0xff);
+                v1 = (float)(int)(int8_t)(e0 >> 8);
+                v2 = (float)(int)(int8_t)(e1 & 0xff);
+                v3 = (float)(int)(int8_t)(e1 >> 8);
+            } else {
+                v0 = v2 = a.fill_re; v1 = v3 = a.fill_im;
+            }
+            if (two && (((uintptr_t)o & 15) == 0)) {
+                bb_store4<NT>(o, bb_f4{v0, v1, v2, v3});
+            } else {
+                bb_store1<NT>(o, v0); bb_store1<NT>(o + 1, v1);
+                if (two) { bb_store1<NT>(o + 2, v2); bb_store1<NT>(o + 3, v3); }
+            }
+        }
+        __syncthreads();
+    }
+}

@@ -398,6 +398,8 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */
 #define BB_TUNE_TILE_ELEMS     4   /* elements per tile of bb_decode_i8_tiled (default 8192) */
 #define BB_TUNE_GATHER_BYTES   6   /* payload bytes of all thread slots staged in LDS per work item of k_decode_gather (default 8192) */
+#define BB_TUNE_MKBF_CHANNELS 11      /* channels per MKBF tile in k_decode_i8_stage (even, 2..64; default 32) */
+#define BB_TUNE_TILED_STAGE 10        /* 1 (default): MKBF and GUPPI time-first through k_decode_i8_stage; 0: k_decode_i8_tiled */
 #define BB_TUNE_LDS_PAD 9             /* experiment: bytes of unused dynamic LDS per workgroup of the aligned flat kernel (caps workgroups per CU); 0 = none (default) */
 #define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* the same bound for 8-bit data in the aligned flat kernel (1..32; above 16 selects the 32-tile instantiation) */
 #define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */

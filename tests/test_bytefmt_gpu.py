@@ -71,19 +71,26 @@ def test_guppi_payload_items(manifest, name, item):
         assert bits_equal(frame.data.cpu().numpy(), np.ascontiguousarray(full))
 
 
-def test_tiled_kernel_raw_layouts():
+@pytest.mark.parametrize('stage', [1, 0])
+def test_tiled_kernel_raw_layouts(stage):
     """bb_decode_i8_tiled vs NumPy transposes for all three layouts, odd
-    channel counts, partial time ranges and several frames."""
+    channel counts, partial time ranges (crossing MKBF heaps), several frames,
+    payloads at 2-byte (not 4-byte) aligned offsets; `stage` selects
+    k_decode_i8_stage (default) or k_decode_i8_tiled for MKBF / time-first."""
     import torch
     from baseband_amd import kernels, _lib
+    kernels.tune(_lib.TUNE_TILED_STAGE, stage)
     rng = np.random.default_rng(3)
-    for layout, npol, nchan, T in ((0, 2, 64, 300), (0, 1, 5, 77), (0, 2, 200, 40),
-                                   (1, 2, 32, 512), (1, 1, 3, 256), (2, 2, 8, 100),
-                                   (2, 4, 7, 33), (0, 2, 1, 50)):
+    for layout, npol, nchan, T, head in ((0, 2, 64, 300, 16), (0, 1, 5, 77, 16), (0, 2, 200, 40, 16),
+                                         (1, 2, 32, 512, 16), (1, 1, 3, 256, 16), (2, 2, 8, 100, 16),
+                                         (2, 4, 7, 33, 16), (0, 2, 1, 50, 16),
+                                         (1, 2, 70, 768, 18), (1, 2, 64, 1024, 16), (1, 4, 9, 512, 6),
+                                         (2, 2, 100, 130, 18), (2, 2, 64, 257, 16), (2, 1, 33, 65, 2),
+                                         (2, 2, 1024, 20, 16)):
         nfr = 3
         pn = T * npol * nchan * 2
-        raw = rng.integers(0, 256, size=(nfr, pn + 16), dtype=np.uint8)
-        b = raw[:, 16:].view(np.int8)
+        raw = rng.integers(0, 256, size=(nfr, pn + head), dtype=np.uint8)
+        b = raw[:, head:].view(np.int8)
         if layout == 0:
             ref = b.reshape(nfr, nchan, T, npol, 2).transpose(0, 2, 3, 1, 4)
         elif layout == 1:
@@ -95,7 +102,7 @@ def test_tiled_kernel_raw_layouts():
         dbuf = kernels.to_device_bytes(raw.reshape(-1))
         for lo, hi in ((0, T), (3, T - 5), (T // 2, T // 2 + 1)):
             out = kernels.decode_i8_tiled(dbuf, nfr, layout, npol, nchan, T, lo, hi,
-                                          src0=16, src_stride=pn + 16).cpu().numpy()
+                                          src0=head, src_stride=pn + head).cpu().numpy()
             want = ref[:, lo:hi].reshape(-1)
             assert bits_equal(out, np.ascontiguousarray(want)), (layout, npol, nchan, T, lo, hi)
     # missing frame -> fill
@@ -103,6 +110,7 @@ def test_tiled_kernel_raw_layouts():
     out = kernels.decode_i8_tiled(dbuf, 2, 0, 2, 1, 50, 0, 50, src=src,
                                   fill_value=3 - 4j).cpu().numpy().reshape(2, -1, 2)
     assert np.all(out[1] == np.array([3., -4.], np.float32))
+    kernels.tune(_lib.TUNE_TILED_STAGE, 1)
 
 
 @pytest.mark.parametrize('name', DADA_CASES)
