@@ -40,6 +40,7 @@ TUNE_TILES_PER_WAVE_8BIT = 8
 TUNE_LDS_PAD = 9
 TUNE_TILED_STAGE = 10
 TUNE_MKBF_CHANNELS = 11
+TUNE_GATHER_CHUNKS = 12
 
 
 class BBError(RuntimeError):

@@ -146,14 +146,18 @@ std::atomic<int> g_tune_tpw{12};
 std::atomic<uint64_t *> g_trace{nullptr};
 std::atomic<int> g_tune_lds_pad{0};
 std::atomic<int> g_tune_tiled_stage{1};
+std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
 {
-    if (nt) hipLaunchKernelGGL((k_decode_gather<BPS, LV, true>), grid, dim3(BB_BLOCK), lds, st, a);
-    else    hipLaunchKernelGGL((k_decode_gather<BPS, LV, false>), grid, dim3(BB_BLOCK), lds, st, a);
+    const bool wide = a.lchunk >= 2;
+#define BB_G(NT, W) hipLaunchKernelGGL((k_decode_gather<BPS, LV, NT, W>), grid, dim3(BB_BLOCK), lds, st, a)
+    if (nt) { if (wide) BB_G(true, true); else BB_G(true, false); }
+    else    { if (wide) BB_G(false, true); else BB_G(false, false); }
+#undef BB_G
 }
 
 template <int BPS, int LV, int NW, int TPW>
@@ -265,6 +269,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_TILES_PER_WAVE_8BIT: g_tune_tpw8 = (value >= 1 && value <= 32) ? value : 12; return BB_OK;
         case BB_TUNE_GATHER_BYTES: g_tune_gather_bytes = value > 0 ? value : 8192; return BB_OK;
         case BB_TUNE_TILED_STAGE: g_tune_tiled_stage = value; return BB_OK;
+        case BB_TUNE_GATHER_CHUNKS: g_tune_gather_chunks = value > 0 ? value : 32; return BB_OK;
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         default: return BB_EINVAL;
@@ -487,14 +492,31 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         return BB_OK;
     }
 
-    if (om == BB_OUT_SCATTER && d_src && variant >= 2
+    // rows kernel or LDS gather for chunks of at least four floats: with the
+    // default knob (32) up to four thread slots always gather (one wave per
+    // slot leaves the rows kernel with 2-4 waves per workgroup: 5.6 / 6.1 TB/s
+    // against 6.4 / 6.3), eight or more only below 32 floats
+    // (profiles/r01i_exp_interleave_thr.log)
+    const int gchunks = g_tune_gather_chunks.load();
+    const bool gather_wide = om == BB_OUT_ROWS4
+        && (gchunks == 32 ? (p->nslot <= 4 || p->chunk < 32) : p->chunk < gchunks);
+    if ((om == BB_OUT_SCATTER || gather_wide)
+        && d_src && variant >= 2
         && (size_t)p->nslot * 528 + 1024 + 64 <= 48 * 1024) {
-        // narrow chunks: assemble output rows in LDS (k_gather.h)
+        // narrow chunks (a thread's sample is less than 128 bytes of output):
+        // assemble output rows in LDS (k_gather.h).  Through the rows kernel,
+        // whose waves each write their own 16..64-byte pieces of every row,
+        // chunks of 4 / 8 / 16 floats ran at 0.55 / 1.15 / 3.45 TB/s
+        // (profiles/r01i_exp_interleave.log)
         bb_gather_args ga;
         ga.buf = a.buf; ga.src = d_src; ga.out = d_out; ga.tab = a.tab;
         ga.nframes = nframes; ga.ndw = a.ndw;
         ga.nslot = a.nslot; ga.chunk = a.chunk; ga.lchunk = a.lchunk;
-        uint32_t gt = (uint32_t)((size_t)g_tune_gather_bytes.load() / ((size_t)p->nslot * 256));
+        // bytes staged per work item: 16 KiB, 4 KiB for 1-bit data whose items
+        // expand 32-fold (profiles/r01i_exp_interleave_gb.log); knob value 8192 = this default
+        size_t gbytes = (size_t)g_tune_gather_bytes.load();
+        if (gbytes == 8192) gbytes = p->bps == 1 ? 4096 : 16384;
+        uint32_t gt = (uint32_t)(gbytes / ((size_t)p->nslot * 256));
         if (gt < 1) gt = 1;
         if (gt > 32) gt = 32;
         if ((uint64_t)gt > ntiles) gt = (uint32_t)ntiles;

@@ -32,7 +32,8 @@ struct bb_gather_args {
     int32_t  aligned;       // buf is 256-byte aligned: use aligned block loads
 };
 
-template <int BPS, int LV, bool NT>
+// WIDE: chunks of at least four floats (a float4 never straddles thread slots)
+template <int BPS, int LV, bool NT, bool WIDE>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_decode_gather(bb_gather_args a)
 {
@@ -71,18 +72,22 @@ void k_decode_gather(bb_gather_args a)
         // slot at a time: coalesced 256-byte loads, no index arithmetic)
         if (threadIdx.x == 0) s_base[a.nslot] = 0;      // count of missing slots
         __syncthreads();
-        for (uint32_t s = bb_wave(); s < a.nslot; s += BB_WAVES_PER_BLOCK) {
+        // one wave per slot at a time; with one or two slots the idle waves
+        // share a slot's pieces, so that all four keep loading
+        const uint32_t wps = a.nslot == 1 ? 4u : (a.nslot == 2 ? 2u : 1u);    // waves per slot
+        const uint32_t wsub = bb_wave() % wps;
+        for (uint32_t s = bb_wave() / wps; s < a.nslot; s += BB_WAVES_PER_BLOCK / wps) {
             const int64_t so = a.src[f * a.nslot + s];
             const uint64_t b0 = so >= 0 ? (uint64_t)so : 0;
             // misalignment of the payload against 256-byte blocks, in dwords
             // (payloads at odd byte offsets keep plain loads: sh = 0)
             const uint32_t sh = (a.aligned && !(b0 & 3)) ? (uint32_t)((b0 >> 2) & 63) : 0u;
             const uint32_t *blk = reinterpret_cast<const uint32_t *>(a.buf + b0) - sh;
-            for (uint32_t j = bb_lane(); j < gdw + 64; j += BB_WAVE) {
+            for (uint32_t j = wsub * BB_WAVE + bb_lane(); j < gdw + 64; j += BB_WAVE * wps) {
                 const uint64_t q = dw0 + j;             // block dword q = payload dword q - sh
                 s_raw[s * pitch + j] = (so >= 0 && q >= sh && q - sh < a.ndw) ? blk[q] : 0u;
             }
-            if (bb_lane() == 0) {
+            if (bb_lane() == 0 && wsub == 0) {
                 s_valid[s] = so >= 0 ? 1u : 0u;
                 s_base[s] = (s * pitch + sh) * 4;
                 if (so < 0) atomicAdd(&s_base[a.nslot], 1u);
@@ -102,6 +107,24 @@ void k_decode_gather(bb_gather_args a)
             if (a.lrow >= 0) { row = q >> a.lrow; rem = q & (rowlen - 1); }   // power-of-two rows
             else             { row = q / rowlen;  rem = q - row * rowlen; }
             float r[4];
+            if (WIDE) {
+                // the four elements belong to one thread slot and are adjacent
+                // in its payload: one LDS read of 4 * BPS bits
+                const uint32_t s = rem >> a.lchunk;
+                const uint32_t within = rem & (a.chunk - 1);
+                const uint32_t bit = ((row << a.lchunk) + within) * BPS;
+                const uint32_t off = s_base[s] + (bit >> 3);
+                uint32_t bits;
+                if (BPS == 8)      bits = *reinterpret_cast<const uint32_t *>(rawb + off);
+                else if (BPS == 4) bits = *reinterpret_cast<const uint16_t *>(rawb + off);
+                else               bits = (uint32_t)rawb[off] >> (bit & 7);
+                const bool hole = holes && !s_valid[s];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r[j] = lv.get((bits >> (j * BPS)) & CMASK);
+                    if (hole) r[j] = (a.complex_data && (j & 1)) ? a.fill_im : a.fill_re;
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t s = rem >> a.lchunk;
@@ -113,6 +136,7 @@ void k_decode_gather(bb_gather_args a)
                 if (holes && !s_valid[s])
                     r[j] = (a.complex_data && (within & 1)) ? a.fill_im : a.fill_re;
                 if (++rem == rowlen) { rem = 0; ++row; }
+            }
             }
             bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
         }
