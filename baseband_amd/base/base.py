@@ -11,7 +11,6 @@ frame sets, streams the corresponding bytes to HBM in large windows
 (`staging.WindowPipeline`), and per window launches header scan ->
 index build -> decode.  The result is a device tensor.
 """
-import io
 import operator
 import warnings
 

@@ -2,7 +2,6 @@
 import io
 from math import gcd
 
-import numpy as np
 import torch
 
 from .. import _lib, kernels

@@ -19,7 +19,6 @@ from ..base.writer import GPUStreamWriterBase, LazyWriteFile
 from ..staging import host_image
 from .header import GSBHeader
 from .payload import GSBPayload
-from .frame import GSBFrame
 
 __all__ = ['GSBTimeStampIO', 'GSBFileReader', 'GSBFileWriter', 'GSBStreamReader',
            'GSBStreamWriter', 'open']

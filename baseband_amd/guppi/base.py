@@ -1,8 +1,5 @@
 """GUPPI file and stream readers, and ``open`` (guppi/base.py:27-278)."""
-import io
 
-import numpy as np
-import torch
 
 from .. import _lib, kernels
 from ..base.base import FileBase, VLBIFileReaderBase

@@ -6,7 +6,6 @@ Mirrors ``Mark4FileReader`` (mark4/base.py:28-207) and ``Mark4StreamReader``
 ``bb_build_index`` -> ``bb_decode_mark4`` (track demultiplexing + header
 fill).
 """
-import io
 import operator
 
 import numpy as np
@@ -15,8 +14,7 @@ import torch
 from .. import _lib, kernels
 from ..base.base import (FileBase, VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
-from .header import Mark4Header, MARK4_DTYPES, stream2words
-from .payload import Mark4Payload
+from .header import Mark4Header, MARK4_DTYPES
 from .frame import Mark4Frame
 from ._bitmaps import BITMAPS
 from ..base.writer import GPUStreamWriterBase
@@ -266,7 +264,6 @@ class Mark4StreamWriter(GPUStreamWriterBase):
                        header0.fanout)
 
     def _write_frames(self, data, valid):
-        from .. import synth
         from .header import words2stream
         h0 = self.header0
         maps = BITMAPS[self._coder]

@@ -5,11 +5,9 @@ Mirrors ``Mark5BFileReader`` (mark5b/base.py:25-155) and
 stream reader launches ``bb_mark5b_scan`` (sync word, BCD time -> frame
 index, fill-pattern validity) -> ``bb_build_index`` -> ``bb_decode_frames``.
 """
-import io
 import operator
 
 import numpy as np
-import torch
 
 from .. import _lib, kernels
 from ..base.base import (FileBase, VLBIFileReaderBase, GPUStreamReaderBase,

@@ -2,7 +2,6 @@
 (mark5b/payload.py:27-94,112-150).  Fixed 10000-byte payloads."""
 from collections import namedtuple
 
-import numpy as np
 
 from .. import _lib
 from ..base.payload import PayloadBase

@@ -7,7 +7,6 @@ modes ``'rb'`` and ``'rs'``.  The stream reader's per-frame-set Python loop
 window by three launches: ``bb_vdif_scan`` -> ``bb_build_index`` ->
 ``bb_decode_frames``.
 """
-import io
 
 import numpy as np
 import torch

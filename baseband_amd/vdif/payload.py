@@ -7,7 +7,6 @@ vdif/payload.py:151-154.
 """
 from collections import namedtuple
 
-import numpy as np
 
 from .. import _lib
 from ..base.payload import PayloadBase
