@@ -481,6 +481,17 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     int variant = g_tune_variant.load();
     if (variant == 5 && p->bps == 8 && om == BB_OUT_FLAT && g_tune_tpw8.load() <= 16)
         variant = 0;
+    // Mid-size launches: the persistent pipelined kernel only pays off when a
+    // launch is a multiple of its grid (6.2-6.6 TB/s from about 8 x 131072
+    // work items, i.e. 2^19 frames of 8000 bytes); between one and six grids
+    // it does 5.1-5.2 where the plain kernel does 5.4-5.5
+    // (profiles/r01i_exp_launch_size.log).  An explicit BB_TUNE_BLOCKS keeps
+    // the pipelined kernel (experiments).
+    if (variant == 5 && om == BB_OUT_FLAT && tb == 0) {
+        const uint64_t seg5 = 2ull * (uint64_t)g_tune_tpw.load();
+        const uint64_t nwork5 = nfs * ((ntiles + seg5 - 1) / seg5);
+        if (nwork5 >= BB_GRID_CAP && nwork5 < 6 * BB_GRID_CAP) variant = 0;
+    }
 
     if (variant == 1 && p->bps == 2 && om == BB_OUT_FLAT) {
         uint64_t b2 = nfs;
