@@ -149,37 +149,76 @@ class GSBStreamReader(GPUStreamReaderBase):
                 for fh in pair:
                     fh.close()
 
-    def _read_sets(self, first, last, into=None):
-        kernels.require_gpu()
+    # -- staging: the base class streams "frame sets" of a byte image through
+    # pinned buffers (staging.WindowPipeline); here set k is block k of every
+    # raw file, [pol][part] order, presented as one virtual image
+    _file_offset0 = 0
+
+    def _image(self):
+        if getattr(self, '_set_image', None) is None:
+            self._set_image = _BlockSetImage(self._images, self._payload_nbytes)
+        return self._set_image
+
+    @property
+    def _set_nbytes(self):
+        return self._payload_nbytes * len(self._images) * self._nfiles
+
+    def _process_window(self, dbuf, first, last, out_flat):
+        """Decode sets [first, last) staged in `dbuf` ([set][pol][part][block])."""
         nsets = last - first
         pn = self._payload_nbytes
         npol = len(self._images)
         F = self._nfiles
-        # stage [first, last) blocks of every raw file back to back
-        staged = np.empty((npol, F, nsets * pn), dtype=np.uint8)
-        for p in range(npol):
-            for f in range(F):
-                staged[p, f] = self._images[p][f][first * pn:last * pn]
-        dbuf = kernels.to_device_bytes(staged.reshape(-1))
         nchan = self._unsliced_shape[-1]
         chunk = nchan * (2 if self.complex_data else 1)
         if self._rawdump:
-            flat = kernels.decode_frames(dbuf, nsets, pn, _lib.CODER_INT, self.bps,
-                                         chunk=chunk, src0=0, src_stride=pn, out=into)
-        else:
-            # output frame (k, part f), slot = polarisation p
-            k = np.arange(nsets)[:, None, None]
-            f = np.arange(F)[None, :, None]
-            p = np.arange(npol)[None, None, :]
-            src = ((p * F + f) * nsets + k) * pn
-            dsrc = torch.from_numpy(np.ascontiguousarray(src.reshape(-1)).astype(np.int64)).to(dbuf.device)
-            flat = kernels.decode_frames(dbuf, nsets * F, pn, _lib.CODER_INT,
-                                         self.bps, chunk=chunk, nslot=npol,
-                                         src=dsrc, complex_data=self.complex_data, out=into)
-        if self.complex_data:
-            flat = torch.view_as_complex(flat.view(-1, 2))
-        return flat.reshape((nsets * self.samples_per_frame,)
-                            + tuple(self._unsliced_shape))
+            kernels.decode_frames(dbuf, nsets, pn, _lib.CODER_INT, self.bps,
+                                  chunk=chunk, src0=0, src_stride=pn, out=out_flat)
+            return
+        # output frame (k, part f), slot = polarisation p
+        k = torch.arange(nsets, device=dbuf.device, dtype=torch.int64)[:, None, None]
+        f = torch.arange(F, device=dbuf.device, dtype=torch.int64)[None, :, None]
+        p = torch.arange(npol, device=dbuf.device, dtype=torch.int64)[None, None, :]
+        dsrc = (((k * npol + p) * F + f) * pn).reshape(-1).contiguous()
+        kernels.decode_frames(dbuf, nsets * F, pn, _lib.CODER_INT, self.bps,
+                              chunk=chunk, nslot=npol, src=dsrc,
+                              complex_data=self.complex_data, out=out_flat)
+
+
+class _BlockSetImage:
+    """Virtual byte image over the raw files of a GSB observation: set k is
+    block k (`pn` bytes) of every file in [pol][part] order.  `pieces(lo, hi)`
+    yields the mapped pieces of a byte range (what `staging._stage` copies into
+    the pinned buffer); slicing gives a copy."""
+
+    def __init__(self, images, pn):
+        self.parts = [im for pair in images for im in pair]
+        self.pn = pn
+        self.nset = min(len(im) for im in self.parts) // pn
+        self.set_nbytes = pn * len(self.parts)
+
+    def __len__(self):
+        return self.nset * self.set_nbytes
+
+    def pieces(self, lo, hi):
+        pn, m = self.pn, len(self.parts)
+        pos = lo
+        while pos < hi:
+            blk, within = divmod(pos, pn)
+            k, j = divmod(blk, m)
+            n = min(hi - pos, pn - within)
+            yield self.parts[j][k * pn + within:k * pn + within + n]
+            pos += n
+
+    def __getitem__(self, item):
+        lo, hi, step = item.indices(len(self))
+        assert step == 1
+        out = np.empty(max(hi - lo, 0), dtype=np.uint8)
+        o = 0
+        for part in self.pieces(lo, hi):
+            out[o:o + len(part)] = part
+            o += len(part)
+        return out
 
 
 class GSBStreamWriter(GPUStreamWriterBase):

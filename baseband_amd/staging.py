@@ -61,15 +61,27 @@ def _parallel_copy(dst, src):
 
 
 def _stage(dst, image, lo, hi):
-    """dst[:hi-lo] = image[lo:hi]; a file sequence is copied file by file,
-    straight from each mapping."""
+    """dst[:hi-lo] = image[lo:hi]; images made of several mappings (a file
+    sequence, the raw files of a GSB observation) are copied piece by piece,
+    straight from each mapping, the pieces spread over the copy threads."""
+    global _copy_pool
     if not hasattr(image, 'pieces'):
         _parallel_copy(dst, image[lo:hi])
         return
-    o = 0
+    jobs, o = [], 0
     for part in image.pieces(lo, hi):
-        _parallel_copy(dst[o:o + len(part)], part)
+        for a in range(0, len(part), 4 << 20):          # at most 4 MiB per task
+            b = min(len(part), a + (4 << 20))
+            jobs.append((dst[o + a:o + b], part[a:b]))
         o += len(part)
+    if len(jobs) < 2 or _COPY_THREADS == 1 or o < (8 << 20):
+        for d, src in jobs:
+            d[:] = src
+        return
+    if _copy_pool is None:
+        _copy_pool = ThreadPoolExecutor(_COPY_THREADS)
+    for f in [_copy_pool.submit(np.copyto, d, src) for d, src in jobs]:
+        f.result()
 
 
 class WindowPipeline:
