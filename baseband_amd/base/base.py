@@ -291,7 +291,8 @@ class GPUStreamReaderBase:
         self._closed = True
         self._ahead = None
         if self._pipeline is not None:
-            self._pipeline.drain()
+            self._pipeline.release()
+            self._pipeline = None
         self.fh_raw.close()
 
     def __enter__(self):

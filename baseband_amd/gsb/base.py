@@ -141,6 +141,10 @@ class GSBStreamReader(GPUStreamReaderBase):
 
     def close(self):
         self._closed = True
+        self._ahead = None
+        if self._pipeline is not None:
+            self._pipeline.release()
+            self._pipeline = None
         self.fh_ts.close()
         if self._rawdump:
             self.fh_raw.close()

@@ -100,15 +100,23 @@ class VDIFFileReader(VLBIFileReaderBase):
         with self.temporary_offset(0):
             header0 = self.read_header()
         hw = self._header_table(header0)
-        frame_nr = hw[:, 1] & 0xffffff
-        # skip the first frame number, then walk until the count wraps to 0
-        differ = np.nonzero(frame_nr != frame_nr[0])[0]
-        if len(differ):
-            i = differ[0]
-            wrap = np.nonzero(frame_nr[i:] == 0)[0]
-            if len(wrap):
-                j = i + wrap[0]
-                return int(max(frame_nr[0], frame_nr[i:j].max() if j > i else 0)) + 1
+        # the table is a strided view of the whole (mapped) file: look at a
+        # growing prefix, so that a multi-GiB file is not paged in to find the
+        # first wrap of the frame counter
+        m = min(len(hw), 4096)
+        while True:
+            frame_nr = hw[:m, 1] & 0xffffff
+            # skip the first frame number, then walk until the count wraps to 0
+            differ = np.nonzero(frame_nr != frame_nr[0])[0]
+            if len(differ):
+                i = differ[0]
+                wrap = np.nonzero(frame_nr[i:] == 0)[0]
+                if len(wrap):
+                    j = i + wrap[0]
+                    return int(max(frame_nr[0], frame_nr[i:j].max() if j > i else 0)) + 1
+            if m == len(hw):
+                break
+            m = min(len(hw), m * 8)
         rate = header0.frame_rate
         if rate is None:
             raise EOFError("file contains less than one second of data and "
@@ -122,20 +130,26 @@ class VDIFFileReader(VLBIFileReaderBase):
         with self.temporary_offset():
             header0 = self.read_header()
         hw = self._header_table(header0, offset=pos)
-        frame_nrs = hw[:, 1] & 0xffffff
-        threads = (hw[:, 3] >> 16) & 0x3ff
-        seen, n_check, k, n = set(), 1, 0, len(hw)
-        while n_check > 0:
-            if k >= n:
-                # very short files (like the samples) are let through
-                if len(self.image()) - pos > check * len(seen) * header0.frame_nbytes:
+        n = len(hw)
+        m = min(n, 256)                     # growing prefix of the strided view
+        while True:
+            frame_nrs = hw[:m, 1] & 0xffffff
+            threads = (hw[:m, 3] >> 16) & 0x3ff
+            seen, n_check, k = set(), 1, 0
+            while n_check > 0 and k < m:
+                fnr, n0 = frame_nrs[k], len(seen)
+                while k < m and frame_nrs[k] == fnr:
+                    seen.add(int(threads[k]))
+                    k += 1
+                n_check = check if len(seen) > n0 else n_check - 1
+            if n_check <= 0 and k < m:
+                break                       # decided inside the prefix
+            if m == n:
+                # ran off the end: very short files (like the samples) are let through
+                if n_check > 0 and len(self.image()) - pos > check * len(seen) * header0.frame_nbytes:
                     raise EOFError
                 break
-            fnr, n0 = frame_nrs[k], len(seen)
-            while k < n and frame_nrs[k] == fnr:
-                seen.add(int(threads[k]))
-                k += 1
-            n_check = check if len(seen) > n0 else n_check - 1
+            m = min(n, m * 8)
         return sorted(seen)
 
 
