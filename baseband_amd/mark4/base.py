@@ -14,7 +14,7 @@ import torch
 from .. import _lib, kernels
 from ..base.base import (FileBase, VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
-from .header import Mark4Header, MARK4_DTYPES
+from .header import Mark4Header, MARK4_DTYPES, frame_header_streams
 from .frame import Mark4Frame
 from ._bitmaps import BITMAPS
 from ..base.writer import GPUStreamWriterBase
@@ -264,7 +264,6 @@ class Mark4StreamWriter(GPUStreamWriterBase):
                        header0.fanout)
 
     def _write_frames(self, data, valid):
-        from .header import words2stream
         h0 = self.header0
         maps = BITMAPS[self._coder]
         spf = self.samples_per_frame
@@ -272,18 +271,10 @@ class Mark4StreamWriter(GPUStreamWriterBase):
         nfill = 160 * h0.fanout
         body = data.reshape(nfr, spf, h0.nchan)[:, nfill:].contiguous()
         words = kernels.encode_mark4(body, h0.ntrack, maps['sign_bit'], maps['mag_bit'])
-        words = words.cpu().numpy().view(h0.stream_dtype).reshape(nfr, 20000 - 160)
-        frames = np.empty((nfr, 20000), dtype=h0.stream_dtype)
-        frames[:, 160:] = words
-        for i in range(nfr):
-            h = h0.copy()
-            ns = int(round((self._nframes_written + i) * 1e9 / self._frame_rate))
-            h.set_time(self._start_time + np.timedelta64(ns, 'ns'))
-            if not valid[i]:
-                h['communication_error'] = np.ones(h0.ntrack, bool)
-            h.update_crc()
-            frames[i, :160] = words2stream(h.words)
-        self.fh_raw.write(frames.tobytes())
+        k = np.arange(self._nframes_written, self._nframes_written + nfr)
+        times = self._start_time + np.rint(k * 1e9 / self._frame_rate).astype('m8[ns]')
+        heads = frame_header_streams(h0, times, invalid=~np.asarray(valid, bool))
+        self._emit_frames(heads.view(np.uint8).reshape(nfr, -1), words)
 
 
 open = FormatOpener('Mark4', {'rb': Mark4FileReader, 'wb': Mark4FileWriter,

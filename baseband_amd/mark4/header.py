@@ -10,7 +10,7 @@ follow mark4/header.py:540-650.  Times are ``numpy.datetime64[ns]``.
 import numpy as np
 
 __all__ = ['Mark4Header', 'stream2words', 'words2stream', 'MARK4_DTYPES',
-           'PAYLOAD_NBITS']
+           'PAYLOAD_NBITS', 'frame_header_streams']
 
 MARK4_DTYPES = {8: '<u1', 16: '<u2', 32: '<u4', 64: '<u8'}
 PAYLOAD_NBITS = 20000
@@ -616,3 +616,55 @@ class Mark4Header:
         return "<Mark4Header ntrack={} fanout={} bps={} nchan={} time={}>".format(
             self.ntrack, self.fanout, self.bps, self.nchan,
             self.get_time() if self.decade is not None else '?')
+
+
+def frame_header_streams(header0, times, invalid=None):
+    """(nframes, 160) stream-word headers for frames at `times`
+    (datetime64[ns] array): `header0` with each frame's time code, the
+    'communication_error' flag of every track set where `invalid` is true,
+    and the CRC-12 of every track recomputed -- what ``header0.copy();
+    set_time(t); update_crc(); words2stream(words)`` gives frame by frame
+    (`set_time`, `crc12_stream`, `words2stream` above), for all frames at once."""
+    from ..base.utils import bcd_encode as bcd_array
+    times = np.asarray(times, dtype='M8[ns]')
+    n = len(times)
+    ntrack = header0.ntrack
+    dtype = header0.stream_dtype
+    year = times.astype('M8[Y]').astype(np.int64) + 1970
+    ns = (times - times.astype('M8[Y]').astype('M8[ns]')).astype(np.int64)
+    ms_total, rem = np.divmod(ns, 1000000)
+    frac_ms = ms_total % 1000 + rem / 1e6
+    if np.any(np.abs(frac_ms / 1.25 - np.rint(frac_ms / 1.25)) > 1e-6):
+        raise ValueError("times are not multiples of 1.25 ms")
+    sec_total = ms_total // 1000
+    day, sec_of_day = np.divmod(sec_total, 86400)
+    hour, rest = np.divmod(sec_of_day, 3600)
+    minute, second = np.divmod(rest, 60)
+    w3 = ((year % 10) << 28) | (bcd_array(day + 1) << 16) | (bcd_array(hour) << 8) | bcd_array(minute)
+    w4 = (bcd_array(second) << 24) | (bcd_array(np.floor(frac_ms + 1e-6).astype(np.int64)) << 12)
+    words = np.empty((n, 5, ntrack), dtype=np.uint32)
+    words[:] = header0.words
+    words[:, 3, :] = w3[:, None].astype(np.uint32)
+    words[:, 4, :] = w4[:, None].astype(np.uint32)            # crc bits zero for now
+    if invalid is not None:
+        bit = np.uint32(1 << _FIELDS['communication_error'][1])
+        words[np.asarray(invalid, bool), 1, :] |= bit
+    out = np.empty((n, 160), dtype=dtype)
+    taps = np.array([np.iinfo(dtype).max if b == '1' else 0 for b in '{:b}'.format(0x180f)],
+                    dtype=dtype)
+    for lo in range(0, n, 256):                             # bounded temporaries
+        w = words[lo:lo + 256]
+        # bit 31 of a word comes first in the stream: big-endian bytes, MSB first
+        bits = np.unpackbits(w.astype('>u4').view(np.uint8).reshape(len(w), 5, ntrack, 4), axis=3)
+        bits = np.ascontiguousarray(bits.transpose(0, 1, 3, 2))             # (m, 5, 32, ntrack)
+        # track t is bit t of the stream word: pack the track axis, little endian
+        stream = np.packbits(bits, axis=3, bitorder='little').reshape(len(w), 160, -1)
+        stream = np.ascontiguousarray(stream).view(dtype).reshape(len(w), 160).copy()
+        # CRC-12 of the first 148 stream words of every track at once
+        work = stream.copy()
+        work[:, 148:] = 0
+        for i in range(148):
+            work[:, i:i + 13] ^= work[:, i:i + 1] & taps
+        stream[:, 148:] = work[:, 148:]
+        out[lo:lo + 256] = stream
+    return out

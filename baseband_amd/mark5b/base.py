@@ -8,12 +8,13 @@ index, fill-pattern validity) -> ``bb_build_index`` -> ``bb_decode_frames``.
 import operator
 
 import numpy as np
+import torch
 
 from .. import _lib, kernels
 from ..base.base import (FileBase, VLBIFileReaderBase, GPUStreamReaderBase,
                          HeaderNotFoundError)
 from ..base.header import strided_header_words
-from .header import Mark5BHeader, crc16_mark5b
+from .header import Mark5BHeader, frame_header_words, crc16_mark5b
 from .frame import Mark5BFrame
 from ..base.writer import GPUStreamWriterBase
 from ..base.opener import FormatOpener
@@ -234,22 +235,15 @@ class Mark5BStreamWriter(GPUStreamWriterBase):
 
     def _write_frames(self, data, valid):
         nfr = data.shape[0] // self.samples_per_frame
-        packed = kernels.encode_flat(data, _lib.CODER_MARK5B, self.bps).cpu().numpy()
-        packed = packed.reshape(nfr, 10000)
-        out = np.empty((nfr, FRAME_NBYTES), np.uint8)
-        for i in range(nfr):
-            k = self._nframes_written + i
-            ns = int(round(k * 1e9 / self._frame_rate))
-            h = Mark5BHeader.fromvalues(time=self._start_time + np.timedelta64(ns, 'ns'),
-                                        frame_rate=self._frame_rate,
-                                        user=self.header0['user'],
-                                        internal_tvg=self.header0['internal_tvg'])
-            out[i, :16] = np.array(h.words, '<u4').view(np.uint8)
-            if valid[i]:
-                out[i, 16:] = packed[i]
-            else:                       # invalid frames carry the fill pattern
-                out[i, 16:] = np.full(2500, 0x11223344, '<u4').view(np.uint8)
-        self.fh_raw.write(out.tobytes())
+        packed = kernels.encode_flat(data, _lib.CODER_MARK5B, self.bps).reshape(nfr, 10000)
+        valid = np.asarray(valid, bool)
+        if not valid.all():             # invalid frames carry the fill pattern
+            bad = torch.from_numpy(np.nonzero(~valid)[0]).to(packed.device)
+            packed.view(torch.int32)[bad] = 0x11223344
+        words = frame_header_words(self._start_time, self._frame_rate, self._nframes_written,
+                                   nfr, user=self.header0['user'],
+                                   internal_tvg=self.header0['internal_tvg'])
+        self._emit_frames(words.view(np.uint8), packed)
 
 
 open = FormatOpener('Mark5B', {'rb': Mark5BFileReader, 'wb': Mark5BFileWriter,

@@ -487,17 +487,16 @@ class VDIFStreamWriter(GPUStreamWriterBase):
         nsets = data.shape[0] // spf
         # (set, sample, thread, chan) -> (set, thread, sample, chan): payload order
         block = data.reshape(nsets, spf, nthread, nchan).permute(0, 2, 1, 3).contiguous()
-        packed = kernels.encode_flat(block, self._coder, self.bps).cpu().numpy()
-        payloads = packed.reshape(nsets, nthread, self.header0.payload_nbytes)
+        packed = kernels.encode_flat(block, self._coder, self.bps)
         h = self.header0.copy()
         idx = self.header0['frame_nr'] + self._nframes_written
         h['seconds'] = self.header0['seconds'] + idx // self._frame_rate
         h['frame_nr'] = idx % self._frame_rate
-        invalid = [(s, t) for s in np.nonzero(~np.asarray(valid))[0] for t in range(nthread)]
         # thread ids are 0..n-1 whatever header0 holds (vdif/frame.py:277-285)
-        image = synth.vdif_file_image(payloads, h, list(range(nthread)),
-                                      self._frame_rate, invalid=invalid)
-        self.fh_raw.write(image.tobytes())
+        words = synth.vdif_frame_headers(h, nsets, list(range(nthread)), self._frame_rate)
+        heads = words.view(np.uint8).reshape(nsets, nthread, -1)
+        heads[~np.asarray(valid, bool), :, 3] |= 0x80          # invalid_data bit of the whole set
+        self._emit_frames(heads.reshape(nsets * nthread, -1), packed)
 
 
 open = FormatOpener('VDIF', {'rb': VDIFFileReader, 'wb': VDIFFileWriter, 'rs': VDIFStreamReader,

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""End-to-end stream writers: samples resident in HBM -> GPU encoder -> host
+-> file (page cache, TMPDIR).  File bytes per second."""
+import json, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from baseband_amd import vdif, mark4, mark5b, dada, guppi   # noqa: E402
+
+
+def run(case, path, opener, data, chunk):
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        with opener() as fw:
+            for lo in range(0, data.shape[0], chunk):
+                fw.write(data[lo:lo + chunk])
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    size = os.path.getsize(path)
+    print(json.dumps(dict(case=case, file_GiB=round(size / 2 ** 30, 3), seconds=round(best, 4),
+                          file_GBps=round(size / best / 1e9, 2))), flush=True)
+    os.remove(path)
+
+
+def main():
+    tmp = os.environ.get('TMPDIR', '/tmp')
+    g = torch.Generator(device='cuda').manual_seed(1)
+    t0 = np.datetime64('2014-06-13T05:30:01')
+    # VDIF 1 thread 2-bit: 0.5 GiB file = 2^31 samples
+    n = 32000 * 65536
+    data = torch.randn(n, device='cuda', generator=g) * 2.
+    path = os.path.join(tmp, 'bb_w.vdif')
+    from baseband_amd.vdif.header import VDIFHeader
+    h0 = VDIFHeader.fromvalues(edv=0, time=t0, nchan=1, bps=2, complex_data=False, thread_id=0,
+                               samples_per_frame=32000, station='AA')
+    run('VDIF 2-bit 1 thread, 8032-byte frames', path,
+        lambda: vdif.open(path, 'ws', header0=h0, sample_rate=32e6, nthread=1), data, 32000 * 8192)
+    # Mark 5B 16 ch
+    d2 = data[:2500 * 16 * 50000].reshape(-1, 16)
+    path = os.path.join(tmp, 'bb_w.m5b')
+    run('Mark 5B 16 ch 2-bit', path,
+        lambda: mark5b.open(path, 'ws', sample_rate=32e6, nchan=16, bps=2, time=t0), d2, 2500 * 8192)
+    # Mark 4 64 tracks fanout 4
+    d3 = data[:80000 * 8 * 3000].reshape(-1, 8)
+    path = os.path.join(tmp, 'bb_w.m4')
+    run('Mark 4 64 tracks fanout 4', path,
+        lambda: mark4.open(path, 'ws', sample_rate=32e6, ntrack=64, bps=2, fanout=4,
+                           time=np.datetime64('2014-06-13T05:30:01')), d3, 80000 * 512)
+    # DADA 8-bit complex 2 pol, 64 MiB frames
+    from baseband_amd.dada.header import DADAHeader
+    spf = (64 << 20) // 4
+    hd = DADAHeader.fromvalues(time=t0, sample_rate=16e6, bps=8, complex_data=True, npol=2, nchan=1,
+                               samples_per_frame=spf)
+    d4 = torch.view_as_complex((torch.randn(8 * spf, 2, 2, device='cuda', generator=g) * 30.))
+    path = os.path.join(tmp, 'bb_w.dada')
+    run('DADA 8-bit 2 pol complex, 64 MiB frames', path,
+        lambda: dada.open(path, 'ws', header0=hd), d4, spf)
+    # GUPPI 8-bit 2 pol 64 ch, 64 MiB blocks
+    from baseband_amd.guppi.header import GUPPIHeader
+    spf = (64 << 20) // (2 * 64 * 2)
+    hg = GUPPIHeader.fromvalues(time=t0, sample_rate=1e6, samples_per_frame=spf, overlap=0,
+                                npol=2, nchan=64, pktsize=8192, bps=8)
+    d5 = torch.view_as_complex((torch.randn(8 * spf, 2, 64, 2, device='cuda', generator=g) * 30.))
+    path = os.path.join(tmp, 'bb_w.raw')
+    run('GUPPI 8-bit 2 pol 64 ch, 64 MiB blocks', path,
+        lambda: guppi.open(path, 'ws', header0=hg), d5, spf)
+
+
+if __name__ == '__main__':
+    main()
