@@ -81,14 +81,21 @@ class Mark5BFileReader(VLBIFileReaderBase):
             header0 = self.find_header()
             offset0 = self.fh_raw.tell()
         hw = strided_header_words(self.image(), FRAME_NBYTES, 4, offset=offset0)
-        frame_nr = hw[:, 1] & 0x7fff
-        differ = np.nonzero(frame_nr != frame_nr[0])[0]
-        if len(differ):
-            i = differ[0]
-            wrap = np.nonzero(frame_nr[i:] == 0)[0]
-            if len(wrap):
-                j = i + wrap[0]
-                return int(max(frame_nr[0], frame_nr[i:j].max() if j > i else 0)) + 1
+        # growing prefix of the strided view: the first wrap of the frame
+        # counter is within a second of data, the file may be many GiB
+        m = min(len(hw), 4096)
+        while True:
+            frame_nr = hw[:m, 1] & 0x7fff
+            differ = np.nonzero(frame_nr != frame_nr[0])[0]
+            if len(differ):
+                i = differ[0]
+                wrap = np.nonzero(frame_nr[i:] == 0)[0]
+                if len(wrap):
+                    j = i + wrap[0]
+                    return int(max(frame_nr[0], frame_nr[i:j].max() if j > i else 0)) + 1
+            if m == len(hw):
+                break
+            m = min(len(hw), m * 8)
         if len(hw) > 1:
             h1 = Mark5BHeader(hw[1], kday=self.kday, ref_time=self.ref_time)
             tdelta = h1.fraction - header0.fraction
