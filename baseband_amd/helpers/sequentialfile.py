@@ -157,29 +157,75 @@ class SequenceImage:
     def header_words(self, frame_nbytes, nwords, offset=0):
         """(nframes, nwords) little-endian uint32 header words of frames that
         start every `frame_nbytes` bytes from `offset`; frames whose header is
-        cut off by the end of the sequence are left out."""
-        n = len(self) - offset
-        nframes = (n - 4 * nwords) // frame_nbytes + 1 if n >= 4 * nwords else 0
-        out = np.empty((nframes, nwords), '<u4')
+        cut off by the end of the sequence are left out.  The table is lazy:
+        rows are gathered from the mappings when they are indexed (probing the
+        first frames of a multi-GiB sequence must not page all of it in)."""
+        return _HeaderTable(self, frame_nbytes, nwords, offset)
+
+    def _gather_headers(self, frame_nbytes, nwords, offset, first_row, last_row):
+        """Rows [first_row, last_row) of the header table as an array."""
         hb = 4 * nwords
+        out = np.empty((max(last_row - first_row, 0), nwords), '<u4')
         for k, m in enumerate(self._maps):
             base, end = self._starts[k], self._starts[k + 1]
             # frames whose header lies wholly inside file k
-            first = max(0, -(-(base - offset) // frame_nbytes))
-            last = min(nframes, (end - hb - offset) // frame_nbytes + 1) if end - hb >= offset else 0
+            first = max(first_row, -(-(base - offset) // frame_nbytes))
+            last = min(last_row, (end - hb - offset) // frame_nbytes + 1) if end - hb >= offset else 0
             if last > first:
                 o = offset + first * frame_nbytes - base
                 span = m[o:o + (last - first - 1) * frame_nbytes + hb]
                 rows = np.lib.stride_tricks.as_strided(
                     span, shape=(last - first, hb), strides=(frame_nbytes, 1), writeable=False)
-                out[first:last] = np.ascontiguousarray(rows).view('<u4')
+                out[first - first_row:last - first_row] = np.ascontiguousarray(rows).view('<u4')
             # a header straddling the end of file k
             f = (end - offset) // frame_nbytes if end > offset else -1
-            if 0 <= f < nframes:
+            if first_row <= f < last_row:
                 o = offset + f * frame_nbytes
                 if o < end < o + hb:
-                    out[f] = self[o:o + hb].view('<u4')
+                    out[f - first_row] = self[o:o + hb].view('<u4')
         return out
+
+
+class _HeaderTable:
+    """Lazy (nframes, nwords) uint32 view of the headers in a `SequenceImage`:
+    ``len()``, ``table[k]``, ``table[a:b]``, ``table[a:b, col]`` and
+    ``numpy.asarray(table)`` gather just the rows involved."""
+
+    def __init__(self, image, frame_nbytes, nwords, offset):
+        self._image, self._fn, self._nw, self._off = image, frame_nbytes, nwords, offset
+        n = len(image) - offset
+        self._n = (n - 4 * nwords) // frame_nbytes + 1 if n >= 4 * nwords else 0
+        self.shape = (self._n, nwords)
+        self.dtype = np.dtype('<u4')
+
+    def __len__(self):
+        return self._n
+
+    def _rows(self, lo, hi):
+        return self._image._gather_headers(self._fn, self._nw, self._off, lo, hi)
+
+    def __getitem__(self, item):
+        rest = ()
+        if isinstance(item, tuple):
+            item, rest = item[0], item[1:]
+        if isinstance(item, slice):
+            lo, hi, step = item.indices(self._n)
+            rows = self._rows(lo, max(hi, lo)) if step > 0 else self._rows(0, self._n)[item]
+            if step > 1:
+                rows = rows[::step]
+        else:
+            k = int(item)
+            if k < 0:
+                k += self._n
+            if not 0 <= k < self._n:
+                raise IndexError(item)
+            rows = self._rows(k, k + 1)[0]
+        return rows[(slice(None),) + rest] if rest and isinstance(item, slice) else (
+            rows[rest] if rest else rows)
+
+    def __array__(self, dtype=None, copy=None):
+        whole = self._rows(0, self._n)
+        return whole if dtype in (None, whole.dtype) else whole.astype(dtype)
 
 
 class _SequentialBase:
