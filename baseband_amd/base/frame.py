@@ -108,6 +108,12 @@ class FrameBase:
 
     data = property(__getitem__, doc="Full decoded frame (device tensor).")
 
+    def __array__(self, dtype=None, copy=None):
+        """Decoded frame on the host (base/frame.py:182-187): the one place
+        where a frame's samples leave the device."""
+        host = self.data.cpu().numpy()
+        return host if dtype in (None, host.dtype) else host.astype(dtype)
+
     # -- header passthrough
     def keys(self):
         return self.header.keys()

@@ -262,3 +262,7 @@ class VDIFFrameSet:
             self.frames[t].payload[:] = full[:, t]
 
     data = property(__getitem__, doc="Decoded frame set (device tensor).")
+
+    def __array__(self, dtype=None, copy=None):
+        host = self.data.cpu().numpy()
+        return host if dtype in (None, host.dtype) else host.astype(dtype)

@@ -383,3 +383,20 @@ def test_vdif_frame_from_mark5b_frame_matches_reference():
             assert hashlib.sha256(b.getvalue()).hexdigest() == want['frame_sha256']
             assert vf.valid == want['valid']
             assert bool((vf.data == m5.data).all())
+
+
+def test_frames_and_frame_sets_convert_to_numpy(manifest):
+    """``numpy.asarray(frame)`` / ``asarray(frameset)`` bring the decoded data
+    to the host like the reference's ``FrameBase.__array__``
+    (base/frame.py:182-187)."""
+    from baseband_amd import vdif
+    with vdif.open(golden_path('samples/sample.vdif'), 'rb') as fh:
+        frame = fh.read_frame()
+        fh.seek(0)
+        frameset = fh.read_frameset()
+    a = np.asarray(frame)
+    assert a.dtype == np.float32 and a.shape == tuple(frame.shape)
+    assert bits_equal(a, frame.data.cpu().numpy())
+    s = np.asarray(frameset)
+    assert s.shape == tuple(frameset.data.shape) and bits_equal(s, frameset.data.cpu().numpy())
+    assert np.asarray(frame, dtype=np.float64).dtype == np.float64
