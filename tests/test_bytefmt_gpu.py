@@ -86,7 +86,8 @@ def test_tiled_kernel_raw_layouts(stage):
                                          (2, 4, 7, 33, 16), (0, 2, 1, 50, 16),
                                          (1, 2, 70, 768, 18), (1, 2, 64, 1024, 16), (1, 4, 9, 512, 6),
                                          (2, 2, 100, 130, 18), (2, 2, 64, 257, 16), (2, 1, 33, 65, 2),
-                                         (2, 2, 1024, 20, 16)):
+                                         (2, 2, 1024, 20, 16), (1, 2, 1, 256, 16), (2, 2, 1, 64, 16),
+                                         (1, 1, 2, 512, 4), (2, 3, 5, 40, 2)):
         nfr = 3
         pn = T * npol * nchan * 2
         raw = rng.integers(0, 256, size=(nfr, pn + head), dtype=np.uint8)
