@@ -41,6 +41,7 @@ TUNE_LDS_PAD = 9
 TUNE_TILED_STAGE = 10
 TUNE_MKBF_CHANNELS = 11
 TUNE_GATHER_CHUNKS = 12
+TUNE_SEG_TILES = 13
 
 
 class BBError(RuntimeError):
