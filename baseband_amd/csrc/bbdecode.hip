@@ -484,16 +484,17 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     int variant = g_tune_variant.load();
     if (variant == 5 && p->bps == 8 && om == BB_OUT_FLAT && g_tune_tpw8.load() <= 16)
         variant = 0;
-    // Mid-size launches: the persistent pipelined kernel only pays off when a
-    // launch is a multiple of its grid (6.2-6.6 TB/s from about 8 x 131072
-    // work items, i.e. 2^19 frames of 8000 bytes); between one and six grids
-    // it does 5.1-5.2 where the plain kernel does 5.4-5.5
-    // (profiles/r01i_exp_launch_size.log).  An explicit BB_TUNE_BLOCKS keeps
-    // the pipelined kernel (experiments).
+    // Mid-size launches: with one or two work items per workgroup the
+    // persistent pipelined kernel (5.1-5.3 TB/s) loses to the plain one
+    // (5.4-5.5); from four items per workgroup on it is at least as fast on
+    // freshly allocated outputs (5.8-5.9 at 2^18 frames, 6.2-6.6 beyond) --
+    // how fast depends on the allocation, the plain kernel does 5.4-5.7
+    // everywhere (profiles/r01i_exp_launch_size.log, r01i_exp_launch_fresh.log).
+    // An explicit BB_TUNE_BLOCKS keeps the pipelined kernel (experiments).
     if (variant == 5 && om == BB_OUT_FLAT && tb == 0) {
         const uint64_t seg5 = 2ull * (uint64_t)g_tune_tpw.load();
         const uint64_t nwork5 = nfs * ((ntiles + seg5 - 1) / seg5);
-        if (nwork5 >= BB_GRID_CAP && nwork5 < 6 * BB_GRID_CAP) variant = 0;
+        if (nwork5 >= BB_GRID_CAP && nwork5 < 3 * BB_GRID_CAP) variant = 0;
     }
 
     if (variant == 1 && p->bps == 2 && om == BB_OUT_FLAT) {
