@@ -756,3 +756,73 @@ def test_vectorised_frame_headers_equal_the_per_frame_construction():
             assert np.array_equal(words2stream(h.words), streams[i])
     with pytest.raises(ValueError):
         frame_header_streams(h0, np.array([h0.get_time() + np.timedelta64(1, 'ms')]))
+
+
+def test_block_set_image_presents_gsb_blocks_as_frame_sets():
+    """gsb.base._BlockSetImage: set k = block k of every raw file in
+    [pol][part] order; `pieces` and slicing agree with a concatenated image."""
+    from baseband_amd.gsb.base import _BlockSetImage
+    rng = np.random.default_rng(8)
+    pn, nblk = 64, 5
+    files = [[rng.integers(0, 256, nblk * pn + (7 if (p, f) == (1, 0) else 0), dtype=np.uint8)
+              for f in range(2)] for p in range(2)]
+    img = _BlockSetImage(files, pn)
+    want = np.concatenate([files[p][f][k * pn:(k + 1) * pn]
+                           for k in range(nblk) for p in range(2) for f in range(2)])
+    assert len(img) == len(want) == nblk * 4 * pn and img.set_nbytes == 4 * pn
+    assert np.array_equal(img[0:len(img)], want)
+    for lo, hi in ((0, 1), (63, 65), (100, 700), (255, 256), (1000, len(want))):
+        got = np.concatenate(list(img.pieces(lo, hi)))
+        assert np.array_equal(got, want[lo:hi]) and np.array_equal(img[lo:hi], want[lo:hi])
+    assert len(img[5:5]) == 0
+
+
+def test_sequence_header_table_is_lazy_and_matches_the_flat_view(tmp_path):
+    """SequenceImage.header_words returns a table that gathers rows on demand;
+    every way the readers index it equals the strided view of one file."""
+    from baseband_amd.helpers.sequentialfile import SequenceImage
+    from baseband_amd.base.header import strided_header_words
+    rng = np.random.default_rng(9)
+    whole = rng.integers(0, 256, 40 * 1000 + 123, dtype=np.uint8)
+    cuts = [0, 1500, 1501, 9000, 9013, 25000, len(whole)]
+    names = []
+    for i in range(len(cuts) - 1):
+        name = str(tmp_path / ('part%d' % i))
+        whole[cuts[i]:cuts[i + 1]].tofile(name)
+        names.append(name)
+    img = SequenceImage(names)
+    for offset in (0, 36):
+        flat = strided_header_words(whole, 1000, 8, offset=offset)
+        table = strided_header_words(img, 1000, 8, offset=offset)
+        assert len(table) == len(flat) and table.shape == flat.shape
+        assert np.array_equal(np.asarray(table), flat)
+        assert np.array_equal(table[:7, 1], flat[:7, 1])
+        assert np.array_equal(table[3:30:4, 3], flat[3:30:4, 3])
+        assert np.array_equal(table[9], flat[9]) and np.array_equal(table[-1], flat[-1])
+        assert np.array_equal(table[5:12], flat[5:12])
+        with pytest.raises(IndexError):
+            table[len(flat)]
+
+
+def test_lazy_write_file_creates_on_first_use_and_maps(tmp_path):
+    """base.writer.LazyWriteFile: nothing on disk until the first write (a
+    failed open must not clobber a file); `memmap` hands out a writable map of
+    the next bytes, as `memmap_frame` needs."""
+    from baseband_amd.base.writer import LazyWriteFile
+    path = tmp_path / 'x.bin'
+    path.write_bytes(b'keep')
+    fh = LazyWriteFile(str(path))
+    assert fh.tell() == 0 and not fh.closed
+    fh.discard()
+    assert path.read_bytes() == b'keep'
+    fh = LazyWriteFile(str(path))
+    fh.write(b'head')
+    mm = fh.memmap(dtype='<u4', shape=(3,))
+    mm[:] = [1, 2, 3]
+    mm.flush()
+    assert fh.tell() == 16
+    fh.write(b'tail')
+    fh.close()
+    assert path.read_bytes() == b'head' + np.array([1, 2, 3], '<u4').tobytes() + b'tail'
+    with pytest.raises(ValueError):
+        LazyWriteFile(str(path)).memmap(dtype='u1')
