@@ -43,7 +43,10 @@ def test_all_byte_values(coder, bps):
 
 @pytest.mark.parametrize('bps,chunk,nslot', [(2, 1, 8), (2, 2, 4), (2, 32, 8),
                                              (4, 4, 2), (8, 2, 4), (1, 16, 3),
-                                             (2, 4, 5), (8, 1, 2), (4, 1, 2)])
+                                             (2, 4, 5), (8, 1, 2), (4, 1, 2),
+                                             (2, 8, 8), (2, 16, 2), (8, 4, 8), (8, 16, 4),
+                                             (1, 4, 2), (4, 8, 16), (2, 64, 2), (2, 128, 4),
+                                             (8, 64, 2), (2, 4, 1 + 2)])
 def test_multislot_interleave_and_fill(bps, chunk, nslot):
     """Frame-set layout (vdif/frame.py:402-434) with missing/invalid frames."""
     torch = _torch()
