@@ -504,6 +504,8 @@ class GPUStreamReaderBase:
         return flat.reshape((nsets * spf,) + tuple(self._decode_shape))
 
     _ahead = None       # (first set, end set, device bytes) of the read-ahead window
+    _ahead_bytes0 = 256 << 10           # first read-ahead window; grows while reads are sequential
+    _ahead_bytes = 256 << 10
 
     def _read_small(self, first, last, flat, set_floats):
         """Requests much smaller than a staging window (frame-at-a-time loops
@@ -518,7 +520,16 @@ class GPUStreamReaderBase:
         need_end = min(last + look, total)
         ahead = self._ahead
         if ahead is None or first < ahead[0] or need_end > ahead[1]:
-            per_win = max(last - first + look, self.window_bytes // set_nbytes)
+            # adaptive read-ahead: a request that continues where the window
+            # ended (a sequential loop) quadruples the next window, up to
+            # `window_bytes`; anything else (random access) starts small again,
+            # so that seeking around costs tens of microseconds, not the
+            # milliseconds of staging 64 MiB for one frame
+            if ahead is not None and ahead[0] <= first <= ahead[1]:
+                self._ahead_bytes = min(self.window_bytes, 4 * self._ahead_bytes)
+            else:
+                self._ahead_bytes = self._ahead_bytes0
+            per_win = max(last - first + look, self._ahead_bytes // set_nbytes)
             end = min(total, first + per_win)
             lo = self._file_offset0 + first * set_nbytes
             hi = max(lo, self._file_offset0 + end * set_nbytes)

@@ -154,6 +154,12 @@ def upload(image, device='cuda', chunk_bytes=64 << 20):
     n = len(image)
     dev = torch.empty(n + 256, dtype=torch.uint8, device=device)
     dev[n:] = 0
+    if n <= (2 << 20):
+        # small windows (random access): one plain copy beats pinning buffers
+        if n:
+            # (a copy: the mapping is read-only, which torch does not accept)
+            dev[:n].copy_(torch.from_numpy(np.array(image[:n], dtype=np.uint8, copy=True)))
+        return dev
     stream = torch.cuda.Stream(device=device)
     pinned = [torch.empty(min(chunk_bytes, max(n, 1)), dtype=torch.uint8, pin_memory=True)
               for _ in range(2)]
