@@ -66,6 +66,20 @@ class BlockStreamReader(GPUStreamReaderBase):
             else:
                 runs.append([f, f + 1, a, b])
         done = 0
+        # requests of less than one frame (loops of small reads): the frame is
+        # staged once and kept in HBM; following requests inside it only launch
+        # kernels instead of staging the whole block again for every call
+        if count < self.samples_per_frame and len(runs) <= 2 and all(r[1] == r[0] + 1 for r in runs):
+            from ..staging import upload
+            for f0, f1, a, b in runs:
+                if self._ahead is None or self._ahead[0] != f0:
+                    lo, nbytes = self._frame_span(f0)
+                    self._ahead = (f0, upload(image[lo:min(lo + nbytes, len(image))]))
+                o = flat[done * row:(done + (b - a)) * row]
+                self._decode_window(self._ahead[1], 1, a, b, o, self._header_nbytes,
+                                    self._frame_nbytes, f0)
+                done += b - a
+            runs = []
         for f0, f1, a, b in runs:
             off0, nbytes = self._frame_span(f0)
             per_win = max(1, self.window_bytes // self._frame_nbytes)

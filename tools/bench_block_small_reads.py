@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Loops of small reads on block formats (GUPPI 128 MiB blocks)."""
+import json, os, sys, time, io
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from baseband_amd import guppi   # noqa: E402
+from baseband_amd.guppi.header import GUPPIHeader   # noqa: E402
+
+tmp = os.environ.get('TMPDIR', '/tmp')
+path = os.path.join(tmp, 'bb_bs.raw')
+blk = 128 << 20
+spf = blk // (2 * 64 * 2)
+hg = GUPPIHeader.fromvalues(time=np.datetime64('2014-06-13T05:30:01'), sample_rate=1e6, samples_per_frame=spf,
+                            overlap=0, npol=2, nchan=64, pktsize=8192, bps=8)
+rg = np.random.default_rng(3)
+with open(path, 'wb') as f:
+    for k in range(4):
+        b = io.BytesIO(); hg.tofile(b)
+        f.write(b.getvalue()); f.write(rg.integers(0, 256, blk, dtype=np.uint8).tobytes())
+with guppi.open(path, 'rs') as fh:
+    for n in (1024, 65536):
+        fh.seek(0)
+        fh.read(n); torch.cuda.synchronize()
+        reps = min(300, (fh.shape[0] - n) // n - 1)
+        t = time.perf_counter()
+        for _ in range(reps):
+            d = fh.read(n)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        print(json.dumps(dict(case='GUPPI sequential read(%d), 128 MiB blocks' % n,
+                              us_per_read=round(dt / reps * 1e6, 1))), flush=True)
+    # across a block boundary
+    fh.seek(spf - 500)
+    a = fh.read(1000)
+    fh.seek(spf - 500)
+    whole = fh.read(spf)          # pipeline path
+    print(json.dumps(dict(case='boundary read equals the large read', ok=bool((a == whole[:1000]).all()))))
+os.remove(path)
