@@ -7,34 +7,8 @@ writers (tests/golden/synth/*.bin, see tests/test_host_logic.py).
 """
 import numpy as np
 
-from .vdif.header import VDIFHeader
+from .vdif.header import VDIFHeader, frame_header_words as vdif_frame_headers
 from . import synth_codes as enc
-
-
-def vdif_frame_headers(header0, nsets, thread_ids, frame_rate,
-                       thread_order=None):
-    """(nsets * nthread, nwords) uint32 header words for consecutive frame
-    sets starting at header0's time; threads are stored in `thread_order`
-    (positions into thread_ids) within each set."""
-    nthread = len(thread_ids)
-    order = list(range(nthread)) if thread_order is None else list(thread_order)
-    nwords = header0.nbytes // 4
-    words = np.empty((nsets, nthread, nwords), dtype=np.uint32)
-    words[...] = np.array(header0.words, dtype=np.uint32)
-    idx = np.arange(nsets, dtype=np.int64) + header0['frame_nr']
-    seconds = header0['seconds'] + idx // frame_rate
-    frame_nr = idx % frame_rate
-    words[:, :, 0] = ((words[:, :, 0] & np.uint32(0xc0000000))
-                      | seconds[:, None].astype(np.uint32))
-    words[:, :, 1] = ((words[:, :, 1] & np.uint32(0xff000000))
-                      | frame_nr[:, None].astype(np.uint32))
-    tids = np.array([thread_ids[p] for p in order], dtype=np.uint32)
-    words[:, :, 3] = ((words[:, :, 3] & np.uint32(0xfc00ffff))
-                      | (tids[None, :] << np.uint32(16)))
-    if header0.edv == 0xab:
-        words[:, :, 5] = ((words[:, :, 5] & np.uint32(0xffff8000))
-                          | frame_nr[:, None].astype(np.uint32))
-    return words.reshape(nsets * nthread, nwords)
 
 
 def vdif_file_image(payloads, header0, thread_ids=(0,), frame_rate=100,

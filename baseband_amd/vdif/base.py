@@ -17,7 +17,7 @@ from ..base.base import (FileBase, VLBIFileReaderBase, GPUStreamReaderBase,
 from ..base.writer import GPUStreamWriterBase
 from ..base.opener import FormatOpener
 from ..base.header import strided_header_words
-from .header import VDIFHeader
+from .header import VDIFHeader, frame_header_words
 from .frame import VDIFFrame, VDIFFrameSet
 
 __all__ = ['VDIFFileReader', 'VDIFFileWriter', 'VDIFStreamReader', 'VDIFStreamWriter',
@@ -481,7 +481,6 @@ class VDIFStreamWriter(GPUStreamWriterBase):
         self._coder = (_lib.CODER_MARK5B if header0.edv == 0xab else _lib.CODER_VDIF)
 
     def _write_frames(self, data, valid):
-        from .. import synth
         nthread, nchan = self._unsliced_shape
         spf = self.samples_per_frame
         nsets = data.shape[0] // spf
@@ -493,7 +492,7 @@ class VDIFStreamWriter(GPUStreamWriterBase):
         h['seconds'] = self.header0['seconds'] + idx // self._frame_rate
         h['frame_nr'] = idx % self._frame_rate
         # thread ids are 0..n-1 whatever header0 holds (vdif/frame.py:277-285)
-        words = synth.vdif_frame_headers(h, nsets, list(range(nthread)), self._frame_rate)
+        words = frame_header_words(h, nsets, list(range(nthread)), self._frame_rate)
         heads = words.view(np.uint8).reshape(nsets, nthread, -1)
         heads[~np.asarray(valid, bool), :, 3] |= 0x80          # invalid_data bit of the whole set
         self._emit_frames(heads.reshape(nsets * nthread, -1), packed)
