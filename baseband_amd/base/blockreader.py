@@ -26,6 +26,16 @@ class BlockStreamReader(GPUStreamReaderBase):
                        payload_offset, frame_stride, first_frame):
         raise NotImplementedError
 
+    def _row_range_source(self, frame, a, b):
+        """For rows [a, b) of `frame`: ``(pieces, decode)`` where `pieces` is a
+        list of (byte offset in the file image, nbytes) that together hold
+        those rows and ``decode(dbuf, out_flat)`` decodes them from a device
+        buffer in which the pieces lie back to back -- or None when the format
+        has no such shortcut (the whole frame is staged then)."""
+        return None
+
+    _touched = None         # sample offset at which the previous small request ended
+
     def _frame_span(self, frame):
         """(byte offset of the frame in the file, number of bytes to stage)."""
         return (self._file_offset0 + frame * self._frame_nbytes,
@@ -72,14 +82,26 @@ class BlockStreamReader(GPUStreamReaderBase):
         if count < self.samples_per_frame and len(runs) <= 2 and all(r[1] == r[0] + 1 for r in runs):
             from ..staging import upload
             for f0, f1, a, b in runs:
-                if self._ahead is None or self._ahead[0] != f0:
+                o = flat[done * row:(done + (b - a)) * row]
+                done += b - a
+                cached = self._ahead is not None and self._ahead[0] == f0
+                # random access: stage just the rows asked for; a request that
+                # continues where the previous small one ended (a sequential
+                # loop) brings the whole frame in
+                source = None if cached or self._touched == self.offset else self._row_range_source(f0, a, b)
+                if source is not None:
+                    pieces, decode = source
+                    host = np.concatenate([image[lo:lo + n] for lo, n in pieces]) if len(pieces) > 1 \
+                        else image[pieces[0][0]:pieces[0][0] + pieces[0][1]]
+                    decode(upload(host), o)
+                    continue
+                if not cached:
                     lo, nbytes = self._frame_span(f0)
                     self._ahead = (f0, upload(image[lo:min(lo + nbytes, len(image))]))
-                o = flat[done * row:(done + (b - a)) * row]
                 self._decode_window(self._ahead[1], 1, a, b, o, self._header_nbytes,
                                     self._frame_nbytes, f0)
-                done += b - a
             runs = []
+            self._touched = self.offset + count
         for f0, f1, a, b in runs:
             off0, nbytes = self._frame_span(f0)
             per_win = max(1, self.window_bytes // self._frame_nbytes)

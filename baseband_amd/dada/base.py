@@ -129,6 +129,28 @@ class DADAStreamReader(BlockStreamReader):
             done += n
         return pieces
 
+    def _row_range_source(self, frame, a, b):
+        """Rows [a, b) of a frame are contiguous (whole heaps for MKBF)."""
+        if self.bps != 8:
+            return None
+        base = self._frame_span(frame)[0] + self._header_nbytes
+        npol, nchan = self._unsliced_shape
+        if self._mkbf:
+            h0, h1 = a // 256, -(-b // 256)
+            heap = npol * nchan * 256 * 2
+            pieces = [(base + h0 * heap, (h1 - h0) * heap)]
+
+            def decode(dbuf, out_flat):
+                kernels.decode_i8_tiled(dbuf, 1, _lib.LAYOUT_MKBF, npol, nchan, (h1 - h0) * 256,
+                                        a - h0 * 256, b - h0 * 256, src0=0, out=out_flat)
+            return pieces, decode
+        rb = self._row_nbytes
+        pieces = [(base + a * rb, (b - a) * rb)]
+
+        def decode(dbuf, out_flat):
+            out_flat[:(b - a) * rb] = decode_i8_rows(dbuf, 0, rb, 0, b - a)
+        return pieces, decode
+
     def _decode_window(self, dbuf, nframes, a, b, out_flat, payload_offset,
                        frame_stride, first_frame):
         if self.bps not in (8, 32) or (self._mkbf and self.bps != 8):

@@ -101,6 +101,30 @@ class GUPPIStreamReader(BlockStreamReader):
             done += n
         return pieces
 
+    def _row_range_source(self, frame, a, b):
+        """Times [a, b) of a block: one run per channel (channels first) or one
+        run in all (time first); staged back to back they are a block of
+        b - a times in the same storage order."""
+        h = self.header0
+        if self.bps != 8 or not self.complex_data:
+            return None
+        npol, nchan, T = h.npol, h.nchan, self._spf_full
+        base = self._frame_span(frame)[0] + self._header_nbytes
+        step = npol * 2                                   # bytes per time of one channel
+        if h.channels_first:
+            if nchan > 4096:
+                return None
+            pieces = [(base + (c * T + a) * step, (b - a) * step) for c in range(nchan)]
+            layout = _lib.LAYOUT_GUPPI_CF
+        else:
+            pieces = [(base + a * nchan * step, (b - a) * nchan * step)]
+            layout = _lib.LAYOUT_GUPPI_TF
+
+        def decode(dbuf, out_flat):
+            kernels.decode_i8_tiled(dbuf, 1, layout, npol, nchan, b - a, 0, b - a,
+                                    src0=0, out=out_flat)
+        return pieces, decode
+
     def _decode_window(self, dbuf, nframes, a, b, out_flat, payload_offset,
                        frame_stride, first_frame):
         h = self.header0

@@ -300,3 +300,32 @@ def test_gsb_file_level_classes(tmp_path):
             outs[p][k].close()
             n = 8 // 2 * 512 * 2
             assert open(str(tmp_path / ('q%d%d.dat' % (p, k))), 'rb').read() == open(names[p][k], 'rb').read()[:n]
+
+
+@pytest.mark.parametrize('fmt,name', [('guppi', n) for n in GUPPI_CASES] + [('dada', n) for n in DADA_CASES])
+def test_small_reads_row_staging_equals_whole_frame_staging(manifest, fmt, name):
+    """A small request that touches a frame for the first time stages only the
+    rows it needs (`_row_range_source`); touching the frame again stages and
+    caches the whole frame.  Both must give the same samples (the whole-frame
+    path is pinned to the reference by the stream tests above)."""
+    import baseband_amd
+    mod = getattr(baseband_amd, fmt)
+    path = golden_path(manifest[name]['file'])
+    rng = np.random.default_rng(len(name))
+    with mod.open(path, 'rs', squeeze=False) as fh:
+        n, spf = fh.shape[0], fh.samples_per_frame
+        if spf < 4:
+            pytest.skip('frames too short')
+        reads = [(int(rng.integers(0, n - 1)), int(rng.integers(1, max(2, min(spf - 1, 300))))) for _ in range(25)]
+        reads = [(o, min(c, n - o)) for o, c in reads]
+    for off, cnt in reads:
+        with mod.open(path, 'rs', squeeze=False) as fh:
+            fh.seek(off)
+            first = fh.read(cnt).cpu().numpy()          # random access: rows only (when supported)
+            fh.seek(max(off - 1, 0))
+            if off > 0:
+                fh.read(1)                              # a request that ends at `off` ...
+            again = fh.read(cnt).cpu().numpy()          # ... makes this one sequential: whole frame
+            fh.seek(off)
+            third = fh.read(cnt).cpu().numpy()          # served from the cached frame
+        assert bits_equal(first, again) and bits_equal(again, third), (off, cnt)

@@ -22,7 +22,7 @@ with open(path, 'wb') as f:
 with guppi.open(path, 'rs') as fh:
     for n in (1024, 65536):
         fh.seek(0)
-        fh.read(n); torch.cuda.synchronize()
+        fh.read(n); fh.read(n); torch.cuda.synchronize()     # second touch stages the whole block
         reps = min(300, (fh.shape[0] - n) // n - 1)
         t = time.perf_counter()
         for _ in range(reps):
@@ -31,6 +31,15 @@ with guppi.open(path, 'rs') as fh:
         dt = time.perf_counter() - t
         print(json.dumps(dict(case='GUPPI sequential read(%d), 128 MiB blocks' % n,
                               us_per_read=round(dt / reps * 1e6, 1))), flush=True)
+    rng = np.random.default_rng(1)
+    where = rng.integers(0, fh.shape[0] - 2048, 200)
+    fh.seek(int(where[0])); fh.read(1024); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for k in where:
+        fh.seek(int(k)); d = fh.read(1024)
+    torch.cuda.synchronize()
+    print(json.dumps(dict(case='GUPPI random seek + read(1024), 128 MiB blocks',
+                          us_per_read=round((time.perf_counter() - t) / len(where) * 1e6, 1))), flush=True)
     # across a block boundary
     fh.seek(spf - 500)
     a = fh.read(1000)
