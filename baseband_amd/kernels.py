@@ -12,14 +12,29 @@ from . import _lib
 from ._lib import lib, check
 
 
+_gpu_checked = False
+
+
 def require_gpu():
+    global _gpu_checked
+    if _gpu_checked:
+        return
     if not torch.cuda.is_available():
         raise RuntimeError(
             "baseband_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() "
             "is False and there is no CPU decode path in this package.")
+    _gpu_checked = True                 # (the check costs microseconds per call)
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 def _stream():
+    """Handle of torch's current HIP stream on the current device.  The raw
+    getter avoids ~8 us of Python in ``torch.cuda.current_stream()`` per call
+    (three calls per small read)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
