@@ -294,14 +294,14 @@ class GSBStreamWriter(GPUStreamWriterBase):
         if data.is_complex():
             data = torch.view_as_real(data)
         if self._rawdump:
-            packed = kernels.encode_flat(data, _lib.CODER_INT, self.bps).cpu().numpy()
+            packed = self._to_host(kernels.encode_flat(data, _lib.CODER_INT, self.bps))
             self.fh_raw.write(packed.data)
         else:
             npol, F = len(self.fh_raw), self._nfiles
             # (frame, part, time in part, pol, ...) -> (pol, part, frame, time, ...)
             block = data.reshape((nframes, F, spf // F, npol) + tuple(data.shape[2:]))
             block = block.permute(3, 1, 0, 2, *range(4, block.dim()))
-            packed = kernels.encode_flat(block, _lib.CODER_INT, self.bps).cpu().numpy()
+            packed = self._to_host(kernels.encode_flat(block, _lib.CODER_INT, self.bps))
             packed = packed.reshape(npol, F, nframes * self._payload_nbytes)
             for p in range(npol):
                 for f in range(F):
