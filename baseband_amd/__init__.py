@@ -13,3 +13,23 @@ __version__ = '0.1.0'
 from .io import FORMATS, file_info, open   # noqa: E402,F401
 
 __all__ = ['FORMATS', 'file_info', 'open', 'vdif', 'mark5b', 'mark4', 'guppi', 'dada', 'gsb']
+
+
+def asnumpy(data, out=None):
+    """Decoded samples (device tensor) -> NumPy array on the host, through the
+    pinned double-buffered copy of `staging.download` (what the reference
+    returns from ``read()`` in the first place; here an explicit step, because
+    the decoded output is 4-32 times larger than the file and usually wanted on
+    the GPU)."""
+    import numpy as np
+    from .staging import download
+    dtype = np.complex64 if data.is_complex() else np.float32
+    if out is None:
+        out = np.empty(tuple(data.shape), dtype=dtype)
+    if data.is_cuda and out.flags.c_contiguous and out.dtype == dtype:
+        return download(data, out)
+    out[...] = data.cpu().numpy()
+    return out
+
+
+__all__ += ['asnumpy']

@@ -205,6 +205,18 @@ class VLBIFileReaderBase(FileBase):
         return cached
 
 
+def _to_host_array(data, out):
+    """Device tensor -> the caller's NumPy `out`: pinned double-buffered copy
+    for large contiguous destinations, plain copy otherwise."""
+    from ..staging import download
+    want = np.complex64 if data.is_complex() else np.float32
+    if (isinstance(out, np.ndarray) and out.flags.c_contiguous and out.dtype == want
+            and out.nbytes >= (32 << 20)):
+        download(data, out)
+    else:
+        out[...] = data.cpu().numpy()
+
+
 def _apply_squeeze(shape):
     return tuple(s for s in shape if s > 1)
 
@@ -446,7 +458,7 @@ class GPUStreamReaderBase:
         if isinstance(out, torch.Tensor):
             out.copy_(data)
         else:
-            out[...] = data.cpu().numpy()
+            _to_host_array(data, out)
         return out
 
     def _direct_target(self, out, off0, count, nrows):

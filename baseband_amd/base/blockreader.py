@@ -12,7 +12,7 @@ import torch
 
 from .. import kernels
 from ..staging import WindowPipeline
-from .base import GPUStreamReaderBase
+from .base import GPUStreamReaderBase, _to_host_array
 
 
 class BlockStreamReader(GPUStreamReaderBase):
@@ -140,5 +140,5 @@ class BlockStreamReader(GPUStreamReaderBase):
         if isinstance(out, torch.Tensor):
             out.copy_(data)
         else:
-            out[...] = data.cpu().numpy()
+            _to_host_array(data, out)
         return out

@@ -400,3 +400,31 @@ def test_frames_and_frame_sets_convert_to_numpy(manifest):
     s = np.asarray(frameset)
     assert s.shape == tuple(frameset.data.shape) and bits_equal(s, frameset.data.cpu().numpy())
     assert np.asarray(frame, dtype=np.float64).dtype == np.float64
+
+
+def test_read_into_numpy_and_asnumpy(tmp_path):
+    """``read(out=<ndarray>)`` for a large request and ``baseband_amd.asnumpy``
+    go through the pinned double-buffered download; the samples must equal the
+    device result."""
+    import torch
+    import baseband_amd
+    from baseband_amd import vdif, synth
+    image, h0 = synth.random_vdif(11, 400, payload_nbytes=8000, frame_rate=1000)
+    path = str(tmp_path / 'x.vdif')
+    image.tofile(path)
+    with vdif.open(path, 'rs', sample_rate=32e6) as fh:
+        dev = fh.read()
+        fh.seek(0)
+        host = np.empty(tuple(dev.shape), np.float32)
+        assert host.nbytes > (32 << 20)
+        got = fh.read(out=host)
+        assert got is host and bits_equal(host, dev.cpu().numpy())
+        fh.seek(5)
+        small = np.empty((1000,), np.float32)
+        fh.read(out=small)
+        assert bits_equal(small, dev[5:1005].cpu().numpy())
+    assert bits_equal(baseband_amd.asnumpy(dev), dev.cpu().numpy())
+    z = torch.view_as_complex(torch.randn(100, 3, 2, device='cuda'))
+    assert np.array_equal(baseband_amd.asnumpy(z), z.cpu().numpy())
+    strided = np.empty((dev.shape[0], 2), np.float32)[:, 0]
+    assert bits_equal(baseband_amd.asnumpy(dev, out=strided), dev.cpu().numpy())
