@@ -10,6 +10,8 @@ back as device tensors.
 import numpy as np
 import torch
 
+from ..staging import to_numpy
+
 
 def _delegate(owner, name, doc=None):
     """Read-only attribute forwarded to ``self.<owner>.<name>``."""
@@ -111,7 +113,7 @@ class FrameBase:
     def __array__(self, dtype=None, copy=None):
         """Decoded frame on the host (base/frame.py:182-187): the one place
         where a frame's samples leave the device."""
-        host = self.data.cpu().numpy()
+        host = to_numpy(self.data)
         return host if dtype in (None, host.dtype) else host.astype(dtype)
 
     # -- header passthrough

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .. import kernels
+from ..staging import to_numpy
 
 
 def _resolve_index(index, length, who):
@@ -300,7 +301,7 @@ class PayloadBase:
     data = property(__getitem__, doc="Full decoded payload (device tensor).")
 
     def __array__(self, dtype=None, copy=None):
-        host = self.data.cpu().numpy()
+        host = to_numpy(self.data)
         return host if dtype in (None, host.dtype) else host.astype(dtype)
 
     def __eq__(self, other):

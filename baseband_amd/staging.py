@@ -215,3 +215,14 @@ def download(dev, host, chunk_bytes=64 << 20):
             events[pb].synchronize()
             _parallel_copy(dst[plo:phi], pinned[pb].numpy()[:phi - plo])
     return host
+
+
+def to_numpy(dev):
+    """Device tensor -> new NumPy array: `download` for large tensors, a plain
+    copy for small ones."""
+    if dev.is_cuda and dev.numel() * dev.element_size() >= (32 << 20):
+        out = np.empty(tuple(dev.shape), dtype=np.complex64 if dev.is_complex() else
+                       {torch.float32: np.float32, torch.uint8: np.uint8}.get(dev.dtype, None))
+        if out.dtype in (np.float32, np.complex64):
+            return download(dev, out)
+    return dev.cpu().numpy()

@@ -12,6 +12,8 @@ come back as ``fill_value``.
 import numpy as np
 import torch
 
+from ..staging import to_numpy
+
 from .. import kernels
 from ..base.frame import FrameBase
 from .header import VDIFHeader
@@ -264,5 +266,5 @@ class VDIFFrameSet:
     data = property(__getitem__, doc="Decoded frame set (device tensor).")
 
     def __array__(self, dtype=None, copy=None):
-        host = self.data.cpu().numpy()
+        host = to_numpy(self.data)
         return host if dtype in (None, host.dtype) else host.astype(dtype)
