@@ -117,7 +117,8 @@ class GPUStreamWriterBase:
         if self._closed:
             raise ValueError("I/O operation on closed stream.")
         if not isinstance(data, torch.Tensor):
-            data = torch.from_numpy(np.ascontiguousarray(data))
+            from ..staging import upload_array
+            data = upload_array(data)
         assert tuple(data.shape[1:]) == self.sample_shape, (
             "'data' should have trailing shape {}".format(self.sample_shape))
         want = torch.complex64 if self.complex_data else torch.float32

@@ -299,7 +299,8 @@ def as_device_samples(data):
     arrays and host tensors are uploaded)."""
     require_gpu()
     if not isinstance(data, torch.Tensor):
-        data = torch.from_numpy(np.ascontiguousarray(data))
+        from .staging import upload_array
+        data = upload_array(data)
     want = torch.complex64 if data.is_complex() else torch.float32
     return data.to(device='cuda', dtype=want)
 

@@ -226,3 +226,16 @@ def to_numpy(dev):
         if out.dtype in (np.float32, np.complex64):
             return download(dev, out)
     return dev.cpu().numpy()
+
+
+def upload_array(array, device='cuda'):
+    """float32 / complex64 NumPy array -> device tensor of the same shape:
+    large C-contiguous arrays go through the pinned chunk pipeline of `upload`
+    (a pageable source copied in one go runs at a fifth of the link rate)."""
+    array = np.asarray(array)
+    tdtype = {np.dtype(np.float32): torch.float32, np.dtype(np.complex64): torch.complex64}.get(array.dtype)
+    if tdtype is None or not array.flags.c_contiguous or array.nbytes < (32 << 20):
+        return torch.from_numpy(np.ascontiguousarray(array)).to(device)
+    raw = array.reshape(-1).view(np.uint8)
+    dev = upload(raw, device=device)[:raw.size]
+    return dev.view(tdtype).reshape(array.shape)

@@ -539,3 +539,28 @@ def test_base_encoding_module_matches_oracle_and_library_tables(gold):
     assert bits_equal(out.cpu().numpy(), orc.code_levels('vdif', 8)[words])
     out2 = enc.decode_8bit(torch.from_numpy(words).cuda())
     assert bool((out2 == out).all())
+
+
+def test_large_host_arrays_are_written_like_device_tensors(tmp_path):
+    """A large NumPy input goes to the GPU through the pinned upload
+    (`staging.upload_array`); the file must equal the one written from the
+    same samples already on the device."""
+    import torch
+    from baseband_amd import vdif
+    from baseband_amd.vdif.header import VDIFHeader
+    from baseband_amd.staging import upload_array
+    rng = np.random.default_rng(21)
+    data = (rng.standard_normal(32000 * 300) * 2.).astype(np.float32)      # 38 MB
+    assert data.nbytes > (32 << 20)
+    dev = upload_array(data)
+    assert dev.is_cuda and dev.dtype == torch.float32 and bool((dev.cpu() == torch.from_numpy(data)).all())
+    z = (rng.standard_normal((5_000_000, 2)) + 0j).astype(np.complex64)
+    assert bool((upload_array(z).cpu() == torch.from_numpy(z)).all())
+    h0 = VDIFHeader.fromvalues(edv=0, time=np.datetime64('2014-06-13T05:30:01'), nchan=1, bps=2,
+                               complex_data=False, thread_id=0, samples_per_frame=32000, station='AA')
+    a, b = str(tmp_path / 'a.vdif'), str(tmp_path / 'b.vdif')
+    with vdif.open(a, 'ws', header0=h0, sample_rate=32e6, nthread=1) as fw:
+        fw.write(data)
+    with vdif.open(b, 'ws', header0=h0, sample_rate=32e6, nthread=1) as fw:
+        fw.write(torch.from_numpy(data).cuda())
+    assert open(a, 'rb').read() == open(b, 'rb').read()
