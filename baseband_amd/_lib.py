@@ -42,6 +42,8 @@ TUNE_TILED_STAGE = 10
 TUNE_MKBF_CHANNELS = 11
 TUNE_GATHER_CHUNKS = 12
 TUNE_SEG_TILES = 13
+TUNE_FRONT_GROUP = 14
+TUNE_FRONT_STEPS = 15
 
 
 class BBError(RuntimeError):
@@ -125,6 +127,7 @@ SIGNATURES = [
     ('bb_abi_version', C.c_int, []),
     ('bb_strerror', C.c_char_p, [C.c_int]),
     ('bb_last_hip_error', C.c_int, []),
+    ('bb_last_kernel', C.c_char_p, []),
     ('bb_init', C.c_int, []),
     ('bb_get_levels', C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _sz]),
     ('bb_get_encode_thresholds', C.c_int, [C.POINTER(C.c_float)]),
@@ -161,6 +164,12 @@ def check(code, where):
             # _decoders dict (base/payload.py:314-315)
             raise KeyError("{}: unsupported coder / bits per sample".format(where))
         raise BBError(code, where)
+
+
+def last_kernel():
+    """Name / template arguments / grid of the decode kernel this thread
+    launched last (bb_last_kernel)."""
+    return lib.bb_last_kernel().decode()
 
 
 def get_levels(coder, bps):

@@ -413,6 +413,41 @@ class GPUStreamReaderBase:
                              "'current', or 2 or 'end'.")
         return self.offset
 
+    # -- file image resident in HBM (resident.py)
+    _staged = None
+
+    def stage(self):
+        """Upload the whole file once and keep it in HBM: every later
+        ``read()`` decodes straight from there with one scan / index / decode
+        launch per request (no staging windows, no PCIe).  A reader opened on
+        a device tensor is resident from the start.  Returns self."""
+        from ..staging import upload
+        image = self._image()
+        if getattr(image, 'device_tensor', None) is None and self._staged is None:
+            kernels.require_gpu()
+            self._staged = upload(image)[:len(image)]
+        return self
+
+    def unstage(self):
+        """Drop the HBM copy made by `stage`."""
+        self._staged = None
+
+    def _resident_bytes(self):
+        """Device tensor holding the file bytes, or None."""
+        if self._staged is not None:
+            return self._staged
+        return getattr(self._image(), 'device_tensor', None)
+
+    @staticmethod
+    def _device_window(dev, lo, hi, align=8):
+        """``dev[lo:hi]`` for the kernels: a view when `lo` is aligned the way
+        the library wants its buffers, an aligned copy otherwise (files with
+        leading junk bytes)."""
+        part = dev[lo:hi]
+        if part.numel() and part.data_ptr() % align:
+            part = part.clone()
+        return part
+
     # -- the hot path
     def read(self, count=None, out=None):
         """Read and decode `count` complete samples -> device tensor of shape
@@ -433,13 +468,7 @@ class GPUStreamReaderBase:
         if self._pending_warning:
             warnings.warn(self._pending_warning)
             self._pending_warning = None
-        spf = self.samples_per_frame
-        first, off0 = divmod(self.offset, spf)
-        last = -(-(self.offset + count) // spf) if count else first
-        # a frame-aligned request into a suitable device tensor is decoded in
-        # place: no second pass over the 16x larger output
-        into = self._direct_target(out, off0, count, (last - first) * spf)
-        data = self._read_sets(first, last, into)       # (nsets*spf, *unsliced)
+        data, direct = self._fill_request(out, count)
         if not self._resolve_checks():
             # verify='fix': frames are missing or out of place.  Build the
             # corruption-tolerant index (byte-granular header search) and
@@ -447,11 +476,10 @@ class GPUStreamReaderBase:
             self._relocate()
             if self.offset + count > self.shape[0]:
                 raise EOFError("cannot read from beyond end of input.")
-            data = self._read_sets(first, last, into)
+            data, direct = self._fill_request(out, count)
         self.offset += count
-        if into is not None:
+        if direct:
             return out
-        data = data[off0:off0 + count]
         data = self._squeeze_and_subset(data)
         if out is None:
             return data
@@ -461,12 +489,40 @@ class GPUStreamReaderBase:
             _to_host_array(data, out)
         return out
 
-    def _direct_target(self, out, off0, count, nrows):
+    def _fill_request(self, out, count):
+        """Decode samples [offset, offset + count).  Returns ``(data, direct)``:
+        with a suitable device tensor as `out` the whole frame sets inside the
+        request are decoded in place (no second pass over the 16x larger
+        output) and only a partial first / last frame set goes through a
+        temporary -- `direct` is True and `out` is complete; otherwise `data`
+        holds the samples before squeeze / subset."""
+        spf = self.samples_per_frame
+        first, off0 = divmod(self.offset, spf)
+        stop = self.offset + count
+        last = -(-stop // spf) if count else first
+        flat = self._direct_target(out)
+        body0, body1 = first + (1 if off0 else 0), stop // spf
+        if flat is not None and count and body1 > body0:
+            row = flat.numel() // count
+            o0 = body0 * spf - self.offset
+            self._read_sets(body0, body1, flat[o0 * row:(o0 + (body1 - body0) * spf) * row])
+            if off0:
+                head = self._squeeze_and_subset(self._read_sets(first, body0))
+                out[:o0] = head[off0:]
+            if body1 < last:
+                ntail = stop - body1 * spf
+                tail = self._squeeze_and_subset(self._read_sets(body1, last))
+                out[count - ntail:] = tail[:ntail]
+            return out, True
+        data = self._read_sets(first, last)
+        return data[off0:off0 + count], False
+
+    def _direct_target(self, out):
         """Flat float32 view of `out` when the decode may write straight into
-        it: a contiguous device tensor of the stream's dtype covering whole
-        frame sets, and no subset (squeezing only drops unit dimensions)."""
-        if (not isinstance(out, torch.Tensor) or not out.is_cuda or off0 or count != nrows
-                or count == 0 or not out.is_contiguous() or self.subset
+        it: a contiguous device tensor of the stream's dtype, and no subset
+        (squeezing only drops unit dimensions)."""
+        if (not isinstance(out, torch.Tensor) or not out.is_cuda
+                or not out.is_contiguous() or self.subset
                 or getattr(self, '_frameset_subset', None)
                 or tuple(self._decode_shape) != tuple(self._unsliced_shape)
                 or out.dtype != (torch.complex64 if self.complex_data else torch.float32)):
@@ -485,7 +541,19 @@ class GPUStreamReaderBase:
         flat = into if into is not None else torch.empty(
             nsets * spf * row, dtype=torch.float32, device='cuda')
         set_nbytes = self._set_nbytes
-        if nsets and nsets * set_nbytes * 8 <= self.window_bytes:
+        resident = self._resident_bytes() if nsets else None
+        if resident is not None:
+            # the file is in HBM already: ONE scan -> index -> decode over the
+            # whole request, straight from where the bytes lie
+            lo = min(self._file_offset0 + first * set_nbytes, resident.numel())
+            look = 1 if self.verify else 0
+            hi = max(lo, min(self._file_offset0 + (last + look) * set_nbytes, resident.numel()))
+            try:
+                self._process_window(self._device_window(resident, lo, hi), first, last, flat)
+            except Exception:
+                self._nmissing, self._checked = 0, False
+                raise
+        elif nsets and nsets * set_nbytes * 8 <= self.window_bytes:
             # small request: serve it from the read-ahead window kept in HBM
             self._read_small(first, last, flat, spf * row)
         elif nsets:
@@ -496,12 +564,14 @@ class GPUStreamReaderBase:
             ranges, spans = [], []
             for s in range(first, last, per_win):
                 e = min(last, s + per_win)
-                lo = self._file_offset0 + s * set_nbytes
+                lo = min(self._file_offset0 + s * set_nbytes, len(image))
                 # when verifying, the frame set after the last one requested
                 # travels along: a frame only counts as good if the header
                 # behind it is in place too (base/base.py:1083-1125)
                 look = 1 if (self.verify and e == last) else 0
-                hi = min(self._file_offset0 + (e + look) * set_nbytes, len(image))
+                # (a file with bytes missing ends before its last headers say:
+                # such windows are short or empty, never negative)
+                hi = max(lo, min(self._file_offset0 + (e + look) * set_nbytes, len(image)))
                 ranges.append((lo, hi))
                 spans.append((s, e))
 
@@ -510,7 +580,12 @@ class GPUStreamReaderBase:
                 o = flat[(s - first) * spf * row:(e - first) * spf * row]
                 self._process_window(dbuf, s, e, o)
 
-            self._pipeline.run(ranges, process)
+            try:
+                self._pipeline.run(ranges, process)
+            except Exception:
+                # do not leave half a read's verification state for the next one
+                self._nmissing, self._checked = 0, False
+                raise
         if self.complex_data:
             flat = torch.view_as_complex(flat.view(-1, 2))
         return flat.reshape((nsets * spf,) + tuple(self._decode_shape))

@@ -68,6 +68,7 @@ class BlockStreamReader(GPUStreamReaderBase):
             flat = torch.empty(count * row, dtype=torch.float32, device='cuda')
         pieces = self._pieces(self.offset, count)
         image = self._image()
+        resident = self._resident_bytes()
         # merge consecutive frames that use the same row range into runs
         runs = []
         for f, a, b in pieces:
@@ -89,6 +90,12 @@ class BlockStreamReader(GPUStreamReaderBase):
                 # continues where the previous small one ended (a sequential
                 # loop) brings the whole frame in
                 source = None if cached or self._touched == self.offset else self._row_range_source(f0, a, b)
+                if resident is not None:
+                    # the frame is in HBM already: decode from where it lies
+                    lo, nbytes = self._frame_span(f0)
+                    self._decode_window(self._device_window(resident, lo, min(lo + nbytes, resident.numel())),
+                                        1, a, b, o, self._header_nbytes, self._frame_nbytes, f0)
+                    continue
                 if source is not None:
                     pieces, decode = source
                     host = np.concatenate([image[lo:lo + n] for lo, n in pieces]) if len(pieces) > 1 \
@@ -103,6 +110,16 @@ class BlockStreamReader(GPUStreamReaderBase):
             runs = []
             self._touched = self.offset + count
         for f0, f1, a, b in runs:
+            if resident is not None:
+                # ONE launch for the whole run of frames, straight from HBM
+                lo = self._frame_span(f0)[0]
+                last_lo, last_n = self._frame_span(f1 - 1)
+                hi = min(last_lo + last_n, resident.numel())
+                o = flat[done * row:(done + (f1 - f0) * (b - a)) * row]
+                self._decode_window(self._device_window(resident, lo, hi), f1 - f0, a, b, o,
+                                    self._header_nbytes, self._frame_nbytes, f0)
+                done += (f1 - f0) * (b - a)
+                continue
             off0, nbytes = self._frame_span(f0)
             per_win = max(1, self.window_bytes // self._frame_nbytes)
             cap = max(per_win * self._frame_nbytes, nbytes)

@@ -15,8 +15,17 @@ from .writer import LazyWriteFile
 __all__ = ['FormatOpener', 'source_kind']
 
 
+def _is_device_bytes(name):
+    """A tensor on the GPU: the file image itself, already staged in HBM."""
+    import torch
+    return isinstance(name, torch.Tensor)
+
+
 def source_kind(name):
-    """'fh', 'name', 'sequence' or 'template' (base/base.py:1694-1741)."""
+    """'fh', 'name', 'sequence' or 'template' (base/base.py:1694-1741);
+    'device' for a GPU tensor holding the file bytes (resident.py)."""
+    if _is_device_bytes(name):
+        return 'device'
     if isinstance(name, str):
         return 'template' if ('{' in name and '}' in name) else 'name'
     if isinstance(name, os.PathLike):
@@ -90,6 +99,11 @@ class FormatOpener:
         kind = source_kind(name)
         if kind == 'fh':
             return name, None
+        if kind == 'device':
+            if mode[0] != 'r':
+                raise ValueError("a device tensor can only be opened for reading.")
+            from ..resident import DeviceFile
+            return DeviceFile(name), None
         if kind == 'template':
             name, kind = self._sequencer_for(name, mode, kwargs), 'sequence'
         if mode[0] == 'r':

@@ -228,9 +228,17 @@ class PayloadBase:
         return slice(w0, w1), (index,) + rest
 
     def _device_words(self):
-        if self._dwords is None:
-            self._dwords = kernels.to_device_bytes(self.words)
-        return self._dwords
+        """Payload bytes in HBM.  The upload is kept only for read-only words
+        (bytes read from a file, read-only mappings): writable words can be
+        changed behind our back (a writable ``memmap_frame``, an array shared
+        with another payload), and the reference decodes the CURRENT words on
+        every access (base/payload.py:327-330)."""
+        if self._dwords is not None:
+            return self._dwords
+        dwords = kernels.to_device_bytes(self.words)
+        if not getattr(self.words, 'flags', None) or not self.words.flags.writeable:
+            self._dwords = dwords
+        return dwords
 
     def _decode(self, byte_start, byte_stop):
         """Flat float32 device tensor for payload bytes [byte_start,

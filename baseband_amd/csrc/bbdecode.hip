@@ -4,6 +4,7 @@
 #include "bb_common.h"
 #include "k_scan.h"
 #include "k_flat.h"
+#include "k_front.h"
 #include "k_gather.h"
 #include "k_mark4.h"
 #include "k_tiled.h"
@@ -11,11 +12,19 @@
 
 #include <atomic>
 #include <mutex>
+#include <stdio.h>
 #include <string.h>
 
 namespace {
 
 thread_local int t_last_hip = 0;
+// name of the decode kernel the calling thread launched last (bb_last_kernel)
+thread_local char t_last_kernel[160] = "";
+#define BB_NOTE(...) snprintf(t_last_kernel, sizeof(t_last_kernel), __VA_ARGS__)
+inline const char *lv_name(int bps, int coder)
+{
+    return bps <= 2 ? "REG" : (bps == 8 && coder == BB_CODER_INT) ? "INT8" : "LDS";
+}
 
 inline int hip_fail(hipError_t e) { t_last_hip = (int)e; return BB_EIO; }
 #define BB_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_); } while (0)
@@ -150,6 +159,8 @@ std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_front_g{2048};  // k_decode_flat_front: workgroups per group (one write front)
+std::atomic<int> g_tune_front_k{16};    // k_decode_flat_front: steps a group sweeps
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
@@ -187,6 +198,41 @@ void launch_flat_aln32(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a
 {
     if (nt) hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, true, 2, 32>), grid, dim3(2 * BB_WAVE), 0, st, a);
     else    hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, false, 2, 32>), grid, dim3(2 * BB_WAVE), 0, st, a);
+}
+
+// k_decode_flat_front: geometry + launch.  Returns the grid size used.
+template <int BPS, int LV, int NW, int TPW>
+unsigned launch_flat_front(bool nt, hipStream_t st, const bb_flat_args &a)
+{
+    const uint64_t ntiles = (a.ndw + 63) / 64;
+    bb_front_geom g;
+    g.ipf = (uint32_t)((ntiles + TPW - 1) / TPW);
+    g.nitems = a.nfs * g.ipf;
+    uint64_t G = (uint64_t)g_tune_front_g.load(), K = (uint64_t)g_tune_front_k.load();
+    const uint64_t wgs = (g.nitems + NW - 1) / NW;              // workgroup-steps in all
+    if (G > wgs) G = wgs;                                       // small launch: one short group
+    if (K * G > wgs) K = (wgs + G - 1) / G;
+    const uint64_t ngroups = (wgs + G * K - 1) / (G * K);
+    g.G = (uint32_t)G; g.K = (uint32_t)K;
+    g.step_fs = (uint32_t)((G * NW) / g.ipf);
+    g.step_j = (uint32_t)((G * NW) % g.ipf);
+    const dim3 grid((unsigned)(ngroups * G));
+    if (nt) hipLaunchKernelGGL((k_decode_flat_front<BPS, LV, true, NW, TPW>), grid, dim3(NW * BB_WAVE), 0, st, a, g);
+    else    hipLaunchKernelGGL((k_decode_flat_front<BPS, LV, false, NW, TPW>), grid, dim3(NW * BB_WAVE), 0, st, a, g);
+    return grid.x;
+}
+
+template <int NW, int TPW>
+unsigned launch_flat_front_any(int bps, int coder, bool nt, hipStream_t st, const bb_flat_args &a)
+{
+    switch (bps) {
+        case 1: return launch_flat_front<1, BB_LV_REG, NW, TPW>(nt, st, a);
+        case 2: return launch_flat_front<2, BB_LV_REG, NW, TPW>(nt, st, a);
+        case 4: return launch_flat_front<4, BB_LV_LDS, NW, TPW>(nt, st, a);
+        default:
+            if (coder == BB_CODER_INT) return launch_flat_front<8, BB_LV_INT8, NW, TPW>(nt, st, a);
+            return launch_flat_front<8, BB_LV_LDS, NW, TPW>(nt, st, a);
+    }
 }
 
 template <int BPS, int LV>
@@ -237,6 +283,8 @@ const char *bb_strerror(int code)
 
 int bb_last_hip_error(void) { return t_last_hip; }
 
+const char *bb_last_kernel(void) { return t_last_kernel; }
+
 int bb_init(void) { return ensure_init(); }
 
 int bb_get_levels(int coder, int bps, float *h_out, size_t n)
@@ -274,6 +322,8 @@ int bb_tune(int knob, int value)
         case BB_TUNE_GATHER_CHUNKS: g_tune_gather_chunks = value > 0 ? value : 32; return BB_OK;
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
+        case BB_TUNE_FRONT_GROUP: g_tune_front_g = (value >= 1 && value <= (1 << 20)) ? value : 2048; return BB_OK;
+        case BB_TUNE_FRONT_STEPS: g_tune_front_k = (value >= 1 && value <= (1 << 20)) ? value : 16; return BB_OK;
         default: return BB_EINVAL;
     }
 }
@@ -497,12 +547,29 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         if (nwork5 >= BB_GRID_CAP && nwork5 < 3 * BB_GRID_CAP) variant = 0;
     }
 
+    if (variant >= 6 && variant <= 9 && om == BB_OUT_FLAT) {
+        // explicit write front (k_front.h): 6 = 4 waves x 1 tile, 7 = 4 x 2, 8 = 2 x 4, 9 = 4 x 4
+        unsigned gx;
+        switch (variant) {
+            case 6:  gx = launch_flat_front_any<4, 1>(p->bps, p->coder, nt, st, a); break;
+            case 7:  gx = launch_flat_front_any<4, 2>(p->bps, p->coder, nt, st, a); break;
+            case 8:  gx = launch_flat_front_any<2, 4>(p->bps, p->coder, nt, st, a); break;
+            default: gx = launch_flat_front_any<4, 4>(p->bps, p->coder, nt, st, a); break;
+        }
+        BB_NOTE("k_decode_flat_front<%d,%s,%s,%s> grid %u G %d K %d", p->bps, lv_name(p->bps, p->coder),
+                nt ? "nt" : "plain", variant == 6 ? "4,1" : variant == 7 ? "4,2" : variant == 8 ? "2,4" : "4,4",
+                gx, g_tune_front_g.load(), g_tune_front_k.load());
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
+
     if (variant == 1 && p->bps == 2 && om == BB_OUT_FLAT) {
         uint64_t b2 = nfs;
         if (tb > 0 && b2 > (uint64_t)tb) b2 = (uint64_t)tb;
         if (b2 > 0x7fffffffull) b2 = 0x7fffffffull;
         if (nt) hipLaunchKernelGGL(k_decode_flat2_bytes<true>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
         else    hipLaunchKernelGGL(k_decode_flat2_bytes<false>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
+        BB_NOTE("k_decode_flat2_bytes<%s> grid %u", nt ? "nt" : "plain", (unsigned)b2);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
@@ -543,7 +610,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             ga.lrow = -1;
             if ((rl & (rl - 1)) == 0) { ga.lrow = 0; while ((1u << ga.lrow) < rl) ++ga.lrow; }
         }
-        ga.aligned = (variant >= 5 && ((uintptr_t)d_buf & 255) == 0) ? 1 : 0;
+        ga.aligned = variant >= 5 ? 1 : 0;
         const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024;
         // persistent grid: a workgroup walks about five work items (8 KiB of
         // payload each); one workgroup per item costs 15 %, a few thousand
@@ -562,6 +629,8 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
                 else                          launch_gather<8, BB_LV_LDS>(nt, gg, lds, st, ga);
                 break;
         }
+        BB_NOTE("k_decode_gather<%d,%s,%s,%s> grid %u gtiles %u lds %zu", p->bps, lv_name(p->bps, p->coder),
+                nt ? "nt" : "plain", ga.lchunk >= 2 ? "wide" : "narrow", gg.x, ga.gtiles, lds);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
@@ -570,7 +639,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // thread interleave with wide chunks: one wave per thread slot, all
         // waves on the same 8 tiles (k_decode_rows_pipe)
         const int nw = p->nslot >= 8 ? 8 : (p->nslot >= 4 ? 4 : 2);
-        const bool aln = variant >= 5 && ((uintptr_t)d_buf & 255) == 0;
+        const bool aln = variant >= 5;
         const uint64_t seg_max = g_tune_tpw.load() < 8 ? (uint64_t)g_tune_tpw.load() : 8;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
@@ -589,6 +658,8 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
                 else                          launch_rows_pipe<8, BB_LV_LDS>(nt, aln, nw, g2, st, a);
                 break;
         }
+        BB_NOTE("k_decode_rows_pipe<%d,%s,%s,%d,8,%s> grid %u", p->bps, lv_name(p->bps, p->coder),
+                nt ? "nt" : "plain", nw, aln ? "aligned" : "plain-loads", g2.x);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
@@ -610,6 +681,8 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
                 else                          launch_flat_span<8, BB_LV_LDS>(nt, g2, st, a);
                 break;
         }
+        BB_NOTE("k_decode_flat_span<%d,%s,%s,2,16> grid %u", p->bps, lv_name(p->bps, p->coder),
+                nt ? "nt" : "plain", g2.x);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
@@ -623,8 +696,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // 4 x 8 geometry; 2 x 32 tiles was tried for 8-bit data and lost 27 %.
         const bool wide = variant >= 3;
         const int nw = wide ? 2 : 4;
-        const bool aln = wide && om == BB_OUT_FLAT && variant == 5
-                         && ((uintptr_t)d_buf & 255) == 0;
+        const bool aln = wide && om == BB_OUT_FLAT && variant == 5;
         const int tpw8 = g_tune_tpw8.load();
         const bool long8 = aln && p->bps == 8 && tpw8 > 16;
         const int tpw_max = long8 ? (tpw8 > 32 ? 32 : tpw8) : wide ? g_tune_tpw.load() : 8;
@@ -671,6 +743,10 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
                     break;
             }
         }
+        BB_NOTE("%s<%d,%s,%s,%d,%d> out-mode %d grid %u tiles/wave %u",
+                !wide ? "k_decode_flat_pipe" : (long8 || aln) ? "k_decode_flat_aln" : "k_decode_flat_pipe",
+                p->bps, lv_name(p->bps, p->coder), nt ? "nt" : "plain", nw, long8 ? 32 : wide ? 16 : 8,
+                om, g2.x, a.tpw);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
@@ -685,6 +761,8 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             break;
         default: return BB_ENOTSUP;
     }
+    BB_NOTE("k_decode_flat<%d,%s,%d,%s> grid %u", p->bps, lv_name(p->bps, p->coder), om,
+            nt ? "nt" : "plain", grid.x);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }
@@ -804,6 +882,7 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
         default: BB_M4(64); break;
     }
 #undef BB_M4
+    BB_NOTE("k_decode_mark4<%d,%s> grid %u", p->ntrack, nt ? "nt" : "plain", grid.x);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }
@@ -904,6 +983,9 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     }
 #undef BB_TS
 #undef BB_TL
+    BB_NOTE("%s<%d,%s> grid %u tile %u times x %u chans lds %zu",
+            (stage && p->layout != BB_LAYOUT_GUPPI_CF) ? "k_decode_i8_stage" : "k_decode_i8_tiled",
+            p->layout, nt ? "nt" : "plain", grid.x, a.tt, a.tc, lds);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }

@@ -348,9 +348,12 @@ void k_decode_flat_aln(bb_flat_args a)
         // bits are the misalignment against 256-byte blocks
         // payloads found by the byte-granular search may start at odd bytes:
         // those keep plain (hardware-unaligned) loads, s = 0
-        const uint64_t b0 = valid ? (uint64_t)so : 0;
+        // (taken from the ADDRESS, not the offset: the buffer may be a view
+        // into a file image resident in HBM and start anywhere)
+        const uint8_t *pp = a.buf + (valid ? (uint64_t)so : 0);
+        const uintptr_t b0 = reinterpret_cast<uintptr_t>(pp);
         s = (b0 & 3) ? 0u : (uint32_t)((b0 >> 2) & 63);
-        const uint32_t *blk = reinterpret_cast<const uint32_t *>(a.buf + b0) - s;
+        const uint32_t *blk = reinterpret_cast<const uint32_t *>(pp) - s;
         const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
         const uint64_t dw_end = (seg + 1) * a.seg_tiles * 64 < a.ndw
                                 ? (seg + 1) * a.seg_tiles * 64 : a.ndw;
@@ -586,9 +589,10 @@ void k_decode_rows_pipe(bb_flat_args a)
         valid = so >= 0;
         const uint64_t tile0 = seg * a.seg_tiles;
         if (ALN) {
-            const uint64_t b0 = valid ? (uint64_t)so : 0;           // odd byte offsets: s = 0
+            const uint8_t *pp = a.buf + (valid ? (uint64_t)so : 0);
+            const uintptr_t b0 = reinterpret_cast<uintptr_t>(pp);   // odd byte addresses: s = 0
             s = (b0 & 3) ? 0u : (uint32_t)((b0 >> 2) & 63);
-            const uint32_t *blk = reinterpret_cast<const uint32_t *>(a.buf + b0) - s;
+            const uint32_t *blk = reinterpret_cast<const uint32_t *>(pp) - s;
 #pragma unroll
             for (int u = 0; u < NR; ++u) {
                 const uint64_t j = (tile0 + u) * 64 + lane;     // block dword j = payload dword j - s

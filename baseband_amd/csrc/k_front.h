@@ -1,0 +1,140 @@
+// Flat LUT decode with an explicit, launch-size independent write front.
+//
+// Same arithmetic as k_decode_flat_aln (k_flat.h: the reference's LUT take,
+// vdif/payload.py:69-103, mark5b/payload.py:78-94, base/encoding.py:131-144,
+// dada/payload.py:13-14, gsb/payload.py:24-36; fill base/frame.py:191-199) --
+// what changes is WHICH piece of the output a wave writes WHEN.
+//
+// k_decode_flat_aln maps work item -> workgroup as blockIdx + k * gridDim with a
+// grid of ~10^5 workgroups: the ~2000 resident workgroups then write into
+// min(16, items per workgroup) windows that lie gridDim items apart, and how
+// many windows there are depends on the launch size (DESIGN.md section 3,
+// "Launch size": 5.1-5.6 TB/s for 9-70 GB launches against 6.4-6.6 for 145 GB).
+// Here the map is explicit.  Work items (TPW tiles of 256 input bytes = up to
+// TPW x 4 KiB of output for 2-bit data) are numbered in output order.  The
+// grid is cut into GROUPS of G consecutive workgroups (G ~ the number of
+// workgroups resident on the chip); a group owns a contiguous region of
+// K * G * NW items and sweeps it in K steps: at step k, wave w of the group's
+// j-th workgroup decodes item  region + k * (G * NW) + j * NW + w.  All waves
+// of a group thus write side by side into one moving front of G * NW items
+// (tens of MiB) -- the store pattern of a grid-stride fill, which is what the
+// HBM system sustains best (tools/kbench: 6.9-7.3 TB/s) -- whatever the launch
+// size.  Groups follow each other in dispatch order.  Input loads for step
+// k + 1 are issued before the stores of step k (register double buffer), as
+// 256-byte ALIGNED blocks with the payload's misalignment folded into the bit
+// hand-out (see k_decode_flat_aln).
+#pragma once
+#include "k_flat.h"
+
+struct bb_front_geom {
+    uint64_t nitems;        // nfs * ipf
+    uint32_t ipf;           // work items per frame-slot = ceil(ntiles / TPW)
+    uint32_t G, K;          // workgroups per group, steps per group
+    uint32_t step_fs;       // (G * NW) / ipf   } one step advances an item index
+    uint32_t step_j;        // (G * NW) % ipf   } by G * NW
+};
+
+template <int BPS, int LV, bool NT, int NW, int TPW>
+__global__ __launch_bounds__(NW * BB_WAVE)
+void k_decode_flat_front(bb_flat_args a, bb_front_geom g)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr int EPT = 2048 / BPS;
+    constexpr int PASSES = 8 / BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
+
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += NW * BB_WAVE) s_tab[i] = a.tab[i];
+        __syncthreads();
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    const int lane = bb_lane();
+    const int wave = __builtin_amdgcn_readfirstlane(bb_wave());
+    const uint64_t E = a.ndw * (32 / BPS);
+    const uint32_t ntiles = (uint32_t)((a.ndw + 63) / 64);
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+    const int src_lane0 = (lane * BPS) >> 3;
+    const int shift = (4 * lane * BPS) & 31;
+
+    // first item of this wave, as (frame-slot, item within it); wave-uniform
+    const uint32_t grp = blockIdx.x / g.G, jb = blockIdx.x - grp * g.G;
+    const uint64_t ws = (uint64_t)g.G * NW;                     // items per step
+    uint64_t item = (uint64_t)grp * g.K * ws + (uint64_t)jb * NW + wave;
+    uint64_t fs = item / g.ipf;
+    uint32_t j = (uint32_t)(item - fs * g.ipf);
+
+    uint32_t cur[TPW + 1], nxt[TPW + 1];
+    bool cur_valid = false, nxt_valid = false;
+    uint32_t cur_s = 0, nxt_s = 0;
+
+    auto issue = [&](uint64_t f, uint32_t jj, uint32_t (&w)[TPW + 1], bool &valid, uint32_t &s) {
+        const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
+        valid = so >= 0;
+        const uint8_t *p = a.buf + (valid ? so : 0);
+        // misalignment of the payload against 256-byte blocks of the address
+        // space; payloads at odd byte offsets (repaired files) keep plain loads
+        const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
+        s = (ad & 3) ? 0u : (uint32_t)((ad >> 2) & 63);
+        const uint32_t *blk = reinterpret_cast<const uint32_t *>(p) - s;
+        const uint32_t tile0 = jj * TPW;
+#pragma unroll
+        for (int u = 0; u <= TPW; ++u) {
+            const uint64_t q = (uint64_t)(tile0 + u) * 64 + lane;   // block dword q = payload dword q - s
+            const bool want = valid && q >= s && q - s < a.ndw && (u < TPW || s != 0);
+            w[u] = want ? blk[q] : 0u;
+        }
+    };
+
+    if (item < g.nitems) issue(fs, j, cur, cur_valid, cur_s);
+    for (uint32_t k = 0; k < g.K && item < g.nitems; ++k) {
+        // position of the next step
+        uint64_t nfs_ = fs + g.step_fs;
+        uint32_t nj = j + g.step_j;
+        if (nj >= g.ipf) { nj -= g.ipf; ++nfs_; }
+        const uint64_t nitem = item + ws;
+        if (k + 1 < g.K && nitem < g.nitems) issue(nfs_, nj, nxt, nxt_valid, nxt_s);
+
+        float *obase = a.out + fs * E;
+        const uint32_t tile0 = j * TPW;
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const uint32_t tile = tile0 + u;
+            const bool live = tile < ntiles;                    // wave-uniform
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const uint32_t idx = (uint32_t)(BPS == 8 ? lane : p * 8 * BPS + src_lane0) + cur_s;
+                const uint32_t lo = (uint32_t)__shfl((int)cur[u], (int)(idx & 63));
+                uint32_t bits = lo;
+                if (cur_s) {                                    // uniform: aligned frames need one shuffle
+                    const uint32_t hi = (uint32_t)__shfl((int)cur[u + 1], (int)(idx & 63));
+                    bits = idx >= 64 ? hi : lo;
+                }
+                bits >>= (BPS == 8 ? 0 : shift);
+                const uint64_t e0 = (uint64_t)tile * EPT + 256 * p + 4 * lane;
+                if (!live || e0 >= E) continue;
+                bb_f4 v;
+                if (cur_valid) {
+                    v.x = lv.get(bits & CMASK);
+                    v.y = lv.get((bits >> BPS) & CMASK);
+                    v.z = lv.get((bits >> (2 * BPS)) & CMASK);
+                    v.w = lv.get((bits >> (3 * BPS)) & CMASK);
+                } else {
+                    v = fillv;
+                }
+                bb_store4<NT>(obase + e0, v);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u <= TPW; ++u) cur[u] = nxt[u];
+        cur_valid = nxt_valid;
+        cur_s = nxt_s;
+        fs = nfs_; j = nj; item = nitem;
+    }
+}

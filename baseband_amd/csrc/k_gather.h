@@ -29,7 +29,7 @@ struct bb_gather_args {
     float    fill_re, fill_im;
     int32_t  complex_data;
     int32_t  lrow;          // log2(nslot * chunk) when that is a power of two, else -1
-    int32_t  aligned;       // buf is 256-byte aligned: use aligned block loads
+    int32_t  aligned;       // use 256-byte aligned block loads
 };
 
 // WIDE: chunks of at least four floats (a float4 never straddles thread slots)
@@ -78,11 +78,12 @@ void k_decode_gather(bb_gather_args a)
         const uint32_t wsub = bb_wave() % wps;
         for (uint32_t s = bb_wave() / wps; s < a.nslot; s += BB_WAVES_PER_BLOCK / wps) {
             const int64_t so = a.src[f * a.nslot + s];
-            const uint64_t b0 = so >= 0 ? (uint64_t)so : 0;
-            // misalignment of the payload against 256-byte blocks, in dwords
-            // (payloads at odd byte offsets keep plain loads: sh = 0)
+            const uint8_t *pp = a.buf + (so >= 0 ? (uint64_t)so : 0);
+            const uintptr_t b0 = reinterpret_cast<uintptr_t>(pp);
+            // misalignment of the payload against 256-byte blocks of the
+            // address space, in dwords (odd byte addresses keep plain loads)
             const uint32_t sh = (a.aligned && !(b0 & 3)) ? (uint32_t)((b0 >> 2) & 63) : 0u;
-            const uint32_t *blk = reinterpret_cast<const uint32_t *>(a.buf + b0) - sh;
+            const uint32_t *blk = reinterpret_cast<const uint32_t *>(pp) - sh;
             for (uint32_t j = wsub * BB_WAVE + bb_lane(); j < gdw + 64; j += BB_WAVE * wps) {
                 const uint64_t q = dw0 + j;             // block dword q = payload dword q - sh
                 s_raw[s * pitch + j] = (so >= 0 && q >= sh && q - sh < a.ndw) ? blk[q] : 0u;

@@ -41,7 +41,10 @@ void k_vdif_scan(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
     }
     const unsigned long long bal = __ballot(ok);
     const int base = lane & ~7;
-    const bool frame_ok = ((bal >> base) & 0xffull) == 0xffull;
+    // a frame counts only when all of it lies inside the buffer: the decode
+    // kernels take payload offsets from these records without a length check
+    const bool frame_ok = ((bal >> base) & 0xffull) == 0xffull
+                          && off + (uint64_t)p.frame_nbytes <= nbytes;
     const uint32_t w1 = (uint32_t)__shfl((int)w, base + 1);
     const uint32_t w3 = (uint32_t)__shfl((int)w, base + 3);
     if (wi == 0 && frame < nframes) {

@@ -29,12 +29,20 @@ def require_gpu():
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
-def _stream():
+def _stream(t=None):
     """Handle of torch's current HIP stream on the current device.  The raw
     getter avoids ~8 us of Python in ``torch.cuda.current_stream()`` per call
-    (three calls per small read)."""
+    (three calls per small read).  `t` is a tensor the launch works on: the
+    library launches on the CURRENT device (its level tables are per device),
+    so data living on another GPU is refused instead of being addressed from
+    the wrong device's stream."""
+    dev = torch.cuda.current_device()
+    if t is not None and t.device.index is not None and t.device.index != dev:
+        raise RuntimeError(
+            "tensor lives on cuda:{} but the current device is cuda:{}: wrap the call in "
+            "`with torch.cuda.device({}):`".format(t.device.index, dev, t.device.index))
     if _raw_stream is not None:
-        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
+        return C.c_void_p(_raw_stream(dev))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -75,7 +83,7 @@ def vdif_scan(dbuf, nframes, frame_nbytes, header_nbytes, pattern, mask,
     p.frame_rate = frame_rate
     recs = torch.empty((nframes, 4), dtype=torch.int32, device=dbuf.device)
     check(lib.bb_vdif_scan(_ptr(dbuf), dbuf.numel(), C.byref(p), _ptr(recs),
-                           nframes, _stream()), 'bb_vdif_scan')
+                           nframes, _stream(dbuf)), 'bb_vdif_scan')
     return recs
 
 
@@ -102,7 +110,7 @@ def vdif_locate(dbuf, nbytes, frame_nbytes, header_nbytes, pattern, mask):
     offs = torch.empty(cap, dtype=torch.int64, device=dbuf.device)
     count = torch.zeros(1, dtype=torch.int64, device=dbuf.device)
     check(lib.bb_vdif_locate(_ptr(dbuf), nbytes, C.byref(p), _ptr(offs), cap,
-                             _ptr(count), _stream()), 'bb_vdif_locate')
+                             _ptr(count), _stream(dbuf)), 'bb_vdif_locate')
     n = min(int(count.item()), cap)
     return torch.sort(offs[:n]).values
 
@@ -114,7 +122,7 @@ def vdif_scan_at(dbuf, nbytes, offsets, frame_nbytes, header_nbytes, pattern,
     n = offsets.numel()
     recs = torch.empty((n, 4), dtype=torch.int32, device=dbuf.device)
     check(lib.bb_vdif_scan_at(_ptr(dbuf), nbytes, C.byref(p), _ptr(offsets), n,
-                              _ptr(recs), _stream()), 'bb_vdif_scan_at')
+                              _ptr(recs), _stream(dbuf)), 'bb_vdif_scan_at')
     return recs
 
 
@@ -127,7 +135,7 @@ def mark5b_scan(dbuf, nframes, ref_seconds, ref_frame_nr, frame_rate,
     p.frame_rate = frame_rate
     recs = torch.empty((nframes, 4), dtype=torch.int32, device=dbuf.device)
     check(lib.bb_mark5b_scan(_ptr(dbuf), dbuf.numel(), C.byref(p), _ptr(recs),
-                             nframes, _stream()), 'bb_mark5b_scan')
+                             nframes, _stream(dbuf)), 'bb_mark5b_scan')
     return recs
 
 
@@ -142,7 +150,7 @@ def _collect_offsets(launch, dbuf, cap, where):
 def mark5b_locate(dbuf, nbytes):
     """Byte-granular Mark 5B frame search -> sorted int64 device offsets."""
     return _collect_offsets(
-        lambda offs, cap, count: lib.bb_mark5b_locate(_ptr(dbuf), nbytes, offs, cap, count, _stream()),
+        lambda offs, cap, count: lib.bb_mark5b_locate(_ptr(dbuf), nbytes, offs, cap, count, _stream(dbuf)),
         dbuf, nbytes // 10016 + 16, 'bb_mark5b_locate')
 
 
@@ -153,7 +161,7 @@ def mark5b_scan_at(dbuf, nbytes, offsets, ref_seconds, ref_frame_nr, frame_rate)
     n = offsets.numel()
     recs = torch.empty((n, 4), dtype=torch.int32, device=dbuf.device)
     check(lib.bb_mark5b_scan_at(_ptr(dbuf), nbytes, C.byref(p), _ptr(offsets), n,
-                                _ptr(recs), _stream()), 'bb_mark5b_scan_at')
+                                _ptr(recs), _stream(dbuf)), 'bb_mark5b_scan_at')
     return recs
 
 
@@ -161,7 +169,7 @@ def mark4_locate(dbuf, nbytes, ntrack):
     """Byte-granular Mark 4 frame search -> sorted int64 device offsets."""
     return _collect_offsets(
         lambda offs, cap, count: lib.bb_mark4_locate(_ptr(dbuf), nbytes, ntrack, offs, cap, count,
-                                                     _stream()),
+                                                     _stream(dbuf)),
         dbuf, nbytes // (ntrack * 2500) + 16, 'bb_mark4_locate')
 
 
@@ -172,7 +180,7 @@ def mark4_scan_at(dbuf, nbytes, offsets, ntrack, ref_year, ref_qms, frame_qms):
     n = offsets.numel()
     recs = torch.empty((n, 4), dtype=torch.int32, device=dbuf.device)
     check(lib.bb_mark4_scan_at(_ptr(dbuf), nbytes, C.byref(p), _ptr(offsets), n,
-                               _ptr(recs), _stream()), 'bb_mark4_scan_at')
+                               _ptr(recs), _stream(dbuf)), 'bb_mark4_scan_at')
     return recs
 
 
@@ -180,7 +188,7 @@ def verify_records(recs, nrecs, first_index, recs_per_index, nstrict, nbad):
     """Add to the device counter `nbad` (int32[1]) the number of records that
     fail verification (see bb_verify_records)."""
     check(lib.bb_verify_records(_ptr(recs), nrecs, first_index, recs_per_index, nstrict,
-                                _ptr(nbad), _stream()), 'bb_verify_records')
+                                _ptr(nbad), _stream(recs)), 'bb_verify_records')
 
 
 def recs_fields(recs):
@@ -203,7 +211,7 @@ def thread_slot_map(thread_ids, device):
 def build_index(recs, nframes_out, nslot=1, thread_slot=None):
     src = torch.empty(nframes_out * nslot, dtype=torch.int64, device=recs.device)
     check(lib.bb_build_index(_ptr(recs), recs.shape[0], _ptr(thread_slot), nslot,
-                             _ptr(src), nframes_out, _stream()), 'bb_build_index')
+                             _ptr(src), nframes_out, _stream(recs)), 'bb_build_index')
     return src
 
 
@@ -227,7 +235,7 @@ def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
     if out is None:
         out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
     check(lib.bb_decode_frames(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
-                               C.byref(p), _ptr(out), out.numel(), _stream()),
+                               C.byref(p), _ptr(out), out.numel(), _stream(dbuf)),
           'bb_decode_frames')
     return out
 
@@ -242,7 +250,7 @@ def mark4_scan(dbuf, nframes, ntrack, ref_year, ref_qms, frame_qms,
     p.frame_qms = frame_qms
     recs = torch.empty((nframes, 4), dtype=torch.int32, device=dbuf.device)
     check(lib.bb_mark4_scan(_ptr(dbuf), dbuf.numel(), C.byref(p), _ptr(recs),
-                            nframes, _stream()), 'bb_mark4_scan')
+                            nframes, _stream(dbuf)), 'bb_mark4_scan')
     return recs
 
 
@@ -264,7 +272,7 @@ def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
         out = torch.empty(nframes * nwords * (ntrack // 2), dtype=torch.float32,
                           device=dbuf.device)
     check(lib.bb_decode_mark4(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
-                              C.byref(p), _ptr(out), out.numel(), _stream()),
+                              C.byref(p), _ptr(out), out.numel(), _stream(dbuf)),
           'bb_decode_mark4')
     return out
 
@@ -289,7 +297,7 @@ def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
     if out is None:
         out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
     check(lib.bb_decode_i8_tiled(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
-                                 C.byref(p), _ptr(out), out.numel(), _stream()),
+                                 C.byref(p), _ptr(out), out.numel(), _stream(dbuf)),
           'bb_decode_i8_tiled')
     return out
 
@@ -321,7 +329,7 @@ def encode_flat(values, coder, bps):
     out = torch.empty(values.numel() * bps // 8 if bps in (1, 2, 4, 8) else 0,
                       dtype=torch.uint8, device=values.device)
     check(lib.bb_encode_flat(_ptr(values), values.numel(), coder, bps, _ptr(out),
-                             out.numel(), _stream()), 'bb_encode_flat')
+                             out.numel(), _stream(values)), 'bb_encode_flat')
     return out[:nbytes]
 
 
@@ -335,7 +343,7 @@ def encode_mark4(values, ntrack, sign_bit, mag_bit):
     mb = (C.c_uint8 * 32)(*mag_bit)
     out = torch.empty(nwords * (ntrack // 8), dtype=torch.uint8, device=values.device)
     check(lib.bb_encode_mark4(_ptr(values), nwords, ntrack, sb, mb, _ptr(out),
-                              out.numel(), _stream()), 'bb_encode_mark4')
+                              out.numel(), _stream(values)), 'bb_encode_mark4')
     return out
 
 

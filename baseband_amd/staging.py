@@ -104,6 +104,11 @@ class WindowPipeline:
             self._pinned[b] = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True)
             # +256 slack: kernels may read whole dwords at the tail
             self._dev[b] = torch.empty(self.cap + 256, dtype=torch.uint8, device=self.device)
+            # the caching allocator may hand back a block whose previous owner
+            # still has kernels queued on the compute stream: the side-stream
+            # copy into it must come after them
+            if self._copy_stream is not None:
+                self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         return self._pinned[b], self._dev[b]
 
     def release(self):
@@ -122,6 +127,8 @@ class WindowPipeline:
         main = torch.cuda.current_stream(self.device)
         for i, (lo, hi) in enumerate(ranges):
             n = hi - lo
+            if n < 0:
+                raise ValueError("window ends before it starts ({} > {})".format(lo, hi))
             if n > self.cap:
                 raise ValueError("window larger than staging buffer")
             b = self._count % self.nbuf         # rotation continues across run() calls
@@ -161,6 +168,9 @@ def upload(image, device='cuda', chunk_bytes=64 << 20):
             dev[:n].copy_(torch.from_numpy(np.array(image[:n], dtype=np.uint8, copy=True)))
         return dev
     stream = torch.cuda.Stream(device=device)
+    # `dev` may be a recycled block with work of its previous owner still
+    # queued on the compute stream (and the tail was just zeroed there)
+    stream.wait_stream(torch.cuda.current_stream(device))
     pinned = [torch.empty(min(chunk_bytes, max(n, 1)), dtype=torch.uint8, pin_memory=True)
               for _ in range(2)]
     events = [None, None]

@@ -4,22 +4,44 @@
 One step = one pass of the hot path (header scan -> index build -> packed
 sample decode) over one synthetic file image that is already resident in HBM:
 BASELINE.json configs[1], "synthetic 8 GiB single-thread VDIF, 2-bit real,
-1 channel, EDV 0" (8032-byte frames, 32000 samples per frame).  With N > 1
-GPUs every rank decodes its own time slab of the same size (weak scaling, no
-data-path collective: frames are independent).
+1 channel, EDV 0" (8032-byte frames, 32000 samples per frame).
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events
-around the dominant kernel (k_decode_flat) on the launching stream;
-`cpu_baseline` times the NumPy restatement of the reference's per-frame read
-loop (oracle/, "port") on one host core over a bounded sample -- plus, as extra
-keys, the same loop on all cores (forked workers, before the GPU is touched)
-and the bare LUT take as the NumPy ceiling.
+``python bench.py --gpus N``: one process per GPU.  Under
+``python -m torch.distributed.run`` (the driver's way) the ranks come from the
+environment; started plainly with N > 1 this process -- before it touches the
+GPU -- starts ``torch.distributed.run`` with N workers itself and passes their
+output through.  Every rank decodes its own time slab of the same size (weak
+scaling, no data-path collective: frames are independent, SURVEY.md section
+8e); rank 0 prints ONE JSON line.
+
+Besides the contract's keys the line carries
+  roofline      dominant kernel (named by the library: bb_last_kernel) timed
+                with HIP events on the launching stream; `traffic` = HBM bytes
+                per launch from two rocprofv3 --pmc child passes of this same
+                script (run before this process touches the GPU), or the
+                committed profiles/traffic_latest.json when that fails
+  cpu_baseline  the NumPy restatement of the reference's per-frame loop
+                (oracle/, kind "port") on a bounded sample, rank 0 at N = 1,
+                with the calibration against the real reference
+                (tests/golden/cpu_calibration.json)
+  api_read      the same 8 GiB image through the drop-in API:
+                ``vdif.open(<device tensor>, 'rs').read(out=out)``
+  cfg3          BASELINE configs[2] (8-thread 2-bit complex 16-channel VDIF):
+                rank 0 scans the whole file and builds the frame index, ONE
+                broadcast (RCCL) replicates it, every rank decodes its slab
+  other_configs Mark 5B / Mark 4 / GUPPI / DADA / 8-thread real VDIF kernels
+                on 4 GiB inputs (N = 1 only)
 """
 import argparse
-import ctypes as C
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,39 +56,50 @@ HEADER_NBYTES = 32
 PAYLOAD_NBYTES = 8000
 SPF = 32000                     # samples per frame (2-bit, real, 1 channel)
 FRAME_RATE = 1000               # frames per second -> 32 MHz sample rate
+CFG3_THREADS = 8
+CFG3_NCHAN = 16
+CFG3_ORDER = (1, 3, 5, 7, 0, 2, 4, 6)       # thread id at disk position p (sample.vdif's order)
+CFG3_SET_RATE = 1000
 
 
-def make_file_image_on_device(nframes, seed, first_frame, device):
-    """cfg2 file image born in HBM: uniform random payload bytes + EDV-0
-    headers (seconds / frame_nr incrementing).  Same header words as
-    baseband_amd.synth / the reference writer would produce."""
+def _s32(x):
+    return x - (1 << 32) if x >= (1 << 31) else x
+
+
+def make_file_image_on_device(nsets, seed, first_set, device, nthread=1, nchan=1,
+                              complex_data=False, order=(0,), set_rate=FRAME_RATE):
+    """VDIF file image born in HBM: uniform random payload bytes + EDV-0
+    headers (seconds / frame_nr from the frame-set index, thread ids in
+    `order`).  Same header words as baseband_amd.synth / the reference writer
+    would produce.  Returns (uint8 tensor, header0)."""
     from baseband_amd.vdif.header import VDIFHeader
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     words_per_frame = FRAME_NBYTES // 4
+    nframes = nsets * nthread
     img = torch.empty(nframes * words_per_frame, dtype=torch.int32, device=device)
     step = 1 << 28
     for lo in range(0, img.numel(), step):          # bounded temporaries
         hi = min(img.numel(), lo + step)
         img[lo:hi] = torch.randint(-2 ** 31, 2 ** 31 - 1, (hi - lo,), generator=g,
                                    device=device, dtype=torch.int64).to(torch.int32)
-    h0 = VDIFHeader.fromvalues(edv=0, bps=2, nchan=1, complex_data=False,
+    h0 = VDIFHeader.fromvalues(edv=0, bps=2, nchan=nchan, complex_data=complex_data,
                                payload_nbytes=PAYLOAD_NBYTES, station='AA',
+                               thread_id=order[0],
                                time=np.datetime64('2020-01-01T00:00:00'))
     w = [int(x) for x in h0.words]
-    v = img.view(nframes, words_per_frame)
-    idx = torch.arange(first_frame, first_frame + nframes, device=device, dtype=torch.int64)
-    v[:, 0] = (w[0] + idx // FRAME_RATE).to(torch.int32)
-    v[:, 1] = ((w[1] & 0xff000000) + idx % FRAME_RATE).to(torch.int32)
-
-    def s32(x):
-        return x - (1 << 32) if x >= (1 << 31) else x
-    v[:, 2] = s32(w[2])
-    v[:, 3] = s32(w[3])
-    v[:, 4:8] = 0
+    v = img.view(nsets, nthread, words_per_frame)
+    idx = torch.arange(first_set, first_set + nsets, device=device, dtype=torch.int64)[:, None]
+    v[:, :, 0] = (w[0] + idx // set_rate).to(torch.int32)
+    v[:, :, 1] = ((w[1] & 0xff000000) + idx % set_rate).to(torch.int32)
+    v[:, :, 2] = _s32(w[2])
+    tid = torch.tensor(list(order), device=device, dtype=torch.int64)[None, :]
+    v[:, :, 3] = ((w[3] & ~(0x3ff << 16)) | (tid << 16)).to(torch.int32) if nthread > 1 else _s32(w[3])
+    v[:, :, 4:8] = 0
     return img.view(torch.uint8), h0
 
 
+# ---------------------------------------------------------------- CPU baseline
 def _cpu_worker(args):
     """One process of the all-cores CPU leg: its own slab of cfg2 frames through
     the reference-as-written loop for about `seconds`."""
@@ -110,6 +143,23 @@ def cpu_baseline(target_seconds=12.0):
                         "oracle/bb_oracle_np.vdif_read (per-frame NumPy LUT take loop)"
                         .format(reps, nframes, image.size / 2 ** 20),
               "host": "{} logical cores; numpy {}".format(os.cpu_count(), np.__version__)}
+    # how the port relates to the real reference (measured in the development
+    # container, where the reference can be imported: tools/calibrate_cpu_baseline.py)
+    try:
+        with open(os.path.join(ROOT, 'tests', 'golden', 'cpu_calibration.json')) as f:
+            cal = json.load(f)
+        ratio = float(cal["ratio_port_over_reference"])
+        result["calibration"] = {
+            "ratio_port_over_reference": ratio,
+            "ratio_port_over_reference_verify_false": cal.get("ratio_port_over_reference_verify_false"),
+            "reference_as_written_estimate_Msps": round(msps / ratio, 2),
+            "measured_on": cal.get("host"),
+            "reference_Msps_there": cal["reference"]["verify_true_Msps"],
+            "port_Msps_there": cal["port"]["Msps"],
+            "source": "tests/golden/cpu_calibration.json (tools/calibrate_cpu_baseline.py: real "
+                      "baseband.vdif.open().read() vs the port on the same seeded file, outputs bit-identical)"}
+    except Exception as exc:
+        result["calibration"] = {"error": repr(exc)}
     # bare take: every payload byte of the sample through the 256 x 4 table in
     # one call (no headers, no per-frame Python)
     try:
@@ -147,25 +197,427 @@ def cpu_baseline(target_seconds=12.0):
     return result
 
 
+# ------------------------------------------------------------------ HBM traffic
+def _git_commit():
+    try:
+        return subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'],
+                              capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def live_traffic(gib, timeout=240):
+    """HBM bytes per launch of the decode kernel from the memory-side counters:
+    two child runs of THIS script under ``rocprofv3 --pmc`` (FETCH_SIZE and
+    WRITE_SIZE cannot share a pass; MI355X_MICROARCH.md, rocprofv3 PMC slots),
+    program directly after ``--``.  Called before this process touches the
+    GPU.  FETCH_SIZE is doubled (gfx950 tallies 128-byte requests at 64 bytes,
+    same guide, HBM section).  Returns a dict or raises."""
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    tmp = tempfile.mkdtemp(prefix='bbpmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    vals = {}
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, '--pmc', counter, '-d', d, '-o', 'c', '--output-format', 'csv', '--',
+                   sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child',
+                   '--steps', '1', '--warmup', '1', '--gib', repr(gib)]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError("rocprofv3 --pmc {} failed (rc {}): {}".format(
+                    counter, r.returncode, (r.stderr or '')[-300:]))
+            got = []
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if 'k_decode' in row['Kernel_Name'] and row['Counter_Name'] == counter:
+                        got.append(float(row['Counter_Value']))
+            if not got:
+                raise RuntimeError("no k_decode rows for " + counter)
+            vals[counter] = sum(got) / len(got) * 1024.0            # counters are in KiB
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"source": "live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of this run",
+            "fetch_bytes_raw": vals['FETCH_SIZE'], "write_bytes": vals['WRITE_SIZE'],
+            "fetch_bytes_corrected": 2 * vals['FETCH_SIZE'],
+            "correction": "FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section)",
+            "hbm_bytes_per_launch": 2 * vals['FETCH_SIZE'] + vals['WRITE_SIZE'],
+            "commit": _git_commit(), "date": time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime())}
+
+
+def file_traffic():
+    with open(os.path.join(ROOT, 'profiles', 'traffic_latest.json')) as f:
+        d = json.load(f)
+    d["source"] = "committed file (not from this run): " + str(d.get("source"))
+    return d
+
+
+# --------------------------------------------------------------------- helpers
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` without a launcher: start N workers with
+    torch.distributed.run (this process has not touched the GPU) and pass
+    their output through."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py')] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.run(cmd, env=env).returncode
+
+
+def timed_launches(fn, reps):
+    """Median and mean ms of `fn` (one launch) by HIP events on torch's current
+    stream, which is the stream the library launches on (kernels._stream)."""
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts)), float(np.mean(ts))
+
+
+def expand_2bit(raw, lev):
+    """Host re-expansion of 2-bit VDIF payload bytes from the library's own
+    level table (4 samples per byte, least significant pair first): the
+    in-bench sanity spot check, NOT the parity proof (that lives in tests/)."""
+    return lev[(raw[:, None] >> np.array([0, 2, 4, 6], np.uint8)) & 3].reshape(-1)
+
+
+# ------------------------------------------------------------------ dry run
+def dry_run(args, rank, world):
+    """CPU rehearsal of the multi-rank plumbing (tests/test_bench_cli.py): gloo
+    rendezvous, slab partition, the index broadcast, barrier + max-over-ranks
+    timing, one JSON line from rank 0.  Nothing is decoded and nothing is
+    measured: ``value`` is null and ``dry_run`` is true."""
+    import torch.distributed as dist
+    from baseband_amd.parallel import frame_slab, broadcast_frame_index
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+    nsets = 1000 * world
+    lo, hi = frame_slab(nsets, rank, world)
+    src = torch.arange(nsets * CFG3_THREADS, dtype=torch.int64) * FRAME_NBYTES + HEADER_NBYTES \
+        if rank == 0 else None
+    t0 = time.perf_counter()
+    if world > 1:
+        src = broadcast_frame_index(src, nsets * CFG3_THREADS, src_rank=0)
+    coll_ms = (time.perf_counter() - t0) * 1e3
+    ok = bool((src[lo * CFG3_THREADS:hi * CFG3_THREADS]
+               == torch.arange(lo * CFG3_THREADS, hi * CFG3_THREADS) * FRAME_NBYTES + HEADER_NBYTES).all())
+    seen = torch.ones(1)
+    elapsed = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(seen)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "decoded Msamples/s, VDIF 2-bit 1-thread (scan + index + decode, input resident in HBM)",
+            "value": None, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "float32", "data": "synthetic",
+            "dry_run": True, "ranks_seen": int(seen.item()), "slab_of_rank0": [lo, hi],
+            "max_over_ranks_s": float(elapsed.item()),
+            "cfg3": {"collective": {"bytes": nsets * CFG3_THREADS * 8, "ms": round(coll_ms, 3),
+                                    "ranks_seen": int(seen.item()), "backend": "gloo"},
+                     "index_ok": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------- legs
+def leg_cfg3(args, rank, world, device, dist, out):
+    """BASELINE configs[2]: 8-thread 2-bit complex 16-channel VDIF sharded by
+    time slab.  Rank 0 holds the whole file image, scans every header and
+    builds the dense (frame set, thread) -> payload offset index; ONE
+    broadcast replicates it (RCCL over xGMI under 'nccl'); every rank rebases
+    its slab of the index and decodes its own bytes into its own HBM."""
+    from baseband_amd import kernels, _lib
+    from baseband_amd.parallel import frame_slab, broadcast_frame_index, local_index
+    set_nbytes = FRAME_NBYTES * CFG3_THREADS
+    nsets = int(args.cfg3_gib * 2 ** 30) // set_nbytes
+    nsets_world = nsets * world
+    lo, hi = frame_slab(nsets_world, rank, world)
+    slab, h0 = make_file_image_on_device(nsets, 777 + rank, lo, device, nthread=CFG3_THREADS,
+                                         nchan=CFG3_NCHAN, complex_data=True, order=CFG3_ORDER,
+                                         set_rate=CFG3_SET_RATE)
+    if rank == 0:
+        parts = [slab] + [make_file_image_on_device(
+            nsets, 777 + r, frame_slab(nsets_world, r, world)[0], device, nthread=CFG3_THREADS,
+            nchan=CFG3_NCHAN, complex_data=True, order=CFG3_ORDER, set_rate=CFG3_SET_RATE)[0]
+            for r in range(1, world)]
+        whole = torch.cat(parts) if world > 1 else slab
+        del parts
+    pattern, mask = h0.invariant_pattern()
+    thread_slot = kernels.thread_slot_map(list(range(CFG3_THREADS)), device)
+    chunk = CFG3_NCHAN * 2
+    nelem = nsets * CFG3_THREADS * PAYLOAD_NBYTES * 4
+    o = out[:nelem]
+    nentries = nsets_world * CFG3_THREADS
+    coll = []
+    dec = []
+    kname = [None]
+
+    def step(k=None):
+        src = None
+        if rank == 0:
+            recs = kernels.vdif_scan(whole, nsets_world * CFG3_THREADS, FRAME_NBYTES, HEADER_NBYTES,
+                                     pattern, mask, h0['seconds'], h0['frame_nr'], CFG3_SET_RATE)
+            src = kernels.build_index(recs, nsets_world, CFG3_THREADS, thread_slot)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        if world > 1:
+            src = broadcast_frame_index(src, nentries, src_rank=0, device=device)
+        e[1].record()
+        local, byte_lo, byte_hi = local_index(src, lo, hi, CFG3_THREADS, PAYLOAD_NBYTES)
+        assert byte_lo >= lo * set_nbytes and byte_hi <= hi * set_nbytes
+        local = local + (byte_lo - lo * set_nbytes)             # offsets into this rank's slab image
+        e[2].record()
+        kernels.decode_frames(slab, nsets, PAYLOAD_NBYTES, _lib.CODER_VDIF, 2, chunk=chunk,
+                              nslot=CFG3_THREADS, src=local, complex_data=True, out=o)
+        e[3].record()
+        kname[0] = _lib.last_kernel()
+        if k is not None:
+            coll.append((e[0], e[1]))
+            dec.append((e[2], e[3]))
+
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    seen = torch.ones(1, device=device)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.all_reduce(seen)
+    # sanity: set 5 of this slab, every thread, against a host re-expansion
+    lev = _lib.get_levels(_lib.CODER_VDIF, 2)
+    ok = True
+    spf = PAYLOAD_NBYTES * 4 // (2 * CFG3_NCHAN)                 # complex samples per frame
+    got = o.view(nsets, spf, CFG3_THREADS, chunk)[5].cpu().numpy()
+    for p, t in enumerate(CFG3_ORDER):
+        fo = (5 * CFG3_THREADS + p) * FRAME_NBYTES
+        raw = slab[fo + HEADER_NBYTES:fo + FRAME_NBYTES].cpu().numpy()
+        want = expand_2bit(raw, lev).reshape(spf, chunk)
+        ok &= bool(np.array_equal(got[:, t].view(np.uint32), want.view(np.uint32)))
+    coll_ms = float(np.mean([a.elapsed_time(b) for a, b in coll]))
+    dec_ms = float(np.mean([a.elapsed_time(b) for a, b in dec]))
+    alg = nsets * CFG3_THREADS * (FRAME_NBYTES + PAYLOAD_NBYTES * 16)
+    achieved = alg / (dec_ms * 1e-3) / 1e9
+    ncomplex = nsets * CFG3_THREADS * PAYLOAD_NBYTES * 2        # complex samples x threads x channels
+    return {
+        "workload": "cfg3: synthetic {:.3f} GiB per GPU 8-thread VDIF, 2-bit complex, 16 channels, "
+                    "EDV 0, thread order on disk {}".format(nsets * set_nbytes / 2 ** 30, list(CFG3_ORDER)),
+        "value": round(ncomplex * world * args.steps / elapsed / 1e6, 1),
+        "unit": "M complex samples/s (threads x channels counted)",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "step": "rank 0: bb_vdif_scan + bb_build_index over the whole file; broadcast; "
+                "every rank: rebase (parallel.local_index) + bb_decode_frames of its slab",
+        "collective": {"op": "broadcast of the dense frame index", "bytes": nentries * 8,
+                       "ms": round(coll_ms, 4), "ranks_seen": int(seen.item()),
+                       "backend": "nccl (RCCL)" if world > 1 else "none (world size 1)"},
+        "roofline": {"bound": "hbm", "kernel": kname[0], "achieved": round(achieved, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "kernel_ms_avg": round(dec_ms, 4), "algorithmic_bytes_per_launch": alg},
+        "sanity_spot_check": ok}
+
+
+def leg_api_read(args, image, out, kern_ms):
+    """The headline image through the drop-in API: a stream reader opened on
+    the device tensor, ``read(out=out)`` -- one scan / index / decode launch for
+    the whole file (base/base.py:919-969 semantics; resident.py)."""
+    from baseband_amd import vdif, _lib
+    t_open = time.perf_counter()
+    fh = vdif.open(image, 'rs', sample_rate=float(SPF * FRAME_RATE))
+    open_ms = (time.perf_counter() - t_open) * 1e3
+    assert fh.shape == (out.numel(),), (fh.shape, out.numel())
+    fh.read(out=out)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(args.steps):
+        fh.seek(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fh.read(out=out)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    kname = _lib.last_kernel()
+    verify = fh.verify
+    fh.close()
+    ms = float(np.mean(ts))
+    return {"call": "baseband_amd.vdif.open(<uint8 device tensor>, 'rs', sample_rate=32e6).read(out=<float32 device tensor>)",
+            "ms": round(ms, 4), "ms_min": round(min(ts), 4), "open_ms": round(open_ms, 2),
+            "value": round(out.numel() / ms / 1e3, 1), "unit": "Msamples/s",
+            "verify": verify, "kernel": kname,
+            "ms_over_kernel_leg": round(ms / kern_ms, 4),
+            "timing": "host wall clock around read() incl. the verification sync, mean of {} calls".format(args.steps)}
+
+
+def leg_other_configs(device, out, gib=4.0, reps=5):
+    """Kernel-level figures for the other BASELINE configurations on `gib` of
+    random input each: (ms, algorithmic GB/s, fraction of 8 TB/s, kernel as
+    named by the library)."""
+    from baseband_amd import kernels, _lib
+    from baseband_amd.mark4._bitmaps import BITMAPS
+    nbytes = int(gib * 2 ** 30)
+    g = torch.Generator(device=device)
+    g.manual_seed(4242)
+    buf = torch.randint(-2 ** 31, 2 ** 31 - 1, (nbytes // 4 + 1024,), generator=g, device=device,
+                        dtype=torch.int64).to(torch.int32).view(torch.uint8)
+    res = []
+
+    def add(name, fn, bytes_in, bytes_out, units, unit_name):
+        med, mean = timed_launches(fn, reps)
+        gbs = (bytes_in + bytes_out) / mean / 1e6
+        res.append({"case": name, "kernel": _lib.last_kernel(), "ms": round(mean, 4),
+                    "ms_median": round(med, 4), "algorithmic_GBps": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_in": bytes_in, "bytes_out": bytes_out,
+                    "M{}_per_s".format(unit_name): round(units / mean / 1e3, 1)})
+
+    # cfg0 layout: 8 threads x 1 channel 2-bit real, 5032-byte frames (sample.vdif)
+    fn_, pn, nth = 5032, 5000, 8
+    nsets = nbytes // (fn_ * nth)
+    perm = torch.tensor([4, 0, 5, 1, 6, 2, 7, 3], device=device)
+    pos = torch.arange(nsets, device=device, dtype=torch.int64)[:, None] * nth + perm[None, :]
+    src = (pos * fn_ + 32).reshape(-1).contiguous()
+    o = out[:nsets * nth * pn * 4]
+    add("VDIF 8 threads x 1 channel 2-bit real (sample.vdif layout)",
+        lambda: kernels.decode_frames(buf, nsets, pn, _lib.CODER_VDIF, 2, chunk=1, nslot=nth, src=src, out=o),
+        nsets * nth * fn_, o.numel() * 4, o.numel(), "samples")
+    # cfg4a: Mark 5B 16 channels 2-bit
+    nfr = nbytes // 10016
+    o = out[:nfr * 40000]
+    add("Mark 5B 16 channels 2-bit",
+        lambda: kernels.decode_frames(buf, nfr, 10000, _lib.CODER_MARK5B, 2, chunk=16, src0=16,
+                                      src_stride=10016, out=o),
+        nfr * 10016, o.numel() * 4, o.numel(), "samples")
+    # cfg4b: Mark 4 64 tracks fanout 4
+    m = BITMAPS[(8, 2, 4)]
+    nfr = nbytes // 160000
+    o = out[:nfr * 20000 * 32]
+    add("Mark 4 64 tracks fanout 4 (8 channels 2-bit)",
+        lambda: kernels.decode_mark4(buf, nfr, 64, 20000, m['sign_bit'], m['mag_bit'], fill_words=160,
+                                     src0=0, src_stride=160000, out=o),
+        nfr * 160000, o.numel() * 4, o.numel(), "samples")
+    # cfg5a: GUPPI 8-bit 2 pol complex 64 channels, channels first, 128 MiB blocks
+    npol, nchan, blk = 2, 64, 128 << 20
+    T = blk // (npol * nchan * 2)
+    nfr = max(1, nbytes // blk)
+    nb = nfr * T * npol * nchan * 2
+    o = out[:nb]
+    add("GUPPI 8-bit 2 pol 64 channels, channels first, OVERLAP 0",
+        lambda: kernels.decode_i8_tiled(buf, nfr, _lib.LAYOUT_GUPPI_CF, npol, nchan, T, 0, T, src0=0,
+                                        src_stride=blk, out=o),
+        nb, nb * 4, nb // 2, "complex_samples")
+    add("GUPPI 8-bit 2 pol 64 channels, time first",
+        lambda: kernels.decode_i8_tiled(buf, nfr, _lib.LAYOUT_GUPPI_TF, npol, nchan, T, 0, T, src0=0,
+                                        src_stride=blk, out=o),
+        nb, nb * 4, nb // 2, "complex_samples")
+    # cfg5b: DADA 8-bit 2 pol complex (flat int8) and MKBF heaps
+    nb = nbytes // 4 * 4
+    o = out[:nb]
+    add("DADA 8-bit 2 pol complex (flat int8 -> float32)",
+        lambda: kernels.decode_frames(buf, 1, nb, _lib.CODER_INT, 8, src0=0, out=o),
+        nb, nb * 4, nb // 2, "complex_samples")
+    nheap_t = 64
+    Tm = 256 * nheap_t
+    blkm = Tm * npol * nchan * 2
+    nfr = max(1, nbytes // blkm)
+    nb = nfr * blkm
+    o = out[:nb]
+    add("DADA MKBF heaps 2 pol 64 channels (256-sample heaps)",
+        lambda: kernels.decode_i8_tiled(buf, nfr, _lib.LAYOUT_MKBF, npol, nchan, Tm, 0, Tm, src0=0,
+                                        src_stride=blkm, out=o),
+        nb, nb * 4, nb // 2, "complex_samples")
+    return res
+
+
+# ------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--gib', type=float, default=8.0, help="file image size per GPU")
+    ap.add_argument('--cfg3-gib', type=float, default=2.0, help="cfg3 leg: file bytes per GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--traffic', choices=('live', 'file', 'none'), default='live')
+    ap.add_argument('--no-extra-legs', action='store_true',
+                    help="skip api_read / cfg3 / other_configs (headline only)")
+    ap.add_argument('--pmc-child', action='store_true',
+                    help="internal: headline kernel only, no JSON extras (run under rocprofv3 --pmc)")
+    ap.add_argument('--dry-run', action='store_true',
+                    help="CPU rehearsal of the multi-rank plumbing with gloo (no GPU, no measurement)")
     args = ap.parse_args()
+    if args.pmc_child:
+        args.no_cpu_baseline, args.no_extra_legs, args.traffic = True, True, 'none'
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # not under a launcher: become one (nothing here has touched the GPU)
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    # the CPU leg runs first: it forks workers, which must happen before this
-    # process initialises the GPU
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus {} but WORLD_SIZE is {}".format(args.gpus, world))
+    # host-side legs run first: they fork / start child processes, which must
+    # happen before this process initialises the GPU
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and torch.cuda.device_count() > 0:
-        cpu = cpu_baseline()
+    traffic_detail = None
+    have_gpu = torch.cuda.device_count() > 0
+    if rank == 0 and world == 1 and have_gpu:
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        if abs(args.gib - 8.0) < 1e-9 and args.traffic != 'none':
+            if args.traffic == 'live':
+                try:
+                    traffic_detail = live_traffic(args.gib)
+                except Exception as exc:
+                    traffic_detail = {"live_error": repr(exc)[:400]}
+            if traffic_detail is None or "hbm_bytes_per_launch" not in traffic_detail:
+                try:
+                    err = (traffic_detail or {}).get("live_error")
+                    traffic_detail = file_traffic()
+                    if err:
+                        traffic_detail["live_error"] = err
+                except Exception:
+                    pass
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback).")
+    if world > torch.cuda.device_count():
+        raise SystemExit("bench.py: {} ranks but only {} GPUs visible".format(world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
@@ -207,17 +659,18 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    kernel_name = _lib.last_kernel()
 
     # sanity spot check (outside the timed region; NOT the parity proof, which
     # lives in tests/): three frames re-expanded on the host from the library's
-    # own level table, 4 samples per byte, least significant pair first
+    # own level table
     lev = _lib.get_levels(_lib.CODER_VDIF, 2)
     ok = True
-    for f in (0, nframes // 3, nframes - 1):
-        raw = image[f * FRAME_NBYTES + HEADER_NBYTES:(f + 1) * FRAME_NBYTES].cpu().numpy()
-        got = out[f * SPF:(f + 1) * SPF].cpu().numpy()
-        want = lev[(raw[:, None] >> np.array([0, 2, 4, 6], np.uint8)) & 3].reshape(-1)
-        ok &= bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+    if args.warmup:
+        for f in (0, nframes // 3, nframes - 1):
+            raw = image[f * FRAME_NBYTES + HEADER_NBYTES:(f + 1) * FRAME_NBYTES].cpu().numpy()
+            got = out[f * SPF:(f + 1) * SPF].cpu().numpy()
+            ok &= bool(np.array_equal(got.view(np.uint32), expand_2bit(raw, lev).view(np.uint32)))
 
     if dist is not None:
         dist.barrier()
@@ -229,29 +682,26 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in ev]
+    kern_avg = sum(kern_ms) / len(kern_ms)
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        allk = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(allk, torch.tensor([kern_avg], dtype=torch.float64, device=device))
+        per_rank = [float(x.item()) for x in allk]
+    if args.pmc_child:
+        return
 
-    kern_ms = [a.elapsed_time(b) for a, b in ev]
-    kern_avg = sum(kern_ms) / len(kern_ms)
     achieved = alg_bytes / (kern_avg * 1e-3) / 1e9
     total_samples = nframes * SPF * world * args.steps
     value = total_samples / elapsed / 1e6
-
-    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE, separate runs of this same command; tools/summarize_prof.py).
-    # Only meaningful for the default 8 GiB workload the counters were taken on.
-    traffic, traffic_detail = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_latest.json')
-    if os.path.exists(tpath) and abs(args.gib - 8.0) < 1e-9:
-        try:
-            with open(tpath) as f:
-                traffic_detail = json.load(f)
-            traffic = traffic_detail["hbm_bytes_per_launch"]
-        except Exception:
-            traffic, traffic_detail = None, None
+    traffic = None
+    if traffic_detail and "hbm_bytes_per_launch" in traffic_detail:
+        traffic = traffic_detail["hbm_bytes_per_launch"]
+        traffic_detail["traffic_over_algorithmic"] = round(traffic / alg_bytes, 4)
 
     line = {
         "metric": "decoded Msamples/s, VDIF 2-bit 1-thread (scan + index + decode, input resident in HBM)",
@@ -259,15 +709,16 @@ def main():
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
+        "dtype": "float32", "data": "synthetic",
         "config": {"workload": "cfg2: synthetic {:.3f} GiB per GPU single-thread VDIF, "
                                "2-bit real, 1 channel, EDV 0, 8032-byte frames"
                                .format(bytes_in / 2 ** 30),
                    "frames_per_gpu": nframes, "bytes_in_per_gpu": bytes_in,
                    "bytes_out_per_gpu": bytes_out,
-                   "output": "full-size float32 tensor kept in HBM (no slab recycling)",
+                   "input": "packed 2-bit codes (uint8 file image)", "output": "float32 samples: "
+                   "full-size tensor kept in HBM (no slab recycling)",
                    "sharding": "time slabs, one per rank, no collective"},
-        "roofline": {"bound": "hbm", "kernel": "k_decode_flat_aln<2, 0, true, 2, 16>",
+        "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "kernel_ms_avg": round(kern_avg, 4),
@@ -275,6 +726,29 @@ def main():
                      "traffic": traffic, "traffic_detail": traffic_detail},
         "sanity_spot_check": ok,
     }
+    if per_rank is not None:
+        line["per_rank"] = {"kernel_ms_avg": [round(x, 4) for x in per_rank],
+                            "roofline_frac": [round(alg_bytes / (x * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                              for x in per_rank]}
+    if not args.no_extra_legs:
+        # (each leg is fenced: a failure is reported in its slot, the headline stands)
+        if rank == 0:
+            try:
+                line["api_read"] = leg_api_read(args, image, out, kern_avg)
+            except Exception as exc:
+                line["api_read"] = {"error": repr(exc)[:500]}
+        del image
+        try:
+            line["cfg3"] = leg_cfg3(args, rank, world, device, dist, out)
+        except Exception as exc:
+            if world > 1:
+                raise                       # ranks must not diverge around a collective
+            line["cfg3"] = {"error": repr(exc)[:500]}
+        if rank == 0 and world == 1:
+            try:
+                line["other_configs"] = leg_other_configs(device, out)
+            except Exception as exc:
+                line["other_configs"] = [{"error": repr(exc)[:500]}]
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -88,6 +88,14 @@ int         bb_abi_version(void);
 const char *bb_strerror(int code);
 /* hipError_t of the last failing HIP call on this host thread (0 if none) */
 int         bb_last_hip_error(void);
+/* Name, template arguments and grid of the decode kernel the calling thread
+ * launched last through bb_decode_frames / bb_decode_mark4 /
+ * bb_decode_i8_tiled ("" before the first launch).  The dispatcher picks
+ * kernels by geometry; benchmarks and profiles report what actually ran
+ * instead of assuming it.  The string is thread-local and valid until the
+ * thread's next decode call.  (No reference counterpart: the reference's
+ * decoders are Python callables, base/payload.py:314-315.) */
+const char *bb_last_kernel(void);
 /* Upload the constant level tables to the current device.  Called lazily by
  * every launch entry point; exported so hosts can front-load it.  Fails with
  * BB_EIO when no usable gfx950 device/code object is present: there is no
@@ -406,6 +414,8 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* the same bound for 8-bit data in the aligned flat kernel (1..32; above 16 selects the 32-tile instantiation) */
 #define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */
 #define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
+#define BB_TUNE_FRONT_GROUP 14        /* k_decode_flat_front (variants 6-9): workgroups per group = width of the write front (default 2048) */
+#define BB_TUNE_FRONT_STEPS 15        /* k_decode_flat_front: steps a group sweeps its region in (default 16) */
 int bb_tune(int knob, int value);
 
 /* Measurement aid: when d_times is not NULL, the contiguous-output flat decode

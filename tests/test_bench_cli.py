@@ -1,0 +1,48 @@
+"""bench.py's multi-rank plumbing on the CPU: ``python bench.py --gpus 2
+--dry-run`` must start two ranks itself (no launcher, no WORLD_SIZE in the
+environment), rendezvous over gloo on 127.0.0.1, broadcast the frame index and
+print ONE JSON line with ``n_gpus == 2`` from rank 0.  Nothing is decoded in
+this mode (no GPU here); the line says so (``dry_run``, ``value`` null)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def _run(argv, env_extra=None):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, env=env,
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    return r, lines
+
+
+def test_gpus_2_spawns_two_ranks_and_prints_one_line():
+    r, lines = _run(['--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2
+    assert line['dry_run'] is True and line['value'] is None
+    assert line['steps'] == 3 and line['warmup'] == 1
+    assert line['scaling'] == 'weak' and line['dtype'] == 'float32'
+    coll = line['cfg3']['collective']
+    assert coll['ranks_seen'] == 2 and coll['bytes'] == 2 * 1000 * 8 * 8
+    assert line['cfg3']['index_ok'] is True
+    assert line['slab_of_rank0'] == [0, 1000]
+    assert abs(line['max_over_ranks_s'] - 0.002) < 1e-9         # rank 1's value: the MAX was taken
+
+
+def test_single_rank_line_and_world_mismatch():
+    r, lines = _run(['--dry-run'])
+    assert r.returncode == 0 and len(lines) == 1
+    assert json.loads(lines[0])['n_gpus'] == 1
+    # under a launcher the ranks come from the environment; a mismatch with
+    # --gpus is an error, not a silently different run
+    r, lines = _run(['--gpus', '4'], {'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and not lines
+    assert 'WORLD_SIZE' in (r.stderr + r.stdout)

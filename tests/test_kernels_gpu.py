@@ -272,3 +272,69 @@ def test_vdif_scan_and_index():
     src = kernels.build_index(recs, 9, 4, slot).cpu().numpy().reshape(9, 4)
     assert src[1, 1] == -1 and src[1, 2] == -1 and src[5, 0] == -1
     assert np.count_nonzero(src < 0) == 3
+
+
+@pytest.mark.parametrize('variant', [6, 7, 8, 9])
+@pytest.mark.parametrize('coder,bps', COMBOS)
+def test_front_kernel_matches_oracle(variant, coder, bps):
+    """k_decode_flat_front (explicit write front, k_front.h): every geometry
+    x coder against the oracle -- ragged payloads, frames through an index
+    with holes, buffers that are unaligned views into a larger allocation,
+    group / step counts that do not divide the work."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(variant * 100 + bps)
+    try:
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+        for pn, nfr, hdr, G, K, shift in ((8000, 37, 32, 2048, 16, 0), (260, 50, 16, 3, 2, 4),
+                                          (10000, 9, 16, 5, 3, 36), (256, 130, 0, 7, 1, 8),
+                                          (8, 11, 8, 2048, 16, 0), (5000, 23, 32, 1, 1000, 100)):
+            kernels.tune(_lib.TUNE_FRONT_GROUP, G)
+            kernels.tune(_lib.TUNE_FRONT_STEPS, K)
+            stride = pn + hdr
+            raw = rng.integers(0, 256, stride * nfr, dtype=np.uint8)
+            big = torch.zeros(shift + raw.size + 256, dtype=torch.uint8, device='cuda')
+            big[shift:shift + raw.size] = torch.from_numpy(raw).cuda()
+            dbuf = big[shift:shift + raw.size]
+            exp = np.concatenate([orc.decode_flat(raw[i * stride + hdr:(i + 1) * stride], coder, bps)
+                                  for i in range(nfr)])
+            out = kernels.decode_frames(dbuf, nfr, pn, CODERS[coder], bps, src0=hdr, src_stride=stride)
+            assert 'k_decode_flat_front' in _lib.last_kernel()
+            assert bits_equal(out.cpu().numpy(), exp), (pn, nfr, G, K)
+            # through an index with holes -> fill
+            src = np.arange(nfr, dtype=np.int64) * stride + hdr
+            holes = rng.choice(nfr, size=max(1, nfr // 5), replace=False)
+            src[holes] = -1
+            out = kernels.decode_frames(dbuf, nfr, pn, CODERS[coder], bps,
+                                        src=torch.from_numpy(src).cuda(), fill_value=-2.5)
+            want = exp.reshape(nfr, -1).copy()
+            want[holes] = -2.5
+            assert bits_equal(out.cpu().numpy(), want.reshape(-1)), (pn, nfr, 'holes')
+    finally:
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
+        kernels.tune(_lib.TUNE_FRONT_GROUP, 2048)
+        kernels.tune(_lib.TUNE_FRONT_STEPS, 16)
+
+
+def test_aligned_kernels_take_unaligned_views():
+    """The aligned-block kernels derive the payload's misalignment from its
+    ADDRESS, so a buffer that is a view at any 4-byte offset into a resident
+    file image decodes identically (flat, thread-interleave rows, LDS gather)."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(77)
+    pn, hdr, nsets = 8000, 32, 12
+    for nslot, chunk in ((1, 1), (8, 32), (8, 1), (2, 4)):
+        nfr = nsets * nslot
+        raw = rng.integers(0, 256, (pn + hdr) * nfr, dtype=np.uint8)
+        src = torch.arange(nfr, dtype=torch.int64, device='cuda') * (pn + hdr) + hdr
+        outs = []
+        for shift in (0, 4, 36, 100, 252):
+            big = torch.zeros(shift + raw.size + 256, dtype=torch.uint8, device='cuda')
+            big[shift:shift + raw.size] = torch.from_numpy(raw).cuda()
+            outs.append(kernels.decode_frames(big[shift:shift + raw.size], nsets, pn, 0, 2, chunk=chunk,
+                                              nslot=nslot, src=src, complex_data=chunk % 2 == 0).cpu().numpy())
+        exp = np.stack([orc.decode_flat(raw[i * (pn + hdr) + hdr:(i + 1) * (pn + hdr)], 'vdif', 2)
+                        for i in range(nfr)]).reshape(nsets, nslot, -1, chunk).transpose(0, 2, 1, 3)
+        for o in outs:
+            assert bits_equal(o, np.ascontiguousarray(exp).reshape(-1)), (nslot, chunk)

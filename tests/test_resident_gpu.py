@@ -1,0 +1,158 @@
+"""``open()`` on a file image that already lives in HBM, and ``fh.stage()``:
+the headline path through the drop-in API (north_star: "frames staged in HBM
+... keeping baseband.open()/StreamReader.read() as the drop-in API";
+reference semantics: base/base.py:919-969).  Every golden case of every format
+is read through a device tensor and through a staged host file and compared
+bit for bit with the reference's output."""
+import numpy as np
+import pytest
+
+from conftest import golden_path, load_expected, load_file, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+VDIF = ['sample_vdif', 'sample_mwa_vdif', 'sample_arochime_vdif', 'sample_bps1_vdif',
+        'vdif_cfg2_small', 'vdif_cfg3_small', 'vdif_bps1_c4', 'vdif_bps4_cplx_t2',
+        'vdif_bps8_real_c2', 'vdif_bps8_cplx_t4', 'vdif_bps2_t8_c1', 'vdif_legacy_bps2',
+        'vdif_bps4_t2_c1', 'vdif_invalid_fill0', 'vdif_invalid_fillm999']
+M5B = ['sample_m5b', 'm5b_c16_b2', 'm5b_c8_b1', 'm5b_c4_b2']
+M4 = ['sample_m4', 'sample_32track_m4', 'sample_32track_fanout2_m4', 'sample_16track_m4',
+      'sample_64track_fanout2_ft_m4', 'm4_t64_f4', 'm4_t32_f4', 'm4_t32_f2', 'm4_t16_f4']
+GUPPI = ['sample_puppi', 'guppi_cf_c64_ov0', 'guppi_cf_c64_ov32', 'guppi_tf_c8_ov16',
+         'guppi_cf_c6_p1', 'guppi_real_c1']
+DADA = ['sample_dada', 'sample_meerkat_dada', 'sample_mkbf_dada', 'dada_p2_c4_cplx',
+        'dada_p1_c1_real', 'dada_p2_c3_real']
+
+
+def _opener(name, case):
+    """(module.open, keyword arguments) for a golden case."""
+    import baseband_amd as bb
+    kw = {'squeeze': False}
+    if name in VDIF:
+        if 'frame_rate' in case:
+            kw['sample_rate'] = case['frame_rate'] * case['samples_per_frame']
+        elif case.get('kwargs'):
+            kw['sample_rate'] = case['kwargs']['sample_rate']
+        if 'fill_value' in case:
+            kw['fill_value'] = case['fill_value']
+        return bb.vdif.open, kw
+    if name in M5B:
+        fr = case.get('frame_rate')
+        kw.update(sample_rate=fr * case['samples_per_frame'] if fr else case['sample_rate_hz'],
+                  kday=case['kday'], nchan=case['nchan'], bps=case['bps'])
+        return bb.mark5b.open, kw
+    if name in M4:
+        if 'frame_rate' in case:
+            kw['sample_rate'] = case['frame_rate'] * case['samples_per_frame']
+        kw.update(ntrack=case['ntrack'], decade=2010, verify=False)
+        return bb.mark4.open, kw
+    if name in GUPPI:
+        return bb.guppi.open, kw
+    return bb.dada.open, kw
+
+
+def _device_image(rel):
+    import torch
+    return torch.from_numpy(load_file(rel).copy()).cuda()
+
+
+@pytest.mark.parametrize('name', VDIF + M5B + M4 + GUPPI + DADA)
+def test_read_from_device_tensor(manifest, name):
+    case = manifest[name]
+    opener, kw = _opener(name, case)
+    exp = load_expected(name)
+    with opener(_device_image(case['file']), 'rs', **kw) as fh:
+        assert fh.shape == tuple(case['shape'])
+        got = fh.read()
+        assert got.is_cuda and bits_equal(got.cpu().numpy(), exp)
+        # partial reads crossing frame boundaries come from the same image
+        spf = fh.samples_per_frame
+        n = exp.shape[0]
+        for start, count in ((1, min(n - 1, spf + 5)), (max(0, n - 7), min(7, n)), (spf // 2, 1)):
+            if start + count > n:
+                continue
+            fh.seek(start)
+            assert bits_equal(fh.read(count).cpu().numpy(), exp[start:start + count]), (start, count)
+
+
+@pytest.mark.parametrize('name', ['sample_vdif', 'vdif_cfg2_small', 'vdif_cfg3_small', 'sample_m5b',
+                                  'sample_m4', 'sample_puppi', 'sample_mkbf_dada', 'sample_dada'])
+def test_stage_keeps_file_in_hbm(manifest, name):
+    case = manifest[name]
+    opener, kw = _opener(name, case)
+    exp = load_expected(name)
+    with opener(golden_path(case['file']), 'rs', **kw) as fh:
+        assert fh.stage() is fh
+        assert fh._resident_bytes() is not None
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        fh.seek(3)
+        assert bits_equal(fh.read(11).cpu().numpy(), exp[3:14])
+        fh.unstage()
+        fh.seek(0)
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+
+
+@pytest.mark.parametrize('name', ['vdif_cfg2_small', 'vdif_cfg3_small', 'sample_m5b', 'm4_t64_f4'])
+@pytest.mark.parametrize('resident', [True, False])
+def test_out_tensor_is_decoded_in_place(manifest, name, resident):
+    """``read(out=<device tensor>)``: whole frames inside the request are
+    decoded straight into `out`, a partial first / last frame through a
+    temporary -- any start, any length."""
+    import torch
+    case = manifest[name]
+    opener, kw = _opener(name, case)
+    kw['squeeze'] = True
+    exp = load_expected(name)
+    exp = exp.reshape((exp.shape[0],) + tuple(s for s in exp.shape[1:] if s > 1))
+    src = _device_image(case['file']) if resident else golden_path(case['file'])
+    with opener(src, 'rs', **kw) as fh:
+        spf = fh.samples_per_frame
+        n = exp.shape[0]
+        tdtype = torch.complex64 if exp.dtype == np.complex64 else torch.float32
+        for start, count in ((0, n), (0, 2 * spf), (spf, spf), (5, 2 * spf), (spf - 3, spf + 10),
+                             (7, n - 7), (spf + 1, 2 * spf - 1), (3, 9)):
+            if start + count > n:
+                continue
+            out = torch.full((count,) + exp.shape[1:], -77., dtype=tdtype, device='cuda')
+            fh.seek(start)
+            assert fh.read(out=out) is out
+            assert fh.tell() == start + count
+            assert bits_equal(out.cpu().numpy(), exp[start:start + count]), (start, count)
+
+
+def test_device_file_handle_protocol():
+    """`DeviceFile`: read / seek / tell like a binary file, headers through the
+    lazy strided table."""
+    import torch
+    from baseband_amd.resident import DeviceFile, DeviceImage
+    from baseband_amd.base.header import strided_header_words
+    raw = load_file('samples/sample.vdif')
+    fh = DeviceFile(torch.from_numpy(raw.copy()).cuda())
+    assert fh.read(32) == raw[:32].tobytes() and fh.tell() == 32
+    fh.seek(-16, 2)
+    assert fh.read() == raw[-16:].tobytes()
+    fh.seek(5032)
+    assert fh.read(8) == raw[5032:5040].tobytes()
+    image = fh.host_image()
+    assert isinstance(image, DeviceImage) and len(image) == raw.size
+    assert np.array_equal(image[100:300], raw[100:300])
+    table = strided_header_words(image, 5032, 8)
+    want = strided_header_words(raw, 5032, 8)
+    assert len(table) == len(want) == 16
+    assert np.array_equal(np.asarray(table), np.asarray(want))
+    assert np.array_equal(table[3], want[3]) and np.array_equal(table[2:9, 1], want[2:9, 1])
+    with pytest.raises(OSError):
+        fh.fileno()
+
+
+def test_file_reader_on_device_image(manifest):
+    """'rb' mode on a device tensor: headers, frames and frame sets."""
+    from baseband_amd import vdif
+    exp = load_expected('sample_vdif')
+    with vdif.open(_device_image('samples/sample.vdif'), 'rb') as fb:
+        header = fb.read_header()
+        assert header['thread_id'] == 1 and header.frame_nbytes == 5032
+        fb.seek(0)
+        fs = fb.read_frameset()
+        assert bits_equal(fs.data.cpu().numpy(), exp[:20000].reshape(20000, 8, 1))
+        assert fb.get_thread_ids() == list(range(8))
