@@ -44,6 +44,8 @@ TUNE_GATHER_CHUNKS = 12
 TUNE_SEG_TILES = 13
 TUNE_FRONT_GROUP = 14
 TUNE_FRONT_STEPS = 15
+TUNE_OUT_STRIPE_W = 16
+TUNE_OUT_STRIPE_S = 17
 
 
 class BBError(RuntimeError):

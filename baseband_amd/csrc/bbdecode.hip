@@ -159,6 +159,8 @@ std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_stripe_w{0};     // experiment: output striping (bb_flat_args::stripe_w)
+std::atomic<int> g_tune_stripe_s{0};     // ... distance between the stripes, in frame-slots
 std::atomic<int> g_tune_front_g{2048};  // k_decode_flat_front: workgroups per group (one write front)
 std::atomic<int> g_tune_front_k{16};    // k_decode_flat_front: steps a group sweeps
 
@@ -322,6 +324,8 @@ int bb_tune(int knob, int value)
         case BB_TUNE_GATHER_CHUNKS: g_tune_gather_chunks = value > 0 ? value : 32; return BB_OK;
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
+        case BB_TUNE_OUT_STRIPE_W: g_tune_stripe_w = value > 0 ? value : 0; return BB_OK;
+        case BB_TUNE_OUT_STRIPE_S: g_tune_stripe_s = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_FRONT_GROUP: g_tune_front_g = (value >= 1 && value <= (1 << 20)) ? value : 2048; return BB_OK;
         case BB_TUNE_FRONT_STEPS: g_tune_front_k = (value >= 1 && value <= (1 << 20)) ? value : 16; return BB_OK;
         default: return BB_EINVAL;
@@ -514,6 +518,15 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     a.complex_data = p->complex_data;
     a.nt_loads = g_tune_nt_loads.load();
     a.trace = g_trace.load();
+    a.stripe_w = 0;
+    a.stripe_s = 0;
+    if (g_tune_stripe_w.load() > 0 && om == BB_OUT_FLAT) {
+        // experiment: the caller's buffer must hold (w - 1) * s + ceil(nfs / w) slots
+        a.stripe_w = (uint32_t)g_tune_stripe_w.load();
+        a.stripe_s = (uint64_t)g_tune_stripe_s.load();
+        const uint64_t need = ((uint64_t)a.stripe_w - 1) * a.stripe_s + (nfs + a.stripe_w - 1) / a.stripe_w;
+        if (out_elems < need * E) return BB_ERANGE;
+    }
 
     const uint64_t nwork = nfs * a.nseg;
     uint64_t blocks = nwork;

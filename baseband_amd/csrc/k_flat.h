@@ -45,7 +45,20 @@ struct bb_flat_args {
     int32_t  complex_data;
     int32_t  nt_loads;      // experiment: non-temporal input loads
     uint64_t *trace;        // experiment: completion time (wall_clock64) per work item, or null
+    // experiment (BB_TUNE_OUT_STRIPE_*): frame-slot fs is written to output slot
+    // (fs % stripe_w) * stripe_s + fs / stripe_w instead of slot fs, i.e. the
+    // launch's output is dealt over stripe_w regions that lie stripe_s slots
+    // apart; 0 = off.  Contiguous-output kernels (k_decode_flat, _aln) only.
+    uint32_t stripe_w;
+    uint64_t stripe_s;
 };
+
+__device__ __forceinline__ uint64_t bb_out_slot(const bb_flat_args &a, uint64_t fs)
+{
+    if (a.stripe_w == 0) return fs;
+    const uint64_t q = fs / a.stripe_w;
+    return (fs - q * a.stripe_w) * a.stripe_s + q;
+}
 
 template <int BPS, int LV>
 struct bb_levels {
@@ -108,7 +121,7 @@ void k_decode_flat(bb_flat_args a)
         float *obase;           // FLAT: start of this frame-slot's output
         uint64_t rowbase = 0, slot = 0;
         if (OM == BB_OUT_FLAT) {
-            obase = a.out + fs * E;
+            obase = a.out + bb_out_slot(a, fs) * E;
         } else {
             const uint64_t f = fs / a.nslot;
             slot = fs - f * a.nslot;
@@ -376,7 +389,7 @@ void k_decode_flat_aln(bb_flat_args a)
         uint64_t fs, seg;
         if (a.nseg == 1) { fs = work; seg = 0; }
         else { fs = work / a.nseg; seg = work - fs * a.nseg; }
-        float *obase = a.out + fs * E;
+        float *obase = a.out + bb_out_slot(a, fs) * E;
         const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
         const uint64_t seg_e_end = (seg + 1) * a.seg_tiles * EPT < E
                                    ? (seg + 1) * a.seg_tiles * EPT : E;

@@ -67,6 +67,29 @@ def to_device_bytes(raw, device=None):
     return torch.from_numpy(np.array(a, copy=True)).to(device or 'cuda')
 
 
+class _Target:
+    """Output tensor for a decode launch.  The kernels store 16 bytes per
+    lane, so the library wants `out` 16-byte aligned; a slice of a larger
+    result that starts elsewhere (a read that enters a frame at an odd row) is
+    decoded into a temporary and copied into place afterwards."""
+    __slots__ = ('want', 'use')
+
+    def __init__(self, out, nelem, device):
+        self.want = out
+        if out is None:
+            self.use = torch.empty(nelem, dtype=torch.float32, device=device)
+        elif out.data_ptr() % 16 or not out.is_contiguous():
+            self.use = torch.empty(out.numel(), dtype=torch.float32, device=device)
+        else:
+            self.use = out
+
+    def done(self):
+        if self.want is None or self.want is self.use:
+            return self.use
+        self.want.copy_(self.use.view_as(self.want))
+        return self.want
+
+
 def vdif_scan(dbuf, nframes, frame_nbytes, header_nbytes, pattern, mask,
               ref_seconds, ref_frame_nr, frame_rate, first_offset=0):
     """-> int32 tensor (nframes, 4): payload offset lo/hi, time_index,
@@ -232,12 +255,11 @@ def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
     p.fill_re = fv.real
     p.fill_im = fv.imag
     nelem = nframes * nslot * (payload_nbytes * 8 // bps) if bps in (1, 2, 4, 8) else 0
-    if out is None:
-        out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
+    tgt = _Target(out, nelem, dbuf.device)
     check(lib.bb_decode_frames(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
-                               C.byref(p), _ptr(out), out.numel(), _stream(dbuf)),
+                               C.byref(p), _ptr(tgt.use), tgt.use.numel(), _stream(dbuf)),
           'bb_decode_frames')
-    return out
+    return tgt.done()
 
 
 def mark4_scan(dbuf, nframes, ntrack, ref_year, ref_qms, frame_qms,
@@ -268,13 +290,11 @@ def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
         p.sign_bit[j] = s
         p.mag_bit[j] = m
     p.fill = float(fill_value)
-    if out is None:
-        out = torch.empty(nframes * nwords * (ntrack // 2), dtype=torch.float32,
-                          device=dbuf.device)
+    tgt = _Target(out, nframes * nwords * (ntrack // 2), dbuf.device)
     check(lib.bb_decode_mark4(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
-                              C.byref(p), _ptr(out), out.numel(), _stream(dbuf)),
+                              C.byref(p), _ptr(tgt.use), tgt.use.numel(), _stream(dbuf)),
           'bb_decode_mark4')
-    return out
+    return tgt.done()
 
 
 def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
@@ -294,12 +314,11 @@ def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
     p.fill_re = fv.real
     p.fill_im = fv.imag
     nelem = nframes * (t_hi - t_lo) * npol * nchan * 2
-    if out is None:
-        out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
+    tgt = _Target(out, nelem, dbuf.device)
     check(lib.bb_decode_i8_tiled(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
-                                 C.byref(p), _ptr(out), out.numel(), _stream(dbuf)),
+                                 C.byref(p), _ptr(tgt.use), tgt.use.numel(), _stream(dbuf)),
           'bb_decode_i8_tiled')
-    return out
+    return tgt.done()
 
 
 def as_device_samples(data):

@@ -370,58 +370,59 @@ class Mark4Header:
     def payload_nbytes(self):
         return self.frame_nbytes - self.nbytes
 
+    # The quantities below are all views of three per-track header fields --
+    # 'fan_out' (which of the fanout samples a track carries), 'magnitude_bit'
+    # and 'lsb_output' / 'converter_id' -- tied together by the track tables of
+    # Mark 4 memo 230.3.  Results are pinned to the reference's for 48 keyword
+    # combinations (tests/golden/mark4_header_cases.json; reference:
+    # mark4/header.py:558-735).
+    _FANOUTS = (1, 2, 4)
+
     @property
     def fanout(self):
-        return int(np.max(self['fan_out']) + 1)
+        return 1 + int(self['fan_out'].max())
 
     @fanout.setter
     def fanout(self, fanout):
-        if fanout not in (1, 2, 4):
+        if fanout not in self._FANOUTS:
             raise ValueError("Mark 4 data only supports fanout=1, 2, or 4, "
                              "not {0}.".format(fanout))
-        if self.ntrack == 16:
-            self['fan_out'] = np.tile(np.arange(fanout), self.ntrack // fanout)
-        else:
-            self['fan_out'] = np.tile(np.repeat(np.arange(fanout), 2),
-                                      self.ntrack // 2 // fanout)
+        # sample number of every track: tracks come in (sign, magnitude or
+        # odd/even) pairs that carry the same sample, except on 16-track tapes
+        # where every other track is absent
+        pair = 1 if self.ntrack == 16 else 2
+        self['fan_out'] = (np.arange(self.ntrack) // pair) % fanout
 
     @property
     def samples_per_frame(self):
-        return self.frame_nbytes * 8 // (self.ntrack // self.fanout)
+        # a stream word holds `fanout` samples of every channel, and the
+        # header's place on tape counts as samples too
+        return (PAYLOAD_NBITS) * self.fanout
 
     @samples_per_frame.setter
     def samples_per_frame(self, samples_per_frame):
-        fanout, extra = divmod(samples_per_frame * self.ntrack,
-                               8 * self.frame_nbytes)
-        if extra or fanout not in (1, 2, 4):
-            raise ValueError(
-                "header cannot store {} samples per frame. "
-                "Should be one of {}."
-                .format(samples_per_frame,
-                        ', '.join([str(f * 8 * self.frame_nbytes)
-                                   for f in (1, 2, 4)])))
-        self.fanout = int(fanout)
+        allowed = [f * PAYLOAD_NBITS for f in self._FANOUTS]
+        if samples_per_frame not in allowed:
+            raise ValueError("header cannot store {} samples per frame. Should be one of {}."
+                             .format(samples_per_frame, ', '.join(map(str, allowed))))
+        self.fanout = samples_per_frame // PAYLOAD_NBITS
 
     @property
     def bps(self):
-        return 2 if self['magnitude_bit'].any() else 1
+        return 1 + int(bool(self['magnitude_bit'].any()))
 
     @bps.setter
     def bps(self, bps):
-        if bps == 1:
-            self['magnitude_bit'] = np.zeros(self.ntrack, bool)
-        elif bps == 2:
-            ta = self._track_assignment(self.ntrack, bps, self.fanout)
-            magnitude_bit = np.empty(self.ntrack, dtype=bool)
-            magnitude_bit[ta] = [False, True]
-            self['magnitude_bit'] = magnitude_bit
-        else:
+        if bps not in (1, 2):
             raise ValueError("Mark 4 data can only have bps=1 or 2, "
                              "not {0}".format(bps))
+        flags = np.zeros(self.ntrack, bool)
+        if bps == 2:
+            # last axis of the track table: (sign track, magnitude track)
+            flags[self._track_assignment(self.ntrack, 2, self.fanout)[..., 1]] = True
+        self['magnitude_bit'] = flags
 
-    @property
-    def complex_data(self):
-        return False
+    complex_data = property(lambda self: False, doc="Mark 4 data are always real.")
 
     @complex_data.setter
     def complex_data(self, complex_data):
@@ -430,108 +431,109 @@ class Mark4Header:
 
     @property
     def nchan(self):
-        return self.ntrack // (self.fanout * self.bps)
+        return self.ntrack // self.fanout // self.bps
 
     @nchan.setter
     def nchan(self, nchan):
-        self.bps = self.ntrack // (self.fanout * nchan)
+        self.bps = self.ntrack // self.fanout // nchan
 
-    @property
-    def sample_shape(self):
-        return (self.nchan,)
+    sample_shape = property(lambda self: (self.nchan,))
 
     @sample_shape.setter
     def sample_shape(self, sample_shape):
-        self.nchan, = sample_shape
+        (self.nchan,) = sample_shape
+
+    # -- per-channel quantities stored per track
+    def _channel_value(self, key):
+        """Value of a per-track field on the first track of every channel."""
+        return self[key][self.track_assignment[0, :, 0]]
+
+    def _set_channel_value(self, key, values, dtype):
+        """Give all tracks of channel c (every fanout sample, sign and
+        magnitude) the value ``values[c]``."""
+        tracks = self.track_assignment                      # (fanout, nchan, bps)
+        full = np.zeros(self.ntrack, dtype)
+        full[tracks] = np.asarray(values, dtype).reshape(1, -1, 1)
+        self[key] = full
 
     @property
     def nsb(self):
-        sb = self['lsb_output']
-        return 1 if (sb == sb[0]).all() else 2
+        lsb = self['lsb_output']
+        return 2 if lsb.min() != lsb.max() else 1
 
     @nsb.setter
     def nsb(self, nsb):
-        """Side bands and default converter ids (mark4/header.py:654-677,
-        690-730)."""
-        if nsb == 1:
-            self['lsb_output'] = np.ones(self.ntrack, bool)
-        elif nsb == 2:
-            # the reference alternates sidebands over 16 track pairs, i.e.
-            # 32 tracks only (mark4/header.py:671-676); a 64-track header is
-            # two such headstacks
-            if self.ntrack not in (32, 64):
-                raise ValueError("two sidebands can only be set for 32 or "
-                                 "64 tracks.")
-            self['lsb_output'] = np.tile([False, True], self.ntrack // 2)
-        else:
+        """1: all tracks carry the same sideband flag (set, like the reference
+        does); 2: the flag alternates from track to track, which the reference
+        lays out for a 32-track headstack (mark4/header.py:654-677; a 64-track
+        header is two of them).  Either way the converters get their default
+        numbering."""
+        if nsb not in (1, 2):
             raise ValueError("number of sidebands can only be 1 or 2.")
-        nconverter = self.ntrack // (self.fanout * self.bps * self.nsb)
-        converters = np.arange(nconverter)
-        if nconverter > 2:
-            converters = converters.reshape(-1, 2, 2).transpose(0, 2, 1).ravel()
-        self.converters = converters
+        if nsb == 2 and self.ntrack not in (32, 64):
+            raise ValueError("two sidebands can only be set for 32 or "
+                             "64 tracks.")
+        self['lsb_output'] = (np.arange(self.ntrack) % 2 == 1) if nsb == 2 \
+            else np.ones(self.ntrack, bool)
+        ids = np.arange(self.ntrack // (self.fanout * self.bps * nsb))
+        if ids.size > 2:
+            # default order within groups of four: 0, 2, 1, 3
+            ids = ids.reshape(-1, 2, 2).swapaxes(1, 2).reshape(-1)
+        self.converters = ids
 
     @property
     def converters(self):
-        """Converter id and sideband of every channel as a structured array
-        with 'converter' and 'lsb' entries (mark4/header.py:690-739).  Can be
-        set with such an array, a dict, or just the converter ids (sidebands
-        as they are; with two sidebands half the number of ids suffices)."""
-        ta_ch = self.track_assignment[0, :, 0]
-        converters = np.empty(len(ta_ch), [("converter", int), ("lsb", bool)])
-        converters['converter'] = self['converter_id'][ta_ch]
-        converters['lsb'] = self['lsb_output'][ta_ch]
-        return converters
+        """Converter id and sideband of every channel: structured array with
+        'converter' and 'lsb' entries (mark4/header.py:690-735).  Can be set
+        with such an array, a dict with those keys, or just the converter ids
+        (sidebands stay as they are; with two sidebands one id per sideband
+        pair suffices)."""
+        table = np.zeros(self.nchan, [("converter", int), ("lsb", bool)])
+        table['converter'] = self._channel_value('converter_id')
+        table['lsb'] = self._channel_value('lsb_output')
+        return table
 
     @converters.setter
     def converters(self, converters):
-        ta = self.track_assignment
-        ta_ch = ta[0, :, 0]
-        nchan = len(ta_ch)
-        msg = ('Mark 4 file with bps={0}, fanout={1} '
-               'needs to define {2} converters')
-        try:
-            converter = converters['converter']
-        except (KeyError, ValueError, IndexError, TypeError):
-            converter = np.array(converters)
-            sb = self['lsb_output'][ta_ch]
-            if self.nsb == 2 and len(converter) == nchan // 2:
-                c = np.empty(nchan, dtype=int)
-                c[sb] = c[~sb] = converter
-                converter = c
-            if len(converter) != nchan:
-                raise ValueError(msg.format(self.bps, self.fanout, nchan))
+        nchan = self.nchan
+        ids = lsb = None
+        if isinstance(converters, dict) or getattr(getattr(converters, 'dtype', None), 'names', None):
+            ids, lsb = np.asarray(converters['converter']), np.asarray(converters['lsb'], bool)
         else:
-            converter = np.asarray(converter)
-            sb = np.array(converters['lsb'])
-            if len(converter) != nchan:
-                raise ValueError(msg.format(self.bps, self.fanout, nchan))
-            lsb_output = np.empty(self.ntrack, bool)
-            lsb_output[ta] = sb[:, np.newaxis]
-            self['lsb_output'] = lsb_output
-        converter_id = np.empty(self.ntrack, dtype=int)
-        converter_id[ta] = converter[:, np.newaxis]
-        self['converter_id'] = converter_id
+            ids = np.array(converters)
+            if ids.size * 2 == nchan and self.nsb == 2:
+                # one id per pair of sidebands: hand it to both members
+                now = self._channel_value('lsb_output')
+                both = np.zeros(nchan, int)
+                both[now] = ids
+                both[~now] = ids
+                ids = both
+        if ids.size != nchan:
+            raise ValueError("Mark 4 file with bps={0}, fanout={1} needs to define {2} converters"
+                             .format(self.bps, self.fanout, nchan))
+        if lsb is not None:
+            self._set_channel_value('lsb_output', lsb, bool)
+        self._set_channel_value('converter_id', ids, int)
 
     @classmethod
     def _track_assignment(cls, ntrack, bps, fanout):
-        try:
-            ta = _TRACK_ASSIGNMENTS[(bps, fanout)]
-        except KeyError:
+        """(fanout, nchan, bps) table of track numbers.  The memo's tables are
+        for a 32-track headstack; 64 tracks are two headstacks side by side
+        (channels of the second follow those of the first), 16 tracks use
+        every other track of one."""
+        table = _TRACK_ASSIGNMENTS.get((bps, fanout))
+        if table is None:
             raise ValueError("Mark 4 reader does not support bps={0}, "
                              "fanout={1}".format(bps, fanout))
-        if ntrack == 64:
-            return np.concatenate((ta, ta + 32), axis=1)
-        if ntrack == 32:
-            return ta
+        if ntrack not in (16, 32, 64):
+            raise ValueError("have Mark 4 track assignments only for "
+                             "ntrack=32 or 64, not {0}".format(ntrack))
         if ntrack == 16:
-            return ta[:, ::2, :] // 2
-        raise ValueError("have Mark 4 track assignments only for "
-                         "ntrack=32 or 64, not {0}".format(ntrack))
+            return table[:, 0::2] // 2
+        return table if ntrack == 32 else np.concatenate([table, 32 + table], axis=1)
 
-    @property
-    def track_assignment(self):
-        return self._track_assignment(self.ntrack, self.bps, self.fanout)
+    track_assignment = property(
+        lambda self: self._track_assignment(self.ntrack, self.bps, self.fanout))
 
     def magnitude_signature(self):
         """None for the standard sign/magnitude placement, else the packed

@@ -88,34 +88,96 @@ class VDIFFrameSet:
 
     @classmethod
     def fromfile(cls, fh, thread_ids=None, edv=None, verify=True):
-        """Read frames until the frame number changes or a thread repeats
-        (vdif/frame.py:176-243)."""
+        """The frames of one time step, from the current file position; the
+        pointer is left at the first frame that is not part of the set.
+
+        Same results as the reference's frame-by-frame walk
+        (vdif/frame.py:176-243): a set ends before the first header with
+        another frame number or a thread id already seen, or where no further
+        header can be read; with `thread_ids` given only those threads are
+        kept and all of them must be there.  Done here on a TABLE: the set's
+        bytes are read in one block (grown until the end of the set is inside
+        it), the headers are looked at as a strided uint32 array -- frame
+        number and thread id of every frame in two vector operations -- and
+        the payloads are views into the block (what the stream path does per
+        window with ``bb_vdif_scan`` / ``bb_build_index``, on the host because
+        a frame set's words live on the host)."""
+        start = fh.tell()
         header0 = VDIFHeader.fromfile(fh, edv, verify)
         edv = header0.edv
-        frame_nr = header0['frame_nr']
-        frames = {}
-        header = header0
+        fn, hn = header0.frame_nbytes, header0.nbytes
+        wanted = None if thread_ids is None else set(thread_ids)
+        fh.seek(start)
+        block = b''
+        nwant = 9                       # frames per block, grown geometrically
         while True:
-            thread_id = header['thread_id']
-            if header['frame_nr'] != frame_nr or thread_id in frames:
-                fh.seek(-header.nbytes, 1)
+            ask = nwant * fn + 32 - len(block)
+            more = fh.read(ask)
+            block += more
+            raw = np.frombuffer(block, np.uint8)
+            # headers that can be parsed: 32 bytes are read even for a legacy one
+            nhead = (len(raw) - 32) // fn + 1
+            table = np.lib.stride_tricks.as_strided(
+                raw[:(nhead - 1) * fn + 32].view('<u4'), shape=(nhead, 4), strides=(fn, 4),
+                writeable=False)
+            frame_nr = table[:, 1] & 0xffffff
+            thread = (table[:, 3] >> 16) & 0x3ff
+            # only threads that are kept can end a set by showing up again
+            kept = np.ones(nhead, bool) if wanted is None else np.isin(thread, sorted(wanted))
+            again = kept.copy()
+            again[np.nonzero(kept)[0][np.unique(thread[kept], return_index=True)[1]]] = False
+            breaks = np.nonzero((frame_nr != frame_nr[0]) | again)[0]
+            if len(breaks) or len(more) < ask:
                 break
-            if thread_ids is None or thread_id in thread_ids:
-                payload = VDIFPayload.fromfile(fh, header=header)
-                frames[thread_id] = VDIFFrame(header, payload, verify=False)
+            nwant *= 4
+        nset = int(breaks[0]) if len(breaks) else nhead      # frames whose header is in the set
+        frames = {}
+        for k in range(nset):
+            if k == 0:
+                header = header0
             else:
-                fh.seek(header.payload_nbytes, 1)
-            try:
-                header = VDIFHeader.fromfile(fh, edv, verify)
-            except (EOFError, AssertionError):
-                if thread_ids is None or len(frames) == len(thread_ids):
+                header = VDIFHeader(np.frombuffer(block, '<u4', 8, k * fn), edv, verify=False)
+                try:
+                    if verify:
+                        header.verify()
+                except AssertionError:
+                    nset = k            # a damaged header ends the set like the end of the file
                     break
-                raise
-        if thread_ids and len(frames) < len(thread_ids):
+            if kept[k]:
+                body = raw[k * fn + hn:(k + 1) * fn]
+                if len(body) < fn - hn:
+                    raise EOFError("could not read full payload.")
+                frames[int(thread[k])] = VDIFFrame(header, VDIFPayload(body.view('<u4'), header),
+                                                   verify=False)
+        complete = wanted is None or len(frames) == len(wanted)
+        end = start + nset * fn
+        if len(breaks) and nset == int(breaks[0]):
+            # ended by a header of the next set; the reference has parsed and
+            # verified that one too before looking at its frame number
+            try:
+                if verify:
+                    VDIFHeader(np.frombuffer(block, '<u4', 8, nset * fn), edv, verify=False).verify()
+            except AssertionError:
+                if not complete:
+                    raise
+                end += hn
+        else:
+            # no further header could be read
+            if not complete:
+                if nset < nhead:        # it is there but damaged: raises
+                    VDIFHeader(np.frombuffer(block, '<u4', 8, nset * fn), edv, verify=False).verify()
+                raise EOFError
+            # the pointer ends where that attempt left it: behind a damaged
+            # header, or at the end of a tail too short to hold one
+            if nset < nhead:
+                end += hn
+            elif start + len(block) - end < 32:
+                end = start + len(block)
+        fh.seek(end)
+        if wanted is not None and len(frames) < len(wanted):
             raise OSError("could not find all requested frames.")
-        if thread_ids is None:
-            thread_ids = sorted(frames.keys())
-        return cls([frames[tid] for tid in thread_ids], header0)
+        order = sorted(frames) if thread_ids is None else list(thread_ids)
+        return cls([frames[tid] for tid in order], header0)
 
     def tofile(self, fh):
         for frame in self.frames:
