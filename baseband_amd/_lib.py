@@ -46,6 +46,8 @@ TUNE_FRONT_GROUP = 14
 TUNE_FRONT_STEPS = 15
 TUNE_OUT_STRIPE_W = 16
 TUNE_OUT_STRIPE_S = 17
+TUNE_WORK_STRIPES = 18
+TUNE_XPOSE = 19
 
 
 class BBError(RuntimeError):

@@ -21,6 +21,31 @@ __device__ float g_levels[3][4][256];
 __device__ __forceinline__ int bb_lane() { return threadIdx.x & (BB_WAVE - 1); }
 __device__ __forceinline__ int bb_wave() { return threadIdx.x / BB_WAVE; }
 
+// Work order of the decode launches ("striping").  A launch's work items are
+// numbered in output order; item w is NOT given to the w-th workgroup-step but
+// dealt over 2^lw contiguous ranges ("stripes") of the launch: step w takes
+// item (w % 2^lw) * stripe + w / 2^lw.  Workgroups that run side by side thus
+// write into 2^lw places spread over the whole output of the launch instead of
+// one moving window.  Why: on MI355X a decode-shaped store stream that stays
+// inside one physical region of HBM runs at 5.4-5.65 TB/s, one that touches
+// two different regions at the same time at 6.3-6.6 (profiles/r02b_exp_stripe.log,
+// r02c_exp_stripe2.log: same kernel, same launch size, only the placement of
+// the output differs); which regions an allocation lies in is the driver's
+// choice, so the launch covers as much of its own output at once as it can.
+// The map is a bijection on [0, n): the n % 2^lw items at the end keep their
+// place.
+struct bb_perm_t {
+    uint64_t n;             // 2^lw * stripe: items that are dealt out (0 = identity)
+    uint64_t stripe;        // items per stripe
+    uint32_t lw;            // log2(number of stripes)
+};
+
+__device__ __forceinline__ uint64_t bb_perm(const bb_perm_t &p, uint64_t w)
+{
+    if (w >= p.n) return w;
+    return (w & ((1ull << p.lw) - 1)) * p.stripe + (w >> p.lw);
+}
+
 // 16-byte store, optionally with the non-temporal hint (streamed output is
 // never re-read by this library).
 template <bool NT>

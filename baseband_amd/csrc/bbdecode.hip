@@ -8,6 +8,7 @@
 #include "k_gather.h"
 #include "k_mark4.h"
 #include "k_tiled.h"
+#include "k_xpose.h"
 #include "k_encode.h"
 
 #include <atomic>
@@ -159,10 +160,26 @@ std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
+std::atomic<int> g_tune_order_lw{4};     // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order
 std::atomic<int> g_tune_stripe_w{0};     // experiment: output striping (bb_flat_args::stripe_w)
 std::atomic<int> g_tune_stripe_s{0};     // ... distance between the stripes, in frame-slots
 std::atomic<int> g_tune_front_g{2048};  // k_decode_flat_front: workgroups per group (one write front)
 std::atomic<int> g_tune_front_k{16};    // k_decode_flat_front: steps a group sweeps
+
+// Work order of a launch of `nwork` items (bb_common.h, bb_perm_t): 16 stripes
+// by default; launches of fewer than 64 items per stripe keep file order.
+bb_perm_t make_perm(uint64_t nwork)
+{
+    bb_perm_t p = {0, 0, 0};
+    const int lw = g_tune_order_lw.load();
+    if (lw > 0 && (nwork >> lw) >= 64) {
+        p.lw = (uint32_t)lw;
+        p.stripe = nwork >> lw;
+        p.n = p.stripe << lw;
+    }
+    return p;
+}
 
 template <int BPS, int LV>
 void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
@@ -324,6 +341,8 @@ int bb_tune(int knob, int value)
         case BB_TUNE_GATHER_CHUNKS: g_tune_gather_chunks = value > 0 ? value : 32; return BB_OK;
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
+        case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
+        case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : 4; return BB_OK;
         case BB_TUNE_OUT_STRIPE_W: g_tune_stripe_w = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_OUT_STRIPE_S: g_tune_stripe_s = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_FRONT_GROUP: g_tune_front_g = (value >= 1 && value <= (1 << 20)) ? value : 2048; return BB_OK;
@@ -529,6 +548,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     }
 
     const uint64_t nwork = nfs * a.nseg;
+    a.perm = make_perm(nwork);              // (branches that cut the work differently set their own)
     uint64_t blocks = nwork;
     const int tb = g_tune_blocks.load();
     if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
@@ -629,6 +649,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // payload each); one workgroup per item costs 15 %, a few thousand
         // long-running ones 5-10 % (profiles/r01f_exp_gather*.log)
         uint64_t gb = (uint64_t)nframes * ga.ngroup;
+        ga.perm = make_perm(gb);
         const uint64_t gcap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (gb > gcap) gb = gcap;
         if (gb > 0x7fffffffull) gb = 0x7fffffffull;
@@ -659,6 +680,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.tpw = a.seg_tiles;
         const uint64_t sgroups = ((uint64_t)p->nslot + nw - 1) / nw;
         uint64_t b2 = (uint64_t)nframes * a.nseg * sgroups;
+        a.perm = make_perm(b2);
         const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
@@ -718,6 +740,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
         a.tpw = (a.seg_tiles + nw - 1) / nw;
         uint64_t b2 = nfs * a.nseg;
+        a.perm = make_perm(b2);
         const uint64_t cap = tb > 0 ? (uint64_t)tb : (uint64_t)(wide ? BB_GRID_CAP : 4096);
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
@@ -881,6 +904,7 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
     a.fill = p->fill;
     a.hi = h_levels[BB_CODER_VDIF][1][3];
     uint64_t blocks = (uint64_t)nframes * a.nseg;
+    a.perm = make_perm(blocks);
     const int tb = g_tune_blocks.load();
     const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;      // persistent grid
     if (blocks > cap) blocks = cap;
@@ -940,6 +964,46 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
         case BB_LAYOUT_MKBF:     a.tb = 256; a.sh = np_ * nc * 256; a.st = 1; a.sp = nc * 256; a.sc = 256; break;
         default:                 a.tb = T ? T : 1; a.sh = 0; a.st = nc * np_; a.sp = 1; a.sc = np_; break;
     }
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = g_tune_nt.load() != 0;
+    const int tb = g_tune_blocks.load();
+    // Fast form (k_xpose.h) for the common geometry: every input run 16-byte
+    // aligned, at least 32 channels.  Fixed stride only (offsets from an index
+    // cannot be checked for alignment here).
+    {
+        const uint64_t rows = (p->t_hi - p->t_lo) * np_;
+        bool ok = g_tune_xpose.load() != 0 && !d_src && nc >= 32 && !(nc & 1)
+                  && !((uintptr_t)d_buf & 15) && !(p->src0 & 15) && !(p->src_stride & 15);
+        if (p->layout == BB_LAYOUT_GUPPI_CF)
+            ok = ok && ((T * np_ * 2) % 16 == 0) && ((p->t_lo * np_ * 2) % 16 == 0);
+        else if (p->layout == BB_LAYOUT_MKBF)
+            ok = ok && (np_ == 1 || np_ == 2) && (p->t_lo % 8 == 0);
+        else
+            ok = ok && np_ == 2 && (nc % 4 == 0);
+        if (ok) {
+            const uint64_t ntt = (rows + BB_XP_ROWS - 1) / BB_XP_ROWS, nct = (nc + BB_XP_TC - 1) / BB_XP_TC;
+            if (ntt > 0xffffffffull) return BB_ERANGE;
+            a.ntt = (uint32_t)ntt; a.nct = (uint32_t)nct;
+            a.tt = (uint32_t)(BB_XP_ROWS / np_); a.tc = BB_XP_TC; a.tcp = 2 * BB_XP_PITCH;
+            uint64_t blocks = (uint64_t)nframes * ntt * nct;
+            a.perm = make_perm(blocks);
+            const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
+            if (blocks > cap) blocks = cap;
+            const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+#define BB_XP(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_xpose<L, true>), grid, block, 0, st, a); \
+                      else    hipLaunchKernelGGL((k_decode_i8_xpose<L, false>), grid, block, 0, st, a); } while (0)
+            switch (p->layout) {
+                case BB_LAYOUT_GUPPI_CF: BB_XP(0); break;
+                case BB_LAYOUT_MKBF:     BB_XP(1); break;
+                default:                 BB_XP(2); break;
+            }
+#undef BB_XP
+            BB_NOTE("k_decode_i8_xpose<%d,%s> grid %u tiles %u x %u per frame", p->layout, nt ? "nt" : "plain",
+                    grid.x, a.ntt, a.nct);
+            BB_HIP(hipGetLastError());
+            return BB_OK;
+        }
+    }
     // tile: up to 64 channels (even count so float4 pieces pair up), and as
     // many times as keep the tile near 8192 elements (16 KiB in, 64 KiB out)
     uint32_t tc = (uint32_t)(nc < 64 ? nc : 64);
@@ -979,12 +1043,10 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     a.nct = (uint32_t)nct;
     if (lds > 64 * 1024) return BB_ENOTSUP;
     uint64_t blocks = (uint64_t)nframes * ntt * nct;
-    const int tb = g_tune_blocks.load();
+    a.perm = make_perm(blocks);
     if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
-    hipStream_t st = (hipStream_t)stream;
-    const bool nt = g_tune_nt.load() != 0;
 #define BB_TL(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_tiled<L, true>), grid, block, lds, st, a); \
                       else    hipLaunchKernelGGL((k_decode_i8_tiled<L, false>), grid, block, lds, st, a); } while (0)
 #define BB_TS(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_stage<L, true>), grid, block, lds, st, a); \

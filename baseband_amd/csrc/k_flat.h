@@ -51,6 +51,7 @@ struct bb_flat_args {
     // apart; 0 = off.  Contiguous-output kernels (k_decode_flat, _aln) only.
     uint32_t stripe_w;
     uint64_t stripe_s;
+    bb_perm_t perm;         // work order (bb_common.h)
 };
 
 __device__ __forceinline__ uint64_t bb_out_slot(const bb_flat_args &a, uint64_t fs)
@@ -110,7 +111,8 @@ void k_decode_flat(bb_flat_args a)
     const int src_lane0 = (lane * BPS) >> 3;
     const int shift = (4 * lane * BPS) & 31;
 
-    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+    for (uint64_t step = blockIdx.x; step < nwork; step += gridDim.x) {
+        const uint64_t work = bb_perm(a.perm, step);
         uint64_t fs, seg;
         if (a.nseg == 1) { fs = work; seg = 0; }
         else { fs = work / a.nseg; seg = work - fs * a.nseg; }
@@ -225,7 +227,8 @@ void k_decode_flat_pipe(bb_flat_args a)
     uint32_t cur[TPW], nxt[TPW];
     bool cur_valid = false, nxt_valid = false;
 
-    auto issue = [&](uint64_t work, uint32_t (&w)[TPW], bool &valid) {
+    auto issue = [&](uint64_t step, uint32_t (&w)[TPW], bool &valid) {
+        const uint64_t work = bb_perm(a.perm, step);
         uint64_t fs, seg;
         if (a.nseg == 1) { fs = work; seg = 0; }
         else { fs = work / a.nseg; seg = work - fs * a.nseg; }
@@ -249,9 +252,10 @@ void k_decode_flat_pipe(bb_flat_args a)
         const uint64_t next = work + gridDim.x;
         if (next < nwork) issue(next, nxt, nxt_valid);
 
+        const uint64_t pwork = bb_perm(a.perm, work);
         uint64_t fs, seg;
-        if (a.nseg == 1) { fs = work; seg = 0; }
-        else { fs = work / a.nseg; seg = work - fs * a.nseg; }
+        if (a.nseg == 1) { fs = pwork; seg = 0; }
+        else { fs = pwork / a.nseg; seg = pwork - fs * a.nseg; }
         float *obase;
         uint64_t rowbase = 0, slot = 0;
         if (OM == BB_OUT_FLAT) {
@@ -351,7 +355,8 @@ void k_decode_flat_aln(bb_flat_args a)
     bool cur_valid = false, nxt_valid = false;
     uint32_t cur_s = 0, nxt_s = 0;
 
-    auto issue = [&](uint64_t work, uint32_t (&w)[TPW + 1], bool &valid, uint32_t &s) {
+    auto issue = [&](uint64_t step, uint32_t (&w)[TPW + 1], bool &valid, uint32_t &s) {
+        const uint64_t work = bb_perm(a.perm, step);
         uint64_t fs, seg;
         if (a.nseg == 1) { fs = work; seg = 0; }
         else { fs = work / a.nseg; seg = work - fs * a.nseg; }
@@ -386,9 +391,10 @@ void k_decode_flat_aln(bb_flat_args a)
         const uint64_t next = work + gridDim.x;
         if (next < nwork) issue(next, nxt, nxt_valid, nxt_s);
 
+        const uint64_t pwork = bb_perm(a.perm, work);
         uint64_t fs, seg;
-        if (a.nseg == 1) { fs = work; seg = 0; }
-        else { fs = work / a.nseg; seg = work - fs * a.nseg; }
+        if (a.nseg == 1) { fs = pwork; seg = 0; }
+        else { fs = pwork / a.nseg; seg = pwork - fs * a.nseg; }
         float *obase = a.out + bb_out_slot(a, fs) * E;
         const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
         const uint64_t seg_e_end = (seg + 1) * a.seg_tiles * EPT < E
@@ -585,7 +591,8 @@ void k_decode_rows_pipe(bb_flat_args a)
     uint32_t cur_s = 0, nxt_s = 0;
 
     // work -> (frame set, segment, slot group); slot = group * NW + wave
-    auto split = [&](uint64_t work, uint64_t &f, uint64_t &seg, uint32_t &slot) {
+    auto split = [&](uint64_t step, uint64_t &f, uint64_t &seg, uint32_t &slot) {
+        const uint64_t work = bb_perm(a.perm, step);
         const uint64_t per_f = a.nseg * sgroups;
         f = work / per_f;
         const uint64_t r = work - f * per_f;

@@ -30,6 +30,7 @@ struct bb_gather_args {
     int32_t  complex_data;
     int32_t  lrow;          // log2(nslot * chunk) when that is a power of two, else -1
     int32_t  aligned;       // use 256-byte aligned block loads
+    bb_perm_t perm;         // work order (bb_common.h)
 };
 
 // WIDE: chunks of at least four floats (a float4 never straddles thread slots)
@@ -64,7 +65,8 @@ void k_decode_gather(bb_gather_args a)
     const uint64_t nwork = a.nframes * a.ngroup;
     const uint32_t gdw = a.gtiles * 64;                 // dwords staged per slot
 
-    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+    for (uint64_t step = blockIdx.x; step < nwork; step += gridDim.x) {
+        const uint64_t work = bb_perm(a.perm, step);
         const uint64_t f = work / a.ngroup;
         const uint32_t g = (uint32_t)(work - f * a.ngroup);
         const uint64_t dw0 = (uint64_t)g * gdw;         // first dword of the group

@@ -166,6 +166,7 @@ struct bb_m4_args {
     uint32_t sign_bit[8];   // 32 x uint8: output j -> bit position of its sign
     uint32_t mag_bit[8];    //                       ... of its magnitude
     float    fill, hi;
+    bb_perm_t perm;         // work order (bb_common.h)
 };
 
 #define BB_M4_SEG_TILES 32
@@ -204,7 +205,8 @@ void k_decode_mark4(bb_m4_args a)
     word_t cur[TPW], nxt[TPW];
     bool cur_valid = false, nxt_valid = false;
 
-    auto issue = [&](uint64_t work, word_t (&w)[TPW], bool &valid) {
+    auto issue = [&](uint64_t step, word_t (&w)[TPW], bool &valid) {
+        const uint64_t work = bb_perm(a.perm, step);
         uint64_t f, seg;
         if (a.nseg == 1) { f = work; seg = 0; }
         else { f = work / a.nseg; seg = work - f * a.nseg; }
@@ -226,9 +228,10 @@ void k_decode_mark4(bb_m4_args a)
     for (; work < nwork; work += gridDim.x) {
         const uint64_t next = work + gridDim.x;
         if (next < nwork) issue(next, nxt, nxt_valid);
+        const uint64_t pwork = bb_perm(a.perm, work);
         uint64_t f, seg;
-        if (a.nseg == 1) { f = work; seg = 0; }
-        else { f = work / a.nseg; seg = work - f * a.nseg; }
+        if (a.nseg == 1) { f = pwork; seg = 0; }
+        else { f = pwork / a.nseg; seg = pwork - f * a.nseg; }
         float *obase = a.out + f * E;
         const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
         const uint64_t w_end = (seg + 1) * a.seg_tiles * 64 < a.nwords

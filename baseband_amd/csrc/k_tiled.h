@@ -37,6 +37,7 @@ struct bb_tiled_args {
     uint32_t tcp;               // LDS row pitch in elements: even, odd number of dwords
     uint32_t ntt, nct;          // tiles per frame along time / channel
     float    fill_re, fill_im;
+    bb_perm_t perm;         // work order (bb_common.h)
 };
 
 template <int LAYOUT, bool NT>
@@ -51,7 +52,8 @@ void k_decode_i8_tiled(bb_tiled_args a)
     const uint64_t nwork = a.nframes * a.ntt * a.nct;
     const uint32_t tile_elems = tt * npol * tc;
 
-    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+    for (uint64_t step = blockIdx.x; step < nwork; step += gridDim.x) {
+        const uint64_t work = bb_perm(a.perm, step);
         const uint64_t f = work / ((uint64_t)a.ntt * a.nct);
         const uint32_t rem = (uint32_t)(work - f * a.ntt * a.nct);
         const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
@@ -187,7 +189,8 @@ void k_decode_i8_stage(bb_tiled_args a)
     const uint64_t nwork = a.nframes * a.ntt * a.nct;
     const int lane = bb_lane(), wave = bb_wave();
 
-    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+    for (uint64_t step = blockIdx.x; step < nwork; step += gridDim.x) {
+        const uint64_t work = bb_perm(a.perm, step);
         const uint64_t f = work / ((uint64_t)a.ntt * a.nct);
         const uint32_t rem = (uint32_t)(work - f * a.ntt * a.nct);
         const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;

@@ -1,0 +1,179 @@
+// int8 (re, im) pairs -> complex64 with an axis permutation: the fast form.
+//
+// Replaces (reference, path:line) what k_tiled.h replaces --
+//   GUPPI channels-first  words.reshape(nchan, -1, npol) -> (time, pol, chan)   (guppi/payload.py:90-96)
+//   GUPPI time-first      .reshape(-1, nchan, npol).transpose(0, 2, 1)          (guppi/payload.py:97-102)
+//   MKBF heaps            np.moveaxis(words["heaps"], -1, 1)                    (dada/payload.py:76-79)
+//   and the int8 -> float32 casts (guppi/payload.py:13-14, dada/payload.py:13-14)
+// -- for the common geometry: payloads whose input runs are 16-byte aligned
+// (bbdecode.hip checks; everything else stays with k_tiled.h).
+//
+// What is different from k_tiled.h (0.57-0.61 of the HBM peak there):
+//  * 16 bytes per lane along the contiguous INPUT axis (a tile's 16 KiB arrive
+//    with four wave-wide 4 KiB loads per workgroup instead of sixteen 1 KiB ones);
+//  * the LDS image is made of DWORDS, never 2-byte pieces: an input dword is two
+//    elements that are neighbours along the input axis; it is written as it is
+//    (conflict-free ds_write_b32, row pitch odd) and the store phase reads the two
+//    dwords that hold its (chan, chan + 1) pair and takes the half it needs;
+//  * persistent grid, software pipelined: the loads of a workgroup's NEXT tile
+//    are in flight (in registers) while the current tile is being stored, as in
+//    k_decode_flat_aln;
+//  * work dealt over 16 stripes of the launch (bb_perm_t).
+//
+// A tile is 128 output rows (of up to 64 channels = 512 bytes each) x 64
+// channels; lanes 0-31 of a store instruction write one output row, lanes
+// 32-63 the next, so a wave stores 1 KiB contiguous when the tile spans all
+// channels.
+//   LAYOUT 0  GUPPI (chan, time, pol): input row = a channel, elements i = t * npol + p;
+//             LDS D[i / 2][chan]; output row = i
+//   LAYOUT 1  MKBF (heap, pol, chan, 256 times): input row = (pol, chan), 128 / npol times;
+//             LDS D[pol][t / 2][chan]; output row = t * npol + pol
+//   LAYOUT 2  GUPPI (time, chan, pol), npol = 2: input row = a time (64 channels x 2 pol);
+//             LDS D[t][chan] (a dword = both pols of one channel); output row = t * 2 + pol
+#pragma once
+#include "k_tiled.h"
+
+#define BB_XP_ROWS 128      // output rows per tile
+#define BB_XP_TC 64         // channels per tile
+#define BB_XP_PITCH 65      // LDS row pitch in dwords (odd)
+
+template <int LAYOUT, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_i8_xpose(bb_tiled_args a)
+{
+    __shared__ uint32_t s_d[64 * BB_XP_PITCH];
+    const uint32_t npol = a.npol;
+    const uint64_t rows_out = (a.t_hi - a.t_lo) * npol;         // output rows per frame
+    const uint64_t rowlen = (uint64_t)a.nchan * 2;              // floats per output row
+    // tile grid of a frame: a.ntt tiles along the output rows, a.nct along channels
+    const uint64_t per_frame = (uint64_t)a.ntt * a.nct;
+    const uint64_t nwork = a.nframes * per_frame;
+    const uint32_t tid = threadIdx.x;
+    // times per tile
+    const uint32_t tt = LAYOUT == 0 ? 0u : BB_XP_ROWS / npol;
+
+    bb_u4 nxt[4];
+    bool nxt_valid = false;
+
+    // which piece of the tile this thread loads in round k (k = 0..3)
+    auto issue = [&](uint64_t step, bb_u4 (&w)[4], bool &valid) {
+        const uint64_t work = bb_perm(a.perm, step);
+        const uint64_t f = work / per_frame;
+        const uint32_t rem = (uint32_t)(work - f * per_frame);
+        const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
+        const uint32_t c0 = ci * BB_XP_TC;
+        const uint32_t ncv = (a.nchan - c0 < BB_XP_TC) ? a.nchan - c0 : BB_XP_TC;
+        const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
+        valid = so >= 0;
+        const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t g = (uint32_t)k * BB_BLOCK + tid;        // 16-byte piece of the tile
+            const uint16_t *ptr = in;
+            bool want = valid;
+            if (LAYOUT == 0) {
+                // 64 channel rows x 16 pieces of 8 elements
+                const uint32_t c = g >> 4, piece = g & 15;
+                const uint64_t i0 = a.t_lo * npol + (uint64_t)ti * BB_XP_ROWS;
+                const uint64_t i = i0 + piece * 8;
+                want = want && c < ncv && i < a.t_hi * npol;
+                ptr = in + (uint64_t)(c0 + c) * a.sc + i;
+            } else if (LAYOUT == 1) {
+                // npol * 64 (pol, chan) rows x (128 / npol / 8) pieces of 8 times
+                const uint32_t ppr = tt >> 3;                       // pieces per row: 16 or 8
+                const uint32_t row = g / ppr, piece = g - row * ppr;
+                const uint32_t p = row >> 6, c = row & 63;
+                const uint64_t t = a.t_lo + (uint64_t)ti * tt + piece * 8;
+                want = want && c < ncv && t < a.t_hi;
+                ptr = in + (t >> 8) * a.sh + (t & 255) + (uint64_t)p * a.sp + (uint64_t)(c0 + c) * a.sc;
+            } else {
+                // 64 times x 16 pieces of 4 channels (both pols)
+                const uint32_t tl = g >> 4, piece = g & 15;
+                const uint64_t t = a.t_lo + (uint64_t)ti * tt + tl;
+                want = want && t < a.t_hi && piece * 4 < ncv;
+                ptr = in + (t * a.nchan + c0 + piece * 4) * 2;
+            }
+            w[k] = want ? *reinterpret_cast<const bb_u4 *>(ptr) : bb_u4{0u, 0u, 0u, 0u};
+        }
+    };
+
+    uint64_t step = blockIdx.x;
+    if (step < nwork) issue(step, nxt, nxt_valid);
+    for (; step < nwork; step += gridDim.x) {
+        // registers -> LDS image of this tile
+        const bool valid = nxt_valid;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t g = (uint32_t)k * BB_BLOCK + tid;
+            uint32_t base;
+            if (LAYOUT == 0) {
+                const uint32_t c = g >> 4, piece = g & 15;
+                base = (piece * 4) * BB_XP_PITCH + c;               // D[piece*4 + j][c]
+                s_d[base] = nxt[k].x;
+                s_d[base + BB_XP_PITCH] = nxt[k].y;
+                s_d[base + 2 * BB_XP_PITCH] = nxt[k].z;
+                s_d[base + 3 * BB_XP_PITCH] = nxt[k].w;
+            } else if (LAYOUT == 1) {
+                const uint32_t ppr = tt >> 3;
+                const uint32_t row = g / ppr, piece = g - row * ppr;
+                const uint32_t p = row >> 6, c = row & 63;
+                base = (p * (tt >> 1) + piece * 4) * BB_XP_PITCH + c;   // D[p][piece*4 + j][c]
+                s_d[base] = nxt[k].x;
+                s_d[base + BB_XP_PITCH] = nxt[k].y;
+                s_d[base + 2 * BB_XP_PITCH] = nxt[k].z;
+                s_d[base + 3 * BB_XP_PITCH] = nxt[k].w;
+            } else {
+                const uint32_t tl = g >> 4, piece = g & 15;
+                base = tl * BB_XP_PITCH + piece * 4;                // D[t][piece*4 + j]
+                s_d[base] = nxt[k].x;
+                s_d[base + 1] = nxt[k].y;
+                s_d[base + 2] = nxt[k].z;
+                s_d[base + 3] = nxt[k].w;
+            }
+        }
+        __syncthreads();
+        const uint64_t next = step + gridDim.x;
+        if (next < nwork) issue(next, nxt, nxt_valid);
+
+        // LDS -> global
+        const uint64_t work = bb_perm(a.perm, step);
+        const uint64_t f = work / per_frame;
+        const uint32_t rem = (uint32_t)(work - f * per_frame);
+        const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
+        const uint32_t c0 = ci * BB_XP_TC;
+        const uint32_t ncv = (a.nchan - c0 < BB_XP_TC) ? a.nchan - c0 : BB_XP_TC;
+        const uint64_t row0 = (uint64_t)ti * BB_XP_ROWS;            // first output row of the tile in its frame
+        float *obase = a.out + (f * rows_out + row0) * rowlen + (uint64_t)c0 * 2;
+        const uint64_t rows_left = rows_out - row0;
+        const uint32_t cp = tid & 31;                               // channel pair
+        const uint32_t rsub = tid >> 5;                             // row within a group of 8
+        const bb_f4 fillv = {a.fill_re, a.fill_im, a.fill_re, a.fill_im};
+#pragma unroll
+        for (int q = 0; q < BB_XP_ROWS / 8; ++q) {
+            const uint32_t r = (uint32_t)q * 8 + rsub;              // output row of the tile
+            uint32_t idx, half;
+            if (LAYOUT == 0) { idx = (r >> 1) * BB_XP_PITCH; half = r & 1; }
+            else if (LAYOUT == 1) {
+                const uint32_t tl = npol == 2 ? r >> 1 : r, p = npol == 2 ? r & 1 : 0;
+                idx = (p * (tt >> 1) + (tl >> 1)) * BB_XP_PITCH; half = tl & 1;
+            } else { idx = (r >> 1) * BB_XP_PITCH; half = r & 1; }
+            const uint32_t x = s_d[idx + 2 * cp], y = s_d[idx + 2 * cp + 1];
+            if (r >= rows_left || 2 * cp >= ncv) continue;
+            const uint32_t e0 = half ? x >> 16 : x & 0xffffu;
+            const uint32_t e1 = half ? y >> 16 : y & 0xffffu;
+            bb_f4 v;
+            if (valid) {
+                v.x = (float)(int)(int8_t)(e0 & 0xff);
+                v.y = (float)(int)(int8_t)(e0 >> 8);
+                v.z = (float)(int)(int8_t)(e1 & 0xff);
+                v.w = (float)(int)(int8_t)(e1 >> 8);
+            } else {
+                v = fillv;
+            }
+            float *o = obase + (uint64_t)r * rowlen + 4 * cp;
+            if (2 * cp + 1 < ncv) bb_store4<NT>(o, v);
+            else { bb_store1<NT>(o, v.x); bb_store1<NT>(o + 1, v.y); }
+        }
+        __syncthreads();
+    }
+}

@@ -329,3 +329,51 @@ def test_small_reads_row_staging_equals_whole_frame_staging(manifest, fmt, name)
             fh.seek(off)
             third = fh.read(cnt).cpu().numpy()          # served from the cached frame
         assert bits_equal(first, again) and bits_equal(again, third), (off, cnt)
+
+
+def test_xpose_kernel_raw_layouts():
+    """k_decode_i8_xpose (16-byte aligned input runs, >= 32 channels): all three
+    layouts vs NumPy transposes -- ragged channel tiles, partial time ranges
+    (GUPPI overlap, MKBF heaps), several frames, time ranges that end inside a
+    16-byte piece; and the geometries it must hand back to k_tiled.h."""
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(31)
+    cases = ((0, 2, 64, 1024, 32), (0, 2, 96, 520, 16), (0, 1, 64, 640, 16), (0, 2, 32, 300, 64),
+             (0, 2, 200, 136, 16), (0, 4, 64, 260, 16),
+             (1, 2, 64, 1024, 16), (1, 2, 96, 512, 32), (1, 1, 64, 768, 16), (1, 2, 32, 256, 16),
+             (2, 2, 64, 300, 16), (2, 2, 100, 130, 32), (2, 2, 1024, 70, 16), (2, 2, 32, 129, 16))
+    for layout, npol, nchan, T, head in cases:
+        nfr = 3
+        pn = T * npol * nchan * 2
+        stride = pn + head + (-(pn + head)) % 16
+        raw = rng.integers(0, 256, size=(nfr, stride), dtype=np.uint8)
+        b = np.ascontiguousarray(raw[:, head:head + pn]).view(np.int8)
+        if layout == 0:
+            ref = b.reshape(nfr, nchan, T, npol, 2).transpose(0, 2, 3, 1, 4)
+        elif layout == 1:
+            ref = b.reshape(nfr, T // 256, npol, nchan, 256, 2).transpose(0, 1, 4, 2, 3, 5) \
+                .reshape(nfr, T, npol, nchan, 2)
+        else:
+            ref = b.reshape(nfr, T, nchan, npol, 2).transpose(0, 1, 3, 2, 4)
+        ref = np.ascontiguousarray(ref).astype(np.float32)
+        dbuf = kernels.to_device_bytes(raw.reshape(-1))
+        unit = 8 // npol if layout == 0 else (8 if layout == 1 else 1)
+        for lo, hi in ((0, T), (unit * 2, T - 5), (0, T - T // 3), (unit * 3, unit * 3 + 1)):
+            out = kernels.decode_i8_tiled(dbuf, nfr, layout, npol, nchan, T, lo, hi,
+                                          src0=head, src_stride=stride).cpu().numpy()
+            assert 'k_decode_i8_xpose' in _lib.last_kernel(), (_lib.last_kernel(), layout, npol, nchan, T, lo)
+            want = ref[:, lo:hi].reshape(-1)
+            assert bits_equal(out, np.ascontiguousarray(want)), (layout, npol, nchan, T, lo, hi)
+        # a start that breaks the 16-byte alignment of the input runs goes to the general kernel
+        if layout in (0, 1):
+            out = kernels.decode_i8_tiled(dbuf, nfr, layout, npol, nchan, T, 3, T,
+                                          src0=head, src_stride=stride).cpu().numpy()
+            assert 'k_decode_i8_xpose' not in _lib.last_kernel()
+            assert bits_equal(out, np.ascontiguousarray(ref[:, 3:].reshape(-1)))
+    # the switch
+    kernels.tune(_lib.TUNE_XPOSE, 0)
+    try:
+        kernels.decode_i8_tiled(dbuf, nfr, layout, npol, nchan, T, 0, T, src0=head, src_stride=stride)
+        assert 'k_decode_i8_xpose' not in _lib.last_kernel()
+    finally:
+        kernels.tune(_lib.TUNE_XPOSE, 1)
