@@ -161,18 +161,23 @@ std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
-std::atomic<int> g_tune_order_lw{4};     // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order
+std::atomic<int> g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 std::atomic<int> g_tune_stripe_w{0};     // experiment: output striping (bb_flat_args::stripe_w)
 std::atomic<int> g_tune_stripe_s{0};     // ... distance between the stripes, in frame-slots
 std::atomic<int> g_tune_front_g{2048};  // k_decode_flat_front: workgroups per group (one write front)
 std::atomic<int> g_tune_front_k{16};    // k_decode_flat_front: steps a group sweeps
 
-// Work order of a launch of `nwork` items (bb_common.h, bb_perm_t): 16 stripes
-// by default; launches of fewer than 64 items per stripe keep file order.
-bb_perm_t make_perm(uint64_t nwork)
+// Work order of a launch of `nwork` items writing `out_bytes` (bb_common.h,
+// bb_perm_t).  Default (knob -1): 16 stripes for outputs of 16 GiB and more,
+// 4 below; launches of fewer than 64 items per stripe keep file order.
+// Measured with every kernel family at 2^16 .. 2^20 frames
+// (profiles/r02e_exp_order.log): 33 GB outputs +12-15 % (5.5-5.6 -> 6.1-6.45
+// TB/s), 67 GB +4-6 %, 134 GB +-2 %, 8 GB: 4 stripes +0-2 %, 16 stripes -0-3 %.
+bb_perm_t make_perm(uint64_t nwork, uint64_t out_bytes)
 {
     bb_perm_t p = {0, 0, 0};
-    const int lw = g_tune_order_lw.load();
+    int lw = g_tune_order_lw.load();
+    if (lw < 0) lw = out_bytes >= (16ull << 30) ? 4 : 2;
     if (lw > 0 && (nwork >> lw) >= 64) {
         p.lw = (uint32_t)lw;
         p.stripe = nwork >> lw;
@@ -342,7 +347,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
-        case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : 4; return BB_OK;
+        case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
         case BB_TUNE_OUT_STRIPE_W: g_tune_stripe_w = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_OUT_STRIPE_S: g_tune_stripe_s = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_FRONT_GROUP: g_tune_front_g = (value >= 1 && value <= (1 << 20)) ? value : 2048; return BB_OK;
@@ -548,7 +553,8 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     }
 
     const uint64_t nwork = nfs * a.nseg;
-    a.perm = make_perm(nwork);              // (branches that cut the work differently set their own)
+    const uint64_t out_bytes = nfs * E * 4;
+    a.perm = make_perm(nwork, out_bytes);   // (branches that cut the work differently set their own)
     uint64_t blocks = nwork;
     const int tb = g_tune_blocks.load();
     if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
@@ -574,11 +580,9 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     // how fast depends on the allocation, the plain kernel does 5.4-5.7
     // everywhere (profiles/r01i_exp_launch_size.log, r01i_exp_launch_fresh.log).
     // An explicit BB_TUNE_BLOCKS keeps the pipelined kernel (experiments).
-    if (variant == 5 && om == BB_OUT_FLAT && tb == 0) {
-        const uint64_t seg5 = 2ull * (uint64_t)g_tune_tpw.load();
-        const uint64_t nwork5 = nfs * ((ntiles + seg5 - 1) / seg5);
-        if (nwork5 >= BB_GRID_CAP && nwork5 < 3 * BB_GRID_CAP) variant = 0;
-    }
+    // (round 2: with the striped work order the two are equal there --
+    // 5.60 / 5.61 TB/s at 2^16 frames, profiles/r02e_exp_order.log -- and the
+    // fallback is gone)
 
     if (variant >= 6 && variant <= 9 && om == BB_OUT_FLAT) {
         // explicit write front (k_front.h): 6 = 4 waves x 1 tile, 7 = 4 x 2, 8 = 2 x 4, 9 = 4 x 4
@@ -649,7 +653,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // payload each); one workgroup per item costs 15 %, a few thousand
         // long-running ones 5-10 % (profiles/r01f_exp_gather*.log)
         uint64_t gb = (uint64_t)nframes * ga.ngroup;
-        ga.perm = make_perm(gb);
+        ga.perm = make_perm(gb, out_bytes);
         const uint64_t gcap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (gb > gcap) gb = gcap;
         if (gb > 0x7fffffffull) gb = 0x7fffffffull;
@@ -680,7 +684,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.tpw = a.seg_tiles;
         const uint64_t sgroups = ((uint64_t)p->nslot + nw - 1) / nw;
         uint64_t b2 = (uint64_t)nframes * a.nseg * sgroups;
-        a.perm = make_perm(b2);
+        a.perm = make_perm(b2, out_bytes);
         const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
@@ -740,7 +744,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
         a.tpw = (a.seg_tiles + nw - 1) / nw;
         uint64_t b2 = nfs * a.nseg;
-        a.perm = make_perm(b2);
+        a.perm = make_perm(b2, out_bytes);
         const uint64_t cap = tb > 0 ? (uint64_t)tb : (uint64_t)(wide ? BB_GRID_CAP : 4096);
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
@@ -904,7 +908,7 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
     a.fill = p->fill;
     a.hi = h_levels[BB_CODER_VDIF][1][3];
     uint64_t blocks = (uint64_t)nframes * a.nseg;
-    a.perm = make_perm(blocks);
+    a.perm = make_perm(blocks, (uint64_t)nframes * E * 4);
     const int tb = g_tune_blocks.load();
     const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;      // persistent grid
     if (blocks > cap) blocks = cap;
@@ -986,7 +990,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
             a.ntt = (uint32_t)ntt; a.nct = (uint32_t)nct;
             a.tt = (uint32_t)(BB_XP_ROWS / np_); a.tc = BB_XP_TC; a.tcp = 2 * BB_XP_PITCH;
             uint64_t blocks = (uint64_t)nframes * ntt * nct;
-            a.perm = make_perm(blocks);
+            a.perm = make_perm(blocks, (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4);
             const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
             if (blocks > cap) blocks = cap;
             const dim3 grid((unsigned)blocks), block(BB_BLOCK);
@@ -1043,7 +1047,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     a.nct = (uint32_t)nct;
     if (lds > 64 * 1024) return BB_ENOTSUP;
     uint64_t blocks = (uint64_t)nframes * ntt * nct;
-    a.perm = make_perm(blocks);
+    a.perm = make_perm(blocks, (uint64_t)nframes * rows * rowlen * 4);
     if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);

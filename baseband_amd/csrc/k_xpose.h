@@ -37,8 +37,12 @@
 #define BB_XP_TC 64         // channels per tile
 #define BB_XP_PITCH 65      // LDS row pitch in dwords (odd)
 
+// (launch bounds: at least 6 waves per SIMD = 6 workgroups per CU; with the
+// store loop fully unrolled the compiler took 123-138 VGPRs = 3-4 workgroups per
+// CU, and a store-bound kernel whose waves all wait at the same barrier needs
+// more of them in flight: profiles/r02e_kernels.csv)
 template <int LAYOUT, bool NT>
-__global__ __launch_bounds__(BB_BLOCK)
+__global__ __launch_bounds__(BB_BLOCK, 6)
 void k_decode_i8_xpose(bb_tiled_args a)
 {
     __shared__ uint32_t s_d[64 * BB_XP_PITCH];
@@ -148,7 +152,7 @@ void k_decode_i8_xpose(bb_tiled_args a)
         const uint32_t cp = tid & 31;                               // channel pair
         const uint32_t rsub = tid >> 5;                             // row within a group of 8
         const bb_f4 fillv = {a.fill_re, a.fill_im, a.fill_re, a.fill_im};
-#pragma unroll
+#pragma unroll 4
         for (int q = 0; q < BB_XP_ROWS / 8; ++q) {
             const uint32_t r = (uint32_t)q * 8 + rsub;              // output row of the tile
             uint32_t idx, half;

@@ -482,17 +482,22 @@ def leg_api_read(args, image, out, kern_ms):
             "timing": "host wall clock around read() incl. the verification sync, mean of {} calls".format(args.steps)}
 
 
-def leg_other_configs(device, out, gib=4.0, reps=5):
-    """Kernel-level figures for the other BASELINE configurations on `gib` of
-    random input each: (ms, algorithmic GB/s, fraction of 8 TB/s, kernel as
-    named by the library)."""
+def leg_other_configs(device, out, gib=4.0, gib8=16.0, reps=5):
+    """Kernel-level figures for the other BASELINE configurations on random
+    input -- `gib` GiB for the 2-bit formats, `gib8` for the 8-bit ones, i.e.
+    64-69 GB of decoded output each: (ms, algorithmic GB/s, fraction of 8 TB/s,
+    kernel as named by the library)."""
     from baseband_amd import kernels, _lib
     from baseband_amd.mark4._bitmaps import BITMAPS
     nbytes = int(gib * 2 ** 30)
+    nbytes8 = int(min(gib8 * 2 ** 30, out.numel()))
     g = torch.Generator(device=device)
     g.manual_seed(4242)
-    buf = torch.randint(-2 ** 31, 2 ** 31 - 1, (nbytes // 4 + 1024,), generator=g, device=device,
-                        dtype=torch.int64).to(torch.int32).view(torch.uint8)
+    buf = torch.empty(max(nbytes, nbytes8) + 4096, dtype=torch.uint8, device=device)
+    for lo in range(0, buf.numel() // 4, 1 << 28):
+        hi = min(buf.numel() // 4, lo + (1 << 28))
+        buf.view(torch.int32)[lo:hi] = torch.randint(-2 ** 31, 2 ** 31 - 1, (hi - lo,), generator=g,
+                                                     device=device, dtype=torch.int64).to(torch.int32)
     res = []
 
     def add(name, fn, bytes_in, bytes_out, units, unit_name):
@@ -531,6 +536,7 @@ def leg_other_configs(device, out, gib=4.0, reps=5):
     # cfg5a: GUPPI 8-bit 2 pol complex 64 channels, channels first, 128 MiB blocks
     npol, nchan, blk = 2, 64, 128 << 20
     T = blk // (npol * nchan * 2)
+    nbytes = nbytes8
     nfr = max(1, nbytes // blk)
     nb = nfr * T * npol * nchan * 2
     o = out[:nb]
@@ -568,7 +574,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--gib', type=float, default=8.0, help="file image size per GPU")
-    ap.add_argument('--cfg3-gib', type=float, default=2.0, help="cfg3 leg: file bytes per GPU")
+    ap.add_argument('--cfg3-gib', type=float, default=4.0, help="cfg3 leg: file bytes per GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic', choices=('live', 'file', 'none'), default='live')
     ap.add_argument('--no-extra-legs', action='store_true',

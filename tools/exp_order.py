@@ -25,7 +25,7 @@ def cases(nfr, o):
     nsets = nfr // 8
     pos = torch.arange(nsets, device=dev, dtype=torch.int64)[:, None] * 8 + perm8[None, :]
     src8 = (pos * stride + header).reshape(-1).contiguous()
-    nf4 = nfr * stride // 160000
+    nf4 = nfr * per // 640000
     return {
         "flat (cfg2)": (lambda: kernels.decode_frames(buf, nfr, payload, 0, 2, src0=header, src_stride=stride, out=o), nfr * (stride + payload * 16)),
         "rows 8 thr x 16 ch complex (cfg3)": (lambda: kernels.decode_frames(buf, nsets, payload, 0, 2, chunk=32, nslot=8, src=src8, complex_data=True, out=o), nsets * 8 * (stride + payload * 16)),
