@@ -48,6 +48,7 @@ TUNE_OUT_STRIPE_W = 16
 TUNE_OUT_STRIPE_S = 17
 TUNE_WORK_STRIPES = 18
 TUNE_XPOSE = 19
+TUNE_XPOSE_ROWS = 20
 
 
 class BBError(RuntimeError):

@@ -160,6 +160,7 @@ std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_xpose_rows{128}; // k_decode_i8_xpose: output rows per tile (128 or 64)
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
 std::atomic<int> g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 std::atomic<int> g_tune_stripe_w{0};     // experiment: output striping (bb_flat_args::stripe_w)
@@ -347,6 +348,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
+        case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : 128; return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
         case BB_TUNE_OUT_STRIPE_W: g_tune_stripe_w = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_OUT_STRIPE_S: g_tune_stripe_s = value > 0 ? value : 0; return BB_OK;
@@ -985,25 +987,34 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
         else
             ok = ok && np_ == 2 && (nc % 4 == 0);
         if (ok) {
-            const uint64_t ntt = (rows + BB_XP_ROWS - 1) / BB_XP_ROWS, nct = (nc + BB_XP_TC - 1) / BB_XP_TC;
+            const uint64_t xrows = (uint64_t)g_tune_xpose_rows.load();
+            const uint64_t ntt = (rows + xrows - 1) / xrows, nct = (nc + BB_XP_TC - 1) / BB_XP_TC;
             if (ntt > 0xffffffffull) return BB_ERANGE;
             a.ntt = (uint32_t)ntt; a.nct = (uint32_t)nct;
-            a.tt = (uint32_t)(BB_XP_ROWS / np_); a.tc = BB_XP_TC; a.tcp = 2 * BB_XP_PITCH;
+            a.tt = (uint32_t)(xrows / np_); a.tc = BB_XP_TC; a.tcp = 2 * BB_XP_PITCH;
             uint64_t blocks = (uint64_t)nframes * ntt * nct;
             a.perm = make_perm(blocks, (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4);
-            const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
+            // one tile per workgroup: with 20 % of the traffic being reads the
+            // dispatcher overlaps loads and stores of many small workgroups
+            // better than a persistent pipelined grid does (16 GiB of input,
+            // profiles/r02g_exp_i8_grid.log: 5.16-5.31 TB/s with 131072
+            // workgroups, 5.62-5.66 with one per tile; the flat int8 kernel
+            // behaves the same way)
+            const uint64_t cap = tb > 0 ? (uint64_t)tb : 0x7fffffffull;
             if (blocks > cap) blocks = cap;
             const dim3 grid((unsigned)blocks), block(BB_BLOCK);
-#define BB_XP(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_xpose<L, true>), grid, block, 0, st, a); \
-                      else    hipLaunchKernelGGL((k_decode_i8_xpose<L, false>), grid, block, 0, st, a); } while (0)
+#define BB_XP(L) do { if (xrows == 64) { if (nt) hipLaunchKernelGGL((k_decode_i8_xpose<L, true, 64>), grid, block, 0, st, a); \
+                                         else    hipLaunchKernelGGL((k_decode_i8_xpose<L, false, 64>), grid, block, 0, st, a); } \
+                      else { if (nt) hipLaunchKernelGGL((k_decode_i8_xpose<L, true, 128>), grid, block, 0, st, a); \
+                             else    hipLaunchKernelGGL((k_decode_i8_xpose<L, false, 128>), grid, block, 0, st, a); } } while (0)
             switch (p->layout) {
                 case BB_LAYOUT_GUPPI_CF: BB_XP(0); break;
                 case BB_LAYOUT_MKBF:     BB_XP(1); break;
                 default:                 BB_XP(2); break;
             }
 #undef BB_XP
-            BB_NOTE("k_decode_i8_xpose<%d,%s> grid %u tiles %u x %u per frame", p->layout, nt ? "nt" : "plain",
-                    grid.x, a.ntt, a.nct);
+            BB_NOTE("k_decode_i8_xpose<%d,%s,%d> grid %u tiles %u x %u per frame", p->layout, nt ? "nt" : "plain",
+                    (int)xrows, grid.x, a.ntt, a.nct);
             BB_HIP(hipGetLastError());
             return BB_OK;
         }

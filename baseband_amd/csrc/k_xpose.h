@@ -20,8 +20,8 @@
 //    k_decode_flat_aln;
 //  * work dealt over 16 stripes of the launch (bb_perm_t).
 //
-// A tile is 128 output rows (of up to 64 channels = 512 bytes each) x 64
-// channels; lanes 0-31 of a store instruction write one output row, lanes
+// A tile is ROWS (128 or 64) output rows (of up to 64 channels = 512 bytes each)
+// x 64 channels; lanes 0-31 of a store instruction write one output row, lanes
 // 32-63 the next, so a wave stores 1 KiB contiguous when the tile spans all
 // channels.
 //   LAYOUT 0  GUPPI (chan, time, pol): input row = a channel, elements i = t * npol + p;
@@ -33,7 +33,6 @@
 #pragma once
 #include "k_tiled.h"
 
-#define BB_XP_ROWS 128      // output rows per tile
 #define BB_XP_TC 64         // channels per tile
 #define BB_XP_PITCH 65      // LDS row pitch in dwords (odd)
 
@@ -41,11 +40,13 @@
 // store loop fully unrolled the compiler took 123-138 VGPRs = 3-4 workgroups per
 // CU, and a store-bound kernel whose waves all wait at the same barrier needs
 // more of them in flight: profiles/r02e_kernels.csv)
-template <int LAYOUT, bool NT>
+template <int LAYOUT, bool NT, int ROWS>
 __global__ __launch_bounds__(BB_BLOCK, 6)
 void k_decode_i8_xpose(bb_tiled_args a)
 {
-    __shared__ uint32_t s_d[64 * BB_XP_PITCH];
+    constexpr int NLOAD = ROWS / 32;            // 16-byte loads per thread and tile
+    constexpr uint32_t LPR = ROWS / 8;          // LAYOUT 0: pieces per channel row (power of two)
+    __shared__ uint32_t s_d[(ROWS / 2) * BB_XP_PITCH];
     const uint32_t npol = a.npol;
     const uint64_t rows_out = (a.t_hi - a.t_lo) * npol;         // output rows per frame
     const uint64_t rowlen = (uint64_t)a.nchan * 2;              // floats per output row
@@ -54,13 +55,13 @@ void k_decode_i8_xpose(bb_tiled_args a)
     const uint64_t nwork = a.nframes * per_frame;
     const uint32_t tid = threadIdx.x;
     // times per tile
-    const uint32_t tt = LAYOUT == 0 ? 0u : BB_XP_ROWS / npol;
+    const uint32_t tt = LAYOUT == 0 ? 0u : ROWS / npol;
 
-    bb_u4 nxt[4];
+    bb_u4 nxt[NLOAD];
     bool nxt_valid = false;
 
     // which piece of the tile this thread loads in round k (k = 0..3)
-    auto issue = [&](uint64_t step, bb_u4 (&w)[4], bool &valid) {
+    auto issue = [&](uint64_t step, bb_u4 (&w)[NLOAD], bool &valid) {
         const uint64_t work = bb_perm(a.perm, step);
         const uint64_t f = work / per_frame;
         const uint32_t rem = (uint32_t)(work - f * per_frame);
@@ -71,27 +72,27 @@ void k_decode_i8_xpose(bb_tiled_args a)
         valid = so >= 0;
         const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NLOAD; ++k) {
             const uint32_t g = (uint32_t)k * BB_BLOCK + tid;        // 16-byte piece of the tile
             const uint16_t *ptr = in;
             bool want = valid;
             if (LAYOUT == 0) {
-                // 64 channel rows x 16 pieces of 8 elements
-                const uint32_t c = g >> 4, piece = g & 15;
-                const uint64_t i0 = a.t_lo * npol + (uint64_t)ti * BB_XP_ROWS;
+                // 64 channel rows x ROWS / 8 pieces of 8 elements
+                const uint32_t c = g / LPR, piece = g % LPR;
+                const uint64_t i0 = a.t_lo * npol + (uint64_t)ti * ROWS;
                 const uint64_t i = i0 + piece * 8;
                 want = want && c < ncv && i < a.t_hi * npol;
                 ptr = in + (uint64_t)(c0 + c) * a.sc + i;
             } else if (LAYOUT == 1) {
-                // npol * 64 (pol, chan) rows x (128 / npol / 8) pieces of 8 times
-                const uint32_t ppr = tt >> 3;                       // pieces per row: 16 or 8
+                // npol * 64 (pol, chan) rows x (ROWS / npol / 8) pieces of 8 times
+                const uint32_t ppr = tt >> 3;                       // pieces per row
                 const uint32_t row = g / ppr, piece = g - row * ppr;
                 const uint32_t p = row >> 6, c = row & 63;
                 const uint64_t t = a.t_lo + (uint64_t)ti * tt + piece * 8;
                 want = want && c < ncv && t < a.t_hi;
                 ptr = in + (t >> 8) * a.sh + (t & 255) + (uint64_t)p * a.sp + (uint64_t)(c0 + c) * a.sc;
             } else {
-                // 64 times x 16 pieces of 4 channels (both pols)
+                // ROWS / 2 times x 16 pieces of 4 channels (both pols)
                 const uint32_t tl = g >> 4, piece = g & 15;
                 const uint64_t t = a.t_lo + (uint64_t)ti * tt + tl;
                 want = want && t < a.t_hi && piece * 4 < ncv;
@@ -107,11 +108,11 @@ void k_decode_i8_xpose(bb_tiled_args a)
         // registers -> LDS image of this tile
         const bool valid = nxt_valid;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NLOAD; ++k) {
             const uint32_t g = (uint32_t)k * BB_BLOCK + tid;
             uint32_t base;
             if (LAYOUT == 0) {
-                const uint32_t c = g >> 4, piece = g & 15;
+                const uint32_t c = g / LPR, piece = g % LPR;
                 base = (piece * 4) * BB_XP_PITCH + c;               // D[piece*4 + j][c]
                 s_d[base] = nxt[k].x;
                 s_d[base + BB_XP_PITCH] = nxt[k].y;
@@ -146,14 +147,14 @@ void k_decode_i8_xpose(bb_tiled_args a)
         const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
         const uint32_t c0 = ci * BB_XP_TC;
         const uint32_t ncv = (a.nchan - c0 < BB_XP_TC) ? a.nchan - c0 : BB_XP_TC;
-        const uint64_t row0 = (uint64_t)ti * BB_XP_ROWS;            // first output row of the tile in its frame
+        const uint64_t row0 = (uint64_t)ti * ROWS;            // first output row of the tile in its frame
         float *obase = a.out + (f * rows_out + row0) * rowlen + (uint64_t)c0 * 2;
         const uint64_t rows_left = rows_out - row0;
         const uint32_t cp = tid & 31;                               // channel pair
         const uint32_t rsub = tid >> 5;                             // row within a group of 8
         const bb_f4 fillv = {a.fill_re, a.fill_im, a.fill_re, a.fill_im};
 #pragma unroll 4
-        for (int q = 0; q < BB_XP_ROWS / 8; ++q) {
+        for (int q = 0; q < ROWS / 8; ++q) {
             const uint32_t r = (uint32_t)q * 8 + rsub;              // output row of the tile
             uint32_t idx, half;
             if (LAYOUT == 0) { idx = (r >> 1) * BB_XP_PITCH; half = r & 1; }

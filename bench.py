@@ -30,7 +30,7 @@ Besides the contract's keys the line carries
                 rank 0 scans the whole file and builds the frame index, ONE
                 broadcast (RCCL) replicates it, every rank decodes its slab
   other_configs Mark 5B / Mark 4 / GUPPI / DADA / 8-thread real VDIF kernels
-                on 4 GiB inputs (N = 1 only)
+                on inputs that decode to the headline's output size (N = 1 only)
 """
 import argparse
 import csv
@@ -482,10 +482,12 @@ def leg_api_read(args, image, out, kern_ms):
             "timing": "host wall clock around read() incl. the verification sync, mean of {} calls".format(args.steps)}
 
 
-def leg_other_configs(device, out, gib=4.0, gib8=16.0, reps=5):
+def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
     """Kernel-level figures for the other BASELINE configurations on random
-    input -- `gib` GiB for the 2-bit formats, `gib8` for the 8-bit ones, i.e.
-    64-69 GB of decoded output each: (ms, algorithmic GB/s, fraction of 8 TB/s,
+    input -- `gib` GiB for the 2-bit formats, `gib8` for the 8-bit ones, i.e. the
+    same 128-137 GB of decoded output as the headline launch each (the output
+    of a launch should span as much of HBM as the headline's does: DESIGN.md,
+    "Where the output lies"): (ms, algorithmic GB/s, fraction of 8 TB/s,
     kernel as named by the library)."""
     from baseband_amd import kernels, _lib
     from baseband_amd.mark4._bitmaps import BITMAPS
@@ -574,7 +576,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--gib', type=float, default=8.0, help="file image size per GPU")
-    ap.add_argument('--cfg3-gib', type=float, default=4.0, help="cfg3 leg: file bytes per GPU")
+    ap.add_argument('--cfg3-gib', type=float, default=8.0, help="cfg3 leg: file bytes per GPU")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic', choices=('live', 'file', 'none'), default='live')
     ap.add_argument('--no-extra-legs', action='store_true',

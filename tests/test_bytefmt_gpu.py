@@ -331,12 +331,14 @@ def test_small_reads_row_staging_equals_whole_frame_staging(manifest, fmt, name)
         assert bits_equal(first, again) and bits_equal(again, third), (off, cnt)
 
 
-def test_xpose_kernel_raw_layouts():
+@pytest.mark.parametrize('tile_rows', [128, 64])
+def test_xpose_kernel_raw_layouts(tile_rows):
     """k_decode_i8_xpose (16-byte aligned input runs, >= 32 channels): all three
     layouts vs NumPy transposes -- ragged channel tiles, partial time ranges
     (GUPPI overlap, MKBF heaps), several frames, time ranges that end inside a
     16-byte piece; and the geometries it must hand back to k_tiled.h."""
     from baseband_amd import kernels, _lib
+    kernels.tune(_lib.TUNE_XPOSE_ROWS, tile_rows)
     rng = np.random.default_rng(31)
     cases = ((0, 2, 64, 1024, 32), (0, 2, 96, 520, 16), (0, 1, 64, 640, 16), (0, 2, 32, 300, 64),
              (0, 2, 200, 136, 16), (0, 4, 64, 260, 16),
@@ -377,3 +379,4 @@ def test_xpose_kernel_raw_layouts():
         assert 'k_decode_i8_xpose' not in _lib.last_kernel()
     finally:
         kernels.tune(_lib.TUNE_XPOSE, 1)
+        kernels.tune(_lib.TUNE_XPOSE_ROWS, 128)
