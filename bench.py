@@ -512,7 +512,7 @@ def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
 
     # cfg0 layout: 8 threads x 1 channel 2-bit real, 5032-byte frames (sample.vdif)
     fn_, pn, nth = 5032, 5000, 8
-    nsets = nbytes // (fn_ * nth)
+    nsets = min(nbytes // (fn_ * nth), out.numel() // (nth * pn * 4))
     perm = torch.tensor([4, 0, 5, 1, 6, 2, 7, 3], device=device)
     pos = torch.arange(nsets, device=device, dtype=torch.int64)[:, None] * nth + perm[None, :]
     src = (pos * fn_ + 32).reshape(-1).contiguous()
@@ -521,7 +521,7 @@ def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
         lambda: kernels.decode_frames(buf, nsets, pn, _lib.CODER_VDIF, 2, chunk=1, nslot=nth, src=src, out=o),
         nsets * nth * fn_, o.numel() * 4, o.numel(), "samples")
     # cfg4a: Mark 5B 16 channels 2-bit
-    nfr = nbytes // 10016
+    nfr = min(nbytes // 10016, out.numel() // 40000)
     o = out[:nfr * 40000]
     add("Mark 5B 16 channels 2-bit",
         lambda: kernels.decode_frames(buf, nfr, 10000, _lib.CODER_MARK5B, 2, chunk=16, src0=16,
@@ -529,7 +529,7 @@ def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
         nfr * 10016, o.numel() * 4, o.numel(), "samples")
     # cfg4b: Mark 4 64 tracks fanout 4
     m = BITMAPS[(8, 2, 4)]
-    nfr = nbytes // 160000
+    nfr = min(nbytes // 160000, out.numel() // (20000 * 32))
     o = out[:nfr * 20000 * 32]
     add("Mark 4 64 tracks fanout 4 (8 channels 2-bit)",
         lambda: kernels.decode_mark4(buf, nfr, 64, 20000, m['sign_bit'], m['mag_bit'], fill_words=160,
