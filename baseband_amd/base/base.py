@@ -302,6 +302,8 @@ class GPUStreamReaderBase:
     def close(self):
         self._closed = True
         self._ahead = None
+        self._staged = self._sink = None
+        self._have = []
         if self._pipeline is not None:
             self._pipeline.release()
             self._pipeline = None
@@ -429,8 +431,73 @@ class GPUStreamReaderBase:
         return self
 
     def unstage(self):
-        """Drop the HBM copy made by `stage`."""
+        """Drop the HBM copy made by `stage` (and what reads have kept)."""
         self._staged = None
+        self._sink, self._have = None, []
+
+    # -- windows that were staged once stay in HBM
+    keep_staged = None      # None: keep when the file is at most a quarter of the GPU's memory
+    _sink = None            # device tensor of the file's size (+ slack), filled window by window
+    _have = ()              # merged byte intervals of `_sink` that hold file bytes
+
+    def _sink_tensor(self):
+        """The file-sized device tensor that large reads fill window by
+        window, or None when windows are not kept.  Keeping them makes a second
+        pass over the same bytes -- the corruption-tolerant re-read of
+        verify='fix', a repeated read -- come from HBM instead of crossing PCIe
+        again."""
+        if self._sink is not None:
+            return self._sink
+        keep = self.keep_staged
+        n = len(self._image())
+        if keep is None:
+            keep = n <= torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory // 4
+        if not keep or n == 0:
+            return None
+        self._sink = torch.empty(n + 256, dtype=torch.uint8, device='cuda')
+        self._sink[n:] = 0
+        self._have = []
+        return self._sink
+
+    def _mark_have(self, lo, hi):
+        if hi <= lo:
+            return
+        merged, placed = [], False
+        for a, b in self._have:
+            if b < lo or a > hi:
+                merged.append((a, b))
+            else:
+                lo, hi = min(lo, a), max(hi, b)
+        merged.append((lo, hi))
+        self._have = sorted(merged)
+
+    def _has_bytes(self, lo, hi):
+        return hi <= lo or any(a <= lo and hi <= b for a, b in self._have)
+
+    def _whole_file_in_hbm(self):
+        """Device tensor holding the complete file: the explicit or implicit
+        resident image, or the kept windows completed by uploading whatever
+        has not been staged yet (each byte crosses PCIe once)."""
+        from ..staging import upload
+        dev = self._resident_bytes()
+        image = self._image()
+        n = len(image)
+        if dev is not None:
+            if dev.data_ptr() % 16:             # the search kernels load 16 bytes per lane
+                dev = self._staged = dev.clone()
+            return dev
+        sink = self._sink_tensor()
+        if sink is None:
+            self._staged = upload(image)[:n]
+            return self._staged
+        pos = 0
+        for a, b in list(self._have) + [(n, n)]:
+            if a > pos:
+                sink[pos:a].copy_(upload(image[pos:a])[:a - pos])
+            pos = max(pos, b)
+        self._have = [(0, n)]
+        self._staged = sink[:n]
+        return self._staged
 
     def _resident_bytes(self):
         """Device tensor holding the file bytes, or None."""
@@ -542,6 +609,13 @@ class GPUStreamReaderBase:
             nsets * spf * row, dtype=torch.float32, device='cuda')
         set_nbytes = self._set_nbytes
         resident = self._resident_bytes() if nsets else None
+        if resident is None and nsets and self._have:
+            # bytes that earlier reads left in HBM serve this one too
+            lo_ = self._file_offset0 + first * set_nbytes
+            hi_ = min(self._file_offset0 + (last + (1 if self.verify else 0)) * set_nbytes,
+                      len(self._image()))
+            if self._has_bytes(min(lo_, hi_), hi_):
+                resident = self._sink[:len(self._image())]
         if resident is not None:
             # the file is in HBM already: ONE scan -> index -> decode over the
             # whole request, straight from where the bytes lie
@@ -561,6 +635,7 @@ class GPUStreamReaderBase:
             per_win = max(1, self.window_bytes // set_nbytes)
             if self._pipeline is None:
                 self._pipeline = WindowPipeline(image, (per_win + 1) * set_nbytes)
+            sink = self._sink_tensor()
             ranges, spans = [], []
             for s in range(first, last, per_win):
                 e = min(last, s + per_win)
@@ -581,11 +656,14 @@ class GPUStreamReaderBase:
                 self._process_window(dbuf, s, e, o)
 
             try:
-                self._pipeline.run(ranges, process)
+                self._pipeline.run(ranges, process, sink=sink)
             except Exception:
                 # do not leave half a read's verification state for the next one
                 self._nmissing, self._checked = 0, False
                 raise
+            if sink is not None:
+                for lo, hi in ranges:
+                    self._mark_have(lo, hi)
         if self.complex_data:
             flat = torch.view_as_complex(flat.view(-1, 2))
         return flat.reshape((nsets * spf,) + tuple(self._decode_shape))

@@ -387,10 +387,11 @@ int bb_vdif_locate(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *
     if (!d_buf || !p || !d_offsets || !d_count) return BB_EINVAL;
     if (p->header_nbytes != 32 && p->header_nbytes != 16) return BB_EINVAL;
     if (p->frame_nbytes < p->header_nbytes) return BB_EINVAL;
-    if ((uintptr_t)d_buf & 3) return BB_EINVAL;
-    if (nbytes < p->frame_nbytes) return BB_OK;
-    uint64_t blocks = (nbytes + BB_BLOCK - 1) / BB_BLOCK;
+    if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
+    if (nbytes < p->frame_nbytes || p->frame_nbytes < 32) return BB_OK;
+    uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
     if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_vdif_locate, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
                        (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_offsets, (uint64_t)cap, d_count);
     BB_HIP(hipGetLastError());
@@ -445,10 +446,11 @@ int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets, size_
                      unsigned long long *d_count, void *stream)
 {
     if (!d_buf || !d_offsets || !d_count) return BB_EINVAL;
-    if ((uintptr_t)d_buf & 3) return BB_EINVAL;
+    if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
     if (nbytes < BB_M5B_FRAME) return BB_OK;
-    uint64_t blocks = (nbytes + BB_BLOCK - 1) / BB_BLOCK;
+    uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
     if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_mark5b_locate, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
                        (const uint8_t *)d_buf, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count);
     BB_HIP(hipGetLastError());
@@ -850,9 +852,11 @@ int bb_mark4_locate(const void *d_buf, size_t nbytes, int ntrack, int64_t *d_off
 {
     if (!d_buf || !d_offsets || !d_count) return BB_EINVAL;
     if (ntrack != 16 && ntrack != 32 && ntrack != 64) return BB_ENOTSUP;
+    if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
     if (nbytes < (size_t)ntrack * 2500) return BB_OK;
-    uint64_t blocks = (nbytes + BB_BLOCK - 1) / BB_BLOCK;
+    uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
     if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks == 0) blocks = 1;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     const uint8_t *b = (const uint8_t *)d_buf;

@@ -17,6 +17,7 @@
 // fill of Mark4Frame.__getitem__ (mark4/frame.py:185-189,248-258).
 #pragma once
 #include "bb_common.h"
+#include "k_scan.h"
 
 template <int NTRACK> struct bb_m4_word;
 template <> struct bb_m4_word<16> { typedef uint16_t type; };
@@ -72,20 +73,27 @@ __device__ __forceinline__ bool bb_m4_sync_at(const uint8_t *buf, uint64_t pos)
     return true;
 }
 
+// The sweep (bb_locate_sweep, k_scan.h) probes for the END of the zero word:
+// a zero byte followed by three 0xff bytes, i.e. the dword 0xffffff00 at
+// z = pos + 64 * ISZ - 1.
 template <int NTRACK>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_mark4_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t cap,
                     unsigned long long *count)
 {
-    constexpr uint64_t FN = (uint64_t)NTRACK * 2500, PAT_END = 96 * (NTRACK / 8);
-    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
-    for (uint64_t pos = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
-         pos + FN <= nbytes; pos += stride) {
-        if (!bb_m4_sync_at<NTRACK>(buf, pos)) continue;
-        if (pos + FN + PAT_END <= nbytes && !bb_m4_sync_at<NTRACK>(buf, pos + FN)) continue;
-        const unsigned long long i = atomicAdd(count, 1ull);
-        if (i < cap) out[i] = (int64_t)pos;
-    }
+    constexpr uint64_t ISZ = NTRACK / 8;
+    constexpr uint64_t FN = (uint64_t)NTRACK * 2500, PAT_END = 96 * ISZ, ZOFF = 64 * ISZ - 1;
+    const uint64_t q_end = nbytes - FN + ZOFF + 1;
+    bb_locate_sweep(buf, nbytes, q_end,
+        [&](uint32_t v) { return v == 0xffffff00u; },
+        [&](uint64_t z) {
+            if (z < ZOFF) return;
+            const uint64_t pos = z - ZOFF;
+            if (pos + FN > nbytes || !bb_m4_sync_at<NTRACK>(buf, pos)) return;
+            if (pos + FN + PAT_END <= nbytes && !bb_m4_sync_at<NTRACK>(buf, pos + FN)) return;
+            const unsigned long long i = atomicAdd(count, 1ull);
+            if (i < cap) out[i] = (int64_t)pos;
+        });
 }
 
 template <int NTRACK>

@@ -98,35 +98,94 @@ __device__ __forceinline__ bool bb_vdif_header_at(const uint8_t *buf, uint64_t n
     return true;
 }
 
-// Byte-granular search for frame headers: position pos is reported when the
-// stream-invariant pattern matches there, the whole frame fits in the buffer,
-// and another header sits exactly one frame later (or two, when the next
-// header is damaged in place; for the last frame in the buffer: one earlier) -- the `check` logic of locate_frames
+// ---- byte-granular frame search -------------------------------------------
+// Skeleton shared by the VDIF / Mark 5B / Mark 4 searches (the
+// masked-pattern search of locate_frames, base/base.py:181-335).  A lane loads
+// 16 aligned bytes (four dwords; the dword behind them comes from the next
+// lane) and forms the little-endian dword at each of its 16 byte positions with
+// one v_alignbyte each: the file is read ONCE, 16 bytes per lane, and a position
+// costs three or four ALU operations.  `probe(v)` is the format's test on the
+// most selective dword of its header pattern -- random bytes pass it once in
+// 2^29 .. 2^32 positions -- and only those candidates go through `confirm(pos)`,
+// the complete test (all header words, frame fits, a header one frame later).
+// Round 1 tested every byte position in full, with every header word rebuilt
+// from two aligned loads: 0.61 TB/s of file bytes.
+template <class Probe, class Confirm>
+__device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nbytes, uint64_t q_end,
+                                                 Probe probe, Confirm confirm)
+{
+    // byte positions q in [0, q_end) are probed; q_end + 4 <= nbytes
+    const uint64_t nchunk = (q_end + 15) / 16;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(buf);
+    const uint64_t ndw = nbytes / 4;
+    const int lane = bb_lane();
+    for (uint64_t j = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x; j < nchunk + (BB_WAVE - 1);
+         j += (uint64_t)gridDim.x * BB_BLOCK) {
+        // (whole waves stay in the loop: the shuffle below needs every lane)
+        bb_u4 d = {0u, 0u, 0u, 0u};
+        const uint64_t dw0 = 4 * j;
+        if (dw0 + 4 <= ndw) d = *reinterpret_cast<const bb_u4 *>(w + dw0);
+        else {
+            if (dw0 < ndw) d.x = w[dw0];
+            if (dw0 + 1 < ndw) d.y = w[dw0 + 1];
+            if (dw0 + 2 < ndw) d.z = w[dw0 + 2];
+        }
+        uint32_t nx = (uint32_t)__shfl_down((int)d.x, 1);
+        if (lane == BB_WAVE - 1) nx = dw0 + 4 < ndw ? w[dw0 + 4] : 0u;
+        if (j >= nchunk) continue;
+        const uint32_t dd[5] = {d.x, d.y, d.z, d.w, nx};
+        uint32_t hits = 0;                              // bit 4k+s: position 16j + 4k + s
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (probe(dd[k])) hits |= 1u << (4 * k);
+            if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 1))) hits |= 2u << (4 * k);
+            if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 2))) hits |= 4u << (4 * k);
+            if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 3))) hits |= 8u << (4 * k);
+        }
+        while (hits) {                                  // rare
+            const int b = __ffs((int)hits) - 1;
+            hits &= hits - 1;
+            const uint64_t q = 16 * j + (uint64_t)b;
+            if (q < q_end) confirm(q);
+        }
+    }
+}
+
+// VDIF: position pos is reported when the stream-invariant pattern matches
+// there, the whole frame fits in the buffer, and another header sits exactly
+// one frame later (or two, when the next header is damaged in place; for the
+// last frame in the buffer: one earlier) -- the `check` logic of locate_frames
 // (base/base.py:181-335) as used by VDIF's _bad_frame recovery
-// (vdif/base.py:536-755).  Matches are appended unordered.
+// (vdif/base.py:536-755).  The probe is header word 2 (version, lg2_nchan,
+// frame_length: 8 bytes into the header).  Matches are appended unordered.
 __global__ __launch_bounds__(BB_BLOCK)
 void k_vdif_locate(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
                    int64_t *out, uint64_t cap, unsigned long long *count)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
-    for (uint64_t pos = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
-         pos + p.frame_nbytes <= nbytes; pos += stride) {
-        if (!bb_vdif_header_at(buf, nbytes, p, pos)) continue;
-        const uint64_t next = pos + p.frame_nbytes;
-        bool ok;
-        if (next + p.header_nbytes <= nbytes) {
-            ok = bb_vdif_header_at(buf, nbytes, p, next);
-            // the following header may be damaged in place (no bytes lost):
-            // then the one after it is still where the stride says
-            if (!ok && next + p.frame_nbytes + p.header_nbytes <= nbytes)
-                ok = bb_vdif_header_at(buf, nbytes, p, next + p.frame_nbytes);
-        } else {
-            ok = pos < p.frame_nbytes || bb_vdif_header_at(buf, nbytes, p, pos - p.frame_nbytes);
-        }
-        if (!ok) continue;
-        const unsigned long long i = atomicAdd(count, 1ull);
-        if (i < cap) out[i] = (int64_t)pos;
-    }
+    // word 2 of a frame that fits lies at q = pos + 8 <= nbytes - frame_nbytes + 8
+    const uint64_t q_end = nbytes - p.frame_nbytes + 8 + 1;
+    const uint32_t pat = p.pattern[2], msk = p.mask[2];
+    bb_locate_sweep(buf, nbytes, q_end,
+        [&](uint32_t v) { return ((v ^ pat) & msk) == 0; },
+        [&](uint64_t q) {
+            if (q < 8) return;
+            const uint64_t pos = q - 8;
+            if (pos + p.frame_nbytes > nbytes || !bb_vdif_header_at(buf, nbytes, p, pos)) return;
+            const uint64_t next = pos + p.frame_nbytes;
+            bool ok;
+            if (next + p.header_nbytes <= nbytes) {
+                ok = bb_vdif_header_at(buf, nbytes, p, next);
+                // the following header may be damaged in place (no bytes lost):
+                // then the one after it is still where the stride says
+                if (!ok && next + p.frame_nbytes + p.header_nbytes <= nbytes)
+                    ok = bb_vdif_header_at(buf, nbytes, p, next + p.frame_nbytes);
+            } else {
+                ok = pos < p.frame_nbytes || bb_vdif_header_at(buf, nbytes, p, pos - p.frame_nbytes);
+            }
+            if (!ok) return;
+            const unsigned long long i = atomicAdd(count, 1ull);
+            if (i < cap) out[i] = (int64_t)pos;
+        });
 }
 
 // Header scan at explicit (possibly unaligned) frame offsets: same record as
@@ -249,17 +308,17 @@ __global__ __launch_bounds__(BB_BLOCK)
 void k_mark5b_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t cap,
                      unsigned long long *count)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
-    for (uint64_t pos = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
-         pos + BB_M5B_FRAME <= nbytes; pos += stride) {
-        if (bb_load_u32_any(buf, nbytes, pos) != 0xABADDEEDu) continue;
-        const uint64_t next = pos + BB_M5B_FRAME;
-        if (next + 4 <= nbytes && bb_load_u32_any(buf, nbytes, next) != 0xABADDEEDu) continue;
-        if (!bb_mark5b_crc_ok(bb_load_u32_any(buf, nbytes, pos + 8),
-                              bb_load_u32_any(buf, nbytes, pos + 12))) continue;
-        const unsigned long long i = atomicAdd(count, 1ull);
-        if (i < cap) out[i] = (int64_t)pos;
-    }
+    const uint64_t q_end = nbytes - BB_M5B_FRAME + 1;       // the sync word is the probe
+    bb_locate_sweep(buf, nbytes, q_end,
+        [&](uint32_t v) { return v == 0xABADDEEDu; },
+        [&](uint64_t pos) {
+            const uint64_t next = pos + BB_M5B_FRAME;
+            if (next + 4 <= nbytes && bb_load_u32_any(buf, nbytes, next) != 0xABADDEEDu) return;
+            if (!bb_mark5b_crc_ok(bb_load_u32_any(buf, nbytes, pos + 8),
+                                  bb_load_u32_any(buf, nbytes, pos + 12))) return;
+            const unsigned long long i = atomicAdd(count, 1ull);
+            if (i < cap) out[i] = (int64_t)pos;
+        });
 }
 
 // Verification of a window's scan records in one launch: counts the records

@@ -201,7 +201,7 @@ class Mark4StreamReader(GPUStreamReaderBase):
         from ..staging import upload
         kernels.require_gpu()
         image = self._image()
-        dev, n = upload(image), len(image)
+        dev, n = self._whole_file_in_hbm(), len(image)
         offs = kernels.mark4_locate(dev, n, self._ntrack)
         recs = kernels.mark4_scan_at(dev, n, offs, self._ntrack, self.header0.year,
                                      self._ref_qms, self._frame_qms)

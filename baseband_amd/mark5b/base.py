@@ -185,7 +185,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         from ..staging import upload
         kernels.require_gpu()
         image = self._image()
-        dev, n = upload(image), len(image)
+        dev, n = self._whole_file_in_hbm(), len(image)
         offs = kernels.mark5b_locate(dev, n)
         recs = kernels.mark5b_scan_at(dev, n, offs, self._ref_seconds,
                                       self.header0['frame_nr'], self._frame_rate)

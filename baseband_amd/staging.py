@@ -121,7 +121,10 @@ class WindowPipeline:
         self._dev = [None] * self.nbuf
         self._done = [None] * self.nbuf
 
-    def run(self, ranges, process):
+    def run(self, ranges, process, sink=None):
+        """`sink`: optional device tensor as large as the image; windows are
+        then copied to their own place in it (and stay there) instead of into
+        the two rotating device buffers, and `process` gets that slice."""
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
@@ -136,13 +139,14 @@ class WindowPipeline:
             if self._done[b] is not None:
                 self._done[b].synchronize()          # buffer b free again
             pinned, dev = self._buffers(b)
+            target = dev[:n] if sink is None else sink[lo:hi]
             _stage(pinned.numpy(), self.image, lo, hi)           # page cache -> pinned (CPU)
             with torch.cuda.stream(self._copy_stream):
-                dev[:n].copy_(pinned[:n], non_blocking=True)
+                target.copy_(pinned[:n], non_blocking=True)
                 copied = torch.cuda.Event()
                 copied.record(self._copy_stream)
             main.wait_event(copied)
-            process(dev[:n], i)
+            process(target, i)
             done = torch.cuda.Event()
             done.record(main)
             self._done[b] = done

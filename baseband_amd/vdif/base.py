@@ -251,7 +251,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
         kernels.require_gpu()
         h0 = self.header0
         image = self._image()
-        dev = upload(image)
+        dev = self._whole_file_in_hbm()         # what earlier windows left in HBM is not sent again
         n = len(image)
         offs = kernels.vdif_locate(dev, n, self._frame_nbytes, h0.nbytes,
                                    self._pattern, self._mask)

@@ -153,3 +153,180 @@ def test_cfg2_multithread_large():
             want_t = orc.decode_flat(raw, 'vdif', 2).reshape(1000, 32)
             got_t = o[fset, :, t].cpu().numpy()
             assert np.array_equal(got_t.view(np.uint32), want_t.view(np.uint32)), (fset, t)
+
+
+def _random_bytes(nbytes, seed, dev):
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    buf = torch.empty(nbytes // 4 + 64, dtype=torch.int32, device=dev)
+    for lo in range(0, buf.numel(), 1 << 28):
+        hi = min(buf.numel(), lo + (1 << 28))
+        buf[lo:hi] = torch.randint(-2 ** 31, 2 ** 31 - 1, (hi - lo,), generator=g, device=dev,
+                                   dtype=torch.int64).to(torch.int32)
+    return buf.view(torch.uint8)
+
+
+def test_cfg4_mark5b_16ch_large():
+    """BASELINE configs[3], Mark 5B half: 2 GiB of 10016-byte frames, 16
+    channels x 2 bit.  Header scan (sync word, BCD time, fill-pattern frames
+    -> invalid), census of the sign/magnitude levels, random frames vs oracle."""
+    import torch
+    from baseband_amd import kernels, _lib
+    from baseband_amd.mark5b.header import frame_header_words
+    dev = torch.device('cuda')
+    fn, pn = 10016, 10000
+    nfr = (2 << 30) // fn
+    image = _random_bytes(nfr * fn, 11, dev)[:nfr * fn]
+    frame_rate = 6400
+    t0 = np.datetime64('2014-06-16T05:56:07', 'ns')
+    hw = frame_header_words(t0, float(frame_rate), 0, nfr)
+    image.view(nfr, fn)[:, :16] = torch.from_numpy(hw.view(np.uint8).reshape(nfr, 16).copy()).to(dev)
+    rng = np.random.default_rng(5)
+    bad = np.sort(rng.choice(nfr, size=50, replace=False))
+    badt = torch.from_numpy(bad).to(dev)
+    image.view(nfr, fn)[badt, 16:] = torch.tensor([0x44, 0x33, 0x22, 0x11], dtype=torch.uint8, device=dev).repeat(pn // 4)
+    w2 = int(hw[0, 2])
+    jday = ((w2 >> 28) & 0xf) * 100 + ((w2 >> 24) & 0xf) * 10 + ((w2 >> 20) & 0xf)
+    secs = sum(((w2 >> (4 * i)) & 0xf) * 10 ** i for i in range(5))
+    recs = kernels.mark5b_scan(image, nfr, jday * 86400 + secs, 0, frame_rate)
+    f = kernels.recs_fields(recs)
+    assert np.array_equal(f['time_index'], np.arange(nfr))
+    assert np.all(f['flags'] & _lib.FRAME_OK)
+    assert np.array_equal(np.nonzero(f['flags'] & _lib.FRAME_INVALID)[0], bad)
+    src = kernels.build_index(recs, nfr, 1, None)
+    out = kernels.decode_frames(image, nfr, pn, _lib.CODER_MARK5B, 2, chunk=16, src=src, fill_value=0.)
+    torch.cuda.synchronize()
+    frames = out.view(nfr, pn * 4)
+    assert float(frames[badt].abs().max()) == 0.0
+    good = torch.ones(nfr, dtype=torch.bool, device=dev)
+    good[badt] = False
+    payload = image.view(nfr, fn)[:, 16:]
+    want = np.zeros(4, np.int64)
+    for lo in range(0, nfr, 1 << 15):
+        want += _code_census(payload[lo:lo + (1 << 15)][good[lo:lo + (1 << 15)]])
+    levels = orc.code_levels('mark5b', 2)
+    got = _level_census(out, levels)
+    order = np.argsort(levels)                      # census by level value
+    assert np.array_equal(got, want), (got, want)
+    pick = np.sort(rng.choice(np.setdiff1d(np.arange(nfr), bad), size=100, replace=False))
+    raw = payload[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    dec = frames[torch.from_numpy(pick).to(dev)].cpu().numpy()
+    for i in range(len(pick)):
+        assert np.array_equal(dec[i].view(np.uint32), orc.decode_flat(raw[i], 'mark5b', 2).view(np.uint32)), pick[i]
+
+
+def test_cfg4_mark4_64track_fanout4_large():
+    """BASELINE configs[3], Mark 4 half: 2 GiB of 160000-byte frames, 64
+    tracks, fanout 4 (8 channels): the first 640 samples of every frame are
+    fill (header place), census of the four levels over the rest, random
+    frames against the oracle's track demultiplexer."""
+    import torch
+    from baseband_amd import kernels
+    from baseband_amd.mark4._bitmaps import BITMAPS
+    dev = torch.device('cuda')
+    fn, nwords = 160000, 20000
+    nfr = (2 << 30) // fn
+    image = _random_bytes(nfr * fn, 13, dev)[:nfr * fn]
+    m = BITMAPS[(8, 2, 4)]
+    fill = -77.0
+    out = kernels.decode_mark4(image, nfr, 64, nwords, m['sign_bit'], m['mag_bit'], fill_words=160,
+                               src0=0, src_stride=fn, fill_value=fill)
+    torch.cuda.synchronize()
+    frames = out.view(nfr, nwords * 4, 8)            # (frame, sample, channel)
+    assert bool((frames[:, :640] == fill).all())
+    assert not bool((frames[:, 640:] == fill).any())
+    # census: every (sign, magnitude) bit pair of the payload words -> one sample
+    hi = float(orc.code_levels('vdif', 2)[3])
+    n_hi = int((frames[:, 640:].abs() == hi).sum().item())
+    n_lo = int((frames[:, 640:].abs() == 1.0).sum().item())
+    assert n_hi + n_lo == nfr * (nwords * 4 - 640) * 8
+    words = image.view(torch.int64).view(nfr, nwords)[:, 160:]
+    want_hi = 0
+    sb = torch.tensor(list(m['sign_bit']), device=dev, dtype=torch.int64)
+    mb = torch.tensor(list(m['mag_bit']), device=dev, dtype=torch.int64)
+    for lo in range(0, nfr, 256):
+        w = words[lo:lo + 256].reshape(-1, 1)
+        s = (w >> sb[None, :]) & 1
+        g = (w >> mb[None, :]) & 1
+        want_hi += int((s == g).sum().item())       # sign == magnitude -> +-Hi
+    assert n_hi == want_hi
+    rng = np.random.default_rng(9)
+    for f in rng.choice(nfr, size=12, replace=False):
+        w = image[f * fn:(f + 1) * fn].cpu().numpy().view('<u8')[160:]
+        want = np.ascontiguousarray(orc.mark4_decode(w, 8, 4, None))
+        got = frames[f, 640:].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f
+
+
+@pytest.mark.parametrize('overlap', [0, 512])
+def test_cfg5_guppi_128mib_blocks(overlap):
+    """BASELINE configs[4]: GUPPI 8-bit, 2 pol, 64 channels, channels first,
+    128 MiB blocks, OVERLAP 0 / 512: checksum of every channel (sum and sum of
+    squares of re / im are permutation invariants), random rows vs NumPy."""
+    import torch
+    from baseband_amd import kernels, _lib
+    dev = torch.device('cuda')
+    npol, nchan, blk = 2, 64, 128 << 20
+    T = blk // (npol * nchan * 2)
+    nfr = 8
+    image = _random_bytes(nfr * blk, 17, dev)[:nfr * blk]
+    keep = T - overlap
+    out = kernels.decode_i8_tiled(image, nfr, _lib.LAYOUT_GUPPI_CF, npol, nchan, T, 0, keep,
+                                  src0=0, src_stride=blk)
+    assert 'k_decode_i8_xpose' in _lib.last_kernel()
+    torch.cuda.synchronize()
+    o = out.view(nfr, keep, npol, nchan, 2)
+    b = image.view(torch.int8).view(nfr, nchan, T, npol, 2)[:, :, :keep]
+    for f in range(nfr):
+        got = o[f].to(torch.float64)
+        want = b[f].to(torch.float64)
+        # per (pol, chan, re/im): sums and sums of squares over time
+        assert torch.equal(got.sum(0), want.sum(1).permute(1, 0, 2))
+        assert torch.equal((got * got).sum(0), (want * want).sum(1).permute(1, 0, 2))
+    rng = np.random.default_rng(21)
+    for f, t in zip(rng.integers(0, nfr, 30), rng.integers(0, keep, 30)):
+        want = b[f, :, t].permute(1, 0, 2).to(torch.float32)         # (pol, chan, 2)
+        assert torch.equal(o[f, t], want), (f, t)
+    # the reader's view of the same thing: first rows of block 1 follow the kept rows of block 0
+    assert torch.equal(o[1, 0], b[1, :, 0].permute(1, 0, 2).to(torch.float32))
+
+
+def test_gather_64_threads_large():
+    """64 thread slots x 1 channel 2-bit real (chunk 1: every output float
+    comes from another payload), 1 GiB: census + random sets vs oracle."""
+    import torch
+    from baseband_amd import kernels, _lib
+    dev = torch.device('cuda')
+    pn, fn, nth = 2000, 2032, 64
+    nsets = (1 << 30) // (fn * nth)
+    image = _random_bytes(nsets * nth * fn, 23, dev)[:nsets * nth * fn]
+    rng = np.random.default_rng(2)
+    perm = torch.from_numpy(rng.permutation(nth)).to(dev)
+    pos = torch.arange(nsets, device=dev, dtype=torch.int64)[:, None] * nth + perm[None, :]
+    src = (pos * fn + 32).reshape(-1).contiguous()
+    hole = rng.choice(nsets * nth, size=500, replace=False)
+    src[torch.from_numpy(hole).to(dev)] = -1
+    out = kernels.decode_frames(image, nsets, pn, _lib.CODER_VDIF, 2, chunk=1, nslot=nth, src=src,
+                                fill_value=0.)
+    assert 'k_decode_gather' in _lib.last_kernel()
+    torch.cuda.synchronize()
+    payload = image.view(nsets * nth, fn)[:, 32:]
+    valid = (src >= 0)
+    rows = torch.div(src[valid] - 32, fn, rounding_mode='floor')
+    want = np.zeros(4, np.int64)
+    for lo in range(0, rows.numel(), 1 << 16):
+        want += _code_census(payload[rows[lo:lo + (1 << 16)]])
+    got = _level_census(out, orc.code_levels('vdif', 2))
+    assert np.array_equal(got, want)
+    assert int((out == 0).sum().item()) == 500 * pn * 4
+    o = out.view(nsets, pn * 4, nth)
+    s = src.view(nsets, nth).cpu().numpy()
+    for fset in rng.choice(nsets, size=10, replace=False):
+        for t in (0, 31, 63):
+            got_t = o[fset, :, t].cpu().numpy()
+            if s[fset, t] < 0:
+                assert not got_t.any()
+                continue
+            raw = image[s[fset, t]:s[fset, t] + pn].cpu().numpy()
+            assert np.array_equal(got_t.view(np.uint32), orc.decode_flat(raw, 'vdif', 2).view(np.uint32)), (fset, t)

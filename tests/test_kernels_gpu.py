@@ -338,3 +338,77 @@ def test_aligned_kernels_take_unaligned_views():
                         for i in range(nfr)]).reshape(nsets, nslot, -1, chunk).transpose(0, 2, 1, 3)
         for o in outs:
             assert bits_equal(o, np.ascontiguousarray(exp).reshape(-1)), (nslot, chunk)
+
+
+@pytest.mark.parametrize('stripes_lw', [0, 2, 4, 6])
+def test_striped_work_order_is_only_an_order(stripes_lw):
+    """The work order (bb_perm_t: a launch dealt over 2^lw stripes) must not
+    change a single output value: every kernel family at sizes where the
+    stripes are active (>= 64 work items per stripe), odd item counts so that
+    the tail keeps its place, holes in the index, against the oracle."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    from baseband_amd.mark4._bitmaps import BITMAPS
+    rng = np.random.default_rng(1000 + stripes_lw)
+    kernels.tune(_lib.TUNE_WORK_STRIPES, stripes_lw)
+    try:
+        # flat, 2-bit, two work items per frame (aligned pipelined kernel) and 8-bit (plain kernel)
+        for coder, bps, pn, nfr in (('vdif', 2, 8000, 2311), ('int', 8, 1000, 4099), ('vdif', 4, 260, 4567)):
+            stride = pn + 32
+            raw = rng.integers(0, 256, stride * nfr, dtype=np.uint8)
+            src = np.arange(nfr, dtype=np.int64) * stride + 32
+            holes = rng.choice(nfr, size=37, replace=False)
+            src[holes] = -1
+            out = kernels.decode_frames(kernels.to_device_bytes(raw), nfr, pn, CODERS[coder], bps,
+                                        src=torch.from_numpy(src).cuda(), fill_value=9.5).cpu().numpy()
+            exp = np.stack([orc.decode_flat(raw[i * stride + 32:(i + 1) * stride], coder, bps)
+                            for i in range(nfr)])
+            exp[holes] = 9.5
+            assert bits_equal(out, exp.reshape(-1)), (coder, bps)
+        # thread interleave: rows kernel (8 x 32 floats) and LDS gather (8 x 1)
+        for nslot, chunk, pn, nsets in ((8, 32, 2560, 523), (8, 1, 1280, 1031)):
+            nfr = nsets * nslot
+            raw = rng.integers(0, 256, pn * nfr, dtype=np.uint8)
+            perm = rng.permutation(nfr)
+            src = (perm * pn).astype(np.int64)
+            src[rng.choice(nfr, size=11, replace=False)] = -1
+            out = kernels.decode_frames(kernels.to_device_bytes(raw), nsets, pn, 0, 2, chunk=chunk, nslot=nslot,
+                                        src=torch.from_numpy(src).cuda(), complex_data=chunk % 2 == 0,
+                                        fill_value=-1.5).cpu().numpy()
+            R = pn * 4 // chunk
+            exp = np.empty((nsets, R, nslot, chunk), np.float32)
+            fillrow = np.tile(np.array([-1.5, 0.], np.float32), chunk // 2) if chunk % 2 == 0 \
+                else np.full(chunk, -1.5, np.float32)
+            for k in range(nfr):
+                f, s = divmod(k, nslot)
+                exp[f, :, s, :] = fillrow if src[k] < 0 else \
+                    orc.decode_flat(raw[src[k]:src[k] + pn], 'vdif', 2).reshape(R, chunk)
+            assert bits_equal(out, exp.reshape(-1)), (nslot, chunk)
+        # Mark 4: 32 tracks, fanout 4, several work items per frame
+        m = BITMAPS[(4, 2, 4)]
+        nwords, nfr = 5000, 301
+        w = rng.integers(0, 2 ** 32, size=nwords * nfr, dtype=np.uint64).astype('<u4')
+        out = kernels.decode_mark4(kernels.to_device_bytes(w.view(np.uint8)), nfr, 32, nwords,
+                                   m['sign_bit'], m['mag_bit'], src0=0, src_stride=nwords * 4).cpu().numpy()
+        exp = orc.mark4_decode(w, 4, 4, None)
+        assert bits_equal(out, np.ascontiguousarray(exp).reshape(-1))
+        # int8 transposes (k_decode_i8_xpose and the general tiled kernels)
+        for layout, npol, nchan, T, lo in ((0, 2, 64, 4096, 0), (1, 2, 64, 2048, 8), (2, 2, 64, 2000, 0),
+                                           (0, 2, 10, 3000, 3), (2, 2, 6, 5000, 0)):
+            nfr = 5
+            pn = T * npol * nchan * 2
+            raw = rng.integers(0, 256, size=(nfr, pn), dtype=np.uint8)
+            b = raw.view(np.int8)
+            if layout == 0:
+                ref = b.reshape(nfr, nchan, T, npol, 2).transpose(0, 2, 3, 1, 4)
+            elif layout == 1:
+                ref = b.reshape(nfr, T // 256, npol, nchan, 256, 2).transpose(0, 1, 4, 2, 3, 5) \
+                    .reshape(nfr, T, npol, nchan, 2)
+            else:
+                ref = b.reshape(nfr, T, nchan, npol, 2).transpose(0, 1, 3, 2, 4)
+            ref = np.ascontiguousarray(ref).astype(np.float32)
+            out = kernels.decode_i8_tiled(kernels.to_device_bytes(raw.reshape(-1)), nfr, layout, npol, nchan, T,
+                                          lo, T, src0=0, src_stride=pn).cpu().numpy()
+            assert bits_equal(out, np.ascontiguousarray(ref[:, lo:].reshape(-1))), (layout, nchan)
+    finally:
+        kernels.tune(_lib.TUNE_WORK_STRIPES, -1)

@@ -1,0 +1,127 @@
+"""Staging of large files: windows stay in HBM once they have been there, a
+file with more than a window of bytes missing does not trip the pipeline
+(negative window), verify='fix' re-reads from HBM."""
+import io
+import warnings
+
+import numpy as np
+import pytest
+
+import bb_oracle_np as orc
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _file(nframes=10500, seed=5):
+    from baseband_amd import synth
+    image, h0 = synth.random_vdif(seed, nframes, payload_nbytes=8000, frame_rate=1000)
+    return image, h0
+
+
+def test_windows_are_kept_and_serve_the_second_read():
+    from baseband_amd import vdif
+    image, h0 = _file(3000)
+    exp, _ = orc.vdif_read(image, frame_rate=1000)
+    with vdif.open(io.BytesIO(image.tobytes()), 'rs', sample_rate=32e6, squeeze=False) as fh:
+        fh.window_bytes = 1 << 20                       # several windows for a 24 MB file
+        first = fh.read()
+        assert fh._sink is not None and fh._has_bytes(0, len(image))
+        assert bits_equal(first.cpu().numpy(), exp)
+        # the second pass and partial reads come from HBM: no pipeline run
+        calls = []
+        orig = fh._pipeline.run
+        fh._pipeline.run = lambda *a, **k: calls.append(1) or orig(*a, **k)
+        fh.seek(0)
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        fh.seek(32000 * 1500 + 7)
+        assert bits_equal(fh.read(32000 * 900).cpu().numpy(), exp[32000 * 1500 + 7:32000 * 2400 + 7])
+        assert not calls
+        fh.unstage()
+        assert fh._sink is None
+        fh.seek(0)
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+    with vdif.open(io.BytesIO(image.tobytes()), 'rs', sample_rate=32e6, squeeze=False) as fh:
+        fh.window_bytes = 1 << 20
+        fh.keep_staged = False
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        assert fh._sink is None
+
+
+def test_large_file_with_more_than_a_window_missing():
+    """> 64 MiB file (default window) whose tail lost more than one window of
+    bytes: the header times promise more frames than the file holds, so the
+    last windows start beyond the end of the file.  verify=False fills,
+    verify='fix' repairs (one byte-granular search over the bytes already in
+    HBM), verify=True raises -- none of them crashes in the staging pipeline."""
+    from baseband_amd import vdif
+    image, h0 = _file(10500)                           # 84 MB
+    fn = 8032
+    keep = image.reshape(-1, fn)
+    # frames 500..9999 are gone (76 MB > one 64 MiB window); the last 500 frames
+    # still carry their late times
+    damaged = np.concatenate([keep[:500].reshape(-1), keep[10000:].reshape(-1)])
+    exp, _ = orc.vdif_read(image, frame_rate=1000)
+    want = exp.copy()
+    want[500 * 32000:10000 * 32000] = 0.
+    for verify in (False, 'fix'):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            with vdif.open(io.BytesIO(damaged.tobytes()), 'rs', sample_rate=32e6, squeeze=False,
+                           verify=verify) as fh:
+                assert fh.shape[0] == exp.shape[0]
+                got = fh.read()
+        if verify == 'fix':
+            assert bits_equal(got.cpu().numpy(), want)
+        else:
+            # without verification frames are taken where the stride says: the
+            # first 500 are right, and nothing beyond the file is touched
+            assert bits_equal(got[:500 * 32000].cpu().numpy(), exp[:500 * 32000])
+            assert got.shape == exp.shape
+    with pytest.raises(ValueError):
+        with vdif.open(io.BytesIO(damaged.tobytes()), 'rs', sample_rate=32e6, verify=True) as fh:
+            fh.read()
+    # the reader is usable after the failed read (no stale verification state)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with vdif.open(io.BytesIO(damaged.tobytes()), 'rs', sample_rate=32e6, squeeze=False,
+                       verify='fix') as fh:
+            fh.seek(32000 * 10100)
+            assert bits_equal(fh.read(32000 * 3).cpu().numpy(), exp[32000 * 10100:32000 * 10103])
+
+
+def test_repair_does_not_upload_twice():
+    """verify='fix' on a damaged file: the windows of the failed pass are
+    already in HBM, so the repair sends only what is still missing."""
+    from baseband_amd import vdif, staging
+    image, h0 = _file(3000)
+    fn = 8032
+    damaged = np.concatenate([image[:fn * 1000], image[fn * 1001:fn * 2000 + 100], image[fn * 2000 + 300:]])
+    sent = []
+    orig = staging.upload
+
+    def counting_upload(img, *a, **k):
+        sent.append(len(img))
+        return orig(img, *a, **k)
+
+    staging.upload = counting_upload
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            with vdif.open(io.BytesIO(damaged.tobytes()), 'rs', sample_rate=32e6, squeeze=False,
+                           verify='fix') as fh:
+                fh.window_bytes = 1 << 20
+                got = fh.read()
+    finally:
+        staging.upload = orig
+    assert sum(sent) < len(damaged) // 4, sent      # (the search works on the kept windows)
+    exp, _ = orc.vdif_read(image, frame_rate=1000)
+    want = exp.copy()
+    want[1000 * 32000:1001 * 32000] = 0.            # the lost frame
+    want[1999 * 32000:2001 * 32000] = 0.            # the two frames around the lost bytes... see below
+    g = got.cpu().numpy()
+    assert g.shape == exp.shape
+    assert bits_equal(g[:1000 * 32000], exp[:1000 * 32000])
+    assert not g[1000 * 32000:1001 * 32000].any()
+    assert bits_equal(g[1001 * 32000:1999 * 32000], exp[1001 * 32000:1999 * 32000])
+    assert bits_equal(g[2001 * 32000:], exp[2001 * 32000:])
