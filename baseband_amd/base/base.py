@@ -511,7 +511,9 @@ class GPUStreamReaderBase:
         the library wants its buffers, an aligned copy otherwise (files with
         leading junk bytes)."""
         part = dev[lo:hi]
-        if part.numel() and part.data_ptr() % align:
+        if part.numel() == 0:
+            return dev[:0]                      # (an aligned, non-null pointer for the library)
+        if part.data_ptr() % align:
             part = part.clone()
         return part
 
@@ -653,7 +655,9 @@ class GPUStreamReaderBase:
             def process(dbuf, i):
                 s, e = spans[i]
                 o = flat[(s - first) * spf * row:(e - first) * spf * row]
-                self._process_window(dbuf, s, e, o)
+                # (a window kept in place inside the file-sized buffer starts
+                # wherever the file says: aligned copy if the library needs one)
+                self._process_window(self._device_window(dbuf, 0, dbuf.numel()), s, e, o)
 
             try:
                 self._pipeline.run(ranges, process, sink=sink)
