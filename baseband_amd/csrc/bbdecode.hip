@@ -367,11 +367,11 @@ int bb_debug_trace(uint64_t *d_times)
 int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
                  bb_frame_rec *d_recs, size_t nframes, void *stream)
 {
+    if (nframes == 0) return BB_OK;                      // (an empty window: nothing to look at)
     if (!d_buf || !p || !d_recs) return BB_EINVAL;
     if (p->header_nbytes != 32 && p->header_nbytes != 16) return BB_EINVAL;
     if (p->frame_nbytes < p->header_nbytes || (p->frame_nbytes & 7)) return BB_EINVAL;
     if ((p->first_offset & 3) || ((uintptr_t)d_buf & 3)) return BB_EINVAL;
-    if (nframes == 0) return BB_OK;
     const uint64_t threads = (uint64_t)nframes * 8;
     const uint64_t blocks = (threads + BB_BLOCK - 1) / BB_BLOCK;
     if (blocks > 0x7fffffffull) return BB_ERANGE;
@@ -417,9 +417,9 @@ static int mark5b_scan_impl(const void *d_buf, size_t nbytes, const bb_mark5b_sc
                             const int64_t *d_offsets, bb_frame_rec *d_recs, size_t nframes,
                             void *stream)
 {
+    if (nframes == 0) return BB_OK;
     if (!d_buf || !p || !d_recs) return BB_EINVAL;
     if ((!d_offsets && (p->first_offset & 3)) || ((uintptr_t)d_buf & 3)) return BB_EINVAL;
-    if (nframes == 0) return BB_OK;
     const uint64_t blocks = ((uint64_t)nframes + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
     if (blocks > 0x7fffffffull) return BB_ERANGE;
     hipLaunchKernelGGL(k_mark5b_scan, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
@@ -815,6 +815,7 @@ static int mark4_scan_impl(const void *d_buf, size_t nbytes, const bb_mark4_scan
                            const int64_t *d_offsets, bb_frame_rec *d_recs, size_t nframes,
                            void *stream)
 {
+    if (nframes == 0) return BB_OK;
     if (!d_buf || !p || !d_recs) return BB_EINVAL;
     if (p->ntrack != 16 && p->ntrack != 32 && p->ntrack != 64) return BB_ENOTSUP;
     if ((!d_offsets && (p->first_offset & (p->ntrack / 8 - 1))) || ((uintptr_t)d_buf & 7)) return BB_EINVAL;
