@@ -512,7 +512,8 @@ class GPUStreamReaderBase:
         leading junk bytes)."""
         part = dev[lo:hi]
         if part.numel() == 0:
-            return dev[:0]                      # (an aligned, non-null pointer for the library)
+            # (an aligned, non-null pointer for the library)
+            return torch.empty(64, dtype=torch.uint8, device=dev.device)[:0]
         if part.data_ptr() % align:
             part = part.clone()
         return part
