@@ -512,8 +512,10 @@ class GPUStreamReaderBase:
         leading junk bytes)."""
         part = dev[lo:hi]
         if part.numel() == 0:
-            # (an aligned, non-null pointer for the library)
-            return torch.empty(64, dtype=torch.uint8, device=dev.device)[:0]
+            # nothing of the file lies here (bytes went missing): hand the
+            # library a few zero bytes -- too few to hold a frame -- rather
+            # than an empty tensor, whose data pointer is null
+            return torch.zeros(64, dtype=torch.uint8, device=dev.device)
         if part.data_ptr() % align:
             part = part.clone()
         return part
