@@ -710,7 +710,7 @@ class GPUStreamReaderBase:
         s0, s1, dev = ahead
         a = (first - s0) * set_nbytes
         b = max(a, (min(need_end, s1) - s0) * set_nbytes)
-        self._process_window(dev[a:b], first, last, flat)
+        self._process_window(self._device_window(dev, a, b), first, last, flat)
 
     _nbad = None        # device counter the verification kernel adds to
     _nmissing = 0       # frames a window should have held but the file did not
