@@ -84,15 +84,14 @@ void k_mark4_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t 
     constexpr uint64_t ISZ = NTRACK / 8;
     constexpr uint64_t FN = (uint64_t)NTRACK * 2500, PAT_END = 96 * ISZ, ZOFF = 64 * ISZ - 1;
     const uint64_t q_end = nbytes - FN + ZOFF + 1;
-    bb_locate_sweep(buf, nbytes, q_end,
+    bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
         [&](uint32_t v) { return v == 0xffffff00u; },
-        [&](uint64_t z) {
-            if (z < ZOFF) return;
+        [&](uint64_t z) -> int64_t {
+            if (z < ZOFF) return -1;
             const uint64_t pos = z - ZOFF;
-            if (pos + FN > nbytes || !bb_m4_sync_at<NTRACK>(buf, pos)) return;
-            if (pos + FN + PAT_END <= nbytes && !bb_m4_sync_at<NTRACK>(buf, pos + FN)) return;
-            const unsigned long long i = atomicAdd(count, 1ull);
-            if (i < cap) out[i] = (int64_t)pos;
+            if (pos + FN > nbytes || !bb_m4_sync_at<NTRACK>(buf, pos)) return -1;
+            if (pos + FN + PAT_END <= nbytes && !bb_m4_sync_at<NTRACK>(buf, pos + FN)) return -1;
+            return (int64_t)pos;
         });
 }
 

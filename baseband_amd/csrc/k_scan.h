@@ -110,10 +110,21 @@ __device__ __forceinline__ bool bb_vdif_header_at(const uint8_t *buf, uint64_t n
 // the complete test (all header words, frame fits, a header one frame later).
 // Round 1 tested every byte position in full, with every header word rebuilt
 // from two aligned loads: 0.61 TB/s of file bytes.
+// Confirmed positions are collected per workgroup in LDS and appended to the
+// global list with ONE atomic per workgroup: a million frames reporting through
+// a single global counter took 12 of the kernel's 13 ms (one word takes about 88
+// returning atomics per microsecond, MI355X_MICROARCH.md price list "dequeue").
+#define BB_LOCATE_LOCAL 1024
 template <class Probe, class Confirm>
 __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nbytes, uint64_t q_end,
+                                                 int64_t *out, uint64_t cap, unsigned long long *count,
                                                  Probe probe, Confirm confirm)
 {
+    __shared__ int64_t s_found[BB_LOCATE_LOCAL];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     // byte positions q in [0, q_end) are probed; q_end + 4 <= nbytes
     const uint64_t nchunk = (q_end + 15) / 16;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(buf);
@@ -146,9 +157,23 @@ __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nby
             const int b = __ffs((int)hits) - 1;
             hits &= hits - 1;
             const uint64_t q = 16 * j + (uint64_t)b;
-            if (q < q_end) confirm(q);
+            if (q >= q_end) continue;
+            const int64_t pos = confirm(q);
+            if (pos < 0) continue;
+            const uint32_t i = atomicAdd(&s_n, 1u);
+            if (i < BB_LOCATE_LOCAL) s_found[i] = pos;
+            else {                                      // local list full: straight to the global one
+                const unsigned long long g = atomicAdd(count, 1ull);
+                if (g < cap) out[g] = pos;
+            }
         }
     }
+    __syncthreads();
+    const uint32_t n = s_n < BB_LOCATE_LOCAL ? s_n : BB_LOCATE_LOCAL;
+    if (threadIdx.x == 0 && n) s_base = atomicAdd(count, (unsigned long long)n);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += BB_BLOCK)
+        if (s_base + i < cap) out[s_base + i] = s_found[i];
 }
 
 // VDIF: position pos is reported when the stream-invariant pattern matches
@@ -165,12 +190,12 @@ void k_vdif_locate(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
     // word 2 of a frame that fits lies at q = pos + 8 <= nbytes - frame_nbytes + 8
     const uint64_t q_end = nbytes - p.frame_nbytes + 8 + 1;
     const uint32_t pat = p.pattern[2], msk = p.mask[2];
-    bb_locate_sweep(buf, nbytes, q_end,
+    bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
         [&](uint32_t v) { return ((v ^ pat) & msk) == 0; },
-        [&](uint64_t q) {
-            if (q < 8) return;
+        [&](uint64_t q) -> int64_t {
+            if (q < 8) return -1;
             const uint64_t pos = q - 8;
-            if (pos + p.frame_nbytes > nbytes || !bb_vdif_header_at(buf, nbytes, p, pos)) return;
+            if (pos + p.frame_nbytes > nbytes || !bb_vdif_header_at(buf, nbytes, p, pos)) return -1;
             const uint64_t next = pos + p.frame_nbytes;
             bool ok;
             if (next + p.header_nbytes <= nbytes) {
@@ -182,9 +207,7 @@ void k_vdif_locate(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
             } else {
                 ok = pos < p.frame_nbytes || bb_vdif_header_at(buf, nbytes, p, pos - p.frame_nbytes);
             }
-            if (!ok) return;
-            const unsigned long long i = atomicAdd(count, 1ull);
-            if (i < cap) out[i] = (int64_t)pos;
+            return ok ? (int64_t)pos : -1;
         });
 }
 
@@ -309,15 +332,14 @@ void k_mark5b_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t
                      unsigned long long *count)
 {
     const uint64_t q_end = nbytes - BB_M5B_FRAME + 1;       // the sync word is the probe
-    bb_locate_sweep(buf, nbytes, q_end,
+    bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
         [&](uint32_t v) { return v == 0xABADDEEDu; },
-        [&](uint64_t pos) {
+        [&](uint64_t pos) -> int64_t {
             const uint64_t next = pos + BB_M5B_FRAME;
-            if (next + 4 <= nbytes && bb_load_u32_any(buf, nbytes, next) != 0xABADDEEDu) return;
+            if (next + 4 <= nbytes && bb_load_u32_any(buf, nbytes, next) != 0xABADDEEDu) return -1;
             if (!bb_mark5b_crc_ok(bb_load_u32_any(buf, nbytes, pos + 8),
-                                  bb_load_u32_any(buf, nbytes, pos + 12))) return;
-            const unsigned long long i = atomicAdd(count, 1ull);
-            if (i < cap) out[i] = (int64_t)pos;
+                                  bb_load_u32_any(buf, nbytes, pos + 12))) return -1;
+            return (int64_t)pos;
         });
 }
 
