@@ -146,8 +146,10 @@ SIGNATURES = [
     ('bb_verify_records', C.c_int, [_vp, _sz, C.c_int32, C.c_uint32, _sz, _vp, _vp]),
     ('bb_build_index', C.c_int, [_vp, _sz, _vp, C.c_int, _vp, _sz, _vp]),
     ('bb_decode_frames', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, _sz, _vp]),
+    ('bb_decode_frames_select', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, C.c_int, _vp, _sz, _vp]),
     ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),
     ('bb_mark4_locate', C.c_int, [_vp, _sz, C.c_int, _vp, _sz, _vp, _vp]),
+    ('bb_mark4_header_crc', C.c_int, [_vp, _sz, C.c_int, _vp, C.c_int64, _sz, _vp, _vp]),
     ('bb_mark4_scan_at', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp, _vp]),
     ('bb_decode_mark4', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(Mark4DecodeParams), _vp, _sz, _vp]),
     ('bb_decode_i8_tiled', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(TiledParams), _vp, _sz, _vp]),

@@ -315,10 +315,61 @@ class GPUStreamReaderBase:
     def __exit__(self, *exc):
         self.close()
 
+    # -- channel selection folded into the decode kernel
+    _within = None          # int32 device tensor: positions of a thread sample that are decoded
+
+    def _plan_channel_select(self, subset):
+        """If `subset` (what `_squeeze_and_subset` would apply to decoded
+        frames) only picks CHANNELS -- the last axis of `_decode_shape` -- the
+        same for every thread, have the decode kernel write just those
+        (bb_decode_frames_select): the reference decodes whole frames and
+        indexes afterwards (base/base.py:706-717, 957-969), which on the GPU
+        would be one or two extra passes over the 16x expanded output.  The
+        test is done by value: the subset is applied to arrays of channel and
+        thread numbers, and folded only if the result is `(threads) x (channel
+        list)` in that order.  Anything else keeps the general path."""
+        shape = tuple(self._decode_shape)
+        if not subset or not shape or len(shape) > 2 or (len(shape) == 2 and shape[0] > 96):
+            return
+        nchan = shape[-1]
+        if nchan & (nchan - 1):
+            return
+        lead = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+        chan = np.broadcast_to(np.arange(nchan), shape)
+        thread = np.broadcast_to(np.arange(lead).reshape(shape[:-1] + (1,)), shape)
+
+        def view(a):
+            a = np.ascontiguousarray(a)[np.newaxis]
+            if self.squeeze:
+                a = a.reshape(a.shape[:1] + _apply_squeeze(a.shape[1:]))
+            return a[(slice(None),) + tuple(subset)]
+        try:
+            c, t = view(chan), view(thread)
+        except Exception:
+            return
+        if c.shape[:1] != (1,) or c.size == 0 or c.size % lead:
+            return
+        c, t = c.reshape(-1), t.reshape(-1)
+        m = c.size // lead
+        picked = c[:m]
+        if not (np.array_equal(t, np.repeat(np.arange(lead), m))
+                and np.array_equal(c, np.tile(picked, lead))):
+            return
+        if m == nchan and np.array_equal(picked, np.arange(nchan)):
+            return                                  # every channel, in order: nothing to fold
+        ncomp = 2 if self.complex_data else 1
+        within = (picked[:, None] * ncomp + np.arange(ncomp)).reshape(-1).astype(np.int32)
+        kernels.require_gpu()
+        self._within = torch.from_numpy(within).to('cuda')
+        self._decode_shape = shape[:-1] + (m,)
+
     # -- shapes
     def _squeeze_and_subset(self, data):
         """Remove unit dimensions, then apply `subset`
         (base/base.py:706-717)."""
+        if self._within is not None:
+            # the kernel wrote exactly the selected samples, in the final order
+            return data.reshape(data.shape[:1] + self.sample_shape)
         if self.squeeze:
             data = data.reshape(data.shape[:1] + _apply_squeeze(data.shape[1:]))
         if self.subset:
@@ -593,11 +644,11 @@ class GPUStreamReaderBase:
         """Flat float32 view of `out` when the decode may write straight into
         it: a contiguous device tensor of the stream's dtype, and no subset
         (squeezing only drops unit dimensions)."""
-        if (not isinstance(out, torch.Tensor) or not out.is_cuda
-                or not out.is_contiguous() or self.subset
-                or getattr(self, '_frameset_subset', None)
-                or tuple(self._decode_shape) != tuple(self._unsliced_shape)
+        if (not isinstance(out, torch.Tensor) or not out.is_cuda or not out.is_contiguous()
                 or out.dtype != (torch.complex64 if self.complex_data else torch.float32)):
+            return None
+        if self._within is None and (self.subset or getattr(self, '_frameset_subset', None)
+                                     or tuple(self._decode_shape) != tuple(self._unsliced_shape)):
             return None
         flat = torch.view_as_real(out) if self.complex_data else out
         return flat.reshape(-1)

@@ -632,6 +632,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // chunks of 4 / 8 / 16 floats ran at 0.55 / 1.15 / 3.45 TB/s
         // (profiles/r01i_exp_interleave.log)
         bb_gather_args ga;
+        ga.within = nullptr; ga.nsel = 0;
         ga.buf = a.buf; ga.src = d_src; ga.out = d_out; ga.tab = a.tab;
         ga.nframes = nframes; ga.ndw = a.ndw;
         ga.nslot = a.nslot; ga.chunk = a.chunk; ga.lchunk = a.lchunk;
@@ -811,6 +812,77 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     return BB_OK;
 }
 
+int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
+                            const int64_t *d_src, size_t nframes,
+                            const bb_decode_params *p,
+                            const int32_t *d_within, int nwithin,
+                            float *d_out, size_t out_elems, void *stream)
+{
+    if (!p) return BB_EINVAL;
+    if (!coder_supported(p->coder, p->bps)) return BB_ENOTSUP;
+    if (nframes == 0) return BB_OK;
+    if (!d_buf || !d_out || !d_src || !d_within) return BB_EINVAL;
+    if (p->nslot < 1 || p->chunk < 1 || nwithin < 1 || nwithin > 4096) return BB_EINVAL;
+    if (p->payload_nbytes == 0 || (p->payload_nbytes & 3)) return BB_EINVAL;
+    if (((uintptr_t)d_buf & 3) || ((uintptr_t)d_out & 3)) return BB_EINVAL;
+    if (p->chunk & (p->chunk - 1)) return BB_ENOTSUP;
+    uint32_t lchunk = 0;
+    while ((1u << lchunk) < (uint32_t)p->chunk) ++lchunk;
+    const uint64_t E = p->payload_nbytes * 8 / (uint64_t)p->bps;
+    if (E % (uint64_t)p->chunk) return BB_EINVAL;
+    const uint64_t R = E >> lchunk;
+    if (out_elems < (uint64_t)nframes * R * (uint64_t)p->nslot * (uint64_t)nwithin) return BB_ERANGE;
+    int rc = ensure_init();
+    if (rc) return rc;
+    const int lb = log2_bps(p->bps);
+    bb_gather_args ga;
+    ga.buf = (const uint8_t *)d_buf; ga.src = d_src; ga.out = d_out;
+    rc = device_levels(p->coder, lb, &ga.tab);
+    if (rc) return rc;
+    ga.nframes = nframes; ga.ndw = p->payload_nbytes / 4;
+    ga.nslot = (uint32_t)p->nslot; ga.chunk = (uint32_t)p->chunk; ga.lchunk = lchunk;
+    const uint64_t ntiles = (ga.ndw + 63) / 64;
+    // stage about 16 KiB of payload per work item (all slots together)
+    uint32_t gt = (uint32_t)(16384 / ((size_t)p->nslot * 256));
+    if (gt < 1) gt = 1;
+    if (gt > 32) gt = 32;
+    if ((uint64_t)gt > ntiles) gt = (uint32_t)ntiles;
+    // a group's elements must be whole rows: gt * 2048 / bps elements, chunk a power of two
+    while (gt > 1 && ((uint64_t)gt * (2048 / p->bps)) % (uint64_t)p->chunk) --gt;
+    if (((uint64_t)gt * (2048 / p->bps)) % (uint64_t)p->chunk) return BB_ENOTSUP;
+    ga.gtiles = gt;
+    ga.ngroup = (uint32_t)((ntiles + gt - 1) / gt);
+    ga.fill_re = p->fill_re; ga.fill_im = p->fill_im; ga.complex_data = p->complex_data;
+    ga.lrow = -1;
+    ga.aligned = 1;
+    ga.within = d_within; ga.nsel = (uint32_t)nwithin;
+    const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024 + (size_t)nwithin * 4;
+    if (lds > 64 * 1024) return BB_ENOTSUP;
+    uint64_t gb = (uint64_t)nframes * ga.ngroup;
+    ga.perm = make_perm(gb, (uint64_t)nframes * R * p->nslot * nwithin * 4);
+    const int tb = g_tune_blocks.load();
+    const uint64_t gcap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
+    if (gb > gcap) gb = gcap;
+    const dim3 gg((unsigned)gb);
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = g_tune_nt.load() != 0;
+#define BB_GS(B, L) do { if (nt) hipLaunchKernelGGL((k_decode_gather_select<B, L, true>), gg, dim3(BB_BLOCK), lds, st, ga); \
+                         else    hipLaunchKernelGGL((k_decode_gather_select<B, L, false>), gg, dim3(BB_BLOCK), lds, st, ga); } while (0)
+    switch (p->bps) {
+        case 1: BB_GS(1, BB_LV_REG); break;
+        case 2: BB_GS(2, BB_LV_REG); break;
+        case 4: BB_GS(4, BB_LV_LDS); break;
+        default:
+            if (p->coder == BB_CODER_INT) BB_GS(8, BB_LV_INT8); else BB_GS(8, BB_LV_LDS);
+            break;
+    }
+#undef BB_GS
+    BB_NOTE("k_decode_gather_select<%d,%s,%s> grid %u gtiles %u select %d of %d", p->bps, lv_name(p->bps, p->coder),
+            nt ? "nt" : "plain", gg.x, gt, nwithin, p->chunk);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
 static int mark4_scan_impl(const void *d_buf, size_t nbytes, const bb_mark4_scan_params *p,
                            const int64_t *d_offsets, bb_frame_rec *d_recs, size_t nframes,
                            void *stream)
@@ -865,6 +937,27 @@ int bb_mark4_locate(const void *d_buf, size_t nbytes, int ntrack, int64_t *d_off
         case 16: hipLaunchKernelGGL(k_mark4_locate<16>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count); break;
         case 32: hipLaunchKernelGGL(k_mark4_locate<32>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count); break;
         default: hipLaunchKernelGGL(k_mark4_locate<64>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count); break;
+    }
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_mark4_header_crc(const void *d_buf, size_t nbytes, int ntrack, const int64_t *d_offsets,
+                        int64_t first_offset, size_t nframes, uint64_t *d_bad_tracks, void *stream)
+{
+    if (nframes == 0) return BB_OK;
+    if (!d_buf || !d_bad_tracks) return BB_EINVAL;
+    if (ntrack != 16 && ntrack != 32 && ntrack != 64) return BB_ENOTSUP;
+    if (!d_offsets && first_offset < 0) return BB_EINVAL;
+    const uint64_t blocks = ((uint64_t)nframes + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 0x7fffffffull) return BB_ERANGE;
+    const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    const uint8_t *b = (const uint8_t *)d_buf;
+    switch (ntrack) {
+        case 16: hipLaunchKernelGGL(k_mark4_header_crc<16>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, first_offset, (uint64_t)nframes, d_bad_tracks); break;
+        case 32: hipLaunchKernelGGL(k_mark4_header_crc<32>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, first_offset, (uint64_t)nframes, d_bad_tracks); break;
+        default: hipLaunchKernelGGL(k_mark4_header_crc<64>, grid, block, 0, st, b, (uint64_t)nbytes, d_offsets, first_offset, (uint64_t)nframes, d_bad_tracks); break;
     }
     BB_HIP(hipGetLastError());
     return BB_OK;

@@ -31,9 +31,91 @@ struct bb_gather_args {
     int32_t  lrow;          // log2(nslot * chunk) when that is a power of two, else -1
     int32_t  aligned;       // use 256-byte aligned block loads
     bb_perm_t perm;         // work order (bb_common.h)
+    // channel selection (bb_decode_frames_select): only positions within[0..nsel)
+    // of every thread sample's chunk are written, in that order; nsel == 0: all
+    const int32_t *within;
+    uint32_t nsel;
 };
 
 // WIDE: chunks of at least four floats (a float4 never straddles thread slots)
+// The same staging with a CHANNEL SELECTION folded in (reader `subset`: the
+// reference decodes whole frames and indexes the result afterwards,
+// base/base.py:706-717, 957-969): only positions within[0 .. nsel) of every
+// thread sample are written, so the output -- and its HBM traffic -- shrinks to
+// nsel / chunk of the full decode and no second pass over it is needed.  One
+// output float per lane and step (a selected row has no 16-byte structure).
+template <int BPS, int LV, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_gather_select(bb_gather_args a)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    const uint32_t pitch = a.gtiles * 64 + 64 + 1;
+    uint32_t *s_raw = s_mem;
+    uint32_t *s_valid = s_mem + (size_t)a.nslot * pitch;
+    uint32_t *s_base = s_valid + a.nslot;
+    float *s_tab = reinterpret_cast<float *>(s_base + a.nslot + 1);
+    uint32_t *s_within = reinterpret_cast<uint32_t *>(s_tab + (LV == BB_LV_LDS ? NCODE : 0));
+
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    for (uint32_t i = threadIdx.x; i < a.nsel; i += BB_BLOCK) s_within[i] = (uint32_t)a.within[i];
+    const uint64_t E = a.ndw * (32 / BPS);
+    const uint64_t R = E >> a.lchunk;
+    const uint32_t rowlen = a.nslot * a.nsel;               // floats per output row
+    const uint64_t nwork = a.nframes * a.ngroup;
+    const uint32_t gdw = a.gtiles * 64;
+
+    for (uint64_t step = blockIdx.x; step < nwork; step += gridDim.x) {
+        const uint64_t work = bb_perm(a.perm, step);
+        const uint64_t f = work / a.ngroup;
+        const uint32_t g = (uint32_t)(work - f * a.ngroup);
+        const uint64_t dw0 = (uint64_t)g * gdw;
+        __syncthreads();
+        for (uint32_t s = bb_wave(); s < a.nslot; s += BB_WAVES_PER_BLOCK) {
+            const int64_t so = a.src[f * a.nslot + s];
+            const uint8_t *pp = a.buf + (so >= 0 ? (uint64_t)so : 0);
+            const uintptr_t b0 = reinterpret_cast<uintptr_t>(pp);
+            const uint32_t sh = (a.aligned && !(b0 & 3)) ? (uint32_t)((b0 >> 2) & 63) : 0u;
+            const uint32_t *blk = reinterpret_cast<const uint32_t *>(pp) - sh;
+            for (uint32_t j = bb_lane(); j < gdw + 64; j += BB_WAVE) {
+                const uint64_t q = dw0 + j;
+                s_raw[s * pitch + j] = (so >= 0 && q >= sh && q - sh < a.ndw) ? blk[q] : 0u;
+            }
+            if (bb_lane() == 0) {
+                s_valid[s] = so >= 0 ? 1u : 0u;
+                s_base[s] = (s * pitch + sh) * 4;
+            }
+        }
+        __syncthreads();
+        const uint64_t e_lo = dw0 * (32 / BPS);
+        const uint64_t e_hi = (e_lo + (uint64_t)gdw * (32 / BPS) < E) ? e_lo + (uint64_t)gdw * (32 / BPS) : E;
+        const uint32_t nrow = (uint32_t)((e_hi - e_lo) >> a.lchunk);
+        const uint32_t nfloat = nrow * rowlen;
+        float *obase = a.out + (f * R + (e_lo >> a.lchunk)) * rowlen;
+        const uint8_t *rawb = reinterpret_cast<const uint8_t *>(s_raw);
+        for (uint32_t q = threadIdx.x; q < nfloat; q += BB_BLOCK) {
+            const uint32_t row = q / rowlen, rem = q - row * rowlen;
+            const uint32_t s = rem / a.nsel, k = rem - s * a.nsel;
+            const uint32_t within = s_within[k];
+            const uint32_t bit = ((row << a.lchunk) + within) * BPS;
+            uint32_t code;
+            if (BPS == 8) code = rawb[s_base[s] + (bit >> 3)];
+            else code = ((uint32_t)rawb[s_base[s] + (bit >> 3)] >> (bit & 7)) & CMASK;
+            float v = lv.get(code);
+            if (!s_valid[s]) v = (a.complex_data && (within & 1)) ? a.fill_im : a.fill_re;
+            bb_store1<NT>(obase + q, v);
+        }
+    }
+}
+
 template <int BPS, int LV, bool NT, bool WIDE>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_decode_gather(bb_gather_args a)

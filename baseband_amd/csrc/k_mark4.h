@@ -160,6 +160,47 @@ void k_mark4_scan(const uint8_t *buf, uint64_t nbytes, bb_mark4_scan_params p,
     }
 }
 
+// Longitudinal (along-track) check of the frame headers: the 160 header bits of
+// every track end in a CRC-12 (x^12 + x^11 + x^3 + x^2 + x + 1, 0x180f:
+// mark4/header.py:34-44; CRCStack, base/utils.py:200-248), so the 160-bit
+// stream of a sound track divides by the polynomial.  The reference computes
+// this for all tracks at once on stream words (`crc12.check(stream)`,
+// mark4/tests/test_mark4.py:57-58) but never applies it while reading; here it
+// is an extra that reports, per frame, the set of tracks whose header fails --
+// it never alters decoded samples.  Bit-sliced like
+// the reference: twelve NTRACK-bit registers hold one remainder bit of every
+// track each; one thread walks the 160 stream words of one frame.
+template <int NTRACK>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_mark4_header_crc(const uint8_t *buf, uint64_t nbytes, const int64_t *offsets,
+                        int64_t first_offset, uint64_t nframes, uint64_t *bad_tracks)
+{
+    typedef typename bb_m4_word<NTRACK>::type word_t;
+    const uint64_t f = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (f >= nframes) return;
+    const uint64_t fn = (uint64_t)NTRACK * 2500;
+    const uint64_t off = offsets ? (uint64_t)offsets[f] : (uint64_t)first_offset + f * fn;
+    if (off + 160 * sizeof(word_t) > nbytes) { bad_tracks[f] = ~0ull >> (64 - NTRACK); return; }
+    word_t r[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) r[k] = 0;
+    for (int j = 0; j < 160; ++j) {
+        const word_t in = bb_m4_load_any<NTRACK>(buf, off + (uint64_t)j * sizeof(word_t));
+        const word_t fb = (word_t)(r[11] ^ in);
+        r[11] = (word_t)(r[10] ^ fb);               // x^11
+#pragma unroll
+        for (int k = 10; k >= 4; --k) r[k] = r[k - 1];
+        r[3] = (word_t)(r[2] ^ fb);                 // x^3
+        r[2] = (word_t)(r[1] ^ fb);                 // x^2
+        r[1] = (word_t)(r[0] ^ fb);                 // x
+        r[0] = fb;                                  // 1
+    }
+    word_t bad = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) bad |= r[k];
+    bad_tracks[f] = (uint64_t)bad;
+}
+
 struct bb_m4_args {
     const uint8_t *buf;
     const int64_t *src;

@@ -196,6 +196,16 @@ def mark4_locate(dbuf, nbytes, ntrack):
         dbuf, nbytes // (ntrack * 2500) + 16, 'bb_mark4_locate')
 
 
+def mark4_header_crc(dbuf, nframes, ntrack, first_offset=0, offsets=None):
+    """Per frame the set of tracks (bit mask, int64 tensor) whose 160 header
+    bits fail the CRC-12 along the track (bb_mark4_header_crc; the reference's
+    ``crc12.check``, mark4/header.py:34-44).  Never alters decoded samples."""
+    bad = torch.empty(nframes, dtype=torch.int64, device=dbuf.device)
+    check(lib.bb_mark4_header_crc(_ptr(dbuf), dbuf.numel(), ntrack, _ptr(offsets), first_offset,
+                                  nframes, _ptr(bad), _stream(dbuf)), 'bb_mark4_header_crc')
+    return bad
+
+
 def mark4_scan_at(dbuf, nbytes, offsets, ntrack, ref_year, ref_qms, frame_qms):
     p = _lib.Mark4ScanParams()
     p.first_offset, p.ntrack, p.ref_year = 0, ntrack, ref_year
@@ -240,8 +250,11 @@ def build_index(recs, nframes_out, nslot=1, thread_slot=None):
 
 def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
                   src=None, src0=0, src_stride=0, complex_data=False,
-                  fill_value=0., out=None):
-    """Decode `nframes` frame(set)s to a flat float32 device tensor."""
+                  fill_value=0., out=None, within=None):
+    """Decode `nframes` frame(set)s to a flat float32 device tensor.  `within`
+    (int32 device tensor of positions inside a thread sample's `chunk`
+    floats) selects channels in the kernel: only those positions are
+    written (bb_decode_frames_select)."""
     p = _lib.DecodeParams()
     p.coder = coder
     p.bps = bps
@@ -255,6 +268,17 @@ def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
     p.fill_re = fv.real
     p.fill_im = fv.imag
     nelem = nframes * nslot * (payload_nbytes * 8 // bps) if bps in (1, 2, 4, 8) else 0
+    if within is not None:
+        if src is None:                 # the selecting kernel works through an index
+            src = src0 + torch.arange(nframes * nslot, dtype=torch.int64, device=dbuf.device) * src_stride
+        nsel = within.numel()
+        nelem = nelem // chunk * nsel
+        if out is None:
+            out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
+        check(lib.bb_decode_frames_select(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes, C.byref(p),
+                                          _ptr(within), nsel, _ptr(out), out.numel(), _stream(dbuf)),
+              'bb_decode_frames_select')
+        return out
     tgt = _Target(out, nelem, dbuf.device)
     check(lib.bb_decode_frames(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
                                C.byref(p), _ptr(tgt.use), tgt.use.numel(), _stream(dbuf)),

@@ -226,6 +226,22 @@ class Mark4StreamReader(GPUStreamReaderBase):
         return flat.reshape(((last - first) * self.samples_per_frame,)
                             + tuple(self._decode_shape))
 
+    def header_crc_errors(self):
+        """Longitudinal check of every frame header: int64 device tensor, one
+        entry per frame of the file, bit t set when track t's 160 header bits
+        fail their CRC-12 (``baseband.mark4.header.crc12.check`` in the
+        reference, mark4/header.py:34-44; the reference does not apply it
+        while reading and neither does `read`: decoded samples are never
+        changed by this report).  The file is looked at in HBM
+        (bb_mark4_header_crc)."""
+        dev = self._whole_file_in_hbm()
+        nframes = (len(self._image()) - self._file_offset0) // self._set_nbytes
+        if self._resident is not None:              # frames were located individually
+            offs = self._resident[1]
+            offs = offs[offs >= 0].contiguous()
+            return kernels.mark4_header_crc(dev, offs.numel(), self._ntrack, offsets=offs)
+        return kernels.mark4_header_crc(dev, nframes, self._ntrack, first_offset=self._file_offset0)
+
     def _process_window(self, dbuf, first, last, out_flat):
         maps = BITMAPS[self._coder]          # KeyError: unsupported Mark 4 mode
         n = last - first

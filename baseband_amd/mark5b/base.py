@@ -143,6 +143,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         self._file_offset0 = offset0
         self._start_time = header0.get_time(frame_rate=self._frame_rate)
         self._ref_seconds = header0.jday * 86400 + header0.seconds
+        self._plan_channel_select(self.subset)
         last = self._last_header()
         self._nsample = (self._get_index(last) + 1) * spf
 
@@ -200,7 +201,8 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         flat = kernels.decode_frames(
             dev, last - first, 10000, _lib.CODER_MARK5B, self.bps,
             chunk=self._unsliced_shape[0], nslot=1,
-            src=src[first:last].contiguous(), fill_value=self.fill_value, out=into)
+            src=src[first:last].contiguous(), fill_value=self.fill_value, out=into,
+            within=self._within)
         return flat.reshape(((last - first) * self.samples_per_frame,)
                             + tuple(self._decode_shape))
 
@@ -215,7 +217,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         kernels.decode_frames(
             dbuf, n, 10000, _lib.CODER_MARK5B, self.bps,
             chunk=self._unsliced_shape[0], nslot=1, src=src,
-            fill_value=self.fill_value, out=out_flat)
+            fill_value=self.fill_value, out=out_flat, within=self._within)
         if self.verify:
             # the look-ahead header (record n) only has to be a header
             self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))

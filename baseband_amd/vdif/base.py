@@ -221,6 +221,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
         self._coder = (_lib.CODER_MARK5B if header0.edv == 0xab
                        else _lib.CODER_VDIF)
         self._resident = None
+        self._plan_channel_select(self._frameset_subset)
         try:
             last = self._last_header()
             self._nsample = (self._get_index(last) + 1) * self.samples_per_frame
@@ -300,7 +301,8 @@ class VDIFStreamReader(GPUStreamReaderBase):
         flat = kernels.decode_frames(
             dev, nsets, h0.payload_nbytes, self._coder, self.bps, chunk=chunk,
             nslot=nslot, src=src[first * nslot:last * nslot].contiguous(),
-            complex_data=self.complex_data, fill_value=self.fill_value, out=into)
+            complex_data=self.complex_data, fill_value=self.fill_value, out=into,
+            within=self._within)
         if self.complex_data:
             flat = torch.view_as_complex(flat.view(-1, 2))
         return flat.reshape((nsets * self.samples_per_frame,) + tuple(self._decode_shape))
@@ -354,6 +356,8 @@ class VDIFStreamReader(GPUStreamReaderBase):
 
     def _squeeze_and_subset(self, data):
         # threads were already selected on read (vdif/base.py:519-528)
+        if self._within is not None:            # ... and so were the channels, in the kernel
+            return data.reshape(data.shape[:1] + self.sample_shape)
         if self.squeeze:
             data = data.reshape(data.shape[:1]
                                 + tuple(sh for sh in data.shape[1:] if sh > 1))
@@ -383,7 +387,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
         kernels.decode_frames(
             dbuf, nsets, h0.payload_nbytes, self._coder, self.bps,
             chunk=chunk, nslot=nslot, src=src, complex_data=self.complex_data,
-            fill_value=self.fill_value, out=out_flat)
+            fill_value=self.fill_value, out=out_flat, within=self._within)
         if self.verify:
             self._check_window(recs, nframes, nthread_file, nframes,
                                missing=nsets * nthread_file - nframes)

@@ -258,6 +258,24 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
                      const bb_decode_params *params,
                      float *d_out, size_t out_elems, void *stream);
 
+/*
+ * bb_decode_frames with a CHANNEL SELECTION folded in: of every thread
+ * sample's `chunk` floats only positions d_within[0 .. nwithin) (device array,
+ * each 0 <= w < chunk, any order, repeats allowed) are written, in that order:
+ *   out[((f * R + r) * nslot + s) * nwithin + k] = sample (f, r, s)[d_within[k]].
+ * Replaces what the reference does for a reader `subset` that picks channels
+ * (decode the whole frame, then index: base/base.py:706-717 with 957-969;
+ * vdif/base.py:519-528) without writing -- and re-reading -- the channels
+ * nobody asked for.  `d_src` is required (one offset per frame-slot, -1 =
+ * fill); `chunk` must be a power of two.  d_out needs 4-byte alignment only.
+ * BB_ENOTSUP when the thread slots do not fit the on-chip staging buffer.
+ */
+int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
+                            const int64_t *d_src, size_t nframes,
+                            const bb_decode_params *params,
+                            const int32_t *d_within, int nwithin,
+                            float *d_out, size_t out_elems, void *stream);
+
 /* ---- Mark 4 ------------------------------------------------------------ */
 
 /*
@@ -284,6 +302,23 @@ typedef struct bb_mark4_scan_params {
 int bb_mark4_scan(const void *d_buf, size_t nbytes,
                   const bb_mark4_scan_params *params,
                   bb_frame_rec *d_recs, size_t nframes, void *stream);
+
+/*
+ * Mark 4 longitudinal (along-track) header check -- BASELINE.json configs[3]
+ * "longitudinal-parity branch", SURVEY 8a row M4-x.  The 160 header bits of
+ * every track end in a CRC-12 (polynomial 0x180f; mark4/header.py:34-44,
+ * CRCStack in base/utils.py:200-248).  For frame k at d_offsets[k] (or, with
+ * d_offsets NULL, at first_offset + k * ntrack*2500; offsets need not be word
+ * aligned) d_bad_tracks[k] receives a mask with bit t set when track t's header
+ * does not divide by the polynomial -- what the reference's
+ * `crc12._crc(stream)` leaves non-zero (its test asserts `crc12.check(stream)`,
+ * mark4/tests/test_mark4.py:57-58).  The reference never applies this check
+ * while reading; neither do the decode entry points: it is an extra report that
+ * does not alter decoded samples.  Pinned by tests/golden/mark4_crc_cases.json.
+ */
+int bb_mark4_header_crc(const void *d_buf, size_t nbytes, int ntrack,
+                        const int64_t *d_offsets, int64_t first_offset, size_t nframes,
+                        uint64_t *d_bad_tracks, void *stream);
 
 /*
  * Corruption-tolerant Mark 4 indexing (reference: _bad_frame,

@@ -824,3 +824,23 @@ def encode_flat(values, coder, bps):
     c = encode_codes(values, coder, bps).reshape(-1, 8 // bps).astype(np.uint8)
     shifts = (np.arange(8 // bps) * bps).astype(np.uint8)
     return np.bitwise_or.reduce(c << shifts, axis=-1).astype(np.uint8)
+
+
+def mark4_header_crc_bad(raw, offset0, ntrack, nframes):
+    """Per frame the mask of tracks whose 160 header bits do not divide by the
+    Mark 4 CRC-12 polynomial 0x180f -- CRCStack._crc / check
+    (base/utils.py:200-248, mark4/header.py:34-44) restated: polynomial long
+    division carried out on stream words, all tracks at once."""
+    raw = np.ascontiguousarray(raw)
+    dt = np.dtype(MARK4_DTYPES[ntrack])
+    fn = ntrack * 2500
+    ones = np.iinfo(dt).max
+    pol = np.array([ones if b == '1' else 0 for b in format(0x180f, 'b')], dtype=dt)
+    out = []
+    for f in range(nframes):
+        start = offset0 + f * fn
+        stream = np.frombuffer(raw[start:start + 160 * dt.itemsize].tobytes(), dt).copy()
+        for i in range(160 - 12):
+            stream[i:i + 13] ^= stream[i] & pol
+        out.append(int(np.bitwise_or.reduce(stream[-12:])))
+    return out

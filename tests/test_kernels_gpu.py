@@ -412,3 +412,41 @@ def test_striped_work_order_is_only_an_order(stripes_lw):
             assert bits_equal(out, np.ascontiguousarray(ref[:, lo:].reshape(-1))), (layout, nchan)
     finally:
         kernels.tune(_lib.TUNE_WORK_STRIPES, -1)
+
+
+@pytest.mark.parametrize('bps,chunk,nslot,sel', [(2, 16, 1, [1, 6]), (2, 32, 8, [6, 7, 18, 19]),
+                                                 (1, 4, 3, [3, 0]), (4, 8, 2, [5]), (8, 2, 4, [1]),
+                                                 (8, 16, 1, [0, 15, 7, 7]), (2, 1, 8, [0]), (2, 64, 2, list(range(0, 64, 5)))])
+def test_decode_with_channel_selection(bps, chunk, nslot, sel):
+    """bb_decode_frames_select == full decode (oracle) indexed afterwards, with
+    missing frames, shuffled payload placement and work-order stripes."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    nframes, pn = 300, 640
+    rng = np.random.default_rng(bps * 100 + chunk + nslot)
+    raw = rng.integers(0, 256, nframes * nslot * pn, dtype=np.uint8)
+    perm = rng.permutation(nframes * nslot)
+    src = (perm * pn).astype(np.int64)
+    src[rng.choice(nframes * nslot, size=7, replace=False)] = -1
+    cplx = chunk % 2 == 0
+    fill = -7.5
+    E = pn * 8 // bps
+    R = E // chunk
+    exp = np.empty((nframes, R, nslot, chunk), np.float32)
+    fillrow = np.tile(np.array([fill, 0.], np.float32), chunk // 2) if cplx \
+        else np.full(chunk, fill, np.float32)
+    for f in range(nframes):
+        for s in range(nslot):
+            o = src[f * nslot + s]
+            exp[f, :, s, :] = fillrow if o < 0 else orc.decode_flat(raw[o:o + pn], 'vdif', bps).reshape(R, chunk)
+    within = torch.tensor(sel, dtype=torch.int32, device='cuda')
+    for lw in (0, 2):
+        kernels.tune(_lib.TUNE_WORK_STRIPES, lw)
+        try:
+            out = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, 0, bps, chunk=chunk,
+                                        nslot=nslot, src=torch.from_numpy(src).cuda(), complex_data=cplx,
+                                        fill_value=fill, within=within)
+        finally:
+            kernels.tune(_lib.TUNE_WORK_STRIPES, -1)
+        assert 'k_decode_gather_select' in _lib.last_kernel()
+        assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(exp[..., sel]).reshape(-1)), lw

@@ -179,3 +179,39 @@ def test_seeded_synthetic_vs_oracle(ntrack, fanout, nframes, tmp_path):
         assert bits_equal(part, exp[s0:s0 + h0.samples_per_frame * 9 + 3])
     finally:
         Mark4StreamReader.window_bytes = old
+
+
+def test_longitudinal_header_crc_matches_reference():
+    """bb_mark4_header_crc == the reference's crc12 over the
+    160 header stream words of every frame (tests/golden/mark4_crc_cases.json),
+    for clean files and files with single header bits flipped; through the raw
+    kernel (fixed stride and explicit, unaligned offsets) and the reader
+    method; decoded samples are the same whether or not the check is run."""
+    import os
+    import torch
+    from conftest import GOLD
+    from baseband_amd import kernels, mark4
+    with open(os.path.join(GOLD, 'mark4_crc_cases.json')) as f:
+        cases = json.load(f)['cases']
+    for c in cases:
+        raw = load_file(c['file']).copy()
+        for byte, bit in c['flips']:
+            raw[byte] ^= np.uint8(1 << bit)
+        want = [int(b, 16) for b in c['bad']]
+        dev = kernels.to_device_bytes(raw)
+        got = kernels.mark4_header_crc(dev, c['nframes'], c['ntrack'], first_offset=c['offset0'])
+        assert [int(x) & ((1 << 64) - 1) for x in got.cpu().tolist()] == want, c['file']
+        # explicit offsets into a copy shifted by one byte (unaligned words)
+        shifted = kernels.to_device_bytes(np.concatenate([np.zeros(1, np.uint8), raw]))
+        offs = torch.arange(c['nframes'], dtype=torch.int64, device='cuda') * (c['ntrack'] * 2500) \
+            + c['offset0'] + 1
+        got = kernels.mark4_header_crc(shifted, c['nframes'], c['ntrack'], offsets=offs)
+        assert [int(x) & ((1 << 64) - 1) for x in got.cpu().tolist()] == want, c['file']
+    # the reader's report, and that it leaves the samples alone
+    case = [c for c in cases if c['file'] == 'samples/sample.m4' and not c['flips']][0]
+    with mark4.open(golden_path('samples/sample.m4'), 'rs', ntrack=64, decade=2010) as fh:
+        before = fh.read().cpu().numpy()
+        bad = fh.header_crc_errors()
+        assert bad.numel() == case['nframes'] and not bool(bad.any())
+        fh.seek(0)
+        assert bits_equal(fh.read().cpu().numpy(), before)

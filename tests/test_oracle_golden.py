@@ -189,3 +189,21 @@ def test_gsb_oracle_matches_reference(manifest):
     assert bits_equal(out, exp)
     for off, cnt, digest in case['reads']:
         assert hashlib.sha256(np.ascontiguousarray(exp[off:off + cnt]).tobytes()).hexdigest() == digest
+
+
+def test_mark4_longitudinal_crc_oracle_vs_reference():
+    """the oracle's restatement of the along-track CRC-12
+    check equals what the reference's crc12 (CRCStack 0x180f) finds for every
+    frame of the golden cases, clean and with single header bits flipped."""
+    import json
+    import os
+    from conftest import GOLD, load_file
+    with open(os.path.join(GOLD, 'mark4_crc_cases.json')) as f:
+        cases = json.load(f)['cases']
+    assert len(cases) >= 10
+    for c in cases:
+        raw = load_file(c['file']).copy()
+        for byte, bit in c['flips']:
+            raw[byte] ^= np.uint8(1 << bit)
+        got = orc.mark4_header_crc_bad(raw, c['offset0'], c['ntrack'], c['nframes'])
+        assert [format(b, 'x') for b in got] == c['bad'], c['file']

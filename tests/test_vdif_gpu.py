@@ -428,3 +428,35 @@ def test_read_into_numpy_and_asnumpy(tmp_path):
     assert np.array_equal(baseband_amd.asnumpy(z), z.cpu().numpy())
     strided = np.empty((dev.shape[0], 2), np.float32)[:, 0]
     assert bits_equal(baseband_amd.asnumpy(dev, out=strided), dev.cpu().numpy())
+
+
+@pytest.mark.parametrize('squeeze,subset,folded', [
+    (True, (slice(None), [3, 1, 14]), True), (True, (slice(None), slice(2, 12, 3)), True),
+    (True, ([6, 1], slice(3, 9)), True), (True, (2, 5), True), (False, (slice(None), 7), True),
+    (True, ([0, 7], [4, 9]), False),             # paired (not outer) indexing: general path
+    (True, ([5], slice(None)), False),           # threads only: nothing to fold
+    (True, (slice(None), [15]), True), (False, ([2], [3]), True)])
+def test_channel_subset_is_folded_into_the_decode(manifest, squeeze, subset, folded):
+    """A `subset` that picks channels is applied BY the decode kernel
+    (bb_decode_frames_select): same values as NumPy indexing of the full
+    reference output (base/base.py:706-717), whole-stream and partial reads,
+    read(out=...) straight into the caller's tensor."""
+    import torch
+    from baseband_amd import vdif, _lib
+    case = manifest['vdif_cfg3_small']
+    exp = load_expected('vdif_cfg3_small')       # (4000, 8, 16) c64
+    full = exp
+    want = full[(slice(None),) + subset]        # (8 threads, 16 channels: nothing to squeeze first)
+    with vdif.open(golden_path(case['file']), 'rs', squeeze=squeeze, subset=subset, **_kw(case)) as fh:
+        assert (fh._within is not None) == folded
+        assert fh.sample_shape == want.shape[1:]
+        got = fh.read()
+        if folded:
+            assert 'k_decode_gather_select' in _lib.last_kernel()
+        assert bits_equal(got.cpu().numpy(), np.ascontiguousarray(want))
+        fh.seek(995)
+        assert bits_equal(fh.read(1010).cpu().numpy(), np.ascontiguousarray(want[995:2005]))
+        out = torch.empty((2000,) + want.shape[1:], dtype=torch.complex64, device='cuda')
+        fh.seek(1000)
+        assert fh.read(out=out) is out
+        assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[1000:3000]))
