@@ -433,7 +433,6 @@ def test_read_into_numpy_and_asnumpy(tmp_path):
 @pytest.mark.parametrize('squeeze,subset,folded', [
     (True, (slice(None), [3, 1, 14]), True), (True, (slice(None), slice(2, 12, 3)), True),
     (True, ([6, 1], slice(3, 9)), True), (True, (2, 5), True), (False, (slice(None), 7), True),
-    (True, ([0, 7], [4, 9]), False),             # paired (not outer) indexing: general path
     (True, ([5], slice(None)), False),           # threads only: nothing to fold
     (True, (slice(None), [15]), True), (False, ([2], [3]), True)])
 def test_channel_subset_is_folded_into_the_decode(manifest, squeeze, subset, folded):
