@@ -1,19 +1,23 @@
 #!/bin/bash
 # Profiles bench.py the way the bench contract asks: one --kernel-trace --stats
-# pass, then FETCH_SIZE and WRITE_SIZE in separate --pmc passes.
-# usage (GPU box, from the repo root): bash tools/prof_round.sh
+# pass over the whole default run (headline + api_read + cfg3 + other_configs),
+# then FETCH_SIZE and WRITE_SIZE in separate --pmc passes of the headline leg
+# (program directly after `--`), then the plain bench line.
+# usage (GPU box, from the repo root): bash tools/prof_round.sh [tag]
 set -u
+TAG=${1:-prof}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write
-rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o st --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/prof_stats.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o f --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/prof_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_write -o w --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/prof_write.err
+rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o st --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --traffic none > $OUT/bench_under_rocprof.json 2> $OUT/prof_stats.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/prof_fetch -o f --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --pmc-child > /dev/null 2> $OUT/prof_fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/prof_write -o w --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --pmc-child > /dev/null 2> $OUT/prof_write.err
 # keep only the small CSVs (gpurun_out is capped)
 find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -type f ! -name '*.csv' -delete
 find $OUT/prof_stats -name '*kernel_trace.csv' -delete
 cd $R
 python3 bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
-tail -1 $OUT/bench_plain.json
+tail -c 600 $OUT/bench_plain.json
