@@ -866,8 +866,13 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
     const dim3 gg((unsigned)gb);
     hipStream_t st = (hipStream_t)stream;
     const bool nt = g_tune_nt.load() != 0;
-#define BB_GS(B, L) do { if (nt) hipLaunchKernelGGL((k_decode_gather_select<B, L, true>), gg, dim3(BB_BLOCK), lds, st, ga); \
-                         else    hipLaunchKernelGGL((k_decode_gather_select<B, L, false>), gg, dim3(BB_BLOCK), lds, st, ga); } while (0)
+    // float4 stores when a selected thread sample is a multiple of four floats
+    // and the output is 16-byte aligned
+    const bool v4 = (nwithin % 4 == 0) && !((uintptr_t)d_out & 15);
+#define BB_GS(B, L) do { if (v4) { if (nt) hipLaunchKernelGGL((k_decode_gather_select<B, L, true, true>), gg, dim3(BB_BLOCK), lds, st, ga); \
+                                   else    hipLaunchKernelGGL((k_decode_gather_select<B, L, false, true>), gg, dim3(BB_BLOCK), lds, st, ga); } \
+                         else { if (nt) hipLaunchKernelGGL((k_decode_gather_select<B, L, true, false>), gg, dim3(BB_BLOCK), lds, st, ga); \
+                                else    hipLaunchKernelGGL((k_decode_gather_select<B, L, false, false>), gg, dim3(BB_BLOCK), lds, st, ga); } } while (0)
     switch (p->bps) {
         case 1: BB_GS(1, BB_LV_REG); break;
         case 2: BB_GS(2, BB_LV_REG); break;
@@ -877,8 +882,8 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
             break;
     }
 #undef BB_GS
-    BB_NOTE("k_decode_gather_select<%d,%s,%s> grid %u gtiles %u select %d of %d", p->bps, lv_name(p->bps, p->coder),
-            nt ? "nt" : "plain", gg.x, gt, nwithin, p->chunk);
+    BB_NOTE("k_decode_gather_select<%d,%s,%s,%s> grid %u gtiles %u select %d of %d", p->bps, lv_name(p->bps, p->coder),
+            nt ? "nt" : "plain", v4 ? "float4" : "scalar", gg.x, gt, nwithin, p->chunk);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }

@@ -42,9 +42,11 @@ struct bb_gather_args {
 // reference decodes whole frames and indexes the result afterwards,
 // base/base.py:706-717, 957-969): only positions within[0 .. nsel) of every
 // thread sample are written, so the output -- and its HBM traffic -- shrinks to
-// nsel / chunk of the full decode and no second pass over it is needed.  One
-// output float per lane and step (a selected row has no 16-byte structure).
-template <int BPS, int LV, bool NT>
+// nsel / chunk of the full decode and no second pass over it is needed.  V4:
+// the selection is a multiple of four floats per thread sample, so a lane
+// writes a float4 that stays inside one thread slot; otherwise one float per
+// lane and step (a selected row has no 16-byte structure then).
+template <int BPS, int LV, bool NT, bool V4>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_decode_gather_select(bb_gather_args a)
 {
@@ -79,17 +81,20 @@ void k_decode_gather_select(bb_gather_args a)
         const uint32_t g = (uint32_t)(work - f * a.ngroup);
         const uint64_t dw0 = (uint64_t)g * gdw;
         __syncthreads();
-        for (uint32_t s = bb_wave(); s < a.nslot; s += BB_WAVES_PER_BLOCK) {
+        // one wave per slot at a time; with one or two slots the waves share a slot's pieces
+        const uint32_t wps = a.nslot == 1 ? 4u : (a.nslot == 2 ? 2u : 1u);
+        const uint32_t wsub = bb_wave() % wps;
+        for (uint32_t s = bb_wave() / wps; s < a.nslot; s += BB_WAVES_PER_BLOCK / wps) {
             const int64_t so = a.src[f * a.nslot + s];
             const uint8_t *pp = a.buf + (so >= 0 ? (uint64_t)so : 0);
             const uintptr_t b0 = reinterpret_cast<uintptr_t>(pp);
             const uint32_t sh = (a.aligned && !(b0 & 3)) ? (uint32_t)((b0 >> 2) & 63) : 0u;
             const uint32_t *blk = reinterpret_cast<const uint32_t *>(pp) - sh;
-            for (uint32_t j = bb_lane(); j < gdw + 64; j += BB_WAVE) {
+            for (uint32_t j = wsub * BB_WAVE + bb_lane(); j < gdw + 64; j += BB_WAVE * wps) {
                 const uint64_t q = dw0 + j;
                 s_raw[s * pitch + j] = (so >= 0 && q >= sh && q - sh < a.ndw) ? blk[q] : 0u;
             }
-            if (bb_lane() == 0) {
+            if (bb_lane() == 0 && wsub == 0) {
                 s_valid[s] = so >= 0 ? 1u : 0u;
                 s_base[s] = (s * pitch + sh) * 4;
             }
@@ -101,9 +106,7 @@ void k_decode_gather_select(bb_gather_args a)
         const uint32_t nfloat = nrow * rowlen;
         float *obase = a.out + (f * R + (e_lo >> a.lchunk)) * rowlen;
         const uint8_t *rawb = reinterpret_cast<const uint8_t *>(s_raw);
-        for (uint32_t q = threadIdx.x; q < nfloat; q += BB_BLOCK) {
-            const uint32_t row = q / rowlen, rem = q - row * rowlen;
-            const uint32_t s = rem / a.nsel, k = rem - s * a.nsel;
+        auto value = [&](uint32_t row, uint32_t s, uint32_t k) -> float {
             const uint32_t within = s_within[k];
             const uint32_t bit = ((row << a.lchunk) + within) * BPS;
             uint32_t code;
@@ -111,7 +114,21 @@ void k_decode_gather_select(bb_gather_args a)
             else code = ((uint32_t)rawb[s_base[s] + (bit >> 3)] >> (bit & 7)) & CMASK;
             float v = lv.get(code);
             if (!s_valid[s]) v = (a.complex_data && (within & 1)) ? a.fill_im : a.fill_re;
-            bb_store1<NT>(obase + q, v);
+            return v;
+        };
+        if (V4) {
+            for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
+                const uint32_t row = q / rowlen, rem = q - row * rowlen;
+                const uint32_t s = rem / a.nsel, k = rem - s * a.nsel;
+                bb_store4<NT>(obase + q, bb_f4{value(row, s, k), value(row, s, k + 1),
+                                               value(row, s, k + 2), value(row, s, k + 3)});
+            }
+        } else {
+            for (uint32_t q = threadIdx.x; q < nfloat; q += BB_BLOCK) {
+                const uint32_t row = q / rowlen, rem = q - row * rowlen;
+                const uint32_t s = rem / a.nsel;
+                bb_store1<NT>(obase + q, value(row, s, rem - s * a.nsel));
+            }
         }
     }
 }
