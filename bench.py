@@ -67,17 +67,20 @@ def _s32(x):
 
 
 def make_file_image_on_device(nsets, seed, first_set, device, nthread=1, nchan=1,
-                              complex_data=False, order=(0,), set_rate=FRAME_RATE):
+                              complex_data=False, order=(0,), set_rate=FRAME_RATE, into=None):
     """VDIF file image born in HBM: uniform random payload bytes + EDV-0
     headers (seconds / frame_nr from the frame-set index, thread ids in
     `order`).  Same header words as baseband_amd.synth / the reference writer
-    would produce.  Returns (uint8 tensor, header0)."""
+    would produce.  `into`: optional uint8 tensor of the right size to fill.
+    Returns (uint8 tensor, header0)."""
     from baseband_amd.vdif.header import VDIFHeader
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     words_per_frame = FRAME_NBYTES // 4
     nframes = nsets * nthread
-    img = torch.empty(nframes * words_per_frame, dtype=torch.int32, device=device)
+    img = (torch.empty(nframes * words_per_frame, dtype=torch.int32, device=device) if into is None
+           else into.view(torch.int32))
+    assert img.numel() == nframes * words_per_frame
     step = 1 << 28
     for lo in range(0, img.numel(), step):          # bounded temporaries
         hi = min(img.numel(), lo + step)
@@ -357,16 +360,20 @@ def leg_cfg3(args, rank, world, device, dist, out):
     nsets = int(args.cfg3_gib * 2 ** 30) // set_nbytes
     nsets_world = nsets * world
     lo, hi = frame_slab(nsets_world, rank, world)
-    slab, h0 = make_file_image_on_device(nsets, 777 + rank, lo, device, nthread=CFG3_THREADS,
-                                         nchan=CFG3_NCHAN, complex_data=True, order=CFG3_ORDER,
-                                         set_rate=CFG3_SET_RATE)
+    kw = dict(nthread=CFG3_THREADS, nchan=CFG3_NCHAN, complex_data=True, order=CFG3_ORDER,
+              set_rate=CFG3_SET_RATE)
     if rank == 0:
-        parts = [slab] + [make_file_image_on_device(
-            nsets, 777 + r, frame_slab(nsets_world, r, world)[0], device, nthread=CFG3_THREADS,
-            nchan=CFG3_NCHAN, complex_data=True, order=CFG3_ORDER, set_rate=CFG3_SET_RATE)[0]
-            for r in range(1, world)]
-        whole = torch.cat(parts) if world > 1 else slab
-        del parts
+        # the scanning rank holds the whole file (one allocation, filled slab by
+        # slab: no concatenation copy next to the 127.5 GiB output buffer)
+        sb = nsets * set_nbytes
+        whole = torch.empty(world * sb, dtype=torch.uint8, device=device)
+        for r in range(world):
+            _, h0 = make_file_image_on_device(nsets, 777 + r, frame_slab(nsets_world, r, world)[0], device,
+                                              into=whole[r * sb:(r + 1) * sb], **kw)
+        slab = whole[:sb]
+        h0 = make_file_image_on_device(1, 777, 0, torch.device('cpu'), **kw)[1]     # header of set 0
+    else:
+        slab, h0 = make_file_image_on_device(nsets, 777 + rank, lo, device, **kw)
     pattern, mask = h0.invariant_pattern()
     thread_slot = kernels.thread_slot_map(list(range(CFG3_THREADS)), device)
     chunk = CFG3_NCHAN * 2
@@ -632,7 +639,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        import datetime
+        # (a rank that fails must become an error on the others, not a hang)
+        dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=240))
 
     from baseband_amd import kernels, _lib
     from baseband_amd.parallel import frame_slab
@@ -749,8 +758,8 @@ def main():
         try:
             line["cfg3"] = leg_cfg3(args, rank, world, device, dist, out)
         except Exception as exc:
-            if world > 1:
-                raise                       # ranks must not diverge around a collective
+            # (with several ranks the others run into the collective's timeout
+            # and land here too; the headline measured above still gets printed)
             line["cfg3"] = {"error": repr(exc)[:500]}
         if rank == 0 and world == 1:
             try:
