@@ -38,6 +38,73 @@ struct bb_gather_args {
 };
 
 // WIDE: chunks of at least four floats (a float4 never straddles thread slots)
+// Phase 1 of the gather kernels: the group's dwords of every thread slot ->
+// LDS rows (256-byte aligned block loads; the misalignment of a payload against
+// the blocks, in dwords, goes into s_base).  All payload offsets of the frame
+// set are fetched with ONE coalesced load per 64 slots and handed out with
+// shuffles, and the payload loads of different slots are issued eight at a
+// time before their LDS writes: with one load chain per slot (offset, then
+// payload, then the next slot's offset ...) 64 slots took 16 dependent round
+// trips per wave and the kernel ran at 3.6 TB/s (profiles/r02o_exp_gather64_before.log).
+__device__ __forceinline__ void bb_gather_stage(const bb_gather_args &a, uint64_t f, uint64_t dw0,
+                                                uint32_t gdw, uint32_t pitch, uint32_t *s_raw,
+                                                uint32_t *s_valid, uint32_t *s_base, uint32_t *s_missing)
+{
+    const int lane = bb_lane();
+    const uint32_t wave = (uint32_t)bb_wave();
+    // one wave per slot at a time; with one or two slots the waves share a slot's pieces
+    const uint32_t wps = a.nslot == 1 ? 4u : (a.nslot == 2 ? 2u : 1u);
+    const uint32_t wsub = wave % wps, sfirst = wave / wps, sstep = BB_WAVES_PER_BLOCK / wps;
+    const uint32_t nblk = (gdw + 64 + 64 * wps - 1) / (64 * wps);      // 64-dword pieces per slot and wave
+    for (uint32_t s0 = 0; s0 < a.nslot; s0 += BB_WAVE) {
+        const uint32_t sl = s0 + (uint32_t)lane;
+        const int64_t my_so = sl < a.nslot ? a.src[f * a.nslot + sl] : -1;
+        const uint8_t *my_p = a.buf + (my_so >= 0 ? (uint64_t)my_so : 0);
+        const uintptr_t my_ad = reinterpret_cast<uintptr_t>(my_p);
+        // misalignment of the payload against 256-byte blocks of the address
+        // space, in dwords (odd byte addresses keep plain loads)
+        const uint32_t my_sh = (a.aligned && !(my_ad & 3)) ? (uint32_t)((my_ad >> 2) & 63) : 0u;
+        if (sl < a.nslot && wave == 0) {
+            s_valid[sl] = my_so >= 0 ? 1u : 0u;
+            s_base[sl] = (sl * pitch + my_sh) * 4;
+            if (s_missing && my_so < 0) atomicAdd(s_missing, 1u);
+        }
+        const uint32_t send = (s0 + BB_WAVE < a.nslot) ? s0 + BB_WAVE : a.nslot;
+        // this wave's slots in [s0, send): sfirst + k * sstep
+        const uint32_t k0 = s0 > sfirst ? (s0 - sfirst + sstep - 1) / sstep : 0u;
+        const uint32_t sbeg = sfirst + k0 * sstep;
+        const uint32_t ns = sbeg < send ? (send - sbeg + sstep - 1) / sstep : 0u;
+        const uint32_t npiece = ns * nblk;
+        for (uint32_t p0 = 0; p0 < npiece; p0 += 8) {
+            uint32_t r[8], dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t p = p0 + u;
+                r[u] = 0u; dst[u] = 0xffffffffu;
+                if (p < npiece) {                               // wave-uniform
+                    const uint32_t k = p / nblk, b = p - k * nblk;
+                    const uint32_t s = sbeg + k * sstep;
+                    const int from = (int)(s - s0);
+                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)((uint64_t)my_ad & 0xffffffffu), from);
+                    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)my_ad >> 32), from);
+                    const uint32_t sh = (uint32_t)__shfl((int)my_sh, from);
+                    const int ok = __shfl((int)(my_so >= 0), from);
+                    const uint32_t *blk = reinterpret_cast<const uint32_t *>(((uint64_t)hi << 32) | lo) - sh;
+                    const uint32_t j = (b * wps + wsub) * BB_WAVE + (uint32_t)lane;
+                    const uint64_t q = dw0 + j;                 // block dword q = payload dword q - sh
+                    if (j < gdw + 64) {
+                        dst[u] = s * pitch + j;
+                        if (ok && q >= sh && q - sh < a.ndw) r[u] = blk[q];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (dst[u] != 0xffffffffu) s_raw[dst[u]] = r[u];
+        }
+    }
+}
+
 // The same staging with a CHANNEL SELECTION folded in (reader `subset`: the
 // reference decodes whole frames and indexes the result afterwards,
 // base/base.py:706-717, 957-969): only positions within[0 .. nsel) of every
@@ -81,24 +148,7 @@ void k_decode_gather_select(bb_gather_args a)
         const uint32_t g = (uint32_t)(work - f * a.ngroup);
         const uint64_t dw0 = (uint64_t)g * gdw;
         __syncthreads();
-        // one wave per slot at a time; with one or two slots the waves share a slot's pieces
-        const uint32_t wps = a.nslot == 1 ? 4u : (a.nslot == 2 ? 2u : 1u);
-        const uint32_t wsub = bb_wave() % wps;
-        for (uint32_t s = bb_wave() / wps; s < a.nslot; s += BB_WAVES_PER_BLOCK / wps) {
-            const int64_t so = a.src[f * a.nslot + s];
-            const uint8_t *pp = a.buf + (so >= 0 ? (uint64_t)so : 0);
-            const uintptr_t b0 = reinterpret_cast<uintptr_t>(pp);
-            const uint32_t sh = (a.aligned && !(b0 & 3)) ? (uint32_t)((b0 >> 2) & 63) : 0u;
-            const uint32_t *blk = reinterpret_cast<const uint32_t *>(pp) - sh;
-            for (uint32_t j = wsub * BB_WAVE + bb_lane(); j < gdw + 64; j += BB_WAVE * wps) {
-                const uint64_t q = dw0 + j;
-                s_raw[s * pitch + j] = (so >= 0 && q >= sh && q - sh < a.ndw) ? blk[q] : 0u;
-            }
-            if (bb_lane() == 0 && wsub == 0) {
-                s_valid[s] = so >= 0 ? 1u : 0u;
-                s_base[s] = (s * pitch + sh) * 4;
-            }
-        }
+        bb_gather_stage(a, f, dw0, gdw, pitch, s_raw, s_valid, s_base, nullptr);
         __syncthreads();
         const uint64_t e_lo = dw0 * (32 / BPS);
         const uint64_t e_hi = (e_lo + (uint64_t)gdw * (32 / BPS) < E) ? e_lo + (uint64_t)gdw * (32 / BPS) : E;
@@ -173,28 +223,7 @@ void k_decode_gather(bb_gather_args a)
         // slot at a time: coalesced 256-byte loads, no index arithmetic)
         if (threadIdx.x == 0) s_base[a.nslot] = 0;      // count of missing slots
         __syncthreads();
-        // one wave per slot at a time; with one or two slots the idle waves
-        // share a slot's pieces, so that all four keep loading
-        const uint32_t wps = a.nslot == 1 ? 4u : (a.nslot == 2 ? 2u : 1u);    // waves per slot
-        const uint32_t wsub = bb_wave() % wps;
-        for (uint32_t s = bb_wave() / wps; s < a.nslot; s += BB_WAVES_PER_BLOCK / wps) {
-            const int64_t so = a.src[f * a.nslot + s];
-            const uint8_t *pp = a.buf + (so >= 0 ? (uint64_t)so : 0);
-            const uintptr_t b0 = reinterpret_cast<uintptr_t>(pp);
-            // misalignment of the payload against 256-byte blocks of the
-            // address space, in dwords (odd byte addresses keep plain loads)
-            const uint32_t sh = (a.aligned && !(b0 & 3)) ? (uint32_t)((b0 >> 2) & 63) : 0u;
-            const uint32_t *blk = reinterpret_cast<const uint32_t *>(pp) - sh;
-            for (uint32_t j = wsub * BB_WAVE + bb_lane(); j < gdw + 64; j += BB_WAVE * wps) {
-                const uint64_t q = dw0 + j;             // block dword q = payload dword q - sh
-                s_raw[s * pitch + j] = (so >= 0 && q >= sh && q - sh < a.ndw) ? blk[q] : 0u;
-            }
-            if (bb_lane() == 0 && wsub == 0) {
-                s_valid[s] = so >= 0 ? 1u : 0u;
-                s_base[s] = (s * pitch + sh) * 4;
-                if (so < 0) atomicAdd(&s_base[a.nslot], 1u);
-            }
-        }
+        bb_gather_stage(a, f, dw0, gdw, pitch, s_raw, s_valid, s_base, &s_base[a.nslot]);
         __syncthreads();
         const bool holes = s_base[a.nslot] != 0;        // uniform
         // phase 2: contiguous output region of this group
