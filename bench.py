@@ -392,7 +392,7 @@ def leg_cfg3(args, rank, world, device, dist, out):
             src = kernels.build_index(recs, nsets_world, CFG3_THREADS, thread_slot)
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record()
-        if world > 1:
+        if dist is not None:
             src = broadcast_frame_index(src, nentries, src_rank=0, device=device)
         e[1].record()
         local, byte_lo, byte_hi = local_index(src, lo, hi, CFG3_THREADS, PAYLOAD_NBYTES)
@@ -451,7 +451,7 @@ def leg_cfg3(args, rank, world, device, dist, out):
                 "every rank: rebase (parallel.local_index) + bb_decode_frames of its slab",
         "collective": {"op": "broadcast of the dense frame index", "bytes": nentries * 8,
                        "ms": round(coll_ms, 4), "ranks_seen": int(seen.item()),
-                       "backend": "nccl (RCCL)" if world > 1 else "none (world size 1)"},
+                       "backend": "nccl (RCCL)" if dist is not None else "none (world size 1)"},
         "roofline": {"bound": "hbm", "kernel": kname[0], "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "kernel_ms_avg": round(dec_ms, 4), "algorithmic_bytes_per_launch": alg},
@@ -590,6 +590,9 @@ def main():
                     help="skip api_read / cfg3 / other_configs (headline only)")
     ap.add_argument('--pmc-child', action='store_true',
                     help="internal: headline kernel only, no JSON extras (run under rocprofv3 --pmc)")
+    ap.add_argument('--force-dist', action='store_true',
+                    help="initialise the RCCL process group even with one rank, so that every "
+                         "collective of the multi-rank path runs (a check of the N > 1 code on a 1-GPU box)")
     ap.add_argument('--dry-run', action='store_true',
                     help="CPU rehearsal of the multi-rank plumbing with gloo (no GPU, no measurement)")
     args = ap.parse_args()
@@ -636,9 +639,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         import datetime
         # (a rank that fails must become an error on the others, not a hang)
         dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=240))
