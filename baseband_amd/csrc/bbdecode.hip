@@ -260,6 +260,33 @@ unsigned launch_flat_front_any(int bps, int coder, bool nt, hipStream_t st, cons
     }
 }
 
+// k_decode_flat_es: one pass, U stripes
+template <int BPS, int LV, int U>
+unsigned launch_flat_es(bool nt, hipStream_t st, const bb_flat_args &a)
+{
+    const uint64_t ntiles = (a.ndw + 63) / 64;
+    const uint64_t total = a.nfs * ntiles;
+    const uint64_t per = (total + U - 1) / U;
+    const uint64_t blocks = (per + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
+    const dim3 grid((unsigned)(blocks > 0x7fffffffull ? 0x7fffffffull : blocks));
+    if (nt) hipLaunchKernelGGL((k_decode_flat_es<BPS, LV, true, U>), grid, dim3(BB_BLOCK), 0, st, a, total, per);
+    else    hipLaunchKernelGGL((k_decode_flat_es<BPS, LV, false, U>), grid, dim3(BB_BLOCK), 0, st, a, total, per);
+    return grid.x;
+}
+
+template <int U>
+unsigned launch_flat_es_any(int bps, int coder, bool nt, hipStream_t st, const bb_flat_args &a)
+{
+    switch (bps) {
+        case 1: return launch_flat_es<1, BB_LV_REG, U>(nt, st, a);
+        case 2: return launch_flat_es<2, BB_LV_REG, U>(nt, st, a);
+        case 4: return launch_flat_es<4, BB_LV_LDS, U>(nt, st, a);
+        default:
+            if (coder == BB_CODER_INT) return launch_flat_es<8, BB_LV_INT8, U>(nt, st, a);
+            return launch_flat_es<8, BB_LV_LDS, U>(nt, st, a);
+    }
+}
+
 template <int BPS, int LV>
 void launch_flat_span(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
@@ -587,6 +614,21 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     // (round 2: with the striped work order the two are equal there --
     // 5.60 / 5.61 TB/s at 2^16 frames, profiles/r02e_exp_order.log -- and the
     // fallback is gone)
+
+    if (variant >= 10 && variant <= 13 && om == BB_OUT_FLAT) {
+        // one pass, striped (k_front.h): 10 = 2 tiles per wave, 11 = 4, 12 = 8, 13 = 16
+        unsigned gx;
+        switch (variant) {
+            case 10: gx = launch_flat_es_any<2>(p->bps, p->coder, nt, st, a); break;
+            case 11: gx = launch_flat_es_any<4>(p->bps, p->coder, nt, st, a); break;
+            case 12: gx = launch_flat_es_any<8>(p->bps, p->coder, nt, st, a); break;
+            default: gx = launch_flat_es_any<16>(p->bps, p->coder, nt, st, a); break;
+        }
+        BB_NOTE("k_decode_flat_es<%d,%s,%s,%d> grid %u", p->bps, lv_name(p->bps, p->coder), nt ? "nt" : "plain",
+                variant == 10 ? 2 : variant == 11 ? 4 : variant == 12 ? 8 : 16, gx);
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
 
     if (variant >= 6 && variant <= 9 && om == BB_OUT_FLAT) {
         // explicit write front (k_front.h): 6 = 4 waves x 1 tile, 7 = 4 x 2, 8 = 2 x 4, 9 = 4 x 4

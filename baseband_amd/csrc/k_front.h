@@ -138,3 +138,87 @@ void k_decode_flat_front(bb_flat_args a, bb_front_geom g)
         fs = nfs_; j = nj; item = nitem;
     }
 }
+
+// ---- one pass, striped ("elementwise") form ---------------------------------
+// tools/kbench.cpp, KB_ELEM (profiles/r02s_kbench_elem.log): a 2-bit decode
+// written like a fill -- every thread owns a few float4 of the output, loads
+// their input first, then stores; the grid is sized for ONE pass; a thread's
+// pieces lie in different stripes of the output, so there are a few write
+// fronts that advance with the dispatch order -- runs at 6.25-6.33 TB/s for 8.5,
+// 34 and 137 GB of output alike, where the workgroup-per-frame and persistent
+// kernels run at 5.4-5.65 below ~33 GB (one physical region).
+// This is that form for real frames: a wave owns U tiles (256 input bytes ->
+// 8/BPS KiB of output each), tile u in stripe u of the launch's tile sequence;
+// all U loads are issued before the first store.  One pass: grid = tiles per
+// stripe / waves per workgroup.
+template <int BPS, int LV, bool NT, int U>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_flat_es(bb_flat_args a, uint64_t ntile_total, uint64_t per_stripe)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr int EPT = 2048 / BPS;
+    constexpr int PASSES = 8 / BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
+        __syncthreads();
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    const int lane = bb_lane();
+    const uint64_t g = (uint64_t)blockIdx.x * BB_WAVES_PER_BLOCK + (uint64_t)__builtin_amdgcn_readfirstlane(bb_wave());
+    if (g >= per_stripe) return;                            // wave-uniform
+    const uint64_t E = a.ndw * (32 / BPS);
+    const uint32_t ntiles = (uint32_t)((a.ndw + 63) / 64);
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+    const int src_lane0 = (lane * BPS) >> 3;
+    const int shift = (4 * lane * BPS) & 31;
+
+    uint32_t w[U];
+    uint64_t fsv[U];
+    uint32_t tilev[U];
+    bool validv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint64_t t = (uint64_t)u * per_stripe + g;
+        w[u] = 0u; fsv[u] = ~0ull; tilev[u] = 0; validv[u] = false;
+        if (t < ntile_total) {                              // wave-uniform
+            const uint64_t fs = t / ntiles;
+            const uint32_t tile = (uint32_t)(t - fs * ntiles);
+            const int64_t so = a.src ? a.src[fs] : a.src0 + (int64_t)fs * a.src_stride;
+            fsv[u] = fs; tilev[u] = tile; validv[u] = so >= 0;
+            const uint64_t dw = (uint64_t)tile * 64 + lane;
+            if (so >= 0 && dw < a.ndw)
+                w[u] = reinterpret_cast<const uint32_t *>(a.buf + so)[dw];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (fsv[u] == ~0ull) continue;
+        float *obase = a.out + fsv[u] * E;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            uint32_t bits;
+            if (BPS == 8) bits = w[u];
+            else bits = (uint32_t)__shfl((int)w[u], p * 8 * BPS + src_lane0) >> shift;
+            const uint64_t e0 = (uint64_t)tilev[u] * EPT + 256 * p + 4 * lane;
+            if (e0 >= E) continue;
+            bb_f4 v;
+            if (validv[u]) {
+                v.x = lv.get(bits & CMASK);
+                v.y = lv.get((bits >> BPS) & CMASK);
+                v.z = lv.get((bits >> (2 * BPS)) & CMASK);
+                v.w = lv.get((bits >> (3 * BPS)) & CMASK);
+            } else {
+                v = fillv;
+            }
+            bb_store4<NT>(obase + e0, v);
+        }
+    }
+}

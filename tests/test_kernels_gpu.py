@@ -450,3 +450,34 @@ def test_decode_with_channel_selection(bps, chunk, nslot, sel):
             kernels.tune(_lib.TUNE_WORK_STRIPES, -1)
         assert 'k_decode_gather_select' in _lib.last_kernel()
         assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(exp[..., sel]).reshape(-1)), lw
+
+
+@pytest.mark.parametrize('variant', [10, 11, 12, 13])
+@pytest.mark.parametrize('coder,bps', COMBOS)
+def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
+    """k_decode_flat_es (one pass, U stripes): every U x coder against the
+    oracle -- ragged payloads, frame counts that do not divide by U, holes."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(variant * 100 + bps)
+    try:
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+        for pn, nfr, hdr in ((8000, 37, 32), (260, 50, 16), (10000, 9, 16), (256, 131, 0), (8, 11, 8), (5000, 23, 32)):
+            stride = pn + hdr
+            raw = rng.integers(0, 256, stride * nfr, dtype=np.uint8)
+            dbuf = kernels.to_device_bytes(raw)
+            exp = np.concatenate([orc.decode_flat(raw[i * stride + hdr:(i + 1) * stride], coder, bps)
+                                  for i in range(nfr)])
+            out = kernels.decode_frames(dbuf, nfr, pn, CODERS[coder], bps, src0=hdr, src_stride=stride)
+            assert 'k_decode_flat_es' in _lib.last_kernel()
+            assert bits_equal(out.cpu().numpy(), exp), (pn, nfr)
+            src = np.arange(nfr, dtype=np.int64) * stride + hdr
+            holes = rng.choice(nfr, size=max(1, nfr // 5), replace=False)
+            src[holes] = -1
+            out = kernels.decode_frames(dbuf, nfr, pn, CODERS[coder], bps,
+                                        src=torch.from_numpy(src).cuda(), fill_value=-2.5)
+            want = exp.reshape(nfr, -1).copy()
+            want[holes] = -2.5
+            assert bits_equal(out.cpu().numpy(), want.reshape(-1)), (pn, nfr, 'holes')
+    finally:
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)

@@ -96,6 +96,63 @@ void k_fill_regions(f4 *out, const uint32_t *in, size_t nregions)
     }
 }
 
+// "Elementwise" 2-bit decode: thread i produces float4 number i of the output
+// (grid-stride over ALL float4 of the launch, exactly the store pattern of
+// k_fill) from dword i / 4 of a headerless input: what does the dependent load
+// cost when the write front is the fill's?  WPT float4 per thread (consecutive
+// iterations of the grid-stride loop), loads issued before the stores.
+template <int WPT>
+__global__ void k_elem_decode(const uint32_t *in, f4 *out, size_t n4)
+{
+    const float lv[4] = {-3.316505f, -1.f, 1.f, 3.316505f};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += stride * WPT) {
+        uint32_t w[WPT];
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const size_t i = i0 + k * stride;
+            w[k] = i < n4 ? in[i >> 2] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) {
+            const size_t i = i0 + k * stride;
+            if (i >= n4) break;
+            const uint32_t b = w[k] >> (8 * (i & 3));
+            f4 v = {lv[b & 3], lv[(b >> 2) & 3], lv[(b >> 4) & 3], lv[(b >> 6) & 3]};
+            __builtin_nontemporal_store(v, &out[i]);
+        }
+    }
+}
+
+// The same in ONE pass with the grid sized for it: a thread owns WPT float4.
+// STRIPED: they lie n4 / WPT apart (WPT write fronts that advance with the
+// dispatch order); otherwise they are consecutive 4 KiB blocks of one front
+// (the workgroup writes WPT * 4 KiB contiguous).
+template <int WPT, bool STRIPED>
+__global__ void k_elem_decode1(const uint32_t *in, f4 *out, size_t n4)
+{
+    const float lv[4] = {-3.316505f, -1.f, 1.f, 3.316505f};
+    const size_t per = (n4 + WPT - 1) / WPT;                // float4 per stripe
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t w[WPT];
+    size_t idx[WPT];
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        idx[k] = STRIPED ? t + k * per
+                         : ((size_t)blockIdx.x * WPT + k) * blockDim.x + threadIdx.x;
+        const bool ok = STRIPED ? (t < per && idx[k] < n4) : idx[k] < n4;
+        if (!ok) idx[k] = ~(size_t)0;
+        w[k] = ok ? in[idx[k] >> 2] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) {
+        if (idx[k] == ~(size_t)0) continue;
+        const uint32_t b = w[k] >> (8 * (idx[k] & 3));
+        f4 v = {lv[b & 3], lv[(b >> 2) & 3], lv[(b >> 4) & 3], lv[(b >> 6) & 3]};
+        __builtin_nontemporal_store(v, &out[idx[k]]);
+    }
+}
+
 static double time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 int main(int argc, char **argv)
@@ -135,6 +192,54 @@ int main(int argc, char **argv)
         std::sort(t.begin(), t.end());
         printf("fill nt=1 grid=%u: median %.3f ms  %.1f GB/s\n", gridsz, t[t.size() / 2],
                out_elems * 4 / t[t.size() / 2] / 1e6);
+    }
+    if (getenv("KB_ELEM")) {
+        // elementwise decode against the fill, same grids
+        const size_t n4 = std::min<size_t>((in_bytes / 4) * 4, out_elems / 4);   // float4 count = 4 per input dword, inside the output buffer
+        for (unsigned gridsz : {8192u, 32768u, 131072u, 524288u, 2097152u, 0u}) {
+            for (int wpt : {1, 4}) {
+                size_t need = (n4 + 255) / 256;
+                unsigned g = gridsz ? gridsz : (unsigned)std::min<size_t>(need, 0x7fffffff);
+                if (gridsz && (size_t)gridsz > need) continue;
+                std::vector<double> t;
+                for (int r = 0; r < reps + 1; ++r) {
+                    CK(hipEventRecord(e0));
+                    if (wpt == 1) hipLaunchKernelGGL(k_elem_decode<1>, dim3(g), dim3(256), 0, 0, (const uint32_t *)d_in, (f4 *)d_out, n4);
+                    else          hipLaunchKernelGGL(k_elem_decode<4>, dim3(g), dim3(256), 0, 0, (const uint32_t *)d_in, (f4 *)d_out, n4);
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    if (r) t.push_back(time_ms(e0, e1));
+                }
+                std::sort(t.begin(), t.end());
+                printf("elem_decode grid=%u%s wpt=%d: %.3f ms  %.1f GB/s (in+out)\n", g, gridsz ? "" : " (one-shot)", wpt,
+                       t[t.size() / 2], (n4 * 16.0 + n4) / t[t.size() / 2] / 1e6);
+            }
+        }
+#define KB_ONE(W, S) do { \
+            const size_t need = ((n4 + (W) - 1) / (W) + 255) / 256; \
+            std::vector<double> t; \
+            for (int r = 0; r < reps + 1; ++r) { \
+                CK(hipEventRecord(e0)); \
+                hipLaunchKernelGGL((k_elem_decode1<W, S>), dim3((unsigned)need), dim3(256), 0, 0, (const uint32_t *)d_in, (f4 *)d_out, n4); \
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
+                if (r) t.push_back(time_ms(e0, e1)); \
+            } \
+            std::sort(t.begin(), t.end()); \
+            printf("elem_decode one pass wpt=%d %s: %.3f ms  %.1f GB/s (in+out)\n", W, (S) ? "striped" : "contiguous", \
+                   t[t.size() / 2], (n4 * 16.0 + n4) / t[t.size() / 2] / 1e6); } while (0)
+        KB_ONE(2, true); KB_ONE(4, true); KB_ONE(8, true); KB_ONE(16, true); KB_ONE(32, true);
+        KB_ONE(2, false); KB_ONE(4, false); KB_ONE(8, false); KB_ONE(16, false);
+        for (unsigned gridsz : {32768u, 2097152u}) {
+            std::vector<double> t;
+            for (int r = 0; r < reps + 1; ++r) {
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(k_fill<true>, dim3(gridsz), dim3(256), 0, 0, (f4 *)d_out, n4);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                if (r) t.push_back(time_ms(e0, e1));
+            }
+            std::sort(t.begin(), t.end());
+            printf("fill same range grid=%u: %.3f ms  %.1f GB/s\n", gridsz, t[t.size() / 2], n4 * 16.0 / t[t.size() / 2] / 1e6);
+        }
+        return 0;
     }
     // fill by runs: run length x threads per workgroup x grid
     if (getenv("KB_RUNS")) {
