@@ -615,17 +615,17 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     // 5.60 / 5.61 TB/s at 2^16 frames, profiles/r02e_exp_order.log -- and the
     // fallback is gone)
 
-    if (variant >= 10 && variant <= 13 && om == BB_OUT_FLAT) {
-        // one pass, striped (k_front.h): 10 = 2 tiles per wave, 11 = 4, 12 = 8, 13 = 16
+    if (variant >= 10 && variant <= 12 && om == BB_OUT_FLAT) {
+        // one pass, striped (k_front.h): 10 = 2 tiles per wave, 11 = 4, 12 = 8
+        // (16 ran at 3.5-4 TB/s, profiles/r02t_exp_es.log, and is gone)
         unsigned gx;
         switch (variant) {
             case 10: gx = launch_flat_es_any<2>(p->bps, p->coder, nt, st, a); break;
             case 11: gx = launch_flat_es_any<4>(p->bps, p->coder, nt, st, a); break;
-            case 12: gx = launch_flat_es_any<8>(p->bps, p->coder, nt, st, a); break;
-            default: gx = launch_flat_es_any<16>(p->bps, p->coder, nt, st, a); break;
+            default: gx = launch_flat_es_any<8>(p->bps, p->coder, nt, st, a); break;
         }
         BB_NOTE("k_decode_flat_es<%d,%s,%s,%d> grid %u", p->bps, lv_name(p->bps, p->coder), nt ? "nt" : "plain",
-                variant == 10 ? 2 : variant == 11 ? 4 : variant == 12 ? 8 : 16, gx);
+                variant == 10 ? 2 : variant == 11 ? 4 : 8, gx);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
