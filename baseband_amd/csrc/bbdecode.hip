@@ -287,6 +287,19 @@ unsigned launch_flat_es_any(int bps, int coder, bool nt, hipStream_t st, const b
     }
 }
 
+// k_decode_flat_elem: one pass, 16 stripes of whole frames, one float4 per thread and stripe
+template <int BPS, int LV>
+unsigned launch_flat_elem(bool nt, hipStream_t st, const bb_flat_args &a)
+{
+    const uint64_t fps = (a.nfs + BB_ELEM_STRIPES - 1) / BB_ELEM_STRIPES;
+    const uint64_t E4 = a.ndw * (32 / BPS) / 4;
+    const uint64_t blocks = (fps * E4 + BB_BLOCK - 1) / BB_BLOCK;
+    const dim3 grid((unsigned)(blocks > 0x7fffffffull ? 0x7fffffffull : blocks));
+    if (nt) hipLaunchKernelGGL((k_decode_flat_elem<BPS, LV, true>), grid, dim3(BB_BLOCK), 0, st, a, fps);
+    else    hipLaunchKernelGGL((k_decode_flat_elem<BPS, LV, false>), grid, dim3(BB_BLOCK), 0, st, a, fps);
+    return grid.x;
+}
+
 template <int BPS, int LV>
 void launch_flat_span(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
@@ -614,6 +627,23 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     // (round 2: with the striped work order the two are equal there --
     // 5.60 / 5.61 TB/s at 2^16 frames, profiles/r02e_exp_order.log -- and the
     // fallback is gone)
+
+    if (variant == 14 && om == BB_OUT_FLAT) {
+        // the fill-shaped decode (k_front.h)
+        unsigned gx;
+        switch (p->bps) {
+            case 1: gx = launch_flat_elem<1, BB_LV_REG>(nt, st, a); break;
+            case 2: gx = launch_flat_elem<2, BB_LV_REG>(nt, st, a); break;
+            case 4: gx = launch_flat_elem<4, BB_LV_LDS>(nt, st, a); break;
+            default:
+                if (p->coder == BB_CODER_INT) gx = launch_flat_elem<8, BB_LV_INT8>(nt, st, a);
+                else                          gx = launch_flat_elem<8, BB_LV_LDS>(nt, st, a);
+                break;
+        }
+        BB_NOTE("k_decode_flat_elem<%d,%s,%s> grid %u", p->bps, lv_name(p->bps, p->coder), nt ? "nt" : "plain", gx);
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
 
     if (variant >= 10 && variant <= 12 && om == BB_OUT_FLAT) {
         // one pass, striped (k_front.h): 10 = 2 tiles per wave, 11 = 4, 12 = 8

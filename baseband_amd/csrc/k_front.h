@@ -222,3 +222,79 @@ void k_decode_flat_es(bb_flat_args a, uint64_t ntile_total, uint64_t per_stripe)
         }
     }
 }
+
+// ---- the fill-shaped decode for real frames ---------------------------------
+// tools/kbench.cpp KB_ELEM carried over with the frame arithmetic it needs: ONE
+// pass; thread j of the grid owns float4 number j of each of the S = 16 stripes
+// of the launch (a stripe = frames [k * fps, (k + 1) * fps)), i.e. 16 float4
+// that lie fps frames apart; their 16 input dwords are loaded first (every
+// stripe has the same frame geometry, so ONE division per thread places all of
+// them), then come the 16 stores.  A wave-store is 1 KiB contiguous and
+// consecutive workgroups write consecutive 4 KiB of every stripe: 16 write
+// fronts that advance with the dispatch order, like a fill's.
+#define BB_ELEM_STRIPES 16
+template <int BPS, int LV, bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_flat_elem(bb_flat_args a, uint64_t fps)
+{
+    constexpr int NCODE = 1 << BPS;
+    constexpr uint32_t CMASK = NCODE - 1;
+    constexpr uint32_t FPD = 8 / BPS;                       // float4 per input dword
+    __shared__ float s_tab[LV == BB_LV_LDS ? NCODE : 1];
+    bb_levels<BPS, LV> lv;
+    lv.lds = s_tab;
+    if (LV == BB_LV_LDS) {
+        for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
+        __syncthreads();
+    } else if (LV == BB_LV_REG) {
+        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
+        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+    }
+    const uint64_t E = a.ndw * (32 / BPS);                  // floats per frame-slot (a multiple of 4)
+    const uint32_t E4 = (uint32_t)(E >> 2);                 // float4 per frame-slot
+    const uint64_t j = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+    // position inside a stripe -> (frame of the stripe, float4 of the frame)
+    uint64_t fl;
+    uint32_t r;
+    if ((fps * E4) >> 32) { fl = j / E4; r = (uint32_t)(j - fl * E4); }
+    else { const uint32_t q = (uint32_t)j / E4; fl = q; r = (uint32_t)j - q * E4; }
+    if (fl >= fps) return;
+    const uint32_t dwi = r / FPD;                           // input dword of the payload (FPD is a power of two)
+    const uint32_t sh = (r & (FPD - 1)) * 4 * BPS;
+    const bb_f4 fillv = a.complex_data
+        ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
+        : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
+
+    uint32_t w[BB_ELEM_STRIPES];
+    int64_t sov[BB_ELEM_STRIPES];
+#pragma unroll
+    for (int k = 0; k < BB_ELEM_STRIPES; ++k) {
+        const uint64_t f = (uint64_t)k * fps + fl;
+        sov[k] = f < a.nfs ? (a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride) : -2;
+    }
+#pragma unroll
+    for (int k = 0; k < BB_ELEM_STRIPES; ++k) {
+        w[k] = 0u;
+        if (sov[k] >= 0) {
+            const uint8_t *p = a.buf + sov[k] + (uint64_t)dwi * 4;
+            if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) w[k] = *reinterpret_cast<const uint32_t *>(p);
+            else w[k] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < BB_ELEM_STRIPES; ++k) {
+        if (sov[k] == -2) continue;                         // beyond the last frame
+        const uint64_t f = (uint64_t)k * fps + fl;
+        bb_f4 v;
+        if (sov[k] >= 0) {
+            const uint32_t bits = w[k] >> sh;
+            v.x = lv.get(bits & CMASK);
+            v.y = lv.get((bits >> BPS) & CMASK);
+            v.z = lv.get((bits >> (2 * BPS)) & CMASK);
+            v.w = lv.get((bits >> (3 * BPS)) & CMASK);
+        } else {
+            v = fillv;
+        }
+        bb_store4<NT>(a.out + f * E + 4ull * r, v);
+    }
+}

@@ -452,7 +452,7 @@ def test_decode_with_channel_selection(bps, chunk, nslot, sel):
         assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(exp[..., sel]).reshape(-1)), lw
 
 
-@pytest.mark.parametrize('variant', [10, 11, 12])
+@pytest.mark.parametrize('variant', [10, 11, 12, 14])
 @pytest.mark.parametrize('coder,bps', COMBOS)
 def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
     """k_decode_flat_es (one pass, U stripes): every U x coder against the
@@ -469,7 +469,7 @@ def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
             exp = np.concatenate([orc.decode_flat(raw[i * stride + hdr:(i + 1) * stride], coder, bps)
                                   for i in range(nfr)])
             out = kernels.decode_frames(dbuf, nfr, pn, CODERS[coder], bps, src0=hdr, src_stride=stride)
-            assert 'k_decode_flat_es' in _lib.last_kernel()
+            assert ('k_decode_flat_elem' if variant == 14 else 'k_decode_flat_es') in _lib.last_kernel()
             assert bits_equal(out.cpu().numpy(), exp), (pn, nfr)
             src = np.arange(nfr, dtype=np.int64) * stride + hdr
             holes = rng.choice(nfr, size=max(1, nfr // 5), replace=False)

@@ -31,11 +31,11 @@ for where in ("fresh", "slice"):
         o = big[:nfr * per] if big is not None else torch.empty(nfr * per, dtype=torch.float32, device='cuda')
         row = {"frames": nfr, "where": where, "out_GB": round(nfr * per * 4 / 1e9, 1)}
         fn = lambda: kernels.decode_frames(buf, nfr, payload, _lib.CODER_VDIF, 2, src0=header, src_stride=stride, out=o)
-        for v in (5, 0, 10, 11, 12):
+        for v in (5, 0, 10, 11, 14):
             row["v%d" % v] = run(fn, nfr * (stride + payload * 16), v)
         src = torch.arange(nfr, device='cuda', dtype=torch.int64) * stride + header
         fn2 = lambda: kernels.decode_frames(buf, nfr, payload, _lib.CODER_VDIF, 2, src=src, out=o)
-        for v in (5, 12):
+        for v in (5, 14):
             row["indexed_v%d" % v] = run(fn2, nfr * (stride + payload * 16), v)
         print(json.dumps(row), flush=True)
         del o
@@ -49,7 +49,7 @@ for where in ("fresh", "slice"):
                 o = big[:n * pn * 8 // bps]
                 row = {"case": name, "frames": n, "out_GB": round(o.numel() * 4 / 1e9, 1)}
                 fn = lambda: kernels.decode_frames(buf, n, pn, coder, bps, src0=hd, src_stride=pn + hd, out=o)
-                for v in (5, 0, 11, 12):
+                for v in (5, 0, 11, 14):
                     row["v%d" % v] = run(fn, n * (pn + hd + pn * 8 // bps * 4), v)
                 print(json.dumps(row), flush=True)
     del big
