@@ -435,7 +435,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
                     void *d_out, size_t out_nbytes, void *stream);
 
 /* ---- tuning knobs (performance experiments; results never change) ------ */
-#define BB_TUNE_FLAT_VARIANT   0   /* 0 = workgroup per frame, 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16 tiles per frame segment, 4 = contiguous output cut in output space (k_decode_flat_span), 5 = as 3 with 256-byte aligned block loads for contiguous output (k_decode_flat_aln; default), 6-9 = explicit write front (k_decode_flat_front; experiment, slower), 10-12 = one pass with 2/4/8 stripes per wave (k_decode_flat_es; experiment, within +-4 % of 0 and 5) */
+#define BB_TUNE_FLAT_VARIANT   0   /* 0 = workgroup per frame, 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16 tiles per frame segment, 4 = contiguous output cut in output space (k_decode_flat_span), 5 = as 3 with 256-byte aligned block loads for contiguous output (k_decode_flat_aln; default), 6-9 = explicit write front (k_decode_flat_front; experiment, slower), 10-12 = one pass with 2/4/8 stripes per wave (k_decode_flat_es; experiment, within +-4 % of 0 and 5), 14 = one float4 per thread and stripe (k_decode_flat_elem; experiment) */
 #define BB_TUNE_NT_STORES      1   /* 1 = non-temporal stores */
 #define BB_TUNE_BLOCKS         2   /* 0 = default grid; >0 = number of workgroups */
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */
