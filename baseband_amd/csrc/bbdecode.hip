@@ -617,6 +617,10 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     int variant = g_tune_variant.load();
     if (variant == 5 && p->bps == 8 && om == BB_OUT_FLAT && g_tune_tpw8.load() <= 16)
         variant = 0;
+    // 4-bit samples (11 % of the traffic is reads): the plain kernel is 3-6 %
+    // ahead as well (profiles/r02t_exp_es.log, r02u_exp_es_elem.log: 5.72-5.82
+    // against 5.43-5.55 TB/s at 4 and 34 GB of output)
+    if (variant == 5 && p->bps == 4 && om == BB_OUT_FLAT) variant = 0;
     // Mid-size launches: with one or two work items per workgroup the
     // persistent pipelined kernel (5.1-5.3 TB/s) loses to the plain one
     // (5.4-5.5); from four items per workgroup on it is at least as fast on
