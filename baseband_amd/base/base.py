@@ -505,7 +505,13 @@ class GPUStreamReaderBase:
             keep = n <= torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory // 4
         if not keep or n == 0:
             return None
-        self._sink = torch.empty(n + 256, dtype=torch.uint8, device='cuda')
+        try:
+            self._sink = torch.empty(n + 256, dtype=torch.uint8, device='cuda')
+        except torch.cuda.OutOfMemoryError:
+            # no room for a copy of the file next to the caller's tensors:
+            # rotate two window buffers as before
+            self.keep_staged = False
+            return None
         self._sink[n:] = 0
         self._have = []
         return self._sink
@@ -513,7 +519,7 @@ class GPUStreamReaderBase:
     def _mark_have(self, lo, hi):
         if hi <= lo:
             return
-        merged, placed = [], False
+        merged = []
         for a, b in self._have:
             if b < lo or a > hi:
                 merged.append((a, b))
