@@ -316,7 +316,19 @@ class GPUStreamReaderBase:
         self.close()
 
     # -- channel selection folded into the decode kernel
-    _within = None          # int32 device tensor: positions of a thread sample that are decoded
+    _within_np = None       # int32 positions of a thread sample that are decoded (None: all)
+    _within_dev = None
+
+    @property
+    def _within(self):
+        """The selection as a device tensor (uploaded on first use, so that a
+        reader can be opened -- for `info`, say -- without a GPU)."""
+        if self._within_np is None:
+            return None
+        if self._within_dev is None:
+            kernels.require_gpu()
+            self._within_dev = torch.from_numpy(self._within_np).to('cuda')
+        return self._within_dev
 
     def _plan_channel_select(self, subset):
         """If `subset` (what `_squeeze_and_subset` would apply to decoded
@@ -359,15 +371,14 @@ class GPUStreamReaderBase:
             return                                  # every channel, in order: nothing to fold
         ncomp = 2 if self.complex_data else 1
         within = (picked[:, None] * ncomp + np.arange(ncomp)).reshape(-1).astype(np.int32)
-        kernels.require_gpu()
-        self._within = torch.from_numpy(within).to('cuda')
+        self._within_np = within
         self._decode_shape = shape[:-1] + (m,)
 
     # -- shapes
     def _squeeze_and_subset(self, data):
         """Remove unit dimensions, then apply `subset`
         (base/base.py:706-717)."""
-        if self._within is not None:
+        if self._within_np is not None:
             # the kernel wrote exactly the selected samples, in the final order
             return data.reshape(data.shape[:1] + self.sample_shape)
         if self.squeeze:
@@ -653,7 +664,7 @@ class GPUStreamReaderBase:
         if (not isinstance(out, torch.Tensor) or not out.is_cuda or not out.is_contiguous()
                 or out.dtype != (torch.complex64 if self.complex_data else torch.float32)):
             return None
-        if self._within is None and (self.subset or getattr(self, '_frameset_subset', None)
+        if self._within_np is None and (self.subset or getattr(self, '_frameset_subset', None)
                                      or tuple(self._decode_shape) != tuple(self._unsliced_shape)):
             return None
         flat = torch.view_as_real(out) if self.complex_data else out

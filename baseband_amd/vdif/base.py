@@ -356,7 +356,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
 
     def _squeeze_and_subset(self, data):
         # threads were already selected on read (vdif/base.py:519-528)
-        if self._within is not None:            # ... and so were the channels, in the kernel
+        if self._within_np is not None:            # ... and so were the channels, in the kernel
             return data.reshape(data.shape[:1] + self.sample_shape)
         if self.squeeze:
             data = data.reshape(data.shape[:1]

@@ -826,3 +826,29 @@ def test_lazy_write_file_creates_on_first_use_and_maps(tmp_path):
     assert path.read_bytes() == b'head' + np.array([1, 2, 3], '<u4').tobytes() + b'tail'
     with pytest.raises(ValueError):
         LazyWriteFile(str(path)).memmap(dtype='u1')
+
+
+def test_channel_selection_is_planned_without_a_gpu():
+    """Opening a reader with a channel subset plans the in-kernel selection
+    (positions of a thread sample that get decoded) on the host; nothing
+    touches the GPU before the first read."""
+    from baseband_amd import vdif, mark5b
+    from conftest import golden_path
+    import json
+    with open(golden_path('manifest.json')) as f:
+        case = json.load(f)['cases']['vdif_cfg3_small']
+    kw = dict(sample_rate=case['frame_rate'] * case['samples_per_frame'])
+    with vdif.open(golden_path(case['file']), 'rs', subset=([6, 1], slice(3, 9)), **kw) as fh:
+        assert fh.sample_shape == (2, 6)
+        assert fh._within_np.tolist() == [6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17]   # complex: (re, im) of channels 3..8
+        assert fh._decode_shape == (2, 6) and fh._within_dev is None
+    with vdif.open(golden_path(case['file']), 'rs', subset=([5],), **kw) as fh:
+        assert fh._within_np is None                     # threads only
+    with vdif.open(golden_path(case['file']), 'rs', subset=(slice(None), slice(None)), **kw) as fh:
+        assert fh._within_np is None                     # every channel
+    with mark5b.open(golden_path('samples/sample.m5b'), 'rs', kday=56000, nchan=8, bps=2,
+                     sample_rate=32e6, subset=[1, 6]) as fh:
+        assert fh._within_np.tolist() == [1, 6] and fh.sample_shape == (2,)
+    with mark5b.open(golden_path('samples/sample.m5b'), 'rs', kday=56000, nchan=8, bps=2,
+                     sample_rate=32e6, subset=3) as fh:
+        assert fh._within_np.tolist() == [3] and fh.sample_shape == ()

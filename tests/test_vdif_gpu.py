@@ -447,7 +447,7 @@ def test_channel_subset_is_folded_into_the_decode(manifest, squeeze, subset, fol
     full = exp
     want = full[(slice(None),) + subset]        # (8 threads, 16 channels: nothing to squeeze first)
     with vdif.open(golden_path(case['file']), 'rs', squeeze=squeeze, subset=subset, **_kw(case)) as fh:
-        assert (fh._within is not None) == folded
+        assert (fh._within_np is not None) == folded
         assert fh.sample_shape == want.shape[1:]
         got = fh.read()
         if folded:

@@ -153,6 +153,26 @@ __global__ void k_elem_decode1(const uint32_t *in, f4 *out, size_t n4)
     }
 }
 
+// Store flavours (MI355X_MICROARCH.md, "stores of each flavour"): plain / nt keep
+// the line in the XCD's L2, sc1 / sc0 sc1 drop it after the write.  Same
+// grid-stride fill, the store written in inline asm.  MODE 0 plain, 1 nt,
+// 2 sc1, 3 sc0 sc1, 4 sc1 nt.
+template <int MODE>
+__global__ void k_fill_flavour(f4 *p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const f4 v = {1.f, 2.f, 3.f, 4.f};
+    for (; i < n; i += stride) {
+        f4 *q = p + i;
+        if (MODE == 0)      asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(q), "v"(v) : "memory");
+        else if (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(q), "v"(v) : "memory");
+        else if (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(q), "v"(v) : "memory");
+        else if (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(q), "v"(v) : "memory");
+        else                asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" :: "v"(q), "v"(v) : "memory");
+    }
+}
+
 static double time_ms(hipEvent_t a, hipEvent_t b) { float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 int main(int argc, char **argv)
@@ -192,6 +212,30 @@ int main(int argc, char **argv)
         std::sort(t.begin(), t.end());
         printf("fill nt=1 grid=%u: median %.3f ms  %.1f GB/s\n", gridsz, t[t.size() / 2],
                out_elems * 4 / t[t.size() / 2] / 1e6);
+    }
+    if (getenv("KB_STORE")) {
+        for (unsigned gridsz : {32768u, 2097152u}) {
+            for (int mode = 0; mode < 5; ++mode) {
+                std::vector<double> t;
+                for (int r = 0; r < reps + 1; ++r) {
+                    CK(hipEventRecord(e0));
+                    switch (mode) {
+                        case 0: hipLaunchKernelGGL(k_fill_flavour<0>, dim3(gridsz), dim3(256), 0, 0, (f4 *)d_out, out_elems / 4); break;
+                        case 1: hipLaunchKernelGGL(k_fill_flavour<1>, dim3(gridsz), dim3(256), 0, 0, (f4 *)d_out, out_elems / 4); break;
+                        case 2: hipLaunchKernelGGL(k_fill_flavour<2>, dim3(gridsz), dim3(256), 0, 0, (f4 *)d_out, out_elems / 4); break;
+                        case 3: hipLaunchKernelGGL(k_fill_flavour<3>, dim3(gridsz), dim3(256), 0, 0, (f4 *)d_out, out_elems / 4); break;
+                        default: hipLaunchKernelGGL(k_fill_flavour<4>, dim3(gridsz), dim3(256), 0, 0, (f4 *)d_out, out_elems / 4); break;
+                    }
+                    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                    if (r) t.push_back(time_ms(e0, e1));
+                }
+                std::sort(t.begin(), t.end());
+                static const char *names[] = {"plain", "nt", "sc1", "sc0 sc1", "sc1 nt"};
+                printf("fill store=%s grid=%u: %.3f ms  %.1f GB/s\n", names[mode], gridsz, t[t.size() / 2],
+                       out_elems * 4 / t[t.size() / 2] / 1e6);
+            }
+        }
+        return 0;
     }
     if (getenv("KB_ELEM")) {
         // elementwise decode against the fill, same grids
