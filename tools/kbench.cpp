@@ -128,7 +128,7 @@ __global__ void k_elem_decode(const uint32_t *in, f4 *out, size_t n4)
 // STRIPED: they lie n4 / WPT apart (WPT write fronts that advance with the
 // dispatch order); otherwise they are consecutive 4 KiB blocks of one front
 // (the workgroup writes WPT * 4 KiB contiguous).
-template <int WPT, bool STRIPED>
+template <int WPT, bool STRIPED, bool HDR = false>
 __global__ void k_elem_decode1(const uint32_t *in, f4 *out, size_t n4)
 {
     const float lv[4] = {-3.316505f, -1.f, 1.f, 3.316505f};
@@ -142,7 +142,14 @@ __global__ void k_elem_decode1(const uint32_t *in, f4 *out, size_t n4)
                          : ((size_t)blockIdx.x * WPT + k) * blockDim.x + threadIdx.x;
         const bool ok = STRIPED ? (t < per && idx[k] < n4) : idx[k] < n4;
         if (!ok) idx[k] = ~(size_t)0;
-        w[k] = ok ? in[idx[k] >> 2] : 0u;
+        if (HDR) {
+            // real frames: 2000 payload dwords behind an 8-dword header (8032-byte
+            // frames); float4 i of the output belongs to frame i / 8000
+            const size_t f = idx[k] / 8000, r = idx[k] - f * 8000;
+            w[k] = ok ? in[f * 2008 + 8 + (r >> 2)] : 0u;
+        } else {
+            w[k] = ok ? in[idx[k] >> 2] : 0u;
+        }
     }
 #pragma unroll
     for (int k = 0; k < WPT; ++k) {
@@ -270,6 +277,20 @@ int main(int argc, char **argv)
             std::sort(t.begin(), t.end()); \
             printf("elem_decode one pass wpt=%d %s: %.3f ms  %.1f GB/s (in+out)\n", W, (S) ? "striped" : "contiguous", \
                    t[t.size() / 2], (n4 * 16.0 + n4) / t[t.size() / 2] / 1e6); } while (0)
+#define KB_ONE_H(W) do { \
+            const size_t n4h = std::min<size_t>(nframes * 8000, out_elems / 4); \
+            const size_t need = ((n4h + (W) - 1) / (W) + 255) / 256; \
+            std::vector<double> t; \
+            for (int r = 0; r < reps + 1; ++r) { \
+                CK(hipEventRecord(e0)); \
+                hipLaunchKernelGGL((k_elem_decode1<W, true, true>), dim3((unsigned)need), dim3(256), 0, 0, (const uint32_t *)d_in, (f4 *)d_out, n4h); \
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
+                if (r) t.push_back(time_ms(e0, e1)); \
+            } \
+            std::sort(t.begin(), t.end()); \
+            printf("elem_decode one pass wpt=%d striped, 8032-byte frames (header skipped, division per piece): %.3f ms  %.1f GB/s (in+out)\n", W, \
+                   t[t.size() / 2], (n4h * 16.0 + nframes * 8032.0) / t[t.size() / 2] / 1e6); } while (0)
+        KB_ONE_H(8); KB_ONE_H(16);
         KB_ONE(2, true); KB_ONE(4, true); KB_ONE(8, true); KB_ONE(16, true); KB_ONE(32, true);
         KB_ONE(2, false); KB_ONE(4, false); KB_ONE(8, false); KB_ONE(16, false);
         for (unsigned gridsz : {32768u, 2097152u}) {
