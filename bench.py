@@ -29,6 +29,7 @@ Besides the contract's keys the line carries
   cfg3          BASELINE configs[2] (8-thread 2-bit complex 16-channel VDIF):
                 rank 0 scans the whole file and builds the frame index, ONE
                 broadcast (RCCL) replicates it, every rank decodes its slab
+  parity_digests sha256 of golden files decoded here vs the reference's digests
   other_configs Mark 5B / Mark 4 / GUPPI / DADA / 8-thread real VDIF kernels
                 on inputs that decode to the headline's output size (N = 1 only)
 """
@@ -345,6 +346,44 @@ def dry_run(args, rank, world):
                      "index_ok": ok}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def parity_digests():
+    """Bit-exactness verdict per configuration:
+    the small reference-written golden files of every format are decoded
+    through the drop-in API on this GPU and the sha256 of the decoded array is
+    compared with the digest of the REFERENCE's output committed in
+    tests/golden/manifest.json (written by oracle/gen_golden.py from the real
+    reference).  Outside every timed region; the parity proof proper is
+    tests/ (-m gpu)."""
+    import hashlib
+    import baseband_amd as bb
+    with open(os.path.join(ROOT, 'tests', 'golden', 'manifest.json')) as f:
+        cases = json.load(f)['cases']
+    plan = [('sample_vdif', bb.vdif.open, {}),
+            ('vdif_cfg2_small', bb.vdif.open, None), ('vdif_cfg3_small', bb.vdif.open, None),
+            ('m5b_c16_b2', bb.mark5b.open, 'm5b'), ('m4_t64_f4', bb.mark4.open, 'm4'),
+            ('guppi_cf_c64_ov0', bb.guppi.open, {}), ('dada_p2_c4_cplx', bb.dada.open, {})]
+    res = {}
+    for name, opener, kw in plan:
+        c = cases[name]
+        if kw is None:
+            kw = dict(sample_rate=c['frame_rate'] * c['samples_per_frame'])
+        elif kw == 'm5b':
+            kw = dict(sample_rate=c['frame_rate'] * c['samples_per_frame'], kday=c['kday'],
+                      nchan=c['nchan'], bps=c['bps'])
+        elif kw == 'm4':
+            kw = dict(sample_rate=c['frame_rate'] * c['samples_per_frame'], ntrack=c['ntrack'],
+                      decade=2010, verify=False)
+        try:
+            with opener(os.path.join(ROOT, 'tests', 'golden', c['file']), 'rs', squeeze=False, **kw) as fh:
+                got = fh.read().cpu().numpy()
+            digest = hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest()
+            res[name] = {"shape": list(got.shape), "sha256_matches_reference": digest == c['sha256']}
+        except Exception as exc:
+            res[name] = {"error": repr(exc)[:200]}
+    res["all_match"] = all(v.get("sha256_matches_reference") is True for v in res.values())
+    return res
 
 
 # --------------------------------------------------------------------- legs
@@ -756,6 +795,10 @@ def main():
     if not args.no_extra_legs:
         # (each leg is fenced: a failure is reported in its slot, the headline stands)
         if rank == 0:
+            try:
+                line["parity_digests"] = parity_digests()
+            except Exception as exc:
+                line["parity_digests"] = {"error": repr(exc)[:300]}
             try:
                 line["api_read"] = leg_api_read(args, image, out, kern_avg)
             except Exception as exc:
