@@ -233,6 +233,39 @@ void k_decode_gather(bb_gather_args a)
         const uint32_t nfloat = nrow * rowlen;          // multiple of 4
         float *obase = a.out + (f * R + (e_lo >> a.lchunk)) * rowlen;
         const uint8_t *rawb = reinterpret_cast<const uint8_t *>(s_raw);
+        if (!WIDE && a.lrow >= 2 && rowlen <= BB_BLOCK * 4) {
+            // Narrow chunks with a power-of-two row of at most 1024 floats (8
+            // threads x 1 channel: 8): a lane's float4 sits at the SAME place
+            // of its row in every pass (the workgroup advances by 1024 floats),
+            // so which slot and which position of the thread sample each of its
+            // four floats comes from -- and that slot's LDS base -- are looked up
+            // once per work item instead of once per float.
+            const uint32_t rem0 = (threadIdx.x * 4) & (rowlen - 1);
+            uint32_t wbit[4], base[4];
+            bool hole[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t rem = rem0 + j;
+                const uint32_t sj = rem >> a.lchunk;
+                wbit[j] = (rem & (a.chunk - 1)) * BPS;
+                base[j] = s_base[sj];
+                hole[j] = holes && !s_valid[sj];
+            }
+            for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
+                const uint32_t rb = ((q >> a.lrow) << a.lchunk) * BPS;
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t bit = rb + wbit[j];
+                    const uint32_t code = ((uint32_t)rawb[base[j] + (bit >> 3)] >> (bit & 7)) & CMASK;
+                    r[j] = lv.get(code);
+                    if (hole[j]) r[j] = (a.complex_data && ((wbit[j] / BPS) & 1)) ? a.fill_im : a.fill_re;
+                }
+                bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
+            }
+            __syncthreads();
+            continue;
+        }
         for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
             uint32_t row, rem;
             if (a.lrow >= 0) { row = q >> a.lrow; rem = q & (rowlen - 1); }   // power-of-two rows
