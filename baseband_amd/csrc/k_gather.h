@@ -266,6 +266,32 @@ void k_decode_gather(bb_gather_args a)
             __syncthreads();
             continue;
         }
+        if (WIDE && a.lrow >= 2 && rowlen <= BB_BLOCK * 4) {
+            // the same for chunks of four floats and more: the lane's slot and
+            // its position inside the thread sample do not change
+            const uint32_t rem0 = (threadIdx.x * 4) & (rowlen - 1);
+            const uint32_t sj = rem0 >> a.lchunk;
+            const uint32_t wbit = (rem0 & (a.chunk - 1)) * BPS;
+            const uint32_t base = s_base[sj];
+            const bool hole = holes && !s_valid[sj];
+            for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
+                const uint32_t bit = ((q >> a.lrow) << a.lchunk) * BPS + wbit;
+                const uint32_t off = base + (bit >> 3);
+                uint32_t bits;
+                if (BPS == 8)      bits = *reinterpret_cast<const uint32_t *>(rawb + off);
+                else if (BPS == 4) bits = *reinterpret_cast<const uint16_t *>(rawb + off);
+                else               bits = (uint32_t)rawb[off] >> (bit & 7);
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r[j] = lv.get((bits >> (j * BPS)) & CMASK);
+                    if (hole) r[j] = (a.complex_data && (j & 1)) ? a.fill_im : a.fill_re;
+                }
+                bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
+            }
+            __syncthreads();
+            continue;
+        }
         for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
             uint32_t row, rem;
             if (a.lrow >= 0) { row = q >> a.lrow; rem = q & (rowlen - 1); }   // power-of-two rows
