@@ -49,6 +49,7 @@ TUNE_OUT_STRIPE_S = 17
 TUNE_WORK_STRIPES = 18
 TUNE_XPOSE = 19
 TUNE_XPOSE_ROWS = 20
+TUNE_BYTE_LUT = 21
 
 
 class BBError(RuntimeError):

@@ -5,6 +5,7 @@
 #include "k_scan.h"
 #include "k_flat.h"
 #include "k_front.h"
+#include "k_lut.h"
 #include "k_gather.h"
 #include "k_mark4.h"
 #include "k_tiled.h"
@@ -15,6 +16,7 @@
 #include <mutex>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -160,6 +162,7 @@ std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
 std::atomic<int> g_tune_xpose_rows{128}; // k_decode_i8_xpose: output rows per tile (128 or 64)
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
 std::atomic<int> g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
@@ -205,6 +208,13 @@ void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_
     else if (om == BB_OUT_ROWS4) { if (nt) BB_L(BB_OUT_ROWS4, true);   else BB_L(BB_OUT_ROWS4, false); }
     else                         { if (nt) BB_L(BB_OUT_SCATTER, true); else BB_L(BB_OUT_SCATTER, false); }
 #undef BB_L
+}
+
+template <int BPS>
+void launch_flat_lut(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+    if (nt) hipLaunchKernelGGL((k_decode_flat_lut<BPS, true, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    else    hipLaunchKernelGGL((k_decode_flat_lut<BPS, false, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
 }
 
 template <int BPS, int LV>
@@ -387,6 +397,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_GATHER_CHUNKS: g_tune_gather_chunks = value > 0 ? value : 32; return BB_OK;
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
+        case BB_TUNE_BYTE_LUT: g_tune_byte_lut = value; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
         case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : 128; return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
@@ -842,6 +853,12 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         } else if (long8) {
             if (p->coder == BB_CODER_INT) launch_flat_aln32<8, BB_LV_INT8>(nt, g2, st, a);
             else                          launch_flat_aln32<8, BB_LV_LDS>(nt, g2, st, a);
+        } else if (aln && p->bps <= 2 && g_tune_byte_lut.load() != 0) {
+            // byte table in LDS instead of the register level select (k_lut.h)
+            if (p->bps == 1) launch_flat_lut<1>(nt, g2, st, a); else launch_flat_lut<2>(nt, g2, st, a);
+            BB_NOTE("k_decode_flat_lut<%d,%s,2,16> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", g2.x, a.tpw);
+            BB_HIP(hipGetLastError());
+            return BB_OK;
         } else if (aln) {
             // aligned 256-byte block loads (k_decode_flat_aln)
             switch (p->bps) {

@@ -449,6 +449,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* the same bound for 8-bit data in the aligned flat kernel (1..32; above 16 selects the 32-tile instantiation) */
 #define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */
 #define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
+#define BB_TUNE_BYTE_LUT 21           /* 1 (default): contiguous 1- and 2-bit decode through the byte table kernel k_decode_flat_lut; 0: k_decode_flat_aln (register level select) */
 #define BB_TUNE_XPOSE_ROWS 20         /* k_decode_i8_xpose: output rows per tile, 128 (default) or 64 */
 #define BB_TUNE_XPOSE 19              /* 1 (default): int8 transposes with 16-byte aligned input runs go through k_decode_i8_xpose; 0: k_decode_i8_tiled / _stage always */
 #define BB_TUNE_WORK_STRIPES 18       /* work order of the decode launches: log2 of the number of stripes a launch's work items are dealt over (0 = file order; default -1 = 16 stripes for outputs of 16 GiB and more, 4 below) */
