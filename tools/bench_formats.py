@@ -57,7 +57,7 @@ def main():
     nfr = nbytes // 8032
     out = torch.empty(nfr * 32000, dtype=torch.float32, device=dev)
     ms = timeit(lambda: kernels.decode_frames(buf, nfr, 8000, 0, 2, src0=32, src_stride=8032, out=out))
-    report('cfg1 VDIF 1 thread x 1 ch 2-bit real (k_decode_flat_aln)', ms, nfr * 8032,
+    report('cfg1 VDIF 1 thread x 1 ch 2-bit real (k_decode_flat_lut)', ms, nfr * 8032,
            out.numel() * 4, out.numel(), nframes=nfr)
     # the same through the dense index, and with 1 % of the frames invalid
     # (index entry -1 -> fill): SURVEY section 8d asks that the fill path cost nothing
