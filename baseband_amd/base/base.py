@@ -55,17 +55,17 @@ class FileBase:
     def temporary_offset(self, offset=None, whence=0):
         return self._TemporaryOffset(self, offset, whence)
 
-    def __enter__(self):
-        return self
-
-    def __exit__(self, exc_type, exc_val, exc_tb):
-        self.close()
-
     def close(self):
         self.fh_raw.close()
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def __repr__(self):
-        return "{0}(fh_raw={1})".format(self.__class__.__name__, self.fh_raw)
+        return "{}(fh_raw={})".format(type(self).__name__, self.fh_raw)
 
 
 class VLBIFileReaderBase(FileBase):
@@ -466,15 +466,13 @@ class GPUStreamReaderBase:
                 offset = int(round(ns * self.sample_rate / 1e9))
             else:
                 offset = int(round(float(offset) * self.sample_rate))
-        if whence == 0 or whence == 'start':
-            self.offset = offset
-        elif whence == 1 or whence == 'current':
-            self.offset += offset
-        elif whence == 2 or whence == 'end':
-            self.offset = self.shape[0] + offset
-        else:
-            raise ValueError("invalid 'whence'; should be 0 or 'start', 1 or "
-                             "'current', or 2 or 'end'.")
+        origin = {0: 0, 'start': 0,
+                  1: self.offset, 'current': self.offset,
+                  2: self.shape[0], 'end': self.shape[0]}
+        if whence not in origin:
+            raise ValueError("whence must be 0 / 'start', 1 / 'current' or 2 / 'end', "
+                             "not {!r}".format(whence))
+        self.offset = origin[whence] + offset
         return self.offset
 
     # -- file image resident in HBM (resident.py)

@@ -26,6 +26,19 @@ __all__ = ['GSBTimeStampIO', 'GSBFileReader', 'GSBFileWriter', 'GSBStreamReader'
 DEFAULT_FRAME_RATE = 1e8 / 6 / 2 ** 22          # Hz (gsb/base.py:170)
 
 
+
+def _raw_handles(fh_raw, rawdump):
+    """Binary handles in the shape the stream classes use: one handle for
+    rawdump, a rectangular (polarisation, file) nest for phased data
+    (gsb/base.py:253-262, 403-411)."""
+    if not isinstance(fh_raw, (tuple, list)):
+        return fh_raw if rawdump else ((fh_raw,),)
+    assert not rawdump, "rawdump data come in one file"
+    nfile = len(fh_raw[0])
+    assert all(isinstance(row, (tuple, list)) and len(row) == nfile for row in fh_raw)
+    return fh_raw
+
+
 class GSBTimeStampIO(FileBase):
     """Timestamp (text) file: one header line per frame (gsb/base.py:23-75)."""
 
@@ -77,15 +90,8 @@ class GSBStreamReader(GPUStreamReaderBase):
         lines = [ln.decode('ascii') if isinstance(ln, bytes) else ln for ln in lines]
         header0 = GSBHeader(lines[0].split())
         rawdump = header0.mode == 'rawdump'
-        if isinstance(fh_raw, (tuple, list)):
-            assert not rawdump
-            for pair in fh_raw:
-                assert isinstance(pair, (tuple, list))
-                assert len(pair) == len(fh_raw[0])
-        elif not rawdump:
-            fh_raw = ((fh_raw,),)
-        complex_data = (complex_data if complex_data is not None
-                        else (False if rawdump else True))
+        fh_raw = _raw_handles(fh_raw, rawdump)
+        complex_data = (not rawdump) if complex_data is None else complex_data
         bps = bps if bps is not None else (4 if rawdump else 8)
         nchan = nchan if nchan is not None else (1 if rawdump else 512)
         bpfs = bps * nchan * (2 if complex_data else 1)
@@ -241,12 +247,7 @@ class GSBStreamWriter(GPUStreamWriterBase):
             raise TypeError("got unexpected arguments {}".format(sorted(kwargs)))
         self.fh_ts = fh_ts
         rawdump = header0.mode == 'rawdump'
-        if isinstance(fh_raw, (tuple, list)):
-            assert not rawdump
-            for pair in fh_raw:
-                assert isinstance(pair, (tuple, list)) and len(pair) == len(fh_raw[0])
-        elif not rawdump:
-            fh_raw = ((fh_raw,),)
+        fh_raw = _raw_handles(fh_raw, rawdump)
         complex_data = (not rawdump) if complex_data is None else complex_data
         bps = bps if bps is not None else (4 if rawdump else 8)
         nchan = nchan if nchan is not None else (1 if rawdump else 512)

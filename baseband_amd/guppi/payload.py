@@ -18,12 +18,14 @@ class GUPPIPayload(RowSetMixin, PayloadBase):
     _coder_id = _lib.CODER_INT
     _sample_shape_maker = namedtuple('SampleShape', 'npol, nchan')
 
-    def __init__(self, words, *, header=None, sample_shape=(), bps=8,
-                 complex_data=False, channels_first=True):
-        super().__init__(words, header=header, sample_shape=sample_shape,
-                         bps=bps, complex_data=complex_data)
-        self.channels_first = (channels_first if header is None
-                               else header.channels_first)
+    def __init__(self, words, *, header=None, sample_shape=(), bps=8, complex_data=False,
+                 channels_first=True):
+        # storage order: the header's word when there is one
+        if header is not None:
+            channels_first = header.channels_first
+        self.channels_first = channels_first
+        super().__init__(words, header=header, sample_shape=sample_shape, bps=bps,
+                         complex_data=complex_data)
 
     @classmethod
     def fromdata(cls, data, header=None, bps=8, channels_first=True):

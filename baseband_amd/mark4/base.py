@@ -72,17 +72,18 @@ class Mark4FileReader(VLBIFileReaderBase):
         pattern of all tracks plus the zero bit before it, for the reader's
         `ntrack` (found with `determine_ntrack` if not known): stream word 63
         zero, words 64-95 all ones (mark4/base.py:110-166)."""
-        ntrack = self.ntrack
-        if frame_nbytes is None:
+        # a frame is 20000 stream words of ntrack bits = 2500 bytes per track
+        if frame_nbytes is not None:
+            if frame_nbytes % 2500:
+                raise ValueError('Mark 4 frames hold 2500 bytes per track: '
+                                 'frame_nbytes must be a multiple of that.')
+            ntrack = frame_nbytes // 2500
+        else:
+            ntrack = self.ntrack
             if ntrack is None:
                 with self.temporary_offset(0):
                     ntrack = self.determine_ntrack(maximum=maximum)
-            frame_nbytes = ntrack * 2500
-        else:
-            ntrack, resid = divmod(frame_nbytes, 2500)
-            if resid:
-                raise ValueError('frame_nbytes must be a multiple of '
-                                 '2500 bytes for Mark 4 data.')
+            frame_nbytes = 2500 * ntrack
         if pattern is None:
             isz = ntrack // 8
             pattern = np.concatenate([np.zeros(isz, np.uint8), np.full(32 * isz, 0xff, np.uint8)])
@@ -131,14 +132,13 @@ class Mark4FileWriter(FileBase):
 class Mark4StreamReader(GPUStreamReaderBase):
     """Mark 4 stream -> device tensor (nsample, nchan)."""
 
-    def __init__(self, fh_raw, sample_rate=None, ntrack=None, decade=None,
-                 ref_time=None, squeeze=True, subset=(), fill_value=0.,
-                 verify='fix'):
-        if decade is None and ref_time is None:
-            raise TypeError("Mark 4 stream reader requires either decade or "
-                            "ref_time to be passed in.")
-        fh_raw = Mark4FileReader(fh_raw, ntrack=ntrack, decade=decade,
-                                 ref_time=ref_time)
+    def __init__(self, fh_raw, sample_rate=None, ntrack=None, decade=None, ref_time=None,
+                 squeeze=True, subset=(), fill_value=0., verify='fix'):
+        # the header's year is a single digit: something has to pin the decade
+        if ref_time is None and decade is None:
+            raise TypeError("reading Mark 4 needs `decade` or `ref_time` to "
+                            "resolve the single-digit year of the headers.")
+        fh_raw = Mark4FileReader(fh_raw, ntrack=ntrack, decade=decade, ref_time=ref_time)
         header0 = fh_raw.find_header()
         offset0 = fh_raw.tell()
         if sample_rate is None:

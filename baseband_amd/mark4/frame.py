@@ -18,8 +18,8 @@ class Mark4Frame(FrameBase):
     _payload_class = Mark4Payload
 
     def __init__(self, header, payload, valid=None, verify=True):
-        self.header = header
-        self.payload = payload
+        self.header, self.payload = header, payload
+        # validity lives in the header's error flags: only touch them on request
         if valid is not None:
             self.valid = valid
         if verify:

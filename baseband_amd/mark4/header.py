@@ -231,17 +231,15 @@ class Mark4Header:
         defaults for headstack and track ids follow from ``ntrack``, one
         sideband unless converters or sidebands are given; ``time``, ``bps``
         and ``fanout`` make it complete.  The CRC is recalculated."""
-        if ntrack == 64:
-            kwargs.setdefault('headstack_id', np.repeat(np.arange(2), 32))
-            kwargs.setdefault('track_id', np.tile(np.arange(2, 34), 2))
-        elif ntrack == 32:
-            kwargs.setdefault('headstack_id', np.zeros(32, dtype=int))
-            kwargs.setdefault('track_id', np.arange(2, 34))
-        elif ntrack == 16:
-            kwargs.setdefault('headstack_id', np.zeros(16, dtype=int))
-            kwargs.setdefault('track_id', np.arange(2, 34, 2))
-        if not any(key in kwargs for key in ('lsb_output', 'converter_id',
-                                             'converter')):
+        if ntrack in (16, 32, 64):
+            # tracks 2..33 of a headstack: every one of them (32 per
+            # headstack, the second headstack for tracks 32-63), or the even
+            # ones for 16 tracks
+            lane = np.arange(ntrack)
+            step = 2 if ntrack == 16 else 1
+            kwargs.setdefault('headstack_id', lane // 32)
+            kwargs.setdefault('track_id', 2 + step * (lane % 32))
+        if not {'lsb_output', 'converter_id', 'converter'} & set(kwargs):
             kwargs.setdefault('nsb', 1)
         self = cls(None, ntrack=ntrack, decade=decade)
         for key, field in _FIELDS.items():

@@ -26,18 +26,16 @@ class Mark4Payload(PayloadBase):
 
     def __init__(self, words, header=None, *, sample_shape=(1,), bps=2,
                  fanout=1, magnitude_bit=None, complex_data=False):
-        if header is not None:
+        if complex_data:
+            raise ValueError("Mark 4 samples are real: complex_data cannot be set.")
+        if header is None:
+            # every channel takes bps * fanout tracks
+            ntrack, magnitude_bit = sample_shape[0] * bps * fanout, None
+        else:
+            ntrack, bps, fanout = header.ntrack, header.bps, header.fanout
             magnitude_bit = header.magnitude_signature()
-            bps = header.bps
-            ntrack = header.ntrack
-            fanout = header.fanout
             sample_shape = (ntrack // (bps * fanout),)
             self._nbytes = header.payload_nbytes
-        else:
-            ntrack = sample_shape[0] * bps * fanout
-            magnitude_bit = None
-        if complex_data:
-            raise ValueError("Mark4 format does not support complex data.")
         self._dtype_word = np.dtype(MARK4_DTYPES[ntrack])
         self.fanout = fanout
         self.ntrack = ntrack

@@ -117,17 +117,16 @@ class Mark5BFileWriter(FileBase):
 class Mark5BStreamReader(GPUStreamReaderBase):
     """Mark 5B stream -> device tensor (nsample, nchan)."""
 
-    def __init__(self, fh_raw, sample_rate=None, kday=None, ref_time=None,
-                 nchan=None, bps=2, squeeze=True, subset=(), fill_value=0.,
-                 verify='fix'):
+    def __init__(self, fh_raw, sample_rate=None, kday=None, ref_time=None, nchan=None,
+                 bps=2, squeeze=True, subset=(), fill_value=0., verify='fix'):
+        # neither the channel count nor the thousands of the MJD are in the file
         if nchan is None:
-            raise TypeError("Mark 5B stream reader requires nchan to be "
-                            "explicity passed in.")
-        if kday is None and ref_time is None:
-            raise TypeError("Mark 5B stream reader requires either kday or "
-                            "ref_time to be passed in.")
-        fh_raw = Mark5BFileReader(fh_raw, nchan=nchan, bps=bps,
-                                  ref_time=ref_time, kday=kday)
+            raise TypeError("reading Mark 5B needs `nchan`: the headers do not "
+                            "record the number of channels.")
+        if ref_time is None and kday is None:
+            raise TypeError("reading Mark 5B needs `kday` or `ref_time` to "
+                            "complete the three-digit day of the headers.")
+        fh_raw = Mark5BFileReader(fh_raw, nchan=nchan, bps=bps, kday=kday, ref_time=ref_time)
         header0 = fh_raw.find_header()
         offset0 = fh_raw.tell()
         spf = header0.payload_nbytes * 8 // bps // nchan

@@ -156,17 +156,18 @@ class Mark5BHeader(BitFieldHeader):
         self['bcd_fraction'] = bcd_encode(int(ns / 100000))
 
     def get_time(self, frame_rate=None):
-        frame_nr = self['frame_nr']
-        if frame_nr == 0:
+        # mark5b/header.py:262-303: the frame number is exact when the rate is
+        # known; the BCD fraction is the fallback (and unusable when zero)
+        nr = int(self['frame_nr'])
+        if nr == 0:
             fraction = 0.
-        elif frame_rate is None:
+        elif frame_rate is not None:
+            fraction = nr / float(frame_rate)
+        else:
             fraction = self.fraction
             if fraction == 0.:
-                raise ValueError('header does not provide correct fractional '
-                                 'second (it is zero for non-zero frame '
-                                 'number). Please pass in a frame_rate.')
-        else:
-            fraction = frame_nr / float(frame_rate)
+                raise ValueError('the fractional second in the header is zero although '
+                                 'the frame number is not: pass in a frame_rate.')
         days = self.kday + self.jday - _MJD_UNIX
         return (np.datetime64('1970-01-01', 'ns') + np.timedelta64(days, 'D')
                 + np.timedelta64(self.seconds, 's')

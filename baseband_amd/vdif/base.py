@@ -176,14 +176,13 @@ class VDIFStreamReader(GPUStreamReaderBase):
     ``sample_rate`` is a plain number in Hz.
     """
 
-    def __init__(self, fh_raw, sample_rate=None, squeeze=True, subset=(),
-                 fill_value=0., verify='fix'):
+    def __init__(self, fh_raw, sample_rate=None, squeeze=True, subset=(), fill_value=0.,
+                 verify='fix'):
         fh_raw = VDIFFileReader(fh_raw)
         header0 = fh_raw.read_header()
         fh_raw.seek(0)
-        thread_ids = fh_raw.get_thread_ids()
+        self._file_threads = thread_ids = fh_raw.get_thread_ids()
         nthread = len(thread_ids)
-        self._file_threads = thread_ids
         if sample_rate is None:
             sample_rate = header0.sample_rate
             if sample_rate is None:
@@ -201,19 +200,19 @@ class VDIFStreamReader(GPUStreamReaderBase):
         self._file_offset0 = 0
         # thread part of the subset is applied while reading
         # (vdif/base.py:464-490)
+        self._thread_ids, self._frameset_subset = thread_ids, self.subset
         if self.subset and (nthread > 1 or not self.squeeze):
-            sel = np.array(thread_ids)[self.subset[0]]
-            self._thread_ids = np.atleast_1d(sel.squeeze()).tolist()
-            if sel.shape == ():
-                new_subset0 = () if self.squeeze else (0,)
-            elif len(self._thread_ids) == 1 and self.squeeze:
-                new_subset0 = (np.newaxis,)
+            picked = np.array(thread_ids)[self.subset[0]]
+            self._thread_ids = np.atleast_1d(picked.squeeze()).tolist()
+            # what is left to do on the thread axis of a decoded frame set,
+            # which holds only the picked threads
+            if picked.ndim == 0:
+                lead = () if self.squeeze else (0,)
+            elif self.squeeze and len(self._thread_ids) == 1:
+                lead = (np.newaxis,)
             else:
-                new_subset0 = (slice(None),)
-            self._frameset_subset = new_subset0 + self.subset[1:]
-        else:
-            self._frameset_subset = self.subset
-            self._thread_ids = thread_ids
+                lead = (slice(None),)
+            self._frameset_subset = lead + self.subset[1:]
         self._decode_shape = (len(self._thread_ids), header0.nchan)
         self._thread_slot = None
         self._pattern, self._mask = header0.invariant_pattern()

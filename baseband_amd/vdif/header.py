@@ -249,12 +249,14 @@ class VDIFHeader(BitFieldHeader):
 
     @property
     def frame_nbytes(self):
-        return self['frame_length'] * 8
+        # the header counts in units of eight bytes
+        return 8 * self['frame_length']
 
     @frame_nbytes.setter
     def frame_nbytes(self, nbytes):
-        assert nbytes % 8 == 0
-        self['frame_length'] = int(nbytes) // 8
+        units, rest = divmod(int(nbytes), 8)
+        assert rest == 0, "VDIF frames are multiples of 8 bytes"
+        self['frame_length'] = units
 
     @property
     def payload_nbytes(self):
@@ -319,11 +321,12 @@ class VDIFHeader(BitFieldHeader):
 
     @station.setter
     def station(self, station):
-        try:
-            station_id = (ord(station[0]) << 8) + ord(station[1])
-        except TypeError:
-            station_id = station
-        self['station_id'] = int(station_id)
+        if isinstance(station, (str, bytes)):
+            # two ASCII characters, the first in the high byte
+            first, second = (station.decode('ascii') if isinstance(station, bytes)
+                             else station)[:2]
+            station = ord(first) << 8 | ord(second)
+        self['station_id'] = int(station)
 
     @property
     def sample_rate(self):

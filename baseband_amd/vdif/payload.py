@@ -25,17 +25,17 @@ class VDIFPayload(PayloadBase):
         super().__init__(words, header=header, sample_shape=sample_shape,
                          bps=bps, complex_data=complex_data)
         # samples do not cross word boundaries (vdif/payload.py:156-169)
-        if (self.bps & (self.bps - 1)) != 0:
+        if bin(self.bps).count('1') != 1:
+            # odd widths: single channel only, padded up to the next width
+            # that divides a 32-bit word
             if tuple(self.sample_shape) != (1,):
-                raise ValueError("multi-channel VDIF data requires "
-                                 "bits per sample that is a power of two.")
-            spw = 32 // self._bpfs
-            if (spw & (spw - 1)) == 0:
-                self._bpfs = 32 // spw
-            else:
-                raise ValueError(
-                    "cannot yet sensibly handle {} data with bps={}"
-                    .format('complex' if self.complex_data else 'real', bps))
+                raise ValueError("VDIF data with several channels needs a bits "
+                                 "per sample that is a power of two.")
+            per_word = 32 // self._bpfs
+            if bin(per_word).count('1') != 1:
+                raise ValueError("no sensible word packing for {} samples of {} bits"
+                                 .format('complex' if self.complex_data else 'real', bps))
+            self._bpfs = 32 // per_word
 
     def _decode(self, byte_start, byte_stop):
         if self.bps not in (1, 2, 4, 8) or (
