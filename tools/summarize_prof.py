@@ -2,7 +2,7 @@
 """Condense rocprofv3 output (gpurun_out/prof_*) into the small, tracked
 summaries under profiles/ and refresh profiles/traffic_latest.json.
 
-usage: tools/summarize_prof.py <round tag> <stats dir> <fetch dir> <write dir>
+usage: tools/summarize_prof.py <round tag> <stats dir> <fetch dir> <write dir> [headline-only stats dir]
 """
 import csv
 import glob
@@ -48,6 +48,17 @@ def main():
             for i, v in enumerate(vals):
                 w.writerow(['k_decode_flat', key, i, v])
     dec = [r for r in rows if 'k_decode' in r['Name']]
+    if len(sys.argv) > 5:
+        # a pass over the headline leg alone: its decode row is not mixed with
+        # the other legs' launches of the same kernel
+        head = list(csv.DictReader(open(one(sys.argv[5] + '/**/*kernel_stats.csv'))))
+        with open(os.path.join(out_dir, tag + '_kernel_stats_headline.csv'), 'w', newline='') as f:
+            w = csv.writer(f)
+            w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+            for r in head:
+                w.writerow([short(r['Name']), r['Calls'], r['TotalDurationNs'], r['AverageNs'],
+                            r['Percentage'], r['MinNs'], r['MaxNs']])
+        dec = [r for r in head if 'k_decode' in r['Name']] or dec
     fetch = sum(res['FETCH_SIZE']) / len(res['FETCH_SIZE']) * 1024
     write = sum(res['WRITE_SIZE']) / len(res['WRITE_SIZE']) * 1024
     traffic = {
