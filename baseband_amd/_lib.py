@@ -50,6 +50,7 @@ TUNE_WORK_STRIPES = 18
 TUNE_XPOSE = 19
 TUNE_XPOSE_ROWS = 20
 TUNE_BYTE_LUT = 21
+TUNE_M4_WIDEN = 22
 
 
 class BBError(RuntimeError):
@@ -153,6 +154,8 @@ SIGNATURES = [
     ('bb_mark4_header_crc', C.c_int, [_vp, _sz, C.c_int, _vp, C.c_int64, _sz, _vp, _vp]),
     ('bb_mark4_scan_at', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp, _vp]),
     ('bb_decode_mark4', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(Mark4DecodeParams), _vp, _sz, _vp]),
+    ('bb_decode_mark4_select', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(Mark4DecodeParams), C.c_int,
+                                         _vp, _sz, _vp]),
     ('bb_decode_i8_tiled', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(TiledParams), _vp, _sz, _vp]),
     ('bb_encode_flat', C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     ('bb_encode_mark4', C.c_int, [_vp, _sz, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _vp, _sz, _vp]),

@@ -162,6 +162,7 @@ std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
 std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
 std::atomic<int> g_tune_xpose_rows{128}; // k_decode_i8_xpose: output rows per tile (128 or 64)
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
@@ -398,6 +399,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         case BB_TUNE_BYTE_LUT: g_tune_byte_lut = value; return BB_OK;
+        case BB_TUNE_M4_WIDEN: g_tune_m4_widen = value; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
         case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : 128; return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
@@ -1061,31 +1063,46 @@ int bb_mark4_header_crc(const void *d_buf, size_t nbytes, int ntrack, const int6
     return BB_OK;
 }
 
-int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
-                    const int64_t *d_src, size_t nframes,
-                    const bb_mark4_decode_params *p,
-                    float *d_out, size_t out_elems, void *stream)
+// Narrow streams as 64-bit super-words.  A 16- or 32-track stream word is 2 or
+// 4 bytes: a wave's coalesced load of one word per lane moves 128 or 256
+// bytes, and a store pass covers as few outputs per word.  64 / ntrack
+// consecutive words ARE one little-endian 64-bit word whose output j (of 32)
+// is output j % (ntrack/2) of narrow word j / (ntrack/2) -- bit position
+// + ntrack * that word's number -- so whenever a unit's word count and fill
+// prefix are multiples of 64 / ntrack (frames: 20000 and 160; payloads: 19840)
+// the 64-track kernel decodes it with widened maps, 8 bytes per lane.
+static bool m4_widen(const bb_mark4_decode_params *p, int nout, bb_mark4_decode_params *q, int *nout_q)
 {
-    if (!p) return BB_EINVAL;
-    if (p->ntrack != 16 && p->ntrack != 32 && p->ntrack != 64) return BB_ENOTSUP;
-    if (nframes == 0) return BB_OK;
-    if (!d_buf || !d_out) return BB_EINVAL;
-    if (p->nwords == 0 || p->fill_words > p->nwords) return BB_EINVAL;
-    if (((uintptr_t)d_buf & 7) || ((uintptr_t)d_out & 15)) return BB_EINVAL;
-    const int opw = p->ntrack / 2;
-    const uint64_t wbytes = (uint64_t)p->ntrack / 8;
-    for (int j = 0; j < opw; ++j)
-        if (p->sign_bit[j] >= p->ntrack || p->mag_bit[j] >= p->ntrack) return BB_EINVAL;
-    const uint64_t E = p->nwords * (uint64_t)opw;
-    if (out_elems < (uint64_t)nframes * E) return BB_ERANGE;
-    if (!d_src) {
-        if (p->src0 < 0 || p->src_stride < 0 || (p->src0 % (int64_t)wbytes) || (p->src_stride % (int64_t)wbytes))
-            return BB_EINVAL;
-        if ((uint64_t)p->src0 + ((uint64_t)nframes - 1) * (uint64_t)p->src_stride + p->nwords * wbytes > buf_nbytes)
-            return BB_ERANGE;
-    }
+    const int r = 64 / p->ntrack;
+    if (r == 1 || g_tune_m4_widen.load() == 0 || (p->nwords % (uint64_t)r) || (p->fill_words % (uint64_t)r)
+            || nout * r > 32)
+        return false;
+    *q = *p;
+    q->ntrack = 64;
+    q->nwords = p->nwords / (uint64_t)r;
+    q->fill_words = p->fill_words / (uint64_t)r;
+    for (int w = 0; w < r; ++w)
+        for (int k = 0; k < nout; ++k) {
+            q->sign_bit[w * nout + k] = (uint8_t)(p->sign_bit[k] + w * p->ntrack);
+            q->mag_bit[w * nout + k] = (uint8_t)(p->mag_bit[k] + w * p->ntrack);
+        }
+    *nout_q = nout * r;
+    return true;
+}
+
+// shared by bb_decode_mark4 (nout = ntrack / 2, pipelined kernel) and
+// bb_decode_mark4_select (any nout, LDS-staged kernel); arguments are checked
+static int m4_decode(const void *d_buf, const int64_t *d_src, size_t nframes,
+                     const bb_mark4_decode_params *p_in, int nout_in, bool select,
+                     float *d_out, void *stream)
+{
     int rc = ensure_init();
     if (rc) return rc;
+    bb_mark4_decode_params wide;
+    const bb_mark4_decode_params *p = p_in;
+    int nout = nout_in;
+    if (m4_widen(p_in, nout_in, &wide, &nout)) p = &wide;
+    const uint64_t E = p->nwords * (uint64_t)nout;
     bb_m4_args a;
     a.buf = (const uint8_t *)d_buf;
     a.src = d_src;
@@ -1101,29 +1118,99 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
     a.src_stride = p->src_stride;
     memset(a.sign_bit, 0, sizeof(a.sign_bit));
     memset(a.mag_bit, 0, sizeof(a.mag_bit));
-    memcpy(a.sign_bit, p->sign_bit, opw);
-    memcpy(a.mag_bit, p->mag_bit, opw);
+    memcpy(a.sign_bit, p->sign_bit, (size_t)nout);
+    memcpy(a.mag_bit, p->mag_bit, (size_t)nout);
     a.fill = p->fill;
     a.hi = h_levels[BB_CODER_VDIF][1][3];
     uint64_t blocks = (uint64_t)nframes * a.nseg;
     a.perm = make_perm(blocks, (uint64_t)nframes * E * 4);
-    const int tb = g_tune_blocks.load();
-    const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;      // persistent grid
-    if (blocks > cap) blocks = cap;
-    const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     const bool nt = g_tune_nt.load() != 0;
+    const dim3 block(BB_BLOCK);
+    if (!select) {
+        const int tb = g_tune_blocks.load();
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;      // persistent grid
+        if (blocks > cap) blocks = cap;
+        const dim3 grid((unsigned)blocks);
 #define BB_M4(N) do { if (nt) hipLaunchKernelGGL((k_decode_mark4<N, true>), grid, block, 0, st, a); \
                       else    hipLaunchKernelGGL((k_decode_mark4<N, false>), grid, block, 0, st, a); } while (0)
-    switch (p->ntrack) {
-        case 16: BB_M4(16); break;
-        case 32: BB_M4(32); break;
-        default: BB_M4(64); break;
-    }
+        switch (p->ntrack) {
+            case 16: BB_M4(16); break;
+            case 32: BB_M4(32); break;
+            default: BB_M4(64); break;
+        }
 #undef BB_M4
-    BB_NOTE("k_decode_mark4<%d,%s> grid %u", p->ntrack, nt ? "nt" : "plain", grid.x);
+        BB_NOTE("k_decode_mark4<%d,%s> grid %u%s", p->ntrack, nt ? "nt" : "plain", grid.x,
+                p == &wide ? " (narrow words as 64-bit super-words)" : "");
+    } else {
+        if (blocks > (1ull << 30)) blocks = 1ull << 30;     // no pipeline to fill: one work item per workgroup
+        const dim3 grid((unsigned)blocks);
+        // float4 stores need every unit to start on a 16-byte boundary
+        const bool v4 = (E % 4 == 0) && (((uintptr_t)d_out & 15) == 0);
+#define BB_M4S(N) do { \
+        if (nt && v4)       hipLaunchKernelGGL((k_decode_mark4_select<N, true, true>), grid, block, 0, st, a, (uint32_t)nout); \
+        else if (nt)        hipLaunchKernelGGL((k_decode_mark4_select<N, true, false>), grid, block, 0, st, a, (uint32_t)nout); \
+        else if (v4)        hipLaunchKernelGGL((k_decode_mark4_select<N, false, true>), grid, block, 0, st, a, (uint32_t)nout); \
+        else                hipLaunchKernelGGL((k_decode_mark4_select<N, false, false>), grid, block, 0, st, a, (uint32_t)nout); } while (0)
+        switch (p->ntrack) {
+            case 16: BB_M4S(16); break;
+            case 32: BB_M4S(32); break;
+            default: BB_M4S(64); break;
+        }
+#undef BB_M4S
+        BB_NOTE("k_decode_mark4_select<%d,%s,%s> nout %d grid %u%s", p->ntrack, nt ? "nt" : "plain",
+                v4 ? "v4" : "scalar", nout, grid.x,
+                p == &wide ? " (narrow words as 64-bit super-words)" : "");
+    }
     BB_HIP(hipGetLastError());
     return BB_OK;
+}
+
+static int m4_check(const void *d_buf, size_t buf_nbytes, const int64_t *d_src, size_t nframes,
+                    const bb_mark4_decode_params *p, int nout, const float *d_out, size_t out_elems,
+                    unsigned out_align)
+{
+    if (!d_buf || !d_out) return BB_EINVAL;
+    if (p->nwords == 0 || p->fill_words > p->nwords) return BB_EINVAL;
+    if (((uintptr_t)d_buf & 7) || ((uintptr_t)d_out & (out_align - 1))) return BB_EINVAL;
+    const uint64_t wbytes = (uint64_t)p->ntrack / 8;
+    for (int j = 0; j < nout; ++j)
+        if (p->sign_bit[j] >= p->ntrack || p->mag_bit[j] >= p->ntrack) return BB_EINVAL;
+    if (out_elems < (uint64_t)nframes * p->nwords * (uint64_t)nout) return BB_ERANGE;
+    if (!d_src) {
+        if (p->src0 < 0 || p->src_stride < 0 || (p->src0 % (int64_t)wbytes) || (p->src_stride % (int64_t)wbytes))
+            return BB_EINVAL;
+        if ((uint64_t)p->src0 + ((uint64_t)nframes - 1) * (uint64_t)p->src_stride + p->nwords * wbytes > buf_nbytes)
+            return BB_ERANGE;
+    }
+    return BB_OK;
+}
+
+int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
+                    const int64_t *d_src, size_t nframes,
+                    const bb_mark4_decode_params *p,
+                    float *d_out, size_t out_elems, void *stream)
+{
+    if (!p) return BB_EINVAL;
+    if (p->ntrack != 16 && p->ntrack != 32 && p->ntrack != 64) return BB_ENOTSUP;
+    if (nframes == 0) return BB_OK;
+    const int rc = m4_check(d_buf, buf_nbytes, d_src, nframes, p, p->ntrack / 2, d_out, out_elems, 16);
+    if (rc) return rc;
+    return m4_decode(d_buf, d_src, nframes, p, p->ntrack / 2, false, d_out, stream);
+}
+
+int bb_decode_mark4_select(const void *d_buf, size_t buf_nbytes,
+                           const int64_t *d_src, size_t nframes,
+                           const bb_mark4_decode_params *p, int nout,
+                           float *d_out, size_t out_elems, void *stream)
+{
+    if (!p) return BB_EINVAL;
+    if (p->ntrack != 16 && p->ntrack != 32 && p->ntrack != 64) return BB_ENOTSUP;
+    if (nout < 1 || nout > 32) return BB_EINVAL;
+    if (nframes == 0) return BB_OK;
+    const int rc = m4_check(d_buf, buf_nbytes, d_src, nframes, p, nout, d_out, out_elems, 4);
+    if (rc) return rc;
+    return m4_decode(d_buf, d_src, nframes, p, nout, true, d_out, stream);
 }
 
 int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,

@@ -328,3 +328,82 @@ void k_decode_mark4(bb_m4_args a)
         cur_valid = nxt_valid;
     }
 }
+
+// Channel selection folded into the track demultiplexing (a reader `subset`
+// that picks channels: the reference decodes whole frames and indexes
+// afterwards, base/base.py:706-717 with 957-969).  The bit maps are data, so
+// a selection is just a SHORTER map: `nout` = fanout x (selected channels)
+// outputs per stream word instead of NTRACK/2, output j of a word taken from
+// (sign_bit[j], mag_bit[j]).  A wave parks its 64-word tile in LDS; the tile's
+// 64 * nout floats are then written as consecutive float4 (lane -> float4 ->
+// up to four (word, output) pairs, each an LDS read and two bit tests), so
+// HBM sees contiguous 16-byte stores whatever `nout` is.  When a unit's float
+// count is not a multiple of four (or the output is only 4-byte aligned) the
+// same walk is done float by float.
+template <int NTRACK, bool NT, bool V4>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_mark4_select(bb_m4_args a, uint32_t nout)
+{
+    typedef typename bb_m4_word<NTRACK>::type word_t;
+    __shared__ word_t s_w[BB_WAVES_PER_BLOCK][64];
+    __shared__ uint8_t s_sb[32], s_mb[32];
+    const int lane = bb_lane();
+    const int wave = bb_wave();
+    if (threadIdx.x < 32) {
+        s_sb[threadIdx.x] = (uint8_t)(a.sign_bit[threadIdx.x / 4] >> (8 * (threadIdx.x % 4)));
+        s_mb[threadIdx.x] = (uint8_t)(a.mag_bit[threadIdx.x / 4] >> (8 * (threadIdx.x % 4)));
+    }
+    const float hi = a.hi, fill = a.fill;
+    const uint64_t E = a.nwords * nout;
+    const uint64_t nwork = a.nframes * a.nseg;
+    auto level = [&](word_t x, uint32_t j) -> float {
+        const bool s = (x >> s_sb[j]) & 1;
+        const bool m = (x >> s_mb[j]) & 1;
+        return (s == m) ? (s ? hi : -hi) : (s ? 1.0f : -1.0f);
+    };
+    for (uint64_t work = blockIdx.x; work < nwork; work += gridDim.x) {
+        const uint64_t pwork = bb_perm(a.perm, work);
+        uint64_t f, seg;
+        if (a.nseg == 1) { f = pwork; seg = 0; }
+        else { f = pwork / a.nseg; seg = pwork - f * a.nseg; }
+        const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
+        const bool valid = so >= 0;
+        float *obase = a.out + f * E;
+        const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
+        const uint64_t w_end = (seg + 1) * a.seg_tiles * 64 < a.nwords
+                               ? (seg + 1) * a.seg_tiles * 64 : a.nwords;
+        // (every wave makes all a.tpw rounds: the barriers are workgroup wide)
+        for (uint32_t u = 0; u < a.tpw; ++u) {
+            const uint64_t wbase = (tile0 + u) * 64;
+            const uint64_t wi = wbase + lane;
+            word_t w = 0;
+            if (valid && wi < w_end && wi >= a.fill_words)
+                w = bb_m4_load_any<NTRACK>(a.buf, (uint64_t)so + wi * sizeof(word_t));
+            __syncthreads();                    // the previous tile has been read
+            s_w[wave][lane] = w;
+            __syncthreads();
+            if (wbase >= w_end) continue;
+            const uint32_t nw = w_end - wbase < 64 ? (uint32_t)(w_end - wbase) : 64u;
+            const uint32_t nfl = nw * nout;
+            float *o = obase + wbase * nout;
+            if (V4) {
+                for (uint32_t q = 4 * lane; q < nfl; q += 256) {
+                    uint32_t wl = q / nout, j = q - wl * nout;
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        r[k] = (!valid || wbase + wl < a.fill_words) ? fill : level(s_w[wave][wl], j);
+                        if (++j == nout) { j = 0; ++wl; }
+                    }
+                    bb_store4<NT>(o + q, bb_f4{r[0], r[1], r[2], r[3]});
+                }
+            } else {
+                for (uint32_t q = lane; q < nfl; q += 64) {
+                    const uint32_t wl = q / nout, j = q - wl * nout;
+                    bb_store1<NT>(o + q, (!valid || wbase + wl < a.fill_words)
+                                             ? fill : level(s_w[wave][wl], j));
+                }
+            }
+        }
+    }
+}

@@ -300,10 +300,22 @@ def mark4_scan(dbuf, nframes, ntrack, ref_year, ref_qms, frame_qms,
     return recs
 
 
+def mark4_select_maps(sign_bit, mag_bit, nchan, channels):
+    """Bit maps of a Mark 4 mode restricted to `channels`: output ``fo * nchan
+    + c`` of a stream word is sample `fo`, channel `c`; the result lists, for
+    every sample of the word, the kept channels in the order given."""
+    fanout = len(sign_bit) // nchan
+    keep = [fo * nchan + int(c) for fo in range(fanout) for c in channels]
+    return [sign_bit[j] for j in keep], [mag_bit[j] for j in keep]
+
+
 def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
-                 src=None, src0=0, src_stride=0, fill_value=0., out=None):
+                 src=None, src0=0, src_stride=0, fill_value=0., out=None, select=False):
     """Track-demultiplex `nframes` units of `nwords` stream words each ->
-    flat float32 device tensor of nframes * nwords * ntrack/2 values."""
+    flat float32 device tensor of nframes * nwords * ntrack/2 values.  With
+    `select` the maps may be shorter (the outputs of the channels a reader's
+    subset keeps, `mark4_select_maps`): every word then gives ``len(sign_bit)``
+    values (bb_decode_mark4_select)."""
     p = _lib.Mark4DecodeParams()
     p.ntrack = ntrack
     p.nwords = nwords
@@ -314,6 +326,15 @@ def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
         p.sign_bit[j] = s
         p.mag_bit[j] = m
     p.fill = float(fill_value)
+    if select:
+        nout = len(sign_bit)
+        nelem = nframes * nwords * nout
+        if out is None:
+            out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
+        check(lib.bb_decode_mark4_select(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes, C.byref(p),
+                                         nout, _ptr(out), out.numel(), _stream(dbuf)),
+              'bb_decode_mark4_select')
+        return out
     tgt = _Target(out, nframes * nwords * (ntrack // 2), dbuf.device)
     check(lib.bb_decode_mark4(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes,
                               C.byref(p), _ptr(tgt.use), tgt.use.numel(), _stream(dbuf)),

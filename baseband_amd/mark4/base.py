@@ -158,6 +158,11 @@ class Mark4StreamReader(GPUStreamReaderBase):
                        header0.fanout)
         self._start_time = header0.get_time()
         self._ref_qms = header0.time_quarter_ms()
+        # a subset that picks channels becomes shorter bit maps for the decode
+        # kernel (bb_decode_mark4_select) instead of an indexing pass afterwards
+        self._plan_channel_select(self.subset)
+        if self._within_np is not None and header0.fanout * len(self._within_np) > 32:
+            self._within_np, self._decode_shape = None, self._unsliced_shape
         last = self._last_header()
         dq = last.time_quarter_ms() - self._ref_qms
         if last.year != header0.year:
@@ -214,15 +219,24 @@ class Mark4StreamReader(GPUStreamReaderBase):
         self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
         self._relocated = True
 
+    def _maps(self):
+        """(sign bits, magnitude bits, selected?) for the decode kernel."""
+        maps = BITMAPS[self._coder]          # KeyError: unsupported Mark 4 mode
+        sign, mag = maps['sign_bit'], maps['mag_bit']
+        if self._within_np is None:
+            return sign, mag, False
+        return kernels.mark4_select_maps(sign, mag, self._unsliced_shape[0],
+                                         self._within_np) + (True,)
+
     def _read_sets(self, first, last, into=None):
         if self._resident is None:
             return super()._read_sets(first, last, into)
         dev, src = self._resident
-        maps = BITMAPS[self._coder]
+        sign, mag, select = self._maps()
         flat = kernels.decode_mark4(
-            dev, last - first, self._ntrack, 20000, maps['sign_bit'], maps['mag_bit'],
+            dev, last - first, self._ntrack, 20000, sign, mag,
             fill_words=160, src=src[first:last].contiguous(), fill_value=self.fill_value,
-            out=into)
+            out=into, select=select)
         return flat.reshape(((last - first) * self.samples_per_frame,)
                             + tuple(self._decode_shape))
 
@@ -243,7 +257,7 @@ class Mark4StreamReader(GPUStreamReaderBase):
         return kernels.mark4_header_crc(dev, nframes, self._ntrack, first_offset=self._file_offset0)
 
     def _process_window(self, dbuf, first, last, out_flat):
-        maps = BITMAPS[self._coder]          # KeyError: unsupported Mark 4 mode
+        sign, mag, select = self._maps()
         n = last - first
         # one header beyond the request is checked too when it was staged
         nframes = min(n + (1 if self.verify else 0), dbuf.numel() // self._set_nbytes)
@@ -252,8 +266,8 @@ class Mark4StreamReader(GPUStreamReaderBase):
             self._ref_qms + first * self._frame_qms, self._frame_qms)
         src = kernels.build_index(recs, n, 1, None)
         kernels.decode_mark4(
-            dbuf, n, self._ntrack, 20000, maps['sign_bit'], maps['mag_bit'],
-            fill_words=160, src=src, fill_value=self.fill_value, out=out_flat)
+            dbuf, n, self._ntrack, 20000, sign, mag,
+            fill_words=160, src=src, fill_value=self.fill_value, out=out_flat, select=select)
         if self.verify:
             # the look-ahead header (record n) only has to be a header
             self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))

@@ -369,6 +369,24 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
                     const bb_mark4_decode_params *params,
                     float *d_out, size_t out_elems, void *stream);
 
+/*
+ * bb_decode_mark4 with a CHANNEL SELECTION folded in.  Output j of a stream
+ * word is sample j / nchan, channel j % nchan of that word (ntrack/2 =
+ * fanout * nchan outputs); a reader `subset` that keeps channels c_0 .. c_{m-1}
+ * (base/base.py:706-717 applied after mark4/payload.py:333-342 in the
+ * reference) is the same decode with the SHORTER maps
+ *     sign_bit'[fo * m + k] = sign_bit[fo * nchan + c_k]   (mag_bit alike)
+ * of nout = fanout * m entries: every word then yields `nout` floats and a
+ * unit nwords * nout, written contiguously -- the channels nobody asked for
+ * are neither written nor re-read.  Only the first `nout` (1 .. 32) entries of
+ * params->sign_bit / mag_bit are used.  d_out needs 4-byte alignment (16 for
+ * the float4 store path, taken when nwords * nout is a multiple of 4).
+ */
+int bb_decode_mark4_select(const void *d_buf, size_t buf_nbytes,
+                           const int64_t *d_src, size_t nframes,
+                           const bb_mark4_decode_params *params, int nout,
+                           float *d_out, size_t out_elems, void *stream);
+
 /* ---- byte-aligned formats with an axis permutation --------------------- */
 
 /*
@@ -449,6 +467,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* the same bound for 8-bit data in the aligned flat kernel (1..32; above 16 selects the 32-tile instantiation) */
 #define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */
 #define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
+#define BB_TUNE_M4_WIDEN 22           /* 1 (default): 16- and 32-track Mark 4 units whose word count and fill prefix allow it are decoded as 64-bit super-words (4 / 2 stream words per lane and load) by the 64-track kernels; 0: always the native word size */
 #define BB_TUNE_BYTE_LUT 21           /* 1 (default): contiguous 1- and 2-bit decode through the byte table kernel k_decode_flat_lut; 0: k_decode_flat_aln (register level select) */
 #define BB_TUNE_XPOSE_ROWS 20         /* k_decode_i8_xpose: output rows per tile, 128 (default) or 64 */
 #define BB_TUNE_XPOSE 19              /* 1 (default): int8 transposes with 16-byte aligned input runs go through k_decode_i8_xpose; 0: k_decode_i8_tiled / _stage always */

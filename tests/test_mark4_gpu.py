@@ -31,10 +31,13 @@ def test_stream_read_matches_reference(manifest, name):
     assert bits_equal(got, load_expected(name))
 
 
-def test_raw_decode_against_bitmaps_oracle():
+@pytest.mark.parametrize('widen', [1, 0])
+def test_raw_decode_against_bitmaps_oracle(widen):
     """bb_decode_mark4 on random words for all five modes == the oracle's
-    restatement of the reference decoders."""
-    from baseband_amd import kernels
+    restatement of the reference decoders; 16- and 32-track words natively and
+    as 64-bit super-words (word counts 1000 and 19840 qualify)."""
+    from baseband_amd import kernels, _lib
+    kernels.tune(_lib.TUNE_M4_WIDEN, widen)
     with open(golden_path('mark4_bitmaps.json')) as f:
         maps = json.load(f)
     for name, e in maps.items():
@@ -48,6 +51,9 @@ def test_raw_decode_against_bitmaps_oracle():
             out = kernels.decode_mark4(dbuf, 1, nt, nwords, e['sign_bit'], e['mag_bit'])
             ref = orc.mark4_decode(w, e['nchan'], e['fanout'], e['signature'])
             assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(ref).reshape(-1)), (name, nwords)
+            if widen and nt < 64 and nwords % (64 // nt) == 0:
+                assert 'super-words' in _lib.last_kernel()
+    kernels.tune(_lib.TUNE_M4_WIDEN, 1)
 
 
 def test_known_answers_and_fill_prefix(manifest):
@@ -215,3 +221,70 @@ def test_longitudinal_header_crc_matches_reference():
         assert bad.numel() == case['nframes'] and not bool(bad.any())
         fh.seek(0)
         assert bits_equal(fh.read().cpu().numpy(), before)
+
+
+def test_raw_decode_with_channel_selection():
+    """bb_decode_mark4_select == the oracle's decode indexed by the selection,
+    for all five modes, float4 and scalar store paths, fill prefix, missing
+    units, unaligned unit offsets."""
+    import torch
+    from baseband_amd import kernels
+    with open(golden_path('mark4_bitmaps.json')) as f:
+        maps = json.load(f)
+    rng = np.random.default_rng(77)
+    for name, e in sorted(maps.items()):
+        nt, nchan = e['ntrack'], e['nchan']
+        dt = np.dtype(orc.MARK4_DTYPES[nt])
+        isz = dt.itemsize
+        for nwords, fill_words in ((1, 0), (63, 0), (64, 0), (1000, 0), (20000, 160), (4100, 7)):
+            for trial in range(3):
+                m = int(rng.integers(1, nchan + 1))
+                chans = rng.choice(nchan, size=m, replace=False) if trial else np.sort(
+                    rng.choice(nchan, size=m, replace=False))
+                nunits = 4
+                lead = (0, isz, 3)[trial]
+                stride = nwords * isz + (0, isz, 5)[trial]
+                raw = rng.integers(0, 256, lead + nunits * stride + 16, dtype=np.uint8)
+                src = lead + stride * np.arange(nunits, dtype=np.int64)
+                src[2] = -1
+                sign, mag = kernels.mark4_select_maps(e['sign_bit'], e['mag_bit'], nchan, chans)
+                out = kernels.decode_mark4(kernels.to_device_bytes(raw), nunits, nt, nwords, sign, mag,
+                                           fill_words=fill_words, src=torch.from_numpy(src).cuda(),
+                                           fill_value=-9., select=True).cpu().numpy()
+                per = e['fanout'] * m
+                exp = np.empty((nunits, nwords * per), np.float32)
+                for u in range(nunits):
+                    if src[u] < 0:
+                        exp[u] = -9.
+                        continue
+                    w = raw[src[u]:src[u] + nwords * isz].copy().view(dt)
+                    full = orc.mark4_decode(w, nchan, e['fanout'], e['signature'])
+                    exp[u] = np.ascontiguousarray(full[:, chans]).reshape(-1)
+                    exp[u, :fill_words * per] = -9.
+                assert bits_equal(out, exp.reshape(-1)), (name, nwords, fill_words, chans.tolist())
+
+
+@pytest.mark.parametrize('name', SAMPLES + SYNTH)
+def test_channel_subsets_are_folded_into_the_decode(manifest, name):
+    """Readers with a channel subset decode only those channels
+    (k_decode_mark4_select) and return what indexing the full decode gives."""
+    from baseband_amd import _lib
+    case = manifest[name]
+    exp = load_expected(name)
+    nchan = exp.shape[1]
+    subsets = [[0], [nchan - 1, 0], slice(1, None, 2), list(range(nchan))[::-1]]
+    for subset in subsets:
+        want = exp[:, subset]
+        with _open(case, subset=subset, verify=False) as fh:
+            assert fh._within_np is not None
+            assert fh.shape == want.shape
+            got = fh.read().cpu().numpy()
+            assert 'k_decode_mark4_select' in _lib.last_kernel()
+            assert bits_equal(got, np.ascontiguousarray(want)), (name, subset)
+            # in-place decode into a caller's tensor, from an odd offset
+            import torch
+            n = min(70000, exp.shape[0] - 123)
+            out = torch.empty((n,) + want.shape[1:], dtype=torch.float32, device='cuda')
+            fh.seek(123)
+            fh.read(out=out)
+            assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[123:123 + n]))

@@ -52,3 +52,25 @@ for chans in ([3], [3, 4, 5, 6], list(range(16))):
     print(json.dumps(dict(case="VDIF 8 thr x 16 ch complex, %d of 16 channels" % len(chans),
                           folded_ms=round(ms_sel, 3), decode_then_index_ms=round(ms_two, 3), full_decode_ms=round(ms_full, 3),
                           folded_GBps_moved=round((nsets * nth * fn + n * 4) / ms_sel / 1e6, 1))), flush=True)
+# Mark 4, 64 tracks fanout 4 (8 channels): shorter bit maps (bb_decode_mark4_select)
+from baseband_amd.mark4._bitmaps import BITMAPS
+maps = BITMAPS[(8, 2, 4)]
+nf4 = nbytes // 160000
+full4 = lambda: kernels.decode_mark4(buf, nf4, 64, 20000, maps['sign_bit'], maps['mag_bit'], fill_words=160,
+                                     src0=0, src_stride=160000, out=out[:nf4 * 640000])
+ms_full = timeit(full4, reps=3)
+for chans in ([5], [0, 5, 7], [0, 1, 2, 3], list(range(8))):
+    sign, mag = kernels.mark4_select_maps(maps['sign_bit'], maps['mag_bit'], 8, chans)
+    n = nf4 * 20000 * len(sign)
+    ms_sel = timeit(lambda: kernels.decode_mark4(buf, nf4, 64, 20000, sign, mag, fill_words=160, src0=0,
+                                                 src_stride=160000, out=out[:n], select=True), reps=3)
+    kname = _lib.last_kernel().split(' grid')[0]
+    idx = torch.tensor(chans, device=dev)
+    def two_pass4():
+        d = full4().view(-1, 8)
+        return d[:, idx].contiguous()
+    ms_two = timeit(two_pass4, reps=3)
+    print(json.dumps(dict(case="Mark 4 64 tracks fanout 4, %d of 8 channels" % len(chans),
+                          kernel=kname,
+                          folded_ms=round(ms_sel, 3), decode_then_index_ms=round(ms_two, 3), full_decode_ms=round(ms_full, 3),
+                          folded_GBps_moved=round((nf4 * 160000 + n * 4) / ms_sel / 1e6, 1))), flush=True)
