@@ -51,6 +51,7 @@ TUNE_XPOSE = 19
 TUNE_XPOSE_ROWS = 20
 TUNE_BYTE_LUT = 21
 TUNE_M4_WIDEN = 22
+TUNE_SELECT_BYTES = 23
 
 
 class BBError(RuntimeError):

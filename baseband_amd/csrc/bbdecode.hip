@@ -162,6 +162,7 @@ std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
 std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
 std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
 std::atomic<int> g_tune_xpose_rows{128}; // k_decode_i8_xpose: output rows per tile (128 or 64)
@@ -400,6 +401,9 @@ int bb_tune(int knob, int value)
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         case BB_TUNE_BYTE_LUT: g_tune_byte_lut = value; return BB_OK;
         case BB_TUNE_M4_WIDEN: g_tune_m4_widen = value; return BB_OK;
+        case BB_TUNE_SELECT_BYTES:
+            if (value < 256 || value > 32768) return BB_EINVAL;
+            g_tune_select_bytes = value; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
         case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : 128; return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
@@ -721,7 +725,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // chunks of 4 / 8 / 16 floats ran at 0.55 / 1.15 / 3.45 TB/s
         // (profiles/r01i_exp_interleave.log)
         bb_gather_args ga;
-        ga.within = nullptr; ga.nsel = 0;
+        ga.within = nullptr; ga.nsel = 0; ga.mag_row = ga.mag_sel = 0;
         ga.buf = a.buf; ga.src = d_src; ga.out = d_out; ga.tab = a.tab;
         ga.nframes = nframes; ga.ndw = a.ndw;
         ga.nslot = a.nslot; ga.chunk = a.chunk; ga.lchunk = a.lchunk;
@@ -937,11 +941,15 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
     ga.nframes = nframes; ga.ndw = p->payload_nbytes / 4;
     ga.nslot = (uint32_t)p->nslot; ga.chunk = (uint32_t)p->chunk; ga.lchunk = lchunk;
     const uint64_t ntiles = (ga.ndw + 63) / 64;
-    // stage about 16 KiB of payload per work item (all slots together)
-    uint32_t gt = (uint32_t)(16384 / ((size_t)p->nslot * 256));
+    // stage at most 16 KiB of payload per work item (all slots together) and
+    // at most 16 tiles of a slot -- a single slot is fastest with 4 KiB per
+    // item, eight with 16 KiB (profiles/r02ac_exp_select.log) -- in groups of
+    // equal size (a 10000-byte Mark 5B payload: 14 + 14 + 12 tiles, not 32 + 8)
+    uint32_t gt = (uint32_t)((size_t)g_tune_select_bytes.load() / ((size_t)p->nslot * 256));
     if (gt < 1) gt = 1;
-    if (gt > 32) gt = 32;
+    if (gt > 16) gt = 16;
     if ((uint64_t)gt > ntiles) gt = (uint32_t)ntiles;
+    gt = (uint32_t)((ntiles + (ntiles + gt - 1) / gt - 1) / ((ntiles + gt - 1) / gt));
     // a group's elements must be whole rows: gt * 2048 / bps elements, chunk a power of two
     while (gt > 1 && ((uint64_t)gt * (2048 / p->bps)) % (uint64_t)p->chunk) --gt;
     if (((uint64_t)gt * (2048 / p->bps)) % (uint64_t)p->chunk) return BB_ENOTSUP;
@@ -951,6 +959,13 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
     ga.lrow = -1;
     ga.aligned = 1;
     ga.within = d_within; ga.nsel = (uint32_t)nwithin;
+    {
+        // floats a work item writes at most, and the two divisors of its index walk
+        const uint64_t qmax = ((uint64_t)gt * (2048 / p->bps) >> lchunk) * (uint64_t)p->nslot * (uint64_t)nwithin;
+        const uint64_t drow = (uint64_t)p->nslot * (uint64_t)nwithin, dsel = (uint64_t)nwithin;
+        ga.mag_row = (drow > 1 && qmax * drow < (1ull << 32)) ? (uint32_t)((1ull << 32) / drow + 1) : 0;
+        ga.mag_sel = (dsel > 1 && qmax * dsel < (1ull << 32)) ? (uint32_t)((1ull << 32) / dsel + 1) : 0;
+    }
     const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024 + (size_t)nwithin * 4;
     if (lds > 64 * 1024) return BB_ENOTSUP;
     uint64_t gb = (uint64_t)nframes * ga.ngroup;

@@ -35,7 +35,16 @@ struct bb_gather_args {
     // of every thread sample's chunk are written, in that order; nsel == 0: all
     const int32_t *within;
     uint32_t nsel;
+    // floor(2^32 / d) + 1 for d = nslot * nsel and d = nsel: q / d ==
+    // __umulhi(q, magic) for every q with q * d < 2^32 (the host checks the
+    // bound); 0 = divide (d == 1, or the bound does not hold)
+    uint32_t mag_row, mag_sel;
 };
+
+__device__ __forceinline__ uint32_t bb_div_magic(uint32_t q, uint32_t d, uint32_t magic)
+{
+    return magic ? __umulhi(q, magic) : q / d;
+}
 
 // WIDE: chunks of at least four floats (a float4 never straddles thread slots)
 // Phase 1 of the gather kernels: the group's dwords of every thread slot ->
@@ -168,15 +177,15 @@ void k_decode_gather_select(bb_gather_args a)
         };
         if (V4) {
             for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
-                const uint32_t row = q / rowlen, rem = q - row * rowlen;
-                const uint32_t s = rem / a.nsel, k = rem - s * a.nsel;
+                const uint32_t row = bb_div_magic(q, rowlen, a.mag_row), rem = q - row * rowlen;
+                const uint32_t s = bb_div_magic(rem, a.nsel, a.mag_sel), k = rem - s * a.nsel;
                 bb_store4<NT>(obase + q, bb_f4{value(row, s, k), value(row, s, k + 1),
                                                value(row, s, k + 2), value(row, s, k + 3)});
             }
         } else {
             for (uint32_t q = threadIdx.x; q < nfloat; q += BB_BLOCK) {
-                const uint32_t row = q / rowlen, rem = q - row * rowlen;
-                const uint32_t s = rem / a.nsel;
+                const uint32_t row = bb_div_magic(q, rowlen, a.mag_row), rem = q - row * rowlen;
+                const uint32_t s = bb_div_magic(rem, a.nsel, a.mag_sel);
                 bb_store1<NT>(obase + q, value(row, s, rem - s * a.nsel));
             }
         }
