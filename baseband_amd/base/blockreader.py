@@ -60,7 +60,7 @@ class BlockStreamReader(GPUStreamReaderBase):
         # pieces land exactly where they belong, so a suitable `out` tensor is
         # decoded into directly
         direct = (isinstance(out, torch.Tensor) and out.is_cuda and out.is_contiguous()
-                  and count > 0 and not self.subset
+                  and count > 0 and (not self.subset or self._within_np is not None)
                   and out.dtype == (torch.complex64 if self.complex_data else torch.float32))
         if direct:
             flat = (torch.view_as_real(out) if self.complex_data else out).reshape(-1)

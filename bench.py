@@ -794,6 +794,13 @@ def main():
                                               for x in per_rank]}
     if not args.no_extra_legs:
         # (each leg is fenced: a failure is reported in its slot, the headline stands)
+        if rank == 0 and world > 1:
+            # the legs below include a collective; should a rank die inside it
+            # the watchdog takes this process down before the line is printed,
+            # so leave the measured headline in the log first (stderr: the
+            # contract's ONE line on stdout is printed at the end)
+            print("bench.py: headline before the extra legs: " + json.dumps(line),
+                  file=sys.stderr, flush=True)
         if rank == 0:
             try:
                 line["parity_digests"] = parity_digests()

@@ -380,3 +380,56 @@ def test_xpose_kernel_raw_layouts(tile_rows):
     finally:
         kernels.tune(_lib.TUNE_XPOSE, 1)
         kernels.tune(_lib.TUNE_XPOSE_ROWS, 128)
+
+
+@pytest.mark.parametrize('name', ['sample_puppi', 'guppi_cf_c64_ov0', 'guppi_cf_c64_ov32', 'guppi_cf_c6_p1'])
+def test_guppi_channel_ranges_are_decoded_alone(manifest, name):
+    """Channels-first blocks: a subset keeping all polarisations and a
+    contiguous channel range enters every block at that range
+    (`_plan_channel_range`); result == indexing the reference's full decode,
+    for whole reads, reads across the overlap, small (row-staged) reads and
+    in-place decodes."""
+    import torch
+    from baseband_amd import guppi
+    case = manifest[name]
+    exp = load_expected(name)
+    n, npol, nchan = exp.shape
+    ranges = [slice(1, 3), slice(nchan // 2, None), slice(0, 1), slice(nchan - 1, nchan)]
+    for sl in ranges:
+        for squeeze in (True, False):
+            # (squeezing drops unit axes of the unsliced sample shape; the subset
+            # is applied to what is left: base/base.py:706-717)
+            subset = (sl,) if (squeeze and npol == 1) else (slice(None), sl)
+            shaped = exp.reshape((n,) + tuple(s for s in exp.shape[1:] if s > 1)) if squeeze else exp
+            want = shaped[(slice(None),) + subset]
+            with guppi.open(golden_path(case['file']), 'rs', subset=subset, squeeze=squeeze) as fh:
+                assert fh._within_np is not None and fh._chan_lo == sl.indices(nchan)[0], (sl, squeeze)
+                assert fh.shape == want.shape
+                assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(want))
+                spf = fh.samples_per_frame
+                for off, cnt in ((spf - 3, 10), (5, 7), (n - 9, 9), (spf + 1, 2 * spf)):
+                    if off + cnt > n:
+                        continue
+                    # (a read that starts inside a later block takes that block's
+                    # own overlap rows: compare with the same read without subset,
+                    # which the manifest's digests pin to the reference)
+                    with guppi.open(golden_path(case['file']), 'rs', squeeze=False) as ref:
+                        ref.seek(off)
+                        piece = ref.read(cnt).cpu().numpy()[:, :, sl]
+                    if squeeze:
+                        piece = piece.reshape((cnt,) + want.shape[1:])
+                    fh.seek(off)
+                    assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(piece)), (sl, off, cnt)
+                out = torch.empty((n - 2,) + want.shape[1:], dtype=torch.complex64, device='cuda')
+                fh.seek(1)
+                fh.read(out=out)
+                assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[1:n - 1]))
+    # selections that are NOT a channel range of all polarisations keep the general path
+    with guppi.open(golden_path(case['file']), 'rs', subset=(slice(None), [0, nchan - 1]), squeeze=False) as fh:
+        if nchan > 2:
+            assert fh._within_np is None
+        assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, :, [0, nchan - 1]]))
+    if npol > 1:
+        with guppi.open(golden_path(case['file']), 'rs', subset=(0, slice(1, 3))) as fh:
+            assert fh._within_np is None
+            assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, 0, 1:3]))

@@ -875,3 +875,22 @@ def test_mark4_channel_selection_shortens_the_bit_maps():
                     sample_rate=32e6) as fh:
         assert fh._maps()[2] is False and fh._decode_shape == (8,)
     assert kernels.mark4_select_maps(list(range(8)), list(range(8, 16)), 4, [3]) == ([3, 7], [11, 15])
+
+
+def test_guppi_channel_range_is_planned_without_a_gpu():
+    """Channels-first GUPPI: a contiguous channel range of all polarisations
+    is planned on the host as 'enter the block at channel lo, decode m
+    channels'; anything else keeps the general path."""
+    from baseband_amd import guppi
+    from conftest import golden_path
+    path = golden_path('samples/sample_puppi.raw')          # 2 pol x 4 channels
+    with guppi.open(path, 'rs', subset=(slice(None), slice(1, 3))) as fh:
+        assert (fh._chan_lo, fh._decode_shape, fh.sample_shape) == (1, (2, 2), (2, 2))
+    with guppi.open(path, 'rs', subset=(slice(None), slice(2, None))) as fh:
+        assert (fh._chan_lo, fh._decode_shape) == (2, (2, 2))
+    for subset in ((0, slice(1, 3)), (slice(None), [0, 2]), (slice(None), slice(None, None, 2)),
+                   (slice(None), slice(None)), ()):
+        with guppi.open(path, 'rs', subset=subset) as fh:
+            assert fh._within_np is None and fh._chan_lo == 0 and fh._decode_shape == (2, 4), subset
+    with guppi.open(golden_path('synth/guppi_tf_c8_ov16.bin'), 'rs', subset=(slice(None), slice(1, 3))) as fh:
+        assert fh._within_np is None                        # time-first blocks: channels are interleaved
