@@ -330,7 +330,7 @@ class GPUStreamReaderBase:
             self._within_dev = torch.from_numpy(self._within_np).to('cuda')
         return self._within_dev
 
-    def _plan_channel_select(self, subset):
+    def _plan_channel_select(self, subset, lead_in_sample=False):
         """If `subset` (what `_squeeze_and_subset` would apply to decoded
         frames) only picks CHANNELS -- the last axis of `_decode_shape` -- the
         same for every thread, have the decode kernel write just those
@@ -339,14 +339,18 @@ class GPUStreamReaderBase:
         would be one or two extra passes over the 16x expanded output.  The
         test is done by value: the subset is applied to arrays of channel and
         thread numbers, and folded only if the result is `(threads) x (channel
-        list)` in that order.  Anything else keeps the general path."""
+        list)` in that order.  Anything else keeps the general path.
+
+        `lead_in_sample`: the leading axis is not a set of thread frames but
+        lies inside every stored sample (DADA: polarisations); the positions
+        then run over the whole (lead, channel) sample."""
         shape = tuple(self._decode_shape)
         if not subset or not shape or len(shape) > 2 or (len(shape) == 2 and shape[0] > 96):
             return
         nchan = shape[-1]
-        if nchan & (nchan - 1):
-            return
         lead = int(np.prod(shape[:-1])) if len(shape) > 1 else 1
+        if (nchan * lead if lead_in_sample else nchan) & ((nchan * lead if lead_in_sample else nchan) - 1):
+            return
         chan = np.broadcast_to(np.arange(nchan), shape)
         thread = np.broadcast_to(np.arange(lead).reshape(shape[:-1] + (1,)), shape)
 
@@ -370,6 +374,10 @@ class GPUStreamReaderBase:
         if m == nchan and np.array_equal(picked, np.arange(nchan)):
             return                                  # every channel, in order: nothing to fold
         ncomp = 2 if self.complex_data else 1
+        if lead_in_sample:
+            picked = (np.arange(lead)[:, None] * nchan + picked).reshape(-1)
+            if picked.size > 4096:
+                return
         within = (picked[:, None] * ncomp + np.arange(ncomp)).reshape(-1).astype(np.int32)
         self._within_np = within
         self._decode_shape = shape[:-1] + (m,)

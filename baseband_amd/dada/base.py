@@ -110,6 +110,10 @@ class DADAStreamReader(BlockStreamReader):
         self._nsample = (nframes - 1) * header0.samples_per_frame + self._last_rows
         self._spf0 = header0.samples_per_frame
         self._start_time = header0.time
+        if self.bps == 8 and not self._mkbf:
+            # plain DADA samples are (pol, chan) runs of int8: a subset that
+            # keeps every polarisation's same channels is folded into the decode
+            self._plan_channel_select(self.subset, lead_in_sample=True)
 
     def _image(self):
         return self.fh_raw.image()
@@ -148,8 +152,32 @@ class DADAStreamReader(BlockStreamReader):
         pieces = [(base + a * rb, (b - a) * rb)]
 
         def decode(dbuf, out_flat):
-            out_flat[:(b - a) * rb] = decode_i8_rows(dbuf, 0, rb, 0, b - a)
+            self._flat_rows(dbuf, 1, 0, (b - a) * rb, 0, out_flat)
         return pieces, decode
+
+    def _flat_rows(self, dbuf, nframes, lo, n, stride, out_flat):
+        """`n` bytes of whole samples from each of `nframes` frames, at ``lo +
+        i * stride`` -> float32 values in `out_flat`; with a planned channel
+        selection only the kept positions of every sample are written."""
+        within = self._within
+        rb = self._row_nbytes                   # int8 values per sample
+        if n % 4 == 0 and lo % 4 == 0 and stride % 4 == 0:
+            # rows of every frame in ONE launch: `nframes` payloads of n bytes
+            # at a fixed stride
+            try:
+                kernels.decode_frames(dbuf, nframes, n, _lib.CODER_INT, 8,
+                                      chunk=rb if within is not None else 1, src0=lo,
+                                      src_stride=stride, out=out_flat, within=within)
+                return
+            except KeyError:
+                if within is None:
+                    raise                       # (selection too wide for the kernel: index below)
+        per = n if within is None else n // rb * within.numel()
+        for i in range(nframes):
+            rows = decode_i8_rows(dbuf, lo + i * stride, rb, 0, n // rb)
+            if within is not None:
+                rows = rows.view(-1, rb)[:, within.long()].reshape(-1)
+            out_flat[i * per:(i + 1) * per] = rows
 
     def _decode_window(self, dbuf, nframes, a, b, out_flat, payload_offset,
                        frame_stride, first_frame):
@@ -182,17 +210,8 @@ class DADAStreamReader(BlockStreamReader):
                 lo = payload_offset + i * frame_stride + a * self._row_nbytes
                 out_flat[i * nb // 4:(i + 1) * nb // 4] = dbuf[lo:lo + nb].view(torch.float32)
             return
-        n = (b - a) * self._row_nbytes
-        lo = payload_offset + a * self._row_nbytes
-        if n % 4 == 0 and lo % 4 == 0 and frame_stride % 4 == 0:
-            # rows [a, b) of every frame in ONE launch: the frames are `nframes`
-            # payloads of n bytes at a fixed stride
-            kernels.decode_frames(dbuf, nframes, n, _lib.CODER_INT, 8, src0=lo,
-                                  src_stride=frame_stride, out=out_flat)
-            return
-        for i in range(nframes):
-            out_flat[i * n:(i + 1) * n] = decode_i8_rows(
-                dbuf, payload_offset + i * frame_stride, self._row_nbytes, a, b)
+        self._flat_rows(dbuf, nframes, payload_offset + a * self._row_nbytes,
+                        (b - a) * self._row_nbytes, frame_stride, out_flat)
 
 
 class DADAStreamWriter(BlockStreamWriter):

@@ -433,3 +433,40 @@ def test_guppi_channel_ranges_are_decoded_alone(manifest, name):
         with guppi.open(golden_path(case['file']), 'rs', subset=(0, slice(1, 3))) as fh:
             assert fh._within_np is None
             assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, 0, 1:3]))
+
+
+def test_dada_channel_subsets_are_folded_into_the_decode(manifest):
+    """Plain DADA (pol, chan) samples: a subset that keeps the same channels of
+    every polarisation is decoded by bb_decode_frames_select with the positions
+    of those channels inside the stored sample; other subsets keep the general
+    path.  Both == indexing the reference's full decode."""
+    import torch
+    from baseband_amd import dada, _lib
+    name = 'dada_p2_c4_cplx'
+    case = manifest[name]
+    exp = load_expected(name)
+    n = exp.shape[0]
+    for subset, folded in (((slice(None), [2, 0]), True), ((slice(None), slice(1, 3)), True),
+                           ((slice(None), 3), True), ((0, [1, 2]), False), ((1,), False),
+                           ((slice(None), slice(None)), False)):
+        want = exp[(slice(None),) + subset]
+        with dada.open(golden_path(case['file']), 'rs', subset=subset) as fh:
+            assert (fh._within_np is not None) == folded, subset
+            assert fh.shape == want.shape
+            got = fh.read().cpu().numpy()
+            if folded:
+                assert 'k_decode_gather_select' in _lib.last_kernel()
+            assert bits_equal(got, np.ascontiguousarray(want)), subset
+            spf = fh.samples_per_frame
+            for off, cnt in ((spf - 3, 10), (5, 7), (n - 9, 9), (1, min(n - 1, 2 * spf + 3))):
+                fh.seek(off)
+                assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(want[off:off + cnt])), (subset, off)
+            out = torch.empty((n - 2,) + want.shape[1:], dtype=torch.complex64, device='cuda')
+            fh.seek(1)
+            fh.read(out=out)
+            assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[1:n - 1]))
+    # a sample size that is not a power of two keeps the general path
+    exp = load_expected('dada_p2_c3_real')
+    with dada.open(golden_path(manifest['dada_p2_c3_real']['file']), 'rs', subset=(slice(None), [2, 0])) as fh:
+        assert fh._within_np is None
+        assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, :, [2, 0]]))

@@ -894,3 +894,18 @@ def test_guppi_channel_range_is_planned_without_a_gpu():
             assert fh._within_np is None and fh._chan_lo == 0 and fh._decode_shape == (2, 4), subset
     with guppi.open(golden_path('synth/guppi_tf_c8_ov16.bin'), 'rs', subset=(slice(None), slice(1, 3))) as fh:
         assert fh._within_np is None                        # time-first blocks: channels are interleaved
+
+
+def test_dada_channel_selection_covers_every_polarisation():
+    """DADA stores (pol, chan) inside every sample: the planned positions run
+    over both, (re, im) pairs of the kept channels of pol 0, then of pol 1."""
+    import json
+    from baseband_amd import dada
+    from conftest import golden_path
+    with open(golden_path('manifest.json')) as f:
+        case = json.load(f)['cases']['dada_p2_c4_cplx']
+    with dada.open(golden_path(case['file']), 'rs', subset=(slice(None), [2, 0])) as fh:
+        assert fh._within_np.tolist() == [4, 5, 0, 1, 12, 13, 8, 9]
+        assert fh._decode_shape == (2, 2) and fh.sample_shape == (2, 2)
+    with dada.open(golden_path(case['file']), 'rs', subset=(0, [2, 0])) as fh:
+        assert fh._within_np is None
