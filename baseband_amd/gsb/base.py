@@ -140,6 +140,9 @@ class GSBStreamReader(GPUStreamReaderBase):
             self._images = [[host_image(fh_raw)]]
         else:
             self._images = [[host_image(fh) for fh in pair] for pair in fh_raw]
+            # phased data are thread-interleaved frames with one slot per
+            # polarisation: a channel subset is folded into that decode
+            self._plan_channel_select(self.subset)
 
     @property
     def payload_nbytes(self):
@@ -192,7 +195,7 @@ class GSBStreamReader(GPUStreamReaderBase):
         dsrc = (((k * npol + p) * F + f) * pn).reshape(-1).contiguous()
         kernels.decode_frames(dbuf, nsets * F, pn, _lib.CODER_INT, self.bps,
                               chunk=chunk, nslot=npol, src=dsrc,
-                              complex_data=self.complex_data, out=out_flat)
+                              complex_data=self.complex_data, out=out_flat, within=self._within)
 
 
 class _BlockSetImage:

@@ -470,3 +470,27 @@ def test_dada_channel_subsets_are_folded_into_the_decode(manifest):
     with dada.open(golden_path(manifest['dada_p2_c3_real']['file']), 'rs', subset=(slice(None), [2, 0])) as fh:
         assert fh._within_np is None
         assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, :, [2, 0]]))
+
+
+def test_gsb_phased_channel_subsets_are_folded(manifest):
+    """GSB phased data decode as thread-interleaved frames with one slot per
+    polarisation: channel subsets go through bb_decode_frames_select."""
+    from baseband_amd import gsb, _lib
+    case = manifest['sample_gsb_phased']
+    exp = load_expected('sample_gsb_phased')
+    raw = [[golden_path(f) for f in pol] for pol in case['files']]
+    n = exp.shape[0]
+    for subset, folded in (((slice(None), slice(10, 20)), True), ((slice(None), [511, 0, 7]), True),
+                           ((slice(None), 300), True), ((1, slice(10, 20)), False), ((0,), False)):
+        want = exp[(slice(None),) + subset]
+        with gsb.open(golden_path(case['timestamp']), 'rs', raw=raw, samples_per_frame=8,
+                      subset=subset) as fh:
+            assert (fh._within_np is not None) == folded, subset
+            assert fh.shape == want.shape
+            got = fh.read().cpu().numpy()
+            if folded:
+                assert 'k_decode_gather_select' in _lib.last_kernel()
+            assert bits_equal(got, np.ascontiguousarray(want)), subset
+            for off, cnt in ((3, 9), (n - 5, 5), (7, 2)):
+                fh.seek(off)
+                assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(want[off:off + cnt]))
