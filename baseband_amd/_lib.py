@@ -104,7 +104,7 @@ class Mark4DecodeParams(C.Structure):
 
 class TiledParams(C.Structure):
     _fields_ = [('layout', C.c_int32), ('npol', C.c_int32), ('nchan', C.c_int32),
-                ('reserved', C.c_int32), ('ntime', C.c_uint64),
+                ('nchan_stored', C.c_int32), ('ntime', C.c_uint64),
                 ('t_lo', C.c_uint64), ('t_hi', C.c_uint64),
                 ('src0', C.c_int64), ('src_stride', C.c_int64),
                 ('fill_re', C.c_float), ('fill_im', C.c_float)]

@@ -35,6 +35,43 @@ class BlockStreamReader(GPUStreamReaderBase):
         return None
 
     _touched = None         # sample offset at which the previous small request ended
+    _chan_lo = 0            # first channel decoded (`_plan_channel_range`)
+
+    def _plan_channel_range(self):
+        """For (pol, chan) samples decoded by bb_decode_i8_tiled: a `subset`
+        that keeps all polarisations and a contiguous RANGE of channels is the
+        same decode with the payload entered at the first kept channel and
+        fewer channels (`nchan_stored` tells the kernel the strides): the other
+        channels are not written and -- where the format stores channels apart
+        (GUPPI channels-first) -- not read either.  The reference decodes whole
+        blocks and indexes afterwards (base/base.py:706-717 after
+        guppi/payload.py:90-102, dada/payload.py:76-79).  Checked by value,
+        like `_plan_channel_select`: the subset is applied to arrays of
+        polarisation and channel numbers."""
+        if not self.subset or len(self._unsliced_shape) != 2:
+            return
+        npol, nchan = self._unsliced_shape
+        chan = np.broadcast_to(np.arange(nchan), (npol, nchan))
+        pol = np.broadcast_to(np.arange(npol)[:, np.newaxis], (npol, nchan))
+
+        def view(a):
+            a = np.ascontiguousarray(a)[np.newaxis]
+            if self.squeeze:
+                a = a.reshape(a.shape[:1] + tuple(s for s in a.shape[1:] if s > 1))
+            return a[(slice(None),) + tuple(self.subset)]
+        try:
+            c, p = view(chan).reshape(-1), view(pol).reshape(-1)
+        except Exception:
+            return
+        if c.size == 0 or c.size % npol:
+            return
+        m, lo = c.size // npol, int(c[0])
+        if m == nchan or not (np.array_equal(p, np.repeat(np.arange(npol), m))
+                              and np.array_equal(c, np.tile(np.arange(lo, lo + m), npol))):
+            return
+        self._chan_lo = lo
+        self._decode_shape = (npol, m)
+        self._within_np = np.arange(lo, lo + m, dtype=np.int32)     # (the decode applies the subset)
 
     def _frame_span(self, frame):
         """(byte offset of the frame in the file, number of bytes to stage)."""

@@ -1243,7 +1243,17 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     if (((uintptr_t)d_buf & 1) || ((uintptr_t)d_out & 15)) return BB_EINVAL;
     const uint64_t rowlen = (uint64_t)p->npol * p->nchan * 2;
     if (out_elems < (uint64_t)nframes * rows * rowlen) return BB_ERANGE;
-    const uint64_t payload = p->ntime * (uint64_t)p->npol * p->nchan * 2;
+    // a channel RANGE of the stored channels: the payload offsets point at the
+    // first kept channel, strides follow the stored count
+    if (p->nchan_stored < 0 || (p->nchan_stored && p->nchan_stored < p->nchan)) return BB_EINVAL;
+    const uint64_t ncs = p->nchan_stored ? (uint64_t)p->nchan_stored : (uint64_t)p->nchan;
+    // bytes from the first kept channel of the first time to the end of the last kept one
+    uint64_t payload = p->ntime * (uint64_t)p->npol * ncs * 2;
+    if (ncs != (uint64_t)p->nchan) {
+        const uint64_t cut = ncs - (uint64_t)p->nchan;              // channels not entered
+        payload -= (p->layout == BB_LAYOUT_GUPPI_CF ? cut * p->ntime * (uint64_t)p->npol
+                    : p->layout == BB_LAYOUT_MKBF ? cut * 256 : cut * (uint64_t)p->npol) * 2;
+    }
     if (!d_src) {
         if (p->src0 < 0 || p->src_stride < 0 || (p->src0 & 1) || (p->src_stride & 1)) return BB_EINVAL;
         if ((uint64_t)p->src0 + ((uint64_t)nframes - 1) * (uint64_t)p->src_stride + payload > buf_nbytes)
@@ -1265,8 +1275,8 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     const uint64_t T = p->ntime, np_ = (uint64_t)p->npol, nc = (uint64_t)p->nchan;
     switch (p->layout) {
         case BB_LAYOUT_GUPPI_CF: a.tb = T ? T : 1; a.sh = 0; a.st = np_; a.sp = 1; a.sc = T * np_; break;
-        case BB_LAYOUT_MKBF:     a.tb = 256; a.sh = np_ * nc * 256; a.st = 1; a.sp = nc * 256; a.sc = 256; break;
-        default:                 a.tb = T ? T : 1; a.sh = 0; a.st = nc * np_; a.sp = 1; a.sc = np_; break;
+        case BB_LAYOUT_MKBF:     a.tb = 256; a.sh = np_ * ncs * 256; a.st = 1; a.sp = ncs * 256; a.sc = 256; break;
+        default:                 a.tb = T ? T : 1; a.sh = 0; a.st = ncs * np_; a.sp = 1; a.sc = np_; break;
     }
     hipStream_t st = (hipStream_t)stream;
     const bool nt = g_tune_nt.load() != 0;
@@ -1283,7 +1293,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
         else if (p->layout == BB_LAYOUT_MKBF)
             ok = ok && (np_ == 1 || np_ == 2) && (p->t_lo % 8 == 0);
         else
-            ok = ok && np_ == 2 && (nc % 4 == 0);
+            ok = ok && np_ == 2 && (nc % 4 == 0) && (ncs % 4 == 0);
         if (ok) {
             const uint64_t xrows = (uint64_t)g_tune_xpose_rows.load();
             const uint64_t ntt = (rows + xrows - 1) / xrows, nct = (nc + BB_XP_TC - 1) / BB_XP_TC;

@@ -207,7 +207,7 @@ void k_decode_i8_stage(bb_tiled_args a)
             const uint32_t run = LAYOUT == 2 ? nc_tile * npol : nt_tile;
             for (uint32_t r = wave; r < nrows_in; r += BB_WAVES_PER_BLOCK) {
                 if (LAYOUT == 2) {
-                    const uint16_t *row = in + ((t0 + r) * a.nchan + c0) * npol;
+                    const uint16_t *row = in + (t0 + r) * a.st + (uint64_t)c0 * npol;    // (st = stored channels x npol)
                     if (((uintptr_t)row & 3) == 0) {
                         for (uint32_t i = lane * 2; i < run; i += 128) {
                             if (i + 1 < run) s32[(r * pe + i) >> 1] = *reinterpret_cast<const uint32_t *>(row + i);

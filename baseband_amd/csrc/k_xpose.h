@@ -96,7 +96,7 @@ void k_decode_i8_xpose(bb_tiled_args a)
                 const uint32_t tl = g >> 4, piece = g & 15;
                 const uint64_t t = a.t_lo + (uint64_t)ti * tt + tl;
                 want = want && t < a.t_hi && piece * 4 < ncv;
-                ptr = in + (t * a.nchan + c0 + piece * 4) * 2;
+                ptr = in + t * a.st + (uint64_t)(c0 + piece * 4) * 2;     // (st = stored channels x 2 pol)
             }
             w[k] = want ? *reinterpret_cast<const bb_u4 *>(ptr) : bb_u4{0u, 0u, 0u, 0u};
         }

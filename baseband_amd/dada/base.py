@@ -114,6 +114,9 @@ class DADAStreamReader(BlockStreamReader):
             # plain DADA samples are (pol, chan) runs of int8: a subset that
             # keeps every polarisation's same channels is folded into the decode
             self._plan_channel_select(self.subset, lead_in_sample=True)
+        elif self.bps == 8:
+            # MKBF heaps: a channel range is the same transpose over fewer channels
+            self._plan_channel_range()
 
     def _image(self):
         return self.fh_raw.image()
@@ -143,10 +146,13 @@ class DADAStreamReader(BlockStreamReader):
             h0, h1 = a // 256, -(-b // 256)
             heap = npol * nchan * 256 * 2
             pieces = [(base + h0 * heap, (h1 - h0) * heap)]
+            nkeep = self._decode_shape[-1]
+            skip = kernels.tiled_channel_skip(_lib.LAYOUT_MKBF, npol, 0, self._chan_lo)
 
             def decode(dbuf, out_flat):
-                kernels.decode_i8_tiled(dbuf, 1, _lib.LAYOUT_MKBF, npol, nchan, (h1 - h0) * 256,
-                                        a - h0 * 256, b - h0 * 256, src0=0, out=out_flat)
+                kernels.decode_i8_tiled(dbuf, 1, _lib.LAYOUT_MKBF, npol, nkeep, (h1 - h0) * 256,
+                                        a - h0 * 256, b - h0 * 256, src0=skip, out=out_flat,
+                                        nchan_stored=nchan)
             return pieces, decode
         rb = self._row_nbytes
         pieces = [(base + a * rb, (b - a) * rb)]
@@ -187,19 +193,22 @@ class DADAStreamReader(BlockStreamReader):
         if self._mkbf:
             # a truncated last frame only holds `_last_rows` samples (whole heaps)
             n_full = nframes
-            row = (b - a) * npol * nchan * 2
+            nkeep = self._decode_shape[-1]          # (a planned channel range: fewer channels,
+            # every heap entered at the first kept one)
+            skip = kernels.tiled_channel_skip(_lib.LAYOUT_MKBF, npol, 0, self._chan_lo)
+            row = (b - a) * npol * nkeep * 2
             if first_frame + nframes == self._nframes and self._last_rows < self._spf0:
                 n_full -= 1
                 kernels.decode_i8_tiled(
-                    dbuf, 1, _lib.LAYOUT_MKBF, npol, nchan,
+                    dbuf, 1, _lib.LAYOUT_MKBF, npol, nkeep,
                     self._last_rows // 256 * 256, a, b,
-                    src0=payload_offset + n_full * frame_stride,
-                    out=out_flat[n_full * row:])
+                    src0=payload_offset + skip + n_full * frame_stride,
+                    out=out_flat[n_full * row:], nchan_stored=nchan)
             if n_full:
-                kernels.decode_i8_tiled(dbuf, n_full, _lib.LAYOUT_MKBF, npol, nchan,
-                                        self._spf0, a, b, src0=payload_offset,
+                kernels.decode_i8_tiled(dbuf, n_full, _lib.LAYOUT_MKBF, npol, nkeep,
+                                        self._spf0, a, b, src0=payload_offset + skip,
                                         src_stride=frame_stride,
-                                        out=out_flat[:n_full * row])
+                                        out=out_flat[:n_full * row], nchan_stored=nchan)
             return
         if self.bps == 32:
             # EXTENSION (no counterpart in the reference, which knows NBIT 8

@@ -80,45 +80,8 @@ class GUPPIStreamReader(BlockStreamReader):
         self._overlap = header0.overlap
         self._nsample = self._nframes * self.samples_per_frame + self._overlap
         self._start_time = header0.time
-        self._plan_channel_range()
-
-    _chan_lo = 0
-
-    def _plan_channel_range(self):
-        """Channels-first blocks store every channel as one contiguous run, so
-        a `subset` that keeps all polarisations and a contiguous range of
-        channels is the same decode with the payload entered at that range and
-        fewer channels: nothing of the other channels is read, written or --
-        for requests staged row-wise -- sent over PCIe.  The reference decodes
-        whole blocks and indexes afterwards (base/base.py:706-717 after
-        guppi/payload.py:90-96).  Checked by value, like
-        `_plan_channel_select`: the subset is applied to arrays of polarisation
-        and channel numbers."""
-        h = self.header0
-        if not (self.subset and h.channels_first and self.complex_data and self.bps == 8):
-            return
-        npol, nchan = self._unsliced_shape
-        chan = np.broadcast_to(np.arange(nchan), (npol, nchan))
-        pol = np.broadcast_to(np.arange(npol)[:, np.newaxis], (npol, nchan))
-
-        def view(a):
-            a = np.ascontiguousarray(a)[np.newaxis]
-            if self.squeeze:
-                a = a.reshape(a.shape[:1] + tuple(s for s in a.shape[1:] if s > 1))
-            return a[(slice(None),) + tuple(self.subset)]
-        try:
-            c, p = view(chan).reshape(-1), view(pol).reshape(-1)
-        except Exception:
-            return
-        if c.size == 0 or c.size % npol:
-            return
-        m, lo = c.size // npol, int(c[0])
-        if m == nchan or not (np.array_equal(p, np.repeat(np.arange(npol), m))
-                              and np.array_equal(c, np.tile(np.arange(lo, lo + m), npol))):
-            return
-        self._chan_lo = lo
-        self._decode_shape = (npol, m)
-        self._within_np = np.arange(lo, lo + m, dtype=np.int32)     # (the decode applies the subset)
+        if self.complex_data and self.bps == 8:
+            self._plan_channel_range()
 
     def _image(self):
         return self.fh_raw.image()
@@ -152,19 +115,22 @@ class GUPPIStreamReader(BlockStreamReader):
         npol, nchan, T = h.npol, h.nchan, self._spf_full
         base = self._frame_span(frame)[0] + self._header_nbytes
         step = npol * 2                                   # bytes per time of one channel
+        c0, nkeep = self._chan_lo, self._decode_shape[-1]           # (the channels asked for)
         if h.channels_first:
-            c0, nchan = self._chan_lo, self._decode_shape[-1]       # (the channels asked for)
-            if nchan > 4096:
+            if nkeep > 4096:
                 return None
-            pieces = [(base + (c * T + a) * step, (b - a) * step) for c in range(c0, c0 + nchan)]
-            layout = _lib.LAYOUT_GUPPI_CF
+            # only the kept channels' runs are staged: together they are a
+            # block of `nkeep` channels
+            pieces = [(base + (c * T + a) * step, (b - a) * step) for c in range(c0, c0 + nkeep)]
+            layout, stored, skip = _lib.LAYOUT_GUPPI_CF, 0, 0
         else:
+            # whole times are staged; the kernel enters each at channel c0
             pieces = [(base + a * nchan * step, (b - a) * nchan * step)]
-            layout = _lib.LAYOUT_GUPPI_TF
+            layout, stored, skip = _lib.LAYOUT_GUPPI_TF, nchan, c0 * step
 
         def decode(dbuf, out_flat):
-            kernels.decode_i8_tiled(dbuf, 1, layout, npol, nchan, b - a, 0, b - a,
-                                    src0=0, out=out_flat)
+            kernels.decode_i8_tiled(dbuf, 1, layout, npol, nkeep, b - a, 0, b - a,
+                                    src0=skip, out=out_flat, nchan_stored=stored)
         return pieces, decode
 
     def _decode_window(self, dbuf, nframes, a, b, out_flat, payload_offset,
@@ -185,10 +151,10 @@ class GUPPIStreamReader(BlockStreamReader):
             return
         layout = _lib.LAYOUT_GUPPI_CF if h.channels_first else _lib.LAYOUT_GUPPI_TF
         # (a planned channel range: enter every block at its first kept channel)
-        skip = self._chan_lo * self._spf_full * h.npol * 2
+        skip = kernels.tiled_channel_skip(layout, h.npol, self._spf_full, self._chan_lo)
         kernels.decode_i8_tiled(dbuf, nframes, layout, h.npol, self._decode_shape[-1],
                                 self._spf_full, a, b, src0=payload_offset + skip,
-                                src_stride=frame_stride, out=out_flat)
+                                src_stride=frame_stride, out=out_flat, nchan_stored=h.nchan)
 
 
 class GUPPIStreamWriter(BlockStreamWriter):

@@ -343,13 +343,16 @@ def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
 
 
 def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
-                    src=None, src0=0, src_stride=0, fill_value=0., out=None):
+                    src=None, src0=0, src_stride=0, fill_value=0., out=None, nchan_stored=0):
     """int8 (re, im) -> complex64 with the (time, pol, chan) permutation of
-    `layout`; rows [t_lo, t_hi) of every frame -> flat float32 tensor."""
+    `layout`; rows [t_lo, t_hi) of every frame -> flat float32 tensor.  With
+    `nchan_stored` the payload holds that many channels and the `nchan`
+    starting at the payload offset are decoded (`tiled_channel_skip`)."""
     p = _lib.TiledParams()
     p.layout = layout
     p.npol = npol
     p.nchan = nchan
+    p.nchan_stored = nchan_stored
     p.ntime = ntime
     p.t_lo = t_lo
     p.t_hi = t_hi
@@ -364,6 +367,16 @@ def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
                                  C.byref(p), _ptr(tgt.use), tgt.use.numel(), _stream(dbuf)),
           'bb_decode_i8_tiled')
     return tgt.done()
+
+
+def tiled_channel_skip(layout, npol, ntime, c_lo):
+    """Bytes from the start of a payload to its channel `c_lo`, for
+    `decode_i8_tiled(..., nchan_stored=...)`."""
+    if layout == _lib.LAYOUT_GUPPI_CF:
+        return c_lo * ntime * npol * 2          # every channel is one run of all times
+    if layout == _lib.LAYOUT_MKBF:
+        return c_lo * 256 * 2                   # 256 times of a channel inside a (heap, pol) block
+    return c_lo * npol * 2                      # channels of one time lie side by side
 
 
 def as_device_samples(data):

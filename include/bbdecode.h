@@ -414,8 +414,12 @@ enum bb_layout {
 typedef struct bb_tiled_params {
     int32_t  layout;          /* enum bb_layout */
     int32_t  npol;
-    int32_t  nchan;
-    int32_t  reserved;
+    int32_t  nchan;           /* channels decoded */
+    int32_t  nchan_stored;    /* channels the payload holds, when only the `nchan` starting at the
+                                 payload offset are decoded (a reader subset that keeps a channel
+                                 range: point src0 / d_src at the first kept channel -- c_lo *
+                                 ntime * npol * 2 bytes into a GUPPI_CF payload, c_lo * 512 into an
+                                 MKBF heap, c_lo * npol * 2 into a GUPPI_TF time); 0 = nchan */
     uint64_t ntime;           /* complete samples stored per frame */
     uint64_t t_lo, t_hi;      /* local sample range to decode, t_hi <= ntime */
     int64_t  src0;            /* payload offsets when d_src == NULL */

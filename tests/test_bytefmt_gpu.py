@@ -382,15 +382,18 @@ def test_xpose_kernel_raw_layouts(tile_rows):
         kernels.tune(_lib.TUNE_XPOSE_ROWS, 128)
 
 
-@pytest.mark.parametrize('name', ['sample_puppi', 'guppi_cf_c64_ov0', 'guppi_cf_c64_ov32', 'guppi_cf_c6_p1'])
+@pytest.mark.parametrize('name', ['sample_puppi', 'guppi_cf_c64_ov0', 'guppi_cf_c64_ov32', 'guppi_cf_c6_p1',
+                                  'guppi_tf_c8_ov16', 'sample_mkbf_dada'])
 def test_guppi_channel_ranges_are_decoded_alone(manifest, name):
-    """Channels-first blocks: a subset keeping all polarisations and a
-    contiguous channel range enters every block at that range
-    (`_plan_channel_range`); result == indexing the reference's full decode,
-    for whole reads, reads across the overlap, small (row-staged) reads and
-    in-place decodes."""
+    """GUPPI blocks of both storage orders and MKBF heaps: a subset keeping all
+    polarisations and a contiguous channel range enters every block at that
+    range (`_plan_channel_range`, `nchan_stored`); result == indexing the
+    reference's full decode, for whole reads, reads across the overlap, small
+    (row-staged) reads and in-place decodes."""
     import torch
-    from baseband_amd import guppi
+    from baseband_amd import guppi, dada
+    if name.endswith('dada'):
+        guppi = dada            # (same reader interface; MKBF heaps are the DADA flavour of this layout)
     case = manifest[name]
     exp = load_expected(name)
     n, npol, nchan = exp.shape
@@ -494,3 +497,35 @@ def test_gsb_phased_channel_subsets_are_folded(manifest):
             for off, cnt in ((3, 9), (n - 5, 5), (7, 2)):
                 fh.seek(off)
                 assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(want[off:off + cnt]))
+
+
+@pytest.mark.parametrize('layout', [0, 1, 2])
+def test_xpose_kernel_channel_ranges(layout):
+    """k_decode_i8_xpose entered at a channel of wider payloads (`nchan_stored`):
+    strides follow the stored channel count, tiles the kept range."""
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(900 + layout)
+    nfr, npol, stored, T, head = 3, 2, 160, 512, 32
+    pn = T * npol * stored * 2
+    stride = pn + head
+    raw = rng.integers(0, 256, size=nfr * stride, dtype=np.uint8)
+    b = np.stack([raw[head + f * stride:head + f * stride + pn] for f in range(nfr)]).view(np.int8)
+    if layout == 0:
+        ref = b.reshape(nfr, stored, T, npol, 2).transpose(0, 2, 3, 1, 4)
+    elif layout == 1:
+        ref = b.reshape(nfr, T // 256, npol, stored, 256, 2).transpose(0, 1, 4, 2, 3, 5) \
+            .reshape(nfr, T, npol, stored, 2)
+    else:
+        ref = b.reshape(nfr, T, stored, npol, 2).transpose(0, 1, 3, 2, 4)
+    ref = np.ascontiguousarray(ref).astype(np.float32)
+    dbuf = kernels.to_device_bytes(raw)
+    for c_lo, keep, lo, hi in ((32, 64, 0, T), (0, 96, 8, T - 8), (96, 64, 256, 512), (4, 36, 0, T)):
+        skip = kernels.tiled_channel_skip(layout, npol, T, c_lo)
+        out = kernels.decode_i8_tiled(dbuf, nfr, layout, npol, keep, T, lo, hi, src0=head + skip,
+                                      src_stride=stride, nchan_stored=stored).cpu().numpy()
+        assert 'k_decode_i8_xpose' in _lib.last_kernel(), (_lib.last_kernel(), c_lo, keep)
+        want = ref[:, lo:hi, :, c_lo:c_lo + keep]
+        assert bits_equal(out, np.ascontiguousarray(want).reshape(-1)), (layout, c_lo, keep, lo, hi)
+    with pytest.raises(_lib.BBError):          # fewer stored than decoded channels
+        kernels.decode_i8_tiled(dbuf, nfr, layout, npol, 64, T, 0, T, src0=head, src_stride=stride,
+                                nchan_stored=32)

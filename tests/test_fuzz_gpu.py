@@ -215,7 +215,7 @@ def _tiled_reference(b, layout, nfr, npol, nchan, T):
     return np.ascontiguousarray(ref).astype(np.float32)
 
 
-@pytest.mark.parametrize('seed', range(150))
+@pytest.mark.parametrize('seed', range(300))
 def test_decode_i8_tiled_random_geometry(seed):
     """bb_decode_i8_tiled: the dispatcher chooses between k_decode_i8_xpose and
     the general kernels by alignment, channel count and time range; whatever it
@@ -250,6 +250,20 @@ def test_decode_i8_tiled_random_geometry(seed):
     lo, hi = min(lo, T - 1), max(min(hi, T), min(lo, T - 1) + 1)
     fill = complex(3., -4.)
     kw = dict(fill_value=fill)
+    # a channel range of the stored channels (nchan_stored): enter the payloads
+    # at channel c_lo and decode nkeep of them
+    c_lo, nkeep = 0, nchan
+    if nchan > 1 and rng.integers(2):
+        nkeep = int(rng.choice([1, 2, 4, 32, 36, 64]))
+        nkeep = min(nkeep, nchan - 1)
+        c_lo = int(rng.integers(0, nchan - nkeep + 1))
+        if rng.integers(2):
+            c_lo -= c_lo % 4                    # (16-byte aligned entry: the fast kernel's case)
+        kw['nchan_stored'] = nchan
+        skip = kernels.tiled_channel_skip(layout, npol, T, c_lo)
+        offs = offs + skip
+        head += skip
+        ref = np.ascontiguousarray(ref[..., c_lo:c_lo + nkeep, :])
     missing = None
     if rng.integers(2):
         src = offs.copy()
@@ -259,10 +273,10 @@ def test_decode_i8_tiled_random_geometry(seed):
         kw['src'] = torch.from_numpy(src).cuda()
     else:
         kw.update(src0=head, src_stride=stride)
-    out = kernels.decode_i8_tiled(kernels.to_device_bytes(raw), nfr, layout, npol, nchan, T,
+    out = kernels.decode_i8_tiled(kernels.to_device_bytes(raw), nfr, layout, npol, nkeep, T,
                                   lo, hi, **kw).cpu().numpy()
     want = ref[:, lo:hi].copy()
     if missing is not None:
         want[missing] = np.array([fill.real, fill.imag], np.float32)
-    assert bits_equal(out, want.reshape(-1)), (layout, npol, nchan, T, nfr, head, stride, lo, hi,
-                                               missing, _lib.last_kernel())
+    assert bits_equal(out, want.reshape(-1)), (layout, npol, nchan, c_lo, nkeep, T, nfr, head, stride,
+                                               lo, hi, missing, _lib.last_kernel())

@@ -893,7 +893,11 @@ def test_guppi_channel_range_is_planned_without_a_gpu():
         with guppi.open(path, 'rs', subset=subset) as fh:
             assert fh._within_np is None and fh._chan_lo == 0 and fh._decode_shape == (2, 4), subset
     with guppi.open(golden_path('synth/guppi_tf_c8_ov16.bin'), 'rs', subset=(slice(None), slice(1, 3))) as fh:
-        assert fh._within_np is None                        # time-first blocks: channels are interleaved
+        # time-first blocks: the kernel enters every time at channel 1 (nchan_stored = 8)
+        assert (fh._chan_lo, fh._decode_shape) == (1, (2, 2))
+    from baseband_amd import dada
+    with dada.open(golden_path('samples/sample_mkbf.dada'), 'rs', subset=(slice(None), slice(3, 9))) as fh:
+        assert fh._mkbf and (fh._chan_lo, fh._decode_shape[-1]) == (3, 6)
 
 
 def test_dada_channel_selection_covers_every_polarisation():
