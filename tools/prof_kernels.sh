@@ -14,7 +14,7 @@ cd /tmp
 run() {   # name, rocprof args...
   local name=$1; shift
   rm -rf $OUT/$name
-  rocprofv3 "$@" -d $OUT/$name -o p --output-format csv -- python3 $R/tools/prof_formats.py $GIB 3 > $OUT/$name.log 2>&1
+  timeout 900 rocprofv3 "$@" -d $OUT/$name -o p --output-format csv -- python3 $R/tools/prof_formats.py $GIB 3 > $OUT/$name.log 2>&1
   find $OUT/$name -type f ! -name '*.csv' -delete
 }
 run stats --kernel-trace --stats
