@@ -301,7 +301,7 @@ class GPUStreamReaderBase:
 
     def close(self):
         self._closed = True
-        self._ahead = None
+        self._ahead = self._decoded = None
         self._staged = self._sink = None
         self._have = []
         if self._pipeline is not None:
@@ -614,6 +614,17 @@ class GPUStreamReaderBase:
         if self._pending_warning:
             warnings.warn(self._pending_warning)
             self._pending_warning = None
+        ahead = self._from_decoded_ahead(count) if count else None
+        if ahead is not None:
+            self.offset += count
+            self._seq_end = self.offset
+            if out is None:
+                return ahead
+            if isinstance(out, torch.Tensor):
+                out.copy_(ahead)
+            else:
+                _to_host_array(ahead, out)
+            return out
         data, direct = self._fill_request(out, count)
         if not self._resolve_checks():
             # verify='fix': frames are missing or out of place.  Build the
@@ -624,6 +635,7 @@ class GPUStreamReaderBase:
                 raise EOFError("cannot read from beyond end of input.")
             data, direct = self._fill_request(out, count)
         self.offset += count
+        self._seq_end = self.offset
         if direct:
             return out
         data = self._squeeze_and_subset(data)
@@ -634,6 +646,64 @@ class GPUStreamReaderBase:
         else:
             _to_host_array(data, out)
         return out
+
+    # -- decoded read-ahead for loops of small sequential reads
+    decode_ahead = True                 # set False to decode exactly what every read() asks for
+    decode_ahead_bytes = 64 << 20       # decoded bytes per read-ahead window at most
+    _decoded = None                     # (first sample, end sample, decoded tensor) of the window
+    _seq_end = None                     # where the previous read() ended
+    _seq_run = 0                        # consecutive reads that continued the one before
+    _ahead_sets = 16                    # frame sets in the next window (x4 per refill)
+
+    def _from_decoded_ahead(self, count):
+        """Frame-at-a-time loops (the reference's own way through a file, and
+        many user scripts) cost a scan, an index and a decode launch per
+        ``read()`` -- tens of microseconds of host time for a microsecond of
+        GPU work.  When the third read in a row continues exactly where the
+        one before ended, a window of following frame sets is decoded at once
+        (growing x4 per refill up to `decode_ahead_bytes` of output) and
+        sequential reads inside it are served as views of that tensor.  Every
+        sample of a window is handed out at most once, and any read that is
+        not a continuation (a seek) drops the window.  If verification finds a
+        problem anywhere in a window the reader goes back to decoding exactly
+        what each read asks for, for good: errors, warnings and repairs then
+        happen at the read that meets the problem, as without read-ahead.
+        Returns the samples, or None for the ordinary path."""
+        off = self.offset
+        if not self.decode_ahead or self._seq_end != off:
+            self._seq_run, self._decoded, self._ahead_sets = 0, None, 16
+            return None
+        self._seq_run += 1
+        d = self._decoded
+        if d is not None and d[0] <= off and off + count <= d[1]:
+            return d[2][off - d[0]:off - d[0] + count]
+        self._decoded = None
+        if self._seq_run < 2:
+            return None
+        spf = self.samples_per_frame
+        ncomp = 2 if self.complex_data else 1
+        set_bytes = spf * int(np.prod(self._decode_shape)) * ncomp * 4
+        max_sets = max(1, self.decode_ahead_bytes // max(1, set_bytes))
+        first = off // spf
+        need = -(-(off + count) // spf) - first
+        if need * 4 > max_sets:
+            return None                 # not a small request: the ordinary path is the fast one
+        last = min(first + max(need, min(self._ahead_sets, max_sets)), -(-self.shape[0] // spf))
+        if last - first < need:
+            return None
+        try:
+            data = self._read_sets(first, last)
+            ok = self._resolve_checks(quiet=True)
+        except Exception:
+            ok = False
+        if not ok:
+            self.decode_ahead = False
+            self._nmissing, self._checked = 0, False
+            return None
+        self._ahead_sets = min(max_sets, self._ahead_sets * 4)
+        data = self._squeeze_and_subset(data)
+        self._decoded = (first * spf, min(last * spf, self.shape[0]), data)
+        return data[off - first * spf:off - first * spf + count]
 
     def _fill_request(self, out, count):
         """Decode samples [offset, offset + count).  Returns ``(data, direct)``:
@@ -799,10 +869,11 @@ class GPUStreamReaderBase:
         self._nmissing += int(missing)
         self._checked = True
 
-    def _resolve_checks(self):
+    def _resolve_checks(self, quiet=False):
         """Look at the verification counters the windows left on the device
         (one host sync per read, none when verify is False).  Returns False
-        when verify='fix' found a problem that `_relocate` can repair."""
+        when verify='fix' found a problem that `_relocate` can repair; with
+        `quiet`, False for any problem, without warning or raising."""
         checked, self._checked = self._checked, False
         if not self.verify or not checked:
             return True
@@ -810,6 +881,8 @@ class GPUStreamReaderBase:
         self._nmissing = 0
         if nbad:
             self._nbad.zero_()
+            if quiet:
+                return False
             msg = ("problem loading frame: {} frame header(s) failed verification "
                    "(bad sync/invariants or unexpected time index)".format(nbad))
             if self.verify == 'fix':

@@ -1,0 +1,135 @@
+"""Decoded read-ahead of small sequential reads (`_from_decoded_ahead`): the
+frame-at-a-time loop must give exactly what exact per-read decoding gives --
+samples, errors and the read at which they occur."""
+import json
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import golden_path, load_expected, load_file, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _open(name, manifest, **kw):
+    import baseband_amd
+    from baseband_amd import vdif, mark5b, mark4, gsb
+    case = manifest[name]
+    if name.startswith('sample_gsb'):
+        if 'files' in case:
+            raw = [[golden_path(f) for f in pol] for pol in case['files']]
+            return gsb.open(golden_path(case['timestamp']), 'rs', raw=raw, samples_per_frame=8, **kw)
+        return gsb.open(golden_path(case['timestamp']), 'rs', raw=golden_path(case['file']),
+                        samples_per_frame=8192, **kw)
+    path = golden_path(case['file'])
+    if 'vdif' in name:
+        if 'frame_rate' in case:
+            kw.setdefault('sample_rate', case['frame_rate'] * case['samples_per_frame'])
+        return vdif.open(path, 'rs', **kw)
+    if name.startswith('m5b') or 'mark5b' in name or name == 'sample_m5b':
+        return mark5b.open(path, 'rs', nchan=case.get('nchan', 8), bps=case.get('bps', 2), kday=56000,
+                           sample_rate=case['frame_rate'] * case['samples_per_frame'], **kw)
+    return mark4.open(path, 'rs', ntrack=case['ntrack'], decade=2010,
+                      sample_rate=case['frame_rate'] * case['samples_per_frame'], **kw)
+
+
+CASES = ['sample_vdif', 'vdif_cfg2_small', 'vdif_cfg3_small', 'm5b_c16_b2', 'm4_t64_f4',
+         'sample_gsb_rawdump', 'sample_gsb_phased']
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('step', ['frame', 'odd', 'tiny'])
+def test_sequential_small_reads_equal_one_read(manifest, name, step):
+    exp = load_expected(name)
+    with _open(name, manifest, squeeze=False) as fh:
+        n, spf = fh.shape[0], fh.samples_per_frame
+        chunk = {'frame': spf, 'odd': max(1, spf // 3 + 7), 'tiny': max(1, min(spf, 5))}[step]
+        nread = min(-(-n // chunk), 400)
+        used, pos = 0, 0
+        for _ in range(nread):
+            cnt = min(chunk, n - pos)
+            got = fh.read(cnt).cpu().numpy()
+            assert bits_equal(got, np.ascontiguousarray(exp[pos:pos + cnt])), (name, pos, cnt)
+            pos += cnt
+            used += fh._decoded is not None
+            assert fh.tell() == pos
+        if nread > 4:
+            assert used > 0, "the loop never ran from the decoded window"
+        # a seek drops the window; reads stay right, and a new sequence builds a new one
+        for off in (1, max(0, n // 2 - 3), 0):
+            fh.seek(off)
+            cnt = min(chunk, n - off)
+            assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(exp[off:off + cnt]))
+            assert fh._decoded is None
+
+
+def test_window_samples_are_served_once_and_out_is_filled(manifest):
+    import torch
+    exp = load_expected('vdif_cfg2_small')
+    with _open('vdif_cfg2_small', manifest) as fh:
+        spf = fh.samples_per_frame
+        want = exp.reshape(exp.shape[0], -1)[:, 0] if exp.ndim > 1 else exp
+        pos = 0
+        first = []
+        for k in range(9):
+            if k % 3 == 0:
+                out = torch.empty((spf,) + fh.sample_shape, dtype=torch.float32, device='cuda')
+                got = fh.read(out=out)
+                assert got is out
+            elif k % 3 == 1:
+                host = np.empty((spf,) + fh.sample_shape, np.float32)
+                got = torch.from_numpy(fh.read(out=host))
+            else:
+                got = fh.read(spf)
+                got.mul_(2.)                    # in-place use of a served view ...
+                got = got / 2.
+            first.append(got.cpu().numpy())
+            pos += spf
+        assert bits_equal(np.concatenate(first).reshape(-1), np.ascontiguousarray(want[:pos]).reshape(-1))
+        # ... is never seen again: going back decodes afresh
+        fh.seek(2 * spf)
+        assert bits_equal(fh.read(spf).cpu().numpy().reshape(-1), np.ascontiguousarray(want[2 * spf:3 * spf]).reshape(-1))
+
+
+@pytest.mark.parametrize('verify', [True, 'fix'])
+def test_problems_surface_at_the_same_read_as_without_read_ahead(tmp_path, verify):
+    """A file with a damaged frame further on: the loop with read-ahead raises
+    (verify=True) or warns and repairs (verify='fix') at the same read, with
+    the same samples, as exact per-read decoding."""
+    from baseband_amd import vdif
+    base = load_file('synth/vdif_triple.bin').copy()
+    with vdif.open(golden_path('synth/vdif_triple.bin'), 'rs') as fh:
+        fnb = fh.header0.frame_nbytes
+        nthread = fh._unsliced_shape[0] if len(fh._unsliced_shape) > 1 else 1
+        spf, n = fh.samples_per_frame, fh.shape[0]
+    nsets = n // spf
+    bad_set = min(nsets - 2, 40)
+    blob = np.delete(base, np.arange(bad_set * nthread * fnb + 100, bad_set * nthread * fnb + 100 + fnb))
+    p = tmp_path / 'damaged.vdif'
+    p.write_bytes(blob.tobytes())
+    chunk = max(1, spf // 4)
+
+    def loop(ahead):
+        events, data = [], []
+        with vdif.open(str(p), 'rs', verify=verify) as fh:
+            fh.decode_ahead = ahead
+            for k in range(min(400, fh.shape[0] // chunk)):
+                with warnings.catch_warnings(record=True) as w:
+                    warnings.simplefilter('always')
+                    try:
+                        data.append(fh.read(chunk).cpu().numpy())
+                    except ValueError:
+                        events.append((k, 'ValueError'))
+                        break
+                    except EOFError:
+                        events.append((k, 'EOFError'))
+                        break
+                if w:
+                    events.append((k, 'warning'))
+        return events, np.concatenate(data) if data else np.empty(0)
+
+    ev_exact, d_exact = loop(False)
+    ev_ahead, d_ahead = loop(True)
+    assert ev_exact and ev_exact == ev_ahead, (ev_exact, ev_ahead)
+    assert bits_equal(d_exact, d_ahead)
