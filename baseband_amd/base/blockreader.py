@@ -35,6 +35,39 @@ class BlockStreamReader(GPUStreamReaderBase):
         return None
 
     _touched = None         # sample offset at which the previous small request ended
+    _prefetch = None        # (frame, future) of a frame on its way to HBM in the background
+    prefetch_next = True    # set False to stage every frame when it is first needed
+
+    def _start_prefetch(self, frame):
+        """A sequential loop of small reads is inside frame - 1: bring `frame`
+        to HBM on the worker thread meanwhile (`staging.upload_in_background`)."""
+        if (not self.prefetch_next or frame >= self._nframes or self._resident_bytes() is not None
+                or (self._prefetch is not None and self._prefetch[0] == frame)):
+            return
+        from ..staging import upload_in_background
+        image = self._image()
+        lo, nbytes = self._frame_span(frame)
+        self._prefetch = (frame, upload_in_background(image, lo, min(lo + nbytes, len(image))))
+
+    def _take_prefetch(self, frame):
+        """The device bytes of `frame` if they were prefetched, else None."""
+        pending, self._prefetch = self._prefetch, None
+        if pending is None:
+            return None
+        dev, done = pending[1].result()             # (also waits out a prefetch nobody wants)
+        if pending[0] != frame:
+            return None
+        torch.cuda.current_stream().wait_event(done)
+        return dev
+
+    def close(self):
+        if self._prefetch is not None:
+            try:
+                self._prefetch[1].result()
+            except Exception:
+                pass
+            self._prefetch = None
+        super().close()
     _chan_lo = 0            # first channel decoded (`_plan_channel_range`)
 
     def _plan_channel_range(self):
@@ -140,8 +173,13 @@ class BlockStreamReader(GPUStreamReaderBase):
                     decode(upload(host), o)
                     continue
                 if not cached:
-                    lo, nbytes = self._frame_span(f0)
-                    self._ahead = (f0, upload(image[lo:min(lo + nbytes, len(image))]))
+                    dev = self._take_prefetch(f0)
+                    if dev is None:
+                        lo, nbytes = self._frame_span(f0)
+                        dev = upload(image[lo:min(lo + nbytes, len(image))])
+                    self._ahead = (f0, dev)
+                    # a sequential loop: the next frame travels while this one is consumed
+                    self._start_prefetch(f0 + 1)
                 self._decode_window(self._ahead[1], 1, a, b, o, self._header_nbytes,
                                     self._frame_nbytes, f0)
             runs = []

@@ -157,10 +157,13 @@ class WindowPipeline:
                 ev.synchronize()
 
 
-def upload(image, device='cuda', chunk_bytes=64 << 20):
+def upload(image, device='cuda', chunk_bytes=64 << 20, join=True):
     """Whole host image -> one device tensor (with 256 bytes of slack), moved
     in pinned chunks on a side stream while the next chunk is being copied by
-    the CPU.  Used when a file is kept resident in HBM."""
+    the CPU.  Used when a file is kept resident in HBM.  With ``join=False``
+    the caller's stream is not made to wait for the copy: returns ``(tensor,
+    event)`` and whoever uses the tensor waits for the event first
+    (`upload_in_background`)."""
     device = torch.device(device)
     n = len(image)
     dev = torch.empty(n + 256, dtype=torch.uint8, device=device)
@@ -170,6 +173,10 @@ def upload(image, device='cuda', chunk_bytes=64 << 20):
         if n:
             # (a copy: the mapping is read-only, which torch does not accept)
             dev[:n].copy_(torch.from_numpy(np.array(image[:n], dtype=np.uint8, copy=True)))
+        if not join:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(device))
+            return dev, ev
         return dev
     stream = torch.cuda.Stream(device=device)
     # `dev` may be a recycled block with work of its previous owner still
@@ -189,11 +196,38 @@ def upload(image, device='cuda', chunk_bytes=64 << 20):
             ev = torch.cuda.Event()
             ev.record(stream)
         events[b] = ev
-    torch.cuda.current_stream(device).wait_stream(stream)
+    if join:
+        torch.cuda.current_stream(device).wait_stream(stream)
     for ev in events:
         if ev is not None:
             ev.synchronize()
+    if not join:
+        done = torch.cuda.Event()
+        done.record(stream)
+        return dev, done
     return dev
+
+
+_prefetch_pool = None
+
+
+def upload_in_background(image, lo, hi, device=None):
+    """Start moving bytes [lo, hi) of a host image to HBM on a worker thread
+    (page cache -> pinned chunks -> hipMemcpyAsync on a side stream) and return
+    a future of ``(device tensor, event)``: the next block of a sequential
+    reader travels while the caller is still working on the current one --
+    the overlap `WindowPipeline` gives inside one large read, carried across
+    `read()` calls.  The consumer makes its stream wait for the event."""
+    global _prefetch_pool
+    if _prefetch_pool is None:
+        _prefetch_pool = ThreadPoolExecutor(1, thread_name_prefix='bb-prefetch')
+    index = torch.cuda.current_device() if device is None else torch.device(device).index
+
+    def job():
+        with torch.cuda.device(index):
+            return upload(image[lo:hi], device=torch.device('cuda', index), chunk_bytes=16 << 20,
+                          join=False)
+    return _prefetch_pool.submit(job)
 
 
 def download(dev, host, chunk_bytes=64 << 20):

@@ -133,3 +133,51 @@ def test_problems_surface_at_the_same_read_as_without_read_ahead(tmp_path, verif
     ev_ahead, d_ahead = loop(True)
     assert ev_exact and ev_exact == ev_ahead, (ev_exact, ev_ahead)
     assert bits_equal(d_exact, d_ahead)
+
+
+@pytest.mark.parametrize('fmt,name', [('guppi', 'guppi_cf_c64_ov0'), ('guppi', 'guppi_cf_c64_ov32'),
+                                      ('guppi', 'guppi_tf_c8_ov16'), ('dada', 'dada_p2_c4_cplx'),
+                                      ('dada', 'sample_meerkat_dada')])
+def test_block_formats_prefetch_the_next_frame(manifest, fmt, name):
+    """Loops of small reads on block formats: once a frame is staged whole, the
+    next one travels to HBM on the worker thread; the samples are those of the
+    one-shot read (pinned to the reference), also after seeks that leave a
+    prefetch unused."""
+    import baseband_amd
+    from baseband_amd import staging
+    mod = getattr(baseband_amd, fmt)
+    case = manifest[name]
+    calls = []
+    real = staging.upload_in_background
+
+    def counting(*a, **k):
+        calls.append(a[1:3])
+        return real(*a, **k)
+    staging.upload_in_background = counting
+    try:
+        with mod.open(golden_path(case['file']), 'rs', squeeze=False) as fh:
+            whole = fh.read().cpu().numpy()
+            n, spf = fh.shape[0], fh.samples_per_frame
+            chunk = max(1, spf // 5 + 1)
+            for start in (0, 3):
+                fh.seek(start)
+                pos = start
+                while pos < n:
+                    cnt = min(chunk, n - pos)
+                    # (a read that starts inside a later GUPPI block takes that block's own
+                    # overlap rows: compare with the same read done afresh)
+                    with mod.open(golden_path(case['file']), 'rs', squeeze=False) as ref:
+                        ref.seek(pos)
+                        want = ref.read(cnt).cpu().numpy()
+                    assert bits_equal(fh.read(cnt).cpu().numpy(), want), (name, pos, cnt)
+                    pos += cnt
+            if fh._nframes > 1:
+                assert calls, "no frame was prefetched"
+            # leave a prefetch behind and go elsewhere
+            fh.seek(0)
+            fh.read(chunk)
+            fh.read(chunk)
+            fh.seek(n - 2)
+            assert bits_equal(fh.read(2).cpu().numpy(), whole[n - 2:])
+    finally:
+        staging.upload_in_background = real

@@ -31,6 +31,27 @@ with guppi.open(path, 'rs') as fh:
         dt = time.perf_counter() - t
         print(json.dumps(dict(case='GUPPI sequential read(%d), 128 MiB blocks' % n,
                               us_per_read=round(dt / reps * 1e6, 1))), flush=True)
+    # the same loop with GPU work on every chunk (what a pipeline does between
+    # reads): with the next block prefetched in the background the staging of
+    # a block hides behind that work
+    work = torch.randn(4096, 4096, device='cuda')
+    for _ in range(3):
+        work @ work                             # (library start-up outside the timing)
+    torch.cuda.synchronize()
+    for prefetch in (False, True, False, True):
+        fh.prefetch_next = prefetch
+        fh.seek(0)
+        fh.read(n); fh.read(n); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            d = fh.read(n)
+            for _ in range(2):
+                work @ work                     # ~0.4 ms of matrix work per chunk
+            torch.cuda.synchronize()            # (a consumer that needs each result)
+        dt = time.perf_counter() - t
+        print(json.dumps(dict(case='GUPPI sequential read(%d) + GPU work per chunk' % n,
+                              prefetch_next_block=prefetch, us_per_iteration=round(dt / reps * 1e6, 1))), flush=True)
+    fh.prefetch_next = True
     rng = np.random.default_rng(1)
     where = rng.integers(0, fh.shape[0] - 2048, 200)
     fh.seek(int(where[0])); fh.read(1024); torch.cuda.synchronize()
