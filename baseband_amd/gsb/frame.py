@@ -11,13 +11,13 @@ class GSBFrame(FrameBase):
     _payload_class = GSBPayload
 
     @classmethod
-    def fromfile(cls, fh_ts, fh_raw, payload_nbytes=1 << 22, sample_shape=(1,),
-                 bps=4, complex_data=False, valid=True, verify=True):
-        header = GSBHeader.fromfile(fh_ts, verify=verify)
-        payload = GSBPayload.fromfile(fh_raw, payload_nbytes=payload_nbytes,
-                                      sample_shape=sample_shape, bps=bps,
-                                      complex_data=complex_data)
-        return cls(header, payload, valid=valid, verify=verify)
+    def fromfile(cls, fh_ts, fh_raw, payload_nbytes=1 << 22, sample_shape=(1,), bps=4,
+                 complex_data=False, valid=True, verify=True):
+        # one timestamp line, one block of every raw file
+        return cls(GSBHeader.fromfile(fh_ts, verify=verify),
+                   GSBPayload.fromfile(fh_raw, payload_nbytes=payload_nbytes, bps=bps,
+                                       sample_shape=sample_shape, complex_data=complex_data),
+                   valid=valid, verify=verify)
 
     @classmethod
     def fromdata(cls, data, header=None, *, bps=4, valid=True, verify=True, **kwargs):

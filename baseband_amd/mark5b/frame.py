@@ -14,21 +14,20 @@ class Mark5BFrame(FrameBase):
 
     def __init__(self, header, payload, valid=None, verify=True):
         if valid is None:
-            # usually valid, so look at the first few words first
-            w = payload.words
-            valid = bool(w[0] != self._fill_pattern
-                         or w[1] != self._fill_pattern
-                         or w[2] != self._fill_pattern
-                         or (w[3:] != self._fill_pattern).any())
+            # invalid = every payload word is the fill pattern; real data differ
+            # from it within a word or two, so a short look settles most frames
+            words = payload.words
+            head = words[:4]
+            valid = bool((head != self._fill_pattern).any()
+                         or (words[4:] != self._fill_pattern).any())
         super().__init__(header, payload, valid, verify)
 
     @classmethod
-    def fromfile(cls, fh, *, kday=None, ref_time=None, sample_shape=(1,),
-                 bps=2, valid=None, verify=True):
-        header = Mark5BHeader.fromfile(fh, kday=kday, ref_time=ref_time,
-                                       verify=verify)
-        payload = Mark5BPayload.fromfile(fh, sample_shape=sample_shape, bps=bps)
-        return cls(header, payload, valid, verify)
+    def fromfile(cls, fh, *, kday=None, ref_time=None, sample_shape=(1,), bps=2, valid=None,
+                 verify=True):
+        return cls(Mark5BHeader.fromfile(fh, kday=kday, ref_time=ref_time, verify=verify),
+                   Mark5BPayload.fromfile(fh, sample_shape=sample_shape, bps=bps),
+                   valid, verify)
 
     @classmethod
     def fromdata(cls, data, header=None, bps=2, valid=True, verify=True, **kwargs):
