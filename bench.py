@@ -210,7 +210,27 @@ def _git_commit():
         return None
 
 
-def live_traffic(gib, timeout=240):
+def _run_group(cmd, cwd, env, timeout):
+    """subprocess.run with the child in its own process group, which is killed
+    as a whole on timeout: a profiler that stops answering must not leave the
+    program it started on the GPU behind (this process is about to allocate
+    nearly all of HBM).  Returns an object with returncode / stdout / stderr."""
+    import signal
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        out, err = p.communicate()
+        raise RuntimeError("timed out after {} s: {}".format(timeout, ' '.join(cmd[:4])))
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
+def live_traffic(gib, timeout=150):
     """HBM bytes per launch of the decode kernel from the memory-side counters:
     two child runs of THIS script under ``rocprofv3 --pmc`` (FETCH_SIZE and
     WRITE_SIZE cannot share a pass; MI355X_MICROARCH.md, rocprofv3 PMC slots),
@@ -231,7 +251,7 @@ def live_traffic(gib, timeout=240):
             cmd = [exe, '--pmc', counter, '-d', d, '-o', 'c', '--output-format', 'csv', '--',
                    sys.executable, os.path.join(ROOT, 'bench.py'), '--pmc-child',
                    '--steps', '1', '--warmup', '1', '--gib', repr(gib)]
-            r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
+            r = _run_group(cmd, cwd='/tmp', env=env, timeout=timeout)
             files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not files:
                 raise RuntimeError("rocprofv3 --pmc {} failed (rc {}): {}".format(
