@@ -976,9 +976,12 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
     const dim3 gg((unsigned)gb);
     hipStream_t st = (hipStream_t)stream;
     const bool nt = g_tune_nt.load() != 0;
-    // float4 stores when a selected thread sample is a multiple of four floats
-    // and the output is 16-byte aligned
-    const bool v4 = (nwithin % 4 == 0) && !((uintptr_t)d_out & 15);
+    // float4 stores when every work item's output starts on a 16-byte boundary
+    // and is a multiple of four floats: whole frame sets and whole groups are
+    const uint64_t row_floats = (uint64_t)p->nslot * (uint64_t)nwithin;
+    const uint64_t group_rows = ((uint64_t)gt * (2048 / p->bps)) >> lchunk;
+    const bool v4 = ((R * row_floats) % 4 == 0) && ((group_rows * row_floats) % 4 == 0)
+                    && !((uintptr_t)d_out & 15);
 #define BB_GS(B, L) do { if (v4) { if (nt) hipLaunchKernelGGL((k_decode_gather_select<B, L, true, true>), gg, dim3(BB_BLOCK), lds, st, ga); \
                                    else    hipLaunchKernelGGL((k_decode_gather_select<B, L, false, true>), gg, dim3(BB_BLOCK), lds, st, ga); } \
                          else { if (nt) hipLaunchKernelGGL((k_decode_gather_select<B, L, true, false>), gg, dim3(BB_BLOCK), lds, st, ga); \

@@ -119,9 +119,9 @@ __device__ __forceinline__ void bb_gather_stage(const bb_gather_args &a, uint64_
 // base/base.py:706-717, 957-969): only positions within[0 .. nsel) of every
 // thread sample are written, so the output -- and its HBM traffic -- shrinks to
 // nsel / chunk of the full decode and no second pass over it is needed.  V4:
-// the selection is a multiple of four floats per thread sample, so a lane
-// writes a float4 that stays inside one thread slot; otherwise one float per
-// lane and step (a selected row has no 16-byte structure then).
+// every work item's share of the output starts on a 16-byte boundary and is a
+// multiple of four floats (the host checks), so lanes write float4 whatever
+// the selection is; otherwise one float per lane and step.
 template <int BPS, int LV, bool NT, bool V4>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_decode_gather_select(bb_gather_args a)
@@ -176,11 +176,29 @@ void k_decode_gather_select(bb_gather_args a)
             return v;
         };
         if (V4) {
+            // four consecutive floats of the (contiguous) output per lane; they
+            // may belong to different thread slots and rows: the position walks
+            // on with carries (k -> slot -> row), one index division per float4
+            if ((a.nsel & 3) == 0) {
+                // (a selection of whole float4s: the four floats share their slot and row)
+                for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
+                    const uint32_t row = bb_div_magic(q, rowlen, a.mag_row), rem = q - row * rowlen;
+                    const uint32_t s = bb_div_magic(rem, a.nsel, a.mag_sel), k = rem - s * a.nsel;
+                    bb_store4<NT>(obase + q, bb_f4{value(row, s, k), value(row, s, k + 1),
+                                                   value(row, s, k + 2), value(row, s, k + 3)});
+                }
+            } else
             for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
-                const uint32_t row = bb_div_magic(q, rowlen, a.mag_row), rem = q - row * rowlen;
-                const uint32_t s = bb_div_magic(rem, a.nsel, a.mag_sel), k = rem - s * a.nsel;
-                bb_store4<NT>(obase + q, bb_f4{value(row, s, k), value(row, s, k + 1),
-                                               value(row, s, k + 2), value(row, s, k + 3)});
+                uint32_t row = bb_div_magic(q, rowlen, a.mag_row);
+                const uint32_t rem = q - row * rowlen;
+                uint32_t s = bb_div_magic(rem, a.nsel, a.mag_sel), k = rem - s * a.nsel;
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r[j] = value(row, s, k);
+                    if (++k == a.nsel) { k = 0; if (++s == a.nslot) { s = 0; ++row; } }
+                }
+                bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
             }
         } else {
             for (uint32_t q = threadIdx.x; q < nfloat; q += BB_BLOCK) {
