@@ -30,6 +30,10 @@ Tm = 256 * 64
 blkm = Tm * npol * nchan * 2
 nfm = nbytes // blkm
 nb = nbytes // 4 * 4
+sel8 = torch.tensor([6, 7, 8, 9, 10, 11, 12, 13], dtype=torch.int32, device=dev)
+sel5 = torch.arange(8, dtype=torch.int32, device=dev)
+src5 = torch.arange(nbytes // 10016, device=dev, dtype=torch.int64) * 10016 + 16
+m4s = kernels.mark4_select_maps(m['sign_bit'], m['mag_bit'], 8, [0, 5, 7])
 runs = [
     lambda: kernels.decode_frames(buf, nfr, payload, 0, 2, src0=header, src_stride=stride, out=out),
     lambda: kernels.decode_frames(buf, nsets, payload, 0, 2, chunk=32, nslot=8, src=src8, complex_data=True, out=out),
@@ -40,6 +44,14 @@ runs = [
     lambda: kernels.decode_i8_tiled(buf, nfg, _lib.LAYOUT_GUPPI_TF, npol, nchan, T, 0, T, src0=0, src_stride=blk, out=out),
     lambda: kernels.decode_i8_tiled(buf, nfm, _lib.LAYOUT_MKBF, npol, nchan, Tm, 0, Tm, src0=0, src_stride=blkm, out=out),
     lambda: kernels.decode_frames(buf, 1, nb, _lib.CODER_INT, 8, src0=0, out=out),
+    # channel selections folded into the decode: 4 of 16 complex channels of 8
+    # threads, 8 of 16 Mark 5B channels, 3 of 8 Mark 4 channels
+    lambda: kernels.decode_frames(buf, nsets, payload, 0, 2, chunk=32, nslot=8, src=src8, complex_data=True,
+                                  out=out, within=sel8),
+    lambda: kernels.decode_frames(buf, nbytes // 10016, 10000, _lib.CODER_MARK5B, 2, chunk=16, src=src5,
+                                  out=out, within=sel5),
+    lambda: kernels.decode_mark4(buf, nf4, 64, 20000, m4s[0], m4s[1], fill_words=160, src0=0, src_stride=160000,
+                                 out=out, select=True),
 ]
 if os.environ.get('BB_PROF_OLD_I8'):
     kernels.tune(_lib.TUNE_XPOSE, 0)
