@@ -88,14 +88,25 @@ __device__ __forceinline__ bool bb_vdif_header_at(const uint8_t *buf, uint64_t n
 {
     const int nwords = (int)(p.header_nbytes >> 2);
     if (pos + p.header_nbytes > nbytes) return false;
-    // most selective word first (word 2: version, lg2_nchan, frame_length)
-    if (((bb_load_u32_any(buf, nbytes, pos + 8) ^ p.pattern[2]) & p.mask[2]) != 0) return false;
+    // all nine aligned dwords that hold the (possibly unaligned) header are
+    // requested before any of them is looked at: ONE memory latency per
+    // header.  (Testing word by word with early exits made every true frame
+    // of a search cost eight dependent loads, twice -- k_vdif_locate 2.7 ms
+    // for 8 GiB against 1.6 ms for the Mark 5B search.)
+    const uint64_t a = pos & ~3ull;
+    const uint32_t sh = (uint32_t)(pos & 3) * 8;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(buf + a);
+    uint32_t d[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        d[k] = (k <= nwords && a + 4 * (uint64_t)k + 4 <= nbytes) ? w[k] : 0u;
+    bool ok = true;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (k == 2 || k >= nwords || p.mask[k] == 0) continue;
-        if (((bb_load_u32_any(buf, nbytes, pos + 4 * k) ^ p.pattern[k]) & p.mask[k]) != 0) return false;
+        const uint32_t v = sh ? (d[k] >> sh) | (d[k + 1] << (32 - sh)) : d[k];
+        if (k < nwords) ok = ok && (((v ^ p.pattern[k]) & p.mask[k]) == 0);
     }
-    return true;
+    return ok;
 }
 
 // ---- byte-granular frame search -------------------------------------------
@@ -121,9 +132,10 @@ __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nby
                                                  Probe probe, Confirm confirm)
 {
     __shared__ int64_t s_found[BB_LOCATE_LOCAL];
-    __shared__ uint32_t s_n;
+    __shared__ uint64_t s_cand[BB_LOCATE_LOCAL];
+    __shared__ uint32_t s_n, s_nc;
     __shared__ unsigned long long s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) { s_n = 0; s_nc = 0; }
     __syncthreads();
     // byte positions q in [0, q_end) are probed; q_end + 4 <= nbytes
     const uint64_t nchunk = (q_end + 15) / 16;
@@ -158,18 +170,27 @@ __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nby
             hits &= hits - 1;
             const uint64_t q = 16 * j + (uint64_t)b;
             if (q >= q_end) continue;
-            const int64_t pos = confirm(q);
+            // candidates are parked: confirming one here would stall the whole
+            // wave on two scattered header fetches (a real frame's header and
+            // the one a frame later) while 63 lanes wait; after the sweep the
+            // workgroup confirms all of its candidates at once, one per thread,
+            // their fetches in flight together
+            const uint32_t c = atomicAdd(&s_nc, 1u);
+            if (c < BB_LOCATE_LOCAL) { s_cand[c] = q; continue; }
+            const int64_t pos = confirm(q);             // (list full: on the spot, to the global list)
             if (pos < 0) continue;
-            const uint32_t i = atomicAdd(&s_n, 1u);
-            if (i < BB_LOCATE_LOCAL) s_found[i] = pos;
-            else {                                      // local list full: straight to the global one
-                const unsigned long long g = atomicAdd(count, 1ull);
-                if (g < cap) out[g] = pos;
-            }
+            const unsigned long long g = atomicAdd(count, 1ull);
+            if (g < cap) out[g] = pos;
         }
     }
     __syncthreads();
-    const uint32_t n = s_n < BB_LOCATE_LOCAL ? s_n : BB_LOCATE_LOCAL;
+    const uint32_t nc = s_nc < BB_LOCATE_LOCAL ? s_nc : BB_LOCATE_LOCAL;
+    for (uint32_t i = threadIdx.x; i < nc; i += BB_BLOCK) {
+        const int64_t pos = confirm(s_cand[i]);
+        if (pos >= 0) s_found[atomicAdd(&s_n, 1u)] = pos;
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
     if (threadIdx.x == 0 && n) s_base = atomicAdd(count, (unsigned long long)n);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += BB_BLOCK)
@@ -190,16 +211,18 @@ void k_vdif_locate(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
     // word 2 of a frame that fits lies at q = pos + 8 <= nbytes - frame_nbytes + 8
     const uint64_t q_end = nbytes - p.frame_nbytes + 8 + 1;
     const uint32_t pat = p.pattern[2], msk = p.mask[2];
-    bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
-        [&](uint32_t v) { return ((v ^ pat) & msk) == 0; },
-        [&](uint64_t q) -> int64_t {
+    auto confirm = [&](uint64_t q) -> int64_t {
             if (q < 8) return -1;
             const uint64_t pos = q - 8;
-            if (pos + p.frame_nbytes > nbytes || !bb_vdif_header_at(buf, nbytes, p, pos)) return -1;
+            if (pos + p.frame_nbytes > nbytes) return -1;
             const uint64_t next = pos + p.frame_nbytes;
+            // (this header and the one a frame later are fetched together)
+            const bool here = bb_vdif_header_at(buf, nbytes, p, pos);
+            const bool there = next + p.header_nbytes <= nbytes && bb_vdif_header_at(buf, nbytes, p, next);
+            if (!here) return -1;
             bool ok;
             if (next + p.header_nbytes <= nbytes) {
-                ok = bb_vdif_header_at(buf, nbytes, p, next);
+                ok = there;
                 // the following header may be damaged in place (no bytes lost):
                 // then the one after it is still where the stride says
                 if (!ok && next + p.frame_nbytes + p.header_nbytes <= nbytes)
@@ -208,7 +231,12 @@ void k_vdif_locate(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
                 ok = pos < p.frame_nbytes || bb_vdif_header_at(buf, nbytes, p, pos - p.frame_nbytes);
             }
             return ok ? (int64_t)pos : -1;
-        });
+        };
+    // (one instantiation of the sweep only: a second one for streams whose
+    // word 2 is invariant in all 32 bits -- an equality probe -- doubled the
+    // kernel's LDS and ran 25 % slower, profiles/r02am_locate.txt)
+    bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
+                    [&](uint32_t v) { return ((v ^ pat) & msk) == 0; }, confirm);
 }
 
 // Header scan at explicit (possibly unaligned) frame offsets: same record as
