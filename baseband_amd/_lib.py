@@ -52,6 +52,8 @@ TUNE_XPOSE_ROWS = 20
 TUNE_BYTE_LUT = 21
 TUNE_M4_WIDEN = 22
 TUNE_SELECT_BYTES = 23
+TUNE_LUT_TILES = 24
+TUNE_LUT_SMALL = 25
 
 
 class BBError(RuntimeError):

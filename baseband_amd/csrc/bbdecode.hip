@@ -162,6 +162,8 @@ std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_lut_small{0};           // 1: the 4-tile instantiation of k_decode_flat_lut when items allow (experiment: slower)
+std::atomic<int> g_tune_lut_tpw{4};             // tiles per wave and work item of k_decode_flat_lut
 std::atomic<int> g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
 std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
 std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
@@ -215,8 +217,19 @@ void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_
 template <int BPS>
 void launch_flat_lut(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
-    if (nt) hipLaunchKernelGGL((k_decode_flat_lut<BPS, true, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
-    else    hipLaunchKernelGGL((k_decode_flat_lut<BPS, false, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    // (an instantiation sized for the default short items, 2 x 5 instead of
+    // 2 x 17 block registers per lane, is SLOWER -- more workgroups per CU, more
+    // write streams at a time: profiles/r02ap_exp_lut_small.log; kept behind
+    // BB_TUNE_LUT_SMALL.  BB_TUNE_LDS_PAD asks for unused LDS to bound the
+    // workgroups per CU from above, for the same experiment.)
+    const unsigned pad = (unsigned)g_tune_lds_pad.load();
+    if (a.tpw <= 4 && g_tune_lut_small.load() != 0) {
+        if (nt) hipLaunchKernelGGL((k_decode_flat_lut<BPS, true, 2, 4>), grid, dim3(2 * BB_WAVE), pad, st, a);
+        else    hipLaunchKernelGGL((k_decode_flat_lut<BPS, false, 2, 4>), grid, dim3(2 * BB_WAVE), pad, st, a);
+        return;
+    }
+    if (nt) hipLaunchKernelGGL((k_decode_flat_lut<BPS, true, 2, 16>), grid, dim3(2 * BB_WAVE), pad, st, a);
+    else    hipLaunchKernelGGL((k_decode_flat_lut<BPS, false, 2, 16>), grid, dim3(2 * BB_WAVE), pad, st, a);
 }
 
 template <int BPS, int LV>
@@ -401,6 +414,8 @@ int bb_tune(int knob, int value)
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         case BB_TUNE_BYTE_LUT: g_tune_byte_lut = value; return BB_OK;
         case BB_TUNE_M4_WIDEN: g_tune_m4_widen = value; return BB_OK;
+        case BB_TUNE_LUT_TILES: g_tune_lut_tpw = (value >= 1 && value <= 16) ? value : 4; return BB_OK;
+        case BB_TUNE_LUT_SMALL: g_tune_lut_small = value; return BB_OK;
         case BB_TUNE_SELECT_BYTES:
             if (value < 256 || value > 32768) return BB_EINVAL;
             g_tune_select_bytes = value; return BB_OK;
@@ -836,14 +851,23 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         const bool aln = wide && om == BB_OUT_FLAT && variant == 5;
         const int tpw8 = g_tune_tpw8.load();
         const bool long8 = aln && p->bps == 8 && tpw8 > 16;
-        const int tpw_max = long8 ? (tpw8 > 32 ? 32 : tpw8) : wide ? g_tune_tpw.load() : 8;
+        // the byte table kernel (1- and 2-bit contiguous output) is at its best
+        // with SHORT work items, one per workgroup: 2 waves x 4 tiles (2 KiB
+        // in, 32 KiB out) on an uncapped grid, +2-4 % over 2 x 8-12 tiles on
+        // 131072 persistent workgroups at every size from 2 to 8 GiB, for
+        // 8000-, 8192- and 10000-byte payloads (profiles/r02ao_exp_tpw_grid*.log)
+        // -- many small workgroups in flight again overlap loads and stores
+        // better than a register pipeline, as for the 8-bit kernels
+        const bool lut = aln && p->bps <= 2 && g_tune_byte_lut.load() != 0;
+        const int tpw_max = long8 ? (tpw8 > 32 ? 32 : tpw8) : lut ? g_tune_lut_tpw.load()
+                            : wide ? g_tune_tpw.load() : 8;
         const uint64_t seg_max = (uint64_t)nw * tpw_max;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
         a.tpw = (a.seg_tiles + nw - 1) / nw;
         uint64_t b2 = nfs * a.nseg;
         a.perm = make_perm(b2, out_bytes);
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : (uint64_t)(wide ? BB_GRID_CAP : 4096);
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : lut ? (1ull << 23) : (uint64_t)(wide ? BB_GRID_CAP : 4096);
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
         if (!wide) {
@@ -859,10 +883,11 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         } else if (long8) {
             if (p->coder == BB_CODER_INT) launch_flat_aln32<8, BB_LV_INT8>(nt, g2, st, a);
             else                          launch_flat_aln32<8, BB_LV_LDS>(nt, g2, st, a);
-        } else if (aln && p->bps <= 2 && g_tune_byte_lut.load() != 0) {
+        } else if (lut) {
             // byte table in LDS instead of the register level select (k_lut.h)
             if (p->bps == 1) launch_flat_lut<1>(nt, g2, st, a); else launch_flat_lut<2>(nt, g2, st, a);
-            BB_NOTE("k_decode_flat_lut<%d,%s,2,16> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", g2.x, a.tpw);
+            BB_NOTE("k_decode_flat_lut<%d,%s,2,%d> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain",
+                    (a.tpw <= 4 && g_tune_lut_small.load() != 0) ? 4 : 16, g2.x, a.tpw);
             BB_HIP(hipGetLastError());
             return BB_OK;
         } else if (aln) {
@@ -1147,7 +1172,9 @@ static int m4_decode(const void *d_buf, const int64_t *d_src, size_t nframes,
     const dim3 block(BB_BLOCK);
     if (!select) {
         const int tb = g_tune_blocks.load();
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;      // persistent grid
+        // (one work item per workgroup up to 2^23: +1 % over 131072 persistent
+        // workgroups at 8 GiB, equal at 2 GiB -- profiles/r02ao_exp_short_items.log)
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
         if (blocks > cap) blocks = cap;
         const dim3 grid((unsigned)blocks);
 #define BB_M4(N) do { if (nt) hipLaunchKernelGGL((k_decode_mark4<N, true>), grid, block, 0, st, a); \

@@ -481,3 +481,34 @@ def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
             assert bits_equal(out.cpu().numpy(), want.reshape(-1)), (pn, nfr, 'holes')
     finally:
         kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
+
+
+@pytest.mark.parametrize('tiles', [1, 2, 3, 4, 5, 8, 16])
+@pytest.mark.parametrize('coder,bps', [('vdif', 1), ('vdif', 2), ('mark5b', 1), ('mark5b', 2)])
+def test_byte_table_kernel_geometries(tiles, coder, bps):
+    """k_decode_flat_lut with 1 .. 16 tiles per wave and work item, persistent
+    (grid capped) and one item per workgroup: payloads that are and are not
+    multiples of the 256-byte block, misaligned headers, missing frames."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(tiles * 10 + bps)
+    kernels.tune(_lib.TUNE_LUT_TILES, tiles)
+    try:
+        for pn, header, nframes, cap in ((8000, 32, 37, 0), (10000, 16, 23, 8), (8192, 32, 19, 0), (264, 4, 300, 16),
+                                         (256, 0, 65, 0), (70000, 12, 3, 2)):
+            kernels.tune(_lib.TUNE_BLOCKS, cap)
+            stride = header + pn
+            raw = rng.integers(0, 256, nframes * stride + 64, dtype=np.uint8)
+            src = header + stride * np.arange(nframes, dtype=np.int64)
+            src[rng.choice(nframes, size=max(1, nframes // 9), replace=False)] = -1
+            out = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, CODERS[coder], bps,
+                                        src=torch.from_numpy(src).cuda(), fill_value=-7.5).cpu().numpy()
+            assert 'k_decode_flat_lut' in _lib.last_kernel()
+            per = pn * 8 // bps
+            exp = np.empty((nframes, per), np.float32)
+            for f in range(nframes):
+                exp[f] = -7.5 if src[f] < 0 else orc.decode_flat(raw[src[f]:src[f] + pn], coder, bps)
+            assert bits_equal(out, exp.reshape(-1)), (tiles, coder, bps, pn, header, cap, _lib.last_kernel())
+    finally:
+        kernels.tune(_lib.TUNE_LUT_TILES, 4)
+        kernels.tune(_lib.TUNE_BLOCKS, 0)
