@@ -652,7 +652,9 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     // 4-bit samples (11 % of the traffic is reads): the plain kernel is 3-6 %
     // ahead as well (profiles/r02t_exp_es.log, r02u_exp_es_elem.log: 5.72-5.82
     // against 5.43-5.55 TB/s at 4 and 34 GB of output)
-    if (variant == 5 && p->bps == 4 && om == BB_OUT_FLAT) variant = 0;
+    // -- against the register-select kernel; the byte table kernel with short
+    // work items (k_lut.h) takes 4-bit samples too and is ahead of both
+    if (variant == 5 && p->bps == 4 && om == BB_OUT_FLAT && g_tune_byte_lut.load() == 0) variant = 0;
     // Mid-size launches: with one or two work items per workgroup the
     // persistent pipelined kernel (5.1-5.3 TB/s) loses to the plain one
     // (5.4-5.5); from four items per workgroup on it is at least as fast on
@@ -851,15 +853,21 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         const bool aln = wide && om == BB_OUT_FLAT && variant == 5;
         const int tpw8 = g_tune_tpw8.load();
         const bool long8 = aln && p->bps == 8 && tpw8 > 16;
-        // the byte table kernel (1- and 2-bit contiguous output) is at its best
+        // the byte table kernel (1-, 2- and 4-bit contiguous output) is at its best
         // with SHORT work items, one per workgroup: 2 waves x 4 tiles (2 KiB
         // in, 32 KiB out) on an uncapped grid, +2-4 % over 2 x 8-12 tiles on
         // 131072 persistent workgroups at every size from 2 to 8 GiB, for
         // 8000-, 8192- and 10000-byte payloads (profiles/r02ao_exp_tpw_grid*.log)
         // -- many small workgroups in flight again overlap loads and stores
         // better than a register pipeline, as for the 8-bit kernels
-        const bool lut = aln && p->bps <= 2 && g_tune_byte_lut.load() != 0;
-        const int tpw_max = long8 ? (tpw8 > 32 ? 32 : tpw8) : lut ? g_tune_lut_tpw.load()
+        const bool lut = aln && p->bps <= 4 && g_tune_byte_lut.load() != 0;
+        // (what counts is the OUTPUT of a work item, 32 KiB: 2 / 4 / 8 tiles per
+        // wave for 1- / 2- / 4-bit samples -- 1-bit 6.58 -> 6.86 TB/s against 4
+        // tiles, 4-bit 5.28 -> 6.62 and +7 % over the plain kernel it used before,
+        // profiles/r02ar_exp_1bit_items.log, r02ar_exp_4bit_lut.log)
+        int lut_tiles = g_tune_lut_tpw.load() * p->bps / 2;
+        lut_tiles = lut_tiles < 1 ? 1 : lut_tiles > 16 ? 16 : lut_tiles;
+        const int tpw_max = long8 ? (tpw8 > 32 ? 32 : tpw8) : lut ? lut_tiles
                             : wide ? g_tune_tpw.load() : 8;
         const uint64_t seg_max = (uint64_t)nw * tpw_max;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
@@ -885,7 +893,9 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             else                          launch_flat_aln32<8, BB_LV_LDS>(nt, g2, st, a);
         } else if (lut) {
             // byte table in LDS instead of the register level select (k_lut.h)
-            if (p->bps == 1) launch_flat_lut<1>(nt, g2, st, a); else launch_flat_lut<2>(nt, g2, st, a);
+            if (p->bps == 1) launch_flat_lut<1>(nt, g2, st, a);
+            else if (p->bps == 2) launch_flat_lut<2>(nt, g2, st, a);
+            else launch_flat_lut<4>(nt, g2, st, a);
             BB_NOTE("k_decode_flat_lut<%d,%s,2,%d> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain",
                     (a.tpw <= 4 && g_tune_lut_small.load() != 0) ? 4 : 16, g2.x, a.tpw);
             BB_HIP(hipGetLastError());

@@ -1,4 +1,4 @@
-// Flat decode of 1- and 2-bit samples through a BYTE table in LDS.
+// Flat decode of 1-, 2- and 4-bit samples through a BYTE table in LDS.
 //
 // Replaces the same reference expressions as k_decode_flat_aln -- and in the
 // same way the reference does it: lut.take(bytes) with a 256-row table of the
@@ -25,18 +25,26 @@ template <int BPS, bool NT, int NW, int TPW>
 __global__ __launch_bounds__(NW * BB_WAVE)
 void k_decode_flat_lut(bb_flat_args a)
 {
-    static_assert(BPS == 1 || BPS == 2, "byte table kernel: 1- or 2-bit samples");
+    static_assert(BPS == 1 || BPS == 2 || BPS == 4, "byte table kernel: 1-, 2- or 4-bit samples");
     constexpr int EPT = 2048 / BPS;             // elements per 256-byte tile
     constexpr int PASSES = 8 / BPS;             // 1 KiB store passes per tile
-    constexpr int FPB = 2 / BPS;                // float4 per input byte: 1 (2-bit), 2 (1-bit)
+    constexpr int FPB = BPS == 1 ? 2 : 1;       // float4 per input byte: 1 (2-bit), 2 (1-bit); 4-bit: below
     constexpr uint32_t CMASK = (1u << BPS) - 1;
-    // s_lut[byte * FPB + h] = the h-th float4 of that byte
-    __shared__ bb_f4 s_lut[256 * FPB];
-    for (int i = threadIdx.x; i < 256 * FPB; i += NW * BB_WAVE) {
-        const uint32_t b = (uint32_t)i / FPB, h = (uint32_t)i % FPB;
-        const uint32_t q = b >> (4 * BPS * h);          // the four codes of this float4
-        s_lut[i] = bb_f4{a.tab[q & CMASK], a.tab[(q >> BPS) & CMASK],
-                         a.tab[(q >> (2 * BPS)) & CMASK], a.tab[(q >> (3 * BPS)) & CMASK]};
+    // 1-/2-bit: s_lut[byte * FPB + h] = the h-th float4 of that byte.
+    // 4-bit: a byte holds two samples -- s_lut2[byte] = (low nibble, high nibble),
+    // and a lane's float4 is two bytes, two 8-byte table reads.
+    __shared__ bb_f4 s_lut[BPS == 4 ? 1 : 256 * FPB];
+    __shared__ float2 s_lut2[BPS == 4 ? 256 : 1];
+    if (BPS == 4) {
+        for (int i = threadIdx.x; i < 256; i += NW * BB_WAVE)
+            s_lut2[i] = float2{a.tab[i & 15], a.tab[i >> 4]};
+    } else {
+        for (int i = threadIdx.x; i < 256 * FPB; i += NW * BB_WAVE) {
+            const uint32_t b = (uint32_t)i / FPB, h = (uint32_t)i % FPB;
+            const uint32_t q = b >> (4 * BPS * h);          // the four codes of this float4
+            s_lut[i] = bb_f4{a.tab[q & CMASK], a.tab[(q >> BPS) & CMASK],
+                             a.tab[(q >> (2 * BPS)) & CMASK], a.tab[(q >> (3 * BPS)) & CMASK]};
+        }
     }
     __syncthreads();
     const int lane = bb_lane();
@@ -46,10 +54,12 @@ void k_decode_flat_lut(bb_flat_args a)
     const bb_f4 fillv = a.complex_data
         ? bb_f4{a.fill_re, a.fill_im, a.fill_re, a.fill_im}
         : bb_f4{a.fill_re, a.fill_re, a.fill_re, a.fill_re};
-    // pass p: lane l writes float4 number 64 p + l of the tile; its codes sit
-    // in byte (64 p + l) / FPB of the tile = dword (16 p / FPB + (l / FPB) / 4)
-    const int src_lane0 = (lane / FPB) >> 2;
-    const uint32_t bshift = (uint32_t)((lane / FPB) & 3) * 8;      // byte of that dword
+    // pass p: lane l writes float4 number 64 p + l of the tile; its 4 BPS code
+    // bits start at bit 4 BPS (64 p + l) of the tile: dword 8 BPS p + l BPS / 8,
+    // byte (1-/2-bit) or halfword (4-bit) of that dword below
+    const int src_lane0 = (lane * BPS) >> 3;
+    const uint32_t bshift = BPS == 4 ? (uint32_t)(lane & 1) * 16
+                                     : (uint32_t)((lane / FPB) & 3) * 8;
     const uint32_t hsel = (uint32_t)(lane % FPB);                   // which float4 of the byte (1-bit)
 
     uint32_t cur[TPW + 1], nxt[TPW + 1];
@@ -86,14 +96,20 @@ void k_decode_flat_lut(bb_flat_args a)
         constexpr bool CHECK = decltype(check_tag)::value;
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const uint32_t idx = (uint32_t)(p * 16 / FPB + src_lane0) + (ALIGNED ? 0u : s);
+            const uint32_t idx = (uint32_t)(p * 8 * BPS + src_lane0) + (ALIGNED ? 0u : s);
             uint32_t word = (uint32_t)__shfl((int)w0, (int)(idx & 63));
             if (!ALIGNED) {
                 const uint32_t hi = (uint32_t)__shfl((int)w1, (int)(idx & 63));
                 word = idx >= 64 ? hi : word;
             }
-            const uint32_t byte = (word >> bshift) & 0xffu;
-            const bb_f4 v = s_lut[byte * FPB + hsel];
+            bb_f4 v;
+            if (BPS == 4) {
+                const uint32_t hw = word >> bshift;
+                const float2 lo = s_lut2[hw & 0xffu], hi = s_lut2[(hw >> 8) & 0xffu];
+                v = bb_f4{lo.x, lo.y, hi.x, hi.y};
+            } else {
+                v = s_lut[((word >> bshift) & 0xffu) * FPB + hsel];
+            }
             if (CHECK && e_tile + 256 * p + 4 * lane >= e_end) continue;
             bb_store4<NT>(otile + 256 * p + 4 * lane, v);
         }

@@ -472,10 +472,10 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */
 #define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
 #define BB_TUNE_LUT_SMALL 25          /* 1: k_decode_flat_lut instantiated for at most 4 tiles per wave when the work items are that short (experiment: slower); 0 (default): the 16-tile instantiation */
-#define BB_TUNE_LUT_TILES 24          /* upper bound of 256-byte tiles per wave and work item in k_decode_flat_lut (1..16, default 4; its grid is one work item per workgroup up to 2^23 unless BB_TUNE_BLOCKS says otherwise) */
+#define BB_TUNE_LUT_TILES 24          /* upper bound of 256-byte tiles per wave and work item in k_decode_flat_lut for 2-bit samples (1..16, default 4; half as many for 1-bit, twice as many for 4-bit samples: 32 KiB of output per work item; its grid is one work item per workgroup up to 2^23 unless BB_TUNE_BLOCKS says otherwise) */
 #define BB_TUNE_SELECT_BYTES 23       /* payload bytes (all thread slots together) that k_decode_gather_select stages in LDS per work item (256..32768, default 16384) */
 #define BB_TUNE_M4_WIDEN 22           /* 1 (default): 16- and 32-track Mark 4 units whose word count and fill prefix allow it are decoded as 64-bit super-words (4 / 2 stream words per lane and load) by the 64-track kernels; 0: always the native word size */
-#define BB_TUNE_BYTE_LUT 21           /* 1 (default): contiguous 1- and 2-bit decode through the byte table kernel k_decode_flat_lut; 0: k_decode_flat_aln (register level select) */
+#define BB_TUNE_BYTE_LUT 21           /* 1 (default): contiguous 1-, 2- and 4-bit decode through the byte table kernel k_decode_flat_lut; 0: k_decode_flat_aln (register level select; the plain kernel for 4-bit) */
 #define BB_TUNE_XPOSE_ROWS 20         /* k_decode_i8_xpose: output rows per tile, 128 (default) or 64 */
 #define BB_TUNE_XPOSE 19              /* 1 (default): int8 transposes with 16-byte aligned input runs go through k_decode_i8_xpose; 0: k_decode_i8_tiled / _stage always */
 #define BB_TUNE_WORK_STRIPES 18       /* work order of the decode launches: log2 of the number of stripes a launch's work items are dealt over (0 = file order; default -1 = 16 stripes for outputs of 16 GiB and more, 4 below) */

@@ -484,7 +484,7 @@ def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
 
 
 @pytest.mark.parametrize('tiles', [1, 2, 3, 4, 5, 8, 16])
-@pytest.mark.parametrize('coder,bps', [('vdif', 1), ('vdif', 2), ('mark5b', 1), ('mark5b', 2)])
+@pytest.mark.parametrize('coder,bps', [('vdif', 1), ('vdif', 2), ('mark5b', 1), ('mark5b', 2), ('vdif', 4), ('int', 4)])
 def test_byte_table_kernel_geometries(tiles, coder, bps):
     """k_decode_flat_lut with 1 .. 16 tiles per wave and work item, persistent
     (grid capped) and one item per workgroup: payloads that are and are not
