@@ -54,6 +54,7 @@ TUNE_M4_WIDEN = 22
 TUNE_SELECT_BYTES = 23
 TUNE_LUT_TILES = 24
 TUNE_LUT_SMALL = 25
+TUNE_M4_TILES = 26
 
 
 class BBError(RuntimeError):

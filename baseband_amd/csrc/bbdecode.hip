@@ -165,6 +165,7 @@ std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects 
 std::atomic<int> g_tune_lut_small{0};           // 1: the 4-tile instantiation of k_decode_flat_lut when items allow (experiment: slower)
 std::atomic<int> g_tune_lut_tpw{4};             // tiles per wave and work item of k_decode_flat_lut
 std::atomic<int> g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
+std::atomic<int> g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
 std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
 std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
 std::atomic<int> g_tune_xpose_rows{128}; // k_decode_i8_xpose: output rows per tile (128 or 64)
@@ -414,6 +415,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
         case BB_TUNE_BYTE_LUT: g_tune_byte_lut = value; return BB_OK;
         case BB_TUNE_M4_WIDEN: g_tune_m4_widen = value; return BB_OK;
+        case BB_TUNE_M4_TILES: g_tune_m4_tiles = (value >= 1 && value <= BB_M4_TPW) ? value : BB_M4_TPW; return BB_OK;
         case BB_TUNE_LUT_TILES: g_tune_lut_tpw = (value >= 1 && value <= 16) ? value : 4; return BB_OK;
         case BB_TUNE_LUT_SMALL: g_tune_lut_small = value; return BB_OK;
         case BB_TUNE_SELECT_BYTES:
@@ -1164,7 +1166,8 @@ static int m4_decode(const void *d_buf, const int64_t *d_src, size_t nframes,
     a.nwords = p->nwords;
     a.fill_words = p->fill_words;
     const uint64_t ntiles = (p->nwords + 63) / 64;
-    a.nseg = (ntiles + BB_M4_SEG_TILES - 1) / BB_M4_SEG_TILES;
+    const uint64_t m4_seg = (uint64_t)BB_WAVES_PER_BLOCK * (uint64_t)g_tune_m4_tiles.load();
+    a.nseg = (ntiles + m4_seg - 1) / m4_seg;
     a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
     a.tpw = (a.seg_tiles + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
     a.src0 = p->src0;

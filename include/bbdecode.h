@@ -471,6 +471,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* the same bound for 8-bit data in the aligned flat kernel (1..32; above 16 selects the 32-tile instantiation) */
 #define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */
 #define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
+#define BB_TUNE_M4_TILES 26           /* 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8, default 8: 4 waves x 8 tiles = 256 KiB of output per work item for 64 tracks) */
 #define BB_TUNE_LUT_SMALL 25          /* 1: k_decode_flat_lut instantiated for at most 4 tiles per wave when the work items are that short (experiment: slower); 0 (default): the 16-tile instantiation */
 #define BB_TUNE_LUT_TILES 24          /* upper bound of 256-byte tiles per wave and work item in k_decode_flat_lut for 2-bit samples (1..16, default 4; half as many for 1-bit, twice as many for 4-bit samples: 32 KiB of output per work item; its grid is one work item per workgroup up to 2^23 unless BB_TUNE_BLOCKS says otherwise) */
 #define BB_TUNE_SELECT_BYTES 23       /* payload bytes (all thread slots together) that k_decode_gather_select stages in LDS per work item (256..32768, default 16384) */
