@@ -56,10 +56,9 @@ class Mark5BFileReader(VLBIFileReaderBase):
         if self.nchan is None:
             raise TypeError("In order to read frames, the file handle should "
                             "be initialized with nchan set.")
-        return Mark5BFrame.fromfile(self.fh_raw, kday=self.kday,
-                                    ref_time=self.ref_time,
-                                    sample_shape=(self.nchan,), bps=self.bps,
-                                    verify=verify)
+        frame = Mark5BFrame.fromfile(self.fh_raw, kday=self.kday, ref_time=self.ref_time,
+                                     sample_shape=(self.nchan,), bps=self.bps, verify=verify)
+        return self._lend_device_words(frame)
 
     def locate_frames(self, pattern=None, **kwargs):
         """As `VLBIFileReaderBase.locate_frames`, with the Mark 5B sync word and

@@ -43,7 +43,7 @@ class VDIFFileReader(VLBIFileReaderBase):
         return VDIFHeader.fromfile(self.fh_raw, edv=edv, verify=verify)
 
     def read_frame(self, edv=None, verify=True):
-        return VDIFFrame.fromfile(self.fh_raw, edv=edv, verify=verify)
+        return self._lend_device_words(VDIFFrame.fromfile(self.fh_raw, edv=edv, verify=verify))
 
     def read_frameset(self, thread_ids=None, edv=None, verify=True):
         return VDIFFrameSet.fromfile(self.fh_raw, thread_ids, edv=edv,

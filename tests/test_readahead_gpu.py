@@ -181,3 +181,44 @@ def test_block_formats_prefetch_the_next_frame(manifest, fmt, name):
             assert bits_equal(fh.read(2).cpu().numpy(), whole[n - 2:])
     finally:
         staging.upload_in_background = real
+
+
+@pytest.mark.parametrize('name', ['sample_vdif', 'vdif_cfg2_small', 'vdif_cfg3_small', 'm5b_c16_b2'])
+def test_frame_loops_decode_from_a_window_in_hbm(manifest, name):
+    """read_frame().data in a loop ('rb'): from the third frame on the payload
+    decodes from a window of the file kept in HBM (`FileBase._lend_device_words`);
+    every frame equals the frame read on its own."""
+    from baseband_amd import vdif, mark5b
+    case = manifest[name]
+    path = golden_path(case['file'])
+    if name.startswith('m5b'):
+        opener = lambda: mark5b.open(path, 'rb', nchan=case['nchan'], bps=case['bps'], kday=56000)   # noqa: E731
+    else:
+        opener = lambda: vdif.open(path, 'rb')       # noqa: E731
+    with opener() as fh:
+        fh.seek(0, 2)
+        size = fh.tell()
+        fh.seek(0)
+        lent, k = 0, 0
+        while fh.tell() < size and k < 200:
+            pos = fh.tell()
+            frame = fh.read_frame()
+            lent += frame.payload._dwords is not None
+            got = frame.data.cpu().numpy()
+            with opener() as ref:                   # the same frame, read alone
+                ref.seek(pos)
+                alone = ref.read_frame()
+                assert alone.payload._dwords is None
+                assert bits_equal(got, alone.data.cpu().numpy()), (name, k)
+            k += 1
+        assert k < 4 or lent >= k - 3
+        # a seek breaks the sequence: the next frames are on their own again
+        fh.seek(0)
+        assert fh.read_frame().payload._dwords is None
+        assert fh.read_frame().payload._dwords is None
+        frame = fh.read_frame()
+        if frame.payload._dwords is not None:
+            # (bytes read from a file are read-only, here as in the reference:
+            # the borrowed device bytes cannot go stale)
+            with pytest.raises(ValueError):
+                frame.payload[0] = frame.payload[1]
