@@ -69,7 +69,7 @@ class FileBase:
         -- without a host-to-device copy for every single payload.  The host
         words stay what they are; writing to them drops the device view
         (`PayloadBase._device_words`)."""
-        payload = getattr(frame, 'payload', None)
+        payload = getattr(frame, 'payload', frame)         # (a frame, or a payload read on its own)
         try:
             end = self.fh_raw.tell()
             nbytes = payload.nbytes
@@ -82,7 +82,9 @@ class FileBase:
             self._frame_run, self._frame_dev, self._frame_dev_bytes = 0, None, 1 << 20
             return frame
         self._frame_run += 1
-        if self._frame_run < 2 or start % 4 or getattr(payload, '_dwords', None) is not None:
+        if (self._frame_run < 2 or start % 4 or nbytes > (16 << 20)
+                or getattr(payload, '_dwords', None) is not None):
+            # (large block payloads stage just the rows they are asked for)
             return frame
         if self._frame_dev is None and not torch.cuda.is_available():
             self._frame_end = None              # (no GPU: `.data` will say so itself)

@@ -144,7 +144,13 @@ class PayloadBase:
         words = cls._read_words(fh, payload_nbytes,
                                 cls._dtype_word if dtype is None else dtype,
                                 cls._memmap if memmap is None else memmap)
-        return cls(words, **kwargs)
+        self = cls(words, **kwargs)
+        # a file reader of this package lends payloads read one after the other
+        # their bytes from a window of the file kept in HBM (FileBase._lend_device_words)
+        lend = getattr(fh, '_lend_device_words', None)
+        if lend is not None:
+            lend(self)
+        return self
 
     @classmethod
     def fromdata(cls, data, header=None, bps=2, **kwargs):
