@@ -82,7 +82,7 @@ class FileBase:
             self._frame_run, self._frame_dev, self._frame_dev_bytes = 0, None, 1 << 20
             return frame
         self._frame_run += 1
-        if (self._frame_run < 2 or start % 4 or nbytes > (16 << 20)
+        if (self._frame_run < 2 or start % 8 or nbytes > (16 << 20)
                 or getattr(payload, '_dwords', None) is not None):
             # (large block payloads stage just the rows they are asked for)
             return frame
@@ -98,7 +98,7 @@ class FileBase:
             from ..staging import upload
             resident = getattr(image, 'device_tensor', None)
             if resident is not None:            # the file IS in HBM (open(<device tensor>, 'rb'))
-                if resident.data_ptr() % 4:
+                if resident.data_ptr() % 8:
                     return frame
                 win = self._frame_dev = (0, len(image), resident)
             else:

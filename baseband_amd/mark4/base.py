@@ -52,9 +52,9 @@ class Mark4FileReader(VLBIFileReaderBase):
                                     decade=self.decade, ref_time=self.ref_time)
 
     def read_frame(self, verify=True):
-        return Mark4Frame.fromfile(self.fh_raw, self.ntrack,
-                                   decade=self.decade, ref_time=self.ref_time,
-                                   verify=verify)
+        frame = Mark4Frame.fromfile(self.fh_raw, self.ntrack, decade=self.decade,
+                                    ref_time=self.ref_time, verify=verify)
+        return self._lend_device_words(frame)
 
     def _sync_at(self, image, o, ntrack):
         """Sync pattern at frame offset o: stream word 63 zero, words 64-95

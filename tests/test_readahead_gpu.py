@@ -183,15 +183,17 @@ def test_block_formats_prefetch_the_next_frame(manifest, fmt, name):
         staging.upload_in_background = real
 
 
-@pytest.mark.parametrize('name', ['sample_vdif', 'vdif_cfg2_small', 'vdif_cfg3_small', 'm5b_c16_b2'])
+@pytest.mark.parametrize('name', ['sample_vdif', 'vdif_cfg2_small', 'vdif_cfg3_small', 'm5b_c16_b2', 'm4_t64_f4', 'm4_t16_f4'])
 def test_frame_loops_decode_from_a_window_in_hbm(manifest, name):
     """read_frame().data in a loop ('rb'): from the third frame on the payload
     decodes from a window of the file kept in HBM (`FileBase._lend_device_words`);
     every frame equals the frame read on its own."""
-    from baseband_amd import vdif, mark5b
+    from baseband_amd import vdif, mark5b, mark4
     case = manifest[name]
     path = golden_path(case['file'])
-    if name.startswith('m5b'):
+    if name.startswith('m4'):
+        opener = lambda: mark4.open(path, 'rb', ntrack=case['ntrack'], decade=2010)     # noqa: E731
+    elif name.startswith('m5b'):
         opener = lambda: mark5b.open(path, 'rb', nchan=case['nchan'], bps=case['bps'], kday=56000)   # noqa: E731
     else:
         opener = lambda: vdif.open(path, 'rb')       # noqa: E731
