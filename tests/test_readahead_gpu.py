@@ -224,3 +224,24 @@ def test_frame_loops_decode_from_a_window_in_hbm(manifest, name):
             # the borrowed device bytes cannot go stale)
             with pytest.raises(ValueError):
                 frame.payload[0] = frame.payload[1]
+
+
+@pytest.mark.parametrize('name,subset', [('sample_vdif', ([1, 3],)), ('vdif_cfg3_small', (slice(None), [3, 9])),
+                                         ('vdif_cfg3_small', ([6, 1], slice(2, 7))), ('m5b_c16_b2', ([1, 6, 7],)),
+                                         ('m4_t64_f4', ([5, 0],)), ('sample_gsb_phased', (slice(None), slice(10, 20)))])
+def test_sequential_small_reads_with_subsets(manifest, name, subset):
+    """The decoded window holds what read() returns -- after squeeze and subset
+    (thread subsets through the index, channel subsets folded into the decode)."""
+    exp = load_expected(name)
+    with _open(name, manifest, subset=subset) as fh:
+        want = exp.reshape((exp.shape[0],) + tuple(s for s in exp.shape[1:] if s > 1))[(slice(None),) + subset]
+        assert fh.shape == want.shape
+        n, spf = fh.shape[0], fh.samples_per_frame
+        chunk = max(1, spf // 2 + 3)
+        pos, used = 0, 0
+        while pos < n and pos < 60 * chunk:
+            cnt = min(chunk, n - pos)
+            assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(want[pos:pos + cnt])), (name, pos)
+            pos += cnt
+            used += fh._decoded is not None
+        assert used > 0 or n <= 3 * chunk
