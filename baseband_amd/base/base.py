@@ -359,7 +359,7 @@ class GPUStreamReaderBase:
 
     def close(self):
         self._closed = True
-        self._ahead = self._decoded = None
+        self._drop_windows()
         self._staged = self._sink = None
         self._have = []
         if self._pipeline is not None:
@@ -903,6 +903,11 @@ class GPUStreamReaderBase:
                 self._ahead_bytes = min(self.window_bytes, 4 * self._ahead_bytes)
             else:
                 self._ahead_bytes = self._ahead_bytes0
+            # (staging the NEXT window on a worker thread meanwhile, as the block
+            # formats do for whole blocks, was tried here and lost: a loop of
+            # read(3200000) on a 2 GiB file 38-44 -> 64-72 us per call, the
+            # worker and the loop fight over the same host cores and link --
+            # profiles/r02aw_bench_small_reads_prefetch.jsonl)
             per_win = max(last - first + look, self._ahead_bytes // set_nbytes)
             end = min(total, first + per_win)
             lo = self._file_offset0 + first * set_nbytes
@@ -913,6 +918,10 @@ class GPUStreamReaderBase:
         a = (first - s0) * set_nbytes
         b = max(a, (min(need_end, s1) - s0) * set_nbytes)
         self._process_window(self._device_window(dev, a, b), first, last, flat)
+
+    def _drop_windows(self):
+        """Forget the read-ahead windows."""
+        self._ahead = self._decoded = None
 
     _nbad = None        # device counter the verification kernel adds to
     _nmissing = 0       # frames a window should have held but the file did not

@@ -150,7 +150,7 @@ class GSBStreamReader(GPUStreamReaderBase):
 
     def close(self):
         self._closed = True
-        self._ahead = None
+        self._drop_windows()
         if self._pipeline is not None:
             self._pipeline.release()
             self._pipeline = None

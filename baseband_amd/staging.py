@@ -225,8 +225,7 @@ def upload_in_background(image, lo, hi, device=None):
 
     def job():
         with torch.cuda.device(index):
-            return upload(image[lo:hi], device=torch.device('cuda', index), chunk_bytes=16 << 20,
-                          join=False)
+            return upload(image[lo:hi], device=torch.device('cuda', index), join=False)
     return _prefetch_pool.submit(job)
 
 

@@ -245,3 +245,4 @@ def test_sequential_small_reads_with_subsets(manifest, name, subset):
             pos += cnt
             used += fh._decoded is not None
         assert used > 0 or n <= 3 * chunk
+

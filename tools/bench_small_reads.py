@@ -24,7 +24,7 @@ for chunk in (32000, 320000, 3200000):
         with vdif.open(path, 'rs', sample_rate=32e6, verify=verify) as fh:
             fh.read(chunk)
             torch.cuda.synchronize()
-            n = min(2000, fh.shape[0] // chunk - 1)
+            n = min(int(os.environ.get('BB_READS', 2000)), fh.shape[0] // chunk - 1)
             t0 = time.perf_counter()
             for _ in range(n):
                 x = fh.read(chunk)
