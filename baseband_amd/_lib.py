@@ -164,6 +164,9 @@ SIGNATURES = [
     ('bb_encode_flat', C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     ('bb_encode_mark4', C.c_int, [_vp, _sz, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _vp, _sz, _vp]),
     ('bb_tune', C.c_int, [C.c_int, C.c_int]),
+    ('bb_host_register', C.c_int, [_vp, _sz]),
+    ('bb_host_unregister', C.c_int, [_vp]),
+    ('bb_copy_to_device', C.c_int, [_vp, _vp, _sz, _vp]),
 ]
 
 for _name, _res, _args in SIGNATURES:

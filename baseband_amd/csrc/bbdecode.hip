@@ -438,6 +438,32 @@ int bb_debug_trace(uint64_t *d_times)
     return BB_OK;
 }
 
+// ---- host staging helpers -----------------------------------------------------
+// A file image that is mapped into the host's address space can be pinned where
+// it lies and handed to the DMA engine, instead of being copied into a pinned
+// buffer by host threads first (staging.py).
+int bb_host_register(const void *h_ptr, size_t nbytes)
+{
+    if (!h_ptr || nbytes == 0) return BB_EINVAL;
+    BB_HIP(hipHostRegister(const_cast<void *>(h_ptr), nbytes, hipHostRegisterDefault));
+    return BB_OK;
+}
+
+int bb_host_unregister(const void *h_ptr)
+{
+    if (!h_ptr) return BB_EINVAL;
+    BB_HIP(hipHostUnregister(const_cast<void *>(h_ptr)));
+    return BB_OK;
+}
+
+int bb_copy_to_device(void *d_dst, const void *h_src, size_t nbytes, void *stream)
+{
+    if (nbytes == 0) return BB_OK;
+    if (!d_dst || !h_src) return BB_EINVAL;
+    BB_HIP(hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return BB_OK;
+}
+
 int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
                  bb_frame_rec *d_recs, size_t nframes, void *stream)
 {

@@ -494,6 +494,20 @@ int bb_tune(int knob, int value);
  * production use: one extra 8-byte store per 32-64 KiB of output. */
 int bb_debug_trace(uint64_t *d_times);
 
+/* ---- host staging helpers (measurement only) -------------------------------
+ * bb_host_register pins a range of host memory where it lies -- e.g. a window
+ * of a read-only file mapping whose pages are in the page cache -- so that
+ * bb_copy_to_device (hipMemcpyAsync on `stream`) moves it without a host-side
+ * copy into a pinned buffer first; bb_host_unregister releases it after the
+ * copy has completed.  Used by tools/exp_hostregister.py: 56-57 GB/s from a
+ * populated mapping, but pinning and unpinning the pages of a freshly mapped
+ * file costs more host time than the staging copy it would replace
+ * (profiles/r02ax_exp_hostregister.log), so the readers keep the pinned
+ * double-buffer pipeline (baseband_amd/staging.py). */
+int bb_host_register(const void *h_ptr, size_t nbytes);
+int bb_host_unregister(const void *h_ptr);
+int bb_copy_to_device(void *d_dst, const void *h_src, size_t nbytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
