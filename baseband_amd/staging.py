@@ -37,7 +37,7 @@ def host_image(fh):
     return np.frombuffer(data, dtype=np.uint8)
 
 
-_COPY_THREADS = max(1, min(8, (os.cpu_count() or 2) // 2))
+_COPY_THREADS = int(os.environ.get('BB_COPY_THREADS', 0)) or max(1, min(8, (os.cpu_count() or 2) // 2))
 _copy_pool = None
 
 
