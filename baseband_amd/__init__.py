@@ -33,3 +33,15 @@ def asnumpy(data, out=None):
 
 
 __all__ += ['asnumpy']
+
+
+def empty_output(shape, dtype=None, candidates=3, device='cuda', report=None):
+    """Uninitialised device tensor for ``read(out=...)``, chosen as the fastest
+    to decode into among a few allocations (`baseband_amd.placement`)."""
+    import torch
+    from .placement import empty_output as _empty
+    return _empty(shape, dtype=torch.float32 if dtype is None else dtype, candidates=candidates,
+                  device=device, report=report)
+
+
+__all__ += ['empty_output']
