@@ -168,7 +168,7 @@ std::atomic<int> g_tune_select_bytes{16384};   // payload bytes k_decode_gather_
 std::atomic<int> g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
 std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
 std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
-std::atomic<int> g_tune_xpose_rows{128}; // k_decode_i8_xpose: output rows per tile (128 or 64)
+std::atomic<int> g_tune_xpose_rows{0};   // k_decode_i8_xpose: output rows per tile, 128 or 64; 0 = by layout
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
 std::atomic<int> g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 std::atomic<int> g_tune_stripe_w{0};     // experiment: output striping (bb_flat_args::stripe_w)
@@ -422,7 +422,7 @@ int bb_tune(int knob, int value)
             if (value < 256 || value > 32768) return BB_EINVAL;
             g_tune_select_bytes = value; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
-        case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : 128; return BB_OK;
+        case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : value == 128 ? 128 : 0; return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
         case BB_TUNE_OUT_STRIPE_W: g_tune_stripe_w = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_OUT_STRIPE_S: g_tune_stripe_s = value > 0 ? value : 0; return BB_OK;
@@ -1364,7 +1364,13 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
         else
             ok = ok && np_ == 2 && (nc % 4 == 0) && (ncs % 4 == 0);
         if (ok) {
-            const uint64_t xrows = (uint64_t)g_tune_xpose_rows.load();
+            // rows per tile: 128 for channels-first blocks (5.9 -> 6.3 TB/s against
+            // 64 at the headline's output size); for time-first blocks and MKBF
+            // heaps 64 below 96 GiB of output (+3 % at 8 GiB of input) and 128
+            // above (+0-1 %): profiles/r02az_exp_xpose_rows.log
+            const int xr = g_tune_xpose_rows.load();
+            const bool big = (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4 >= (96ull << 30);
+            const uint64_t xrows = xr ? (uint64_t)xr : (p->layout == BB_LAYOUT_GUPPI_CF || big) ? 128u : 64u;
             const uint64_t ntt = (rows + xrows - 1) / xrows, nct = (nc + BB_XP_TC - 1) / BB_XP_TC;
             if (ntt > 0xffffffffull) return BB_ERANGE;
             a.ntt = (uint32_t)ntt; a.nct = (uint32_t)nct;

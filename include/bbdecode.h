@@ -477,7 +477,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_SELECT_BYTES 23       /* payload bytes (all thread slots together) that k_decode_gather_select stages in LDS per work item (256..32768, default 16384) */
 #define BB_TUNE_M4_WIDEN 22           /* 1 (default): 16- and 32-track Mark 4 units whose word count and fill prefix allow it are decoded as 64-bit super-words (4 / 2 stream words per lane and load) by the 64-track kernels; 0: always the native word size */
 #define BB_TUNE_BYTE_LUT 21           /* 1 (default): contiguous 1-, 2- and 4-bit decode through the byte table kernel k_decode_flat_lut; 0: k_decode_flat_aln (register level select; the plain kernel for 4-bit) */
-#define BB_TUNE_XPOSE_ROWS 20         /* k_decode_i8_xpose: output rows per tile, 128 (default) or 64 */
+#define BB_TUNE_XPOSE_ROWS 20         /* k_decode_i8_xpose: output rows per tile, 128 or 64; default 0 = 128 for GUPPI channels-first blocks and for outputs of 96 GiB and more, 64 for smaller launches of time-first blocks and MKBF heaps */
 #define BB_TUNE_XPOSE 19              /* 1 (default): int8 transposes with 16-byte aligned input runs go through k_decode_i8_xpose; 0: k_decode_i8_tiled / _stage always */
 #define BB_TUNE_WORK_STRIPES 18       /* work order of the decode launches: log2 of the number of stripes a launch's work items are dealt over (0 = file order; default -1 = 16 stripes for outputs of 16 GiB and more, 4 below) */
 #define BB_TUNE_OUT_STRIPE_W 16       /* experiment: deal the frames of a contiguous-output launch over this many output regions (0 = off) ... */

@@ -379,7 +379,7 @@ def test_xpose_kernel_raw_layouts(tile_rows):
         assert 'k_decode_i8_xpose' not in _lib.last_kernel()
     finally:
         kernels.tune(_lib.TUNE_XPOSE, 1)
-        kernels.tune(_lib.TUNE_XPOSE_ROWS, 128)
+        kernels.tune(_lib.TUNE_XPOSE_ROWS, 0)
 
 
 @pytest.mark.parametrize('name', ['sample_puppi', 'guppi_cf_c64_ov0', 'guppi_cf_c64_ov32', 'guppi_cf_c6_p1',
