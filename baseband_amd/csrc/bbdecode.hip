@@ -158,7 +158,7 @@ std::atomic<int> g_tune_tpw{12};
 std::atomic<uint64_t *> g_trace{nullptr};
 std::atomic<int> g_tune_lds_pad{0};
 std::atomic<int> g_tune_tiled_stage{1};
-std::atomic<int> g_tune_seg_tiles{BB_SEG_TILES};
+std::atomic<int> g_tune_seg_tiles{0};    // plain kernel: tiles per workgroup; 0 = 32, or 16 for 8-bit samples
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
 std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
@@ -409,7 +409,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_TILES_PER_WAVE_8BIT: g_tune_tpw8 = (value >= 1 && value <= 32) ? value : 12; return BB_OK;
         case BB_TUNE_GATHER_BYTES: g_tune_gather_bytes = value > 0 ? value : 8192; return BB_OK;
         case BB_TUNE_TILED_STAGE: g_tune_tiled_stage = value; return BB_OK;
-        case BB_TUNE_SEG_TILES: g_tune_seg_tiles = (value >= 1 && value <= 4096) ? value : BB_SEG_TILES; return BB_OK;
+        case BB_TUNE_SEG_TILES: g_tune_seg_tiles = (value >= 1 && value <= 4096) ? value : 0; return BB_OK;
         case BB_TUNE_GATHER_CHUNKS: g_tune_gather_chunks = value > 0 ? value : 32; return BB_OK;
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
@@ -629,7 +629,11 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     a.nfs = nfs;
     a.ndw = p->payload_nbytes / 4;
     const uint64_t ntiles = (a.ndw + 63) / 64;
-    const uint64_t seg_plain = (uint64_t)g_tune_seg_tiles.load();     // plain kernel: tiles per workgroup
+    // plain kernel: tiles per workgroup.  8-bit samples: 16 (4 KiB in, 16 KiB
+    // out per workgroup) instead of 32: +7 % at 8 GiB, +0-3.5 % at 31 GiB
+    // (profiles/r02ba_exp_int8_seg.log)
+    const int seg_knob = g_tune_seg_tiles.load();
+    const uint64_t seg_plain = seg_knob ? (uint64_t)seg_knob : (p->bps == 8 ? 16u : (uint64_t)BB_SEG_TILES);
     a.nseg = (ntiles + seg_plain - 1) / seg_plain;
     // split a frame-slot's tiles evenly over its work items and a work item's
     // tiles evenly over the four waves (a 10000-byte Mark 5B payload is 40

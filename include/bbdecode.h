@@ -463,7 +463,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */
 #define BB_TUNE_TILE_ELEMS     4   /* elements per tile of bb_decode_i8_tiled (default 8192) */
 #define BB_TUNE_GATHER_BYTES   6   /* payload bytes of all thread slots staged in LDS per work item of k_decode_gather; 8192 (default) = automatic: 16384, or 4096 for 1-bit data */
-#define BB_TUNE_SEG_TILES 13          /* plain flat kernel: 256-byte tiles per workgroup (default 32) */
+#define BB_TUNE_SEG_TILES 13          /* plain flat kernel: 256-byte tiles per workgroup (default 0 = 32, 16 for 8-bit samples) */
 #define BB_TUNE_GATHER_CHUNKS 12      /* thread interleave: chunks (floats per thread sample) below this go through the LDS gather kernel; 32 (default) = automatic: every chunk for up to 4 thread slots, chunks below 32 floats otherwise; 4 = only chunks 1 and 2 */
 #define BB_TUNE_MKBF_CHANNELS 11      /* channels per MKBF tile in k_decode_i8_stage (even, 2..64; default 32) */
 #define BB_TUNE_TILED_STAGE 10        /* 1 (default): MKBF and GUPPI time-first through k_decode_i8_stage; 0: k_decode_i8_tiled */
