@@ -246,3 +246,54 @@ def test_sequential_small_reads_with_subsets(manifest, name, subset):
             used += fh._decoded is not None
         assert used > 0 or n <= 3 * chunk
 
+
+
+FUZZ_CASES = CASES + ['guppi_cf_c64_ov0', 'guppi_cf_c64_ov32', 'guppi_tf_c8_ov16', 'dada_p2_c4_cplx', 'sample_meerkat_dada']
+
+
+def _open_any(name, manifest, **kw):
+    import baseband_amd
+    if name.startswith(('guppi', 'sample_puppi')):
+        return baseband_amd.guppi.open(golden_path(manifest[name]['file']), 'rs', **kw)
+    if name.startswith('dada') or name.endswith('_dada'):
+        return baseband_amd.dada.open(golden_path(manifest[name]['file']), 'rs', **kw)
+    return _open(name, manifest, **kw)
+
+
+@pytest.mark.parametrize('name', FUZZ_CASES)
+@pytest.mark.parametrize('seed', [0, 1, 2, 3])
+def test_random_walks_equal_exact_reads(manifest, name, seed):
+    """Seeded random walks over a stream -- runs of sequential reads of all sizes,
+    seeks, reads into device and host `out` -- with every read-ahead on, against
+    a reader that decodes exactly what each read asks for (which the golden
+    stream tests pin to the reference)."""
+    import torch
+    rng = np.random.default_rng(1000 * seed + len(name))
+    with _open_any(name, manifest, squeeze=False) as fh, _open_any(name, manifest, squeeze=False) as ref:
+        ref.decode_ahead = False
+        if hasattr(ref, 'prefetch_next'):
+            ref.prefetch_next = False
+        n, spf = fh.shape[0], fh.samples_per_frame
+        pos = 0
+        for step in range(150):
+            kind = rng.integers(10)
+            if kind == 0 or pos >= n:                      # seek somewhere
+                pos = int(rng.integers(0, n))
+                fh.seek(pos)
+            size = int(rng.choice([1, 3, max(1, spf // 7), spf, spf + 5, 3 * spf + 1, max(1, n // 3)]))
+            cnt = max(1, min(size, n - pos))
+            ref.seek(pos)
+            want = ref.read(cnt).cpu().numpy()
+            how = rng.integers(4)
+            if how == 0:
+                out = torch.empty((cnt,) + fh.sample_shape, dtype=torch.complex64 if fh.complex_data else torch.float32,
+                                  device='cuda')
+                got = fh.read(out=out).cpu().numpy()
+            elif how == 1:
+                host = np.empty((cnt,) + fh.sample_shape, np.complex64 if fh.complex_data else np.float32)
+                got = fh.read(out=host)
+            else:
+                got = fh.read(cnt).cpu().numpy()
+            assert bits_equal(got, want), (name, seed, step, pos, cnt, int(how))
+            pos += cnt
+            assert fh.tell() == pos
