@@ -297,3 +297,30 @@ def test_random_walks_equal_exact_reads(manifest, name, seed):
             assert bits_equal(got, want), (name, seed, step, pos, cnt, int(how))
             pos += cnt
             assert fh.tell() == pos
+
+
+@pytest.mark.parametrize('name,subset', [('sample_vdif', ([5, 2],)), ('vdif_cfg3_small', (slice(None), [9, 3])),
+                                         ('vdif_cfg3_small', ([0, 7], slice(4, 12))), ('m5b_c16_b2', ([3, 12],)),
+                                         ('m4_t64_f4', (slice(2, 7),)), ('sample_gsb_phased', (slice(None), [511, 0])),
+                                         ('guppi_cf_c64_ov32', (slice(None), slice(8, 40))),
+                                         ('guppi_tf_c8_ov16', (slice(None), slice(2, 6))),
+                                         ('dada_p2_c4_cplx', (slice(None), [3, 1])), ('sample_meerkat_dada', (0,))])
+def test_random_walks_with_subsets(manifest, name, subset):
+    """The same walks with reader subsets (thread subsets, folded channel
+    selections, channel ranges) and squeezing."""
+    rng = np.random.default_rng(len(name) + len(repr(subset)))
+    with _open_any(name, manifest, subset=subset) as fh, _open_any(name, manifest, subset=subset) as ref:
+        ref.decode_ahead = False
+        if hasattr(ref, 'prefetch_next'):
+            ref.prefetch_next = False
+        assert fh.shape == ref.shape
+        n, spf = fh.shape[0], fh.samples_per_frame
+        pos = 0
+        for step in range(120):
+            if rng.integers(8) == 0 or pos >= n:
+                pos = int(rng.integers(0, n))
+                fh.seek(pos)
+            cnt = max(1, min(int(rng.choice([1, 4, max(1, spf // 5), spf, 2 * spf + 3])), n - pos))
+            ref.seek(pos)
+            assert bits_equal(fh.read(cnt).cpu().numpy(), ref.read(cnt).cpu().numpy()), (name, subset, step, pos, cnt)
+            pos += cnt
