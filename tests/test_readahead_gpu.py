@@ -324,3 +324,28 @@ def test_random_walks_with_subsets(manifest, name, subset):
             ref.seek(pos)
             assert bits_equal(fh.read(cnt).cpu().numpy(), ref.read(cnt).cpu().numpy()), (name, subset, step, pos, cnt)
             pos += cnt
+
+
+def test_random_walk_over_a_damaged_file(tmp_path):
+    """verify='fix' on a file with bytes missing: walks with and without
+    read-ahead return the same (repaired) samples."""
+    from baseband_amd import vdif
+    base = load_file('synth/vdif_triple.bin').copy()
+    blob = np.delete(base, np.arange(3 * 8 * 5032 + 77, 3 * 8 * 5032 + 77 + 5032))
+    p = tmp_path / 'damaged.vdif'
+    p.write_bytes(blob.tobytes())
+    rng = np.random.default_rng(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with vdif.open(str(p), 'rs') as fh, vdif.open(str(p), 'rs') as ref:
+            ref.decode_ahead = False
+            n, spf = fh.shape[0], fh.samples_per_frame
+            pos = 0
+            for step in range(200):
+                if rng.integers(6) == 0 or pos >= n:
+                    pos = int(rng.integers(0, n))
+                    fh.seek(pos)
+                cnt = max(1, min(int(rng.choice([1, spf // 9, spf // 2, spf, 2 * spf + 1])), n - pos))
+                ref.seek(pos)
+                assert bits_equal(fh.read(cnt).cpu().numpy(), ref.read(cnt).cpu().numpy()), (step, pos, cnt)
+                pos += cnt
