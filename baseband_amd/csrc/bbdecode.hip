@@ -762,9 +762,14 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     // slot leaves the rows kernel with 2-4 waves per workgroup: 5.6 / 6.1 TB/s
     // against 6.4 / 6.3), eight or more only below 32 floats
     // (profiles/r01i_exp_interleave_thr.log)
+    // -- and, since the staging rewrite of round 2, 2-bit launches of 64 GiB of
+    // output and more whatever the chunk: +1-3.5 % in every cell of 8-64 slots x
+    // 32-256 floats at 8 GiB of input (profiles/r02at_exp_rows_vs_gather_2bit_8GiB.log);
+    // smaller launches and other sample widths show no clear winner and stay
     const int gchunks = g_tune_gather_chunks.load();
+    const bool big2 = p->bps == 2 && p->chunk <= 256 && out_bytes >= (64ull << 30);
     const bool gather_wide = om == BB_OUT_ROWS4
-        && (gchunks == 32 ? (p->nslot <= 4 || p->chunk < 32) : p->chunk < gchunks);
+        && (gchunks == 32 ? (p->nslot <= 4 || p->chunk < 32 || big2) : p->chunk < gchunks);
     if ((om == BB_OUT_SCATTER || gather_wide)
         && d_src && variant >= 2
         && (size_t)p->nslot * 528 + 1024 + 64 <= 48 * 1024) {
