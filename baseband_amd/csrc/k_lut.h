@@ -84,7 +84,7 @@ void k_decode_flat_lut(bb_flat_args a)
         for (int u = 0; u <= TPW; ++u) {
             const uint64_t j = (tile0 + u) * 64 + lane;     // block dword j holds payload dword j - s
             const bool want = valid && u <= (int)a.tpw && j >= s && j - s < dw_end;
-            w[u] = want ? blk[j] : 0u;
+            w[u] = want ? (a.nt_loads ? __builtin_nontemporal_load(&blk[j]) : blk[j]) : 0u;
         }
     };
 
