@@ -18,7 +18,11 @@ for nfr in ((8 << 30) // FN, (2 << 30) // FN):
     one = torch.full((nfr,), 32, device=dev, dtype=torch.int64)
     few = (torch.arange(nfr, device=dev, dtype=torch.int64) % 1024) * FN + 32          # 8 MiB of input, L2 / MALL resident
     res = {}
-    for name, s in (('real index', src), ('one frame', one), ('1024 frames', few), ('real index again', src)):
+    w32 = (torch.arange(nfr, device=dev, dtype=torch.int64) % 4096) * FN + 32          # 33 MB of input
+    w128 = (torch.arange(nfr, device=dev, dtype=torch.int64) % 16384) * FN + 32        # 131 MB
+    w512 = (torch.arange(nfr, device=dev, dtype=torch.int64) % 65536) * FN + 32        # 526 MB (beyond the Infinity Cache)
+    for name, s in (('real index', src), ('one frame', one), ('1024 frames', few), ('33 MB window', w32),
+                    ('131 MB window', w128), ('526 MB window', w512), ('real index again', src)):
         ms = timeit(lambda: kernels.decode_frames(buf, nfr, PN, 0, 2, src=s, out=out), reps=6)
         res[name] = dict(ms=round(ms, 3), write_TBps=round(nfr * PN * 16 / ms / 1e9, 3), alg_TBps=round(nfr * (FN + PN * 16) / ms / 1e9, 3))
     fill = timeit(lambda: out.fill_(1.0), reps=4)
