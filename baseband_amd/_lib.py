@@ -13,7 +13,12 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbbdecode.so')
+# BB_EXPERIMENTS=1 in the environment loads the experiment build (make -C
+# baseband_amd/csrc EXPERIMENTS=1): the same kernels plus the measurement
+# variants and knobs of include/bbdecode_exp.h.  tools/exp_*.py need it; the
+# package, the tests and bench.py run on the product library.
+EXPERIMENTS = os.environ.get('BB_EXPERIMENTS', '') not in ('', '0')
+LIB_PATH = os.path.join(_HERE, 'libbbdecode_exp.so' if EXPERIMENTS else 'libbbdecode.so')
 
 BB_OK = 0
 BB_EIO = -5
@@ -28,33 +33,35 @@ CODER_INT = 2
 FRAME_OK = 0x1
 FRAME_INVALID = 0x2
 
-TUNE_FLAT_VARIANT = 0
-TUNE_NT_STORES = 1
+# include/bbdecode_tune.h (geometry knobs of the product library)
 TUNE_BLOCKS = 2
-TUNE_NT_LOADS = 3
 TUNE_TILE_ELEMS = 4
 TUNE_ENCODE_DIRECT = 5
 TUNE_GATHER_BYTES = 6
 TUNE_TILES_PER_WAVE = 7
-TUNE_TILES_PER_WAVE_8BIT = 8
-TUNE_LDS_PAD = 9
 TUNE_TILED_STAGE = 10
 TUNE_MKBF_CHANNELS = 11
 TUNE_GATHER_CHUNKS = 12
 TUNE_SEG_TILES = 13
+TUNE_WORK_STRIPES = 18
+TUNE_XPOSE = 19
+TUNE_XPOSE_ROWS = 20
+TUNE_M4_WIDEN = 22
+TUNE_SELECT_BYTES = 23
+TUNE_LUT_TILES = 24
+TUNE_M4_TILES = 26
+# include/bbdecode_exp.h (experiment build only: bb_tune answers BB_EINVAL otherwise)
+TUNE_FLAT_VARIANT = 0
+TUNE_NT_STORES = 1
+TUNE_NT_LOADS = 3
+TUNE_TILES_PER_WAVE_8BIT = 8
+TUNE_LDS_PAD = 9
 TUNE_FRONT_GROUP = 14
 TUNE_FRONT_STEPS = 15
 TUNE_OUT_STRIPE_W = 16
 TUNE_OUT_STRIPE_S = 17
-TUNE_WORK_STRIPES = 18
-TUNE_XPOSE = 19
-TUNE_XPOSE_ROWS = 20
 TUNE_BYTE_LUT = 21
-TUNE_M4_WIDEN = 22
-TUNE_SELECT_BYTES = 23
-TUNE_LUT_TILES = 24
 TUNE_LUT_SMALL = 25
-TUNE_M4_TILES = 26
 
 
 class BBError(RuntimeError):
@@ -123,8 +130,8 @@ def _load():
         raise ImportError(
             "baseband_amd: {} not found. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
-            "`make -C baseband_amd/csrc` (needs hipcc, gfx950). There is no "
-            "CPU fallback.".format(LIB_PATH))
+            "`make -C baseband_amd/csrc{}` (needs hipcc, gfx950). There is no "
+            "CPU fallback.".format(LIB_PATH, ' EXPERIMENTS=1' if EXPERIMENTS else ''))
     return C.CDLL(LIB_PATH)
 
 
@@ -134,6 +141,7 @@ _vp = C.c_void_p
 _sz = C.c_size_t
 
 # (name, restype, argtypes) -- must list every symbol of include/bbdecode.h
+# and include/bbdecode_tune.h
 SIGNATURES = [
     ('bb_abi_version', C.c_int, []),
     ('bb_strerror', C.c_char_p, [C.c_int]),
@@ -142,7 +150,6 @@ SIGNATURES = [
     ('bb_init', C.c_int, []),
     ('bb_get_levels', C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float), _sz]),
     ('bb_get_encode_thresholds', C.c_int, [C.POINTER(C.c_float)]),
-    ('bb_debug_trace', C.c_int, [_vp]),
     ('bb_vdif_scan', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp]),
     ('bb_vdif_locate', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_vdif_scan_at', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
@@ -153,6 +160,7 @@ SIGNATURES = [
     ('bb_build_index', C.c_int, [_vp, _sz, _vp, C.c_int, _vp, _sz, _vp]),
     ('bb_decode_frames', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, _sz, _vp]),
     ('bb_decode_frames_select', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, C.c_int, _vp, _sz, _vp]),
+    ('bb_decode_frames_select_check', C.c_int, [C.POINTER(DecodeParams), C.c_int]),
     ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),
     ('bb_mark4_locate', C.c_int, [_vp, _sz, C.c_int, _vp, _sz, _vp, _vp]),
     ('bb_mark4_header_crc', C.c_int, [_vp, _sz, C.c_int, _vp, C.c_int64, _sz, _vp, _vp]),
@@ -164,12 +172,17 @@ SIGNATURES = [
     ('bb_encode_flat', C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     ('bb_encode_mark4', C.c_int, [_vp, _sz, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _vp, _sz, _vp]),
     ('bb_tune', C.c_int, [C.c_int, C.c_int]),
+]
+
+# include/bbdecode_exp.h
+EXPERIMENT_SIGNATURES = [
+    ('bb_debug_trace', C.c_int, [_vp]),
     ('bb_host_register', C.c_int, [_vp, _sz]),
     ('bb_host_unregister', C.c_int, [_vp]),
     ('bb_copy_to_device', C.c_int, [_vp, _vp, _sz, _vp]),
 ]
 
-for _name, _res, _args in SIGNATURES:
+for _name, _res, _args in SIGNATURES + (EXPERIMENT_SIGNATURES if EXPERIMENTS else []):
     _f = getattr(lib, _name)
     _f.restype = _res
     _f.argtypes = _args

@@ -388,7 +388,7 @@ class GPUStreamReaderBase:
             self._within_dev = torch.from_numpy(self._within_np).to('cuda')
         return self._within_dev
 
-    def _plan_channel_select(self, subset, lead_in_sample=False):
+    def _plan_channel_select(self, subset, lead_in_sample=False, payload_nbytes=None):
         """If `subset` (what `_squeeze_and_subset` would apply to decoded
         frames) only picks CHANNELS -- the last axis of `_decode_shape` -- the
         same for every thread, have the decode kernel write just those
@@ -401,7 +401,14 @@ class GPUStreamReaderBase:
 
         `lead_in_sample`: the leading axis is not a set of thread frames but
         lies inside every stored sample (DADA: polarisations); the positions
-        then run over the whole (lead, channel) sample."""
+        then run over the whole (lead, channel) sample.
+
+        `payload_nbytes`: bytes per frame and thread slot, when fixed.  The
+        selecting kernel has limits (at most 4096 kept positions; a thread
+        sample must fit whole rows into a work item of at most 16 tiles; the
+        slots' staging must fit in LDS): the plan is checked against the
+        library's own predicate (`kernels.select_supported`) and dropped --
+        general path -- when the kernel would refuse it."""
         shape = tuple(self._decode_shape)
         if not subset or not shape or len(shape) > 2 or (len(shape) == 2 and shape[0] > 96):
             return
@@ -434,9 +441,11 @@ class GPUStreamReaderBase:
         ncomp = 2 if self.complex_data else 1
         if lead_in_sample:
             picked = (np.arange(lead)[:, None] * nchan + picked).reshape(-1)
-            if picked.size > 4096:
-                return
         within = (picked[:, None] * ncomp + np.arange(ncomp)).reshape(-1).astype(np.int32)
+        chunk = (nchan * lead if lead_in_sample else nchan) * ncomp
+        if not kernels.select_supported(self.bps, chunk, 1 if lead_in_sample else lead, within.size,
+                                        payload_nbytes):
+            return
         self._within_np = within
         self._decode_shape = shape[:-1] + (m,)
 
@@ -562,7 +571,8 @@ class GPUStreamReaderBase:
         self._sink, self._have = None, []
 
     # -- windows that were staged once stay in HBM
-    keep_staged = None      # None: keep when the file is at most a quarter of the GPU's memory
+    keep_staged = None      # None: keep files of at most `keep_staged_max_bytes`; True / False: always / never
+    keep_staged_max_bytes = 4 << 30
     _sink = None            # device tensor of the file's size (+ slack), filled window by window
     _have = ()              # merged byte intervals of `_sink` that hold file bytes
 
@@ -571,13 +581,18 @@ class GPUStreamReaderBase:
         window, or None when windows are not kept.  Keeping them makes a second
         pass over the same bytes -- the corruption-tolerant re-read of
         verify='fix', a repeated read -- come from HBM instead of crossing PCIe
-        again."""
+        again.  By default only files of at most `keep_staged_max_bytes` (4
+        GiB) are kept; ``fh.keep_staged = True`` keeps any file that fits,
+        ``False`` none; `unstage()` / `close()` release the copy."""
         if self._sink is not None:
             return self._sink
         keep = self.keep_staged
         n = len(self._image())
         if keep is None:
-            keep = n <= torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory // 4
+            # a stated cap, not a share of the GPU: the caller's outputs are 16x
+            # the input and sized by the caller (ADVICE r2); larger files rotate
+            # two window buffers, and a repair pass uploads what it needs again
+            keep = n <= self.keep_staged_max_bytes
         if not keep or n == 0:
             return None
         try:
@@ -734,7 +749,7 @@ class GPUStreamReaderBase:
         self._seq_run += 1
         d = self._decoded
         if d is not None and d[0] <= off and off + count <= d[1]:
-            return d[2][off - d[0]:off - d[0] + count]
+            return self._ahead_result(d[2][off - d[0]:off - d[0] + count])
         self._decoded = None
         if self._seq_run < 2:
             return None
@@ -752,16 +767,47 @@ class GPUStreamReaderBase:
         try:
             data = self._read_sets(first, last)
             ok = self._resolve_checks(quiet=True)
-        except Exception:
+        except (EOFError, ValueError, HeaderNotFoundError):
+            # something is wrong with the FILE inside the window (bytes
+            # missing, a header that is not one): the ordinary path meets it
+            # at the read it belongs to and raises or repairs there
             ok = False
+        except torch.cuda.OutOfMemoryError:
+            # no room for a speculative window next to the caller's tensors:
+            # the request itself needs far less, so serve it the ordinary way
+            warnings.warn("decoded read-ahead switched off: out of device memory for a "
+                          "window of {} frame sets".format(last - first))
+            ok = False
+        # (library / HIP errors and programming errors are not caught)
         if not ok:
             self.decode_ahead = False
-            self._nmissing, self._checked = 0, False
+            self._reset_checks()
             return None
         self._ahead_sets = min(max_sets, self._ahead_sets * 4)
         data = self._squeeze_and_subset(data)
         self._decoded = (first * spf, min(last * spf, self.shape[0]), data)
-        return data[off - first * spf:off - first * spf + count]
+        return self._ahead_result(data[off - first * spf:off - first * spf + count])
+
+    decode_ahead_copy_below = 1 << 20   # results smaller than this are copies, not views of the window
+
+    def _ahead_result(self, part):
+        """What a read served from the decoded window returns.  The reference
+        hands out fresh arrays (base/base.py:919-969); a VIEW of the window
+        would keep all of it (up to `decode_ahead_bytes`) alive for as long as
+        the caller keeps a few samples, so small results are copied out --
+        larger ones, where the copy would cost as much as the decode, stay
+        views (documented; `decode_ahead_copy_below = 0` turns copying off)."""
+        if part.numel() * part.element_size() < self.decode_ahead_copy_below:
+            return part.clone()
+        return part
+
+    def _reset_checks(self):
+        """Forget the verification state of windows that were processed for a
+        read that did not complete (or a read-ahead that was abandoned): the
+        next read starts clean -- host counters AND the device counter."""
+        self._nmissing, self._checked = 0, False
+        if self._nbad is not None:
+            self._nbad.zero_()
 
     def _fill_request(self, out, count):
         """Decode samples [offset, offset + count).  Returns ``(data, direct)``:
@@ -832,7 +878,7 @@ class GPUStreamReaderBase:
             try:
                 self._process_window(self._device_window(resident, lo, hi), first, last, flat)
             except Exception:
-                self._nmissing, self._checked = 0, False
+                self._reset_checks()
                 raise
         elif nsets and nsets * set_nbytes * 8 <= self.window_bytes:
             # small request: serve it from the read-ahead window kept in HBM
@@ -868,7 +914,7 @@ class GPUStreamReaderBase:
                 self._pipeline.run(ranges, process, sink=sink)
             except Exception:
                 # do not leave half a read's verification state for the next one
-                self._nmissing, self._checked = 0, False
+                self._reset_checks()
                 raise
             if sink is not None:
                 for lo, hi in ranges:

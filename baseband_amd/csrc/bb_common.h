@@ -4,6 +4,17 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "bbdecode.h"
+#include "bbdecode_tune.h"
+
+// BB_EXPERIMENTS (make EXPERIMENTS=1) builds libbbdecode_exp.so: the product
+// kernels plus the measurement variants of rounds 1-2 and their knobs
+// (include/bbdecode_exp.h).  The product library carries none of that.
+#ifdef BB_EXPERIMENTS
+#define BB_EXP 1
+#include "bbdecode_exp.h"
+#else
+#define BB_EXP 0
+#endif
 
 #define BB_WAVE 64
 #define BB_BLOCK 256            // 4 waves: one per SIMD of a CU
@@ -45,6 +56,14 @@ __device__ __forceinline__ uint64_t bb_perm(const bb_perm_t &p, uint64_t w)
     if (w >= p.n) return w;
     return (w & ((1ull << p.lw) - 1)) * p.stripe + (w >> p.lw);
 }
+
+// A source offset taken from an index is only followed when the whole unit it
+// names lies inside the buffer: `lim` = buffer bytes - unit bytes + 1 (0 when
+// the buffer is shorter than one unit), so one unsigned compare rejects
+// negative offsets (-1 = missing frame) and offsets past the end alike; both
+// decode as fill.  The reference never returns garbage for a short read either
+// (EOFError, base/payload.py:135-136).
+__device__ __forceinline__ bool bb_src_ok(int64_t so, uint64_t lim) { return (uint64_t)so < lim; }
 
 // 16-byte store, optionally with the non-temporal hint (streamed output is
 // never re-read by this library).

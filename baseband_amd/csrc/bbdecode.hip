@@ -4,7 +4,9 @@
 #include "bb_common.h"
 #include "k_scan.h"
 #include "k_flat.h"
-#include "k_front.h"
+#if BB_EXP
+#include "k_exp.h"
+#endif
 #include "k_lut.h"
 #include "k_gather.h"
 #include "k_mark4.h"
@@ -146,35 +148,60 @@ int device_levels(int coder, int lb, const float **p)
 // walks several items with its loads one item ahead.
 #define BB_GRID_CAP 131072ull
 
-// ---- tuning ----------------------------------------------------------------
-std::atomic<int> g_tune_variant{5};   // 5 = persistent pipelined kernel, 2 waves x long runs, aligned block loads
-std::atomic<int> g_tune_nt{1};
+// ---- tuning (include/bbdecode_tune.h; the experiment build adds bbdecode_exp.h) ----
 std::atomic<int> g_tune_blocks{0};
-std::atomic<int> g_tune_nt_loads{0};
 std::atomic<int> g_tune_tile_elems{8192};
 std::atomic<int> g_tune_encode_direct{0};
 std::atomic<int> g_tune_gather_bytes{8192};
-std::atomic<int> g_tune_tpw{12};
-std::atomic<uint64_t *> g_trace{nullptr};
-std::atomic<int> g_tune_lds_pad{0};
 std::atomic<int> g_tune_tiled_stage{1};
 std::atomic<int> g_tune_seg_tiles{0};    // plain kernel: tiles per workgroup; 0 = 32, or 16 for 8-bit samples
 std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
-std::atomic<int> g_tune_mkbf_tc{32};   // bb_debug_trace
-std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
-std::atomic<int> g_tune_lut_small{0};           // 1: the 4-tile instantiation of k_decode_flat_lut when items allow (experiment: slower)
+std::atomic<int> g_tune_mkbf_tc{32};
+std::atomic<int> g_tune_rows_tiles{8};          // tiles per work item of k_decode_rows_pipe (1..8)
 std::atomic<int> g_tune_lut_tpw{4};             // tiles per wave and work item of k_decode_flat_lut
 std::atomic<int> g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
 std::atomic<int> g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
 std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
-std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
 std::atomic<int> g_tune_xpose_rows{0};   // k_decode_i8_xpose: output rows per tile, 128 or 64; 0 = by layout
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
 std::atomic<int> g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
+#if BB_EXP
+std::atomic<int> g_tune_variant{5};      // 5 = the product dispatch; others: include/bbdecode_exp.h
+std::atomic<int> g_tune_nt{1};
+std::atomic<int> g_tune_nt_loads{0};
+std::atomic<int> g_tune_tpw{12};
+std::atomic<uint64_t *> g_trace{nullptr};
+std::atomic<int> g_tune_lds_pad{0};
+std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+std::atomic<int> g_tune_lut_small{0};           // 1: the 4-tile instantiation of k_decode_flat_lut when items allow (experiment: slower)
+std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
 std::atomic<int> g_tune_stripe_w{0};     // experiment: output striping (bb_flat_args::stripe_w)
 std::atomic<int> g_tune_stripe_s{0};     // ... distance between the stripes, in frame-slots
 std::atomic<int> g_tune_front_g{2048};  // k_decode_flat_front: workgroups per group (one write front)
 std::atomic<int> g_tune_front_k{16};    // k_decode_flat_front: steps a group sweeps
+inline bool tune_nt() { return g_tune_nt.load() != 0; }
+#else
+inline bool tune_nt() { return true; }
+#endif
+
+// Non-temporal stores are what the product launches; the experiment build can
+// switch to plain stores (BB_TUNE_NT_STORES) and then instantiates both forms.
+template <class F>
+inline void with_nt(bool nt, F &&f)
+{
+#if BB_EXP
+    if (!nt) { f(std::false_type{}); return; }
+#endif
+    (void)nt;
+    f(std::true_type{});
+}
+
+// offsets taken from an index are followed only while the whole unit of
+// `span` bytes lies inside the buffer (bb_src_ok)
+inline uint64_t src_limit(size_t buf_nbytes, uint64_t span)
+{
+    return buf_nbytes >= span ? (uint64_t)buf_nbytes - span + 1 : 0;
+}
 
 // Work order of a launch of `nwork` items writing `out_bytes` (bb_common.h,
 // bb_perm_t).  Default (knob -1): 16 stripes for outputs of 16 GiB and more,
@@ -195,164 +222,93 @@ bb_perm_t make_perm(uint64_t nwork, uint64_t out_bytes)
     return p;
 }
 
-template <int BPS, int LV>
-void launch_gather(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
+// (bits per sample, coder) -> kernel template arguments <BPS, LV>
+template <class F>
+inline void with_levels(int bps, int coder, F &&f)
+{
+    using std::integral_constant;
+    switch (bps) {
+        case 1: f(integral_constant<int, 1>{}, integral_constant<int, BB_LV_REG>{}); break;
+        case 2: f(integral_constant<int, 2>{}, integral_constant<int, BB_LV_REG>{}); break;
+        case 4: f(integral_constant<int, 4>{}, integral_constant<int, BB_LV_LDS>{}); break;
+        default:
+            if (coder == BB_CODER_INT) f(integral_constant<int, 8>{}, integral_constant<int, BB_LV_INT8>{});
+            else                       f(integral_constant<int, 8>{}, integral_constant<int, BB_LV_LDS>{});
+            break;
+    }
+}
+
+void launch_gather(int bps, int coder, bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_gather_args &a)
 {
     const bool wide = a.lchunk >= 2;
-#define BB_G(NT, W) hipLaunchKernelGGL((k_decode_gather<BPS, LV, NT, W>), grid, dim3(BB_BLOCK), lds, st, a)
-    if (nt) { if (wide) BB_G(true, true); else BB_G(true, false); }
-    else    { if (wide) BB_G(false, true); else BB_G(false, false); }
-#undef BB_G
+    with_levels(bps, coder, [&](auto B, auto L) {
+        with_nt(nt, [&](auto NT) {
+            constexpr int BPS = decltype(B)::value, LV = decltype(L)::value;
+            constexpr bool N = decltype(NT)::value;
+            if (wide) hipLaunchKernelGGL((k_decode_gather<BPS, LV, N, true>), grid, dim3(BB_BLOCK), lds, st, a);
+            else      hipLaunchKernelGGL((k_decode_gather<BPS, LV, N, false>), grid, dim3(BB_BLOCK), lds, st, a);
+        });
+    });
 }
 
-template <int BPS, int LV, int NW, int TPW>
-void launch_flat_pipe(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+void launch_gather_select(int bps, int coder, bool nt, bool v4, dim3 grid, size_t lds, hipStream_t st,
+                          const bb_gather_args &a)
 {
-#define BB_L(OM, NT) hipLaunchKernelGGL((k_decode_flat_pipe<BPS, LV, OM, NT, NW, TPW>), grid, dim3(NW * BB_WAVE), 0, st, a)
-    if (om == BB_OUT_FLAT)       { if (nt) BB_L(BB_OUT_FLAT, true);    else BB_L(BB_OUT_FLAT, false); }
-    else if (om == BB_OUT_ROWS4) { if (nt) BB_L(BB_OUT_ROWS4, true);   else BB_L(BB_OUT_ROWS4, false); }
-    else                         { if (nt) BB_L(BB_OUT_SCATTER, true); else BB_L(BB_OUT_SCATTER, false); }
-#undef BB_L
+    with_levels(bps, coder, [&](auto B, auto L) {
+        with_nt(nt, [&](auto NT) {
+            constexpr int BPS = decltype(B)::value, LV = decltype(L)::value;
+            constexpr bool N = decltype(NT)::value;
+            if (v4) hipLaunchKernelGGL((k_decode_gather_select<BPS, LV, N, true>), grid, dim3(BB_BLOCK), lds, st, a);
+            else    hipLaunchKernelGGL((k_decode_gather_select<BPS, LV, N, false>), grid, dim3(BB_BLOCK), lds, st, a);
+        });
+    });
 }
 
-template <int BPS>
-void launch_flat_lut(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+// thread interleave with wide chunks: one wave per thread slot (2, 4 or 8 per
+// workgroup), aligned block loads
+void launch_rows_pipe(int bps, int coder, bool nt, int nw, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
-    // (an instantiation sized for the default short items, 2 x 5 instead of
-    // 2 x 17 block registers per lane, is SLOWER -- more workgroups per CU, more
-    // write streams at a time: profiles/r02ap_exp_lut_small.log; kept behind
-    // BB_TUNE_LUT_SMALL.  BB_TUNE_LDS_PAD asks for unused LDS to bound the
-    // workgroups per CU from above, for the same experiment.)
-    const unsigned pad = (unsigned)g_tune_lds_pad.load();
-    if (a.tpw <= 4 && g_tune_lut_small.load() != 0) {
-        if (nt) hipLaunchKernelGGL((k_decode_flat_lut<BPS, true, 2, 4>), grid, dim3(2 * BB_WAVE), pad, st, a);
-        else    hipLaunchKernelGGL((k_decode_flat_lut<BPS, false, 2, 4>), grid, dim3(2 * BB_WAVE), pad, st, a);
-        return;
-    }
-    if (nt) hipLaunchKernelGGL((k_decode_flat_lut<BPS, true, 2, 16>), grid, dim3(2 * BB_WAVE), pad, st, a);
-    else    hipLaunchKernelGGL((k_decode_flat_lut<BPS, false, 2, 16>), grid, dim3(2 * BB_WAVE), pad, st, a);
+    with_levels(bps, coder, [&](auto B, auto L) {
+        with_nt(nt, [&](auto NT) {
+            constexpr int BPS = decltype(B)::value, LV = decltype(L)::value;
+            constexpr bool N = decltype(NT)::value;
+            if (nw == 8)      hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, N, 8, 8, true>), grid, dim3(8 * BB_WAVE), 0, st, a);
+            else if (nw == 4) hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, N, 4, 8, true>), grid, dim3(4 * BB_WAVE), 0, st, a);
+            else              hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, N, 2, 8, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        });
+    });
 }
 
-template <int BPS, int LV>
-void launch_flat_aln(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+// the plain kernel: 8-bit samples with contiguous output, and the general
+// fallback (thread interleave without an index or with more thread slots
+// than the gather kernels stage)
+void launch_flat(int bps, int coder, int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
-    // experiment knob: unused dynamic LDS caps the workgroups per CU (160 KiB / pad)
-    const size_t pad = (size_t)g_tune_lds_pad.load();
-    if (nt) hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, true, 2, 16>), grid, dim3(2 * BB_WAVE), pad, st, a);
-    else    hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, false, 2, 16>), grid, dim3(2 * BB_WAVE), pad, st, a);
+    with_levels(bps, coder, [&](auto B, auto L) {
+        with_nt(nt, [&](auto NT) {
+            constexpr int BPS = decltype(B)::value, LV = decltype(L)::value;
+            constexpr bool N = decltype(NT)::value;
+            if (om == BB_OUT_FLAT)       hipLaunchKernelGGL((k_decode_flat<BPS, LV, BB_OUT_FLAT, N>), grid, dim3(BB_BLOCK), 0, st, a);
+            else if (om == BB_OUT_ROWS4) hipLaunchKernelGGL((k_decode_flat<BPS, LV, BB_OUT_ROWS4, N>), grid, dim3(BB_BLOCK), 0, st, a);
+            else                         hipLaunchKernelGGL((k_decode_flat<BPS, LV, BB_OUT_SCATTER, N>), grid, dim3(BB_BLOCK), 0, st, a);
+        });
+    });
 }
 
-// 8-bit data: one dword is only four samples, so a wave needs 32 tiles for a
-// 32 KiB output run (k_decode_flat_aln<.., 2, 32>)
-template <int BPS, int LV>
-void launch_flat_aln32(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+// the byte table kernel: contiguous 1-, 2- and 4-bit output (the headline kernel)
+void launch_flat_lut(int bps, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
-    if (nt) hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, true, 2, 32>), grid, dim3(2 * BB_WAVE), 0, st, a);
-    else    hipLaunchKernelGGL((k_decode_flat_aln<BPS, LV, false, 2, 32>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    with_nt(nt, [&](auto NT) {
+        constexpr bool N = decltype(NT)::value;
+        if (bps == 1)      hipLaunchKernelGGL((k_decode_flat_lut<1, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        else if (bps == 2) hipLaunchKernelGGL((k_decode_flat_lut<2, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        else               hipLaunchKernelGGL((k_decode_flat_lut<4, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    });
 }
 
-// k_decode_flat_front: geometry + launch.  Returns the grid size used.
-template <int BPS, int LV, int NW, int TPW>
-unsigned launch_flat_front(bool nt, hipStream_t st, const bb_flat_args &a)
-{
-    const uint64_t ntiles = (a.ndw + 63) / 64;
-    bb_front_geom g;
-    g.ipf = (uint32_t)((ntiles + TPW - 1) / TPW);
-    g.nitems = a.nfs * g.ipf;
-    uint64_t G = (uint64_t)g_tune_front_g.load(), K = (uint64_t)g_tune_front_k.load();
-    const uint64_t wgs = (g.nitems + NW - 1) / NW;              // workgroup-steps in all
-    if (G > wgs) G = wgs;                                       // small launch: one short group
-    if (K * G > wgs) K = (wgs + G - 1) / G;
-    const uint64_t ngroups = (wgs + G * K - 1) / (G * K);
-    g.G = (uint32_t)G; g.K = (uint32_t)K;
-    g.step_fs = (uint32_t)((G * NW) / g.ipf);
-    g.step_j = (uint32_t)((G * NW) % g.ipf);
-    const dim3 grid((unsigned)(ngroups * G));
-    if (nt) hipLaunchKernelGGL((k_decode_flat_front<BPS, LV, true, NW, TPW>), grid, dim3(NW * BB_WAVE), 0, st, a, g);
-    else    hipLaunchKernelGGL((k_decode_flat_front<BPS, LV, false, NW, TPW>), grid, dim3(NW * BB_WAVE), 0, st, a, g);
-    return grid.x;
-}
-
-template <int NW, int TPW>
-unsigned launch_flat_front_any(int bps, int coder, bool nt, hipStream_t st, const bb_flat_args &a)
-{
-    switch (bps) {
-        case 1: return launch_flat_front<1, BB_LV_REG, NW, TPW>(nt, st, a);
-        case 2: return launch_flat_front<2, BB_LV_REG, NW, TPW>(nt, st, a);
-        case 4: return launch_flat_front<4, BB_LV_LDS, NW, TPW>(nt, st, a);
-        default:
-            if (coder == BB_CODER_INT) return launch_flat_front<8, BB_LV_INT8, NW, TPW>(nt, st, a);
-            return launch_flat_front<8, BB_LV_LDS, NW, TPW>(nt, st, a);
-    }
-}
-
-// k_decode_flat_es: one pass, U stripes
-template <int BPS, int LV, int U>
-unsigned launch_flat_es(bool nt, hipStream_t st, const bb_flat_args &a)
-{
-    const uint64_t ntiles = (a.ndw + 63) / 64;
-    const uint64_t total = a.nfs * ntiles;
-    const uint64_t per = (total + U - 1) / U;
-    const uint64_t blocks = (per + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
-    const dim3 grid((unsigned)(blocks > 0x7fffffffull ? 0x7fffffffull : blocks));
-    if (nt) hipLaunchKernelGGL((k_decode_flat_es<BPS, LV, true, U>), grid, dim3(BB_BLOCK), 0, st, a, total, per);
-    else    hipLaunchKernelGGL((k_decode_flat_es<BPS, LV, false, U>), grid, dim3(BB_BLOCK), 0, st, a, total, per);
-    return grid.x;
-}
-
-template <int U>
-unsigned launch_flat_es_any(int bps, int coder, bool nt, hipStream_t st, const bb_flat_args &a)
-{
-    switch (bps) {
-        case 1: return launch_flat_es<1, BB_LV_REG, U>(nt, st, a);
-        case 2: return launch_flat_es<2, BB_LV_REG, U>(nt, st, a);
-        case 4: return launch_flat_es<4, BB_LV_LDS, U>(nt, st, a);
-        default:
-            if (coder == BB_CODER_INT) return launch_flat_es<8, BB_LV_INT8, U>(nt, st, a);
-            return launch_flat_es<8, BB_LV_LDS, U>(nt, st, a);
-    }
-}
-
-// k_decode_flat_elem: one pass, 16 stripes of whole frames, one float4 per thread and stripe
-template <int BPS, int LV>
-unsigned launch_flat_elem(bool nt, hipStream_t st, const bb_flat_args &a)
-{
-    const uint64_t fps = (a.nfs + BB_ELEM_STRIPES - 1) / BB_ELEM_STRIPES;
-    const uint64_t E4 = a.ndw * (32 / BPS) / 4;
-    const uint64_t blocks = (fps * E4 + BB_BLOCK - 1) / BB_BLOCK;
-    const dim3 grid((unsigned)(blocks > 0x7fffffffull ? 0x7fffffffull : blocks));
-    if (nt) hipLaunchKernelGGL((k_decode_flat_elem<BPS, LV, true>), grid, dim3(BB_BLOCK), 0, st, a, fps);
-    else    hipLaunchKernelGGL((k_decode_flat_elem<BPS, LV, false>), grid, dim3(BB_BLOCK), 0, st, a, fps);
-    return grid.x;
-}
-
-template <int BPS, int LV>
-void launch_flat_span(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
-{
-    if (nt) hipLaunchKernelGGL((k_decode_flat_span<BPS, LV, true, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
-    else    hipLaunchKernelGGL((k_decode_flat_span<BPS, LV, false, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
-}
-
-template <int BPS, int LV>
-void launch_rows_pipe(bool nt, bool aln, int nw, dim3 grid, hipStream_t st, const bb_flat_args &a)
-{
-#define BB_R2(NW, NT, ALN) hipLaunchKernelGGL((k_decode_rows_pipe<BPS, LV, NT, NW, 8, ALN>), grid, dim3(NW * BB_WAVE), 0, st, a)
-#define BB_R(NW) do { if (aln) { if (nt) BB_R2(NW, true, true); else BB_R2(NW, false, true); } \
-                      else     { if (nt) BB_R2(NW, true, false); else BB_R2(NW, false, false); } } while (0)
-    if (nw == 8) BB_R(8); else if (nw == 4) BB_R(4); else BB_R(2);
-#undef BB_R
-#undef BB_R2
-}
-
-template <int BPS, int LV>
-void launch_flat(int om, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
-{
-#define BB_L(OM, NT) hipLaunchKernelGGL((k_decode_flat<BPS, LV, OM, NT>), grid, dim3(BB_BLOCK), 0, st, a)
-    if (om == BB_OUT_FLAT)       { if (nt) BB_L(BB_OUT_FLAT, true);    else BB_L(BB_OUT_FLAT, false); }
-    else if (om == BB_OUT_ROWS4) { if (nt) BB_L(BB_OUT_ROWS4, true);   else BB_L(BB_OUT_ROWS4, false); }
-    else                         { if (nt) BB_L(BB_OUT_SCATTER, true); else BB_L(BB_OUT_SCATTER, false); }
-#undef BB_L
-}
+#if BB_EXP
+#include "bb_exp.inc"
+#endif
 
 } // namespace
 
@@ -399,46 +355,54 @@ int bb_get_encode_thresholds(float h_thr[3])
 int bb_tune(int knob, int value)
 {
     switch (knob) {
-        case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
-        case BB_TUNE_NT_STORES:    g_tune_nt = value;      return BB_OK;
         case BB_TUNE_BLOCKS:       g_tune_blocks = value;  return BB_OK;
-        case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
         case BB_TUNE_TILE_ELEMS:   g_tune_tile_elems = value > 0 ? value : 8192; return BB_OK;
         case BB_TUNE_ENCODE_DIRECT: g_tune_encode_direct = value; return BB_OK;
-        case BB_TUNE_TILES_PER_WAVE: g_tune_tpw = (value >= 1 && value <= 16) ? value : 12; return BB_OK;
-        case BB_TUNE_TILES_PER_WAVE_8BIT: g_tune_tpw8 = (value >= 1 && value <= 32) ? value : 12; return BB_OK;
+        case BB_TUNE_TILES_PER_WAVE:
+            g_tune_rows_tiles = (value >= 1 && value <= 8) ? value : 8;
+#if BB_EXP
+            g_tune_tpw = (value >= 1 && value <= 16) ? value : 12;
+#endif
+            return BB_OK;
         case BB_TUNE_GATHER_BYTES: g_tune_gather_bytes = value > 0 ? value : 8192; return BB_OK;
         case BB_TUNE_TILED_STAGE: g_tune_tiled_stage = value; return BB_OK;
         case BB_TUNE_SEG_TILES: g_tune_seg_tiles = (value >= 1 && value <= 4096) ? value : 0; return BB_OK;
         case BB_TUNE_GATHER_CHUNKS: g_tune_gather_chunks = value > 0 ? value : 32; return BB_OK;
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
-        case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
-        case BB_TUNE_BYTE_LUT: g_tune_byte_lut = value; return BB_OK;
         case BB_TUNE_M4_WIDEN: g_tune_m4_widen = value; return BB_OK;
         case BB_TUNE_M4_TILES: g_tune_m4_tiles = (value >= 1 && value <= BB_M4_TPW) ? value : BB_M4_TPW; return BB_OK;
         case BB_TUNE_LUT_TILES: g_tune_lut_tpw = (value >= 1 && value <= 16) ? value : 4; return BB_OK;
-        case BB_TUNE_LUT_SMALL: g_tune_lut_small = value; return BB_OK;
         case BB_TUNE_SELECT_BYTES:
             if (value < 256 || value > 32768) return BB_EINVAL;
             g_tune_select_bytes = value; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
         case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : value == 128 ? 128 : 0; return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
+#if BB_EXP
+        case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
+        case BB_TUNE_NT_STORES:    g_tune_nt = value;      return BB_OK;
+        case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
+        case BB_TUNE_TILES_PER_WAVE_8BIT: g_tune_tpw8 = (value >= 1 && value <= 32) ? value : 12; return BB_OK;
+        case BB_TUNE_LDS_PAD: g_tune_lds_pad = (value > 0 && value <= 65536) ? value : 0; return BB_OK;
+        case BB_TUNE_BYTE_LUT: g_tune_byte_lut = value; return BB_OK;
+        case BB_TUNE_LUT_SMALL: g_tune_lut_small = value; return BB_OK;
         case BB_TUNE_OUT_STRIPE_W: g_tune_stripe_w = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_OUT_STRIPE_S: g_tune_stripe_s = value > 0 ? value : 0; return BB_OK;
         case BB_TUNE_FRONT_GROUP: g_tune_front_g = (value >= 1 && value <= (1 << 20)) ? value : 2048; return BB_OK;
         case BB_TUNE_FRONT_STEPS: g_tune_front_k = (value >= 1 && value <= (1 << 20)) ? value : 16; return BB_OK;
+#endif
         default: return BB_EINVAL;
     }
 }
 
+#if BB_EXP
 int bb_debug_trace(uint64_t *d_times)
 {
     g_trace = d_times;
     return BB_OK;
 }
 
-// ---- host staging helpers -----------------------------------------------------
+// ---- host staging helpers (measurement only) -----------------------------------
 // A file image that is mapped into the host's address space can be pinned where
 // it lies and handed to the DMA engine, instead of being copied into a pinned
 // buffer by host threads first (staging.py).
@@ -463,6 +427,7 @@ int bb_copy_to_device(void *d_dst, const void *h_src, size_t nbytes, void *strea
     BB_HIP(hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return BB_OK;
 }
+#endif
 
 int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
                  bb_frame_rec *d_recs, size_t nframes, void *stream)
@@ -628,18 +593,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     if (rc) return rc;
     a.nfs = nfs;
     a.ndw = p->payload_nbytes / 4;
-    const uint64_t ntiles = (a.ndw + 63) / 64;
-    // plain kernel: tiles per workgroup.  8-bit samples: 16 (4 KiB in, 16 KiB
-    // out per workgroup) instead of 32: +7 % at 8 GiB, +0-3.5 % at 31 GiB
-    // (profiles/r02ba_exp_int8_seg.log)
-    const int seg_knob = g_tune_seg_tiles.load();
-    const uint64_t seg_plain = seg_knob ? (uint64_t)seg_knob : (p->bps == 8 ? 16u : (uint64_t)BB_SEG_TILES);
-    a.nseg = (ntiles + seg_plain - 1) / seg_plain;
-    // split a frame-slot's tiles evenly over its work items and a work item's
-    // tiles evenly over the four waves (a 10000-byte Mark 5B payload is 40
-    // tiles: 2 items x 20 tiles x 5 per wave, not 32 + 8)
-    a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
-    a.tpw = (a.seg_tiles + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
+    a.nseg = 1; a.seg_tiles = 0; a.tpw = 0;             // (set by the branch that launches)
     a.src0 = p->src0;
     a.src_stride = p->src_stride;
     a.nslot = (uint32_t)p->nslot;
@@ -648,6 +602,13 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     a.fill_re = p->fill_re;
     a.fill_im = p->fill_im;
     a.complex_data = p->complex_data;
+    // an index entry is followed only if its payload lies inside the buffer
+    // (fixed-stride launches were checked above)
+    a.src_lim = src_limit(buf_nbytes, p->payload_nbytes);
+    a.perm = bb_perm_t{0, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = tune_nt();
+#if BB_EXP
     a.nt_loads = g_tune_nt_loads.load();
     a.trace = g_trace.load();
     a.stripe_w = 0;
@@ -659,130 +620,40 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         const uint64_t need = ((uint64_t)a.stripe_w - 1) * a.stripe_s + (nfs + a.stripe_w - 1) / a.stripe_w;
         if (out_elems < need * E) return BB_ERANGE;
     }
+    {
+        const int erc = expd::decode_frames(p, d_src, nframes, a, om, d_out, st);
+        if (erc != 1) return erc;
+    }
+#endif
 
-    const uint64_t nwork = nfs * a.nseg;
+    const uint64_t ntiles = (a.ndw + 63) / 64;
     const uint64_t out_bytes = nfs * E * 4;
-    a.perm = make_perm(nwork, out_bytes);   // (branches that cut the work differently set their own)
-    uint64_t blocks = nwork;
     const int tb = g_tune_blocks.load();
-    if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
-    if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
-    const dim3 grid((unsigned)blocks);
-    hipStream_t st = (hipStream_t)stream;
-    const bool nt = g_tune_nt.load() != 0;
 
-    // Kernel choice.  The default (5) is the persistent pipelined family with
-    // aligned block loads -- except for 8-bit samples with contiguous output:
-    // they read 20 % of their traffic instead of 6 %, and the plain
-    // one-workgroup-per-32-tiles kernel with an uncapped grid is 3-6 % faster
-    // there for every payload size tried (profiles/r01i_exp_int8_v0.log:
-    // 5.34-5.37 -> 5.55-5.67 TB/s int8, 5.10-5.37 -> 5.44-5.58 VDIF 8-bit).
-    // BB_TUNE_TILES_PER_WAVE_8BIT > 16 selects the long pipelined form again.
-    int variant = g_tune_variant.load();
-    if (variant == 5 && p->bps == 8 && om == BB_OUT_FLAT && g_tune_tpw8.load() <= 16)
-        variant = 0;
-    // 4-bit samples (11 % of the traffic is reads): the plain kernel is 3-6 %
-    // ahead as well (profiles/r02t_exp_es.log, r02u_exp_es_elem.log: 5.72-5.82
-    // against 5.43-5.55 TB/s at 4 and 34 GB of output)
-    // -- against the register-select kernel; the byte table kernel with short
-    // work items (k_lut.h) takes 4-bit samples too and is ahead of both
-    if (variant == 5 && p->bps == 4 && om == BB_OUT_FLAT && g_tune_byte_lut.load() == 0) variant = 0;
-    // Mid-size launches: with one or two work items per workgroup the
-    // persistent pipelined kernel (5.1-5.3 TB/s) loses to the plain one
-    // (5.4-5.5); from four items per workgroup on it is at least as fast on
-    // freshly allocated outputs (5.8-5.9 at 2^18 frames, 6.2-6.6 beyond) --
-    // how fast depends on the allocation, the plain kernel does 5.4-5.7
-    // everywhere (profiles/r01i_exp_launch_size.log, r01i_exp_launch_fresh.log).
-    // An explicit BB_TUNE_BLOCKS keeps the pipelined kernel (experiments).
-    // (round 2: with the striped work order the two are equal there --
-    // 5.60 / 5.61 TB/s at 2^16 frames, profiles/r02e_exp_order.log -- and the
-    // fallback is gone)
-
-    if (variant == 14 && om == BB_OUT_FLAT) {
-        // the fill-shaped decode (k_front.h)
-        unsigned gx;
-        switch (p->bps) {
-            case 1: gx = launch_flat_elem<1, BB_LV_REG>(nt, st, a); break;
-            case 2: gx = launch_flat_elem<2, BB_LV_REG>(nt, st, a); break;
-            case 4: gx = launch_flat_elem<4, BB_LV_LDS>(nt, st, a); break;
-            default:
-                if (p->coder == BB_CODER_INT) gx = launch_flat_elem<8, BB_LV_INT8>(nt, st, a);
-                else                          gx = launch_flat_elem<8, BB_LV_LDS>(nt, st, a);
-                break;
-        }
-        BB_NOTE("k_decode_flat_elem<%d,%s,%s> grid %u", p->bps, lv_name(p->bps, p->coder), nt ? "nt" : "plain", gx);
-        BB_HIP(hipGetLastError());
-        return BB_OK;
-    }
-
-    if (variant >= 10 && variant <= 12 && om == BB_OUT_FLAT) {
-        // one pass, striped (k_front.h): 10 = 2 tiles per wave, 11 = 4, 12 = 8
-        // (16 ran at 3.5-4 TB/s, profiles/r02t_exp_es.log, and is gone)
-        unsigned gx;
-        switch (variant) {
-            case 10: gx = launch_flat_es_any<2>(p->bps, p->coder, nt, st, a); break;
-            case 11: gx = launch_flat_es_any<4>(p->bps, p->coder, nt, st, a); break;
-            default: gx = launch_flat_es_any<8>(p->bps, p->coder, nt, st, a); break;
-        }
-        BB_NOTE("k_decode_flat_es<%d,%s,%s,%d> grid %u", p->bps, lv_name(p->bps, p->coder), nt ? "nt" : "plain",
-                variant == 10 ? 2 : variant == 11 ? 4 : 8, gx);
-        BB_HIP(hipGetLastError());
-        return BB_OK;
-    }
-
-    if (variant >= 6 && variant <= 9 && om == BB_OUT_FLAT) {
-        // explicit write front (k_front.h): 6 = 4 waves x 1 tile, 7 = 4 x 2, 8 = 2 x 4, 9 = 4 x 4
-        unsigned gx;
-        switch (variant) {
-            case 6:  gx = launch_flat_front_any<4, 1>(p->bps, p->coder, nt, st, a); break;
-            case 7:  gx = launch_flat_front_any<4, 2>(p->bps, p->coder, nt, st, a); break;
-            case 8:  gx = launch_flat_front_any<2, 4>(p->bps, p->coder, nt, st, a); break;
-            default: gx = launch_flat_front_any<4, 4>(p->bps, p->coder, nt, st, a); break;
-        }
-        BB_NOTE("k_decode_flat_front<%d,%s,%s,%s> grid %u G %d K %d", p->bps, lv_name(p->bps, p->coder),
-                nt ? "nt" : "plain", variant == 6 ? "4,1" : variant == 7 ? "4,2" : variant == 8 ? "2,4" : "4,4",
-                gx, g_tune_front_g.load(), g_tune_front_k.load());
-        BB_HIP(hipGetLastError());
-        return BB_OK;
-    }
-
-    if (variant == 1 && p->bps == 2 && om == BB_OUT_FLAT) {
-        uint64_t b2 = nfs;
-        if (tb > 0 && b2 > (uint64_t)tb) b2 = (uint64_t)tb;
-        if (b2 > 0x7fffffffull) b2 = 0x7fffffffull;
-        if (nt) hipLaunchKernelGGL(k_decode_flat2_bytes<true>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
-        else    hipLaunchKernelGGL(k_decode_flat2_bytes<false>, dim3((unsigned)b2), dim3(BB_BLOCK), 0, st, a);
-        BB_NOTE("k_decode_flat2_bytes<%s> grid %u", nt ? "nt" : "plain", (unsigned)b2);
-        BB_HIP(hipGetLastError());
-        return BB_OK;
-    }
-
-    // rows kernel or LDS gather for chunks of at least four floats: with the
-    // default knob (32) up to four thread slots always gather (one wave per
-    // slot leaves the rows kernel with 2-4 waves per workgroup: 5.6 / 6.1 TB/s
-    // against 6.4 / 6.3), eight or more only below 32 floats
-    // (profiles/r01i_exp_interleave_thr.log)
-    // -- and, since the staging rewrite of round 2, 2-bit launches of 64 GiB of
-    // output and more whatever the chunk: +1-3.5 % in every cell of 8-64 slots x
-    // 32-256 floats at 8 GiB of input (profiles/r02at_exp_rows_vs_gather_2bit_8GiB.log);
-    // smaller launches and other sample widths show no clear winner and stay
+    // 1. Thread interleave through the LDS gather (k_gather.h): narrow chunks
+    // (a thread's sample is less than 128 bytes of output -- through the rows
+    // kernel, whose waves each write their own 16..64-byte pieces of every row,
+    // chunks of 4 / 8 / 16 floats ran at 0.55 / 1.15 / 3.45 TB/s,
+    // profiles/r01i_exp_interleave.log), any chunk with up to four thread
+    // slots (one wave per slot leaves the rows kernel with 2-4 waves per
+    // workgroup: 5.6 / 6.1 TB/s against 6.4 / 6.3,
+    // profiles/r01i_exp_interleave_thr.log) and, since the staging rewrite of
+    // round 2, 2-bit launches of 64 GiB of output and more whatever the chunk
+    // (+1-3.5 % in every cell of 8-64 slots x 32-256 floats at 8 GiB of input,
+    // profiles/r02at_exp_rows_vs_gather_2bit_8GiB.log; smaller launches and
+    // other sample widths show no clear winner and stay with the rows kernel)
     const int gchunks = g_tune_gather_chunks.load();
     const bool big2 = p->bps == 2 && p->chunk <= 256 && out_bytes >= (64ull << 30);
     const bool gather_wide = om == BB_OUT_ROWS4
         && (gchunks == 32 ? (p->nslot <= 4 || p->chunk < 32 || big2) : p->chunk < gchunks);
-    if ((om == BB_OUT_SCATTER || gather_wide)
-        && d_src && variant >= 2
+    if ((om == BB_OUT_SCATTER || gather_wide) && d_src
         && (size_t)p->nslot * 528 + 1024 + 64 <= 48 * 1024) {
-        // narrow chunks (a thread's sample is less than 128 bytes of output):
-        // assemble output rows in LDS (k_gather.h).  Through the rows kernel,
-        // whose waves each write their own 16..64-byte pieces of every row,
-        // chunks of 4 / 8 / 16 floats ran at 0.55 / 1.15 / 3.45 TB/s
-        // (profiles/r01i_exp_interleave.log)
         bb_gather_args ga;
         ga.within = nullptr; ga.nsel = 0; ga.mag_row = ga.mag_sel = 0;
         ga.buf = a.buf; ga.src = d_src; ga.out = d_out; ga.tab = a.tab;
         ga.nframes = nframes; ga.ndw = a.ndw;
         ga.nslot = a.nslot; ga.chunk = a.chunk; ga.lchunk = a.lchunk;
+        ga.src_lim = a.src_lim;
         // bytes staged per work item: 16 KiB, 4 KiB for 1-bit data whose items
         // expand 32-fold (profiles/r01i_exp_interleave_gb.log); knob value 8192 = this default
         size_t gbytes = (size_t)g_tune_gather_bytes.load();
@@ -799,7 +670,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             ga.lrow = -1;
             if ((rl & (rl - 1)) == 0) { ga.lrow = 0; while ((1u << ga.lrow) < rl) ++ga.lrow; }
         }
-        ga.aligned = variant >= 5 ? 1 : 0;
+        ga.aligned = 1;
         const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024;
         // persistent grid: a workgroup walks about five work items (8 KiB of
         // payload each); one workgroup per item costs 15 %, a few thousand
@@ -810,27 +681,18 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         if (gb > gcap) gb = gcap;
         if (gb > 0x7fffffffull) gb = 0x7fffffffull;
         const dim3 gg((unsigned)gb);
-        switch (p->bps) {
-            case 1: launch_gather<1, BB_LV_REG>(nt, gg, lds, st, ga); break;
-            case 2: launch_gather<2, BB_LV_REG>(nt, gg, lds, st, ga); break;
-            case 4: launch_gather<4, BB_LV_LDS>(nt, gg, lds, st, ga); break;
-            default:
-                if (p->coder == BB_CODER_INT) launch_gather<8, BB_LV_INT8>(nt, gg, lds, st, ga);
-                else                          launch_gather<8, BB_LV_LDS>(nt, gg, lds, st, ga);
-                break;
-        }
+        launch_gather(p->bps, p->coder, nt, gg, lds, st, ga);
         BB_NOTE("k_decode_gather<%d,%s,%s,%s> grid %u gtiles %u lds %zu", p->bps, lv_name(p->bps, p->coder),
                 nt ? "nt" : "plain", ga.lchunk >= 2 ? "wide" : "narrow", gg.x, ga.gtiles, lds);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
 
-    if (om == BB_OUT_ROWS4 && variant >= 3) {
-        // thread interleave with wide chunks: one wave per thread slot, all
-        // waves on the same 8 tiles (k_decode_rows_pipe)
+    if (om == BB_OUT_ROWS4) {
+        // 2. thread interleave with wide chunks: one wave per thread slot, all
+        // waves on the same (up to 8) tiles (k_decode_rows_pipe)
         const int nw = p->nslot >= 8 ? 8 : (p->nslot >= 4 ? 4 : 2);
-        const bool aln = variant >= 5;
-        const uint64_t seg_max = g_tune_tpw.load() < 8 ? (uint64_t)g_tune_tpw.load() : 8;
+        const uint64_t seg_max = (uint64_t)g_tune_rows_tiles.load();
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
         a.tpw = a.seg_tiles;
@@ -840,179 +702,89 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
-        switch (p->bps) {
-            case 1: launch_rows_pipe<1, BB_LV_REG>(nt, aln, nw, g2, st, a); break;
-            case 2: launch_rows_pipe<2, BB_LV_REG>(nt, aln, nw, g2, st, a); break;
-            case 4: launch_rows_pipe<4, BB_LV_LDS>(nt, aln, nw, g2, st, a); break;
-            default:
-                if (p->coder == BB_CODER_INT) launch_rows_pipe<8, BB_LV_INT8>(nt, aln, nw, g2, st, a);
-                else                          launch_rows_pipe<8, BB_LV_LDS>(nt, aln, nw, g2, st, a);
-                break;
-        }
-        BB_NOTE("k_decode_rows_pipe<%d,%s,%s,%d,8,%s> grid %u", p->bps, lv_name(p->bps, p->coder),
-                nt ? "nt" : "plain", nw, aln ? "aligned" : "plain-loads", g2.x);
+        launch_rows_pipe(p->bps, p->coder, nt, nw, g2, st, a);
+        BB_NOTE("k_decode_rows_pipe<%d,%s,%s,%d,8,aligned> grid %u", p->bps, lv_name(p->bps, p->coder),
+                nt ? "nt" : "plain", nw, g2.x);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
 
-    if (om == BB_OUT_FLAT && variant == 4 && a.ndw >= 64 * 16) {
-        // contiguous output: cut the work in output space (k_decode_flat_span),
-        // 2 waves x 16 tiles per item whatever the frame size
-        const uint64_t tiles_all = (nfs * a.ndw + 63) / 64;
-        uint64_t b2 = (tiles_all + 31) / 32;
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
-        if (b2 > cap) b2 = cap;
-        const dim3 g2((unsigned)b2);
-        switch (p->bps) {
-            case 1: launch_flat_span<1, BB_LV_REG>(nt, g2, st, a); break;
-            case 2: launch_flat_span<2, BB_LV_REG>(nt, g2, st, a); break;
-            case 4: launch_flat_span<4, BB_LV_LDS>(nt, g2, st, a); break;
-            default:
-                if (p->coder == BB_CODER_INT) launch_flat_span<8, BB_LV_INT8>(nt, g2, st, a);
-                else                          launch_flat_span<8, BB_LV_LDS>(nt, g2, st, a);
-                break;
-        }
-        BB_NOTE("k_decode_flat_span<%d,%s,%s,2,16> grid %u", p->bps, lv_name(p->bps, p->coder),
-                nt ? "nt" : "plain", g2.x);
-        BB_HIP(hipGetLastError());
-        return BB_OK;
-    }
-
-    if (variant >= 2) {
-        // persistent pipelined form.  Geometry (waves per workgroup x tiles
-        // per wave) is chosen so that a wave writes a long contiguous run:
-        // 2 waves x up to 12 tiles (an 8000-byte payload becomes two items of
-        // 2 x 8 tiles = 32 KiB runs; with the large grid that beats 2 x 16 by
-        // 1.5 %, profiles/r01g_exp_tpw.log).  Variant 2 keeps the
-        // 4 x 8 geometry; 2 x 32 tiles was tried for 8-bit data and lost 27 %.
-        const bool wide = variant >= 3;
-        const int nw = wide ? 2 : 4;
-        const bool aln = wide && om == BB_OUT_FLAT && variant == 5;
-        const int tpw8 = g_tune_tpw8.load();
-        const bool long8 = aln && p->bps == 8 && tpw8 > 16;
-        // the byte table kernel (1-, 2- and 4-bit contiguous output) is at its best
-        // with SHORT work items, one per workgroup: 2 waves x 4 tiles (2 KiB
-        // in, 32 KiB out) on an uncapped grid, +2-4 % over 2 x 8-12 tiles on
-        // 131072 persistent workgroups at every size from 2 to 8 GiB, for
-        // 8000-, 8192- and 10000-byte payloads (profiles/r02ao_exp_tpw_grid*.log)
-        // -- many small workgroups in flight again overlap loads and stores
-        // better than a register pipeline, as for the 8-bit kernels
-        const bool lut = aln && p->bps <= 4 && g_tune_byte_lut.load() != 0;
-        // (what counts is the OUTPUT of a work item, 32 KiB: 2 / 4 / 8 tiles per
-        // wave for 1- / 2- / 4-bit samples -- 1-bit 6.58 -> 6.86 TB/s against 4
-        // tiles, 4-bit 5.28 -> 6.62 and +7 % over the plain kernel it used before,
-        // profiles/r02ar_exp_1bit_items.log, r02ar_exp_4bit_lut.log)
+    if (om == BB_OUT_FLAT && p->bps <= 4) {
+        // 3. contiguous 1-, 2- and 4-bit output: the byte table kernel (k_lut.h)
+        // with SHORT work items, one per workgroup -- 32 KiB of OUTPUT each: 2
+        // waves x 2 / 4 / 8 tiles for 1- / 2- / 4-bit samples, grid up to 2^23.
+        // +2-4 % over 2 x 8-12 tiles on 131072 persistent workgroups at every
+        // size from 2 to 8 GiB, for 8000-, 8192- and 10000-byte payloads
+        // (profiles/r02ao_exp_tpw_grid*.log): many small workgroups in flight
+        // overlap loads and stores better than a register pipeline, as for the
+        // 8-bit kernels.  1-bit 6.58 -> 6.86 TB/s against 4 tiles, 4-bit 5.28 ->
+        // 6.62 and +7 % over the plain kernel it used before
+        // (profiles/r02ar_exp_1bit_items.log, r02ar_exp_4bit_lut.log)
         int lut_tiles = g_tune_lut_tpw.load() * p->bps / 2;
         lut_tiles = lut_tiles < 1 ? 1 : lut_tiles > 16 ? 16 : lut_tiles;
-        const int tpw_max = long8 ? (tpw8 > 32 ? 32 : tpw8) : lut ? lut_tiles
-                            : wide ? g_tune_tpw.load() : 8;
-        const uint64_t seg_max = (uint64_t)nw * tpw_max;
+        const uint64_t seg_max = 2ull * (uint64_t)lut_tiles;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
-        a.tpw = (a.seg_tiles + nw - 1) / nw;
+        a.tpw = (a.seg_tiles + 1) / 2;
         uint64_t b2 = nfs * a.nseg;
         a.perm = make_perm(b2, out_bytes);
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : lut ? (1ull << 23) : (uint64_t)(wide ? BB_GRID_CAP : 4096);
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
-        if (!wide) {
-            switch (p->bps) {
-                case 1: launch_flat_pipe<1, BB_LV_REG, 4, 8>(om, nt, g2, st, a); break;
-                case 2: launch_flat_pipe<2, BB_LV_REG, 4, 8>(om, nt, g2, st, a); break;
-                case 4: launch_flat_pipe<4, BB_LV_LDS, 4, 8>(om, nt, g2, st, a); break;
-                default:
-                    if (p->coder == BB_CODER_INT) launch_flat_pipe<8, BB_LV_INT8, 4, 8>(om, nt, g2, st, a);
-                    else                          launch_flat_pipe<8, BB_LV_LDS, 4, 8>(om, nt, g2, st, a);
-                    break;
-            }
-        } else if (long8) {
-            if (p->coder == BB_CODER_INT) launch_flat_aln32<8, BB_LV_INT8>(nt, g2, st, a);
-            else                          launch_flat_aln32<8, BB_LV_LDS>(nt, g2, st, a);
-        } else if (lut) {
-            // byte table in LDS instead of the register level select (k_lut.h)
-            if (p->bps == 1) launch_flat_lut<1>(nt, g2, st, a);
-            else if (p->bps == 2) launch_flat_lut<2>(nt, g2, st, a);
-            else launch_flat_lut<4>(nt, g2, st, a);
-            BB_NOTE("k_decode_flat_lut<%d,%s,2,%d> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain",
-                    (a.tpw <= 4 && g_tune_lut_small.load() != 0) ? 4 : 16, g2.x, a.tpw);
-            BB_HIP(hipGetLastError());
-            return BB_OK;
-        } else if (aln) {
-            // aligned 256-byte block loads (k_decode_flat_aln)
-            switch (p->bps) {
-                case 1: launch_flat_aln<1, BB_LV_REG>(nt, g2, st, a); break;
-                case 2: launch_flat_aln<2, BB_LV_REG>(nt, g2, st, a); break;
-                case 4: launch_flat_aln<4, BB_LV_LDS>(nt, g2, st, a); break;
-                default:
-                    if (p->coder == BB_CODER_INT) launch_flat_aln<8, BB_LV_INT8>(nt, g2, st, a);
-                    else                          launch_flat_aln<8, BB_LV_LDS>(nt, g2, st, a);
-                    break;
-            }
-        } else {
-            switch (p->bps) {
-                case 1: launch_flat_pipe<1, BB_LV_REG, 2, 16>(om, nt, g2, st, a); break;
-                case 2: launch_flat_pipe<2, BB_LV_REG, 2, 16>(om, nt, g2, st, a); break;
-                case 4: launch_flat_pipe<4, BB_LV_LDS, 2, 16>(om, nt, g2, st, a); break;
-                default:
-                    if (p->coder == BB_CODER_INT) launch_flat_pipe<8, BB_LV_INT8, 2, 16>(om, nt, g2, st, a);
-                    else                          launch_flat_pipe<8, BB_LV_LDS, 2, 16>(om, nt, g2, st, a);
-                    break;
-            }
-        }
-        BB_NOTE("%s<%d,%s,%s,%d,%d> out-mode %d grid %u tiles/wave %u",
-                !wide ? "k_decode_flat_pipe" : (long8 || aln) ? "k_decode_flat_aln" : "k_decode_flat_pipe",
-                p->bps, lv_name(p->bps, p->coder), nt ? "nt" : "plain", nw, long8 ? 32 : wide ? 16 : 8,
-                om, g2.x, a.tpw);
+        launch_flat_lut(p->bps, nt, g2, st, a);
+        BB_NOTE("k_decode_flat_lut<%d,%s,2,16> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", g2.x, a.tpw);
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
 
-    switch (p->bps) {
-        case 1: launch_flat<1, BB_LV_REG>(om, nt, grid, st, a); break;
-        case 2: launch_flat<2, BB_LV_REG>(om, nt, grid, st, a); break;
-        case 4: launch_flat<4, BB_LV_LDS>(om, nt, grid, st, a); break;
-        case 8:
-            if (p->coder == BB_CODER_INT) launch_flat<8, BB_LV_INT8>(om, nt, grid, st, a);
-            else                          launch_flat<8, BB_LV_LDS>(om, nt, grid, st, a);
-            break;
-        default: return BB_ENOTSUP;
+    // 4. the plain kernel (k_decode_flat): one workgroup of four waves per work
+    // item, loads and stores in the same iteration, uncapped grid.  8-bit
+    // samples with contiguous output read 20 % of their traffic instead of 6 %,
+    // and many small workgroups overlap that better than a register pipeline
+    // (profiles/r01i_exp_int8_v0.log: 5.34-5.37 -> 5.55-5.67 TB/s int8,
+    // 5.10-5.37 -> 5.44-5.58 VDIF 8-bit); 16 tiles per workgroup (4 KiB in, 16
+    // KiB out) instead of 32: +7 % at 8 GiB, +0-3.5 % at 31 GiB
+    // (profiles/r02ba_exp_int8_seg.log).  Also the general fallback: thread
+    // interleave without an index, or with more slots than the gather stages.
+    {
+        const int seg_knob = g_tune_seg_tiles.load();
+        const uint64_t seg_plain = seg_knob ? (uint64_t)seg_knob : (p->bps == 8 ? 16u : (uint64_t)BB_SEG_TILES);
+        a.nseg = (ntiles + seg_plain - 1) / seg_plain;
+        // split a frame-slot's tiles evenly over its work items and a work item's
+        // tiles evenly over the four waves (a 10000-byte Mark 5B payload is 40
+        // tiles: 2 items x 20 tiles x 5 per wave, not 32 + 8)
+        a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
+        a.tpw = (a.seg_tiles + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
+        const uint64_t nwork = nfs * a.nseg;
+        a.perm = make_perm(nwork, out_bytes);
+        uint64_t blocks = nwork;
+        if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
+        if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
+        const dim3 grid((unsigned)blocks);
+        launch_flat(p->bps, p->coder, om, nt, grid, st, a);
+        BB_NOTE("k_decode_flat<%d,%s,%d,%s> grid %u", p->bps, lv_name(p->bps, p->coder), om,
+                nt ? "nt" : "plain", grid.x);
+        BB_HIP(hipGetLastError());
+        return BB_OK;
     }
-    BB_NOTE("k_decode_flat<%d,%s,%d,%s> grid %u", p->bps, lv_name(p->bps, p->coder), om,
-            nt ? "nt" : "plain", grid.x);
-    BB_HIP(hipGetLastError());
-    return BB_OK;
 }
 
-int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
-                            const int64_t *d_src, size_t nframes,
-                            const bb_decode_params *p,
-                            const int32_t *d_within, int nwithin,
-                            float *d_out, size_t out_elems, void *stream)
+// Argument checks and work geometry of bb_decode_frames_select, shared with
+// bb_decode_frames_select_check (no device is touched here).
+struct select_geom { uint32_t lchunk, gt; uint64_t R, ntiles; size_t lds; };
+
+static int select_geometry(const bb_decode_params *p, int nwithin, select_geom *g)
 {
     if (!p) return BB_EINVAL;
     if (!coder_supported(p->coder, p->bps)) return BB_ENOTSUP;
-    if (nframes == 0) return BB_OK;
-    if (!d_buf || !d_out || !d_src || !d_within) return BB_EINVAL;
     if (p->nslot < 1 || p->chunk < 1 || nwithin < 1 || nwithin > 4096) return BB_EINVAL;
     if (p->payload_nbytes == 0 || (p->payload_nbytes & 3)) return BB_EINVAL;
-    if (((uintptr_t)d_buf & 3) || ((uintptr_t)d_out & 3)) return BB_EINVAL;
     if (p->chunk & (p->chunk - 1)) return BB_ENOTSUP;
     uint32_t lchunk = 0;
     while ((1u << lchunk) < (uint32_t)p->chunk) ++lchunk;
     const uint64_t E = p->payload_nbytes * 8 / (uint64_t)p->bps;
     if (E % (uint64_t)p->chunk) return BB_EINVAL;
-    const uint64_t R = E >> lchunk;
-    if (out_elems < (uint64_t)nframes * R * (uint64_t)p->nslot * (uint64_t)nwithin) return BB_ERANGE;
-    int rc = ensure_init();
-    if (rc) return rc;
-    const int lb = log2_bps(p->bps);
-    bb_gather_args ga;
-    ga.buf = (const uint8_t *)d_buf; ga.src = d_src; ga.out = d_out;
-    rc = device_levels(p->coder, lb, &ga.tab);
-    if (rc) return rc;
-    ga.nframes = nframes; ga.ndw = p->payload_nbytes / 4;
-    ga.nslot = (uint32_t)p->nslot; ga.chunk = (uint32_t)p->chunk; ga.lchunk = lchunk;
-    const uint64_t ntiles = (ga.ndw + 63) / 64;
+    const uint64_t ntiles = (p->payload_nbytes / 4 + 63) / 64;
     // stage at most 16 KiB of payload per work item (all slots together) and
     // at most 16 tiles of a slot -- a single slot is fastest with 4 KiB per
     // item, eight with 16 KiB (profiles/r02ac_exp_select.log) -- in groups of
@@ -1025,6 +797,43 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
     // a group's elements must be whole rows: gt * 2048 / bps elements, chunk a power of two
     while (gt > 1 && ((uint64_t)gt * (2048 / p->bps)) % (uint64_t)p->chunk) --gt;
     if (((uint64_t)gt * (2048 / p->bps)) % (uint64_t)p->chunk) return BB_ENOTSUP;
+    const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024 + (size_t)nwithin * 4;
+    if (lds > 64 * 1024) return BB_ENOTSUP;
+    g->lchunk = lchunk; g->gt = gt; g->R = E >> lchunk; g->ntiles = ntiles; g->lds = lds;
+    return BB_OK;
+}
+
+int bb_decode_frames_select_check(const bb_decode_params *p, int nwithin)
+{
+    select_geom g;
+    return select_geometry(p, nwithin, &g);
+}
+
+int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
+                            const int64_t *d_src, size_t nframes,
+                            const bb_decode_params *p,
+                            const int32_t *d_within, int nwithin,
+                            float *d_out, size_t out_elems, void *stream)
+{
+    select_geom g;
+    int rc = select_geometry(p, nwithin, &g);
+    if (rc) return rc;
+    if (nframes == 0) return BB_OK;
+    if (!d_buf || !d_out || !d_src || !d_within) return BB_EINVAL;
+    if (((uintptr_t)d_buf & 3) || ((uintptr_t)d_out & 3)) return BB_EINVAL;
+    const uint32_t lchunk = g.lchunk, gt = g.gt;
+    const uint64_t R = g.R, ntiles = g.ntiles;
+    if (out_elems < (uint64_t)nframes * R * (uint64_t)p->nslot * (uint64_t)nwithin) return BB_ERANGE;
+    rc = ensure_init();
+    if (rc) return rc;
+    const int lb = log2_bps(p->bps);
+    bb_gather_args ga;
+    ga.buf = (const uint8_t *)d_buf; ga.src = d_src; ga.out = d_out;
+    rc = device_levels(p->coder, lb, &ga.tab);
+    if (rc) return rc;
+    ga.nframes = nframes; ga.ndw = p->payload_nbytes / 4;
+    ga.nslot = (uint32_t)p->nslot; ga.chunk = (uint32_t)p->chunk; ga.lchunk = lchunk;
+    ga.src_lim = src_limit(buf_nbytes, p->payload_nbytes);
     ga.gtiles = gt;
     ga.ngroup = (uint32_t)((ntiles + gt - 1) / gt);
     ga.fill_re = p->fill_re; ga.fill_im = p->fill_im; ga.complex_data = p->complex_data;
@@ -1038,8 +847,7 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
         ga.mag_row = (drow > 1 && qmax * drow < (1ull << 32)) ? (uint32_t)((1ull << 32) / drow + 1) : 0;
         ga.mag_sel = (dsel > 1 && qmax * dsel < (1ull << 32)) ? (uint32_t)((1ull << 32) / dsel + 1) : 0;
     }
-    const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024 + (size_t)nwithin * 4;
-    if (lds > 64 * 1024) return BB_ENOTSUP;
+    const size_t lds = g.lds;
     uint64_t gb = (uint64_t)nframes * ga.ngroup;
     ga.perm = make_perm(gb, (uint64_t)nframes * R * p->nslot * nwithin * 4);
     const int tb = g_tune_blocks.load();
@@ -1047,26 +855,14 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
     if (gb > gcap) gb = gcap;
     const dim3 gg((unsigned)gb);
     hipStream_t st = (hipStream_t)stream;
-    const bool nt = g_tune_nt.load() != 0;
+    const bool nt = tune_nt();
     // float4 stores when every work item's output starts on a 16-byte boundary
     // and is a multiple of four floats: whole frame sets and whole groups are
     const uint64_t row_floats = (uint64_t)p->nslot * (uint64_t)nwithin;
     const uint64_t group_rows = ((uint64_t)gt * (2048 / p->bps)) >> lchunk;
     const bool v4 = ((R * row_floats) % 4 == 0) && ((group_rows * row_floats) % 4 == 0)
                     && !((uintptr_t)d_out & 15);
-#define BB_GS(B, L) do { if (v4) { if (nt) hipLaunchKernelGGL((k_decode_gather_select<B, L, true, true>), gg, dim3(BB_BLOCK), lds, st, ga); \
-                                   else    hipLaunchKernelGGL((k_decode_gather_select<B, L, false, true>), gg, dim3(BB_BLOCK), lds, st, ga); } \
-                         else { if (nt) hipLaunchKernelGGL((k_decode_gather_select<B, L, true, false>), gg, dim3(BB_BLOCK), lds, st, ga); \
-                                else    hipLaunchKernelGGL((k_decode_gather_select<B, L, false, false>), gg, dim3(BB_BLOCK), lds, st, ga); } } while (0)
-    switch (p->bps) {
-        case 1: BB_GS(1, BB_LV_REG); break;
-        case 2: BB_GS(2, BB_LV_REG); break;
-        case 4: BB_GS(4, BB_LV_LDS); break;
-        default:
-            if (p->coder == BB_CODER_INT) BB_GS(8, BB_LV_INT8); else BB_GS(8, BB_LV_LDS);
-            break;
-    }
-#undef BB_GS
+    launch_gather_select(p->bps, p->coder, nt, v4, gg, lds, st, ga);
     BB_NOTE("k_decode_gather_select<%d,%s,%s,%s> grid %u gtiles %u select %d of %d", p->bps, lv_name(p->bps, p->coder),
             nt ? "nt" : "plain", v4 ? "float4" : "scalar", gg.x, gt, nwithin, p->chunk);
     BB_HIP(hipGetLastError());
@@ -1182,7 +978,7 @@ static bool m4_widen(const bb_mark4_decode_params *p, int nout, bb_mark4_decode_
 
 // shared by bb_decode_mark4 (nout = ntrack / 2, pipelined kernel) and
 // bb_decode_mark4_select (any nout, LDS-staged kernel); arguments are checked
-static int m4_decode(const void *d_buf, const int64_t *d_src, size_t nframes,
+static int m4_decode(const void *d_buf, size_t buf_nbytes, const int64_t *d_src, size_t nframes,
                      const bb_mark4_decode_params *p_in, int nout_in, bool select,
                      float *d_out, void *stream)
 {
@@ -1213,10 +1009,12 @@ static int m4_decode(const void *d_buf, const int64_t *d_src, size_t nframes,
     memcpy(a.mag_bit, p->mag_bit, (size_t)nout);
     a.fill = p->fill;
     a.hi = h_levels[BB_CODER_VDIF][1][3];
+    // (the unit's size in bytes is the same before and after widening)
+    a.src_lim = src_limit(buf_nbytes, p_in->nwords * ((uint64_t)p_in->ntrack / 8));
     uint64_t blocks = (uint64_t)nframes * a.nseg;
     a.perm = make_perm(blocks, (uint64_t)nframes * E * 4);
     hipStream_t st = (hipStream_t)stream;
-    const bool nt = g_tune_nt.load() != 0;
+    const bool nt = tune_nt();
     const dim3 block(BB_BLOCK);
     if (!select) {
         const int tb = g_tune_blocks.load();
@@ -1225,8 +1023,8 @@ static int m4_decode(const void *d_buf, const int64_t *d_src, size_t nframes,
         const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
         if (blocks > cap) blocks = cap;
         const dim3 grid((unsigned)blocks);
-#define BB_M4(N) do { if (nt) hipLaunchKernelGGL((k_decode_mark4<N, true>), grid, block, 0, st, a); \
-                      else    hipLaunchKernelGGL((k_decode_mark4<N, false>), grid, block, 0, st, a); } while (0)
+#define BB_M4(N) with_nt(nt, [&](auto NT) { \
+            hipLaunchKernelGGL((k_decode_mark4<N, decltype(NT)::value>), grid, block, 0, st, a); })
         switch (p->ntrack) {
             case 16: BB_M4(16); break;
             case 32: BB_M4(32); break;
@@ -1240,11 +1038,9 @@ static int m4_decode(const void *d_buf, const int64_t *d_src, size_t nframes,
         const dim3 grid((unsigned)blocks);
         // float4 stores need every unit to start on a 16-byte boundary
         const bool v4 = (E % 4 == 0) && (((uintptr_t)d_out & 15) == 0);
-#define BB_M4S(N) do { \
-        if (nt && v4)       hipLaunchKernelGGL((k_decode_mark4_select<N, true, true>), grid, block, 0, st, a, (uint32_t)nout); \
-        else if (nt)        hipLaunchKernelGGL((k_decode_mark4_select<N, true, false>), grid, block, 0, st, a, (uint32_t)nout); \
-        else if (v4)        hipLaunchKernelGGL((k_decode_mark4_select<N, false, true>), grid, block, 0, st, a, (uint32_t)nout); \
-        else                hipLaunchKernelGGL((k_decode_mark4_select<N, false, false>), grid, block, 0, st, a, (uint32_t)nout); } while (0)
+#define BB_M4S(N) with_nt(nt, [&](auto NT) { \
+        if (v4) hipLaunchKernelGGL((k_decode_mark4_select<N, decltype(NT)::value, true>), grid, block, 0, st, a, (uint32_t)nout); \
+        else    hipLaunchKernelGGL((k_decode_mark4_select<N, decltype(NT)::value, false>), grid, block, 0, st, a, (uint32_t)nout); })
         switch (p->ntrack) {
             case 16: BB_M4S(16); break;
             case 32: BB_M4S(32); break;
@@ -1289,7 +1085,7 @@ int bb_decode_mark4(const void *d_buf, size_t buf_nbytes,
     if (nframes == 0) return BB_OK;
     const int rc = m4_check(d_buf, buf_nbytes, d_src, nframes, p, p->ntrack / 2, d_out, out_elems, 16);
     if (rc) return rc;
-    return m4_decode(d_buf, d_src, nframes, p, p->ntrack / 2, false, d_out, stream);
+    return m4_decode(d_buf, buf_nbytes, d_src, nframes, p, p->ntrack / 2, false, d_out, stream);
 }
 
 int bb_decode_mark4_select(const void *d_buf, size_t buf_nbytes,
@@ -1303,7 +1099,7 @@ int bb_decode_mark4_select(const void *d_buf, size_t buf_nbytes,
     if (nframes == 0) return BB_OK;
     const int rc = m4_check(d_buf, buf_nbytes, d_src, nframes, p, nout, d_out, out_elems, 4);
     if (rc) return rc;
-    return m4_decode(d_buf, d_src, nframes, p, nout, true, d_out, stream);
+    return m4_decode(d_buf, buf_nbytes, d_src, nframes, p, nout, true, d_out, stream);
 }
 
 int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
@@ -1350,6 +1146,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     a.nchan = (uint32_t)p->nchan;
     a.fill_re = p->fill_re;
     a.fill_im = p->fill_im;
+    a.src_lim = src_limit(buf_nbytes, payload);
     const uint64_t T = p->ntime, np_ = (uint64_t)p->npol, nc = (uint64_t)p->nchan;
     switch (p->layout) {
         case BB_LAYOUT_GUPPI_CF: a.tb = T ? T : 1; a.sh = 0; a.st = np_; a.sp = 1; a.sc = T * np_; break;
@@ -1357,7 +1154,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
         default:                 a.tb = T ? T : 1; a.sh = 0; a.st = ncs * np_; a.sp = 1; a.sc = np_; break;
     }
     hipStream_t st = (hipStream_t)stream;
-    const bool nt = g_tune_nt.load() != 0;
+    const bool nt = tune_nt();
     const int tb = g_tune_blocks.load();
     // Fast form (k_xpose.h) for the common geometry: every input run 16-byte
     // aligned, at least 32 channels.  Fixed stride only (offsets from an index
@@ -1395,10 +1192,9 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
             const uint64_t cap = tb > 0 ? (uint64_t)tb : 0x7fffffffull;
             if (blocks > cap) blocks = cap;
             const dim3 grid((unsigned)blocks), block(BB_BLOCK);
-#define BB_XP(L) do { if (xrows == 64) { if (nt) hipLaunchKernelGGL((k_decode_i8_xpose<L, true, 64>), grid, block, 0, st, a); \
-                                         else    hipLaunchKernelGGL((k_decode_i8_xpose<L, false, 64>), grid, block, 0, st, a); } \
-                      else { if (nt) hipLaunchKernelGGL((k_decode_i8_xpose<L, true, 128>), grid, block, 0, st, a); \
-                             else    hipLaunchKernelGGL((k_decode_i8_xpose<L, false, 128>), grid, block, 0, st, a); } } while (0)
+#define BB_XP(L) with_nt(nt, [&](auto NT) { \
+                if (xrows == 64) hipLaunchKernelGGL((k_decode_i8_xpose<L, decltype(NT)::value, 64>), grid, block, 0, st, a); \
+                else             hipLaunchKernelGGL((k_decode_i8_xpose<L, decltype(NT)::value, 128>), grid, block, 0, st, a); })
             switch (p->layout) {
                 case BB_LAYOUT_GUPPI_CF: BB_XP(0); break;
                 case BB_LAYOUT_MKBF:     BB_XP(1); break;
@@ -1454,10 +1250,8 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
-#define BB_TL(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_tiled<L, true>), grid, block, lds, st, a); \
-                      else    hipLaunchKernelGGL((k_decode_i8_tiled<L, false>), grid, block, lds, st, a); } while (0)
-#define BB_TS(L) do { if (nt) hipLaunchKernelGGL((k_decode_i8_stage<L, true>), grid, block, lds, st, a); \
-                      else    hipLaunchKernelGGL((k_decode_i8_stage<L, false>), grid, block, lds, st, a); } while (0)
+#define BB_TL(L) with_nt(nt, [&](auto NT) { hipLaunchKernelGGL((k_decode_i8_tiled<L, decltype(NT)::value>), grid, block, lds, st, a); })
+#define BB_TS(L) with_nt(nt, [&](auto NT) { hipLaunchKernelGGL((k_decode_i8_stage<L, decltype(NT)::value>), grid, block, lds, st, a); })
     switch (p->layout) {
         case BB_LAYOUT_GUPPI_CF: BB_TL(0); break;
         case BB_LAYOUT_MKBF:     if (stage) BB_TS(1); else BB_TL(1); break;

@@ -30,6 +30,7 @@ struct bb_gather_args {
     int32_t  complex_data;
     int32_t  lrow;          // log2(nslot * chunk) when that is a power of two, else -1
     int32_t  aligned;       // use 256-byte aligned block loads
+    uint64_t src_lim;       // offsets outside [0, src_lim) decode as fill (bb_src_ok)
     bb_perm_t perm;         // work order (bb_common.h)
     // channel selection (bb_decode_frames_select): only positions within[0..nsel)
     // of every thread sample's chunk are written, in that order; nsel == 0: all
@@ -68,15 +69,16 @@ __device__ __forceinline__ void bb_gather_stage(const bb_gather_args &a, uint64_
     for (uint32_t s0 = 0; s0 < a.nslot; s0 += BB_WAVE) {
         const uint32_t sl = s0 + (uint32_t)lane;
         const int64_t my_so = sl < a.nslot ? a.src[f * a.nslot + sl] : -1;
-        const uint8_t *my_p = a.buf + (my_so >= 0 ? (uint64_t)my_so : 0);
+        const bool my_ok = bb_src_ok(my_so, a.src_lim);
+        const uint8_t *my_p = a.buf + (my_ok ? (uint64_t)my_so : 0);
         const uintptr_t my_ad = reinterpret_cast<uintptr_t>(my_p);
         // misalignment of the payload against 256-byte blocks of the address
         // space, in dwords (odd byte addresses keep plain loads)
         const uint32_t my_sh = (a.aligned && !(my_ad & 3)) ? (uint32_t)((my_ad >> 2) & 63) : 0u;
         if (sl < a.nslot && wave == 0) {
-            s_valid[sl] = my_so >= 0 ? 1u : 0u;
+            s_valid[sl] = my_ok ? 1u : 0u;
             s_base[sl] = (sl * pitch + my_sh) * 4;
-            if (s_missing && my_so < 0) atomicAdd(s_missing, 1u);
+            if (s_missing && !my_ok) atomicAdd(s_missing, 1u);
         }
         const uint32_t send = (s0 + BB_WAVE < a.nslot) ? s0 + BB_WAVE : a.nslot;
         // this wave's slots in [s0, send): sfirst + k * sstep
@@ -97,7 +99,7 @@ __device__ __forceinline__ void bb_gather_stage(const bb_gather_args &a, uint64_
                     const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)((uint64_t)my_ad & 0xffffffffu), from);
                     const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)my_ad >> 32), from);
                     const uint32_t sh = (uint32_t)__shfl((int)my_sh, from);
-                    const int ok = __shfl((int)(my_so >= 0), from);
+                    const int ok = __shfl((int)my_ok, from);
                     const uint32_t *blk = reinterpret_cast<const uint32_t *>(((uint64_t)hi << 32) | lo) - sh;
                     const uint32_t j = (b * wps + wsub) * BB_WAVE + (uint32_t)lane;
                     const uint64_t q = dw0 + j;                 // block dword q = payload dword q - sh

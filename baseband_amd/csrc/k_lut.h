@@ -72,7 +72,7 @@ void k_decode_flat_lut(bb_flat_args a)
         if (a.nseg == 1) { fs = work; seg = 0; }
         else { fs = work / a.nseg; seg = work - fs * a.nseg; }
         const int64_t so = a.src ? a.src[fs] : a.src0 + (int64_t)fs * a.src_stride;
-        valid = so >= 0;
+        valid = bb_src_ok(so, a.src_lim);
         const uint8_t *pp = a.buf + (valid ? (uint64_t)so : 0);
         const uintptr_t b0 = reinterpret_cast<uintptr_t>(pp);
         s = (b0 & 3) ? 0u : (uint32_t)((b0 >> 2) & 63);    // odd byte addresses: plain loads
@@ -84,7 +84,7 @@ void k_decode_flat_lut(bb_flat_args a)
         for (int u = 0; u <= TPW; ++u) {
             const uint64_t j = (tile0 + u) * 64 + lane;     // block dword j holds payload dword j - s
             const bool want = valid && u <= (int)a.tpw && j >= s && j - s < dw_end;
-            w[u] = want ? (a.nt_loads ? __builtin_nontemporal_load(&blk[j]) : blk[j]) : 0u;
+            w[u] = want ? bb_load_dw(a, &blk[j]) : 0u;
         }
     };
 

@@ -214,6 +214,7 @@ struct bb_m4_args {
     uint32_t sign_bit[8];   // 32 x uint8: output j -> bit position of its sign
     uint32_t mag_bit[8];    //                       ... of its magnitude
     float    fill, hi;
+    uint64_t src_lim;       // offsets outside [0, src_lim) decode as fill (bb_src_ok)
     bb_perm_t perm;         // work order (bb_common.h)
 };
 
@@ -259,7 +260,7 @@ void k_decode_mark4(bb_m4_args a)
         if (a.nseg == 1) { f = work; seg = 0; }
         else { f = work / a.nseg; seg = work - f * a.nseg; }
         const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
-        valid = so >= 0;
+        valid = bb_src_ok(so, a.src_lim);
         const word_t *in = reinterpret_cast<const word_t *>(a.buf + (valid ? so : 0));
         const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
         const uint64_t w_end = (seg + 1) * a.seg_tiles * 64 < a.nwords
@@ -367,7 +368,7 @@ void k_decode_mark4_select(bb_m4_args a, uint32_t nout)
         if (a.nseg == 1) { f = pwork; seg = 0; }
         else { f = pwork / a.nseg; seg = pwork - f * a.nseg; }
         const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
-        const bool valid = so >= 0;
+        const bool valid = bb_src_ok(so, a.src_lim);
         float *obase = a.out + f * E;
         const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
         const uint64_t w_end = (seg + 1) * a.seg_tiles * 64 < a.nwords

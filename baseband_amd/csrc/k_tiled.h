@@ -37,6 +37,7 @@ struct bb_tiled_args {
     uint32_t tcp;               // LDS row pitch in elements: even, odd number of dwords
     uint32_t ntt, nct;          // tiles per frame along time / channel
     float    fill_re, fill_im;
+    uint64_t src_lim;       // offsets outside [0, src_lim) decode as fill (bb_src_ok)
     bb_perm_t perm;         // work order (bb_common.h)
 };
 
@@ -62,7 +63,7 @@ void k_decode_i8_tiled(bb_tiled_args a)
         const uint32_t c0 = ci * tc;
         const uint32_t nc_tile = (a.nchan - c0 < tc) ? a.nchan - c0 : tc;
         const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
-        const bool valid = so >= 0;
+        const bool valid = bb_src_ok(so, a.src_lim);
         const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
 
         if (valid) {
@@ -199,7 +200,7 @@ void k_decode_i8_stage(bb_tiled_args a)
         const uint32_t c0 = ci * tc;
         const uint32_t nc_tile = (a.nchan - c0 < tc) ? a.nchan - c0 : tc;
         const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
-        const bool valid = so >= 0;
+        const bool valid = bb_src_ok(so, a.src_lim);
         const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
 
         if (valid) {

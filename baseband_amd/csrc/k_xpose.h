@@ -69,7 +69,7 @@ void k_decode_i8_xpose(bb_tiled_args a)
         const uint32_t c0 = ci * BB_XP_TC;
         const uint32_t ncv = (a.nchan - c0 < BB_XP_TC) ? a.nchan - c0 : BB_XP_TC;
         const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
-        valid = so >= 0;
+        valid = bb_src_ok(so, a.src_lim);
         const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {

@@ -175,9 +175,10 @@ class DADAStreamReader(BlockStreamReader):
                                       chunk=rb if within is not None else 1, src0=lo,
                                       src_stride=stride, out=out_flat, within=within)
                 return
-            except KeyError:
+            except (KeyError, _lib.BBError):
                 if within is None:
-                    raise                       # (selection too wide for the kernel: index below)
+                    raise                       # (a short request the selecting kernel cannot
+                    # cut into whole rows: decode the rows, index below)
         per = n if within is None else n // rb * within.numel()
         for i in range(nframes):
             rows = decode_i8_rows(dbuf, lo + i * stride, rb, 0, n // rb)

@@ -142,7 +142,7 @@ class GSBStreamReader(GPUStreamReaderBase):
             self._images = [[host_image(fh) for fh in pair] for pair in fh_raw]
             # phased data are thread-interleaved frames with one slot per
             # polarisation: a channel subset is folded into that decode
-            self._plan_channel_select(self.subset)
+            self._plan_channel_select(self.subset, payload_nbytes=payload_nbytes)
 
     @property
     def payload_nbytes(self):

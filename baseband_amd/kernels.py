@@ -286,6 +286,24 @@ def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
     return tgt.done()
 
 
+def select_supported(bps, chunk, nslot, nwithin, payload_nbytes=None):
+    """Would `decode_frames(..., within=...)` take this geometry?  Asks the
+    library's own argument / geometry checks (bb_decode_frames_select_check;
+    no device needed), so that readers fold a channel subset into the decode
+    only when the kernel accepts it and keep the reference's
+    decode-then-index order otherwise.  `payload_nbytes` None: a payload long
+    enough not to limit the work items (requests of varying length)."""
+    p = _lib.DecodeParams()
+    p.coder = _lib.CODER_VDIF               # (any coder that has this sample width: the limits do not depend on it)
+    p.bps = bps
+    p.chunk = chunk
+    p.nslot = nslot
+    if payload_nbytes is None:
+        payload_nbytes = max(1 << 20, chunk * bps // 8 * 4) if bps in (1, 2, 4, 8) else 0
+    p.payload_nbytes = payload_nbytes
+    return lib.bb_decode_frames_select_check(C.byref(p), int(nwithin)) == _lib.BB_OK
+
+
 def mark4_scan(dbuf, nframes, ntrack, ref_year, ref_qms, frame_qms,
                first_offset=0):
     p = _lib.Mark4ScanParams()

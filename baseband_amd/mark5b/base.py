@@ -141,7 +141,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         self._file_offset0 = offset0
         self._start_time = header0.get_time(frame_rate=self._frame_rate)
         self._ref_seconds = header0.jday * 86400 + header0.seconds
-        self._plan_channel_select(self.subset)
+        self._plan_channel_select(self.subset, payload_nbytes=header0.payload_nbytes)
         last = self._last_header()
         self._nsample = (self._get_index(last) + 1) * spf
 

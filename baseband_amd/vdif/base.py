@@ -220,7 +220,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
         self._coder = (_lib.CODER_MARK5B if header0.edv == 0xab
                        else _lib.CODER_VDIF)
         self._resident = None
-        self._plan_channel_select(self._frameset_subset)
+        self._plan_channel_select(self._frameset_subset, payload_nbytes=header0.payload_nbytes)
         try:
             last = self._last_header()
             self._nsample = (self._get_index(last) + 1) * self.samples_per_frame

@@ -153,10 +153,16 @@ def cpu_baseline(target_seconds=12.0):
         with open(os.path.join(ROOT, 'tests', 'golden', 'cpu_calibration.json')) as f:
             cal = json.load(f)
         ratio = float(cal["ratio_port_over_reference"])
+        qlo, qhi = cal.get("ratio_port_over_reference_quartile_range", [ratio, ratio])
         result["calibration"] = {
             "ratio_port_over_reference": ratio,
+            "ratio_from": cal.get("ratio_from", "medians"),
+            "ratio_quartile_range": [qlo, qhi],
             "ratio_port_over_reference_verify_false": cal.get("ratio_port_over_reference_verify_false"),
             "reference_as_written_estimate_Msps": round(msps / ratio, 2),
+            "reference_as_written_estimate_range_Msps": [round(msps / qhi, 2), round(msps / qlo, 2)],
+            "what": "the port's figure divided by the MEDIAN ratio reference / port measured where the "
+                    "reference can be imported (one pinned core, 25 interleaved rounds, medians and quartiles)",
             "measured_on": cal.get("host"),
             "reference_Msps_there": cal["reference"]["verify_true_Msps"],
             "port_Msps_there": cal["port"]["Msps"],
@@ -290,17 +296,40 @@ def _free_port():
     return p
 
 
+CPU_JSON_ENV = 'BB_BENCH_CPU_BASELINE_JSON'
+
+
 def spawn_ranks(args, argv):
     """``python bench.py --gpus N`` without a launcher: start N workers with
     torch.distributed.run (this process has not touched the GPU) and pass
-    their output through."""
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py')] + argv
+    their output through.  The CPU baseline is timed HERE, before the workers
+    exist (the host is otherwise idle, no rank waits for it), and handed to
+    rank 0 as a file so that the N > 1 line carries `cpu_baseline` too."""
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '1')
-    return subprocess.run(cmd, env=env).returncode
+    tmp = None
+    if not args.no_cpu_baseline and not args.dry_run and os.path.exists('/dev/kfd'):
+        try:
+            cpu = cpu_baseline()
+            cpu["timed_by"] = "the parent of the {} ranks, before they were started".format(args.gpus)
+            fd, tmp = tempfile.mkstemp(prefix='bb_cpu_', suffix='.json', dir='/tmp')
+            with os.fdopen(fd, 'w') as f:
+                json.dump(cpu, f)
+            env[CPU_JSON_ENV] = tmp
+        except Exception as exc:                    # the bench goes on without it
+            print("bench.py: cpu_baseline failed in the parent: {!r}".format(exc), file=sys.stderr)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py')] + argv
+    try:
+        return subprocess.run(cmd, env=env).returncode
+    finally:
+        if tmp:
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
 
 
 def timed_launches(fn, reps):
@@ -354,8 +383,16 @@ def dry_run(args, rank, world):
         dist.all_reduce(seen)
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     if rank == 0:
+        cpu = None
+        handed = os.environ.get(CPU_JSON_ENV)
+        if handed and os.path.exists(handed):       # what the parent of an N > 1 run timed
+            with open(handed) as f:
+                cpu = json.load(f)
         print(json.dumps({
             "metric": "decoded Msamples/s, VDIF 2-bit 1-thread (scan + index + decode, input resident in HBM)",
+            "cpu_baseline": cpu,
+            "roofline": {"traffic": None, "traffic_detail": {
+                "hbm_bytes_per_launch": None, "reason": "dry run" if world == 1 else "counter passes run at N = 1 only"}},
             "value": None, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "float32", "data": "synthetic",
@@ -425,6 +462,17 @@ def leg_cfg3(args, rank, world, device, dist, out):
         # the scanning rank holds the whole file (one allocation, filled slab by
         # slab: no concatenation copy next to the 127.5 GiB output buffer)
         sb = nsets * set_nbytes
+        # footprint of rank 0 in this leg: the whole file (world x slab) + scan
+        # records (16 B per frame) + the index (8 B per frame) + random-fill
+        # temporaries (4 GiB at most), next to `out`, which the caller holds.
+        # Checked against what the driver reports free, BEFORE allocating: at
+        # N = 8 this is 64 GiB beside the 127.5 GiB output
+        need = world * sb + nsets_world * CFG3_THREADS * 24 + (4 << 30)
+        free_b, total_b = torch.cuda.mem_get_info(device)
+        free_b += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        if need > free_b:
+            raise RuntimeError("cfg3 leg: rank 0 needs {:.1f} GiB (whole file of {} ranks + index) but {:.1f} GiB "
+                               "are free: lower --cfg3-gib".format(need / 2 ** 30, world, free_b / 2 ** 30))
         whole = torch.empty(world * sb, dtype=torch.uint8, device=device)
         for r in range(world):
             _, h0 = make_file_image_on_device(nsets, 777 + r, frame_slab(nsets_world, r, world)[0], device,
@@ -503,6 +551,7 @@ def leg_cfg3(args, rank, world, device, dist, out):
     return {
         "workload": "cfg3: synthetic {:.3f} GiB per GPU 8-thread VDIF, 2-bit complex, 16 channels, "
                     "EDV 0, thread order on disk {}".format(nsets * set_nbytes / 2 ** 30, list(CFG3_ORDER)),
+        "rank0_file_GiB": round(world * nsets * set_nbytes / 2 ** 30, 3),
         "value": round(ncomplex * world * args.steps / elapsed / 1e6, 1),
         "unit": "M complex samples/s (threads x channels counted)",
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -673,10 +722,28 @@ def main():
     # happen before this process initialises the GPU
     cpu = None
     traffic_detail = None
-    have_gpu = torch.cuda.device_count() > 0
-    if rank == 0 and world == 1 and have_gpu:
-        if not args.no_cpu_baseline:
+    # (is there a GPU?  Asked WITHOUT initialising the HIP runtime: the legs
+    # below fork workers and start profiler children, and a forked child must
+    # not inherit a live runtime -- torch.cuda.device_count() can initialise it
+    # on this build)
+    have_gpu = os.path.exists('/dev/kfd')
+    if rank == 0 and have_gpu and not args.no_cpu_baseline:
+        handed = os.environ.get(CPU_JSON_ENV)
+        if handed and os.path.exists(handed):
+            with open(handed) as f:
+                cpu = json.load(f)                  # timed by the parent that started the ranks
+        else:
+            # N = 1, or N > 1 under an external launcher: rank 0 times it before it
+            # touches the GPU (the other ranks wait in the rendezvous meanwhile)
             cpu = cpu_baseline()
+            if world > 1:
+                cpu["timed_by"] = "rank 0 before initialising the GPU; the other ranks waited in the rendezvous"
+    if rank == 0 and world > 1:
+        traffic_detail = {"hbm_bytes_per_launch": None,
+                          "reason": "counter passes run at N = 1 only: they are child runs of this script "
+                                    "under rocprofv3 --pmc on the first GPU, which the ranks of an N > 1 "
+                                    "run are about to use; the N = 1 line of the same commit carries the counters"}
+    if rank == 0 and world == 1 and have_gpu:
         if abs(args.gib - 8.0) < 1e-9 and args.traffic != 'none':
             if args.traffic == 'live':
                 try:
@@ -781,7 +848,7 @@ def main():
     total_samples = nframes * SPF * world * args.steps
     value = total_samples / elapsed / 1e6
     traffic = None
-    if traffic_detail and "hbm_bytes_per_launch" in traffic_detail:
+    if traffic_detail and traffic_detail.get("hbm_bytes_per_launch"):
         traffic = traffic_detail["hbm_bytes_per_launch"]
         traffic_detail["traffic_over_algorithmic"] = round(traffic / alg_bytes, 4)
 

@@ -237,7 +237,16 @@ int bb_build_index(const bb_frame_rec *d_recs, size_t nrecs,
  * i.e. rows of `chunk` values (chunk = nchan * (2 if complex)) interleaved
  * over nslot threads.  A source of -1 writes fill (re, im alternating when
  * `complex_data`).  With d_src == NULL frames are taken at
- * src0 + (f*nslot + s)*src_stride (fixed-stride file, all valid).
+ * src0 + (f*nslot + s)*src_stride (fixed-stride file, all valid; the last one
+ * must end inside buf_nbytes, else BB_ERANGE).
+ *
+ * Bounds: every decode entry point follows an index entry only when the whole
+ * unit it names (payload_nbytes here; the stream words of a Mark 4 unit; the
+ * kept channels' bytes of a block) lies inside [0, buf_nbytes).  Any other
+ * entry -- negative, past the end, a stale or corrupt index -- decodes as
+ * fill, exactly like -1; nothing outside the buffer is read.  The reference
+ * never returns garbage for bytes a file does not hold either (short read ->
+ * EOFError, base/payload.py:135-136).
  */
 typedef struct bb_decode_params {
     int32_t  coder;            /* enum bb_coder */
@@ -275,6 +284,19 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
                             const bb_decode_params *params,
                             const int32_t *d_within, int nwithin,
                             float *d_out, size_t out_elems, void *stream);
+
+/*
+ * The argument and geometry checks of bb_decode_frames_select without a launch
+ * (no device needed): BB_OK when a launch with these parameters and `nwithin`
+ * kept positions would be accepted, else the code it would return (BB_EINVAL:
+ * more than 4096 positions, sizes that do not fit; BB_ENOTSUP: a thread sample
+ * wider than a work item can hold whole rows of -- 16 tiles of 256 bytes -- or
+ * more thread slots than the on-chip staging buffer takes).  Readers ask this
+ * when they plan a subset (baseband_amd/base/base.py _plan_channel_select) and
+ * keep the reference's decode-then-index order otherwise (base/base.py:706-717).
+ * Only coder, bps, chunk, nslot and payload_nbytes of `params` are looked at.
+ */
+int bb_decode_frames_select_check(const bb_decode_params *params, int nwithin);
 
 /* ---- Mark 4 ------------------------------------------------------------ */
 
@@ -455,58 +477,6 @@ int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
 int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
                     const uint8_t sign_bit[32], const uint8_t mag_bit[32],
                     void *d_out, size_t out_nbytes, void *stream);
-
-/* ---- tuning knobs (performance experiments; results never change) ------ */
-#define BB_TUNE_FLAT_VARIANT   0   /* 0 = workgroup per frame, 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16 tiles per frame segment, 4 = contiguous output cut in output space (k_decode_flat_span), 5 = as 3 with 256-byte aligned block loads for contiguous output (k_decode_flat_aln; default), 6-9 = explicit write front (k_decode_flat_front; experiment, slower), 10-12 = one pass with 2/4/8 stripes per wave (k_decode_flat_es; experiment, within +-4 % of 0 and 5), 14 = one float4 per thread and stripe (k_decode_flat_elem; experiment) */
-#define BB_TUNE_NT_STORES      1   /* 1 = non-temporal stores */
-#define BB_TUNE_BLOCKS         2   /* 0 = default grid; >0 = number of workgroups */
-#define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (experiment) */
-#define BB_TUNE_TILE_ELEMS     4   /* elements per tile of bb_decode_i8_tiled (default 8192) */
-#define BB_TUNE_GATHER_BYTES   6   /* payload bytes of all thread slots staged in LDS per work item of k_decode_gather; 8192 (default) = automatic: 16384, or 4096 for 1-bit data */
-#define BB_TUNE_SEG_TILES 13          /* plain flat kernel: 256-byte tiles per workgroup (default 0 = 32, 16 for 8-bit samples) */
-#define BB_TUNE_GATHER_CHUNKS 12      /* thread interleave: chunks (floats per thread sample) below this go through the LDS gather kernel; 32 (default) = automatic: every chunk for up to 4 thread slots, chunks below 32 floats otherwise; 4 = only chunks 1 and 2 */
-#define BB_TUNE_MKBF_CHANNELS 11      /* channels per MKBF tile in k_decode_i8_stage (even, 2..64; default 32) */
-#define BB_TUNE_TILED_STAGE 10        /* 1 (default): MKBF and GUPPI time-first through k_decode_i8_stage; 0: k_decode_i8_tiled */
-#define BB_TUNE_LDS_PAD 9             /* experiment: bytes of unused dynamic LDS per workgroup of the aligned flat kernel (caps workgroups per CU); 0 = none (default) */
-#define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* the same bound for 8-bit data in the aligned flat kernel (1..32; above 16 selects the 32-tile instantiation) */
-#define BB_TUNE_TILES_PER_WAVE 7   /* upper bound of 256-byte tiles per wave and work item in the flat kernels (1..16, default 12) */
-#define BB_TUNE_ENCODE_DIRECT  5   /* 1 = 2-bit encoders evaluate the reference clip/add/floor_divide arithmetic per sample instead of comparing with the three thresholds derived from it (check mode) */
-#define BB_TUNE_M4_TILES 26           /* 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8, default 8: 4 waves x 8 tiles = 256 KiB of output per work item for 64 tracks) */
-#define BB_TUNE_LUT_SMALL 25          /* 1: k_decode_flat_lut instantiated for at most 4 tiles per wave when the work items are that short (experiment: slower); 0 (default): the 16-tile instantiation */
-#define BB_TUNE_LUT_TILES 24          /* upper bound of 256-byte tiles per wave and work item in k_decode_flat_lut for 2-bit samples (1..16, default 4; half as many for 1-bit, twice as many for 4-bit samples: 32 KiB of output per work item; its grid is one work item per workgroup up to 2^23 unless BB_TUNE_BLOCKS says otherwise) */
-#define BB_TUNE_SELECT_BYTES 23       /* payload bytes (all thread slots together) that k_decode_gather_select stages in LDS per work item (256..32768, default 16384) */
-#define BB_TUNE_M4_WIDEN 22           /* 1 (default): 16- and 32-track Mark 4 units whose word count and fill prefix allow it are decoded as 64-bit super-words (4 / 2 stream words per lane and load) by the 64-track kernels; 0: always the native word size */
-#define BB_TUNE_BYTE_LUT 21           /* 1 (default): contiguous 1-, 2- and 4-bit decode through the byte table kernel k_decode_flat_lut; 0: k_decode_flat_aln (register level select; the plain kernel for 4-bit) */
-#define BB_TUNE_XPOSE_ROWS 20         /* k_decode_i8_xpose: output rows per tile, 128 or 64; default 0 = 128 for GUPPI channels-first blocks and for outputs of 96 GiB and more, 64 for smaller launches of time-first blocks and MKBF heaps */
-#define BB_TUNE_XPOSE 19              /* 1 (default): int8 transposes with 16-byte aligned input runs go through k_decode_i8_xpose; 0: k_decode_i8_tiled / _stage always */
-#define BB_TUNE_WORK_STRIPES 18       /* work order of the decode launches: log2 of the number of stripes a launch's work items are dealt over (0 = file order; default -1 = 16 stripes for outputs of 16 GiB and more, 4 below) */
-#define BB_TUNE_OUT_STRIPE_W 16       /* experiment: deal the frames of a contiguous-output launch over this many output regions (0 = off) ... */
-#define BB_TUNE_OUT_STRIPE_S 17       /* ... that lie this many frame-slots apart: frame fs goes to slot (fs % W) * S + fs / W */
-#define BB_TUNE_FRONT_GROUP 14        /* k_decode_flat_front (variants 6-9): workgroups per group = width of the write front (default 2048) */
-#define BB_TUNE_FRONT_STEPS 15        /* k_decode_flat_front: steps a group sweeps its region in (default 16) */
-int bb_tune(int knob, int value);
-
-/* Measurement aid: when d_times is not NULL, the contiguous-output flat decode
- * kernels store the device wall clock (100 MHz ticks) at which each work item
- * was completed into d_times[item] (the caller sizes it for the launch: frames
- * x work items per frame, plus one slot per workgroup of the launch behind
- * them, where the aligned kernel stores its start time).  NULL switches it off (default).  Not for
- * production use: one extra 8-byte store per 32-64 KiB of output. */
-int bb_debug_trace(uint64_t *d_times);
-
-/* ---- host staging helpers (measurement only) -------------------------------
- * bb_host_register pins a range of host memory where it lies -- e.g. a window
- * of a read-only file mapping whose pages are in the page cache -- so that
- * bb_copy_to_device (hipMemcpyAsync on `stream`) moves it without a host-side
- * copy into a pinned buffer first; bb_host_unregister releases it after the
- * copy has completed.  Used by tools/exp_hostregister.py: 56-57 GB/s from a
- * populated mapping, but pinning and unpinning the pages of a freshly mapped
- * file costs more host time than the staging copy it would replace
- * (profiles/r02ax_exp_hostregister.log), so the readers keep the pinned
- * double-buffer pipeline (baseband_amd/staging.py). */
-int bb_host_register(const void *h_ptr, size_t nbytes);
-int bb_host_unregister(const void *h_ptr);
-int bb_copy_to_device(void *d_dst, const void *h_src, size_t nbytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -64,3 +64,35 @@ def bits_equal(a, b):
     b = np.ascontiguousarray(b)
     return (a.shape == b.shape and a.dtype == b.dtype
             and np.array_equal(a.view(np.uint32), b.view(np.uint32)))
+
+
+# -- product / experiment build (baseband_amd/_lib.py EXPERIMENTS) -------------
+# The product library has ONE dispatch; the measurement variants of rounds 1-2
+# (BB_TUNE_FLAT_VARIANT etc., include/bbdecode_exp.h) exist in the experiment
+# build only (make -C baseband_amd/csrc EXPERIMENTS=1; BB_EXPERIMENTS=1 pytest ...).
+def _experiments():
+    from baseband_amd import _lib
+    return _lib.EXPERIMENTS
+
+
+def variants(*wanted):
+    """Flat-kernel variants a test may force: all of `wanted` on the
+    experiment build, the product dispatch (5) otherwise."""
+    return tuple(wanted) if _experiments() else (5,)
+
+
+def nt_modes():
+    return (0, 1) if _experiments() else (1,)
+
+
+def tune_exp(knob, value):
+    """Set an experiment-only knob; a no-op on the product library (whose
+    only state is the default the tests restore)."""
+    if _experiments():
+        from baseband_amd import kernels
+        kernels.tune(knob, value)
+
+
+needs_experiments = pytest.mark.skipif(
+    os.environ.get('BB_EXPERIMENTS', '') in ('', '0'),
+    reason="measurement variant: experiment build only (BB_EXPERIMENTS=1)")

@@ -10,22 +10,68 @@ import pytest
 from conftest import ROOT
 
 
-def declared_symbols():
-    with open(os.path.join(ROOT, 'include', 'bbdecode.h')) as f:
-        text = f.read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(bb_[a-z0-9_]+)\s*\(', text)))
+def declared_symbols(*headers):
+    syms = set()
+    for header in headers:
+        with open(os.path.join(ROOT, 'include', header)) as f:
+            text = f.read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        syms |= set(re.findall(r'\b(bb_[a-z0-9_]+)\s*\(', text))
+    return sorted(syms)
+
+
+PRODUCT_HEADERS = ('bbdecode.h', 'bbdecode_tune.h')
 
 
 def test_library_exports_all_declared_symbols():
     from baseband_amd import _lib
-    syms = declared_symbols()
+    assert sorted(h for h in os.listdir(os.path.join(ROOT, 'include')) if h.endswith('.h')) == \
+        sorted(PRODUCT_HEADERS + ('bbdecode_exp.h',))
+    syms = declared_symbols(*PRODUCT_HEADERS)
     assert len(syms) >= 9
     for s in syms:
         assert hasattr(_lib.lib, s), s
     bound = {name for name, _, _ in _lib.SIGNATURES}
     assert bound == set(syms)
     assert _lib.lib.bb_abi_version() == 1
+
+
+def test_product_library_carries_no_experiments():
+    """Measurement variants, their knobs and the trace / pinning aids live in
+    the experiment build only (make EXPERIMENTS=1, include/bbdecode_exp.h)."""
+    from baseband_amd import _lib
+    if _lib.EXPERIMENTS:
+        pytest.skip('experiment build loaded')
+    exp = set(declared_symbols('bbdecode_exp.h')) - set(declared_symbols(*PRODUCT_HEADERS))
+    assert exp == {name for name, _, _ in _lib.EXPERIMENT_SIGNATURES}
+    for s in exp:
+        assert not hasattr(_lib.lib, s), s
+    for knob in (_lib.TUNE_FLAT_VARIANT, _lib.TUNE_NT_STORES, _lib.TUNE_BYTE_LUT, _lib.TUNE_FRONT_GROUP):
+        assert _lib.lib.bb_tune(knob, 1) == _lib.BB_EINVAL
+    assert _lib.lib.bb_tune(_lib.TUNE_BLOCKS, 0) == _lib.BB_OK
+
+
+def test_select_check_mirrors_the_launch_limits():
+    """bb_decode_frames_select_check: the limits of the selecting decode,
+    asked without a device (readers plan a subset against them)."""
+    from baseband_amd import _lib
+
+    def ask(bps, chunk, nslot, payload, nwithin, coder=_lib.CODER_VDIF):
+        p = _lib.DecodeParams()
+        p.coder, p.bps, p.chunk, p.nslot, p.payload_nbytes = coder, bps, chunk, nslot, payload
+        return _lib.lib.bb_decode_frames_select_check(ctypes.byref(p), nwithin)
+
+    assert ask(2, 32, 8, 8000, 4) == _lib.BB_OK
+    assert ask(2, 32, 8, 8000, 4096) == _lib.BB_OK
+    assert ask(2, 32, 8, 8000, 4097) == _lib.BB_EINVAL            # too many kept positions
+    assert ask(2, 32, 8, 8000, 0) == _lib.BB_EINVAL
+    assert ask(8, 16384, 1, 1 << 20, 16, _lib.CODER_INT) == _lib.BB_ENOTSUP   # sample wider than 16 tiles
+    assert ask(8, 4096, 1, 1 << 20, 16, _lib.CODER_INT) == _lib.BB_OK
+    assert ask(8, 4096, 1, 4096, 16, _lib.CODER_INT) == _lib.BB_OK           # 16 tiles hold one row
+    assert ask(8, 4096, 1, 2048, 16, _lib.CODER_INT) == _lib.BB_EINVAL       # payload is not whole rows
+    assert ask(2, 24, 2, 8000, 4) == _lib.BB_ENOTSUP              # chunk not a power of two
+    assert ask(2, 4, 512, 8000, 4) == _lib.BB_ENOTSUP             # more slots than the staging buffer takes
+    assert ask(3, 4, 1, 8000, 4) == _lib.BB_ENOTSUP               # no such sample width
 
 
 def test_struct_layouts_match_header():

@@ -46,3 +46,36 @@ def test_single_rank_line_and_world_mismatch():
     r, lines = _run(['--gpus', '4'], {'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
     assert r.returncode != 0 and not lines
     assert 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_under_torch_distributed_run_like_the_driver(tmp_path):
+    """The driver's way for N > 1: ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    ...`` -- ranks from the environment, no self-spawn.  Rank 0 picks up the CPU
+    baseline a parent handed over (BB_BENCH_CPU_BASELINE_JSON) and reports
+    `traffic` null with the reason."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    handed = tmp_path / 'cpu.json'
+    handed.write_text(json.dumps({"value": 123.5, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                  "sample": "test"}))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['BB_BENCH_CPU_BASELINE_JSON'] = str(handed)
+    env.setdefault('OMP_NUM_THREADS', '1')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--dry-run'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['dry_run'] is True
+    assert line['cpu_baseline']['value'] == 123.5 and line['cpu_baseline']['kind'] == 'port'
+    assert line['roofline']['traffic'] is None
+    assert 'N = 1' in line['roofline']['traffic_detail']['reason']
+    assert line['cfg3']['collective']['ranks_seen'] == 2 and line['cfg3']['index_ok'] is True

@@ -1,0 +1,190 @@
+"""Indexed sources are bounds-checked INSIDE the library (VERDICT r2 missing 4 /
+next 3): an index entry whose unit does not lie inside [0, buf_nbytes) --
+past the end, far past the end, negative other than -1 -- decodes as fill
+through the raw C ABI, never reads outside the buffer, and leaves every other
+frame bit-exact.  Semantics: the reference never returns garbage for bytes a
+file does not hold (short read -> EOFError, base/payload.py:135-136)."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+import bb_oracle_np as orc
+from conftest import bits_equal, golden_path
+
+pytestmark = pytest.mark.gpu
+
+
+def _bad_offsets(nbytes, unit):
+    """Offsets that must be refused for a unit of `unit` bytes in a buffer of
+    `nbytes`: the first one too far, far beyond, negative, huge."""
+    return [nbytes - unit + 1, nbytes - unit + 4, nbytes, nbytes + (1 << 33), -5, -(1 << 40),
+            (1 << 62)]
+
+
+def _view(raw, slack=4096):
+    """Device tensor of exactly len(raw) bytes that is a VIEW into a larger
+    allocation filled with a marker: reads past the end would not fault, they
+    would decode the marker -- which the comparison then catches."""
+    import torch
+    big = torch.full((raw.size + 2 * slack,), 0xa5, dtype=torch.uint8, device='cuda')
+    big[slack:slack + raw.size] = torch.from_numpy(raw).cuda()
+    return big[slack:slack + raw.size]
+
+
+@pytest.mark.parametrize('coder,bps,nslot,chunk', [
+    ('vdif', 2, 1, 1),        # k_decode_flat_lut
+    ('vdif', 1, 1, 1),
+    ('vdif', 4, 1, 1),
+    ('vdif', 8, 1, 1),        # k_decode_flat (plain)
+    ('int', 8, 1, 1),
+    ('vdif', 2, 8, 32),       # k_decode_rows_pipe
+    ('vdif', 2, 8, 1),        # k_decode_gather (narrow)
+    ('vdif', 2, 4, 8),        # k_decode_gather (wide)
+    ('vdif', 8, 100, 2),      # too many slots for the gather: plain kernel, scattered stores
+])
+def test_decode_frames_refuses_sources_outside_the_buffer(coder, bps, nslot, chunk):
+    import torch
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(bps * 10 + nslot)
+    pn, nframes = 1000, 12
+    stride = pn + 32
+    raw = rng.integers(0, 256, stride * nframes * nslot, dtype=np.uint8)
+    dbuf = _view(raw)
+    nfs = nframes * nslot
+    src = (np.arange(nfs, dtype=np.int64) * stride + 32)
+    src[-1] = raw.size - pn                                    # the last place a payload still fits
+    bad = _bad_offsets(raw.size, pn)
+    where = rng.choice(nfs - 1, size=len(bad), replace=False)
+    src[where] = bad
+    src[0 if 0 not in where else 1] = -1
+    E = pn * 8 // bps
+    R = E // chunk
+    code = {'vdif': 0, 'int': 2}[coder]
+    out = kernels.decode_frames(dbuf, nframes, pn, code, bps, chunk=chunk, nslot=nslot,
+                                src=torch.from_numpy(src).cuda(), fill_value=-7.25).cpu().numpy()
+    got = out.reshape(nframes, R, nslot, chunk)
+    for fs in range(nfs):
+        f, sl = divmod(fs, nslot)
+        o = int(src[fs])
+        if 0 <= o <= raw.size - pn:
+            want = orc.decode_flat(raw[o:o + pn], coder, bps).reshape(R, chunk)
+        else:
+            want = np.full((R, chunk), -7.25, np.float32)
+        assert bits_equal(np.ascontiguousarray(got[f, :, sl, :]), want), (fs, o, _lib.last_kernel())
+
+
+def test_select_refuses_sources_outside_the_buffer():
+    import torch
+    from baseband_amd import kernels
+    rng = np.random.default_rng(3)
+    pn, nframes, nslot, chunk = 4000, 9, 8, 32
+    stride = pn + 32
+    raw = rng.integers(0, 256, stride * nframes * nslot, dtype=np.uint8)
+    dbuf = _view(raw)
+    nfs = nframes * nslot
+    src = (np.arange(nfs, dtype=np.int64) * stride + 32)
+    bad = _bad_offsets(raw.size, pn)
+    where = rng.choice(nfs, size=len(bad), replace=False)
+    src[where] = bad
+    within = np.array([5, 4, 31, 0], np.int32)
+    out = kernels.decode_frames(dbuf, nframes, pn, 0, 2, chunk=chunk, nslot=nslot,
+                                src=torch.from_numpy(src).cuda(), fill_value=3.5,
+                                within=torch.from_numpy(within).cuda()).cpu().numpy()
+    R = pn * 4 // chunk
+    got = out.reshape(nframes, R, nslot, within.size)
+    for fs in range(nfs):
+        f, sl = divmod(fs, nslot)
+        o = int(src[fs])
+        if 0 <= o <= raw.size - pn:
+            want = orc.decode_flat(raw[o:o + pn], 'vdif', 2).reshape(R, chunk)[:, within]
+        else:
+            want = np.full((R, within.size), 3.5, np.float32)
+        assert bits_equal(np.ascontiguousarray(got[f, :, sl, :]), np.ascontiguousarray(want)), (fs, o)
+
+
+@pytest.mark.parametrize('mode', ['m4_64_f4', 'm4_16_f4'])
+@pytest.mark.parametrize('select', [False, True])
+def test_mark4_refuses_sources_outside_the_buffer(mode, select):
+    import torch
+    from baseband_amd import kernels
+    with open(golden_path('mark4_bitmaps.json')) as f:
+        maps = json.load(f)
+    e = next(v for v in maps.values() if (v['ntrack'], v['fanout']) == ((64, 4) if mode == 'm4_64_f4' else (16, 4)))
+    nt = e['ntrack']
+    dt = np.dtype(orc.MARK4_DTYPES[nt])
+    nwords, nframes = 1000, 10
+    rng = np.random.default_rng(nt)
+    w = rng.integers(0, 256, size=(nwords * nframes, dt.itemsize), dtype=np.uint8).view(dt).ravel()
+    raw = w.view(np.uint8)
+    dbuf = _view(raw)
+    unit = nwords * dt.itemsize
+    src = np.arange(nframes, dtype=np.int64) * unit
+    bad = _bad_offsets(raw.size, unit)
+    # (offsets stay multiples of the word size where they could be followed at all)
+    bad[0] = raw.size - unit + dt.itemsize
+    bad[1] = raw.size - dt.itemsize
+    where = rng.choice(nframes, size=len(bad), replace=False)
+    src[where] = bad
+    sign, mag = e['sign_bit'], e['mag_bit']
+    nchan = e['nchan']
+    keep = [1, 0]
+    if select:
+        sign, mag = kernels.mark4_select_maps(sign, mag, nchan, keep)
+    out = kernels.decode_mark4(dbuf, nframes, nt, nwords, sign, mag, src=torch.from_numpy(src).cuda(),
+                               fill_value=-9.0, select=select).cpu().numpy()
+    per = nwords * len(sign)
+    for f in range(nframes):
+        o = int(src[f])
+        if 0 <= o <= raw.size - unit:
+            ref = orc.mark4_decode(w[o // dt.itemsize:o // dt.itemsize + nwords], nchan, e['fanout'], e['signature'])
+            want = np.ascontiguousarray(ref[:, keep] if select else ref).reshape(-1)
+        else:
+            want = np.full(per, -9.0, np.float32)
+        assert bits_equal(out[f * per:(f + 1) * per], want), (f, o)
+
+
+@pytest.mark.parametrize('layout', [0, 1, 2])
+def test_tiled_refuses_sources_outside_the_buffer(layout):
+    """bb_decode_i8_tiled with an index: blocks named outside the buffer are fill."""
+    import torch
+    from baseband_amd import kernels
+    rng = np.random.default_rng(layout)
+    npol, nchan, ntime, nframes = 2, 8, 256, 9
+    unit = ntime * npol * nchan * 2
+    raw = rng.integers(0, 256, unit * nframes, dtype=np.uint8)
+    dbuf = _view(raw)
+    src = np.arange(nframes, dtype=np.int64) * unit
+    bad = _bad_offsets(raw.size, unit)
+    bad[0] = raw.size - unit + 2
+    bad[1] = raw.size - 2
+    where = rng.choice(nframes, size=len(bad), replace=False)
+    src[where] = bad
+    out = kernels.decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, 0, ntime,
+                                  src=torch.from_numpy(src).cuda(), fill_value=2 - 1j).cpu().numpy()
+    per = ntime * npol * nchan * 2
+    for f in range(nframes):
+        o = int(src[f])
+        got = out[f * per:(f + 1) * per].reshape(ntime, npol, nchan, 2)
+        if 0 <= o <= raw.size - unit:
+            b = raw[o:o + unit].view(np.int8).astype(np.float32)
+            if layout == 0:
+                want = b.reshape(nchan, ntime, npol, 2).transpose(1, 2, 0, 3)
+            elif layout == 1:
+                want = b.reshape(ntime // 256, npol, nchan, 256, 2).transpose(0, 3, 1, 2, 4).reshape(ntime, npol, nchan, 2)
+            else:
+                want = b.reshape(ntime, nchan, npol, 2).transpose(0, 2, 1, 3)
+        else:
+            want = np.broadcast_to(np.array([2., -1.], np.float32), (ntime, npol, nchan, 2))
+        assert bits_equal(got, np.ascontiguousarray(want)), (f, o)
+
+
+def test_fixed_stride_past_the_end_is_erange():
+    """Without an index the host side checks the last frame: BB_ERANGE."""
+    from baseband_amd import kernels, _lib
+    raw = np.zeros(8032 * 4, np.uint8)
+    dbuf = kernels.to_device_bytes(raw)
+    with pytest.raises(_lib.BBError) as e:
+        kernels.decode_frames(dbuf, 5, 8000, 0, 2, src0=32, src_stride=8032)
+    assert e.value.code == _lib.BB_ERANGE

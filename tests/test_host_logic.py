@@ -913,3 +913,46 @@ def test_dada_channel_selection_covers_every_polarisation():
         assert fh._decode_shape == (2, 2) and fh.sample_shape == (2, 2)
     with dada.open(golden_path(case['file']), 'rs', subset=(0, [2, 0])) as fh:
         assert fh._within_np is None
+
+
+def test_channel_selection_respects_the_kernel_limits():
+    """a subset is folded into the decode only when
+    bb_decode_frames_select would take it -- at most 4096 kept positions, a
+    thread sample that fits whole rows into 16 tiles, staging within LDS;
+    otherwise the reader keeps the decode-then-index order of the reference
+    (base/base.py:706-717)."""
+    from baseband_amd.base.base import GPUStreamReaderBase
+
+    def plan(shape, subset, bps, cplx, payload_nbytes=None, lead_in_sample=False):
+        fh = object.__new__(GPUStreamReaderBase)
+        fh._decode_shape, fh._squeeze, fh.bps, fh.complex_data = shape, True, bps, cplx
+        fh._within_np = fh._within_dev = None
+        fh._plan_channel_select(subset, lead_in_sample=lead_in_sample, payload_nbytes=payload_nbytes)
+        return fh._within_np, fh._decode_shape
+
+    w, shape = plan((8, 16), (slice(None), [3, 1]), 2, True, 8000)
+    assert w.tolist() == [6, 7, 2, 3] and shape == (8, 2)
+    # 8-bit data with 8192 channels: one sample is wider than a work item's 16 tiles
+    w, shape = plan((8192,), ([5, 9],), 8, False, 16384)
+    assert w is None and shape == (8192,)
+    # the same selection with 4096 channels fits
+    w, shape = plan((4096,), ([5, 9],), 8, False, 16384)
+    assert w.tolist() == [5, 9] and shape == (2,)
+    # ... but not when the payload is a single row of two tiles more than it can group
+    w, _ = plan((4096,), ([5, 9],), 8, False, 4096)
+    assert w.tolist() == [5, 9]
+    # complex subset of 2049 channels = 4098 kept floats: over the kernel's 4096
+    w, shape = plan((4096,), (np.arange(2049),), 4, True, 1 << 16)
+    assert w is None and shape == (4096,)
+    w, _ = plan((4096,), (np.arange(2048),), 4, True, 1 << 16)
+    assert w is not None and w.size == 4096
+    # DADA-style (pol, chan) samples: the limit applies to all polarisations together
+    w, _ = plan((2, 2048), (slice(None), np.arange(1025)), 8, True, None, lead_in_sample=True)
+    assert w is None
+    w, _ = plan((2, 1024), (slice(None), np.arange(1000)), 8, True, None, lead_in_sample=True)
+    assert w is not None and w.size == 4000
+    # many thread slots: up to 96 are staged together, more keep the general path
+    w, _ = plan((96, 256), (slice(None), [1]), 2, False, 8192)
+    assert w is not None
+    w, _ = plan((97, 256), (slice(None), [1]), 2, False, 8192)
+    assert w is None

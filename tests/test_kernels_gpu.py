@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import bb_oracle_np as orc
-from conftest import bits_equal
+from conftest import bits_equal, variants, nt_modes, tune_exp, needs_experiments
 
 pytestmark = pytest.mark.gpu
 
@@ -99,11 +99,11 @@ def test_tuning_variants_agree():
     dbuf = kernels.to_device_bytes(raw)
     ref = None
     try:
-        for variant in (0, 1, 2, 3, 4, 5):
-            for nt in (0, 1):
+        for variant in variants(0, 1, 2, 3, 4, 5):
+            for nt in nt_modes():
                 for blocks in (0, 7, 2048):
-                    kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
-                    kernels.tune(_lib.TUNE_NT_STORES, nt)
+                    tune_exp(_lib.TUNE_FLAT_VARIANT, variant)
+                    tune_exp(_lib.TUNE_NT_STORES, nt)
                     kernels.tune(_lib.TUNE_BLOCKS, blocks)
                     out = kernels.decode_frames(dbuf, 64, 8000, 0, 2, src0=32,
                                                 src_stride=8032).cpu().numpy()
@@ -111,8 +111,8 @@ def test_tuning_variants_agree():
                         ref = out
                     assert bits_equal(out, ref)
     finally:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
-        kernels.tune(_lib.TUNE_NT_STORES, 1)
+        tune_exp(_lib.TUNE_FLAT_VARIANT, 5)
+        tune_exp(_lib.TUNE_NT_STORES, 1)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
 
 
@@ -137,8 +137,8 @@ def test_output_space_kernel_matches_per_frame_kernel(coder, bps, pn):
     name = {0: 'vdif', 1: 'mark5b', 2: 'int'}[coder]
     got = {}
     try:
-        for variant in (3, 4, 5):
-            kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+        for variant in variants(3, 4, 5):
+            tune_exp(_lib.TUNE_FLAT_VARIANT, variant)
             for blocks in (0, 3):
                 kernels.tune(_lib.TUNE_BLOCKS, blocks)
                 a = kernels.decode_frames(dbuf, nframes, pn, coder, bps,
@@ -148,17 +148,20 @@ def test_output_space_kernel_matches_per_frame_kernel(coder, bps, pn):
                                           src=torch.from_numpy(src).cuda(), fill_value=1 - 3j)
                 got[variant, blocks] = [x.cpu().numpy() for x in (a, b, c)]
     finally:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
+        tune_exp(_lib.TUNE_FLAT_VARIANT, 5)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
     E = pn * 8 // bps
     want = np.empty((nframes, E), np.float32)
     for f, o in enumerate(src):
         want[f] = -2.5 if o < 0 else orc.decode_flat(raw[o:o + pn], name, bps)
+    first = got[variants(3, 4, 5)[0], 0]
+    want_b = np.concatenate([orc.decode_flat(raw[32 + f * stride:32 + f * stride + pn], name, bps)
+                             for f in range(nframes)])
     for key, (a, b, c) in got.items():
         assert bits_equal(a, want.reshape(-1)), key
-        assert bits_equal(b, got[3, 0][1]), key
-        assert bits_equal(c, got[3, 0][2]), key
-    cplx = got[4, 0][2].reshape(nframes, E // 2, 2)
+        assert bits_equal(b, want_b), key
+        assert bits_equal(c, first[2]), key
+    cplx = first[2].reshape(nframes, E // 2, 2)
     assert np.all(cplx[0] == np.array([1., -3.], np.float32))
 
 
@@ -181,15 +184,15 @@ def test_thread_interleave_aligned_loads_agree(bps, coder, nslot, chunk, cplx):
     src[[1, nslot, nframes * nslot - 1]] = -1
     outs = {}
     try:
-        for variant in (3, 5):
-            kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+        for variant in variants(3, 5):
+            tune_exp(_lib.TUNE_FLAT_VARIANT, variant)
             outs[variant] = kernels.decode_frames(
                 dbuf, nframes, pn, coder, bps, chunk=chunk, nslot=nslot,
                 src=torch.from_numpy(src).cuda(), complex_data=cplx,
                 fill_value=(2 - 1j) if cplx else 9.).cpu().numpy()
     finally:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
-    assert bits_equal(outs[3], outs[5])
+        tune_exp(_lib.TUNE_FLAT_VARIANT, 5)
+    assert all(bits_equal(o, outs[5]) for o in outs.values())
     E = pn * 8 // bps
     R = E // chunk
     name = {0: 'vdif', 2: 'int'}[coder]
@@ -274,6 +277,7 @@ def test_vdif_scan_and_index():
     assert np.count_nonzero(src < 0) == 3
 
 
+@needs_experiments
 @pytest.mark.parametrize('variant', [6, 7, 8, 9])
 @pytest.mark.parametrize('coder,bps', COMBOS)
 def test_front_kernel_matches_oracle(variant, coder, bps):
@@ -285,12 +289,12 @@ def test_front_kernel_matches_oracle(variant, coder, bps):
     from baseband_amd import kernels, _lib
     rng = np.random.default_rng(variant * 100 + bps)
     try:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+        tune_exp(_lib.TUNE_FLAT_VARIANT, variant)
         for pn, nfr, hdr, G, K, shift in ((8000, 37, 32, 2048, 16, 0), (260, 50, 16, 3, 2, 4),
                                           (10000, 9, 16, 5, 3, 36), (256, 130, 0, 7, 1, 8),
                                           (8, 11, 8, 2048, 16, 0), (5000, 23, 32, 1, 1000, 100)):
-            kernels.tune(_lib.TUNE_FRONT_GROUP, G)
-            kernels.tune(_lib.TUNE_FRONT_STEPS, K)
+            tune_exp(_lib.TUNE_FRONT_GROUP, G)
+            tune_exp(_lib.TUNE_FRONT_STEPS, K)
             stride = pn + hdr
             raw = rng.integers(0, 256, stride * nfr, dtype=np.uint8)
             big = torch.zeros(shift + raw.size + 256, dtype=torch.uint8, device='cuda')
@@ -311,9 +315,9 @@ def test_front_kernel_matches_oracle(variant, coder, bps):
             want[holes] = -2.5
             assert bits_equal(out.cpu().numpy(), want.reshape(-1)), (pn, nfr, 'holes')
     finally:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
-        kernels.tune(_lib.TUNE_FRONT_GROUP, 2048)
-        kernels.tune(_lib.TUNE_FRONT_STEPS, 16)
+        tune_exp(_lib.TUNE_FLAT_VARIANT, 5)
+        tune_exp(_lib.TUNE_FRONT_GROUP, 2048)
+        tune_exp(_lib.TUNE_FRONT_STEPS, 16)
 
 
 def test_aligned_kernels_take_unaligned_views():
@@ -452,6 +456,7 @@ def test_decode_with_channel_selection(bps, chunk, nslot, sel):
         assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(exp[..., sel]).reshape(-1)), lw
 
 
+@needs_experiments
 @pytest.mark.parametrize('variant', [10, 11, 12, 14])
 @pytest.mark.parametrize('coder,bps', COMBOS)
 def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
@@ -461,7 +466,7 @@ def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
     from baseband_amd import kernels, _lib
     rng = np.random.default_rng(variant * 100 + bps)
     try:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
+        tune_exp(_lib.TUNE_FLAT_VARIANT, variant)
         for pn, nfr, hdr in ((8000, 37, 32), (260, 50, 16), (10000, 9, 16), (256, 131, 0), (8, 11, 8), (5000, 23, 32)):
             stride = pn + hdr
             raw = rng.integers(0, 256, stride * nfr, dtype=np.uint8)
@@ -480,7 +485,7 @@ def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
             want[holes] = -2.5
             assert bits_equal(out.cpu().numpy(), want.reshape(-1)), (pn, nfr, 'holes')
     finally:
-        kernels.tune(_lib.TUNE_FLAT_VARIANT, 5)
+        tune_exp(_lib.TUNE_FLAT_VARIANT, 5)
 
 
 @pytest.mark.parametrize('tiles', [1, 2, 3, 4, 5, 8, 16])

@@ -349,3 +349,79 @@ def test_random_walk_over_a_damaged_file(tmp_path):
                 ref.seek(pos)
                 assert bits_equal(fh.read(cnt).cpu().numpy(), ref.read(cnt).cpu().numpy()), (step, pos, cnt)
                 pos += cnt
+
+
+def test_small_results_are_copies_and_large_ones_views(manifest):
+    """A read served from the decoded window returns a fresh tensor when it is
+    small (the reference returns fresh arrays, base/base.py:919-969; a view
+    would pin the whole window) and a view when copying would cost a second
+    pass (`decode_ahead_copy_below`)."""
+    with _open('vdif_cfg2_small', manifest) as fh:
+        spf = fh.samples_per_frame
+        for _ in range(4):
+            fh.read(spf)
+        assert fh._decoded is not None
+        win = fh._decoded[2]
+        lo, hi = win.data_ptr(), win.data_ptr() + win.numel() * win.element_size()
+        small = fh.read(spf)
+        assert small.numel() * small.element_size() < fh.decode_ahead_copy_below
+        assert not (lo <= small.data_ptr() < hi), "small read-ahead result aliases the window"
+        assert small.untyped_storage().nbytes() == small.numel() * small.element_size()
+        fh.decode_ahead_copy_below = 0
+        view = fh.read(spf)
+        assert fh._decoded is not None and lo <= view.data_ptr() < hi
+
+
+def test_read_ahead_failures_that_are_not_about_the_file_surface(manifest, monkeypatch):
+    """Out of memory for a speculative window: a warning, read-ahead off, the
+    read itself still served.  Anything else (library errors, bugs) is not
+    swallowed."""
+    import torch
+    exp = load_expected('vdif_cfg2_small')
+    with _open('vdif_cfg2_small', manifest, squeeze=False) as fh:
+        spf = fh.samples_per_frame
+        real = type(fh)._read_sets
+        state = {'n': 0}
+
+        def oom_once(self, first, last, into=None):
+            if last - first > 4 and state['n'] == 0:
+                state['n'] = 1
+                raise torch.cuda.OutOfMemoryError("simulated")
+            return real(self, first, last, into)
+        monkeypatch.setattr(type(fh), '_read_sets', oom_once)
+        pos = 0
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            for _ in range(5):
+                got = fh.read(spf).cpu().numpy()
+                assert bits_equal(got, np.ascontiguousarray(exp[pos:pos + spf]))
+                pos += spf
+        assert state['n'] == 1 and fh.decode_ahead is False
+        assert any('read-ahead switched off' in str(x.message) for x in w)
+    with _open('vdif_cfg2_small', manifest, squeeze=False) as fh:
+        spf = fh.samples_per_frame
+        real = type(fh)._read_sets
+
+        def broken(self, first, last, into=None):
+            if last - first > 4:
+                raise RuntimeError("simulated library failure")
+            return real(self, first, last, into)
+        monkeypatch.setattr(type(fh), '_read_sets', broken)
+        with pytest.raises(RuntimeError, match="simulated library failure"):
+            for _ in range(5):
+                fh.read(spf)
+
+
+def test_abandoned_windows_leave_no_bad_frame_count_behind(manifest):
+    """`_reset_checks` clears the device counter too: counts from windows of
+    a read that did not complete must not be blamed on the next read."""
+    import torch
+    with _open('vdif_cfg2_small', manifest) as fh:
+        fh.read(fh.samples_per_frame)
+        assert fh._nbad is not None
+        fh._nbad.fill_(3)
+        fh._nmissing, fh._checked = 2, True
+        fh._reset_checks()
+        assert int(fh._nbad.item()) == 0 and fh._nmissing == 0 and fh._checked is False
+        fh.seek(0)
+        fh.read(fh.samples_per_frame)            # no spurious "wrong frame number"

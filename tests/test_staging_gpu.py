@@ -125,3 +125,27 @@ def test_repair_does_not_upload_twice():
     assert not g[1000 * 32000:1001 * 32000].any()
     assert bits_equal(g[1001 * 32000:1999 * 32000], exp[1001 * 32000:1999 * 32000])
     assert bits_equal(g[2001 * 32000:], exp[2001 * 32000:])
+
+
+def test_kept_windows_have_a_stated_byte_cap():
+    """keep_staged=None keeps files of at most `keep_staged_max_bytes` (4 GiB
+    by default), not a share of the GPU's memory (ADVICE r2 / VERDICT r2 weak
+    5); larger files rotate two window buffers and still read correctly,
+    keep_staged=True keeps them anyway."""
+    from baseband_amd import vdif
+    from baseband_amd.base.base import GPUStreamReaderBase
+    assert GPUStreamReaderBase.keep_staged is None
+    assert GPUStreamReaderBase.keep_staged_max_bytes == 4 << 30
+    image, h0 = _file(3000)
+    exp, _ = orc.vdif_read(image, frame_rate=1000)
+    with vdif.open(io.BytesIO(image.tobytes()), 'rs', sample_rate=32e6, squeeze=False) as fh:
+        fh.window_bytes = 1 << 20
+        fh.keep_staged_max_bytes = len(image) - 1       # this file is "too large"
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        assert fh._sink is None and not fh._have
+    with vdif.open(io.BytesIO(image.tobytes()), 'rs', sample_rate=32e6, squeeze=False) as fh:
+        fh.window_bytes = 1 << 20
+        fh.keep_staged_max_bytes = len(image) - 1
+        fh.keep_staged = True
+        assert bits_equal(fh.read().cpu().numpy(), exp)
+        assert fh._sink is not None and fh._has_bytes(0, len(image))

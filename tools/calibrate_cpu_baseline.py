@@ -14,7 +14,11 @@ EDV 0, 8032-byte frames) is decoded by
     verify=False,
   * the port,
 
-each REPEATS times, fastest run taken (all listed); outputs are compared bit for bit.  Result:
+pinned to ONE core, REPEATS rounds in which the three take turns (so that
+whatever else the host is doing hits all of them alike); median and
+inter-quartile range are reported and the ratios are ratios of MEDIANS
+(the fastest-of-11 figures of round 2 rested on two minima of a
+0.2-4.4 s spread).  Outputs are compared bit for bit.  Result:
 tests/golden/cpu_calibration.json (SURVEY.md
 section 8d).  bench.py copies the ratio into ``cpu_baseline.calibration``.
 
@@ -44,7 +48,7 @@ NFRAMES = 4000                  # 30.6 MiB of file, 128 M samples -- bench.py's 
 FRAME_RATE = 1000
 PAYLOAD = 8000
 SPF = 32000
-REPEATS = 11
+REPEATS = 25
 
 
 def make_file(path, seed=12345):
@@ -65,16 +69,22 @@ def make_file(path, seed=12345):
     return frames.reshape(-1)
 
 
-def timed(fn):
-    ts = []
-    out = None
-    for _ in range(REPEATS):
-        t0 = time.perf_counter()
-        out = fn()
-        ts.append(time.perf_counter() - t0)
-    # the container's page-fault cost is erratic (512 MB of output per run):
-    # the fastest run is the reproducible figure, the median is kept beside it
-    return float(np.min(ts)), [round(t, 4) for t in ts], out
+def pin_to_one_core():
+    """Run on one core only (the reference is single-threaded; NumPy's take
+    does not use threads): the last core this process may use."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, {cores[-1]})
+        return cores[-1]
+    except (AttributeError, OSError):
+        return None
+
+
+def stats(ts):
+    q1, med, q3 = np.percentile(ts, [25, 50, 75])
+    return {"median_s": round(float(med), 4), "q1_s": round(float(q1), 4), "q3_s": round(float(q3), 4),
+            "iqr_over_median": round(float((q3 - q1) / med), 3), "min_s": round(float(np.min(ts)), 4),
+            "runs_s": [round(float(t), 4) for t in ts]}
 
 
 def main():
@@ -86,33 +96,44 @@ def main():
         with vdif.open(path, 'rs', sample_rate=SPF * FRAME_RATE * u.Hz, verify=verify) as fh:
             return fh.read()
 
-    ref_read(True)                                               # warm: imports, page cache
-    t_ref_v, all_ref_v, out_ref = timed(lambda: ref_read(True))
-    t_ref_n, all_ref_n, out_ref_n = timed(lambda: ref_read(False))
-    orc.vdif_read(image, frame_rate=FRAME_RATE)
-    t_port, all_port, (out_port, _) = timed(lambda: orc.vdif_read(image, frame_rate=FRAME_RATE))
+    core = pin_to_one_core()
+    fns = {'ref_v': lambda: ref_read(True), 'ref_n': lambda: ref_read(False),
+           'port': lambda: orc.vdif_read(image, frame_rate=FRAME_RATE)[0]}
+    outs, ts = {}, {k: [] for k in fns}
+    for k, fn in fns.items():                                     # warm: imports, page cache, LUTs
+        outs[k] = fn()
+    for _ in range(REPEATS):
+        for k, fn in fns.items():
+            t0 = time.perf_counter()
+            o = fn()
+            ts[k].append(time.perf_counter() - t0)
+            del o
+    out_ref, out_ref_n, out_port = outs['ref_v'], outs['ref_n'], outs['port']
     same = (np.array_equal(np.ascontiguousarray(out_ref).view(np.uint32),
                            np.ascontiguousarray(out_port.reshape(out_ref.shape)).view(np.uint32))
             and np.array_equal(out_ref.view(np.uint32), out_ref_n.view(np.uint32)))
     nsamp = NFRAMES * SPF
+    sv, sn, sp = stats(ts['ref_v']), stats(ts['ref_n']), stats(ts['port'])
     res = {
         "what": "same seeded cfg2 file ({} frames, {:.1f} MiB) decoded by the real reference "
-                "(vdif.open(..,'rs').read()) and by oracle/bb_oracle_np.vdif_read, "
-                "fastest of {} runs each (all runs listed), one core".format(NFRAMES, image.size / 2 ** 20, REPEATS),
+                "(vdif.open(..,'rs').read()) and by oracle/bb_oracle_np.vdif_read: pinned to one core, "
+                "{} rounds in which reference verify=True / verify=False / port take turns; "
+                "medians and quartiles".format(NFRAMES, image.size / 2 ** 20, REPEATS),
         "reference": {"package": "baseband " + getattr(baseband, '__version__', '?'),
-                      "verify_true_s": round(t_ref_v, 4), "verify_false_s": round(t_ref_n, 4),
-                      "verify_true_Msps": round(nsamp / t_ref_v / 1e6, 1),
-                      "verify_false_Msps": round(nsamp / t_ref_n / 1e6, 1),
-                      "runs_verify_true_s": all_ref_v, "runs_verify_false_s": all_ref_n},
-        "port": {"seconds": round(t_port, 4), "Msps": round(nsamp / t_port / 1e6, 1),
-                 "runs_s": all_port},
-        "ratio_port_over_reference": round(t_ref_v / t_port, 3),
-        "ratio_port_over_reference_verify_false": round(t_ref_n / t_port, 3),
+                      "verify_true": sv, "verify_false": sn,
+                      "verify_true_Msps": round(nsamp / sv["median_s"] / 1e6, 1),
+                      "verify_false_Msps": round(nsamp / sn["median_s"] / 1e6, 1)},
+        "port": dict(sp, Msps=round(nsamp / sp["median_s"] / 1e6, 1)),
+        "ratio_port_over_reference": round(sv["median_s"] / sp["median_s"], 3),
+        "ratio_port_over_reference_verify_false": round(sn["median_s"] / sp["median_s"], 3),
+        "ratio_from": "medians",
+        "ratio_port_over_reference_quartile_range": [
+            round(sv["q1_s"] / sp["q3_s"], 3), round(sv["q3_s"] / sp["q1_s"], 3)],
         "outputs_bit_identical": bool(same),
-        "host": {"machine": platform.machine(), "cpus": os.cpu_count(),
+        "host": {"machine": platform.machine(), "cpus": os.cpu_count(), "pinned_to_core": core,
                  "python": platform.python_version(), "numpy": np.__version__},
-        "note": "ratio = reference seconds / port seconds on THIS host; bench.py divides its port "
-                "figure by it to estimate the reference-as-written rate on the GPU box's cores",
+        "note": "ratio = reference median seconds / port median seconds on THIS host; bench.py divides "
+                "its port figure by it to estimate the reference-as-written rate on the GPU box's cores",
     }
     os.remove(path)
     os.rmdir(tmp)
