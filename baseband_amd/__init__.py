@@ -35,13 +35,13 @@ def asnumpy(data, out=None):
 __all__ += ['asnumpy']
 
 
-def empty_output(shape, dtype=None, candidates=3, device='cuda', report=None):
-    """Uninitialised device tensor for ``read(out=...)``, chosen as the fastest
-    to decode into among a few allocations (`baseband_amd.placement`)."""
+def empty_output(shape, dtype=None, device=None):
+    """Uninitialised device tensor for ``read(out=...)`` and for outputs of the
+    caller's own: from the placement arena when there is one with room, else
+    ``torch.empty`` (`baseband_amd.placement`)."""
     import torch
     from .placement import empty_output as _empty
-    return _empty(shape, dtype=torch.float32 if dtype is None else dtype, candidates=candidates,
-                  device=device, report=report)
+    return _empty(shape, dtype=torch.float32 if dtype is None else dtype, device=device)
 
 
 __all__ += ['empty_output']

@@ -120,6 +120,14 @@ class TiledParams(C.Structure):
                 ('fill_re', C.c_float), ('fill_im', C.c_float)]
 
 
+class ArenaStats(C.Structure):
+    _fields_ = [('base', C.c_uint64), ('capacity', C.c_uint64), ('bytes_backed', C.c_uint64),
+                ('bytes_in_use', C.c_uint64), ('largest_free', C.c_uint64), ('bytes_grown', C.c_uint64),
+                ('bytes_trimmed', C.c_uint64), ('chunk_bytes', C.c_uint32), ('steps', C.c_uint32),
+                ('blocks', C.c_uint32), ('reserved', C.c_uint32), ('create_ms', C.c_double),
+                ('grow_ms', C.c_double)]
+
+
 LAYOUT_GUPPI_CF = 0
 LAYOUT_MKBF = 1
 LAYOUT_GUPPI_TF = 2
@@ -141,7 +149,7 @@ _vp = C.c_void_p
 _sz = C.c_size_t
 
 # (name, restype, argtypes) -- must list every symbol of include/bbdecode.h
-# and include/bbdecode_tune.h
+# include/bbdecode_tune.h and include/bbdecode_arena.h
 SIGNATURES = [
     ('bb_abi_version', C.c_int, []),
     ('bb_strerror', C.c_char_p, [C.c_int]),
@@ -172,6 +180,13 @@ SIGNATURES = [
     ('bb_encode_flat', C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     ('bb_encode_mark4', C.c_int, [_vp, _sz, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _vp, _sz, _vp]),
     ('bb_tune', C.c_int, [C.c_int, C.c_int]),
+    # include/bbdecode_arena.h
+    ('bb_arena_create', C.c_int, [_sz, C.POINTER(_vp)]),
+    ('bb_arena_alloc', C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    ('bb_arena_free', C.c_int, [_vp, _vp]),
+    ('bb_arena_trim', C.c_int, [_vp, C.POINTER(_sz)]),
+    ('bb_arena_get_stats', C.c_int, [_vp, C.POINTER(ArenaStats)]),
+    ('bb_arena_destroy', C.c_int, [_vp]),
 ]
 
 # include/bbdecode_exp.h

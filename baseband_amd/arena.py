@@ -1,0 +1,144 @@
+"""Output memory for the decode launches (include/bbdecode_arena.h).
+
+The write rate of a decode launch depends on how its output was allocated
+(DESIGN.md 3.2): into plain allocations of 4-34 GB it is 5.3-5.7 TB/s in most
+draws and 6.4-6.8 in some; into memory created as chunks with the HIP virtual
+memory API and mapped into one virtual range it is 6.5-6.8 in every draw.  An
+`Arena` is such a range: backed on demand by 32 MiB chunks, first-fit
+allocator on top.  Tensors come from `Arena.empty()`; they alias arena memory
+through ``__cuda_array_interface__`` and give their block back when the last
+view of them dies.  `trim()` returns unused physical memory to the device.
+
+Blocks are not stream-tracked: a block is reusable as soon as its tensor is
+garbage collected.  The readers of this package launch on torch's current
+stream, so a program that stays on one stream needs no care.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+class _Block:
+    """Owner of one arena block; torch keeps it alive through the array
+    interface and drops it with the last tensor that views the block."""
+    __slots__ = ('arena', 'ptr', '__cuda_array_interface__', '__weakref__')
+
+    def __init__(self, arena, ptr, shape, typestr):
+        self.arena, self.ptr = arena, ptr
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (ptr, False),
+                                         'version': 2, 'strides': None}
+
+    def __del__(self):
+        arena = self.arena
+        if arena is not None and arena._handle:
+            lib.bb_arena_free(arena._handle, C.c_void_p(self.ptr))
+
+
+_TYPESTR = {torch.float32: '<f4', torch.uint8: '|u1', torch.int32: '<i4', torch.int64: '<i8',
+            torch.int8: '|i1', torch.float64: '<f8'}
+
+
+class Arena:
+    """``Arena(capacity_bytes)`` on the current (or given) device.  Nothing is
+    taken from the device until tensors are asked for."""
+
+    def __init__(self, capacity, device=None):
+        from . import kernels
+        kernels.require_gpu()
+        self._handle = None
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            kernels.init()
+            check(lib.bb_arena_create(int(capacity), C.byref(h)), 'bb_arena_create')
+        self._handle = h
+        st = self.stats()
+        self._range = (st['base'], st['base'] + st['capacity'])
+
+    def empty(self, shape, dtype=torch.float32):
+        """Uninitialised tensor of `shape` in arena memory, or None when
+        neither the arena's capacity nor the device's free memory allow it (the
+        caller falls back to ``torch.empty``).  complex64 is allocated as
+        float32 pairs."""
+        if self._handle is None:
+            return None
+        shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        cplx = dtype == torch.complex64
+        base = torch.float32 if cplx else dtype
+        n = int(np.prod(shape, dtype=np.int64)) * (2 if cplx else 1)
+        if n == 0:
+            return torch.empty(shape, dtype=dtype, device=self.device)
+        item = torch.empty(0, dtype=base).element_size()
+        p = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = lib.bb_arena_alloc(self._handle, n * item, C.byref(p))
+        if rc == _lib.BB_ERANGE or not p.value:
+            return None
+        check(rc, 'bb_arena_alloc')
+        block = _Block(self, p.value, (n,), _TYPESTR[base])
+        t = torch.as_tensor(block, device=self.device)
+        if cplx:
+            t = torch.view_as_complex(t.view(-1, 2))
+        return t.view(shape)
+
+    def owns(self, tensor):
+        """Does `tensor` live in this arena?"""
+        return (self._handle is not None and tensor.is_cuda
+                and self._range[0] <= tensor.data_ptr() < self._range[1])
+
+    def trim(self):
+        """Give physical memory that no live tensor uses back to the device
+        (whole growth steps from the end of the backed part); returns bytes."""
+        if self._handle is None:
+            return 0
+        n = C.c_size_t()
+        check(lib.bb_arena_trim(self._handle, C.byref(n)), 'bb_arena_trim')
+        return int(n.value)
+
+    def stats(self):
+        s = _lib.ArenaStats()
+        check(lib.bb_arena_get_stats(self._handle, C.byref(s)), 'bb_arena_get_stats')
+        return {f: getattr(s, f) for f, _ in s._fields_ if f != 'reserved'}
+
+    def close(self):
+        """Release the arena's memory.  Tensors still alive become invalid."""
+        h, self._handle = self._handle, None
+        if h:
+            check(lib.bb_arena_destroy(h), 'bb_arena_destroy')
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = None
+
+
+def enable(capacity=None):
+    """Create the process-wide arena the readers take their output tensors
+    from (`placement.empty_output`) and return it; `capacity` None: the whole
+    memory of the current device (virtual range only: physical memory follows
+    the tensors).  ``disable()`` drops it."""
+    global _default
+    disable()
+    if capacity is None:
+        capacity = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
+    _default = Arena(capacity)
+    return _default
+
+
+def disable():
+    global _default
+    a, _default = _default, None
+    if a is not None:
+        a.close()
+
+
+def default():
+    return _default

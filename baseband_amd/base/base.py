@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from .. import kernels
+from ..placement import empty_output
 from ..staging import host_image, WindowPipeline
 
 __all__ = ['FileBase', 'VLBIFileReaderBase', 'GPUStreamReaderBase',
@@ -858,8 +859,7 @@ class GPUStreamReaderBase:
         spf = self.samples_per_frame
         ncomp = 2 if self.complex_data else 1
         row = int(np.prod(self._decode_shape)) * ncomp
-        flat = into if into is not None else torch.empty(
-            nsets * spf * row, dtype=torch.float32, device='cuda')
+        flat = into if into is not None else empty_output(nsets * spf * row, torch.float32)
         set_nbytes = self._set_nbytes
         resident = self._resident_bytes() if nsets else None
         if resident is None and nsets and self._have:
@@ -890,8 +890,18 @@ class GPUStreamReaderBase:
                 self._pipeline = WindowPipeline(image, (per_win + 1) * set_nbytes)
             sink = self._sink_tensor()
             ranges, spans = [], []
-            for s in range(first, last, per_win):
-                e = min(last, s + per_win)
+            # the first two windows are short (1/16 and 1/4 of a window): nothing
+            # overlaps the first host copy and the first H2D, so they should be
+            # small; from the third window on the pipeline runs at the link's rate
+            # (profiles/r03h_prof_pipeline_windows.log -> r03i_)
+            starts, s = [], first
+            for size in (max(1, per_win // 16), max(1, per_win // 4)):
+                if s < last:
+                    starts.append(s)
+                    s += size
+            starts.extend(range(s, last, per_win))
+            for i, s in enumerate(starts):
+                e = min(last, starts[i + 1] if i + 1 < len(starts) else s + per_win)
                 lo = min(self._file_offset0 + s * set_nbytes, len(image))
                 # when verifying, the frame set after the last one requested
                 # travels along: a frame only counts as good if the header

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from .. import kernels
+from ..placement import empty_output
 from ..staging import WindowPipeline
 from .base import GPUStreamReaderBase, _to_host_array
 
@@ -135,7 +136,7 @@ class BlockStreamReader(GPUStreamReaderBase):
         if direct:
             flat = (torch.view_as_real(out) if self.complex_data else out).reshape(-1)
         else:
-            flat = torch.empty(count * row, dtype=torch.float32, device='cuda')
+            flat = empty_output(count * row, torch.float32)
         pieces = self._pieces(self.offset, count)
         image = self._image()
         resident = self._resident_bytes()

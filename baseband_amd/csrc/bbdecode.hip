@@ -1348,3 +1348,6 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 }
 
 } // extern "C"
+
+#include "bbdecode_arena.h"
+#include "bb_arena.inc"

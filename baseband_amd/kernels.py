@@ -67,6 +67,13 @@ def to_device_bytes(raw, device=None):
     return torch.from_numpy(np.array(a, copy=True)).to(device or 'cuda')
 
 
+def _empty_output(nelem, device):
+    """float32 output tensor of a decode launch: from the placement arena when
+    there is one (placement.empty_output), else torch.empty."""
+    from .placement import empty_output
+    return empty_output(nelem, torch.float32, device)
+
+
 class _Target:
     """Output tensor for a decode launch.  The kernels store 16 bytes per
     lane, so the library wants `out` 16-byte aligned; a slice of a larger
@@ -77,9 +84,9 @@ class _Target:
     def __init__(self, out, nelem, device):
         self.want = out
         if out is None:
-            self.use = torch.empty(nelem, dtype=torch.float32, device=device)
+            self.use = _empty_output(nelem, device)
         elif out.data_ptr() % 16 or not out.is_contiguous():
-            self.use = torch.empty(out.numel(), dtype=torch.float32, device=device)
+            self.use = _empty_output(out.numel(), device)
         else:
             self.use = out
 
@@ -274,7 +281,7 @@ def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
         nsel = within.numel()
         nelem = nelem // chunk * nsel
         if out is None:
-            out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
+            out = _empty_output(nelem, dbuf.device)
         check(lib.bb_decode_frames_select(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes, C.byref(p),
                                           _ptr(within), nsel, _ptr(out), out.numel(), _stream(dbuf)),
               'bb_decode_frames_select')
@@ -348,7 +355,7 @@ def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
         nout = len(sign_bit)
         nelem = nframes * nwords * nout
         if out is None:
-            out = torch.empty(nelem, dtype=torch.float32, device=dbuf.device)
+            out = _empty_output(nelem, dbuf.device)
         check(lib.bb_decode_mark4_select(_ptr(dbuf), dbuf.numel(), _ptr(src), nframes, C.byref(p),
                                          nout, _ptr(out), out.numel(), _stream(dbuf)),
               'bb_decode_mark4_select')

@@ -1,69 +1,87 @@
-"""Choosing WHERE in HBM an output tensor lies.
+"""Where the decoded output lies in HBM.
 
-The write rate of a decode launch depends on where its output lies in physical
-memory more than on anything inside the kernels (the
-same launch runs at 5.3 TB/s in one allocation and at 6.4-6.9 in another; the
-L2's write-credit stalls towards the memory controllers tell the two apart).
-The library cannot place memory, but a caller who decodes into the same
-buffer again and again -- a pipeline that reads chunk after chunk with
-``fh.read(out=buffer)`` -- can choose among several allocations once:
-`empty_output` allocates a few candidates, times a decode-shaped probe launch
-on each while all of them are held (so that they lie in different places) and
-keeps the fastest.
+The write rate of a decode launch depends on how its output was allocated more
+than on anything inside the kernels: into a plain
+allocation of 4-34 GB -- the output of an ordinary ``read()`` -- the same
+launch runs at 5.3-5.7 TB/s in most draws and at 6.4-6.8 in some, while every
+tensor cut from an arena of VMM chunks (`baseband_amd.arena`) decodes at
+6.5-6.8 (profiles/r03f_exp_arena.log, r03g_exp_arena_*.log, r03h_*).
+
+`empty_output` is what the readers allocate their outputs with: from the
+process-wide arena for outputs of at least `ARENA_MIN_BYTES`, else (and
+whenever the arena cannot serve) ``torch.empty``.  The arena is created on
+first use; it is only a virtual range until tensors need memory, and
+`release_unused()` gives unused memory back (done automatically when torch
+runs out of memory here).
+
+    BB_ARENA=0          never create one (plain ``torch.empty`` everywhere)
+    BB_ARENA_GIB=<n>    capacity of the arena in GiB (default: the device's memory)
+    baseband_amd.arena.enable(capacity) / .disable()   the same from the program
+
+Round 2's `empty_output(shape, candidates=k)` -- allocate k tensors, probe
+each, keep the fastest -- is gone: it needed k times the memory and still lost
+when all k draws were slow.
 """
+import os
+import warnings
+
+import numpy as np
 import torch
 
-from . import _lib, kernels
+from . import arena as _arena
 
-__all__ = ['empty_output', 'probe_rate']
+__all__ = ['empty_output', 'release_unused', 'ARENA_MIN_BYTES']
 
-_FRAME, _PAYLOAD = 8032, 8000           # the probe decodes 2-bit VDIF-like frames
-
-
-def probe_rate(out, reps=3):
-    """TB/s (input + output bytes) of a 2-bit decode launch that fills `out`
-    (float32 or complex64 device tensor; it is overwritten)."""
-    flat = torch.view_as_real(out).reshape(-1) if out.is_complex() else out.reshape(-1)
-    if flat.dtype != torch.float32 or not flat.is_cuda or flat.data_ptr() % 16:
-        raise ValueError("a float32 / complex64 device tensor with 16-byte alignment is needed")
-    nframes = flat.numel() // (4 * _PAYLOAD)
-    if nframes == 0:
-        raise ValueError("the tensor is smaller than one probe frame")
-    raw = torch.randint(0, 256, (nframes * _FRAME + 256,), dtype=torch.uint8, device=flat.device)
-    src = torch.arange(nframes, device=flat.device, dtype=torch.int64) * _FRAME + (_FRAME - _PAYLOAD)
-    target = flat[:nframes * 4 * _PAYLOAD]
-    best = None
-    for k in range(reps + 1):
-        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        kernels.decode_frames(raw, nframes, _PAYLOAD, _lib.CODER_VDIF, 2, src=src, out=target)
-        stop.record()
-        stop.synchronize()
-        ms = start.elapsed_time(stop)
-        if k and (best is None or ms < best):           # (the first launch warms up)
-            best = ms
-    return nframes * (_FRAME + 16 * _PAYLOAD) / best / 1e9
+# smaller outputs come from torch's allocator: their launches are latency bound
+# (a 64 MiB decode takes 10 us) and the arena's granule is 32 MiB
+ARENA_MIN_BYTES = 64 << 20
+_failed = False                 # arena creation failed once: do not try again in this process
 
 
-def empty_output(shape, dtype=torch.float32, candidates=3, device='cuda', report=None):
-    """An uninitialised device tensor like ``torch.empty(shape, dtype=dtype)``,
-    the fastest to decode into of `candidates` allocations (all of them are held
-    while they are probed: `candidates` times the size must fit).  `report`, if
-    a list, receives the probed rates in TB/s."""
-    kernels.require_gpu()
-    held, rates = [], []
-    for _ in range(max(1, int(candidates))):
-        try:
-            t = torch.empty(shape, dtype=dtype, device=device)
-        except torch.cuda.OutOfMemoryError:
-            break
-        held.append(t)
-        rates.append(probe_rate(t) if candidates > 1 else 0.)
-    if not held:
-        raise torch.cuda.OutOfMemoryError("no room for an output of shape {}".format(tuple(shape)))
-    if report is not None:
-        report.extend(rates)
-    keep = held[max(range(len(held)), key=rates.__getitem__)]
-    del held
-    torch.cuda.empty_cache()        # (the losers go back to the driver, not into torch's cache)
-    return keep
+def _arena_for(device):
+    """The process-wide arena (created now if there is none yet); None when
+    switched off, on another device, or not available."""
+    global _failed
+    ar = _arena.default()
+    if ar is not None:
+        return ar if ar.device == device else None
+    if _failed or os.environ.get('BB_ARENA', '1') in ('0', 'off', 'no'):
+        return None
+    env = os.environ.get('BB_ARENA_GIB')
+    try:
+        with torch.cuda.device(device):
+            return _arena.enable(int(float(env) * 2 ** 30) if env else None)
+    except Exception as exc:            # no VMM on this system: the readers work without it
+        _failed = True
+        warnings.warn("baseband_amd: no output arena ({!r}); outputs come from torch.empty".format(exc))
+        return None
+
+
+def release_unused():
+    """Give the arena's unused physical memory back to the device; bytes."""
+    ar = _arena.default()
+    return ar.trim() if ar is not None else 0
+
+
+def empty_output(shape, dtype=torch.float32, device=None):
+    """Uninitialised device tensor like ``torch.empty(shape, dtype=dtype,
+    device='cuda')`` for a decode launch to write into: from the arena when the
+    output is large, else from torch's allocator."""
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+    item = 8 if dtype == torch.complex64 else torch.empty(0, dtype=dtype).element_size()
+    nbytes = int(np.prod(shape, dtype=np.int64)) * item
+    if nbytes >= ARENA_MIN_BYTES:
+        ar = _arena_for(device)
+        if ar is not None:
+            t = ar.empty(shape, dtype)
+            if t is not None:
+                return t
+    try:
+        return torch.empty(shape, dtype=dtype, device=device)
+    except torch.cuda.OutOfMemoryError:
+        if not release_unused():
+            raise
+        return torch.empty(shape, dtype=dtype, device=device)

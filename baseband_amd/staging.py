@@ -99,9 +99,13 @@ class WindowPipeline:
         self._copy_stream = None
         self._count = 0
 
-    def _buffers(self, b):
+    def _buffers(self, b, need_dev=True):
         if self._pinned[b] is None:
             self._pinned[b] = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True)
+        if need_dev and self._dev[b] is None:
+            # (windows that go to their own place in a file-sized `sink` need no
+            # rotating device buffer: 2 x 64 MiB less to allocate per read,
+            # profiles/r03h_prof_pipeline_windows.log)
             # +256 slack: kernels may read whole dwords at the tail
             self._dev[b] = torch.empty(self.cap + 256, dtype=torch.uint8, device=self.device)
             # the caching allocator may hand back a block whose previous owner
@@ -138,7 +142,7 @@ class WindowPipeline:
             self._count += 1
             if self._done[b] is not None:
                 self._done[b].synchronize()          # buffer b free again
-            pinned, dev = self._buffers(b)
+            pinned, dev = self._buffers(b, need_dev=sink is None)
             target = dev[:n] if sink is None else sink[lo:hi]
             _stage(pinned.numpy(), self.image, lo, hi)           # page cache -> pinned (CPU)
             with torch.cuda.stream(self._copy_stream):

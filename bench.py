@@ -32,6 +32,10 @@ Besides the contract's keys the line carries
   parity_digests sha256 of golden files decoded here vs the reference's digests
   other_configs Mark 5B / Mark 4 / GUPPI / DADA / 8-thread real VDIF kernels
                 on inputs that decode to the headline's output size (N = 1 only)
+  mid_size      the launch sizes ordinary read() calls issue (2^15, 2^16, 2^18
+                cfg2 frames; GUPPI 8 GiB in) into FRESH outputs, torch.empty
+                against the placement arena the readers allocate from, min /
+                median / max over the draws (N = 1 only)
 """
 import argparse
 import csv
@@ -681,6 +685,142 @@ def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
         lambda: kernels.decode_i8_tiled(buf, nfr, _lib.LAYOUT_MKBF, npol, nchan, Tm, 0, Tm, src0=0,
                                         src_stride=blkm, out=o),
         nb, nb * 4, nb // 2, "complex_samples")
+    # cfg5 "DADA float32 passthrough": NBIT 32 is an EXTENSION of this package
+    # (the reference raises KeyError(32), dada/payload.py:40-41; parity is
+    # unpinned by construction): the reader copies the payload bytes device to
+    # device (dada/base.py `_decode_window`), no kernel of this library runs
+    nb = min(nbytes8, out.numel() * 4) // 16 * 16
+    o = out[:nb // 4]
+    src32 = buf[:nb].view(torch.float32)
+    med, mean = timed_launches(lambda: o.copy_(src32), reps)
+    res.append({"case": "DADA NBIT=32 float32 passthrough (extension, parity unpinned: no reference counterpart)",
+                "kernel": "torch copy_ (device to device; no libbbdecode kernel)", "ms": round(mean, 4),
+                "ms_median": round(med, 4), "algorithmic_GBps": round(2 * nb / mean / 1e6, 1),
+                "frac": round(2 * nb / mean / 1e6 / HBM_PEAK_GBS, 4), "bytes_in": nb, "bytes_out": nb,
+                "Msamples_per_s": round(nb / 4 / mean / 1e3, 1)})
+    return res
+
+
+def leg_mid_size(device, image, draws=5, launches=6):
+    """the launch sizes an ordinary ``read()`` issues
+    (/root/reference semantics: base/base.py:919-969) -- cfg2 windows of 2^15,
+    2^16 and 2^18 frames (4.2, 8.4, 33.6 GB of output) and a GUPPI
+    channels-first read of 8 GiB (34 GB of output).  Every draw is a FRESH
+    output: `draws` new ``torch.empty`` allocations (the cache emptied in
+    between, so each is a new piece of HBM), and `draws` new blocks from the
+    placement arena -- what the readers allocate from by default
+    (baseband_amd/placement.py) -- taking turns.  Every launch decodes the NEXT
+    window of the 8 GiB image (nothing of the input can still be in the 256
+    MiB Infinity Cache); a draw's figure is the median of `launches` launches by
+    HIP events on the launching stream; reported: min / median / max over the
+    draws of the fraction of 8 TB/s.  Also one timed pass through the drop-in
+    API per size: ``fh.read(count)`` allocating its own output."""
+    import baseband_amd
+    from baseband_amd import kernels, _lib, arena, placement, vdif
+    img_frames = image.numel() // FRAME_NBYTES
+    nxt = [0]
+
+    def rate(out, nf):
+        ts = []
+        for r in range(launches + 1):
+            if nxt[0] + nf > img_frames:
+                nxt[0] = 0
+            first = nxt[0]
+            nxt[0] += nf
+            win = image[first * FRAME_NBYTES:(first + nf) * FRAME_NBYTES]
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            kernels.decode_frames(win, nf, PAYLOAD_NBYTES, _lib.CODER_VDIF, 2, src0=HEADER_NBYTES,
+                                  src_stride=FRAME_NBYTES, out=out)
+            b.record()
+            b.synchronize()
+            if r:
+                ts.append(a.elapsed_time(b))
+        return nf * (FRAME_NBYTES + PAYLOAD_NBYTES * 16) / float(np.median(ts)) / 1e6      # GB/s
+
+    def summary(v):
+        f = np.array(v) / HBM_PEAK_GBS
+        return {"GBps_per_draw": [round(x, 1) for x in v],
+                "frac_min": round(float(f.min()), 4), "frac_median": round(float(np.median(f)), 4),
+                "frac_max": round(float(f.max()), 4)}
+
+    torch.cuda.empty_cache()
+    # the arena the readers create on their first large output (placement.py)
+    ar = placement._arena_for(device)
+    res = {"arena": None if ar is None else ar.stats(),
+           "method": "fresh output per draw ({} draws, torch.empty and arena blocks taking turns); per draw the median of "
+                     "{} launches, each on the next window of the resident 8 GiB image; HIP events".format(draws, launches),
+           "sizes": []}
+    for lf in (15, 16, 18):
+        nf = 1 << lf
+        n = nf * SPF
+        v_t, v_a, held = [], [], []
+        for d in range(draws):
+            o = torch.empty(n, dtype=torch.float32, device=device)
+            v_t.append(rate(o, nf))
+            del o
+            torch.cuda.empty_cache()
+            o = ar.empty(n) if ar is not None else None
+            if o is None and held:
+                held.clear()                         # the arena is full of the pieces held back: start over
+                o = ar.empty(n)
+            if o is not None:
+                v_a.append(rate(o, nf))
+                held.append(ar.empty((64 << 20) // 4))      # so that the next block starts elsewhere
+                del o
+        del held
+        row = {"frames": nf, "output_GB": round(n * 4 / 1e9, 2), "kernel": _lib.last_kernel(),
+               "torch_empty": summary(v_t), "arena": summary(v_a) if v_a else None}
+        # the drop-in API on the same image: read(count) allocates its own output
+        try:
+            with vdif.open(image, 'rs', sample_rate=float(SPF * FRAME_RATE)) as fh:
+                ts = []
+                for k in range(4):
+                    fh.seek(((k * 3 + 1) * nf % (img_frames - nf)) * SPF)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    got = fh.read(nf * SPF)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                    inside = ar is not None and ar.owns(got)
+                    del got
+                ms = float(np.median(ts[1:])) * 1e3
+                row["api_read"] = {"call": "fh.read({} * 32000) at changing offsets, output allocated by the reader".format(nf),
+                                   "ms_median": round(ms, 3), "output_in_arena": bool(inside),
+                                   "GBps": round(nf * (FRAME_NBYTES + PAYLOAD_NBYTES * 16) / ms / 1e6, 1),
+                                   "frac": round(nf * (FRAME_NBYTES + PAYLOAD_NBYTES * 16) / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                   "timing": "host wall clock incl. scan, index, allocation and the verification sync"}
+        except Exception as exc:
+            row["api_read"] = {"error": repr(exc)[:300]}
+        res["sizes"].append(row)
+    # GUPPI channels first, 8 GiB in -> 34 GB out (the first 8 GiB of the image as 64 blocks of 128 MiB)
+    try:
+        npol, nchan, blk = 2, 64, 128 << 20
+        T = blk // (npol * nchan * 2)
+        nfr = min(64, image.numel() // blk)
+        nb = nfr * blk
+        v_t, v_a = [], []
+
+        def grate(o):
+            med, mean = timed_launches(lambda: kernels.decode_i8_tiled(image, nfr, _lib.LAYOUT_GUPPI_CF, npol, nchan, T, 0, T,
+                                                                       src0=0, src_stride=blk, out=o), launches)
+            return (nb + nb * 4) / med / 1e6
+        for d in range(draws):
+            o = torch.empty(nb, dtype=torch.float32, device=device)
+            v_t.append(grate(o))
+            del o
+            torch.cuda.empty_cache()
+            o = ar.empty(nb) if ar is not None else None
+            if o is not None:
+                v_a.append(grate(o))
+                del o
+        res["guppi_cf_8GiB_in"] = {"output_GB": round(nb * 4 / 1e9, 2), "kernel": _lib.last_kernel(),
+                                   "torch_empty": summary(v_t), "arena": summary(v_a) if v_a else None}
+    except Exception as exc:
+        res["guppi_cf_8GiB_in"] = {"error": repr(exc)[:300]}
+    if ar is not None:
+        res["arena_after"] = ar.stats()
+        res["arena_released_bytes"] = placement.release_unused()
     return res
 
 
@@ -909,6 +1049,16 @@ def main():
                 line["other_configs"] = leg_other_configs(device, out)
             except Exception as exc:
                 line["other_configs"] = [{"error": repr(exc)[:500]}]
+            # the launch sizes of ordinary read() calls, into fresh outputs: the
+            # 127.5 GiB headline output goes first, the 8 GiB image comes back
+            del out
+            torch.cuda.empty_cache()
+            try:
+                image, _ = make_file_image_on_device(nframes, 12345, 0, device)
+                line["mid_size"] = leg_mid_size(device, image)
+                del image
+            except Exception as exc:
+                line["mid_size"] = {"error": repr(exc)[:500]}
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -1,0 +1,78 @@
+/*
+ * bbdecode_arena.h -- OUTPUT memory for the decode launches (part of
+ * libbbdecode.so; optional: every decode entry point takes any device pointer).
+ *
+ * Why: on MI355X the write rate of a decode-shaped store stream depends on how
+ * its output was allocated.  Into a plain allocation (hipMalloc, torch.empty)
+ * of 4-34 GB -- the output of an ordinary read(), base/base.py:919-969 in the
+ * reference -- the same launch runs at 5.3-5.7 TB/s in most draws and at
+ * 6.4-6.8 in some; into memory that was created as chunks with the HIP virtual
+ * memory API and mapped into one virtual range it runs at 6.5-6.8 in EVERY
+ * draw, for chunks of 2 to 128 MiB alike (same-process A/B, six fresh outputs
+ * per size, five processes: profiles/r03f_exp_arena.log, r03g_exp_arena_*.log,
+ * r03h_exp_arena_chunk*.log).  The arena is that: a virtual
+ * range of `capacity` bytes, backed on demand in steps of whole GiB by 32 MiB
+ * chunks (dealt round robin over the step's 1 GiB "teeth", +1 %), with a
+ * first-fit allocator of 32 MiB granules on top.  Memory is taken from the
+ * device only when a block needs it and goes back with bb_arena_trim.
+ *
+ * Not stream-ordered: bb_arena_free makes the block available to the next
+ * bb_arena_alloc at once; the caller must have ordered its work on the block
+ * before freeing (the Python host frees when the last tensor view dies; it
+ * launches everything on torch's current stream).  Thread safe.
+ */
+#ifndef BBDECODE_ARENA_H
+#define BBDECODE_ARENA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bb_arena bb_arena;
+
+typedef struct bb_arena_stats {
+    uint64_t base;           /* device address of the arena's virtual range */
+    uint64_t capacity;       /* size of the virtual range (whole GiB) */
+    uint64_t bytes_backed;   /* physical memory mapped now */
+    uint64_t bytes_in_use;   /* handed out by bb_arena_alloc and not freed */
+    uint64_t largest_free;   /* largest block that fits without growing */
+    uint64_t bytes_grown;    /* physical memory taken from the device so far ... */
+    uint64_t bytes_trimmed;  /* ... and given back by bb_arena_trim */
+    uint32_t chunk_bytes;    /* mapping and allocation granule (32 MiB) */
+    uint32_t steps;          /* growth steps mapped now */
+    uint32_t blocks;         /* live blocks */
+    uint32_t reserved;
+    double   create_ms;      /* wall time of bb_arena_create */
+    double   grow_ms;        /* wall time spent growing (hipMemCreate + hipMemMap), total */
+} bb_arena_stats;
+
+/* Reserve a virtual range of `capacity` bytes (rounded up to whole GiB) on the
+ * CURRENT device.  No physical memory is taken yet.  BB_EINVAL: capacity == 0;
+ * BB_EIO: a HIP call failed (no virtual memory management). */
+int bb_arena_create(size_t capacity, bb_arena **arena);
+
+/* A block of at least `bytes` (rounded up to whole granules), granule aligned.
+ * Grows the backed part by whole GiB when no free range is large enough.
+ * *d_ptr = NULL and BB_ERANGE when the capacity or the device's memory is
+ * exhausted. */
+int bb_arena_alloc(bb_arena *arena, size_t bytes, void **d_ptr);
+
+/* Return a block (the pointer bb_arena_alloc gave).  BB_EINVAL: not a live block. */
+int bb_arena_free(bb_arena *arena, void *d_ptr);
+
+/* Give physical memory back to the device: growth steps at the END of the
+ * backed part that hold no live block.  *released (may be NULL) = bytes. */
+int bb_arena_trim(bb_arena *arena, size_t *released);
+
+int bb_arena_get_stats(bb_arena *arena, bb_arena_stats *stats);
+
+/* Unmap and release everything.  Live blocks become invalid. */
+int bb_arena_destroy(bb_arena *arena);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBDECODE_ARENA_H */

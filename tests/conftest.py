@@ -5,6 +5,11 @@ import sys
 import numpy as np
 import pytest
 
+# the readers create a placement arena on their first large output (a quarter
+# of the free device memory by default): keep it small in the test process,
+# which also runs full-size cases that want most of the GPU for themselves
+os.environ.setdefault('BB_ARENA_GIB', '6')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 for p in (ROOT, os.path.join(ROOT, 'oracle')):

@@ -1,0 +1,166 @@
+"""The output arena (include/bbdecode_arena.h, baseband_amd/arena.py,
+placement.py): tensors cut from it are ordinary device tensors that decode
+bit-exactly, blocks come back when their tensors die, the allocator grows on
+demand, coalesces and trims, and the readers allocate their outputs from it."""
+import ctypes as C
+import gc
+
+import numpy as np
+import pytest
+
+from conftest import golden_path, load_expected, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+GIB = 1 << 30
+
+
+@pytest.fixture
+def small_arena():
+    from baseband_amd import arena
+    ar = arena.Arena(8 * GIB)
+    yield ar
+    ar.close()
+
+
+def test_arena_tensors_are_plain_tensors_and_decode_right(manifest, small_arena):
+    import torch
+    from baseband_amd import vdif
+    case = manifest['vdif_cfg2_small']
+    exp = load_expected('vdif_cfg2_small')
+    st = small_arena.stats()
+    assert st['capacity'] == 8 * GIB and st['bytes_backed'] == 0 and st['blocks'] == 0
+    G = st['chunk_bytes']
+    assert G == 32 << 20
+    out = small_arena.empty((exp.shape[0],))
+    assert out.shape == (exp.shape[0],) and out.dtype == torch.float32 and out.is_cuda
+    assert out.data_ptr() % G == 0 and small_arena.owns(out)
+    assert small_arena.stats()['bytes_backed'] == 2 * GIB          # grown by the minimum step
+    with vdif.open(golden_path(case['file']), 'rs', sample_rate=case['frame_rate'] * case['samples_per_frame']) as fh:
+        assert fh.read(out=out) is out
+    assert bits_equal(out.cpu().numpy(), exp.reshape(-1))
+    # torch ops work on it like on any tensor; views keep the block alive
+    assert float((out * 0 + 1).sum()) == out.numel()
+    view = out[5:9]
+    assert small_arena.stats()['blocks'] == 1
+    del out
+    gc.collect()
+    assert small_arena.stats()['blocks'] == 1
+    del view
+    gc.collect()
+    assert small_arena.stats()['blocks'] == 0 and small_arena.stats()['bytes_in_use'] == 0
+    c = small_arena.empty((1000, 8, 16), dtype=torch.complex64)
+    assert c.shape == (1000, 8, 16) and c.dtype == torch.complex64
+    c.fill_(1 + 2j)
+    assert complex(c[3, 2, 1]) == 1 + 2j
+
+
+def test_blocks_are_cut_first_fit_coalesce_grow_and_trim(small_arena):
+    import torch
+    G = small_arena.stats()['chunk_bytes']
+    f = G // 4                                     # float32 per granule
+    a = small_arena.empty(3 * f)                   # 3 granules
+    b = small_arena.empty(5 * f)                   # 5 granules
+    c = small_arena.empty(f + 1)                   # 1 granule + 4 bytes -> 2 granules
+    base = a.data_ptr()
+    assert base == small_arena.stats()['base']
+    assert b.data_ptr() == base + 3 * G and c.data_ptr() == base + 8 * G
+    assert small_arena.stats()['bytes_in_use'] == 10 * G
+    del b
+    gc.collect()
+    d = small_arena.empty(4 * f)                   # fits the hole b left
+    assert d.data_ptr() == base + 3 * G
+    e = small_arena.empty(2 * f)                   # the granule left of the hole is too small
+    assert e.data_ptr() == base + 10 * G
+    # growth: 3 GiB does not fit behind the 12 granules in use of the first 2 GiB step
+    big = small_arena.empty(3 * GIB // 4)
+    st = small_arena.stats()
+    assert big is not None and big.data_ptr() == base + 12 * G
+    assert st['steps'] == 2 and st['bytes_backed'] == 4 * GIB         # 2 GiB + what was missing, in whole GiB
+    big.fill_(2.5)
+    assert float(big[-1]) == 2.5 and float(big[big.numel() // 2]) == 2.5     # across the step boundary
+    # more than the capacity: None, nothing changes
+    assert small_arena.empty(9 * GIB // 4) is None
+    assert small_arena.stats()['bytes_backed'] == 4 * GIB
+    del a, c, d, e, big
+    gc.collect()
+    st = small_arena.stats()
+    assert st['bytes_in_use'] == 0 and st['largest_free'] == 4 * GIB          # everything coalesced
+    free0, _ = torch.cuda.mem_get_info()
+    assert small_arena.trim() == 4 * GIB
+    st = small_arena.stats()
+    assert st['bytes_backed'] == 0 and st['steps'] == 0 and st['bytes_trimmed'] == 4 * GIB
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 - free0 >= 3 * GIB                                           # the device has it back
+    # a live block in the last step pins it (and what lies before it)
+    x = small_arena.empty(f)
+    y = small_arena.empty(3 * GIB // 4)
+    del x
+    gc.collect()
+    assert small_arena.trim() == 0
+    del y
+    gc.collect()
+    assert small_arena.trim() == small_arena.stats()['bytes_trimmed'] - 4 * GIB > 0
+
+
+def test_raw_abi_rejects_what_is_not_a_block(small_arena):
+    from baseband_amd import _lib
+    lib, h = _lib.lib, small_arena._handle
+    G = small_arena.stats()['chunk_bytes']
+    p = C.c_void_p()
+    assert lib.bb_arena_alloc(h, 100, C.byref(p)) == _lib.BB_OK and p.value
+    q = C.c_void_p()
+    assert lib.bb_arena_alloc(h, 100, C.byref(q)) == _lib.BB_OK and q.value == p.value + G
+    assert lib.bb_arena_free(h, C.c_void_p(p.value + 2 * G)) == _lib.BB_EINVAL    # not a live block
+    assert lib.bb_arena_free(h, C.c_void_p(p.value + 8)) == _lib.BB_EINVAL        # not a block start
+    assert lib.bb_arena_free(h, C.c_void_p(p.value)) == _lib.BB_OK
+    assert lib.bb_arena_free(h, C.c_void_p(p.value)) == _lib.BB_EINVAL            # twice
+    assert lib.bb_arena_free(h, C.c_void_p(q.value)) == _lib.BB_OK
+    assert lib.bb_arena_create(0, C.byref(p)) == _lib.BB_EINVAL
+    # a capacity beyond the device's memory is only a virtual range; blocks fail when memory runs out
+    huge = C.c_void_p()
+    assert lib.bb_arena_create(1 << 40, C.byref(huge)) == _lib.BB_OK
+    assert lib.bb_arena_alloc(huge, 1 << 39, C.byref(p)) == _lib.BB_ERANGE and not p.value
+    assert lib.bb_arena_destroy(huge) == _lib.BB_OK
+
+
+def test_readers_take_their_outputs_from_the_arena(manifest, monkeypatch):
+    """placement.empty_output: read() results of at least ARENA_MIN_BYTES live
+    in the process-wide arena (created on first use) and are freed into it;
+    smaller ones, and everything when the arena is switched off, are torch
+    allocations."""
+    import torch
+    import baseband_amd
+    from baseband_amd import arena, placement, vdif
+    case = manifest['vdif_cfg2_small']
+    exp = load_expected('vdif_cfg2_small')
+    kw = dict(sample_rate=case['frame_rate'] * case['samples_per_frame'])
+    arena.disable()
+    try:
+        monkeypatch.setattr(placement, 'ARENA_MIN_BYTES', 1 << 16)
+        with vdif.open(golden_path(case['file']), 'rs', **kw) as fh:
+            fh.decode_ahead = False
+            got = fh.read()
+        ar = arena.default()
+        assert ar is not None, "the first output did not create the arena"
+        assert ar.owns(got), "read() output is not in the arena"
+        assert bits_equal(got.cpu().numpy(), exp.reshape(got.shape))
+        assert ar.stats()['blocks'] >= 1
+        del got
+        gc.collect()
+        assert ar.stats()['blocks'] == 0
+        mine = baseband_amd.empty_output((4 << 20,))
+        assert ar.owns(mine) and not ar.owns(torch.empty(4, device='cuda'))
+        small = baseband_amd.empty_output((100,))
+        assert not ar.owns(small)                                  # below the threshold: torch's allocator
+        del mine
+        gc.collect()
+        assert placement.release_unused() == ar.stats()['bytes_trimmed'] > 0
+        assert ar.stats()['bytes_backed'] == 0
+    finally:
+        arena.disable()
+    monkeypatch.setenv('BB_ARENA', '0')
+    with vdif.open(golden_path(case['file']), 'rs', **kw) as fh:
+        got = fh.read()
+    assert bits_equal(got.cpu().numpy(), exp.reshape(got.shape))
+    assert arena.default() is None

@@ -377,10 +377,11 @@ def test_read_ahead_failures_that_are_not_about_the_file_surface(manifest, monke
     read itself still served.  Anything else (library errors, bugs) is not
     swallowed."""
     import torch
+    from baseband_amd.vdif.base import VDIFStreamReader
     exp = load_expected('vdif_cfg2_small')
+    real = VDIFStreamReader._read_sets              # (before anything is patched)
     with _open('vdif_cfg2_small', manifest, squeeze=False) as fh:
         spf = fh.samples_per_frame
-        real = type(fh)._read_sets
         state = {'n': 0}
 
         def oom_once(self, first, last, into=None):
@@ -400,7 +401,6 @@ def test_read_ahead_failures_that_are_not_about_the_file_surface(manifest, monke
         assert any('read-ahead switched off' in str(x.message) for x in w)
     with _open('vdif_cfg2_small', manifest, squeeze=False) as fh:
         spf = fh.samples_per_frame
-        real = type(fh)._read_sets
 
         def broken(self, first, last, into=None):
             if last - first > 4:
