@@ -117,14 +117,15 @@ class TiledParams(C.Structure):
                 ('nchan_stored', C.c_int32), ('ntime', C.c_uint64),
                 ('t_lo', C.c_uint64), ('t_hi', C.c_uint64),
                 ('src0', C.c_int64), ('src_stride', C.c_int64),
-                ('fill_re', C.c_float), ('fill_im', C.c_float)]
+                ('fill_re', C.c_float), ('fill_im', C.c_float),
+                ('npol_stored', C.c_int32), ('pol_first', C.c_int32), ('d_chan_map', C.c_void_p)]
 
 
 class ArenaStats(C.Structure):
     _fields_ = [('base', C.c_uint64), ('capacity', C.c_uint64), ('bytes_backed', C.c_uint64),
                 ('bytes_in_use', C.c_uint64), ('largest_free', C.c_uint64), ('bytes_grown', C.c_uint64),
                 ('bytes_trimmed', C.c_uint64), ('chunk_bytes', C.c_uint32), ('steps', C.c_uint32),
-                ('blocks', C.c_uint32), ('reserved', C.c_uint32), ('create_ms', C.c_double),
+                ('blocks', C.c_uint32), ('probes', C.c_uint32), ('last_probe_gbps', C.c_double), ('create_ms', C.c_double),
                 ('grow_ms', C.c_double)]
 
 

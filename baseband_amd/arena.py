@@ -102,7 +102,7 @@ class Arena:
     def stats(self):
         s = _lib.ArenaStats()
         check(lib.bb_arena_get_stats(self._handle, C.byref(s)), 'bb_arena_get_stats')
-        return {f: getattr(s, f) for f, _ in s._fields_ if f != 'reserved'}
+        return {f: getattr(s, f) for f, _ in s._fields_}
 
     def close(self):
         """Release the arena's memory.  Tensors still alive become invalid."""

@@ -572,6 +572,7 @@ class GPUStreamReaderBase:
         self._sink, self._have = None, []
 
     # -- windows that were staged once stay in HBM
+    ramp_windows = True     # the first two staging windows of a large read are short (pipeline fill)
     keep_staged = None      # None: keep files of at most `keep_staged_max_bytes`; True / False: always / never
     keep_staged_max_bytes = 4 << 30
     _sink = None            # device tensor of the file's size (+ slack), filled window by window
@@ -895,7 +896,7 @@ class GPUStreamReaderBase:
             # small; from the third window on the pipeline runs at the link's rate
             # (profiles/r03h_prof_pipeline_windows.log -> r03i_)
             starts, s = [], first
-            for size in (max(1, per_win // 16), max(1, per_win // 4)):
+            for size in ((max(1, per_win // 16), max(1, per_win // 4)) if self.ramp_windows else ()):
                 if s < last:
                     starts.append(s)
                     s += size

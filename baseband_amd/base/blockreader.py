@@ -70,18 +70,27 @@ class BlockStreamReader(GPUStreamReaderBase):
             self._prefetch = None
         super().close()
     _chan_lo = 0            # first channel decoded (`_plan_channel_range`)
+    _sel = None             # (first pol, pols kept, int32 channel list): a selection that is not a plain range
+    _cmap_dev = None
 
     def _plan_channel_range(self):
-        """For (pol, chan) samples decoded by bb_decode_i8_tiled: a `subset`
-        that keeps all polarisations and a contiguous RANGE of channels is the
-        same decode with the payload entered at the first kept channel and
-        fewer channels (`nchan_stored` tells the kernel the strides): the other
-        channels are not written and -- where the format stores channels apart
-        (GUPPI channels-first) -- not read either.  The reference decodes whole
-        blocks and indexes afterwards (base/base.py:706-717 after
-        guppi/payload.py:90-102, dada/payload.py:76-79).  Checked by value,
-        like `_plan_channel_select`: the subset is applied to arrays of
-        polarisation and channel numbers."""
+        """For (pol, chan) samples decoded by bb_decode_i8_tiled: fold a
+        `subset` into the decode instead of decoding whole blocks and indexing
+        afterwards, as the reference does (base/base.py:706-717 after
+        guppi/payload.py:90-102, dada/payload.py:76-79).
+
+        * all polarisations and a contiguous RANGE of channels: the same decode
+          with the payload entered at the first kept channel and fewer channels
+          (`nchan_stored` tells the kernel the strides); the other channels are
+          not written and -- where the format stores channels apart (GUPPI
+          channels-first) -- not read either.  Every kernel takes this.
+        * any channel LIST (gaps, any order) and / or one of two polarisations:
+          `chan_map` / `pol_first` of bb_tiled_params (`_sel`); taken by the
+          fast transposing kernel only -- `_tiled_decode` falls back to decoding
+          whole blocks and indexing when the library answers ENOTSUP.
+
+        Checked by value, like `_plan_channel_select`: the subset is applied to
+        arrays of polarisation and channel numbers."""
         if not self.subset or len(self._unsliced_shape) != 2:
             return
         npol, nchan = self._unsliced_shape
@@ -97,15 +106,65 @@ class BlockStreamReader(GPUStreamReaderBase):
             c, p = view(chan).reshape(-1), view(pol).reshape(-1)
         except Exception:
             return
-        if c.size == 0 or c.size % npol:
+        if c.size == 0:
             return
-        m, lo = c.size // npol, int(c[0])
-        if m == nchan or not (np.array_equal(p, np.repeat(np.arange(npol), m))
-                              and np.array_equal(c, np.tile(np.arange(lo, lo + m), npol))):
+        # the polarisations kept: a run pf, pf + 1, ... each with the same channel list
+        npk = int(np.unique(p).size)
+        if c.size % npk:
             return
-        self._chan_lo = lo
-        self._decode_shape = (npol, m)
-        self._within_np = np.arange(lo, lo + m, dtype=np.int32)     # (the decode applies the subset)
+        m, pf, lo = c.size // npk, int(p[0]), int(c[0])
+        cl = c[:m]
+        if not (np.array_equal(p, np.repeat(np.arange(pf, pf + npk), m))
+                and np.array_equal(c, np.tile(cl, npk))):
+            return
+        whole_pols = npk == npol
+        if whole_pols and np.array_equal(cl, np.arange(lo, lo + m)):
+            if m == nchan:
+                return                              # everything, in order: nothing to fold
+            self._chan_lo = lo
+            self._decode_shape = (npol, m)
+            self._within_np = np.arange(lo, lo + m, dtype=np.int32)     # (the decode applies the subset)
+            return
+        if not (whole_pols or (npol == 2 and npk == 1)) or m % 2 or m > 65536:
+            return                                  # (the kernel writes channel pairs; odd counts index afterwards)
+        self._sel = (pf, npk, cl.astype(np.int32))
+        self._decode_shape = (npk, m)
+        self._within_np = cl.astype(np.int32)
+
+    def _tiled_decode(self, dbuf, nframes, layout, ntime, a, b, src0, src_stride, out_flat):
+        """Times [a, b) of `nframes` blocks of `ntime` stored times each (payloads
+        at ``src0 + i * src_stride``) -> `out_flat`, honouring the planned channel
+        range or selection."""
+        npol_s, nchan_s = self._unsliced_shape
+        if self._sel is None:
+            skip = kernels.tiled_channel_skip(layout, npol_s, ntime, self._chan_lo)
+            kernels.decode_i8_tiled(dbuf, nframes, layout, npol_s, self._decode_shape[-1], ntime, a, b,
+                                    src0=src0 + skip, src_stride=src_stride, out=out_flat,
+                                    nchan_stored=nchan_s)
+            return
+        pf, npk, cl = self._sel
+        if self._cmap_dev is None or self._cmap_dev.device != dbuf.device:
+            self._cmap_dev = torch.from_numpy(cl).to(dbuf.device)
+        try:
+            kernels.decode_i8_tiled(dbuf, nframes, layout, npk, cl.size, ntime, a, b, src0=src0,
+                                    src_stride=src_stride, out=out_flat, nchan_stored=nchan_s,
+                                    npol_stored=npol_s, pol_first=pf, chan_map=self._cmap_dev)
+            return
+        except KeyError:
+            pass
+        # a geometry the selecting kernel does not take (unaligned payloads):
+        # whole blocks, then the index -- the reference's order -- in pieces of
+        # at most 1 GiB of decoded samples
+        rows = b - a
+        per = max(1, (1 << 28) // max(1, rows * npol_s * nchan_s * 2))
+        idx = self._cmap_dev.long()
+        n_out = rows * npk * cl.size * 2
+        for f0 in range(0, nframes, per):
+            n = min(per, nframes - f0)
+            tmp = kernels.decode_i8_tiled(dbuf, n, layout, npol_s, nchan_s, ntime, a, b,
+                                          src0=src0 + f0 * src_stride, src_stride=src_stride)
+            part = tmp.view(n * rows, npol_s, nchan_s, 2)[:, pf:pf + npk][:, :, idx]
+            out_flat[f0 * n_out:(f0 + n) * n_out] = part.reshape(-1)
 
     def _frame_span(self, frame):
         """(byte offset of the frame in the file, number of bytes to stage)."""

@@ -8,6 +8,7 @@
 #include "k_exp.h"
 #endif
 #include "k_lut.h"
+#include "k_lds.h"
 #include "k_gather.h"
 #include "k_mark4.h"
 #include "k_tiled.h"
@@ -295,12 +296,25 @@ void launch_flat(int bps, int coder, int om, bool nt, dim3 grid, hipStream_t st,
     });
 }
 
-// the byte table kernel: contiguous 1-, 2- and 4-bit output (the headline kernel)
+// the byte table kernel with 16-byte loads staged through LDS: contiguous 2-bit
+// output (the headline kernel; k_lds.h)
+template <int BPS>
+void launch_flat_lds(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+    with_nt(nt, [&](auto NT) {
+        hipLaunchKernelGGL((k_decode_flat_lds<BPS, decltype(NT)::value, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    });
+}
+
+// the byte table kernel with dword loads handed out by ds_bpermute: contiguous
+// 1- and 4-bit output (k_lut.h)
 void launch_flat_lut(int bps, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
     with_nt(nt, [&](auto NT) {
         constexpr bool N = decltype(NT)::value;
-        if (bps == 1)      hipLaunchKernelGGL((k_decode_flat_lut<1, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        // (1-bit work items are at most 8 tiles per wave: the 8-tile instantiation
+        // stays below 128 VGPRs, the 16-tile one needs 129 = one wave per SIMD less)
+        if (bps == 1)      hipLaunchKernelGGL((k_decode_flat_lut<1, N, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
         else if (bps == 2) hipLaunchKernelGGL((k_decode_flat_lut<2, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
         else               hipLaunchKernelGGL((k_decode_flat_lut<4, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
     });
@@ -720,8 +734,15 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // 8-bit kernels.  1-bit 6.58 -> 6.86 TB/s against 4 tiles, 4-bit 5.28 ->
         // 6.62 and +7 % over the plain kernel it used before
         // (profiles/r02ar_exp_1bit_items.log, r02ar_exp_4bit_lut.log)
+        // 2-bit samples: k_decode_flat_lds (16-byte loads through LDS, at most 8 tiles
+        // per wave); 1- and 4-bit: k_decode_flat_lut -- profiles/r03j_exp_lds.log
+        bool lds = p->bps == 2;
+#if BB_EXP
+        if (g_tune_variant.load() == 15) lds = true;        // A/B: force either kernel for every sample width
+        if (g_tune_variant.load() == 16) lds = false;
+#endif
         int lut_tiles = g_tune_lut_tpw.load() * p->bps / 2;
-        lut_tiles = lut_tiles < 1 ? 1 : lut_tiles > 16 ? 16 : lut_tiles;
+        lut_tiles = lut_tiles < 1 ? 1 : lut_tiles > (lds ? 8 : 16) ? (lds ? 8 : 16) : lut_tiles;
         const uint64_t seg_max = 2ull * (uint64_t)lut_tiles;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
@@ -731,8 +752,18 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
-        launch_flat_lut(p->bps, nt, g2, st, a);
-        BB_NOTE("k_decode_flat_lut<%d,%s,2,16> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", g2.x, a.tpw);
+        if (lds) {
+#if BB_EXP
+            if (p->bps == 1) launch_flat_lds<1>(nt, g2, st, a);
+            else if (p->bps == 4) launch_flat_lds<4>(nt, g2, st, a);
+            else
+#endif
+            launch_flat_lds<2>(nt, g2, st, a);
+            BB_NOTE("k_decode_flat_lds<%d,%s,2,8> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", g2.x, a.tpw);
+        } else {
+            launch_flat_lut(p->bps, nt, g2, st, a);
+            BB_NOTE("k_decode_flat_lut<%d,%s,2,16> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", g2.x, a.tpw);
+        }
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
@@ -1115,15 +1146,22 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     if (nframes == 0 || rows == 0) return BB_OK;
     if (!d_buf || !d_out) return BB_EINVAL;
     if (((uintptr_t)d_buf & 1) || ((uintptr_t)d_out & 15)) return BB_EINVAL;
-    const uint64_t rowlen = (uint64_t)p->npol * p->nchan * 2;
+    const uint64_t rowlen = (uint64_t)p->npol * p->nchan * 2;           // floats per output time
     if (out_elems < (uint64_t)nframes * rows * rowlen) return BB_ERANGE;
     // a channel RANGE of the stored channels: the payload offsets point at the
     // first kept channel, strides follow the stored count
-    if (p->nchan_stored < 0 || (p->nchan_stored && p->nchan_stored < p->nchan)) return BB_EINVAL;
+    if (p->nchan_stored < 0 || (p->nchan_stored && p->nchan_stored < p->nchan && !p->d_chan_map)) return BB_EINVAL;
     const uint64_t ncs = p->nchan_stored ? (uint64_t)p->nchan_stored : (uint64_t)p->nchan;
+    // a selection (channel list and / or one of two polarisations): offsets
+    // point at the payload start, strides follow the stored counts
+    if (p->npol_stored < 0 || p->pol_first < 0) return BB_EINVAL;
+    const uint64_t nps = p->npol_stored ? (uint64_t)p->npol_stored : (uint64_t)p->npol;
+    if ((uint64_t)p->pol_first + (uint64_t)p->npol > nps) return BB_EINVAL;
+    const bool selecting = p->d_chan_map != nullptr || nps != (uint64_t)p->npol;
+    if (p->d_chan_map && !p->nchan_stored) return BB_EINVAL;
     // bytes from the first kept channel of the first time to the end of the last kept one
-    uint64_t payload = p->ntime * (uint64_t)p->npol * ncs * 2;
-    if (ncs != (uint64_t)p->nchan) {
+    uint64_t payload = p->ntime * nps * ncs * 2;
+    if (!selecting && ncs != (uint64_t)p->nchan) {
         const uint64_t cut = ncs - (uint64_t)p->nchan;              // channels not entered
         payload -= (p->layout == BB_LAYOUT_GUPPI_CF ? cut * p->ntime * (uint64_t)p->npol
                     : p->layout == BB_LAYOUT_MKBF ? cut * 256 : cut * (uint64_t)p->npol) * 2;
@@ -1147,7 +1185,10 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     a.fill_re = p->fill_re;
     a.fill_im = p->fill_im;
     a.src_lim = src_limit(buf_nbytes, payload);
-    const uint64_t T = p->ntime, np_ = (uint64_t)p->npol, nc = (uint64_t)p->nchan;
+    a.nps = (uint32_t)nps;
+    a.pf = (uint32_t)p->pol_first;
+    a.cmap = p->d_chan_map;
+    const uint64_t T = p->ntime, np_ = nps, nc = (uint64_t)p->nchan;
     switch (p->layout) {
         case BB_LAYOUT_GUPPI_CF: a.tb = T ? T : 1; a.sh = 0; a.st = np_; a.sp = 1; a.sc = T * np_; break;
         case BB_LAYOUT_MKBF:     a.tb = 256; a.sh = np_ * ncs * 256; a.st = 1; a.sp = ncs * 256; a.sc = 256; break;
@@ -1160,15 +1201,19 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     // aligned, at least 32 channels.  Fixed stride only (offsets from an index
     // cannot be checked for alignment here).
     {
-        const uint64_t rows = (p->t_hi - p->t_lo) * np_;
-        bool ok = g_tune_xpose.load() != 0 && !d_src && nc >= 32 && !(nc & 1)
-                  && !((uintptr_t)d_buf & 15) && !(p->src0 & 15) && !(p->src_stride & 15);
+        const uint64_t npd = (uint64_t)p->npol;                          // polarisations decoded
+        const uint64_t rows = (p->t_hi - p->t_lo) * npd;                 // output rows per frame
+        // (a selection may keep few channels; without one, narrow blocks stay with k_tiled.h)
+        bool ok = g_tune_xpose.load() != 0 && !d_src && (selecting ? nc >= 2 : nc >= 32) && !(nc & 1)
+                  && !((uintptr_t)d_buf & 15) && !(p->src0 & 15) && !(p->src_stride & 15)
+                  && (npd == np_ || (np_ == 2 && npd == 1));
         if (p->layout == BB_LAYOUT_GUPPI_CF)
             ok = ok && ((T * np_ * 2) % 16 == 0) && ((p->t_lo * np_ * 2) % 16 == 0);
         else if (p->layout == BB_LAYOUT_MKBF)
             ok = ok && (np_ == 1 || np_ == 2) && (p->t_lo % 8 == 0);
         else
-            ok = ok && np_ == 2 && (nc % 4 == 0) && (ncs % 4 == 0);
+            ok = ok && np_ == 2 && (p->d_chan_map ? true : (nc % 4 == 0)) && (ncs % 4 == 0);
+        if (!ok && selecting) return BB_ENOTSUP;
         if (ok) {
             // rows per tile: 128 for channels-first blocks (5.9 -> 6.3 TB/s against
             // 64 at the headline's output size); for time-first blocks and MKBF
@@ -1177,10 +1222,12 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
             const int xr = g_tune_xpose_rows.load();
             const bool big = (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4 >= (96ull << 30);
             const uint64_t xrows = xr ? (uint64_t)xr : (p->layout == BB_LAYOUT_GUPPI_CF || big) ? 128u : 64u;
-            const uint64_t ntt = (rows + xrows - 1) / xrows, nct = (nc + BB_XP_TC - 1) / BB_XP_TC;
+            // output rows per tile: half an LDS image when one of two pols is dropped (layouts 0, 2)
+            const uint64_t rpt = p->layout == BB_LAYOUT_MKBF ? xrows : xrows / (np_ / npd);
+            const uint64_t ntt = (rows + rpt - 1) / rpt, nct = (nc + BB_XP_TC - 1) / BB_XP_TC;
             if (ntt > 0xffffffffull) return BB_ERANGE;
             a.ntt = (uint32_t)ntt; a.nct = (uint32_t)nct;
-            a.tt = (uint32_t)(xrows / np_); a.tc = BB_XP_TC; a.tcp = 2 * BB_XP_PITCH;
+            a.tt = (uint32_t)(xrows / npd); a.tc = BB_XP_TC; a.tcp = 2 * BB_XP_PITCH;
             uint64_t blocks = (uint64_t)nframes * ntt * nct;
             a.perm = make_perm(blocks, (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4);
             // one tile per workgroup: with 20 % of the traffic being reads the

@@ -417,4 +417,3 @@ void k_decode_flat2_bytes(bb_flat_args a)
 }
 
 #include "k_front.h"
-#include "k_lds.h"

@@ -137,15 +137,31 @@ void k_decode_gather_select(bb_gather_args a)
     uint32_t *s_base = s_valid + a.nslot;
     float *s_tab = reinterpret_cast<float *>(s_base + a.nslot + 1);
     uint32_t *s_within = reinterpret_cast<uint32_t *>(s_tab + (LV == BB_LV_LDS ? NCODE : 0));
+    __shared__ float s_fill[2];
+    if (threadIdx.x == 0) { s_fill[0] = a.fill_re; s_fill[1] = a.fill_im; }
 
-    bb_levels<BPS, LV> lv;
-    lv.lds = s_tab;
+    // (levels as plain locals, not the bb_levels struct: captured by reference
+    // by the lambda below, the struct was kept on the stack in the table
+    // variants -- 16 bytes of scratch per lane)
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     if (LV == BB_LV_LDS) {
         for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
     } else if (LV == BB_LV_REG) {
-        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
-        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+        t0 = a.tab[0]; t1 = a.tab[1];
+        if (BPS == 2) { t2 = a.tab[2]; t3 = a.tab[3]; }
     }
+    auto level = [&](uint32_t code) -> float {
+        if constexpr (LV == BB_LV_REG) {
+            if (BPS == 1) return code ? t1 : t0;
+            const float lo = (code & 1) ? t1 : t0;
+            const float hi = (code & 1) ? t3 : t2;
+            return (code & 2) ? hi : lo;
+        } else if constexpr (LV == BB_LV_LDS) {
+            return s_tab[code];
+        } else {
+            return (float)(int)(int8_t)code;
+        }
+    };
     for (uint32_t i = threadIdx.x; i < a.nsel; i += BB_BLOCK) s_within[i] = (uint32_t)a.within[i];
     const uint64_t E = a.ndw * (32 / BPS);
     const uint64_t R = E >> a.lchunk;
@@ -173,8 +189,10 @@ void k_decode_gather_select(bb_gather_args a)
             uint32_t code;
             if (BPS == 8) code = rawb[s_base[s] + (bit >> 3)];
             else code = ((uint32_t)rawb[s_base[s] + (bit >> 3)] >> (bit & 7)) & CMASK;
-            float v = lv.get(code);
-            if (!s_valid[s]) v = (a.complex_data && (within & 1)) ? a.fill_im : a.fill_re;
+            float v = level(code);
+            // (the fill values wait in LDS: held in SGPRs across the kernel they were
+            // the two values the table variants spilled to scratch)
+            if (!s_valid[s]) v = s_fill[(a.complex_data && (within & 1)) ? 1 : 0];
             return v;
         };
         if (V4) {
@@ -229,14 +247,28 @@ void k_decode_gather(bb_gather_args a)
     uint32_t *s_base = s_valid + a.nslot;
     float *s_tab = reinterpret_cast<float *>(s_base + a.nslot + 1);
 
-    bb_levels<BPS, LV> lv;
-    lv.lds = s_tab;
+    // (levels as plain locals, not the bb_levels struct: captured by reference
+    // by the lambda below, the struct was kept on the stack in the table
+    // variants -- 16 bytes of scratch per lane)
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
     if (LV == BB_LV_LDS) {
         for (int i = threadIdx.x; i < NCODE; i += BB_BLOCK) s_tab[i] = a.tab[i];
     } else if (LV == BB_LV_REG) {
-        lv.t0 = a.tab[0]; lv.t1 = a.tab[1];
-        if (BPS == 2) { lv.t2 = a.tab[2]; lv.t3 = a.tab[3]; }
+        t0 = a.tab[0]; t1 = a.tab[1];
+        if (BPS == 2) { t2 = a.tab[2]; t3 = a.tab[3]; }
     }
+    auto level = [&](uint32_t code) -> float {
+        if constexpr (LV == BB_LV_REG) {
+            if (BPS == 1) return code ? t1 : t0;
+            const float lo = (code & 1) ? t1 : t0;
+            const float hi = (code & 1) ? t3 : t2;
+            return (code & 2) ? hi : lo;
+        } else if constexpr (LV == BB_LV_LDS) {
+            return s_tab[code];
+        } else {
+            return (float)(int)(int8_t)code;
+        }
+    };
     const uint64_t E = a.ndw * (32 / BPS);              // elements per slot
     const uint64_t R = E >> a.lchunk;                   // rows per frame set
     const uint32_t rowlen = a.nslot << a.lchunk;        // floats per output row
@@ -287,7 +319,7 @@ void k_decode_gather(bb_gather_args a)
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t bit = rb + wbit[j];
                     const uint32_t code = ((uint32_t)rawb[base[j] + (bit >> 3)] >> (bit & 7)) & CMASK;
-                    r[j] = lv.get(code);
+                    r[j] = level(code);
                     if (hole[j]) r[j] = (a.complex_data && ((wbit[j] / BPS) & 1)) ? a.fill_im : a.fill_re;
                 }
                 bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
@@ -313,7 +345,7 @@ void k_decode_gather(bb_gather_args a)
                 float r[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    r[j] = lv.get((bits >> (j * BPS)) & CMASK);
+                    r[j] = level((bits >> (j * BPS)) & CMASK);
                     if (hole) r[j] = (a.complex_data && (j & 1)) ? a.fill_im : a.fill_re;
                 }
                 bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
@@ -340,7 +372,7 @@ void k_decode_gather(bb_gather_args a)
                 const bool hole = holes && !s_valid[s];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    r[j] = lv.get((bits >> (j * BPS)) & CMASK);
+                    r[j] = level((bits >> (j * BPS)) & CMASK);
                     if (hole) r[j] = (a.complex_data && (j & 1)) ? a.fill_im : a.fill_re;
                 }
             } else {
@@ -351,7 +383,7 @@ void k_decode_gather(bb_gather_args a)
                 const uint32_t bit = ((row << a.lchunk) + within) * BPS;
                 const uint32_t byte = rawb[s_base[s] + (bit >> 3)];
                 const uint32_t code = (byte >> (bit & 7)) & CMASK;
-                r[j] = lv.get(code);
+                r[j] = level(code);
                 if (holes && !s_valid[s])
                     r[j] = (a.complex_data && (within & 1)) ? a.fill_im : a.fill_re;
                 if (++rem == rowlen) { rem = 0; ++row; }

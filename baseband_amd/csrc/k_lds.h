@@ -1,6 +1,11 @@
-// Experiment: the byte-table decode with 16-BYTE input
-// loads staged through LDS, against k_decode_flat_lut's dword-per-lane loads
-// handed out by ds_bpermute.
+// The byte-table decode with 16-BYTE input loads staged through LDS (VERDICT r2
+// next 4), the product's kernel for contiguous 2-BIT output: against
+// k_decode_flat_lut's dword-per-lane loads handed out by ds_bpermute it is
+// +1.0-1.5 % at the headline size and +1.3-5.4 % at 2^16-2^18 frames for
+// 8000-, 8192- and 10000-byte payloads, bit-identical (same-process A/B,
+// profiles/r03j_exp_lds.log); 1-bit samples show no difference and 4-bit
+// samples lose 3-12 % (two table reads per store), so those stay with
+// k_decode_flat_lut.
 //
 // A lane that loads 16 contiguous bytes holds the codes of 64 (2-bit) samples
 // = 256 B of output, but the store pattern that HBM wants is 1 KiB contiguous
@@ -14,8 +19,8 @@
 // LDS address offset here, not a second shuffle.  Payload edges: a 16-byte
 // piece that is not entirely inside the payload is loaded dword by dword, only
 // the dwords inside (nothing outside the payload is read, as in k_lut.h).
-// Payloads at odd byte addresses are not handled (the dispatcher keeps
-// k_decode_flat_lut for them).
+// Payloads at odd byte addresses (files repaired by the byte-granular search)
+// are staged byte by byte: rare, correctness only.
 //
 // One work item per workgroup-step (2 waves x tpw tiles), no register prefetch
 // -- k_decode_flat_lut runs one item per workgroup at its default grid too.
@@ -77,8 +82,14 @@ void k_decode_flat_lds(bb_flat_args a)
         if (b0 < seg_b_end) { nb = seg_b_end - b0; if (nb > (uint64_t)a.tpw * 256) nb = (uint64_t)a.tpw * 256; }
         float *obase = a.out + bb_out_slot(a, fs) * E + b0 * (8 / BPS);
         uint32_t s = 0;
-        if (valid && nb) {
-            const uint8_t *pp = a.buf + (uint64_t)so + b0;                // 4-byte aligned (host checks)
+        if (valid && nb && (reinterpret_cast<uintptr_t>(a.buf + (uint64_t)so) & 3)) {
+            // a payload at an odd address: byte loads, staged from offset 0
+            const uint8_t *pp = a.buf + (uint64_t)so + b0;
+            uint8_t *st8 = reinterpret_cast<uint8_t *>(&s_stage[wave][0]);
+#pragma nounroll
+            for (uint32_t i = (uint32_t)lane; i < (uint32_t)nb; i += BB_WAVE) st8[i] = pp[i];
+        } else if (valid && nb) {
+            const uint8_t *pp = a.buf + (uint64_t)so + b0;                // 4-byte aligned
             s = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 255);
             const uint8_t *base = pp - s;                                 // 256-byte aligned address
             const uint32_t lo = s, hi = s + (uint32_t)nb;                 // wanted bytes of the staged image

@@ -39,6 +39,11 @@ struct bb_tiled_args {
     float    fill_re, fill_im;
     uint64_t src_lim;       // offsets outside [0, src_lim) decode as fill (bb_src_ok)
     bb_perm_t perm;         // work order (bb_common.h)
+    // a reader subset folded into the decode (k_decode_i8_xpose only): `npol`
+    // polarisations starting at `pf` of the `nps` stored ones, and channel c of
+    // the output = stored channel cmap[c] (null: c)
+    uint32_t nps, pf;
+    const int32_t *cmap;
 };
 
 template <int LAYOUT, bool NT>

@@ -30,6 +30,18 @@
 //             LDS D[pol][t / 2][chan]; output row = t * npol + pol
 //   LAYOUT 2  GUPPI (time, chan, pol), npol = 2: input row = a time (64 channels x 2 pol);
 //             LDS D[t][chan] (a dword = both pols of one channel); output row = t * 2 + pol
+//
+// A reader `subset` that keeps some channels (any list: a.cmap) and / or one of
+// two polarisations (a.nps stored, a.npol decoded from a.pf on) is folded in
+// (the reference decodes whole blocks and indexes afterwards:
+// base/base.py:706-717 after guppi/payload.py:90-102, dada/payload.py:76-79):
+// channel c of a tile is loaded from stored channel cmap[c0 + c] -- rows of the
+// other channels are never read in layouts 0 and 1; in layout 2, whose rows hold
+// all channels of a time, a mapped tile loads one dword (both pols of a channel)
+// per channel instead of 16-byte pieces.  A dropped polarisation: layout 1
+// loads only the kept (pol, chan) rows; layouts 0 and 2 hold both pols in every
+// LDS dword, so the image is the same and the store phase takes output row r
+// from element i = r * (nps / npol) + pf: only the kept half is written.
 #pragma once
 #include "k_tiled.h"
 
@@ -47,7 +59,10 @@ void k_decode_i8_xpose(bb_tiled_args a)
     constexpr int NLOAD = ROWS / 32;            // 16-byte loads per thread and tile
     constexpr uint32_t LPR = ROWS / 8;          // LAYOUT 0: pieces per channel row (power of two)
     __shared__ uint32_t s_d[(ROWS / 2) * BB_XP_PITCH];
-    const uint32_t npol = a.npol;
+    const uint32_t npol = a.npol, nps = a.nps;
+    // output rows per LDS image: ROWS, or half of it when one of two pols is dropped (layouts 0, 2)
+    const uint32_t estep = LAYOUT == 1 ? 1u : nps / npol;
+    const uint32_t rpt = ROWS / estep;
     const uint64_t rows_out = (a.t_hi - a.t_lo) * npol;         // output rows per frame
     const uint64_t rowlen = (uint64_t)a.nchan * 2;              // floats per output row
     // tile grid of a frame: a.ntt tiles along the output rows, a.nct along channels
@@ -55,7 +70,8 @@ void k_decode_i8_xpose(bb_tiled_args a)
     const uint64_t nwork = a.nframes * per_frame;
     const uint32_t tid = threadIdx.x;
     // times per tile
-    const uint32_t tt = LAYOUT == 0 ? 0u : ROWS / npol;
+    const uint32_t tt = LAYOUT == 0 ? 0u : LAYOUT == 1 ? ROWS / npol : ROWS / nps;
+    auto cm = [&](uint32_t c) -> uint32_t { return a.cmap ? (uint32_t)a.cmap[c] : c; };
 
     bb_u4 nxt[NLOAD];
     bool nxt_valid = false;
@@ -79,10 +95,10 @@ void k_decode_i8_xpose(bb_tiled_args a)
             if (LAYOUT == 0) {
                 // 64 channel rows x ROWS / 8 pieces of 8 elements
                 const uint32_t c = g / LPR, piece = g % LPR;
-                const uint64_t i0 = a.t_lo * npol + (uint64_t)ti * ROWS;
+                const uint64_t i0 = a.t_lo * nps + (uint64_t)ti * ROWS;
                 const uint64_t i = i0 + piece * 8;
-                want = want && c < ncv && i < a.t_hi * npol;
-                ptr = in + (uint64_t)(c0 + c) * a.sc + i;
+                want = want && c < ncv && i < a.t_hi * nps;
+                if (want) ptr = in + (uint64_t)cm(c0 + c) * a.sc + i;
             } else if (LAYOUT == 1) {
                 // npol * 64 (pol, chan) rows x (ROWS / npol / 8) pieces of 8 times
                 const uint32_t ppr = tt >> 3;                       // pieces per row
@@ -90,13 +106,27 @@ void k_decode_i8_xpose(bb_tiled_args a)
                 const uint32_t p = row >> 6, c = row & 63;
                 const uint64_t t = a.t_lo + (uint64_t)ti * tt + piece * 8;
                 want = want && c < ncv && t < a.t_hi;
-                ptr = in + (t >> 8) * a.sh + (t & 255) + (uint64_t)p * a.sp + (uint64_t)(c0 + c) * a.sc;
+                if (want) ptr = in + (t >> 8) * a.sh + (t & 255) + (uint64_t)(a.pf + p) * a.sp + (uint64_t)cm(c0 + c) * a.sc;
             } else {
                 // ROWS / 2 times x 16 pieces of 4 channels (both pols)
                 const uint32_t tl = g >> 4, piece = g & 15;
                 const uint64_t t = a.t_lo + (uint64_t)ti * tt + tl;
                 want = want && t < a.t_hi && piece * 4 < ncv;
                 ptr = in + t * a.st + (uint64_t)(c0 + piece * 4) * 2;     // (st = stored channels x 2 pol)
+                if (a.cmap) {
+                    // mapped channels are not neighbours: one dword (both pols) per channel
+                    bb_u4 v = {0u, 0u, 0u, 0u};
+                    if (want) {
+                        const uint16_t *row = in + t * a.st;
+                        const uint32_t cb = piece * 4;
+                        v.x = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb) * 2);
+                        if (cb + 1 < ncv) v.y = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 1) * 2);
+                        if (cb + 2 < ncv) v.z = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 2) * 2);
+                        if (cb + 3 < ncv) v.w = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 3) * 2);
+                    }
+                    w[k] = v;
+                    continue;
+                }
             }
             w[k] = want ? *reinterpret_cast<const bb_u4 *>(ptr) : bb_u4{0u, 0u, 0u, 0u};
         }
@@ -147,7 +177,7 @@ void k_decode_i8_xpose(bb_tiled_args a)
         const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
         const uint32_t c0 = ci * BB_XP_TC;
         const uint32_t ncv = (a.nchan - c0 < BB_XP_TC) ? a.nchan - c0 : BB_XP_TC;
-        const uint64_t row0 = (uint64_t)ti * ROWS;            // first output row of the tile in its frame
+        const uint64_t row0 = (uint64_t)ti * rpt;             // first output row of the tile in its frame
         float *obase = a.out + (f * rows_out + row0) * rowlen + (uint64_t)c0 * 2;
         const uint64_t rows_left = rows_out - row0;
         const uint32_t cp = tid & 31;                               // channel pair
@@ -157,11 +187,16 @@ void k_decode_i8_xpose(bb_tiled_args a)
         for (int q = 0; q < ROWS / 8; ++q) {
             const uint32_t r = (uint32_t)q * 8 + rsub;              // output row of the tile
             uint32_t idx, half;
-            if (LAYOUT == 0) { idx = (r >> 1) * BB_XP_PITCH; half = r & 1; }
-            else if (LAYOUT == 1) {
+            if (LAYOUT == 1) {
                 const uint32_t tl = npol == 2 ? r >> 1 : r, p = npol == 2 ? r & 1 : 0;
                 idx = (p * (tt >> 1) + (tl >> 1)) * BB_XP_PITCH; half = tl & 1;
-            } else { idx = (r >> 1) * BB_XP_PITCH; half = r & 1; }
+            } else {
+                // element i of the (time, pol) run: row r as it is, or -- one of two
+                // pols dropped -- the kept pol of time r
+                const uint32_t i = r * estep + a.pf;
+                idx = (i >> 1) * BB_XP_PITCH; half = i & 1;
+            }
+            if (r >= rpt) continue;                                 // (wave-uniform: rsub is)
             const uint32_t x = s_d[idx + 2 * cp], y = s_d[idx + 2 * cp + 1];
             if (r >= rows_left || 2 * cp >= ncv) continue;
             const uint32_t e0 = half ? x >> 16 : x & 0xffffu;

@@ -2,6 +2,7 @@
 import io
 from math import gcd
 
+import numpy as np
 import torch
 
 from .. import _lib, kernels
@@ -142,6 +143,8 @@ class DADAStreamReader(BlockStreamReader):
             return None
         base = self._frame_span(frame)[0] + self._header_nbytes
         npol, nchan = self._unsliced_shape
+        if self._mkbf and self._sel is not None:
+            return None                 # (a channel list / one polarisation: whole frames, `_tiled_decode`)
         if self._mkbf:
             h0, h1 = a // 256, -(-b // 256)
             heap = npol * nchan * 256 * 2
@@ -194,22 +197,14 @@ class DADAStreamReader(BlockStreamReader):
         if self._mkbf:
             # a truncated last frame only holds `_last_rows` samples (whole heaps)
             n_full = nframes
-            nkeep = self._decode_shape[-1]          # (a planned channel range: fewer channels,
-            # every heap entered at the first kept one)
-            skip = kernels.tiled_channel_skip(_lib.LAYOUT_MKBF, npol, 0, self._chan_lo)
-            row = (b - a) * npol * nkeep * 2
+            row = (b - a) * int(np.prod(self._decode_shape)) * 2       # (a planned range / selection: fewer values)
             if first_frame + nframes == self._nframes and self._last_rows < self._spf0:
                 n_full -= 1
-                kernels.decode_i8_tiled(
-                    dbuf, 1, _lib.LAYOUT_MKBF, npol, nkeep,
-                    self._last_rows // 256 * 256, a, b,
-                    src0=payload_offset + skip + n_full * frame_stride,
-                    out=out_flat[n_full * row:], nchan_stored=nchan)
+                self._tiled_decode(dbuf, 1, _lib.LAYOUT_MKBF, self._last_rows // 256 * 256, a, b,
+                                   payload_offset + n_full * frame_stride, 0, out_flat[n_full * row:])
             if n_full:
-                kernels.decode_i8_tiled(dbuf, n_full, _lib.LAYOUT_MKBF, npol, nkeep,
-                                        self._spf0, a, b, src0=payload_offset + skip,
-                                        src_stride=frame_stride,
-                                        out=out_flat[:n_full * row], nchan_stored=nchan)
+                self._tiled_decode(dbuf, n_full, _lib.LAYOUT_MKBF, self._spf0, a, b, payload_offset,
+                                   frame_stride, out_flat[:n_full * row])
             return
         if self.bps == 32:
             # EXTENSION (no counterpart in the reference, which knows NBIT 8

@@ -112,6 +112,8 @@ class GUPPIStreamReader(BlockStreamReader):
         h = self.header0
         if self.bps != 8 or not self.complex_data:
             return None
+        if self._sel is not None:
+            return None                 # (a channel list / one polarisation: whole blocks, `_tiled_decode`)
         npol, nchan, T = h.npol, h.nchan, self._spf_full
         base = self._frame_span(frame)[0] + self._header_nbytes
         step = npol * 2                                   # bytes per time of one channel
@@ -150,11 +152,8 @@ class GUPPIStreamReader(BlockStreamReader):
                 out_flat[i * n:(i + 1) * n] = tmp[b0 - lo:b1 - lo]
             return
         layout = _lib.LAYOUT_GUPPI_CF if h.channels_first else _lib.LAYOUT_GUPPI_TF
-        # (a planned channel range: enter every block at its first kept channel)
-        skip = kernels.tiled_channel_skip(layout, h.npol, self._spf_full, self._chan_lo)
-        kernels.decode_i8_tiled(dbuf, nframes, layout, h.npol, self._decode_shape[-1],
-                                self._spf_full, a, b, src0=payload_offset + skip,
-                                src_stride=frame_stride, out=out_flat, nchan_stored=h.nchan)
+        # (a planned channel range or selection is applied by the decode)
+        self._tiled_decode(dbuf, nframes, layout, self._spf_full, a, b, payload_offset, frame_stride, out_flat)
 
 
 class GUPPIStreamWriter(BlockStreamWriter):

@@ -368,16 +368,24 @@ def decode_mark4(dbuf, nframes, ntrack, nwords, sign_bit, mag_bit, fill_words=0,
 
 
 def decode_i8_tiled(dbuf, nframes, layout, npol, nchan, ntime, t_lo, t_hi,
-                    src=None, src0=0, src_stride=0, fill_value=0., out=None, nchan_stored=0):
+                    src=None, src0=0, src_stride=0, fill_value=0., out=None, nchan_stored=0,
+                    npol_stored=0, pol_first=0, chan_map=None):
     """int8 (re, im) -> complex64 with the (time, pol, chan) permutation of
     `layout`; rows [t_lo, t_hi) of every frame -> flat float32 tensor.  With
     `nchan_stored` the payload holds that many channels and the `nchan`
-    starting at the payload offset are decoded (`tiled_channel_skip`)."""
+    starting at the payload offset are decoded (`tiled_channel_skip`).  A
+    SELECTION -- `chan_map` (int32 device tensor of `nchan` stored-channel
+    numbers) and / or `npol` of `npol_stored` polarisations from `pol_first` on
+    -- is decoded from payload offsets that point at the payload start;
+    KeyError when the library's fast form does not take the geometry."""
     p = _lib.TiledParams()
     p.layout = layout
     p.npol = npol
     p.nchan = nchan
     p.nchan_stored = nchan_stored
+    p.npol_stored = npol_stored
+    p.pol_first = pol_first
+    p.d_chan_map = chan_map.data_ptr() if chan_map is not None else None
     p.ntime = ntime
     p.t_lo = t_lo
     p.t_hi = t_hi

@@ -84,11 +84,43 @@ def _stage(dst, image, lo, hi):
         f.result()
 
 
+# Pinned staging buffers are kept between pipelines: pinning 2 x 64 MiB costs
+# 5.7-6 ms per reader (hipHostMalloc; torch's pinned allocator did not hand the
+# blocks back in time for the next reader) -- 12 % of a 2 GiB read
+# (profiles/r03i_prof_pipeline_windows.log).  At most `_PINNED_KEEP` bytes are
+# kept; `release_pinned()` drops them.
+_NBUF = int(os.environ.get('BB_STAGING_BUFFERS', 0)) or 2      # pinned buffers per pipeline
+_PINNED_KEEP = 512 << 20
+_pinned_pool = []           # [(capacity, tensor)]
+
+
+def _pinned_take(cap):
+    for i, (c, t) in enumerate(_pinned_pool):
+        if c >= cap and c <= 2 * cap:
+            del _pinned_pool[i]
+            return t
+    return torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+
+
+def _pinned_give(t):
+    if t is None:
+        return
+    if sum(c for c, _ in _pinned_pool) + t.numel() <= _PINNED_KEEP:
+        _pinned_pool.append((t.numel(), t))
+
+
+def release_pinned():
+    """Drop the pinned staging buffers kept for the next reader."""
+    _pinned_pool.clear()
+
+
 class WindowPipeline:
     """Stream byte windows of a host image through pinned buffers to HBM and
     call ``process(dev_bytes, index)`` for each on the compute stream."""
 
-    def __init__(self, image, max_window_bytes, nbuf=2, device='cuda'):
+    def __init__(self, image, max_window_bytes, nbuf=None, device='cuda'):
+        if nbuf is None:
+            nbuf = _NBUF
         self.image = image
         self.nbuf = nbuf
         self.device = torch.device(device)
@@ -101,7 +133,7 @@ class WindowPipeline:
 
     def _buffers(self, b, need_dev=True):
         if self._pinned[b] is None:
-            self._pinned[b] = torch.empty(self.cap, dtype=torch.uint8, pin_memory=True)
+            self._pinned[b] = _pinned_take(self.cap)
         if need_dev and self._dev[b] is None:
             # (windows that go to their own place in a file-sized `sink` need no
             # rotating device buffer: 2 x 64 MiB less to allocate per read,
@@ -121,6 +153,8 @@ class WindowPipeline:
         reader; keeping an own pool of them measured no gain, and 20 % slower
         64 MiB windows: `BB_STAGING_POOL` A/B in profiles/r01i_exp_staging_pool.log)."""
         self.drain()
+        for t in self._pinned:
+            _pinned_give(t)             # (drained: no copy out of them is pending)
         self._pinned = [None] * self.nbuf
         self._dev = [None] * self.nbuf
         self._done = [None] * self.nbuf

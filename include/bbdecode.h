@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BB_ABI_VERSION 1
+#define BB_ABI_VERSION 2   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
 
 /* error codes (negative errno values) */
 #define BB_OK        0
@@ -447,6 +447,21 @@ typedef struct bb_tiled_params {
     int64_t  src0;            /* payload offsets when d_src == NULL */
     int64_t  src_stride;
     float    fill_re, fill_im;
+    /* A reader subset that keeps a LIST of channels and / or one of two
+     * polarisations, folded into the decode (the reference decodes whole blocks
+     * and indexes afterwards: base/base.py:706-717 after guppi/payload.py:90-102,
+     * dada/payload.py:76-79).  The payload offsets point at the payload START
+     * (no channel skip), nchan_stored / npol_stored give the stored counts:
+     *   out[f, t, p, c] = stored[f, t, pol_first + p, d_chan_map[c]]
+     * for p < npol, c < nchan.  d_chan_map: device array of `nchan` stored-channel
+     * numbers (each < nchan_stored; any order, repeats allowed), NULL = channels
+     * 0 .. nchan-1.  npol_stored 0 = npol.  Only the 16-byte-aligned fast form
+     * takes a selection (payload and buffer 16-byte aligned, even nchan, fixed
+     * stride); anything else answers BB_ENOTSUP and the caller decodes whole
+     * blocks and indexes, like the reference. */
+    int32_t  npol_stored;
+    int32_t  pol_first;
+    const int32_t *d_chan_map;
 } bb_tiled_params;
 
 int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,

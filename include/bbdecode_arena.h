@@ -10,11 +10,22 @@
  * memory API and mapped into one virtual range it runs at 6.5-6.8 in EVERY
  * draw, for chunks of 2 to 128 MiB alike (same-process A/B, six fresh outputs
  * per size, five processes: profiles/r03f_exp_arena.log, r03g_exp_arena_*.log,
- * r03h_exp_arena_chunk*.log).  The arena is that: a virtual
- * range of `capacity` bytes, backed on demand in steps of whole GiB by 32 MiB
- * chunks (dealt round robin over the step's 1 GiB "teeth", +1 %), with a
- * first-fit allocator of 32 MiB granules on top.  Memory is taken from the
- * device only when a block needs it and goes back with bb_arena_trim.
+ * r03h_exp_arena_chunk*.log) -- provided the block's physical
+ * memory spans a wide range of the device: blocks of 8 GiB steps taken first
+ * thing in a fresh process decode at 5.3 TB/s for good
+ * (profiles/r03k_exp_arena_history.log).  The arena is that: a virtual range
+ * of `capacity` bytes, backed on demand in steps of at least 48 GiB (less if
+ * the device has less free; BB_ARENA_STEP_GIB) by 32 MiB chunks that are DEALT
+ * round robin over the step's 1 GiB "teeth" -- consecutive 32 MiB pieces of any
+ * block lie a GiB apart, every block of 1.5 GiB or more spans the whole step --
+ * with a first-fit allocator of 32 MiB granules on top.  A wide step is not
+ * always enough: in one process every block of a 48 GiB step decoded at 5.5
+ * TB/s (profiles/r03n/bench_plain.json).  Since the rate belongs to the memory,
+ * a new step is PROBED with a decode-shaped launch (2^16 frames, three
+ * launches, about 5 ms) and, when it is slow, held aside while the next
+ * candidate is created somewhere else (up to BB_ARENA_TRIES = 4; below
+ * BB_ARENA_MIN_GBPS = 6200 counts as slow); the fastest stays.  Memory is taken
+ * from the device when a block needs it and goes back with bb_arena_trim.
  *
  * Not stream-ordered: bb_arena_free makes the block available to the next
  * bb_arena_alloc at once; the caller must have ordered its work on the block
@@ -44,9 +55,10 @@ typedef struct bb_arena_stats {
     uint32_t chunk_bytes;    /* mapping and allocation granule (32 MiB) */
     uint32_t steps;          /* growth steps mapped now */
     uint32_t blocks;         /* live blocks */
-    uint32_t reserved;
+    uint32_t probes;         /* candidate steps probed so far */
+    double   last_probe_gbps;/* decode rate the probe measured on the step taken last (0: not probed) */
     double   create_ms;      /* wall time of bb_arena_create */
-    double   grow_ms;        /* wall time spent growing (hipMemCreate + hipMemMap), total */
+    double   grow_ms;        /* wall time spent growing (create, map, probe), total */
 } bb_arena_stats;
 
 /* Reserve a virtual range of `capacity` bytes (rounded up to whole GiB) on the
@@ -54,7 +66,8 @@ typedef struct bb_arena_stats {
  * BB_EIO: a HIP call failed (no virtual memory management). */
 int bb_arena_create(size_t capacity, bb_arena **arena);
 
-/* A block of at least `bytes` (rounded up to whole granules), granule aligned.
+/* A block of at least `bytes` (rounded up to whole granules), a whole number of
+ * granules from the base (which is 2 MiB aligned at least).
  * Grows the backed part by whole GiB when no free range is large enough.
  * *d_ptr = NULL and BB_ERANGE when the capacity or the device's memory is
  * exhausted. */

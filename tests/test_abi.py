@@ -33,7 +33,7 @@ def test_library_exports_all_declared_symbols():
         assert hasattr(_lib.lib, s), s
     bound = {name for name, _, _ in _lib.SIGNATURES}
     assert bound == set(syms)
-    assert _lib.lib.bb_abi_version() == 1
+    assert _lib.lib.bb_abi_version() == 2
 
 
 def test_product_library_carries_no_experiments():
@@ -136,3 +136,24 @@ def test_encode_thresholds_equal_the_oracle_steps():
         want = orc.encode_codes(x, 'vdif', 2)
         got = (x[:, None] >= thr[None, :]).sum(1)
         assert np.array_equal(got, want)
+
+
+def test_shipped_kernels_have_no_scratch_and_keep_four_waves_per_simd():
+    """the product code object holds fewer than 150 kernel
+    instantiations, none of them spills to scratch, and every streaming decode
+    kernel stays at or below 128 VGPRs (at 164 the 2-bit byte-table kernel ran
+    15 % slower: one wave per SIMD less).  Read from the device ISA that hipcc
+    emits for gfx950 (tools/check_isa.py; no GPU needed)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_isa.py'), '--build'],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    n, flagged = int(last.split()[0]), int(last.split()[2])
+    assert flagged == 0 and 60 <= n < 150, last
+    assert 'k_decode_flat_lds<2, true, 2, 8>' in r.stdout
+    # the measurement variants are not in the product code object
+    for name in ('k_decode_flat_front', 'k_decode_flat_es', 'k_decode_flat_pipe', 'k_decode_flat_aln',
+                 'k_decode_flat_span', 'k_decode_flat_elem', 'k_decode_flat2_bytes'):
+        assert name not in r.stdout, name

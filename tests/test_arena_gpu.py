@@ -16,11 +16,36 @@ GIB = 1 << 30
 
 
 @pytest.fixture
-def small_arena():
+def small_arena(monkeypatch):
     from baseband_amd import arena
+    # (the library backs the arena in steps of 48 GiB by default; small steps here)
+    monkeypatch.setenv('BB_ARENA_STEP_GIB', '2')
     ar = arena.Arena(8 * GIB)
     yield ar
     ar.close()
+
+
+def test_default_growth_step_is_wide(monkeypatch):
+    """The first block takes a wide step (48 GiB, or what capacity and free
+    memory allow): blocks must span a wide physical range to decode fast
+    (profiles/r03k_exp_arena_history.log); trim gives it back."""
+    from baseband_amd import arena
+    monkeypatch.delenv('BB_ARENA_STEP_GIB', raising=False)
+    ar = arena.Arena(64 * GIB)
+    try:
+        t = ar.empty(1 << 20)
+        st = ar.stats()
+        assert st['bytes_backed'] == 48 * GIB and st['steps'] == 1
+        del t
+        gc.collect()
+        assert ar.trim() == 48 * GIB
+        small = arena.Arena(5 * GIB)
+        t = small.empty(1 << 20)
+        assert small.stats()['bytes_backed'] == 5 * GIB               # the capacity bounds the step
+        del t
+        small.close()
+    finally:
+        ar.close()
 
 
 def test_arena_tensors_are_plain_tensors_and_decode_right(manifest, small_arena):
@@ -34,7 +59,7 @@ def test_arena_tensors_are_plain_tensors_and_decode_right(manifest, small_arena)
     assert G == 32 << 20
     out = small_arena.empty((exp.shape[0],))
     assert out.shape == (exp.shape[0],) and out.dtype == torch.float32 and out.is_cuda
-    assert out.data_ptr() % G == 0 and small_arena.owns(out)
+    assert out.data_ptr() % (2 << 20) == 0 and small_arena.owns(out)
     assert small_arena.stats()['bytes_backed'] == 2 * GIB          # grown by the minimum step
     with vdif.open(golden_path(case['file']), 'rs', sample_rate=case['frame_rate'] * case['samples_per_frame']) as fh:
         assert fh.read(out=out) is out

@@ -427,76 +427,124 @@ def test_guppi_channel_ranges_are_decoded_alone(manifest, name):
                 fh.seek(1)
                 fh.read(out=out)
                 assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[1:n - 1]))
-    # selections that are NOT a channel range of all polarisations keep the general path
+    # a channel LIST of all polarisations and a range of ONE polarisation are selections
+    # (bb_tiled_params.d_chan_map / pol_first): planned when the kept count is even
     with guppi.open(golden_path(case['file']), 'rs', subset=(slice(None), [0, nchan - 1]), squeeze=False) as fh:
         if nchan > 2:
-            assert fh._within_np is None
+            assert fh._sel is not None and fh._sel[2].tolist() == [0, nchan - 1]
         assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, :, [0, nchan - 1]]))
     if npol > 1:
         with guppi.open(golden_path(case['file']), 'rs', subset=(0, slice(1, 3))) as fh:
-            assert fh._within_np is None
+            assert fh._sel is not None and fh._sel[:2] == (0, 1) and fh._sel[2].tolist() == [1, 2]
             assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, 0, 1:3]))
+        with guppi.open(golden_path(case['file']), 'rs', subset=(slice(None), [2, 0, 1])) as fh:
+            assert fh._sel is None and fh._within_np is None        # odd count: decode, then index
+            assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, :, [2, 0, 1]]))
 
 
-def test_dada_channel_subsets_are_folded_into_the_decode(manifest):
-    """Plain DADA (pol, chan) samples: a subset that keeps the same channels of
-    every polarisation is decoded by bb_decode_frames_select with the positions
-    of those channels inside the stored sample; other subsets keep the general
-    path.  Both == indexing the reference's full decode."""
+@pytest.mark.parametrize('name', ['sample_puppi', 'guppi_cf_c64_ov0', 'guppi_cf_c64_ov32',
+                                  'guppi_tf_c8_ov16', 'sample_mkbf_dada'])
+def test_block_channel_lists_and_single_polarisations(manifest, name):
+    """channel lists with gaps / in any order and single
+    polarisations of GUPPI blocks (both storage orders) and MKBF heaps are
+    folded into the decode (`_sel`; bb_tiled_params.d_chan_map, pol_first,
+    npol_stored) -- through the fast transposing kernel where the payloads are
+    16-byte aligned, through whole-block decode + index where they are not.
+    Result == indexing the reference's full decode: whole reads, reads across
+    block boundaries and the overlap, small reads, in-place decodes."""
     import torch
-    from baseband_amd import dada, _lib
-    name = 'dada_p2_c4_cplx'
+    from baseband_amd import guppi, dada
+    if name.endswith('dada'):
+        guppi = dada
     case = manifest[name]
     exp = load_expected(name)
-    n = exp.shape[0]
-    for subset, folded in (((slice(None), [2, 0]), True), ((slice(None), slice(1, 3)), True),
-                           ((slice(None), 3), True), ((0, [1, 2]), False), ((1,), False),
-                           ((slice(None), slice(None)), False)):
+    n, npol, nchan = exp.shape
+    rng = np.random.default_rng(nchan)
+    lists = [[nchan - 1, 0], sorted(rng.choice(nchan, size=min(nchan, 6) // 2 * 2, replace=False).tolist()),
+             rng.choice(nchan, size=max(2, nchan // 3 // 2 * 2), replace=True).tolist()]
+    subsets = [(slice(None), cl) for cl in lists]
+    if npol == 2:
+        subsets += [(0,), (1,), (1, lists[1]), (0, slice(0, nchan, 2))]
+    for subset in subsets:
         want = exp[(slice(None),) + subset]
-        with dada.open(golden_path(case['file']), 'rs', subset=subset) as fh:
-            assert (fh._within_np is not None) == folded, subset
-            assert fh.shape == want.shape
-            got = fh.read().cpu().numpy()
-            if folded:
-                assert 'k_decode_gather_select' in _lib.last_kernel()
-            assert bits_equal(got, np.ascontiguousarray(want)), subset
+        with guppi.open(golden_path(case['file']), 'rs', subset=subset) as fh:
+            # folded into the decode one way or the other (a drawn list may happen
+            # to be a plain range, or everything)
+            everything = want.shape[1:] == exp.shape[1:] and np.array_equal(want, exp)
+            assert fh._sel is not None or fh._within_np is not None or everything, subset
+            assert fh.shape == want.shape, (subset, fh.shape, want.shape)
+            assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(want)), subset
             spf = fh.samples_per_frame
-            for off, cnt in ((spf - 3, 10), (5, 7), (n - 9, 9), (1, min(n - 1, 2 * spf + 3))):
+            for off, cnt in ((spf - 3, 10), (5, 7), (n - 9, 9), (spf + 1, 2 * spf)):
+                if off + cnt > n:
+                    continue
+                with guppi.open(golden_path(case['file']), 'rs', squeeze=False) as ref:
+                    ref.seek(off)
+                    piece = ref.read(cnt).cpu().numpy()[(slice(None),) + subset]
                 fh.seek(off)
-                assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(want[off:off + cnt])), (subset, off)
+                assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(piece)), (subset, off, cnt)
             out = torch.empty((n - 2,) + want.shape[1:], dtype=torch.complex64, device='cuda')
             fh.seek(1)
             fh.read(out=out)
-            assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[1:n - 1]))
-    # a sample size that is not a power of two keeps the general path
-    exp = load_expected('dada_p2_c3_real')
-    with dada.open(golden_path(manifest['dada_p2_c3_real']['file']), 'rs', subset=(slice(None), [2, 0])) as fh:
-        assert fh._within_np is None
-        assert bits_equal(fh.read().cpu().numpy(), np.ascontiguousarray(exp[:, :, [2, 0]]))
+            assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[1:n - 1])), subset
 
 
-def test_gsb_phased_channel_subsets_are_folded(manifest):
-    """GSB phased data decode as thread-interleaved frames with one slot per
-    polarisation: channel subsets go through bb_decode_frames_select."""
-    from baseband_amd import gsb, _lib
-    case = manifest['sample_gsb_phased']
-    exp = load_expected('sample_gsb_phased')
-    raw = [[golden_path(f) for f in pol] for pol in case['files']]
-    n = exp.shape[0]
-    for subset, folded in (((slice(None), slice(10, 20)), True), ((slice(None), [511, 0, 7]), True),
-                           ((slice(None), 300), True), ((1, slice(10, 20)), False), ((0,), False)):
-        want = exp[(slice(None),) + subset]
-        with gsb.open(golden_path(case['timestamp']), 'rs', raw=raw, samples_per_frame=8,
-                      subset=subset) as fh:
-            assert (fh._within_np is not None) == folded, subset
-            assert fh.shape == want.shape
-            got = fh.read().cpu().numpy()
-            if folded:
-                assert 'k_decode_gather_select' in _lib.last_kernel()
-            assert bits_equal(got, np.ascontiguousarray(want)), subset
-            for off, cnt in ((3, 9), (n - 5, 5), (7, 2)):
-                fh.seek(off)
-                assert bits_equal(fh.read(cnt).cpu().numpy(), np.ascontiguousarray(want[off:off + cnt]))
+@pytest.mark.parametrize('tile_rows', [0, 64, 128])
+@pytest.mark.parametrize('layout', [0, 1, 2])
+def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows):
+    """k_decode_i8_xpose with a SELECTION: out[f, t, p, c] = stored[f, t,
+    pol_first + p, chan_map[c]] -- lists with gaps, repeats and any order, more
+    channels than a tile, ragged last tiles, one of two polarisations, both at
+    once, partial time ranges; and the geometries that must answer KeyError."""
+    import torch
+    from baseband_amd import kernels, _lib
+    kernels.tune(_lib.TUNE_XPOSE_ROWS, tile_rows)
+    rng = np.random.default_rng(700 + layout)
+    nfr, nps, stored, T, head = 3, 2, 160, 512, 32
+    pn = T * nps * stored * 2
+    stride = pn + head
+    raw = rng.integers(0, 256, size=nfr * stride, dtype=np.uint8)
+    b = np.stack([raw[head + f * stride:head + f * stride + pn] for f in range(nfr)]).view(np.int8)
+    if layout == 0:
+        ref = b.reshape(nfr, stored, T, nps, 2).transpose(0, 2, 3, 1, 4)
+    elif layout == 1:
+        ref = b.reshape(nfr, T // 256, nps, stored, 256, 2).transpose(0, 1, 4, 2, 3, 5) \
+            .reshape(nfr, T, nps, stored, 2)
+    else:
+        ref = b.reshape(nfr, T, stored, nps, 2).transpose(0, 1, 3, 2, 4)
+    ref = np.ascontiguousarray(ref).astype(np.float32)
+    dbuf = kernels.to_device_bytes(raw)
+    lists = [np.array([159, 0]), np.sort(rng.choice(stored, 66, replace=False)), rng.choice(stored, 130, replace=True),
+             np.arange(0, stored, 2), None]
+    try:
+        for cl in lists:
+            for pf, npk in ((0, 2), (0, 1), (1, 1)):
+                if cl is None and npk == 2:
+                    continue                        # (nothing selected: the plain decode)
+                for lo, hi in ((0, T), (8, T - 8), (256, 512), (16, 17)):
+                    cmap = None if cl is None else torch.from_numpy(cl.astype(np.int32)).cuda()
+                    nc = stored if cl is None else cl.size
+                    out = kernels.decode_i8_tiled(dbuf, nfr, layout, npk, nc, T, lo, hi, src0=head, src_stride=stride,
+                                                  nchan_stored=stored, npol_stored=nps, pol_first=pf,
+                                                  chan_map=cmap).cpu().numpy()
+                    assert 'k_decode_i8_xpose' in _lib.last_kernel()
+                    want = ref[:, lo:hi, pf:pf + npk]
+                    if cl is not None:
+                        want = want[:, :, :, cl]
+                    assert bits_equal(out, np.ascontiguousarray(want).reshape(-1)), (layout, pf, npk, lo, hi, cl)
+        cmap = torch.tensor([3, 1, 2], dtype=torch.int32, device='cuda')
+        with pytest.raises(KeyError):               # odd channel count: no float4 rows
+            kernels.decode_i8_tiled(dbuf, nfr, layout, 2, 3, T, 0, T, src0=head, src_stride=stride,
+                                    nchan_stored=stored, npol_stored=nps, chan_map=cmap)
+        cmap = torch.tensor([3, 1], dtype=torch.int32, device='cuda')
+        with pytest.raises(KeyError):               # payloads off the 16-byte grid
+            kernels.decode_i8_tiled(dbuf, nfr, layout, 2, 2, T, 0, T, src0=head + 2, src_stride=stride - 2,
+                                    nchan_stored=stored, npol_stored=nps, chan_map=cmap)
+        with pytest.raises(_lib.BBError):           # a polarisation the payload does not hold
+            kernels.decode_i8_tiled(dbuf, nfr, layout, 1, 2, T, 0, T, src0=head, src_stride=stride,
+                                    nchan_stored=stored, npol_stored=nps, pol_first=2, chan_map=cmap)
+    finally:
+        kernels.tune(_lib.TUNE_XPOSE_ROWS, 0)
 
 
 @pytest.mark.parametrize('layout', [0, 1, 2])

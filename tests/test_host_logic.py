@@ -888,10 +888,22 @@ def test_guppi_channel_range_is_planned_without_a_gpu():
         assert (fh._chan_lo, fh._decode_shape, fh.sample_shape) == (1, (2, 2), (2, 2))
     with guppi.open(path, 'rs', subset=(slice(None), slice(2, None))) as fh:
         assert (fh._chan_lo, fh._decode_shape) == (2, (2, 2))
-    for subset in ((0, slice(1, 3)), (slice(None), [0, 2]), (slice(None), slice(None, None, 2)),
-                   (slice(None), slice(None)), ()):
+    for subset in ((slice(None), slice(None)), ()):
         with guppi.open(path, 'rs', subset=subset) as fh:
-            assert fh._within_np is None and fh._chan_lo == 0 and fh._decode_shape == (2, 4), subset
+            assert fh._within_np is None and fh._sel is None and fh._chan_lo == 0 and fh._decode_shape == (2, 4), subset
+    # channel lists and single polarisations are SELECTIONS (bb_tiled_params.d_chan_map / pol_first)
+    for subset, sel, shape in (((0, slice(1, 3)), (0, 1, [1, 2]), (1, 2)),
+                               ((slice(None), [0, 2]), (0, 2, [0, 2]), (2, 2)),
+                               ((slice(None), slice(None, None, 2)), (0, 2, [0, 2]), (2, 2)),
+                               ((1,), (1, 1, [0, 1, 2, 3]), (1, 4)),
+                               ((slice(None), [3, 3, 0, 1]), (0, 2, [3, 3, 0, 1]), (2, 4))):
+        with guppi.open(path, 'rs', subset=subset) as fh:
+            assert fh._sel is not None and fh._sel[:2] == sel[:2] and fh._sel[2].tolist() == sel[2], subset
+            assert fh._chan_lo == 0 and fh._decode_shape == shape
+    # an odd number of kept channels, or polarisations in another order: decode, then index
+    for subset in ((slice(None), [0, 2, 3]), ([1, 0], slice(None))):
+        with guppi.open(path, 'rs', subset=subset) as fh:
+            assert fh._within_np is None and fh._sel is None, subset
     with guppi.open(golden_path('synth/guppi_tf_c8_ov16.bin'), 'rs', subset=(slice(None), slice(1, 3))) as fh:
         # time-first blocks: the kernel enters every time at channel 1 (nchan_stored = 8)
         assert (fh._chan_lo, fh._decode_shape) == (1, (2, 2))

@@ -92,3 +92,6 @@ for lf in (15, 16, 17, 18):
         print(json.dumps({"log2_frames": lf, "output_GB": round(n * 4 / 1e9, 2), "kind": name, "TBps": v,
                           "frac_min_median_max": [round(float(f.min()), 4), round(float(np.median(f)), 4),
                                                   round(float(f.max()), 4)]}), flush=True)
+
+for name, ar in arenas:
+    print(json.dumps({"arena_stats_at_end": name, "stats": ar.stats()}), flush=True)

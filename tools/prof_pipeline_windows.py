@@ -46,7 +46,7 @@ def run(self, ranges, process, sink=None):
         if self._done[b] is not None:
             self._done[b].synchronize()
         t1 = time.perf_counter()
-        pinned, dev = self._buffers(b)
+        pinned, dev = self._buffers(b, need_dev=(sink is None) or OLD[0])
         target = dev[:n] if sink is None else sink[lo:hi]
         t2 = time.perf_counter()
         staging._stage(pinned.numpy(), self.image, lo, hi)
@@ -71,7 +71,18 @@ def run(self, ranges, process, sink=None):
 
 staging.WindowPipeline.run = run
 vdif.VDIFStreamReader.window_bytes = win_mib << 20
-for rep in range(3):
+OLD = [False]
+KEEP = staging._PINNED_KEEP
+# A/B in one process: round 2's pipeline (rotating device buffers allocated although the windows go
+# to the sink, pinned buffers allocated per reader, all windows full size) against this round's,
+# the latter with two and with three pinned buffers
+for rep in range(12):
+    OLD[0] = rep % 3 == 1
+    staging._NBUF = 3 if rep % 3 == 2 else 2
+    staging._PINNED_KEEP = 0 if OLD[0] else KEEP
+    if OLD[0]:
+        staging.release_pinned()
+    vdif.VDIFStreamReader.ramp_windows = not OLD[0]
     rows.clear()
     t_open = time.perf_counter()
     with vdif.open(path, 'rs', sample_rate=32e6, verify=False) as fh:
@@ -86,7 +97,7 @@ for rep in range(3):
     ker = [r['ev'][2].elapsed_time(r['ev'][3]) for r in rows]
     tot = {k: sum(r[k] for r in rows) for k in ('wait_ms', 'buffers_ms', 'stage_ms', 'enqueue_ms')}
     nb = sum(r['bytes'] for r in rows)
-    print(json.dumps(dict(rep=rep, file_GiB=round(fsize / 2 ** 30, 3), window_MiB=win_mib, windows=len(rows),
+    print(json.dumps(dict(rep=rep, pipeline="round 2" if OLD[0] else "round 3, {} buffers".format(staging._NBUF), file_GiB=round(fsize / 2 ** 30, 3), window_MiB=win_mib, windows=len(rows),
                           read_s=round(dt, 4), file_GBps=round(fsize / dt / 1e9, 2), open_ms=round(open_ms, 1),
                           host_ms={k: round(v, 1) for k, v in tot.items()},
                           host_ms_unaccounted=round(dt * 1e3 - sum(tot.values()), 1),
