@@ -108,12 +108,20 @@ class VDIFFrameSet:
         fn, hn = header0.frame_nbytes, header0.nbytes
         wanted = None if thread_ids is None else set(thread_ids)
         fh.seek(start)
-        block = b''
-        nwant = 9                       # frames per block, grown geometrically
+        # frames per block: the set that is asked for plus the header behind it
+        # (a single-thread file: two frames, not nine), grown geometrically;
+        # pieces are joined once per growth.  Every frame of a set
+        # is taken to have header0's size, as the reference's readers do
+        # (vdif/base.py: fixed `frame_nbytes` per stream).
+        pieces, have = [], 0
+        nwant = 2 if wanted is None else len(wanted) + 1
         while True:
-            ask = nwant * fn + 32 - len(block)
+            ask = nwant * fn + 32 - have
             more = fh.read(ask)
-            block += more
+            pieces.append(more)
+            have += len(more)
+            block = pieces[0] if len(pieces) == 1 else b''.join(pieces)
+            pieces = [block]
             raw = np.frombuffer(block, np.uint8)
             # headers that can be parsed: 32 bytes are read even for a legacy one
             nhead = (len(raw) - 32) // fn + 1
@@ -131,6 +139,19 @@ class VDIFFrameSet:
                 break
             nwant *= 4
         nset = int(breaks[0]) if len(breaks) else nhead      # frames whose header is in the set
+        # the table takes every frame to have header0's size.  Where a header in
+        # reach says otherwise (garbage behind a damaged frame, mixed legacy
+        # headers), walk frame by frame, every header's own length honoured
+        look = min(nset + 1, nhead)
+        if (np.any((table[:look, 2] & 0xffffff) * 8 != fn)
+                or np.any(((table[:look, 0] >> 30) & 1) != (table[0, 0] >> 30) & 1)):
+            fh.seek(start + hn)
+            frames = cls._walk(fh, header0, thread_ids, edv, verify)
+            if wanted is not None and len(frames) < len(wanted):
+                raise OSError("could not find all requested frames.")
+            order = sorted(frames) if thread_ids is None else list(thread_ids)
+            return cls([frames[tid] for tid in order], header0)
+        eof = start + len(block)
         frames = {}
         for k in range(nset):
             if k == 0:
@@ -159,25 +180,60 @@ class VDIFFrameSet:
                     VDIFHeader(np.frombuffer(block, '<u4', 8, nset * fn), edv, verify=False).verify()
             except AssertionError:
                 if not complete:
+                    fh.seek(cls._behind_header(start, block, nset * fn))
                     raise
-                end += hn
+                end = cls._behind_header(start, block, nset * fn)
         else:
-            # no further header could be read
+            # no further header could be read.  The pointer ends where that
+            # attempt left it: behind a damaged header; else at the end of a
+            # tail too short to hold one -- or BEYOND the end of the file, when
+            # the last frame was one that is skipped, not read, and is cut short
+            if nset < nhead:
+                behind = cls._behind_header(start, block, nset * fn)
+            else:
+                behind = max(end, eof)
             if not complete:
+                fh.seek(behind)
                 if nset < nhead:        # it is there but damaged: raises
                     VDIFHeader(np.frombuffer(block, '<u4', 8, nset * fn), edv, verify=False).verify()
                 raise EOFError
-            # the pointer ends where that attempt left it: behind a damaged
-            # header, or at the end of a tail too short to hold one
-            if nset < nhead:
-                end += hn
-            elif start + len(block) - end < 32:
-                end = start + len(block)
+            end = behind
         fh.seek(end)
         if wanted is not None and len(frames) < len(wanted):
             raise OSError("could not find all requested frames.")
         order = sorted(frames) if thread_ids is None else list(thread_ids)
         return cls([frames[tid] for tid in order], header0)
+
+    @classmethod
+    def _walk(cls, fh, header0, thread_ids, edv, verify):
+        """The set frame by frame, from behind header0: a frame is read (wanted
+        thread) or skipped by ITS header's length, then the next header is
+        looked at, until one belongs to another set (the pointer goes back in
+        front of it) or cannot be read (vdif/frame.py:203-234)."""
+        frames, header, nr0 = {}, header0, header0['frame_nr']
+        while header['frame_nr'] == nr0 and header['thread_id'] not in frames:
+            tid = header['thread_id']
+            if thread_ids is None or tid in thread_ids:
+                frames[tid] = VDIFFrame(header, VDIFPayload.fromfile(fh, header=header), verify=False)
+            else:
+                fh.seek(header.payload_nbytes, 1)
+            try:
+                header = VDIFHeader.fromfile(fh, edv, verify)
+            except (EOFError, AssertionError):
+                if thread_ids is not None and len(frames) < len(thread_ids):
+                    raise
+                return frames
+        fh.seek(-header.nbytes, 1)
+        return frames
+
+    @staticmethod
+    def _behind_header(start, block, offset):
+        """File position the reference is left at when the header at `offset`
+        of the block fails verification: VDIFHeader.fromfile has read its four
+        or -- unless the legacy bit is set -- eight words
+        (vdif/header.py:158-186), then `verify` raised."""
+        legacy = bool(np.frombuffer(block, '<u4', 1, offset)[0] & (1 << 30))
+        return start + offset + (16 if legacy else 32)
 
     def tofile(self, fh):
         for frame in self.frames:

@@ -33,6 +33,7 @@ nb = nbytes // 4 * 4
 sel8 = torch.tensor([6, 7, 8, 9, 10, 11, 12, 13], dtype=torch.int32, device=dev)
 sel5 = torch.arange(8, dtype=torch.int32, device=dev)
 src5 = torch.arange(nbytes // 10016, device=dev, dtype=torch.int64) * 10016 + 16
+cm32 = torch.arange(0, 64, 2, dtype=torch.int32, device=dev)
 m4s = kernels.mark4_select_maps(m['sign_bit'], m['mag_bit'], 8, [0, 5, 7])
 runs = [
     lambda: kernels.decode_frames(buf, nfr, payload, 0, 2, src0=header, src_stride=stride, out=out),
@@ -52,6 +53,16 @@ runs = [
                                   out=out, within=sel5),
     lambda: kernels.decode_mark4(buf, nf4, 64, 20000, m4s[0], m4s[1], fill_words=160, src0=0, src_stride=160000,
                                  out=out, select=True),
+    # round 3: 1- and 4-bit flat (k_decode_flat_lut; `gib` / 2 of input for 1-bit so that the output fits),
+    # channel list / single polarisation folded into the int8 transposes
+    lambda: kernels.decode_frames(buf, nfr // 2, payload, 0, 1, src0=header, src_stride=stride, out=out),
+    lambda: kernels.decode_frames(buf, nfr, payload, 0, 4, src0=header, src_stride=stride, out=out),
+    lambda: kernels.decode_i8_tiled(buf, nfg, _lib.LAYOUT_GUPPI_CF, npol, 32, T, 0, T, src0=0, src_stride=blk, out=out,
+                                    nchan_stored=nchan, npol_stored=npol, chan_map=cm32),
+    lambda: kernels.decode_i8_tiled(buf, nfg, _lib.LAYOUT_GUPPI_TF, 1, nchan, T, 0, T, src0=0, src_stride=blk, out=out,
+                                    nchan_stored=nchan, npol_stored=npol, pol_first=1),
+    lambda: kernels.decode_i8_tiled(buf, nfm, _lib.LAYOUT_MKBF, 1, 32, Tm, 0, Tm, src0=0, src_stride=blkm, out=out,
+                                    nchan_stored=nchan, npol_stored=npol, pol_first=0, chan_map=cm32),
 ]
 if os.environ.get('BB_PROF_OLD_I8'):
     kernels.tune(_lib.TUNE_XPOSE, 0)
