@@ -189,3 +189,61 @@ def test_readers_take_their_outputs_from_the_arena(manifest, monkeypatch):
         got = fh.read()
     assert bits_equal(got.cpu().numpy(), exp.reshape(got.shape))
     assert arena.default() is None
+
+
+def test_large_read_lifecycle_through_the_default_arena(tmp_path, monkeypatch):
+    """A 600 MB VDIF file read whole (9.6 GB of output) with the defaults a
+    user gets: the output lives in the arena, whose first step was PROBED; the
+    samples are right; deleting the result frees the block; `release_unused`
+    gives the memory back to the device; threads may allocate concurrently."""
+    import threading
+    import torch
+    from baseband_amd import arena, placement, synth, vdif
+    import bb_oracle_np as orc
+    monkeypatch.delenv('BB_ARENA_GIB', raising=False)
+    monkeypatch.delenv('BB_ARENA_STEP_GIB', raising=False)
+    arena.disable()
+    nframes = 75000
+    image, h0 = synth.random_vdif(77, nframes, payload_nbytes=8000, frame_rate=1000)
+    path = tmp_path / 'big.vdif'
+    image.tofile(str(path))
+    try:
+        free0, _ = torch.cuda.mem_get_info()
+        with vdif.open(str(path), 'rs', sample_rate=32e6) as fh:
+            got = fh.read()
+        ar = arena.default()
+        assert ar is not None and ar.owns(got)
+        st = ar.stats()
+        assert st['steps'] == 1 and st['probes'] >= 1 and st['last_probe_gbps'] > 3000, st
+        assert st['bytes_backed'] >= 9 << 30
+        # spot check against the oracle: first, a middle and the last frame
+        for f in (0, nframes // 2, nframes - 1):
+            want, _ = orc.vdif_read(image[f * 8032:(f + 1) * 8032], frame_rate=1000)
+            assert bits_equal(got[f * 32000:(f + 1) * 32000].cpu().numpy(), want.reshape(-1))
+        del got
+        gc.collect()
+        assert ar.stats()['blocks'] == 0
+        # concurrent allocations from two threads
+        errs = []
+
+        def worker(seed):
+            try:
+                for k in range(20):
+                    t = placement.empty_output((64 << 20) // 4 * (1 + (seed + k) % 3))
+                    t[:4] = seed
+                    assert ar.owns(t) and float(t[0]) == seed
+                    del t
+            except Exception as exc:        # pragma: no cover
+                errs.append(exc)
+        ths = [threading.Thread(target=worker, args=(s,)) for s in (1, 2)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not errs, errs
+        gc.collect()
+        assert ar.stats()['blocks'] == 0
+        assert placement.release_unused() == st['bytes_backed']
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 >= free0 - (2 << 30), (free0, free1)
+    finally:
+        arena.disable()
