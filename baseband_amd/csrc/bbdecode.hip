@@ -164,6 +164,8 @@ std::atomic<int> g_tune_select_bytes{16384};   // payload bytes k_decode_gather_
 std::atomic<int> g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
 std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
 std::atomic<int> g_tune_xpose_rows{0};   // k_decode_i8_xpose: output rows per tile, 128 or 64; 0 = by layout
+std::atomic<int> g_tune_xpose_tc{0};     // k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; 0 = by channel count
+std::atomic<int> g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a selection: from this many channels on
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
 std::atomic<int> g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 #if BB_EXP
@@ -391,6 +393,8 @@ int bb_tune(int knob, int value)
             g_tune_select_bytes = value; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
         case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : value == 128 ? 128 : 0; return BB_OK;
+        case BB_TUNE_XPOSE_TC: g_tune_xpose_tc = (value == 64 || value == 32 || value == 16 || value == 8) ? value : 0; return BB_OK;
+        case BB_TUNE_XPOSE_MIN_NC: g_tune_xpose_min_nc = value < 2 ? 2 : value; return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
 #if BB_EXP
         case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
@@ -1203,8 +1207,9 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     {
         const uint64_t npd = (uint64_t)p->npol;                          // polarisations decoded
         const uint64_t rows = (p->t_hi - p->t_lo) * npd;                 // output rows per frame
-        // (a selection may keep few channels; without one, narrow blocks stay with k_tiled.h)
-        bool ok = g_tune_xpose.load() != 0 && !d_src && (selecting ? nc >= 2 : nc >= 32) && !(nc & 1)
+        // (a selection may keep as few as two channels; without one, blocks of
+        // fewer than 8 stay with k_tiled.h)
+        bool ok = g_tune_xpose.load() != 0 && !d_src && (selecting ? nc >= 2 : nc >= (uint64_t)g_tune_xpose_min_nc.load()) && !(nc & 1)
                   && !((uintptr_t)d_buf & 15) && !(p->src0 & 15) && !(p->src_stride & 15)
                   && (npd == np_ || (np_ == 2 && npd == 1));
         if (p->layout == BB_LAYOUT_GUPPI_CF)
@@ -1221,13 +1226,19 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
             // above (+0-1 %): profiles/r02az_exp_xpose_rows.log
             const int xr = g_tune_xpose_rows.load();
             const bool big = (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4 >= (96ull << 30);
-            const uint64_t xrows = xr ? (uint64_t)xr : (p->layout == BB_LAYOUT_GUPPI_CF || big) ? 128u : 64u;
+            uint64_t xrows = xr ? (uint64_t)xr : (p->layout == BB_LAYOUT_GUPPI_CF || big) ? 128u : 64u;
             // output rows per tile: half an LDS image when one of two pols is dropped (layouts 0, 2)
-            const uint64_t rpt = p->layout == BB_LAYOUT_MKBF ? xrows : xrows / (np_ / npd);
-            const uint64_t ntt = (rows + rpt - 1) / rpt, nct = (nc + BB_XP_TC - 1) / BB_XP_TC;
+            // channels per tile: the narrowest of 64 / 32 / 16 / 8 that holds them all
+            // (narrow tiles are longer, 128 * 64 / tc rows: only that size is built)
+            const int xt = g_tune_xpose_tc.load();
+            const uint64_t xtc = xt ? (uint64_t)xt : nc > 32 ? 64u : nc > 16 ? 32u : nc > 8 ? 16u : 8u;
+            if (xtc != 64) xrows = 128;
+            const uint64_t rt = xrows * 64 / xtc;
+            const uint64_t rpt = p->layout == BB_LAYOUT_MKBF ? rt : rt / (np_ / npd);
+            const uint64_t ntt = (rows + rpt - 1) / rpt, nct = (nc + xtc - 1) / xtc;
             if (ntt > 0xffffffffull) return BB_ERANGE;
             a.ntt = (uint32_t)ntt; a.nct = (uint32_t)nct;
-            a.tt = (uint32_t)(xrows / npd); a.tc = BB_XP_TC; a.tcp = 2 * BB_XP_PITCH;
+            a.tt = (uint32_t)(rt / npd); a.tc = (uint32_t)xtc; a.tcp = 2 * ((uint32_t)xtc + 1);
             uint64_t blocks = (uint64_t)nframes * ntt * nct;
             a.perm = make_perm(blocks, (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4);
             // one tile per workgroup: with 20 % of the traffic being reads the
@@ -1240,16 +1251,20 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
             if (blocks > cap) blocks = cap;
             const dim3 grid((unsigned)blocks), block(BB_BLOCK);
 #define BB_XP(L) with_nt(nt, [&](auto NT) { \
-                if (xrows == 64) hipLaunchKernelGGL((k_decode_i8_xpose<L, decltype(NT)::value, 64>), grid, block, 0, st, a); \
-                else             hipLaunchKernelGGL((k_decode_i8_xpose<L, decltype(NT)::value, 128>), grid, block, 0, st, a); })
+                constexpr bool N = decltype(NT)::value; \
+                if (xtc == 8)        hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 128, 8>), grid, block, 0, st, a); \
+                else if (xtc == 16)  hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 128, 16>), grid, block, 0, st, a); \
+                else if (xtc == 32)  hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 128, 32>), grid, block, 0, st, a); \
+                else if (xrows == 64) hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 64, 64>), grid, block, 0, st, a); \
+                else                 hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 128, 64>), grid, block, 0, st, a); })
             switch (p->layout) {
                 case BB_LAYOUT_GUPPI_CF: BB_XP(0); break;
                 case BB_LAYOUT_MKBF:     BB_XP(1); break;
                 default:                 BB_XP(2); break;
             }
 #undef BB_XP
-            BB_NOTE("k_decode_i8_xpose<%d,%s,%d> grid %u tiles %u x %u per frame", p->layout, nt ? "nt" : "plain",
-                    (int)xrows, grid.x, a.ntt, a.nct);
+            BB_NOTE("k_decode_i8_xpose<%d,%s,%d,%d> grid %u tiles %u x %u per frame", p->layout, nt ? "nt" : "plain",
+                    (int)xrows, (int)xtc, grid.x, a.ntt, a.nct);
             BB_HIP(hipGetLastError());
             return BB_OK;
         }

@@ -20,7 +20,7 @@
 //    k_decode_flat_aln;
 //  * work dealt over 16 stripes of the launch (bb_perm_t).
 //
-// A tile is ROWS (128 or 64) output rows (of up to 64 channels = 512 bytes each)
+// A tile (TC = 64) is ROWS (128 or 64) output rows (of up to 64 channels = 512 bytes each)
 // x 64 channels; lanes 0-31 of a store instruction write one output row, lanes
 // 32-63 the next, so a wave stores 1 KiB contiguous when the tile spans all
 // channels.
@@ -45,24 +45,32 @@
 #pragma once
 #include "k_tiled.h"
 
-#define BB_XP_TC 64         // channels per tile
-#define BB_XP_PITCH 65      // LDS row pitch in dwords (odd)
+// Channels per tile TC = 64, or 32 / 16 / 8 for narrow outputs (few channels
+// stored, or few kept by a selection): the tile keeps its 16 KiB of input, so a
+// narrow tile is RT = ROWS * 64 / TC output rows long and no load or store lane
+// idles on channels that are not there.  LDS row pitch TC + 1 dwords (odd).
 
 // (launch bounds: at least 6 waves per SIMD = 6 workgroups per CU; with the
 // store loop fully unrolled the compiler took 123-138 VGPRs = 3-4 workgroups per
 // CU, and a store-bound kernel whose waves all wait at the same barrier needs
 // more of them in flight: profiles/r02e_kernels.csv)
-template <int LAYOUT, bool NT, int ROWS>
+template <int LAYOUT, bool NT, int ROWS, int TC>
 __global__ __launch_bounds__(BB_BLOCK, 6)
 void k_decode_i8_xpose(bb_tiled_args a)
 {
+    static_assert(TC == 64 || TC == 32 || TC == 16 || TC == 8, "channels per tile");
+    constexpr int RT = ROWS * 64 / TC;          // elements of a (time, pol) run per tile
+    constexpr int PITCH = TC + 1;
     constexpr int NLOAD = ROWS / 32;            // 16-byte loads per thread and tile
-    constexpr uint32_t LPR = ROWS / 8;          // LAYOUT 0: pieces per channel row (power of two)
-    __shared__ uint32_t s_d[(ROWS / 2) * BB_XP_PITCH];
+    constexpr uint32_t LPR = RT / 8;            // LAYOUT 0: pieces per channel row (power of two)
+    constexpr uint32_t PPT = TC / 4;            // LAYOUT 2: pieces of 4 channels per time
+    constexpr uint32_t PR = TC / 2;             // store phase: channel pairs per row ...
+    constexpr uint32_t RPI = BB_BLOCK / PR;     // ... and rows per pass of the workgroup
+    __shared__ uint32_t s_d[(RT / 2) * PITCH];
     const uint32_t npol = a.npol, nps = a.nps;
     // output rows per LDS image: ROWS, or half of it when one of two pols is dropped (layouts 0, 2)
     const uint32_t estep = LAYOUT == 1 ? 1u : nps / npol;
-    const uint32_t rpt = ROWS / estep;
+    const uint32_t rpt = RT / estep;
     const uint64_t rows_out = (a.t_hi - a.t_lo) * npol;         // output rows per frame
     const uint64_t rowlen = (uint64_t)a.nchan * 2;              // floats per output row
     // tile grid of a frame: a.ntt tiles along the output rows, a.nct along channels
@@ -70,7 +78,7 @@ void k_decode_i8_xpose(bb_tiled_args a)
     const uint64_t nwork = a.nframes * per_frame;
     const uint32_t tid = threadIdx.x;
     // times per tile
-    const uint32_t tt = LAYOUT == 0 ? 0u : LAYOUT == 1 ? ROWS / npol : ROWS / nps;
+    const uint32_t tt = LAYOUT == 0 ? 0u : LAYOUT == 1 ? RT / npol : RT / nps;
     auto cm = [&](uint32_t c) -> uint32_t { return a.cmap ? (uint32_t)a.cmap[c] : c; };
 
     bb_u4 nxt[NLOAD];
@@ -82,8 +90,8 @@ void k_decode_i8_xpose(bb_tiled_args a)
         const uint64_t f = work / per_frame;
         const uint32_t rem = (uint32_t)(work - f * per_frame);
         const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
-        const uint32_t c0 = ci * BB_XP_TC;
-        const uint32_t ncv = (a.nchan - c0 < BB_XP_TC) ? a.nchan - c0 : BB_XP_TC;
+        const uint32_t c0 = ci * TC;
+        const uint32_t ncv = (a.nchan - c0 < TC) ? a.nchan - c0 : TC;
         const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
         valid = bb_src_ok(so, a.src_lim);
         const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
@@ -93,23 +101,23 @@ void k_decode_i8_xpose(bb_tiled_args a)
             const uint16_t *ptr = in;
             bool want = valid;
             if (LAYOUT == 0) {
-                // 64 channel rows x ROWS / 8 pieces of 8 elements
+                // TC channel rows x RT / 8 pieces of 8 elements
                 const uint32_t c = g / LPR, piece = g % LPR;
-                const uint64_t i0 = a.t_lo * nps + (uint64_t)ti * ROWS;
+                const uint64_t i0 = a.t_lo * nps + (uint64_t)ti * RT;
                 const uint64_t i = i0 + piece * 8;
                 want = want && c < ncv && i < a.t_hi * nps;
                 if (want) ptr = in + (uint64_t)cm(c0 + c) * a.sc + i;
             } else if (LAYOUT == 1) {
-                // npol * 64 (pol, chan) rows x (ROWS / npol / 8) pieces of 8 times
+                // npol * TC (pol, chan) rows x (RT / npol / 8) pieces of 8 times
                 const uint32_t ppr = tt >> 3;                       // pieces per row
                 const uint32_t row = g / ppr, piece = g - row * ppr;
-                const uint32_t p = row >> 6, c = row & 63;
+                const uint32_t p = row / TC, c = row % TC;
                 const uint64_t t = a.t_lo + (uint64_t)ti * tt + piece * 8;
                 want = want && c < ncv && t < a.t_hi;
                 if (want) ptr = in + (t >> 8) * a.sh + (t & 255) + (uint64_t)(a.pf + p) * a.sp + (uint64_t)cm(c0 + c) * a.sc;
             } else {
-                // ROWS / 2 times x 16 pieces of 4 channels (both pols)
-                const uint32_t tl = g >> 4, piece = g & 15;
+                // RT / 2 times x TC / 4 pieces of 4 channels (both pols)
+                const uint32_t tl = g / PPT, piece = g % PPT;
                 const uint64_t t = a.t_lo + (uint64_t)ti * tt + tl;
                 want = want && t < a.t_hi && piece * 4 < ncv;
                 ptr = in + t * a.st + (uint64_t)(c0 + piece * 4) * 2;     // (st = stored channels x 2 pol)
@@ -143,23 +151,23 @@ void k_decode_i8_xpose(bb_tiled_args a)
             uint32_t base;
             if (LAYOUT == 0) {
                 const uint32_t c = g / LPR, piece = g % LPR;
-                base = (piece * 4) * BB_XP_PITCH + c;               // D[piece*4 + j][c]
+                base = (piece * 4) * PITCH + c;               // D[piece*4 + j][c]
                 s_d[base] = nxt[k].x;
-                s_d[base + BB_XP_PITCH] = nxt[k].y;
-                s_d[base + 2 * BB_XP_PITCH] = nxt[k].z;
-                s_d[base + 3 * BB_XP_PITCH] = nxt[k].w;
+                s_d[base + PITCH] = nxt[k].y;
+                s_d[base + 2 * PITCH] = nxt[k].z;
+                s_d[base + 3 * PITCH] = nxt[k].w;
             } else if (LAYOUT == 1) {
                 const uint32_t ppr = tt >> 3;
                 const uint32_t row = g / ppr, piece = g - row * ppr;
-                const uint32_t p = row >> 6, c = row & 63;
-                base = (p * (tt >> 1) + piece * 4) * BB_XP_PITCH + c;   // D[p][piece*4 + j][c]
+                const uint32_t p = row / TC, c = row % TC;
+                base = (p * (tt >> 1) + piece * 4) * PITCH + c;   // D[p][piece*4 + j][c]
                 s_d[base] = nxt[k].x;
-                s_d[base + BB_XP_PITCH] = nxt[k].y;
-                s_d[base + 2 * BB_XP_PITCH] = nxt[k].z;
-                s_d[base + 3 * BB_XP_PITCH] = nxt[k].w;
+                s_d[base + PITCH] = nxt[k].y;
+                s_d[base + 2 * PITCH] = nxt[k].z;
+                s_d[base + 3 * PITCH] = nxt[k].w;
             } else {
-                const uint32_t tl = g >> 4, piece = g & 15;
-                base = tl * BB_XP_PITCH + piece * 4;                // D[t][piece*4 + j]
+                const uint32_t tl = g / PPT, piece = g % PPT;
+                base = tl * PITCH + piece * 4;                // D[t][piece*4 + j]
                 s_d[base] = nxt[k].x;
                 s_d[base + 1] = nxt[k].y;
                 s_d[base + 2] = nxt[k].z;
@@ -175,28 +183,28 @@ void k_decode_i8_xpose(bb_tiled_args a)
         const uint64_t f = work / per_frame;
         const uint32_t rem = (uint32_t)(work - f * per_frame);
         const uint32_t ti = rem / a.nct, ci = rem - ti * a.nct;
-        const uint32_t c0 = ci * BB_XP_TC;
-        const uint32_t ncv = (a.nchan - c0 < BB_XP_TC) ? a.nchan - c0 : BB_XP_TC;
+        const uint32_t c0 = ci * TC;
+        const uint32_t ncv = (a.nchan - c0 < TC) ? a.nchan - c0 : TC;
         const uint64_t row0 = (uint64_t)ti * rpt;             // first output row of the tile in its frame
         float *obase = a.out + (f * rows_out + row0) * rowlen + (uint64_t)c0 * 2;
         const uint64_t rows_left = rows_out - row0;
-        const uint32_t cp = tid & 31;                               // channel pair
-        const uint32_t rsub = tid >> 5;                             // row within a group of 8
+        const uint32_t cp = tid % PR;                               // channel pair
+        const uint32_t rsub = tid / PR;                             // row within a pass
         const bb_f4 fillv = {a.fill_re, a.fill_im, a.fill_re, a.fill_im};
 #pragma unroll 4
         for (int q = 0; q < ROWS / 8; ++q) {
-            const uint32_t r = (uint32_t)q * 8 + rsub;              // output row of the tile
+            const uint32_t r = (uint32_t)q * RPI + rsub;              // output row of the tile
             uint32_t idx, half;
             if (LAYOUT == 1) {
                 const uint32_t tl = npol == 2 ? r >> 1 : r, p = npol == 2 ? r & 1 : 0;
-                idx = (p * (tt >> 1) + (tl >> 1)) * BB_XP_PITCH; half = tl & 1;
+                idx = (p * (tt >> 1) + (tl >> 1)) * PITCH; half = tl & 1;
             } else {
                 // element i of the (time, pol) run: row r as it is, or -- one of two
                 // pols dropped -- the kept pol of time r
                 const uint32_t i = r * estep + a.pf;
-                idx = (i >> 1) * BB_XP_PITCH; half = i & 1;
+                idx = (i >> 1) * PITCH; half = i & 1;
             }
-            if (r >= rpt) continue;                                 // (wave-uniform: rsub is)
+            if (r >= rpt) continue;
             const uint32_t x = s_d[idx + 2 * cp], y = s_d[idx + 2 * cp + 1];
             if (r >= rows_left || 2 * cp >= ncv) continue;
             const uint32_t e0 = half ? x >> 16 : x & 0xffffu;

@@ -331,19 +331,24 @@ def test_small_reads_row_staging_equals_whole_frame_staging(manifest, fmt, name)
         assert bits_equal(first, again) and bits_equal(again, third), (off, cnt)
 
 
-@pytest.mark.parametrize('tile_rows', [128, 64])
-def test_xpose_kernel_raw_layouts(tile_rows):
-    """k_decode_i8_xpose (16-byte aligned input runs, >= 32 channels): all three
-    layouts vs NumPy transposes -- ragged channel tiles, partial time ranges
-    (GUPPI overlap, MKBF heaps), several frames, time ranges that end inside a
-    16-byte piece; and the geometries it must hand back to k_tiled.h."""
+@pytest.mark.parametrize('tile_rows,tile_chans', [(128, 0), (64, 0), (0, 8), (0, 16), (0, 32), (0, 64)])
+def test_xpose_kernel_raw_layouts(tile_rows, tile_chans):
+    """k_decode_i8_xpose (16-byte aligned input runs, >= 8 channels): all three
+    layouts vs NumPy transposes -- ragged channel tiles, narrow blocks (tiles of
+    8, 16, 32 channels), partial time ranges (GUPPI overlap, MKBF heaps),
+    several frames, time ranges that end inside a 16-byte piece; and the
+    geometries it must hand back to k_tiled.h."""
     from baseband_amd import kernels, _lib
     kernels.tune(_lib.TUNE_XPOSE_ROWS, tile_rows)
+    kernels.tune(_lib.TUNE_XPOSE_TC, tile_chans)
     rng = np.random.default_rng(31)
     cases = ((0, 2, 64, 1024, 32), (0, 2, 96, 520, 16), (0, 1, 64, 640, 16), (0, 2, 32, 300, 64),
              (0, 2, 200, 136, 16), (0, 4, 64, 260, 16),
+             (0, 2, 8, 2048, 16), (0, 2, 12, 1100, 16), (0, 1, 16, 4096, 16), (0, 2, 24, 520, 32),
              (1, 2, 64, 1024, 16), (1, 2, 96, 512, 32), (1, 1, 64, 768, 16), (1, 2, 32, 256, 16),
-             (2, 2, 64, 300, 16), (2, 2, 100, 130, 32), (2, 2, 1024, 70, 16), (2, 2, 32, 129, 16))
+             (1, 2, 8, 1024, 16), (1, 1, 16, 2048, 16), (1, 2, 20, 512, 16), (1, 1, 10, 1280, 16),
+             (2, 2, 64, 300, 16), (2, 2, 100, 130, 32), (2, 2, 1024, 70, 16), (2, 2, 32, 129, 16),
+             (2, 2, 8, 3000, 16), (2, 2, 16, 1029, 16), (2, 2, 28, 700, 16))
     for layout, npol, nchan, T, head in cases:
         nfr = 3
         pn = T * npol * nchan * 2
@@ -380,6 +385,10 @@ def test_xpose_kernel_raw_layouts(tile_rows):
     finally:
         kernels.tune(_lib.TUNE_XPOSE, 1)
         kernels.tune(_lib.TUNE_XPOSE_ROWS, 0)
+        kernels.tune(_lib.TUNE_XPOSE_TC, 0)
+    # blocks of fewer than 8 channels stay with the general kernel unless a selection asks
+    kernels.decode_i8_tiled(dbuf, 1, 0, 2, 4, 64, 0, 64, src0=0, src_stride=1024)
+    assert 'k_decode_i8_xpose' not in _lib.last_kernel()
 
 
 @pytest.mark.parametrize('name', ['sample_puppi', 'guppi_cf_c64_ov0', 'guppi_cf_c64_ov32', 'guppi_cf_c6_p1',
@@ -489,9 +498,9 @@ def test_block_channel_lists_and_single_polarisations(manifest, name):
             assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[1:n - 1])), subset
 
 
-@pytest.mark.parametrize('tile_rows', [0, 64, 128])
+@pytest.mark.parametrize('tile_rows,tile_chans', [(0, 0), (64, 0), (128, 0), (0, 8), (0, 32), (0, 64)])
 @pytest.mark.parametrize('layout', [0, 1, 2])
-def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows):
+def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows, tile_chans):
     """k_decode_i8_xpose with a SELECTION: out[f, t, p, c] = stored[f, t,
     pol_first + p, chan_map[c]] -- lists with gaps, repeats and any order, more
     channels than a tile, ragged last tiles, one of two polarisations, both at
@@ -499,6 +508,7 @@ def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows):
     import torch
     from baseband_amd import kernels, _lib
     kernels.tune(_lib.TUNE_XPOSE_ROWS, tile_rows)
+    kernels.tune(_lib.TUNE_XPOSE_TC, tile_chans)
     rng = np.random.default_rng(700 + layout)
     nfr, nps, stored, T, head = 3, 2, 160, 512, 32
     pn = T * nps * stored * 2
@@ -515,7 +525,8 @@ def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows):
     ref = np.ascontiguousarray(ref).astype(np.float32)
     dbuf = kernels.to_device_bytes(raw)
     lists = [np.array([159, 0]), np.sort(rng.choice(stored, 66, replace=False)), rng.choice(stored, 130, replace=True),
-             np.arange(0, stored, 2), None]
+             np.arange(0, stored, 2), rng.choice(stored, 8, replace=False), rng.choice(stored, 20, replace=False),
+             np.arange(40, 72), None]
     try:
         for cl in lists:
             for pf, npk in ((0, 2), (0, 1), (1, 1)):
@@ -545,6 +556,7 @@ def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows):
                                     nchan_stored=stored, npol_stored=nps, pol_first=2, chan_map=cmap)
     finally:
         kernels.tune(_lib.TUNE_XPOSE_ROWS, 0)
+        kernels.tune(_lib.TUNE_XPOSE_TC, 0)
 
 
 @pytest.mark.parametrize('layout', [0, 1, 2])
@@ -567,7 +579,8 @@ def test_xpose_kernel_channel_ranges(layout):
         ref = b.reshape(nfr, T, stored, npol, 2).transpose(0, 1, 3, 2, 4)
     ref = np.ascontiguousarray(ref).astype(np.float32)
     dbuf = kernels.to_device_bytes(raw)
-    for c_lo, keep, lo, hi in ((32, 64, 0, T), (0, 96, 8, T - 8), (96, 64, 256, 512), (4, 36, 0, T)):
+    for c_lo, keep, lo, hi in ((32, 64, 0, T), (0, 96, 8, T - 8), (96, 64, 256, 512), (4, 36, 0, T),
+                               (8, 8, 0, T), (100, 16, 8, T - 8), (12, 24, 0, T)):
         skip = kernels.tiled_channel_skip(layout, npol, T, c_lo)
         out = kernels.decode_i8_tiled(dbuf, nfr, layout, npol, keep, T, lo, hi, src0=head + skip,
                                       src_stride=stride, nchan_stored=stored).cpu().numpy()

@@ -42,6 +42,11 @@ for layout, name in ((_lib.LAYOUT_GUPPI_CF, "GUPPI channels first"), (_lib.LAYOU
                                                         nchan_stored=nchan, npol_stored=npol, pol_first=pf, chan_map=cmap),
                         reps=3)
         kname = _lib.last_kernel().split(' grid')[0]
+        kernels.tune(_lib.TUNE_XPOSE_TC, 64)            # round 3's first form: tiles of 64 channels always
+        ms_tc64 = timeit(lambda: kernels.decode_i8_tiled(buf, nfr, layout, npk, nc, T, 0, T, src0=0, src_stride=blk, out=out,
+                                                         nchan_stored=nchan, npol_stored=npol, pol_first=pf, chan_map=cmap),
+                         reps=3)
+        kernels.tune(_lib.TUNE_XPOSE_TC, 0)
         idx = torch.arange(nchan, device=dev) if chans is None else torch.tensor(chans, device=dev)
 
         def two_pass():
@@ -56,8 +61,24 @@ for layout, name in ((_lib.LAYOUT_GUPPI_CF, "GUPPI channels first"), (_lib.LAYOU
             read = nbytes * nc // nchan * npk // npol
         else:
             read = nbytes
-        print(json.dumps(dict(case="{}, {}".format(name, label), kernel=kname, folded_ms=round(ms_sel, 3),
+        print(json.dumps(dict(case="{}, {}".format(name, label), kernel=kname, folded_ms=round(ms_sel, 3), folded_tiles_of_64_ms=round(ms_tc64, 3),
                               decode_then_index_ms=round(ms_two, 3), full_decode_ms=round(ms_full, 3),
                               bytes_read=read, bytes_written=n * 4,
                               folded_GBps_moved=round((read + n * 4) / ms_sel / 1e6, 1))), flush=True)
         del out
+
+# narrow blocks decoded whole: tiles as wide as the block (k_decode_i8_xpose<.., TC>) against the general kernel
+for layout, name in ((_lib.LAYOUT_GUPPI_CF, "GUPPI channels first"), (_lib.LAYOUT_GUPPI_TF, "GUPPI time first"),
+                     (_lib.LAYOUT_MKBF, "MKBF heaps")):
+    for nch in (8, 16, 32):
+        Tn = blk // (npol * nch * 2)
+        res = {}
+        for label, knob in (("xpose", 8), ("general", 65)):
+            kernels.tune(_lib.TUNE_XPOSE_MIN_NC, knob)
+            ms = timeit(lambda: kernels.decode_i8_tiled(buf, nfr, layout, npol, nch, Tn, 0, Tn, src0=0, src_stride=blk,
+                                                        out=full_out), reps=3)
+            res[label + "_ms"] = round(ms, 3)
+            res[label + "_kernel"] = _lib.last_kernel().split(' grid')[0]
+            res[label + "_GBps"] = round(5 * nbytes / ms / 1e6, 1)
+        kernels.tune(_lib.TUNE_XPOSE_MIN_NC, 8)
+        print(json.dumps(dict(case="{}, whole blocks of {} channels".format(name, nch), **res)), flush=True)
