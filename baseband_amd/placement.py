@@ -32,9 +32,11 @@ from . import arena as _arena
 
 __all__ = ['empty_output', 'release_unused', 'ARENA_MIN_BYTES']
 
-# smaller outputs come from torch's allocator: their launches are latency bound
-# (a 64 MiB decode takes 10 us) and the arena's granule is 32 MiB
-ARENA_MIN_BYTES = 64 << 20
+# smaller outputs come from torch's allocator: where they lie changes a launch
+# of 0.15 ms by tens of microseconds at most, and the arena takes the device's
+# memory in steps of 48 GiB -- a script that only reads small pieces (and its
+# 64 MiB read-ahead window) should not make it take one
+ARENA_MIN_BYTES = 1 << 30
 _failed = False                 # arena creation failed once: do not try again in this process
 
 

@@ -223,7 +223,14 @@ def test_large_read_lifecycle_through_the_default_arena(tmp_path, monkeypatch):
         del got
         gc.collect()
         assert ar.stats()['blocks'] == 0
+        # a loop of small reads (and its 64 MiB read-ahead window) stays out of the arena
+        with vdif.open(str(path), 'rs', sample_rate=32e6) as fh:
+            for _ in range(8):
+                piece = fh.read(32000)
+            assert fh._decoded is not None and not ar.owns(fh._decoded[2]) and not ar.owns(piece)
+        assert ar.stats()['blocks'] == 0
         # concurrent allocations from two threads
+        monkeypatch.setattr(placement, 'ARENA_MIN_BYTES', 64 << 20)
         errs = []
 
         def worker(seed):
