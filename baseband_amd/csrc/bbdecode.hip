@@ -1202,7 +1202,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     const bool nt = tune_nt();
     const int tb = g_tune_blocks.load();
     // Fast form (k_xpose.h) for the common geometry: every input run 16-byte
-    // aligned, at least 32 channels.  Fixed stride only (offsets from an index
+    // aligned, at least 8 channels (a selection: 2).  Fixed stride only (offsets from an index
     // cannot be checked for alignment here).
     {
         const uint64_t npd = (uint64_t)p->npol;                          // polarisations decoded

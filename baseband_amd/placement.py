@@ -8,8 +8,11 @@ tensor cut from an arena of VMM chunks (`baseband_amd.arena`) decodes at
 6.5-6.8 (profiles/r03f_exp_arena.log, r03g_exp_arena_*.log, r03h_*).
 
 `empty_output` is what the readers allocate their outputs with: from the
-process-wide arena for outputs of at least `ARENA_MIN_BYTES`, else (and
-whenever the arena cannot serve) ``torch.empty``.  The arena is created on
+process-wide arena for outputs of `ARENA_MIN_BYTES` to `ARENA_MAX_BYTES`, else
+(and whenever the arena cannot serve) ``torch.empty``.  File bytes kept in HBM
+(``dtype=torch.uint8``: the staged copy of a file, `fh.stage()`) come from it
+too: the same launches run 1-2 % faster when their INPUT lies in arena memory
+(profiles/r03u_exp_image_arena.log, r03u_exp_headline_alloc.log).  The arena is created on
 first use; it is only a virtual range until tensors need memory, and
 `release_unused()` gives unused memory back (done automatically when torch
 runs out of memory here).
@@ -30,13 +33,18 @@ import torch
 
 from . import arena as _arena
 
-__all__ = ['empty_output', 'release_unused', 'ARENA_MIN_BYTES']
+__all__ = ['empty_output', 'release_unused', 'ARENA_MIN_BYTES', 'ARENA_MAX_BYTES']
 
 # smaller outputs come from torch's allocator: where they lie changes a launch
 # of 0.15 ms by tens of microseconds at most, and the arena takes the device's
 # memory in steps of 48 GiB -- a script that only reads small pieces (and its
 # 64 MiB read-ahead window) should not make it take one
 ARENA_MIN_BYTES = 1 << 30
+# larger outputs as well: a plain allocation of that size spans most of the
+# device anyway and decodes as fast or faster (127.5 GiB, one combination per
+# process, three processes each: plain 0.82-0.85 of the peak, arena 0.73-0.82;
+# profiles/r03u_exp_headline_alloc.log)
+ARENA_MAX_BYTES = 64 << 30
 _failed = False                 # arena creation failed once: do not try again in this process
 
 
@@ -75,7 +83,7 @@ def empty_output(shape, dtype=torch.float32, device=None):
     shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
     item = 8 if dtype == torch.complex64 else torch.empty(0, dtype=dtype).element_size()
     nbytes = int(np.prod(shape, dtype=np.int64)) * item
-    if nbytes >= ARENA_MIN_BYTES:
+    if ARENA_MIN_BYTES <= nbytes <= ARENA_MAX_BYTES:
         ar = _arena_for(device)
         if ar is not None:
             t = ar.empty(shape, dtype)

@@ -13,6 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
+from .placement import empty_output
 
 
 def host_image(fh):
@@ -204,7 +205,7 @@ def upload(image, device='cuda', chunk_bytes=64 << 20, join=True):
     (`upload_in_background`)."""
     device = torch.device(device)
     n = len(image)
-    dev = torch.empty(n + 256, dtype=torch.uint8, device=device)
+    dev = empty_output((n + 256,), dtype=torch.uint8, device=device)
     dev[n:] = 0
     if n <= (2 << 20):
         # small windows (random access): one plain copy beats pinning buffers

@@ -107,6 +107,18 @@ def make_file_image_on_device(nsets, seed, first_set, device, nthread=1, nchan=1
     return img.view(torch.uint8), h0
 
 
+def image_buffer(nbytes, device):
+    """Device memory for a file image, allocated the way the package keeps
+    file bytes in HBM (`fh.stage()`, the staged copy of a large read):
+    `baseband_amd.empty_output(dtype=uint8)` -- arena memory from 1 GiB on,
+    torch.empty below or with BB_ARENA=0.  Returns (tensor, "arena" | "torch")."""
+    import baseband_amd
+    from baseband_amd import arena
+    t = baseband_amd.empty_output((int(nbytes),), dtype=torch.uint8, device=device)
+    ar = arena.default()
+    return t, ("arena" if ar is not None and ar.owns(t) else "torch")
+
+
 # ---------------------------------------------------------------- CPU baseline
 def _cpu_worker(args):
     """One process of the all-cores CPU leg: its own slab of cfg2 frames through
@@ -922,7 +934,8 @@ def main():
     nframes = int(args.gib * 2 ** 30) // FRAME_NBYTES
     # time-slab sharding: rank r owns frames [r*nframes, (r+1)*nframes)
     first_frame, _ = frame_slab(nframes * world, rank, world)
-    image, h0 = make_file_image_on_device(nframes, 12345 + rank, first_frame, device)
+    image, image_memory = image_buffer(nframes * FRAME_NBYTES, device)
+    image, h0 = make_file_image_on_device(nframes, 12345 + rank, first_frame, device, into=image)
     pattern, mask = h0.invariant_pattern()
     out = torch.empty(nframes * SPF, dtype=torch.float32, device=device)
     bytes_in = nframes * FRAME_NBYTES
@@ -1004,7 +1017,8 @@ def main():
                                .format(bytes_in / 2 ** 30),
                    "frames_per_gpu": nframes, "bytes_in_per_gpu": bytes_in,
                    "bytes_out_per_gpu": bytes_out,
-                   "input": "packed 2-bit codes (uint8 file image)", "output": "float32 samples: "
+                   "input": "packed 2-bit codes (uint8 file image; memory: {})".format(image_memory),
+                   "output": "float32 samples: "
                    "full-size tensor kept in HBM (no slab recycling)",
                    "sharding": "time slabs, one per rank, no collective"},
         "roofline": {"bound": "hbm", "kernel": kernel_name,
@@ -1054,7 +1068,8 @@ def main():
             del out
             torch.cuda.empty_cache()
             try:
-                image, _ = make_file_image_on_device(nframes, 12345, 0, device)
+                image, _ = image_buffer(nframes * FRAME_NBYTES, device)
+                image, _ = make_file_image_on_device(nframes, 12345, 0, device, into=image)
                 line["mid_size"] = leg_mid_size(device, image)
                 del image
             except Exception as exc:

@@ -24,7 +24,7 @@
  * a new step is PROBED with a decode-shaped launch (2^16 frames, three
  * launches, about 5 ms) and, when it is slow, held aside while the next
  * candidate is created somewhere else (up to BB_ARENA_TRIES = 4; below
- * BB_ARENA_MIN_GBPS = 6200 counts as slow); the fastest stays.  Memory is taken
+ * BB_ARENA_MIN_GBPS = 6350 counts as slow); the fastest stays.  Memory is taken
  * from the device when a block needs it and goes back with bb_arena_trim.
  *
  * Not stream-ordered: bb_arena_free makes the block available to the next
