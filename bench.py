@@ -26,6 +26,8 @@ Besides the contract's keys the line carries
                 (tests/golden/cpu_calibration.json)
   api_read      the same 8 GiB image through the drop-in API:
                 ``vdif.open(<device tensor>, 'rs').read(out=out)``
+  invalid_fill  the headline step with `invalid_data` set in 1 % of the frames
+                (the fill path must cost nothing)
   cfg3          BASELINE configs[2] (8-thread 2-bit complex 16-channel VDIF):
                 rank 0 scans the whole file and builds the frame index, ONE
                 broadcast (RCCL) replicates it, every rank decodes its slab
@@ -613,6 +615,54 @@ def leg_api_read(args, image, out, kern_ms):
             "timing": "host wall clock around read() incl. the verification sync, mean of {} calls".format(args.steps)}
 
 
+def leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_ms):
+    """SURVEY 8(d) "value distributions": the headline file with the
+    `invalid_data` bit (word 0, bit 31) set in 1 % of the frames, through the
+    same scan + index + decode step: flagged frames come out as the fill value
+    (base/frame.py:191-199, vdif/frame.py:79-90) and the fill path costs
+    nothing.  The bits are cleared again afterwards."""
+    from baseband_amd import kernels, _lib
+    pattern, mask = h0.invariant_pattern()
+    g = torch.Generator(device=image.device)
+    g.manual_seed(99)
+    bad = torch.nonzero(torch.rand(nframes, generator=g, device=image.device) < 0.01).reshape(-1)
+    w0 = image.view(torch.int32)[::FRAME_NBYTES // 4]
+    w0[bad] |= -2 ** 31
+    try:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+        src = None
+        for k in range(-1, args.steps):
+            recs = kernels.vdif_scan(image, nframes, FRAME_NBYTES, HEADER_NBYTES, pattern, mask,
+                                     h0['seconds'], h0['frame_nr'] + first_frame, FRAME_RATE)
+            src = kernels.build_index(recs, nframes, 1, None)
+            if k >= 0:
+                ev[k][0].record()
+            kernels.decode_frames(image, nframes, PAYLOAD_NBYTES, _lib.CODER_VDIF, 2, src=src, out=out)
+            if k >= 0:
+                ev[k][1].record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        nbad = int(bad.numel())
+        filled = int((src < 0).sum().item())
+        # flagged frames are fill, their neighbours are data
+        f = int(bad[nbad // 2].item())
+        is_fill = bool((out[f * SPF:(f + 1) * SPF] == 0).all().item())
+        g_ = f + 1 if f + 1 < nframes and not bool((bad == f + 1).any().item()) else max(0, f - 1)
+        lev = _lib.get_levels(_lib.CODER_VDIF, 2)
+        raw = image[g_ * FRAME_NBYTES + HEADER_NBYTES:(g_ + 1) * FRAME_NBYTES].cpu().numpy()
+        neighbour_ok = bool(np.array_equal(out[g_ * SPF:(g_ + 1) * SPF].cpu().numpy().view(np.uint32),
+                                           expand_2bit(raw, lev).view(np.uint32)))
+    finally:
+        w0[bad] &= 2 ** 31 - 1
+    alg = nframes * (FRAME_NBYTES + PAYLOAD_NBYTES * 16)
+    return {"what": "the headline step with invalid_data set in 1 % of the frames (scan -> index entry -1 -> fill 0.0)",
+            "frames_flagged": nbad, "index_entries_invalid": filled, "kernel": _lib.last_kernel(),
+            "kernel_ms_avg": round(ms, 4), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+            "ms_over_headline_kernel": round(ms / kern_ms, 4),
+            "flagged_frame_is_fill": is_fill, "neighbour_frame_is_data": neighbour_ok}
+
+
 def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
     """Kernel-level figures for the other BASELINE configurations on random
     input -- `gib` GiB for the 2-bit formats, `gib8` for the 8-bit ones, i.e. the
@@ -1051,6 +1101,10 @@ def main():
                 line["api_read"] = leg_api_read(args, image, out, kern_avg)
             except Exception as exc:
                 line["api_read"] = {"error": repr(exc)[:500]}
+            try:
+                line["invalid_fill"] = leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_avg)
+            except Exception as exc:
+                line["invalid_fill"] = {"error": repr(exc)[:500]}
         del image
         try:
             line["cfg3"] = leg_cfg3(args, rank, world, device, dist, out)
