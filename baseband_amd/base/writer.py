@@ -46,6 +46,9 @@ class LazyWriteFile:
         if self._fh is not None:
             self._fh.flush()
 
+    def fileno(self):
+        return self._open().fileno()
+
     @property
     def closed(self):
         return self._fh is not None and self._fh.closed
@@ -148,21 +151,21 @@ class GPUStreamWriterBase:
     def _write_frames(self, data, valid):
         raise NotImplementedError
 
-    _staging = None                     # pinned host buffer of this writer
-
     def _emit_frames(self, header_bytes, packed, fh=None):
         """Glue ``header_bytes`` (host uint8 array, one row per frame) in front
         of the payload rows of ``packed`` (device uint8 tensor) ON THE GPU,
         bring whole frames to the host with one copy into a pinned buffer and
         hand that buffer to the file -- no per-frame work and no further host
         copies (three of them, at 5-10 GB/s each, used to sit between the
-        encoder and the file; tools/bench_writers.py)."""
+        encoder and the file; tools/bench_writers.py).  Large writes are
+        pipelined, copy against write (`staging.write_device_bytes`)."""
         nfr, hn = header_bytes.shape
         pk = packed.reshape(nfr, -1)
         frames = torch.empty((nfr, hn + pk.shape[1]), dtype=torch.uint8, device=pk.device)
         frames[:, hn:] = pk
         frames[:, :hn] = torch.from_numpy(np.ascontiguousarray(header_bytes)).to(pk.device)
-        (self.fh_raw if fh is None else fh).write(memoryview(self._to_host(frames)))
+        from ..staging import write_device_bytes
+        write_device_bytes(self.fh_raw if fh is None else fh, frames)
 
     def _to_host(self, dev):
         """Device uint8 tensor -> flat uint8 NumPy view of this writer's pinned
@@ -228,10 +231,10 @@ class BlockStreamWriter(GPUStreamWriterBase):
         if data.is_complex():
             data = torch.view_as_real(data)
         block = self._storage_order(data.reshape((nframes, spf) + tuple(data.shape[1:])))
-        packed = self._to_host(kernels.encode_flat(block, _lib.CODER_INT, self.bps))
-        payloads = packed.reshape(nframes, -1)
+        from ..staging import write_device_bytes
+        payloads = kernels.encode_flat(block, _lib.CODER_INT, self.bps).reshape(nframes, -1)
         for k in range(nframes):
             header = self._frame_header(self._nframes_written + k)
             assert header.payload_nbytes == payloads.shape[1]
             header.tofile(self.fh_raw)
-            self.fh_raw.write(payloads[k].data)
+            write_device_bytes(self.fh_raw, payloads[k])

@@ -16,7 +16,7 @@ import torch
 from .. import _lib, kernels
 from ..base.base import FileBase, GPUStreamReaderBase
 from ..base.writer import GPUStreamWriterBase, LazyWriteFile
-from ..staging import host_image
+from ..staging import host_image, write_device_bytes
 from .header import GSBHeader
 from .payload import GSBPayload
 
@@ -298,18 +298,17 @@ class GSBStreamWriter(GPUStreamWriterBase):
         if data.is_complex():
             data = torch.view_as_real(data)
         if self._rawdump:
-            packed = self._to_host(kernels.encode_flat(data, _lib.CODER_INT, self.bps))
-            self.fh_raw.write(packed.data)
+            write_device_bytes(self.fh_raw, kernels.encode_flat(data, _lib.CODER_INT, self.bps))
         else:
             npol, F = len(self.fh_raw), self._nfiles
             # (frame, part, time in part, pol, ...) -> (pol, part, frame, time, ...)
             block = data.reshape((nframes, F, spf // F, npol) + tuple(data.shape[2:]))
             block = block.permute(3, 1, 0, 2, *range(4, block.dim()))
-            packed = self._to_host(kernels.encode_flat(block, _lib.CODER_INT, self.bps))
+            packed = kernels.encode_flat(block, _lib.CODER_INT, self.bps)
             packed = packed.reshape(npol, F, nframes * self._payload_nbytes)
             for p in range(npol):
                 for f in range(F):
-                    self.fh_raw[p][f].write(packed[p, f].data)
+                    write_device_bytes(self.fh_raw[p][f], packed[p, f])
         for k in range(nframes):
             self._frame_header(self._nframes_written + k).tofile(self.fh_ts)
 

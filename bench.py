@@ -643,6 +643,17 @@ def leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_ms):
                 ev[k][1].record()
         torch.cuda.synchronize()
         ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        # every frame invalid: the same kernel with the same store pattern and NO
+        # reads -- what this device does write-only ("measured achievable")
+        none = torch.full_like(src, -1)
+        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+        for a_, b_ in ev2:
+            a_.record()
+            kernels.decode_frames(image, nframes, PAYLOAD_NBYTES, _lib.CODER_VDIF, 2, src=none, out=out)
+            b_.record()
+        torch.cuda.synchronize()
+        ms_w = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev2][1:]))
+        del none
         nbad = int(bad.numel())
         filled = int((src < 0).sum().item())
         # flagged frames are fill, their neighbours are data
@@ -660,7 +671,12 @@ def leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_ms):
             "frames_flagged": nbad, "index_entries_invalid": filled, "kernel": _lib.last_kernel(),
             "kernel_ms_avg": round(ms, 4), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
             "ms_over_headline_kernel": round(ms / kern_ms, 4),
-            "flagged_frame_is_fill": is_fill, "neighbour_frame_is_data": neighbour_ok}
+            "flagged_frame_is_fill": is_fill, "neighbour_frame_is_data": neighbour_ok,
+            "all_frames_invalid": {"what": "the same launch with every index entry -1: the kernel's stores, no reads",
+                                   "kernel_ms": round(ms_w, 4),
+                                   "write_GBps": round(nframes * PAYLOAD_NBYTES * 16 / ms_w / 1e6, 1),
+                                   "frac_of_peak": round(nframes * PAYLOAD_NBYTES * 16 / ms_w / 1e6 / HBM_PEAK_GBS, 4),
+                                   "headline_kernel_ms_over_this": round(kern_ms / ms_w, 4)}}
 
 
 def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):

@@ -149,3 +149,33 @@ def test_kept_windows_have_a_stated_byte_cap():
         fh.keep_staged = True
         assert bits_equal(fh.read().cpu().numpy(), exp)
         assert fh._sink is not None and fh._has_bytes(0, len(image))
+
+
+def test_write_device_bytes_to_files_and_streams(tmp_path, monkeypatch):
+    """staging.write_device_bytes: device bytes -> file at its current position;
+    large writes go out in chunks (copy of the next against write of this one),
+    small ones in one piece -- same bytes, same file position."""
+    import io
+    import torch
+    from baseband_amd import staging
+    g = torch.Generator(device='cuda').manual_seed(5)
+    for n in (0, 1000, (32 << 20) + 12345, (72 << 20) + 1):
+        dev = torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda', generator=g)
+        want = dev.cpu().numpy().tobytes()
+        path = tmp_path / 'w{}.bin'.format(n)
+        with open(path, 'w+b') as fh:
+            fh.write(b'head')
+            staging.write_device_bytes(fh, dev)
+            assert fh.tell() == 4 + n
+            fh.write(b'tail')
+        assert path.read_bytes() == b'head' + want + b'tail'
+        bio = io.BytesIO()
+        bio.write(b'head')
+        staging.write_device_bytes(bio, dev)
+        assert bio.getvalue() == b'head' + want
+        # a strided view is written in its logical order
+        if n >= 1000:
+            v = dev[:n // 2 * 2].reshape(-1, 2)[:, 0]
+            bio = io.BytesIO()
+            staging.write_device_bytes(bio, v)
+            assert bio.getvalue() == v.contiguous().cpu().numpy().tobytes()
