@@ -1220,19 +1220,23 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
             ok = ok && np_ == 2 && (p->d_chan_map ? true : (nc % 4 == 0)) && (ncs % 4 == 0);
         if (!ok && selecting) return BB_ENOTSUP;
         if (ok) {
-            // rows per tile: 128 for channels-first blocks (5.9 -> 6.3 TB/s against
-            // 64 at the headline's output size); for time-first blocks and MKBF
-            // heaps 64 below 96 GiB of output (+3 % at 8 GiB of input) and 128
-            // above (+0-1 %): profiles/r02az_exp_xpose_rows.log
-            const int xr = g_tune_xpose_rows.load();
-            const bool big = (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4 >= (96ull << 30);
-            uint64_t xrows = xr ? (uint64_t)xr : (p->layout == BB_LAYOUT_GUPPI_CF || big) ? 128u : 64u;
-            // output rows per tile: half an LDS image when one of two pols is dropped (layouts 0, 2)
-            // channels per tile: the narrowest of 64 / 32 / 16 / 8 that holds them all
-            // (narrow tiles are longer, 128 * 64 / tc rows: only that size is built)
-            const int xt = g_tune_xpose_tc.load();
-            const uint64_t xtc = xt ? (uint64_t)xt : nc > 32 ? 64u : nc > 16 ? 32u : nc > 8 ? 16u : 8u;
-            if (xtc != 64) xrows = 128;
+            // Tile shape (the tile keeps its 16 KiB of input; a narrower tile is
+            // longer along the input's contiguous axis).  Blocks of 64 channels, 8 and
+            // 31 GiB of input, all eight shapes in one process on two boxes
+            // (profiles/r03zb_exp_xpose_tc*.log):
+            //   channels first  32 channels x 256 elements (512-byte input runs): 6.48 /
+            //                   6.65 TB/s against 6.21 / 6.55 with 64 x 128 (16 x 512 the same)
+            //   time first      16 channels x 256 times: 6.55 / 6.68 against 6.44 / 6.55
+            //   MKBF heaps      64 channels x 64 rows: 6.47 / 6.63 against 6.20 / 6.35 with 128
+            // and never wider than the channels there are (8 at least: rows of 64 bytes).
+            const int xr = g_tune_xpose_rows.load(), xt = g_tune_xpose_tc.load();
+            const uint64_t fit = nc > 32 ? 64u : nc > 16 ? 32u : nc > 8 ? 16u : 8u;
+            // (time-first blocks with a channel map load single dwords: wide tiles
+            // reuse the cache lines of a time's row, 8.6 against 10.1 ms for 64 mapped channels)
+            const uint64_t pref = p->layout == BB_LAYOUT_GUPPI_CF ? 32u
+                                : (p->layout == BB_LAYOUT_MKBF || p->d_chan_map) ? 64u : 16u;
+            const uint64_t xtc = xt ? (uint64_t)xt : (fit < pref ? fit : pref);
+            const uint64_t xrows = xr ? (uint64_t)xr : (p->layout == BB_LAYOUT_MKBF && xtc == 64) ? 64u : 128u;
             const uint64_t rt = xrows * 64 / xtc;
             const uint64_t rpt = p->layout == BB_LAYOUT_MKBF ? rt : rt / (np_ / npd);
             const uint64_t ntt = (rows + rpt - 1) / rpt, nct = (nc + xtc - 1) / xtc;
@@ -1250,18 +1254,20 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
             const uint64_t cap = tb > 0 ? (uint64_t)tb : 0x7fffffffull;
             if (blocks > cap) blocks = cap;
             const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+#define BB_XP1(L, R) \
+                if (xtc == 8)        hipLaunchKernelGGL((k_decode_i8_xpose<L, N, R, 8>), grid, block, 0, st, a); \
+                else if (xtc == 16)  hipLaunchKernelGGL((k_decode_i8_xpose<L, N, R, 16>), grid, block, 0, st, a); \
+                else if (xtc == 32)  hipLaunchKernelGGL((k_decode_i8_xpose<L, N, R, 32>), grid, block, 0, st, a); \
+                else                 hipLaunchKernelGGL((k_decode_i8_xpose<L, N, R, 64>), grid, block, 0, st, a);
 #define BB_XP(L) with_nt(nt, [&](auto NT) { \
                 constexpr bool N = decltype(NT)::value; \
-                if (xtc == 8)        hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 128, 8>), grid, block, 0, st, a); \
-                else if (xtc == 16)  hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 128, 16>), grid, block, 0, st, a); \
-                else if (xtc == 32)  hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 128, 32>), grid, block, 0, st, a); \
-                else if (xrows == 64) hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 64, 64>), grid, block, 0, st, a); \
-                else                 hipLaunchKernelGGL((k_decode_i8_xpose<L, N, 128, 64>), grid, block, 0, st, a); })
+                if (xrows == 64) { BB_XP1(L, 64) } else { BB_XP1(L, 128) } })
             switch (p->layout) {
                 case BB_LAYOUT_GUPPI_CF: BB_XP(0); break;
                 case BB_LAYOUT_MKBF:     BB_XP(1); break;
                 default:                 BB_XP(2); break;
             }
+#undef BB_XP1
 #undef BB_XP
             BB_NOTE("k_decode_i8_xpose<%d,%s,%d,%d> grid %u tiles %u x %u per frame", p->layout, nt ? "nt" : "plain",
                     (int)xrows, (int)xtc, grid.x, a.ntt, a.nct);

@@ -26,11 +26,11 @@ extern "C" {
 #define BB_TUNE_SEG_TILES     13   /* plain flat kernel: 256-byte tiles per workgroup (default 0 = 32, 16 for 8-bit samples) */
 #define BB_TUNE_WORK_STRIPES  18   /* work order of the decode launches: log2 of the number of stripes a launch's work items are dealt over (0 = file order; default -1 = 16 stripes for outputs of 16 GiB and more, 4 below) */
 #define BB_TUNE_XPOSE         19   /* 1 (default): int8 transposes with 16-byte aligned input runs go through k_decode_i8_xpose; 0: k_decode_i8_tiled / _stage always */
-#define BB_TUNE_XPOSE_ROWS    20   /* k_decode_i8_xpose: output rows per tile, 128 or 64; default 0 = 128 for GUPPI channels-first blocks and for outputs of 96 GiB and more, 64 for smaller launches of time-first blocks and MKBF heaps */
+#define BB_TUNE_XPOSE_ROWS    20   /* k_decode_i8_xpose: tile length, 128 or 64 (output rows of a 64-channel tile); default 0 = 64 for MKBF heaps in 64-channel tiles, 128 otherwise */
 #define BB_TUNE_M4_WIDEN      22   /* 1 (default): 16- and 32-track Mark 4 units whose word count and fill prefix allow it are decoded as 64-bit super-words by the 64-track kernels; 0: always the native word size */
 #define BB_TUNE_SELECT_BYTES  23   /* payload bytes (all thread slots together) that k_decode_gather_select stages in LDS per work item (256..32768, default 16384) */
 #define BB_TUNE_LUT_TILES     24   /* upper bound of 256-byte tiles per wave and work item in k_decode_flat_lut for 2-bit samples (1..16, default 4; half as many for 1-bit, twice as many for 4-bit samples: 32 KiB of output per work item) */
-#define BB_TUNE_XPOSE_TC      27   /* k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; default 0 = the narrowest that holds all decoded channels (64 above 32 channels) */
+#define BB_TUNE_XPOSE_TC      27   /* k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; default 0 = 32 for channels-first blocks, 16 for time-first blocks, 64 for MKBF heaps, and never wider than the decoded channels need */
 #define BB_TUNE_XPOSE_MIN_NC  28   /* blocks decoded whole go through k_decode_i8_xpose from this many channels on (default 8; selections: always from 2) */
 #define BB_TUNE_M4_TILES      26   /* 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8, default 8) */
 

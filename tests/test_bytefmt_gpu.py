@@ -331,7 +331,7 @@ def test_small_reads_row_staging_equals_whole_frame_staging(manifest, fmt, name)
         assert bits_equal(first, again) and bits_equal(again, third), (off, cnt)
 
 
-@pytest.mark.parametrize('tile_rows,tile_chans', [(128, 0), (64, 0), (0, 8), (0, 16), (0, 32), (0, 64)])
+@pytest.mark.parametrize('tile_rows,tile_chans', [(128, 0), (64, 0), (0, 8), (0, 16), (0, 32), (0, 64), (64, 8), (64, 16), (64, 32), (128, 64)])
 def test_xpose_kernel_raw_layouts(tile_rows, tile_chans):
     """k_decode_i8_xpose (16-byte aligned input runs, >= 8 channels): all three
     layouts vs NumPy transposes -- ragged channel tiles, narrow blocks (tiles of
@@ -498,7 +498,7 @@ def test_block_channel_lists_and_single_polarisations(manifest, name):
             assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(want[1:n - 1])), subset
 
 
-@pytest.mark.parametrize('tile_rows,tile_chans', [(0, 0), (64, 0), (128, 0), (0, 8), (0, 32), (0, 64)])
+@pytest.mark.parametrize('tile_rows,tile_chans', [(0, 0), (64, 0), (128, 0), (0, 8), (0, 32), (0, 64), (64, 16), (128, 64)])
 @pytest.mark.parametrize('layout', [0, 1, 2])
 def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows, tile_chans):
     """k_decode_i8_xpose with a SELECTION: out[f, t, p, c] = stored[f, t,
