@@ -64,6 +64,7 @@ TUNE_OUT_STRIPE_W = 16
 TUNE_OUT_STRIPE_S = 17
 TUNE_BYTE_LUT = 21
 TUNE_LUT_SMALL = 25
+TUNE_FLAT8_LDS = 29
 
 
 class BBError(RuntimeError):

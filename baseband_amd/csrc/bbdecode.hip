@@ -164,6 +164,9 @@ std::atomic<int> g_tune_select_bytes{16384};   // payload bytes k_decode_gather_
 std::atomic<int> g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
 std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
 std::atomic<int> g_tune_xpose_rows{0};   // k_decode_i8_xpose: output rows per tile, 128 or 64; 0 = by layout
+#if BB_EXP
+std::atomic<int> g_tune_flat8_lds{0};    // experiment: 1 = contiguous 8-bit output through k_decode_flat_lds<8>
+#endif
 std::atomic<int> g_tune_xpose_tc{0};     // k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; 0 = by channel count
 std::atomic<int> g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a selection: from this many channels on
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
@@ -308,6 +311,21 @@ void launch_flat_lds(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
     });
 }
 
+#if BB_EXP
+// the same staging for contiguous 8-bit output: 2 waves x up to 16 tiles.  Experiment
+// build only: measured against the plain kernel (profiles/r03zd_exp_flat8*.log) it
+// loses 2-5 % on VDIF 8-bit frames (four table reads per store) and is -1 .. +3 %
+// on int8 blocks depending on size and tiles per wave.
+void launch_flat_lds8(int coder, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+{
+    with_nt(nt, [&](auto NT) {
+        constexpr bool N = decltype(NT)::value;
+        if (coder == BB_CODER_INT) hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_INT8>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        else                       hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_LDS>), grid, dim3(2 * BB_WAVE), 0, st, a);
+    });
+}
+#endif
+
 // the byte table kernel with dword loads handed out by ds_bpermute: contiguous
 // 1- and 4-bit output (k_lut.h)
 void launch_flat_lut(int bps, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
@@ -398,6 +416,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
 #if BB_EXP
         case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
+        case BB_TUNE_FLAT8_LDS: g_tune_flat8_lds = value; return BB_OK;
         case BB_TUNE_NT_STORES:    g_tune_nt = value;      return BB_OK;
         case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
         case BB_TUNE_TILES_PER_WAVE_8BIT: g_tune_tpw8 = (value >= 1 && value <= 32) ? value : 12; return BB_OK;
@@ -771,6 +790,28 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         BB_HIP(hipGetLastError());
         return BB_OK;
     }
+
+#if BB_EXP
+    if (om == BB_OUT_FLAT && p->bps == 8 && g_tune_flat8_lds.load() != 0) {
+        // 3b. contiguous 8-bit output: 16-byte loads staged through LDS
+        // (k_decode_flat_lds<8>), 2 waves x 16 tiles = 32 KiB of output per workgroup
+        int t8 = g_tune_lut_tpw.load() * 4;
+        t8 = t8 < 1 ? 1 : t8 > 16 ? 16 : t8;
+        const uint64_t seg_max = 2ull * (uint64_t)t8;
+        a.nseg = (ntiles + seg_max - 1) / seg_max;
+        a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
+        a.tpw = (a.seg_tiles + 1) / 2;
+        uint64_t b2 = nfs * a.nseg;
+        a.perm = make_perm(b2, out_bytes);
+        const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
+        if (b2 > cap) b2 = cap;
+        const dim3 g2((unsigned)b2);
+        launch_flat_lds8(p->coder, nt, g2, st, a);
+        BB_NOTE("k_decode_flat_lds<8,%s,%s,2,16> grid %u tiles/wave %u", lv_name(p->bps, p->coder), nt ? "nt" : "plain", g2.x, a.tpw);
+        BB_HIP(hipGetLastError());
+        return BB_OK;
+    }
+#endif
 
     // 4. the plain kernel (k_decode_flat): one workgroup of four waves per work
     // item, loads and stores in the same iteration, uncapped grid.  8-bit

@@ -27,21 +27,30 @@
 #pragma once
 #include "k_flat.h"
 
-template <int BPS, bool NT, int NW, int MAXT>
+// 8-BIT samples (VDIF 8-bit, DADA / GSB / GUPPI-real int8; round 3): the same
+// staging with nothing to look up per bit field -- a lane's float4 is ONE staged
+// dword (ds_read_b32, consecutive lanes consecutive dwords), converted by cast
+// (LV = BB_LV_INT8) or through the 256-entry level table (BB_LV_LDS).  These
+// payloads read 20 % of their traffic, not 6 %: 16-byte loads matter more.
+template <int BPS, bool NT, int NW, int MAXT, int LV = BB_LV_REG>
 __global__ __launch_bounds__(NW * BB_WAVE)
 void k_decode_flat_lds(bb_flat_args a)
 {
-    static_assert(BPS == 1 || BPS == 2 || BPS == 4, "byte table kernel: 1-, 2- or 4-bit samples");
+    static_assert(BPS == 1 || BPS == 2 || BPS == 4 || BPS == 8, "1-, 2-, 4- or 8-bit samples");
     constexpr int EPT = 2048 / BPS;
     constexpr int PASSES = 8 / BPS;
     constexpr int FPB = BPS == 1 ? 2 : 1;
     constexpr uint32_t CMASK = (1u << BPS) - 1;
     constexpr int NPIECE = (MAXT + 1) * 16;                 // 16-byte pieces a wave stages at most
     constexpr int NLOAD = (NPIECE + BB_WAVE - 1) / BB_WAVE;
-    __shared__ bb_f4 s_lut[BPS == 4 ? 1 : 256 * FPB];
+    __shared__ bb_f4 s_lut[BPS >= 4 ? 1 : 256 * FPB];
     __shared__ float2 s_lut2[BPS == 4 ? 256 : 1];
+    __shared__ float s_tab8[(BPS == 8 && LV == BB_LV_LDS) ? 256 : 1];
     __shared__ bb_u4 s_stage[NW][NPIECE];
-    if (BPS == 4) {
+    if (BPS == 8) {
+        if (LV == BB_LV_LDS)
+            for (int i = threadIdx.x; i < 256; i += NW * BB_WAVE) s_tab8[i] = a.tab[i];
+    } else if (BPS == 4) {
         for (int i = threadIdx.x; i < 256; i += NW * BB_WAVE)
             s_lut2[i] = float2{a.tab[i & 15], a.tab[i >> 4]};
     } else {
@@ -65,7 +74,8 @@ void k_decode_flat_lds(bb_flat_args a)
     uint32_t *stage32 = reinterpret_cast<uint32_t *>(&s_stage[wave][0]);
     // byte of the tile a lane's float4 comes from in pass p: 1-bit 32 p + l / 2,
     // 2-bit 64 p + l, 4-bit two bytes at 128 p + 2 l
-    const uint32_t lane_byte = BPS == 1 ? (uint32_t)lane >> 1 : BPS == 2 ? (uint32_t)lane : 2u * (uint32_t)lane;
+    const uint32_t lane_byte = BPS == 1 ? (uint32_t)lane >> 1 : BPS == 2 ? (uint32_t)lane
+                             : BPS == 4 ? 2u * (uint32_t)lane : 4u * (uint32_t)lane;
     const uint32_t hsel = (uint32_t)(lane % FPB);
 
     for (uint64_t step = blockIdx.x; step < nwork; step += gridDim.x) {
@@ -126,7 +136,14 @@ void k_decode_flat_lds(bb_flat_args a)
                     v = fillv;
                 } else {
                     const uint32_t b = s + (uint32_t)u * 256 + (uint32_t)(256 / PASSES) * p + lane_byte;
-                    if (BPS == 4) {
+                    if (BPS == 8) {
+                        const uint32_t w = stage32[b >> 2];         // (s and lane_byte are multiples of 4)
+                        if (LV == BB_LV_LDS)
+                            v = bb_f4{s_tab8[w & 0xff], s_tab8[(w >> 8) & 0xff], s_tab8[(w >> 16) & 0xff], s_tab8[w >> 24]};
+                        else
+                            v = bb_f4{(float)(int)(int8_t)(w & 0xff), (float)(int)(int8_t)((w >> 8) & 0xff),
+                                      (float)(int)(int8_t)((w >> 16) & 0xff), (float)(int)(int8_t)(w >> 24)};
+                    } else if (BPS == 4) {
                         const float2 l2 = s_lut2[stage8[b]], h2 = s_lut2[stage8[b + 1]];
                         v = bb_f4{l2.x, l2.y, h2.x, h2.y};
                     } else {

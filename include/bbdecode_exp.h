@@ -29,6 +29,7 @@ extern "C" {
 #define BB_TUNE_OUT_STRIPE_S  17   /* ... that lie this many frame-slots apart: frame fs goes to slot (fs % W) * S + fs / W */
 #define BB_TUNE_BYTE_LUT      21   /* 1 (default): contiguous 1-, 2- and 4-bit decode through k_decode_flat_lut; 0: k_decode_flat_aln (register level select) */
 #define BB_TUNE_LUT_SMALL     25   /* 1: k_decode_flat_lut instantiated for at most 4 tiles per wave when the work items are that short (slower) */
+#define BB_TUNE_FLAT8_LDS     29   /* 1: contiguous 8-bit output through k_decode_flat_lds<8> (16-byte loads staged in LDS; BB_TUNE_LUT_TILES x 4 tiles per wave) instead of k_decode_flat<8>: -2..-5 % VDIF 8-bit, -1..+3 % int8 blocks (profiles/r03zd_exp_flat8*.log) */
 
 /* When d_times is not NULL, the contiguous-output flat decode kernels store
  * the device wall clock (100 MHz ticks) at which each work item was completed

@@ -517,3 +517,63 @@ def test_byte_table_kernel_geometries(tiles, coder, bps):
     finally:
         kernels.tune(_lib.TUNE_LUT_TILES, 4)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
+
+
+@needs_experiments
+@pytest.mark.parametrize('coder', ['vdif', 'int'])
+def test_8bit_staged_kernel_geometries(coder):
+    """k_decode_flat_lds<8> (experiment build; measured, not faster than the plain
+    kernel): contiguous 8-bit output with 16-byte loads staged
+    in LDS (table for VDIF's levels, cast for int8) -- payloads that are and are
+    not multiples of 256 bytes or of a work item, headers that put payloads at
+    any 4-byte and at odd addresses, missing frames, a capped grid; and
+    bit-identical to the plain kernel behind BB_TUNE_FLAT8_LDS = 0."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(808)
+    kernels.tune(_lib.TUNE_FLAT8_LDS, 1)
+    try:
+        for pn, header, nframes, cap in ((8000, 32, 37, 0), (10000, 16, 23, 8), (8192, 32, 19, 0), (264, 4, 300, 16),
+                                         (256, 0, 65, 0), (70000, 12, 3, 2), (4, 8, 50, 0), (8196, 36, 11, 0),
+                                         (1 << 20, 4096, 3, 0)):
+            kernels.tune(_lib.TUNE_BLOCKS, cap)
+            stride = header + pn
+            raw = rng.integers(0, 256, nframes * stride + 64, dtype=np.uint8)
+            src = header + stride * np.arange(nframes, dtype=np.int64)
+            src[rng.choice(nframes, size=max(1, nframes // 9), replace=False)] = -1
+            dsrc = torch.from_numpy(src).cuda()
+            exp = np.empty((nframes, pn), np.float32)
+            for f in range(nframes):
+                exp[f] = -7.5 if src[f] < 0 else orc.decode_flat(raw[src[f]:src[f] + pn], coder, 8)
+            for shift in (0, 4, 100):
+                big = torch.zeros(shift + raw.size + 256, dtype=torch.uint8, device='cuda')
+                big[shift:shift + raw.size] = torch.from_numpy(raw).cuda()
+                view = big[shift:shift + raw.size]
+                out = kernels.decode_frames(view, nframes, pn, CODERS[coder], 8, src=dsrc, fill_value=-7.5)
+                assert 'k_decode_flat_lds<8' in _lib.last_kernel(), _lib.last_kernel()
+                assert bits_equal(out.cpu().numpy(), exp.reshape(-1)), (coder, pn, header, cap, shift)
+            # payloads at odd addresses (files repaired by the byte-granular search): byte staging
+            src2 = src.copy()
+            ok = np.nonzero(src2 >= 0)[0]
+            src2[ok] += np.where(np.arange(ok.size) % 3 == 0, 1, np.where(np.arange(ok.size) % 3 == 1, 3, 0))
+            exp2 = np.empty((nframes, pn), np.float32)
+            for f in range(nframes):
+                exp2[f] = -7.5 if src2[f] < 0 else orc.decode_flat(raw[src2[f]:src2[f] + pn], coder, 8)
+            out = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, CODERS[coder], 8,
+                                        src=torch.from_numpy(src2).cuda(), fill_value=-7.5)
+            assert bits_equal(out.cpu().numpy(), exp2.reshape(-1)), (coder, pn, header, cap, 'odd')
+            # fixed stride, no index
+            out = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, CODERS[coder], 8,
+                                        src0=header, src_stride=stride)
+            full = np.stack([orc.decode_flat(raw[header + f * stride:header + f * stride + pn], coder, 8)
+                             for f in range(nframes)])
+            assert bits_equal(out.cpu().numpy(), full.reshape(-1)), (coder, pn)
+            kernels.tune(_lib.TUNE_FLAT8_LDS, 0)
+            plain = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, CODERS[coder], 8,
+                                          src0=header, src_stride=stride)
+            assert 'k_decode_flat<8' in _lib.last_kernel()
+            kernels.tune(_lib.TUNE_FLAT8_LDS, 1)
+            assert torch.equal(plain.view(torch.int32), out.view(torch.int32))
+    finally:
+        kernels.tune(_lib.TUNE_BLOCKS, 0)
+        kernels.tune(_lib.TUNE_FLAT8_LDS, 0)
