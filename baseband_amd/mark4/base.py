@@ -265,12 +265,13 @@ class Mark4StreamReader(GPUStreamReaderBase):
             dbuf, nframes, self._ntrack, self.header0.year,
             self._ref_qms + first * self._frame_qms, self._frame_qms)
         src = kernels.build_index(recs, n, 1, None)
+        if self.verify:
+            # the look-ahead header (record n) only has to be a header
+            # (queued before the decode: `_resolve_checks` waits for this alone)
+            self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))
         kernels.decode_mark4(
             dbuf, n, self._ntrack, 20000, sign, mag,
             fill_words=160, src=src, fill_value=self.fill_value, out=out_flat, select=select)
-        if self.verify:
-            # the look-ahead header (record n) only has to be a header
-            self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))
 
 
 class Mark4StreamWriter(GPUStreamWriterBase):

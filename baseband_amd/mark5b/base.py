@@ -212,13 +212,14 @@ class Mark5BStreamReader(GPUStreamReaderBase):
                                    self.header0['frame_nr'] + first,
                                    self._frame_rate)
         src = kernels.build_index(recs, n, 1, None)
+        if self.verify:
+            # the look-ahead header (record n) only has to be a header
+            # (queued before the decode: `_resolve_checks` waits for this alone)
+            self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))
         kernels.decode_frames(
             dbuf, n, 10000, _lib.CODER_MARK5B, self.bps,
             chunk=self._unsliced_shape[0], nslot=1, src=src,
             fill_value=self.fill_value, out=out_flat, within=self._within)
-        if self.verify:
-            # the look-ahead header (record n) only has to be a header
-            self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))
 
 
 class Mark5BStreamWriter(GPUStreamWriterBase):

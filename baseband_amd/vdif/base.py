@@ -383,13 +383,15 @@ class VDIFStreamReader(GPUStreamReaderBase):
         nslot = len(self._thread_ids)
         src = kernels.build_index(recs, nsets, nslot, self._thread_slot)
         chunk = h0.nchan * (2 if self.complex_data else 1)
+        if self.verify:
+            # (queued BEFORE the decode: read() waits for this verdict only,
+            # the decode goes on behind it -- `_resolve_checks`)
+            self._check_window(recs, nframes, nthread_file, nframes,
+                               missing=nsets * nthread_file - nframes)
         kernels.decode_frames(
             dbuf, nsets, h0.payload_nbytes, self._coder, self.bps,
             chunk=chunk, nslot=nslot, src=src, complex_data=self.complex_data,
             fill_value=self.fill_value, out=out_flat, within=self._within)
-        if self.verify:
-            self._check_window(recs, nframes, nthread_file, nframes,
-                               missing=nsets * nthread_file - nframes)
 
 
     # -- frame index as a first-class object (multi-GPU sharding, parallel.py)

@@ -863,11 +863,27 @@ def leg_mid_size(device, image, draws=5, launches=6):
                     inside = ar is not None and ar.owns(got)
                     del got
                 ms = float(np.median(ts[1:])) * 1e3
+                # the same calls back to back, no host sync in between: read()
+                # returns once its frames are verified, the decode goes on behind it
+                nb2b = 8
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for k in range(nb2b):
+                    fh.seek(((k * 5 + 2) * nf % (img_frames - nf)) * SPF)
+                    got = fh.read(nf * SPF)
+                    del got
+                t_host = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                ms_b2b = (time.perf_counter() - t0) / nb2b * 1e3
                 row["api_read"] = {"call": "fh.read({} * 32000) at changing offsets, output allocated by the reader".format(nf),
                                    "ms_median": round(ms, 3), "output_in_arena": bool(inside),
                                    "GBps": round(nf * (FRAME_NBYTES + PAYLOAD_NBYTES * 16) / ms / 1e6, 1),
                                    "frac": round(nf * (FRAME_NBYTES + PAYLOAD_NBYTES * 16) / ms / 1e6 / HBM_PEAK_GBS, 4),
-                                   "timing": "host wall clock incl. scan, index, allocation and the verification sync"}
+                                   "timing": "host wall clock incl. scan, index, allocation and the verification sync",
+                                   "back_to_back": {"reads": nb2b, "ms_per_read": round(ms_b2b, 3),
+                                                    "host_ms_per_read": round(t_host / nb2b * 1e3, 3),
+                                                    "frac": round(nf * (FRAME_NBYTES + PAYLOAD_NBYTES * 16) / ms_b2b / 1e6 / HBM_PEAK_GBS, 4),
+                                                    "what": "the same read() calls without a host sync in between"}}
         except Exception as exc:
             row["api_read"] = {"error": repr(exc)[:300]}
         res["sizes"].append(row)
