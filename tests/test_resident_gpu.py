@@ -156,3 +156,52 @@ def test_file_reader_on_device_image(manifest):
         fs = fb.read_frameset()
         assert bits_equal(fs.data.cpu().numpy(), exp[:20000].reshape(20000, 8, 1))
         assert fb.get_thread_ids() == list(range(8))
+
+
+def test_reads_back_to_back_without_host_syncs(monkeypatch):
+    """read() returns once its frames are verified while the decode goes on
+    behind the returned tensor (`_resolve_checks` fetches the verdict on a side
+    stream): a loop of reads without host syncs, whose results are dropped at
+    once so that the next read's output reuses the same arena block, gives what
+    the same loop gives with a sync after every read; and a damaged frame
+    still raises at the read that holds it."""
+    import torch
+    from baseband_amd import arena, placement, synth, vdif
+    import bb_oracle_np as orc
+    monkeypatch.setattr(placement, 'ARENA_MIN_BYTES', 1 << 20)
+    nframes, nf = 6000, 500
+    image, h0 = synth.random_vdif(99, nframes, payload_nbytes=8000, frame_rate=1000)
+    dev = torch.from_numpy(image.copy()).cuda()
+    starts = [((k * 7 + 1) * nf) % (nframes - nf) for k in range(10)]
+
+    def loop(sync):
+        sums = []
+        with vdif.open(dev, 'rs', sample_rate=32e6) as fh:
+            for f0 in starts:
+                fh.seek(f0 * 32000)
+                got = fh.read(nf * 32000)
+                sums.append((got.double().sum(), got[::4001].clone()))
+                del got
+                if sync:
+                    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return [(float(a), b.cpu().numpy()) for a, b in sums]
+
+    try:
+        fast, slow = loop(False), loop(True)
+        for (a, b), (c, d), f0 in zip(fast, slow, starts):
+            assert a == c and bits_equal(b, d), f0
+        want, _ = orc.vdif_read(image[starts[3] * 8032:(starts[3] + nf) * 8032], frame_rate=1000)
+        assert bits_equal(fast[3][1], want.reshape(-1)[::4001])
+        # a frame whose header is not a header: verify=True raises at that read, not later
+        bad = dev.clone()
+        f_bad = starts[5] + 17
+        bad[f_bad * 8032:f_bad * 8032 + 16] = 0xff
+        with vdif.open(bad, 'rs', sample_rate=32e6, verify=True) as fh:
+            fh.seek(starts[4] * 32000)
+            fh.read(10 * 32000)                      # (starts[4] .. +10 does not hold the damage)
+            fh.seek(starts[5] * 32000)
+            with pytest.raises(ValueError):
+                fh.read(nf * 32000)
+    finally:
+        arena.disable()
