@@ -280,13 +280,17 @@ def live_traffic(gib, timeout=150):
             if r.returncode != 0 or not files:
                 raise RuntimeError("rocprofv3 --pmc {} failed (rc {}): {}".format(
                     counter, r.returncode, (r.stderr or '')[-300:]))
-            got = []
+            rows = []
             with open(files[0]) as f:
                 for row in csv.DictReader(f):
                     if 'k_decode' in row['Kernel_Name'] and row['Counter_Name'] == counter:
-                        got.append(float(row['Counter_Value']))
-            if not got:
+                        rows.append((int(float(row.get('Grid_Size') or 0)), float(row['Counter_Value'])))
+            if not rows:
                 raise RuntimeError("no k_decode rows for " + counter)
+            # the headline launches are the ones with the largest grid (the output
+            # arena probes a new step with short launches of the same kernel)
+            top = max(g for g, _ in rows)
+            got = [v for g, v in rows if g == top]
             vals[counter] = sum(got) / len(got) * 1024.0            # counters are in KiB
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -1086,6 +1090,11 @@ def main():
     if traffic_detail and traffic_detail.get("hbm_bytes_per_launch"):
         traffic = traffic_detail["hbm_bytes_per_launch"]
         traffic_detail["traffic_over_algorithmic"] = round(traffic / alg_bytes, 4)
+        if traffic < 0.98 * alg_bytes:
+            # fewer bytes than the kernel must move: the counter rows are not the
+            # headline launches' (say so rather than report an impossible figure)
+            traffic_detail["rejected"] = "counters below the algorithmic bytes: {:.4g} B".format(traffic)
+            traffic = None
 
     line = {
         "metric": "decoded Msamples/s, VDIF 2-bit 1-thread (scan + index + decode, input resident in HBM)",
