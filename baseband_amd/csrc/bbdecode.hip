@@ -303,11 +303,17 @@ void launch_flat(int bps, int coder, int om, bool nt, dim3 grid, hipStream_t st,
 
 // the byte table kernel with 16-byte loads staged through LDS: contiguous 2-bit
 // output (the headline kernel; k_lds.h)
+thread_local bool t_arena_probe = false;        // set around the launches of arena_probe (bb_arena.inc)
+
 template <int BPS>
 void launch_flat_lds(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
     with_nt(nt, [&](auto NT) {
-        hipLaunchKernelGGL((k_decode_flat_lds<BPS, decltype(NT)::value, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        constexpr bool N = decltype(NT)::value;
+        if (BPS == 2 && t_arena_probe)
+            hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 1>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_decode_flat_lds<BPS, N, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
     });
 }
 

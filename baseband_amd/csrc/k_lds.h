@@ -32,7 +32,10 @@
 // dword (ds_read_b32, consecutive lanes consecutive dwords), converted by cast
 // (LV = BB_LV_INT8) or through the 256-entry level table (BB_LV_LDS).  These
 // payloads read 20 % of their traffic, not 6 %: 16-byte loads matter more.
-template <int BPS, bool NT, int NW, int MAXT, int LV = BB_LV_REG>
+// TAG only names an instantiation: the output arena probes new memory with
+// launches of TAG 1, so that a profile's per-kernel statistics of the decode
+// launches proper (TAG 0) are not averaged with the probes' short ones.
+template <int BPS, bool NT, int NW, int MAXT, int LV = BB_LV_REG, int TAG = 0>
 __global__ __launch_bounds__(NW * BB_WAVE)
 void k_decode_flat_lds(bb_flat_args a)
 {
