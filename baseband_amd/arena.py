@@ -9,11 +9,18 @@ allocator on top.  Tensors come from `Arena.empty()`; they alias arena memory
 through ``__cuda_array_interface__`` and give their block back when the last
 view of them dies.  `trim()` returns unused physical memory to the device.
 
-Blocks are not stream-tracked: a block is reusable as soon as its tensor is
-garbage collected.  The readers of this package launch on torch's current
-stream, so a program that stays on one stream needs no care.
+Streams: a block goes back to the arena when the last tensor viewing it is
+garbage collected -- at once, without waiting for the work queued on it (the
+readers return before their decode has finished).  Reuse on the SAME stream is
+ordered by the stream itself; when memory of a freed block is handed out on
+ANOTHER stream, that stream is first made to wait (``wait_event``, no host
+sync) for everything that had been queued, at the time of the free, on the
+stream the block was allocated on.  As with torch's own allocator, a tensor
+that is USED on a stream other than the one it was allocated on is the
+caller's to order.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -25,16 +32,20 @@ from ._lib import lib, check
 class _Block:
     """Owner of one arena block; torch keeps it alive through the array
     interface and drops it with the last tensor that views the block."""
-    __slots__ = ('arena', 'ptr', '__cuda_array_interface__', '__weakref__')
+    __slots__ = ('arena', 'ptr', 'nbytes', 'stream', '__cuda_array_interface__', '__weakref__')
 
-    def __init__(self, arena, ptr, shape, typestr):
-        self.arena, self.ptr = arena, ptr
+    def __init__(self, arena, ptr, nbytes, shape, typestr, stream):
+        self.arena, self.ptr, self.nbytes, self.stream = arena, ptr, nbytes, stream
         self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (ptr, False),
                                          'version': 2, 'strides': None}
 
     def __del__(self):
         arena = self.arena
         if arena is not None and arena._handle:
+            try:
+                arena._note_free(self)
+            except Exception:           # interpreter shutdown: torch may be half gone
+                pass
             lib.bb_arena_free(arena._handle, C.c_void_p(self.ptr))
 
 
@@ -58,6 +69,30 @@ class Arena:
         self._handle = h
         st = self.stats()
         self._range = (st['base'], st['base'] + st['capacity'])
+        self._granule = int(st['chunk_bytes'])
+        self._freed = []            # [(lo, hi, event, stream)] of blocks freed with work possibly in flight
+        self._lock = threading.Lock()
+
+    def _note_free(self, block):
+        """Remember what was queued on the block's stream when it was freed."""
+        ev = torch.cuda.Event()
+        ev.record(block.stream)
+        hi = block.ptr + -(-block.nbytes // self._granule) * self._granule
+        with self._lock:
+            if len(self._freed) >= 64:
+                self._freed = [f for f in self._freed if not f[2].query()]
+            self._freed.append((block.ptr, hi, ev, block.stream))
+
+    def _order_reuse(self, lo, hi, stream):
+        """Memory [lo, hi) is about to be used on `stream`: wait there for the
+        work that was queued on OTHER streams when blocks inside it were freed."""
+        with self._lock:
+            hits = [f for f in self._freed if f[0] < hi and lo < f[1]]
+            if hits:        # (an entry only partly covered stays: the rest of it may go to another stream)
+                self._freed = [f for f in self._freed if not (lo <= f[0] and f[1] <= hi)]
+        for flo, fhi, ev, fstream in hits:
+            if fstream != stream:
+                stream.wait_event(ev)
 
     def empty(self, shape, dtype=torch.float32):
         """Uninitialised tensor of `shape` in arena memory, or None when
@@ -79,7 +114,10 @@ class Arena:
         if rc == _lib.BB_ERANGE or not p.value:
             return None
         check(rc, 'bb_arena_alloc')
-        block = _Block(self, p.value, (n,), _TYPESTR[base])
+        stream = torch.cuda.current_stream(self.device)
+        nbytes = n * item
+        self._order_reuse(p.value, p.value + -(-nbytes // self._granule) * self._granule, stream)
+        block = _Block(self, p.value, nbytes, (n,), _TYPESTR[base], stream)
         t = torch.as_tensor(block, device=self.device)
         if cplx:
             t = torch.view_as_complex(t.view(-1, 2))

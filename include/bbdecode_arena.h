@@ -29,8 +29,10 @@
  *
  * Not stream-ordered: bb_arena_free makes the block available to the next
  * bb_arena_alloc at once; the caller must have ordered its work on the block
- * before freeing (the Python host frees when the last tensor view dies; it
- * launches everything on torch's current stream).  Thread safe.
+ * before freeing or before using the next block (the Python host frees when the
+ * last tensor view dies and, when freed memory is handed out on another stream
+ * than the one it was used on, makes that stream wait for an event recorded at
+ * the free: baseband_amd/arena.py).  Thread safe.
  */
 #ifndef BBDECODE_ARENA_H
 #define BBDECODE_ARENA_H

@@ -254,3 +254,39 @@ def test_large_read_lifecycle_through_the_default_arena(tmp_path, monkeypatch):
         assert free1 >= free0 - (2 << 30), (free0, free1)
     finally:
         arena.disable()
+
+
+def test_blocks_reused_on_another_stream_wait_for_the_work_left_behind():
+    """A block freed while work is still queued on it (the readers return
+    before their decode is done) and handed out again on ANOTHER stream: that
+    stream is made to wait for what had been queued at the free, so the new
+    owner's writes land after the old owner's."""
+    import torch
+    from baseband_amd import arena
+    ar = arena.Arena(4 << 30)
+    try:
+        n = (512 << 20) // 4
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        big = torch.empty(256 << 20, dtype=torch.float32, device='cuda')
+        for rep in range(5):
+            with torch.cuda.stream(s1):
+                a = ar.empty(n)
+                p = a.data_ptr()
+                for _ in range(20):                 # a long queue of work, then writes into the block
+                    big.mul_(1.0001)
+                a.fill_(1.0)
+                del a                               # freed at once, the fills are still queued
+            with torch.cuda.stream(s2):
+                b = ar.empty(n)
+                assert b.data_ptr() == p            # first fit: the same memory
+                b.fill_(2.0)
+            torch.cuda.synchronize()
+            assert float(b.min()) == 2.0 and float(b.max()) == 2.0, rep
+            del b
+        # same stream: no events needed, and the bookkeeping stays bounded
+        for _ in range(200):
+            t = ar.empty(n)
+            del t
+        assert len(ar._freed) <= 65
+    finally:
+        ar.close()
