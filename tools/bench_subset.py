@@ -12,7 +12,9 @@ kernels.init()
 dev = torch.device('cuda')
 nbytes = 4 << 30
 buf = torch.randint(0, 256, (nbytes + 4096,), dtype=torch.uint8, device=dev)
-out = torch.empty(17 << 30, dtype=torch.float32, device=dev)
+from baseband_amd import arena
+ar = arena.Arena(120 << 30)
+out = ar.empty(17 << 30)                  # (arena memory: what the readers allocate from)
 # Mark 5B 16 channels 2 bit
 nfr = nbytes // 10016
 src = torch.arange(nfr, device=dev, dtype=torch.int64) * 10016 + 16
