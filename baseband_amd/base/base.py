@@ -807,7 +807,7 @@ class GPUStreamReaderBase:
         """Forget the verification state of windows that were processed for a
         read that did not complete (or a read-ahead that was abandoned): the
         next read starts clean -- host counters AND the device counter."""
-        self._nmissing, self._checked = 0, False
+        self._nmissing, self._checked, self._check_recs = 0, False, 0
         if self._nbad is not None:
             self._nbad.zero_()
 
@@ -993,9 +993,11 @@ class GPUStreamReaderBase:
         if self._check_event is None:
             self._check_event = torch.cuda.Event()
         self._check_event.record()
+        self._check_recs += int(nrecs)
         self._nmissing += int(missing)
         self._checked = True
 
+    _check_recs = 0         # scan records queued for verification since the last verdict
     _check_event = None     # recorded behind the last verification launch
     _check_stream = None    # side stream the verdict is fetched on
     _nbad_host = None       # pinned int32[1]
@@ -1014,15 +1016,21 @@ class GPUStreamReaderBase:
         # decode: 0.12 instead of 0.8 ms for 2^15 cfg2 frames, and the host side
         # of the next read() overlaps this one's decode.  The result is ordered on
         # the caller's stream as any torch result is.
-        if self._check_stream is None:
-            self._check_stream = torch.cuda.Stream(device=self._nbad.device)
-            self._nbad_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
-        side = self._check_stream
-        side.wait_event(self._check_event)
-        with torch.cuda.stream(side):
-            self._nbad_host.copy_(self._nbad, non_blocking=True)
-        side.synchronize()
-        nbad = int(self._nbad_host[0]) + self._nmissing
+        # (Small reads -- a few frames, microseconds of decode -- take the plain
+        # readback on the current stream: the side stream's bookkeeping costs 15 us.)
+        nrecs, self._check_recs = self._check_recs, 0
+        if nrecs < 2048:
+            nbad = int(self._nbad.item()) + self._nmissing
+        else:
+            if self._check_stream is None:
+                self._check_stream = torch.cuda.Stream(device=self._nbad.device)
+                self._nbad_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            side = self._check_stream
+            side.wait_event(self._check_event)
+            with torch.cuda.stream(side):
+                self._nbad_host.copy_(self._nbad, non_blocking=True)
+            side.synchronize()
+            nbad = int(self._nbad_host[0]) + self._nmissing
         self._nmissing = 0
         if nbad:
             self._nbad.zero_()
