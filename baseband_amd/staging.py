@@ -9,6 +9,7 @@ Ordering is by events only; nothing blocks the device.
 """
 import mmap
 import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -196,6 +197,26 @@ class WindowPipeline:
                 ev.synchronize()
 
 
+_SMALL_BYTES = 2 << 20
+_small_ring = []            # [[pinned tensor, event of the copy that last read it]]
+_small_next = 0
+_small_lock = threading.Lock()
+
+
+def _small_slot():
+    """The next pinned scratch buffer of the ring, free to be written (the
+    copy that read it last has finished)."""
+    global _small_next
+    if not _small_ring:
+        for _ in range(4):
+            _small_ring.append([torch.empty(_SMALL_BYTES + 256, dtype=torch.uint8, pin_memory=True), None])
+    slot = _small_ring[_small_next]
+    _small_next = (_small_next + 1) % len(_small_ring)
+    if slot[1] is not None:
+        slot[1].synchronize()
+    return slot
+
+
 def upload(image, device='cuda', chunk_bytes=64 << 20, join=True):
     """Whole host image -> one device tensor (with 256 bytes of slack), moved
     in pinned chunks on a side stream while the next chunk is being copied by
@@ -206,17 +227,26 @@ def upload(image, device='cuda', chunk_bytes=64 << 20, join=True):
     device = torch.device(device)
     n = len(image)
     dev = empty_output((n + 256,), dtype=torch.uint8, device=device)
-    dev[n:] = 0
-    if n <= (2 << 20):
-        # small windows (random access): one plain copy beats pinning buffers
-        if n:
-            # (a copy: the mapping is read-only, which torch does not accept)
-            dev[:n].copy_(torch.from_numpy(np.array(image[:n], dtype=np.uint8, copy=True)))
+    if n <= _SMALL_BYTES:
+        # small windows (random access): through one of a few pinned scratch
+        # buffers, zero tail included, with ONE asynchronous copy (a pageable
+        # source makes the copy synchronous: 28 us for two frames; the tail's
+        # own fill was another launch)
+        with _small_lock:
+            slot = _small_slot()
+            host = slot[0].numpy()
+            if n:
+                host[:n] = image[:n]
+            host[n:n + 256] = 0
+            dev.copy_(slot[0][:n + 256], non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(torch.cuda.current_stream(device))
         if not join:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(device))
             return dev, ev
         return dev
+    dev[n:] = 0
     stream = torch.cuda.Stream(device=device)
     # `dev` may be a recycled block with work of its previous owner still
     # queued on the compute stream (and the tail was just zeroed there)
