@@ -52,6 +52,7 @@ TUNE_LUT_TILES = 24
 TUNE_M4_TILES = 26
 TUNE_XPOSE_TC = 27
 TUNE_XPOSE_MIN_NC = 28
+TUNE_ENCODE_RUNS = 30
 # include/bbdecode_exp.h (experiment build only: bb_tune answers BB_EINVAL otherwise)
 TUNE_FLAT_VARIANT = 0
 TUNE_NT_STORES = 1

@@ -167,6 +167,7 @@ std::atomic<int> g_tune_xpose_rows{0};   // k_decode_i8_xpose: output rows per t
 #if BB_EXP
 std::atomic<int> g_tune_flat8_lds{0};    // experiment: 1 = contiguous 8-bit output through k_decode_flat_lds<8>
 #endif
+std::atomic<int> g_tune_encode_runs{0};  // k_encode_flat: 256-quad runs per wave and step (1 or 2); 0 = by sample width
 std::atomic<int> g_tune_xpose_tc{0};     // k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; 0 = by channel count
 std::atomic<int> g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a selection: from this many channels on
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
@@ -301,6 +302,21 @@ void launch_flat(int bps, int coder, int om, bool nt, dim3 grid, hipStream_t st,
     });
 }
 
+// (direct arithmetic: 2-bit only; two runs per wave: built for 4-bit codes, and for
+// every width in the experiment build)
+template <int C, int B>
+void launch_encode_flat(bool direct, int eruns, dim3 grid, dim3 block, hipStream_t st,
+                               const float *d_in, uint64_t nquad, uint8_t *o)
+{
+    if constexpr (B == 2) {
+        if (direct) { hipLaunchKernelGGL((k_encode_flat<C, 2, true>), grid, block, 0, st, d_in, nquad, o); return; }
+    }
+    if constexpr (B == 4 || BB_EXP) {
+        if (eruns == 2) { hipLaunchKernelGGL((k_encode_flat<C, B, false, 2>), grid, block, 0, st, d_in, nquad, o); return; }
+    }
+    hipLaunchKernelGGL((k_encode_flat<C, B, false>), grid, block, 0, st, d_in, nquad, o);
+}
+
 // the byte table kernel with 16-byte loads staged through LDS: contiguous 2-bit
 // output (the headline kernel; k_lds.h)
 thread_local bool t_arena_probe = false;        // set around the launches of arena_probe (bb_arena.inc)
@@ -417,6 +433,7 @@ int bb_tune(int knob, int value)
             g_tune_select_bytes = value; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
         case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : value == 128 ? 128 : 0; return BB_OK;
+        case BB_TUNE_ENCODE_RUNS: g_tune_encode_runs = (value == 1 || value == 2) ? value : 0; return BB_OK;
         case BB_TUNE_XPOSE_TC: g_tune_xpose_tc = (value == 64 || value == 32 || value == 16 || value == 8) ? value : 0; return BB_OK;
         case BB_TUNE_XPOSE_MIN_NC: g_tune_xpose_min_nc = value < 2 ? 2 : value; return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
@@ -1392,7 +1409,11 @@ int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
     if (out_nbytes < nelem * (size_t)bps / 8) return BB_ERANGE;
     { const int rc_ = ensure_init(); if (rc_) return rc_; }
     const uint64_t nquad = nelem / 4;
-    uint64_t blocks = (nquad / 256 + 3) / 4;              // one 256-quad run per wave
+    // 4-bit codes (16-bit stores) gain from two runs per wave, 5.57 -> 6.05 TB/s at
+    // 32 GiB in; every other width loses 1-8 % (profiles/r03zj_exp_encode_runs.log)
+    const int eknob = g_tune_encode_runs.load();
+    const int eruns = eknob ? eknob : (bps == 4 ? 2 : 1);
+    uint64_t blocks = (nquad / 256 / eruns + 3) / 4 + 1;  // RUNS 256-quad runs per wave
     // one run per wave and as many workgroups as that takes: the encoder is a
     // streaming read without a software pipeline, the dispatcher overlaps it
     // best (profiles/r01g_exp_encode_grid.log: 4.7 -> 5.6 TB/s against 4096)
@@ -1404,8 +1425,7 @@ int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
     hipStream_t st = (hipStream_t)stream;
     uint8_t *o = (uint8_t *)d_out;
     const bool direct = g_tune_encode_direct.load() != 0;
-#define BB_E(C, B) do { if (direct && (B) == 2) hipLaunchKernelGGL((k_encode_flat<C, B, true>), grid, block, 0, st, d_in, nquad, o); \
-                        else hipLaunchKernelGGL((k_encode_flat<C, B, false>), grid, block, 0, st, d_in, nquad, o); } while (0)
+#define BB_E(C, B) launch_encode_flat<C, B>(direct, eruns, grid, block, st, d_in, nquad, o)
     if (coder == BB_CODER_VDIF) {
         switch (bps) { case 1: BB_E(BB_CODER_VDIF, 1); break; case 2: BB_E(BB_CODER_VDIF, 2); break;
                        case 4: BB_E(BB_CODER_VDIF, 4); break; default: BB_E(BB_CODER_VDIF, 8); break; }

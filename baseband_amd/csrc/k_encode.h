@@ -101,7 +101,9 @@ __device__ __forceinline__ uint32_t bb_encode_quad(const bb_f4 v)
 // lane are transposed across the wave (ds_bpermute) so that the run leaves as
 // ONE coalesced 256-byte store.  Quads past the last whole run go through the
 // per-quad tail at the end.
-template <int CODER, int BPS, bool DIRECT>
+// RUNS: runs a wave takes per step (its loads are all in flight before the
+// first compare: 4 x RUNS float4 per lane).
+template <int CODER, int BPS, bool DIRECT, int RUNS = 1>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out)
 {
@@ -110,14 +112,23 @@ void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out)
     const uint64_t nrun = nquad >> 8;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x) >> 6;
     const uint64_t nwave = ((uint64_t)gridDim.x * BB_BLOCK) >> 6;
-    for (uint64_t r = wave0; r < nrun; r += nwave) {
-        const uint64_t q0 = (r << 8) + lane;
-        bb_f4 v[4];
+    for (uint64_t rr = wave0 * RUNS; rr < nrun; rr += nwave * RUNS) {
+      bb_f4 vv[RUNS][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(in4 + q0 + 64 * j);
+      for (int h = 0; h < RUNS; ++h) {
+          const uint64_t q0 = ((rr + h) << 8) + lane;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+              vv[h][j] = (rr + h < nrun) ? __builtin_nontemporal_load(in4 + q0 + 64 * j) : bb_f4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int h = 0; h < RUNS; ++h) {
+        const uint64_t r = rr + h;
+        if (r >= nrun) break;                                   // (wave-uniform)
+        const uint64_t q0 = (r << 8) + lane;
         uint32_t bits[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bits[j] = bb_encode_quad<CODER, BPS, DIRECT>(v[j]);
+        for (int j = 0; j < 4; ++j) bits[j] = bb_encode_quad<CODER, BPS, DIRECT>(vv[h][j]);
         if (BPS == 8) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) reinterpret_cast<uint32_t *>(out)[q0 + 64 * j] = bits[j];
@@ -142,6 +153,7 @@ void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out)
                 if (!(lane & 1)) out[(q0 + 64 * j) >> 1] = (uint8_t)(bits[j] | (other << 4));
             }
         }
+      }
     }
     // tail: fewer than 256 quads, first workgroup only (whole waves for the shuffle)
     if (blockIdx.x == 0) {
