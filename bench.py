@@ -109,6 +109,22 @@ def make_file_image_on_device(nsets, seed, first_set, device, nthread=1, nchan=1
     return img.view(torch.uint8), h0
 
 
+def empty_with_patience(n, dtype, device, tries=12):
+    """``torch.empty`` for the 127.5 GiB output.  The image was allocated just
+    before, and an arena that had to try several candidate steps has released up
+    to 144 GiB a moment ago: memory the driver is still clearing is not
+    allocatable yet (seen with tools/arena_probe3.cpp), so an out-of-memory here
+    is retried for a few seconds before it counts."""
+    for k in range(tries):
+        try:
+            return torch.empty(n, dtype=dtype, device=device)
+        except torch.cuda.OutOfMemoryError:
+            if k == tries - 1:
+                raise
+            torch.cuda.empty_cache()
+            time.sleep(0.5)
+
+
 def image_buffer(nbytes, device):
     """Device memory for a file image, allocated the way the package keeps
     file bytes in HBM (`fh.stage()`, the staged copy of a large read):
@@ -1023,7 +1039,7 @@ def main():
     image, image_memory = image_buffer(nframes * FRAME_NBYTES, device)
     image, h0 = make_file_image_on_device(nframes, 12345 + rank, first_frame, device, into=image)
     pattern, mask = h0.invariant_pattern()
-    out = torch.empty(nframes * SPF, dtype=torch.float32, device=device)
+    out = empty_with_patience(nframes * SPF, torch.float32, device)
     bytes_in = nframes * FRAME_NBYTES
     bytes_out = nframes * SPF * 4
     alg_bytes = bytes_in + bytes_out
