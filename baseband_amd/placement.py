@@ -26,6 +26,7 @@ each, keep the fastest -- is gone: it needed k times the memory and still lost
 when all k draws were slow.
 """
 import os
+import time
 import warnings
 
 import numpy as np
@@ -94,4 +95,13 @@ def empty_output(shape, dtype=torch.float32, device=None):
     except torch.cuda.OutOfMemoryError:
         if not release_unused():
             raise
-        return torch.empty(shape, dtype=dtype, device=device)
+    # memory the arena gave back a moment ago is not allocatable until the
+    # driver has cleared it: a little patience before the error counts
+    for attempt in range(8):
+        try:
+            return torch.empty(shape, dtype=dtype, device=device)
+        except torch.cuda.OutOfMemoryError:
+            if attempt == 7:
+                raise
+            torch.cuda.empty_cache()
+            time.sleep(0.25)
