@@ -642,29 +642,40 @@ def frame_header_streams(header0, times, invalid=None):
     minute, second = np.divmod(rest, 60)
     w3 = ((year % 10) << 28) | (bcd_array(day + 1) << 16) | (bcd_array(hour) << 8) | bcd_array(minute)
     w4 = (bcd_array(second) << 24) | (bcd_array(np.floor(frac_ms + 1e-6).astype(np.int64)) << 12)
-    words = np.empty((n, 5, ntrack), dtype=np.uint32)
-    words[:] = header0.words
-    words[:, 3, :] = w3[:, None].astype(np.uint32)
-    words[:, 4, :] = w4[:, None].astype(np.uint32)            # crc bits zero for now
-    if invalid is not None:
-        bit = np.uint32(1 << _FIELDS['communication_error'][1])
-        words[np.asarray(invalid, bool), 1, :] |= bit
+    # Only words 3 and 4 (the time code) and one flag bit differ from frame to
+    # frame, and they are THE SAME IN EVERY TRACK: their stream words (track t =
+    # bit t) are all ones or zero.  Words 0-2 are transposed once.
+    ones = dtype.type(np.iinfo(dtype).max)
+    base = words2stream(header0.words)[:96]                    # bit 31 of a word comes first
     out = np.empty((n, 160), dtype=dtype)
-    taps = np.array([np.iinfo(dtype).max if b == '1' else 0 for b in '{:b}'.format(0x180f)],
-                    dtype=dtype)
-    for lo in range(0, n, 256):                             # bounded temporaries
-        w = words[lo:lo + 256]
-        # bit 31 of a word comes first in the stream: big-endian bytes, MSB first
-        bits = np.unpackbits(w.astype('>u4').view(np.uint8).reshape(len(w), 5, ntrack, 4), axis=3)
-        bits = np.ascontiguousarray(bits.transpose(0, 1, 3, 2))             # (m, 5, 32, ntrack)
-        # track t is bit t of the stream word: pack the track axis, little endian
-        stream = np.packbits(bits, axis=3, bitorder='little').reshape(len(w), 160, -1)
-        stream = np.ascontiguousarray(stream).view(dtype).reshape(len(w), 160).copy()
-        # CRC-12 of the first 148 stream words of every track at once
-        work = stream.copy()
-        work[:, 148:] = 0
+    out[:, :96] = base
+    shifts = np.arange(31, -1, -1, dtype=np.int64)
+    out[:, 96:128] = ((w3[:, None] >> shifts) & 1).astype(dtype) * ones
+    out[:, 128:160] = ((w4[:, None] >> shifts) & 1).astype(dtype) * ones      # (crc bits zero for now)
+    if invalid is not None:
+        pos = 32 + 31 - _FIELDS['communication_error'][1]
+        out[np.asarray(invalid, bool), pos] = ones
+    # CRC-12 of the first 148 stream words of every track: polynomial division
+    # without initial value is linear over GF(2), so crc bit k of every track is
+    # the XOR of the stream words whose unit message has that bit in its remainder
+    for k, idx in enumerate(_crc12_taps()):
+        out[:, 148 + k] = np.bitwise_xor.reduce(out[:, idx], axis=1)
+    return out
+
+
+_CRC12_TAPS = None
+
+
+def _crc12_taps():
+    """For each of the 12 CRC bits: the positions i < 148 whose unit message
+    e_i leaves that bit set in the remainder of the division by 0x180f (the
+    bit-serial division `crc12_stream` does, run once on the identity)."""
+    global _CRC12_TAPS
+    if _CRC12_TAPS is None:
+        taps = np.array([b == '1' for b in '{:b}'.format(0x180f)], dtype=bool)
+        work = np.zeros((148, 160), dtype=bool)
+        work[np.arange(148), np.arange(148)] = True
         for i in range(148):
             work[:, i:i + 13] ^= work[:, i:i + 1] & taps
-        stream[:, 148:] = work[:, 148:]
-        out[lo:lo + 256] = stream
-    return out
+        _CRC12_TAPS = [np.nonzero(work[:, 148 + k])[0] for k in range(12)]
+    return _CRC12_TAPS
