@@ -598,7 +598,7 @@ class GPUStreamReaderBase:
         if not keep or n == 0:
             return None
         try:
-            self._sink = empty_output((n + 256,), dtype=torch.uint8)
+            self._sink = empty_output((n + 256,), dtype=torch.uint8, create=False)
         except torch.cuda.OutOfMemoryError:
             # no room for a copy of the file next to the caller's tensors:
             # rotate two window buffers as before

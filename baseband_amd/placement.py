@@ -49,14 +49,14 @@ ARENA_MAX_BYTES = 64 << 30
 _failed = False                 # arena creation failed once: do not try again in this process
 
 
-def _arena_for(device):
-    """The process-wide arena (created now if there is none yet); None when
-    switched off, on another device, or not available."""
+def _arena_for(device, create=True):
+    """The process-wide arena (created now if there is none yet and `create`
+    allows); None when switched off, on another device, or not available."""
     global _failed
     ar = _arena.default()
     if ar is not None:
         return ar if ar.device == device else None
-    if _failed or os.environ.get('BB_ARENA', '1') in ('0', 'off', 'no'):
+    if not create or _failed or os.environ.get('BB_ARENA', '1') in ('0', 'off', 'no'):
         return None
     env = os.environ.get('BB_ARENA_GIB')
     try:
@@ -74,10 +74,12 @@ def release_unused():
     return ar.trim() if ar is not None else 0
 
 
-def empty_output(shape, dtype=torch.float32, device=None):
+def empty_output(shape, dtype=torch.float32, device=None, create=True):
     """Uninitialised device tensor like ``torch.empty(shape, dtype=dtype,
     device='cuda')`` for a decode launch to write into: from the arena when the
-    output is large, else from torch's allocator."""
+    output is large, else from torch's allocator.  ``create=False``: only from
+    an arena that exists already (the readers' copies of file bytes: a staged
+    file alone should not make the arena take its first 48 GiB step)."""
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
     if device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
@@ -85,7 +87,7 @@ def empty_output(shape, dtype=torch.float32, device=None):
     item = 8 if dtype == torch.complex64 else torch.empty(0, dtype=dtype).element_size()
     nbytes = int(np.prod(shape, dtype=np.int64)) * item
     if ARENA_MIN_BYTES <= nbytes <= ARENA_MAX_BYTES:
-        ar = _arena_for(device)
+        ar = _arena_for(device, create)
         if ar is not None:
             t = ar.empty(shape, dtype)
             if t is not None:

@@ -226,7 +226,7 @@ def upload(image, device='cuda', chunk_bytes=64 << 20, join=True):
     (`upload_in_background`)."""
     device = torch.device(device)
     n = len(image)
-    dev = empty_output((n + 256,), dtype=torch.uint8, device=device)
+    dev = empty_output((n + 256,), dtype=torch.uint8, device=device, create=False)
     if n <= _SMALL_BYTES:
         # small windows (random access): through one of a few pinned scratch
         # buffers, zero tail included, with ONE asynchronous copy (a pageable
