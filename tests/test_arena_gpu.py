@@ -154,6 +154,7 @@ def test_readers_take_their_outputs_from_the_arena(manifest, monkeypatch):
     in the process-wide arena (created on first use) and are freed into it;
     smaller ones, and everything when the arena is switched off, are torch
     allocations."""
+    monkeypatch.setenv('BB_ARENA', '1')
     import torch
     import baseband_amd
     from baseband_amd import arena, placement, vdif
@@ -196,6 +197,7 @@ def test_large_read_lifecycle_through_the_default_arena(tmp_path, monkeypatch):
     user gets: the output lives in the arena, whose first step was PROBED; the
     samples are right; deleting the result frees the block; `release_unused`
     gives the memory back to the device; threads may allocate concurrently."""
+    monkeypatch.setenv('BB_ARENA', '1')
     import threading
     import torch
     from baseband_amd import arena, placement, synth, vdif

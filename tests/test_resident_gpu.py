@@ -165,6 +165,7 @@ def test_reads_back_to_back_without_host_syncs(monkeypatch):
     once so that the next read's output reuses the same arena block, gives what
     the same loop gives with a sync after every read; and a damaged frame
     still raises at the read that holds it."""
+    monkeypatch.setenv('BB_ARENA', '1')
     import torch
     from baseband_amd import arena, placement, synth, vdif
     import bb_oracle_np as orc
