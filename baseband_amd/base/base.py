@@ -997,6 +997,23 @@ class GPUStreamReaderBase:
         self._nmissing += int(missing)
         self._checked = True
 
+    def _note_checked(self, nrecs, missing=0):
+        """Book a verification that a fused window call launched itself
+        (kernels.VDIFWindow: the event behind it is recorded by the library)."""
+        self._check_recs += int(nrecs)
+        self._nmissing += int(missing)
+        self._checked = True
+
+    def _verdict_targets(self):
+        """(device counter, raw handle of the event to record behind the
+        verification launch) for a fused window call."""
+        if self._nbad is None:
+            self._nbad = torch.zeros(1, dtype=torch.int32, device='cuda')
+        if self._check_event is None:
+            self._check_event = torch.cuda.Event()
+            self._check_event.record()              # (creates the HIP event: the handle exists from here on)
+        return self._nbad, self._check_event.cuda_event
+
     _check_recs = 0         # scan records queued for verification since the last verdict
     _check_event = None     # recorded behind the last verification launch
     _check_stream = None    # side stream the verdict is fetched on

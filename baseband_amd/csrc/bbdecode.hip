@@ -902,6 +902,31 @@ static int select_geometry(const bb_decode_params *p, int nwithin, select_geom *
     return BB_OK;
 }
 
+int bb_vdif_read_window(const void *d_buf, size_t nbytes,
+                        const bb_vdif_scan_params *scan, size_t nframes,
+                        const int16_t *d_thread_slot, size_t nsets,
+                        const bb_decode_params *dec,
+                        const int32_t *d_within, int nwithin,
+                        bb_frame_rec *d_recs, int64_t *d_src,
+                        float *d_out, size_t out_elems,
+                        uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad,
+                        void *verified, void *stream)
+{
+    if (!scan || !dec) return BB_EINVAL;
+    int rc = bb_vdif_scan(d_buf, nbytes, scan, d_recs, nframes, stream);
+    if (rc != BB_OK) return rc;
+    rc = bb_build_index(d_recs, nframes, d_thread_slot, dec->nslot, d_src, nsets, stream);
+    if (rc != BB_OK) return rc;
+    if (d_nbad) {
+        rc = bb_verify_records(d_recs, nframes, 0, recs_per_index, nstrict, d_nbad, stream);
+        if (rc != BB_OK) return rc;
+    }
+    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
+    if (nwithin > 0)
+        return bb_decode_frames_select(d_buf, nbytes, d_src, nsets, dec, d_within, nwithin, d_out, out_elems, stream);
+    return bb_decode_frames(d_buf, nbytes, d_src, nsets, dec, d_out, out_elems, stream);
+}
+
 int bb_decode_frames_select_check(const bb_decode_params *p, int nwithin)
 {
     select_geom g;

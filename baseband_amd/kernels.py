@@ -132,6 +132,51 @@ def _vdif_params(frame_nbytes, header_nbytes, pattern, mask, ref_seconds,
     return p
 
 
+class VDIFWindow:
+    """One window of a VDIF stream read -- scan, index, verification, decode --
+    as ONE library call (bb_vdif_read_window) with argument blocks that are
+    built once per reader: a third of the host time of a small read() went
+    into marshalling the same constants for four calls."""
+    __slots__ = ('scan', 'dec', 'recs', 'src', 'fill_value')
+
+    def __init__(self, frame_nbytes, header_nbytes, pattern, mask, ref_seconds, frame_rate,
+                 payload_nbytes, coder, bps, chunk, nslot, complex_data, fill_value):
+        self.scan = _vdif_params(frame_nbytes, header_nbytes, pattern, mask, ref_seconds, 0, frame_rate)
+        p = self.dec = _lib.DecodeParams()
+        p.coder, p.bps, p.chunk, p.nslot = coder, bps, chunk, nslot
+        p.payload_nbytes = payload_nbytes
+        p.complex_data = int(bool(complex_data))
+        self.set_fill(fill_value)
+        self.recs = self.src = None
+
+    def set_fill(self, fill_value):
+        fv = complex(fill_value)
+        self.dec.fill_re, self.dec.fill_im = fv.real, fv.imag
+        self.fill_value = fill_value
+
+    def run(self, dbuf, ref_frame_nr, nframes, thread_slot, nsets, within, out,
+            recs_per_index, nstrict, nbad, verified):
+        """Launch the window on torch's current stream.  `out`: flat float32
+        device tensor; `nbad`: int32[1] device counter, or None for no
+        verification; `verified`: raw handle of the event to record behind the
+        verification launch, or None."""
+        dev = dbuf.device
+        self.scan.ref_frame_nr = ref_frame_nr
+        if self.recs is None or self.recs.shape[0] < nframes or self.recs.device != dev:
+            self.recs = torch.empty((max(nframes, 64), 4), dtype=torch.int32, device=dev)
+        nsrc = nsets * self.dec.nslot
+        if self.src is None or self.src.numel() < nsrc or self.src.device != dev:
+            self.src = torch.empty(max(nsrc, 64), dtype=torch.int64, device=dev)
+        tgt = _Target(out, out.numel(), dev)
+        nsel = within.numel() if within is not None else 0
+        check(lib.bb_vdif_read_window(
+            _ptr(dbuf), dbuf.numel(), C.byref(self.scan), nframes, _ptr(thread_slot), nsets,
+            C.byref(self.dec), _ptr(within), nsel, _ptr(self.recs), _ptr(self.src),
+            _ptr(tgt.use), tgt.use.numel(), recs_per_index, nstrict, _ptr(nbad),
+            C.c_void_p(verified) if verified else C.c_void_p(0), _stream(dbuf)), 'bb_vdif_read_window')
+        tgt.done()
+
+
 def vdif_locate(dbuf, nbytes, frame_nbytes, header_nbytes, pattern, mask):
     """Byte-granular header search -> sorted int64 device tensor of frame
     offsets (corruption-tolerant discovery)."""

@@ -96,19 +96,24 @@ _PINNED_KEEP = 512 << 20
 _pinned_pool = []           # [(capacity, tensor)]
 
 
+_pinned_lock = threading.Lock()     # (readers on several threads, the background uploader)
+
+
 def _pinned_take(cap):
-    for i, (c, t) in enumerate(_pinned_pool):
-        if c >= cap and c <= 2 * cap:
-            del _pinned_pool[i]
-            return t
+    with _pinned_lock:
+        for i, (c, t) in enumerate(_pinned_pool):
+            if c >= cap and c <= 2 * cap:
+                del _pinned_pool[i]
+                return t
     return torch.empty(cap, dtype=torch.uint8, pin_memory=True)
 
 
 def _pinned_give(t):
     if t is None:
         return
-    if sum(c for c, _ in _pinned_pool) + t.numel() <= _PINNED_KEEP:
-        _pinned_pool.append((t.numel(), t))
+    with _pinned_lock:
+        if sum(c for c, _ in _pinned_pool) + t.numel() <= _PINNED_KEEP:
+            _pinned_pool.append((t.numel(), t))
 
 
 def release_pinned():
@@ -251,8 +256,12 @@ def upload(image, device='cuda', chunk_bytes=64 << 20, join=True):
     # `dev` may be a recycled block with work of its previous owner still
     # queued on the compute stream (and the tail was just zeroed there)
     stream.wait_stream(torch.cuda.current_stream(device))
-    pinned = [torch.empty(min(chunk_bytes, max(n, 1)), dtype=torch.uint8, pin_memory=True)
-              for _ in range(2)]
+    # (from the pool of pinned buffers kept between readers: pinning 2 x 64 MiB
+    # costs 6-25 ms, which a loop of small reads paid once per reader while its
+    # read-ahead windows grew)
+    cap = chunk_bytes               # (one size: every later window finds it in the pool)
+    n_second = 0 if n <= chunk_bytes else cap
+    pinned = [_pinned_take(cap), _pinned_take(n_second) if n_second else None]
     events = [None, None]
     for i, lo in enumerate(range(0, n, chunk_bytes)):
         hi = min(n, lo + chunk_bytes)
@@ -270,6 +279,8 @@ def upload(image, device='cuda', chunk_bytes=64 << 20, join=True):
     for ev in events:
         if ev is not None:
             ev.synchronize()
+    for t in pinned:
+        _pinned_give(t)
     if not join:
         done = torch.cuda.Event()
         done.record(stream)

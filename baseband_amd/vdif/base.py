@@ -367,32 +367,35 @@ class VDIFStreamReader(GPUStreamReaderBase):
             data = data[(slice(None),) + sub]
         return data
 
+    _window = None          # kernels.VDIFWindow: argument blocks of the fused window call
+
     def _process_window(self, dbuf, first_set, last_set, out_flat):
-        """scan -> index -> decode for frame sets [first_set, last_set)."""
+        """scan -> index -> verification -> decode for frame sets [first_set,
+        last_set): one library call (bb_vdif_read_window)."""
         h0 = self.header0
         nsets = last_set - first_set
         nthread_file = len(self._file_threads)
         nframes = min(nsets * nthread_file, dbuf.numel() // self._frame_nbytes)
-        recs = kernels.vdif_scan(
-            dbuf, nframes, self._frame_nbytes, h0.nbytes, self._pattern,
-            self._mask, h0['seconds'], h0['frame_nr'] + first_set,
-            self._frame_rate)
         if self._thread_slot is None:
             self._thread_slot = kernels.thread_slot_map(self._thread_ids,
                                                         dbuf.device)
-        nslot = len(self._thread_ids)
-        src = kernels.build_index(recs, nsets, nslot, self._thread_slot)
-        chunk = h0.nchan * (2 if self.complex_data else 1)
+        w = self._window
+        if w is None:
+            w = self._window = kernels.VDIFWindow(
+                self._frame_nbytes, h0.nbytes, self._pattern, self._mask, h0['seconds'], self._frame_rate,
+                h0.payload_nbytes, self._coder, self.bps, h0.nchan * (2 if self.complex_data else 1),
+                len(self._thread_ids), self.complex_data, self.fill_value)
+        if w.fill_value != self.fill_value:
+            w.set_fill(self.fill_value)
+        nbad = verified = None
         if self.verify:
-            # (queued BEFORE the decode: read() waits for this verdict only,
-            # the decode goes on behind it -- `_resolve_checks`)
-            self._check_window(recs, nframes, nthread_file, nframes,
-                               missing=nsets * nthread_file - nframes)
-        kernels.decode_frames(
-            dbuf, nsets, h0.payload_nbytes, self._coder, self.bps,
-            chunk=chunk, nslot=nslot, src=src, complex_data=self.complex_data,
-            fill_value=self.fill_value, out=out_flat, within=self._within)
-
+            # (the verification is queued BEFORE the decode and an event recorded
+            # behind it: read() waits for this verdict only -- `_resolve_checks`)
+            nbad, verified = self._verdict_targets()
+        w.run(dbuf, h0['frame_nr'] + first_set, nframes, self._thread_slot, nsets, self._within, out_flat,
+              nthread_file, nframes, nbad, verified)
+        if self.verify:
+            self._note_checked(nframes, missing=nsets * nthread_file - nframes)
 
     # -- frame index as a first-class object (multi-GPU sharding, parallel.py)
     def build_index(self, first=0, last=None):

@@ -298,6 +298,32 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
  */
 int bb_decode_frames_select_check(const bb_decode_params *params, int nwithin);
 
+/*
+ * One window of a VDIF stream read in ONE call: bb_vdif_scan over `nframes`
+ * frames at scan->first_offset, bb_build_index for `nsets` frame sets,
+ * bb_verify_records (when d_nbad is given; `nstrict` records checked for their
+ * time index, `recs_per_index` = threads per set in the file), then
+ * bb_decode_frames -- or bb_decode_frames_select when nwithin > 0 -- through
+ * that index.  The body of the reference's read loop for the frames of a
+ * request (base/base.py:957-967 with 1083-1125; vdif/base.py:386-390,464-490;
+ * vdif/frame.py:176-243,402-434).  Same results and error codes as the four
+ * calls; what it saves is host time (three library entries and their argument
+ * marshalling per read() of a binding: 25 us of 65 through ctypes).
+ * `verified`: optional hipEvent_t, recorded on `stream` behind the verification
+ * launch and AHEAD of the decode, so that a host that only needs the verdict
+ * does not wait for the decode.  d_recs (nframes records) and d_src
+ * (nsets * dec->nslot entries) are scratch the caller provides.
+ */
+int bb_vdif_read_window(const void *d_buf, size_t nbytes,
+                        const bb_vdif_scan_params *scan, size_t nframes,
+                        const int16_t *d_thread_slot, size_t nsets,
+                        const bb_decode_params *dec,
+                        const int32_t *d_within, int nwithin,
+                        bb_frame_rec *d_recs, int64_t *d_src,
+                        float *d_out, size_t out_elems,
+                        uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad,
+                        void *verified, void *stream);
+
 /* ---- Mark 4 ------------------------------------------------------------ */
 
 /*

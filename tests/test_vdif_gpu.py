@@ -330,12 +330,12 @@ def test_read_into_device_tensor_is_decoded_in_place(manifest):
     from baseband_amd import vdif, kernels
     exp = load_expected('sample_vdif')[:, :, 0]
     calls = []
-    orig = kernels.decode_frames
+    orig = kernels.VDIFWindow.run
 
-    def spy(*a, **k):
-        calls.append(k.get('out'))
-        return orig(*a, **k)
-    kernels.decode_frames = spy
+    def spy(self, dbuf, ref, nframes, slots, nsets, within, out, *a, **k):
+        calls.append(out)
+        return orig(self, dbuf, ref, nframes, slots, nsets, within, out, *a, **k)
+    kernels.VDIFWindow.run = spy
     try:
         with vdif.open(golden_path('samples/sample.vdif'), 'rs') as fh:
             out = torch.full((40000, 8), -1., dtype=torch.float32, device='cuda')
@@ -361,7 +361,7 @@ def test_read_into_device_tensor_is_decoded_in_place(manifest):
             fh.read(out=sub)
             assert bits_equal(sub.cpu().numpy(), exp[:20000][:, [1, 3]])
     finally:
-        kernels.decode_frames = orig
+        kernels.VDIFWindow.run = orig
 
 
 def test_vdif_frame_from_mark5b_frame_matches_reference():
