@@ -577,3 +577,49 @@ def test_8bit_staged_kernel_geometries(coder):
     finally:
         kernels.tune(_lib.TUNE_BLOCKS, 0)
         kernels.tune(_lib.TUNE_FLAT8_LDS, 0)
+
+
+def test_window_call_equals_the_four_calls():
+    """bb_vdif_read_window = bb_vdif_scan + bb_build_index + bb_verify_records +
+    bb_decode_frames(_select) in one entry: same samples, same verification
+    count, for a file with shuffled threads, invalid and corrupt frames, a
+    thread subset, a channel selection, an unaligned output slice, and no
+    verification at all."""
+    torch = _torch()
+    from baseband_amd import kernels, synth, _lib
+    image, h0 = synth.random_vdif(3, 9, nthread=4, nchan=2, bps=2, payload_nbytes=64, frame_rate=4,
+                                  thread_order=[2, 0, 3, 1], invalid=[(1, 2), (5, 0)])
+    image = image.copy()
+    fn = h0.frame_nbytes
+    image[7 * fn + 8] ^= 0xff            # corrupt frame_length of file frame 7
+    pattern, mask = h0.invariant_pattern()
+    dbuf = kernels.to_device_bytes(image)
+    for threads, within in (([0, 1, 2, 3], None), ([3, 0], None), ([0, 1, 2, 3], [1]), ([2], [0, 1])):
+        nslot = len(threads)
+        slot = kernels.thread_slot_map(threads, dbuf.device)
+        wdev = None if within is None else torch.tensor(within, dtype=torch.int32, device='cuda')
+        for first, nsets in ((0, 9), (2, 5), (8, 1)):
+            sub = dbuf[first * 4 * fn:]
+            nframes = nsets * 4
+            recs = kernels.vdif_scan(sub, nframes, fn, 32, pattern, mask, h0['seconds'], h0['frame_nr'] + first, 4)
+            src = kernels.build_index(recs, nsets, nslot, slot)
+            nbad = torch.zeros(1, dtype=torch.int32, device='cuda')
+            kernels.verify_records(recs, nframes, 0, 4, nframes, nbad)
+            want = kernels.decode_frames(sub, nsets, 64, _lib.CODER_VDIF, 2, chunk=2, nslot=nslot, src=src,
+                                         fill_value=-3.5, within=wdev)
+            w = kernels.VDIFWindow(fn, 32, pattern, mask, h0['seconds'], 4, 64, _lib.CODER_VDIF, 2, 2, nslot,
+                                   False, -3.5)
+            for verify in (True, False):
+                nbad2 = torch.zeros(1, dtype=torch.int32, device='cuda') if verify else None
+                ev = torch.cuda.Event()
+                ev.record()
+                room = torch.full((want.numel() + 8,), 9., dtype=torch.float32, device='cuda')
+                for off in (0, 4, 1):                       # 16-byte aligned or not: a temporary inside
+                    out = room[off:off + want.numel()]
+                    out.fill_(9.)
+                    w.run(sub, h0['frame_nr'] + first, nframes, slot, nsets, wdev, out, 4, nframes, nbad2,
+                          ev.cuda_event if verify else None)
+                    assert torch.equal(out.view(torch.int32), want.view(torch.int32)), (threads, within, first, off)
+                if verify:
+                    ev.synchronize()
+                    assert int(nbad2.item()) == 3 * int(nbad.item()), (threads, first)
