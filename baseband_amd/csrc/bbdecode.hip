@@ -927,6 +927,16 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
     return bb_decode_frames(d_buf, nbytes, d_src, nsets, dec, d_out, out_elems, stream);
 }
 
+int bb_fetch_counter(const uint32_t *d_counter, uint32_t *h_value, void *after, void *side_stream)
+{
+    if (!d_counter || !h_value) return BB_EINVAL;
+    hipStream_t st = (hipStream_t)side_stream;
+    if (after) BB_HIP(hipStreamWaitEvent(st, (hipEvent_t)after, 0));
+    BB_HIP(hipMemcpyAsync(h_value, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    BB_HIP(hipStreamSynchronize(st));
+    return BB_OK;
+}
+
 int bb_decode_frames_select_check(const bb_decode_params *p, int nwithin)
 {
     select_geom g;

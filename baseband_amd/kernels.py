@@ -276,6 +276,14 @@ def verify_records(recs, nrecs, first_index, recs_per_index, nstrict, nbad):
                                 _ptr(nbad), _stream(recs)), 'bb_verify_records')
 
 
+def fetch_counter(counter, host, event, side_stream):
+    """``host[0] = counter[0]`` fetched on `side_stream` once `event` has
+    happened (bb_fetch_counter); returns when the value is there.  `host`: a
+    pinned int32 tensor; `event`: torch.cuda.Event that has been recorded."""
+    check(lib.bb_fetch_counter(_ptr(counter), C.c_void_p(host.data_ptr()), C.c_void_p(event.cuda_event),
+                               C.c_void_p(side_stream.cuda_stream)), 'bb_fetch_counter')
+
+
 def recs_fields(recs):
     """Split scan records (device int32 (n,4)) into named host arrays."""
     r = recs.cpu().numpy()

@@ -324,6 +324,15 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
                         uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad,
                         void *verified, void *stream);
 
+/*
+ * Fetch a device counter (the d_nbad of bb_verify_records) on `side_stream`
+ * once `after` (a hipEvent_t, may be NULL) has happened: the stream waits for
+ * the event, copies the counter to *h_value (pinned host memory) and the call
+ * returns when that copy is done -- without waiting for work queued on other
+ * streams behind the event (the decode of the window that was verified).
+ */
+int bb_fetch_counter(const uint32_t *d_counter, uint32_t *h_value, void *after, void *side_stream);
+
 /* ---- Mark 4 ------------------------------------------------------------ */
 
 /*
