@@ -175,6 +175,11 @@ SIGNATURES = [
     ('bb_decode_frames_select', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, C.c_int, _vp, _sz, _vp]),
     ('bb_decode_frames_select_check', C.c_int, [C.POINTER(DecodeParams), C.c_int]),
     ('bb_fetch_counter', C.c_int, [_vp, _vp, _vp, _vp]),
+    ('bb_mark5b_read_window', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _sz, _sz, C.POINTER(DecodeParams),
+                                        _vp, C.c_int, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    ('bb_mark4_read_window', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _sz, _sz,
+                                       C.POINTER(Mark4DecodeParams), C.c_int, _vp, _vp, _vp, _sz, _sz, _vp, _vp,
+                                       _vp]),
     ('bb_vdif_read_window', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _sz, _vp, _sz, C.POINTER(DecodeParams),
                                       _vp, C.c_int, _vp, _vp, _vp, _sz, C.c_uint32, _sz, _vp, _vp, _vp]),
     ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),

@@ -927,6 +927,51 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
     return bb_decode_frames(d_buf, nbytes, d_src, nsets, dec, d_out, out_elems, stream);
 }
 
+int bb_mark5b_read_window(const void *d_buf, size_t nbytes,
+                          const bb_mark5b_scan_params *scan, size_t nframes, size_t n,
+                          const bb_decode_params *dec,
+                          const int32_t *d_within, int nwithin,
+                          bb_frame_rec *d_recs, int64_t *d_src,
+                          float *d_out, size_t out_elems,
+                          size_t nstrict, uint32_t *d_nbad, void *verified, void *stream)
+{
+    if (!scan || !dec) return BB_EINVAL;
+    int rc = bb_mark5b_scan(d_buf, nbytes, scan, d_recs, nframes, stream);
+    if (rc != BB_OK) return rc;
+    rc = bb_build_index(d_recs, nframes, nullptr, 1, d_src, n, stream);
+    if (rc != BB_OK) return rc;
+    if (d_nbad) {
+        rc = bb_verify_records(d_recs, nframes, 0, 1, nstrict, d_nbad, stream);
+        if (rc != BB_OK) return rc;
+    }
+    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
+    if (nwithin > 0)
+        return bb_decode_frames_select(d_buf, nbytes, d_src, n, dec, d_within, nwithin, d_out, out_elems, stream);
+    return bb_decode_frames(d_buf, nbytes, d_src, n, dec, d_out, out_elems, stream);
+}
+
+int bb_mark4_read_window(const void *d_buf, size_t nbytes,
+                         const bb_mark4_scan_params *scan, size_t nframes, size_t n,
+                         const bb_mark4_decode_params *dec, int nout,
+                         bb_frame_rec *d_recs, int64_t *d_src,
+                         float *d_out, size_t out_elems,
+                         size_t nstrict, uint32_t *d_nbad, void *verified, void *stream)
+{
+    if (!scan || !dec) return BB_EINVAL;
+    int rc = bb_mark4_scan(d_buf, nbytes, scan, d_recs, nframes, stream);
+    if (rc != BB_OK) return rc;
+    rc = bb_build_index(d_recs, nframes, nullptr, 1, d_src, n, stream);
+    if (rc != BB_OK) return rc;
+    if (d_nbad) {
+        rc = bb_verify_records(d_recs, nframes, 0, 1, nstrict, d_nbad, stream);
+        if (rc != BB_OK) return rc;
+    }
+    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
+    if (nout > 0)
+        return bb_decode_mark4_select(d_buf, nbytes, d_src, n, dec, nout, d_out, out_elems, stream);
+    return bb_decode_mark4(d_buf, nbytes, d_src, n, dec, d_out, out_elems, stream);
+}
+
 int bb_fetch_counter(const uint32_t *d_counter, uint32_t *h_value, void *after, void *side_stream)
 {
     if (!d_counter || !h_value) return BB_EINVAL;

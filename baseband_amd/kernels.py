@@ -177,6 +177,81 @@ class VDIFWindow:
         tgt.done()
 
 
+class _FrameWindow:
+    """Scratch and output handling shared by the single-thread window calls."""
+    __slots__ = ('recs', 'src', 'fill_value')
+
+    def _scratch(self, nframes, n, dev):
+        if self.recs is None or self.recs.shape[0] < nframes or self.recs.device != dev:
+            self.recs = torch.empty((max(nframes, 64), 4), dtype=torch.int32, device=dev)
+        if self.src is None or self.src.numel() < n or self.src.device != dev:
+            self.src = torch.empty(max(n, 64), dtype=torch.int64, device=dev)
+
+
+class Mark5BWindow(_FrameWindow):
+    """One window of a Mark 5B stream read as one library call
+    (bb_mark5b_read_window); see `VDIFWindow`."""
+    __slots__ = ('scan', 'dec')
+
+    def __init__(self, ref_seconds, frame_rate, bps, chunk, fill_value):
+        p = self.scan = _lib.Mark5BScanParams()
+        p.first_offset, p.ref_seconds, p.frame_rate = 0, ref_seconds, frame_rate
+        d = self.dec = _lib.DecodeParams()
+        d.coder, d.bps, d.chunk, d.nslot, d.payload_nbytes = _lib.CODER_MARK5B, bps, chunk, 1, 10000
+        self.recs = self.src = None
+        self.set_fill(fill_value)
+
+    def set_fill(self, fill_value):
+        fv = complex(fill_value)
+        self.dec.fill_re, self.dec.fill_im = fv.real, fv.imag
+        self.fill_value = fill_value
+
+    def run(self, dbuf, ref_frame_nr, nframes, n, within, out, nstrict, nbad, verified):
+        self.scan.ref_frame_nr = ref_frame_nr
+        self._scratch(nframes, n, dbuf.device)
+        tgt = _Target(out, out.numel(), dbuf.device)
+        check(lib.bb_mark5b_read_window(
+            _ptr(dbuf), dbuf.numel(), C.byref(self.scan), nframes, n, C.byref(self.dec), _ptr(within),
+            within.numel() if within is not None else 0, _ptr(self.recs), _ptr(self.src), _ptr(tgt.use),
+            tgt.use.numel(), nstrict, _ptr(nbad), C.c_void_p(verified) if verified else C.c_void_p(0),
+            _stream(dbuf)), 'bb_mark5b_read_window')
+        tgt.done()
+
+
+class Mark4Window(_FrameWindow):
+    """One window of a Mark 4 stream read as one library call
+    (bb_mark4_read_window); see `VDIFWindow`."""
+    __slots__ = ('scan', 'dec', 'nout', 'frame_qms', 'ref_qms')
+
+    def __init__(self, ntrack, ref_year, ref_qms, frame_qms, nwords, sign_bit, mag_bit, select, fill_words,
+                 fill_value):
+        p = self.scan = _lib.Mark4ScanParams()
+        p.first_offset, p.ntrack, p.ref_year, p.frame_qms = 0, ntrack, ref_year, frame_qms
+        self.ref_qms, self.frame_qms = ref_qms, frame_qms
+        d = self.dec = _lib.Mark4DecodeParams()
+        d.ntrack, d.nwords, d.fill_words = ntrack, nwords, fill_words
+        for j, (s, m) in enumerate(zip(sign_bit, mag_bit)):
+            d.sign_bit[j] = s
+            d.mag_bit[j] = m
+        self.nout = len(sign_bit) if select else 0
+        self.recs = self.src = None
+        self.set_fill(fill_value)
+
+    def set_fill(self, fill_value):
+        self.dec.fill = float(fill_value)
+        self.fill_value = fill_value
+
+    def run(self, dbuf, first, nframes, n, out, nstrict, nbad, verified):
+        self.scan.ref_qms = self.ref_qms + first * self.frame_qms
+        self._scratch(nframes, n, dbuf.device)
+        tgt = _Target(out, out.numel(), dbuf.device)
+        check(lib.bb_mark4_read_window(
+            _ptr(dbuf), dbuf.numel(), C.byref(self.scan), nframes, n, C.byref(self.dec), self.nout,
+            _ptr(self.recs), _ptr(self.src), _ptr(tgt.use), tgt.use.numel(), nstrict, _ptr(nbad),
+            C.c_void_p(verified) if verified else C.c_void_p(0), _stream(dbuf)), 'bb_mark4_read_window')
+        tgt.done()
+
+
 def vdif_locate(dbuf, nbytes, frame_nbytes, header_nbytes, pattern, mask):
     """Byte-granular header search -> sorted int64 device tensor of frame
     offsets (corruption-tolerant discovery)."""

@@ -256,22 +256,31 @@ class Mark4StreamReader(GPUStreamReaderBase):
             return kernels.mark4_header_crc(dev, offs.numel(), self._ntrack, offsets=offs)
         return kernels.mark4_header_crc(dev, nframes, self._ntrack, first_offset=self._file_offset0)
 
+    _window = None          # kernels.Mark4Window: argument blocks of the one-call window
+
     def _process_window(self, dbuf, first, last, out_flat):
-        sign, mag, select = self._maps()
+        """scan -> index -> verification -> decode of frames [first, last): one
+        library call (bb_mark4_read_window)."""
         n = last - first
         # one header beyond the request is checked too when it was staged
         nframes = min(n + (1 if self.verify else 0), dbuf.numel() // self._set_nbytes)
-        recs = kernels.mark4_scan(
-            dbuf, nframes, self._ntrack, self.header0.year,
-            self._ref_qms + first * self._frame_qms, self._frame_qms)
-        src = kernels.build_index(recs, n, 1, None)
+        w = self._window
+        if w is None:
+            sign, mag, select = self._maps()
+            w = self._window = kernels.Mark4Window(self._ntrack, self.header0.year, self._ref_qms,
+                                                   self._frame_qms, 20000, sign, mag, select, 160,
+                                                   self.fill_value)
+        if w.fill_value != self.fill_value:
+            w.set_fill(self.fill_value)
+        nbad = verified = None
         if self.verify:
-            # the look-ahead header (record n) only has to be a header
-            # (queued before the decode: `_resolve_checks` waits for this alone)
-            self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))
-        kernels.decode_mark4(
-            dbuf, n, self._ntrack, 20000, sign, mag,
-            fill_words=160, src=src, fill_value=self.fill_value, out=out_flat, select=select)
+            # (queued before the decode, an event behind it: `_resolve_checks`
+            # waits for this verdict alone)
+            nbad, verified = self._verdict_targets()
+        # the look-ahead header (record n) only has to be a header
+        w.run(dbuf, first, nframes, n, out_flat, min(n, nframes), nbad, verified)
+        if self.verify:
+            self._note_checked(nframes, missing=max(0, n - nframes))
 
 
 class Mark4StreamWriter(GPUStreamWriterBase):

@@ -204,22 +204,30 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         return flat.reshape(((last - first) * self.samples_per_frame,)
                             + tuple(self._decode_shape))
 
+    _window = None          # kernels.Mark5BWindow: argument blocks of the one-call window
+
     def _process_window(self, dbuf, first, last, out_flat):
+        """scan -> index -> verification -> decode of frames [first, last): one
+        library call (bb_mark5b_read_window)."""
         n = last - first
         # one header beyond the request is checked too when it was staged
         nframes = min(n + (1 if self.verify else 0), dbuf.numel() // FRAME_NBYTES)
-        recs = kernels.mark5b_scan(dbuf, nframes, self._ref_seconds,
-                                   self.header0['frame_nr'] + first,
-                                   self._frame_rate)
-        src = kernels.build_index(recs, n, 1, None)
+        w = self._window
+        if w is None:
+            w = self._window = kernels.Mark5BWindow(self._ref_seconds, self._frame_rate, self.bps,
+                                                    self._unsliced_shape[0], self.fill_value)
+        if w.fill_value != self.fill_value:
+            w.set_fill(self.fill_value)
+        nbad = verified = None
         if self.verify:
-            # the look-ahead header (record n) only has to be a header
-            # (queued before the decode: `_resolve_checks` waits for this alone)
-            self._check_window(recs, nframes, 1, min(n, nframes), missing=max(0, n - nframes))
-        kernels.decode_frames(
-            dbuf, n, 10000, _lib.CODER_MARK5B, self.bps,
-            chunk=self._unsliced_shape[0], nslot=1, src=src,
-            fill_value=self.fill_value, out=out_flat, within=self._within)
+            # (queued before the decode, an event behind it: `_resolve_checks`
+            # waits for this verdict alone)
+            nbad, verified = self._verdict_targets()
+        # the look-ahead header (record n) only has to be a header
+        w.run(dbuf, self.header0['frame_nr'] + first, nframes, n, self._within, out_flat,
+              min(n, nframes), nbad, verified)
+        if self.verify:
+            self._note_checked(nframes, missing=max(0, n - nframes))
 
 
 class Mark5BStreamWriter(GPUStreamWriterBase):

@@ -325,6 +325,22 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
                         void *verified, void *stream);
 
 /*
+ * The same for Mark 5B and Mark 4 (single-thread formats: one record per
+ * frame, slot 0): `nframes` headers are scanned -- the readers look one header
+ * beyond the request when it was staged (mark5b/base.py:136-155,
+ * base/base.py:1083-1125) -- and the first `n` frames are decoded; `nstrict` of
+ * the records must carry the expected time index.  Mark 4: `nout` > 0 decodes
+ * through shorter bit maps (bb_decode_mark4_select), 0 through the full ones.
+ */
+int bb_mark5b_read_window(const void *d_buf, size_t nbytes,
+                          const bb_mark5b_scan_params *scan, size_t nframes, size_t n,
+                          const bb_decode_params *dec,
+                          const int32_t *d_within, int nwithin,
+                          bb_frame_rec *d_recs, int64_t *d_src,
+                          float *d_out, size_t out_elems,
+                          size_t nstrict, uint32_t *d_nbad, void *verified, void *stream);
+
+/*
  * Fetch a device counter (the d_nbad of bb_verify_records) on `side_stream`
  * once `after` (a hipEvent_t, may be NULL) has happened: the stream waits for
  * the event, copies the counter to *h_value (pinned host memory) and the call
@@ -443,6 +459,14 @@ int bb_decode_mark4_select(const void *d_buf, size_t buf_nbytes,
                            const int64_t *d_src, size_t nframes,
                            const bb_mark4_decode_params *params, int nout,
                            float *d_out, size_t out_elems, void *stream);
+
+/* One window of a Mark 4 stream read in one call (see bb_mark5b_read_window). */
+int bb_mark4_read_window(const void *d_buf, size_t nbytes,
+                         const bb_mark4_scan_params *scan, size_t nframes, size_t n,
+                         const bb_mark4_decode_params *dec, int nout,
+                         bb_frame_rec *d_recs, int64_t *d_src,
+                         float *d_out, size_t out_elems,
+                         size_t nstrict, uint32_t *d_nbad, void *verified, void *stream);
 
 /* ---- byte-aligned formats with an axis permutation --------------------- */
 
