@@ -984,22 +984,10 @@ class GPUStreamReaderBase:
     _nmissing = 0       # frames a window should have held but the file did not
     _checked = False
 
-    def _check_window(self, recs, nrecs, recs_per_index, nstrict, missing=0):
-        """Queue the verification of a window's scan records (one launch;
-        the counter is read once per read() in `_resolve_checks`)."""
-        if self._nbad is None:
-            self._nbad = torch.zeros(1, dtype=torch.int32, device=recs.device)
-        kernels.verify_records(recs, nrecs, 0, recs_per_index, nstrict, self._nbad)
-        if self._check_event is None:
-            self._check_event = torch.cuda.Event()
-        self._check_event.record()
-        self._check_recs += int(nrecs)
-        self._nmissing += int(missing)
-        self._checked = True
-
     def _note_checked(self, nrecs, missing=0):
-        """Book a verification that a fused window call launched itself
-        (kernels.VDIFWindow: the event behind it is recorded by the library)."""
+        """Book the verification a window call launched (kernels.VDIFWindow,
+        Mark5BWindow, Mark4Window: the library records the event behind it; the
+        counter is read once per read() in `_resolve_checks`)."""
         self._check_recs += int(nrecs)
         self._nmissing += int(missing)
         self._checked = True
