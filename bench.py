@@ -1160,6 +1160,13 @@ def main():
                 line["api_read"] = {"error": repr(exc)[:500]}
             try:
                 line["invalid_fill"] = leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_avg)
+                # the fraction of the spec peak AND of what the device
+                # was measured to do -- this launch's stores without its reads
+                w = line["invalid_fill"]["all_frames_invalid"]
+                line["roofline"]["measured_write_only"] = {
+                    "GBps": w["write_GBps"], "frac_of_peak": w["frac_of_peak"],
+                    "kernel_time_over_write_only_time": w["headline_kernel_ms_over_this"],
+                    "what": "the headline launch with every index entry -1 (fill): same kernel, same stores, no reads"}
             except Exception as exc:
                 line["invalid_fill"] = {"error": repr(exc)[:500]}
         del image
