@@ -370,6 +370,64 @@ def spawn_ranks(args, argv):
                 pass
 
 
+FORCE_FAIL_ENV = 'BB_BENCH_FORCE_CHECK_FALSE'       # tests: make the named check read false
+CHECKS_RC = 3                                       # exit status when a check of the line is false
+
+
+def collect_checks(line):
+    """Every self-check the line carries, folded into one verdict.  Returns
+    (checks_ok, {name: bool}).  A leg that is in the line but failed before
+    its check was evaluated counts as false: a check that did not run is not a
+    passed check.  ``BB_BENCH_FORCE_CHECK_FALSE=<name>`` forces one false
+    (tests/test_bench_cli.py: the exit status must follow)."""
+    checks = {}
+
+    def put(name, leg, *path):
+        v = leg
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+        checks[name] = v is True
+
+    put("headline.sanity_spot_check", line, "sanity_spot_check")
+    if "parity_digests" in line:
+        put("parity_digests.all_match", line, "parity_digests", "all_match")
+    if "invalid_fill" in line:
+        put("invalid_fill.flagged_frame_is_fill", line, "invalid_fill", "flagged_frame_is_fill")
+        put("invalid_fill.neighbour_frame_is_data", line, "invalid_fill", "neighbour_frame_is_data")
+        put("invalid_fill.all_invalid_output_is_fill", line, "invalid_fill", "all_frames_invalid", "output_is_fill")
+    if "cfg3" in line:
+        if line.get("dry_run"):
+            put("cfg3.index_ok", line, "cfg3", "index_ok")
+        else:
+            put("cfg3.sanity_spot_check", line, "cfg3", "sanity_spot_check")
+            if isinstance(line["cfg3"], dict) and "rank_local_scan" in line["cfg3"]:
+                put("cfg3.rank_local_scan.index_equals_broadcast", line, "cfg3", "rank_local_scan",
+                    "index_equals_broadcast")
+    if "pipeline" in line:
+        put("pipeline.all_match", line, "pipeline", "all_match")
+    if "other_configs" in line:
+        oc = line["other_configs"]
+        checks["other_configs.spot_checks"] = bool(oc) and all(
+            isinstance(c, dict) and "error" not in c and c.get("spot_check", True) is True for c in oc)
+    forced = os.environ.get(FORCE_FAIL_ENV)
+    if forced:
+        checks[forced] = False
+    return all(checks.values()), checks
+
+
+def finish(line):
+    """Attach `checks_ok` / `checks`, print THE line, return the exit status."""
+    ok, checks = collect_checks(line)
+    line["checks_ok"] = ok
+    line["checks"] = checks
+    print(json.dumps(line), flush=True)
+    if not ok:
+        print("bench.py: self-checks FAILED: " + ", ".join(k for k, v in checks.items() if not v),
+              file=sys.stderr, flush=True)
+        return CHECKS_RC
+    return 0
+
+
 def timed_launches(fn, reps):
     """Median and mean ms of `fn` (one launch) by HIP events on torch's current
     stream, which is the stream the library launches on (kernels._stream)."""
@@ -426,8 +484,9 @@ def dry_run(args, rank, world):
         if handed and os.path.exists(handed):       # what the parent of an N > 1 run timed
             with open(handed) as f:
                 cpu = json.load(f)
-        print(json.dumps({
+        rc = finish({
             "metric": "decoded Msamples/s, VDIF 2-bit 1-thread (scan + index + decode, input resident in HBM)",
+            "sanity_spot_check": True,              # nothing is decoded in a dry run
             "cpu_baseline": cpu,
             "roofline": {"traffic": None, "traffic_detail": {
                 "hbm_bytes_per_launch": None, "reason": "dry run" if world == 1 else "counter passes run at N = 1 only"}},
@@ -438,9 +497,12 @@ def dry_run(args, rank, world):
             "max_over_ranks_s": float(elapsed.item()),
             "cfg3": {"collective": {"bytes": nsets * CFG3_THREADS * 8, "ms": round(coll_ms, 3),
                                     "ranks_seen": int(seen.item()), "backend": "gloo"},
-                     "index_ok": ok}}), flush=True)
+                     "index_ok": ok}})
+    else:
+        rc = 0
     if world > 1:
         dist.destroy_process_group()
+    return rc
 
 
 def parity_digests():
@@ -663,6 +725,21 @@ def leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_ms):
                 ev[k][1].record()
         torch.cuda.synchronize()
         ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        nbad = int(bad.numel())
+        filled = int((src < 0).sum().item())
+        # flagged frames are fill, their neighbours are data -- checked HERE, on
+        # the output of the timed 1 %-invalid launches, before anything else
+        # writes into `out` (base/frame.py:191-199)
+        f = int(bad[nbad // 2].item())
+        is_fill = bool((out[f * SPF:(f + 1) * SPF] == 0).all().item())
+        g_ = f + 1 if f + 1 < nframes and not bool((bad == f + 1).any().item()) else max(0, f - 1)
+        assert not bool((bad == g_).any().item()), "no unflagged neighbour to check"
+        lev = _lib.get_levels(_lib.CODER_VDIF, 2)
+        raw = image[g_ * FRAME_NBYTES + HEADER_NBYTES:(g_ + 1) * FRAME_NBYTES].cpu().numpy()
+        neighbour_ok = bool(np.array_equal(out[g_ * SPF:(g_ + 1) * SPF].cpu().numpy().view(np.uint32),
+                                           expand_2bit(raw, lev).view(np.uint32)))
+        # a data frame is not all zeros (so `is_fill` above is not vacuous)
+        neighbour_not_fill = not bool((out[g_ * SPF:(g_ + 1) * SPF] == 0).all().item())
         # every frame invalid: the same kernel with the same store pattern and NO
         # reads -- what this device does write-only ("measured achievable")
         none = torch.full_like(src, -1)
@@ -674,16 +751,7 @@ def leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_ms):
         torch.cuda.synchronize()
         ms_w = float(np.median([a_.elapsed_time(b_) for a_, b_ in ev2][1:]))
         del none
-        nbad = int(bad.numel())
-        filled = int((src < 0).sum().item())
-        # flagged frames are fill, their neighbours are data
-        f = int(bad[nbad // 2].item())
-        is_fill = bool((out[f * SPF:(f + 1) * SPF] == 0).all().item())
-        g_ = f + 1 if f + 1 < nframes and not bool((bad == f + 1).any().item()) else max(0, f - 1)
-        lev = _lib.get_levels(_lib.CODER_VDIF, 2)
-        raw = image[g_ * FRAME_NBYTES + HEADER_NBYTES:(g_ + 1) * FRAME_NBYTES].cpu().numpy()
-        neighbour_ok = bool(np.array_equal(out[g_ * SPF:(g_ + 1) * SPF].cpu().numpy().view(np.uint32),
-                                           expand_2bit(raw, lev).view(np.uint32)))
+        all_fill = bool((out[g_ * SPF:(g_ + 1) * SPF] == 0).all().item())
     finally:
         w0[bad] &= 2 ** 31 - 1
     alg = nframes * (FRAME_NBYTES + PAYLOAD_NBYTES * 16)
@@ -691,8 +759,10 @@ def leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_ms):
             "frames_flagged": nbad, "index_entries_invalid": filled, "kernel": _lib.last_kernel(),
             "kernel_ms_avg": round(ms, 4), "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
             "ms_over_headline_kernel": round(ms / kern_ms, 4),
-            "flagged_frame_is_fill": is_fill, "neighbour_frame_is_data": neighbour_ok,
+            "flagged_frame_is_fill": is_fill, "neighbour_frame_is_data": neighbour_ok and neighbour_not_fill,
+            "checked": "on the output of the timed 1 %-invalid launches, before the all-invalid launch below",
             "all_frames_invalid": {"what": "the same launch with every index entry -1: the kernel's stores, no reads",
+                                   "output_is_fill": all_fill,
                                    "kernel_ms": round(ms_w, 4),
                                    "write_GBps": round(nframes * PAYLOAD_NBYTES * 16 / ms_w / 1e6, 1),
                                    "frac_of_peak": round(nframes * PAYLOAD_NBYTES * 16 / ms_w / 1e6 / HBM_PEAK_GBS, 4),
@@ -1192,13 +1262,15 @@ def main():
                 del image
             except Exception as exc:
                 line["mid_size"] = {"error": repr(exc)[:500]}
+    rc = 0
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
+        rc = finish(line)
     if dist is not None:
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main() or 0)

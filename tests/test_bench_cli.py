@@ -79,3 +79,49 @@ def test_under_torch_distributed_run_like_the_driver(tmp_path):
     assert line['roofline']['traffic'] is None
     assert 'N = 1' in line['roofline']['traffic_detail']['reason']
     assert line['cfg3']['collective']['ranks_seen'] == 2 and line['cfg3']['index_ok'] is True
+
+
+def test_a_false_self_check_fails_the_bench():
+    """every self-check of the line is folded into
+    `checks_ok`, and a false one makes bench.py exit non-zero (the line is
+    still printed).  One rank and two ranks (the launcher must pass rank 0's
+    status on)."""
+    r, lines = _run(['--dry-run'])
+    assert r.returncode == 0
+    line = json.loads(lines[0])
+    assert line['checks_ok'] is True and line['checks']['cfg3.index_ok'] is True
+    r, lines = _run(['--dry-run'], {'BB_BENCH_FORCE_CHECK_FALSE': 'cfg3.index_ok'})
+    assert r.returncode == 3, (r.returncode, r.stderr[-500:])
+    line = json.loads(lines[0])
+    assert line['checks_ok'] is False and line['checks']['cfg3.index_ok'] is False
+    assert 'self-checks FAILED' in r.stderr and 'cfg3.index_ok' in r.stderr
+    r, lines = _run(['--gpus', '2', '--dry-run'], {'BB_BENCH_FORCE_CHECK_FALSE': 'cfg3.index_ok'})
+    assert r.returncode != 0 and len(lines) == 1
+    assert json.loads(lines[0])['checks_ok'] is False
+
+
+def test_collect_checks_reads_every_leg():
+    """The verdict is false when any leg's check is false, when a leg that
+    carries a check failed before evaluating it, and true otherwise."""
+    sys.path.insert(0, ROOT)
+    import bench
+    good = {"sanity_spot_check": True, "parity_digests": {"all_match": True},
+            "invalid_fill": {"flagged_frame_is_fill": True, "neighbour_frame_is_data": True,
+                             "all_frames_invalid": {"output_is_fill": True}},
+            "cfg3": {"sanity_spot_check": True}}
+    ok, checks = bench.collect_checks(good)
+    assert ok and len(checks) == 6 and all(checks.values())
+    import copy
+    for path in (("sanity_spot_check",), ("parity_digests", "all_match"),
+                 ("invalid_fill", "neighbour_frame_is_data"), ("invalid_fill", "flagged_frame_is_fill"),
+                 ("invalid_fill", "all_frames_invalid", "output_is_fill"), ("cfg3", "sanity_spot_check")):
+        bad = copy.deepcopy(good)
+        d = bad
+        for k in path[:-1]:
+            d = d[k]
+        d[path[-1]] = False
+        assert bench.collect_checks(bad)[0] is False, path
+    bad = dict(good, invalid_fill={"error": "RuntimeError('x')"})
+    ok, checks = bench.collect_checks(bad)
+    assert ok is False and checks["invalid_fill.neighbour_frame_is_data"] is False
+    assert bench.collect_checks({"sanity_spot_check": True})[0] is True
