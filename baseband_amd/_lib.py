@@ -66,6 +66,10 @@ TUNE_OUT_STRIPE_S = 17
 TUNE_BYTE_LUT = 21
 TUNE_LUT_SMALL = 25
 TUNE_FLAT8_LDS = 29
+TUNE_BURST = 31
+TUNE_BURST_BYTES = 32
+TUNE_BURST_PERIOD = 33
+TUNE_BURST_WAVES = 34
 
 
 class BBError(RuntimeError):

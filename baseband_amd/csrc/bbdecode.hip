@@ -9,6 +9,9 @@
 #endif
 #include "k_lut.h"
 #include "k_lds.h"
+#if BB_EXP
+#include "k_burst.h"
+#endif
 #include "k_gather.h"
 #include "k_mark4.h"
 #include "k_tiled.h"
@@ -173,7 +176,11 @@ std::atomic<int> g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a selectio
 std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
 std::atomic<int> g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 #if BB_EXP
-std::atomic<int> g_tune_variant{5};      // 5 = the product dispatch; others: include/bbdecode_exp.h
+std::atomic<int> g_tune_variant{5};
+std::atomic<int> g_tune_burst{0};         // 1: contiguous 2-bit output through k_decode_flat_burst (k_burst.h)
+std::atomic<int> g_tune_burst_bytes{65536};   // ... LDS bytes per staging buffer
+std::atomic<int> g_tune_burst_period{0};  // ... loader time slot, wall-clock ticks (10 ns); 0 = none
+std::atomic<int> g_tune_burst_waves{15};  // ... store waves per workgroup (3, 7 or 15)      // 5 = the product dispatch; others: include/bbdecode_exp.h
 std::atomic<int> g_tune_nt{1};
 std::atomic<int> g_tune_nt_loads{0};
 std::atomic<int> g_tune_tpw{12};
@@ -328,12 +335,35 @@ void launch_flat_lds(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
         constexpr bool N = decltype(NT)::value;
         if (BPS == 2 && t_arena_probe)
             hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 1>), grid, dim3(2 * BB_WAVE), 0, st, a);
+#if BB_EXP
+        else if (BPS == 2 && g_tune_variant.load() == 18)
+            hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+#endif
         else
             hipLaunchKernelGGL((k_decode_flat_lds<BPS, N, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
     });
 }
 
 #if BB_EXP
+// the loader-wave kernel (k_burst.h): dynamic LDS up to the CU's 160 KiB
+template <int NSTORE>
+int launch_flat_burst(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_burst_args &a)
+{
+    int rc = BB_OK;
+    with_nt(nt, [&](auto NT) {
+        constexpr bool N = decltype(NT)::value;
+        auto kern = k_decode_flat_burst<2, N, NSTORE>;
+        static std::atomic<size_t> allowed{0};
+        if (lds > allowed.load()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) { rc = hip_fail(hipGetLastError()); return; }
+            allowed = lds;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3((NSTORE + 1) * BB_WAVE), lds, st, a);
+    });
+    return rc;
+}
+
 // the same staging for contiguous 8-bit output: 2 waves x up to 16 tiles.  Experiment
 // build only: measured against the plain kernel (profiles/r03zd_exp_flat8*.log) it
 // loses 2-5 % on VDIF 8-bit frames (four table reads per store) and is -1 .. +3 %
@@ -439,6 +469,10 @@ int bb_tune(int knob, int value)
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
 #if BB_EXP
         case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
+        case BB_TUNE_BURST: g_tune_burst = value; return BB_OK;
+        case BB_TUNE_BURST_BYTES: g_tune_burst_bytes = (value >= 4096 && value <= 79360) ? (value & ~255) : 65536; return BB_OK;
+        case BB_TUNE_BURST_PERIOD: g_tune_burst_period = value > 0 ? value : 0; return BB_OK;
+        case BB_TUNE_BURST_WAVES: g_tune_burst_waves = (value == 3 || value == 7 || value == 15) ? value : 15; return BB_OK;
         case BB_TUNE_FLAT8_LDS: g_tune_flat8_lds = value; return BB_OK;
         case BB_TUNE_NT_STORES:    g_tune_nt = value;      return BB_OK;
         case BB_TUNE_NT_LOADS:     g_tune_nt_loads = value; return BB_OK;
@@ -782,9 +816,55 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // (profiles/r02ar_exp_1bit_items.log, r02ar_exp_4bit_lut.log)
         // 2-bit samples: k_decode_flat_lds (16-byte loads through LDS, at most 8 tiles
         // per wave); 1- and 4-bit: k_decode_flat_lut -- profiles/r03j_exp_lds.log
+#if BB_EXP
+        if (p->bps == 2 && g_tune_burst.load() != 0 && p->payload_nbytes >= 256) {
+            // 3a. the loader-wave kernel (k_burst.h): items of up to one staging buffer
+            bb_burst_args b;
+            b.buf = a.buf; b.src = d_src; b.out = d_out; b.tab = a.tab;
+            b.nfs = nfs; b.pbytes = p->payload_nbytes;
+            b.buf_bytes = (uint32_t)g_tune_burst_bytes.load();
+            const uint64_t fst = (b.pbytes + 30) & ~15ull;
+            if (fst <= b.buf_bytes) {
+                b.nseg = 1; b.seg_bytes = 0; b.fstride = (uint32_t)fst;
+                uint64_t k = b.buf_bytes / fst;
+                if (k > BB_BURST_MAXK) k = BB_BURST_MAXK;
+                b.kpi = (uint32_t)k;
+            } else {
+                b.seg_bytes = (b.buf_bytes - 32) & ~255u;
+                b.nseg = (b.pbytes + b.seg_bytes - 1) / b.seg_bytes;
+                b.fstride = b.buf_bytes; b.kpi = 1;
+            }
+            b.magic = (uint32_t)((1ull << 32) / b.pbytes) + 1;
+            const uint64_t nwork = nfs * b.nseg;
+            b.nitems = (nwork + b.kpi - 1) / b.kpi;
+            b.period = (uint32_t)g_tune_burst_period.load();
+            b.src0 = a.src0; b.src_stride = a.src_stride;
+            b.fill_re = a.fill_re; b.fill_im = a.fill_im; b.complex_data = a.complex_data;
+            b.src_lim = a.src_lim;
+            b.perm = make_perm(b.nitems, out_bytes);
+            const int nst = g_tune_burst_waves.load();
+            const size_t ldsb = BB_BURST_HEAD + 2 * (size_t)b.buf_bytes;
+            uint64_t per_cu = (160 * 1024) / ldsb;
+            const uint64_t by_waves = 32 / (uint64_t)(nst + 1);
+            if (per_cu > by_waves) per_cu = by_waves;
+            if (per_cu < 1) per_cu = 1;
+            uint64_t gb = tb > 0 ? (uint64_t)tb : 256 * per_cu;
+            if (gb > b.nitems) gb = b.nitems;
+            const dim3 gg((unsigned)gb);
+            int brc;
+            if (nst == 3) brc = launch_flat_burst<3>(nt, gg, ldsb, st, b);
+            else if (nst == 7) brc = launch_flat_burst<7>(nt, gg, ldsb, st, b);
+            else brc = launch_flat_burst<15>(nt, gg, ldsb, st, b);
+            if (brc) return brc;
+            BB_NOTE("k_decode_flat_burst<2,%s,%d> grid %u pieces/item %u buffer %u period %u", nt ? "nt" : "plain", nst,
+                    gg.x, b.kpi, b.buf_bytes, b.period);
+            BB_HIP(hipGetLastError());
+            return BB_OK;
+        }
+#endif
         bool lds = p->bps == 2;
 #if BB_EXP
-        if (g_tune_variant.load() == 15) lds = true;        // A/B: force either kernel for every sample width
+        if (g_tune_variant.load() == 15 || g_tune_variant.load() == 18) lds = true;        // A/B: force either kernel for every sample width
         if (g_tune_variant.load() == 16) lds = false;
 #endif
         int lut_tiles = g_tune_lut_tpw.load() * p->bps / 2;
@@ -805,7 +885,11 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             else
 #endif
             launch_flat_lds<2>(nt, g2, st, a);
-            BB_NOTE("k_decode_flat_lds<%d,%s,2,8> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", g2.x, a.tpw);
+            const char *gl = "";
+#if BB_EXP
+            if (p->bps == 2 && g_tune_variant.load() == 18) gl = ",glds";
+#endif
+            BB_NOTE("k_decode_flat_lds<%d,%s,2,8%s> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", gl, g2.x, a.tpw);
         } else {
             launch_flat_lut(p->bps, nt, g2, st, a);
             BB_NOTE("k_decode_flat_lut<%d,%s,2,16> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", g2.x, a.tpw);

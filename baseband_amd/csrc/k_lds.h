@@ -35,7 +35,9 @@
 // TAG only names an instantiation: the output arena probes new memory with
 // launches of TAG 1, so that a profile's per-kernel statistics of the decode
 // launches proper (TAG 0) are not averaged with the probes' short ones.
-template <int BPS, bool NT, int NW, int MAXT, int LV = BB_LV_REG, int TAG = 0>
+// GL (experiment build, variant 18): whole 16-byte pieces by global_load_lds_dwordx4
+// straight into the stage, no VGPR round trip.
+template <int BPS, bool NT, int NW, int MAXT, int LV = BB_LV_REG, int TAG = 0, bool GL = false>
 __global__ __launch_bounds__(NW * BB_WAVE)
 void k_decode_flat_lds(bb_flat_args a)
 {
@@ -112,7 +114,12 @@ void k_decode_flat_lds(bb_flat_args a)
                 const uint32_t p0 = piece * 16;
                 if (piece >= (uint32_t)NPIECE || p0 + 16 <= lo || p0 >= hi) continue;
                 if (p0 >= lo && p0 + 16 <= hi) {
-                    s_stage[wave][piece] = *reinterpret_cast<const bb_u4 *>(base + p0);
+                    if (GL)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(base + p0),
+                            (__attribute__((address_space(3))) void *)(&s_stage[wave][k * BB_WAVE]), 16, 0, 0);
+                    else
+                        s_stage[wave][piece] = *reinterpret_cast<const bb_u4 *>(base + p0);
                 } else {
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -122,6 +129,7 @@ void k_decode_flat_lds(bb_flat_args a)
                 }
             }
         }
+        if (GL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the direct-to-LDS loads have landed
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

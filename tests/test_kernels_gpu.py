@@ -623,3 +623,86 @@ def test_window_call_equals_the_four_calls():
                 if verify:
                     ev.synchronize()
                     assert int(nbad2.item()) == 3 * int(nbad.item()), (threads, first)
+
+
+def _burst(on, nbytes=65536, period=0, waves=15, blocks=0):
+    from baseband_amd import kernels, _lib
+    kernels.tune(_lib.TUNE_BURST, on)
+    kernels.tune(_lib.TUNE_BURST_BYTES, nbytes)
+    kernels.tune(_lib.TUNE_BURST_PERIOD, period)
+    kernels.tune(_lib.TUNE_BURST_WAVES, waves)
+    kernels.tune(_lib.TUNE_BLOCKS, blocks)
+
+
+@needs_experiments
+@pytest.mark.parametrize('pn', [256, 260, 1000, 8000, 10000, 16384, 70000, 200000])
+@pytest.mark.parametrize('cfg', [(65536, 15, 0, 0), (16384, 7, 0, 3), (8192, 3, 50, 0), (79360, 15, 200, 2)])
+def test_loader_wave_kernel_matches_the_oracle(pn, cfg):
+    """k_decode_flat_burst (k_burst.h: a loader wave stages long work items in
+    LDS with direct-to-LDS loads, 3 / 7 / 15 store waves expand them) against
+    the oracle: payloads shorter and longer than a staging buffer (items of
+    several payloads / segments of one), shuffled positions at every 4-byte
+    alignment, missing frames at the start / middle / end, a grid that makes
+    workgroups loop, the clocked loader, complex fill; and a fixed stride."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    nbuf, waves, period, blocks = cfg
+    rng = np.random.default_rng(pn + nbuf)
+    nframes = 37 if pn <= 20000 else 5
+    stride = pn + 36                               # positions run through every alignment mod 16
+    raw = rng.integers(0, 256, stride * (nframes + 3) + 16, dtype=np.uint8)
+    perm = rng.permutation(nframes + 3)[:nframes]
+    src = (perm * stride + 4 * (perm % 7)).astype(np.int64)
+    src[[0, nframes // 2, nframes - 1]] = -1
+    fill = -3.25
+    dbuf = kernels.to_device_bytes(raw)
+    try:
+        _burst(1, nbuf, period, waves, blocks)
+        out = kernels.decode_frames(dbuf, nframes, pn, 0, 2, chunk=2, nslot=1, src=torch.from_numpy(src).cuda(),
+                                    complex_data=True, fill_value=fill)
+        assert 'k_decode_flat_burst' in _lib.last_kernel()
+        out = out.cpu().numpy()
+        out2 = kernels.decode_frames(dbuf, nframes, pn, 0, 2, src0=20, src_stride=stride).cpu().numpy()
+    finally:
+        _burst(0)
+    E = pn * 4
+    exp = np.empty((nframes, E), np.float32)
+    for f in range(nframes):
+        if src[f] < 0:
+            exp[f] = np.tile(np.array([fill, 0.], np.float32), E // 2)
+        else:
+            exp[f] = orc.decode_flat(raw[src[f]:src[f] + pn], 'vdif', 2)
+    assert bits_equal(out, exp.reshape(-1))
+    exp2 = np.concatenate([orc.decode_flat(raw[20 + i * stride:20 + i * stride + pn], 'vdif', 2)
+                           for i in range(nframes)])
+    assert bits_equal(out2, exp2)
+
+
+@needs_experiments
+def test_loader_wave_kernel_odd_addresses_and_many_items():
+    """Payloads at odd byte addresses (files repaired by the byte-granular
+    search) are staged byte by byte; a launch of many items on a small grid
+    walks both staging buffers many times, in the striped work order."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(77)
+    pn, nframes = 8000, 3000
+    stride = 8032
+    raw = rng.integers(0, 256, stride * nframes + 64, dtype=np.uint8)
+    dbuf = kernels.to_device_bytes(raw)
+    src = (np.arange(nframes) * stride + 32).astype(np.int64)
+    src[5::7] += 1                                  # odd addresses
+    src[6::11] += 2
+    src[100:110] = -1
+    try:
+        _burst(1, 65536, 100, 15, 9)
+        out = kernels.decode_frames(dbuf, nframes, pn, 0, 2, src=torch.from_numpy(src).cuda()).cpu().numpy()
+        assert 'k_decode_flat_burst' in _lib.last_kernel()
+    finally:
+        _burst(0)
+    ref = kernels.decode_frames(dbuf, nframes, pn, 0, 2, src=torch.from_numpy(src).cuda()).cpu().numpy()
+    assert 'k_decode_flat_lds' in _lib.last_kernel()
+    assert bits_equal(out, ref)
+    for f in (0, 5, 6, 105, 2999):
+        e = np.zeros(pn * 4, np.float32) if src[f] < 0 else orc.decode_flat(raw[src[f]:src[f] + pn], 'vdif', 2)
+        assert bits_equal(out[f * pn * 4:(f + 1) * pn * 4], e)
