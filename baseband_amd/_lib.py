@@ -178,6 +178,7 @@ SIGNATURES = [
     ('bb_decode_frames', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, _sz, _vp]),
     ('bb_decode_frames_select', C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(DecodeParams), _vp, C.c_int, _vp, _sz, _vp]),
     ('bb_decode_frames_select_check', C.c_int, [C.POINTER(DecodeParams), C.c_int]),
+    ('bb_copy_frames', C.c_int, [_vp, _sz, _sz, C.c_uint64, C.c_int64, C.c_int64, _vp, _sz, _vp]),
     ('bb_fetch_counter', C.c_int, [_vp, _vp, _vp, _vp]),
     ('bb_mark5b_read_window', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _sz, _sz, C.POINTER(DecodeParams),
                                         _vp, C.c_int, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),

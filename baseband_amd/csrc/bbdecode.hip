@@ -9,6 +9,7 @@
 #endif
 #include "k_lut.h"
 #include "k_lds.h"
+#include "k_copy.h"
 #if BB_EXP
 #include "k_burst.h"
 #endif
@@ -1063,6 +1064,46 @@ int bb_fetch_counter(const uint32_t *d_counter, uint32_t *h_value, void *after, 
     if (after) BB_HIP(hipStreamWaitEvent(st, (hipEvent_t)after, 0));
     BB_HIP(hipMemcpyAsync(h_value, d_counter, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     BB_HIP(hipStreamSynchronize(st));
+    return BB_OK;
+}
+
+// float32 samples: a strided frame copy (k_copy.h).  EXTENSION -- the reference
+// has no NBIT 32 decoder (dada/payload.py:40-41).
+int bb_copy_frames(const void *d_buf, size_t buf_nbytes, size_t nframes, uint64_t nbytes_per_frame,
+                   int64_t src0, int64_t src_stride, void *d_out, size_t out_nbytes, void *stream)
+{
+    if (nframes == 0 || nbytes_per_frame == 0) { BB_NOTE("none"); return BB_OK; }
+    if (!d_buf || !d_out) return BB_EINVAL;
+    if ((nbytes_per_frame & 3) || (src0 & 3) || (src_stride & 3) || src0 < 0 || src_stride < 0
+        || (reinterpret_cast<uintptr_t>(d_buf) & 3) || (reinterpret_cast<uintptr_t>(d_out) & 3)) return BB_EINVAL;
+    if (nframes > 1 && (uint64_t)src_stride < nbytes_per_frame && src_stride != 0) return BB_EINVAL;
+    if ((uint64_t)nframes > (~0ull) / nbytes_per_frame || (uint64_t)nframes * nbytes_per_frame > out_nbytes) return BB_ERANGE;
+    if ((uint64_t)src0 + (uint64_t)(nframes - 1) * (uint64_t)src_stride + nbytes_per_frame > buf_nbytes) return BB_ERANGE;
+    int rc = ensure_init();
+    if (rc) return rc;
+    bb_copy_args a;
+    a.buf = (const uint8_t *)d_buf; a.out = (uint8_t *)d_out;
+    a.nframes = nframes; a.n = nbytes_per_frame;
+    a.nseg = (nbytes_per_frame + BB_COPY_ITEM - 1) / BB_COPY_ITEM;
+    a.src0 = src0; a.src_stride = src_stride;
+    const uint64_t nwork = (uint64_t)nframes * a.nseg;
+    a.perm = make_perm(nwork, (uint64_t)nframes * nbytes_per_frame);
+    const bool v16 = !((reinterpret_cast<uintptr_t>(d_buf) | reinterpret_cast<uintptr_t>(d_out) | (uint64_t)src0
+                        | (uint64_t)src_stride | nbytes_per_frame) & 15);
+    const int tb = g_tune_blocks.load();
+    uint64_t blocks = nwork;
+    const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
+    if (blocks > cap) blocks = cap;
+    const dim3 grid((unsigned)blocks);
+    hipStream_t st = (hipStream_t)stream;
+    const bool nt = tune_nt();
+    with_nt(nt, [&](auto NT) {
+        constexpr bool N = decltype(NT)::value;
+        if (v16) hipLaunchKernelGGL((k_copy_frames<N, true>), grid, dim3(BB_BLOCK), 0, st, a);
+        else     hipLaunchKernelGGL((k_copy_frames<N, false>), grid, dim3(BB_BLOCK), 0, st, a);
+    });
+    BB_NOTE("k_copy_frames<%s,%s> grid %u", nt ? "nt" : "plain", v16 ? "16B" : "4B", grid.x);
+    BB_HIP(hipGetLastError());
     return BB_OK;
 }
 

@@ -209,11 +209,16 @@ class DADAStreamReader(BlockStreamReader):
         if self.bps == 32:
             # EXTENSION (no counterpart in the reference, which knows NBIT 8
             # only: dada/payload.py:40-41): float32 samples are passed through
-            # as they are -- a device-to-device copy, byte-identical to the file
+            # as they are -- ONE strided copy launch of the library
+            # (bb_copy_frames, k_copy.h), byte-identical to the file
             nb = (b - a) * self._row_nbytes
-            for i in range(nframes):
-                lo = payload_offset + i * frame_stride + a * self._row_nbytes
-                out_flat[i * nb // 4:(i + 1) * nb // 4] = dbuf[lo:lo + nb].view(torch.float32)
+            lo = payload_offset + a * self._row_nbytes
+            if lo % 4 == 0 and frame_stride % 4 == 0 and dbuf.data_ptr() % 4 == 0:
+                kernels.copy_frames(dbuf, nframes, nb, src0=lo, src_stride=frame_stride, out=out_flat)
+                return
+            for i in range(nframes):                    # (an odd header size: byte moves by torch)
+                out_flat[i * nb // 4:(i + 1) * nb // 4] = \
+                    dbuf[lo + i * frame_stride:lo + i * frame_stride + nb].clone().view(torch.float32)
             return
         self._flat_rows(dbuf, nframes, payload_offset + a * self._row_nbytes,
                         (b - a) * self._row_nbytes, frame_stride, out_flat)

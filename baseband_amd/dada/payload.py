@@ -56,7 +56,13 @@ class DADAPayload(RowSetMixin, PayloadBase):
         row = npol * nchan * (2 if self.complex_data else 1)
         if self.bps == 32:
             # EXTENSION: NBIT 32 = float32 passthrough (not in the reference)
-            flat = self._device_words()[start * row * 4:stop * row * 4].view(torch.float32).clone()
+            # (bb_copy_frames, csrc/k_copy.h)
+            words = self._device_words()
+            nb = (stop - start) * row * 4
+            if nb and words.data_ptr() % 4 == 0:
+                flat = kernels.copy_frames(words, 1, nb, src0=start * row * 4)
+            else:
+                flat = words[start * row * 4:stop * row * 4].clone().view(torch.float32)
         else:
             flat = decode_i8_rows(self._device_words(), 0, row, start, stop)
         if self.complex_data:

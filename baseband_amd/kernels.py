@@ -421,6 +421,18 @@ def decode_frames(dbuf, nframes, payload_nbytes, coder, bps, chunk=1, nslot=1,
     return tgt.done()
 
 
+def copy_frames(dbuf, nframes, nbytes_per_frame, src0=0, src_stride=0, out=None):
+    """`nframes` runs of `nbytes_per_frame` bytes of `dbuf` (uint8) at ``src0 +
+    f * src_stride`` -> one contiguous float32 device tensor (bb_copy_frames):
+    float32 samples passed through as they are.  EXTENSION -- the reference
+    has no NBIT 32 decoder (dada/payload.py:40-41)."""
+    nelem = nframes * nbytes_per_frame // 4
+    tgt = _Target(out, nelem, dbuf.device)
+    check(lib.bb_copy_frames(_ptr(dbuf), dbuf.numel(), nframes, nbytes_per_frame, src0, src_stride,
+                             _ptr(tgt.use), tgt.use.numel() * 4, _stream(dbuf)), 'bb_copy_frames')
+    return tgt.done()
+
+
 def select_supported(bps, chunk, nslot, nwithin, payload_nbytes=None):
     """Would `decode_frames(..., within=...)` take this geometry?  Asks the
     library's own argument / geometry checks (bb_decode_frames_select_check;

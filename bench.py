@@ -769,7 +769,39 @@ def leg_invalid_fill(args, image, out, nframes, h0, first_frame, kern_ms):
                                    "headline_kernel_ms_over_this": round(kern_ms / ms_w, 4)}}
 
 
-def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
+def leg_locate(image, h0, nframes, reps=5):
+    """The corruption-tolerant frame search (base/base.py:181-335
+    `locate_frames` as the `_bad_frame` recoveries use it) over the whole
+    headline image: a read-only sweep that tests EVERY byte position against
+    the header pattern and confirms hits one frame later (bb_vdif_locate,
+    k_scan.h).  Algorithmic bytes = the file, read once."""
+    import ctypes as C
+    from baseband_amd import kernels, _lib
+    pattern, mask = h0.invariant_pattern()
+    p = kernels._vdif_params(FRAME_NBYTES, HEADER_NBYTES, pattern, mask, 0, 0, 0)
+    nbytes = image.numel()
+    cap = nbytes // FRAME_NBYTES + 16
+    offs = torch.empty(cap, dtype=torch.int64, device=image.device)
+    count = torch.zeros(1, dtype=torch.int64, device=image.device)
+
+    def run():
+        count.zero_()
+        _lib.check(_lib.lib.bb_vdif_locate(image.data_ptr(), nbytes, C.byref(p), offs.data_ptr(), cap,
+                                           count.data_ptr(), kernels._stream(image)), 'bb_vdif_locate')
+    med, mean = timed_launches(run, reps)
+    n = int(count.item())
+    found = torch.sort(offs[:min(n, cap)]).values
+    ok = n == nframes and bool((found == torch.arange(nframes, device=image.device, dtype=torch.int64)
+                                * FRAME_NBYTES).all().item())
+    return {"case": "bb_vdif_locate: byte-granular header search over the {:.3f} GiB cfg2 image".format(nbytes / 2 ** 30),
+            "kernel": "k_vdif_locate (bb_locate_sweep)", "ms": round(mean, 4), "ms_median": round(med, 4),
+            "timing": "incl. the memset of the hit counter",
+            "algorithmic_GBps": round(nbytes / mean / 1e6, 1), "frac": round(nbytes / mean / 1e6 / HBM_PEAK_GBS, 4),
+            "bytes_in": nbytes, "bytes_out": n * 8, "frames_found": n, "spot_check": ok,
+            "spot_check_what": "every frame of the image found, at its offset, nothing else"}
+
+
+def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5, res=None):
     """Kernel-level figures for the other BASELINE configurations on random
     input -- `gib` GiB for the 2-bit formats, `gib8` for the 8-bit ones, i.e. the
     same 128-137 GB of decoded output as the headline launch each (the output
@@ -787,7 +819,7 @@ def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
         hi = min(buf.numel() // 4, lo + (1 << 28))
         buf.view(torch.int32)[lo:hi] = torch.randint(-2 ** 31, 2 ** 31 - 1, (hi - lo,), generator=g,
                                                      device=device, dtype=torch.int64).to(torch.int32)
-    res = []
+    res = [] if res is None else res            # (the caller's list keeps the rows measured before a failure)
 
     def add(name, fn, bytes_in, bytes_out, units, unit_name):
         med, mean = timed_launches(fn, reps)
@@ -855,17 +887,101 @@ def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5):
         nb, nb * 4, nb // 2, "complex_samples")
     # cfg5 "DADA float32 passthrough": NBIT 32 is an EXTENSION of this package
     # (the reference raises KeyError(32), dada/payload.py:40-41; parity is
-    # unpinned by construction): the reader copies the payload bytes device to
-    # device (dada/base.py `_decode_window`), no kernel of this library runs
-    nb = min(nbytes8, out.numel() * 4) // 16 * 16
-    o = out[:nb // 4]
-    src32 = buf[:nb].view(torch.float32)
-    med, mean = timed_launches(lambda: o.copy_(src32), reps)
-    res.append({"case": "DADA NBIT=32 float32 passthrough (extension, parity unpinned: no reference counterpart)",
-                "kernel": "torch copy_ (device to device; no libbbdecode kernel)", "ms": round(mean, 4),
-                "ms_median": round(med, 4), "algorithmic_GBps": round(2 * nb / mean / 1e6, 1),
-                "frac": round(2 * nb / mean / 1e6 / HBM_PEAK_GBS, 4), "bytes_in": nb, "bytes_out": nb,
-                "Msamples_per_s": round(nb / 4 / mean / 1e3, 1)})
+    # unpinned by construction): the reader's `_decode_window` is ONE strided
+    # copy launch of the library (bb_copy_frames, csrc/k_copy.h); here 128 MiB
+    # payloads behind 4096-byte headers
+    blk32 = 128 << 20
+    nfr = max(1, min(nbytes8 - 4096, out.numel() * 4) // (blk32 + 4096))
+    o = out[:nfr * blk32 // 4]
+    add("DADA NBIT=32 float32 passthrough (extension, parity unpinned: no reference counterpart)",
+        lambda: kernels.copy_frames(buf, nfr, blk32, src0=4096, src_stride=blk32 + 4096, out=o),
+        nfr * blk32, nfr * blk32, nfr * blk32 // 4, "samples")
+    k = nfr - 1
+    res[-1]["spot_check"] = bool(torch.equal(
+        o[k * (blk32 // 4):k * (blk32 // 4) + 4096].view(torch.int32),
+        buf[4096 + k * (blk32 + 4096):4096 + k * (blk32 + 4096) + 16384].view(torch.int32)))
+
+    # ---- the secondary kernels -------------------------
+    def expand_bits(raw, lev, bps):
+        """host re-expansion of packed codes, least significant field first"""
+        sh = np.arange(0, 8, bps, dtype=np.uint8)
+        return lev[(raw[:, None] >> sh) & ((1 << bps) - 1)].reshape(-1)
+
+    def flat_case(name, coder, bps, frame, pay, hdr, limit):
+        nfr_ = min(int(limit) // frame, out.numel() // (pay * 8 // bps))
+        o_ = out[:nfr_ * (pay * 8 // bps)]
+        add(name, lambda: kernels.decode_frames(buf, nfr_, pay, coder, bps, src0=hdr, src_stride=frame, out=o_),
+            nfr_ * frame, o_.numel() * 4, o_.numel(), "samples")
+        f = nfr_ - 1
+        raw = buf[f * frame + hdr:f * frame + hdr + pay].cpu().numpy()
+        got = o_[f * (pay * 8 // bps):(f + 1) * (pay * 8 // bps)].cpu().numpy()
+        res[-1]["spot_check"] = bool(np.array_equal(
+            got.view(np.uint32), expand_bits(raw, _lib.get_levels(coder, bps), bps).view(np.uint32)))
+
+    flat_case("VDIF 1-bit real 1 channel, 8032-byte frames", _lib.CODER_VDIF, 1, 8032, 8000, 32, gib * 2 ** 30)
+    flat_case("VDIF 4-bit real 1 channel, 8032-byte frames", _lib.CODER_VDIF, 4, 8032, 8000, 32, 2 * gib * 2 ** 30)
+    flat_case("VDIF 8-bit real 1 channel, 8032-byte frames", _lib.CODER_VDIF, 8, 8032, 8000, 32, nbytes8)
+    flat_case("GSB rawdump 4-bit real (2^22-byte blocks, no headers)", _lib.CODER_INT, 4, 1 << 22, 1 << 22, 0,
+              2 * gib * 2 ** 30)
+    # a reader `subset` of 2 of 16 channels folded into the decode of 8-thread
+    # 16-channel complex VDIF (k_decode_gather_select); bytes moved = every frame
+    # read + the kept channels written
+    nth, nch, pn, fn_ = 8, 16, 8000, 8032
+    nsets = int(gib * 2 ** 30) // (fn_ * nth)
+    src = (torch.arange(nsets * nth, device=device, dtype=torch.int64) * fn_ + 32).contiguous()
+    within = torch.tensor([6, 7, 24, 25], dtype=torch.int32, device=device)          # channels 3 and 12 (re, im)
+    spf = pn * 4 // (2 * nch)
+    o = out[:nsets * spf * nth * 4]
+    add("VDIF 8 threads x 16 channels 2-bit complex, subset of 2 of 16 channels folded into the decode",
+        lambda: kernels.decode_frames(buf, nsets, pn, _lib.CODER_VDIF, 2, chunk=2 * nch, nslot=nth, src=src,
+                                      complex_data=True, out=o, within=within),
+        nsets * nth * fn_, o.numel() * 4, o.numel() // 2, "complex_samples")
+    full = kernels.decode_frames(buf, 1, pn, _lib.CODER_VDIF, 2, chunk=2 * nch, nslot=nth,
+                                 src=src[(nsets - 1) * nth:], complex_data=True)
+    res[-1]["spot_check"] = bool(torch.equal(
+        full.view(spf, nth, 2 * nch)[:, :, within.long()].reshape(-1).view(torch.int32),
+        o[(nsets - 1) * spf * nth * 4:].view(torch.int32)))
+    del full
+    # a channel LIST (8 scattered of 64) of time-first GUPPI blocks
+    npol, nchan, blk = 2, 64, 128 << 20
+    T = blk // (npol * nchan * 2)
+    nfr = max(1, int(gib * 2 ** 30) // blk)
+    cmap = torch.tensor([1, 5, 9, 20, 33, 40, 41, 63], dtype=torch.int32, device=device)
+    nsel = int(cmap.numel())
+    o = out[:nfr * T * npol * nsel * 2]
+    add("GUPPI 8-bit 2 pol 64 channels, time first, channel list of 8 of 64 (bytes moved: every block read, kept channels written)",
+        lambda: kernels.decode_i8_tiled(buf, nfr, _lib.LAYOUT_GUPPI_TF, npol, nsel, T, 0, T, src0=0, src_stride=blk,
+                                        out=o, nchan_stored=nchan, npol_stored=npol, chan_map=cmap),
+        nfr * blk, o.numel() * 4, o.numel() // 2, "complex_samples")
+    full = kernels.decode_i8_tiled(buf, 1, _lib.LAYOUT_GUPPI_TF, npol, nchan, 4096, 0, 4096, src0=(nfr - 1) * blk,
+                                   src_stride=blk)
+    res[-1]["spot_check"] = bool(torch.equal(
+        full.view(4096, npol, nchan, 2)[:, :, cmap.long()].reshape(-1).view(torch.int32),
+        o[(nfr - 1) * T * npol * nsel * 2:][:4096 * npol * nsel * 2].view(torch.int32)))
+    del full
+    # the encoders (SURVEY 8f N2): float32 -> packed codes; 4 B read per sample
+    from baseband_amd._lib import lib as _L, check as _check
+    for bps_, coder_ in ((2, _lib.CODER_VDIF), (4, _lib.CODER_VDIF), (8, _lib.CODER_VDIF)):
+        nval = min(out.numel(), (buf.numel() - 4096) * 8 // bps_) // 1024 * 1024
+        vals = out[:nval]
+        packed = buf[:nval * bps_ // 8]
+
+        def enc():
+            _check(_L.bb_encode_flat(vals.data_ptr(), nval, coder_, bps_, packed.data_ptr(), packed.numel(),
+                                     kernels._stream(vals)), 'bb_encode_flat')
+        if bps_ == 2:
+            # `out` holds decoded 2-bit levels nowhere in particular by now: fill its
+            # head with a decode, so that encode(decode(x)) == x can be checked
+            nchk = 4096
+            raw0 = buf[:nchk * 8032].clone()
+            kernels.decode_frames(raw0, nchk, 8000, _lib.CODER_VDIF, 2, src0=32, src_stride=8032, out=out[:nchk * 32000])
+        add("bb_encode_flat VDIF {}-bit (float32 -> packed codes)".format(bps_), enc, nval * 4, nval * bps_ // 8,
+            nval, "samples")
+        if bps_ == 2:
+            res[-1]["spot_check"] = bool(torch.equal(
+                packed[:nchk * 8000].view(nchk, 8000), raw0.view(nchk, 8032)[:, 32:]))
+            res[-1]["spot_check_what"] = "encode(decode(x)) == x on 4096 payloads"
+            del raw0
     return res
 
 
@@ -1239,6 +1355,12 @@ def main():
                     "what": "the headline launch with every index entry -1 (fill): same kernel, same stores, no reads"}
             except Exception as exc:
                 line["invalid_fill"] = {"error": repr(exc)[:500]}
+        locate = None
+        if rank == 0 and world == 1:
+            try:
+                locate = leg_locate(image, h0, nframes)
+            except Exception as exc:
+                locate = {"case": "bb_vdif_locate", "error": repr(exc)[:500]}
         del image
         try:
             line["cfg3"] = leg_cfg3(args, rank, world, device, dist, out)
@@ -1248,9 +1370,12 @@ def main():
             line["cfg3"] = {"error": repr(exc)[:500]}
         if rank == 0 and world == 1:
             try:
-                line["other_configs"] = leg_other_configs(device, out)
+                line["other_configs"] = []
+                leg_other_configs(device, out, res=line["other_configs"])
             except Exception as exc:
-                line["other_configs"] = [{"error": repr(exc)[:500]}]
+                line["other_configs"].append({"error": repr(exc)[:500]})
+            if locate is not None:
+                line["other_configs"].append(locate)
             # the launch sizes of ordinary read() calls, into fresh outputs: the
             # 127.5 GiB headline output goes first, the 8 GiB image comes back
             del out

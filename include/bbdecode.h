@@ -468,6 +468,24 @@ int bb_mark4_read_window(const void *d_buf, size_t nbytes,
                          float *d_out, size_t out_elems,
                          size_t nstrict, uint32_t *d_nbad, void *verified, void *stream);
 
+/* ---- float32 samples (extension) ---------------------------------------- */
+
+/*
+ * `nframes` runs of `nbytes_per_frame` bytes at src0 + f * src_stride of d_buf
+ * -> d_out, contiguous: what "decoding" float32 samples amounts to.  EXTENSION
+ * -- the reference has no such decoder: DADAPayload._decoders = {8: ...}
+ * (dada/payload.py:40-41), NBIT 32 raises KeyError(32) there; BASELINE.json
+ * configs[4] names "DADA float32 passthrough".  Nothing to be bit-exact
+ * against except the file's own bytes: parity is unpinned by construction and
+ * the test is byte identity.  Sizes, offsets and pointers are multiples of 4
+ * (BB_EINVAL otherwise); 16-byte loads and stores when they are multiples of
+ * 16 (DADA: 4096-byte headers).  BB_ERANGE when a run ends outside
+ * buf_nbytes or the output is too small.  Stream-ordered, no host sync.
+ */
+int bb_copy_frames(const void *d_buf, size_t buf_nbytes, size_t nframes,
+                   uint64_t nbytes_per_frame, int64_t src0, int64_t src_stride,
+                   void *d_out, size_t out_nbytes, void *stream);
+
 /* ---- byte-aligned formats with an axis permutation --------------------- */
 
 /*

@@ -237,6 +237,42 @@ def test_dada_float32_passthrough_extension(tmp_path):
         assert bits_equal(frame.data.cpu().numpy(), data[:spf])
 
 
+def test_copy_frames_is_byte_identical():
+    """bb_copy_frames (k_copy.h; EXTENSION, no reference counterpart -- parity
+    unpinned by construction): strided runs come out byte-identical, with
+    16-byte and 4-byte alignment, in a looping grid, with NaN payloads; bad
+    arguments are refused."""
+    import torch
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(3232)
+    raw = rng.integers(0, 256, 5_000_000, dtype=np.uint8)
+    dbuf = kernels.to_device_bytes(raw)
+    for nframes, n, src0, stride, blocks in [(1, 4096, 0, 0, 0), (7, 160000, 4096, 164096, 0),
+                                             (5, 20004, 12, 20020, 0), (3, 1 << 20, 16, (1 << 20) + 4096, 3),
+                                             (300, 16400, 64, 16464, 17), (2, 4, 4, 8, 0)]:
+        kernels.tune(_lib.TUNE_BLOCKS, blocks)
+        try:
+            out = kernels.copy_frames(dbuf, nframes, n, src0=src0, src_stride=stride)
+        finally:
+            kernels.tune(_lib.TUNE_BLOCKS, 0)
+        assert 'k_copy_frames' in _lib.last_kernel()
+        assert ('16B' in _lib.last_kernel()) == (n % 16 == 0 and src0 % 16 == 0 and stride % 16 == 0)
+        exp = np.concatenate([raw[src0 + i * stride:src0 + i * stride + n] for i in range(nframes)])
+        assert out.dtype == torch.float32 and out.numel() == nframes * n // 4
+        assert np.array_equal(out.cpu().numpy().view(np.uint8), exp)
+    # into a caller's tensor, also one that is not 16-byte aligned
+    big = torch.zeros(1000 + 40000 // 4, dtype=torch.float32, device='cuda')
+    o = big[1:1 + 10000]
+    assert kernels.copy_frames(dbuf, 2, 20000, src0=8, src_stride=30000, out=o) is o
+    assert np.array_equal(o.cpu().numpy().view(np.uint8), np.concatenate([raw[8:20008], raw[30008:50008]]))
+    assert float(big[0]) == 0 and float(big[10001]) == 0
+    for args in [(1, 6, 0, 0), (1, 8, 2, 0), (2, 8, 0, 6)]:                # not multiples of 4
+        with pytest.raises(_lib.BBError):
+            kernels.copy_frames(dbuf, args[0], args[1], src0=args[2], src_stride=args[3])
+    with pytest.raises(_lib.BBError):                                       # a run past the end of the buffer
+        kernels.copy_frames(dbuf, 3, 2_000_000, src0=0, src_stride=2_000_000)
+
+
 def test_block_readers_decode_into_out_tensor(manifest):
     """GUPPI (with overlap) and DADA read(out=device tensor): decoded in place."""
     import torch
