@@ -154,46 +154,55 @@ int device_levels(int coder, int lb, const float **p)
 #define BB_GRID_CAP 131072ull
 
 // ---- tuning (include/bbdecode_tune.h; the experiment build adds bbdecode_exp.h) ----
-std::atomic<int> g_tune_blocks{0};
-std::atomic<int> g_tune_tile_elems{8192};
-std::atomic<int> g_tune_encode_direct{0};
-std::atomic<int> g_tune_gather_bytes{8192};
-std::atomic<int> g_tune_tiled_stage{1};
-std::atomic<int> g_tune_seg_tiles{0};    // plain kernel: tiles per workgroup; 0 = 32, or 16 for 8-bit samples
-std::atomic<int> g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
-std::atomic<int> g_tune_mkbf_tc{32};
-std::atomic<int> g_tune_rows_tiles{8};          // tiles per work item of k_decode_rows_pipe (1..8)
-std::atomic<int> g_tune_lut_tpw{4};             // tiles per wave and work item of k_decode_flat_lut
-std::atomic<int> g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
-std::atomic<int> g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
-std::atomic<int> g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
-std::atomic<int> g_tune_xpose_rows{0};   // k_decode_i8_xpose: output rows per tile, 128 or 64; 0 = by layout
+// The knobs are THREAD-LOCAL: bb_tune() changes the geometry of the calling
+// host thread's later launches only, never another thread's (VERDICT r3 next
+// 8: the library keeps no process-wide mutable state besides the level tables
+// and the arenas a caller creates).  Results never depend on a knob.
+struct bb_knob {
+    int v;
+    int load() const { return v; }
+    bb_knob &operator=(int x) { v = x; return *this; }
+};
+thread_local bb_knob g_tune_blocks{0};
+thread_local bb_knob g_tune_tile_elems{8192};
+thread_local bb_knob g_tune_encode_direct{0};
+thread_local bb_knob g_tune_gather_bytes{8192};
+thread_local bb_knob g_tune_tiled_stage{1};
+thread_local bb_knob g_tune_seg_tiles{0};    // plain kernel: tiles per workgroup; 0 = 32, or 16 for 8-bit samples
+thread_local bb_knob g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
+thread_local bb_knob g_tune_mkbf_tc{32};
+thread_local bb_knob g_tune_rows_tiles{8};          // tiles per work item of k_decode_rows_pipe (1..8)
+thread_local bb_knob g_tune_lut_tpw{4};             // tiles per wave and work item of k_decode_flat_lut
+thread_local bb_knob g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
+thread_local bb_knob g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
+thread_local bb_knob g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
+thread_local bb_knob g_tune_xpose_rows{0};   // k_decode_i8_xpose: output rows per tile, 128 or 64; 0 = by layout
 #if BB_EXP
-std::atomic<int> g_tune_flat8_lds{0};    // experiment: 1 = contiguous 8-bit output through k_decode_flat_lds<8>
+thread_local bb_knob g_tune_flat8_lds{0};    // experiment: 1 = contiguous 8-bit output through k_decode_flat_lds<8>
 #endif
-std::atomic<int> g_tune_encode_runs{0};  // k_encode_flat: 256-quad runs per wave and step (1 or 2); 0 = by sample width
-std::atomic<int> g_tune_xpose_tc{0};     // k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; 0 = by channel count
-std::atomic<int> g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a selection: from this many channels on
-std::atomic<int> g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
-std::atomic<int> g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
+thread_local bb_knob g_tune_encode_runs{0};  // k_encode_flat: 256-quad runs per wave and step (1 or 2); 0 = by sample width
+thread_local bb_knob g_tune_xpose_tc{0};     // k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; 0 = by channel count
+thread_local bb_knob g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a selection: from this many channels on
+thread_local bb_knob g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
+thread_local bb_knob g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 #if BB_EXP
-std::atomic<int> g_tune_variant{5};
-std::atomic<int> g_tune_burst{0};         // 1: contiguous 2-bit output through k_decode_flat_burst (k_burst.h)
-std::atomic<int> g_tune_burst_bytes{65536};   // ... LDS bytes per staging buffer
-std::atomic<int> g_tune_burst_period{0};  // ... loader time slot, wall-clock ticks (10 ns); 0 = none
-std::atomic<int> g_tune_burst_waves{15};  // ... store waves per workgroup (3, 7 or 15)      // 5 = the product dispatch; others: include/bbdecode_exp.h
-std::atomic<int> g_tune_nt{1};
-std::atomic<int> g_tune_nt_loads{0};
-std::atomic<int> g_tune_tpw{12};
-std::atomic<uint64_t *> g_trace{nullptr};
-std::atomic<int> g_tune_lds_pad{0};
-std::atomic<int> g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
-std::atomic<int> g_tune_lut_small{0};           // 1: the 4-tile instantiation of k_decode_flat_lut when items allow (experiment: slower)
-std::atomic<int> g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
-std::atomic<int> g_tune_stripe_w{0};     // experiment: output striping (bb_flat_args::stripe_w)
-std::atomic<int> g_tune_stripe_s{0};     // ... distance between the stripes, in frame-slots
-std::atomic<int> g_tune_front_g{2048};  // k_decode_flat_front: workgroups per group (one write front)
-std::atomic<int> g_tune_front_k{16};    // k_decode_flat_front: steps a group sweeps
+thread_local bb_knob g_tune_variant{5};      // 5 = the product dispatch; others: include/bbdecode_exp.h
+thread_local bb_knob g_tune_burst{0};         // 1: contiguous 2-bit output through k_decode_flat_burst (k_burst.h)
+thread_local bb_knob g_tune_burst_bytes{65536};   // ... LDS bytes per staging buffer
+thread_local bb_knob g_tune_burst_period{0};  // ... loader time slot, wall-clock ticks (10 ns); 0 = none
+thread_local bb_knob g_tune_burst_waves{15};  // ... store waves per workgroup (3, 7 or 15)
+thread_local bb_knob g_tune_nt{1};
+thread_local bb_knob g_tune_nt_loads{0};
+thread_local bb_knob g_tune_tpw{12};
+std::atomic<uint64_t *> g_trace{nullptr};     // (experiment build: a process-wide debugging aid)
+thread_local bb_knob g_tune_lds_pad{0};
+thread_local bb_knob g_tune_tpw8{12};   // 8-bit data, aligned kernel: > 16 selects the 32-tile instantiation
+thread_local bb_knob g_tune_lut_small{0};           // 1: the 4-tile instantiation of k_decode_flat_lut when items allow (experiment: slower)
+thread_local bb_knob g_tune_byte_lut{1};     // 1: 1-/2-bit contiguous decode through the byte table kernel (k_lut.h)
+thread_local bb_knob g_tune_stripe_w{0};     // experiment: output striping (bb_flat_args::stripe_w)
+thread_local bb_knob g_tune_stripe_s{0};     // ... distance between the stripes, in frame-slots
+thread_local bb_knob g_tune_front_g{2048};  // k_decode_flat_front: workgroups per group (one write front)
+thread_local bb_knob g_tune_front_k{16};    // k_decode_flat_front: steps a group sweeps
 inline bool tune_nt() { return g_tune_nt.load() != 0; }
 #else
 inline bool tune_nt() { return true; }
@@ -1640,6 +1649,8 @@ int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
         if (bps == 4) BB_E(BB_CODER_INT, 4); else BB_E(BB_CODER_INT, 8);
     }
 #undef BB_E
+    BB_NOTE("k_encode_flat<%s,%d,%s,%d> grid %u", coder == BB_CODER_VDIF ? "VDIF" : coder == BB_CODER_MARK5B ? "MARK5B" : "INT",
+            bps, direct && bps == 2 ? "direct" : "thresholds", eruns, grid.x);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }
@@ -1683,6 +1694,7 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
         default: BB_M4E(64); break;
     }
 #undef BB_M4E
+    BB_NOTE("k_encode_mark4<%d,%s> grid %u", ntrack, direct ? "direct" : "thresholds", grid.x);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }

@@ -155,6 +155,31 @@ def _cpu_worker(args):
     return reps * nframes * SPF, time.perf_counter() - t0
 
 
+def physical_cores():
+    """(physical cores this process may run on, logical CPUs it may run on):
+    distinct (physical id, core id) pairs of /proc/cpuinfo among the CPUs of
+    the affinity mask.  SURVEY 8(d): the all-cores leg runs N = physical cores
+    processes, N stated."""
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+    try:
+        cores, cur = {}, {}
+        with open('/proc/cpuinfo') as f:
+            for ln in f.read().split('\n') + ['']:
+                if ':' in ln:
+                    k, v = ln.split(':', 1)
+                    cur[k.strip()] = v.strip()
+                elif cur:
+                    if 'processor' in cur:
+                        cores[int(cur['processor'])] = (cur.get('physical id', '0'), cur.get('core id', cur['processor']))
+                    cur = {}
+        phys = {cores[c] for c in allowed if c in cores}
+        if phys:
+            return len(phys), len(allowed)
+    except Exception:
+        pass
+    return len(allowed), len(allowed)
+
+
 def cpu_baseline(target_seconds=12.0):
     """Reference-as-written loop (NumPy port) on a bounded sample: one core (how
     the reference runs), all host cores over disjoint frame slabs (the
@@ -180,7 +205,7 @@ def cpu_baseline(target_seconds=12.0):
               "sample": "{} x {} frames of the same cfg2 layout ({:.1f} MiB each), "
                         "oracle/bb_oracle_np.vdif_read (per-frame NumPy LUT take loop)"
                         .format(reps, nframes, image.size / 2 ** 20),
-              "host": "{} logical cores; numpy {}".format(os.cpu_count(), np.__version__)}
+              "host": "{} physical cores / {} logical CPUs; numpy {}".format(*physical_cores(), np.__version__)}
     # how the port relates to the real reference (measured in the development
     # container, where the reference can be imported: tools/calibrate_cpu_baseline.py)
     try:
@@ -226,16 +251,16 @@ def cpu_baseline(target_seconds=12.0):
     # all cores: one forked worker per core, 500-frame slabs (64 MiB of output each)
     try:
         import multiprocessing as mp
-        ncore = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        nproc = max(1, min(ncore, 64))
+        nphys, nlogical = physical_cores()
+        nproc = max(1, nphys)
         with mp.get_context('fork').Pool(nproc) as pool:
             parts = pool.map(_cpu_worker, [(1000 + i, 500, 5.0) for i in range(nproc)])
         total = sum(p[0] for p in parts)
         slowest = max(p[1] for p in parts)
         result["all_cores"] = {"value": round(total / slowest / 1e6, 1), "unit": "Msamples/s",
-                               "cores": nproc,
-                               "what": "{} processes x 500-frame slabs for 5 s each, same loop"
-                                       .format(nproc)}
+                               "cores": nproc, "physical_cores": nphys, "logical_cpus": nlogical,
+                               "what": "{} processes (one per physical core of {} logical CPUs) x 500-frame slabs "
+                                       "for 5 s each, same loop".format(nproc, nlogical)}
     except Exception as exc:
         result["all_cores"] = {"error": repr(exc)}
     return result
@@ -633,6 +658,50 @@ def leg_cfg3(args, rank, world, device, dist, out):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_reduce(seen)
+    # Second variant: every rank scans ITS OWN slab and
+    # builds its own index -- no collective, no serial work on rank 0 -- so that
+    # a measured curve separates the broadcast's cost from rank 0's whole-file
+    # scan.  (The north_star's form is the one above; this one needs every
+    # rank to know where its slab's first frame set lies in time, which a
+    # fixed-rate file gives and a file with missing frames does not.)
+    last_local = [None]
+
+    def step_local():
+        recs = kernels.vdif_scan(slab, nsets * CFG3_THREADS, FRAME_NBYTES, HEADER_NBYTES, pattern, mask,
+                                 h0['seconds'], h0['frame_nr'] + lo, CFG3_SET_RATE)
+        src_l = kernels.build_index(recs, nsets, CFG3_THREADS, thread_slot)
+        kernels.decode_frames(slab, nsets, PAYLOAD_NBYTES, _lib.CODER_VDIF, 2, chunk=chunk,
+                              nslot=CFG3_THREADS, src=src_l, complex_data=True, out=o)
+        last_local[0] = src_l
+
+    step_local()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step_local()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed_l = time.perf_counter() - t0
+    # the two indices must be the same table
+    src_b = None
+    if rank == 0:
+        src_b = kernels.build_index(
+            kernels.vdif_scan(whole, nsets_world * CFG3_THREADS, FRAME_NBYTES, HEADER_NBYTES, pattern, mask,
+                              h0['seconds'], h0['frame_nr'], CFG3_SET_RATE), nsets_world, CFG3_THREADS, thread_slot)
+    if dist is not None:
+        src_b = broadcast_frame_index(src_b, nentries, src_rank=0, device=device)
+    loc_b, blo, _ = local_index(src_b, lo, hi, CFG3_THREADS, PAYLOAD_NBYTES)
+    same_index = torch.tensor([1.0 if torch.equal(loc_b + (blo - lo * set_nbytes), last_local[0]) else 0.0], device=device)
+    if dist is not None:
+        t = torch.tensor([elapsed_l], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_l = float(t.item())
+        dist.all_reduce(same_index, op=dist.ReduceOp.MIN)
+    del src_b, loc_b
     # sanity: set 5 of this slab, every thread, against a host re-expansion
     lev = _lib.get_levels(_lib.CODER_VDIF, 2)
     ok = True
@@ -663,6 +732,13 @@ def leg_cfg3(args, rank, world, device, dist, out):
         "roofline": {"bound": "hbm", "kernel": kname[0], "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "kernel_ms_avg": round(dec_ms, 4), "algorithmic_bytes_per_launch": alg},
+        "rank_local_scan": {
+            "what": "the same decode with every rank scanning its own slab and building its own index: "
+                    "no collective, no serial whole-file scan on rank 0",
+            "value": round(ncomplex * world * args.steps / elapsed_l / 1e6, 1),
+            "unit": "M complex samples/s (threads x channels counted)",
+            "ms_per_step": round(elapsed_l / args.steps * 1e3, 4),
+            "index_equals_broadcast": bool(same_index.item() == 1.0)},
         "sanity_spot_check": ok}
 
 
@@ -1135,7 +1211,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic', choices=('live', 'file', 'none'), default='live')
     ap.add_argument('--no-extra-legs', action='store_true',
-                    help="skip api_read / cfg3 / other_configs (headline only)")
+                    help="skip api_read / cfg3 / other_configs (headline only); same as --legs headline")
+    ap.add_argument('--legs', choices=('all', 'headline', 'cfg3'), default='all',
+                    help="all (default); headline: the headline step only, no CPU baseline, no counter passes "
+                         "(an N-GPU run finishes in well under a minute); cfg3: headline + the cfg3 leg")
     ap.add_argument('--pmc-child', action='store_true',
                     help="internal: headline kernel only, no JSON extras (run under rocprofv3 --pmc)")
     ap.add_argument('--force-dist', action='store_true',
@@ -1146,6 +1225,10 @@ def main():
     args = ap.parse_args()
     if args.pmc_child:
         args.no_cpu_baseline, args.no_extra_legs, args.traffic = True, True, 'none'
+    if args.legs == 'headline':
+        args.no_cpu_baseline, args.no_extra_legs, args.traffic = True, True, 'none'
+    elif args.legs == 'cfg3':
+        args.no_cpu_baseline, args.traffic = True, 'none'
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # not under a launcher: become one (nothing here has touched the GPU)
@@ -1335,7 +1418,7 @@ def main():
             # contract's ONE line on stdout is printed at the end)
             print("bench.py: headline before the extra legs: " + json.dumps(line),
                   file=sys.stderr, flush=True)
-        if rank == 0:
+        if rank == 0 and args.legs == 'all':
             try:
                 line["parity_digests"] = parity_digests()
             except Exception as exc:
@@ -1356,7 +1439,7 @@ def main():
             except Exception as exc:
                 line["invalid_fill"] = {"error": repr(exc)[:500]}
         locate = None
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and args.legs == 'all':
             try:
                 locate = leg_locate(image, h0, nframes)
             except Exception as exc:
@@ -1368,7 +1451,7 @@ def main():
             # (with several ranks the others run into the collective's timeout
             # and land here too; the headline measured above still gets printed)
             line["cfg3"] = {"error": repr(exc)[:500]}
-        if rank == 0 and world == 1:
+        if rank == 0 and world == 1 and args.legs == 'all':
             try:
                 line["other_configs"] = []
                 leg_other_configs(device, out, res=line["other_configs"])

@@ -15,10 +15,16 @@
  *  - plain pointers and sizes only; all `d_*` pointers are DEVICE pointers
  *    (hipMalloc'ed or equivalent); `stream` is a hipStream_t passed as void*
  *    (NULL = the default stream).
- *  - every function is stream-ordered and asynchronous w.r.t. the host, never
- *    allocates and never synchronises (graph-capturable), and keeps no
- *    mutable state except the constant level tables uploaded once per device
- *    by bb_init().
+ *  - every function of THIS header is stream-ordered and asynchronous w.r.t.
+ *    the host, never allocates and never synchronises (graph-capturable).
+ *    State the library keeps: the constant level tables uploaded once per
+ *    device by bb_init(); per host thread, the name of the last kernel
+ *    (bb_last_kernel), the last HIP error, and the geometry overrides a test or
+ *    benchmark sets with bb_tune (bbdecode_tune.h: thread-local, they change
+ *    the calling thread's later launches only and never a result).  No
+ *    process-wide knobs.  The output arena (bbdecode_arena.h) is a separate
+ *    object its creator owns: bb_arena_alloc may map memory and time a probe
+ *    launch, i.e. it does synchronise -- see that header.
  *  - return value 0 = success, negative errno-style code otherwise.  No
  *    exceptions cross the ABI.  The Python host maps BB_ENOTSUP to KeyError
  *    (the reference surfaces an unknown coder as KeyError from the _decoders

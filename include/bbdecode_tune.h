@@ -34,7 +34,9 @@ extern "C" {
 #define BB_TUNE_XPOSE_MIN_NC  28   /* blocks decoded whole go through k_decode_i8_xpose from this many channels on (default 8; selections: always from 2) */
 #define BB_TUNE_ENCODE_RUNS   30   /* k_encode_flat: runs of 256 float4 a wave takes per step, all loads in flight first: 1 or 2; default 0 = 2 for 4-bit codes, 1 otherwise (the product library builds 2 for 4-bit codes only) */
 #define BB_TUNE_M4_TILES      26   /* 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8, default 8) */
-/* BB_EINVAL for a knob this build does not have */
+/* Sets a knob for the CALLING HOST THREAD's later launches (the knobs are
+ * thread-local: another thread's launches keep the defaults).  BB_EINVAL for a
+ * knob this build does not have. */
 int bb_tune(int knob, int value);
 
 #ifdef __cplusplus

@@ -706,3 +706,32 @@ def test_loader_wave_kernel_odd_addresses_and_many_items():
     for f in (0, 5, 6, 105, 2999):
         e = np.zeros(pn * 4, np.float32) if src[f] < 0 else orc.decode_flat(raw[src[f]:src[f] + pn], 'vdif', 2)
         assert bits_equal(out[f * pn * 4:(f + 1) * pn * 4], e)
+
+
+def test_tune_knobs_are_thread_local():
+    """bb_tune changes the CALLING host thread's later launches only
+    (include/bbdecode_tune.h; VERDICT r3 next 8: no process-wide knobs): with
+    BB_TUNE_BLOCKS = 7 set on this thread, a launch from another thread keeps
+    the default grid, and this thread's launch has 7 workgroups."""
+    import threading
+    from baseband_amd import kernels, _lib
+    rng = np.random.default_rng(8)
+    raw = rng.integers(0, 256, 8032 * 64, dtype=np.uint8)
+    dbuf = kernels.to_device_bytes(raw)
+    seen = {}
+
+    def launch(name):
+        out = kernels.decode_frames(dbuf, 64, 8000, 0, 2, src0=32, src_stride=8032)
+        seen[name] = (_lib.last_kernel(), out.cpu().numpy())
+
+    kernels.tune(_lib.TUNE_BLOCKS, 7)
+    try:
+        launch('here')
+        t = threading.Thread(target=launch, args=('other',))
+        t.start()
+        t.join()
+    finally:
+        kernels.tune(_lib.TUNE_BLOCKS, 0)
+    assert ' grid 7 ' in seen['here'][0], seen['here'][0]
+    assert ' grid 7 ' not in seen['other'][0], seen['other'][0]
+    assert bits_equal(seen['here'][1], seen['other'][1])
