@@ -7,7 +7,12 @@ memory API and mapped into one virtual range it is 6.5-6.8 in every draw.  An
 `Arena` is such a range: backed on demand by 32 MiB chunks, first-fit
 allocator on top.  Tensors come from `Arena.empty()`; they alias arena memory
 through ``__cuda_array_interface__`` and give their block back when the last
-view of them dies.  `trim()` returns unused physical memory to the device.
+view of them dies.  `trim()` returns unused physical memory to the device;
+the per-device arenas of the readers (`default(device)`) trim themselves when
+their last block dies while no reader is open (`placement`): a program that
+has finished reading does not sit on a 48 GiB step (growing again costs about
+25 ms plus 5 ms per probe).  Unmapping waits first for the work that was
+queued on freed blocks (the events recorded at each free).
 
 Streams: a block goes back to the arena when the last tensor viewing it is
 garbage collected -- at once, without waiting for the work queued on it (the
@@ -47,6 +52,12 @@ class _Block:
             except Exception:           # interpreter shutdown: torch may be half gone
                 pass
             lib.bb_arena_free(arena._handle, C.c_void_p(self.ptr))
+            hook = arena.on_block_freed
+            if hook is not None:
+                try:
+                    hook(arena)
+                except Exception:
+                    pass
 
 
 _TYPESTR = {torch.float32: '<f4', torch.uint8: '|u1', torch.int32: '<i4', torch.int64: '<i8',
@@ -71,7 +82,8 @@ class Arena:
         self._range = (st['base'], st['base'] + st['capacity'])
         self._granule = int(st['chunk_bytes'])
         self._freed = []            # [(lo, hi, event, stream)] of blocks freed with work possibly in flight
-        self._lock = threading.Lock()
+        self._lock = threading.RLock()      # (re-entrant: a block's __del__ may run while it is held)
+        self.on_block_freed = None  # called with the arena after a block went back (placement: auto trim)
 
     def _note_free(self, block):
         """Remember what was queued on the block's stream when it was freed."""
@@ -107,6 +119,8 @@ class Arena:
         n = int(np.prod(shape, dtype=np.int64)) * (2 if cplx else 1)
         if n == 0:
             return torch.empty(shape, dtype=dtype, device=self.device)
+        if base not in _TYPESTR:
+            return None                 # (checked BEFORE a block is taken: the caller uses torch.empty)
         item = torch.empty(0, dtype=base).element_size()
         p = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -128,11 +142,29 @@ class Arena:
         return (self._handle is not None and tensor.is_cuda
                 and self._range[0] <= tensor.data_ptr() < self._range[1])
 
+    def _wait_freed(self):
+        """Host-wait for everything that was queued on blocks at the time they
+        were freed: their memory is about to be unmapped (bb_arena_trim /
+        bb_arena_destroy), and a kernel still writing there would fault
+        (ADVICE r3).  Live blocks are never unmapped by a trim."""
+        with self._lock:
+            pending, self._freed = self._freed, []
+        for _, _, ev, _ in pending:
+            try:
+                ev.synchronize()
+            except Exception:           # interpreter shutdown
+                pass
+
+    def live_blocks(self):
+        return int(self.stats()['blocks']) if self._handle else 0
+
     def trim(self):
         """Give physical memory that no live tensor uses back to the device
-        (whole growth steps from the end of the backed part); returns bytes."""
+        (whole growth steps from the end of the backed part); returns bytes.
+        Waits for the work queued on freed blocks first."""
         if self._handle is None:
             return 0
+        self._wait_freed()
         n = C.c_size_t()
         check(lib.bb_arena_trim(self._handle, C.byref(n)), 'bb_arena_trim')
         return int(n.value)
@@ -146,6 +178,11 @@ class Arena:
         """Release the arena's memory.  Tensors still alive become invalid."""
         h, self._handle = self._handle, None
         if h:
+            self._wait_freed()
+            try:
+                torch.cuda.synchronize(self.device)     # (work on still-live tensors, which become invalid)
+            except Exception:
+                pass
             check(lib.bb_arena_destroy(h), 'bb_arena_destroy')
 
     def __del__(self):
@@ -155,28 +192,70 @@ class Arena:
             pass
 
 
-_default = None
+_arenas = {}                    # device index -> the readers' arena on that device
+_arenas_lock = threading.Lock()
 
 
-def enable(capacity=None):
-    """Create the process-wide arena the readers take their output tensors
-    from (`placement.empty_output`) and return it; `capacity` None: the whole
-    memory of the current device (virtual range only: physical memory follows
-    the tensors).  ``disable()`` drops it."""
-    global _default
-    disable()
+def _index(device):
+    if device is None:
+        return torch.cuda.current_device()
+    device = torch.device(device)
+    return torch.cuda.current_device() if device.index is None else device.index
+
+
+def enable(capacity=None, device=None):
+    """Create the arena the readers take their output tensors from on
+    `device` (default: the current one) and return it, REPLACING one that
+    exists there (its tensors become invalid: only the program itself should
+    call this); `capacity` None: the whole memory of the device (virtual range
+    only: physical memory follows the tensors).  ``disable()`` drops it."""
+    idx = _index(device)
+    with _arenas_lock:
+        old = _arenas.pop(idx, None)
+    if old is not None:
+        old.close()
     if capacity is None:
-        capacity = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory
-    _default = Arena(capacity)
-    return _default
+        capacity = torch.cuda.get_device_properties(idx).total_memory
+    ar = Arena(capacity, device=idx)
+    with _arenas_lock:
+        _arenas[idx] = ar
+    return ar
 
 
-def disable():
-    global _default
-    a, _default = _default, None
-    if a is not None:
+def get_or_create(device, capacity=None):
+    """The arena of `device`, created if there is none yet -- under a lock and
+    WITHOUT replacing one another thread made meanwhile (lazy creation by the
+    readers: two first reads on two threads share one arena)."""
+    idx = _index(device)
+    with _arenas_lock:
+        ar = _arenas.get(idx)
+        if ar is None:
+            if capacity is None:
+                capacity = torch.cuda.get_device_properties(idx).total_memory
+            ar = _arenas[idx] = Arena(capacity, device=idx)
+        return ar
+
+
+def disable(device=None):
+    """Drop the arena of `device`; None: the arenas of every device."""
+    with _arenas_lock:
+        if device is None:
+            gone = list(_arenas.values())
+            _arenas.clear()
+        else:
+            a = _arenas.pop(_index(device), None)
+            gone = [a] if a is not None else []
+    for a in gone:
         a.close()
 
 
-def default():
-    return _default
+def default(device=None):
+    """The readers' arena on `device` (default: the current device), or None."""
+    if not _arenas:
+        return None
+    return _arenas.get(_index(device))
+
+
+def all_arenas():
+    with _arenas_lock:
+        return list(_arenas.values())

@@ -19,6 +19,7 @@ import torch
 
 from .. import kernels
 from ..placement import empty_output
+from .. import placement as _placement
 from ..staging import host_image, WindowPipeline
 
 __all__ = ['FileBase', 'VLBIFileReaderBase', 'GPUStreamReaderBase',
@@ -309,6 +310,20 @@ class GPUStreamReaderBase:
         self.offset = 0
         self._pipeline = None
         self._closed = False
+        # (open readers keep the output arena's memory; the last one to close
+        # lets it go back to the device: placement.reader_closed)
+        self._registered = True
+        _placement.reader_opened()
+
+    def _unregister(self):
+        if self.__dict__.pop('_registered', False):
+            _placement.reader_closed()
+
+    def __del__(self):
+        try:
+            self._unregister()
+        except Exception:
+            pass
 
     # -- simple attributes
     @property
@@ -367,6 +382,7 @@ class GPUStreamReaderBase:
             self._pipeline.release()
             self._pipeline = None
         self.fh_raw.close()
+        self._unregister()
 
     def __enter__(self):
         return self

@@ -161,6 +161,7 @@ class GSBStreamReader(GPUStreamReaderBase):
             for pair in self.fh_raw:
                 for fh in pair:
                     fh.close()
+        self._unregister()
 
     # -- staging: the base class streams "frame sets" of a byte image through
     # pinned buffers (staging.WindowPipeline); here set k is block k of every

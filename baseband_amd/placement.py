@@ -15,7 +15,8 @@ too: the same launches run 1-2 % faster when their INPUT lies in arena memory
 (profiles/r03u_exp_image_arena.log, r03u_exp_headline_alloc.log).  The arena is created on
 first use; it is only a virtual range until tensors need memory, and
 `release_unused()` gives unused memory back (done automatically when torch
-runs out of memory here).
+runs out of memory here, and when the last block of an arena dies while no
+reader is open).  One arena per device.
 
     BB_ARENA=0          never create one (plain ``torch.empty`` everywhere)
     BB_ARENA_GIB=<n>    capacity of the arena in GiB (default: the device's memory)
@@ -26,6 +27,7 @@ each, keep the fastest -- is gone: it needed k times the memory and still lost
 when all k draws were slow.
 """
 import os
+import threading
 import time
 import warnings
 
@@ -49,29 +51,73 @@ ARENA_MAX_BYTES = 64 << 30
 _failed = False                 # arena creation failed once: do not try again in this process
 
 
+_open_readers = 0               # stream readers open right now (GPUStreamReaderBase registers itself)
+_count_lock = threading.Lock()
+
+
+def reader_opened():
+    global _open_readers
+    with _count_lock:
+        _open_readers += 1
+
+
+def reader_closed():
+    """The last reader to close gives unused arena memory back."""
+    global _open_readers
+    with _count_lock:
+        _open_readers = max(0, _open_readers - 1)
+        last = _open_readers == 0
+    if last:
+        _auto_trim()
+
+
+def _auto_trim(ar=None):
+    """Trim when nothing needs the memory: no reader open and no live block in
+    the arena.  Growing again costs about 25 ms + 5 ms
+    per probe; BB_ARENA_KEEP=1 keeps the memory instead."""
+    if _open_readers or os.environ.get('BB_ARENA_KEEP', '0') not in ('0', '', 'no', 'off'):
+        return 0
+    freed = 0
+    for a in ([ar] if ar is not None else _arena.all_arenas()):
+        try:
+            if a._handle and a.live_blocks() == 0 and a.stats()['bytes_backed']:
+                freed += a.trim()
+        except Exception:
+            pass
+    return freed
+
+
 def _arena_for(device, create=True):
-    """The process-wide arena (created now if there is none yet and `create`
-    allows); None when switched off, on another device, or not available."""
+    """The readers' arena on `device` (one per device; created now if there is
+    none yet and `create` allows); None when switched off or not available."""
     global _failed
-    ar = _arena.default()
+    device = torch.device(device)
+    ar = _arena.default(device)
     if ar is not None:
-        return ar if ar.device == device else None
+        return ar
     if not create or _failed or os.environ.get('BB_ARENA', '1') in ('0', 'off', 'no'):
         return None
     env = os.environ.get('BB_ARENA_GIB')
     try:
-        with torch.cuda.device(device):
-            return _arena.enable(int(float(env) * 2 ** 30) if env else None)
+        ar = _arena.get_or_create(device, int(float(env) * 2 ** 30) if env else None)
+        ar.on_block_freed = _auto_trim
+        return ar
     except Exception as exc:            # no VMM on this system: the readers work without it
         _failed = True
         warnings.warn("baseband_amd: no output arena ({!r}); outputs come from torch.empty".format(exc))
         return None
 
 
-def release_unused():
-    """Give the arena's unused physical memory back to the device; bytes."""
-    ar = _arena.default()
-    return ar.trim() if ar is not None else 0
+def release_unused(device=None):
+    """Give the unused physical memory of the arenas (of `device`, default: of
+    every device) back to the device; bytes.  Call it before a large
+    allocation of your own next to open readers; the readers do it themselves
+    when THEIR allocation runs out of memory, and arenas trim by themselves
+    once nothing of theirs is alive and no reader is open."""
+    if device is not None:
+        ar = _arena.default(device)
+        return ar.trim() if ar is not None else 0
+    return sum(a.trim() for a in _arena.all_arenas())
 
 
 def empty_output(shape, dtype=torch.float32, device=None, create=True):

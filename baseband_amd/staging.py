@@ -118,7 +118,8 @@ def _pinned_give(t):
 
 def release_pinned():
     """Drop the pinned staging buffers kept for the next reader."""
-    _pinned_pool.clear()
+    with _pinned_lock:
+        _pinned_pool.clear()
 
 
 class WindowPipeline:
@@ -386,6 +387,11 @@ def write_device_bytes(fh, dev, chunk_bytes=16 << 20):
     finally:
         # (the tensor must outlive the copies that read it on the side stream)
         torch.cuda.current_stream(dev.device).wait_stream(stream)
+        # A device-to-host copy may still be writing a pinned buffer when an error
+        # (a full disk, a closed file) brings us here: the buffers go back to the
+        # SHARED pool, so the copies must have finished on the host's clock too
+        # (ADVICE r3); on the normal path everything was waited for already.
+        stream.synchronize()
         for t in pinned:
             _pinned_give(t)
 

@@ -133,7 +133,7 @@ def image_buffer(nbytes, device):
     import baseband_amd
     from baseband_amd import arena
     t = baseband_amd.empty_output((int(nbytes),), dtype=torch.uint8, device=device)
-    ar = arena.default()
+    ar = arena.default(device)
     return t, ("arena" if ar is not None and ar.owns(t) else "torch")
 
 
@@ -1079,8 +1079,11 @@ def leg_mid_size(device, image, draws=5, launches=6):
     from baseband_amd import kernels, _lib, arena, placement, vdif
     img_frames = image.numel() // FRAME_NBYTES
     nxt = [0]
+    peak_use = [0]
 
     def rate(out, nf):
+        if ar is not None:
+            peak_use[0] = max(peak_use[0], int(ar.stats()["bytes_in_use"]))
         ts = []
         for r in range(launches + 1):
             if nxt[0] + nf > img_frames:
@@ -1105,7 +1108,11 @@ def leg_mid_size(device, image, draws=5, launches=6):
                 "frac_max": round(float(f.max()), 4)}
 
     torch.cuda.empty_cache()
-    # the arena the readers create on their first large output (placement.py)
+    # the arena the readers create on their first large output (placement.py);
+    # registered as an open reader for the length of this leg: an arena whose last
+    # block dies while no reader is open gives its memory back, and every draw
+    # below would grow (and probe) a new step
+    placement.reader_opened()
     ar = placement._arena_for(device)
     res = {"arena": None if ar is None else ar.stats(),
            "method": "fresh output per draw ({} draws, torch.empty and arena blocks taking turns); per draw the median of "
@@ -1195,8 +1202,14 @@ def leg_mid_size(device, image, draws=5, launches=6):
     except Exception as exc:
         res["guppi_cf_8GiB_in"] = {"error": repr(exc)[:300]}
     if ar is not None:
-        res["arena_after"] = ar.stats()
-        res["arena_released_bytes"] = placement.release_unused()
+        st = ar.stats()
+        res["arena_after"] = st
+        res["arena_bytes_backed_per_byte_in_use_peak"] = (
+            round(st["bytes_backed"] / max(1, peak_use[0]), 2) if peak_use[0] else None)
+        res["arena_peak_bytes_in_use"] = peak_use[0]
+    placement.reader_closed()           # (the arena trims itself now: nothing of it is alive)
+    if ar is not None:
+        res["arena_bytes_backed_after_last_reader_closed"] = ar.stats()["bytes_backed"]
     return res
 
 

@@ -22,10 +22,27 @@
  * always enough: in one process every block of a 48 GiB step decoded at 5.5
  * TB/s (profiles/r03n/bench_plain.json).  Since the rate belongs to the memory,
  * a new step is PROBED with a decode-shaped launch (2^16 frames, three
- * launches, about 5 ms) and, when it is slow, held aside while the next
- * candidate is created somewhere else (up to BB_ARENA_TRIES = 4; below
- * BB_ARENA_MIN_GBPS = 6350 counts as slow); the fastest stays.  Memory is taken
- * from the device when a block needs it and goes back with bb_arena_trim.
+ * launches, about 5 ms) and, when it is slow, held aside -- unmapped -- while
+ * the next candidate is created somewhere else (up to BB_ARENA_TRIES = 4; below
+ * BB_ARENA_MIN_GBPS = 6350 counts as slow); the fastest stays.  Footprint: a
+ * step is at most HALF of the device's free memory (behind a 4 GiB margin); at
+ * most two steps exist at any moment (the best so far and the one being
+ * probed: a slower candidate goes back to the device at once); another
+ * candidate is only created while the device reports room for it plus 4 GiB.
+ * Memory is taken from the device when a block needs it and goes back with
+ * bb_arena_trim (the Python host trims by itself when the last block of the
+ * arena dies and no reader is open; growing again costs about 25 ms + 5 ms
+ * per probe).
+ *
+ * SYNCHRONISATION (unlike include/bbdecode.h's entry points): bb_arena_alloc,
+ * when it has to grow, creates and maps memory and runs the probe -- launches
+ * on the NULL stream and hipEventSynchronize -- under the arena's mutex: it
+ * blocks the calling host thread (and other threads allocating from the same
+ * arena) for 25 ms to a few hundred ms, and it is not graph-capturable.  An
+ * allocation served from free ranges does neither.  bb_arena_trim and
+ * bb_arena_destroy unmap memory: the CALLER must have waited for every launch
+ * that touches blocks freed earlier (baseband_amd/arena.py synchronises the
+ * events it recorded at each free before it calls them).
  *
  * Not stream-ordered: bb_arena_free makes the block available to the next
  * bb_arena_alloc at once; the caller must have ordered its work on the block

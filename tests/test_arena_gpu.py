@@ -153,8 +153,10 @@ def test_readers_take_their_outputs_from_the_arena(manifest, monkeypatch):
     """placement.empty_output: read() results of at least ARENA_MIN_BYTES live
     in the process-wide arena (created on first use) and are freed into it;
     smaller ones, and everything when the arena is switched off, are torch
-    allocations."""
+    allocations.  (BB_ARENA_KEEP=1: no automatic trim, so that the explicit
+    `release_unused` can be checked; the automatic one has its own test.)"""
     monkeypatch.setenv('BB_ARENA', '1')
+    monkeypatch.setenv('BB_ARENA_KEEP', '1')
     import torch
     import baseband_amd
     from baseband_amd import arena, placement, vdif
@@ -198,6 +200,7 @@ def test_large_read_lifecycle_through_the_default_arena(tmp_path, monkeypatch):
     samples are right; deleting the result frees the block; `release_unused`
     gives the memory back to the device; threads may allocate concurrently."""
     monkeypatch.setenv('BB_ARENA', '1')
+    monkeypatch.setenv('BB_ARENA_KEEP', '1')
     import threading
     import torch
     from baseband_amd import arena, placement, synth, vdif
@@ -292,3 +295,186 @@ def test_blocks_reused_on_another_stream_wait_for_the_work_left_behind():
         assert len(ar._freed) <= 65
     finally:
         ar.close()
+
+
+def test_trim_waits_for_work_queued_on_freed_blocks():
+    """a block is freed at garbage collection while its
+    decode may still be queued on a side stream; `trim()` / `close()` unmap the
+    memory, so they first wait for the events recorded at each free.  Here a
+    long chain of fills is queued on a side stream, the tensor dropped and the
+    arena trimmed at once: no fault, the device is alive afterwards, the memory
+    is back."""
+    import torch
+    from baseband_amd import arena
+    ar = arena.Arena(8 << 30)
+    try:
+        side = torch.cuda.Stream()
+        n = (1 << 30) // 4
+        with torch.cuda.stream(side):
+            t = ar.empty(n)
+            for k in range(40):                       # tens of ms of queued writes into the block
+                t.fill_(float(k))
+            del t                                     # freed with the work still in flight
+        gc.collect()
+        assert ar.stats()['blocks'] == 0 and ar.stats()['bytes_backed'] > 0
+        released = ar.trim()                          # must not unmap under the running fills
+        assert released > 0 and ar.stats()['bytes_backed'] == 0
+        assert side.query(), "trim() returned before the work on the freed block had finished"
+        torch.cuda.synchronize()
+        assert float(torch.ones(4, device='cuda').sum()) == 4.0
+        # the same through close()
+        with torch.cuda.stream(side):
+            t = ar.empty(n)
+            for k in range(40):
+                t.fill_(float(k))
+            del t
+        gc.collect()
+    finally:
+        ar.close()
+    torch.cuda.synchronize()
+    assert float(torch.ones(4, device='cuda').sum()) == 4.0
+
+
+def test_unsupported_dtype_takes_no_block():
+    """a dtype the array interface table does not know is
+    refused BEFORE a block is taken (None -> the caller uses torch.empty), and
+    `empty_output` falls back to torch for it."""
+    import torch
+    import baseband_amd
+    from baseband_amd import arena, placement
+    ar = arena.Arena(4 << 30)
+    try:
+        for dt in (torch.float16, torch.bfloat16, torch.int16, torch.bool, torch.complex128):
+            assert ar.empty(1 << 20, dtype=dt) is None
+        assert ar.stats()['blocks'] == 0 and ar.stats()['bytes_in_use'] == 0
+        assert ar.empty(1 << 20, dtype=torch.float64) is not None
+    finally:
+        ar.close()
+    t = baseband_amd.empty_output(((1 << 30) // 2 + 8,), dtype=torch.float16)       # >= 1 GiB
+    assert t.dtype == torch.float16 and t.is_cuda
+    ar = arena.default()
+    assert ar is None or not ar.owns(t)
+
+
+def test_one_arena_per_device_created_once_under_a_lock(monkeypatch):
+    """VERDICT r3 next 4c / ADVICE r3 (low): the readers' arenas are kept per
+    device; lazy creation from several threads at once yields ONE arena and
+    never replaces (closes) one that exists; only an explicit enable() does."""
+    monkeypatch.setenv('BB_ARENA', '1')
+    import threading
+    import torch
+    from baseband_amd import arena, placement
+    arena.disable()
+    try:
+        dev = torch.device('cuda', 0)
+        got = []
+        ths = [threading.Thread(target=lambda: got.append(placement._arena_for(dev))) for _ in range(8)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert len(got) == 8 and all(g is got[0] and g is not None for g in got)
+        assert arena.default(dev) is got[0] and arena.default() is got[0]
+        assert arena.default(torch.device('cuda', 7)) is None           # (no arena there: never another device's)
+        assert got[0].device == dev
+        t = got[0].empty(1 << 20)
+        assert placement._arena_for(dev) is got[0] and got[0].owns(t)   # still the same, tensor still valid
+        t.fill_(3.0)
+        assert float(t[5]) == 3.0
+        new = arena.enable(2 << 30, device=0)                           # the program's own choice replaces it
+        assert arena.default(dev) is new and new is not got[0]
+    finally:
+        arena.disable()
+
+
+def test_arena_gives_memory_back_when_nothing_needs_it(tmp_path, monkeypatch):
+    """the arena trims by itself when its last block dies
+    and no reader is open; while a reader is open the memory stays (the next
+    read reuses it); a step is at most half of the free memory."""
+    monkeypatch.setenv('BB_ARENA', '1')
+    monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
+    monkeypatch.delenv('BB_ARENA_GIB', raising=False)
+    import torch
+    from baseband_amd import arena, placement, synth, vdif
+    arena.disable()
+    nframes = 40000                                  # 5.1 GB of output
+    image, h0 = synth.random_vdif(78, nframes, payload_nbytes=8000, frame_rate=1000)
+    path = tmp_path / 'mid.vdif'
+    image.tofile(str(path))
+    try:
+        torch.cuda.empty_cache()
+        free0, _ = torch.cuda.mem_get_info()
+        fh = vdif.open(str(path), 'rs', sample_rate=32e6)
+        got = fh.read()
+        ar = arena.default()
+        assert ar is not None and ar.owns(got)
+        backed = ar.stats()['bytes_backed']
+        assert 0 < backed <= free0 // 2, (backed, free0)
+        del got
+        gc.collect()
+        assert ar.stats()['bytes_backed'] == backed, "trimmed although a reader is open"
+        fh.seek(0)
+        got = fh.read()                              # served from the same step
+        assert ar.stats()['bytes_grown'] == backed
+        fh.close()
+        assert ar.stats()['bytes_backed'] == backed, "trimmed although a block is alive"
+        last = got[-32000:].cpu().numpy()
+        del got
+        gc.collect()
+        assert ar.stats()['bytes_backed'] == 0, "the last block died with no reader open: memory goes back"
+        import bb_oracle_np as orc
+        want, _ = orc.vdif_read(image[(nframes - 1) * 8032:], frame_rate=1000)
+        assert bits_equal(last, want.reshape(-1))
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        assert free1 >= free0 - (2 << 30), (free0, free1)
+    finally:
+        arena.disable()
+
+
+def test_two_readers_and_a_callers_allocation_of_the_rest(tmp_path, monkeypatch):
+    """VERDICT r3 next 4 "done" test: with the arena limited to 64 GiB
+    (BB_ARENA_GIB), two readers each return an output of 1 GiB or more, and a
+    caller's own torch.empty of the REST of the device (what was free at the
+    start minus 64 GiB and a margin) does not run out of memory while both
+    outputs are alive: growing probes at most two steps at a time and gives
+    the slower one back at once, and never holds more than the capacity."""
+    monkeypatch.setenv('BB_ARENA', '1')
+    monkeypatch.setenv('BB_ARENA_GIB', '64')
+    monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
+    import torch
+    from baseband_amd import arena, synth, vdif
+    arena.disable()
+    nframes = 12000                                  # 1.5 GB of output each
+    paths = []
+    for k in range(2):
+        image, h0 = synth.random_vdif(80 + k, nframes, payload_nbytes=8000, frame_rate=1000)
+        p = tmp_path / 'r{}.vdif'.format(k)
+        image.tofile(str(p))
+        paths.append(str(p))
+    try:
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        free0, total = torch.cuda.mem_get_info()
+        fhs = [vdif.open(p, 'rs', sample_rate=32e6) for p in paths]
+        outs = [fh.read() for fh in fhs]
+        ar = arena.default()
+        assert ar is not None and all(ar.owns(o) for o in outs)
+        st = ar.stats()
+        assert st['capacity'] == 64 << 30 and st['bytes_backed'] <= 64 << 30
+        rest = free0 - (64 << 30) - (6 << 30)
+        assert rest > 0
+        mine = torch.empty(rest, dtype=torch.uint8, device='cuda')      # must not raise OutOfMemoryError
+        mine[:16] = 1
+        mine[-16:] = 2
+        torch.cuda.synchronize()
+        assert int(mine[0]) == 1 and int(mine[-1]) == 2
+        more = [fh.read(32000 * 100) for fh in fhs if not fh.seek(0)]   # the readers still work next to it
+        assert all(m.numel() == 3200000 for m in more)
+        del mine, more
+        for fh in fhs:
+            fh.close()
+        del outs
+        gc.collect()
+        assert ar.stats()['bytes_backed'] == 0
+    finally:
+        arena.disable()
+        torch.cuda.empty_cache()
