@@ -343,14 +343,26 @@ void launch_flat_lds(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
     with_nt(nt, [&](auto NT) {
         constexpr bool N = decltype(NT)::value;
-        if (BPS == 2 && t_arena_probe)
-            hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 1>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        // 2-bit: whole 16-byte pieces go HBM -> LDS directly (global_load_lds_dwordx4,
+        // GL = true): +1.7 % over load + ds_write_b128 at the headline size, bit-identical
+        // (profiles/r04b_exp_glds.log); variant 19 of the experiment build = the register form
+        if constexpr (BPS == 2) {
+            if (t_arena_probe)
+                hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 1, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
 #if BB_EXP
-        else if (BPS == 2 && g_tune_variant.load() == 18)
-            hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+            else if (g_tune_variant.load() == 19)
+                hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, false>), grid, dim3(2 * BB_WAVE), 0, st, a);
 #endif
-        else
+            else
+                hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        } else {
+#if BB_EXP
+            if (g_tune_variant.load() == 20)
+                hipLaunchKernelGGL((k_decode_flat_lds<BPS, N, 2, 8, BB_LV_REG, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+            else
+#endif
             hipLaunchKernelGGL((k_decode_flat_lds<BPS, N, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        }
     });
 }
 
@@ -374,19 +386,29 @@ int launch_flat_burst(bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_b
     return rc;
 }
 
-// the same staging for contiguous 8-bit output: 2 waves x up to 16 tiles.  Experiment
-// build only: measured against the plain kernel (profiles/r03zd_exp_flat8*.log) it
-// loses 2-5 % on VDIF 8-bit frames (four table reads per store) and is -1 .. +3 %
-// on int8 blocks depending on size and tiles per wave.
-void launch_flat_lds8(int coder, bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
+#endif
+
+// the same staging for contiguous 8-bit output: 2 waves x up to 16 tiles.  The
+// product builds the int8 form with direct-to-LDS loads (3b below); the
+// experiment build also the register-staged form and the table-level (VDIF
+// 8-bit) instantiations it was measured against (profiles/r03zd_exp_flat8*.log,
+// r04c_exp_glds2.log, r04d_exp_glds3_box*.log).
+void launch_flat_lds8(int coder, bool nt, bool gl, dim3 grid, hipStream_t st, const bb_flat_args &a)
 {
     with_nt(nt, [&](auto NT) {
         constexpr bool N = decltype(NT)::value;
-        if (coder == BB_CODER_INT) hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_INT8>), grid, dim3(2 * BB_WAVE), 0, st, a);
-        else                       hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_LDS>), grid, dim3(2 * BB_WAVE), 0, st, a);
+#if BB_EXP
+        if (coder == BB_CODER_INT && !gl) { hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_INT8>), grid, dim3(2 * BB_WAVE), 0, st, a); return; }
+        if (coder != BB_CODER_INT) {
+            if (gl) hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_LDS, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+            else    hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_LDS>), grid, dim3(2 * BB_WAVE), 0, st, a);
+            return;
+        }
+#endif
+        (void)coder; (void)gl;
+        hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_INT8, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
     });
 }
-#endif
 
 // the byte table kernel with dword loads handed out by ds_bpermute: contiguous
 // 1- and 4-bit output (k_lut.h)
@@ -874,10 +896,14 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
 #endif
         bool lds = p->bps == 2;
 #if BB_EXP
-        if (g_tune_variant.load() == 15 || g_tune_variant.load() == 18) lds = true;        // A/B: force either kernel for every sample width
+        if (g_tune_variant.load() == 15 || g_tune_variant.load() == 19 || g_tune_variant.load() == 20) lds = true;        // A/B: force either kernel for every sample width
         if (g_tune_variant.load() == 16) lds = false;
 #endif
-        int lut_tiles = g_tune_lut_tpw.load() * p->bps / 2;
+        // (2-bit through k_decode_flat_lds: 6 tiles per wave -- 0.851-0.859 of the peak with
+        // and without an index on three boxes, 4 tiles: 0.850-0.858 with, 0.837-0.848
+        // without; profiles/r04d_exp_glds3_box*.log.  Knob value 4 = that default.)
+        const int lt_knob = g_tune_lut_tpw.load();
+        int lut_tiles = (lds && p->bps == 2 && lt_knob == 4) ? 6 : lt_knob * p->bps / 2;
         lut_tiles = lut_tiles < 1 ? 1 : lut_tiles > (lds ? 8 : 16) ? (lds ? 8 : 16) : lut_tiles;
         const uint64_t seg_max = 2ull * (uint64_t)lut_tiles;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
@@ -897,7 +923,8 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             launch_flat_lds<2>(nt, g2, st, a);
             const char *gl = "";
 #if BB_EXP
-            if (p->bps == 2 && g_tune_variant.load() == 18) gl = ",glds";
+            if (p->bps == 2 && g_tune_variant.load() == 19) gl = ",regs";
+            if (p->bps != 2 && g_tune_variant.load() == 20) gl = ",glds";
 #endif
             BB_NOTE("k_decode_flat_lds<%d,%s,2,8%s> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", gl, g2.x, a.tpw);
         } else {
@@ -908,27 +935,43 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         return BB_OK;
     }
 
+    // 3b. contiguous int8 output (DADA, GSB, GUPPI real; 20 % of the traffic is
+    // reads): k_decode_flat_lds<8> with direct-to-LDS loads, 2 waves x 4 tiles = 8
+    // KiB of output per work item.  Against the plain kernel (4): +4.7 % at 8 GiB in
+    // on three boxes, +1.2 % at 31 GiB (profiles/r04d_exp_glds3_box*.log,
+    // r04c_exp_glds2.log); with 8 / 16 tiles per wave or register staging it
+    // loses.  VDIF 8-bit frames (table levels) stay with the plain kernel:
+    // -6 % at 8 GiB, +3 % at 31 GiB.
+    {
+        bool lds8 = om == BB_OUT_FLAT && p->bps == 8 && p->coder == BB_CODER_INT;
+        bool gl8 = true;
+        int t8 = 4;
 #if BB_EXP
-    if (om == BB_OUT_FLAT && p->bps == 8 && g_tune_flat8_lds.load() != 0) {
-        // 3b. contiguous 8-bit output: 16-byte loads staged through LDS
-        // (k_decode_flat_lds<8>), 2 waves x 16 tiles = 32 KiB of output per workgroup
-        int t8 = g_tune_lut_tpw.load() * 4;
-        t8 = t8 < 1 ? 1 : t8 > 16 ? 16 : t8;
-        const uint64_t seg_max = 2ull * (uint64_t)t8;
-        a.nseg = (ntiles + seg_max - 1) / seg_max;
-        a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
-        a.tpw = (a.seg_tiles + 1) / 2;
-        uint64_t b2 = nfs * a.nseg;
-        a.perm = make_perm(b2, out_bytes);
-        const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
-        if (b2 > cap) b2 = cap;
-        const dim3 g2((unsigned)b2);
-        launch_flat_lds8(p->coder, nt, g2, st, a);
-        BB_NOTE("k_decode_flat_lds<8,%s,%s,2,16> grid %u tiles/wave %u", lv_name(p->bps, p->coder), nt ? "nt" : "plain", g2.x, a.tpw);
-        BB_HIP(hipGetLastError());
-        return BB_OK;
-    }
+        const int f8 = g_tune_flat8_lds.load();                 // 1: staged for every coder, knobs apply; 2: plain kernel
+        if (f8 == 1) {
+            lds8 = om == BB_OUT_FLAT && p->bps == 8;
+            t8 = g_tune_lut_tpw.load() * 4;
+            t8 = t8 < 1 ? 1 : t8 > 16 ? 16 : t8;
+            gl8 = g_tune_variant.load() == 20;
+        } else if (f8 == 2) lds8 = false;
 #endif
+        if (lds8) {
+            const uint64_t seg_max = 2ull * (uint64_t)t8;
+            a.nseg = (ntiles + seg_max - 1) / seg_max;
+            a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
+            a.tpw = (a.seg_tiles + 1) / 2;
+            uint64_t b2 = nfs * a.nseg;
+            a.perm = make_perm(b2, out_bytes);
+            const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
+            if (b2 > cap) b2 = cap;
+            const dim3 g2((unsigned)b2);
+            launch_flat_lds8(p->coder, nt, gl8, g2, st, a);
+            BB_NOTE("k_decode_flat_lds<8,%s,%s,2,16%s> grid %u tiles/wave %u", lv_name(p->bps, p->coder), nt ? "nt" : "plain",
+                    gl8 ? ",glds" : "", g2.x, a.tpw);
+            BB_HIP(hipGetLastError());
+            return BB_OK;
+        }
+    }
 
     // 4. the plain kernel (k_decode_flat): one workgroup of four waves per work
     // item, loads and stores in the same iteration, uncapped grid.  8-bit

@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define BB_TUNE_FLAT_VARIANT   0   /* 5 (default) = the product dispatch; 0 = plain kernel (workgroup per work item), 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16 tiles, 4 = contiguous output cut in output space (k_decode_flat_span), 6-9 = explicit write front (k_decode_flat_front; slower), 10-12 = one pass with 2/4/8 stripes per wave (k_decode_flat_es; within +-4 % of 0 and 5), 14 = one float4 per thread and stripe (k_decode_flat_elem), 15 / 16 = the product dispatch with k_decode_flat_lds / k_decode_flat_lut forced for every sample width (A/B of the two byte-table kernels) */
+#define BB_TUNE_FLAT_VARIANT   0   /* 5 (default) = the product dispatch; 0 = plain kernel (workgroup per work item), 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16 tiles, 4 = contiguous output cut in output space (k_decode_flat_span), 6-9 = explicit write front (k_decode_flat_front; slower), 10-12 = one pass with 2/4/8 stripes per wave (k_decode_flat_es; within +-4 % of 0 and 5), 14 = one float4 per thread and stripe (k_decode_flat_elem), 15 / 16 = the product dispatch with k_decode_flat_lds / k_decode_flat_lut forced for every sample width (A/B of the two byte-table kernels), 19 = k_decode_flat_lds with register-staged loads (round 3) instead of direct-to-LDS loads, 20 = k_decode_flat_lds with direct-to-LDS loads for every sample width (with BB_TUNE_FLAT8_LDS also 8-bit) */
 #define BB_TUNE_NT_STORES      1   /* 1 (default) = non-temporal stores; 0 = plain stores */
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (no effect measured) */
 #define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* > 16: 8-bit contiguous data through the 32-tile instantiation of k_decode_flat_aln instead of the plain kernel */
@@ -29,7 +29,7 @@ extern "C" {
 #define BB_TUNE_OUT_STRIPE_S  17   /* ... that lie this many frame-slots apart: frame fs goes to slot (fs % W) * S + fs / W */
 #define BB_TUNE_BYTE_LUT      21   /* 1 (default): contiguous 1-, 2- and 4-bit decode through k_decode_flat_lut; 0: k_decode_flat_aln (register level select) */
 #define BB_TUNE_LUT_SMALL     25   /* 1: k_decode_flat_lut instantiated for at most 4 tiles per wave when the work items are that short (slower) */
-#define BB_TUNE_FLAT8_LDS     29   /* 1: contiguous 8-bit output through k_decode_flat_lds<8> (16-byte loads staged in LDS; BB_TUNE_LUT_TILES x 4 tiles per wave) instead of k_decode_flat<8>: -2..-5 % VDIF 8-bit, -1..+3 % int8 blocks (profiles/r03zd_exp_flat8*.log) */
+#define BB_TUNE_FLAT8_LDS     29   /* 0 (default): the product dispatch (int8 through k_decode_flat_lds<8> with direct-to-LDS loads, VDIF 8-bit through k_decode_flat<8>); 2: k_decode_flat<8> for both; 1: contiguous 8-bit output of every coder through k_decode_flat_lds<8> (16-byte loads staged in LDS; BB_TUNE_LUT_TILES x 4 tiles per wave) instead of k_decode_flat<8>: -2..-5 % VDIF 8-bit, -1..+3 % int8 blocks (profiles/r03zd_exp_flat8*.log) */
 
 #define BB_TUNE_BURST         31   /* 1: contiguous 2-bit output through k_decode_flat_burst (a loader wave stages long work items in LDS with direct-to-LDS loads for 3 / 7 / 15 store waves); default 0.  Measured against k_decode_flat_lds (profiles/r04a_exp_burst.log): the same time to 0.2 % in the best configuration, 2-6 % slower with the clocked loader */
 #define BB_TUNE_BURST_BYTES   32   /* ... LDS bytes per staging buffer (two per workgroup; 4096..79360, default 65536) */
