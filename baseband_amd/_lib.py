@@ -134,7 +134,7 @@ class ArenaStats(C.Structure):
                 ('bytes_in_use', C.c_uint64), ('largest_free', C.c_uint64), ('bytes_grown', C.c_uint64),
                 ('bytes_trimmed', C.c_uint64), ('chunk_bytes', C.c_uint32), ('steps', C.c_uint32),
                 ('blocks', C.c_uint32), ('probes', C.c_uint32), ('last_probe_gbps', C.c_double), ('create_ms', C.c_double),
-                ('grow_ms', C.c_double)]
+                ('grow_ms', C.c_double), ('va_reserved', C.c_uint64), ('va_used', C.c_uint64)]
 
 
 LAYOUT_GUPPI_CF = 0

@@ -79,7 +79,7 @@ class Arena:
             check(lib.bb_arena_create(int(capacity), C.byref(h)), 'bb_arena_create')
         self._handle = h
         st = self.stats()
-        self._range = (st['base'], st['base'] + st['capacity'])
+        self._range = (st['base'], st['base'] + st['va_reserved'])
         self._granule = int(st['chunk_bytes'])
         self._freed = []            # [(lo, hi, event, stream)] of blocks freed with work possibly in flight
         self._lock = threading.RLock()      # (re-entrant: a block's __del__ may run while it is held)

@@ -78,25 +78,32 @@ typedef struct bb_arena_stats {
     double   last_probe_gbps;/* decode rate the probe measured on the step taken last (0: not probed) */
     double   create_ms;      /* wall time of bb_arena_create */
     double   grow_ms;        /* wall time spent growing (create, map, probe), total */
+    uint64_t va_reserved;    /* size of the virtual range blocks lie in: [base, base + va_reserved) */
+    uint64_t va_used;        /* addresses handed to growth steps so far (never reused) */
 } bb_arena_stats;
 
-/* Reserve a virtual range of `capacity` bytes (rounded up to whole GiB) on the
- * CURRENT device.  No physical memory is taken yet.  BB_EINVAL: capacity == 0;
- * BB_EIO: a HIP call failed (no virtual memory management). */
+/* An arena that backs at most `capacity` bytes (rounded up to whole GiB) of the
+ * CURRENT device at one time.  Reserves a virtual range many times that size
+ * (32 TiB if the runtime allows; BB_ARENA_VA_GIB): addresses are handed to
+ * growth steps -- and to every probed candidate -- by a bump pointer and never
+ * reused, because new memory mapped at an address that was unmapped a moment
+ * ago can receive a kernel's stores at the OLD pages on this runtime
+ * (csrc/bb_arena.inc).  No physical memory is taken yet.  BB_EINVAL: capacity
+ * == 0; BB_EIO: a HIP call failed (no virtual memory management). */
 int bb_arena_create(size_t capacity, bb_arena **arena);
 
 /* A block of at least `bytes` (rounded up to whole granules), a whole number of
  * granules from the base (which is 2 MiB aligned at least).
- * Grows the backed part by whole GiB when no free range is large enough.
- * *d_ptr = NULL and BB_ERANGE when the capacity or the device's memory is
- * exhausted. */
+ * Grows by a step of whole GiB that holds the whole block when no free range
+ * is large enough.  *d_ptr = NULL and BB_ERANGE when the capacity, the
+ * device's memory or the virtual range is exhausted. */
 int bb_arena_alloc(bb_arena *arena, size_t bytes, void **d_ptr);
 
 /* Return a block (the pointer bb_arena_alloc gave).  BB_EINVAL: not a live block. */
 int bb_arena_free(bb_arena *arena, void *d_ptr);
 
-/* Give physical memory back to the device: growth steps at the END of the
- * backed part that hold no live block.  *released (may be NULL) = bytes. */
+/* Give physical memory back to the device: every growth step that holds no
+ * live block.  *released (may be NULL) = bytes. */
 int bb_arena_trim(bb_arena *arena, size_t *released);
 
 int bb_arena_get_stats(bb_arena *arena, bb_arena_stats *stats);

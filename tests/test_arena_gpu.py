@@ -97,35 +97,113 @@ def test_blocks_are_cut_first_fit_coalesce_grow_and_trim(small_arena):
     assert d.data_ptr() == base + 3 * G
     e = small_arena.empty(2 * f)                   # the granule left of the hole is too small
     assert e.data_ptr() == base + 10 * G
-    # growth: 3 GiB does not fit behind the 12 granules in use of the first 2 GiB step
+    # growth: 3 GiB does not fit behind the 12 granules in use of the first 2 GiB step:
+    # a new step that could hold the whole block, at addresses of its own -- here right
+    # behind the first step (nothing was burnt in between), so the free tail of
+    # the first step and the new step are one range and the block starts in the tail
     big = small_arena.empty(3 * GIB // 4)
     st = small_arena.stats()
     assert big is not None and big.data_ptr() == base + 12 * G
-    assert st['steps'] == 2 and st['bytes_backed'] == 4 * GIB         # 2 GiB + what was missing, in whole GiB
+    assert st['steps'] == 2 and st['bytes_backed'] == 5 * GIB
+    assert st['va_used'] == 5 * GIB and st['va_reserved'] >= 8 * GIB
     big.fill_(2.5)
     assert float(big[-1]) == 2.5 and float(big[big.numel() // 2]) == 2.5     # across the step boundary
-    # more than the capacity: None, nothing changes
-    assert small_arena.empty(9 * GIB // 4) is None
-    assert small_arena.stats()['bytes_backed'] == 4 * GIB
+    # more than the capacity allows next to what is backed: None, nothing changes
+    assert small_arena.empty(4 * GIB // 4) is None
+    assert small_arena.stats()['bytes_backed'] == 5 * GIB
     del a, c, d, e, big
     gc.collect()
     st = small_arena.stats()
-    assert st['bytes_in_use'] == 0 and st['largest_free'] == 4 * GIB          # everything coalesced
+    assert st['bytes_in_use'] == 0 and st['largest_free'] == 5 * GIB          # everything coalesced (adjacent steps)
     free0, _ = torch.cuda.mem_get_info()
-    assert small_arena.trim() == 4 * GIB
+    assert small_arena.trim() == 5 * GIB
     st = small_arena.stats()
-    assert st['bytes_backed'] == 0 and st['steps'] == 0 and st['bytes_trimmed'] == 4 * GIB
+    assert st['bytes_backed'] == 0 and st['steps'] == 0 and st['bytes_trimmed'] == 5 * GIB
     free1, _ = torch.cuda.mem_get_info()
-    assert free1 - free0 >= 3 * GIB                                           # the device has it back
-    # a live block in the last step pins it (and what lies before it)
-    x = small_arena.empty(f)
+    assert free1 - free0 >= 4 * GIB                                           # the device has it back
+    # after a trim the arena grows at NEW addresses (never where memory was unmapped
+    # before: csrc/bb_arena.inc) and what is decoded there is right
+    x = small_arena.empty(2 * GIB // 4)               # the whole of a new 2 GiB step
+    assert x.data_ptr() == base + 5 * GIB and small_arena.stats()['va_used'] == 7 * GIB
+    # a live block pins its step; free steps go back whatever their place
     y = small_arena.empty(3 * GIB // 4)
+    assert small_arena.stats()['steps'] == 2
     del x
     gc.collect()
-    assert small_arena.trim() == 0
+    assert small_arena.trim() == 2 * GIB and small_arena.stats()['steps'] == 1       # the FIRST of the two steps
+    y.fill_(1.25)
+    assert float(y[-1]) == 1.25
     del y
     gc.collect()
-    assert small_arena.trim() == small_arena.stats()['bytes_trimmed'] - 4 * GIB > 0
+    assert small_arena.trim() == 3 * GIB and small_arena.stats()['bytes_backed'] == 0
+
+
+def test_regrown_memory_holds_what_is_decoded_into_it(monkeypatch):
+    """Round 4: trim and grow again at once, several times, decoding DIFFERENT
+    data each time into the block and verifying all of it on the device and a
+    piece on the host.  With steps mapped at the addresses that had just been
+    unmapped, whole 32 MiB granules came back stale or zeroed (the kernel's
+    stores went to the pages mapped there before); addresses are never reused
+    now.  Also with probing (steps wide enough for the probe launch)."""
+    import torch
+    from baseband_amd import arena, kernels, _lib
+    monkeypatch.setenv('BB_ARENA_STEP_GIB', '10')
+    monkeypatch.setenv('BB_ARENA_MIN_GBPS', '7999')          # every candidate counts as slow: all tries are used
+    monkeypatch.setenv('BB_ARENA_TRIES', '3')
+    dev = torch.device('cuda')
+    npol, nchan, blk = 2, 64, 64 << 20
+    T = blk // (npol * nchan * 2)
+    nfr = 8
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    ar = arena.Arena(32 * GIB)
+    try:
+        ptrs = set()
+        for rnd in range(5):
+            image = torch.randint(0, 256, (nfr * blk,), generator=g, device=dev, dtype=torch.uint8)
+            b = image.view(torch.int8).view(nfr, nchan, T, npol, 2)
+            keep = T - 64 * rnd                      # another row layout every round
+            o = ar.empty(nfr * keep * npol * nchan * 2)
+            ptrs.add(o.data_ptr())
+            kernels.decode_i8_tiled(image, nfr, _lib.LAYOUT_GUPPI_CF, npol, nchan, T, 0, keep, src0=0, src_stride=blk, out=o)
+            torch.cuda.synchronize()
+            ov = o.view(nfr, keep, npol, nchan, 2)
+            for fr in range(nfr):
+                assert torch.equal(ov[fr], b[fr, :, :keep].permute(1, 2, 0, 3).to(torch.float32)), (rnd, fr)
+            host = ov[nfr - 1, :2048].cpu().numpy()
+            assert np.array_equal(host, b[nfr - 1, :, :2048].permute(1, 2, 0, 3).to(torch.float32).cpu().numpy())
+            st = ar.stats()
+            assert st['steps'] == 1 and st['probes'] == 3 * (rnd + 1)
+            del o, ov
+            gc.collect()
+            assert ar.trim() == 10 * GIB
+        assert len(ptrs) == 5, "a step was mapped at addresses used before"
+        assert ar.stats()['va_used'] >= 5 * 3 * 10 * GIB
+    finally:
+        ar.close()
+
+
+def test_a_used_up_virtual_range_is_an_orderly_failure(monkeypatch):
+    """When the bump pointer reaches the end of the reserved range the arena
+    answers None (the readers then use torch.empty) instead of reusing addresses."""
+    import torch
+    from baseband_amd import arena
+    monkeypatch.setenv('BB_ARENA_STEP_GIB', '2')
+    monkeypatch.setenv('BB_ARENA_VA_GIB', '6')
+    ar = arena.Arena(4 * GIB)
+    try:
+        assert ar.stats()['va_reserved'] == 6 * GIB
+        for k in range(3):
+            t = ar.empty(1 << 20)
+            assert t is not None
+            t.fill_(k)
+            del t
+            gc.collect()
+            assert ar.trim() == 2 * GIB
+        assert ar.stats()['va_used'] == 6 * GIB
+        assert ar.empty(1 << 20) is None
+    finally:
+        ar.close()
 
 
 def test_raw_abi_rejects_what_is_not_a_block(small_arena):
