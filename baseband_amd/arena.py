@@ -8,10 +8,9 @@ memory API and mapped into one virtual range it is 6.5-6.8 in every draw.  An
 allocator on top.  Tensors come from `Arena.empty()`; they alias arena memory
 through ``__cuda_array_interface__`` and give their block back when the last
 view of them dies.  `trim()` returns unused physical memory to the device;
-the per-device arenas of the readers (`default(device)`) trim themselves when
-their last block dies while no reader is open (`placement`): a program that
-has finished reading does not sit on a 48 GiB step (growing again costs about
-25 ms plus 5 ms per probe).  Unmapping waits first for the work that was
+the per-device arenas of the readers (`default(device)`) trim themselves once
+they have held no block for a few seconds with no reader open (`placement`): a
+program that has finished reading does not sit on a 48 GiB step.  Unmapping waits first for the work that was
 queued on freed blocks (the events recorded at each free).
 
 Streams: a block goes back to the arena when the last tensor viewing it is

@@ -172,7 +172,7 @@ thread_local bb_knob g_tune_seg_tiles{0};    // plain kernel: tiles per workgrou
 thread_local bb_knob g_tune_gather_chunks{32};   // chunks below this many floats go through k_decode_gather
 thread_local bb_knob g_tune_mkbf_tc{32};
 thread_local bb_knob g_tune_rows_tiles{8};          // tiles per work item of k_decode_rows_pipe (1..8)
-thread_local bb_knob g_tune_lut_tpw{4};             // tiles per wave and work item of k_decode_flat_lut
+thread_local bb_knob g_tune_lut_tpw{0};             // tiles per wave and work item of the byte-table kernels; 0 = by kernel
 thread_local bb_knob g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
 thread_local bb_knob g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
 thread_local bb_knob g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
@@ -489,7 +489,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_MKBF_CHANNELS: g_tune_mkbf_tc = (value >= 2 && value <= 64 && !(value & 1)) ? value : 32; return BB_OK;
         case BB_TUNE_M4_WIDEN: g_tune_m4_widen = value; return BB_OK;
         case BB_TUNE_M4_TILES: g_tune_m4_tiles = (value >= 1 && value <= BB_M4_TPW) ? value : BB_M4_TPW; return BB_OK;
-        case BB_TUNE_LUT_TILES: g_tune_lut_tpw = (value >= 1 && value <= 16) ? value : 4; return BB_OK;
+        case BB_TUNE_LUT_TILES: g_tune_lut_tpw = (value >= 1 && value <= 16) ? value : 0; return BB_OK;
         case BB_TUNE_SELECT_BYTES:
             if (value < 256 || value > 32768) return BB_EINVAL;
             g_tune_select_bytes = value; return BB_OK;
@@ -901,9 +901,9 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
 #endif
         // (2-bit through k_decode_flat_lds: 6 tiles per wave -- 0.851-0.859 of the peak with
         // and without an index on three boxes, 4 tiles: 0.850-0.858 with, 0.837-0.848
-        // without; profiles/r04d_exp_glds3_box*.log.  Knob value 4 = that default.)
+        // without; profiles/r04d_exp_glds3_box*.log.  Knob 0 = these defaults.)
         const int lt_knob = g_tune_lut_tpw.load();
-        int lut_tiles = (lds && p->bps == 2 && lt_knob == 4) ? 6 : lt_knob * p->bps / 2;
+        int lut_tiles = lt_knob == 0 ? ((lds && p->bps == 2) ? 6 : 4 * p->bps / 2) : lt_knob * p->bps / 2;
         lut_tiles = lut_tiles < 1 ? 1 : lut_tiles > (lds ? 8 : 16) ? (lds ? 8 : 16) : lut_tiles;
         const uint64_t seg_max = 2ull * (uint64_t)lut_tiles;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
@@ -950,7 +950,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         const int f8 = g_tune_flat8_lds.load();                 // 1: staged for every coder, knobs apply; 2: plain kernel
         if (f8 == 1) {
             lds8 = om == BB_OUT_FLAT && p->bps == 8;
-            t8 = g_tune_lut_tpw.load() * 4;
+            t8 = (g_tune_lut_tpw.load() ? g_tune_lut_tpw.load() : 4) * 4;
             t8 = t8 < 1 ? 1 : t8 > 16 ? 16 : t8;
             gl8 = g_tune_variant.load() == 20;
         } else if (f8 == 2) lds8 = false;

@@ -15,11 +15,14 @@ too: the same launches run 1-2 % faster when their INPUT lies in arena memory
 (profiles/r03u_exp_image_arena.log, r03u_exp_headline_alloc.log).  The arena is created on
 first use; it is only a virtual range until tensors need memory, and
 `release_unused()` gives unused memory back (done automatically when torch
-runs out of memory here, and when the last block of an arena dies while no
-reader is open).  One arena per device.
+runs out of memory here, and once the arenas have held no block for
+BB_ARENA_IDLE_S = 5 seconds with no reader open).  One arena per device.
 
     BB_ARENA=0          never create one (plain ``torch.empty`` everywhere)
     BB_ARENA_GIB=<n>    capacity of the arena in GiB (default: the device's memory)
+    BB_ARENA_IDLE_S=<s> seconds without a live block or an open reader after which the
+                        arenas give their memory back (default 5; 0 = at once)
+    BB_ARENA_KEEP=1     never give memory back automatically
     baseband_amd.arena.enable(capacity) / .disable()   the same from the program
 
 Round 2's `empty_output(shape, candidates=k)` -- allocate k tensors, probe
@@ -71,20 +74,60 @@ def reader_closed():
         _auto_trim()
 
 
-def _auto_trim(ar=None):
-    """Trim when nothing needs the memory: no reader open and no live block in
-    the arena.  Growing again costs about 25 ms + 5 ms
-    per probe; BB_ARENA_KEEP=1 keeps the memory instead."""
-    if _open_readers or os.environ.get('BB_ARENA_KEEP', '0') not in ('0', '', 'no', 'off'):
+_idle_timer = None
+_idle_lock = threading.Lock()
+
+
+def _idle_seconds():
+    try:
+        return float(os.environ.get('BB_ARENA_IDLE_S', '5'))
+    except ValueError:
+        return 5.0
+
+
+def _nothing_alive():
+    return not _open_readers and all(a.live_blocks() == 0 for a in _arena.all_arenas() if a._handle)
+
+
+def _trim_idle():
+    """Timer body: trim the arenas if STILL nothing needs their memory."""
+    global _idle_timer
+    with _idle_lock:
+        _idle_timer = None
+    if os.environ.get('BB_ARENA_KEEP', '0') not in ('0', '', 'no', 'off') or not _nothing_alive():
         return 0
     freed = 0
-    for a in ([ar] if ar is not None else _arena.all_arenas()):
+    for a in _arena.all_arenas():
         try:
             if a._handle and a.live_blocks() == 0 and a.stats()['bytes_backed']:
                 freed += a.trim()
         except Exception:
             pass
     return freed
+
+
+def _auto_trim(ar=None):
+    """A block died or the last reader closed: when no reader is open and no
+    arena holds a live block, give the memory back -- after BB_ARENA_IDLE_S
+    seconds (default 5) in which that stays so.  Not at
+    once: growing again is not cheap -- memory that was released before is
+    cleared by the driver when it is created again, 1.5 s for a 48 GiB step
+    (profiles/r04h_prof_arena_grow.log) -- and a script that reads file after
+    file drops to "nothing alive" between two reads all the time.
+    BB_ARENA_IDLE_S=0: at once; BB_ARENA_KEEP=1: never."""
+    global _idle_timer
+    if _open_readers or os.environ.get('BB_ARENA_KEEP', '0') not in ('0', '', 'no', 'off'):
+        return 0
+    delay = _idle_seconds()
+    if delay <= 0:
+        return _trim_idle() if _nothing_alive() else 0
+    with _idle_lock:
+        if _idle_timer is not None:
+            _idle_timer.cancel()
+        _idle_timer = threading.Timer(delay, _trim_idle)
+        _idle_timer.daemon = True
+        _idle_timer.start()
+    return 0
 
 
 def _arena_for(device, create=True):

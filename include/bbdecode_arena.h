@@ -23,22 +23,29 @@
  * TB/s (profiles/r03n/bench_plain.json).  Since the rate belongs to the memory,
  * a new step is PROBED with a decode-shaped launch (2^16 frames, three
  * launches, about 5 ms) and, when it is slow, held aside -- unmapped -- while
- * the next candidate is created somewhere else (up to BB_ARENA_TRIES = 4; below
- * BB_ARENA_MIN_GBPS = 6350 counts as slow); the fastest stays.  Footprint: a
+ * the next candidate is created somewhere else (BB_ARENA_TRIES = 2 candidates
+ * by default: one second try; with more, none once two candidates probe within
+ * 4 % of each other; below BB_ARENA_MIN_GBPS = 6350 counts as slow); the
+ * fastest stays.  Fourteen candidates on one box probed at 5.77-6.52 TB/s, the
+ * first one of a growth (memory nothing else holds) mostly the fastest
+ * (profiles/r04h_prof_arena_grow.log).  Footprint: a
  * step is at most HALF of the device's free memory (behind a 4 GiB margin); at
  * most two steps exist at any moment (the best so far and the one being
  * probed: a slower candidate goes back to the device at once); another
  * candidate is only created while the device reports room for it plus 4 GiB.
  * Memory is taken from the device when a block needs it and goes back with
- * bb_arena_trim (the Python host trims by itself when the last block of the
- * arena dies and no reader is open; growing again costs about 25 ms + 5 ms
- * per probe).
+ * bb_arena_trim (the Python host trims by itself once an arena has held no
+ * block for BB_ARENA_IDLE_S = 5 seconds with no reader open).  What growing
+ * costs (profiles/r04h_prof_arena_grow.log): creating 48 GiB of memory that was
+ * never used in this boot takes 11 ms, of memory that was released before --
+ * by this or an earlier process -- 1.5-1.9 s (the driver clears it on
+ * creation); mapping 12 ms; a probe 7 ms.
  *
  * SYNCHRONISATION (unlike include/bbdecode.h's entry points): bb_arena_alloc,
  * when it has to grow, creates and maps memory and runs the probe -- launches
  * on the NULL stream and hipEventSynchronize -- under the arena's mutex: it
  * blocks the calling host thread (and other threads allocating from the same
- * arena) for 25 ms to a few hundred ms, and it is not graph-capturable.  An
+ * arena) for 30 ms to several seconds, and it is not graph-capturable.  An
  * allocation served from free ranges does neither.  bb_arena_trim and
  * bb_arena_destroy unmap memory: the CALLER must have waited for every launch
  * that touches blocks freed earlier (baseband_amd/arena.py synchronises the

@@ -29,7 +29,7 @@ extern "C" {
 #define BB_TUNE_XPOSE_ROWS    20   /* k_decode_i8_xpose: tile length, 128 or 64 (output rows of a 64-channel tile); default 0 = 64 for MKBF heaps in 64-channel tiles, 128 otherwise */
 #define BB_TUNE_M4_WIDEN      22   /* 1 (default): 16- and 32-track Mark 4 units whose word count and fill prefix allow it are decoded as 64-bit super-words by the 64-track kernels; 0: always the native word size */
 #define BB_TUNE_SELECT_BYTES  23   /* payload bytes (all thread slots together) that k_decode_gather_select stages in LDS per work item (256..32768, default 16384) */
-#define BB_TUNE_LUT_TILES     24   /* upper bound of 256-byte tiles per wave and work item of the byte-table kernels, stated for 2-bit samples (1..16; half as many for 1-bit, twice as many for 4-bit samples).  Default 4 = 32 KiB of output per work item for k_decode_flat_lut (1- and 4-bit) and SIX tiles (48 KiB) for the 2-bit kernel k_decode_flat_lds; any other value is taken as it is */
+#define BB_TUNE_LUT_TILES     24   /* upper bound of 256-byte tiles per wave and work item of the byte-table kernels, stated for 2-bit samples (1..16; half as many for 1-bit, twice as many for 4-bit samples).  Default 0 = by kernel: 4 (32 KiB of output per work item) for k_decode_flat_lut (1- and 4-bit), 6 (48 KiB) for the 2-bit kernel k_decode_flat_lds */
 #define BB_TUNE_XPOSE_TC      27   /* k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; default 0 = 32 for channels-first blocks, 16 for time-first blocks, 64 for MKBF heaps, and never wider than the decoded channels need */
 #define BB_TUNE_XPOSE_MIN_NC  28   /* blocks decoded whole go through k_decode_i8_xpose from this many channels on (default 8; selections: always from 2) */
 #define BB_TUNE_ENCODE_RUNS   30   /* k_encode_flat: runs of 256 float4 a wave takes per step, all loads in flight first: 1 or 2; default 0 = 2 for 4-bit codes, 1 otherwise (the product library builds 2 for 4-bit codes only) */

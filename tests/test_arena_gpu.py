@@ -173,12 +173,12 @@ def test_regrown_memory_holds_what_is_decoded_into_it(monkeypatch):
             host = ov[nfr - 1, :2048].cpu().numpy()
             assert np.array_equal(host, b[nfr - 1, :, :2048].permute(1, 2, 0, 3).to(torch.float32).cpu().numpy())
             st = ar.stats()
-            assert st['steps'] == 1 and st['probes'] == 3 * (rnd + 1)
+            assert st['steps'] == 1 and 2 * (rnd + 1) <= st['probes'] <= 3 * (rnd + 1)     # (two within 4 %: no third)
             del o, ov
             gc.collect()
             assert ar.trim() == 10 * GIB
         assert len(ptrs) == 5, "a step was mapped at addresses used before"
-        assert ar.stats()['va_used'] >= 5 * 3 * 10 * GIB
+        assert ar.stats()['va_used'] >= 5 * 3 * 10 * GIB          # two or three candidates + the best mapped again, per growth
     finally:
         ar.close()
 
@@ -468,6 +468,7 @@ def test_arena_gives_memory_back_when_nothing_needs_it(tmp_path, monkeypatch):
     and no reader is open; while a reader is open the memory stays (the next
     read reuses it); a step is at most half of the free memory."""
     monkeypatch.setenv('BB_ARENA', '1')
+    monkeypatch.setenv('BB_ARENA_IDLE_S', '0')           # (the default waits 5 s; its timer has a test of its own)
     monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
     monkeypatch.delenv('BB_ARENA_GIB', raising=False)
     import torch
@@ -517,6 +518,7 @@ def test_two_readers_and_a_callers_allocation_of_the_rest(tmp_path, monkeypatch)
     the slower one back at once, and never holds more than the capacity."""
     monkeypatch.setenv('BB_ARENA', '1')
     monkeypatch.setenv('BB_ARENA_GIB', '64')
+    monkeypatch.setenv('BB_ARENA_IDLE_S', '0')
     monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
     import torch
     from baseband_amd import arena, synth, vdif
@@ -556,3 +558,39 @@ def test_two_readers_and_a_callers_allocation_of_the_rest(tmp_path, monkeypatch)
     finally:
         arena.disable()
         torch.cuda.empty_cache()
+
+
+def test_idle_arena_trims_after_the_delay_and_not_between_reads(monkeypatch):
+    """The automatic trim waits BB_ARENA_IDLE_S with nothing alive: a block
+    taken inside the delay cancels it (no trim / regrow between two reads of a
+    loop), an arena left alone gives its memory back."""
+    import time
+    import torch
+    import baseband_amd
+    from baseband_amd import arena, placement
+    monkeypatch.setenv('BB_ARENA', '1')
+    monkeypatch.setenv('BB_ARENA_IDLE_S', '1.0')
+    monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
+    arena.disable()
+    try:
+        monkeypatch.setattr(placement, 'ARENA_MIN_BYTES', 1 << 20)
+        t = baseband_amd.empty_output((1 << 22,))
+        ar = arena.default()
+        assert ar is not None and ar.owns(t)
+        backed = ar.stats()['bytes_backed']
+        for k in range(3):                                   # "reads" 0.4 s apart: never trimmed
+            del t
+            gc.collect()
+            time.sleep(0.4)
+            assert ar.stats()['bytes_backed'] == backed
+            t = baseband_amd.empty_output((1 << 22,))
+            assert ar.stats()['bytes_grown'] == backed
+        time.sleep(1.5)
+        assert ar.stats()['bytes_backed'] == backed, "trimmed under a live block"
+        del t
+        gc.collect()
+        assert ar.stats()['bytes_backed'] == backed          # not at once ...
+        time.sleep(2.0)
+        assert ar.stats()['bytes_backed'] == 0               # ... but after the delay
+    finally:
+        arena.disable()

@@ -488,7 +488,7 @@ def test_one_pass_striped_kernel_matches_oracle(variant, coder, bps):
         tune_exp(_lib.TUNE_FLAT_VARIANT, 5)
 
 
-@pytest.mark.parametrize('tiles', [1, 2, 3, 4, 5, 8, 16])
+@pytest.mark.parametrize('tiles', [0, 1, 2, 3, 4, 5, 6, 8, 16])
 @pytest.mark.parametrize('coder,bps', [('vdif', 1), ('vdif', 2), ('mark5b', 1), ('mark5b', 2), ('vdif', 4), ('int', 4)])
 def test_byte_table_kernel_geometries(tiles, coder, bps):
     """k_decode_flat_lut with 1 .. 16 tiles per wave and work item, persistent
@@ -515,7 +515,7 @@ def test_byte_table_kernel_geometries(tiles, coder, bps):
                 exp[f] = -7.5 if src[f] < 0 else orc.decode_flat(raw[src[f]:src[f] + pn], coder, bps)
             assert bits_equal(out, exp.reshape(-1)), (tiles, coder, bps, pn, header, cap, _lib.last_kernel())
     finally:
-        kernels.tune(_lib.TUNE_LUT_TILES, 4)
+        kernels.tune(_lib.TUNE_LUT_TILES, 0)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
 
 

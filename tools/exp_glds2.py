@@ -1,5 +1,5 @@
-"""(Knob values as of the round-4 promotion: BB_TUNE_LUT_TILES 4 = the default = 6 tiles per wave
-for the 2-bit kernel, 2 = 4 tiles; BB_TUNE_FLAT8_LDS 2 = the plain 8-bit kernel.)
+"""(Knob values as of the round-4 promotion: BB_TUNE_LUT_TILES 0 = the default = 6 tiles per wave
+for the 2-bit kernel; BB_TUNE_FLAT8_LDS 2 = the plain 8-bit kernel.)
 Round 4: direct-to-LDS loads (global_load_lds_dwordx4) beyond the headline
 case.  Same process, same buffers, interleaved repeats, bit-identity checked:
   (1) 2-bit headline launch: tiles per wave 2 / 4 / 6 / 8 with the glds kernel;
@@ -53,7 +53,7 @@ def digest(o, n=1 << 26):
     return [int(w[k:k + n].to(torch.int64).sum().item()) for k in (0, (m // 2) & ~3, m - n)]
 
 
-def setk(variant=5, tiles=4, flat8=0):
+def setk(variant=5, tiles=0, flat8=0):
     kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
     kernels.tune(_lib.TUNE_LUT_TILES, tiles)
     kernels.tune(_lib.TUNE_FLAT8_LDS, flat8)

@@ -1,5 +1,5 @@
-"""(Knob values as of the round-4 promotion: BB_TUNE_LUT_TILES 4 = the default = 6 tiles per wave
-for the 2-bit kernel, 2 = 4 tiles; BB_TUNE_FLAT8_LDS 2 = the plain 8-bit kernel.)
+"""(Knob values as of the round-4 promotion: BB_TUNE_LUT_TILES 0 = the default = 6 tiles per wave
+for the 2-bit kernel; BB_TUNE_FLAT8_LDS 2 = the plain 8-bit kernel.)
 Round 4: is the direct-to-LDS form worth keeping?  A/Bs of +-1.5 % flip
 between boxes and allocations, so this script is run on SEVERAL fresh boxes
 (profiles/r04d_exp_glds3_box*.log) under the conditions of bench.py: the 8 GiB
@@ -49,7 +49,7 @@ def digest(o, n=1 << 26):
     return [int(w[k:k + n].to(torch.int64).sum().item()) for k in (0, (m // 2) & ~3, m - n)]
 
 
-def setk(variant=5, tiles=4, flat8=0):
+def setk(variant=5, tiles=0, flat8=0):
     kernels.tune(_lib.TUNE_FLAT_VARIANT, variant)
     kernels.tune(_lib.TUNE_LUT_TILES, tiles)
     kernels.tune(_lib.TUNE_FLAT8_LDS, flat8)
@@ -76,11 +76,11 @@ def compare(name, fn, alg, arms, rounds=4):
 compare("headline: cfg2 image + index -> 127.5 GiB",
         lambda: kernels.decode_frames(image, nframes, PAY, _lib.CODER_VDIF, 2, src=src, out=out),
         nframes * (FRAME + PAY * 16),
-        [("regs_t4", dict(variant=19, tiles=2)), ("glds_t4", dict(tiles=2)), ("regs_t6", dict(variant=19)), ("glds_t6", dict())])
+        [("regs_t4", dict(variant=19, tiles=4)), ("glds_t4", dict(tiles=4)), ("regs_t6", dict(variant=19, tiles=6)), ("glds_t6", dict())])
 compare("the same without the index (fixed stride)",
         lambda: kernels.decode_frames(image, nframes, PAY, _lib.CODER_VDIF, 2, src0=HDR, src_stride=FRAME, out=out),
         nframes * (FRAME + PAY * 16),
-        [("regs_t4", dict(variant=19, tiles=2)), ("glds_t4", dict(tiles=2)), ("regs_t6", dict(variant=19)), ("glds_t6", dict())])
+        [("regs_t4", dict(variant=19, tiles=4)), ("glds_t4", dict(tiles=4)), ("regs_t6", dict(variant=19, tiles=6)), ("glds_t6", dict())])
 o4 = out[:nframes * 16000]
 compare("VDIF 4-bit, the same image",
         lambda: kernels.decode_frames(image, nframes, PAY, _lib.CODER_VDIF, 4, src0=HDR, src_stride=FRAME, out=o4),
