@@ -10,6 +10,7 @@ Ordering is by events only; nothing blocks the device.
 import mmap
 import os
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -122,6 +123,28 @@ def release_pinned():
         _pinned_pool.clear()
 
 
+# When a list, WindowPipeline.run appends one record per window: host time
+# waiting for a pinned buffer, host time of the page-cache copy, host time to
+# enqueue, and the events around the H2D copy and around the window's kernels
+# (`window_trace_summary`).  bench.py's `pipeline` leg and tools/ set it.
+trace = None
+
+
+def window_trace_summary(rows):
+    """Totals of a `trace` list (call after the read has been synchronised)."""
+    if not rows:
+        return None
+    nb = sum(r["bytes"] for r in rows)
+    h2d = sum(r["events"][0].elapsed_time(r["events"][1]) for r in rows)
+    ker = sum(r["events"][2].elapsed_time(r["events"][3]) for r in rows)
+    host = {k: sum(r[k] for r in rows) for k in ("wait_ms", "host_copy_ms", "enqueue_ms")}
+    return {"windows": len(rows), "bytes": nb,
+            "host_wait_for_buffer_ms": round(host["wait_ms"], 2), "host_copy_ms": round(host["host_copy_ms"], 2),
+            "host_enqueue_ms": round(host["enqueue_ms"], 2),
+            "host_copy_GBps": round(nb / max(host["host_copy_ms"], 1e-6) / 1e6, 1),
+            "h2d_ms": round(h2d, 2), "h2d_GBps": round(nb / max(h2d, 1e-6) / 1e6, 1), "kernels_ms": round(ker, 2)}
+
+
 class WindowPipeline:
     """Stream byte windows of a host image through pinned buffers to HBM and
     call ``process(dev_bytes, index)`` for each on the compute stream."""
@@ -182,20 +205,34 @@ class WindowPipeline:
                 raise ValueError("window larger than staging buffer")
             b = self._count % self.nbuf         # rotation continues across run() calls
             self._count += 1
+            tr = trace                          # (per-window times for bench.py / tools: None in normal use)
+            t0 = time.perf_counter() if tr is not None else 0.0
             if self._done[b] is not None:
                 self._done[b].synchronize()          # buffer b free again
+            t1 = time.perf_counter() if tr is not None else 0.0
             pinned, dev = self._buffers(b, need_dev=sink is None)
             target = dev[:n] if sink is None else sink[lo:hi]
             _stage(pinned.numpy(), self.image, lo, hi)           # page cache -> pinned (CPU)
+            t2 = time.perf_counter() if tr is not None else 0.0
             with torch.cuda.stream(self._copy_stream):
+                if tr is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self._copy_stream)
                 target.copy_(pinned[:n], non_blocking=True)
-                copied = torch.cuda.Event()
+                copied = torch.cuda.Event(enable_timing=tr is not None)
                 copied.record(self._copy_stream)
             main.wait_event(copied)
+            if tr is not None:
+                k0 = torch.cuda.Event(enable_timing=True)
+                k0.record(main)
             process(target, i)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=tr is not None)
             done.record(main)
             self._done[b] = done
+            if tr is not None:
+                t3 = time.perf_counter()
+                tr.append({"bytes": n, "wait_ms": (t1 - t0) * 1e3, "host_copy_ms": (t2 - t1) * 1e3,
+                           "enqueue_ms": (t3 - t2) * 1e3, "t_start": t0, "t_end": t3, "events": (e0, copied, k0, done)})
 
     def drain(self):
         for ev in self._done:
