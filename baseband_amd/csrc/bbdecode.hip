@@ -152,6 +152,7 @@ int device_levels(int coder, int lb, const float **p)
 // ~4000 resident ones lets the dispatcher even out the tail, while each still
 // walks several items with its loads one item ahead.
 #define BB_GRID_CAP 131072ull
+#define BB_LOCATE_GRID 65536ull      // the byte-granular searches (bb_*_locate)
 
 // ---- tuning (include/bbdecode_tune.h; the experiment build adds bbdecode_exp.h) ----
 // The knobs are THREAD-LOCAL: bb_tune() changes the geometry of the calling
@@ -186,6 +187,7 @@ thread_local bb_knob g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a sele
 thread_local bb_knob g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
 thread_local bb_knob g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 #if BB_EXP
+thread_local bb_knob g_tune_copy{0};         // k_copy_frames: loads per lane | non-temporal loads << 8 (0 = 4 | 1 << 8)
 thread_local bb_knob g_tune_variant{5};      // 5 = the product dispatch; others: include/bbdecode_exp.h
 thread_local bb_knob g_tune_burst{0};         // 1: contiguous 2-bit output through k_decode_flat_burst (k_burst.h)
 thread_local bb_knob g_tune_burst_bytes{65536};   // ... LDS bytes per staging buffer
@@ -501,6 +503,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
 #if BB_EXP
         case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
+        case BB_TUNE_COPY: g_tune_copy = value; return BB_OK;
         case BB_TUNE_BURST: g_tune_burst = value; return BB_OK;
         case BB_TUNE_BURST_BYTES: g_tune_burst_bytes = (value >= 4096 && value <= 79360) ? (value & ~255) : 65536; return BB_OK;
         case BB_TUNE_BURST_PERIOD: g_tune_burst_period = value > 0 ? value : 0; return BB_OK;
@@ -581,7 +584,10 @@ int bb_vdif_locate(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *
     if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
     if (nbytes < p->frame_nbytes || p->frame_nbytes < 32) return BB_OK;
     uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    // (65536 workgroups: 5.1-5.8 TB/s on the 8 GiB image, 16384: 5.0-5.2, 131072: 4.3-4.4;
+    // profiles/r04l_locate.log -- the workgroups' confirm phases overlap other workgroups' sweeps)
+    const uint64_t lcap = g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID;
+    if (blocks > lcap) blocks = lcap;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_vdif_locate, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
                        (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_offsets, (uint64_t)cap, d_count);
@@ -640,7 +646,7 @@ int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets, size_
     if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
     if (nbytes < BB_M5B_FRAME) return BB_OK;
     uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks > (g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID)) blocks = g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_mark5b_locate, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
                        (const uint8_t *)d_buf, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count);
@@ -1136,7 +1142,13 @@ int bb_copy_frames(const void *d_buf, size_t buf_nbytes, size_t nframes, uint64_
     bb_copy_args a;
     a.buf = (const uint8_t *)d_buf; a.out = (uint8_t *)d_out;
     a.nframes = nframes; a.n = nbytes_per_frame;
-    a.nseg = (nbytes_per_frame + BB_COPY_ITEM - 1) / BB_COPY_ITEM;
+    int nl = 4, ntl = 1;
+#if BB_EXP
+    { const int cv = g_tune_copy.load(); if (cv) { nl = cv & 0xff; ntl = (cv >> 8) & 1; } }
+    if (nl != 2 && nl != 4 && nl != 8 && nl != 16) nl = 4;
+#endif
+    const uint64_t item = (uint64_t)nl * BB_BLOCK * 16;
+    a.nseg = (nbytes_per_frame + item - 1) / item;
     a.src0 = src0; a.src_stride = src_stride;
     const uint64_t nwork = (uint64_t)nframes * a.nseg;
     a.perm = make_perm(nwork, (uint64_t)nframes * nbytes_per_frame);
@@ -1151,10 +1163,18 @@ int bb_copy_frames(const void *d_buf, size_t buf_nbytes, size_t nframes, uint64_
     const bool nt = tune_nt();
     with_nt(nt, [&](auto NT) {
         constexpr bool N = decltype(NT)::value;
-        if (v16) hipLaunchKernelGGL((k_copy_frames<N, true>), grid, dim3(BB_BLOCK), 0, st, a);
-        else     hipLaunchKernelGGL((k_copy_frames<N, false>), grid, dim3(BB_BLOCK), 0, st, a);
+        if (!v16) { hipLaunchKernelGGL((k_copy_frames<N, false>), grid, dim3(BB_BLOCK), 0, st, a); return; }
+#if BB_EXP
+        if (nl == 2 && ntl)  { hipLaunchKernelGGL((k_copy_frames<N, true, 2, true>), grid, dim3(BB_BLOCK), 0, st, a); return; }
+        if (nl == 8 && ntl)  { hipLaunchKernelGGL((k_copy_frames<N, true, 8, true>), grid, dim3(BB_BLOCK), 0, st, a); return; }
+        if (nl == 16 && ntl) { hipLaunchKernelGGL((k_copy_frames<N, true, 16, true>), grid, dim3(BB_BLOCK), 0, st, a); return; }
+        if (nl == 4 && !ntl) { hipLaunchKernelGGL((k_copy_frames<N, true, 4, false>), grid, dim3(BB_BLOCK), 0, st, a); return; }
+        if (nl == 8 && !ntl) { hipLaunchKernelGGL((k_copy_frames<N, true, 8, false>), grid, dim3(BB_BLOCK), 0, st, a); return; }
+#endif
+        hipLaunchKernelGGL((k_copy_frames<N, true>), grid, dim3(BB_BLOCK), 0, st, a);
     });
-    BB_NOTE("k_copy_frames<%s,%s> grid %u", nt ? "nt" : "plain", v16 ? "16B" : "4B", grid.x);
+    (void)ntl;
+    BB_NOTE("k_copy_frames<%s,%s,%d,%s> grid %u", nt ? "nt" : "plain", v16 ? "16B" : "4B", nl, ntl ? "ntload" : "load", grid.x);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }
@@ -1270,7 +1290,7 @@ int bb_mark4_locate(const void *d_buf, size_t nbytes, int ntrack, int64_t *d_off
     if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
     if (nbytes < (size_t)ntrack * 2500) return BB_OK;
     uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (blocks > (g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID)) blocks = g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID;
     if (blocks == 0) blocks = 1;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);
     hipStream_t st = (hipStream_t)stream;

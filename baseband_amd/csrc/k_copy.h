@@ -28,29 +28,34 @@ struct bb_copy_args {
 
 #define BB_COPY_ITEM 16384u
 
-template <bool NT, bool V16>
+// NL: 16-byte loads a lane has in flight before its first store (work item = NL x
+// 4 KiB); NTL: non-temporal loads.  The product builds <.., 4, true>; the
+// experiment build the others (tools/exp_copy.py, profiles/r04k_exp_copy.log).
+template <bool NT, bool V16, int NL = 4, bool NTL = true>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_copy_frames(bb_copy_args a)
 {
+    constexpr uint32_t ITEM = (uint32_t)NL * BB_BLOCK * 16;
     const uint64_t nwork = a.nframes * a.nseg;
     for (uint64_t step = blockIdx.x; step < nwork; step += gridDim.x) {
         const uint64_t work = bb_perm(a.perm, step);
         const uint64_t f = a.nseg == 1 ? work : work / a.nseg;
         const uint64_t seg = work - f * a.nseg;
-        const uint64_t b0 = seg * BB_COPY_ITEM;
-        const uint32_t nb = (uint32_t)(a.n - b0 < BB_COPY_ITEM ? a.n - b0 : BB_COPY_ITEM);
+        const uint64_t b0 = seg * ITEM;
+        const uint32_t nb = (uint32_t)(a.n - b0 < ITEM ? a.n - b0 : ITEM);
         const uint8_t *src = a.buf + (uint64_t)(a.src0 + (int64_t)f * a.src_stride) + b0;
         uint8_t *dst = a.out + f * a.n + b0;
         if (V16) {
-            bb_u4 v[4];
+            bb_u4 v[NL];
             const uint32_t np = nb >> 4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NL; ++k) {
                 const uint32_t p = (uint32_t)k * BB_BLOCK + threadIdx.x;
-                if (p < np) v[k] = __builtin_nontemporal_load(reinterpret_cast<const bb_u4 *>(src) + p);
+                if (p < np) v[k] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const bb_u4 *>(src) + p)
+                                       : reinterpret_cast<const bb_u4 *>(src)[p];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NL; ++k) {
                 const uint32_t p = (uint32_t)k * BB_BLOCK + threadIdx.x;
                 if (p < np) {
                     if (NT) __builtin_nontemporal_store(v[k], reinterpret_cast<bb_u4 *>(dst) + p);

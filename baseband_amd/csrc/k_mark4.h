@@ -85,7 +85,7 @@ void k_mark4_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t 
     constexpr uint64_t FN = (uint64_t)NTRACK * 2500, PAT_END = 96 * ISZ, ZOFF = 64 * ISZ - 1;
     const uint64_t q_end = nbytes - FN + ZOFF + 1;
     bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
-        [&](uint32_t v) { return v == 0xffffff00u; },
+        [&](uint32_t v) { return v ^ 0xffffff00u; },
         [&](uint64_t z) -> int64_t {
             if (z < ZOFF) return -1;
             const uint64_t pos = z - ZOFF;

@@ -126,6 +126,9 @@ __device__ __forceinline__ bool bb_vdif_header_at(const uint8_t *buf, uint64_t n
 // a single global counter took 12 of the kernel's 13 ms (one word takes about 88
 // returning atomics per microsecond, MI355X_MICROARCH.md price list "dequeue").
 #define BB_LOCATE_LOCAL 1024
+#ifndef BB_LOCATE_U
+#define BB_LOCATE_U 4
+#endif
 template <class Probe, class Confirm>
 __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nbytes, uint64_t q_end,
                                                  int64_t *out, uint64_t cap, unsigned long long *count,
@@ -142,45 +145,83 @@ __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nby
     const uint32_t *w = reinterpret_cast<const uint32_t *>(buf);
     const uint64_t ndw = nbytes / 4;
     const int lane = bb_lane();
-    for (uint64_t j = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x; j < nchunk + (BB_WAVE - 1);
-         j += (uint64_t)gridDim.x * BB_BLOCK) {
+    // BB_LOCATE_U chunks of 16 bytes per lane and iteration, all their loads issued
+    // before the first probe: with one load in flight per lane the sweep was
+    // latency bound -- 32 waves x 1 KiB per CU in flight = 8 MiB on the chip, at 2
+    // us per load 4.2 TB/s, which is what it measured (4.0-4.3; round 4)
+    constexpr int U = BB_LOCATE_U;
+    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
+    for (uint64_t j0 = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x; j0 < nchunk + (BB_WAVE - 1);
+         j0 += stride * U) {
         // (whole waves stay in the loop: the shuffle below needs every lane)
-        bb_u4 d = {0u, 0u, 0u, 0u};
-        const uint64_t dw0 = 4 * j;
-        if (dw0 + 4 <= ndw) d = *reinterpret_cast<const bb_u4 *>(w + dw0);
-        else {
-            if (dw0 < ndw) d.x = w[dw0];
-            if (dw0 + 1 < ndw) d.y = w[dw0 + 1];
-            if (dw0 + 2 < ndw) d.z = w[dw0 + 2];
-        }
-        uint32_t nx = (uint32_t)__shfl_down((int)d.x, 1);
-        if (lane == BB_WAVE - 1) nx = dw0 + 4 < ndw ? w[dw0 + 4] : 0u;
-        if (j >= nchunk) continue;
-        const uint32_t dd[5] = {d.x, d.y, d.z, d.w, nx};
-        uint32_t hits = 0;                              // bit 4k+s: position 16j + 4k + s
+        bb_u4 dv[U];
+        uint32_t tail[U];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (probe(dd[k])) hits |= 1u << (4 * k);
-            if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 1))) hits |= 2u << (4 * k);
-            if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 2))) hits |= 4u << (4 * k);
-            if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 3))) hits |= 8u << (4 * k);
+        for (int u = 0; u < U; ++u) {
+            const uint64_t j = j0 + (uint64_t)u * stride;
+            const uint64_t dw0 = 4 * j;
+            dv[u] = bb_u4{0u, 0u, 0u, 0u};
+            tail[u] = 0u;
+            if (j < nchunk + (BB_WAVE - 1)) {
+                if (dw0 + 4 <= ndw) dv[u] = *reinterpret_cast<const bb_u4 *>(w + dw0);
+                else {
+                    if (dw0 < ndw) dv[u].x = w[dw0];
+                    if (dw0 + 1 < ndw) dv[u].y = w[dw0 + 1];
+                    if (dw0 + 2 < ndw) dv[u].z = w[dw0 + 2];
+                }
+                if (lane == BB_WAVE - 1 && dw0 + 4 < ndw) tail[u] = w[dw0 + 4];
+            }
         }
-        while (hits) {                                  // rare
-            const int b = __ffs((int)hits) - 1;
-            hits &= hits - 1;
-            const uint64_t q = 16 * j + (uint64_t)b;
-            if (q >= q_end) continue;
-            // candidates are parked: confirming one here would stall the whole
-            // wave on two scattered header fetches (a real frame's header and
-            // the one a frame later) while 63 lanes wait; after the sweep the
-            // workgroup confirms all of its candidates at once, one per thread,
-            // their fetches in flight together
-            const uint32_t c = atomicAdd(&s_nc, 1u);
-            if (c < BB_LOCATE_LOCAL) { s_cand[c] = q; continue; }
-            const int64_t pos = confirm(q);             // (list full: on the spot, to the global list)
-            if (pos < 0) continue;
-            const unsigned long long g = atomicAdd(count, 1ull);
-            if (g < cap) out[g] = pos;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t j = j0 + (uint64_t)u * stride;
+            const bb_u4 d = dv[u];
+            uint32_t nx = (uint32_t)__shfl_down((int)d.x, 1);
+            if (lane == BB_WAVE - 1) nx = tail[u];
+            if (j >= nchunk) continue;
+            const uint32_t dd[5] = {d.x, d.y, d.z, d.w, nx};
+            // `probe` gives the MISMATCHING bits of a dword (0 = it is the pattern): the
+            // minimum over the sixteen positions is zero iff one of them hits -- three
+            // operations and a third of a v_min3 per position instead of a compare and
+            // two mask updates each; which positions hit is worked out only then
+            uint32_t worst = 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t m0 = probe(dd[k]);
+                const uint32_t m1 = probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 1));
+                const uint32_t m2 = probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 2));
+                const uint32_t m3 = probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 3));
+                const uint32_t a01 = m0 < m1 ? m0 : m1, a23 = m2 < m3 ? m2 : m3;
+                const uint32_t a = a01 < a23 ? a01 : a23;
+                worst = worst < a ? worst : a;
+            }
+            uint32_t hits = 0;                              // bit 4k+s: position 16j + 4k + s
+            if (worst == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (probe(dd[k]) == 0) hits |= 1u << (4 * k);
+                    if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 1)) == 0) hits |= 2u << (4 * k);
+                    if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 2)) == 0) hits |= 4u << (4 * k);
+                    if (probe(__builtin_amdgcn_alignbyte(dd[k + 1], dd[k], 3)) == 0) hits |= 8u << (4 * k);
+                }
+            }
+            while (hits) {                                  // rare
+                const int b = __ffs((int)hits) - 1;
+                hits &= hits - 1;
+                const uint64_t q = 16 * j + (uint64_t)b;
+                if (q >= q_end) continue;
+                // candidates are parked: confirming one here would stall the whole
+                // wave on two scattered header fetches (a real frame's header and
+                // the one a frame later) while 63 lanes wait; after the sweep the
+                // workgroup confirms all of its candidates at once, one per thread,
+                // their fetches in flight together
+                const uint32_t c = atomicAdd(&s_nc, 1u);
+                if (c < BB_LOCATE_LOCAL) { s_cand[c] = q; continue; }
+                const int64_t pos = confirm(q);             // (list full: on the spot, to the global list)
+                if (pos < 0) continue;
+                const unsigned long long g = atomicAdd(count, 1ull);
+                if (g < cap) out[g] = pos;
+            }
         }
     }
     __syncthreads();
@@ -236,7 +277,7 @@ void k_vdif_locate(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
     // word 2 is invariant in all 32 bits -- an equality probe -- doubled the
     // kernel's LDS and ran 25 % slower, profiles/r02am_locate.txt)
     bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
-                    [&](uint32_t v) { return ((v ^ pat) & msk) == 0; }, confirm);
+                    [&](uint32_t v) { return (v ^ pat) & msk; }, confirm);
 }
 
 // Header scan at explicit (possibly unaligned) frame offsets: same record as
@@ -361,7 +402,7 @@ void k_mark5b_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t
 {
     const uint64_t q_end = nbytes - BB_M5B_FRAME + 1;       // the sync word is the probe
     bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
-        [&](uint32_t v) { return v == 0xABADDEEDu; },
+        [&](uint32_t v) { return v ^ 0xABADDEEDu; },
         [&](uint64_t pos) -> int64_t {
             const uint64_t next = pos + BB_M5B_FRAME;
             if (next + 4 <= nbytes && bb_load_u32_any(buf, nbytes, next) != 0xABADDEEDu) return -1;
