@@ -10,6 +10,7 @@
 #include "k_lut.h"
 #include "k_lds.h"
 #include "k_copy.h"
+#include "k_tfpick.h"
 #if BB_EXP
 #include "k_burst.h"
 #endif
@@ -1560,6 +1561,37 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
         else
             ok = ok && np_ == 2 && (p->d_chan_map ? true : (nc % 4 == 0)) && (ncs % 4 == 0);
         if (!ok && selecting) return BB_ENOTSUP;
+        // a channel LIST of time-first blocks: whole rows by direct-to-LDS loads, the
+        // kept channels picked out of LDS (k_tfpick.h; round 3: dword gathers in k_xpose.h)
+        if (ok && p->layout == BB_LAYOUT_GUPPI_TF && p->d_chan_map && g_tune_xpose_tc.load() == 0
+            && ncs * 4 <= BB_TFPICK_STAGE && nc <= BB_TFPICK_MAXSEL) {
+            bb_tfpick_args b;
+            b.buf = a.buf; b.out = d_out; b.cmap = p->d_chan_map;
+            b.nframes = nframes; b.t_lo = p->t_lo; b.t_hi = p->t_hi;
+            b.src0 = p->src0; b.src_stride = p->src_stride; b.src_lim = a.src_lim;
+            b.rb = (uint32_t)(ncs * 4); b.nsel = (uint32_t)nc; b.npd = (uint32_t)npd; b.pf = (uint32_t)p->pol_first;
+            b.tt = BB_TFPICK_STAGE / b.rb;
+            const uint64_t ntt = ((p->t_hi - p->t_lo) + b.tt - 1) / b.tt;
+            if (ntt > 0xffffffffull) return BB_ERANGE;
+            b.ntt = (uint32_t)ntt;
+            const uint32_t halfp = b.nsel / 2, ppt = halfp * b.npd;
+            b.magic_ppt = (uint32_t)((1ull << 32) / ppt) + 1;
+            b.magic_half = (uint32_t)((1ull << 32) / halfp) + 1;
+            b.fill_re = p->fill_re; b.fill_im = p->fill_im;
+            uint64_t blocks = (uint64_t)nframes * ntt;
+            b.perm = make_perm(blocks, (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4);
+            const uint64_t cap = tb > 0 ? (uint64_t)tb : 0x7fffffffull;
+            if (blocks > cap) blocks = cap;
+            const dim3 grid((unsigned)blocks), block(BB_BLOCK);
+            with_nt(nt, [&](auto NT) {
+                constexpr bool N = decltype(NT)::value;
+                hipLaunchKernelGGL((k_decode_i8_tf_pick<N>), grid, block, 0, st, b);
+            });
+            BB_NOTE("k_decode_i8_tf_pick<%s> grid %u tiles of %u times, %u of %u channels", nt ? "nt" : "plain",
+                    grid.x, b.tt, b.nsel, (unsigned)ncs);
+            BB_HIP(hipGetLastError());
+            return BB_OK;
+        }
         if (ok) {
             // Tile shape (the tile keeps its 16 KiB of input; a narrower tile is
             // longer along the input's contiguous axis).  Blocks of 64 channels, 8 and

@@ -537,7 +537,8 @@ def test_block_channel_lists_and_single_polarisations(manifest, name):
 @pytest.mark.parametrize('tile_rows,tile_chans', [(0, 0), (64, 0), (128, 0), (0, 8), (0, 32), (0, 64), (64, 16), (128, 64)])
 @pytest.mark.parametrize('layout', [0, 1, 2])
 def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows, tile_chans):
-    """k_decode_i8_xpose with a SELECTION: out[f, t, p, c] = stored[f, t,
+    """k_decode_i8_xpose (and k_decode_i8_tf_pick, which takes the channel lists
+    of time-first blocks) with a SELECTION: out[f, t, p, c] = stored[f, t,
     pol_first + p, chan_map[c]] -- lists with gaps, repeats and any order, more
     channels than a tile, ragged last tiles, one of two polarisations, both at
     once, partial time ranges; and the geometries that must answer KeyError."""
@@ -574,7 +575,10 @@ def test_xpose_kernel_channel_lists_and_polarisations(layout, tile_rows, tile_ch
                     out = kernels.decode_i8_tiled(dbuf, nfr, layout, npk, nc, T, lo, hi, src0=head, src_stride=stride,
                                                   nchan_stored=stored, npol_stored=nps, pol_first=pf,
                                                   chan_map=cmap).cpu().numpy()
-                    assert 'k_decode_i8_xpose' in _lib.last_kernel()
+                    # (channel lists of time-first blocks: whole rows through LDS, k_tfpick.h --
+                    # unless a tile width is forced, which keeps round 3's form in k_xpose.h)
+                    picked = layout == 2 and cl is not None and tile_chans == 0
+                    assert ('k_decode_i8_tf_pick' if picked else 'k_decode_i8_xpose') in _lib.last_kernel()
                     want = ref[:, lo:hi, pf:pf + npk]
                     if cl is not None:
                         want = want[:, :, :, cl]
