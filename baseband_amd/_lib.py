@@ -15,7 +15,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BB_EXPERIMENTS=1 in the environment loads the experiment build (make -C
 # baseband_amd/csrc EXPERIMENTS=1): the same kernels plus the measurement
-# variants and knobs of include/bbdecode_exp.h.  tools/exp_*.py need it; the
+# variants and knobs of include/bbdecode_exp.h.  tools/experiments/exp_*.py need it; the
 # package, the tests and bench.py run on the product library.
 EXPERIMENTS = os.environ.get('BB_EXPERIMENTS', '') not in ('', '0')
 LIB_PATH = os.path.join(_HERE, 'libbbdecode_exp.so' if EXPERIMENTS else 'libbbdecode.so')

@@ -30,7 +30,7 @@ struct bb_copy_args {
 
 // NL: 16-byte loads a lane has in flight before its first store (work item = NL x
 // 4 KiB); NTL: non-temporal loads.  The product builds <.., 4, true>; the
-// experiment build the others (tools/exp_copy.py, profiles/r04k_exp_copy.log).
+// experiment build the others (tools/experiments/exp_copy.py, profiles/r04k_exp_copy.log).
 template <bool NT, bool V16, int NL = 4, bool NTL = true>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_copy_frames(bb_copy_args a)

@@ -391,7 +391,7 @@ def write_device_bytes(fh, dev, chunk_bytes=16 << 20):
     GPU box 12 GB/s into a new file, and neither ``os.pwrite`` from 4-16 threads
     (11-12 GB/s: buffered writes to one file serialise on its inode lock) nor a
     memory map filled by 8 threads (2.4 GB/s into a new file) does better
-    (tools/exp_file_write.py, profiles/r03y_exp_file_write.log)."""
+    (tools/experiments/exp_file_write.py, profiles/r03y_exp_file_write.log)."""
     src = dev.reshape(-1)
     n = src.numel()
     if n < 2 * chunk_bytes:

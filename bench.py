@@ -116,7 +116,7 @@ def empty_with_patience(n, dtype, device, tries=12):
     """``torch.empty`` for the 127.5 GiB output.  The image was allocated just
     before, and an arena that had to try several candidate steps has released up
     to 144 GiB a moment ago: memory the driver is still clearing is not
-    allocatable yet (seen with tools/arena_probe3.cpp), so an out-of-memory here
+    allocatable yet (seen with tools/experiments/arena_probe3.cpp), so an out-of-memory here
     is retried for a few seconds before it counts."""
     for k in range(tries):
         try:

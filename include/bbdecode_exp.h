@@ -46,7 +46,7 @@ int bb_debug_trace(uint64_t *d_times);
 /* bb_host_register pins a range of host memory where it lies -- e.g. a window
  * of a read-only file mapping -- so that bb_copy_to_device (hipMemcpyAsync on
  * `stream`) moves it without a host-side copy into a pinned buffer first
- * (tools/exp_hostregister.py; profiles/r02ax_exp_hostregister.log: pinning a
+ * (tools/experiments/exp_hostregister.py; profiles/r02ax_exp_hostregister.log: pinning a
  * freshly mapped file costs more than the staging copy it would replace). */
 int bb_host_register(const void *h_ptr, size_t nbytes);
 int bb_host_unregister(const void *h_ptr);

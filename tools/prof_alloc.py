@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The allocation sequence of tools/exp_alloc.py with THREE decode launches per
+"""The allocation sequence of tools/experiments/exp_alloc.py with THREE decode launches per
 size (one untimed, two timed with HIP events), for counter passes under
 rocprofv3: which hardware counters differ between a launch whose output
 landed well (6.4-6.8 TB/s) and one whose output landed badly (5.3)?"""
