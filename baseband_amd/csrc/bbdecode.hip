@@ -559,10 +559,13 @@ int bb_copy_to_device(void *d_dst, const void *h_src, size_t nbytes, void *strea
 }
 #endif
 
-int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
-                 bb_frame_rec *d_recs, size_t nframes, void *stream)
+static int vdif_scan_impl(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
+                          bb_frame_rec *d_recs, size_t nframes, int64_t *d_fill, size_t fill_n, void *stream)
 {
-    if (nframes == 0) return BB_OK;                      // (an empty window: nothing to look at)
+    if (nframes == 0) {                                  // (an empty window: nothing to look at)
+        if (d_fill && fill_n) BB_HIP(hipMemsetAsync(d_fill, 0xff, fill_n * sizeof(int64_t), (hipStream_t)stream));
+        return BB_OK;
+    }
     if (!d_buf || !p || !d_recs) return BB_EINVAL;
     if (p->header_nbytes != 32 && p->header_nbytes != 16) return BB_EINVAL;
     if (p->frame_nbytes < p->header_nbytes || (p->frame_nbytes & 7)) return BB_EINVAL;
@@ -571,7 +574,31 @@ int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
     const uint64_t blocks = (threads + BB_BLOCK - 1) / BB_BLOCK;
     if (blocks > 0x7fffffffull) return BB_ERANGE;
     hipLaunchKernelGGL(k_vdif_scan, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
-                       (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes);
+                       (const uint8_t *)d_buf, (uint64_t)nbytes, *p, d_recs, (uint64_t)nframes, d_fill, (uint64_t)fill_n);
+    BB_HIP(hipGetLastError());
+    return BB_OK;
+}
+
+int bb_vdif_scan(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *p,
+                 bb_frame_rec *d_recs, size_t nframes, void *stream)
+{
+    return vdif_scan_impl(d_buf, nbytes, p, d_recs, nframes, nullptr, 0, stream);
+}
+
+// records -> dense index (pre-filled by the caller's scan launch, or here) + verification, one launch
+static int index_verify(const bb_frame_rec *d_recs, size_t nrecs, const int16_t *d_thread_slot, int nslot,
+                        int64_t *d_src, size_t nframes_out, bool prefilled, uint32_t recs_per_index, size_t nstrict,
+                        uint32_t *d_nbad, void *stream)
+{
+    if (!d_src || nslot < 1 || (nrecs && !d_recs) || recs_per_index == 0) return BB_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (!prefilled && nframes_out)
+        BB_HIP(hipMemsetAsync(d_src, 0xff, nframes_out * (size_t)nslot * sizeof(int64_t), st));
+    if (nrecs == 0) return BB_OK;
+    const uint64_t blocks = ((uint64_t)nrecs + BB_BLOCK - 1) / BB_BLOCK;
+    if (blocks > 0x7fffffffull) return BB_ERANGE;
+    hipLaunchKernelGGL(k_index_verify, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, st, d_recs, (uint64_t)nrecs,
+                       d_thread_slot, nslot, d_src, (uint64_t)nframes_out, recs_per_index, (uint64_t)nstrict, d_nbad);
     BB_HIP(hipGetLastError());
     return BB_OK;
 }
@@ -1056,15 +1083,13 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
                         uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad,
                         void *verified, void *stream)
 {
-    if (!scan || !dec) return BB_EINVAL;
-    int rc = bb_vdif_scan(d_buf, nbytes, scan, d_recs, nframes, stream);
+    if (!scan || !dec || !d_src || dec->nslot < 1) return BB_EINVAL;
+    // three launches: scan (which also pre-sets the index to -1), index + verification, decode
+    int rc = vdif_scan_impl(d_buf, nbytes, scan, d_recs, nframes, d_src, nsets * (size_t)dec->nslot, stream);
     if (rc != BB_OK) return rc;
-    rc = bb_build_index(d_recs, nframes, d_thread_slot, dec->nslot, d_src, nsets, stream);
+    rc = index_verify(d_recs, nframes, d_thread_slot, dec->nslot, d_src, nsets, true, recs_per_index ? recs_per_index : 1,
+                      nstrict, d_nbad, stream);
     if (rc != BB_OK) return rc;
-    if (d_nbad) {
-        rc = bb_verify_records(d_recs, nframes, 0, recs_per_index, nstrict, d_nbad, stream);
-        if (rc != BB_OK) return rc;
-    }
     if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
     if (nwithin > 0)
         return bb_decode_frames_select(d_buf, nbytes, d_src, nsets, dec, d_within, nwithin, d_out, out_elems, stream);
@@ -1082,12 +1107,8 @@ int bb_mark5b_read_window(const void *d_buf, size_t nbytes,
     if (!scan || !dec) return BB_EINVAL;
     int rc = bb_mark5b_scan(d_buf, nbytes, scan, d_recs, nframes, stream);
     if (rc != BB_OK) return rc;
-    rc = bb_build_index(d_recs, nframes, nullptr, 1, d_src, n, stream);
+    rc = index_verify(d_recs, nframes, nullptr, 1, d_src, n, false, 1, nstrict, d_nbad, stream);
     if (rc != BB_OK) return rc;
-    if (d_nbad) {
-        rc = bb_verify_records(d_recs, nframes, 0, 1, nstrict, d_nbad, stream);
-        if (rc != BB_OK) return rc;
-    }
     if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
     if (nwithin > 0)
         return bb_decode_frames_select(d_buf, nbytes, d_src, n, dec, d_within, nwithin, d_out, out_elems, stream);
@@ -1104,12 +1125,8 @@ int bb_mark4_read_window(const void *d_buf, size_t nbytes,
     if (!scan || !dec) return BB_EINVAL;
     int rc = bb_mark4_scan(d_buf, nbytes, scan, d_recs, nframes, stream);
     if (rc != BB_OK) return rc;
-    rc = bb_build_index(d_recs, nframes, nullptr, 1, d_src, n, stream);
+    rc = index_verify(d_recs, nframes, nullptr, 1, d_src, n, false, 1, nstrict, d_nbad, stream);
     if (rc != BB_OK) return rc;
-    if (d_nbad) {
-        rc = bb_verify_records(d_recs, nframes, 0, 1, nstrict, d_nbad, stream);
-        if (rc != BB_OK) return rc;
-    }
     if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
     if (nout > 0)
         return bb_decode_mark4_select(d_buf, nbytes, d_src, n, dec, nout, d_out, out_elems, stream);

@@ -15,9 +15,13 @@
 // per-word invariant tests are combined with one wave-wide ballot.
 __global__ __launch_bounds__(BB_BLOCK)
 void k_vdif_scan(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
-                 bb_frame_rec *recs, uint64_t nframes)
+                 bb_frame_rec *recs, uint64_t nframes, int64_t *fill, uint64_t fill_n)
 {
     const uint64_t gtid = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+    // (bb_vdif_read_window: the dense index this window's records are scattered into
+    // by the NEXT launch is pre-set to -1 here instead of by a memset of its own)
+    if (fill)
+        for (uint64_t i = gtid; i < fill_n; i += (uint64_t)gridDim.x * BB_BLOCK) fill[i] = -1;
     const uint64_t frame = gtid >> 3;
     const int wi = (int)(gtid & 7);
     const int lane = bb_lane();
@@ -432,6 +436,35 @@ void k_verify_records(const bb_frame_rec *recs, uint64_t nrecs, int32_t first_in
     }
     const unsigned long long m = __ballot(bad);
     if (bb_lane() == 0 && m) atomicAdd(nbad, (uint32_t)__popcll(m));
+}
+
+// k_build_index and k_verify_records in ONE launch (the read_window entry points:
+// a mid-size read is five launches otherwise, and the three small ones between two
+// decodes cost 20-30 us of a 650 us read; round 4).  `nbad` may be null.
+__global__ __launch_bounds__(BB_BLOCK)
+void k_index_verify(const bb_frame_rec *recs, uint64_t nrecs, const int16_t *thread_slot, int nslot,
+                    int64_t *src, uint64_t nframes_out, uint32_t recs_per_index, uint64_t nstrict, uint32_t *nbad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+    bool bad = false;
+    if (i < nrecs) {
+        const bb_u4 raw = *reinterpret_cast<const bb_u4 *>(&recs[i]);
+        bb_frame_rec r;
+        *reinterpret_cast<bb_u4 *>(&r) = raw;
+        bad = !(r.flags & BB_FRAME_OK) || (i < nstrict && r.time_index != (int32_t)(i / recs_per_index));
+        bool put = (r.flags & BB_FRAME_OK) && r.time_index >= 0 && (uint64_t)r.time_index < nframes_out
+                   && !(r.flags & BB_FRAME_INVALID);
+        int slot = 0;
+        if (put && thread_slot) {
+            slot = thread_slot[r.thread_id & 0x3ff];
+            put = slot >= 0 && slot < nslot;
+        }
+        if (put) src[(uint64_t)r.time_index * nslot + slot] = r.payload_offset;
+    }
+    if (nbad) {
+        const unsigned long long m = __ballot(bad);
+        if (bb_lane() == 0 && m) atomicAdd(nbad, (uint32_t)__popcll(m));
+    }
 }
 
 // Scatter scan records into the dense output-ordered source table (which the
