@@ -1,7 +1,7 @@
 """Output memory for the decode launches (include/bbdecode_arena.h).
 
 The write rate of a decode launch depends on how its output was allocated
-(DESIGN.md 3.2): into plain allocations of 4-34 GB it is 5.3-5.7 TB/s in most
+(docs/DESIGN_rounds1-3.md 3.2): into plain allocations of 4-34 GB it is 5.3-5.7 TB/s in most
 draws and 6.4-6.8 in some; into memory created as chunks with the HIP virtual
 memory API and mapped into one virtual range it is 6.5-6.8 in every draw.  An
 `Arena` is such a range: backed on demand by 32 MiB chunks, first-fit

@@ -8,7 +8,7 @@
 //
 // Why: the 6 % of the traffic that is reads costs 14 % of the time of
 // k_decode_flat_lds, and a streaming reader NEXT to a cache-fed decode costs
-// the same -- what the memory sees is a steady trickle of
+// the same (docs/DESIGN_rounds1-3.md 3.3) -- what the memory sees is a steady trickle of
 // reads inside a write stream, however the waves issue them.  Here a CU asks
 // for its next 64 KiB in one go and then only writes for tens of
 // microseconds; with `period` set, all loader waves of the device issue at

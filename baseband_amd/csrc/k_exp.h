@@ -3,7 +3,7 @@
 // k_decode_flat_pipe, k_decode_flat_aln (round 1's headline kernel),
 // k_decode_flat_span, k_decode_flat2_bytes -- and, through k_front.h, the
 // write-front / one-pass experiments.  None of them is launched by the product
-// library; they stay as the record of those measurements.
+// library; they stay as the record of those measurements (docs/DESIGN_rounds1-3.md 3.2, 3.3).
 #pragma once
 #include "k_flat.h"
 

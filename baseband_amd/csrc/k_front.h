@@ -8,7 +8,7 @@
 // k_decode_flat_aln maps work item -> workgroup as blockIdx + k * gridDim with a
 // grid of ~10^5 workgroups: the ~2000 resident workgroups then write into
 // min(16, items per workgroup) windows that lie gridDim items apart, and how
-// many windows there are depends on the launch size (DESIGN.md section 3,
+// many windows there are depends on the launch size (docs/DESIGN_rounds1-3.md section 3,
 // "Launch size": 5.1-5.6 TB/s for 9-70 GB launches against 6.4-6.6 for 145 GB).
 // Here the map is explicit.  Work items (TPW tiles of 256 input bytes = up to
 // TPW x 4 KiB of output for 2-bit data) are numbered in output order.  The
@@ -146,7 +146,7 @@ void k_decode_flat_front(bb_flat_args a, bb_front_geom g)
 // pieces lie in different stripes of the output, so there are a few write
 // fronts that advance with the dispatch order -- runs at 6.25-6.33 TB/s for 8.5,
 // 34 and 137 GB of output alike, where the workgroup-per-frame and persistent
-// kernels run at 5.4-5.65 below ~33 GB (one physical region).
+// kernels run at 5.4-5.65 below ~33 GB (one physical region, docs/DESIGN_rounds1-3.md 3.2).
 // This is that form for real frames: a wave owns U tiles (256 input bytes ->
 // 8/BPS KiB of output each), tile u in stripe u of the launch's tile sequence;
 // all U loads are issued before the first store.  One pass: grid = tiles per

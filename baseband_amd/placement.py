@@ -1,7 +1,7 @@
 """Where the decoded output lies in HBM.
 
 The write rate of a decode launch depends on how its output was allocated more
-than on anything inside the kernels: into a plain
+than on anything inside the kernels (docs/DESIGN_rounds1-3.md section 3.2): into a plain
 allocation of 4-34 GB -- the output of an ordinary ``read()`` -- the same
 launch runs at 5.3-5.7 TB/s in most draws and at 6.4-6.8 in some, while every
 tensor cut from an arena of VMM chunks (`baseband_amd.arena`) decodes at

@@ -884,8 +884,8 @@ def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5, res=None):
     """Kernel-level figures for the other BASELINE configurations on random
     input -- `gib` GiB for the 2-bit formats, `gib8` for the 8-bit ones, i.e. the
     same 128-137 GB of decoded output as the headline launch each (the output
-    of a launch should span as much of HBM as the headline's does: DESIGN.md,
-    "Where the output lies"): (ms, algorithmic GB/s, fraction of 8 TB/s,
+    of a launch should span as much of HBM as the headline's does: DESIGN.md 3.1,
+    docs/DESIGN_rounds1-3.md "Where the output lies"): (ms, algorithmic GB/s, fraction of 8 TB/s,
     kernel as named by the library)."""
     from baseband_amd import kernels, _lib
     from baseband_amd.mark4._bitmaps import BITMAPS

@@ -10,7 +10,7 @@
  * memory API and mapped into one virtual range it runs at 6.5-6.8 in EVERY
  * draw, for chunks of 2 to 128 MiB alike (same-process A/B, six fresh outputs
  * per size, five processes: profiles/r03f_exp_arena.log, r03g_exp_arena_*.log,
- * r03h_exp_arena_chunk*.log) -- provided the block's physical
+ * r03h_exp_arena_chunk*.log; docs/DESIGN_rounds1-3.md 3.2) -- provided the block's physical
  * memory spans a wide range of the device: blocks of 8 GiB steps taken first
  * thing in a fresh process decode at 5.3 TB/s for good
  * (profiles/r03k_exp_arena_history.log).  The arena is that: a virtual range

@@ -5,7 +5,7 @@
  * variants rounds 1 and 2 measured against (csrc/k_exp.h, k_front.h, the
  * dispatcher in csrc/bb_exp.inc) and their knobs, a completion-time trace, and
  * the pinned-mapping copy helpers.  Nothing here is part of the product
- * library or of the drop-in boundary; the measurements are in DESIGN.md 3.2-3.3.
+ * library or of the drop-in boundary; the measurements are in docs/DESIGN_rounds1-3.md 3.2-3.3 and DESIGN.md 3.3.
  */
 #ifndef BBDECODE_EXP_H
 #define BBDECODE_EXP_H
