@@ -186,6 +186,7 @@ thread_local bb_knob g_tune_encode_runs{0};  // k_encode_flat: 256-quad runs per
 thread_local bb_knob g_tune_xpose_tc{0};     // k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; 0 = by channel count
 thread_local bb_knob g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a selection: from this many channels on
 thread_local bb_knob g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
+thread_local bb_knob g_tune_gather_glds{-1}; // gather kernels stage with direct-to-LDS loads: 1 / 0; -1 = by kernel (selecting: yes, +4.9 %; whole decodes: no, -0.2..-0.8 %; profiles/r04q_exp_gather_glds.log)
 thread_local bb_knob g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 #if BB_EXP
 thread_local bb_knob g_tune_copy{0};         // k_copy_frames: loads per lane | non-temporal loads << 8 (0 = 4 | 1 << 8)
@@ -501,6 +502,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_ENCODE_RUNS: g_tune_encode_runs = (value == 1 || value == 2) ? value : 0; return BB_OK;
         case BB_TUNE_XPOSE_TC: g_tune_xpose_tc = (value == 64 || value == 32 || value == 16 || value == 8) ? value : 0; return BB_OK;
         case BB_TUNE_XPOSE_MIN_NC: g_tune_xpose_min_nc = value < 2 ? 2 : value; return BB_OK;
+        case BB_TUNE_GATHER_GLDS: g_tune_gather_glds = value < 0 ? -1 : (value != 0); return BB_OK;
         case BB_TUNE_WORK_STRIPES: g_tune_order_lw = (value >= 0 && value <= 10) ? value : -1; return BB_OK;
 #if BB_EXP
         case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
@@ -831,6 +833,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             if ((rl & (rl - 1)) == 0) { ga.lrow = 0; while ((1u << ga.lrow) < rl) ++ga.lrow; }
         }
         ga.aligned = 1;
+        ga.glds = g_tune_gather_glds.load() == 1;
         const size_t lds = ((size_t)p->nslot * (gt * 64 + 65) + 2 * p->nslot + 1) * 4 + 1024;
         // persistent grid: a workgroup walks about five work items (8 KiB of
         // payload each); one workgroup per item costs 15 %, a few thousand
@@ -1233,6 +1236,7 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
     ga.fill_re = p->fill_re; ga.fill_im = p->fill_im; ga.complex_data = p->complex_data;
     ga.lrow = -1;
     ga.aligned = 1;
+    ga.glds = g_tune_gather_glds.load() != 0;
     ga.within = d_within; ga.nsel = (uint32_t)nwithin;
     {
         // floats a work item writes at most, and the two divisors of its index walk

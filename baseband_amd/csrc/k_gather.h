@@ -30,6 +30,7 @@ struct bb_gather_args {
     int32_t  complex_data;
     int32_t  lrow;          // log2(nslot * chunk) when that is a power of two, else -1
     int32_t  aligned;       // use 256-byte aligned block loads
+    int32_t  glds;          // stage with direct-to-LDS loads (global_load_lds_dword) instead of load + ds_write
     uint64_t src_lim;       // offsets outside [0, src_lim) decode as fill (bb_src_ok)
     bb_perm_t perm;         // work order (bb_common.h)
     // channel selection (bb_decode_frames_select): only positions within[0..nsel)
@@ -86,6 +87,34 @@ __device__ __forceinline__ void bb_gather_stage(const bb_gather_args &a, uint64_
         const uint32_t sbeg = sfirst + k0 * sstep;
         const uint32_t ns = sbeg < send ? (send - sbeg + sstep - 1) / sstep : 0u;
         const uint32_t npiece = ns * nblk;
+        if (a.glds) {
+            // Direct-to-LDS (round 4): a piece = 64 consecutive dwords of one slot = one
+            // global_load_lds_dword per wave, landing lane-linear in the slot's row; no
+            // VGPR round trip, no ds_write, all pieces in flight at once (the barrier
+            // behind the staging waits for them).  Dwords outside the payload are not
+            // loaded (and never decoded).  Payloads at odd addresses keep the path below.
+            for (uint32_t p = 0; p < npiece; ++p) {
+                const uint32_t k = p / nblk, b = p - k * nblk;
+                const uint32_t s = sbeg + k * sstep;
+                const int from = (int)(s - s0);
+                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)((uint64_t)my_ad & 0xffffffffu), from);
+                const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)my_ad >> 32), from);
+                const uint32_t sh = (uint32_t)__shfl((int)my_sh, from);
+                const int ok = __shfl((int)my_ok, from);
+                const uint32_t *blk = reinterpret_cast<const uint32_t *>(((uint64_t)hi << 32) | lo) - sh;
+                const uint32_t jb = (b * wps + wsub) * BB_WAVE;           // wave-uniform
+                const uint32_t j = jb + (uint32_t)lane;
+                const uint64_t q = dw0 + j;
+                if (!ok || jb >= gdw + 64) continue;                       // wave-uniform
+                if (lo & 3) {                                              // odd address: through registers
+                    if (j < gdw + 64 && q >= sh && q - sh < a.ndw) s_raw[s * pitch + j] = blk[q];
+                    continue;
+                }
+                if (j < gdw + 64 && q >= sh && q - sh < a.ndw)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + q),
+                                                     (__attribute__((address_space(3))) void *)(s_raw + s * pitch + jb), 4, 0, 0);
+            }
+        } else
         for (uint32_t p0 = 0; p0 < npiece; p0 += 8) {
             uint32_t r[8], dst[8];
 #pragma unroll

@@ -735,3 +735,55 @@ def test_tune_knobs_are_thread_local():
     assert ' grid 7 ' in seen['here'][0], seen['here'][0]
     assert ' grid 7 ' not in seen['other'][0], seen['other'][0]
     assert bits_equal(seen['here'][1], seen['other'][1])
+
+
+@pytest.mark.parametrize('bps,chunk,nslot,pn', [(2, 1, 8, 640), (2, 32, 8, 8000), (4, 4, 2, 1000), (8, 2, 4, 516), (1, 16, 3, 2048), (2, 2, 16, 260)])
+def test_gather_staging_forms_agree(bps, chunk, nslot, pn):
+    """The LDS gather kernels with direct-to-LDS staging (global_load_lds_dword) and
+    with load + ds_write (BB_TUNE_GATHER_GLDS 1 / 0; by default the selecting
+    kernel uses the first, the whole-decode kernel the second): the same output
+    as each other and as the oracle, with shuffled and missing payloads, payloads
+    at odd byte addresses, a grid that makes workgroups loop, and a folded subset."""
+    torch = _torch()
+    from baseband_amd import kernels, _lib
+    nframes = 9
+    rng = np.random.default_rng(bps * 100 + chunk * 10 + nslot + pn)
+    stride = pn + 40
+    raw = rng.integers(0, 256, (nframes * nslot + 2) * stride + 64, dtype=np.uint8)
+    perm = rng.permutation(nframes * nslot)
+    src = (perm * stride + 4 * (perm % 5)).astype(np.int64)
+    src[rng.choice(nframes * nslot, size=4, replace=False)] = -1
+    odd = rng.choice(np.nonzero(src >= 0)[0], size=3, replace=False)
+    src[odd] += 1                                         # repaired files: odd byte addresses
+    cplx = chunk % 2 == 0
+    dbuf = kernels.to_device_bytes(raw)
+    dsrc = torch.from_numpy(src).cuda()
+    E = pn * 8 // bps
+    R = E // chunk
+    exp = np.empty((nframes, R, nslot, chunk), np.float32)
+    fillrow = np.tile(np.array([2.5, 0.], np.float32), chunk // 2) if cplx else np.full(chunk, 2.5, np.float32)
+    for f in range(nframes):
+        for s in range(nslot):
+            o = src[f * nslot + s]
+            exp[f, :, s, :] = fillrow if o < 0 else orc.decode_flat(raw[o:o + pn], 'vdif', bps).reshape(R, chunk)
+    keep = np.array(sorted(rng.choice(chunk, size=max(1, chunk // 2), replace=False)), np.int32) if chunk >= 2 else None
+    try:
+        for form in (1, 0):
+            for blocks in (0, 5):
+                kernels.tune(_lib.TUNE_GATHER_GLDS, form)
+                kernels.tune(_lib.TUNE_BLOCKS, blocks)
+                kernels.tune(_lib.TUNE_GATHER_CHUNKS, 1 << 20)          # every chunk through the gather kernel
+                out = kernels.decode_frames(dbuf, nframes, pn, 0, bps, chunk=chunk, nslot=nslot, src=dsrc,
+                                            complex_data=cplx, fill_value=2.5).cpu().numpy()
+                assert 'k_decode_gather' in _lib.last_kernel(), _lib.last_kernel()
+                assert bits_equal(out, exp.reshape(-1)), (form, blocks)
+                if keep is not None and (chunk & (chunk - 1)) == 0 and kernels.select_supported(bps, chunk, nslot, keep.size, pn):
+                    sel = kernels.decode_frames(dbuf, nframes, pn, 0, bps, chunk=chunk, nslot=nslot, src=dsrc,
+                                                complex_data=cplx, fill_value=2.5,
+                                                within=torch.from_numpy(keep).cuda()).cpu().numpy()
+                    assert 'k_decode_gather_select' in _lib.last_kernel()
+                    assert bits_equal(sel, np.ascontiguousarray(exp[:, :, :, keep]).reshape(-1)), (form, blocks)
+    finally:
+        kernels.tune(_lib.TUNE_GATHER_GLDS, -1)
+        kernels.tune(_lib.TUNE_BLOCKS, 0)
+        kernels.tune(_lib.TUNE_GATHER_CHUNKS, 32)

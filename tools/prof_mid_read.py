@@ -74,5 +74,5 @@ for nf in (1 << 13, 1 << 15, 1 << 16):
         print("frames %d: read() returns after %.3f ms, done after %.3f ms; decode kernel alone %.3f ms" %
               (nf, host, wall, float(np.median(ev[1:]))))
         s = io.StringIO()
-        pstats.Stats(pr, stream=s).sort_stats('cumtime').print_stats(6)
+        pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(24)
         print(s.getvalue()[s.getvalue().index('ncalls'):][:6500])
