@@ -359,6 +359,16 @@ void launch_flat_lds(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 #endif
             else
                 hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        } else if constexpr (BPS == 4) {
+            // 4-bit (round 4): direct-to-LDS too -- against k_decode_flat_lut +2.6-3.4 % on VDIF
+            // frames and +6.7-8.5 % on GSB blocks at 16 GiB in, +1.3 % at 8 GiB, two boxes
+            // (profiles/r04r_exp_glds5_box*.log); register staging lost 3-12 % in round 3
+#if BB_EXP
+            if (g_tune_variant.load() == 19)
+                hipLaunchKernelGGL((k_decode_flat_lds<4, N, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
+            else
+#endif
+            hipLaunchKernelGGL((k_decode_flat_lds<4, N, 2, 8, BB_LV_REG, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
         } else {
 #if BB_EXP
             if (g_tune_variant.load() == 20)
@@ -422,9 +432,14 @@ void launch_flat_lut(int bps, bool nt, dim3 grid, hipStream_t st, const bb_flat_
         constexpr bool N = decltype(NT)::value;
         // (1-bit work items are at most 8 tiles per wave: the 8-tile instantiation
         // stays below 128 VGPRs, the 16-tile one needs 129 = one wave per SIMD less)
-        if (bps == 1)      hipLaunchKernelGGL((k_decode_flat_lut<1, N, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
-        else if (bps == 2) hipLaunchKernelGGL((k_decode_flat_lut<2, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
-        else               hipLaunchKernelGGL((k_decode_flat_lut<4, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        // (the product sends 1-bit samples here; 2- and 4-bit ones go through k_decode_flat_lds,
+        // their instantiations of this kernel stay in the experiment build for A/B: variant 16)
+#if BB_EXP
+        if (bps == 2) { hipLaunchKernelGGL((k_decode_flat_lut<2, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a); return; }
+        if (bps == 4) { hipLaunchKernelGGL((k_decode_flat_lut<4, N, 2, 16>), grid, dim3(2 * BB_WAVE), 0, st, a); return; }
+#endif
+        (void)bps;
+        hipLaunchKernelGGL((k_decode_flat_lut<1, N, 2, 8>), grid, dim3(2 * BB_WAVE), 0, st, a);
     });
 }
 
@@ -931,7 +946,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             return BB_OK;
         }
 #endif
-        bool lds = p->bps == 2;
+        bool lds = p->bps == 2 || p->bps == 4;
 #if BB_EXP
         if (g_tune_variant.load() == 15 || g_tune_variant.load() == 19 || g_tune_variant.load() == 20) lds = true;        // A/B: force either kernel for every sample width
         if (g_tune_variant.load() == 16) lds = false;
@@ -940,7 +955,8 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // and without an index on three boxes, 4 tiles: 0.850-0.858 with, 0.837-0.848
         // without; profiles/r04d_exp_glds3_box*.log.  Knob 0 = these defaults.)
         const int lt_knob = g_tune_lut_tpw.load();
-        int lut_tiles = lt_knob == 0 ? ((lds && p->bps == 2) ? 6 : 4 * p->bps / 2) : lt_knob * p->bps / 2;
+        // (4-bit through k_decode_flat_lds: 4 tiles per wave; r04r_exp_glds5_box*.log)
+        int lut_tiles = lt_knob == 0 ? ((lds && p->bps == 2) ? 6 : (lds && p->bps == 4) ? 4 : 4 * p->bps / 2) : lt_knob * p->bps / 2;
         lut_tiles = lut_tiles < 1 ? 1 : lut_tiles > (lds ? 8 : 16) ? (lds ? 8 : 16) : lut_tiles;
         const uint64_t seg_max = 2ull * (uint64_t)lut_tiles;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
@@ -954,14 +970,14 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         if (lds) {
 #if BB_EXP
             if (p->bps == 1) launch_flat_lds<1>(nt, g2, st, a);
-            else if (p->bps == 4) launch_flat_lds<4>(nt, g2, st, a);
             else
 #endif
-            launch_flat_lds<2>(nt, g2, st, a);
+            if (p->bps == 4) launch_flat_lds<4>(nt, g2, st, a);
+            else launch_flat_lds<2>(nt, g2, st, a);
             const char *gl = "";
 #if BB_EXP
-            if (p->bps == 2 && g_tune_variant.load() == 19) gl = ",regs";
-            if (p->bps != 2 && g_tune_variant.load() == 20) gl = ",glds";
+            if (p->bps != 1 && g_tune_variant.load() == 19) gl = ",regs";
+            if (p->bps == 1 && g_tune_variant.load() == 20) gl = ",glds";
 #endif
             BB_NOTE("k_decode_flat_lds<%d,%s,2,8%s> grid %u tiles/wave %u", p->bps, nt ? "nt" : "plain", gl, g2.x, a.tpw);
         } else {

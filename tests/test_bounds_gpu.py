@@ -34,7 +34,7 @@ def _view(raw, slack=4096):
 
 
 @pytest.mark.parametrize('coder,bps,nslot,chunk', [
-    ('vdif', 2, 1, 1),        # k_decode_flat_lut
+    ('vdif', 2, 1, 1),        # k_decode_flat_lds
     ('vdif', 1, 1, 1),
     ('vdif', 4, 1, 1),
     ('vdif', 8, 1, 1),        # k_decode_flat (plain)

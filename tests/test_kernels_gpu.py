@@ -508,7 +508,7 @@ def test_byte_table_kernel_geometries(tiles, coder, bps):
             src[rng.choice(nframes, size=max(1, nframes // 9), replace=False)] = -1
             out = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, CODERS[coder], bps,
                                         src=torch.from_numpy(src).cuda(), fill_value=-7.5).cpu().numpy()
-            assert ('k_decode_flat_lds' if bps == 2 else 'k_decode_flat_lut') in _lib.last_kernel()
+            assert ('k_decode_flat_lds' if bps in (2, 4) else 'k_decode_flat_lut') in _lib.last_kernel()
             per = pn * 8 // bps
             exp = np.empty((nframes, per), np.float32)
             for f in range(nframes):
