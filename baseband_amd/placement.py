@@ -74,7 +74,8 @@ def reader_closed():
         _auto_trim()
 
 
-_idle_timer = None
+_idle_deadline = None            # time.monotonic() after which the watcher trims (None: nothing scheduled)
+_idle_watcher = None             # the daemon thread waiting for that deadline
 _idle_lock = threading.Lock()
 
 
@@ -90,10 +91,7 @@ def _nothing_alive():
 
 
 def _trim_idle():
-    """Timer body: trim the arenas if STILL nothing needs their memory."""
-    global _idle_timer
-    with _idle_lock:
-        _idle_timer = None
+    """Trim the arenas if STILL nothing needs their memory."""
     if os.environ.get('BB_ARENA_KEEP', '0') not in ('0', '', 'no', 'off') or not _nothing_alive():
         return 0
     freed = 0
@@ -106,6 +104,26 @@ def _trim_idle():
     return freed
 
 
+def _watch_idle():
+    """Body of the watcher thread: sleep until the deadline (which later frees
+    push back), trim, leave."""
+    global _idle_deadline, _idle_watcher
+    while True:
+        with _idle_lock:
+            wait = None if _idle_deadline is None else _idle_deadline - time.monotonic()
+            if wait is None or wait <= 0:
+                _idle_deadline = None
+                _idle_watcher = None
+                due = wait is not None
+                break
+        time.sleep(min(wait, 1.0))
+    if due:
+        try:
+            _trim_idle()
+        except Exception:
+            pass
+
+
 def _auto_trim(ar=None):
     """A block died or the last reader closed: when no reader is open and no
     arena holds a live block, give the memory back -- after BB_ARENA_IDLE_S
@@ -113,20 +131,20 @@ def _auto_trim(ar=None):
     once: growing again is not cheap -- memory that was released before is
     cleared by the driver when it is created again, 1.5 s for a 48 GiB step
     (profiles/r04h_prof_arena_grow.log) -- and a script that reads file after
-    file drops to "nothing alive" between two reads all the time.
-    BB_ARENA_IDLE_S=0: at once; BB_ARENA_KEEP=1: never."""
-    global _idle_timer
+    file drops to "nothing alive" between two reads all the time.  Costs a
+    clock reading per call: ONE daemon thread waits for the deadline, which
+    every later call pushes back.  BB_ARENA_IDLE_S=0: at once; BB_ARENA_KEEP=1: never."""
+    global _idle_deadline, _idle_watcher
     if _open_readers or os.environ.get('BB_ARENA_KEEP', '0') not in ('0', '', 'no', 'off'):
         return 0
     delay = _idle_seconds()
     if delay <= 0:
         return _trim_idle() if _nothing_alive() else 0
     with _idle_lock:
-        if _idle_timer is not None:
-            _idle_timer.cancel()
-        _idle_timer = threading.Timer(delay, _trim_idle)
-        _idle_timer.daemon = True
-        _idle_timer.start()
+        _idle_deadline = time.monotonic() + delay
+        if _idle_watcher is None:
+            _idle_watcher = threading.Thread(target=_watch_idle, name='bb-arena-idle', daemon=True)
+            _idle_watcher.start()
     return 0
 
 
