@@ -52,6 +52,8 @@ ARENA_MIN_BYTES = 1 << 30
 # profiles/r03u_exp_headline_alloc.log)
 ARENA_MAX_BYTES = 64 << 30
 _failed = False                 # arena creation failed once: do not try again in this process
+_ITEMSIZE = {torch.float32: 4, torch.complex64: 8, torch.uint8: 1, torch.int32: 4, torch.int64: 8, torch.int8: 1,
+             torch.float64: 8, torch.float16: 2, torch.bfloat16: 2, torch.int16: 2, torch.bool: 1, torch.complex128: 16}
 
 
 _open_readers = 0               # stream readers open right now (GPUStreamReaderBase registers itself)
@@ -152,8 +154,9 @@ def _arena_for(device, create=True):
     """The readers' arena on `device` (one per device; created now if there is
     none yet and `create` allows); None when switched off or not available."""
     global _failed
-    device = torch.device(device)
-    ar = _arena.default(device)
+    if not isinstance(device, torch.device):
+        device = torch.device(device)
+    ar = _arena._arenas.get(device.index) if device.index is not None else _arena.default(device)
     if ar is not None:
         return ar
     if not create or _failed or os.environ.get('BB_ARENA', '1') in ('0', 'off', 'no'):
@@ -187,12 +190,19 @@ def empty_output(shape, dtype=torch.float32, device=None, create=True):
     output is large, else from torch's allocator.  ``create=False``: only from
     an arena that exists already (the readers' copies of file bytes: a staged
     file alone should not make the arena take its first 48 GiB step)."""
-    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
-    if device.index is None:
+    if device is None:
         device = torch.device('cuda', torch.cuda.current_device())
-    shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
-    item = 8 if dtype == torch.complex64 else torch.empty(0, dtype=dtype).element_size()
-    nbytes = int(np.prod(shape, dtype=np.int64)) * item
+    elif not isinstance(device, torch.device) or device.index is None:
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+    shape = (int(shape),) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
+    item = _ITEMSIZE.get(dtype)
+    if item is None:
+        item = torch.empty(0, dtype=dtype).element_size()
+    nbytes = item
+    for s_ in shape:
+        nbytes *= s_
     if ARENA_MIN_BYTES <= nbytes <= ARENA_MAX_BYTES:
         ar = _arena_for(device, create)
         if ar is not None:

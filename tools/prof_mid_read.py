@@ -73,6 +73,8 @@ for nf in (1 << 13, 1 << 15, 1 << 16):
         wall = np.median([t[1] for t in ts]) * 1e3
         print("frames %d: read() returns after %.3f ms, done after %.3f ms; decode kernel alone %.3f ms" %
               (nf, host, wall, float(np.median(ev[1:]))))
-        s = io.StringIO()
-        pstats.Stats(pr, stream=s).sort_stats('tottime').print_stats(24)
-        print(s.getvalue()[s.getvalue().index('ncalls'):][:6500])
+        st = pstats.Stats(pr)
+        rows = sorted(st.stats.items(), key=lambda kv: -kv[1][2])[:22]
+        print("   us/read (own)  us/read (cum)  calls/read  function")
+        for (fn, ln, name), (cc, nc, tt, ct, _) in rows:
+            print("   %12.1f  %13.1f  %10.1f  %s:%d %s" % (tt / 20 * 1e6, ct / 20 * 1e6, nc / 20, os.path.basename(fn), ln, name))
