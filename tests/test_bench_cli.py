@@ -125,3 +125,12 @@ def test_collect_checks_reads_every_leg():
     ok, checks = bench.collect_checks(bad)
     assert ok is False and checks["invalid_fill.neighbour_frame_is_data"] is False
     assert bench.collect_checks({"sanity_spot_check": True})[0] is True
+
+
+def test_physical_core_count_is_stated():
+    """the all-cores CPU leg runs one process per PHYSICAL core of
+    the affinity mask and says how many that is."""
+    sys.path.insert(0, ROOT)
+    import bench
+    nphys, nlog = bench.physical_cores()
+    assert 1 <= nphys <= nlog == len(os.sched_getaffinity(0))
