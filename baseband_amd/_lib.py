@@ -69,6 +69,7 @@ TUNE_LUT_SMALL = 25
 TUNE_FLAT8_LDS = 29
 TUNE_BURST = 31
 TUNE_COPY = 35
+TUNE_M4_LDS = 37
 TUNE_BURST_BYTES = 32
 TUNE_BURST_PERIOD = 33
 TUNE_BURST_WAVES = 34

@@ -189,6 +189,7 @@ thread_local bb_knob g_tune_xpose{1};        // 1: aligned int8 transposes throu
 thread_local bb_knob g_tune_gather_glds{-1}; // gather kernels stage with direct-to-LDS loads: 1 / 0; -1 = by kernel (selecting: yes, +4.9 %; whole decodes: no, -0.2..-0.8 %; profiles/r04q_exp_gather_glds.log)
 thread_local bb_knob g_tune_order_lw{-1};    // work order: log2(stripes) a launch is dealt over (bb_perm_t); 0 = file order, -1 = by output size
 #if BB_EXP
+thread_local bb_knob g_tune_m4_lds{0};       // 1: 64-bit Mark 4 words staged in LDS by direct-to-LDS loads (k_decode_mark4_lds)
 thread_local bb_knob g_tune_copy{0};         // k_copy_frames: loads per lane | non-temporal loads << 8 (0 = 4 | 1 << 8)
 thread_local bb_knob g_tune_variant{5};      // 5 = the product dispatch; others: include/bbdecode_exp.h
 thread_local bb_knob g_tune_burst{0};         // 1: contiguous 2-bit output through k_decode_flat_burst (k_burst.h)
@@ -522,6 +523,7 @@ int bb_tune(int knob, int value)
 #if BB_EXP
         case BB_TUNE_FLAT_VARIANT: g_tune_variant = value; return BB_OK;
         case BB_TUNE_COPY: g_tune_copy = value; return BB_OK;
+        case BB_TUNE_M4_LDS: g_tune_m4_lds = value != 0; return BB_OK;
         case BB_TUNE_BURST: g_tune_burst = value; return BB_OK;
         case BB_TUNE_BURST_BYTES: g_tune_burst_bytes = (value >= 4096 && value <= 79360) ? (value & ~255) : 65536; return BB_OK;
         case BB_TUNE_BURST_PERIOD: g_tune_burst_period = value > 0 ? value : 0; return BB_OK;
@@ -1439,13 +1441,22 @@ static int m4_decode(const void *d_buf, size_t buf_nbytes, const int64_t *d_src,
         const dim3 grid((unsigned)blocks);
 #define BB_M4(N) with_nt(nt, [&](auto NT) { \
             hipLaunchKernelGGL((k_decode_mark4<N, decltype(NT)::value>), grid, block, 0, st, a); })
+        bool m4lds = false;
+#if BB_EXP
+        // experiment (BB_TUNE_M4_LDS 1): 64-bit words staged in LDS by direct-to-LDS loads -- slower
+        // than the shuffle form at 8 GiB (0.81 vs 0.83), +2.7 % at 2 GiB: profiles/r04s_exp_m4lds.log
+        m4lds = p->ntrack == 64 && g_tune_m4_lds.load() != 0;
+        if (m4lds) {
+            with_nt(nt, [&](auto NT) { hipLaunchKernelGGL((k_decode_mark4_lds<decltype(NT)::value>), grid, block, 0, st, a); });
+        } else
+#endif
         switch (p->ntrack) {
             case 16: BB_M4(16); break;
             case 32: BB_M4(32); break;
             default: BB_M4(64); break;
         }
 #undef BB_M4
-        BB_NOTE("k_decode_mark4<%d,%s> grid %u%s", p->ntrack, nt ? "nt" : "plain", grid.x,
+        BB_NOTE("k_decode_mark4%s<%d,%s> grid %u%s", m4lds ? "_lds" : "", p->ntrack, nt ? "nt" : "plain", grid.x,
                 p == &wide ? " (narrow words as 64-bit super-words)" : "");
     } else {
         if (blocks > (1ull << 30)) blocks = 1ull << 30;     // no pipeline to fill: one work item per workgroup

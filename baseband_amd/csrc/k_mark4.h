@@ -330,6 +330,122 @@ void k_decode_mark4(bb_m4_args a)
     }
 }
 
+#if BB_EXP
+// (experiment build; measured and not kept: profiles/r04s_exp_m4lds.log)
+// The same decode for 64-bit stream words (64 tracks, and the narrower modes as
+// super-words) with the words staged in LDS by direct-to-LDS loads
+// (global_load_lds_dwordx4; round 4, as in k_lds.h): a wave brings its (up to)
+// 8 tiles x 512 bytes in with four 1 KiB load instructions, no VGPR round trip
+// and no shuffles -- a store pass reads its word from LDS (ds_read_b64; the
+// eight lanes of a word read the same address: a broadcast).  Words of the fill
+// prefix and of invalid frames are not loaded.  Units at addresses that are not
+// multiples of 16 bytes keep every load aligned (the image starts at the
+// 16-byte boundary below the first word); pieces that are not entirely inside
+// the wave's words are loaded dword by dword, units at odd addresses byte by byte.
+template <bool NT>
+__global__ __launch_bounds__(BB_BLOCK)
+void k_decode_mark4_lds(bb_m4_args a)
+{
+    constexpr int LPW = 8, WPP = 8, OPW = 32, TPW = BB_M4_TPW;
+    constexpr int NPIECE = TPW * 32 + 1;                    // 16-byte pieces a wave stages at most
+    __shared__ bb_u4 s_stage[BB_WAVES_PER_BLOCK][NPIECE];
+    const int lane = bb_lane();
+    const int wave = __builtin_amdgcn_readfirstlane(bb_wave());
+    const int sub = lane % LPW;
+    const int wsel = lane / LPW;
+    uint32_t spack = 0, mpack = 0;
+#pragma unroll
+    for (int k = 0; k < LPW; ++k)
+        if (sub == k) { spack = a.sign_bit[k]; mpack = a.mag_bit[k]; }
+    const float hi = a.hi;
+    const bb_f4 fillv = {a.fill, a.fill, a.fill, a.fill};
+    const uint64_t E = a.nwords * OPW;
+    const uint64_t nwork = a.nframes * a.nseg;
+    const uint8_t *stage8 = reinterpret_cast<const uint8_t *>(&s_stage[wave][0]);
+    uint32_t *stage32 = reinterpret_cast<uint32_t *>(&s_stage[wave][0]);
+
+    for (uint64_t step = blockIdx.x; step < nwork; step += gridDim.x) {
+        const uint64_t work = bb_perm(a.perm, step);
+        uint64_t f, seg;
+        if (a.nseg == 1) { f = work; seg = 0; }
+        else { f = work / a.nseg; seg = work - f * a.nseg; }
+        const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
+        const bool valid = bb_src_ok(so, a.src_lim);
+        const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
+        const uint64_t w_end = (seg + 1) * a.seg_tiles * 64 < a.nwords ? (seg + 1) * a.seg_tiles * 64 : a.nwords;
+        uint64_t w0 = tile0 * 64;                               // first word of this wave
+        uint64_t w1 = w0 + (uint64_t)a.tpw * 64 < w_end ? w0 + (uint64_t)a.tpw * 64 : w_end;
+        // words to load: [wl, w1), without the fill prefix
+        const uint64_t wl = w0 > a.fill_words ? w0 : a.fill_words;
+        uint32_t sh = 0;                                        // byte of word w0 in the staged image
+        if (valid && wl < w1) {
+            const uint8_t *p0 = a.buf + (uint64_t)so + w0 * 8;  // word w0 (may lie in the fill prefix: not read)
+            if (reinterpret_cast<uintptr_t>(p0) & 3) {
+                uint8_t *st8 = reinterpret_cast<uint8_t *>(&s_stage[wave][0]);
+                const uint32_t lo8 = (uint32_t)(wl - w0) * 8, hi8 = (uint32_t)(w1 - w0) * 8;
+#pragma nounroll
+                for (uint32_t i = lo8 + (uint32_t)lane; i < hi8; i += BB_WAVE) st8[i] = p0[i];
+            } else {
+                sh = (uint32_t)(reinterpret_cast<uintptr_t>(p0) & 15);
+                const uint8_t *base = p0 - sh;                  // 16-byte aligned
+                const uint32_t lo = sh + (uint32_t)(wl - w0) * 8, hiB = sh + (uint32_t)(w1 - w0) * 8;
+#pragma unroll
+                for (int k = 0; k < (NPIECE + BB_WAVE - 1) / BB_WAVE; ++k) {
+                    const uint32_t piece = (uint32_t)k * BB_WAVE + (uint32_t)lane;
+                    const uint32_t b0 = piece * 16;
+                    if (piece >= (uint32_t)NPIECE || b0 + 16 <= lo || b0 >= hiB) continue;
+                    if (b0 >= lo && b0 + 16 <= hiB) {
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(base + b0),
+                            (__attribute__((address_space(3))) void *)(&s_stage[wave][k * BB_WAVE]), 16, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t q = b0 + 4 * d;
+                            if (q >= lo && q + 4 <= hiB) stage32[piece * 4 + d] = *reinterpret_cast<const uint32_t *>(base + q);
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float *obase = a.out + f * E;
+        // (tiles one after the other, the eight passes of a tile unrolled: all 64 unrolled
+        // took 251 VGPRs = one wave per SIMD)
+#pragma nounroll
+        for (int u = 0; u < (int)a.tpw; ++u) {
+#pragma unroll
+            for (int p = 0; p < LPW; ++p) {
+                const uint32_t wt = (uint32_t)u * 64 + (uint32_t)(p * WPP + wsel);     // word of this wave
+                const uint64_t widx = w0 + wt;
+                if (widx >= w1) continue;
+                bb_f4 v = fillv;
+                if (valid && widx >= a.fill_words) {
+                    const uint32_t off = sh + wt * 8;
+                    const uint64_t x = (uint64_t)*reinterpret_cast<const uint32_t *>(stage8 + off)
+                                     | ((uint64_t)*reinterpret_cast<const uint32_t *>(stage8 + off + 4) << 32);
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t sb = (spack >> (8 * k)) & 0xff;
+                        const uint32_t mb = (mpack >> (8 * k)) & 0xff;
+                        const bool s = (x >> sb) & 1;
+                        const bool m = (x >> mb) & 1;
+                        r[k] = (s == m) ? (s ? hi : -hi) : (s ? 1.0f : -1.0f);
+                    }
+                    v = bb_f4{r[0], r[1], r[2], r[3]};
+                }
+                bb_store4<NT>(obase + widx * OPW + 4 * sub, v);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();          // the next step overwrites the staging area
+    }
+}
+#endif
+
 // Channel selection folded into the track demultiplexing (a reader `subset`
 // that picks channels: the reference decodes whole frames and indexes
 // afterwards, base/base.py:706-717 with 957-969).  The bit maps are data, so

@@ -31,6 +31,7 @@ extern "C" {
 #define BB_TUNE_LUT_SMALL     25   /* 1: k_decode_flat_lut instantiated for at most 4 tiles per wave when the work items are that short (slower) */
 #define BB_TUNE_FLAT8_LDS     29   /* 0 (default): the product dispatch (int8 through k_decode_flat_lds<8> with direct-to-LDS loads, VDIF 8-bit through k_decode_flat<8>); 2: k_decode_flat<8> for both; 1: contiguous 8-bit output of every coder through k_decode_flat_lds<8> (16-byte loads staged in LDS; BB_TUNE_LUT_TILES x 4 tiles per wave) instead of k_decode_flat<8>: -2..-5 % VDIF 8-bit, -1..+3 % int8 blocks (profiles/r03zd_exp_flat8*.log) */
 
+#define BB_TUNE_M4_LDS        37   /* 1: Mark 4 units of 64-bit words through k_decode_mark4_lds (words staged in LDS by direct-to-LDS loads, no shuffles); default 0 = k_decode_mark4.  0.81 against 0.83 at 8 GiB in, +2.7 % at 2 GiB (profiles/r04s_exp_m4lds.log) */
 #define BB_TUNE_COPY          35   /* k_copy_frames: (16-byte loads a lane has in flight: 2 / 4 / 8 / 16) | (non-temporal loads << 8); 0 = the product's 4 | 256 */
 #define BB_TUNE_BURST         31   /* 1: contiguous 2-bit output through k_decode_flat_burst (a loader wave stages long work items in LDS with direct-to-LDS loads for 3 / 7 / 15 store waves); default 0.  Measured against k_decode_flat_lds (profiles/r04a_exp_burst.log): the same time to 0.2 % in the best configuration, 2-6 % slower with the clocked loader */
 #define BB_TUNE_BURST_BYTES   32   /* ... LDS bytes per staging buffer (two per workgroup; 4096..79360, default 65536) */
