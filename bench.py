@@ -1490,7 +1490,24 @@ def main():
         os.environ.setdefault('WORLD_SIZE', '1')
         import datetime
         # (a rank that fails must become an error on the others, not a hang)
-        dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=240))
+        # (RCCL prints a version banner on the C library's stdout when the communicator is
+        # made; the contract is ONE JSON line there: the banner goes to stderr)
+        import ctypes
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', device_id=device, timeout=datetime.timedelta(seconds=240))
+            warm = torch.zeros(1, device=device)
+            dist.all_reduce(warm)               # (communicators are made lazily on some builds)
+            torch.cuda.synchronize()
+        finally:
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from baseband_amd import kernels, _lib
     from baseband_amd.parallel import frame_slab
