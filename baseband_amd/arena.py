@@ -45,18 +45,22 @@ class _Block:
 
     def __del__(self):
         arena = self.arena
-        if arena is not None and arena._handle:
-            try:
-                arena._note_free(self)
-            except Exception:           # interpreter shutdown: torch may be half gone
-                pass
+        if arena is None or not arena._handle:
+            return
+        try:
+            arena._note_free(self)
+        except Exception:           # interpreter shutdown: torch may be half gone
+            pass
+        try:
             lib.bb_arena_free(arena._handle, C.c_void_p(self.ptr))
-            hook = arena.on_block_freed
-            if hook is not None:
-                try:
-                    hook(arena)
-                except Exception:
-                    pass
+        except Exception:           # ... and so may this module's globals
+            return
+        hook = arena.on_block_freed
+        if hook is not None:
+            try:
+                hook(arena)
+            except Exception:
+                pass
 
 
 _TYPESTR = {torch.float32: '<f4', torch.uint8: '|u1', torch.int32: '<i4', torch.int64: '<i8',
