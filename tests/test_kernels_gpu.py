@@ -519,19 +519,28 @@ def test_byte_table_kernel_geometries(tiles, coder, bps):
         kernels.tune(_lib.TUNE_BLOCKS, 0)
 
 
-@needs_experiments
+@pytest.mark.parametrize('form', ['product', 'staged_regs', 'staged_glds'])
 @pytest.mark.parametrize('coder', ['vdif', 'int'])
-def test_8bit_staged_kernel_geometries(coder):
-    """k_decode_flat_lds<8> (experiment build; measured, not faster than the plain
-    kernel): contiguous 8-bit output with 16-byte loads staged
-    in LDS (table for VDIF's levels, cast for int8) -- payloads that are and are
-    not multiples of 256 bytes or of a work item, headers that put payloads at
-    any 4-byte and at odd addresses, missing frames, a capped grid; and
-    bit-identical to the plain kernel behind BB_TUNE_FLAT8_LDS = 0."""
+def test_8bit_staged_kernel_geometries(coder, form):
+    """k_decode_flat_lds<8>: contiguous 8-bit output with 16-byte loads staged in
+    LDS -- the product's kernel for int8 samples (direct-to-LDS loads, 4 tiles
+    per wave; round 4), and in the experiment build also with register staging
+    and for VDIF's table levels -- payloads that are and are not multiples of 256
+    bytes or of a work item, headers that put payloads at any 4-byte and at odd
+    addresses, missing frames, a capped grid; and, experiment build, bit-identical
+    to the plain kernel behind BB_TUNE_FLAT8_LDS = 2."""
     torch = _torch()
     from baseband_amd import kernels, _lib
+    exp_build = _lib.EXPERIMENTS
+    if form == 'product':
+        if coder != 'int':
+            pytest.skip("VDIF 8-bit goes through the plain kernel in the product dispatch")
+    elif not exp_build:
+        pytest.skip("measurement variant: experiment build only (BB_EXPERIMENTS=1)")
     rng = np.random.default_rng(808)
-    kernels.tune(_lib.TUNE_FLAT8_LDS, 1)
+    if form != 'product':
+        kernels.tune(_lib.TUNE_FLAT8_LDS, 1)
+        kernels.tune(_lib.TUNE_FLAT_VARIANT, 20 if form == 'staged_glds' else 5)
     try:
         for pn, header, nframes, cap in ((8000, 32, 37, 0), (10000, 16, 23, 8), (8192, 32, 19, 0), (264, 4, 300, 16),
                                          (256, 0, 65, 0), (70000, 12, 3, 2), (4, 8, 50, 0), (8196, 36, 11, 0),
@@ -568,15 +577,17 @@ def test_8bit_staged_kernel_geometries(coder):
             full = np.stack([orc.decode_flat(raw[header + f * stride:header + f * stride + pn], coder, 8)
                              for f in range(nframes)])
             assert bits_equal(out.cpu().numpy(), full.reshape(-1)), (coder, pn)
-            kernels.tune(_lib.TUNE_FLAT8_LDS, 0)
-            plain = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, CODERS[coder], 8,
-                                          src0=header, src_stride=stride)
-            assert 'k_decode_flat<8' in _lib.last_kernel()
-            kernels.tune(_lib.TUNE_FLAT8_LDS, 1)
-            assert torch.equal(plain.view(torch.int32), out.view(torch.int32))
+            if exp_build:
+                kernels.tune(_lib.TUNE_FLAT8_LDS, 2)
+                plain = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, CODERS[coder], 8,
+                                              src0=header, src_stride=stride)
+                assert 'k_decode_flat<8' in _lib.last_kernel()
+                kernels.tune(_lib.TUNE_FLAT8_LDS, 0 if form == 'product' else 1)
+                assert torch.equal(plain.view(torch.int32), out.view(torch.int32))
     finally:
         kernels.tune(_lib.TUNE_BLOCKS, 0)
-        kernels.tune(_lib.TUNE_FLAT8_LDS, 0)
+        tune_exp(_lib.TUNE_FLAT8_LDS, 0)
+        tune_exp(_lib.TUNE_FLAT_VARIANT, 5)
 
 
 def test_window_call_equals_the_four_calls():
