@@ -357,6 +357,10 @@ void launch_flat_lds(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
 #if BB_EXP
             else if (g_tune_variant.load() == 19)
                 hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, false>), grid, dim3(2 * BB_WAVE), 0, st, a);
+            else if (g_tune_variant.load() == 21)
+                hipLaunchKernelGGL((k_decode_flat_lds<2, N, 4, 8, BB_LV_REG, 0, true>), grid, dim3(4 * BB_WAVE), 0, st, a);
+            else if (g_tune_variant.load() == 22)
+                hipLaunchKernelGGL((k_decode_flat_lds<2, N, 1, 8, BB_LV_REG, 0, true>), grid, dim3(1 * BB_WAVE), 0, st, a);
 #endif
             else
                 hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
@@ -950,7 +954,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
 #endif
         bool lds = p->bps == 2 || p->bps == 4;
 #if BB_EXP
-        if (g_tune_variant.load() == 15 || g_tune_variant.load() == 19 || g_tune_variant.load() == 20) lds = true;        // A/B: force either kernel for every sample width
+        if (g_tune_variant.load() == 15 || (g_tune_variant.load() >= 19 && g_tune_variant.load() <= 22)) lds = true;        // A/B: force either kernel for every sample width
         if (g_tune_variant.load() == 16) lds = false;
 #endif
         // (2-bit through k_decode_flat_lds: 6 tiles per wave -- 0.851-0.859 of the peak with
@@ -960,10 +964,15 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // (4-bit through k_decode_flat_lds: 4 tiles per wave; r04r_exp_glds5_box*.log)
         int lut_tiles = lt_knob == 0 ? ((lds && p->bps == 2) ? 6 : (lds && p->bps == 4) ? 4 : 4 * p->bps / 2) : lt_knob * p->bps / 2;
         lut_tiles = lut_tiles < 1 ? 1 : lut_tiles > (lds ? 8 : 16) ? (lds ? 8 : 16) : lut_tiles;
-        const uint64_t seg_max = 2ull * (uint64_t)lut_tiles;
+        uint64_t nwv = 2;                                   // waves per workgroup
+#if BB_EXP
+        if (lds && p->bps == 2 && g_tune_variant.load() == 21) nwv = 4;     // A/B: 4 / 1 waves per workgroup
+        if (lds && p->bps == 2 && g_tune_variant.load() == 22) nwv = 1;
+#endif
+        const uint64_t seg_max = nwv * (uint64_t)lut_tiles;
         a.nseg = (ntiles + seg_max - 1) / seg_max;
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
-        a.tpw = (a.seg_tiles + 1) / 2;
+        a.tpw = (uint32_t)((a.seg_tiles + nwv - 1) / nwv);
         uint64_t b2 = nfs * a.nseg;
         a.perm = make_perm(b2, out_bytes);
         const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
