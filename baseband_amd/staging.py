@@ -32,7 +32,9 @@ def host_image(fh):
         if size == 0:
             return np.empty(0, dtype=np.uint8)
         mm = mmap.mmap(fileno, size, access=mmap.ACCESS_READ)
-        return np.frombuffer(mm, dtype=np.uint8)
+        img = np.frombuffer(mm, dtype=np.uint8).view(FileImage)
+        img.fd = fileno                     # (large windows get a mapping of their own: `_stage`)
+        return img
     pos = fh.tell()
     fh.seek(0)
     data = fh.read()
@@ -40,6 +42,25 @@ def host_image(fh):
     return np.frombuffer(data, dtype=np.uint8)
 
 
+class FileImage(np.ndarray):
+    """The mapped bytes of a real file, remembering its descriptor.  With
+    BB_STAGE_WINDOW_MMAP=1 the windows of a large read are copied out of
+    SHORT-LIVED mappings of their own (`_stage`) instead of this whole-file
+    mapping, whose pages then never get populated: tearing down a mapping costs
+    per populated page -- 6 ms for a 2 GiB file that was read through it, paid
+    by the NEXT open() (or at exit) -- while a window's mapping is torn down
+    inside the pipeline's loop.  Measured (profiles/r04w_pipeline_window_mmap.log):
+    open() 6-7 -> 0.4 ms, but the page-cache copies slow down (fresh mappings
+    fault their pages in while the previous window's is being torn down) and
+    the totals scatter over each other on this host: OFF by default."""
+    fd = None
+
+    def __array_finalize__(self, obj):
+        self.fd = None                      # (views and slices are plain arrays as far as staging cares)
+
+
+_WINDOW_MMAP = os.environ.get('BB_STAGE_WINDOW_MMAP', '0') not in ('0', 'no', 'off')
+_GRAN = mmap.ALLOCATIONGRANULARITY
 _COPY_THREADS = int(os.environ.get('BB_COPY_THREADS', 0)) or max(1, min(8, (os.cpu_count() or 2) // 2))
 _copy_pool = None
 
@@ -69,6 +90,19 @@ def _stage(dst, image, lo, hi):
     straight from each mapping, the pieces spread over the copy threads."""
     global _copy_pool
     if not hasattr(image, 'pieces'):
+        fd = getattr(image, 'fd', None) if _WINDOW_MMAP else None
+        if fd is not None and hi - lo >= (4 << 20):
+            try:
+                a_lo = lo - lo % _GRAN
+                win = mmap.mmap(fd, hi - a_lo, access=mmap.ACCESS_READ, offset=a_lo)
+            except (OSError, ValueError):       # a closed or unusual descriptor: the whole-file mapping serves
+                win = None
+            if win is not None:
+                try:
+                    _parallel_copy(dst, np.frombuffer(win, dtype=np.uint8)[lo - a_lo:])
+                finally:
+                    del win                     # (unmapped here, inside the loop)
+                return
         _parallel_copy(dst, image[lo:hi])
         return
     jobs, o = [], 0

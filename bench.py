@@ -1121,17 +1121,23 @@ def leg_pipeline(device, gib=2.0, reads=3):
             with open(path, 'rb') as f:                      # warm the page cache
                 while f.read(64 << 20):
                     pass
-            ts = []
+            ts, parts = [], []
             got = None
             for r in range(reads + 1):
                 del got
                 torch.cuda.synchronize()
                 t = time.perf_counter()
-                with opener(path, 'rs', **reader_kw) as fh:
-                    got = fh.read()
+                fh = opener(path, 'rs', **reader_kw)
+                t_open = time.perf_counter()
+                got = fh.read()
+                t_read = time.perf_counter()
                 torch.cuda.synchronize()
+                t_sync = time.perf_counter()
+                fh.close()
+                t_end = time.perf_counter()
                 if r:
-                    ts.append(time.perf_counter() - t)
+                    ts.append(t_end - t)
+                    parts.append((t_open - t, t_read - t_open, t_sync - t_read, t_end - t_sync))
             # one more, traced per window
             del got
             staging.trace = []
@@ -1157,6 +1163,8 @@ def leg_pipeline(device, gib=2.0, reads=3):
             row.update({"file_bytes": size, "shape": list(got.shape), "read_s_best": round(best, 4),
                         "file_GBps_best": round(size / best / 1e9, 2), "file_GBps_median": round(size / med / 1e9, 2),
                         "fraction_of_pinned_h2d": round(size / best / 1e9 / link, 3),
+                        "host_ms_of_the_best_read": dict(zip(("open", "read_call", "final_sync", "close"),
+                                                             [round(x * 1e3, 2) for x in parts[int(np.argmin(ts))]])),
                         "windows": summary, "traced_read_s": round(traced_s, 4),
                         "equals_resident_decode": same})
             del got, ref, dev, raw
