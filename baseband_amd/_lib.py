@@ -161,7 +161,7 @@ _vp = C.c_void_p
 _sz = C.c_size_t
 
 # (name, restype, argtypes) -- must list every symbol of include/bbdecode.h
-# include/bbdecode_tune.h, include/bbdecode_arena.h and include/bbdecode_host.h
+# include/bbdecode_tune.h and include/bbdecode_arena.h
 SIGNATURES = [
     ('bb_abi_version', C.c_int, []),
     ('bb_strerror', C.c_char_p, [C.c_int]),
@@ -201,8 +201,6 @@ SIGNATURES = [
     ('bb_encode_flat', C.c_int, [_vp, _sz, C.c_int, C.c_int, _vp, _sz, _vp]),
     ('bb_encode_mark4', C.c_int, [_vp, _sz, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), _vp, _sz, _vp]),
     ('bb_tune', C.c_int, [C.c_int, C.c_int]),
-    # include/bbdecode_host.h
-    ('bb_host_copy_nt', C.c_int, [_vp, _vp, _sz]),
     # include/bbdecode_arena.h
     ('bb_arena_create', C.c_int, [_sz, C.POINTER(_vp)]),
     ('bb_arena_alloc', C.c_int, [_vp, _sz, C.POINTER(_vp)]),

@@ -1855,4 +1855,3 @@ int bb_encode_mark4(const float *d_in, size_t nwords, int ntrack,
 
 #include "bbdecode_arena.h"
 #include "bb_arena.inc"
-#include "bb_host.inc"

@@ -63,13 +63,6 @@ _WINDOW_MMAP = os.environ.get('BB_STAGE_WINDOW_MMAP', '0') not in ('0', 'no', 'o
 _GRAN = mmap.ALLOCATIONGRANULARITY
 _COPY_THREADS = int(os.environ.get('BB_COPY_THREADS', 0)) or max(1, min(8, (os.cpu_count() or 2) // 2))
 _copy_pool = None
-# BB_STAGE_NT=0: NumPy's copy (glibc memcpy) instead of the library's streaming-store copy
-_NT_COPY = os.environ.get('BB_STAGE_NT', '1') not in ('0', 'no', 'off')
-
-
-def _nt_copy(dst_ptr, src_ptr, n):
-    from ._lib import lib
-    lib.bb_host_copy_nt(dst_ptr, src_ptr, n)
 
 
 def _parallel_copy(dst, src):
@@ -85,14 +78,8 @@ def _parallel_copy(dst, src):
         _copy_pool = ThreadPoolExecutor(_COPY_THREADS)
     step = -(-n // _COPY_THREADS)
     step += -step % 4096
-    if _NT_COPY and src.flags.c_contiguous and dst.flags.c_contiguous and dst.flags.writeable:
-        # streaming stores into the pinned buffer (include/bbdecode_host.h): ctypes
-        # releases the GIL for the call, one chunk per copy thread
-        dp, sp = dst.ctypes.data, src.ctypes.data
-        futs = [_copy_pool.submit(_nt_copy, dp + o, sp + o, min(n, o + step) - o) for o in range(0, n, step)]
-    else:
-        futs = [_copy_pool.submit(np.copyto, dst[o:min(n, o + step)], src[o:min(n, o + step)])
-                for o in range(0, n, step)]
+    futs = [_copy_pool.submit(np.copyto, dst[o:min(n, o + step)], src[o:min(n, o + step)])
+            for o in range(0, n, step)]
     for f in futs:
         f.result()
 

@@ -20,7 +20,7 @@ def declared_symbols(*headers):
     return sorted(syms)
 
 
-PRODUCT_HEADERS = ('bbdecode.h', 'bbdecode_tune.h', 'bbdecode_arena.h', 'bbdecode_host.h')
+PRODUCT_HEADERS = ('bbdecode.h', 'bbdecode_tune.h', 'bbdecode_arena.h')
 
 
 def test_library_exports_all_declared_symbols():

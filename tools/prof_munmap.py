@@ -46,27 +46,4 @@ for nthr in (4, 8, 16, 32, 64):
     print("threads %2d: fresh mapping %.1f GB/s, populated %.1f GB/s, munmap %.1f ms; MAP_POPULATE %.1f ms then %.1f GB/s"
           % (nthr, size / t_fresh / 1e9, size / t_again / 1e9, t_un * 1e3, t_pop * 1e3, size / t_popcopy / 1e9), flush=True)
 
-# the library's streaming-store copy (include/bbdecode_host.h) against np.copyto, same threads
-from baseband_amd._lib import lib                       # noqa: E402
-with open(path, 'wb') as f:
-    for _ in range(size // len(blk)):
-        f.write(blk)
-dp = dst.ctypes.data
-for nthr in (4, 8, 12, 16, 24):
-    pool = ThreadPoolExecutor(nthr)
-    f = open(path, 'rb')
-    mm = mmap.mmap(f.fileno(), size, access=mmap.ACCESS_READ)
-    arr = np.frombuffer(mm, np.uint8)
-    sp = arr.ctypes.data
-    step = W // nthr
-    copy_all(arr, pool, nthr)                           # populate
-    t_np = copy_all(arr, pool, nthr)
-    t0 = time.perf_counter()
-    for lo in range(0, size, W):
-        futs = [pool.submit(lib.bb_host_copy_nt, dp + o, sp + lo + o, step) for o in range(0, W, step)]
-        for f_ in futs:
-            f_.result()
-    t_nt = time.perf_counter() - t0
-    del arr; mm.close(); f.close(); pool.shutdown()
-    print("threads %2d: np.copyto %.1f GB/s, bb_host_copy_nt %.1f GB/s" % (nthr, size / t_np / 1e9, size / t_nt / 1e9), flush=True)
 os.remove(path)
