@@ -100,7 +100,8 @@ def _trim_idle():
     for a in _arena.all_arenas():
         try:
             if a._handle and a.live_blocks() == 0 and a.stats()['bytes_backed']:
-                freed += a.trim()
+                with torch.cuda.device(a.device):       # (this may be the watcher thread: its current device is 0)
+                    freed += a.trim()
         except Exception:
             pass
     return freed
