@@ -22,13 +22,14 @@
  * always enough: in one process every block of a 48 GiB step decoded at 5.5
  * TB/s (profiles/r03n/bench_plain.json).  Since the rate belongs to the memory,
  * a new step is PROBED with a decode-shaped launch (2^16 frames, three
- * launches, about 5 ms) and, when it is slow, held aside -- unmapped -- while
- * the next candidate is created somewhere else (BB_ARENA_TRIES = 2 candidates
- * by default: one second try; with more, none once two candidates probe within
- * 4 % of each other; below BB_ARENA_MIN_GBPS = 6350 counts as slow); the
- * fastest stays.  Fourteen candidates on one box probed at 5.77-6.52 TB/s, the
- * first one of a growth (memory nothing else holds) mostly the fastest
- * (profiles/r04h_prof_arena_grow.log).  Footprint: a
+ * launches, about 7 ms).  With BB_ARENA_TRIES = n > 1 a step that probes below
+ * BB_ARENA_MIN_GBPS = 6350 is held aside -- unmapped -- while the next candidate
+ * is created somewhere else (none once two candidates probe within 4 % of each
+ * other) and the
+ * fastest stays.  The DEFAULT is ONE try (the probe then only feeds the
+ * statistics): fourteen candidates on one box probed at 5.77-6.52 TB/s, and in
+ * every growth the first one -- memory nothing else holds -- was the fastest or
+ * tied, while a second candidate cost 0.2-1.5 s (profiles/r04h_prof_arena_grow.log).  Footprint: a
  * step is at most HALF of the device's free memory (behind a 4 GiB margin); at
  * most two steps exist at any moment (the best so far and the one being
  * probed: a slower candidate goes back to the device at once); another
