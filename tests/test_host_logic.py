@@ -1006,3 +1006,62 @@ def test_frameset_fromfile_differential_fuzz_against_the_reference():
                         {k: got.get(k) for k in ('raises', 'tell', 'threads')},
                         {k: c['expect'].get(k) for k in ('raises', 'tell', 'threads')}))
     assert not bad, "{} of {} cases differ, first: {}".format(len(bad), len(cases), bad[:5])
+
+
+def test_idle_trim_policy_without_a_device(monkeypatch):
+    """placement's automatic trim as pure host logic, with
+    stand-ins for the arenas: nothing happens while a reader is open or a block
+    is alive; a deadline is pushed back by every later free; after it passes
+    the arenas are trimmed once; BB_ARENA_IDLE_S=0 trims at once; BB_ARENA_KEEP
+    never."""
+    import time
+    import torch
+    from baseband_amd import placement, arena
+
+    class FakeArena:
+        def __init__(self):
+            self._handle, self.device, self.blocks, self.backed, self.trims = 1, torch.device('cpu'), 0, 48, 0
+
+        def live_blocks(self):
+            return self.blocks
+
+        def stats(self):
+            return {'bytes_backed': self.backed}
+
+        def trim(self):
+            self.trims += 1
+            freed, self.backed = self.backed, 0
+            return freed
+
+    fake = FakeArena()
+    monkeypatch.setattr(arena, 'all_arenas', lambda: [fake])
+    monkeypatch.setattr(torch.cuda, 'device', lambda d: __import__('contextlib').nullcontext())
+    monkeypatch.setattr(placement, '_open_readers', 0)
+    monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
+    # at once
+    monkeypatch.setenv('BB_ARENA_IDLE_S', '0')
+    fake.blocks = 1
+    assert placement._auto_trim() == 0 and fake.trims == 0          # a block is alive
+    fake.blocks = 0
+    placement.reader_opened()
+    assert placement._auto_trim() == 0 and fake.trims == 0          # a reader is open
+    placement.reader_closed()                                        # the last reader to close trims
+    assert fake.trims == 1 and fake.backed == 0
+    # never
+    fake.backed = 48
+    monkeypatch.setenv('BB_ARENA_KEEP', '1')
+    assert placement._auto_trim() == 0 and fake.trims == 1
+    monkeypatch.delenv('BB_ARENA_KEEP')
+    # after a delay that later frees push back
+    monkeypatch.setenv('BB_ARENA_IDLE_S', '0.3')
+    for _ in range(3):
+        placement._auto_trim()
+        time.sleep(0.15)
+        assert fake.trims == 1, "trimmed although a free pushed the deadline back"
+    fake.blocks = 1                                                  # a new block before the deadline: no trim at all
+    time.sleep(0.5)
+    assert fake.trims == 1 and placement._idle_watcher is None
+    fake.blocks = 0
+    placement._auto_trim()
+    time.sleep(0.7)
+    assert fake.trims == 2 and fake.backed == 0 and placement._idle_watcher is None
