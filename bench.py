@@ -971,14 +971,29 @@ def leg_other_configs(device, out, gib=8.0, gib8=31.0, reps=5, res=None):
     # payloads behind 4096-byte headers
     blk32 = 128 << 20
     nfr = max(1, min(nbytes8 - 4096, out.numel() * 4) // (blk32 + 4096))
-    o = out[:nfr * blk32 // 4]
+    # the output where the reader puts it: a read() result of 1-64 GiB is a block of the
+    # output arena (placement.empty_output); a slice of the headline tensor if that fails
+    o, o_mem = None, "a slice of the 127.5 GiB headline tensor"
+    try:
+        import baseband_amd
+        from baseband_amd import arena as _ar
+        o = baseband_amd.empty_output((nfr * blk32 // 4,), dtype=torch.float32, device=device)
+        a_ = _ar.default(device)
+        o_mem = "arena block (placement.empty_output, as dada.open().read() allocates it)" \
+            if a_ is not None and a_.owns(o) else "torch.empty"
+    except Exception:
+        o = None
+    if o is None:
+        o = out[:nfr * blk32 // 4]
     add("DADA NBIT=32 float32 passthrough (extension, parity unpinned: no reference counterpart)",
         lambda: kernels.copy_frames(buf, nfr, blk32, src0=4096, src_stride=blk32 + 4096, out=o),
         nfr * blk32, nfr * blk32, nfr * blk32 // 4, "samples")
+    res[-1]["output_memory"] = o_mem
     k = nfr - 1
     res[-1]["spot_check"] = bool(torch.equal(
         o[k * (blk32 // 4):k * (blk32 // 4) + 4096].view(torch.int32),
         buf[4096 + k * (blk32 + 4096):4096 + k * (blk32 + 4096) + 16384].view(torch.int32)))
+    del o
 
     # ---- the secondary kernels -------------------------
     def expand_bits(raw, lev, bps):
