@@ -361,6 +361,12 @@ void launch_flat_lds(bool nt, dim3 grid, hipStream_t st, const bb_flat_args &a)
                 hipLaunchKernelGGL((k_decode_flat_lds<2, N, 4, 8, BB_LV_REG, 0, true>), grid, dim3(4 * BB_WAVE), 0, st, a);
             else if (g_tune_variant.load() == 22)
                 hipLaunchKernelGGL((k_decode_flat_lds<2, N, 1, 8, BB_LV_REG, 0, true>), grid, dim3(1 * BB_WAVE), 0, st, a);
+            else if (g_tune_variant.load() == 23)
+                hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true, 1>), grid, dim3(2 * BB_WAVE), 0, st, a);
+            else if (g_tune_variant.load() == 24)
+                hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true, 2>), grid, dim3(2 * BB_WAVE), 0, st, a);
+            else if (g_tune_variant.load() == 25)
+                hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true, 3>), grid, dim3(2 * BB_WAVE), 0, st, a);
 #endif
             else
                 hipLaunchKernelGGL((k_decode_flat_lds<2, N, 2, 8, BB_LV_REG, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
@@ -954,7 +960,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
 #endif
         bool lds = p->bps == 2 || p->bps == 4;
 #if BB_EXP
-        if (g_tune_variant.load() == 15 || (g_tune_variant.load() >= 19 && g_tune_variant.load() <= 22)) lds = true;        // A/B: force either kernel for every sample width
+        if (g_tune_variant.load() == 15 || (g_tune_variant.load() >= 19 && g_tune_variant.load() <= 25)) lds = true;        // A/B: force either kernel for every sample width
         if (g_tune_variant.load() == 16) lds = false;
 #endif
         // (2-bit through k_decode_flat_lds: 6 tiles per wave -- 0.851-0.859 of the peak with

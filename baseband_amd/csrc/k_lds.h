@@ -35,9 +35,10 @@
 // TAG only names an instantiation: the output arena probes new memory with
 // launches of TAG 1, so that a profile's per-kernel statistics of the decode
 // launches proper (TAG 0) are not averaged with the probes' short ones.
-// GL (experiment build, variant 18): whole 16-byte pieces by global_load_lds_dwordx4
-// straight into the stage, no VGPR round trip.
-template <int BPS, bool NT, int NW, int MAXT, int LV = BB_LV_REG, int TAG = 0, bool GL = false>
+// GL: whole 16-byte pieces by global_load_lds_dwordx4 straight into the stage, no VGPR
+// round trip (the product's form since round 4).  AUX: cache
+// policy bits of those loads (experiment build: 1 = sc0, 2 = nt, 3 = both).
+template <int BPS, bool NT, int NW, int MAXT, int LV = BB_LV_REG, int TAG = 0, bool GL = false, int AUX = 0>
 __global__ __launch_bounds__(NW * BB_WAVE)
 void k_decode_flat_lds(bb_flat_args a)
 {
@@ -117,7 +118,7 @@ void k_decode_flat_lds(bb_flat_args a)
                     if (GL)
                         __builtin_amdgcn_global_load_lds(
                             (const __attribute__((address_space(1))) void *)(base + p0),
-                            (__attribute__((address_space(3))) void *)(&s_stage[wave][k * BB_WAVE]), 16, 0, 0);
+                            (__attribute__((address_space(3))) void *)(&s_stage[wave][k * BB_WAVE]), 16, 0, AUX);
                     else
                         s_stage[wave][piece] = *reinterpret_cast<const bb_u4 *>(base + p0);
                 } else {

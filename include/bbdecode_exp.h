@@ -18,7 +18,7 @@
 extern "C" {
 #endif
 
-#define BB_TUNE_FLAT_VARIANT   0   /* 5 (default) = the product dispatch; 0 = plain kernel (workgroup per work item), 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16 tiles, 4 = contiguous output cut in output space (k_decode_flat_span), 6-9 = explicit write front (k_decode_flat_front; slower), 10-12 = one pass with 2/4/8 stripes per wave (k_decode_flat_es; within +-4 % of 0 and 5), 14 = one float4 per thread and stripe (k_decode_flat_elem), 15 / 16 = the product dispatch with k_decode_flat_lds / k_decode_flat_lut forced for every sample width (A/B of the two byte-table kernels), 19 = k_decode_flat_lds with register-staged loads (round 3) instead of direct-to-LDS loads, 20 = k_decode_flat_lds with direct-to-LDS loads for every sample width (with BB_TUNE_FLAT8_LDS also 8-bit), 21 / 22 = the 2-bit kernel with 4 / 1 waves per workgroup instead of 2 */
+#define BB_TUNE_FLAT_VARIANT   0   /* 5 (default) = the product dispatch; 0 = plain kernel (workgroup per work item), 1 = byte loads (2-bit), 2 = persistent pipelined 4 waves x 8 tiles, 3 = 2 waves x 16 tiles, 4 = contiguous output cut in output space (k_decode_flat_span), 6-9 = explicit write front (k_decode_flat_front; slower), 10-12 = one pass with 2/4/8 stripes per wave (k_decode_flat_es; within +-4 % of 0 and 5), 14 = one float4 per thread and stripe (k_decode_flat_elem), 15 / 16 = the product dispatch with k_decode_flat_lds / k_decode_flat_lut forced for every sample width (A/B of the two byte-table kernels), 19 = k_decode_flat_lds with register-staged loads (round 3) instead of direct-to-LDS loads, 20 = k_decode_flat_lds with direct-to-LDS loads for every sample width (with BB_TUNE_FLAT8_LDS also 8-bit), 21 / 22 = the 2-bit kernel with 4 / 1 waves per workgroup instead of 2, 23 / 24 / 25 = its direct-to-LDS loads with the sc0 / nt / sc0+nt cache policy bits */
 #define BB_TUNE_NT_STORES      1   /* 1 (default) = non-temporal stores; 0 = plain stores */
 #define BB_TUNE_NT_LOADS       3   /* 1 = non-temporal input loads (no effect measured) */
 #define BB_TUNE_TILES_PER_WAVE_8BIT 8 /* > 16: 8-bit contiguous data through the 32-tile instantiation of k_decode_flat_aln instead of the plain kernel */

@@ -30,6 +30,9 @@ def ms_of(fn, reps=4):
 
 
 arms = [("2w_t6", 5, 0), ("4w_t3", 21, 3), ("4w_t4", 21, 4), ("4w_t6", 21, 6), ("1w_t6", 22, 6), ("1w_t8", 22, 8), ("2w_t5", 5, 5), ("2w_t7", 5, 7)]
+if len(sys.argv) > 1 and sys.argv[1] == 'aux':
+    # cache policy bits of the direct-to-LDS loads: default / sc0 / nt / sc0 nt
+    arms = [("default", 5, 0), ("sc0", 23, 0), ("nt", 24, 0), ("sc0_nt", 25, 0)]
 res = {a[0]: [] for a in arms}
 dg = {}
 for rnd in range(3):
