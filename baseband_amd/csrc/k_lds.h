@@ -1,11 +1,15 @@
 // The byte-table decode with 16-BYTE input loads staged through LDS (VERDICT r2
-// next 4), the product's kernel for contiguous 2-BIT output: against
-// k_decode_flat_lut's dword-per-lane loads handed out by ds_bpermute it is
-// +1.0-1.5 % at the headline size and +1.3-5.4 % at 2^16-2^18 frames for
-// 8000-, 8192- and 10000-byte payloads, bit-identical (same-process A/B,
-// profiles/r03j_exp_lds.log); 1-bit samples show no difference and 4-bit
-// samples lose 3-12 % (two table reads per store), so those stay with
-// k_decode_flat_lut.
+// next 4) -- since round 4 by DIRECT-TO-LDS loads (GL: global_load_lds_dwordx4,
+// no VGPR round trip) -- the product's kernel for contiguous 2-bit output (the
+// headline kernel, 6 tiles per wave), 4-bit output (4 tiles) and int8 output
+// (k_decode_flat_lds<8,..,INT8,..,GL>, 4 tiles); 1-bit samples stay with
+// k_decode_flat_lut (k_lut.h).  Measurements: round 3, register staging against
+// k_decode_flat_lut's dword-per-lane loads handed out by ds_bpermute: +1.0-1.5 %
+// at the headline size, +1.3-5.4 % at 2^16-2^18 frames, 4-bit -3..-12 %
+// (profiles/r03j_exp_lds.log); round 4, direct-to-LDS against register staging:
+// 2-bit +2.4-2.8 % with an index on three boxes (r04d_exp_glds3_box*.log), 4-bit
+// +2.6-8.5 % against k_decode_flat_lut (r04r_exp_glds5_box*.log), int8 +1.2-4.7 %
+// against the plain kernel (r04c, r04d); 1-bit -18 %.
 //
 // A lane that loads 16 contiguous bytes holds the codes of 64 (2-bit) samples
 // = 256 B of output, but the store pattern that HBM wants is 1 KiB contiguous
