@@ -116,6 +116,10 @@ class FileBase:
 
     def close(self):
         self._frame_dev = None
+        img, self._image = getattr(self, '_image', None), None
+        if img is not None:
+            from ..staging import retire_image
+            retire_image(img)
         self.fh_raw.close()
 
     def __enter__(self):

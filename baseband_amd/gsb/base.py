@@ -16,7 +16,7 @@ import torch
 from .. import _lib, kernels
 from ..base.base import FileBase, GPUStreamReaderBase
 from ..base.writer import GPUStreamWriterBase, LazyWriteFile
-from ..staging import host_image, write_device_bytes
+from ..staging import host_image, retire_image, write_device_bytes
 from .header import GSBHeader
 from .payload import GSBPayload
 
@@ -154,6 +154,11 @@ class GSBStreamReader(GPUStreamReaderBase):
         if self._pipeline is not None:
             self._pipeline.release()
             self._pipeline = None
+        images, self._images, self._set_image = self._images, [], None
+        for pair in images:                 # (large mappings are torn down in the background)
+            for img in pair:
+                retire_image(img)
+        del images
         self.fh_ts.close()
         if self._rawdump:
             self.fh_raw.close()

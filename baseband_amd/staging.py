@@ -7,6 +7,7 @@ cache into a pinned buffer while the DMA engine moves window k on a side
 stream (hipMemcpyAsync) and the compute stream scans/decodes window k-1.
 Ordering is by events only; nothing blocks the device.
 """
+import ctypes
 import mmap
 import os
 import threading
@@ -33,7 +34,8 @@ def host_image(fh):
             return np.empty(0, dtype=np.uint8)
         mm = mmap.mmap(fileno, size, access=mmap.ACCESS_READ)
         img = np.frombuffer(mm, dtype=np.uint8).view(FileImage)
-        img.fd = fileno                     # (large windows get a mapping of their own: `_stage`)
+        img.fd = fileno                     # (BB_STAGE_WINDOW_MMAP: large windows get a mapping of their own)
+        img.mm = mm                         # (`retire_image` empties the mapping's page tables in the background)
         return img
     pos = fh.tell()
     fh.seek(0)
@@ -54,9 +56,56 @@ class FileImage(np.ndarray):
     fault their pages in while the previous window's is being torn down) and
     the totals scatter over each other on this host: OFF by default."""
     fd = None
+    mm = None
 
     def __array_finalize__(self, obj):
         self.fd = None                      # (views and slices are plain arrays as far as staging cares)
+        self.mm = None
+
+
+_reaper = None
+_RETIRE = os.environ.get('BB_STAGE_RETIRE', '1') not in ('0', 'no', 'off')
+
+
+def _zap(keep, addr, n):
+    # One madvise over the whole mapping through ctypes, which drops the GIL for
+    # the call (mmap.madvise keeps it: the reader's thread then waits a GIL
+    # switch interval, 5 ms, at its next bytecode -- profiles/r04zy_prof_close.log).
+    # MADV_DONTNEED takes the address space lock for READING: page faults of a
+    # read that runs meanwhile are not held up, unlike by munmap.  `keep` (the
+    # mmap object and a view of it, which also bars an explicit close()) is only
+    # held so that the mapping outlives the call.
+    global _madvise
+    try:
+        if _madvise is None:
+            libc = ctypes.CDLL(None, use_errno=True)
+            libc.madvise.argtypes = (ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
+            libc.madvise.restype = ctypes.c_int
+            _madvise = libc.madvise
+        _madvise(addr, n, mmap.MADV_DONTNEED)
+    except Exception:
+        pass
+
+
+_madvise = None
+
+
+def retire_image(img):
+    """A reader is done with the whole-file mapping `img` (from `host_image`):
+    empty its page tables on a background thread.  Tearing down a mapping costs
+    per populated page -- 6 ms for a 2 GiB file that was read through it
+    (profiles/r04x_prof_munmap.log) -- and without this close() pays for it when
+    the last view of the mapping goes (a loop over 2 GiB files: 0.80 -> 0.93 of
+    the link, profiles/r04zx_pipeline_retire.log).
+    The pages stay in the page cache; views of the image that are still around
+    simply fault them in again."""
+    global _reaper
+    mm = getattr(img, 'mm', None)
+    if not _RETIRE or mm is None or len(img) < (64 << 20):
+        return
+    if _reaper is None:
+        _reaper = ThreadPoolExecutor(1, thread_name_prefix='bb-retire')
+    _reaper.submit(_zap, (mm, img), img.ctypes.data, len(img))
 
 
 _WINDOW_MMAP = os.environ.get('BB_STAGE_WINDOW_MMAP', '0') not in ('0', 'no', 'off')

@@ -152,7 +152,7 @@ def test_shipped_kernels_have_no_scratch_and_keep_four_waves_per_simd():
     last = r.stdout.strip().splitlines()[-1]
     n, flagged = int(last.split()[0]), int(last.split()[2])
     assert flagged == 0 and 60 <= n < 150, last
-    assert 'k_decode_flat_lds<2, true, 2, 8, 0, 0, true>' in r.stdout
+    assert 'k_decode_flat_lds<2, true, 2, 8, 0, 0, true, 0>' in r.stdout
     # the measurement variants are not in the product code object
     for name in ('k_decode_flat_front', 'k_decode_flat_es', 'k_decode_flat_pipe', 'k_decode_flat_aln',
                  'k_decode_flat_span', 'k_decode_flat_elem', 'k_decode_flat2_bytes'):

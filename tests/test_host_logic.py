@@ -1065,3 +1065,35 @@ def test_idle_trim_policy_without_a_device(monkeypatch):
     placement._auto_trim()
     time.sleep(0.7)
     assert fake.trims == 2 and fake.backed == 0 and placement._idle_watcher is None
+
+
+def test_retired_file_mapping_still_reads_the_same(tmp_path):
+    """`staging.retire_image` empties the page tables of a whole-file mapping
+    in the background (close() of a reader); views that are still around keep
+    reading the file's bytes, and small files are left alone."""
+    from baseband_amd import staging
+    rng = np.random.default_rng(5)
+    block = rng.integers(0, 256, 1 << 20, dtype=np.uint8)
+    path = tmp_path / 'big.bin'
+    with open(path, 'wb') as f:
+        for _ in range(65):
+            f.write(block.tobytes())
+    with open(path, 'rb') as f:
+        img = staging.host_image(f)
+        assert isinstance(img, staging.FileImage) and img.mm is not None
+        view = img[3 << 20:4 << 20]
+        assert view.mm is None and np.array_equal(view, block)
+        total = int(img.sum(dtype=np.uint64))
+        staging.retire_image(img)
+        assert staging._reaper is not None
+        staging._reaper.submit(lambda: None).result(timeout=30)      # (the zap before it has run)
+        assert np.array_equal(view, block)
+        assert int(img.sum(dtype=np.uint64)) == total
+    small = tmp_path / 'small.bin'
+    small.write_bytes(block.tobytes())
+    with open(small, 'rb') as f:
+        simg = staging.host_image(f)
+        before = staging._reaper
+        staging.retire_image(simg)                  # below 64 MiB: nothing to do
+        staging.retire_image(np.zeros(4, np.uint8))  # not a mapping: nothing to do
+        assert staging._reaper is before
