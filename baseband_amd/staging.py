@@ -68,13 +68,15 @@ _RETIRE = os.environ.get('BB_STAGE_RETIRE', '1') not in ('0', 'no', 'off')
 
 
 def _zap(keep, addr, n):
-    # One madvise over the whole mapping through ctypes, which drops the GIL for
-    # the call (mmap.madvise keeps it: the reader's thread then waits a GIL
-    # switch interval, 5 ms, at its next bytecode -- profiles/r04zy_prof_close.log).
-    # MADV_DONTNEED takes the address space lock for READING: page faults of a
-    # read that runs meanwhile are not held up, unlike by munmap.  `keep` (the
-    # mmap object and a view of it, which also bars an explicit close()) is only
-    # held so that the mapping outlives the call.
+    # madvise through ctypes, which drops the GIL for the call (mmap.madvise
+    # keeps it: the reader's thread then waits a GIL switch interval, 5 ms, at
+    # its next bytecode -- profiles/r04zy_prof_close.log), in pieces of 16 MiB:
+    # MADV_DONTNEED holds the address space lock for READING, which page faults
+    # of a read that runs meanwhile share, but an mmap() inside the HIP runtime
+    # (the next reader's first copy on a new stream) waits for -- 6.8 ms behind
+    # one call over 2 GiB, 50 us behind a piece.  `keep` (the mmap object and a
+    # view of it, which also bars an explicit close()) is only held so that the
+    # mapping outlives the calls.
     global _madvise
     try:
         if _madvise is None:
@@ -82,11 +84,14 @@ def _zap(keep, addr, n):
             libc.madvise.argtypes = (ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int)
             libc.madvise.restype = ctypes.c_int
             _madvise = libc.madvise
-        _madvise(addr, n, mmap.MADV_DONTNEED)
+        step = _ZAP_STEP
+        for lo in range(0, n, step):
+            _madvise(addr + lo, min(step, n - lo), mmap.MADV_DONTNEED)
     except Exception:
         pass
 
 
+_ZAP_STEP = int(os.environ.get('BB_STAGE_RETIRE_STEP_MIB', 16)) << 20
 _madvise = None
 
 
@@ -220,10 +225,10 @@ def window_trace_summary(rows):
     nb = sum(r["bytes"] for r in rows)
     h2d = sum(r["events"][0].elapsed_time(r["events"][1]) for r in rows)
     ker = sum(r["events"][2].elapsed_time(r["events"][3]) for r in rows)
-    host = {k: sum(r[k] for r in rows) for k in ("wait_ms", "host_copy_ms", "enqueue_ms")}
+    host = {k: sum(r[k] for r in rows) for k in ("wait_ms", "host_copy_ms", "enqueue_ms", "enqueue_h2d_ms")}
     return {"windows": len(rows), "bytes": nb,
             "host_wait_for_buffer_ms": round(host["wait_ms"], 2), "host_copy_ms": round(host["host_copy_ms"], 2),
-            "host_enqueue_ms": round(host["enqueue_ms"], 2),
+            "host_enqueue_ms": round(host["enqueue_ms"], 2), "host_enqueue_h2d_ms": round(host["enqueue_h2d_ms"], 2),
             "host_copy_GBps": round(nb / max(host["host_copy_ms"], 1e-6) / 1e6, 1),
             "h2d_ms": round(h2d, 2), "h2d_GBps": round(nb / max(h2d, 1e-6) / 1e6, 1), "kernels_ms": round(ker, 2)}
 
@@ -306,6 +311,7 @@ class WindowPipeline:
                 copied.record(self._copy_stream)
             main.wait_event(copied)
             if tr is not None:
+                t2b = time.perf_counter()
                 k0 = torch.cuda.Event(enable_timing=True)
                 k0.record(main)
             process(target, i)
@@ -315,7 +321,7 @@ class WindowPipeline:
             if tr is not None:
                 t3 = time.perf_counter()
                 tr.append({"bytes": n, "wait_ms": (t1 - t0) * 1e3, "host_copy_ms": (t2 - t1) * 1e3,
-                           "enqueue_ms": (t3 - t2) * 1e3, "t_start": t0, "t_end": t3, "events": (e0, copied, k0, done)})
+                           "enqueue_ms": (t3 - t2) * 1e3, "enqueue_h2d_ms": (t2b - t2) * 1e3, "t_start": t0, "t_end": t3, "events": (e0, copied, k0, done)})
 
     def drain(self):
         for ev in self._done:

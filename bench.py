@@ -1189,6 +1189,7 @@ def leg_pipeline(device, gib=2.0, reads=3):
                         "fraction_of_pinned_h2d": round(size / best / 1e9 / link, 3),
                         "host_ms_of_the_best_read": dict(zip(("open", "read_call", "final_sync", "close"),
                                                              [round(x * 1e3, 2) for x in parts[int(np.argmin(ts))]])),
+                        "host_ms_of_each_read": [[round(x * 1e3, 2) for x in p_] for p_ in parts],
                         "windows": summary, "traced_read_s": round(traced_s, 4),
                         "equals_resident_decode": same})
             del got, ref, dev, raw
