@@ -154,7 +154,7 @@ class VLBIFileReaderBase(FileBase):
         return np.atleast_1d(arr).astype('<u4').view(np.uint8)
 
     def locate_frames(self, pattern, *, mask=None, frame_nbytes=None, offset=0,
-                      forward=True, maximum=None, check=1):
+                      forward=True, maximum=None, check=1, _here_first=False):
         """Frame starts near the current position, nearest first, at which the
         (masked) byte `pattern` sits `offset` bytes into the frame, whose frame
         fits in the file, and for which the pattern is also found `check` frames
@@ -204,6 +204,23 @@ class VLBIFileReaderBase(FileBase):
         size = min(maximum + 1 + check_max - check_min, stop - start - pat.size)
         if size <= 0:
             return []
+        if _here_first:
+            # (`find_header`: the current position is the nearest candidate in
+            # either direction; when it qualifies -- a file of whole frames read
+            # from its start, or backwards from its end -- two or three compares
+            # of the pattern replace the search over two frames: Mark 4 open()
+            # 1.65 -> 1.0 ms.  Same conditions as the filter below.)
+            if not (max(seek_start, 0) <= here < min(seek_start + maximum + 1, stop - need + 1)):
+                return []
+            lo_ok, hi_ok = start, stop - offset - pat.size
+            for c in [0] + [c for c in checks.tolist() if lo_ok <= here + c < hi_ok]:
+                at = here + c + offset
+                if at < 0 or at + pat.size > len(image):
+                    return []
+                piece = np.asarray(image[at:at + pat.size])
+                if np.any(piece != pat) if msk is None else np.any((piece ^ pat) & msk):
+                    return []
+            return [here]
         data = np.asarray(image[start:start + size + pat.size])
 
         def matches_at(lo, hi):
@@ -234,15 +251,16 @@ class VLBIFileReaderBase(FileBase):
         """Nearest header from the current position (arguments as for
         `locate_frames`); the file pointer is left at its start
         (base/base.py:337-368)."""
-        for location in self.locate_frames(*args, **kwargs):
-            with self.temporary_offset(location):
-                try:
-                    header = self.read_header()
-                except Exception:
-                    continue
-            if self._accept_header(header):
-                self.fh_raw.seek(location)
-                return header
+        for here_first in (True, False):
+            for location in self.locate_frames(*args, _here_first=here_first, **kwargs):
+                with self.temporary_offset(location):
+                    try:
+                        header = self.read_header()
+                    except Exception:
+                        continue
+                if self._accept_header(header):
+                    self.fh_raw.seek(location)
+                    return header
         raise HeaderNotFoundError('could not locate a a nearby frame.')
 
     def _accept_header(self, header):

@@ -67,7 +67,7 @@ class Mark4FileReader(VLBIFileReaderBase):
         return bool(w[0] == 0 and np.all(w[1:] == np.iinfo(dt).max))
 
     def locate_frames(self, pattern=None, *, mask=None, frame_nbytes=None, offset=0,
-                      forward=True, maximum=None, check=1):
+                      forward=True, maximum=None, check=1, _here_first=False):
         """As `VLBIFileReaderBase.locate_frames`; by default the Mark 4 sync
         pattern of all tracks plus the zero bit before it, for the reader's
         `ntrack` (found with `determine_ntrack` if not known): stream word 63
@@ -90,7 +90,7 @@ class Mark4FileReader(VLBIFileReaderBase):
             offset = offset + 63 * isz
         return super().locate_frames(pattern, mask=mask, frame_nbytes=frame_nbytes,
                                      offset=offset, forward=forward, maximum=maximum,
-                                     check=check)
+                                     check=check, _here_first=_here_first)
 
     def determine_ntrack(self, maximum=None):
         """Try 16, 32 and 64 tracks (mark4/base.py:168-207)."""

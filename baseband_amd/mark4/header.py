@@ -106,6 +106,20 @@ def _bcd_decode_array(value):
     return result
 
 
+def _bcd_decode_int(value):
+    """`_bcd_decode_array` for one number, in plain Python (a header's time at
+    open(): 15 array decodes cost 1 ms of a 1.6 ms open)."""
+    value, result, factor = int(value), 0, 1
+    while value > 0:
+        digit = value & 0xf
+        if digit > 9:
+            raise ValueError("invalid BCD encoded value")
+        result += digit * factor
+        factor *= 10
+        value >>= 4
+    return result
+
+
 def _bcd_encode(value):
     result, shift, value = 0, 0, int(value)
     while value > 0:
@@ -568,11 +582,11 @@ class Mark4Header:
     def time_quarter_ms(self, track=0):
         """Time of `track` in units of 0.25 ms since the start of its year
         (what the scan kernel works in)."""
-        day = int(_bcd_decode_array(self['bcd_day'][track]))
-        hour = int(_bcd_decode_array(self['bcd_hour'][track]))
-        minute = int(_bcd_decode_array(self['bcd_minute'][track]))
-        second = int(_bcd_decode_array(self['bcd_second'][track]))
-        ms = int(_bcd_decode_array(self['bcd_fraction'][track]))
+        day = _bcd_decode_int(self['bcd_day'][track])
+        hour = _bcd_decode_int(self['bcd_hour'][track])
+        minute = _bcd_decode_int(self['bcd_minute'][track])
+        second = _bcd_decode_int(self['bcd_second'][track])
+        ms = _bcd_decode_int(self['bcd_fraction'][track])
         return (((day * 24 + hour) * 60 + minute) * 60 + second) * 4000 + 4 * ms + ms % 5
 
     @property

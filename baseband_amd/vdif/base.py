@@ -59,9 +59,11 @@ class VDIFFileReader(VLBIFileReaderBase):
         almost any bytes parse as a VDIF header -- and accepted when the same
         stream invariants are found `check` frames away."""
         if pattern is not None:
-            locations = self.locate_frames(pattern, mask=mask, frame_nbytes=frame_nbytes,
-                                           offset=offset, forward=forward, maximum=maximum,
-                                           check=check)
+            kw = dict(mask=mask, frame_nbytes=frame_nbytes, offset=offset, forward=forward,
+                      maximum=maximum, check=check)
+            # (the current position first: it is the nearest candidate there can be)
+            locations = (self.locate_frames(pattern, _here_first=True, **kw)
+                         or self.locate_frames(pattern, **kw))
             if not locations:
                 raise HeaderNotFoundError('could not locate a a nearby frame.')
             self.fh_raw.seek(locations[0])

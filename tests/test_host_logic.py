@@ -1097,3 +1097,45 @@ def test_retired_file_mapping_still_reads_the_same(tmp_path):
         staging.retire_image(simg)                  # below 64 MiB: nothing to do
         staging.retire_image(np.zeros(4, np.uint8))  # not a mapping: nothing to do
         assert staging._reaper is before
+
+
+def test_find_header_shortcut_agrees_with_the_search(tmp_path):
+    """`find_header` looks at the current position before it searches
+    (`locate_frames(_here_first=True)`): that answers [here] exactly when the
+    full search has `here` as its nearest location, [] otherwise -- forwards
+    and backwards, at frame starts, beside them, and at the ends of the file."""
+    from baseband_amd import mark4
+    image, header0 = synth.random_mark4(11, 6, ntrack=32, fanout=2, lead_bytes=1234)
+    path = tmp_path / 'lead.m4'
+    path.write_bytes(image.tobytes())
+    nb = header0.frame_nbytes
+    with mark4.open(str(path), 'rb', ntrack=32, decade=2010) as fh:
+        size = len(image)
+        spots = [0, 1233, 1234, 1235, 1234 + nb, 1234 + nb - 1, 1234 + 3 * nb + 7,
+                 1234 + 5 * nb, size - nb, size - 1]
+        for forward in (True, False):
+            for here in spots:
+                fh.seek(here)
+                full = fh.locate_frames(forward=forward)
+                fh.seek(here)
+                quick = fh.locate_frames(forward=forward, _here_first=True)
+                assert quick == ([here] if full and full[0] == here else []), (forward, here, full, quick)
+                fh.seek(here)
+                try:
+                    h = fh.find_header(forward=forward)
+                    assert fh.tell() == full[0] and h == fh.read_header()
+                except Exception:
+                    assert not full
+    # VDIF: the pattern of a header, one thread, frames from the start of the file
+    image, header0 = synth.random_vdif(5, 8, nthread=1, nchan=1, bps=2, payload_nbytes=1000)
+    vpath = tmp_path / 'x.vdif'
+    vpath.write_bytes(np.asarray(image).tobytes())
+    with vdif.open(str(vpath), 'rb') as fh:
+        nb = header0.frame_nbytes
+        for forward in (True, False):
+            for here in (0, 1, nb, 3 * nb - 1, 3 * nb, len(image) - nb):
+                fh.seek(here)
+                full = fh.locate_frames(header0, forward=forward)
+                fh.seek(here)
+                quick = fh.locate_frames(header0, forward=forward, _here_first=True)
+                assert quick == ([here] if full and full[0] == here else []), (forward, here)
