@@ -183,6 +183,7 @@ thread_local bb_knob g_tune_xpose_rows{0};   // k_decode_i8_xpose: output rows p
 thread_local bb_knob g_tune_flat8_lds{0};    // experiment: 1 = contiguous 8-bit output through k_decode_flat_lds<8>
 #endif
 thread_local bb_knob g_tune_encode_runs{0};  // k_encode_flat: 256-quad runs per wave and step (1 or 2); 0 = by sample width
+thread_local bb_knob g_tune_encode_lw{0};    // k_encode_flat: log2(stripes) the runs are dealt over (bb_perm_t); 0 = input order
 thread_local bb_knob g_tune_xpose_tc{0};     // k_decode_i8_xpose: channels per tile, 64 / 32 / 16 / 8; 0 = by channel count
 thread_local bb_knob g_tune_xpose_min_nc{8}; // k_decode_i8_xpose without a selection: from this many channels on
 thread_local bb_knob g_tune_xpose{1};        // 1: aligned int8 transposes through k_decode_i8_xpose; 0: k_tiled.h only
@@ -328,15 +329,15 @@ void launch_flat(int bps, int coder, int om, bool nt, dim3 grid, hipStream_t st,
 // every width in the experiment build)
 template <int C, int B>
 void launch_encode_flat(bool direct, int eruns, dim3 grid, dim3 block, hipStream_t st,
-                               const float *d_in, uint64_t nquad, uint8_t *o)
+                               const float *d_in, uint64_t nquad, uint8_t *o, bb_perm_t perm)
 {
     if constexpr (B == 2) {
-        if (direct) { hipLaunchKernelGGL((k_encode_flat<C, 2, true>), grid, block, 0, st, d_in, nquad, o); return; }
+        if (direct) { hipLaunchKernelGGL((k_encode_flat<C, 2, true>), grid, block, 0, st, d_in, nquad, o, perm); return; }
     }
     if constexpr (B == 4 || BB_EXP) {
-        if (eruns == 2) { hipLaunchKernelGGL((k_encode_flat<C, B, false, 2>), grid, block, 0, st, d_in, nquad, o); return; }
+        if (eruns == 2) { hipLaunchKernelGGL((k_encode_flat<C, B, false, 2>), grid, block, 0, st, d_in, nquad, o, perm); return; }
     }
-    hipLaunchKernelGGL((k_encode_flat<C, B, false>), grid, block, 0, st, d_in, nquad, o);
+    hipLaunchKernelGGL((k_encode_flat<C, B, false>), grid, block, 0, st, d_in, nquad, o, perm);
 }
 
 // the byte table kernel with 16-byte loads staged through LDS: contiguous 2-bit
@@ -526,6 +527,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
         case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : value == 128 ? 128 : 0; return BB_OK;
         case BB_TUNE_ENCODE_RUNS: g_tune_encode_runs = (value == 1 || value == 2) ? value : 0; return BB_OK;
+        case BB_TUNE_ENCODE_STRIPES: g_tune_encode_lw = (value >= 0 && value <= 10) ? value : 0; return BB_OK;
         case BB_TUNE_XPOSE_TC: g_tune_xpose_tc = (value == 64 || value == 32 || value == 16 || value == 8) ? value : 0; return BB_OK;
         case BB_TUNE_XPOSE_MIN_NC: g_tune_xpose_min_nc = value < 2 ? 2 : value; return BB_OK;
         case BB_TUNE_GATHER_GLDS: g_tune_gather_glds = value < 0 ? -1 : (value != 0); return BB_OK;
@@ -1797,7 +1799,14 @@ int bb_encode_flat(const float *d_in, size_t nelem, int coder, int bps,
     hipStream_t st = (hipStream_t)stream;
     uint8_t *o = (uint8_t *)d_out;
     const bool direct = g_tune_encode_direct.load() != 0;
-#define BB_E(C, B) launch_encode_flat<C, B>(direct, eruns, grid, block, st, d_in, nquad, o)
+    bb_perm_t perm = {0, 0, 0};
+    const int elw = g_tune_encode_lw.load();
+    if (elw > 0 && ((nquad >> 8) >> elw) >= 64) {
+        perm.lw = (uint32_t)elw;
+        perm.stripe = (nquad >> 8) >> elw;
+        perm.n = perm.stripe << elw;
+    }
+#define BB_E(C, B) launch_encode_flat<C, B>(direct, eruns, grid, block, st, d_in, nquad, o, perm)
     if (coder == BB_CODER_VDIF) {
         switch (bps) { case 1: BB_E(BB_CODER_VDIF, 1); break; case 2: BB_E(BB_CODER_VDIF, 2); break;
                        case 4: BB_E(BB_CODER_VDIF, 4); break; default: BB_E(BB_CODER_VDIF, 8); break; }

@@ -105,7 +105,7 @@ __device__ __forceinline__ uint32_t bb_encode_quad(const bb_f4 v)
 // first compare: 4 x RUNS float4 per lane).
 template <int CODER, int BPS, bool DIRECT, int RUNS = 1>
 __global__ __launch_bounds__(BB_BLOCK)
-void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out)
+void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out, bb_perm_t perm)
 {
     const int lane = bb_lane();
     const bb_f4 *in4 = reinterpret_cast<const bb_f4 *>(in);
@@ -116,15 +116,15 @@ void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out)
       bb_f4 vv[RUNS][4];
 #pragma unroll
       for (int h = 0; h < RUNS; ++h) {
-          const uint64_t q0 = ((rr + h) << 8) + lane;
+          const uint64_t q0 = (bb_perm(perm, rr + h) << 8) + lane;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
               vv[h][j] = (rr + h < nrun) ? __builtin_nontemporal_load(in4 + q0 + 64 * j) : bb_f4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int h = 0; h < RUNS; ++h) {
-        const uint64_t r = rr + h;
-        if (r >= nrun) break;                                   // (wave-uniform)
+        if (rr + h >= nrun) break;                              // (wave-uniform)
+        const uint64_t r = bb_perm(perm, rr + h);
         const uint64_t q0 = (r << 8) + lane;
         uint32_t bits[4];
 #pragma unroll

@@ -248,6 +248,30 @@ void k_decode_gather_select(bb_gather_args a)
                     fl[j] = s_fill[(a.complex_data && (within & 1)) ? 1 : 0];
                 }
                 const uint32_t lrow = 31u - (uint32_t)__clz((int)rowlen);
+                if (BPS != 8 && ((BPS << a.lchunk) & 7) == 0) {
+                    // rows of whole bytes (every multi-channel layout): a kept value's
+                    // byte within its row and its shift are fixed per lane, and values
+                    // that share a byte -- the re / im of a complex channel always do --
+                    // share one LDS read: 2 instead of 4 ds_read_u8 per float4 for two
+                    // complex channels, 1 for a neighbouring aligned pair
+                    const uint32_t rowbytes = (uint32_t)(BPS << a.lchunk) >> 3;
+                    uint32_t bo[4], sh[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { bo[j] = base + (wb[j] >> 3); sh[j] = wb[j] & 7; }
+                    const bool s1 = bo[1] == bo[0], s2 = bo[2] == bo[1], s3 = bo[3] == bo[2];
+                    for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
+                        const uint32_t rb = (q >> lrow) * rowbytes;
+                        uint32_t b[4];
+                        b[0] = rawb[rb + bo[0]];
+                        b[1] = s1 ? b[0] : (uint32_t)rawb[rb + bo[1]];
+                        b[2] = s2 ? b[1] : (uint32_t)rawb[rb + bo[2]];
+                        b[3] = s3 ? b[2] : (uint32_t)rawb[rb + bo[3]];
+                        float r[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[j] = ok ? level((b[j] >> sh[j]) & CMASK) : fl[j];
+                        bb_store4<NT>(obase + q, bb_f4{r[0], r[1], r[2], r[3]});
+                    }
+                } else
                 for (uint32_t q = threadIdx.x * 4; q < nfloat; q += BB_BLOCK * 4) {
                     const uint32_t rbit = ((q >> lrow) << a.lchunk) * BPS;
                     float r[4];
