@@ -16,12 +16,12 @@ too: the same launches run 1-2 % faster when their INPUT lies in arena memory
 first use; it is only a virtual range until tensors need memory, and
 `release_unused()` gives unused memory back (done automatically when torch
 runs out of memory here, and once the arenas have held no block for
-BB_ARENA_IDLE_S = 5 seconds with no reader open).  One arena per device.
+BB_ARENA_IDLE_S = 30 seconds with no reader open).  One arena per device.
 
     BB_ARENA=0          never create one (plain ``torch.empty`` everywhere)
     BB_ARENA_GIB=<n>    capacity of the arena in GiB (default: the device's memory)
     BB_ARENA_IDLE_S=<s> seconds without a live block or an open reader after which the
-                        arenas give their memory back (default 5; 0 = at once)
+                        arenas give their memory back (default 30; 0 = at once)
     BB_ARENA_KEEP=1     never give memory back automatically
     baseband_amd.arena.enable(capacity) / .disable()   the same from the program
 
@@ -83,9 +83,9 @@ _idle_lock = threading.Lock()
 
 def _idle_seconds():
     try:
-        return float(os.environ.get('BB_ARENA_IDLE_S', '5'))
+        return float(os.environ.get('BB_ARENA_IDLE_S', '30'))
     except ValueError:
-        return 5.0
+        return 30.0
 
 
 def _nothing_alive():
@@ -130,11 +130,14 @@ def _watch_idle():
 def _auto_trim(ar=None):
     """A block died or the last reader closed: when no reader is open and no
     arena holds a live block, give the memory back -- after BB_ARENA_IDLE_S
-    seconds (default 5) in which that stays so.  Not at
-    once: growing again is not cheap -- memory that was released before is
-    cleared by the driver when it is created again, 1.5 s for a 48 GiB step
-    (profiles/r04h_prof_arena_grow.log) -- and a script that reads file after
-    file drops to "nothing alive" between two reads all the time.  Costs a
+    seconds (default 30) in which that stays so.  Not at
+    once, and not after a few seconds: growing again is not cheap -- memory
+    that was released before is cleared by the driver when it is created
+    again, 1.5 s for a 48 GiB step on some boxes and 4.6 s on others
+    (profiles/r04h_prof_arena_grow.log, r04zzz_bench.json `mid_size.arena.grow_ms`),
+    and decodes 6 % slower afterwards (0.77 against 0.81-0.84 of the peak into
+    memory that was never used) -- and a script that reads file after file
+    drops to "nothing alive" between two reads all the time.  Costs a
     clock reading per call: ONE daemon thread waits for the deadline, which
     every later call pushes back.  BB_ARENA_IDLE_S=0: at once; BB_ARENA_KEEP=1: never."""
     global _idle_deadline, _idle_watcher

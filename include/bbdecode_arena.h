@@ -36,11 +36,11 @@
  * candidate is only created while the device reports room for it plus 4 GiB.
  * Memory is taken from the device when a block needs it and goes back with
  * bb_arena_trim (the Python host trims by itself once an arena has held no
- * block for BB_ARENA_IDLE_S = 5 seconds with no reader open).  What growing
+ * block for BB_ARENA_IDLE_S = 30 seconds with no reader open).  What growing
  * costs (profiles/r04h_prof_arena_grow.log): creating 48 GiB of memory that was
  * never used in this boot takes 6-11 ms, of memory that was released before --
- * by this or an earlier process -- 1.5-1.9 s on some boxes (the driver clears
- * it on creation) and 7 ms on others; mapping 12 ms; a probe 6-7 ms.
+ * by this or an earlier process -- 1.5-4.6 s on some boxes (the driver clears
+ * it on creation; such a step then decodes about 6 % slower) and 7 ms on others; mapping 12 ms; a probe 6-7 ms.
  *
  * SYNCHRONISATION (unlike include/bbdecode.h's entry points): bb_arena_alloc,
  * when it has to grow, creates and maps memory and runs the probe -- launches

@@ -468,7 +468,7 @@ def test_arena_gives_memory_back_when_nothing_needs_it(tmp_path, monkeypatch):
     and no reader is open; while a reader is open the memory stays (the next
     read reuses it); a step is at most half of the free memory."""
     monkeypatch.setenv('BB_ARENA', '1')
-    monkeypatch.setenv('BB_ARENA_IDLE_S', '0')           # (the default waits 5 s; its timer has a test of its own)
+    monkeypatch.setenv('BB_ARENA_IDLE_S', '0')           # (the default waits 30 s; its timer has a test of its own)
     monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
     monkeypatch.delenv('BB_ARENA_GIB', raising=False)
     import torch
