@@ -312,6 +312,9 @@ class GPUStreamReaderBase:
     """
     # window of file bytes staged per pipeline step
     window_bytes = 64 << 20
+    # ... of a large read streamed from the host (128 and 256 MiB: 1-5 % slower, the
+    # two short windows at the start grow with it; profiles/r04zs_pipeline_buffers.log)
+    pipeline_window_bytes = 64 << 20
 
     def __init__(self, fh_raw, header0, *, sample_rate, samples_per_frame,
                  unsliced_shape, bps, complex_data, squeeze=True, subset=(),
@@ -924,7 +927,7 @@ class GPUStreamReaderBase:
             self._read_small(first, last, flat, spf * row)
         elif nsets:
             image = self._image()
-            per_win = max(1, self.window_bytes // set_nbytes)
+            per_win = max(1, self.pipeline_window_bytes // set_nbytes)
             if self._pipeline is None:
                 self._pipeline = WindowPipeline(image, (per_win + 1) * set_nbytes)
             sink = self._sink_tensor()

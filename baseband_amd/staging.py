@@ -179,8 +179,13 @@ def _stage(dst, image, lo, hi):
 # 5.7-6 ms per reader (hipHostMalloc; torch's pinned allocator did not hand the
 # blocks back in time for the next reader) -- 12 % of a 2 GiB read
 # (profiles/r03i_prof_pipeline_windows.log).  At most `_PINNED_KEEP` bytes are
-# kept; `release_pinned()` drops them.
-_NBUF = int(os.environ.get('BB_STAGING_BUFFERS', 0)) or 2      # pinned buffers per pipeline
+# kept; `release_pinned()` drops them.  THREE buffers per pipeline (two until late in
+# round 4): with two, the page-cache copy of window k+1 can only start when the H2D
+# of window k-1 has ended and has the length of one H2D (1.15 ms) to finish in; a
+# copy that takes longer -- the host is shared -- idles the link.  cfg2 47.8-48.7 ->
+# 52.9-53.0 GB/s, Mark 4 48.8-52.0 -> 52.4-53.1 on a box with slow copies
+# (profiles/r04zs_pipeline_buffers.log); four: no further gain.
+_NBUF = int(os.environ.get('BB_STAGING_BUFFERS', 0)) or 3      # pinned buffers per pipeline
 _PINNED_KEEP = 512 << 20
 _pinned_pool = []           # [(capacity, tensor)]
 
@@ -226,7 +231,15 @@ def window_trace_summary(rows):
     h2d = sum(r["events"][0].elapsed_time(r["events"][1]) for r in rows)
     ker = sum(r["events"][2].elapsed_time(r["events"][3]) for r in rows)
     host = {k: sum(r[k] for r in rows) for k in ("wait_ms", "host_copy_ms", "enqueue_ms", "enqueue_h2d_ms")}
-    return {"windows": len(rows), "bytes": nb,
+    # the copy stream from the start of the first H2D to the end of the last one
+    # (span - h2d_ms = time the link stood idle in between), what the compute
+    # stream still had to do after the last copy, and the host's time before
+    # the first copy was queued (first window's page-cache copy and set-up)
+    span = rows[0]["events"][0].elapsed_time(rows[-1]["events"][1])
+    tail = rows[-1]["events"][1].elapsed_time(rows[-1]["events"][3])
+    lead = (rows[0]["t_end"] - rows[0]["t_start"]) * 1e3
+    return {"windows": len(rows), "bytes": nb, "h2d_span_ms": round(span, 2), "kernels_after_last_h2d_ms": round(tail, 2),
+            "host_before_first_h2d_ms": round(lead, 2),
             "host_wait_for_buffer_ms": round(host["wait_ms"], 2), "host_copy_ms": round(host["host_copy_ms"], 2),
             "host_enqueue_ms": round(host["enqueue_ms"], 2), "host_enqueue_h2d_ms": round(host["enqueue_h2d_ms"], 2),
             "host_copy_GBps": round(nb / max(host["host_copy_ms"], 1e-6) / 1e6, 1),
