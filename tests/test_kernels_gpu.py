@@ -420,7 +420,11 @@ def test_striped_work_order_is_only_an_order(stripes_lw):
 
 @pytest.mark.parametrize('bps,chunk,nslot,sel', [(2, 16, 1, [1, 6]), (2, 32, 8, [6, 7, 18, 19]),
                                                  (1, 4, 3, [3, 0]), (4, 8, 2, [5]), (8, 2, 4, [1]),
-                                                 (8, 16, 1, [0, 15, 7, 7]), (2, 1, 8, [0]), (2, 64, 2, list(range(0, 64, 5)))])
+                                                 (8, 16, 1, [0, 15, 7, 7]), (2, 1, 8, [0]), (2, 64, 2, list(range(0, 64, 5))),
+                                                 # power-of-two rows of whole float4s: values that share a byte share an LDS read
+                                                 (4, 8, 2, [5, 2, 3, 0]), (1, 32, 4, [0, 1, 2, 3, 9, 17, 30, 31]),
+                                                 (2, 32, 4, [0, 1, 2, 3]), (2, 16, 2, [4, 5, 6, 7, 15, 14, 1, 8]),
+                                                 (4, 4, 8, [3, 2, 1, 0]), (2, 4, 16, [2, 0, 3, 3])])
 def test_decode_with_channel_selection(bps, chunk, nslot, sel):
     """bb_decode_frames_select == full decode (oracle) indexed afterwards, with
     missing frames, shuffled payload placement and work-order stripes."""
