@@ -1142,6 +1142,10 @@ def leg_pipeline(device, gib=2.0, reads=3):
             writer()
             row["write_s"] = round(time.perf_counter() - tw, 3)
             size = os.path.getsize(path)
+            # (the stream writer: GPU encode -> pinned -> one write() per 16 MiB; a buffered
+            # write() into a new file is what bounds it, 11-12 GB/s on this host class:
+            # profiles/r03y_exp_file_write.log)
+            row["writer_GBps"] = round(size / max(row["write_s"], 1e-9) / 1e9, 2)
             with open(path, 'rb') as f:                      # warm the page cache
                 while f.read(64 << 20):
                     pass
