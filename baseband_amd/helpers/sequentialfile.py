@@ -102,15 +102,17 @@ class SequenceImage:
     range file by file, and `header_words`, the strided header gather."""
 
     def __init__(self, names):
-        self._maps, starts, total = [], [0], 0
+        self._maps, self._mms, starts, total = [], [], [0], 0
         for name in names:
             size = os.path.getsize(name)
             if size:
                 with io.open(name, 'rb') as f:
                     mm = mmap.mmap(f.fileno(), size, access=mmap.ACCESS_READ)
                 self._maps.append(np.frombuffer(mm, dtype=np.uint8))
+                self._mms.append(mm)
             else:
                 self._maps.append(np.empty(0, np.uint8))
+                self._mms.append(None)
             total += size
             starts.append(total)
         self._starts = starts
@@ -120,6 +122,14 @@ class SequenceImage:
         return self._starts[-1]
 
     shape = property(lambda self: (len(self),))
+
+    def retire(self):
+        """The reader is done with the image: large mappings are torn down on
+        the background thread of `staging.retire_image`."""
+        from ..staging import retire_mapping
+        for mm, arr in zip(self._mms, self._maps):
+            if mm is not None:
+                retire_mapping(mm, arr)
 
     def pieces(self, lo, hi):
         """Array views that together hold bytes [lo, hi)."""

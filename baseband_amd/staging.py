@@ -50,8 +50,8 @@ class FileImage(np.ndarray):
     SHORT-LIVED mappings of their own (`_stage`) instead of this whole-file
     mapping, whose pages then never get populated: tearing down a mapping costs
     per populated page -- 6 ms for a 2 GiB file that was read through it, paid
-    by the NEXT open() (or at exit) -- while a window's mapping is torn down
-    inside the pipeline's loop.  Measured (profiles/r04w_pipeline_window_mmap.log):
+    at close() (since late in round 4 on a background thread: `retire_image`) --
+    while a window's mapping is torn down inside the pipeline's loop.  Measured (profiles/r04w_pipeline_window_mmap.log):
     open() 6-7 -> 0.4 ms, but the page-cache copies slow down (fresh mappings
     fault their pages in while the previous window's is being torn down) and
     the totals scatter over each other on this host: OFF by default."""
@@ -65,6 +65,7 @@ class FileImage(np.ndarray):
 
 _reaper = None
 _RETIRE = os.environ.get('BB_STAGE_RETIRE', '1') not in ('0', 'no', 'off')
+_RETIRE_MIN = int(os.environ.get('BB_STAGE_RETIRE_MIN_MIB', 8)) << 20      # smaller mappings: ordinary teardown (3 us per MiB)
 
 
 def _zap(keep, addr, n):
@@ -95,22 +96,32 @@ _ZAP_STEP = int(os.environ.get('BB_STAGE_RETIRE_STEP_MIB', 16)) << 20
 _madvise = None
 
 
+def retire_mapping(mm, view):
+    """Empty the page tables of mapping `mm` (of which `view` is a uint8 array
+    from offset 0) on the background thread; mappings below 8 MiB are left to
+    the ordinary teardown."""
+    global _reaper
+    if not _RETIRE or mm is None or len(view) < _RETIRE_MIN:
+        return
+    if _reaper is None:
+        _reaper = ThreadPoolExecutor(1, thread_name_prefix='bb-retire')
+    _reaper.submit(_zap, (mm, view), view.ctypes.data, len(view))
+
+
 def retire_image(img):
-    """A reader is done with the whole-file mapping `img` (from `host_image`):
-    empty its page tables on a background thread.  Tearing down a mapping costs
-    per populated page -- 6 ms for a 2 GiB file that was read through it
+    """A reader is done with the whole-file mapping `img` (from `host_image`;
+    a `SequenceImage` retires the mappings of its files): empty its page tables
+    on a background thread.  Tearing down a mapping costs per populated page --
+    6 ms for a 2 GiB file that was read through it
     (profiles/r04x_prof_munmap.log) -- and without this close() pays for it when
     the last view of the mapping goes (a loop over 2 GiB files: 0.80 -> 0.93 of
     the link, profiles/r04zx_pipeline_retire.log).
     The pages stay in the page cache; views of the image that are still around
     simply fault them in again."""
-    global _reaper
-    mm = getattr(img, 'mm', None)
-    if not _RETIRE or mm is None or len(img) < (64 << 20):
+    if hasattr(img, 'retire'):
+        img.retire()
         return
-    if _reaper is None:
-        _reaper = ThreadPoolExecutor(1, thread_name_prefix='bb-retire')
-    _reaper.submit(_zap, (mm, img), img.ctypes.data, len(img))
+    retire_mapping(getattr(img, 'mm', None), img)
 
 
 _WINDOW_MMAP = os.environ.get('BB_STAGE_WINDOW_MMAP', '0') not in ('0', 'no', 'off')

@@ -1093,12 +1093,24 @@ def test_retired_file_mapping_still_reads_the_same(tmp_path):
         staging._reaper.submit(lambda: None).result(timeout=30)      # (the zap before it has run)
         assert np.array_equal(view, block)
         assert int(img.sum(dtype=np.uint64)) == total
+    # a file sequence retires the mappings of its (large) files
+    from baseband_amd.helpers.sequentialfile import SequenceImage
+    second = tmp_path / 'big2.bin'
+    with open(second, 'wb') as f:
+        for _ in range(64):
+            f.write(block[::-1].tobytes())
+    seq = SequenceImage([str(path), str(second)])
+    cut = seq[(65 << 20) - 100:(65 << 20) + 100].copy()
+    staging.retire_image(seq)
+    staging._reaper.submit(lambda: None).result(timeout=30)
+    assert np.array_equal(seq[(65 << 20) - 100:(65 << 20) + 100], cut)
+    assert np.array_equal(seq[(65 << 20):(66 << 20)], block[::-1])
     small = tmp_path / 'small.bin'
     small.write_bytes(block.tobytes())
     with open(small, 'rb') as f:
         simg = staging.host_image(f)
         before = staging._reaper
-        staging.retire_image(simg)                  # below 64 MiB: nothing to do
+        staging.retire_image(simg)                  # below 8 MiB: nothing to do
         staging.retire_image(np.zeros(4, np.uint8))  # not a mapping: nothing to do
         assert staging._reaper is before
 
