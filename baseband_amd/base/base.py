@@ -21,6 +21,7 @@ from .. import kernels
 from ..placement import empty_output
 from .. import placement as _placement
 from ..staging import host_image, WindowPipeline
+from .quantities import as_time, as_timedelta, is_time_like, is_duration_like
 
 __all__ = ['FileBase', 'VLBIFileReaderBase', 'GPUStreamReaderBase',
            'HeaderNotFoundError']
@@ -567,17 +568,26 @@ class GPUStreamReaderBase:
             return self.time
         if unit == 's':
             return self.offset / self.sample_rate
-        raise ValueError("unit should be None, 'time' or 's'")
+        if hasattr(unit, 'to'):
+            # a unit object of the caller's (astropy: ``fh.tell(u.ms)``): the
+            # offset in that unit, as whatever number * unit makes (a Quantity)
+            return (self.offset / self.sample_rate / float(unit.to('s'))) * unit
+        raise ValueError("unit should be None, 'time', 's' or a unit of time")
 
     def seek(self, offset, whence=0):
         """Move the sample pointer (base/base.py:876-917).  `offset` may be an
-        integer sample count, a ``numpy.timedelta64`` or a ``numpy.datetime64``."""
+        integer sample count, a ``numpy.timedelta64`` or a ``numpy.datetime64``,
+        a float number of seconds -- or what the reference's callers pass: a
+        `Time` (absolute; `whence` is ignored), a `TimeDelta` or a `Quantity`
+        of time (base/quantities.py)."""
         try:
             offset = operator.index(offset)
         except Exception:
-            if isinstance(offset, np.datetime64):
-                offset = offset - self.start_time
+            if isinstance(offset, np.datetime64) or is_time_like(offset):
+                offset = as_time(offset) - self.start_time
                 whence = 0
+            elif is_duration_like(offset):
+                offset = as_timedelta(offset)
             if isinstance(offset, np.timedelta64):
                 ns = offset / np.timedelta64(1, 'ns')
                 offset = int(round(ns * self.sample_rate / 1e9))

@@ -11,6 +11,7 @@ import os
 
 from ..helpers import sequentialfile as sf
 from .writer import LazyWriteFile
+from .quantities import normalize_kwargs
 
 __all__ = ['FormatOpener', 'source_kind']
 
@@ -119,6 +120,9 @@ class FormatOpener:
 
     def __call__(self, name, mode='rs', **kwargs):
         mode = self.normalize_mode(mode)
+        # what reference callers pass (Quantity rates and sizes, Time instants:
+        # vdif/base.py:422-454 there) -> plain Hz / bytes / datetime64[ns]
+        kwargs = normalize_kwargs(kwargs)
         if (mode == 'ws' and self.default_file_size is not None
                 and source_kind(name) in ('sequence', 'template')
                 and 'file_size' not in kwargs and kwargs.get('header0') is not None):

@@ -12,6 +12,7 @@ import warnings
 
 import numpy as np
 import torch
+from .quantities import hz
 
 
 class LazyWriteFile:
@@ -79,7 +80,7 @@ class GPUStreamWriterBase:
                  unsliced_shape, bps, complex_data, squeeze=True):
         self.fh_raw = fh_raw
         self.header0 = header0
-        self.sample_rate = float(sample_rate)
+        self.sample_rate = hz(sample_rate)
         self.samples_per_frame = samples_per_frame
         self._unsliced_shape = tuple(unsliced_shape)
         self.bps = bps

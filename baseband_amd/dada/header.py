@@ -2,6 +2,7 @@
 (default 4096) (dada/header.py:117-200,289-440).  Times are
 ``numpy.datetime64[ns]``; sample rates are in Hz."""
 import numpy as np
+from ..base.quantities import as_time, hz, seconds
 
 __all__ = ['DADAHeader']
 
@@ -221,7 +222,7 @@ class DADAHeader(dict):
     def sample_rate(self, sample_rate):
         # TSAMP in us, BW in MHz keeping the sign (sideband) it had
         # (dada/header.py:346-351)
-        mhz = float(sample_rate) / 1e6
+        mhz = hz(sample_rate) / 1e6
         self['TSAMP'] = 1. / abs(mhz)
         bw = mhz * self['NCHAN'] / (1 if self.complex_data else 2)
         self['BW'] = (-1 if self.get('BW', bw) < 0 else 1) * bw
@@ -269,9 +270,9 @@ class DADAHeader(dict):
 
     @offset.setter
     def offset(self, offset):
-        """`offset` in seconds (float) or a numpy timedelta64."""
-        if isinstance(offset, np.timedelta64):
-            offset = offset.astype('timedelta64[ns]').astype(np.int64) * 1e-9
+        """`offset` in seconds (float), a numpy timedelta64, a Quantity of
+        time or a TimeDelta."""
+        offset = seconds(offset)
         self['OBS_OFFSET'] = (int(round(offset / (self['TSAMP'] * 1e-6)))
                               * ((self._sample_nbits + 7) // 8))
 
@@ -290,7 +291,7 @@ class DADAHeader(dict):
     def start_time(self, start_time):
         """UTC_START as yyyy-mm-dd-hh:mm:ss[.fffffffff] and MJD_START with 15
         decimals (dada/header.py:409-421)."""
-        t = np.datetime64(start_time, 'ns')
+        t = as_time(start_time)
         text = str(t).replace('T', '-')
         self['UTC_START'] = text[:-10] if text.endswith('.000000000') else text
         day = t.astype('datetime64[D]')
@@ -306,7 +307,7 @@ class DADAHeader(dict):
     def time(self, time):
         """Sets the start time if there is none yet, else the offset
         (dada/header.py:428-444)."""
-        time = np.datetime64(time, 'ns')
+        time = as_time(time)
         if 'MJD_START' not in self:
             self.start_time = time - np.timedelta64(int(round(self.offset * 1e9)), 'ns')
         else:

@@ -19,6 +19,7 @@ from ..base.writer import GPUStreamWriterBase, LazyWriteFile
 from ..staging import host_image, retire_image, write_device_bytes
 from .header import GSBHeader
 from .payload import GSBPayload
+from ..base.quantities import hz
 
 __all__ = ['GSBTimeStampIO', 'GSBFileReader', 'GSBFileWriter', 'GSBStreamReader',
            'GSBStreamWriter', 'open']
@@ -114,7 +115,7 @@ class GSBStreamReader(GPUStreamReaderBase):
             sample_rate = samples_per_frame * DEFAULT_FRAME_RATE
         shape = (nchan,) if rawdump else (len(fh_raw), nchan)
         super().__init__(
-            fh_raw, header0, sample_rate=float(sample_rate),
+            fh_raw, header0, sample_rate=hz(sample_rate),
             samples_per_frame=samples_per_frame, unsliced_shape=shape, bps=bps,
             complex_data=complex_data, squeeze=squeeze, subset=subset,
             fill_value=0., verify=verify)
@@ -277,7 +278,7 @@ class GSBStreamWriter(GPUStreamWriterBase):
         if sample_rate is None:
             sample_rate = samples_per_frame * DEFAULT_FRAME_RATE
         shape = (nchan,) if rawdump else (len(fh_raw), nchan)
-        super().__init__(fh_raw, header0, sample_rate=float(sample_rate),
+        super().__init__(fh_raw, header0, sample_rate=hz(sample_rate),
                          samples_per_frame=samples_per_frame, unsliced_shape=shape,
                          bps=bps, complex_data=complex_data, squeeze=squeeze)
         self._payload_nbytes, self._rawdump, self._nfiles = payload_nbytes, rawdump, nfiles

@@ -3,6 +3,7 @@ frame.  Rawdump lines carry the PC time only; phased lines carry PC time,
 GPS time, sequence number and memory block.  Times are IST (UTC+5:30) in the
 file and ``numpy.datetime64[ns]`` UTC here."""
 import numpy as np
+from ..base.quantities import as_time
 
 __all__ = ['GSBHeader', 'GSBRawdumpHeader', 'GSBPhasedHeader']
 
@@ -21,7 +22,7 @@ def _parse_time(items):
 def _format_time(time, precision):
     """UTC ``datetime64`` -> the seven items ``YYYY MM DD HH MM SS 0.fff...``
     in IST, rounded to `precision` decimals (gsb/header.py:19-68)."""
-    t = np.datetime64(time, 'ns') + _IST
+    t = as_time(time) + _IST
     unit = 10 ** (9 - precision)
     ticks = (int(t.astype(np.int64)) + unit // 2) // unit        # nearest tick
     sec, frac = divmod(ticks, 10 ** precision)

@@ -5,6 +5,7 @@ guppi/header.py:216-352.  Times are ``numpy.datetime64[ns]``."""
 import operator
 
 import numpy as np
+from ..base.quantities import as_time, hz, seconds
 
 __all__ = ['GUPPIHeader']
 
@@ -235,7 +236,7 @@ class GUPPIHeader(dict):
     @sample_rate.setter
     def sample_rate(self, sample_rate):
         # TBIN in s; OBSBW in MHz (guppi/header.py:303-308)
-        sample_rate = float(sample_rate)
+        sample_rate = hz(sample_rate)
         self['TBIN'] = 1. / abs(sample_rate)
         self['OBSBW'] = (sample_rate / 1e6 * int(self['OBSNCHAN'])
                          / (1 if self.complex_data else 2))
@@ -286,9 +287,9 @@ class GUPPIHeader(dict):
 
     @offset.setter
     def offset(self, offset):
-        """`offset` in seconds (float) or a numpy timedelta64."""
-        if isinstance(offset, np.timedelta64):
-            offset = offset.astype('timedelta64[ns]').astype(np.int64) * 1e-9
+        """`offset` in seconds (float), a numpy timedelta64, a Quantity of
+        time or a TimeDelta."""
+        offset = seconds(offset)
         self['PKTIDX'] = int(round(offset / float(self['TBIN']) * ((self._bpcs + 7) // 8)))
 
     @property
@@ -302,7 +303,7 @@ class GUPPIHeader(dict):
     def start_time(self, start_time):
         """STT_IMJD (int), STT_SMJD and STT_OFFS (floats: whole and fractional
         seconds of the day, guppi/header.py:392-400)."""
-        t = np.datetime64(start_time, 'ns')
+        t = as_time(start_time)
         day = t.astype('datetime64[D]')
         seconds = int((t - day).astype(np.int64)) / 1e9
         self['STT_IMJD'] = int(day.astype(np.int64)) + _MJD_UNIX
@@ -314,7 +315,7 @@ class GUPPIHeader(dict):
 
     @time.setter
     def time(self, time):
-        time = np.datetime64(time, 'ns')
+        time = as_time(time)
         if 'STT_IMJD' not in self:
             self.start_time = time - np.timedelta64(int(round(self.offset * 1e9)), 'ns')
         else:

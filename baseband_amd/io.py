@@ -11,6 +11,7 @@ import importlib
 import inspect
 
 import numpy as np
+from .base.quantities import as_time, normalize_kwargs
 
 __all__ = ['FORMATS', 'file_info', 'open']
 
@@ -51,7 +52,7 @@ def _consistent(key, value, info):
     if start is not None and key in ('ref_time', 'kday', 'decade'):
         start = np.datetime64(start, 'ns')
         if key == 'ref_time':
-            return abs((np.datetime64(value, 'ns') - start) / np.timedelta64(1, 'D')) < 500
+            return abs((as_time(value) - start) / np.timedelta64(1, 'D')) < 500
         if key == 'kday':
             mjd = int(start.astype('datetime64[D]').astype(np.int64)) + 40587
             return mjd // 1000 * 1000 == value
@@ -104,6 +105,7 @@ def file_info(name, format=None, **kwargs):
     """Info on a baseband file of unknown format: every format in `format`
     (default: all) is tried in turn (io/__init__.py:99-176)."""
     formats = FORMATS if format is None else (format,) if isinstance(format, str) else tuple(format)
+    kwargs = normalize_kwargs(kwargs)
     reasons = []
     for fmt in formats:
         info = _format_info(fmt, name, dict(kwargs))
@@ -116,6 +118,7 @@ def file_info(name, format=None, **kwargs):
 def open(name, mode='rs', format=None, **kwargs):
     """Open a baseband file; without `format` (or with a tuple of candidates)
     the format is determined from the file (io/__init__.py:178-231)."""
+    kwargs = normalize_kwargs(kwargs)
     if format is None or isinstance(format, tuple):
         if 'w' in mode:
             raise ValueError("cannot specify multiple formats for writing.")

@@ -19,6 +19,7 @@ from .frame import Mark4Frame
 from ._bitmaps import BITMAPS
 from ..base.writer import GPUStreamWriterBase
 from ..base.opener import FormatOpener
+from ..base.quantities import hz
 
 __all__ = ['Mark4FileReader', 'Mark4StreamReader', 'Mark4StreamWriter', 'open', 'Mark4FileWriter']
 
@@ -144,7 +145,7 @@ class Mark4StreamReader(GPUStreamReaderBase):
         if sample_rate is None:
             sample_rate = fh_raw.get_frame_rate() * header0.samples_per_frame
         super().__init__(
-            fh_raw, header0, sample_rate=float(sample_rate),
+            fh_raw, header0, sample_rate=hz(sample_rate),
             samples_per_frame=header0.samples_per_frame,
             unsliced_shape=(header0.nchan,), bps=header0.bps,
             complex_data=False, squeeze=squeeze, subset=subset,

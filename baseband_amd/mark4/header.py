@@ -8,6 +8,7 @@ quantities (``fanout, bps, nchan, samples_per_frame, frame_nbytes, ...``)
 follow mark4/header.py:540-650.  Times are ``numpy.datetime64[ns]``.
 """
 import numpy as np
+from ..base.quantities import as_time
 
 __all__ = ['Mark4Header', 'stream2words', 'words2stream', 'MARK4_DTYPES',
            'PAYLOAD_NBITS', 'frame_header_streams']
@@ -558,8 +559,8 @@ class Mark4Header:
 
     # -- time (mark4/header.py:181-262)
     def infer_decade(self, ref_time):
-        year = np.datetime64(ref_time, 'ns').astype('datetime64[Y]').astype(int) + 1970
-        frac = ((np.datetime64(ref_time, 'ns') - np.datetime64(str(year), 'ns'))
+        year = as_time(ref_time).astype('datetime64[Y]').astype(int) + 1970
+        frac = ((as_time(ref_time) - np.datetime64(str(year), 'ns'))
                 / np.timedelta64(365, 'D'))
         self.decade = int(np.around(year + frac - int(self['bcd_unit_year'][0]),
                                     decimals=-1))
@@ -599,7 +600,7 @@ class Mark4Header:
                 + np.timedelta64(q * 250000 - 86400 * 10 ** 9, 'ns'))
 
     def set_time(self, time):
-        time = np.datetime64(time, 'ns')
+        time = as_time(time)
         year = int(time.astype('datetime64[Y]').astype(int)) + 1970
         ns = int((time - np.datetime64('{:04d}-01-01'.format(year), 'ns'))
                  / np.timedelta64(1, 'ns'))

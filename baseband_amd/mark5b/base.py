@@ -18,6 +18,7 @@ from .header import Mark5BHeader, frame_header_words, crc16_mark5b
 from .frame import Mark5BFrame
 from ..base.writer import GPUStreamWriterBase
 from ..base.opener import FormatOpener
+from ..base.quantities import hz
 
 __all__ = ['Mark5BFileReader', 'Mark5BFileWriter', 'Mark5BStreamReader',
            'Mark5BStreamWriter', 'open']
@@ -132,7 +133,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         if sample_rate is None:
             sample_rate = fh_raw.get_frame_rate() * spf
         super().__init__(
-            fh_raw, header0, sample_rate=float(sample_rate),
+            fh_raw, header0, sample_rate=hz(sample_rate),
             samples_per_frame=spf, unsliced_shape=(nchan,), bps=bps,
             complex_data=False, squeeze=squeeze, subset=subset,
             fill_value=fill_value, verify=verify)
@@ -240,7 +241,7 @@ class Mark5BStreamWriter(GPUStreamWriterBase):
         if sample_rate is None:
             raise ValueError("Mark 5B stream writer needs a sample_rate.")
         spf = 10000 * 8 // bps // nchan
-        frame_rate = float(sample_rate) / spf
+        frame_rate = hz(sample_rate) / spf
         if header0 is None:
             header0 = Mark5BHeader.fromvalues(time=time, frame_rate=frame_rate, **kwargs)
         super().__init__(fh_raw, header0, sample_rate=sample_rate, samples_per_frame=spf,

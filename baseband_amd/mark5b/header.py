@@ -4,6 +4,7 @@ frames (mark5b/header.py:60-68,91-97,177-185,235-262).  Times are
 import numpy as np
 
 from ..base.header import BitFieldHeader, four_word_struct
+from ..base.quantities import as_time, hz
 
 __all__ = ['Mark5BHeader', 'bcd_decode', 'bcd_encode', 'crc16_mark5b',
            'frame_header_words']
@@ -123,7 +124,7 @@ class Mark5BHeader(BitFieldHeader):
     def infer_kday(self, ref_time):
         """Thousands of MJD such that the time is within 500 days of ref_time
         (mark5b/header.py:160-175)."""
-        ref_mjd = (np.datetime64(ref_time, 'ns') - np.datetime64('1970-01-01', 'ns')
+        ref_mjd = (as_time(ref_time) - np.datetime64('1970-01-01', 'ns')
                    ) / np.timedelta64(1, 'D') + _MJD_UNIX
         self.kday = int(np.around(ref_mjd - self.jday, decimals=-3))
 
@@ -162,7 +163,7 @@ class Mark5BHeader(BitFieldHeader):
         if nr == 0:
             fraction = 0.
         elif frame_rate is not None:
-            fraction = nr / float(frame_rate)
+            fraction = nr / hz(frame_rate)
         else:
             fraction = self.fraction
             if fraction == 0.:
@@ -174,7 +175,7 @@ class Mark5BHeader(BitFieldHeader):
                 + np.timedelta64(int(round(fraction * 1e9)), 'ns'))
 
     def set_time(self, time, frame_rate=None):
-        time = np.datetime64(time, 'ns')
+        time = as_time(time)
         dt = int((time - np.datetime64('1970-01-01', 'ns')) / np.timedelta64(1, 'ns'))
         days, ns = divmod(dt, 86400 * 1000000000)
         mjd = days + _MJD_UNIX
@@ -186,8 +187,8 @@ class Mark5BHeader(BitFieldHeader):
             if frame_rate is None:
                 raise ValueError("cannot calculate frame rate. Pass it "
                                  "in explicitly.")
-            frame_nr = int(round(ns * float(frame_rate) / 1e9))
-            frac = frame_nr / float(frame_rate)
+            frame_nr = int(round(ns * hz(frame_rate) / 1e9))
+            frac = frame_nr / hz(frame_rate)
             if abs(frac - 1.) < 1e-9:
                 int_sec, frame_nr, frac = int_sec + 1, 0, 0.
         self.seconds = int_sec
@@ -205,8 +206,8 @@ def frame_header_words(start_time, frame_rate, first, count, user=0, internal_tv
     at once -- the stream writer's per-frame Python loop cost 15 us a frame."""
     from ..base.utils import bcd_encode as bcd_array, CRC
     k = np.arange(first, first + count, dtype=np.int64)
-    rate = float(frame_rate)
-    t0 = int((np.datetime64(start_time, 'ns') - np.datetime64('1970-01-01', 'ns'))
+    rate = hz(frame_rate)
+    t0 = int((as_time(start_time) - np.datetime64('1970-01-01', 'ns'))
              / np.timedelta64(1, 'ns'))
     dt = t0 + np.rint(k * 1e9 / rate).astype(np.int64)
     days, ns = np.divmod(dt, 86400 * 1000000000)

@@ -19,6 +19,7 @@ from ..base.opener import FormatOpener
 from ..base.header import strided_header_words
 from .header import VDIFHeader, frame_header_words
 from .frame import VDIFFrame, VDIFFrameSet
+from ..base.quantities import hz
 
 __all__ = ['VDIFFileReader', 'VDIFFileWriter', 'VDIFStreamReader', 'VDIFStreamWriter',
            'open']
@@ -189,7 +190,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
             sample_rate = header0.sample_rate
             if sample_rate is None:
                 sample_rate = fh_raw.get_frame_rate() * header0.samples_per_frame
-        sample_rate = float(sample_rate)
+        sample_rate = hz(sample_rate)
         super().__init__(
             fh_raw, header0, sample_rate=sample_rate,
             samples_per_frame=header0.samples_per_frame,

@@ -10,6 +10,7 @@ import numpy as np
 
 from ..base.header import (BitFieldHeader, four_word_struct,
                            eight_word_struct)
+from ..base.quantities import as_time, hz
 
 __all__ = ['VDIFHeader', 'ref_epoch_time']
 
@@ -94,7 +95,7 @@ def _leaps_between(t0, t1):
 
 def ref_epoch_for(time):
     """Latest reference epoch not after `time` (vdif/header.py:393-397)."""
-    time = np.datetime64(time, 'ns')
+    time = as_time(time)
     ym = time.astype('datetime64[M]').astype(int)       # months since 1970-01
     months = ym - (2000 - 1970) * 12
     return int(months // 6)
@@ -341,7 +342,7 @@ class VDIFHeader(BitFieldHeader):
     def sample_rate(self, sample_rate):
         if 'sampling_rate' not in self._fields:
             return
-        rate = int(round(float(sample_rate)))
+        rate = int(round(hz(sample_rate)))
         rate //= (1 if self['complex_data'] else 2)
         if rate % 1000000 == 0:
             self['sampling_unit'] = True
@@ -370,14 +371,14 @@ class VDIFHeader(BitFieldHeader):
             if frame_rate is None:
                 raise ValueError("this header does not provide a frame "
                                  "rate. Pass it in explicitly.")
-            ns = int(round(frame_nr * 1e9 / float(frame_rate)))
+            ns = int(round(frame_nr * 1e9 / hz(frame_rate)))
         ref = self.ref_time
         utc = ref + np.timedelta64(self['seconds'], 's')
         utc = utc - np.timedelta64(_leaps_between(ref, utc), 's')
         return utc + np.timedelta64(ns, 'ns')
 
     def set_time(self, time, frame_rate=None):
-        time = np.datetime64(time, 'ns')
+        time = as_time(time)
         self['ref_epoch'] = ref_epoch_for(time)
         dt = int((time - self.ref_time) / np.timedelta64(1, 'ns'))
         seconds, ns = divmod(dt, 1000000000)
@@ -389,8 +390,8 @@ class VDIFHeader(BitFieldHeader):
             if frame_rate is None:
                 raise ValueError("this header does not provide a frame "
                                  "rate. Pass it in explicitly.")
-            frame_nr = int(round(ns * float(frame_rate) / 1e9))
-            if frame_nr >= int(round(float(frame_rate))):
+            frame_nr = int(round(ns * hz(frame_rate) / 1e9))
+            if frame_nr >= int(round(hz(frame_rate))):
                 frame_nr = 0
                 seconds += 1
         self['seconds'] = seconds
