@@ -138,7 +138,9 @@ class ArenaStats(C.Structure):
                 ('bytes_in_use', C.c_uint64), ('largest_free', C.c_uint64), ('bytes_grown', C.c_uint64),
                 ('bytes_trimmed', C.c_uint64), ('chunk_bytes', C.c_uint32), ('steps', C.c_uint32),
                 ('blocks', C.c_uint32), ('probes', C.c_uint32), ('last_probe_gbps', C.c_double), ('create_ms', C.c_double),
-                ('grow_ms', C.c_double), ('va_reserved', C.c_uint64), ('va_used', C.c_uint64)]
+                ('grow_ms', C.c_double), ('va_reserved', C.c_uint64), ('va_used', C.c_uint64),
+                ('va_ranges', C.c_uint32), ('va_ranges_made', C.c_uint32), ('prepares', C.c_uint32),
+                ('growing', C.c_uint32), ('prepare_ms', C.c_double), ('prepare_wait_ms', C.c_double)]
 
 
 LAYOUT_GUPPI_CF = 0
@@ -205,6 +207,8 @@ SIGNATURES = [
     # include/bbdecode_arena.h
     ('bb_arena_create', C.c_int, [_sz, C.POINTER(_vp)]),
     ('bb_arena_alloc', C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    ('bb_arena_prepare', C.c_int, [_vp, _sz]),
+    ('bb_arena_owns', C.c_int, [_vp, _vp]),
     ('bb_arena_free', C.c_int, [_vp, _vp]),
     ('bb_arena_trim', C.c_int, [_vp, C.POINTER(_sz)]),
     ('bb_arena_get_stats', C.c_int, [_vp, C.POINTER(ArenaStats)]),

@@ -47,14 +47,26 @@ class _Block:
         arena = self.arena
         if arena is None or not arena._handle:
             return
+        # under the arena's lock: a trim on another thread (placement's idle
+        # watcher) either sees this free -- and waits for the event recorded
+        # here before it unmaps -- or has finished before the block counts as
+        # free (between its wait and its unmap nothing may slip in)
         try:
-            arena._note_free(self)
-        except Exception:           # interpreter shutdown: torch may be half gone
-            pass
-        try:
-            lib.bb_arena_free(arena._handle, C.c_void_p(self.ptr))
-        except Exception:           # ... and so may this module's globals
+            lock = arena._lock
+            lock.acquire()
+        except Exception:           # interpreter shutdown
             return
+        try:
+            try:
+                arena._note_free(self)
+            except Exception:       # interpreter shutdown: torch may be half gone
+                pass
+            try:
+                lib.bb_arena_free(arena._handle, C.c_void_p(self.ptr))
+            except Exception:       # ... and so may this module's globals
+                return
+        finally:
+            lock.release()
         hook = arena.on_block_freed
         if hook is not None:
             try:
@@ -83,7 +95,6 @@ class Arena:
             check(lib.bb_arena_create(int(capacity), C.byref(h)), 'bb_arena_create')
         self._handle = h
         st = self.stats()
-        self._range = (st['base'], st['base'] + st['va_reserved'])
         self._granule = int(st['chunk_bytes'])
         self._freed = []            # [(lo, hi, event, stream)] of blocks freed with work possibly in flight
         self._lock = threading.RLock()      # (re-entrant: a block's __del__ may run while it is held)
@@ -150,8 +161,22 @@ class Arena:
 
     def owns(self, tensor):
         """Does `tensor` live in this arena?"""
-        return (self._handle is not None and tensor.is_cuda
-                and self._range[0] <= tensor.data_ptr() < self._range[1])
+        return bool(self._handle is not None and tensor.is_cuda
+                    and lib.bb_arena_owns(self._handle, C.c_void_p(tensor.data_ptr())))
+
+    def prepare(self, nbytes):
+        """Start growing NOW, on a thread of the library, for a block of
+        `nbytes` that will be asked for soon (`bb_arena_prepare`): returns at
+        once; the next `empty()` that needs the step waits only for what is
+        left of its creation.  True if a growth was started or none is needed."""
+        if self._handle is None:
+            return False
+        if torch.cuda.current_device() == self.device.index:
+            rc = lib.bb_arena_prepare(self._handle, int(nbytes))
+        else:
+            with torch.cuda.device(self.device):
+                rc = lib.bb_arena_prepare(self._handle, int(nbytes))
+        return rc == _lib.BB_OK
 
     def _wait_freed(self):
         """Host-wait for everything that was queued on blocks at the time they
@@ -175,9 +200,12 @@ class Arena:
         Waits for the work queued on freed blocks first."""
         if self._handle is None:
             return 0
-        self._wait_freed()
         n = C.c_size_t()
-        check(lib.bb_arena_trim(self._handle, C.byref(n)), 'bb_arena_trim')
+        with self._lock:                # (frees wait: see _Block.__del__)
+            if self._handle is None:
+                return 0
+            self._wait_freed()
+            check(lib.bb_arena_trim(self._handle, C.byref(n)), 'bb_arena_trim')
         return int(n.value)
 
     def stats(self):
@@ -187,14 +215,15 @@ class Arena:
 
     def close(self):
         """Release the arena's memory.  Tensors still alive become invalid."""
-        h, self._handle = self._handle, None
-        if h:
-            self._wait_freed()
-            try:
-                torch.cuda.synchronize(self.device)     # (work on still-live tensors, which become invalid)
-            except Exception:
-                pass
-            check(lib.bb_arena_destroy(h), 'bb_arena_destroy')
+        with self._lock:
+            h, self._handle = self._handle, None
+            if h:
+                self._wait_freed()
+                try:
+                    torch.cuda.synchronize(self.device)     # (work on still-live tensors, which become invalid)
+                except Exception:
+                    pass
+                check(lib.bb_arena_destroy(h), 'bb_arena_destroy')
 
     def __del__(self):
         try:

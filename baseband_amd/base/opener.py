@@ -141,7 +141,25 @@ class FormatOpener:
         if mode == 'rs' and source is not None:
             # what GPUStreamReaderBase.__reduce__ needs to come back after pickling
             opened._pickle_recipe = (_reopen_stream, self, source, init_args)
+        if mode == 'rs':
+            _prepare_output_memory(opened)
         return opened
+
+
+def _prepare_output_memory(reader):
+    """A stream whose decoded samples are 1 GiB and more: let the output arena
+    start taking its memory now, in the background, instead of inside the first
+    large ``read()`` (placement.prepare_output; a no-op without a GPU, with
+    BB_ARENA=0 / BB_ARENA_PREPARE=0, or when the arena has room already)."""
+    try:
+        n = 8 if reader.complex_data else 4
+        for dim in reader.shape:
+            n *= int(dim)
+        if n >= (1 << 30):
+            from ..placement import prepare_output
+            prepare_output(n)
+    except Exception:
+        pass
 
 
 class _CaseBlind(dict):

@@ -114,6 +114,9 @@ __device__ __forceinline__ void bb_gather_stage(const bb_gather_args &a, uint64_
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(blk + q),
                                                      (__attribute__((address_space(3))) void *)(s_raw + s * pitch + jb), 4, 0, 0);
             }
+            // LDS-DMA loads are counted by vmcnt, which a barrier does not wait for
+            // by itself: other waves read what this wave staged (as k_lds.h, k_tfpick.h)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else
         for (uint32_t p0 = 0; p0 < npiece; p0 += 8) {
             uint32_t r[8], dst[8];

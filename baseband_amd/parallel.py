@@ -31,14 +31,22 @@ def broadcast_frame_index(src, nentries, src_rank=0, device=None, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return src
+    # "nccl" (RCCL) moves device tensors; "gloo" -- CPU tests, and ranks that share
+    # ONE GPU, which RCCL refuses (tests/test_multiprocess_gpu.py) -- goes through
+    # host memory: 8 bytes per frame, once per file
+    via_host = dist.get_backend(group) == 'gloo'
     if dist.get_rank(group) == src_rank:
         buf = src.to(torch.int64).contiguous()
         assert buf.numel() == nentries
+        if device is None:
+            device = buf.device
+        if via_host:
+            buf = buf.cpu()
     else:
         buf = torch.empty(nentries, dtype=torch.int64,
-                          device=device if device is not None else 'cpu')
+                          device='cpu' if via_host or device is None else device)
     dist.broadcast(buf, src=src_rank, group=group)
-    return buf
+    return buf if device is None else buf.to(device)
 
 
 def local_index(src, lo_set, hi_set, nslot, payload_nbytes, align=8):

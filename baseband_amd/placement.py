@@ -23,6 +23,7 @@ BB_ARENA_IDLE_S = 30 seconds with no reader open).  One arena per device.
     BB_ARENA_IDLE_S=<s> seconds without a live block or an open reader after which the
                         arenas give their memory back (default 30; 0 = at once)
     BB_ARENA_KEEP=1     never give memory back automatically
+    BB_ARENA_PREPARE=0  do not start growing when a reader of a large stream is opened
     baseband_amd.arena.enable(capacity) / .disable()   the same from the program
 
 Round 2's `empty_output(shape, candidates=k)` -- allocate k tensors, probe
@@ -30,6 +31,7 @@ each, keep the fastest -- is gone: it needed k times the memory and still lost
 when all k draws were slow.
 """
 import os
+import sys
 import threading
 import time
 import warnings
@@ -39,7 +41,7 @@ import torch
 
 from . import arena as _arena
 
-__all__ = ['empty_output', 'release_unused', 'ARENA_MIN_BYTES', 'ARENA_MAX_BYTES']
+__all__ = ['empty_output', 'prepare_output', 'release_unused', 'ARENA_MIN_BYTES', 'ARENA_MAX_BYTES']
 
 # smaller outputs come from torch's allocator: where they lie changes a launch
 # of 0.15 ms by tens of microseconds at most, and the arena takes the device's
@@ -95,6 +97,8 @@ def _nothing_alive():
 def _trim_idle():
     """Trim the arenas if STILL nothing needs their memory."""
     if os.environ.get('BB_ARENA_KEEP', '0') not in ('0', '', 'no', 'off') or not _nothing_alive():
+        return 0
+    if sys.is_finalizing():         # (the watcher thread must not be inside hipMemUnmap while the interpreter goes)
         return 0
     freed = 0
     for a in _arena.all_arenas():
@@ -174,6 +178,27 @@ def _arena_for(device, create=True):
         _failed = True
         warnings.warn("baseband_amd: no output arena ({!r}); outputs come from torch.empty".format(exc))
         return None
+
+
+def prepare_output(nbytes, device=None):
+    """A reader has been opened whose whole decoded stream is `nbytes`: if that
+    is an output the arena would hold (`ARENA_MIN_BYTES` and more; capped at
+    `ARENA_MAX_BYTES`) and the arena has no room for it, start growing in the
+    background (`Arena.prepare`), so that the step's creation runs next to the
+    rest of ``open()``, the header scan and the first staging windows instead of
+    inside the first ``read()``.  BB_ARENA_PREPARE=0 switches
+    it off.  Never raises; returns True if the arena was asked."""
+    try:
+        if nbytes < ARENA_MIN_BYTES or os.environ.get('BB_ARENA_PREPARE', '1') in ('0', 'off', 'no'):
+            return False
+        if not torch.cuda.is_available():
+            return False
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        ar = _arena_for(device, True)
+        return bool(ar is not None and ar.prepare(min(int(nbytes), ARENA_MAX_BYTES)))
+    except Exception:
+        return False
 
 
 def release_unused(device=None):

@@ -35,6 +35,8 @@ def host_image(fh):
         mm = mmap.mmap(fileno, size, access=mmap.ACCESS_READ)
         img = np.frombuffer(mm, dtype=np.uint8).view(FileImage)
         img.fd = fileno                     # (BB_STAGE_WINDOW_MMAP: large windows get a mapping of their own)
+        st = os.fstat(fileno)
+        img.fd_id = (st.st_dev, st.st_ino, st.st_size)      # ... if the number still names THIS file then
         img.mm = mm                         # (`retire_image` empties the mapping's page tables in the background)
         return img
     pos = fh.tell()
@@ -56,10 +58,12 @@ class FileImage(np.ndarray):
     fault their pages in while the previous window's is being torn down) and
     the totals scatter over each other on this host: OFF by default."""
     fd = None
+    fd_id = None
     mm = None
 
     def __array_finalize__(self, obj):
         self.fd = None                      # (views and slices are plain arrays as far as staging cares)
+        self.fd_id = None
         self.mm = None
 
 
@@ -158,6 +162,11 @@ def _stage(dst, image, lo, hi):
         fd = getattr(image, 'fd', None) if _WINDOW_MMAP else None
         if fd is not None and hi - lo >= (4 << 20):
             try:
+                # the number may have been closed and handed to another file since the
+                # image was made: map a window only from the file recorded
+                st = os.fstat(fd)
+                if (st.st_dev, st.st_ino, st.st_size) != image.fd_id:
+                    raise OSError("descriptor {} no longer names the image's file".format(fd))
                 a_lo = lo - lo % _GRAN
                 win = mmap.mmap(fd, hi - a_lo, access=mmap.ACCESS_READ, offset=a_lo)
             except (OSError, ValueError):       # a closed or unusual descriptor: the whole-file mapping serves

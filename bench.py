@@ -41,6 +41,10 @@ Besides the contract's keys the line carries
                 cfg2 frames; GUPPI 8 GiB in) into FRESH outputs, torch.empty
                 against the placement arena the readers allocate from, min /
                 median / max over the draws (N = 1 only)
+  cold_first_read fresh child processes: the first open(2 GiB file).read() of a
+                process against the same call again; on a clean device, and
+                after the child dirtied nearly all of the device's memory
+                (with and without the arena's background growth)
 
 The LAST stdout line is a compact JSON object (at most 2,000 bytes: the
 contract's keys, `roofline`, `cpu_baseline`, `checks_ok`, a short `secondary`
@@ -75,6 +79,7 @@ from bench_legs.cfg3 import leg_cfg3                                            
 from bench_legs.other_configs import leg_locate, leg_other_configs               # noqa: E402,F401
 from bench_legs.pipeline import pinned_h2d_rate, leg_pipeline                    # noqa: E402,F401
 from bench_legs.mid_size import leg_mid_size                                     # noqa: E402,F401
+from bench_legs.cold_read import leg_cold_first_read                             # noqa: E402,F401
 
 
 def main():
@@ -160,6 +165,12 @@ def main():
                         traffic_detail["live_error"] = err
                 except Exception:
                     pass
+    cold = None
+    if rank == 0 and world == 1 and have_gpu and args.legs == 'all' and not args.no_extra_legs:
+        try:        # fresh child processes on the GPU this process has not touched yet
+            cold = leg_cold_first_read()
+        except Exception as exc:
+            cold = {"error": repr(exc)[:400]}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback).")
     if world > torch.cuda.device_count():
@@ -378,6 +389,8 @@ def main():
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if cold is not None:
+            line["cold_first_read"] = cold
         rc = finish(line, args.detail)
     if dist is not None:
         dist.destroy_process_group()

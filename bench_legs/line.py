@@ -45,6 +45,8 @@ def collect_checks(line):
                     "index_equals_broadcast")
     if "pipeline" in line and not (isinstance(line["pipeline"], dict) and "skipped" in line["pipeline"]):
         put("pipeline.all_match", line, "pipeline", "all_match")
+    if "cold_first_read" in line:
+        put("cold_first_read.all_ok", line, "cold_first_read", "all_ok")
     if "other_configs" in line:
         oc = line["other_configs"]
         checks["other_configs.spot_checks"] = bool(oc) and all(
@@ -104,9 +106,10 @@ def secondary_summary(line):
     if ms and isinstance(ms[0], dict):
         sec["mid_2p15_arena_min"] = _get(ms[0], "arena", "frac_min")
         sec["mid_2p15_api_read"] = _get(ms[0], "api_read", "frac")
-    v = _get(line, "cold_first_read", "cold_minus_warm_ms")
-    if v is not None:
-        sec["cold_minus_warm_ms"] = v
+    for k in ("cold_minus_warm_ms", "cold_minus_warm_ms_dirty_memory"):
+        v = _get(line, "cold_first_read", k)
+        if v is not None:
+            sec[k] = v
     return {k: v for k, v in sec.items() if v is not None}
 
 

@@ -86,8 +86,14 @@ typedef struct bb_arena_stats {
     double   last_probe_gbps;/* decode rate the probe measured on the step taken last (0: not probed) */
     double   create_ms;      /* wall time of bb_arena_create */
     double   grow_ms;        /* wall time spent growing (create, map, probe), total */
-    uint64_t va_reserved;    /* size of the virtual range blocks lie in: [base, base + va_reserved) */
-    uint64_t va_used;        /* addresses handed to growth steps so far (never reused) */
+    uint64_t va_reserved;    /* size of the virtual range NEW steps are placed in: [base, base + va_reserved) */
+    uint64_t va_used;        /* addresses handed to growth steps so far, all ranges (never reused) */
+    uint32_t va_ranges;      /* virtual ranges reserved now (> 1: an older, used-up one still holds a step) */
+    uint32_t va_ranges_made; /* ... and reserved so far */
+    uint32_t prepares;       /* growth steps started by bb_arena_prepare */
+    uint32_t growing;        /* 1 while one of them is on its way */
+    double   prepare_ms;     /* their wall time, total (spent on the library's thread) */
+    double   prepare_wait_ms;/* time bb_arena_alloc waited for one, total */
 } bb_arena_stats;
 
 /* An arena that backs at most `capacity` bytes (rounded up to whole GiB) of the
@@ -96,16 +102,33 @@ typedef struct bb_arena_stats {
  * growth steps -- and to every probed candidate -- by a bump pointer and never
  * reused, because new memory mapped at an address that was unmapped a moment
  * ago can receive a kernel's stores at the OLD pages on this runtime
- * (csrc/bb_arena.inc).  No physical memory is taken yet.  BB_EINVAL: capacity
+ * (csrc/bb_arena.inc); a range that is used up is followed by another one and
+ * given back once no step lives in it.  No physical memory is taken yet.  BB_EINVAL: capacity
  * == 0; BB_EIO: a HIP call failed (no virtual memory management). */
 int bb_arena_create(size_t capacity, bb_arena **arena);
 
 /* A block of at least `bytes` (rounded up to whole granules), a whole number of
  * granules from the base (which is 2 MiB aligned at least).
  * Grows by a step of whole GiB that holds the whole block when no free range
- * is large enough.  *d_ptr = NULL and BB_ERANGE when the capacity, the
- * device's memory or the virtual range is exhausted. */
+ * is large enough (after waiting for a growth bb_arena_prepare started).
+ * *d_ptr = NULL and BB_ERANGE when the capacity or the device's memory is
+ * exhausted (a used-up virtual range is replaced by a new one). */
 int bb_arena_alloc(bb_arena *arena, size_t bytes, void **d_ptr);
+
+/* Start taking memory for a block of `bytes` NOW, on a thread of the library,
+ * and return at once: the same step bb_arena_alloc(bytes) would grow by (not
+ * probed), unless a free range already holds such a block or a growth is on
+ * its way.  bb_arena_alloc waits for a growth in flight before it grows
+ * itself, so the sequence prepare -> other work -> alloc pays only what is
+ * left of the growth.  What this buys depends on WHY growing is slow: creating
+ * memory costs 7 ms per 48 GiB unless the driver is still clearing memory that
+ * was released a moment ago -- then the creation waits for that, seconds
+ * (profiles/r05b_grow_probe.log, r05c_grow_probe2.log).  BB_ERANGE: capacity
+ * or device memory exhausted (nothing started). */
+int bb_arena_prepare(bb_arena *arena, size_t bytes);
+
+/* 1 if `d_ptr` lies in one of the arena's virtual ranges, else 0. */
+int bb_arena_owns(bb_arena *arena, const void *d_ptr);
 
 /* Return a block (the pointer bb_arena_alloc gave).  BB_EINVAL: not a live block. */
 int bb_arena_free(bb_arena *arena, void *d_ptr);

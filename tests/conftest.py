@@ -17,9 +17,43 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
         sys.path.insert(0, p)
 
 
+_launcher = None
+
+
 def pytest_configure(config):
     config.addinivalue_line(
         "markers", "gpu: test needs a real MI355X (run with -m gpu)")
+    # tests/test_multiprocess_gpu.py needs rank processes whose PARENT never
+    # initialised the GPU (a process that has must not fork + exec): start the
+    # small helper that will start them NOW, before anything here touches the
+    # GPU (`_has_gpu` below does).  It idles on stdin and ends with the session.
+    global _launcher
+    if _launcher is None and os.path.exists('/dev/kfd'):
+        import subprocess
+        try:
+            _launcher = subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'mp_launcher.py')],
+                                         stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        except Exception:
+            _launcher = None
+
+
+def pytest_unconfigure(config):
+    global _launcher
+    if _launcher is not None:
+        try:
+            _launcher.stdin.close()
+            _launcher.wait(timeout=10)
+        except Exception:
+            try:
+                _launcher.kill()
+            except Exception:
+                pass
+        _launcher = None
+
+
+def rank_launcher():
+    """The helper process that starts rank processes (None without a GPU)."""
+    return _launcher if _launcher is not None and _launcher.poll() is None else None
 
 
 def _has_gpu():

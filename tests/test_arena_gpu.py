@@ -183,16 +183,21 @@ def test_regrown_memory_holds_what_is_decoded_into_it(monkeypatch):
         ar.close()
 
 
-def test_a_used_up_virtual_range_is_an_orderly_failure(monkeypatch):
-    """When the bump pointer reaches the end of the reserved range the arena
-    answers None (the readers then use torch.empty) instead of reusing addresses."""
+def test_a_used_up_virtual_range_is_followed_by_another(monkeypatch):
+    """Round 5: when the bump pointer reaches the
+    end of the reserved range, ANOTHER range is reserved (while the old one still
+    is: no address can come back) and the old one is given back once no step
+    lives in it -- it was BB_ERANGE and plain allocations for the rest of the
+    process before.  Blocks of the old range stay valid and are freed normally."""
     import torch
     from baseband_amd import arena
     monkeypatch.setenv('BB_ARENA_STEP_GIB', '2')
     monkeypatch.setenv('BB_ARENA_VA_GIB', '6')
-    ar = arena.Arena(4 * GIB)
+    ar = arena.Arena(12 * GIB)
     try:
-        assert ar.stats()['va_reserved'] == 6 * GIB
+        st = ar.stats()
+        assert st['va_reserved'] == 6 * GIB and st['va_ranges'] == 1 and st['va_ranges_made'] == 1
+        bases = {st['base']}
         for k in range(3):
             t = ar.empty(1 << 20)
             assert t is not None
@@ -200,10 +205,166 @@ def test_a_used_up_virtual_range_is_an_orderly_failure(monkeypatch):
             del t
             gc.collect()
             assert ar.trim() == 2 * GIB
-        assert ar.stats()['va_used'] == 6 * GIB
-        assert ar.empty(1 << 20) is None
+        assert ar.stats()['va_used'] == 6 * GIB and ar.stats()['va_ranges'] == 1
+        keep = ar.empty(1 << 20)                    # the range is used up: this one lies in a new one
+        assert keep is not None and ar.owns(keep)
+        keep.fill_(7.)
+        st = ar.stats()
+        assert st['va_ranges'] == 1 and st['va_ranges_made'] == 2 and st['base'] not in bases     # the old one held no step: gone
+        bases.add(st['base'])
+        # use this range up while `keep` lives in it: it stays reserved next to the third one
+        others = []
+        for k in range(3):                          # (the first fits behind `keep`; two more steps fill the range)
+            others.append(ar.empty((2 * GIB - (64 << 20)) // 4))
+            assert others[-1] is not None
+        assert ar.stats()['va_ranges_made'] == 2 and ar.stats()['steps'] == 3
+        more = ar.empty((3 * GIB) // 2 // 4)        # 1.5 GiB: no room in the rests of the live steps -> a step in range 3
+        st = ar.stats()
+        assert more is not None and st['va_ranges_made'] == 3 and st['va_ranges'] == 2
+        assert ar.owns(keep) and ar.owns(more) and float(keep.sum()) == 7. * keep.numel()
+        kp = keep.data_ptr()
+        del keep, others
+        gc.collect()
+        assert ar.trim() == 6 * GIB
+        st = ar.stats()
+        assert st['va_ranges'] == 1 and st['blocks'] == 1              # range 2 went back with its last step
+        probe = torch.empty(4, device='cuda')
+        assert not ar.owns(probe)
+        assert not arena.lib.bb_arena_owns(ar._handle, C.c_void_p(kp))
     finally:
         ar.close()
+
+
+def test_a_thousand_grow_and_trim_cycles_still_serve_blocks(monkeypatch):
+    """A service that idles between bursts trims and regrows for ever: 1,000
+    cycles through a 4 GiB virtual range in 1 GiB steps (250 ranges) -- every
+    block is served by the arena and holds what is written into it."""
+    import torch
+    from baseband_amd import arena
+    monkeypatch.setenv('BB_ARENA_STEP_GIB', '1')
+    monkeypatch.setenv('BB_ARENA_VA_GIB', '4')
+    ar = arena.Arena(2 * GIB)
+    try:
+        seen = set()
+        for k in range(1000):
+            t = ar.empty((96 << 20) // 4)
+            assert t is not None and ar.owns(t), k
+            if k % 50 == 0:
+                t.fill_(float(k))
+                assert float(t[::4096].sum()) == float(k) * t[::4096].numel()
+            seen.add(t.data_ptr())
+            del t
+            gc.collect()
+            assert ar.trim() == 1 * GIB, k
+        st = ar.stats()
+        assert st['va_ranges_made'] == 250 and st['va_ranges'] == 1 and st['va_used'] == 1000 * GIB
+        assert st['bytes_grown'] == st['bytes_trimmed'] == 1000 * GIB and st['bytes_backed'] == 0
+        assert len(seen) >= 4                    # (within a range no address comes back; across ranges the OS may reuse one)
+    finally:
+        ar.close()
+
+
+def test_a_growth_that_fails_burns_no_addresses(monkeypatch):
+    """addresses are taken only once a step's memory exists -- a
+    growth that cannot get device memory leaves the range as it was."""
+    import torch
+    from baseband_amd import arena
+    monkeypatch.setenv('BB_ARENA_STEP_GIB', '2')
+    free_b, total_b = torch.cuda.mem_get_info()
+    ar = arena.Arena(2 * total_b)
+    try:
+        for _ in range(3):
+            assert ar.empty(int(free_b * 1.5) // 4) is None       # more than the device has
+        assert ar.stats()['va_used'] == 0 and ar.stats()['bytes_backed'] == 0
+        t = ar.empty(1 << 20)
+        assert t is not None and ar.stats()['va_used'] == 2 * GIB
+    finally:
+        ar.close()
+
+
+def test_prepare_grows_in_the_background_and_alloc_waits_for_it(monkeypatch):
+    """bb_arena_prepare: returns at once, the step arrives
+    on a thread of the library, the next block comes out of it (no second
+    step), kernels on the caller's streams run meanwhile; a prepare that is not
+    needed starts nothing."""
+    import time
+    import torch
+    from baseband_amd import arena
+    monkeypatch.setenv('BB_ARENA_STEP_GIB', '16')
+    ar = arena.Arena(64 * GIB)
+    try:
+        t0 = time.perf_counter()
+        assert ar.prepare(3 * GIB)
+        dt_call = time.perf_counter() - t0
+        st = ar.stats()
+        assert st['prepares'] == 1
+        x = torch.ones(1 << 20, device='cuda')
+        for _ in range(20):                        # the caller's own work goes on
+            x = x * 1.0001
+        torch.cuda.synchronize()
+        t = ar.empty((3 * GIB) // 4)                # waits for the growth in flight if need be
+        st = ar.stats()
+        assert t is not None and ar.owns(t)
+        assert st['steps'] == 1 and st['bytes_backed'] == 16 * GIB and st['growing'] == 0
+        assert st['probes'] == 0                    # (background steps are not probed: no NULL-stream launch from that thread)
+        assert st['prepare_ms'] > 0 and dt_call < max(0.05, st['prepare_ms'] * 1e-3)
+        t.fill_(3.)
+        assert float(t[::65536].sum()) == 3. * t[::65536].numel()
+        assert ar.prepare(1 * GIB) and ar.stats()['prepares'] == 1          # room already: nothing started
+        assert ar.prepare(15 * GIB) and ar.stats()['prepares'] == 2         # no room for that: a second step
+        u = ar.empty((15 * GIB) // 4)
+        assert u is not None and ar.stats()['steps'] == 2
+        del t, u
+        gc.collect()
+        assert ar.trim() == 32 * GIB
+        # closing with a growth in flight waits for it and gives everything back
+        assert ar.prepare(2 * GIB)
+    finally:
+        ar.close()
+    free_b, total_b = torch.cuda.mem_get_info()
+    assert free_b > total_b - 40 * GIB
+
+
+def test_opening_a_large_stream_prepares_the_arena(tmp_path, monkeypatch):
+    """open() of a stream that decodes to >= 1 GiB starts the arena's first step
+    in the background; BB_ARENA_PREPARE=0 does not; a small stream never does."""
+    import torch
+    from baseband_amd import vdif, arena, placement, synth
+    monkeypatch.setenv('BB_ARENA_STEP_GIB', '4')
+    image, h0 = synth.random_vdif(5, 9000, payload_nbytes=8000, frame_rate=1000)       # 72 MB -> 1.15 GB decoded
+    path = tmp_path / 'big.vdif'
+    path.write_bytes(image.tobytes())
+    small, _ = synth.random_vdif(6, 100, payload_nbytes=8000, frame_rate=1000)
+    spath = tmp_path / 'small.vdif'
+    spath.write_bytes(small.tobytes())
+    arena.disable()
+    try:
+        with vdif.open(str(spath), 'rs', sample_rate=32e6) as fh:
+            assert arena.default() is None                                            # nothing to prepare for
+        monkeypatch.setenv('BB_ARENA_PREPARE', '0')
+        with vdif.open(str(path), 'rs', sample_rate=32e6) as fh:
+            assert arena.default() is None
+        monkeypatch.delenv('BB_ARENA_PREPARE')
+        with vdif.open(str(path), 'rs', sample_rate=32e6) as fh:
+            ar = arena.default()
+            assert ar is not None and ar.stats()['prepares'] == 1
+            got = fh.read()
+            st = ar.stats()
+            assert ar.owns(got) and st['steps'] == 1 and st['bytes_backed'] == 4 * GIB
+        exp = kernels_reference(image, h0)
+        assert torch.equal(got.view(torch.int32).cpu(), torch.from_numpy(exp.view(np.int32)))
+    finally:
+        del got
+        gc.collect()
+        arena.disable()
+
+
+def kernels_reference(image, h0):
+    """2-bit VDIF payloads re-expanded on the host from the library's own level table."""
+    from baseband_amd import _lib
+    lev = _lib.get_levels(_lib.CODER_VDIF, 2)
+    pay = image.reshape(-1, 8032)[:, 32:].reshape(-1)
+    return lev[(pay[:, None] >> np.array([0, 2, 4, 6], np.uint8)) & 3].reshape(-1)
 
 
 def test_raw_abi_rejects_what_is_not_a_block(small_arena):
