@@ -55,6 +55,8 @@ TUNE_XPOSE_MIN_NC = 28
 TUNE_ENCODE_RUNS = 30
 TUNE_GATHER_GLDS = 36
 TUNE_ENCODE_STRIPES = 38
+TUNE_SELECT_PICK = 39
+TUNE_PICK_BYTES = 40
 # include/bbdecode_exp.h (experiment build only: bb_tune answers BB_EINVAL otherwise)
 TUNE_FLAT_VARIANT = 0
 TUNE_NT_STORES = 1

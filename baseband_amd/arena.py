@@ -255,7 +255,7 @@ def enable(capacity=None, device=None):
     if old is not None:
         old.close()
     if capacity is None:
-        capacity = torch.cuda.get_device_properties(idx).total_memory
+        capacity = torch.cuda.mem_get_info(idx)[1]
     ar = Arena(capacity, device=idx)
     with _arenas_lock:
         _arenas[idx] = ar
@@ -271,7 +271,8 @@ def get_or_create(device, capacity=None):
         ar = _arenas.get(idx)
         if ar is None:
             if capacity is None:
-                capacity = torch.cuda.get_device_properties(idx).total_memory
+                # (not get_device_properties: its first call takes 107 ms, tools/prof_cold_open.py)
+                capacity = torch.cuda.mem_get_info(idx)[1]
             ar = _arenas[idx] = Arena(capacity, device=idx)
         return ar
 

@@ -15,6 +15,7 @@
 #include "k_burst.h"
 #endif
 #include "k_gather.h"
+#include "k_pick.h"
 #include "k_mark4.h"
 #include "k_tiled.h"
 #include "k_xpose.h"
@@ -153,6 +154,7 @@ int device_levels(int coder, int lb, const float **p)
 // ~4000 resident ones lets the dispatcher even out the tail, while each still
 // walks several items with its loads one item ahead.
 #define BB_GRID_CAP 131072ull
+#define BB_PICK_NW 2                                // waves per workgroup of k_decode_pick (each has its own work item)
 #define BB_LOCATE_GRID 65536ull      // the byte-granular searches (bb_*_locate)
 
 // ---- tuning (include/bbdecode_tune.h; the experiment build adds bbdecode_exp.h) ----
@@ -175,6 +177,8 @@ thread_local bb_knob g_tune_gather_chunks{32};   // chunks below this many float
 thread_local bb_knob g_tune_mkbf_tc{32};
 thread_local bb_knob g_tune_rows_tiles{8};          // tiles per work item of k_decode_rows_pipe (1..8)
 thread_local bb_knob g_tune_lut_tpw{0};             // tiles per wave and work item of the byte-table kernels; 0 = by kernel
+thread_local bb_knob g_tune_select_pick{1};        // folded channel subsets go through k_decode_pick where it applies
+thread_local bb_knob g_tune_pick_bytes{8192};      // payload bytes (all slots) a wave of k_decode_pick stages per item
 thread_local bb_knob g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
 thread_local bb_knob g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
 thread_local bb_knob g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
@@ -290,6 +294,17 @@ void launch_gather_select(int bps, int coder, bool nt, bool v4, dim3 grid, size_
             constexpr bool N = decltype(NT)::value;
             if (v4) hipLaunchKernelGGL((k_decode_gather_select<BPS, LV, N, true>), grid, dim3(BB_BLOCK), lds, st, a);
             else    hipLaunchKernelGGL((k_decode_gather_select<BPS, LV, N, false>), grid, dim3(BB_BLOCK), lds, st, a);
+        });
+    });
+}
+
+void launch_pick(int bps, int coder, bool nt, dim3 grid, size_t lds, hipStream_t st, const bb_pick_args &a)
+{
+    with_levels(bps, coder, [&](auto B, auto L) {
+        with_nt(nt, [&](auto NT) {
+            constexpr int BPS = decltype(B)::value, LV = decltype(L)::value;
+            constexpr bool N = decltype(NT)::value;
+            hipLaunchKernelGGL((k_decode_pick<BPS, LV, N, BB_PICK_NW>), grid, dim3(BB_PICK_NW * BB_WAVE), lds, st, a);
         });
     });
 }
@@ -524,6 +539,10 @@ int bb_tune(int knob, int value)
         case BB_TUNE_SELECT_BYTES:
             if (value < 256 || value > 32768) return BB_EINVAL;
             g_tune_select_bytes = value; return BB_OK;
+        case BB_TUNE_SELECT_PICK: g_tune_select_pick = value != 0; return BB_OK;
+        case BB_TUNE_PICK_BYTES:
+            if (value < 1024 || value > 32768) return BB_EINVAL;
+            g_tune_pick_bytes = value; return BB_OK;
         case BB_TUNE_XPOSE: g_tune_xpose = value; return BB_OK;
         case BB_TUNE_XPOSE_ROWS: g_tune_xpose_rows = value == 64 ? 64 : value == 128 ? 128 : 0; return BB_OK;
         case BB_TUNE_ENCODE_RUNS: g_tune_encode_runs = (value == 1 || value == 2) ? value : 0; return BB_OK;
@@ -1279,6 +1298,45 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
         const uint64_t drow = (uint64_t)p->nslot * (uint64_t)nwithin, dsel = (uint64_t)nwithin;
         ga.mag_row = (drow > 1 && qmax * drow < (1ull << 32)) ? (uint32_t)((1ull << 32) / drow + 1) : 0;
         ga.mag_sel = (dsel > 1 && qmax * dsel < (1ull << 32)) ? (uint32_t)((1ull << 32) / dsel + 1) : 0;
+    }
+    {
+        // k_decode_pick (k_pick.h): whole-byte thread samples, an output row of 4..256
+        // floats that is a power of two, at most 32 slots, whole rows per staged piece
+        const uint64_t rowlen = (uint64_t)p->nslot * (uint64_t)nwithin;
+        const uint32_t rowbits = (uint32_t)p->bps << lchunk;
+        if (g_tune_select_pick.load() && !(rowbits & 7) && rowlen >= 4 && rowlen <= 256 && !(rowlen & (rowlen - 1))
+            && p->nslot <= 32 && !((uintptr_t)d_out & 15)) {
+            const uint32_t rowbytes = rowbits >> 3;
+            uint32_t sb = ((uint32_t)g_tune_pick_bytes.load() / (uint32_t)p->nslot) & ~255u;
+            if (sb > 4096) sb = 4096;
+            if ((uint64_t)sb > ((p->payload_nbytes + 255) & ~255ull)) sb = (uint32_t)((p->payload_nbytes + 255) & ~255ull);
+            if (sb >= 256 && rowbytes <= 256 && sb % rowbytes == 0 && p->payload_nbytes % rowbytes == 0
+                && ((R * rowlen) % 4) == 0) {
+                bb_pick_args pa;
+                pa.buf = ga.buf; pa.src = d_src; pa.out = d_out; pa.tab = ga.tab; pa.within = d_within;
+                pa.nframes = nframes; pa.pbytes = p->payload_nbytes; pa.src_lim = ga.src_lim;
+                pa.nslot = (uint32_t)p->nslot; pa.nsel = (uint32_t)nwithin;
+                pa.lrowlen = 0;
+                while ((1ull << pa.lrowlen) < rowlen) ++pa.lrowlen;
+                pa.rowbytes = rowbytes; pa.sb = sb;
+                pa.nitem = (uint32_t)((p->payload_nbytes + sb - 1) / sb);
+                pa.pitch = sb + 80;                          // 16 bytes of misalignment + a bank skew between the slots' rows
+                pa.fill_re = p->fill_re; pa.fill_im = p->fill_im; pa.complex_data = p->complex_data;
+                const uint64_t nwork = (uint64_t)nframes * pa.nitem;
+                pa.perm = make_perm(nwork, (uint64_t)nframes * R * rowlen * 4);
+                uint64_t gbp = (nwork + BB_PICK_NW - 1) / BB_PICK_NW;
+                const int tbp = g_tune_blocks.load();
+                const uint64_t capp = tbp > 0 ? (uint64_t)tbp : (BB_GRID_CAP << 3);
+                if (gbp > capp) gbp = capp;
+                const size_t ldsp = (size_t)BB_PICK_NW * pa.nslot * pa.pitch;
+                launch_pick(p->bps, p->coder, tune_nt(), dim3((unsigned)gbp), ldsp, (hipStream_t)stream, pa);
+                BB_NOTE("k_decode_pick<%d,%s,%s,%d> grid %u items of %u B x %u slots, select %d of %d", p->bps,
+                        lv_name(p->bps, p->coder), tune_nt() ? "nt" : "plain", BB_PICK_NW, (unsigned)gbp, sb, pa.nslot,
+                        nwithin, p->chunk);
+                BB_HIP(hipGetLastError());
+                return BB_OK;
+            }
+        }
     }
     const size_t lds = g.lds;
     uint64_t gb = (uint64_t)nframes * ga.ngroup;

@@ -16,9 +16,11 @@ since ``open()``, `prepare_wait_ms` the read waited for it).
 Three children:
     clean            the device as the bench finds it
     dirty            the child first takes nearly all of the device's memory,
-                     writes it and frees it: what the arena then creates is
-                     memory the driver has to clear first (the 1.5-4.6 s of
-                     round 4's DESIGN section 6; profiles/r05b_grow_probe.log)
+                     writes it and frees it: the driver clears what was freed,
+                     and the NEXT allocation of the process -- whoever makes it,
+                     here the arena's step -- waits for that (the 1.5-4.6 s of
+                     round 4's DESIGN section 6; profiles/r05b_grow_probe.log,
+                     r05d_cold_read.json)
     dirty_noprepare  the same with BB_ARENA_PREPARE=0: the growth inside read()
 """
 import json
@@ -66,6 +68,14 @@ def _child(gib, mode, path):
     torch.zeros(1, device='cuda')
     torch.cuda.synchronize()
     t_ctx = time.perf_counter() - t0
+    # the library's kernels and tables: a small read from memory (code objects load at first launch)
+    import io
+    t0 = time.perf_counter()
+    with bb.vdif.open(io.BytesIO(small.tobytes()), 'rs', sample_rate=32e6) as fh:
+        fh.read()
+    torch.cuda.synchronize()
+    t_small = time.perf_counter() - t0
+
     dirtied = None
     if mode.startswith('dirty'):
         free_b, total_b = torch.cuda.mem_get_info()
@@ -77,13 +87,6 @@ def _child(gib, mode, path):
         del x
         torch.cuda.empty_cache()
         dirtied = {"GiB": round(n / 2 ** 30, 1), "alloc_fill_free_ms": round((time.perf_counter() - t0) * 1e3, 1)}
-    # the library's kernels and tables: a small read from memory (code objects load at first launch)
-    import io
-    t0 = time.perf_counter()
-    with bb.vdif.open(io.BytesIO(small.tobytes()), 'rs', sample_rate=32e6) as fh:
-        fh.read()
-    torch.cuda.synchronize()
-    t_small = time.perf_counter() - t0
 
     def one():
         t = time.perf_counter()

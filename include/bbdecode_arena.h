@@ -88,7 +88,7 @@ typedef struct bb_arena_stats {
     double   grow_ms;        /* wall time spent growing (create, map, probe), total */
     uint64_t va_reserved;    /* size of the virtual range NEW steps are placed in: [base, base + va_reserved) */
     uint64_t va_used;        /* addresses handed to growth steps so far, all ranges (never reused) */
-    uint32_t va_ranges;      /* virtual ranges reserved now (> 1: an older, used-up one still holds a step) */
+    uint32_t va_ranges;      /* virtual ranges reserved now (used-up ones stay reserved: their addresses must not come back) */
     uint32_t va_ranges_made; /* ... and reserved so far */
     uint32_t prepares;       /* growth steps started by bb_arena_prepare */
     uint32_t growing;        /* 1 while one of them is on its way */
@@ -102,8 +102,11 @@ typedef struct bb_arena_stats {
  * growth steps -- and to every probed candidate -- by a bump pointer and never
  * reused, because new memory mapped at an address that was unmapped a moment
  * ago can receive a kernel's stores at the OLD pages on this runtime
- * (csrc/bb_arena.inc); a range that is used up is followed by another one and
- * given back once no step lives in it.  No physical memory is taken yet.  BB_EINVAL: capacity
+ * (csrc/bb_arena.inc; tools/experiments/va_reuse_probe.cpp shows it for any
+ * address that had a mapping before, however long ago); a range that is used
+ * up is followed by another one and stays reserved, so the process's address
+ * space bounds what an arena can map over its lifetime (about 2,700 steps of
+ * 48 GiB).  No physical memory is taken yet.  BB_EINVAL: capacity
  * == 0; BB_EIO: a HIP call failed (no virtual memory management). */
 int bb_arena_create(size_t capacity, bb_arena **arena);
 
@@ -111,8 +114,9 @@ int bb_arena_create(size_t capacity, bb_arena **arena);
  * granules from the base (which is 2 MiB aligned at least).
  * Grows by a step of whole GiB that holds the whole block when no free range
  * is large enough (after waiting for a growth bb_arena_prepare started).
- * *d_ptr = NULL and BB_ERANGE when the capacity or the device's memory is
- * exhausted (a used-up virtual range is replaced by a new one). */
+ * *d_ptr = NULL and BB_ERANGE when the capacity, the device's memory or the
+ * process's address space is exhausted (a used-up virtual range is followed by
+ * a new one as long as one can be reserved). */
 int bb_arena_alloc(bb_arena *arena, size_t bytes, void **d_ptr);
 
 /* Start taking memory for a block of `bytes` NOW, on a thread of the library,

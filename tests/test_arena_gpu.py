@@ -185,10 +185,12 @@ def test_regrown_memory_holds_what_is_decoded_into_it(monkeypatch):
 
 def test_a_used_up_virtual_range_is_followed_by_another(monkeypatch):
     """Round 5: when the bump pointer reaches the
-    end of the reserved range, ANOTHER range is reserved (while the old one still
-    is: no address can come back) and the old one is given back once no step
-    lives in it -- it was BB_ERANGE and plain allocations for the rest of the
-    process before.  Blocks of the old range stay valid and are freed normally."""
+    end of the reserved range, ANOTHER range is reserved -- it was BB_ERANGE and
+    plain allocations for the rest of the process before.  The used-up range
+    STAYS reserved: were it given back, the next reservation could return its
+    addresses, and memory mapped where a mapping was before reads back wrong
+    (tools/experiments/va_reuse_probe.cpp, profiles/r05e_va_reuse.log).  Blocks
+    of the old range stay valid and are freed normally."""
     import torch
     from baseband_amd import arena
     monkeypatch.setenv('BB_ARENA_STEP_GIB', '2')
@@ -210,9 +212,8 @@ def test_a_used_up_virtual_range_is_followed_by_another(monkeypatch):
         assert keep is not None and ar.owns(keep)
         keep.fill_(7.)
         st = ar.stats()
-        assert st['va_ranges'] == 1 and st['va_ranges_made'] == 2 and st['base'] not in bases     # the old one held no step: gone
+        assert st['va_ranges'] == 2 and st['va_ranges_made'] == 2 and st['base'] not in bases
         bases.add(st['base'])
-        # use this range up while `keep` lives in it: it stays reserved next to the third one
         others = []
         for k in range(3):                          # (the first fits behind `keep`; two more steps fill the range)
             others.append(ar.empty((2 * GIB - (64 << 20)) // 4))
@@ -220,25 +221,25 @@ def test_a_used_up_virtual_range_is_followed_by_another(monkeypatch):
         assert ar.stats()['va_ranges_made'] == 2 and ar.stats()['steps'] == 3
         more = ar.empty((3 * GIB) // 2 // 4)        # 1.5 GiB: no room in the rests of the live steps -> a step in range 3
         st = ar.stats()
-        assert more is not None and st['va_ranges_made'] == 3 and st['va_ranges'] == 2
+        assert more is not None and st['va_ranges_made'] == 3 and st['va_ranges'] == 3 and st['base'] not in bases
         assert ar.owns(keep) and ar.owns(more) and float(keep.sum()) == 7. * keep.numel()
-        kp = keep.data_ptr()
         del keep, others
         gc.collect()
         assert ar.trim() == 6 * GIB
         st = ar.stats()
-        assert st['va_ranges'] == 1 and st['blocks'] == 1              # range 2 went back with its last step
-        probe = torch.empty(4, device='cuda')
-        assert not ar.owns(probe)
-        assert not arena.lib.bb_arena_owns(ar._handle, C.c_void_p(kp))
+        assert st['va_ranges'] == 3 and st['blocks'] == 1 and st['steps'] == 1
+        more.fill_(2.)
+        assert float(more[::1024].sum()) == 2. * more[::1024].numel()
+        assert not ar.owns(torch.empty(4, device='cuda'))
     finally:
         ar.close()
 
 
 def test_a_thousand_grow_and_trim_cycles_still_serve_blocks(monkeypatch):
     """A service that idles between bursts trims and regrows for ever: 1,000
-    cycles through a 4 GiB virtual range in 1 GiB steps (250 ranges) -- every
-    block is served by the arena and holds what is written into it."""
+    cycles through 4 GiB virtual ranges in 1 GiB steps (250 ranges, all kept
+    reserved) -- every block is served by the arena, at an address never used
+    before, and holds what is written into it."""
     import torch
     from baseband_amd import arena
     monkeypatch.setenv('BB_ARENA_STEP_GIB', '1')
@@ -249,17 +250,17 @@ def test_a_thousand_grow_and_trim_cycles_still_serve_blocks(monkeypatch):
         for k in range(1000):
             t = ar.empty((96 << 20) // 4)
             assert t is not None and ar.owns(t), k
-            if k % 50 == 0:
+            if k % 10 == 0:                      # (a mapping at a reused address reads back wrong: it did, r05d)
                 t.fill_(float(k))
-                assert float(t[::4096].sum()) == float(k) * t[::4096].numel()
+                assert float(t[::1024].sum()) == float(k) * t[::1024].numel(), k
             seen.add(t.data_ptr())
             del t
             gc.collect()
             assert ar.trim() == 1 * GIB, k
         st = ar.stats()
-        assert st['va_ranges_made'] == 250 and st['va_ranges'] == 1 and st['va_used'] == 1000 * GIB
+        assert st['va_ranges_made'] == 250 and st['va_ranges'] == 250 and st['va_used'] == 1000 * GIB
         assert st['bytes_grown'] == st['bytes_trimmed'] == 1000 * GIB and st['bytes_backed'] == 0
-        assert len(seen) >= 4                    # (within a range no address comes back; across ranges the OS may reuse one)
+        assert len(seen) == 1000                 # no address ever came back (used-up ranges stay reserved)
     finally:
         ar.close()
 
