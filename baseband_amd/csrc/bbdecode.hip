@@ -178,7 +178,7 @@ thread_local bb_knob g_tune_mkbf_tc{32};
 thread_local bb_knob g_tune_rows_tiles{8};          // tiles per work item of k_decode_rows_pipe (1..8)
 thread_local bb_knob g_tune_lut_tpw{0};             // tiles per wave and work item of the byte-table kernels; 0 = by kernel
 thread_local bb_knob g_tune_select_pick{1};        // folded channel subsets go through k_decode_pick where it applies
-thread_local bb_knob g_tune_pick_bytes{8192};      // payload bytes (all slots) a wave of k_decode_pick stages per item
+thread_local bb_knob g_tune_pick_bytes{4096};      // payload bytes (all slots) a wave of k_decode_pick stages per item
 thread_local bb_knob g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
 thread_local bb_knob g_tune_m4_tiles{BB_M4_TPW};   // 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8)
 thread_local bb_knob g_tune_m4_widen{1};     // 1: 16-/32-track Mark 4 words decoded as 64-bit super-words (m4_widen)
@@ -539,7 +539,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_SELECT_BYTES:
             if (value < 256 || value > 32768) return BB_EINVAL;
             g_tune_select_bytes = value; return BB_OK;
-        case BB_TUNE_SELECT_PICK: g_tune_select_pick = value != 0; return BB_OK;
+        case BB_TUNE_SELECT_PICK: g_tune_select_pick = value < 0 ? 1 : (value > 2 ? 2 : value); return BB_OK;
         case BB_TUNE_PICK_BYTES:
             if (value < 1024 || value > 32768) return BB_EINVAL;
             g_tune_pick_bytes = value; return BB_OK;
@@ -1304,7 +1304,14 @@ int bb_decode_frames_select(const void *d_buf, size_t buf_nbytes,
         // floats that is a power of two, at most 32 slots, whole rows per staged piece
         const uint64_t rowlen = (uint64_t)p->nslot * (uint64_t)nwithin;
         const uint32_t rowbits = (uint32_t)p->bps << lchunk;
-        if (g_tune_select_pick.load() && !(rowbits & 7) && rowlen >= 4 && rowlen <= 256 && !(rowlen & (rowlen - 1))
+        // Measured at the bench's shape (8 threads x 16 complex channels, 8 GiB in; profiles/r05f_exp_pick.log):
+        // 1 of 16 channels 0.517 -> 0.769 of the peak on bytes moved, 2 of 16 0.688 -> 0.769 (4 KiB staged per
+        // item; 8 KiB 0.739, 16 KiB 0.719), 4 of 16 0.737 -> 0.734 and 8 of 16 0.756 -> 0.747 at best: the wave
+        // items win where the stores are few, so selections of up to an eighth of a thread sample take them
+        // (BB_TUNE_SELECT_PICK = 2: whenever the conditions hold).
+        const int pick_mode = g_tune_select_pick.load();
+        if (pick_mode && (pick_mode == 2 || (uint64_t)nwithin * 8 <= (uint64_t)p->chunk)
+            && !(rowbits & 7) && rowlen >= 4 && rowlen <= 256 && !(rowlen & (rowlen - 1))
             && p->nslot <= 32 && !((uintptr_t)d_out & 15)) {
             const uint32_t rowbytes = rowbits >> 3;
             uint32_t sb = ((uint32_t)g_tune_pick_bytes.load() / (uint32_t)p->nslot) & ~255u;

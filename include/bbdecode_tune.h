@@ -35,8 +35,8 @@ extern "C" {
 #define BB_TUNE_ENCODE_RUNS   30   /* k_encode_flat: runs of 256 float4 a wave takes per step, all loads in flight first: 1 or 2; default 0 = 2 for 4-bit codes, 1 otherwise (the product library builds 2 for 4-bit codes only) */
 #define BB_TUNE_M4_TILES      26   /* 64-word tiles per wave and work item of the Mark 4 decode kernels (1..8, default 8) */
 #define BB_TUNE_GATHER_GLDS   36   /* the LDS gather kernels stage payload bytes with direct-to-LDS loads (1) or load + ds_write (0); default -1 = by kernel: folded channel subsets (k_decode_gather_select) yes, whole thread interleaves (k_decode_gather) no */
-#define BB_TUNE_SELECT_PICK    39   /* folded channel subsets: 1 (default) = k_decode_pick (one work item per wave, direct-to-LDS 16-byte loads) where its conditions hold, 0 = k_decode_gather_select always */
-#define BB_TUNE_PICK_BYTES     40   /* k_decode_pick: payload bytes of all thread slots a wave stages per work item (1024..32768, default 8192) */
+#define BB_TUNE_SELECT_PICK    39   /* folded channel subsets: 1 (default) = k_decode_pick (one work item per wave, direct-to-LDS 16-byte loads) for selections of up to an eighth of a thread sample where its conditions hold, 2 = wherever they hold, 0 = k_decode_gather_select always */
+#define BB_TUNE_PICK_BYTES     40   /* k_decode_pick: payload bytes of all thread slots a wave stages per work item (1024..32768, default 4096) */
 #define BB_TUNE_ENCODE_STRIPES 38 /* k_encode_flat: log2 of the number of stripes the 16 KiB input runs of a launch are dealt over (the decode launches' work order, applied to the read stream): 0-10; default 0 = input order */
 
 /* Sets a knob for the CALLING HOST THREAD's later launches (the knobs are

@@ -459,7 +459,9 @@ def test_large_read_lifecycle_through_the_default_arena(tmp_path, monkeypatch):
         ar = arena.default()
         assert ar is not None and ar.owns(got)
         st = ar.stats()
-        assert st['steps'] == 1 and st['probes'] >= 1 and st['last_probe_gbps'] > 3000, st
+        # (the step was started by open(): placement.prepare_output -> bb_arena_prepare, whose
+        # background steps are not probed; a step the read itself grows is)
+        assert st['steps'] == 1 and (st['prepares'] == 1 or (st['probes'] >= 1 and st['last_probe_gbps'] > 3000)), st
         assert st['bytes_backed'] >= 9 << 30
         # spot check against the oracle: first, a middle and the last frame
         for f in (0, nframes // 2, nframes - 1):

@@ -70,7 +70,7 @@ def test_pick_matches_host_expansion_and_the_gather_kernel(bps, chunk, cplx, cod
                 dw = torch.from_numpy(within).cuda()
                 fill = (-2.5 + 1.5j) if cplx else -2.5
                 for blocks, pick_bytes in ((0, 8192), (3, 8192), (0, 1024), (0, 32768)):
-                    kernels.tune(_lib.TUNE_SELECT_PICK, 1)
+                    kernels.tune(_lib.TUNE_SELECT_PICK, 2)             # wherever its conditions hold
                     kernels.tune(_lib.TUNE_BLOCKS, blocks)
                     kernels.tune(_lib.TUNE_PICK_BYTES, pick_bytes)
                     got = kernels.decode_frames(d, nsets, pn, CODERS[coder], bps, chunk=chunk, nslot=nslot, src=dsrc,
@@ -89,7 +89,7 @@ def test_pick_matches_host_expansion_and_the_gather_kernel(bps, chunk, cplx, cod
     finally:
         kernels.tune(_lib.TUNE_SELECT_PICK, 1)
         kernels.tune(_lib.TUNE_BLOCKS, 0)
-        kernels.tune(_lib.TUNE_PICK_BYTES, 8192)
+        kernels.tune(_lib.TUNE_PICK_BYTES, 4096)
 
 
 def test_pick_is_what_a_reader_subset_launches():
