@@ -57,6 +57,7 @@ TUNE_GATHER_GLDS = 36
 TUNE_ENCODE_STRIPES = 38
 TUNE_SELECT_PICK = 39
 TUNE_PICK_BYTES = 40
+TUNE_VDIF8_LDS_GIB = 41
 # include/bbdecode_exp.h (experiment build only: bb_tune answers BB_EINVAL otherwise)
 TUNE_FLAT_VARIANT = 0
 TUNE_NT_STORES = 1

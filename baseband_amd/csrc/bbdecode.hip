@@ -177,6 +177,7 @@ thread_local bb_knob g_tune_gather_chunks{32};   // chunks below this many float
 thread_local bb_knob g_tune_mkbf_tc{32};
 thread_local bb_knob g_tune_rows_tiles{8};          // tiles per work item of k_decode_rows_pipe (1..8)
 thread_local bb_knob g_tune_lut_tpw{0};             // tiles per wave and work item of the byte-table kernels; 0 = by kernel
+thread_local bb_knob g_tune_vdif8_lds_gib{20};     // GiB of payload from which VDIF 8-bit frames take k_decode_flat_lds<8,LDS,glds>
 thread_local bb_knob g_tune_select_pick{1};        // folded channel subsets go through k_decode_pick where it applies
 thread_local bb_knob g_tune_pick_bytes{4096};      // payload bytes (all slots) a wave of k_decode_pick stages per item
 thread_local bb_knob g_tune_select_bytes{16384};   // payload bytes k_decode_gather_select stages per work item
@@ -440,14 +441,11 @@ void launch_flat_lds8(int coder, bool nt, bool gl, dim3 grid, hipStream_t st, co
         constexpr bool N = decltype(NT)::value;
 #if BB_EXP
         if (coder == BB_CODER_INT && !gl) { hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_INT8>), grid, dim3(2 * BB_WAVE), 0, st, a); return; }
-        if (coder != BB_CODER_INT) {
-            if (gl) hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_LDS, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
-            else    hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_LDS>), grid, dim3(2 * BB_WAVE), 0, st, a);
-            return;
-        }
+        if (coder != BB_CODER_INT && !gl) { hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_LDS>), grid, dim3(2 * BB_WAVE), 0, st, a); return; }
 #endif
-        (void)coder; (void)gl;
-        hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_INT8, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        (void)gl;
+        if (coder != BB_CODER_INT) hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_LDS, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
+        else hipLaunchKernelGGL((k_decode_flat_lds<8, N, 2, 16, BB_LV_INT8, 0, true>), grid, dim3(2 * BB_WAVE), 0, st, a);
     });
 }
 
@@ -539,6 +537,7 @@ int bb_tune(int knob, int value)
         case BB_TUNE_SELECT_BYTES:
             if (value < 256 || value > 32768) return BB_EINVAL;
             g_tune_select_bytes = value; return BB_OK;
+        case BB_TUNE_VDIF8_LDS_GIB: g_tune_vdif8_lds_gib = value < 0 ? 20 : value; return BB_OK;
         case BB_TUNE_SELECT_PICK: g_tune_select_pick = value < 0 ? 1 : (value > 2 ? 2 : value); return BB_OK;
         case BB_TUNE_PICK_BYTES:
             if (value < 1024 || value > 32768) return BB_EINVAL;
@@ -1031,12 +1030,21 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     // KiB of output per work item.  Against the plain kernel (4): +4.7 % at 8 GiB in
     // on three boxes, +1.2 % at 31 GiB (profiles/r04d_exp_glds3_box*.log,
     // r04c_exp_glds2.log); with 8 / 16 tiles per wave or register staging it
-    // loses.  VDIF 8-bit frames (table levels) stay with the plain kernel:
-    // -6 % at 8 GiB, +3 % at 31 GiB.
+    // loses.  VDIF 8-bit frames (table levels) stay with the plain kernel up to
+    // 20 GiB of payload: -6 % at 8 GiB, +3-4 % at 31 GiB (the switch below).
     {
         bool lds8 = om == BB_OUT_FLAT && p->bps == 8 && p->coder == BB_CODER_INT;
         bool gl8 = true;
         int t8 = 4;
+        // VDIF 8-bit frames (table levels), round 5: BY SIZE.  k_decode_flat_lds<8,LDS,glds> with 16
+        // tiles per wave against the plain kernel, 8032-byte frames (profiles/r05g_exp_vdif8_size.log):
+        // 0.5-12 GiB in: -0.1 .. -3.4 %; 16 GiB +0.4 %, 24 GiB +2.5 %, 31 GiB +4.1 % (0.791 -> 0.823 of
+        // the peak).  From 20 GiB of payload on it takes the staged kernel.
+        if (om == BB_OUT_FLAT && p->bps == 8 && p->coder != BB_CODER_INT
+            && nfs * (uint64_t)p->payload_nbytes >= ((uint64_t)g_tune_vdif8_lds_gib.load() << 30)) {
+            lds8 = true;
+            t8 = 16;
+        }
 #if BB_EXP
         const int f8 = g_tune_flat8_lds.load();                 // 1: staged for every coder, knobs apply; 2: plain kernel
         if (f8 == 1) {

@@ -37,6 +37,7 @@ extern "C" {
 #define BB_TUNE_GATHER_GLDS   36   /* the LDS gather kernels stage payload bytes with direct-to-LDS loads (1) or load + ds_write (0); default -1 = by kernel: folded channel subsets (k_decode_gather_select) yes, whole thread interleaves (k_decode_gather) no */
 #define BB_TUNE_SELECT_PICK    39   /* folded channel subsets: 1 (default) = k_decode_pick (one work item per wave, direct-to-LDS 16-byte loads) for selections of up to an eighth of a thread sample where its conditions hold, 2 = wherever they hold, 0 = k_decode_gather_select always */
 #define BB_TUNE_PICK_BYTES     40   /* k_decode_pick: payload bytes of all thread slots a wave stages per work item (1024..32768, default 4096) */
+#define BB_TUNE_VDIF8_LDS_GIB   41   /* VDIF 8-bit frames with contiguous output: GiB of payload from which a launch takes k_decode_flat_lds<8,LDS,glds> (16 tiles per wave) instead of the plain kernel (default 20; 0 = always, 100000 = never) */
 #define BB_TUNE_ENCODE_STRIPES 38 /* k_encode_flat: log2 of the number of stripes the 16 KiB input runs of a launch are dealt over (the decode launches' work order, applied to the read stream): 0-10; default 0 = input order */
 
 /* Sets a knob for the CALLING HOST THREAD's later launches (the knobs are

@@ -39,7 +39,7 @@ def main():
         for name in cases:
             c = manifest[name]
             path = os.path.join(ROOT, 'tests', 'golden', c['file'])
-            rate = c['frame_rate'] * c['samples_per_frame']
+            rate = c['frame_rate'] * c['samples_per_frame'] if 'frame_rate' in c else None
             if name.startswith('vdif'):
                 with bb.vdif.open(path, 'rs', squeeze=False, sample_rate=rate) as fh:
                     data, (a, b) = parallel.sharded_vdif_read(fh)        # ranks from the process group

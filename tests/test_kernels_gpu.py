@@ -538,7 +538,12 @@ def test_8bit_staged_kernel_geometries(coder, form):
     exp_build = _lib.EXPERIMENTS
     if form == 'product':
         if coder != 'int':
-            pytest.skip("VDIF 8-bit goes through the plain kernel in the product dispatch")
+            # VDIF 8-bit takes the staged kernel (16 tiles per wave) from 20 GiB of payload
+            # on (round 5, profiles/r05g_exp_vdif8_size.log): here from 0
+            out = kernels.decode_frames(kernels.to_device_bytes(np.zeros(8032 * 4, np.uint8)), 4, 8000, CODERS[coder], 8,
+                                        src0=32, src_stride=8032)
+            assert 'k_decode_flat<8' in _lib.last_kernel(), _lib.last_kernel()      # small launches: the plain kernel
+            kernels.tune(_lib.TUNE_VDIF8_LDS_GIB, 0)
     elif not exp_build:
         pytest.skip("measurement variant: experiment build only (BB_EXPERIMENTS=1)")
     rng = np.random.default_rng(808)
@@ -583,13 +588,16 @@ def test_8bit_staged_kernel_geometries(coder, form):
             assert bits_equal(out.cpu().numpy(), full.reshape(-1)), (coder, pn)
             if exp_build:
                 kernels.tune(_lib.TUNE_FLAT8_LDS, 2)
+                kernels.tune(_lib.TUNE_VDIF8_LDS_GIB, 100000)
                 plain = kernels.decode_frames(kernels.to_device_bytes(raw), nframes, pn, CODERS[coder], 8,
                                               src0=header, src_stride=stride)
                 assert 'k_decode_flat<8' in _lib.last_kernel()
                 kernels.tune(_lib.TUNE_FLAT8_LDS, 0 if form == 'product' else 1)
+                kernels.tune(_lib.TUNE_VDIF8_LDS_GIB, 0 if (form == 'product' and coder != 'int') else -1)
                 assert torch.equal(plain.view(torch.int32), out.view(torch.int32))
     finally:
         kernels.tune(_lib.TUNE_BLOCKS, 0)
+        kernels.tune(_lib.TUNE_VDIF8_LDS_GIB, -1)
         tune_exp(_lib.TUNE_FLAT8_LDS, 0)
         tune_exp(_lib.TUNE_FLAT_VARIANT, 5)
 

@@ -1,9 +1,16 @@
 """Writes profiles/INDEX.md: every file under profiles/, grouped by round and
 kind, with the places (sources, headers, tests) that cite it.
-    python tools/make_profiles_index.py"""
+    python tools/make_profiles_index.py [--archive-uncited <round>]
+
+``--archive-uncited 05``: files of rounds BEFORE round 05 that nothing cites
+are moved into ``profiles/archive_uncited_before_r05.tar.gz`` (VERDICT r4 next
+8: 176 of 372 files were cited by nothing) -- still in the tree, one file, and
+listed by name in the index."""
 import os
 import re
 import subprocess
+import sys
+import tarfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, 'profiles')
@@ -26,6 +33,40 @@ for f in files:
     cited[f] = sorted(set(who))
 
 
+archived = []
+if '--archive-uncited' in sys.argv:
+    cur = sys.argv[sys.argv.index('--archive-uncited') + 1]
+    tar_name = 'archive_uncited_before_r{}.tar.gz'.format(cur)
+    victims = [f for f in files if not cited[f] and re.match(r'r(\d\d)', f) and re.match(r'r(\d\d)', f).group(1) < cur
+               and not f.startswith('archive_')]
+    if victims:
+        old = []
+        tar_path = os.path.join(P, tar_name)
+        if os.path.exists(tar_path):                 # keep what an earlier run put there
+            import io
+            with tarfile.open(tar_path, 'r:gz') as t:
+                old = [(m, t.extractfile(m).read() if m.isfile() else None) for m in t.getmembers()]
+        with tarfile.open(tar_path, 'w:gz') as t:
+            for m, data in old:
+                if data is not None:
+                    t.addfile(m, io.BytesIO(data))
+            for f in victims:
+                t.add(os.path.join(P, f), arcname=f)
+        import shutil
+        for f in victims:
+            path = os.path.join(P, f)
+            shutil.rmtree(path) if os.path.isdir(path) else os.remove(path)
+        archived = victims
+        files = [f for f in files if f not in victims]
+        if tar_name not in files:
+            files.append(tar_name)
+            cited[tar_name] = ['tools/make_profiles_index.py']
+        files.sort()
+for f in files:
+    if f.startswith('archive_uncited'):
+        cited.setdefault(f, ['tools/make_profiles_index.py'])
+
+
 def kind(f):
     if 'kernel_stats' in f or f.endswith('_kernels.csv'):
         return 'rocprofv3 --kernel-trace --stats summaries'
@@ -45,13 +86,19 @@ for f in files:
     m = re.match(r'r(\d\d)', f)
     rounds.setdefault(m.group(1) if m else 'zz', []).append(f)
 out = ["# profiles/ -- index", "",
-       "Every measurement file of rounds 1-4, grouped by round and kind.  `rNN<x>_` = round NN, run x (a, b, ... z, za, ...).",
+       "Every measurement file of rounds 1-5, grouped by round and kind.  `rNN<x>_` = round NN, run x (a, b, ... z, za, ...).",
        "\"cited in\" lists the documents and sources whose statements rest on the file.  Regenerate with",
        "`python tools/make_profiles_index.py`.", "",
        "Where to start: the newest `*_bench.json` (the driver-format line), the `*_kernel_stats*.csv` of the same run",
        "(rocprofv3 per-kernel averages: must agree with the line's `roofline.kernel_ms_avg`), `traffic_latest.json` /",
        "`*_pmc_decode.csv` (HBM bytes per launch), then DESIGN.md, which cites the experiment logs by name.", ""]
-names = {'01': 'Round 1', '02': 'Round 2', '03': 'Round 3', '04': 'Round 4', 'zz': 'Not tied to a round'}
+for f in files:
+    if f.startswith('archive_uncited') and f.endswith('.tar.gz'):
+        with tarfile.open(os.path.join(P, f), 'r:gz') as t:
+            inside = sorted({m.name.split('/')[0] for m in t.getmembers()})
+        out += ["## Archived: `{}` ({} entries nothing cites)".format(f, len(inside)), "",
+                ', '.join('`{}`'.format(n) for n in inside), ""]
+names = {'01': 'Round 1', '02': 'Round 2', '03': 'Round 3', '04': 'Round 4', '05': 'Round 5', 'zz': 'Not tied to a round'}
 for r in sorted(rounds, reverse=True):
     out.append("## {} ({} files)".format(names.get(r, 'Round ' + r), len(rounds[r])))
     out.append("")
