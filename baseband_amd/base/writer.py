@@ -194,7 +194,41 @@ class GPUStreamWriterBase:
             self._nframes_written += 1
             self._pending, self._npending = [], 0
         self._closed = True
-        self._close_files()
+        try:
+            self._finish_writes()
+        finally:
+            self._close_files()
+
+    def _raw_files(self):
+        """Every handle device bytes are written to (flattened)."""
+        out, todo = [], [self.fh_raw]
+        while todo:
+            x = todo.pop()
+            if isinstance(x, (tuple, list)):
+                todo.extend(x)
+            elif x is not None:
+                out.append(x)
+        return out
+
+    def flush(self):
+        """Wait until everything written so far is in the file(s) (the pieces
+        travel through a background sink: staging.write_device_bytes)."""
+        from ..staging import finish_writes
+        for fh in self._raw_files():
+            finish_writes(fh, close_sink=False)
+            if hasattr(fh, 'flush'):
+                fh.flush()
+
+    def _finish_writes(self):
+        from ..staging import finish_writes
+        err = None
+        for fh in self._raw_files():
+            try:
+                finish_writes(fh)
+            except BaseException as exc:
+                err = err or exc
+        if err is not None:
+            raise err
 
     def _close_files(self):
         self.fh_raw.close()
@@ -232,10 +266,10 @@ class BlockStreamWriter(GPUStreamWriterBase):
         if data.is_complex():
             data = torch.view_as_real(data)
         block = self._storage_order(data.reshape((nframes, spf) + tuple(data.shape[1:])))
-        from ..staging import write_device_bytes
+        from ..staging import write_device_bytes, HostWriteOrder
         payloads = kernels.encode_flat(block, _lib.CODER_INT, self.bps).reshape(nframes, -1)
         for k in range(nframes):
             header = self._frame_header(self._nframes_written + k)
             assert header.payload_nbytes == payloads.shape[1]
-            header.tofile(self.fh_raw)
+            header.tofile(HostWriteOrder(self.fh_raw))       # (in order with the queued payloads)
             write_device_bytes(self.fh_raw, payloads[k])

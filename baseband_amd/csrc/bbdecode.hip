@@ -1146,16 +1146,19 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
                         bb_frame_rec *d_recs, int64_t *d_src,
                         float *d_out, size_t out_elems,
                         uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad,
-                        void *verified, void *stream)
+                        void *verified, void *scan_stream, void *stream)
 {
     if (!scan || !dec || !d_src || dec->nslot < 1) return BB_EINVAL;
+    if (scan_stream && !verified) return BB_EINVAL;        // (the decode's stream waits for that event)
+    void *ss = scan_stream ? scan_stream : stream;
     // three launches: scan (which also pre-sets the index to -1), index + verification, decode
-    int rc = vdif_scan_impl(d_buf, nbytes, scan, d_recs, nframes, d_src, nsets * (size_t)dec->nslot, stream);
+    int rc = vdif_scan_impl(d_buf, nbytes, scan, d_recs, nframes, d_src, nsets * (size_t)dec->nslot, ss);
     if (rc != BB_OK) return rc;
     rc = index_verify(d_recs, nframes, d_thread_slot, dec->nslot, d_src, nsets, true, recs_per_index ? recs_per_index : 1,
-                      nstrict, d_nbad, stream);
+                      nstrict, d_nbad, ss);
     if (rc != BB_OK) return rc;
-    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
+    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)ss));
+    if (scan_stream) BB_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)verified, 0));
     if (nwithin > 0)
         return bb_decode_frames_select(d_buf, nbytes, d_src, nsets, dec, d_within, nwithin, d_out, out_elems, stream);
     return bb_decode_frames(d_buf, nbytes, d_src, nsets, dec, d_out, out_elems, stream);
@@ -1167,14 +1170,17 @@ int bb_mark5b_read_window(const void *d_buf, size_t nbytes,
                           const int32_t *d_within, int nwithin,
                           bb_frame_rec *d_recs, int64_t *d_src,
                           float *d_out, size_t out_elems,
-                          size_t nstrict, uint32_t *d_nbad, void *verified, void *stream)
+                          size_t nstrict, uint32_t *d_nbad, void *verified, void *scan_stream, void *stream)
 {
     if (!scan || !dec) return BB_EINVAL;
-    int rc = bb_mark5b_scan(d_buf, nbytes, scan, d_recs, nframes, stream);
+    if (scan_stream && !verified) return BB_EINVAL;
+    void *ss = scan_stream ? scan_stream : stream;
+    int rc = bb_mark5b_scan(d_buf, nbytes, scan, d_recs, nframes, ss);
     if (rc != BB_OK) return rc;
-    rc = index_verify(d_recs, nframes, nullptr, 1, d_src, n, false, 1, nstrict, d_nbad, stream);
+    rc = index_verify(d_recs, nframes, nullptr, 1, d_src, n, false, 1, nstrict, d_nbad, ss);
     if (rc != BB_OK) return rc;
-    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
+    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)ss));
+    if (scan_stream) BB_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)verified, 0));
     if (nwithin > 0)
         return bb_decode_frames_select(d_buf, nbytes, d_src, n, dec, d_within, nwithin, d_out, out_elems, stream);
     return bb_decode_frames(d_buf, nbytes, d_src, n, dec, d_out, out_elems, stream);
@@ -1185,14 +1191,17 @@ int bb_mark4_read_window(const void *d_buf, size_t nbytes,
                          const bb_mark4_decode_params *dec, int nout,
                          bb_frame_rec *d_recs, int64_t *d_src,
                          float *d_out, size_t out_elems,
-                         size_t nstrict, uint32_t *d_nbad, void *verified, void *stream)
+                         size_t nstrict, uint32_t *d_nbad, void *verified, void *scan_stream, void *stream)
 {
     if (!scan || !dec) return BB_EINVAL;
-    int rc = bb_mark4_scan(d_buf, nbytes, scan, d_recs, nframes, stream);
+    if (scan_stream && !verified) return BB_EINVAL;
+    void *ss = scan_stream ? scan_stream : stream;
+    int rc = bb_mark4_scan(d_buf, nbytes, scan, d_recs, nframes, ss);
     if (rc != BB_OK) return rc;
-    rc = index_verify(d_recs, nframes, nullptr, 1, d_src, n, false, 1, nstrict, d_nbad, stream);
+    rc = index_verify(d_recs, nframes, nullptr, 1, d_src, n, false, 1, nstrict, d_nbad, ss);
     if (rc != BB_OK) return rc;
-    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)stream));
+    if (verified) BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)ss));
+    if (scan_stream) BB_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)verified, 0));
     if (nout > 0)
         return bb_decode_mark4_select(d_buf, nbytes, d_src, n, dec, nout, d_out, out_elems, stream);
     return bb_decode_mark4(d_buf, nbytes, d_src, n, dec, d_out, out_elems, stream);

@@ -321,8 +321,7 @@ class GSBStreamWriter(GPUStreamWriterBase):
 
     def flush(self):
         self.fh_ts.flush()
-        for fh in ([self.fh_raw] if self._rawdump else [f for pair in self.fh_raw for f in pair]):
-            fh.flush()
+        super().flush()                 # (waits for the queued pieces of every raw file, then flushes it)
 
     def _close_files(self):
         self.fh_ts.close()

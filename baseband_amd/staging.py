@@ -10,6 +10,7 @@ Ordering is by events only; nothing blocks the device.
 import ctypes
 import mmap
 import os
+import queue
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -504,55 +505,155 @@ def download(dev, host, chunk_bytes=64 << 20):
     return host
 
 
+class _FileSink:
+    """Ordered background writes to ONE file handle: the caller's thread queues
+    device-to-pinned copies (side stream, events) and host bytes; a thread of
+    the sink waits for each copy and puts the bytes into the file -- so the
+    ``write()`` of piece k overlaps the encode and the device-to-host copy of
+    everything behind it, ACROSS the writer's ``write()`` calls (round 5: the
+    buffered write of a piece was 80 % of a call and ran alone,
+    profiles/r04zn_prof_writer.log).  At most `depth` pinned pieces are in
+    flight.  An error of the file (a full disk) is raised by the next call
+    that touches the sink."""
+
+    def __init__(self, fh, depth=6):
+        self.fh = fh
+        self.q = queue.Queue()
+        self.slots = threading.Semaphore(depth)
+        self.error = None
+        self.stream = None
+        self.thread = threading.Thread(target=self._run, name='bb-file-sink', daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            item = self.q.get()
+            try:
+                if item is None:
+                    return
+                kind, payload, n, event = item
+                if self.error is None:
+                    try:
+                        if kind == 'dev':
+                            event.synchronize()
+                            self.fh.write(memoryview(payload.numpy()[:n]))
+                        else:
+                            self.fh.write(payload)
+                    except BaseException as exc:        # kept for the caller's thread
+                        self.error = exc
+                if kind == 'dev':
+                    _pinned_give(payload)
+                    self.slots.release()
+            finally:
+                self.q.task_done()
+
+    def _check(self):
+        if self.error is not None:
+            exc, self.error = self.error, None
+            raise exc
+
+    def put_device(self, src, chunk_bytes):
+        self._check()
+        dev = src.device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        n = src.numel()
+        for lo in range(0, n, chunk_bytes):
+            hi = min(n, lo + chunk_bytes)
+            self.slots.acquire()                        # back-pressure: `depth` pieces in flight
+            host = _pinned_take(chunk_bytes)
+            with torch.cuda.stream(self.stream):
+                host[:hi - lo].copy_(src[lo:hi], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            self.q.put(('dev', host, hi - lo, ev))
+        # (the tensor must outlive the copies that read it on the side stream)
+        try:
+            src.record_stream(self.stream)
+        except Exception:               # memory torch's allocator does not manage (an arena block)
+            torch.cuda.current_stream(dev).wait_stream(self.stream)
+
+    def put_host(self, data):
+        self._check()
+        self.q.put(('host', bytes(data), 0, None))
+
+    def drain(self):
+        self.q.join()
+        self._check()
+
+    def close(self):
+        self.q.join()
+        self.q.put(None)
+        self.thread.join()
+        self._check()
+
+
+_sinks = {}                 # id(file handle) -> _FileSink
+_sinks_lock = threading.Lock()
+_WRITE_ASYNC = os.environ.get('BB_WRITE_ASYNC', '1') not in ('0', 'no', 'off')
+
+
+def _sink_for(fh, create=True):
+    with _sinks_lock:
+        s = _sinks.get(id(fh))
+        if s is None and create:
+            s = _sinks[id(fh)] = _FileSink(fh)
+        return s
+
+
+def write_host_bytes(fh, data):
+    """Host bytes -> `fh`, IN ORDER with the device pieces `write_device_bytes`
+    has queued for the same handle (frame headers of the block formats)."""
+    s = _sink_for(fh, create=False)
+    if s is None:
+        fh.write(data)
+    else:
+        s.put_host(data)
+
+
+class HostWriteOrder:
+    """File-like ``write`` for header ``tofile`` calls that must stay in order
+    with queued device pieces: ``header.tofile(HostWriteOrder(fh))``."""
+
+    def __init__(self, fh):
+        self.fh = fh
+
+    def write(self, data):
+        write_host_bytes(self.fh, data)
+        return len(data)
+
+
+def finish_writes(fh, close_sink=True):
+    """Wait until everything queued for `fh` is in the file (before the handle
+    is closed, flushed, or asked where it stands); raises what a write raised."""
+    with _sinks_lock:
+        s = _sinks.pop(id(fh), None) if close_sink else _sinks.get(id(fh))
+    if s is not None:
+        s.close() if close_sink else s.drain()
+
+
 def write_device_bytes(fh, dev, chunk_bytes=16 << 20):
     """Device uint8 tensor -> `fh` at its current position (the stream
     writers' way to the file; the reference fills a memory map of the file
-    frame by frame, base/base.py:1276-1342).  Large tensors are pipelined:
-    chunk k + 1 travels to a pinned buffer on a side stream while ``fh.write``
-    puts chunk k into the page cache.  One ``write`` is all a file takes: on the
-    GPU box 12 GB/s into a new file, and neither ``os.pwrite`` from 4-16 threads
-    (11-12 GB/s: buffered writes to one file serialise on its inode lock) nor a
-    memory map filled by 8 threads (2.4 GB/s into a new file) does better
-    (tools/experiments/exp_file_write.py, profiles/r03y_exp_file_write.log)."""
+    frame by frame, base/base.py:1276-1342).  ASYNCHRONOUS since round 5: the
+    pieces (16 MiB) travel to pinned buffers on a side stream and a thread of
+    the handle's `_FileSink` writes them in order while the caller encodes the
+    next frames; `finish_writes(fh)` -- the writers call it when they close --
+    waits for them.  BB_WRITE_ASYNC=0: each call returns when its bytes are in
+    the file.  One ``write`` at a time is all a file takes: on the GPU box 12
+    GB/s into a new file whatever the number of threads (buffered writes to
+    one file serialise on its inode lock: profiles/r03y_exp_file_write.log);
+    files written AT THE SAME TIME scale -- 2 / 4 / 8 files 23 / 40 / 69 GB/s
+    (profiles/r05g_exp_file_write2.log) -- which the GSB writer's several raw
+    files get from their own sinks."""
     src = dev.reshape(-1)
-    n = src.numel()
-    if n < 2 * chunk_bytes:
-        host = _pinned_take(max(n, 1))
-        try:
-            host[:n].copy_(src)
-            fh.write(memoryview(host.numpy()[:n]))
-        finally:
-            _pinned_give(host)
+    if src.numel() == 0:
         return
-    stream = torch.cuda.Stream(device=dev.device)
-    stream.wait_stream(torch.cuda.current_stream(dev.device))
-    pinned = [_pinned_take(chunk_bytes) for _ in range(2)]
-    events = [None, None]
-    spans = [(lo, min(n, lo + chunk_bytes)) for lo in range(0, n, chunk_bytes)]
-    try:
-        for i in range(len(spans) + 1):
-            if i < len(spans):
-                lo, hi = spans[i]
-                b = i % 2
-                with torch.cuda.stream(stream):
-                    pinned[b][:hi - lo].copy_(src[lo:hi], non_blocking=True)
-                    events[b] = torch.cuda.Event()
-                    events[b].record(stream)
-            if i > 0:                               # write chunk i-1 while chunk i is in flight
-                plo, phi = spans[i - 1]
-                pb = (i - 1) % 2
-                events[pb].synchronize()
-                fh.write(memoryview(pinned[pb].numpy()[:phi - plo]))
-    finally:
-        # (the tensor must outlive the copies that read it on the side stream)
-        torch.cuda.current_stream(dev.device).wait_stream(stream)
-        # A device-to-host copy may still be writing a pinned buffer when an error
-        # (a full disk, a closed file) brings us here: the buffers go back to the
-        # SHARED pool, so the copies must have finished on the host's clock too
-        # (ADVICE r3); on the normal path everything was waited for already.
-        stream.synchronize()
-        for t in pinned:
-            _pinned_give(t)
+    s = _sink_for(fh)
+    s.put_device(src, chunk_bytes)
+    if not _WRITE_ASYNC:
+        s.drain()
 
 
 def to_numpy(dev):

@@ -315,9 +315,19 @@ int bb_decode_frames_select_check(const bb_decode_params *params, int nwithin);
  * vdif/frame.py:176-243,402-434).  Same results and error codes as the four
  * calls; what it saves is host time (three library entries and their argument
  * marshalling per read() of a binding: 25 us of 65 through ctypes).
- * `verified`: optional hipEvent_t, recorded on `stream` behind the verification
- * launch and AHEAD of the decode, so that a host that only needs the verdict
- * does not wait for the decode.  d_recs (nframes records) and d_src
+ * `verified`: optional hipEvent_t, recorded behind the verification launch and
+ * AHEAD of the decode, so that a host that only needs the verdict does not wait
+ * for the decode.  `scan_stream` (round 5; NULL = `stream`): the scan, index
+ * and verification launches go on THIS stream, `verified` (then required) is
+ * recorded there and `stream` -- which takes the decode -- is made to wait for
+ * it.  A reader that decodes request after request from bytes that are in HBM
+ * already gets the verdict of request k + 1 while the decode of request k is
+ * still running on `stream` (back-to-back reads of 2^15 frames: the host waits
+ * 0.1 instead of 0.7 ms per read).  The CALLER orders the rest: the input must
+ * be complete as far as `scan_stream` can tell, and d_recs / d_src must not be
+ * in use by a decode still running on `stream` (two sets of scratch, taking
+ * turns, and a wait for the decode two requests back:
+ * baseband_amd/kernels.py).  d_recs (nframes records) and d_src
  * (nsets * dec->nslot entries) are scratch the caller provides.
  */
 int bb_vdif_read_window(const void *d_buf, size_t nbytes,
@@ -328,7 +338,7 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
                         bb_frame_rec *d_recs, int64_t *d_src,
                         float *d_out, size_t out_elems,
                         uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad,
-                        void *verified, void *stream);
+                        void *verified, void *scan_stream, void *stream);
 
 /*
  * The same for Mark 5B and Mark 4 (single-thread formats: one record per
@@ -344,7 +354,7 @@ int bb_mark5b_read_window(const void *d_buf, size_t nbytes,
                           const int32_t *d_within, int nwithin,
                           bb_frame_rec *d_recs, int64_t *d_src,
                           float *d_out, size_t out_elems,
-                          size_t nstrict, uint32_t *d_nbad, void *verified, void *stream);
+                          size_t nstrict, uint32_t *d_nbad, void *verified, void *scan_stream, void *stream);
 
 /*
  * Fetch a device counter (the d_nbad of bb_verify_records) on `side_stream`
@@ -472,7 +482,7 @@ int bb_mark4_read_window(const void *d_buf, size_t nbytes,
                          const bb_mark4_decode_params *dec, int nout,
                          bb_frame_rec *d_recs, int64_t *d_src,
                          float *d_out, size_t out_elems,
-                         size_t nstrict, uint32_t *d_nbad, void *verified, void *stream);
+                         size_t nstrict, uint32_t *d_nbad, void *verified, void *scan_stream, void *stream);
 
 /* ---- float32 samples (extension) ---------------------------------------- */
 
