@@ -190,12 +190,12 @@ SIGNATURES = [
     ('bb_copy_frames', C.c_int, [_vp, _sz, _sz, C.c_uint64, C.c_int64, C.c_int64, _vp, _sz, _vp]),
     ('bb_fetch_counter', C.c_int, [_vp, _vp, _vp, _vp]),
     ('bb_mark5b_read_window', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _sz, _sz, C.POINTER(DecodeParams),
-                                        _vp, C.c_int, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+                                        _vp, C.c_int, _vp, _vp, _vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     ('bb_mark4_read_window', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _sz, _sz,
                                        C.POINTER(Mark4DecodeParams), C.c_int, _vp, _vp, _vp, _sz, _sz, _vp, _vp,
-                                       _vp]),
+                                       _vp, _vp]),
     ('bb_vdif_read_window', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _sz, _vp, _sz, C.POINTER(DecodeParams),
-                                      _vp, C.c_int, _vp, _vp, _vp, _sz, C.c_uint32, _sz, _vp, _vp, _vp]),
+                                      _vp, C.c_int, _vp, _vp, _vp, _sz, C.c_uint32, _sz, _vp, _vp, _vp, _vp]),
     ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),
     ('bb_mark4_locate', C.c_int, [_vp, _sz, C.c_int, _vp, _sz, _vp, _vp]),
     ('bb_mark4_header_crc', C.c_int, [_vp, _sz, C.c_int, _vp, C.c_int64, _sz, _vp, _vp]),

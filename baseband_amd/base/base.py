@@ -12,6 +12,7 @@ frame sets, streams the corresponding bytes to HBM in large windows
 index build -> decode.  The result is a device tensor.
 """
 import operator
+import os
 import warnings
 
 import numpy as np
@@ -22,6 +23,9 @@ from ..placement import empty_output
 from .. import placement as _placement
 from ..staging import host_image, WindowPipeline
 from .quantities import as_time, as_timedelta, is_time_like, is_duration_like
+
+# BB_SIDE_SCAN=0: the scan of a request on resident bytes stays on the caller's stream
+_SIDE_SCAN = os.environ.get('BB_SIDE_SCAN', '1') not in ('0', 'no', 'off')
 
 __all__ = ['FileBase', 'VLBIFileReaderBase', 'GPUStreamReaderBase',
            'HeaderNotFoundError']
@@ -854,13 +858,43 @@ class GPUStreamReaderBase:
             return part.clone()
         return part
 
+    _scan_side = None       # side stream for the scan of the window being processed (resident bytes only)
+    _scan_stream = None
+    _scan_ready_for = None
+
+    def _scan_stream_for(self, resident):
+        """The side stream the scan / index / verification launches of requests
+        on `resident` go to (kernels._FrameWindow): their verdict -- all that
+        read() waits for -- then does not queue behind the previous request's
+        decode on the caller's stream.  The stream first waits for everything
+        that is queued on the caller's stream NOW (whatever produced the
+        bytes); bytes changed later, between two reads, are the caller's to
+        order."""
+        dev = resident.device
+        if self._scan_stream is None:
+            self._scan_stream = torch.cuda.Stream(device=dev, priority=-1)
+        key = (resident.data_ptr(), resident.numel())
+        if self._scan_ready_for != key:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._scan_stream.wait_event(ev)
+            self._scan_ready_for = key
+        return self._scan_stream
+
+    def _zero_nbad(self):
+        if self._nbad is not None:
+            if self._scan_stream is not None:           # (verification launches on the side stream add to it)
+                self._scan_stream.synchronize()
+            self._nbad.zero_()
+            if self._scan_stream is not None:
+                torch.cuda.current_stream(self._nbad.device).synchronize()
+
     def _reset_checks(self):
         """Forget the verification state of windows that were processed for a
         read that did not complete (or a read-ahead that was abandoned): the
         next read starts clean -- host counters AND the device counter."""
         self._nmissing, self._checked, self._check_recs = 0, False, 0
-        if self._nbad is not None:
-            self._nbad.zero_()
+        self._zero_nbad()
 
     def _fill_request(self, out, count):
         """Decode samples [offset, offset + count).  Returns ``(data, direct)``:
@@ -927,11 +961,19 @@ class GPUStreamReaderBase:
             lo = min(self._file_offset0 + first * set_nbytes, resident.numel())
             look = 1 if self.verify else 0
             hi = max(lo, min(self._file_offset0 + (last + look) * set_nbytes, resident.numel()))
+            win = self._device_window(resident, lo, hi)
+            # (requests large enough for the side-stream verdict of `_resolve_checks`, bytes read in
+            # place: the scan of this request need not queue behind the decode of the one before)
+            if (self.verify and _SIDE_SCAN and nsets * set_nbytes >= (16 << 20)
+                    and win.data_ptr() == resident.data_ptr() + lo):
+                self._scan_side = self._scan_stream_for(resident)
             try:
-                self._process_window(self._device_window(resident, lo, hi), first, last, flat)
+                self._process_window(win, first, last, flat)
             except Exception:
                 self._reset_checks()
                 raise
+            finally:
+                self._scan_side = None
         elif nsets and nsets * set_nbytes * 8 <= self.window_bytes:
             # small request: serve it from the read-ahead window kept in HBM
             self._read_small(first, last, flat, spf * row)
@@ -1087,7 +1129,7 @@ class GPUStreamReaderBase:
             nbad = int(self._nbad_host[0]) + self._nmissing
         self._nmissing = 0
         if nbad:
-            self._nbad.zero_()
+            self._zero_nbad()
             if quiet:
                 return False
             msg = ("problem loading frame: {} frame header(s) failed verification "

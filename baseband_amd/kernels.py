@@ -132,12 +132,50 @@ def _vdif_params(frame_nbytes, header_nbytes, pattern, mask, ref_seconds,
     return p
 
 
-class VDIFWindow:
+class _FrameWindow:
+    """Scratch handling shared by the window calls: the scan records and the
+    index of a window.  With the scan on a SIDE stream (`scan_stream`: the
+    verdict of request k + 1 does not queue behind the decode of request k on
+    the caller's stream, include/bbdecode.h) there are TWO sets taking turns:
+    the decode of request k still reads set A while the scan of request k + 1
+    fills set B, and before a set is filled again the side stream waits for the
+    event recorded behind the decode that used it last."""
+    __slots__ = ('recs', 'src', 'fill_value', '_sets', '_turn')
+
+    def _scratch(self, nframes, n, dev, scan_stream=None):
+        sets = getattr(self, '_sets', None)
+        if sets is None:
+            sets = self._sets = [[None, None, None], [None, None, None]]
+            self._turn = 0
+        k = 0
+        if scan_stream is not None:
+            self._turn ^= 1
+            k = self._turn
+        st = sets[k]
+        if st[0] is None or st[0].shape[0] < nframes or st[0].device != dev:
+            st[0] = torch.empty((max(nframes, 64), 4), dtype=torch.int32, device=dev)
+        if st[1] is None or st[1].numel() < n or st[1].device != dev:
+            st[1] = torch.empty(max(n, 64), dtype=torch.int64, device=dev)
+        self.recs, self.src = st[0], st[1]
+        if scan_stream is not None and st[2] is not None:
+            scan_stream.wait_event(st[2])           # the decode that read this set last
+        return st
+
+    @staticmethod
+    def _decode_queued(st, scan_stream, dev):
+        """Behind a window call: remember where the decode that reads set `st` stands."""
+        if scan_stream is not None:
+            if st[2] is None:
+                st[2] = torch.cuda.Event()
+            st[2].record(torch.cuda.current_stream(dev))
+
+
+class VDIFWindow(_FrameWindow):
     """One window of a VDIF stream read -- scan, index, verification, decode --
     as ONE library call (bb_vdif_read_window) with argument blocks that are
     built once per reader: a third of the host time of a small read() went
     into marshalling the same constants for four calls."""
-    __slots__ = ('scan', 'dec', 'recs', 'src', 'fill_value')
+    __slots__ = ('scan', 'dec')
 
     def __init__(self, frame_nbytes, header_nbytes, pattern, mask, ref_seconds, frame_rate,
                  payload_nbytes, coder, bps, chunk, nslot, complex_data, fill_value):
@@ -147,7 +185,7 @@ class VDIFWindow:
         p.payload_nbytes = payload_nbytes
         p.complex_data = int(bool(complex_data))
         self.set_fill(fill_value)
-        self.recs = self.src = None
+        self.recs = self.src = self._sets = None
 
     def set_fill(self, fill_value):
         fv = complex(fill_value)
@@ -155,37 +193,28 @@ class VDIFWindow:
         self.fill_value = fill_value
 
     def run(self, dbuf, ref_frame_nr, nframes, thread_slot, nsets, within, out,
-            recs_per_index, nstrict, nbad, verified):
+            recs_per_index, nstrict, nbad, verified, scan_stream=None):
         """Launch the window on torch's current stream.  `out`: flat float32
         device tensor; `nbad`: int32[1] device counter, or None for no
         verification; `verified`: raw handle of the event to record behind the
-        verification launch, or None."""
+        verification launch, or None; `scan_stream`: torch stream for the scan /
+        index / verification launches (needs `verified`; `_FrameWindow`)."""
         dev = dbuf.device
         self.scan.ref_frame_nr = ref_frame_nr
-        if self.recs is None or self.recs.shape[0] < nframes or self.recs.device != dev:
-            self.recs = torch.empty((max(nframes, 64), 4), dtype=torch.int32, device=dev)
-        nsrc = nsets * self.dec.nslot
-        if self.src is None or self.src.numel() < nsrc or self.src.device != dev:
-            self.src = torch.empty(max(nsrc, 64), dtype=torch.int64, device=dev)
+        if not verified:
+            scan_stream = None
+        st = self._scratch(nframes, nsets * self.dec.nslot, dev, scan_stream)
         tgt = _Target(out, out.numel(), dev)
         nsel = within.numel() if within is not None else 0
         check(lib.bb_vdif_read_window(
             _ptr(dbuf), dbuf.numel(), C.byref(self.scan), nframes, _ptr(thread_slot), nsets,
             C.byref(self.dec), _ptr(within), nsel, _ptr(self.recs), _ptr(self.src),
             _ptr(tgt.use), tgt.use.numel(), recs_per_index, nstrict, _ptr(nbad),
-            C.c_void_p(verified) if verified else C.c_void_p(0), _stream(dbuf)), 'bb_vdif_read_window')
+            C.c_void_p(verified) if verified else C.c_void_p(0),
+            C.c_void_p(scan_stream.cuda_stream) if scan_stream is not None else C.c_void_p(0),
+            _stream(dbuf)), 'bb_vdif_read_window')
+        self._decode_queued(st, scan_stream, dev)
         tgt.done()
-
-
-class _FrameWindow:
-    """Scratch and output handling shared by the single-thread window calls."""
-    __slots__ = ('recs', 'src', 'fill_value')
-
-    def _scratch(self, nframes, n, dev):
-        if self.recs is None or self.recs.shape[0] < nframes or self.recs.device != dev:
-            self.recs = torch.empty((max(nframes, 64), 4), dtype=torch.int32, device=dev)
-        if self.src is None or self.src.numel() < n or self.src.device != dev:
-            self.src = torch.empty(max(n, 64), dtype=torch.int64, device=dev)
 
 
 class Mark5BWindow(_FrameWindow):
@@ -198,7 +227,7 @@ class Mark5BWindow(_FrameWindow):
         p.first_offset, p.ref_seconds, p.frame_rate = 0, ref_seconds, frame_rate
         d = self.dec = _lib.DecodeParams()
         d.coder, d.bps, d.chunk, d.nslot, d.payload_nbytes = _lib.CODER_MARK5B, bps, chunk, 1, 10000
-        self.recs = self.src = None
+        self.recs = self.src = self._sets = None
         self.set_fill(fill_value)
 
     def set_fill(self, fill_value):
@@ -206,15 +235,19 @@ class Mark5BWindow(_FrameWindow):
         self.dec.fill_re, self.dec.fill_im = fv.real, fv.imag
         self.fill_value = fill_value
 
-    def run(self, dbuf, ref_frame_nr, nframes, n, within, out, nstrict, nbad, verified):
+    def run(self, dbuf, ref_frame_nr, nframes, n, within, out, nstrict, nbad, verified, scan_stream=None):
         self.scan.ref_frame_nr = ref_frame_nr
-        self._scratch(nframes, n, dbuf.device)
+        if not verified:
+            scan_stream = None
+        st = self._scratch(nframes, n, dbuf.device, scan_stream)
         tgt = _Target(out, out.numel(), dbuf.device)
         check(lib.bb_mark5b_read_window(
             _ptr(dbuf), dbuf.numel(), C.byref(self.scan), nframes, n, C.byref(self.dec), _ptr(within),
             within.numel() if within is not None else 0, _ptr(self.recs), _ptr(self.src), _ptr(tgt.use),
             tgt.use.numel(), nstrict, _ptr(nbad), C.c_void_p(verified) if verified else C.c_void_p(0),
+            C.c_void_p(scan_stream.cuda_stream) if scan_stream is not None else C.c_void_p(0),
             _stream(dbuf)), 'bb_mark5b_read_window')
+        self._decode_queued(st, scan_stream, dbuf.device)
         tgt.done()
 
 
@@ -234,21 +267,26 @@ class Mark4Window(_FrameWindow):
             d.sign_bit[j] = s
             d.mag_bit[j] = m
         self.nout = len(sign_bit) if select else 0
-        self.recs = self.src = None
+        self.recs = self.src = self._sets = None
         self.set_fill(fill_value)
 
     def set_fill(self, fill_value):
         self.dec.fill = float(fill_value)
         self.fill_value = fill_value
 
-    def run(self, dbuf, first, nframes, n, out, nstrict, nbad, verified):
+    def run(self, dbuf, first, nframes, n, out, nstrict, nbad, verified, scan_stream=None):
         self.scan.ref_qms = self.ref_qms + first * self.frame_qms
-        self._scratch(nframes, n, dbuf.device)
+        if not verified:
+            scan_stream = None
+        st = self._scratch(nframes, n, dbuf.device, scan_stream)
         tgt = _Target(out, out.numel(), dbuf.device)
         check(lib.bb_mark4_read_window(
             _ptr(dbuf), dbuf.numel(), C.byref(self.scan), nframes, n, C.byref(self.dec), self.nout,
             _ptr(self.recs), _ptr(self.src), _ptr(tgt.use), tgt.use.numel(), nstrict, _ptr(nbad),
-            C.c_void_p(verified) if verified else C.c_void_p(0), _stream(dbuf)), 'bb_mark4_read_window')
+            C.c_void_p(verified) if verified else C.c_void_p(0),
+            C.c_void_p(scan_stream.cuda_stream) if scan_stream is not None else C.c_void_p(0),
+            _stream(dbuf)), 'bb_mark4_read_window')
+        self._decode_queued(st, scan_stream, dbuf.device)
         tgt.done()
 
 

@@ -226,7 +226,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
             nbad, verified = self._verdict_targets()
         # the look-ahead header (record n) only has to be a header
         w.run(dbuf, self.header0['frame_nr'] + first, nframes, n, self._within, out_flat,
-              min(n, nframes), nbad, verified)
+              min(n, nframes), nbad, verified, scan_stream=self._scan_side)
         if self.verify:
             self._note_checked(nframes, missing=max(0, n - nframes))
 

@@ -516,7 +516,7 @@ class _FileSink:
     flight.  An error of the file (a full disk) is raised by the next call
     that touches the sink."""
 
-    def __init__(self, fh, depth=6):
+    def __init__(self, fh, depth=4):
         self.fh = fh
         self.q = queue.Queue()
         self.slots = threading.Semaphore(depth)
@@ -559,10 +559,13 @@ class _FileSink:
             self.stream = torch.cuda.Stream(device=dev)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         n = src.numel()
-        for lo in range(0, n, chunk_bytes):
-            hi = min(n, lo + chunk_bytes)
+        npiece = max(1, (n + chunk_bytes // 4) // chunk_bytes)          # (no small tail piece: up to 1.25 chunks go as one)
+        step = -(-n // npiece)
+        step += -step % 4096
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
             self.slots.acquire()                        # back-pressure: `depth` pieces in flight
-            host = _pinned_take(chunk_bytes)
+            host = _pinned_take(step)
             with torch.cuda.stream(self.stream):
                 host[:hi - lo].copy_(src[lo:hi], non_blocking=True)
                 ev = torch.cuda.Event()
@@ -633,11 +636,11 @@ def finish_writes(fh, close_sink=True):
         s.close() if close_sink else s.drain()
 
 
-def write_device_bytes(fh, dev, chunk_bytes=16 << 20):
+def write_device_bytes(fh, dev, chunk_bytes=32 << 20):
     """Device uint8 tensor -> `fh` at its current position (the stream
     writers' way to the file; the reference fills a memory map of the file
     frame by frame, base/base.py:1276-1342).  ASYNCHRONOUS since round 5: the
-    pieces (16 MiB) travel to pinned buffers on a side stream and a thread of
+    pieces (32 MiB) travel to pinned buffers on a side stream and a thread of
     the handle's `_FileSink` writes them in order while the caller encodes the
     next frames; `finish_writes(fh)` -- the writers call it when they close --
     waits for them.  BB_WRITE_ASYNC=0: each call returns when its bytes are in

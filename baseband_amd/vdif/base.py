@@ -396,7 +396,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
             # behind it: read() waits for this verdict only -- `_resolve_checks`)
             nbad, verified = self._verdict_targets()
         w.run(dbuf, h0['frame_nr'] + first_set, nframes, self._thread_slot, nsets, self._within, out_flat,
-              nthread_file, nframes, nbad, verified)
+              nthread_file, nframes, nbad, verified, scan_stream=self._scan_side)
         if self.verify:
             self._note_checked(nframes, missing=nsets * nthread_file - nframes)
 

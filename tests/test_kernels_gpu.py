@@ -456,7 +456,8 @@ def test_decode_with_channel_selection(bps, chunk, nslot, sel):
                                         fill_value=fill, within=within)
         finally:
             kernels.tune(_lib.TUNE_WORK_STRIPES, -1)
-        assert 'k_decode_gather_select' in _lib.last_kernel()
+        # (k_decode_pick for selections of up to an eighth of a thread sample, round 5)
+        assert 'k_decode_gather_select' in _lib.last_kernel() or 'k_decode_pick' in _lib.last_kernel()
         assert bits_equal(out.cpu().numpy(), np.ascontiguousarray(exp[..., sel]).reshape(-1)), lw
 
 
