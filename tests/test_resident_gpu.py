@@ -206,3 +206,105 @@ def test_reads_back_to_back_without_host_syncs(monkeypatch):
                 fh.read(nf * 32000)
     finally:
         arena.disable()
+
+
+@pytest.mark.parametrize('nthread', [1, 8])
+def test_scan_on_a_side_stream_gives_the_same_reads(monkeypatch, nthread):
+    """Round 5: for requests on bytes that are in HBM already the scan / index /
+    verification launches go to a side stream (kernels._FrameWindow,
+    bb_vdif_read_window's `scan_stream`), two sets of scratch taking turns, so
+    that read() k + 1 gets its verdict while decode k still runs.  Same samples
+    as with BB_SIDE_SCAN off -- back to back without host syncs, requests of
+    different sizes (below the threshold too), results dropped at once -- and a
+    damaged frame raises at the read that holds it."""
+    import torch
+    from baseband_amd import synth, vdif
+    from baseband_amd.base import base as bbase
+    pn = 8000 if nthread == 1 else 2000
+    nsets = 14000 if nthread == 1 else 7000
+    image, h0 = synth.random_vdif(4, nsets, nthread=nthread, nchan=1 if nthread == 1 else 4, bps=2,
+                                  complex_data=nthread > 1, payload_nbytes=pn, frame_rate=1000,
+                                  thread_order=None if nthread == 1 else [1, 3, 5, 7, 0, 2, 4, 6],
+                                  invalid=[(2500, 0), (2501, nthread - 1)])
+    spf = h0.samples_per_frame
+    rate = 1000 * spf
+    dev = torch.from_numpy(image.copy()).cuda()
+    big = (17 << 20) // (nthread * (pn + 32)) + 3            # frame sets of a request above the 16 MiB threshold
+    plan = [(100, big), (2400, big), (50, 40), (big + 900, big + 77), (0, big), (nsets - big - 1, big), (2450, big)]
+
+    def loop(side):
+        monkeypatch.setattr(bbase, '_SIDE_SCAN', side)
+        outs = []
+        with vdif.open(dev, 'rs', sample_rate=rate, squeeze=False) as fh:
+            for f0, n in plan:
+                fh.seek(f0 * spf)
+                got = fh.read(n * spf)
+                outs.append((torch.view_as_real(got).double().sum() if got.is_complex() else got.double().sum(),
+                             got.reshape(-1)[::997].clone()))
+                del got
+            used = fh._scan_stream is not None
+        torch.cuda.synchronize()
+        return [(float(a), b.cpu().numpy()) for a, b in outs], used
+
+    on, used_on = loop(True)
+    off, used_off = loop(False)
+    assert used_on and not used_off
+    for (a, b), (c, d), pl in zip(on, off, plan):
+        assert a == c and np.array_equal(b.view(np.uint8), d.view(np.uint8)), pl
+    # damage in the third large request only
+    monkeypatch.setattr(bbase, '_SIDE_SCAN', True)
+    bad = dev.clone()
+    fb = (big + 900 + 5) * nthread * (pn + 32)
+    bad[fb:fb + 16] = 0xff
+    with vdif.open(bad, 'rs', sample_rate=rate, squeeze=False, verify=True) as fh:
+        for k, (f0, n) in enumerate(plan[:5]):
+            fh.seek(f0 * spf)
+            if k == 3:
+                with pytest.raises(ValueError):
+                    fh.read(n * spf)
+            else:
+                fh.read(n * spf)
+
+
+@pytest.mark.parametrize('fmt', ['mark5b', 'mark4'])
+def test_side_stream_scan_for_the_single_thread_formats(monkeypatch, fmt):
+    import torch
+    import baseband_amd as bb
+    from baseband_amd import synth
+    from baseband_amd.base import base as bbase
+    if fmt == 'mark4':
+        image, h0 = synth.random_mark4(3, 260, ntrack=64, fanout=4, frame_rate=400)
+        frame = 160000
+        op, kw = bb.mark4.open, dict(ntrack=64, decade=2010, sample_rate=400 * 80000)
+        spf = 80000
+    else:
+        nfr = 4200
+        rng = np.random.default_rng(8)
+        words = rng.integers(0, 2 ** 32, (nfr, 2504), dtype=np.uint64).astype(np.uint32)
+        from baseband_amd.mark5b.header import frame_header_words
+        words[:, :4] = frame_header_words(np.datetime64('2014-06-13T05:30:01'), 6400, 0, nfr)
+        image = words.view(np.uint8).reshape(-1)
+        frame, spf = 10016, 5000
+        op, kw = bb.mark5b.open, dict(kday=56000, nchan=8, bps=2, sample_rate=6400 * 5000)
+    dev = torch.from_numpy(np.ascontiguousarray(image)).cuda()
+    n_big = (17 << 20) // frame + 2
+
+    def loop(side):
+        monkeypatch.setattr(bbase, '_SIDE_SCAN', side)
+        outs = []
+        with op(dev, 'rs', **kw) as fh:
+            total = fh.shape[0] // spf
+            for f0 in (0, 7, total - n_big, 3):
+                fh.seek(f0 * spf)
+                got = fh.read(n_big * spf)
+                outs.append((float(got.double().sum()), got.reshape(-1)[::1013].clone()))
+                del got
+            used = fh._scan_stream is not None
+        torch.cuda.synchronize()
+        return outs, used
+
+    on, used = loop(True)
+    off, _ = loop(False)
+    assert used
+    for (a, b), (c, d) in zip(on, off):
+        assert a == c and torch.equal(b.view(torch.int32), d.view(torch.int32))
