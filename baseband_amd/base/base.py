@@ -859,6 +859,7 @@ class GPUStreamReaderBase:
         return part
 
     _scan_side = None       # side stream for the scan of the window being processed (resident bytes only)
+    _last_scan_side = None  # ... of the window processed last (where its verdict is fetched)
     _scan_stream = None
     _scan_ready_for = None
 
@@ -872,7 +873,7 @@ class GPUStreamReaderBase:
         order."""
         dev = resident.device
         if self._scan_stream is None:
-            self._scan_stream = torch.cuda.Stream(device=dev, priority=-1)
+            self._scan_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('BB_SIDE_SCAN_PRIORITY', '-1')))
         key = (resident.data_ptr(), resident.numel())
         if self._scan_ready_for != key:
             ev = torch.cuda.Event()
@@ -941,6 +942,7 @@ class GPUStreamReaderBase:
         """Decode frame sets [first, last) -> tensor (nsets*spf, *unsliced);
         `into` is an optional flat float32 device tensor to decode into."""
         kernels.require_gpu()
+        self._last_scan_side = None
         nsets = last - first
         spf = self.samples_per_frame
         ncomp = 2 if self.complex_data else 1
@@ -973,7 +975,7 @@ class GPUStreamReaderBase:
                 self._reset_checks()
                 raise
             finally:
-                self._scan_side = None
+                self._last_scan_side, self._scan_side = self._scan_side, None
         elif nsets and nsets * set_nbytes * 8 <= self.window_bytes:
             # small request: serve it from the read-ahead window kept in HBM
             self._read_small(first, last, flat, spf * row)
@@ -1125,7 +1127,11 @@ class GPUStreamReaderBase:
                 self._nbad_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
             # (one library call: stream-wait-event, 4-byte copy, stream synchronise --
             # torch's stream context manager alone cost 15 us)
-            kernels.fetch_counter(self._nbad, self._nbad_host, self._check_event, self._check_stream)
+            # When the verification ran on the scan stream (`_scan_stream_for`) the copy is queued
+            # right behind it THERE: no third stream, no event to wait for.
+            on_scan = self._last_scan_side
+            kernels.fetch_counter(self._nbad, self._nbad_host, None if on_scan is not None else self._check_event,
+                                  on_scan if on_scan is not None else self._check_stream)
             nbad = int(self._nbad_host[0]) + self._nmissing
         self._nmissing = 0
         if nbad:

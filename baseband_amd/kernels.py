@@ -393,7 +393,8 @@ def fetch_counter(counter, host, event, side_stream):
     """``host[0] = counter[0]`` fetched on `side_stream` once `event` has
     happened (bb_fetch_counter); returns when the value is there.  `host`: a
     pinned int32 tensor; `event`: torch.cuda.Event that has been recorded."""
-    check(lib.bb_fetch_counter(_ptr(counter), C.c_void_p(host.data_ptr()), C.c_void_p(event.cuda_event),
+    check(lib.bb_fetch_counter(_ptr(counter), C.c_void_p(host.data_ptr()),
+                               C.c_void_p(event.cuda_event) if event is not None else C.c_void_p(0),
                                C.c_void_p(side_stream.cuda_stream)), 'bb_fetch_counter')
 
 

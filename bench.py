@@ -80,6 +80,7 @@ from bench_legs.other_configs import leg_locate, leg_other_configs              
 from bench_legs.pipeline import pinned_h2d_rate, leg_pipeline                    # noqa: E402,F401
 from bench_legs.mid_size import leg_mid_size                                     # noqa: E402,F401
 from bench_legs.cold_read import leg_cold_first_read                             # noqa: E402,F401
+from bench_legs.arena_headline import leg_arena_headline                         # noqa: E402,F401
 
 
 def main():
@@ -385,6 +386,11 @@ def main():
                 line["pipeline"] = leg_pipeline(device, gib=args.pipeline_gib)
             except Exception as exc:
                 line["pipeline"] = {"error": repr(exc)[:500]}
+            torch.cuda.empty_cache()
+            try:        # (last: the 127.5 GiB plain output is gone, an arena block of that size fits)
+                line["roofline"]["arena_placed_output"] = leg_arena_headline(device, gib=args.gib)
+            except Exception as exc:
+                line["roofline"]["arena_placed_output"] = {"error": repr(exc)[:500]}
     rc = 0
     if rank == 0:
         if cpu is not None:

@@ -47,6 +47,9 @@ def collect_checks(line):
         put("pipeline.all_match", line, "pipeline", "all_match")
     if "cold_first_read" in line:
         put("cold_first_read.all_ok", line, "cold_first_read", "all_ok")
+    ap = _get(line, "roofline", "arena_placed_output")
+    if isinstance(ap, dict) and "skipped" not in ap:
+        put("roofline.arena_placed_output.spot_check", line, "roofline", "arena_placed_output", "spot_check")
     if "other_configs" in line:
         oc = line["other_configs"]
         checks["other_configs.spot_checks"] = bool(oc) and all(

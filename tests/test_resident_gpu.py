@@ -251,10 +251,12 @@ def test_scan_on_a_side_stream_gives_the_same_reads(monkeypatch, nthread):
     assert used_on and not used_off
     for (a, b), (c, d), pl in zip(on, off, plan):
         assert a == c and np.array_equal(b.view(np.uint8), d.view(np.uint8)), pl
-    # damage in the third large request only
+    # damage in a frame set that only the request plan[3] holds
     monkeypatch.setattr(bbase, '_SIDE_SCAN', True)
     bad = dev.clone()
-    fb = (big + 900 + 5) * nthread * (pn + 32)
+    fset = 5000 if nthread == 1 else 2100
+    assert [k for k, (f0, n) in enumerate(plan) if f0 <= fset < f0 + n] == [3]
+    fb = fset * nthread * (pn + 32)
     bad[fb:fb + 16] = 0xff
     with vdif.open(bad, 'rs', sample_rate=rate, squeeze=False, verify=True) as fh:
         for k, (f0, n) in enumerate(plan[:5]):
