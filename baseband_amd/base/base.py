@@ -13,6 +13,7 @@ index build -> decode.  The result is a device tensor.
 """
 import operator
 import os
+import threading
 import warnings
 
 import numpy as np
@@ -26,6 +27,8 @@ from .quantities import as_time, as_timedelta, is_time_like, is_duration_like
 
 # BB_SIDE_SCAN=0: the scan of a request on resident bytes stays on the caller's stream
 _SIDE_SCAN = os.environ.get('BB_SIDE_SCAN', '1') not in ('0', 'no', 'off')
+_scan_streams = {}              # device index -> the side stream of every reader's scans there
+_scan_streams_lock = threading.Lock()
 
 __all__ = ['FileBase', 'VLBIFileReaderBase', 'GPUStreamReaderBase',
            'HeaderNotFoundError']
@@ -873,7 +876,17 @@ class GPUStreamReaderBase:
         order."""
         dev = resident.device
         if self._scan_stream is None:
-            self._scan_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get('BB_SIDE_SCAN_PRIORITY', '-1')))
+            # ONE stream per device for all readers (streams share a few hardware queues in
+            # creation order: a stream per reader made the early verdict a matter of luck,
+            # profiles/r05j_back_to_back.log), high priority: the few microseconds of a scan
+            # should not wait for a free slot behind a decode launch that fills the device
+            # (normal priority: 0.954 against 0.837 ms per read of 2^15 frames back to back)
+            with _scan_streams_lock:
+                st = _scan_streams.get(dev.index)
+                if st is None:
+                    st = _scan_streams[dev.index] = torch.cuda.Stream(
+                        device=dev, priority=int(os.environ.get('BB_SIDE_SCAN_PRIORITY', '-1')))
+            self._scan_stream = st
         key = (resident.data_ptr(), resident.numel())
         if self._scan_ready_for != key:
             ev = torch.cuda.Event()

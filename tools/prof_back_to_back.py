@@ -24,6 +24,7 @@ for nf in (1 << 14, 1 << 15, 1 << 16):
                               ("side stream, normal priority", True, '0')):
         bbase._SIDE_SCAN = side
         os.environ['BB_SIDE_SCAN_PRIORITY'] = prio
+        bbase._scan_streams.clear()
         with vdif.open(image, 'rs', sample_rate=float(SPF * bench.FRAME_RATE)) as fh:
             for k in range(4):
                 fh.seek(((k * 3 + 1) * nf % (nframes - nf)) * SPF)
