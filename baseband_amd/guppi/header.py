@@ -71,6 +71,23 @@ def _format_card(key, value, comment=None):
     return card.ljust(80)[:80]
 
 
+class _NoSeekPastEnd:
+    """File-like over a bytes buffer whose ``seek`` past the end is harmless
+    (`fromfile` positions itself behind the header's padding)."""
+
+    def __init__(self, fh):
+        self.fh = fh
+
+    def read(self, n):
+        return self.fh.read(n)
+
+    def tell(self):
+        return self.fh.tell()
+
+    def seek(self, pos, whence=0):
+        return self.fh.seek(pos, whence)
+
+
 class GUPPIHeader(dict):
     """Dictionary of header cards with the reference's derived properties."""
 
@@ -154,6 +171,94 @@ class GUPPIHeader(dict):
         out = (''.join(self._cards()) + 'END'.ljust(80)).encode('ascii')
         out += (self.nbytes - len(out)) * b'\x00'
         return fh.write(out)
+
+    # -- the part of ``astropy.io.fits.Header``'s interface that callers of the
+    # reference's GUPPIHeader (a fits.Header subclass, guppi/header.py:17) use on
+    # a header: cards, comments, case-blind keys, text round trip
+    @property
+    def cards(self):
+        """[(keyword, value, comment)] in file order."""
+        layout = self._layout if self._layout is not None else []
+        placed = {key for key, _ in layout if key is not None}
+        order = [key for key, _ in layout if key is not None and key in self] + [k for k in self if k not in placed]
+        return [(key, self[key], self.comments.get(key, '') or '') for key in order]
+
+    def tostring(self, sep='', endcard=True, padding=False):
+        """The header as card text (80 characters per card)."""
+        cards = self._cards() + (['END'.ljust(80)] if endcard else [])
+        text = sep.join(cards)
+        if padding:
+            text += ' ' * (-len(text) % 2880)
+        return text
+
+    @classmethod
+    def fromstring(cls, data, verify=True):
+        """Header from card text (``tostring`` output, or the bytes of a file)."""
+        import io
+        if isinstance(data, str):
+            data = data.encode('ascii')
+        if b'END' + b' ' * 77 not in data:
+            data = data + b'END'.ljust(80)
+        self = cls.fromfile(_NoSeekPastEnd(io.BytesIO(data)), verify=verify)
+        return self
+
+    def set(self, keyword, value=None, comment=None):
+        """Set a card's value and / or comment (fits.Header.set)."""
+        key = keyword.upper()
+        if value is not None or key not in self:
+            self[key] = value
+        if comment is not None:
+            self.comments[key] = comment
+
+    def append(self, card):
+        key, value = card[0], card[1]
+        self.set(key, value, card[2] if len(card) > 2 else None)
+
+    def remove(self, keyword, ignore_missing=False):
+        key = keyword.upper()
+        if key not in self:
+            if ignore_missing:
+                return
+            raise KeyError("Keyword '{}' not found.".format(keyword))
+        del self[key]
+
+    def index(self, keyword):
+        return [k for k, _, _ in self.cards].index(keyword.upper())
+
+    def rename_keyword(self, old, new):
+        old, new = old.upper(), new.upper()
+        if new in self:
+            raise ValueError("keyword {} already exists".format(new))
+        value, comment = self[old], self.comments.pop(old, None)
+        if self._layout is not None:
+            self._layout = [(new if k == old else k, t) for k, t in self._layout]
+        dict.__delitem__(self, old)
+        dict.__setitem__(self, new, value)
+        if comment:
+            self.comments[new] = comment
+
+    def __getitem__(self, key):
+        try:
+            return dict.__getitem__(self, key)
+        except KeyError:
+            if isinstance(key, str) and key.upper() != key:
+                return dict.__getitem__(self, key.upper())
+            raise
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (isinstance(key, str) and dict.__contains__(self, key.upper()))
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __delitem__(self, key):
+        if not getattr(self, 'mutable', True):
+            raise TypeError("immutable {0} does not support deletion.".format(type(self).__name__))
+        key = key.upper()
+        dict.__delitem__(self, key)
+        self.comments.pop(key, None)
+        if self._layout is not None:
+            self._layout = [(k, t) for k, t in self._layout if k != key]
 
     def copy(self):
         new = GUPPIHeader(self, verify=False, mutable=True)

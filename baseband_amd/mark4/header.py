@@ -7,10 +7,13 @@ column per track), fields come back as per-track arrays, and the derived
 quantities (``fanout, bps, nchan, samples_per_frame, frame_nbytes, ...``)
 follow mark4/header.py:540-650.  Times are ``numpy.datetime64[ns]``.
 """
+import struct
+
 import numpy as np
+from ..base.header import BitFieldHeader
 from ..base.quantities import as_time
 
-__all__ = ['Mark4Header', 'stream2words', 'words2stream', 'MARK4_DTYPES',
+__all__ = ['Mark4Header', 'Mark4TrackHeader', 'stream2words', 'words2stream', 'MARK4_DTYPES',
            'PAYLOAD_NBITS', 'frame_header_streams']
 
 MARK4_DTYPES = {8: '<u1', 16: '<u2', 32: '<u4', 64: '<u8'}
@@ -143,8 +146,93 @@ def crc12_stream(stream):
     return stream[-12:]
 
 
+class Mark4TrackHeader(BitFieldHeader):
+    """Header of ONE Mark 4 track: five 32-bit words, the fields of memo 230.3
+    (mark4/header.py:91-262 in the reference).  `Mark4Header` holds one such
+    column per track; ``Mark4Header.track_header(k)`` gives track k's."""
+    _fields = _FIELDS
+    _struct = struct.Struct('<5I')
+    _invariants = {'sync_pattern', '_1_0_1_sync'}
+    _stream_invariants = _invariants | {'bcd_headstack1', 'bcd_headstack2', 'track_roll_enabled',
+                                        'sequence_suspended', 'system_id'}
+    _properties = ('decade', 'track_id', 'fraction', 'time')
+    decade = None
+
+    def __init__(self, words, decade=None, ref_time=None, verify=True):
+        if decade is not None:
+            self.decade = decade
+        super().__init__(words, verify=verify)
+        if decade is None and ref_time is not None:
+            self.infer_decade(ref_time)
+
+    def verify(self):
+        assert len(self.words) == 5
+        assert self['sync_pattern'] == 0xffffffff
+        assert (self['bcd_fraction'] & 0xf) % 5 != 4
+        if self.decade is not None:
+            assert 1950 < self.decade < 3000
+            assert self.decade % 10 == 0, "decade must end in zero"
+
+    def infer_decade(self, ref_time):
+        t = as_time(ref_time)
+        year = int(t.astype('datetime64[Y]').astype(int)) + 1970
+        frac = (t - np.datetime64(str(year), 'ns')) / np.timedelta64(365, 'D')
+        self.decade = int(np.around(year + frac - int(self['bcd_unit_year']), decimals=-1))
+
+    @property
+    def track_id(self):
+        return _bcd_decode_int(self['bcd_track_id'])
+
+    @track_id.setter
+    def track_id(self, track_id):
+        self['bcd_track_id'] = _bcd_encode(int(track_id))
+
+    @property
+    def fraction(self):
+        ms = _bcd_decode_int(self['bcd_fraction'])
+        return (ms + (ms % 5) * 0.25) / 1000.
+
+    @fraction.setter
+    def fraction(self, fraction):
+        ms = float(fraction) * 1000.
+        if abs(ms / 1.25 - round(ms / 1.25)) > 1e-6:
+            raise ValueError("{0} ms is not a multiple of 1.25 ms".format(ms))
+        self['bcd_fraction'] = _bcd_encode(int(np.floor(ms + 1e-6)))
+
+    def get_time(self):
+        day = _bcd_decode_int(self['bcd_day'])
+        sec = ((day - 1) * 24 + _bcd_decode_int(self['bcd_hour'])) * 3600 \
+            + _bcd_decode_int(self['bcd_minute']) * 60 + _bcd_decode_int(self['bcd_second'])
+        ns = sec * 10 ** 9 + int(round(self.fraction * 1e9))
+        return (np.datetime64('{:04d}-01-01'.format(self.decade + int(self['bcd_unit_year'])), 'ns')
+                + np.timedelta64(ns, 'ns'))
+
+    def set_time(self, time):
+        time = as_time(time)
+        year = int(time.astype('datetime64[Y]').astype(int)) + 1970
+        ns = int((time - np.datetime64('{:04d}-01-01'.format(year), 'ns')) / np.timedelta64(1, 'ns'))
+        sec, rem = divmod(ns, 10 ** 9)
+        self.fraction = rem / 1e9           # (first: it checks the 1.25 ms grid)
+        day, sod = divmod(sec, 86400)
+        hour, rest = divmod(sod, 3600)
+        minute, second = divmod(rest, 60)
+        self.decade = year // 10 * 10
+        self['bcd_unit_year'] = year % 10
+        self['bcd_day'] = _bcd_encode(day + 1)
+        self['bcd_hour'] = _bcd_encode(hour)
+        self['bcd_minute'] = _bcd_encode(minute)
+        self['bcd_second'] = _bcd_encode(second)
+
+    time = property(get_time, set_time)
+
+
 class Mark4Header:
     """Decoder of a Mark 4 header containing all tracks."""
+    _track_header = Mark4TrackHeader
+
+    def track_header(self, track):
+        """The header of one track as a `Mark4TrackHeader`."""
+        return Mark4TrackHeader([int(w) for w in self.words[:, track]], decade=self.decade, verify=False)
 
     decade = None
 

@@ -12,7 +12,9 @@ from ..base.header import (BitFieldHeader, four_word_struct,
                            eight_word_struct)
 from ..base.quantities import as_time, hz
 
-__all__ = ['VDIFHeader', 'ref_epoch_time']
+__all__ = ['VDIFHeader', 'VDIFBaseHeader', 'VDIFSampleRateHeader', 'VDIFNoSampleRateHeader', 'VDIFLegacyHeader',
+           'VDIFHeader0', 'VDIFHeader1', 'VDIFHeader2', 'VDIFHeader3', 'VDIFMark5BHeader', 'VDIF_HEADER_CLASSES',
+           'ref_epoch_time']
 
 _LEGACY_FIELDS = {
     'invalid_data': (0, 31, 1, False),
@@ -109,7 +111,23 @@ class VDIFHeader(BitFieldHeader):
     (vdif/header.py:124-143).  Unknown EDVs get the base (EDV-agnostic) table.
     """
 
+    _class_edv = None       # the EDV a subclass stands for (`VDIF_HEADER_CLASSES`); None: any
+
+    def __new__(cls, words=None, edv=None, verify=True, **kwargs):
+        """``VDIFHeader(words)`` returns an instance of the class registered
+        for the words' EDV (`VDIFHeader0` ... `VDIFMark5BHeader`,
+        `VDIFLegacyHeader`; `VDIFBaseHeader` for an EDV nothing is registered
+        for), as the reference's does (vdif/header.py:125-143)."""
+        if cls is VDIFHeader:
+            if edv is None and words is not None:
+                edv = False if (int(words[0]) >> 30) & 1 else (int(words[4]) >> 24) & 0xff
+            # (key -1 for legacy headers: a dict takes False and 0 for the same key)
+            cls = VDIF_HEADER_CLASSES.get(-1 if edv is False else edv, VDIFBaseHeader if edv is not None else VDIFHeader)
+        return super().__new__(cls)
+
     def __init__(self, words=None, edv=None, verify=True, **kwargs):
+        if edv is None and type(self)._class_edv is not None:
+            edv = type(self)._class_edv
         if edv is None and words is not None:
             edv = False if (int(words[0]) >> 30) & 1 else (int(words[4]) >> 24) & 0xff
         self._edv = edv
@@ -121,6 +139,10 @@ class VDIFHeader(BitFieldHeader):
         if words is not None and edv is False:
             words = words[:4]
         super().__init__(words, verify=verify)
+
+    def __reduce__(self):
+        # (the struct object held per instance does not pickle; words + EDV say it all)
+        return (_rebuild, (list(self.words), self._edv, bool(getattr(self, '_mutable', False))))
 
     @classmethod
     def fromfile(cls, fh, edv=None, verify=True):
@@ -408,6 +430,80 @@ class VDIFHeader(BitFieldHeader):
             self['mark5b_frame_nr'] = frame_nr
 
     time = property(get_time, set_time)
+
+
+def _rebuild(words, edv, mutable):
+    h = VDIFHeader(words, edv=edv, verify=False)
+    if mutable:
+        h.words = list(h.words)
+        h._mutable = True
+    return h
+
+
+class VDIFNoSampleRateHeader(VDIFHeader):
+    """Headers that do not carry a sample rate: `update` takes ``sample_rate``
+    / ``frame_rate`` only to place a time (vdif/header.py:484-518)."""
+
+    def update(self, *, time=None, frame_rate=None, sample_rate=None, verify=True, **kwargs):
+        if frame_rate is None and sample_rate is not None:
+            frame_rate = hz(sample_rate) / self.samples_per_frame
+        super().update(time=time, frame_rate=frame_rate, verify=verify, **kwargs)
+
+
+class VDIFLegacyHeader(VDIFNoSampleRateHeader):
+    """Legacy four-word header (vdif/header.py:521-551)."""
+    _class_edv = False
+
+
+class VDIFBaseHeader(VDIFHeader):
+    """Eight-word header of any EDV; the table of an EDV nothing is registered
+    for is the common one (vdif/header.py:554-577)."""
+
+
+class VDIFHeader0(VDIFBaseHeader, VDIFNoSampleRateHeader):
+    """EDV 0: words 4-7 zero (vdif/header.py:580-589)."""
+    _class_edv = 0
+
+
+class VDIFSampleRateHeader(VDIFBaseHeader):
+    """EDVs that carry the sample rate (vdif/header.py:592-692)."""
+
+    @property
+    def frame_rate(self):
+        """Frames per second, from the header's sample rate."""
+        rate = self.sample_rate
+        return None if rate is None else rate / self.samples_per_frame
+
+    @frame_rate.setter
+    def frame_rate(self, frame_rate):
+        self.sample_rate = hz(frame_rate) * self.samples_per_frame
+
+
+class VDIFHeader1(VDIFSampleRateHeader):
+    """EDV 1: NICT (vdif/header.py:695-706)."""
+    _class_edv = 1
+
+
+class VDIFHeader3(VDIFSampleRateHeader):
+    """EDV 3: VLBA (vdif/header.py:709-747)."""
+    _class_edv = 3
+
+
+class VDIFHeader2(VDIFBaseHeader, VDIFNoSampleRateHeader):
+    """EDV 2: ALMA / R2DBE (vdif/header.py:750-782)."""
+    _class_edv = 2
+
+
+class VDIFMark5BHeader(VDIFBaseHeader, VDIFNoSampleRateHeader):
+    """EDV 0xab: a Mark 5B frame wrapped in VDIF (vdif/header.py:785-900)."""
+    _class_edv = 0xab
+
+
+VDIF_HEADER_CLASSES = {-1: VDIFLegacyHeader, 0: VDIFHeader0, 1: VDIFHeader1, 2: VDIFHeader2, 3: VDIFHeader3,
+                       0xab: VDIFMark5BHeader}
+"""EDV -> header class (-1: legacy); ``VDIFHeader(words)`` and ``fromvalues(edv=...)`` return
+instances of these (all are `VDIFHeader`).  Unlike the reference's, the table
+is not extended by subclassing (no metaclass): register a class here."""
 
 
 def frame_header_words(header0, nsets, thread_ids, frame_rate,
