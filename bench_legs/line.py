@@ -113,7 +113,13 @@ def secondary_summary(line):
         v = _get(line, "cold_first_read", k)
         if v is not None:
             sec[k] = v
-    return {k: v for k, v in sec.items() if v is not None}
+    def r3(v):
+        if isinstance(v, float):
+            return round(v, 3)
+        if isinstance(v, list):
+            return [r3(x) for x in v]
+        return v
+    return {k: r3(v) for k, v in sec.items() if v is not None}
 
 
 def compact_line(line, detail=DETAIL_NAME):
@@ -124,8 +130,7 @@ def compact_line(line, detail=DETAIL_NAME):
     c = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                   "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     cfg = line.get("config") or {}
-    c["config"] = {k: cfg[k] for k in ("workload", "frames_per_gpu", "input_memory", "output_memory", "sharding")
-                   if k in cfg}
+    c["config"] = {k: cfg[k] for k in ("workload", "input_memory", "output_memory") if k in cfg}
     rf = line.get("roofline") or {}
     c["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms_avg",
                                             "algorithmic_bytes_per_launch", "traffic")}
@@ -138,7 +143,7 @@ def compact_line(line, detail=DETAIL_NAME):
     cpu = line.get("cpu_baseline")
     if isinstance(cpu, dict):
         c["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind")}
-        c["cpu_baseline"]["sample"] = str(cpu.get("sample_short") or cpu.get("sample") or "")[:120]
+        c["cpu_baseline"]["sample"] = str(cpu.get("sample_short") or cpu.get("sample") or "")[:72]
         c["cpu_baseline"]["all_cores"] = {"value": _get(cpu, "all_cores", "value"),
                                           "cores": _get(cpu, "all_cores", "cores")}
         c["cpu_baseline"]["reference_as_written_estimate"] = _get(cpu, "calibration",
@@ -200,8 +205,11 @@ def finish(line, detail_path=None):
     line["checks_ok"] = ok
     line["checks"] = checks
     where = write_detail(line, detail_path)
-    c = compact_line(line, detail=os.path.basename(where) if where and os.path.dirname(where) == ROOT
-                     else (where or "not written"))
+    # (relative to the repository when it lies inside: the line has 2,000 bytes)
+    shown = where or "not written"
+    if where and os.path.abspath(where).startswith(ROOT + os.sep):
+        shown = os.path.relpath(where, ROOT)
+    c = compact_line(line, detail=shown)
     sys.stderr.flush()
     print(json.dumps(c, separators=(',', ':')), flush=True)
     if not ok:
