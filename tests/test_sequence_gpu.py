@@ -139,3 +139,52 @@ def test_vdif_sequence_writer_matches_reference(gold, tmp_path):
     with vdif.open(template, 'rs') as fr:
         back = fr.read()
     assert bool((back == __import__('torch').cat([data, data])).all())
+
+
+@pytest.mark.parametrize('fmt', ['vdif', 'dada'])
+def test_sequence_writer_fills_several_files_at_once(tmp_path, fmt, monkeypatch):
+    """Round 5: the writers' background sink writes the files of a sequence
+    POSITIONALLY, a thread per file (`SequentialFileWriter.pwrite_stream`,
+    staging._FileSink): same files, byte for byte, as the sequential path
+    (BB_WRITE_ASYNC off), for file sizes that do and do not divide the pieces,
+    frames that straddle files, and writes continued after a flush."""
+    import torch
+    import baseband_amd as bb
+    from baseband_amd import staging
+    from baseband_amd.vdif.header import VDIFHeader
+    g = torch.Generator(device='cuda')
+    g.manual_seed(5)
+
+    def write(sub, asynchronous, file_size):
+        monkeypatch.setattr(staging, '_WRITE_ASYNC', asynchronous)
+        d = tmp_path / sub
+        d.mkdir()
+        g.manual_seed(5)
+        if fmt == 'vdif':
+            h0 = VDIFHeader.fromvalues(edv=0, time=np.datetime64('2014-06-13T05:30:01'), nchan=1, bps=2,
+                                       complex_data=False, thread_id=0, samples_per_frame=32000, station='AA')
+            fw = bb.vdif.open(str(d / 'f{file_nr:03d}.vdif'), 'ws', header0=h0, sample_rate=32e6, nthread=1,
+                              file_size=file_size)
+            chunks = [torch.randn(n * 32000, device='cuda', generator=g) * 2. for n in (700, 1, 2300, 64)]
+        else:
+            from baseband_amd.dada.header import DADAHeader
+            h0 = DADAHeader.fromvalues(time=np.datetime64('2013-07-02T01:39:20'), offset=0., sample_rate=16e6, bps=8,
+                                       complex_data=True, npol=2, nchan=1, payload_nbytes=4 << 20,
+                                       start_time=np.datetime64('2013-07-02T01:39:20'), telescope='GMRT')
+            fw = bb.dada.open(str(d / '{utc_start}_{obs_offset:016d}.{file_nr:06d}.dada'), 'ws', header0=h0)
+            spf = h0.samples_per_frame
+            chunks = [(torch.randn(n, 2, 2, device='cuda', generator=g) * 20.) for n in (3 * spf, spf // 2, spf // 2, 5 * spf)]
+            chunks = [torch.view_as_complex(c.contiguous()) for c in chunks]
+        with fw:
+            for k, c in enumerate(chunks):
+                fw.write(c)
+                if k == 1:
+                    fw.flush()
+        return {n: hashlib.sha256(open(d / n, 'rb').read()).hexdigest() for n in sorted(os.listdir(d))}
+
+    sizes = [8032 * 400, 8032 * 1000 + 4000, 50_000_000] if fmt == 'vdif' else [None]
+    for fs in sizes:
+        tag = str(fs)
+        want = write('seq_' + tag, False, fs)
+        got = write('par_' + tag, True, fs)
+        assert len(want) >= 3 and got == want, (fs, sorted(want), sorted(got))

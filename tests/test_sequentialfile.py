@@ -236,3 +236,43 @@ def test_sequence_image_header_words(tmp_path, cuts):
     short = sf.SequenceImage(names[:2])
     want = strided_header_words(ref[:edges[2]], 5032, 8)
     assert np.array_equal(strided_header_words(short, 5032, 8), want)
+
+
+def test_positional_writes_equal_sequential_writes(tmp_path):
+    """`SequentialFileWriter.pwrite_stream` + `sync_position` (what the stream
+    writers' background sink uses to fill several files at once): same files as
+    ``write()``, from several threads, mixed with ordinary writes before and after."""
+    import threading
+    from baseband_amd.helpers import sequentialfile as sf
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 256, 10_000, dtype=np.uint8).tobytes()
+    a = sf.open(sf.FileNameSequencer(str(tmp_path / 'a{file_nr:02d}.bin')), 'w+b', file_size=3000)
+    a.write(data[:1000]), a.write(data[1000:7500]), a.write(data[7500:])
+    assert a.tell() == 10000
+    a.close()
+    b = sf.open(sf.FileNameSequencer(str(tmp_path / 'b{file_nr:02d}.bin')), 'w+b', file_size=3000)
+    assert b.can_pwrite
+    b.write(data[:1000])
+    ths = [threading.Thread(target=b.pwrite_stream, args=(data[lo:min(7500, lo + 1300)], lo)) for lo in range(1000, 7500, 1300)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert b.tell() == 1000                     # positional writes do not move the writer
+    b.sync_position(7500)
+    assert b.tell() == 7500 and b.file_nr == 2
+    b.write(data[7500:])
+    assert b.tell() == 10000
+    b.close()
+    for k in range(4):
+        assert (tmp_path / ('a%02d.bin' % k)).read_bytes() == (tmp_path / ('b%02d.bin' % k)).read_bytes(), k
+    # an exact multiple of the file size: the last file stays the current one, no empty file follows
+    c = sf.open(sf.FileNameSequencer(str(tmp_path / 'c{file_nr:02d}.bin')), 'w+b', file_size=2500)
+    c.pwrite_stream(data, 0)
+    c.sync_position(10000)
+    assert c.tell() == 10000 and c.file_nr == 3
+    c.close()
+    assert [os.path.getsize(tmp_path / ('c%02d.bin' % k)) for k in range(4)] == [2500] * 4
+    assert not (tmp_path / 'c04.bin').exists()
+    # no fixed file size, or handles instead of names: no positional writes
+    d = sf.open([str(tmp_path / 'd0.bin'), str(tmp_path / 'd1.bin')], 'w+b')
+    assert not d.can_pwrite
+    d.close()
