@@ -45,6 +45,9 @@ def collect_checks(line):
                     "index_equals_broadcast")
     if "pipeline" in line and not (isinstance(line["pipeline"], dict) and "skipped" in line["pipeline"]):
         put("pipeline.all_match", line, "pipeline", "all_match")
+        sw = _get(line, "pipeline", "sequence_writer")
+        if isinstance(sw, dict):
+            put("pipeline.sequence_writer.read_back_matches", line, "pipeline", "sequence_writer", "read_back_matches")
     if "cold_first_read" in line:
         put("cold_first_read.all_ok", line, "cold_first_read", "all_ok")
     ap = _get(line, "roofline", "arena_placed_output")
@@ -105,6 +108,9 @@ def secondary_summary(line):
         if w:
             sec["writer_GBps"] = [min(w), max(w)]
         sec["pinned_h2d_GBps"] = _get(line, "pipeline", "pinned_h2d_GBps")
+    v = _get(line, "pipeline", "sequence_writer", "writer_GBps")
+    if v is not None:
+        sec["writer_sequence_GBps"] = v
     ms = _get(line, "mid_size", "sizes")
     if ms and isinstance(ms[0], dict):
         sec["mid_2p15_arena_min"] = _get(ms[0], "arena", "frac_min")

@@ -203,6 +203,34 @@ def leg_pipeline(device, gib=2.0, reads=3):
         case("DADA 8-bit 2 pol complex, 128 MiB frames", path,
              lambda: write(lambda: bb.dada.open(path, 'ws', header0=hd), chunk, nbytes // (128 << 20)),
              dict(), bb.dada.open)
+        # the same stream into a SEQUENCE of files, one frame each (the format's default for
+        # templates): the writer's sink fills several files at a time (staging._FileSink)
+        try:
+            seq = os.path.join(tmp, 'seq')
+            os.mkdir(seq)
+            tmpl = os.path.join(seq, '{utc_start}_{obs_offset:016d}.{file_nr:06d}.dada')
+            best = None
+            for _ in range(2):
+                for n in os.listdir(seq):
+                    os.remove(os.path.join(seq, n))
+                torch.cuda.synchronize()
+                tw = time.perf_counter()
+                write(lambda: bb.dada.open(tmpl, 'ws', header0=hd), chunk, nbytes // (128 << 20))
+                dt = time.perf_counter() - tw
+                best = dt if best is None else min(best, dt)
+            names = sorted(os.listdir(seq))
+            size = sum(os.path.getsize(os.path.join(seq, n)) for n in names)
+            with bb.dada.open(tmpl, 'rs') as fh:            # read back through the template: same samples as the single file
+                fh.seek(fh.shape[0] - 4096)
+                tail = fh.read(4096)
+            exp = torch.clamp(torch.round(torch.view_as_real(chunk[-4096:])), -128, 127)
+            res["sequence_writer"] = {
+                "case": "DADA 8-bit 2 pol complex, one 128 MiB frame per file ({} files)".format(len(names)),
+                "file_bytes": size, "write_s_best": round(best, 3), "writer_GBps": round(size / best / 1e9, 2),
+                "threads": staging._FileSink._NWORKER,
+                "read_back_matches": bool(torch.equal(torch.view_as_real(tail.reshape(-1, 2)).reshape(exp.shape), exp))}
+        except Exception as exc:
+            res["sequence_writer"] = {"error": repr(exc)[:300]}
         del chunk
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
