@@ -27,9 +27,19 @@ for s in srcs:
             texts[s] = f.read()
     except OSError:
         pass
+import fnmatch
+# citations with wildcards (`r04d_exp_glds3_box*.log`, `r05b/c_grow_probe*.log`, `r05k_*`)
+patterns = {}
+for src, t in texts.items():
+    for tok in set(re.findall(r'r\d\d[A-Za-z0-9_./*-]*\*[A-Za-z0-9_.*-]*', t)):
+        if len(tok.split('*')[0]) >= 5:                 # (`r03*` in a sentence about a whole round is not a citation)
+            patterns.setdefault(tok.rstrip('.'), set()).add(src)
 for f in files:
     stem = f.rsplit('.', 1)[0]
     who = [s for s, t in texts.items() if f in t or (stem + '*') in t or (stem.rsplit('_', 1)[0] + '*') in t]
+    for pat, srcs in patterns.items():
+        if fnmatch.fnmatch(f, pat) or fnmatch.fnmatch(f, pat + '*'):
+            who.extend(srcs)
     cited[f] = sorted(set(who))
 
 
