@@ -152,30 +152,52 @@ def test_kept_windows_have_a_stated_byte_cap():
 
 
 def test_write_device_bytes_to_files_and_streams(tmp_path, monkeypatch):
-    """staging.write_device_bytes: device bytes -> file at its current position;
-    large writes go out in chunks (copy of the next against write of this one),
-    small ones in one piece -- same bytes, same file position."""
+    """staging.write_device_bytes: device bytes -> file at its current position,
+    through the handle's background sink (round 5: pieces travel to pinned
+    buffers on a side stream, a thread writes them in order; `finish_writes`
+    waits; host bytes queued with `write_host_bytes` keep their place) or, with
+    BB_WRITE_ASYNC off, before the call returns -- same bytes, same file position."""
     import io
     import torch
     from baseband_amd import staging
     g = torch.Generator(device='cuda').manual_seed(5)
-    for n in (0, 1000, (32 << 20) + 12345, (72 << 20) + 1):
-        dev = torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda', generator=g)
-        want = dev.cpu().numpy().tobytes()
-        path = tmp_path / 'w{}.bin'.format(n)
-        with open(path, 'w+b') as fh:
-            fh.write(b'head')
-            staging.write_device_bytes(fh, dev)
-            assert fh.tell() == 4 + n
-            fh.write(b'tail')
-        assert path.read_bytes() == b'head' + want + b'tail'
-        bio = io.BytesIO()
-        bio.write(b'head')
-        staging.write_device_bytes(bio, dev)
-        assert bio.getvalue() == b'head' + want
-        # a strided view is written in its logical order
-        if n >= 1000:
-            v = dev[:n // 2 * 2].reshape(-1, 2)[:, 0]
+    for asynchronous in (True, False):
+        monkeypatch.setattr(staging, '_WRITE_ASYNC', asynchronous)
+        for n in (0, 1000, (32 << 20) + 12345, (72 << 20) + 1):
+            dev = torch.randint(0, 256, (n,), dtype=torch.uint8, device='cuda', generator=g)
+            want = dev.cpu().numpy().tobytes()
+            path = tmp_path / 'w{}_{}.bin'.format(n, asynchronous)
+            with open(path, 'w+b') as fh:
+                fh.write(b'head')
+                staging.write_device_bytes(fh, dev)
+                staging.write_host_bytes(fh, b'mid')            # in order behind the queued pieces
+                staging.write_device_bytes(fh, dev[:777])
+                if not asynchronous:
+                    assert fh.tell() == 4 + n + 3 + min(n, 777)
+                staging.finish_writes(fh)
+                assert fh.tell() == 4 + n + 3 + min(n, 777)
+                fh.write(b'tail')
+            assert path.read_bytes() == b'head' + want + b'mid' + want[:777] + b'tail'
             bio = io.BytesIO()
-            staging.write_device_bytes(bio, v)
-            assert bio.getvalue() == v.contiguous().cpu().numpy().tobytes()
+            bio.write(b'head')
+            staging.write_device_bytes(bio, dev)
+            staging.finish_writes(bio)
+            assert bio.getvalue() == b'head' + want
+            # a strided view is written in its logical order
+            if n >= 1000:
+                v = dev[:n // 2 * 2].reshape(-1, 2)[:, 0]
+                bio = io.BytesIO()
+                staging.write_device_bytes(bio, v)
+                staging.finish_writes(bio)
+                assert bio.getvalue() == v.contiguous().cpu().numpy().tobytes()
+    # an error of the file comes back from the sink at the next call
+    monkeypatch.setattr(staging, '_WRITE_ASYNC', True)
+
+    class Full:
+        def write(self, data):
+            raise OSError(28, 'No space left on device')
+
+    full = Full()
+    staging.write_device_bytes(full, torch.zeros(1000, dtype=torch.uint8, device='cuda'))
+    with pytest.raises(OSError):
+        staging.finish_writes(full)
