@@ -208,7 +208,7 @@ def leg_pipeline(device, gib=2.0, reads=3):
         try:
             seq = os.path.join(tmp, 'seq')
             os.mkdir(seq)
-            tmpl = os.path.join(seq, 'obs_{obs_offset:016d}.{file_nr:06d}.dada')
+            tmpl = os.path.join(seq, 'obs.{file_nr:06d}.dada')
             best = None
             for _ in range(2):
                 for n in os.listdir(seq):
