@@ -135,6 +135,15 @@ def leg_cold_first_read(gib=2.0, timeout=240):
     """Run the children (the caller has NOT touched the GPU yet).  Returns the
     leg's dict; a child that fails is reported in its slot."""
     tmp_root = os.environ.get('TMPDIR', '/tmp')
+    try:
+        import shutil
+        free_b = shutil.disk_usage(tmp_root).free
+    except OSError:
+        free_b = 0
+    if free_b < int(gib * 2 ** 30) + (1 << 30):
+        # (an environment matter, not a result: the leg is skipped and counts for no check)
+        return {"skipped": "{} has {:.1f} GiB free, a {:.1f} GiB temporary file does not fit".format(
+            tmp_root, free_b / 2 ** 30, gib)}
     res = {"what": "fresh child process: first open(2 GiB cfg2 file).read() against the same call again "
                    "(wall ms incl. sync; page cache warm; the library's kernels loaded by a small read before)",
            "runs": []}

@@ -48,7 +48,7 @@ def collect_checks(line):
         sw = _get(line, "pipeline", "sequence_writer")
         if isinstance(sw, dict):
             put("pipeline.sequence_writer.read_back_matches", line, "pipeline", "sequence_writer", "read_back_matches")
-    if "cold_first_read" in line:
+    if "cold_first_read" in line and not (isinstance(line["cold_first_read"], dict) and "skipped" in line["cold_first_read"]):
         put("cold_first_read.all_ok", line, "cold_first_read", "all_ok")
     ap = _get(line, "roofline", "arena_placed_output")
     if isinstance(ap, dict) and "skipped" not in ap:
