@@ -7,6 +7,7 @@ cache into a pinned buffer while the DMA engine moves window k on a side
 stream (hipMemcpyAsync) and the compute stream scans/decodes window k-1.
 Ordering is by events only; nothing blocks the device.
 """
+import atexit
 import ctypes
 import mmap
 import os
@@ -634,6 +635,22 @@ class _FileSink:
 _sinks = {}                 # id(file handle) -> _FileSink
 _sinks_lock = threading.Lock()
 _WRITE_ASYNC = os.environ.get('BB_WRITE_ASYNC', '1') not in ('0', 'no', 'off')
+
+
+def _drain_all_sinks():
+    """At interpreter exit: what writers that were never closed have queued still
+    reaches their files (the sinks' threads are daemons and would die with it)."""
+    with _sinks_lock:
+        sinks = list(_sinks.values())
+        _sinks.clear()
+    for s_ in sinks:
+        try:
+            s_.close()
+        except BaseException:
+            pass
+
+
+atexit.register(_drain_all_sinks)
 
 
 def _sink_for(fh, create=True):
