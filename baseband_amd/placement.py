@@ -83,11 +83,22 @@ _idle_watcher = None             # the daemon thread waiting for that deadline
 _idle_lock = threading.Lock()
 
 
+_idle_trims = 0                  # idle trims that released memory so far (each doubles the next delay)
+
+
 def _idle_seconds():
+    """Seconds of "nothing alive" after which the arenas trim: BB_ARENA_IDLE_S
+    (default 30), DOUBLED by every idle trim that released memory, up to an
+    hour.  Every trim + regrow burns a step's worth of virtual addresses, which
+    are never reused (csrc/bb_arena.inc: about 2,700 steps of 48 GiB per
+    process): a service whose bursts lie a minute apart would use them up in
+    two days at a fixed 30 s; with the doubling it soon keeps its memory between
+    bursts and trims once an hour of idleness at most (112 days of that)."""
     try:
-        return float(os.environ.get('BB_ARENA_IDLE_S', '30'))
+        base = float(os.environ.get('BB_ARENA_IDLE_S', '30'))
     except ValueError:
-        return 30.0
+        base = 30.0
+    return min(base * 2 ** min(_idle_trims, 12), max(base, 3600.0))
 
 
 def _nothing_alive():
@@ -100,6 +111,7 @@ def _trim_idle():
         return 0
     if sys.is_finalizing():         # (the watcher thread must not be inside hipMemUnmap while the interpreter goes)
         return 0
+    global _idle_trims
     freed = 0
     for a in _arena.all_arenas():
         try:
@@ -108,6 +120,8 @@ def _trim_idle():
                     freed += a.trim()
         except Exception:
             pass
+    if freed:
+        _idle_trims += 1
     return freed
 
 

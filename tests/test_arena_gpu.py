@@ -735,6 +735,7 @@ def test_idle_arena_trims_after_the_delay_and_not_between_reads(monkeypatch):
     monkeypatch.setenv('BB_ARENA', '1')
     monkeypatch.setenv('BB_ARENA_IDLE_S', '1.0')
     monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
+    monkeypatch.setattr(placement, '_idle_trims', 0)         # (every idle trim doubles the next delay)
     arena.disable()
     try:
         monkeypatch.setattr(placement, 'ARENA_MIN_BYTES', 1 << 20)
@@ -756,5 +757,14 @@ def test_idle_arena_trims_after_the_delay_and_not_between_reads(monkeypatch):
         assert ar.stats()['bytes_backed'] == backed          # not at once ...
         time.sleep(2.0)
         assert ar.stats()['bytes_backed'] == 0               # ... but after the delay
+        # the next idle trim waits twice as long: trim + regrow burns addresses (placement._idle_seconds)
+        assert placement._idle_trims == 1 and placement._idle_seconds() == 2.0
+        t = baseband_amd.empty_output((1 << 22,))
+        del t
+        gc.collect()
+        time.sleep(1.4)
+        assert ar.stats()['bytes_backed'] == backed          # 1.0 s would have trimmed by now
+        time.sleep(1.6)
+        assert ar.stats()['bytes_backed'] == 0 and placement._idle_trims == 2
     finally:
         arena.disable()

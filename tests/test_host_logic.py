@@ -1037,6 +1037,7 @@ def test_idle_trim_policy_without_a_device(monkeypatch):
     monkeypatch.setattr(arena, 'all_arenas', lambda: [fake])
     monkeypatch.setattr(torch.cuda, 'device', lambda d: __import__('contextlib').nullcontext())
     monkeypatch.setattr(placement, '_open_readers', 0)
+    monkeypatch.setattr(placement, '_idle_trims', 0)
     monkeypatch.delenv('BB_ARENA_KEEP', raising=False)
     # at once
     monkeypatch.setenv('BB_ARENA_IDLE_S', '0')
