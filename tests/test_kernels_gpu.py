@@ -802,9 +802,13 @@ def test_gather_staging_forms_agree(bps, chunk, nslot, pn):
                 assert 'k_decode_gather' in _lib.last_kernel(), _lib.last_kernel()
                 assert bits_equal(out, exp.reshape(-1)), (form, blocks)
                 if keep is not None and (chunk & (chunk - 1)) == 0 and kernels.select_supported(bps, chunk, nslot, keep.size, pn):
-                    sel = kernels.decode_frames(dbuf, nframes, pn, 0, bps, chunk=chunk, nslot=nslot, src=dsrc,
-                                                complex_data=cplx, fill_value=2.5,
-                                                within=torch.from_numpy(keep).cuda()).cpu().numpy()
+                    kernels.tune(_lib.TUNE_SELECT_PICK, 0)             # (this test is about the gather kernels' staging forms)
+                    try:
+                        sel = kernels.decode_frames(dbuf, nframes, pn, 0, bps, chunk=chunk, nslot=nslot, src=dsrc,
+                                                    complex_data=cplx, fill_value=2.5,
+                                                    within=torch.from_numpy(keep).cuda()).cpu().numpy()
+                    finally:
+                        kernels.tune(_lib.TUNE_SELECT_PICK, 1)
                     assert 'k_decode_gather_select' in _lib.last_kernel()
                     assert bits_equal(sel, np.ascontiguousarray(exp[:, :, :, keep]).reshape(-1)), (form, blocks)
     finally:

@@ -451,7 +451,8 @@ def test_channel_subset_is_folded_into_the_decode(manifest, squeeze, subset, fol
         assert fh.sample_shape == want.shape[1:]
         got = fh.read()
         if folded:
-            assert 'k_decode_gather_select' in _lib.last_kernel()
+            # (k_decode_pick for selections of up to an eighth of a thread sample, k_decode_gather_select beyond)
+            assert 'k_decode_gather_select' in _lib.last_kernel() or 'k_decode_pick' in _lib.last_kernel()
         assert bits_equal(got.cpu().numpy(), np.ascontiguousarray(want))
         fh.seek(995)
         assert bits_equal(fh.read(1010).cpu().numpy(), np.ascontiguousarray(want[995:2005]))
