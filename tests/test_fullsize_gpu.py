@@ -153,6 +153,26 @@ def test_cfg2_multithread_large():
             want_t = orc.decode_flat(raw, 'vdif', 2).reshape(1000, 32)
             got_t = o[fset, :, t].cpu().numpy()
             assert np.array_equal(got_t.view(np.uint32), want_t.view(np.uint32)), (fset, t)
+    # a reader's subset of 2 of the 16 channels folded into the decode (k_decode_pick, round 5)
+    # equals the full decode indexed afterwards -- every sample of the 4 GiB, compared on the device
+    keep = torch.tensor([6, 7, 24, 25], dtype=torch.int32, device=dev)           # channels 3 and 12 (re, im)
+    part = kernels.decode_frames(image, nsets, pn, _lib.CODER_VDIF, 2, chunk=32, nslot=nth, src=src,
+                                 complex_data=True, within=keep)
+    assert 'k_decode_pick' in _lib.last_kernel(), _lib.last_kernel()
+    p4 = part.view(nsets, 1000, nth, 4)
+    step = 1 << 12
+    for lo in range(0, nsets, step):
+        assert torch.equal(p4[lo:lo + step].view(torch.int32), o[lo:lo + step][..., keep.long()].view(torch.int32)), lo
+    # ... and with one thread missing in every 1000th frame set, through the fill path
+    src2 = src.clone()
+    src2.view(nsets, nth)[::1000, 5] = -1
+    part = kernels.decode_frames(image, nsets, pn, _lib.CODER_VDIF, 2, chunk=32, nslot=nth, src=src2,
+                                 complex_data=True, within=keep, fill_value=-3. + 2.j)
+    p4 = part.view(nsets, 1000, nth, 4)
+    fillrow = torch.tensor([-3., 2., -3., 2.], device=dev)
+    assert bool((p4[::1000, :, 5] == fillrow).all())
+    assert torch.equal(p4[1::1000].view(torch.int32), o[1::1000][..., keep.long()].view(torch.int32))
+    assert torch.equal(p4[::1000, :, :5].view(torch.int32), o[::1000, :, :5][..., keep.long()].view(torch.int32))
 
 
 def _random_bytes(nbytes, seed, dev):
