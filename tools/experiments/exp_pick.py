@@ -58,3 +58,24 @@ run([6, 7, 24, 25], "2 of 16 complex channels (bench row)")
 run([6, 7], "1 of 16 complex channels")
 run([0, 1, 6, 7, 24, 25, 30, 31], "4 of 16 complex channels")
 run(list(range(16)), "8 of 16 complex channels")
+
+# the whole thread sample kept (32 of 32 = the cfg3 decode itself): k_decode_pick against k_decode_gather
+w = torch.arange(32, dtype=torch.int32, device=dev)
+n = nsets * spf * nth * 32
+out = baseband_amd.empty_output((n,), dtype=torch.float32, device=dev) if n * 4 <= (64 << 30) else torch.empty(n, dtype=torch.float32, device=dev)
+moved = nsets * nth * fn_ + n * 4
+rows = []
+fn = lambda: kernels.decode_frames(buf, nsets, pn, _lib.CODER_VDIF, 2, chunk=2 * nch, nslot=nth, src=src, complex_data=True, out=out)
+med, _ = bench.timed_launches(fn, 7)
+ref = out[::257].clone()
+rows.append(("k_decode_gather (product)", med, _lib.last_kernel(), True))
+for pb in (8192, 16384, 32768):
+    kernels.tune(_lib.TUNE_SELECT_PICK, 2)
+    kernels.tune(_lib.TUNE_PICK_BYTES, pb)
+    fn = lambda: kernels.decode_frames(buf, nsets, pn, _lib.CODER_VDIF, 2, chunk=2 * nch, nslot=nth, src=src, complex_data=True, out=out, within=w)
+    med, _ = bench.timed_launches(fn, 7)
+    rows.append(("pick %d KiB" % (pb >> 10), med, _lib.last_kernel(), bool(torch.equal(ref.view(torch.int32), out[::257].view(torch.int32)))))
+kernels.tune(_lib.TUNE_SELECT_PICK, 1); kernels.tune(_lib.TUNE_PICK_BYTES, 4096)
+print("## all 16 channels (the cfg3 decode; bytes moved {:.2f} GB)".format(moved / 1e9))
+for name, med, k, same in rows:
+    print("  {:26s} {:7.3f} ms  {:7.1f} GB/s  {:.4f} of 8 TB/s  identical {}   {}".format(name, med, moved / med / 1e6, moved / med / 1e6 / 8000, same, k))
