@@ -132,24 +132,29 @@ def _vdif_params(frame_nbytes, header_nbytes, pattern, mask, ref_seconds,
     return p
 
 
+_NSCRATCH = 4       # sets of window scratch taking turns when the scan runs on a side stream
+
+
 class _FrameWindow:
     """Scratch handling shared by the window calls: the scan records and the
     index of a window.  With the scan on a SIDE stream (`scan_stream`: the
     verdict of request k + 1 does not queue behind the decode of request k on
-    the caller's stream, include/bbdecode.h) there are TWO sets taking turns:
-    the decode of request k still reads set A while the scan of request k + 1
-    fills set B, and before a set is filled again the side stream waits for the
-    event recorded behind the decode that used it last."""
+    the caller's stream, include/bbdecode.h) there are `_NSCRATCH` = 4 sets
+    taking turns: the decode of request k still reads one set while the scans
+    of the next requests fill the others -- a caller can queue a burst of three
+    more reads before the host is paced by the GPU -- and before a set is filled
+    again the side stream waits for the event recorded behind the decode that
+    used it last (16 bytes per frame and 8 per index entry each)."""
     __slots__ = ('recs', 'src', 'fill_value', '_sets', '_turn')
 
     def _scratch(self, nframes, n, dev, scan_stream=None):
         sets = getattr(self, '_sets', None)
         if sets is None:
-            sets = self._sets = [[None, None, None], [None, None, None]]
+            sets = self._sets = [[None, None, None] for _ in range(_NSCRATCH)]
             self._turn = 0
         k = 0
         if scan_stream is not None:
-            self._turn ^= 1
+            self._turn = (self._turn + 1) % _NSCRATCH
             k = self._turn
         st = sets[k]
         if st[0] is None or st[0].shape[0] < nframes or st[0].device != dev:

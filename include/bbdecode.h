@@ -325,8 +325,8 @@ int bb_decode_frames_select_check(const bb_decode_params *params, int nwithin);
  * still running on `stream` (back-to-back reads of 2^15 frames: the host waits
  * 0.1 instead of 0.7 ms per read).  The CALLER orders the rest: the input must
  * be complete as far as `scan_stream` can tell, and d_recs / d_src must not be
- * in use by a decode still running on `stream` (two sets of scratch, taking
- * turns, and a wait for the decode two requests back:
+ * in use by a decode still running on `stream` (a few sets of scratch, taking
+ * turns, and a wait for the decode that read a set last:
  * baseband_amd/kernels.py).  d_recs (nframes records) and d_src
  * (nsets * dec->nslot entries) are scratch the caller provides.
  */
