@@ -212,7 +212,7 @@ def test_reads_back_to_back_without_host_syncs(monkeypatch):
 def test_scan_on_a_side_stream_gives_the_same_reads(monkeypatch, nthread):
     """Round 5: for requests on bytes that are in HBM already the scan / index /
     verification launches go to a side stream (kernels._FrameWindow,
-    bb_vdif_read_window's `scan_stream`), two sets of scratch taking turns, so
+    bb_vdif_read_window's `scan_stream`), four sets of scratch taking turns, so
     that read() k + 1 gets its verdict while decode k still runs.  Same samples
     as with BB_SIDE_SCAN off -- back to back without host syncs, requests of
     different sizes (below the threshold too), results dropped at once -- and a
