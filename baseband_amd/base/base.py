@@ -866,6 +866,12 @@ class GPUStreamReaderBase:
     _scan_stream = None
     _scan_ready_for = None
 
+    def _prepare_window_state(self, device):
+        """Device state a window call needs besides its scratch (the verdict
+        counter; VDIF: the thread-slot map): made here, ahead of the call."""
+        if self.verify:
+            self._verdict_targets()
+
     def _scan_stream_for(self, resident):
         """The side stream the scan / index / verification launches of requests
         on `resident` go to (kernels._FrameWindow): their verdict -- all that
@@ -887,13 +893,18 @@ class GPUStreamReaderBase:
                     st = _scan_streams[dev.index] = torch.cuda.Stream(
                         device=dev, priority=int(os.environ.get('BB_SIDE_SCAN_PRIORITY', '-1')))
             self._scan_stream = st
-        key = (resident.data_ptr(), resident.numel())
+        key = (resident.data_ptr(), resident.numel(), None if self._nbad is None else self._nbad.data_ptr(),
+               self._side_state_key())
         if self._scan_ready_for != key:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             self._scan_stream.wait_event(ev)
             self._scan_ready_for = key
         return self._scan_stream
+
+    def _side_state_key(self):
+        """Identity of further device state the side stream reads (subclasses)."""
+        return None
 
     def _zero_nbad(self):
         if self._nbad is not None:
@@ -981,6 +992,10 @@ class GPUStreamReaderBase:
             # place: the scan of this request need not queue behind the decode of the one before)
             if (self.verify and _SIDE_SCAN and nsets * set_nbytes >= (16 << 20)
                     and win.data_ptr() == resident.data_ptr() + lo):
+                # (what the side stream's launches read or add to must exist -- and be
+                # initialised on the caller's stream -- BEFORE the side stream's first
+                # wait for that stream: `_scan_stream_for`)
+                self._prepare_window_state(win.device)
                 self._scan_side = self._scan_stream_for(resident)
             try:
                 self._process_window(win, first, last, flat)

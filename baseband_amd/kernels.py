@@ -135,6 +135,10 @@ def _vdif_params(frame_nbytes, header_nbytes, pattern, mask, ref_seconds,
 _NSCRATCH = 4       # sets of window scratch taking turns when the scan runs on a side stream
 
 
+def _pow2(n):
+    return 1 << max(0, int(n) - 1).bit_length()
+
+
 class _FrameWindow:
     """Scratch handling shared by the window calls: the scan records and the
     index of a window.  With the scan on a SIDE stream (`scan_stream`: the
@@ -145,7 +149,7 @@ class _FrameWindow:
     more reads before the host is paced by the GPU -- and before a set is filled
     again the side stream waits for the event recorded behind the decode that
     used it last (16 bytes per frame and 8 per index entry each)."""
-    __slots__ = ('recs', 'src', 'fill_value', '_sets', '_turn')
+    __slots__ = ('recs', 'src', 'fill_value', '_sets', '_turn', '_rotating')
 
     def _scratch(self, nframes, n, dev, scan_stream=None):
         sets = getattr(self, '_sets', None)
@@ -157,19 +161,34 @@ class _FrameWindow:
             self._turn = (self._turn + 1) % _NSCRATCH
             k = self._turn
         st = sets[k]
+        fresh = False
         if st[0] is None or st[0].shape[0] < nframes or st[0].device != dev:
-            st[0] = torch.empty((max(nframes, 64), 4), dtype=torch.int32, device=dev)
+            # (with headroom: a set is re-made when a request outgrows it, and a new one costs a stream wait)
+            st[0] = torch.empty((max(_pow2(nframes), 64), 4), dtype=torch.int32, device=dev)
+            fresh = True
         if st[1] is None or st[1].numel() < n or st[1].device != dev:
-            st[1] = torch.empty(max(n, 64), dtype=torch.int64, device=dev)
+            st[1] = torch.empty(max(_pow2(n), 64), dtype=torch.int64, device=dev)
+            fresh = True
         self.recs, self.src = st[0], st[1]
-        if scan_stream is not None and st[2] is not None:
-            scan_stream.wait_event(st[2])           # the decode that read this set last
+        if scan_stream is not None:
+            if fresh:
+                # torch's allocator hands out memory whose last user may still have work
+                # queued on the CALLER's stream -- safe there, not on another stream: the
+                # side stream waits for that point once per (re)allocation
+                # (tools/stress_side_scan.py found a scan overwritten by such work)
+                scan_stream.wait_stream(torch.cuda.current_stream(dev))
+            elif st[2] is not None:
+                scan_stream.wait_event(st[2])       # the decode that read this set last
         return st
 
-    @staticmethod
-    def _decode_queued(st, scan_stream, dev):
-        """Behind a window call: remember where the decode that reads set `st` stands."""
-        if scan_stream is not None:
+    def _decode_queued(self, st, scan_stream, dev):
+        """Behind a window call: remember where the decode that reads set `st`
+        stands -- also for a call that did NOT use the side stream, once the
+        sets rotate (a small read between large ones uses set 0 on the caller's
+        stream; a later side-stream scan must not refill that set under its
+        decode: found by tools/stress_side_scan.py)."""
+        if scan_stream is not None or getattr(self, '_rotating', False):
+            self._rotating = True
             if st[2] is None:
                 st[2] = torch.cuda.Event()
             st[2].record(torch.cuda.current_stream(dev))

@@ -207,6 +207,9 @@ class Mark5BStreamReader(GPUStreamReaderBase):
 
     _window = None          # kernels.Mark5BWindow: argument blocks of the one-call window
 
+    def _side_state_key(self):
+        return None if self._within is None else self._within.data_ptr()
+
     def _process_window(self, dbuf, first, last, out_flat):
         """scan -> index -> verification -> decode of frames [first, last): one
         library call (bb_mark5b_read_window)."""

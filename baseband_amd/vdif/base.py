@@ -372,6 +372,15 @@ class VDIFStreamReader(GPUStreamReaderBase):
 
     _window = None          # kernels.VDIFWindow: argument blocks of the fused window call
 
+    def _prepare_window_state(self, device):
+        super()._prepare_window_state(device)
+        if self._thread_slot is None:
+            self._thread_slot = kernels.thread_slot_map(self._thread_ids, device)
+
+    def _side_state_key(self):
+        ts, w = self._thread_slot, self._within
+        return (None if ts is None else ts.data_ptr(), None if w is None else w.data_ptr())
+
     def _process_window(self, dbuf, first_set, last_set, out_flat):
         """scan -> index -> verification -> decode for frame sets [first_set,
         last_set): one library call (bb_vdif_read_window)."""
