@@ -310,3 +310,44 @@ def test_side_stream_scan_for_the_single_thread_formats(monkeypatch, fmt):
     assert used
     for (a, b), (c, d) in zip(on, off):
         assert a == c and torch.equal(b.view(torch.int32), d.view(torch.int32))
+
+
+def test_side_stream_scan_soak(monkeypatch):
+    """400 reads of random sizes and places from a resident image on two readers
+    taking turns, no host syncs, results reduced and dropped at once (temporaries
+    come and go in torch's allocator between the reads): every read equals the
+    direct decode.  tools/stress_side_scan.py (1,500 reads) found what this
+    guards against: scratch newly taken from torch's allocator was filled on the
+    side stream while work of its previous user was still queued on the caller's."""
+    import torch
+    from baseband_amd import synth, vdif, kernels, _lib
+    from baseband_amd.base import base as bbase
+    monkeypatch.setattr(bbase, '_SIDE_SCAN', True)
+    nframes = 36000
+    image, h0 = synth.random_vdif(21, nframes, payload_nbytes=8000, frame_rate=1000)
+    dev = torch.from_numpy(image.copy()).cuda()
+    rng = np.random.default_rng(2)
+    plan = []
+    for k in range(400):
+        n = int(rng.integers(200, 5000)) if k % 3 else int(rng.integers(2100, 9000))
+        plan.append((int(rng.integers(0, nframes - n)), n, int(rng.integers(0, 2))))
+    sums = torch.zeros(len(plan), dtype=torch.float64, device='cuda')
+    fhs = [vdif.open(dev, 'rs', sample_rate=32e6) for _ in range(2)]
+    try:
+        for k, (f0, n, which) in enumerate(plan):
+            fhs[which].seek(f0 * 32000)
+            got = fhs[which].read(n * 32000)
+            sums[k] = got.double().sum()
+            del got
+        torch.cuda.synchronize()
+        assert all(fh._scan_stream is not None for fh in fhs)
+    finally:
+        for fh in fhs:
+            fh.close()
+    want = np.zeros(len(plan))
+    for k, (f0, n, which) in enumerate(plan):
+        ref = kernels.decode_frames(dev, n, 8000, _lib.CODER_VDIF, 2, src0=32 + f0 * 8032, src_stride=8032)
+        want[k] = float(ref.double().sum())
+        del ref
+    bad = np.nonzero(sums.cpu().numpy() != want)[0]
+    assert len(bad) == 0, [(int(k), plan[k]) for k in bad[:5]]
