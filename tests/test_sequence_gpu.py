@@ -188,3 +188,32 @@ def test_sequence_writer_fills_several_files_at_once(tmp_path, fmt, monkeypatch)
         want = write('seq_' + tag, False, fs)
         got = write('par_' + tag, True, fs)
         assert len(want) >= 3 and got == want, (fs, sorted(want), sorted(got))
+
+
+def test_background_sink_writes_the_same_single_file(tmp_path, monkeypatch):
+    """One file, 330 MB, written in calls of very different sizes with temporaries
+    coming and going in between: the background sink (pieces in flight across
+    write() calls) gives the file the synchronous path gives."""
+    import torch
+    import baseband_amd as bb
+    from baseband_amd import staging
+    from baseband_amd.vdif.header import VDIFHeader
+    h0 = VDIFHeader.fromvalues(edv=0, time=np.datetime64('2014-06-13T05:30:01'), nchan=1, bps=2,
+                               complex_data=False, thread_id=0, samples_per_frame=32000, station='AA')
+    g = torch.Generator(device='cuda')
+
+    def write(name, asynchronous):
+        monkeypatch.setattr(staging, '_WRITE_ASYNC', asynchronous)
+        g.manual_seed(11)
+        path = tmp_path / name
+        with bb.vdif.open(str(path), 'ws', header0=h0, sample_rate=32e6, nthread=1) as fw:
+            for n in (9000, 1, 17, 12000, 300, 8000, 5, 11000, 640):
+                x = torch.randn(n * 32000, device='cuda', generator=g) * 2.
+                fw.write(x)
+                junk = (x[:1000].double() * 3).sum()        # temporaries between the calls
+                del x, junk
+        return hashlib.sha256(path.read_bytes()).hexdigest(), path.stat().st_size
+
+    want = write('sync.vdif', False)
+    got = write('async.vdif', True)
+    assert got == want and want[1] == 40963 * 8032
