@@ -87,6 +87,7 @@ class GSBStreamReader(GPUStreamReaderBase):
                  payload_nbytes=None, nchan=None, bps=None, complex_data=None,
                  squeeze=True, subset=(), verify=True):
         self.fh_ts = fh_ts
+        sample_rate = hz(sample_rate)           # (a Quantity from callers of the reference: base/quantities.py)
         lines = [ln for ln in fh_ts.read().splitlines() if ln.strip()]
         lines = [ln.decode('ascii') if isinstance(ln, bytes) else ln for ln in lines]
         header0 = GSBHeader(lines[0].split())
@@ -256,6 +257,7 @@ class GSBStreamWriter(GPUStreamWriterBase):
         elif kwargs:
             raise TypeError("got unexpected arguments {}".format(sorted(kwargs)))
         self.fh_ts = fh_ts
+        sample_rate = hz(sample_rate)
         rawdump = header0.mode == 'rawdump'
         fh_raw = _raw_handles(fh_raw, rawdump)
         complex_data = (not rawdump) if complex_data is None else complex_data
@@ -334,6 +336,8 @@ def open(name, mode='rs', **kwargs):
     (``'rs'``) or writing (``'ws'``) (gsb/base.py:460-560).  ``raw`` is one
     file for rawdump, a (nested) tuple ``((polL1, polL2), (polR1, polR2))``
     for phased data; ``header_mode`` overrides the mode inferred from it."""
+    from ..base.quantities import normalize_kwargs
+    kwargs = normalize_kwargs(kwargs)      # (Quantity rates, Time instants of reference callers)
     if mode in ('rt', 'wt'):
         fh = name if hasattr(name, 'read') or hasattr(name, 'write') else io.open(name, mode[0])
         return GSBTimeStampIO(fh, **kwargs)

@@ -184,3 +184,20 @@ def test_writer_header_keywords_take_them():
         if hasattr(bb.dada.header.DADAHeader, 'fromvalues') else None
     if d is not None:
         assert d.sample_rate == 16e6 and abs(d.offset - 0.5) < 1e-9
+
+
+def test_gsb_takes_a_quantity_sample_rate():
+    """Found by tools/check_plugin_seam.py with a real Quantity: the GSB reader
+    did arithmetic on the rate before converting it."""
+    d = os.path.join(SAMPLES, 'gsb')
+    rate = 100e6 / 3.
+    for r in (rate, Q(100. / 3., 'MHz')):
+        with bb.gsb.open(os.path.join(d, 'sample_gsb_rawdump.timestamp'), 'rs',
+                         raw=os.path.join(d, 'sample_gsb_rawdump.dat'), sample_rate=r) as fh:
+            assert abs(fh.sample_rate - rate) < 1e-3 and fh.shape[0] > 0
+            shape = fh.shape
+    with bb.gsb.open(os.path.join(d, 'sample_gsb_phased.timestamp'), 'rs',
+                     raw=[[os.path.join(d, 'sample_gsb_phased.Pol-{}{}.dat'.format(p, k)) for k in (1, 2)] for p in ('L', 'R')],
+                     sample_rate=Q(100. / 3., 'MHz')) as fh:
+        assert abs(fh.sample_rate - rate) < 1e-3 and fh.shape[1:] == (2, 512)
+    assert shape[0] > 0

@@ -228,6 +228,27 @@ def part2():
     assert same(m4.start_time, r4.start_time) and m4.shape == r4.shape
     m4.close()
     r4.close()
+    # the block formats and GSB through the same dispatcher
+    S = os.path.join(ROOT, 'tests', 'golden', 'samples')
+    for fmt, name, kw in (('dada', 'sample.dada', {}), ('guppi', 'sample_puppi.raw', {}),
+                          ('gsb', os.path.join('gsb', 'sample_gsb_rawdump.timestamp'),
+                           dict(raw=os.path.join(S, 'gsb', 'sample_gsb_rawdump.dat'), sample_rate=(100. / 3.) * u.MHz)),
+                          ('gsb', os.path.join('gsb', 'sample_gsb_phased.timestamp'),
+                           dict(raw=[[os.path.join(S, 'gsb', 'sample_gsb_phased.Pol-{}{}.dat'.format(p, k)) for k in (1, 2)]
+                                     for p in ('L', 'R')], sample_rate=(100. / 3.) * u.MHz))):
+        path = os.path.join(S, name)
+        if not os.path.exists(path):
+            print("  (no {} in tests/golden/samples: skipped)".format(name))
+            continue
+        ours = baseband.open(path, 'rs', format=fmt + '_hip', **kw)
+        theirs = baseband.open(path, 'rs', format=fmt, **kw)
+        assert ours.shape == theirs.shape, (fmt, ours.shape, theirs.shape)
+        assert same(ours.start_time, theirs.start_time) and same(ours.stop_time, theirs.stop_time), fmt
+        assert abs(ours.sample_rate - theirs.sample_rate.to_value(u.Hz)) < 1e-6 * ours.sample_rate
+        t = theirs.start_time + 10 * u.us
+        assert ours.seek(t) == theirs.seek(t), fmt
+        ours.close()
+        theirs.close()
     # a writer: header keywords with a Time and a Quantity through the dispatcher
     import io as _io
     buf = _io.BytesIO()
@@ -236,8 +257,9 @@ def part2():
                        time=Time('2018-01-02T03:04:05'))
     assert fw.sample_rate == 16e6 and str(fw.start_time) == '2018-01-02T03:04:05.000000000'
     assert fw.header0.sample_rate == 16e6
-    print("part 2: baseband.open(format='vdif_hip' / 'mark5b_hip' / 'mark4_hip', sample_rate=32*u.MHz, ref_time=Time) "
-          "returned this package's readers; seek / tell agree with the reference's; read() -> " + where)
+    print("part 2: baseband.open(format='vdif_hip' / 'mark5b_hip' / 'mark4_hip' / 'dada_hip' / 'guppi_hip' / 'gsb_hip', "
+          "sample_rate=32*u.MHz, ref_time=Time) returned this package's readers; shapes, times, seek / tell agree "
+          "with the reference's; read() -> " + where)
 
 
 if __name__ == '__main__':
