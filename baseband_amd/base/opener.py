@@ -62,10 +62,14 @@ class FormatOpener:
         the caller gives none (DADA, GUPPI: one frame per file).
     """
     def __init__(self, fmt, classes, sequencer=sf.FileNameSequencer,
-                 default_file_size=None):
+                 default_file_size=None, adopt_header=None):
         self.fmt, self.classes = fmt, dict(classes)
         self.sequencer = sequencer
         self.default_file_size = default_file_size
+        # ``f(header) -> this package's header``: a ``header0=`` that is the
+        # REFERENCE's header object (what its callers have in hand when they
+        # write through the plugin seam) is rebuilt from its words / cards
+        self.adopt_header = adopt_header
 
     def __reduce__(self):
         # the opener of a format is a module-level singleton named `open`
@@ -123,6 +127,8 @@ class FormatOpener:
         # what reference callers pass (Quantity rates and sizes, Time instants:
         # vdif/base.py:422-454 there) -> plain Hz / bytes / datetime64[ns]
         kwargs = normalize_kwargs(kwargs)
+        if self.adopt_header is not None and kwargs.get('header0') is not None:
+            kwargs['header0'] = self.adopt_header(kwargs['header0'])
         if (mode == 'ws' and self.default_file_size is not None
                 and source_kind(name) in ('sequence', 'template')
                 and 'file_size' not in kwargs and kwargs.get('header0') is not None):

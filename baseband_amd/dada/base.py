@@ -260,11 +260,20 @@ class _DADAOpener(FormatOpener):
         return fns
 
 
+def _adopt_header(h):
+    """The reference's DADAHeader (an ordered mapping with `comments`) -> ours."""
+    if isinstance(h, DADAHeader) or not hasattr(h, 'items'):
+        return h
+    new = DADAHeader({k: v for k, v in h.items() if not str(k).startswith('_')}, verify=False, mutable=True)
+    new.comments = {k: v for k, v in dict(getattr(h, 'comments', {}) or {}).items() if not str(k).startswith('_')}
+    return new
+
+
 open = _DADAOpener('DADA', {'rb': DADAFileReader, 'wb': DADAFileWriter,
                             'rs': DADAStreamReader,
                             'ws': DADAStreamWriter},
                    sequencer=DADAFileNameSequencer,
-                   default_file_size=lambda header0: header0.frame_nbytes)
+                   default_file_size=lambda header0: header0.frame_nbytes, adopt_header=_adopt_header)
 open.__doc__ = """Open DADA file(s) (dada/base.py:366-470): ``'rb'``, ``'rs'`` or ``'ws'``;
 names, handles, lists of names, or a template such as
 ``'{utc_start}_{obs_offset:016d}.000000.dada'``.  A written sequence gets one

@@ -199,10 +199,22 @@ class _GUPPIOpener(FormatOpener):
         return super().__call__(name, mode, **kwargs)
 
 
+def _adopt_header(h):
+    """The reference's GUPPIHeader (an `astropy.io.fits.Header`) -> ours: the
+    cards' keywords, values and comments."""
+    if isinstance(h, GUPPIHeader) or not hasattr(h, 'cards'):
+        return h
+    cards = [(c.keyword, c.value, c.comment) for c in h.cards if c.keyword not in ('', 'COMMENT', 'HISTORY', 'END')]
+    new = GUPPIHeader({k: (bool(v) if isinstance(v, (bool, np.bool_)) else v) for k, v, _ in cards}, verify=False,
+                      mutable=True)
+    new.comments = {k: c for k, _, c in cards if c}
+    return new
+
+
 open = _GUPPIOpener('GUPPI', {'rb': GUPPIFileReader, 'wb': GUPPIFileWriter,
                             'rs': GUPPIStreamReader,
                               'ws': GUPPIStreamWriter},
-                    sequencer=GUPPIFileNameSequencer)
+                    sequencer=GUPPIFileNameSequencer, adopt_header=_adopt_header)
 open.__doc__ = """Open GUPPI raw file(s) (guppi/base.py:305-396): ``'rb'``, ``'rs'`` or
 ``'ws'``; names, handles, lists of names, or a template such as
 ``'puppi_{stt_imjd}_{src_name}_{scannum}.{file_nr:04d}.raw'``.  A written

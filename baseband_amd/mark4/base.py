@@ -318,9 +318,16 @@ class Mark4StreamWriter(GPUStreamWriterBase):
         self._emit_frames(heads.view(np.uint8).reshape(nfr, -1), words)
 
 
+def _adopt_header(h):
+    """The reference's Mark4Header -> ours (same (5, ntrack) words, decade)."""
+    if isinstance(h, Mark4Header) or not hasattr(h, 'words'):
+        return h
+    return Mark4Header(np.array(h.words, dtype=np.uint32), decade=getattr(h, 'decade', None), verify=False).copy()
+
+
 open = FormatOpener('Mark4', {'rb': Mark4FileReader, 'wb': Mark4FileWriter,
                               'rs': Mark4StreamReader,
-                              'ws': Mark4StreamWriter})
+                              'ws': Mark4StreamWriter}, adopt_header=_adopt_header)
 open.__doc__ = """Open Mark 4 file(s): ``'rb'`` -> `Mark4FileReader`, ``'rs'`` ->
 `Mark4StreamReader`, ``'ws'`` -> `Mark4StreamWriter` (mark4/base.py:337-430);
 names, handles, lists of names and ``{file_nr}`` templates are accepted."""

@@ -266,9 +266,16 @@ class Mark5BStreamWriter(GPUStreamWriterBase):
         self._emit_frames(words.view(np.uint8), packed)
 
 
+def _adopt_header(h):
+    """The reference's Mark5BHeader -> ours (same words, kday)."""
+    if isinstance(h, Mark5BHeader) or not hasattr(h, 'words'):
+        return h
+    return Mark5BHeader([int(w) for w in h.words], kday=getattr(h, 'kday', None), verify=False).copy()
+
+
 open = FormatOpener('Mark5B', {'rb': Mark5BFileReader, 'wb': Mark5BFileWriter,
                                'rs': Mark5BStreamReader,
-                               'ws': Mark5BStreamWriter})
+                               'ws': Mark5BStreamWriter}, adopt_header=_adopt_header)
 open.__doc__ = """Open Mark 5B file(s): ``'rb'`` -> `Mark5BFileReader`, ``'rs'`` ->
 `Mark5BStreamReader`, ``'ws'`` -> `Mark5BStreamWriter` (mark5b/base.py:356-428);
 names, handles, lists of names and ``{file_nr}`` templates are accepted."""

@@ -518,8 +518,17 @@ class VDIFStreamWriter(GPUStreamWriterBase):
         self._emit_frames(heads.reshape(nsets * nthread, -1), packed)
 
 
+def _adopt_header(h):
+    """The reference's VDIFHeader (anything with `words` that is not ours) ->
+    ours, same words and EDV, mutable like the copy a writer works on."""
+    if isinstance(h, VDIFHeader) or not hasattr(h, 'words'):
+        return h
+    new = VDIFHeader([int(w) for w in h.words], edv=getattr(h, 'edv', None), verify=False)
+    return new.copy()
+
+
 open = FormatOpener('VDIF', {'rb': VDIFFileReader, 'wb': VDIFFileWriter, 'rs': VDIFStreamReader,
-                             'ws': VDIFStreamWriter})
+                             'ws': VDIFStreamWriter}, adopt_header=_adopt_header)
 open.__doc__ = """Open VDIF file(s): ``'rb'`` gives a `VDIFFileReader`, ``'rs'`` a
 `VDIFStreamReader`, ``'ws'`` a `VDIFStreamWriter` (vdif/base.py:810-884).
 `name` may be a file name, a file handle, a list of names or a ``{file_nr}``

@@ -201,3 +201,53 @@ def test_gsb_takes_a_quantity_sample_rate():
                      sample_rate=Q(100. / 3., 'MHz')) as fh:
         assert abs(fh.sample_rate - rate) < 1e-3 and fh.shape[1:] == (2, 512)
     assert shape[0] > 0
+
+
+def test_writers_adopt_a_foreign_header0():
+    """``header0=`` may be the REFERENCE's header object (what its callers pass
+    through the plugin seam): anything with `words` (VDIF, Mark 5B, Mark 4), a
+    mapping with `comments` (DADA), `cards` (GUPPI: a fits.Header) is rebuilt as
+    this package's header.  tools/check_plugin_seam.py does it with the real
+    objects; here with look-alikes made from this package's own."""
+    import collections
+    with open(os.path.join(SAMPLES, 'sample.vdif'), 'rb') as f:
+        ours = bb.vdif.header.VDIFHeader.fromfile(f)
+
+    class ForeignWords:
+        def __init__(self, words, **attrs):
+            self.words = words
+            self.__dict__.update(attrs)
+
+    fw = bb.vdif.open(io.BytesIO(), 'ws', header0=ForeignWords(tuple(ours.words), edv=ours.edv), sample_rate=Q(32, 'MHz'),
+                      nthread=8)
+    assert isinstance(fw.header0, bb.vdif.header.VDIFHeader3) and tuple(fw.header0.words) == tuple(ours.words)
+    with bb.mark5b.open(os.path.join(SAMPLES, 'sample.m5b'), 'rs', nchan=8, bps=2, kday=56000, sample_rate=32e6) as fr:
+        m5 = fr.header0
+    fw = bb.mark5b.open(io.BytesIO(), 'ws', header0=ForeignWords(tuple(m5.words), kday=56000), sample_rate=32e6, nchan=8, bps=2)
+    assert tuple(fw.header0.words) == tuple(m5.words) and fw.start_time == m5.time
+    with bb.mark4.open(os.path.join(SAMPLES, 'sample.m4'), 'rs', ntrack=64, decade=2010, sample_rate=32e6) as fr:
+        m4 = fr.header0
+    fw = bb.mark4.open(io.BytesIO(), 'ws', header0=ForeignWords(np.array(m4.words), decade=2010), sample_rate=32e6)
+    assert np.array_equal(fw.header0.words, m4.words) and fw.start_time == m4.time
+    with bb.dada.open(os.path.join(SAMPLES, 'sample.dada'), 'rs') as fr:
+        dd = fr.header0
+
+    class ForeignDADA(collections.OrderedDict):
+        comments = {'NBIT': 'bits', '_3': 'a comment line'}
+
+    foreign = ForeignDADA(list(dd.items()) + [('_3', None)])
+    fw = bb.dada.open(io.BytesIO(), 'ws', header0=foreign)
+    assert isinstance(fw.header0, bb.dada.header.DADAHeader) and dict(fw.header0) == dict(dd)
+    assert fw.header0.comments == {'NBIT': 'bits'}
+    with open(os.path.join(SAMPLES, 'sample_puppi.raw'), 'rb') as f:
+        gg = bb.guppi.header.GUPPIHeader.fromfile(f)
+    Card = collections.namedtuple('Card', 'keyword value comment')
+
+    class ForeignFits:
+        def __init__(self, h):
+            self.cards = [Card(k, (0 if k == 'OVERLAP' else v), c) for k, v, c in h.cards] + [Card('COMMENT', 'x', '')]
+            self.frame_nbytes = h.frame_nbytes
+
+    fw = bb.guppi.open(io.BytesIO(), 'ws', header0=ForeignFits(gg))
+    assert isinstance(fw.header0, bb.guppi.header.GUPPIHeader) and fw.header0['SRC_NAME'] == gg['SRC_NAME']
+    assert fw.header0['OVERLAP'] == 0 and 'COMMENT' not in fw.header0

@@ -257,9 +257,35 @@ def part2():
                        time=Time('2018-01-02T03:04:05'))
     assert fw.sample_rate == 16e6 and str(fw.start_time) == '2018-01-02T03:04:05.000000000'
     assert fw.header0.sample_rate == 16e6
+    # writers handed the REFERENCE's header objects as header0 (what its callers have in hand)
+    from baseband import vdif as rvdif, mark5b as rm5b, mark4 as rm4, dada as rdada, guppi as rguppi
+    with rvdif.open(sample, 'rs') as fr:
+        rh = fr.header0
+    fw = baseband.open(_io.BytesIO(), 'ws', format='vdif_hip', header0=rh, sample_rate=32 * u.MHz, nthread=8)
+    assert [int(w) for w in fw.header0.words] == [int(w) for w in rh.words] and fw.header0.edv == rh.edv
+    assert type(fw.header0).__module__ == 'baseband_amd.vdif.header'
+    with rm5b.open(os.path.join(S, 'sample.m5b'), 'rs', nchan=8, bps=2, kday=56000, sample_rate=32 * u.MHz) as fr:
+        rh = fr.header0
+    fw = baseband.open(_io.BytesIO(), 'ws', format='mark5b_hip', header0=rh, sample_rate=32 * u.MHz, nchan=8, bps=2)
+    assert [int(w) for w in fw.header0.words] == [int(w) for w in rh.words] and same(fw.start_time, rh.time)
+    with rm4.open(os.path.join(S, 'sample.m4'), 'rs', ntrack=64, decade=2010, sample_rate=32 * u.MHz) as fr:
+        rh = fr.header0
+    fw = baseband.open(_io.BytesIO(), 'ws', format='mark4_hip', header0=rh, sample_rate=32 * u.MHz)
+    assert np.array_equal(np.asarray(fw.header0.words), np.asarray(rh.words)) and same(fw.start_time, rh.time)
+    with rdada.open(os.path.join(S, 'sample.dada'), 'rs') as fr:
+        rh = fr.header0
+    fw = baseband.open(_io.BytesIO(), 'ws', format='dada_hip', header0=rh)
+    assert fw.header0['NBIT'] == rh['NBIT'] and fw.header0.payload_nbytes == rh.payload_nbytes
+    assert fw.sample_rate == rh.sample_rate.to_value(u.Hz) and same(fw.start_time, rh.time)
+    with rguppi.open(os.path.join(S, 'sample_puppi.raw'), 'rs') as fr:
+        rh = fr.header0.copy()
+    rh['OVERLAP'] = 0                    # (neither writer takes overlapping frames)
+    fw = baseband.open(_io.BytesIO(), 'ws', format='guppi_hip', header0=rh)
+    assert fw.header0['NBITS'] == rh['NBITS'] and fw.header0.payload_nbytes == rh.payload_nbytes
+    assert abs(fw.sample_rate - rh.sample_rate.to_value(u.Hz)) < 1e-6 and fw.header0['SRC_NAME'] == rh['SRC_NAME']
     print("part 2: baseband.open(format='vdif_hip' / 'mark5b_hip' / 'mark4_hip' / 'dada_hip' / 'guppi_hip' / 'gsb_hip', "
           "sample_rate=32*u.MHz, ref_time=Time) returned this package's readers; shapes, times, seek / tell agree "
-          "with the reference's; read() -> " + where)
+          "with the reference's; writers accept the reference's own header objects as header0; read() -> " + where)
 
 
 if __name__ == '__main__':
