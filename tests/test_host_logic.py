@@ -675,8 +675,22 @@ def test_plugin_entry_points_name_format_modules():
     assert set(entries) == {f + '_hip' for f in ('vdif', 'mark5b', 'mark4', 'guppi', 'dada', 'gsb')}
     for name, target in entries.items():
         assert ':' not in target                   # a module entry = a format
+        assert target == 'baseband_amd.plugin.' + name[:-4]
         mod = importlib.import_module(target)
         assert callable(mod.open) and callable(mod.info)
+    # the plugin modules hand back views with the reference's types (plain values here:
+    # astropy is not installed next to torch; tools/check_plugin_seam.py sees Time / Quantity)
+    from baseband_amd.plugin import vdif as pv
+    from baseband_amd.plugin._proxy import ReferenceTyped
+    with pv.open(golden_path('samples/sample.vdif'), 'rs', sample_rate=32e6) as fh:
+        assert isinstance(fh, ReferenceTyped) and type(fh._wrapped).__name__ == 'VDIFStreamReader'
+        assert fh.shape == (40000, 8) and fh.sample_rate == 32e6 and fh.seek(100) == 100 and fh.tell() == 100
+        assert str(fh.tell('time')) == '2014-06-16T05:56:07.000003125' and fh.info.format == 'vdif'
+        fh.decode_ahead = False                     # attributes are set on the reader, not on the view
+        assert fh._wrapped.decode_ahead is False and 'decode_ahead' not in vars(fh)
+    with pv.open(golden_path('samples/sample.vdif'), 'rb') as fb:
+        assert type(fb).__name__ == 'VDIFFileReader'          # file readers are handed on as they are
+    assert pv.info(golden_path('samples/sample.vdif')).format == 'vdif'
 
 
 def test_utils_match_reference_known_answers():

@@ -45,3 +45,40 @@ def test_documented_binding_decodes_like_the_reference():
     # an unknown coder / bps surfaces as KeyError, like a missing _decoders entry
     with pytest.raises(KeyError):
         ns['make_decoder'](1, 4)(words)
+
+
+def test_plugin_modules_return_numpy_arrays(manifest):
+    """The ``baseband.io`` entry points (baseband_amd/plugin/): ``read()`` hands a
+    caller of the reference the NumPy array the reference would (bit-identical to
+    its output), ``read_tensor()`` the device tensor, ``out=`` a NumPy array or a
+    device tensor is filled in place."""
+    import torch
+    from conftest import golden_path, load_expected, bits_equal
+    from baseband_amd.plugin import vdif as pv, mark5b as pm, dada as pd
+    exp = load_expected('sample_vdif')
+    with pv.open(golden_path('samples/sample.vdif'), 'rs') as fh:
+        got = fh.read()
+        assert isinstance(got, np.ndarray) and bits_equal(got.reshape(exp.shape), exp)
+        fh.seek(0)
+        t = fh.read_tensor(1000)
+        assert isinstance(t, torch.Tensor) and t.is_cuda and bits_equal(t.cpu().numpy().reshape(exp[:1000].shape), exp[:1000])
+        out = np.empty((500,) + got.shape[1:], got.dtype)
+        assert fh.read(out=out) is out and bits_equal(out.reshape(exp[1000:1500].shape), exp[1000:1500])
+        dev = torch.empty((250,) + got.shape[1:], dtype=torch.float32, device='cuda')
+        assert fh.read(out=dev) is dev and bits_equal(dev.cpu().numpy().reshape(exp[1500:1750].shape), exp[1500:1750])
+    c = manifest['m5b_c16_b2']
+    with pm.open(golden_path(c['file']), 'rs', sample_rate=c['frame_rate'] * c['samples_per_frame'], kday=c['kday'],
+                 nchan=c['nchan'], bps=c['bps']) as fh:
+        assert bits_equal(fh.read(), load_expected('m5b_c16_b2'))
+    with pd.open(golden_path(manifest['dada_p2_c4_cplx']['file']), 'rs') as fh:
+        got = fh.read()
+        assert got.dtype == np.complex64 and bits_equal(got, load_expected('dada_p2_c4_cplx'))
+    # a writer through the plugin module takes NumPy samples and gives the reference-written bytes back
+    import io
+    buf = io.BytesIO()
+    with pv.open(golden_path('samples/sample.vdif'), 'rs') as fr:
+        h0, data = fr.header0, fr.read()
+    with pv.open(buf, 'ws', header0=h0, sample_rate=32e6, nthread=8) as fw:
+        fw.write(data)
+    with open(golden_path('samples/sample.vdif'), 'rb') as f:
+        assert buf.getvalue() == f.read()
