@@ -47,7 +47,7 @@ def test_documented_binding_decodes_like_the_reference():
         ns['make_decoder'](1, 4)(words)
 
 
-def test_plugin_modules_return_numpy_arrays(manifest):
+def test_plugin_modules_return_numpy_arrays(manifest, tmp_path):
     """The ``baseband.io`` entry points (baseband_amd/plugin/): ``read()`` hands a
     caller of the reference the NumPy array the reference would (bit-identical to
     its output), ``read_tensor()`` the device tensor, ``out=`` a NumPy array or a
@@ -74,11 +74,9 @@ def test_plugin_modules_return_numpy_arrays(manifest):
         got = fh.read()
         assert got.dtype == np.complex64 and bits_equal(got, load_expected('dada_p2_c4_cplx'))
     # a writer through the plugin module takes NumPy samples and gives the reference-written bytes back
-    import io
-    buf = io.BytesIO()
     with pv.open(golden_path('samples/sample.vdif'), 'rs') as fr:
         h0, data = fr.header0, fr.read()
-    with pv.open(buf, 'ws', header0=h0, sample_rate=32e6, nthread=8) as fw:
+    with pv.open(str(tmp_path / 'again.vdif'), 'ws', header0=h0, sample_rate=32e6, nthread=8) as fw:
         fw.write(data)
     with open(golden_path('samples/sample.vdif'), 'rb') as f:
-        assert buf.getvalue() == f.read()
+        assert (tmp_path / 'again.vdif').read_bytes() == f.read()
