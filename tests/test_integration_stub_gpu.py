@@ -73,10 +73,13 @@ def test_plugin_modules_return_numpy_arrays(manifest, tmp_path):
     with pd.open(golden_path(manifest['dada_p2_c4_cplx']['file']), 'rs') as fh:
         got = fh.read()
         assert got.dtype == np.complex64 and bits_equal(got, load_expected('dada_p2_c4_cplx'))
-    # a writer through the plugin module takes NumPy samples and gives the reference-written bytes back
+    # a writer through the plugin module takes NumPy samples
     with pv.open(golden_path('samples/sample.vdif'), 'rs') as fr:
         h0, data = fr.header0, fr.read()
     with pv.open(str(tmp_path / 'again.vdif'), 'ws', header0=h0, sample_rate=32e6, nthread=8) as fw:
         fw.write(data)
-    with open(golden_path('samples/sample.vdif'), 'rb') as f:
-        assert (tmp_path / 'again.vdif').read_bytes() == f.read()
+    # (the writer stores the threads in increasing order, sample.vdif holds them as 1, 3, 5, 7, 0, 2, 4, 6:
+    # the same samples, not the same bytes; byte identity of the writers is tests/test_encode_gpu.py's)
+    with pv.open(str(tmp_path / 'again.vdif'), 'rs') as fr:
+        assert fr.header0['thread_id'] == 0 and fr.shape == data.shape
+        assert bits_equal(fr.read(), data)
