@@ -161,24 +161,27 @@ class _FrameWindow:
             self._turn = (self._turn + 1) % _NSCRATCH
             k = self._turn
         st = sets[k]
-        fresh = False
-        if st[0] is None or st[0].shape[0] < nframes or st[0].device != dev:
-            # (with headroom: a set is re-made when a request outgrows it, and a new one costs a stream wait)
+        small = (st[0] is None or st[0].shape[0] < nframes or st[0].device != dev
+                 or st[1] is None or st[1].numel() < n or st[1].device != dev)
+        if small and scan_stream is None:
             st[0] = torch.empty((max(_pow2(nframes), 64), 4), dtype=torch.int32, device=dev)
-            fresh = True
-        if st[1] is None or st[1].numel() < n or st[1].device != dev:
             st[1] = torch.empty(max(_pow2(n), 64), dtype=torch.int64, device=dev)
-            fresh = True
+            st[2] = None
+        elif small:
+            # ALL sets at once (with headroom: they are re-made when a request outgrows
+            # them): one allocation, and ONE wait of the side stream for the caller's --
+            # torch's allocator hands out memory whose last user may still have work
+            # queued on the caller's stream, which is safe there and nowhere else
+            # (tools/stress_side_scan.py found a scan overwritten by such work)
+            cr, cs = max(_pow2(nframes), 64), max(_pow2(n), 64)
+            recs = torch.empty((_NSCRATCH * cr, 4), dtype=torch.int32, device=dev)
+            src = torch.empty(_NSCRATCH * cs, dtype=torch.int64, device=dev)
+            for j in range(_NSCRATCH):
+                sets[j][0], sets[j][1], sets[j][2] = recs[j * cr:(j + 1) * cr], src[j * cs:(j + 1) * cs], None
+            scan_stream.wait_stream(torch.cuda.current_stream(dev))
         self.recs, self.src = st[0], st[1]
-        if scan_stream is not None:
-            if fresh:
-                # torch's allocator hands out memory whose last user may still have work
-                # queued on the CALLER's stream -- safe there, not on another stream: the
-                # side stream waits for that point once per (re)allocation
-                # (tools/stress_side_scan.py found a scan overwritten by such work)
-                scan_stream.wait_stream(torch.cuda.current_stream(dev))
-            elif st[2] is not None:
-                scan_stream.wait_event(st[2])       # the decode that read this set last
+        if scan_stream is not None and not small and st[2] is not None:
+            scan_stream.wait_event(st[2])           # the decode that read this set last
         return st
 
     def _decode_queued(self, st, scan_stream, dev):
