@@ -78,6 +78,7 @@ def cpu_baseline(target_seconds=12.0):
               "sample": "{} x {} frames of the same cfg2 layout ({:.1f} MiB each), "
                         "oracle/bb_oracle_np.vdif_read (per-frame NumPy LUT take loop)"
                         .format(reps, nframes, image.size / 2 ** 20),
+              "sample_short": "{} x {} cfg2 frames, oracle/bb_oracle_np.vdif_read".format(reps, nframes),
               "host": "{} physical cores / {} logical CPUs; numpy {}".format(*physical_cores(), np.__version__)}
     # how the port relates to the real reference (measured in the development
     # container, where the reference can be imported: tools/calibrate_cpu_baseline.py)
