@@ -1185,6 +1185,35 @@ class GPUStreamReaderBase:
     def _relocate(self):
         raise NotImplementedError
 
+    _located = None             # (frame starts, records) of `_relocate`'s search
+
+    @property
+    def _raw_offsets(self):
+        """Where the frames (VDIF: frame sets) of the file start, as the
+        reference's table of the same name (base/base.py:1064,1081; written
+        by `_bad_frame`, base/base.py:1189, vdif/base.py:615,729): a
+        `RawOffsets` whose ``[k]`` is the file position of frame (set) `k`.
+        Before `_relocate` that is the fixed stride from the first frame;
+        after it, the positions of the frames the search found, folded into
+        steps -- a frame set counts from its earliest frame that was found,
+        frames of which nothing was found take the slip of the one before."""
+        from .offsets import RawOffsets
+        from .. import _lib
+        if self._located is None:
+            table = RawOffsets(frame_nbytes=self._set_nbytes)
+            if self._file_offset0:
+                table[0] = self._file_offset0
+            return table
+        offs, recs = self._located
+        nsets = self._nsample // self.samples_per_frame
+        when = recs[:, 2].to(torch.int64)
+        ok = (((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0) & (when >= 0) & (when < nsets)
+        none = torch.iinfo(torch.int64).max
+        start = torch.full((nsets,), none, dtype=torch.int64, device=offs.device)
+        start.scatter_reduce_(0, when[ok], offs.to(torch.int64)[ok], 'amin')
+        start = start.cpu().numpy()
+        return RawOffsets.from_index(start, self._set_nbytes, known=start != none)
+
     # -- pickling: reopen by file name at the saved offset
     # (base/base.py:123-151,1020-1032); device buffers are re-creatable
     def __reduce__(self):

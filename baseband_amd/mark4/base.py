@@ -218,6 +218,7 @@ class Mark4StreamReader(GPUStreamReaderBase):
                                  "(a frame time occurs more than once).")
         nsets = self._nsample // self.samples_per_frame
         self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
+        self._located = (offs, recs)
         self._relocated = True
 
     def _maps(self):

@@ -191,6 +191,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
                                       self.header0['frame_nr'], self._frame_rate)
         nsets = self._nsample // self.samples_per_frame
         self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
+        self._located = (offs, recs)
         self._relocated = True
 
     def _read_sets(self, first, last, into=None):

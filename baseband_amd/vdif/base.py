@@ -290,6 +290,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
         src = kernels.build_index(recs, nsets, len(self._thread_ids), self._thread_slot)
         self._resident = (dev, src)
         self._nsample = nsets * self.samples_per_frame
+        self._located = (offs, recs)
         self._relocated = True
 
     def _read_sets(self, first, last, into=None):

@@ -186,3 +186,53 @@ def test_mark4_locate_kernel():
     # frame 1 has no successor in place; frame 2 lost bytes 10..100 of its header but
     # its sync pattern (bytes 126..191) survives 90 bytes early, like all later frames
     assert offs == [0] + [k * 40000 - 90 for k in range(2, 8)]
+
+
+# ---- the byte-slip table the readers show (`fh._raw_offsets`), against the table
+# ---- the reference's readers were left with on the same files
+# ---- (tests/golden/raw_offsets_cases.json, oracle/gen_golden_offsets.py)
+with open(golden_path('raw_offsets_cases.json')) as _f:
+    RAW_OFFSETS = json.load(_f)['readers']
+
+
+def _same_table(fh, want, zeroed_sets):
+    table = fh._raw_offsets
+    assert table.frame_nbytes == want['frame_nbytes']
+    # every frame (set) of which something was found lies where the reference puts it
+    found = [k for k in range(len(want['lookup'])) if k not in zeroed_sets]
+    assert [table[k] for k in found] == [want['lookup'][k] for k in found]
+    # ... and the steps are the same ones, up to what either side says about frames that read as fill
+    from baseband_amd.base.offsets import RawOffsets
+    known = np.isin(np.arange(len(want['lookup'])), found)
+    mine = RawOffsets.from_index([table[k] for k in range(len(known))], table.frame_nbytes, known=known)
+    theirs = RawOffsets.from_index(want['lookup'], table.frame_nbytes, known=known)
+    assert (mine.frame_nr, mine.offset) == (theirs.frame_nr, theirs.offset)
+    if not zeroed_sets:
+        assert (table.frame_nr, table.offset) == (want['frame_nr'], want['offset'])
+
+
+@pytest.mark.parametrize('i', range(len(CASES)), ids=[c['kind'] + str(i) for i, c in enumerate(CASES)])
+def test_vdif_raw_offsets_table(i, tmp_path):
+    from baseband_amd import vdif
+    case, want = CASES[i], RAW_OFFSETS['vdif_triple'][i]
+    p = tmp_path / 'corrupt.vdif'
+    p.write_bytes(_corrupt(case).tobytes())
+    with vdif.open(str(p), 'rs', squeeze=False) as fh:
+        assert len(fh._raw_offsets) == 0 or case['kind'] == 'bytes'
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fh.read()
+        whole = [s for s in range(6) if all(s * 8 + t in case['zeroed'] for t in range(8))]
+        _same_table(fh, want, whole)
+
+
+@pytest.mark.parametrize('group,i', [(g, i) for g, i in _FIXED_PARAMS if 'error' not in FIXED[g][i]],
+                         ids=['%s-%s%d' % (g, FIXED[g][i]['kind'], i) for g, i in _FIXED_PARAMS
+                              if 'error' not in FIXED[g][i]])
+def test_mark5b_mark4_raw_offsets_table(group, i, tmp_path):
+    case, want = FIXED[group][i], RAW_OFFSETS[group][i]
+    with _fixed_open(group, _fixed_blob(group, case), tmp_path) as fh:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            fh.read()
+        _same_table(fh, want, case['zeroed'])
