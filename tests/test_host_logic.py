@@ -688,9 +688,68 @@ def test_plugin_entry_points_name_format_modules():
         assert str(fh.tell('time')) == '2014-06-16T05:56:07.000003125' and fh.info.format == 'vdif'
         fh.decode_ahead = False                     # attributes are set on the reader, not on the view
         assert fh._wrapped.decode_ahead is False and 'decode_ahead' not in vars(fh)
-    with pv.open(golden_path('samples/sample.vdif'), 'rb') as fb:
-        assert type(fb).__name__ == 'VDIFFileReader'          # file readers are handed on as they are
     assert pv.info(golden_path('samples/sample.vdif')).format == 'vdif'
+
+
+class _FakeUnit:
+    def __init__(self, name):
+        self.name = name
+
+    def __rmul__(self, value):
+        return (value, self.name)
+
+
+def _fake_astropy():
+    def Time(jd1, jd2, format=None, scale=None, precision=None):
+        ns = round((jd1 - 2440587.5) * 86400) * 10 ** 9 + round(jd2 * 86400e9)
+        return ('Time', scale, str(np.datetime64(ns, 'ns')))
+    return type('u', (), {'Hz': _FakeUnit('Hz'), 's': _FakeUnit('s')}), Time
+
+
+def test_plugin_views_answer_with_the_reference_types(monkeypatch):
+    """The views of baseband_amd/plugin/_proxy.py: WHICH attributes are converted
+    (with a stand-in for astropy: the real one is seen by tools/check_plugin_seam.py),
+    on streams, headers, info and binary file readers; arguments that are views are
+    unwrapped on the way in."""
+    from baseband_amd.plugin import vdif as pv, dada as pd, mark5b as pm
+    from baseband_amd.plugin import _proxy
+    monkeypatch.setattr(_proxy, '_astropy', _fake_astropy)
+    sample = golden_path('samples/sample.vdif')
+    with pv.open(sample, 'rs') as fh:
+        assert fh.start_time == ('Time', 'utc', '2014-06-16T05:56:07.000000000')
+        assert fh.sample_rate == (32e6, 'Hz')
+        h0 = fh.header0
+        assert isinstance(h0, _proxy.HeaderView) and type(h0._wrapped).__name__ == 'VDIFHeader3'
+        assert h0.time == h0.get_time() == ('Time', 'utc', '2014-06-16T05:56:07.000000000')
+        assert h0.sample_rate == (32e6, 'Hz') and h0.frame_rate == (1600.0, 'Hz')
+        assert h0['frame_nr'] == 0 and h0.edv == 3 and 'seconds' in h0.keys() and h0.nbytes == 32
+        assert h0 == h0._wrapped and h0 == h0.copy() and isinstance(h0.copy(), _proxy.HeaderView)
+        info = fh.info
+        assert isinstance(info, _proxy.InfoView) and info.format == 'vdif'
+        assert "start_time = ('Time', 'utc', '2014-06-16T05:56:07.000000000')" in repr(info)
+        assert info.start_time == fh.start_time and info.sample_rate == (32e6, 'Hz')
+        assert info()['start_time'] == fh.start_time and info()['sample_rate'] == (32e6, 'Hz')
+        assert info.file_info.frame_rate == (1600.0, 'Hz') and info.file_info()['edv'] == 3
+        assert isinstance(fh.fh_raw, _proxy.FileReaderView)
+        # a writer handed the VIEW of a header gets the header
+        buf = io.BytesIO()
+        fw = pv.open(buf, 'ws', header0=h0, nthread=8)
+        assert type(fw._wrapped.header0).__name__ == 'VDIFHeader3' and fw.header0 == h0
+        assert fw.sample_rate == (32e6, 'Hz')
+    with pv.open(sample, 'rb') as fb:
+        assert isinstance(fb, _proxy.FileReaderView) and type(fb._wrapped).__name__ == 'VDIFFileReader'
+        header = fb.read_header()
+        assert isinstance(header, _proxy.HeaderView) and header.time[0] == 'Time'
+        assert fb.get_frame_rate() == (1600.0, 'Hz') and fb.tell() == 32
+        assert fb.seek(0) == 0 and fb.find_header(forward=True) == header
+        assert fb.info.frame_rate == (1600.0, 'Hz') and fb.info.start_time == header.time
+    with pd.open(golden_path('samples/sample.dada'), 'rs') as fh:
+        h0 = fh.header0
+        assert h0.offset == (100.0, 's') and h0.start_time[0] == 'Time' and h0.time == fh.start_time
+        assert h0.sample_rate == fh.sample_rate == (16e6, 'Hz') and h0['NBIT'] == 8
+    with pm.open(golden_path('samples/sample.m5b'), 'rs', sample_rate=32e6, kday=56000, nchan=8, bps=2) as fh:
+        assert fh.header0.get_time(frame_rate=6400.0)[0] == 'Time' and fh.header0.kday == 56000
+    assert pv.info(sample).start_time == ('Time', 'utc', '2014-06-16T05:56:07.000000000')
 
 
 def test_utils_match_reference_known_answers():

@@ -83,3 +83,38 @@ def test_plugin_modules_return_numpy_arrays(manifest, tmp_path):
     with pv.open(str(tmp_path / 'again.vdif'), 'rs') as fr:
         assert fr.header0['thread_id'] == 0 and fr.shape == data.shape
         assert bits_equal(fr.read(), data)
+
+
+def test_plugin_binary_readers_hand_out_numpy_frames(tmp_path):
+    """'rb' / 'wb' through the plugin modules: ``read_frame()`` / ``read_frameset()``
+    come back as views whose ``data`` and ``frame[item]`` are NumPy arrays equal to
+    the reference's (its frame API: vdif/frame.py:31-223, base/frame.py:160-199),
+    headers as header views; a frame read this way can be written back."""
+    from conftest import golden_path, load_expected, bits_equal
+    from baseband_amd.plugin import vdif as pv, mark5b as pm
+    from baseband_amd.plugin._proxy import FrameView, HeaderView, PayloadView
+    exp = load_expected('sample_vdif').reshape(40000, 8)    # thread order 0..7
+    with pv.open(golden_path('samples/sample.vdif'), 'rb') as fb:
+        frame = fb.read_frame()
+        assert isinstance(frame, FrameView) and isinstance(frame.header, HeaderView)
+        thread = frame.header['thread_id']
+        data = frame.data
+        assert isinstance(data, np.ndarray) and data.shape == (20000, 1)
+        assert bits_equal(data[:, 0], exp[:20000, thread])
+        assert isinstance(frame[10:20], np.ndarray) and bits_equal(frame[10:20], data[10:20])
+        assert isinstance(frame.payload, PayloadView) and isinstance(frame.payload.data, np.ndarray)
+        assert frame.payload.words.dtype == np.dtype('<u4') and frame.nbytes == 5032 and frame.valid
+        fb.seek(0)
+        fset = fb.read_frameset()
+        assert isinstance(fset, FrameView) and isinstance(fset.data, np.ndarray)
+        assert fset.data.shape == (20000, 8, 1) and bits_equal(fset.data[..., 0], exp[:20000])
+        assert all(isinstance(f, FrameView) for f in fset.frames) and len(fset.frames) == 8
+        # ... and written back through a 'wb' view: the same bytes as in the file
+        with pv.open(str(tmp_path / 'one.vdif'), 'wb') as fw:
+            fw.write_frame(frame)
+        with open(golden_path('samples/sample.vdif'), 'rb') as f:
+            assert (tmp_path / 'one.vdif').read_bytes() == f.read(5032)
+    with pm.open(golden_path('samples/sample.m5b'), 'rb', kday=56000, nchan=8, bps=2) as fb:
+        frame = fb.read_frame()
+        assert isinstance(frame.data, np.ndarray) and frame.data.shape == (5000, 8)
+        assert bits_equal(frame.data, load_expected('sample_m5b')[:5000])

@@ -210,6 +210,34 @@ def part2():
     assert fh.seek(TimeDelta(0.0005, format='sec'), 1) == ref.seek(TimeDelta(0.0005, format='sec'), 1) == 24000
     assert abs(fh.tell(u.ms).to_value(u.ms) - ref.tell(u.ms).to_value(u.ms)) < 1e-12
     assert same(fh.tell('time'), ref.tell('time'))
+    # header0 and info through the views: the reference's types and values
+    h0, r0 = fh.header0, ref.header0
+    assert type(h0).__name__ == 'HeaderView' and isinstance(h0.time, Time) and same(h0.time, r0.time)
+    assert same(h0.get_time(), r0.get_time()) and isinstance(h0.sample_rate, u.Quantity)
+    assert h0.sample_rate == r0.sample_rate and h0.frame_rate == r0.frame_rate and h0.edv == r0.edv
+    assert same(h0.ref_time, r0.ref_time) and h0['frame_nr'] == r0['frame_nr'] and h0.station == r0.station
+    assert list(h0.keys()) == list(r0.keys()) and all(h0[k] == r0[k] for k in r0.keys())
+    ours_info, ref_info = fh.info, ref.info
+    assert isinstance(ours_info.start_time, Time) and same(ours_info.start_time, ref_info.start_time)
+    assert same(ours_info.stop_time, ref_info.stop_time) and ours_info.sample_rate == ref_info.sample_rate
+    assert isinstance(ours_info()['start_time'], Time) and ours_info()['sample_rate'] == 32 * u.MHz
+    assert ours_info.format == ref_info.format and ours_info.shape == ref_info.shape and ours_info.bps == ref_info.bps
+    fi, rfi = ours_info.file_info, ref_info.file_info
+    assert fi.frame_rate == rfi.frame_rate and isinstance(fi.frame_rate, u.Quantity) and same(fi.start_time, rfi.start_time)
+    assert fi.number_of_frames == rfi.number_of_frames and fi.thread_ids == rfi.thread_ids and fi.edv == rfi.edv
+    # a binary reader through the dispatcher: headers typed, frame rate a Quantity
+    fb = baseband.open(sample, 'rb', format='vdif_hip')
+    rb = baseband.open(sample, 'rb', format='vdif')
+    assert type(fb).__name__ == 'FileReaderView'
+    hb, hr = fb.read_header(), rb.read_header()
+    assert same(hb.time, hr.time) and fb.tell() == rb.tell() == 32
+    assert fb.get_frame_rate() == rb.get_frame_rate() and isinstance(fb.get_frame_rate(), u.Quantity)
+    fb.seek(5032 * 3 + 17)
+    rb.seek(5032 * 3 + 17)
+    assert fb.find_header(forward=True)['thread_id'] == rb.find_header(forward=True)['thread_id'] and fb.tell() == rb.tell()
+    assert same(fb.info.start_time, rb.info.start_time) and fb.info.frame_rate == rb.info.frame_rate
+    fb.close()
+    rb.close()
     try:
         fh.read(16)
     except RuntimeError as exc:
@@ -254,6 +282,12 @@ def part2():
         assert abs((ours.sample_rate - theirs.sample_rate).to_value(u.Hz)) < 1e-6 * theirs.sample_rate.to_value(u.Hz)
         t = theirs.start_time + 10 * u.us
         assert ours.seek(t) == theirs.seek(t), fmt
+        assert same(ours.header0.time, theirs.header0.time), fmt
+        if fmt in ('dada', 'guppi'):
+            assert same(ours.header0.start_time, theirs.header0.start_time), fmt
+            assert abs((ours.header0.offset - theirs.header0.offset).to_value(u.ns)) < 0.01, fmt
+            assert abs((ours.header0.sample_rate - theirs.header0.sample_rate).to_value(u.Hz)) < 1e-6, fmt
+        assert same(ours.info.start_time, theirs.info.start_time), fmt
         ours.close()
         theirs.close()
     # a writer: header keywords with a Time and a Quantity through the dispatcher
@@ -263,14 +297,14 @@ def part2():
                        complex_data=False, samples_per_frame=16000, station='me', edv=1,
                        time=Time('2018-01-02T03:04:05'))
     assert fw.sample_rate == 16 * u.MHz and fw.start_time.utc.isot[:19] == '2018-01-02T03:04:05'
-    assert fw.header0.sample_rate == 16e6
+    assert fw.header0.sample_rate == 16 * u.MHz and fw._wrapped.header0.sample_rate == 16e6
     # writers handed the REFERENCE's header objects as header0 (what its callers have in hand)
     from baseband import vdif as rvdif, mark5b as rm5b, mark4 as rm4, dada as rdada, guppi as rguppi
     with rvdif.open(sample, 'rs') as fr:
         rh = fr.header0
     fw = baseband.open(_io.BytesIO(), 'ws', format='vdif_hip', header0=rh, sample_rate=32 * u.MHz, nthread=8)
     assert [int(w) for w in fw.header0.words] == [int(w) for w in rh.words] and fw.header0.edv == rh.edv
-    assert type(fw.header0).__module__ == 'baseband_amd.vdif.header' and type(fw).__name__ == 'ReferenceTyped'
+    assert type(fw._wrapped.header0).__module__ == 'baseband_amd.vdif.header' and type(fw).__name__ == 'ReferenceTyped'
     with rm5b.open(os.path.join(S, 'sample.m5b'), 'rs', nchan=8, bps=2, kday=56000, sample_rate=32 * u.MHz) as fr:
         rh = fr.header0
     fw = baseband.open(_io.BytesIO(), 'ws', format='mark5b_hip', header0=rh, sample_rate=32 * u.MHz, nchan=8, bps=2)
@@ -293,7 +327,9 @@ def part2():
     print("part 2: baseband.open(format='vdif_hip' / 'mark5b_hip' / 'mark4_hip' / 'dada_hip' / 'guppi_hip' / 'gsb_hip', "
           "sample_rate=32*u.MHz, ref_time=Time) returned this package's readers behind baseband_amd.plugin's views: "
           "start_time / stop_time / time / tell('time') are Time, sample_rate a Quantity, equal to the reference's "
-          "(instants to 0.01 ns); shapes, seek / tell agree; writers accept the reference's own header objects as "
+          "(instants to 0.01 ns); header0 (time, get_time, ref_time, sample_rate, frame_rate, offset, every key), "
+          "info / info() / info.file_info and an 'rb' reader's read_header / find_header / get_frame_rate answer "
+          "with the reference's types and values; shapes, seek / tell agree; writers accept the reference's own header objects as "
           "header0; read() -> " + where)
 
 
