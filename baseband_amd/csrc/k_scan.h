@@ -160,6 +160,22 @@ __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nby
         // (whole waves stay in the loop: the shuffle below needs every lane)
         bb_u4 dv[U];
         uint32_t tail[U];
+        // Everything this wave touches in this iteration lies inside the buffer (all
+        // iterations but the last ones): plain loads, nothing between them.  (With the
+        // bounds tests of the ragged end in the way the compiler waited for the first
+        // chunk before it issued the second: round 5.)
+        const uint64_t wave_last = (j0 - (uint64_t)lane) + (BB_WAVE - 1) + (uint64_t)(U - 1) * stride;
+        if (4 * wave_last + 5 <= ndw) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                dv[u] = *reinterpret_cast<const bb_u4 *>(w + 4 * (j0 + (uint64_t)u * stride));
+            // (the dword after a lane's sixteen bytes: the next lane's first -- every lane
+            // fetches its own, out of the lines the loads above bring in: no shuffle, no
+            // lane that differs)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                tail[u] = w[4 * (j0 + (uint64_t)u * stride) + 4];
+        } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t j = j0 + (uint64_t)u * stride;
@@ -175,13 +191,15 @@ __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nby
                 }
                 if (lane == BB_WAVE - 1 && dw0 + 4 < ndw) tail[u] = w[dw0 + 4];
             }
+            const uint32_t nx = (uint32_t)__shfl_down((int)dv[u].x, 1);
+            if (lane != BB_WAVE - 1) tail[u] = nx;
+        }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t j = j0 + (uint64_t)u * stride;
             const bb_u4 d = dv[u];
-            uint32_t nx = (uint32_t)__shfl_down((int)d.x, 1);
-            if (lane == BB_WAVE - 1) nx = tail[u];
+            const uint32_t nx = tail[u];
             if (j >= nchunk) continue;
             const uint32_t dd[5] = {d.x, d.y, d.z, d.w, nx};
             // `probe` gives the MISMATCHING bits of a dword (0 = it is the pattern): the
