@@ -54,9 +54,10 @@
 // store loop fully unrolled the compiler took 123-138 VGPRs = 3-4 workgroups per
 // CU, and a store-bound kernel whose waves all wait at the same barrier needs
 // more of them in flight: profiles/r02e_kernels.csv)
-template <int LAYOUT, bool NT, int ROWS, int TC>
-__global__ __launch_bounds__(BB_BLOCK, 6)
-void k_decode_i8_xpose(bb_tiled_args a)
+// (MAPPED: a channel list -- its own instantiation of the body, so that the plain
+// path's loads are not tied to the look-ups' waits where the two would merge)
+template <int LAYOUT, bool NT, int ROWS, int TC, bool MAPPED>
+__device__ __forceinline__ void bb_xpose_body(const bb_tiled_args &a, uint32_t *s_d)
 {
     static_assert(TC == 64 || TC == 32 || TC == 16 || TC == 8, "channels per tile");
     constexpr int RT = ROWS * 64 / TC;          // elements of a (time, pol) run per tile
@@ -66,7 +67,6 @@ void k_decode_i8_xpose(bb_tiled_args a)
     constexpr uint32_t PPT = TC / 4;            // LAYOUT 2: pieces of 4 channels per time
     constexpr uint32_t PR = TC / 2;             // store phase: channel pairs per row ...
     constexpr uint32_t RPI = BB_BLOCK / PR;     // ... and rows per pass of the workgroup
-    __shared__ uint32_t s_d[(RT / 2) * PITCH];
     const uint32_t npol = a.npol, nps = a.nps;
     // output rows per LDS image: ROWS, or half of it when one of two pols is dropped (layouts 0, 2)
     const uint32_t estep = LAYOUT == 1 ? 1u : nps / npol;
@@ -79,13 +79,14 @@ void k_decode_i8_xpose(bb_tiled_args a)
     const uint32_t tid = threadIdx.x;
     // times per tile
     const uint32_t tt = LAYOUT == 0 ? 0u : LAYOUT == 1 ? RT / npol : RT / nps;
-    auto cm = [&](uint32_t c) -> uint32_t { return a.cmap ? (uint32_t)a.cmap[c] : c; };
+    auto cm = [&](uint32_t c) -> uint32_t { return MAPPED ? (uint32_t)a.cmap[c] : c; };
 
     bb_u4 nxt[NLOAD];
+    bool nxt_keep[NLOAD];
     bool nxt_valid = false;
 
     // which piece of the tile this thread loads in round k (k = 0..3)
-    auto issue = [&](uint64_t step, bb_u4 (&w)[NLOAD], bool &valid) {
+    auto issue = [&](uint64_t step, bb_u4 (&w)[NLOAD], bool (&keep)[NLOAD], bool &valid) {
         const uint64_t work = bb_perm(a.perm, step);
         const uint64_t f = work / per_frame;
         const uint32_t rem = (uint32_t)(work - f * per_frame);
@@ -95,6 +96,11 @@ void k_decode_i8_xpose(bb_tiled_args a)
         const int64_t so = a.src ? a.src[f] : a.src0 + (int64_t)f * a.src_stride;
         valid = bb_src_ok(so, a.src_lim);
         const uint16_t *in = reinterpret_cast<const uint16_t *>(a.buf + (valid ? so : 0));
+        // Addresses first (a mapped channel costs a look-up, and the wait for it also
+        // waited for the 16-byte load issued just before: one load in flight per thread
+        // instead of NLOAD; round 5), then the loads back to back.
+        const uint16_t *ptrs[NLOAD];
+        bool wants[NLOAD];
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
             const uint32_t g = (uint32_t)k * BB_BLOCK + tid;        // 16-byte piece of the tile
@@ -121,33 +127,51 @@ void k_decode_i8_xpose(bb_tiled_args a)
                 const uint64_t t = a.t_lo + (uint64_t)ti * tt + tl;
                 want = want && t < a.t_hi && piece * 4 < ncv;
                 ptr = in + t * a.st + (uint64_t)(c0 + piece * 4) * 2;     // (st = stored channels x 2 pol)
-                if (a.cmap) {
-                    // mapped channels are not neighbours: one dword (both pols) per channel
-                    bb_u4 v = {0u, 0u, 0u, 0u};
-                    if (want) {
-                        const uint16_t *row = in + t * a.st;
-                        const uint32_t cb = piece * 4;
-                        v.x = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb) * 2);
-                        if (cb + 1 < ncv) v.y = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 1) * 2);
-                        if (cb + 2 < ncv) v.z = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 2) * 2);
-                        if (cb + 3 < ncv) v.w = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 3) * 2);
-                    }
-                    w[k] = v;
-                    continue;
-                }
             }
-            w[k] = want ? *reinterpret_cast<const bb_u4 *>(ptr) : bb_u4{0u, 0u, 0u, 0u};
+            ptrs[k] = ptr;
+            wants[k] = want;
         }
+        if (LAYOUT == 2 && MAPPED) {
+#pragma unroll
+            for (int k = 0; k < NLOAD; ++k) {
+                // mapped channels are not neighbours: one dword (both pols) per channel
+                const uint32_t g = (uint32_t)k * BB_BLOCK + tid;
+                const uint32_t tl = g / PPT, piece = g % PPT;
+                const uint64_t t = a.t_lo + (uint64_t)ti * tt + tl;
+                bb_u4 v = {0u, 0u, 0u, 0u};
+                if (wants[k]) {
+                    const uint16_t *row = in + t * a.st;
+                    const uint32_t cb = piece * 4;
+                    v.x = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb) * 2);
+                    if (cb + 1 < ncv) v.y = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 1) * 2);
+                    if (cb + 2 < ncv) v.z = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 2) * 2);
+                    if (cb + 3 < ncv) v.w = *reinterpret_cast<const uint32_t *>(row + (uint64_t)cm(c0 + cb + 3) * 2);
+                }
+                w[k] = v;
+                keep[k] = true;
+            }
+            return;
+        }
+        // (pieces outside the tile read the first bytes of the buffer and are zeroed
+        // afterwards: loads without a branch around them stay in flight together ...
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k)
+            w[k] = *reinterpret_cast<const bb_u4 *>(wants[k] ? ptrs[k] : reinterpret_cast<const uint16_t *>(a.buf));
+        // (... when they are written to LDS, not here: a use of the values at this point
+        // would wait for the loads that are meant to fly during the stores of the tile before)
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) keep[k] = wants[k];
     };
 
     uint64_t step = blockIdx.x;
-    if (step < nwork) issue(step, nxt, nxt_valid);
+    if (step < nwork) issue(step, nxt, nxt_keep, nxt_valid);
     for (; step < nwork; step += gridDim.x) {
         // registers -> LDS image of this tile
         const bool valid = nxt_valid;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) {
             const uint32_t g = (uint32_t)k * BB_BLOCK + tid;
+            if (!nxt_keep[k]) nxt[k] = bb_u4{0u, 0u, 0u, 0u};
             uint32_t base;
             if (LAYOUT == 0) {
                 const uint32_t c = g / LPR, piece = g % LPR;
@@ -176,7 +200,7 @@ void k_decode_i8_xpose(bb_tiled_args a)
         }
         __syncthreads();
         const uint64_t next = step + gridDim.x;
-        if (next < nwork) issue(next, nxt, nxt_valid);
+        if (next < nwork) issue(next, nxt, nxt_keep, nxt_valid);
 
         // LDS -> global
         const uint64_t work = bb_perm(a.perm, step);
@@ -224,4 +248,13 @@ void k_decode_i8_xpose(bb_tiled_args a)
         }
         __syncthreads();
     }
+}
+
+template <int LAYOUT, bool NT, int ROWS, int TC>
+__global__ __launch_bounds__(BB_BLOCK, 6)
+void k_decode_i8_xpose(bb_tiled_args a)
+{
+    __shared__ uint32_t s_d[(ROWS * 64 / TC / 2) * (TC + 1)];
+    if (a.cmap) bb_xpose_body<LAYOUT, NT, ROWS, TC, true>(a, s_d);
+    else bb_xpose_body<LAYOUT, NT, ROWS, TC, false>(a, s_d);
 }
