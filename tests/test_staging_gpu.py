@@ -201,3 +201,51 @@ def test_write_device_bytes_to_files_and_streams(tmp_path, monkeypatch):
     staging.write_device_bytes(full, torch.zeros(1000, dtype=torch.uint8, device='cuda'))
     with pytest.raises(OSError):
         staging.finish_writes(full)
+
+
+def test_new_host_arrays_live_on_pinned_memory_up_to_a_limit(monkeypatch):
+    """`asnumpy(t)` / the plugin modules' ``read()``: results of 1 MiB to 1 GiB are
+    NumPy arrays on pinned memory (no host copy), accounted while they are alive;
+    beyond the outstanding limit, and for larger arrays, the staged copy into
+    ordinary memory takes over.  Same values either way."""
+    import gc
+    import torch
+    import baseband_amd
+    from baseband_amd import staging
+    dev = torch.device('cuda', 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    t = torch.randn((3 << 20) + 5, generator=g, device=dev)          # 12 MiB
+    c = torch.view_as_complex(torch.randn((1 << 19, 3, 2), generator=g, device=dev))
+    gc.collect()
+    before = staging._pinned_results['bytes']
+    a = baseband_amd.asnumpy(t)
+    assert a.dtype == np.float32 and a.shape == tuple(t.shape) and a.flags.writeable and not a.flags.owndata
+    assert staging._pinned_results['bytes'] == before + t.numel() * 4
+    assert np.array_equal(a, t.cpu().numpy())
+    b = baseband_amd.asnumpy(c)
+    assert b.dtype == np.complex64 and b.shape == (1 << 19, 3) and np.array_equal(b, c.cpu().numpy())
+    view = a[100:200]
+    del a, b
+    gc.collect()
+    assert staging._pinned_results['bytes'] == before + t.numel() * 4    # a view keeps its array, memory and account
+    assert np.array_equal(view, t[100:200].cpu().numpy())
+    del view
+    gc.collect()
+    assert staging._pinned_results['bytes'] == before
+    # small results: a plain copy
+    small = baseband_amd.asnumpy(t[:1000])
+    assert small.flags.owndata or small.base is not None
+    assert staging._pinned_results['bytes'] == before
+    # the outstanding limit: ordinary memory from there on
+    monkeypatch.setattr(staging, '_PINNED_RESULT_TOTAL', before + 16 * (1 << 20))
+    keep = [baseband_amd.asnumpy(t) for _ in range(3)]
+    assert staging._pinned_results['bytes'] == before + t.numel() * 4   # one fitted
+    assert all(np.array_equal(k, keep[0]) for k in keep) and keep[1].flags.owndata
+    # larger than the per-array limit: staged copy
+    monkeypatch.setattr(staging, '_PINNED_RESULT_MAX', 1 << 20)
+    big = baseband_amd.asnumpy(t)
+    assert big.flags.owndata and np.array_equal(big, keep[0])
+    del keep, big
+    gc.collect()
+    assert staging._pinned_results['bytes'] == before
