@@ -747,11 +747,15 @@ class GPUStreamReaderBase:
         if self._pending_warning:
             warnings.warn(self._pending_warning)
             self._pending_warning = None
-        ahead = self._from_decoded_ahead(count) if count else None
+        host = self.host_results and out is None
+        ahead = self._from_decoded_ahead(count, host) if count else None
         if ahead is not None:
             self.offset += count
             self._seq_end = self.offset
             if out is None:
+                if host and isinstance(ahead, torch.Tensor):
+                    from ..staging import download_new
+                    return download_new(ahead)
                 return ahead
             if isinstance(out, torch.Tensor):
                 out.copy_(ahead)
@@ -773,12 +777,23 @@ class GPUStreamReaderBase:
             return out
         data = self._squeeze_and_subset(data)
         if out is None:
+            if host:
+                from ..staging import download_new
+                return download_new(data)
             return data
         if isinstance(out, torch.Tensor):
             out.copy_(data)
         else:
             _to_host_array(data, out)
         return out
+
+    # ``host_results = True``: ``read()`` without `out` returns NEW NumPy arrays, as the
+    # reference does (what the ``baseband.io`` plugin modules switch on): arrays on pinned
+    # memory filled by the DMA engine (`staging.download_new`), and -- in loops of small
+    # sequential reads -- pieces cut out of a host copy of the decoded window.
+    host_results = False
+    host_window_copy_below = 256 << 10  # results up to this size come out of the window's host copy
+    _decoded_host = None                # (the window tensor it mirrors, NumPy array on pinned memory)
 
     # -- decoded read-ahead for loops of small sequential reads
     decode_ahead = True                 # set False to decode exactly what every read() asks for
@@ -788,7 +803,7 @@ class GPUStreamReaderBase:
     _seq_run = 0                        # consecutive reads that continued the one before
     _ahead_sets = 16                    # frame sets in the next window (x4 per refill)
 
-    def _from_decoded_ahead(self, count):
+    def _from_decoded_ahead(self, count, host=False):
         """Frame-at-a-time loops (the reference's own way through a file, and
         many user scripts) cost a scan, an index and a decode launch per
         ``read()`` -- tens of microseconds of host time for a microsecond of
@@ -809,7 +824,7 @@ class GPUStreamReaderBase:
         self._seq_run += 1
         d = self._decoded
         if d is not None and d[0] <= off and off + count <= d[1]:
-            return self._ahead_result(d[2][off - d[0]:off - d[0] + count])
+            return self._ahead_result(d[2][off - d[0]:off - d[0] + count], off - d[0], host)
         self._decoded = None
         if self._seq_run < 2:
             return None
@@ -846,18 +861,29 @@ class GPUStreamReaderBase:
         self._ahead_sets = min(max_sets, self._ahead_sets * 4)
         data = self._squeeze_and_subset(data)
         self._decoded = (first * spf, min(last * spf, self.shape[0]), data)
-        return self._ahead_result(data[off - first * spf:off - first * spf + count])
+        return self._ahead_result(data[off - first * spf:off - first * spf + count], off - first * spf, host)
 
     decode_ahead_copy_below = 1 << 20   # results smaller than this are copies, not views of the window
 
-    def _ahead_result(self, part):
+    def _ahead_result(self, part, lo=0, host=False):
         """What a read served from the decoded window returns.  The reference
         hands out fresh arrays (base/base.py:919-969); a VIEW of the window
         would keep all of it (up to `decode_ahead_bytes`) alive for as long as
         the caller keeps a few samples, so small results are copied out --
         larger ones, where the copy would cost as much as the decode, stay
         views (documented; `decode_ahead_copy_below = 0` turns copying off)."""
-        if part.numel() * part.element_size() < self.decode_ahead_copy_below:
+        nbytes = part.numel() * part.element_size()
+        if host and nbytes <= self.host_window_copy_below:
+            # a frame-at-a-time loop that wants NumPy arrays: one device-to-host copy per
+            # WINDOW (1.2 ms for 64 MiB), then every read is a memcpy of its piece -- a
+            # synchronous copy per read cost 25 us of the 38 us a read(32000) took
+            window = self._decoded[2]
+            mirror = self._decoded_host
+            if mirror is None or mirror[0] is not window:
+                from ..staging import download_new
+                mirror = self._decoded_host = (window, download_new(window))
+            return mirror[1][lo:lo + part.shape[0]].copy()
+        if nbytes < self.decode_ahead_copy_below:
             return part.clone()
         return part
 
@@ -1101,7 +1127,7 @@ class GPUStreamReaderBase:
 
     def _drop_windows(self):
         """Forget the read-ahead windows."""
-        self._ahead = self._decoded = None
+        self._ahead = self._decoded = self._decoded_host = None
 
     _nbad = None        # device counter the verification kernel adds to
     _nmissing = 0       # frames a window should have held but the file did not

@@ -288,6 +288,9 @@ class BlockStreamReader(GPUStreamReaderBase):
         data = self._squeeze_and_subset(data)
         self.offset += count
         if out is None:
+            if self.host_results:           # (what the plugin modules switch on: NumPy arrays, base/base.py)
+                from ..staging import download_new
+                return download_new(data)
             return data
         if isinstance(out, torch.Tensor):
             out.copy_(data)

@@ -250,7 +250,12 @@ class ReferenceTyped(_View):
 
     def read_tensor(self, count=None, out=None):
         """The decoded samples where they are: a device tensor."""
-        return self._wrapped.read(count, out=out)
+        wrapped = self._wrapped
+        was, wrapped.host_results = getattr(wrapped, 'host_results', False), False
+        try:
+            return wrapped.read(count, out=out)
+        finally:
+            wrapped.host_results = was
 
     def write(self, data, valid=True):
         return self._wrapped.write(_plain(data), valid=valid)
@@ -263,6 +268,8 @@ def make_module_api(fmt):
     def open(name, mode='rs', **kwargs):
         opened = module.open(_plain(name), mode, **{k: _plain(v) for k, v in kwargs.items()})
         if 's' in mode or len(mode) == 1:
+            if hasattr(opened, 'host_results'):
+                opened.host_results = True              # read() hands out NumPy arrays (base/base.py)
             return ReferenceTyped(opened)
         return (FileWriterView if 'w' in mode else FileReaderView)(opened)      # 'rb' / 'wb', GSB 'rt' / 'wt'
 

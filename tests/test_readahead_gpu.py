@@ -425,3 +425,39 @@ def test_abandoned_windows_leave_no_bad_frame_count_behind(manifest):
         assert int(fh._nbad.item()) == 0 and fh._nmissing == 0 and fh._checked is False
         fh.seek(0)
         fh.read(fh.samples_per_frame)            # no spurious "wrong frame number"
+
+
+def test_host_results_small_read_loops_come_from_the_window_mirror(tmp_path):
+    """``host_results = True`` (what the plugin modules switch on): ``read()`` returns
+    new NumPy arrays; in a loop of small sequential reads they are cut out of ONE host
+    copy per decoded window.  Same samples as the device path, read for read, also
+    across window refills, a seek, and with verify off."""
+    import numpy as np
+    import torch
+    from baseband_amd import vdif, synth
+    image, h0 = synth.random_vdif(11, 700, payload_nbytes=8000, frame_rate=1000)
+    p = tmp_path / 'loop.vdif'
+    image.tofile(str(p))
+    with vdif.open(str(p), 'rs', sample_rate=32e6) as ref:
+        want = ref.read().cpu().numpy()
+    for verify in ('fix', False):
+        with vdif.open(str(p), 'rs', sample_rate=32e6, verify=verify) as fh:
+            fh.host_results = True
+            pos, sizes, mirrors = 0, [32000] * 40 + [5000, 27000, 64000, 1000] * 20 + [32000] * 100, set()
+            for n in sizes:
+                got = fh.read(n)
+                assert isinstance(got, np.ndarray) and got.flags.writeable and got.shape == (n,)
+                assert np.array_equal(got, want[pos:pos + n]), pos
+                pos += n
+                if fh._decoded_host is not None:
+                    mirrors.add(id(fh._decoded_host[1]))
+            assert 1 <= len(mirrors) <= 8                   # a few windows, not one copy per read
+            got[:] = 0                                      # results are the caller's own
+            fh.seek(123)
+            assert np.array_equal(fh.read(1000), want[123:1123])
+            big = fh.read(3000000)                          # a large result: its own pinned array
+            assert isinstance(big, np.ndarray) and np.array_equal(big, want[1123:3001123])
+            out = torch.empty(32000, device='cuda')
+            assert fh.read(out=out) is out                  # `out` decides, as before
+            fh.host_results = False
+            assert isinstance(fh.read(32000), torch.Tensor)

@@ -56,3 +56,34 @@ for chunk in (1 << 24, 1 << 27):
         return n
     timed("loop of fh.read(%d) -> NumPy" % chunk, loop)
 os.remove(path)
+
+# ---- small reads and a writer, as a script written against the reference does them
+image.tofile(path)
+for chunk in (32000, 320000, 3200000):
+    with pv.open(path, 'rs', sample_rate=32e6) as fh:
+        fh.read(chunk)
+        n = min(2000, fh.shape[0] // chunk - 1)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            x = fh.read(chunk)
+        dt = time.perf_counter() - t0
+    print(json.dumps(dict(case="loop of fh.read(%d) -> NumPy" % chunk, reads=n, us_per_read=round(dt / n * 1e6, 1),
+                          Msamples_per_s=round(n * chunk / dt / 1e6, 1))), flush=True)
+with pv.open(path, 'rs', sample_rate=32e6) as fh:
+    h0v = fh.header0
+    data = fh.read(64 * 1000 * 32000 // 8)            # 8000 frames = 1.0 GB of float32
+os.remove(path)
+wpath = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'bb_dropin_w.vdif')
+for piece in (data.shape[0], 32000 * 100):
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        with pv.open(wpath, 'ws', header0=h0v, sample_rate=32e6, nthread=1) as fw:
+            for lo in range(0, data.shape[0], piece):
+                fw.write(data[lo:lo + piece])
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    print(json.dumps(dict(case="fw.write(NumPy), pieces of %d samples" % piece, samples=int(data.shape[0]),
+                          seconds=round(best, 4), Msamples_per_s=round(data.shape[0] / best / 1e6, 1),
+                          in_GBps=round(data.nbytes / best / 1e9, 2))), flush=True)
+os.remove(wpath)
