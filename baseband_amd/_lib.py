@@ -96,7 +96,7 @@ class VDIFScanParams(C.Structure):
                 ('header_nbytes', C.c_uint32), ('pattern', C.c_uint32 * 8),
                 ('mask', C.c_uint32 * 8), ('ref_seconds', C.c_int32),
                 ('ref_frame_nr', C.c_int32), ('frame_rate', C.c_int32),
-                ('reserved', C.c_int32)]
+                ('set_nframes', C.c_int32)]
 
 
 class Mark5BScanParams(C.Structure):

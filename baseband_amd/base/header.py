@@ -14,6 +14,45 @@ four_word_struct = struct.Struct('<4I')
 eight_word_struct = struct.Struct('<8I')
 
 
+class HeaderParser(dict):
+    """Field table of a header: ``name -> (word, bit, nbits[, default])`` in the
+    order given -- the reference's class of the same name as far as header
+    DEFINITIONS use it (base/header.py:122-286; docs/tutorials/new_edv.rst):
+    made from a tuple of ``(name, (word, bit, nbits[, default]))`` pairs or a
+    mapping, joined with ``|`` (or ``+``, the spelling before baseband 4.0),
+    with `defaults`.  Entries of 64 bits span two words."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for name, spec in dict(*args, **kwargs).items():
+            spec = tuple(spec)
+            if not 3 <= len(spec) <= 4:
+                raise ValueError("header entry {!r} needs (word, bit, nbits[, default])".format(name))
+            self[name] = spec
+
+    def __or__(self, other):
+        new = type(self)(self)
+        new.update(type(self)(other))
+        return new
+
+    __add__ = __or__
+
+    def __ior__(self, other):
+        self.update(type(self)(other))
+        return self
+
+    def copy(self):
+        return type(self)(self)
+
+    @property
+    def defaults(self):
+        """name -> default value (None where an entry has none)."""
+        return {name: (spec[3] if len(spec) > 3 else None) for name, spec in self.items()}
+
+    def __repr__(self):
+        return "{}({})".format(type(self).__name__, tuple(self.items()))
+
+
 class BitFieldHeader:
     """Header made of 32-bit little-endian words with named bit fields."""
 
@@ -46,7 +85,8 @@ class BitFieldHeader:
             raise KeyError("{0} header does not contain {1}"
                            .format(self.__class__.__name__, key))
         if nbits == 64:
-            return self.words[word] + (self.words[word + 1] << 32)
+            # (an unsigned 64-bit NumPy integer, as the reference's word arithmetic gives)
+            return np.uint64(int(self.words[word]) + (int(self.words[word + 1]) << 32))
         v = (self.words[word] >> bit) & ((1 << nbits) - 1)
         return bool(v) if nbits == 1 else v
 
@@ -64,6 +104,8 @@ class BitFieldHeader:
         elif value is True:
             value = mask                 # all bits: used for invariant masks
         else:
+            if isinstance(value, np.ndarray):       # (a one-element array, e.g. packed bits viewed as '>u8')
+                value = value.reshape(-1)[0]
             value = int(value)
             if value & mask != value:
                 raise ValueError("{0} cannot be represented with {1} bits"

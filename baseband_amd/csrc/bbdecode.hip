@@ -1152,7 +1152,9 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
     if (scan_stream && !verified) return BB_EINVAL;        // (the decode's stream waits for that event)
     void *ss = scan_stream ? scan_stream : stream;
     // three launches: scan (which also pre-sets the index to -1), index + verification, decode
-    int rc = vdif_scan_impl(d_buf, nbytes, scan, d_recs, nframes, d_src, nsets * (size_t)dec->nslot, ss);
+    bb_vdif_scan_params sp = *scan;
+    sp.set_nframes = (int32_t)recs_per_index;               // frame sets in file order (bbdecode.h)
+    int rc = vdif_scan_impl(d_buf, nbytes, &sp, d_recs, nframes, d_src, nsets * (size_t)dec->nslot, ss);
     if (rc != BB_OK) return rc;
     rc = index_verify(d_recs, nframes, d_thread_slot, dec->nslot, d_src, nsets, true, recs_per_index ? recs_per_index : 1,
                       nstrict, d_nbad, ss);

@@ -62,6 +62,20 @@ void k_vdif_scan(const uint8_t *buf, uint64_t nbytes, bb_vdif_scan_params p,
                    + (frame_nr - p.ref_frame_nr);
         else
             tidx = (int64_t)frame;
+        // Frame sets as the reference forms them (VDIFFrameSet.fromfile, vdif/frame.py:201-243):
+        // the frames that follow a set's first header with the SAME frame_nr are that
+        // set, whatever their seconds say; the set is placed by its first header.
+        if (p.set_nframes > 1 && p.frame_rate > 0) {
+            const uint64_t lead = frame - frame % (uint64_t)p.set_nframes;
+            const uint64_t loff = p.first_offset + lead * (uint64_t)p.frame_nbytes;
+            if (lead != frame && loff + 8 <= nbytes) {
+                const uint32_t l0 = *reinterpret_cast<const uint32_t *>(buf + loff);
+                const uint32_t l1 = *reinterpret_cast<const uint32_t *>(buf + loff + 4);
+                if ((int32_t)(l1 & 0x00ffffffu) == frame_nr)
+                    tidx = (int64_t)((int32_t)(l0 & 0x3fffffffu) - p.ref_seconds) * p.frame_rate
+                           + (frame_nr - p.ref_frame_nr);
+            }
+        }
         if (tidx > 0x7fffffffll) tidx = 0x7fffffffll;
         if (tidx < -0x7fffffffll) tidx = -0x7fffffffll;
         bb_frame_rec r;

@@ -98,10 +98,13 @@ class _Target:
 
 
 def vdif_scan(dbuf, nframes, frame_nbytes, header_nbytes, pattern, mask,
-              ref_seconds, ref_frame_nr, frame_rate, first_offset=0):
+              ref_seconds, ref_frame_nr, frame_rate, first_offset=0, set_nframes=0):
     """-> int32 tensor (nframes, 4): payload offset lo/hi, time_index,
-    thread_id | flags << 16 (the 16-byte bb_frame_rec)."""
+    thread_id | flags << 16 (the 16-byte bb_frame_rec).  `set_nframes`:
+    frames per frame set in file order -- sets are then formed as the
+    reference's VDIFFrameSet.fromfile forms them (include/bbdecode.h)."""
     p = _lib.VDIFScanParams()
+    p.set_nframes = set_nframes
     p.first_offset = first_offset
     p.frame_nbytes = frame_nbytes
     p.header_nbytes = header_nbytes

@@ -439,7 +439,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
             nframes = min((e - s) * nthread_file, dbuf.numel() // self._frame_nbytes)
             recs = kernels.vdif_scan(dbuf, nframes, self._frame_nbytes, h0.nbytes,
                                      self._pattern, self._mask, h0['seconds'],
-                                     h0['frame_nr'] + s, self._frame_rate)
+                                     h0['frame_nr'] + s, self._frame_rate, set_nframes=nthread_file)
             part = kernels.build_index(recs, e - s, nslot, self._thread_slot)
             part = torch.where(part >= 0, part + ranges[i][0], part)
             src[(s - first) * nslot:(e - first) * nslot] = part

@@ -8,7 +8,7 @@ small built-in leap-second table) instead of astropy ``Time``.
 """
 import numpy as np
 
-from ..base.header import (BitFieldHeader, four_word_struct,
+from ..base.header import (BitFieldHeader, HeaderParser, four_word_struct,
                            eight_word_struct)
 from ..base.quantities import as_time, hz
 
@@ -103,6 +103,15 @@ def ref_epoch_for(time):
     return int(months // 6)
 
 
+VDIF_HEADER_CLASSES = {}
+"""EDV -> header class (-1: legacy); ``VDIFHeader(words)`` and ``fromvalues(edv=...)`` return
+instances of these (all are `VDIFHeader`).  As in the reference (its metaclass,
+vdif/header.py:39-79; docs/tutorials/new_edv.rst), DEFINING a subclass of `VDIFHeader` with an
+``_edv`` (and a ``_header_parser``) enters it here; an EDV that is taken raises ValueError --
+``VDIF_HEADER_CLASSES.pop(edv)`` first to replace a class."""
+_ABSTRACT_HEADERS = ('VDIFBaseHeader', 'VDIFNoSampleRateHeader', 'VDIFSampleRateHeader')
+
+
 class VDIFHeader(BitFieldHeader):
     """VDIF header for any supported Extended Data Version.
 
@@ -111,7 +120,19 @@ class VDIFHeader(BitFieldHeader):
     (vdif/header.py:124-143).  Unknown EDVs get the base (EDV-agnostic) table.
     """
 
-    _class_edv = None       # the EDV a subclass stands for (`VDIF_HEADER_CLASSES`); None: any
+    _edv = None             # the EDV a subclass stands for (`VDIF_HEADER_CLASSES`); None: any
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        if cls.__name__ in _ABSTRACT_HEADERS:
+            return
+        edv = cls._edv
+        if edv is None:
+            raise ValueError("EDV cannot be None.  It should be overridden by the subclass.")
+        key = -1 if edv is False else edv
+        if key in VDIF_HEADER_CLASSES:
+            raise ValueError("EDV {0} already registered in VDIF_HEADER_CLASSES".format(key))
+        VDIF_HEADER_CLASSES[key] = cls
 
     def __new__(cls, words=None, edv=None, verify=True, **kwargs):
         """``VDIFHeader(words)`` returns an instance of the class registered
@@ -126,15 +147,18 @@ class VDIFHeader(BitFieldHeader):
         return super().__new__(cls)
 
     def __init__(self, words=None, edv=None, verify=True, **kwargs):
-        if edv is None and type(self)._class_edv is not None:
-            edv = type(self)._class_edv
+        if edv is None and type(self)._edv is not None:
+            edv = type(self)._edv
         if edv is None and words is not None:
             edv = False if (int(words[0]) >> 30) & 1 else (int(words[4]) >> 24) & 0xff
         self._edv = edv
         key = -1 if edv is False else edv
-        self._fields = _EDV_FIELDS.get(key, _BASE_FIELDS)
+        # the class's own table when it has one (every registered class does), else by EDV
+        parser = getattr(type(self), '_header_parser', None)
+        self._fields = parser if parser is not None else _EDV_FIELDS.get(key, _BASE_FIELDS)
         self._stream_invariants = _STREAM_INVARIANTS.get(
-            key, _STREAM_INV_COMMON | {'edv'})
+            key, _STREAM_INV_COMMON | {'edv'} | ({'sync_pattern'} & set(self._fields)))
+        self._stream_invariants = {k for k in self._stream_invariants if k in self._fields}
         self._struct = four_word_struct if edv is False else eight_word_struct
         if words is not None and edv is False:
             words = words[:4]
@@ -177,7 +201,7 @@ class VDIFHeader(BitFieldHeader):
         frame_rate = kwargs.pop('frame_rate', None)
         for key in [k for k in kwargs if k in self._fields]:
             self[key] = kwargs.pop(key)
-        for key in props:
+        for key in props + tuple(k for k in type(self)._properties if k not in props and k != 'time'):
             if key in kwargs:
                 setattr(self, key, kwargs.pop(key))
         if kwargs:
@@ -452,21 +476,25 @@ class VDIFNoSampleRateHeader(VDIFHeader):
 
 class VDIFLegacyHeader(VDIFNoSampleRateHeader):
     """Legacy four-word header (vdif/header.py:521-551)."""
-    _class_edv = False
+    _edv = False
+    _header_parser = HeaderParser(_LEGACY_FIELDS)
 
 
 class VDIFBaseHeader(VDIFHeader):
     """Eight-word header of any EDV; the table of an EDV nothing is registered
     for is the common one (vdif/header.py:554-577)."""
+    _header_parser = HeaderParser(_BASE_FIELDS)
 
 
 class VDIFHeader0(VDIFBaseHeader, VDIFNoSampleRateHeader):
     """EDV 0: words 4-7 zero (vdif/header.py:580-589)."""
-    _class_edv = 0
+    _edv = 0
+    _header_parser = HeaderParser(_EDV_FIELDS[0])
 
 
 class VDIFSampleRateHeader(VDIFBaseHeader):
     """EDVs that carry the sample rate (vdif/header.py:592-692)."""
+    _header_parser = HeaderParser(_SAMPLE_RATE_FIELDS)
 
     @property
     def frame_rate(self):
@@ -481,29 +509,26 @@ class VDIFSampleRateHeader(VDIFBaseHeader):
 
 class VDIFHeader1(VDIFSampleRateHeader):
     """EDV 1: NICT (vdif/header.py:695-706)."""
-    _class_edv = 1
+    _edv = 1
+    _header_parser = HeaderParser(_EDV_FIELDS[1])
 
 
 class VDIFHeader3(VDIFSampleRateHeader):
     """EDV 3: VLBA (vdif/header.py:709-747)."""
-    _class_edv = 3
+    _edv = 3
+    _header_parser = HeaderParser(_EDV_FIELDS[3])
 
 
 class VDIFHeader2(VDIFBaseHeader, VDIFNoSampleRateHeader):
     """EDV 2: ALMA / R2DBE (vdif/header.py:750-782)."""
-    _class_edv = 2
+    _edv = 2
+    _header_parser = HeaderParser(_EDV_FIELDS[2])
 
 
 class VDIFMark5BHeader(VDIFBaseHeader, VDIFNoSampleRateHeader):
     """EDV 0xab: a Mark 5B frame wrapped in VDIF (vdif/header.py:785-900)."""
-    _class_edv = 0xab
-
-
-VDIF_HEADER_CLASSES = {-1: VDIFLegacyHeader, 0: VDIFHeader0, 1: VDIFHeader1, 2: VDIFHeader2, 3: VDIFHeader3,
-                       0xab: VDIFMark5BHeader}
-"""EDV -> header class (-1: legacy); ``VDIFHeader(words)`` and ``fromvalues(edv=...)`` return
-instances of these (all are `VDIFHeader`).  Unlike the reference's, the table
-is not extended by subclassing (no metaclass): register a class here."""
+    _edv = 0xab
+    _header_parser = HeaderParser(_EDV_FIELDS[0xab])
 
 
 def frame_header_words(header0, nsets, thread_ids, frame_rate,

@@ -133,7 +133,14 @@ typedef struct bb_vdif_scan_params {
     int32_t  ref_seconds;     /* header0['seconds'] */
     int32_t  ref_frame_nr;    /* header0['frame_nr'] */
     int32_t  frame_rate;      /* frames per second per thread (integer Hz) */
-    int32_t  reserved;
+    int32_t  set_nframes;     /* frames per frame set in file order (threads in the file), 0 or 1: every
+                               * frame is placed by its own seconds.  With n > 1 the frames at positions
+                               * k*n .. k*n+n-1 from first_offset form a set as VDIFFrameSet.fromfile
+                               * builds it (vdif/frame.py:201-243): a frame whose frame_nr equals that of
+                               * the set's FIRST frame belongs to the set and takes its time index, whatever
+                               * its own seconds say ("we cannot always rely on header['seconds']": VLBA
+                               * files whose threads carry different seconds, sample_vlbi.vdif).
+                               * bb_vdif_read_window sets it from recs_per_index. */
 } bb_vdif_scan_params;
 
 int bb_vdif_scan(const void *d_buf, size_t nbytes,

@@ -107,8 +107,15 @@ long orc_vdif_read(const uint8_t *buf, size_t nbytes, int header_nbytes,
             w = (const uint32_t *)(buf + o);
             slot = thread_slot[(w[3] >> 16) & 0x3ff];
             if (slot < 0) continue;
-            idx = (long)((int32_t)(w[0] & 0x3fffffff) - s0) * frame_rate
-                  + (int32_t)(w[1] & 0xffffff) - f0;
+            /* a set = the frames sharing the frame_nr of its first header, placed by
+             * that header (VDIFFrameSet.fromfile, vdif/frame.py:201-243: the seconds
+             * of the other threads are not looked at) */
+            {
+                const uint32_t *wl = (const uint32_t *)(buf + (set * nthread_file) * (size_t)frame_nbytes);
+                if ((w[1] & 0xffffff) != (wl[1] & 0xffffff)) return -3;
+                idx = (long)((int32_t)(wl[0] & 0x3fffffff) - s0) * frame_rate
+                      + (int32_t)(wl[1] & 0xffffff) - f0;
+            }
             if (idx != (long)set) return -3;
             p = buf + o + header_nbytes;
             if (w[0] >> 31) {                      /* invalid_data -> fill */

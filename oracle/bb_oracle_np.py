@@ -275,9 +275,15 @@ def vdif_read(raw, frame_rate=None, fill_value=0., thread_ids=None,
             tid = int(w[3] >> 16) & 0x3ff
             if tid not in slot:
                 continue
-            idx = int((int(w[0] & 0x3fffffff) - h0['seconds']) * frame_rate
-                      + int(w[1] & 0xffffff) - h0['frame_nr'])
-            assert idx == i, "wrong frame number"      # base/base.py:1108-1110
+            # A set is the run of frames that share the frame_nr of its first header
+            # (VDIFFrameSet.fromfile, vdif/frame.py:201-216: "we cannot always rely on
+            # header['seconds']"), and it is that first header whose index is checked
+            # (frameset['seconds'] is header0's, vdif/frame.py:243; base/base.py:1108-1110).
+            wl = buf[base:base + hn].view('<u4')
+            assert int(w[1] & 0xffffff) == int(wl[1] & 0xffffff), "could not find all requested frames."
+            idx = int((int(wl[0] & 0x3fffffff) - h0['seconds']) * frame_rate
+                      + int(wl[1] & 0xffffff) - h0['frame_nr'])
+            assert idx == i, "wrong frame number"
             if w[0] >> 31:                     # base/frame.py:191-199
                 out[i * spf:(i + 1) * spf, slot[tid]] = fill_value
                 continue
