@@ -58,6 +58,12 @@ class GSBTimeStampIO(FileBase):
             t1 = self.read_timestamp().time
         return 1e9 / float((t1 - t0) / np.timedelta64(1, 'ns'))
 
+    @property
+    def info(self):
+        """What the timestamp file says by itself (gsb/file_info.py:16-95)."""
+        from .info import GSBTimeStampInfo
+        return GSBTimeStampInfo(self)
+
 
 class GSBFileReader(FileBase):
     """Raw data file: fixed-size payload blocks (gsb/base.py:78-121)."""
@@ -86,7 +92,7 @@ class GSBStreamReader(GPUStreamReaderBase):
     def __init__(self, fh_ts, fh_raw, sample_rate=None, samples_per_frame=None,
                  payload_nbytes=None, nchan=None, bps=None, complex_data=None,
                  squeeze=True, subset=(), verify=True):
-        self.fh_ts = fh_ts
+        self.fh_ts = fh_ts = fh_ts if isinstance(fh_ts, GSBTimeStampIO) else GSBTimeStampIO(fh_ts)
         sample_rate = hz(sample_rate)           # (a Quantity from callers of the reference: base/quantities.py)
         lines = [ln for ln in fh_ts.read().splitlines() if ln.strip()]
         lines = [ln.decode('ascii') if isinstance(ln, bytes) else ln for ln in lines]
@@ -123,20 +129,9 @@ class GSBStreamReader(GPUStreamReaderBase):
         self._payload_nbytes = payload_nbytes
         self._rawdump = rawdump
         self._nfiles = nfiles
-        # last usable timestamp line (gsb/base.py:314-347)
-        last = GSBHeader(lines[-1].split(), verify=False)
-        try:
-            last.verify()
-            assert len(' '.join(last.words)) >= len(' '.join(header0.words))
-            last.time
-        except Exception:
-            last = GSBHeader(lines[-2].split())
-        if rawdump:
-            dt = (last.time - header0.time) / np.timedelta64(1, 'ns') * 1e-9
-            nframes = int(round(dt * self.sample_rate / samples_per_frame)) + 1
-        else:
-            nframes = last['seq_nr'] - header0['seq_nr'] + 1
-        self._nsample = nframes * samples_per_frame
+        # (the number of frames follows from the last usable timestamp line, looked
+        # for when first asked for: `_last_header`, `_nsample`)
+        self._lines = lines
         self._start_time = header0.time
         if rawdump:
             self._images = [[host_image(fh_raw)]]
@@ -149,6 +144,56 @@ class GSBStreamReader(GPUStreamReaderBase):
     @property
     def payload_nbytes(self):
         return self._payload_nbytes
+
+    @property
+    def _last_header(self):
+        """Last header of the timestamp file; one that is cut short or does not
+        parse is passed over for the one before it, with a warning
+        (gsb/base.py:333-372)."""
+        found = self.__dict__.get('_last_header_found')
+        if found is None:
+            import warnings
+            lines, h0 = self._lines, self.header0
+            last_line = lines[-1]
+            try:
+                if len(" ".join(last_line.split())) < len(" ".join(h0.words)):
+                    raise EOFError
+                found = GSBHeader(last_line.split())
+                found.time
+            except Exception:
+                warnings.warn("The last header entry, '{0}', has an incorect "
+                              "length. Using the second-to-last entry instead.".format(last_line))
+                found = GSBHeader(lines[-2].split()) if len(lines) > 1 else h0
+            self._last_header_found = found
+        return found
+
+    @property
+    def _nsample(self):
+        n = self.__dict__.get('_nsample_found')
+        if n is None:
+            # by the TIMES of the first and the last header for both modes, as the
+            # reference counts (base/base.py:827-841): a phased stream opened with half
+            # of its raw files then claims twice the samples the files hold, which
+            # `info.consistent` reports (gsb/file_info.py:130-160)
+            last, h0 = self._last_header, self.header0
+            dt = float((last.time - h0.time) / np.timedelta64(1, 'ns')) * 1e-9
+            n = self._nsample_found = int(round(dt * self.sample_rate)) + self.samples_per_frame
+        return n
+
+    @_nsample.setter
+    def _nsample(self, value):
+        self._nsample_found = value
+
+    @property
+    def info(self):
+        """Timestamps and raw files together (gsb/file_info.py:98-184): standard
+        stream information plus `bandwidth`, `n_raw`, `payload_nbytes` and whether
+        the raw files are as long as the timestamps say (`consistent`)."""
+        from .info import GSBStreamReaderInfo
+        cached = self.__dict__.get('_info')
+        if cached is None or cached.closed != self.closed:
+            cached = self.__dict__['_info'] = GSBStreamReaderInfo(self)
+        return cached
 
     def close(self):
         self._closed = True

@@ -270,6 +270,10 @@ class GUPPIHeader(dict):
         if not getattr(self, 'mutable', True):
             raise TypeError("immutable {0} does not support assignment."
                             .format(type(self).__name__))
+        if isinstance(value, tuple) and len(value) == 2 and isinstance(value[1], str):
+            # ``header[key] = value, 'comment'`` as astropy.io.fits headers take it
+            value, comment = value
+            self.comments[key.upper()] = comment
         super().__setitem__(key.upper(), value)
 
     # -- sizes and shapes (guppi/header.py:216-352)
