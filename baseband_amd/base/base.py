@@ -1208,6 +1208,35 @@ class GPUStreamReaderBase:
     _relocated = False
     _pending_warning = None
 
+    # The last header of a stream and the number of samples that follows from it are
+    # looked up when first asked for, as the reference's lazy properties are
+    # (base/base.py:827-841,1060-1077): a damaged file opens, and raises
+    # HeaderNotFoundError where its length is needed.  Formats give
+    # `_find_last_header()` and `_count_samples()`, or assign `_nsample` outright.
+    @property
+    def _last_header(self):
+        found = self.__dict__.get('_last_header_found')
+        if found is None:
+            found = self._last_header_found = self._find_last_header()
+        return found
+
+    @property
+    def _nsample(self):
+        n = self.__dict__.get('_nsample_found')
+        if n is None:
+            n = self._nsample_found = self._count_samples()
+        return n
+
+    @_nsample.setter
+    def _nsample(self, value):
+        self._nsample_found = value
+
+    def _find_last_header(self):
+        raise NotImplementedError
+
+    def _count_samples(self):
+        raise NotImplementedError
+
     def _relocate(self):
         raise NotImplementedError
 

@@ -74,6 +74,13 @@ class FileReaderInfo(_Snapshot):
             header0 = self._guarded('header0', lambda: self._first_header(reader))
         self.header0 = header0
         if header0 is None:
+            # frames can be there although no header could be made of them (Mark 5B
+            # with an impossible kday: mark5b/file_info.py:70-75 decides the format
+            # by `locate_frames` alone)
+            find = getattr(reader, '_info_format_by_search', None)
+            if find is not None:
+                with reader.temporary_offset(0):
+                    self.format = self._guarded('format', lambda: fmt if find() else None)
             self.readable = False
             return
         self.format = fmt

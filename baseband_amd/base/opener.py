@@ -103,7 +103,20 @@ class FormatOpener:
     def _handle(self, name, mode, kwargs):
         kind = source_kind(name)
         if kind == 'fh':
-            return name, None
+            # a handle the caller opened: a reader on it can still be pickled when the
+            # handle says where its bytes come from -- a sequence of named files
+            # (helpers.sequentialfile) or one named file -- as the reference's readers
+            # can (base/base.py:123-151: the file name and position travel)
+            source = None
+            if mode[0] == 'r':
+                files = getattr(name, 'files', None)
+                if isinstance(name, sf.SequentialFileReader) and files is not None \
+                        and all(isinstance(f, (str, os.PathLike)) for f in
+                                (files if isinstance(files, (list, tuple)) else [])):
+                    source = list(files) if isinstance(files, (list, tuple)) else None
+                elif isinstance(getattr(name, 'name', None), (str, os.PathLike)) and os.path.exists(name.name):
+                    source = os.fspath(name.name)
+            return name, source
         if kind == 'device':
             if mode[0] != 'r':
                 raise ValueError("a device tensor can only be opened for reading.")

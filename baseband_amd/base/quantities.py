@@ -106,6 +106,10 @@ def as_time(x):
         return np.datetime64(_jd_to_ns(utc.jd1, utc.jd2), 'ns')
     if isinstance(x, _dt.datetime) and x.tzinfo is not None:
         x = x.astimezone(_dt.timezone.utc).replace(tzinfo=None)
+    if isinstance(x, str) and '-' not in x.strip()[1:] and ':' not in x:
+        # ('56000': numpy.datetime64 would read the year 56000; astropy's Time refuses
+        # a string that is not a date, and so do the readers' ref_time / time arguments)
+        raise ValueError("time string {!r} is not a date (YYYY-MM-DD[Thh:mm:ss])".format(x))
     return np.datetime64(x, 'ns')
 
 

@@ -111,6 +111,10 @@ class DADAStreamReader(BlockStreamReader):
         self._nsample = (nframes - 1) * header0.samples_per_frame + self._last_rows
         self._spf0 = header0.samples_per_frame
         self._start_time = header0.time
+        if nframes == 1 and self._last_rows != header0.samples_per_frame:
+            # one frame, cut short: the stream's header is that frame's header with the
+            # payload size the file really holds (dada/base.py:266-270)
+            self._header0 = self._last_header
         if self.bps == 8 and not self._mkbf:
             # plain DADA samples are (pol, chan) runs of int8: a subset that
             # keeps every polarisation's same channels is folded into the decode
@@ -121,6 +125,21 @@ class DADAStreamReader(BlockStreamReader):
 
     def _image(self):
         return self.fh_raw.image()
+
+    @property
+    def _frame_rate(self):
+        return self.sample_rate / self._spf0
+
+    def _find_last_header(self):
+        """Header of the last frame; when that frame is cut short, a mutable copy whose
+        payload size is what the file holds in whole words and complete samples
+        (dada/base.py:277-306)."""
+        with self.fh_raw.temporary_offset((self._nframes - 1) * self._frame_nbytes):
+            header = self.fh_raw.read_header()
+        if self._last_rows != self._spf0:
+            header = header.copy()
+            header.payload_nbytes = self._last_rows * self._row_nbytes
+        return header
 
     def _frame_span(self, frame):
         lo = frame * self._frame_nbytes

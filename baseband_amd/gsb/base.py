@@ -145,44 +145,32 @@ class GSBStreamReader(GPUStreamReaderBase):
     def payload_nbytes(self):
         return self._payload_nbytes
 
-    @property
-    def _last_header(self):
+    def _find_last_header(self):
         """Last header of the timestamp file; one that is cut short or does not
         parse is passed over for the one before it, with a warning
         (gsb/base.py:333-372)."""
-        found = self.__dict__.get('_last_header_found')
-        if found is None:
-            import warnings
-            lines, h0 = self._lines, self.header0
-            last_line = lines[-1]
-            try:
-                if len(" ".join(last_line.split())) < len(" ".join(h0.words)):
-                    raise EOFError
-                found = GSBHeader(last_line.split())
-                found.time
-            except Exception:
-                warnings.warn("The last header entry, '{0}', has an incorect "
-                              "length. Using the second-to-last entry instead.".format(last_line))
-                found = GSBHeader(lines[-2].split()) if len(lines) > 1 else h0
-            self._last_header_found = found
+        import warnings
+        lines, h0 = self._lines, self.header0
+        last_line = lines[-1]
+        try:
+            if len(" ".join(last_line.split())) < len(" ".join(h0.words)):
+                raise EOFError
+            found = GSBHeader(last_line.split())
+            found.time
+        except Exception:
+            warnings.warn("The last header entry, '{0}', has an incorect "
+                          "length. Using the second-to-last entry instead.".format(last_line))
+            found = GSBHeader(lines[-2].split()) if len(lines) > 1 else h0
         return found
 
-    @property
-    def _nsample(self):
-        n = self.__dict__.get('_nsample_found')
-        if n is None:
-            # by the TIMES of the first and the last header for both modes, as the
-            # reference counts (base/base.py:827-841): a phased stream opened with half
-            # of its raw files then claims twice the samples the files hold, which
-            # `info.consistent` reports (gsb/file_info.py:130-160)
-            last, h0 = self._last_header, self.header0
-            dt = float((last.time - h0.time) / np.timedelta64(1, 'ns')) * 1e-9
-            n = self._nsample_found = int(round(dt * self.sample_rate)) + self.samples_per_frame
-        return n
-
-    @_nsample.setter
-    def _nsample(self, value):
-        self._nsample_found = value
+    def _count_samples(self):
+        # by the TIMES of the first and the last header for both modes, as the
+        # reference counts (base/base.py:827-841): a phased stream opened with half
+        # of its raw files then claims twice the samples the files hold, which
+        # `info.consistent` reports (gsb/file_info.py:130-160)
+        last, h0 = self._last_header, self.header0
+        dt = float((last.time - h0.time) / np.timedelta64(1, 'ns')) * 1e-9
+        return int(round(dt * self.sample_rate)) + self.samples_per_frame
 
     @property
     def info(self):

@@ -86,6 +86,14 @@ class GUPPIStreamReader(BlockStreamReader):
     def _image(self):
         return self.fh_raw.image()
 
+    @property
+    def _frame_rate(self):
+        return self.sample_rate / self.samples_per_frame        # (frames advance by samples_per_frame - overlap)
+
+    def _find_last_header(self):
+        with self.fh_raw.temporary_offset((self._nframes - 1) * self._frame_nbytes):
+            return self.fh_raw.read_header()
+
     def _pieces(self, offset, count):
         """The reference loop: the frame a read starts in is taken up to its
         END (overlap tail included); following frames are entered at their

@@ -164,18 +164,20 @@ class Mark4StreamReader(GPUStreamReaderBase):
         self._plan_channel_select(self.subset)
         if self._within_np is not None and header0.fanout * len(self._within_np) > 32:
             self._within_np, self._decode_shape = None, self._unsliced_shape
-        last = self._last_header()
+
+    def _count_samples(self):
+        last, header0 = self._last_header, self.header0
         dq = last.time_quarter_ms() - self._ref_qms
         if last.year != header0.year:
             y = header0.year
             leap = (y % 4 == 0 and (y % 100 != 0 or y % 400 == 0))
             dq += (365 + leap) * 86400 * 4000
-        self._nsample = (int(round(dq / self._frame_qms)) + 1) * self.samples_per_frame
+        return (int(round(dq / self._frame_qms)) + 1) * self.samples_per_frame
 
     def _image(self):
         return self.fh_raw.image()
 
-    def _last_header(self):
+    def _find_last_header(self):
         """Last frame of the file: searched backwards from one frame before
         the end, with a sync pattern required one frame earlier and (if inside
         the file) one later (base/base.py:1066-1077; mark4/base.py:307-314)."""
@@ -291,9 +293,13 @@ class Mark4StreamWriter(GPUStreamWriterBase):
     are dropped because the headers occupy their place on tape."""
 
     def __init__(self, fh_raw, header0=None, sample_rate=None, squeeze=True,
-                 time=None, ntrack=64, bps=2, fanout=4):
+                 time=None, ntrack=64, bps=2, fanout=4, **kwargs):
         if header0 is None:
-            header0 = Mark4Header.fromvalues(ntrack, time=time, bps=bps, fanout=fanout)
+            # (further keywords -- nchan / sample_shape, decade, ... -- are the header's,
+            # as in the reference, whose opener hands all of them to fromvalues)
+            header0 = Mark4Header.fromvalues(ntrack, time=time, bps=bps, fanout=fanout, **kwargs)
+        elif kwargs:
+            raise TypeError("unexpected keyword(s) {} next to header0".format(sorted(kwargs)))
         if sample_rate is None:
             raise ValueError("Mark 4 stream writer needs a sample_rate.")
         super().__init__(fh_raw, header0, sample_rate=sample_rate,

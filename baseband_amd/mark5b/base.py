@@ -18,7 +18,7 @@ from .header import Mark5BHeader, frame_header_words, crc16_mark5b
 from .frame import Mark5BFrame
 from ..base.writer import GPUStreamWriterBase
 from ..base.opener import FormatOpener
-from ..base.quantities import hz
+from ..base.quantities import hz, as_time
 
 __all__ = ['Mark5BFileReader', 'Mark5BFileWriter', 'Mark5BStreamReader',
            'Mark5BStreamWriter', 'open']
@@ -39,12 +39,15 @@ class Mark5BFileReader(VLBIFileReaderBase):
             needs['kday'] = needs['ref_time'] = "needed to infer full times."
         return needs
 
+    def _info_format_by_search(self):
+        return len(self.locate_frames()) > 0
+
     def _info_extras(self, header0, offset0):
         return {'offset0': offset0}
 
     def __init__(self, fh_raw, kday=None, ref_time=None, nchan=None, bps=2):
         self.kday = operator.index(kday) if kday is not None else None
-        self.ref_time = ref_time
+        self.ref_time = as_time(ref_time)       # (ValueError for what is not a time, as Time(ref_time) there)
         self.nchan = operator.index(nchan) if nchan is not None else None
         self.bps = operator.index(bps)
         super().__init__(fh_raw)
@@ -143,8 +146,9 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         self._start_time = header0.get_time(frame_rate=self._frame_rate)
         self._ref_seconds = header0.jday * 86400 + header0.seconds
         self._plan_channel_select(self.subset, payload_nbytes=header0.payload_nbytes)
-        last = self._last_header()
-        self._nsample = (self._get_index(last) + 1) * spf
+
+    def _count_samples(self):
+        return (self._get_index(self._last_header) + 1) * self.samples_per_frame
 
     def _image(self):
         return self.fh_raw.image()
@@ -157,7 +161,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
                                        + header.jday - self.header0.jday))
                          + header['frame_nr'] - self.header0['frame_nr']))
 
-    def _last_header(self):
+    def _find_last_header(self):
         """Last frame of the file: searched backwards from one frame before
         the end, with a sync word required one frame earlier and (if inside
         the file) one later (base/base.py:1066-1077)."""

@@ -229,16 +229,8 @@ class VDIFStreamReader(GPUStreamReaderBase):
         # property does: a file whose tail holds no frame of header0's thread opens,
         # and raises HeaderNotFoundError where its length is needed, vdif/base.py:492-517)
 
-    @property
-    def _nsample(self):
-        n = self.__dict__.get('_nsample_found')
-        if n is None:
-            n = self._nsample_found = (self._get_index(self._last_header) + 1) * self.samples_per_frame
-        return n
-
-    @_nsample.setter
-    def _nsample(self, value):
-        self._nsample_found = value
+    def _count_samples(self):
+        return (self._get_index(self._last_header) + 1) * self.samples_per_frame
 
     _can_relocate = True
 
@@ -319,17 +311,10 @@ class VDIFStreamReader(GPUStreamReaderBase):
                    * self._frame_rate
                    + header['frame_nr'] - self.header0['frame_nr'])
 
-    @property
-    def _last_header(self):
+    def _find_last_header(self):
         """Last header of header0's thread, searching backwards from the end
         of the file (vdif/base.py:492-517); HeaderNotFoundError if the last
         two frame sets' worth of bytes hold none."""
-        found = self.__dict__.get('_last_header_found')
-        if found is None:
-            found = self._last_header_found = self._find_last_header()
-        return found
-
-    def _find_last_header(self):
         hw = self.fh_raw._header_table(self.header0)
         nfull = len(self._image()) // self._frame_nbytes
         look = 2 * len(self._file_threads) + 1
