@@ -322,7 +322,13 @@ class PayloadBase:
         if type(other) is not type(self):
             return False
         same_meta = (self.shape, self.dtype) == (other.shape, other.dtype)
-        return same_meta and (self.words is other.words
-                              or bool(np.all(self.words == other.words)))
+        if not same_meta:
+            return False
+        if self.words is other.words:
+            return True
+        # (byte for byte: one may hold its words as int8 samples, the other as dwords)
+        a = np.ascontiguousarray(self.words).reshape(-1).view(np.uint8)
+        b = np.ascontiguousarray(other.words).reshape(-1).view(np.uint8)
+        return a.size == b.size and bool(np.array_equal(a, b))
 
     __hash__ = None

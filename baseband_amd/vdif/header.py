@@ -194,7 +194,7 @@ class VDIFHeader(BitFieldHeader):
         self['legacy_mode'] = edv is False
         if edv is not False:
             self['edv'] = edv
-        props = ('bps', 'complex_data', 'nchan', 'frame_nbytes',
+        props = ('bps', 'complex_data', 'nchan', 'sample_shape', 'frame_nbytes',
                  'payload_nbytes', 'samples_per_frame', 'station',
                  'sample_rate')
         time = kwargs.pop('time', None)
@@ -261,6 +261,7 @@ class VDIFHeader(BitFieldHeader):
         self['mark5b_frame_nr'] = mark5b_header['frame_nr']
         self['bcd_fraction'] = fraction
         self['crc'] = crc
+        self.kday = mark5b_header.kday
         return self
 
     def verify(self):
@@ -407,6 +408,15 @@ class VDIFHeader(BitFieldHeader):
     def ref_time(self):
         return ref_epoch_time(self['ref_epoch'])
 
+    @property
+    def sample_shape(self):
+        """(nchan,): the shape of a frame's complete sample (vdif/header.py:331-340)."""
+        return (self.nchan,)
+
+    @sample_shape.setter
+    def sample_shape(self, sample_shape):
+        (self.nchan,) = sample_shape
+
     def get_time(self, frame_rate=None):
         """ref_epoch + seconds + frame_nr / frame_rate as datetime64[ns]."""
         frame_nr = self['frame_nr']
@@ -526,9 +536,73 @@ class VDIFHeader2(VDIFBaseHeader, VDIFNoSampleRateHeader):
 
 
 class VDIFMark5BHeader(VDIFBaseHeader, VDIFNoSampleRateHeader):
-    """EDV 0xab: a Mark 5B frame wrapped in VDIF (vdif/header.py:785-900)."""
+    """EDV 0xab: a Mark 5B frame wrapped in VDIF (vdif/header.py:785-900): words 4-7
+    are the Mark 5B header, whose BCD time code is readable here too (`kday`, `jday`,
+    `seconds`, `fraction`) and gives the time of a frame when no frame rate is known."""
     _edv = 0xab
     _header_parser = HeaderParser(_EDV_FIELDS[0xab])
+    kday = None             # thousands of MJD (not in the header: from the Mark 5B header or `infer_kday`)
+
+    def copy(self):
+        new = super().copy()
+        new.kday = self.kday
+        return new
+
+    def infer_kday(self, ref_time):
+        ref_mjd = (as_time(ref_time) - np.datetime64('1858-11-17', 'ns')) / np.timedelta64(1, 'D')
+        self.kday = int(np.around(ref_mjd - self.jday, decimals=-3))
+
+    @property
+    def jday(self):
+        from ..base.utils import bcd_decode
+        return bcd_decode(self['bcd_jday'])
+
+    @property
+    def seconds(self):
+        from ..base.utils import bcd_decode
+        return bcd_decode(self['bcd_seconds'])
+
+    @property
+    def fraction(self):
+        """Fractional second, 'unrounded' from the 0.1 ms stamp (mark5b/header.py:206-225)."""
+        from ..base.utils import bcd_decode
+        ns = bcd_decode(self['bcd_fraction']) * 100000
+        return (156250 * ((ns + 156249) // 156250)) / 1e9
+
+    @property
+    def complex_data(self):
+        return False
+
+    @complex_data.setter
+    def complex_data(self, complex_data):
+        if complex_data:
+            raise ValueError("Mark 5B data cannot be complex.")
+
+    def __setitem__(self, item, value):
+        if item == 'complex_data':
+            self.complex_data = value           # (can only be False)
+            value = False
+        super().__setitem__(item, value)
+        if item == 'frame_nr' and 'mark5b_frame_nr' in self._fields:
+            super().__setitem__('mark5b_frame_nr', value)
+
+    def get_time(self, frame_rate=None):
+        """ref_epoch + seconds + the fraction of a second: from the frame number when a
+        frame rate is given, else from the Mark 5B time code -- which some recorders
+        leave at zero: ValueError then (vdif/header.py:841-878)."""
+        frame_nr = self['frame_nr']
+        if frame_nr and frame_rate is None:
+            fraction = self.fraction
+            if fraction == 0.:
+                raise ValueError('header does not provide correct fractional second (it is zero for '
+                                 'non-zero frame number). Please pass in a frame_rate.')
+            ref = self.ref_time
+            utc = ref + np.timedelta64(self['seconds'], 's')
+            utc = utc - np.timedelta64(_leaps_between(ref, utc), 's')
+            return utc + np.timedelta64(int(round(fraction * 1e9)), 'ns')
+        return super().get_time(frame_rate=frame_rate)
+
+    time = property(get_time, VDIFHeader.set_time)
 
 
 def frame_header_words(header0, nsets, thread_ids, frame_rate,

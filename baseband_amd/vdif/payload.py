@@ -5,6 +5,7 @@ per-bps decoder dict of the reference becomes the (coder, bps) pair handed to
 ``bb_decode_frames``; EDV 0xab payloads switch to the Mark 5B coder as in
 vdif/payload.py:151-154.
 """
+import numpy as np
 from collections import namedtuple
 
 
@@ -54,6 +55,8 @@ class VDIFPayload(PayloadBase):
             edv = header.edv
         if edv == 0xab:                                     # Mark 5B payload in a VDIF frame
             from .. import kernels
+            if data.is_complex() if hasattr(data, 'is_complex') else np.iscomplexobj(data):
+                raise ValueError("Mark 5B data cannot be complex.")
             data = kernels.as_device_samples(data)
             bps = bps if header is None else header.bps
             words = cls._encode_device(data, bps, edv=edv)
