@@ -39,6 +39,8 @@ class _Snapshot:
         return getattr(self, 'format', None) is not None
 
     def __repr__(self):
+        if getattr(self, 'closed', False):
+            return "File closed. Not parsable."
         lines = [self.title + ':']
         for name in self.attr_names:
             value = getattr(self, name, None)
@@ -51,6 +53,8 @@ class _Snapshot:
                 pad = ' ' * (len(name) + 3)
                 body = ('\n' + pad).join('{}: {}'.format(k, v) for k, v in entries.items())
                 lines.append('\n{}:  {}'.format(name, body))
+        if not self:
+            lines.append('\nNot parsable. Wrong format?')
         return '\n'.join(lines)
 
 
@@ -174,6 +178,15 @@ class StreamReaderInfo(_Snapshot):
     def __init__(self, stream):
         super().__init__()
         self.title = type(stream).__name__.replace('Reader', '') + ' information'
+        if stream.closed:
+            # nothing can be asked of a closed file: every item is an error, the info is
+            # false and says so (base/file_info.py:60-75,247-248 in the reference)
+            self.closed, self.file_info, self.format, self.readable = True, None, None, False
+            for name in ('start_time', 'stop_time', 'sample_rate', 'shape', 'bps', 'complex_data'):
+                setattr(self, name, None)
+                self.errors[name] = ValueError('I/O operation on closed file')
+            self.verify = stream.verify
+            return
         for name in ('start_time', 'stop_time', 'sample_rate', 'shape', 'bps',
                      'complex_data', 'verify'):
             setattr(self, name, self._guarded(name, lambda n=name: getattr(stream, n)))

@@ -145,6 +145,15 @@ class GSBStreamReader(GPUStreamReaderBase):
     def payload_nbytes(self):
         return self._payload_nbytes
 
+    def _check_first_frame(self):
+        """EOFError unless every raw file holds the first payload whole (what reading
+        frame 0 needs: gsb/frame.py fromfile in the reference)."""
+        for pair in self._images:
+            for img in pair:
+                if len(img) < self._payload_nbytes:
+                    raise EOFError("could not get full payload of {} bytes: raw file has {}"
+                                   .format(self._payload_nbytes, len(img)))
+
     def _find_last_header(self):
         """Last header of the timestamp file; one that is cut short or does not
         parse is passed over for the one before it, with a warning

@@ -105,6 +105,19 @@ class GSBStreamReaderInfo(StreamReaderInfo):
         self.readable = False
         if stream.closed:
             return
+        # the first frame: when it cannot be had (raw files too short for the payload
+        # size assumed), that is the one error and nothing else is checked
+        # (gsb/file_info.py:108-116,178-184: `readable` needs `frame0`)
+        try:
+            here = stream.tell()
+            try:
+                stream.seek(0)
+                stream._check_first_frame()
+            finally:
+                stream.seek(here)
+        except Exception as exc:
+            self.errors['frame0'] = exc
+            return
         self.checks['decodable'] = self._decodable(stream)
         self.consistent = self.checks['consistent'] = self._consistent(stream)
         self.readable = all(bool(v) for v in self.checks.values())

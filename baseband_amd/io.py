@@ -64,24 +64,72 @@ def _format_info(fmt, name, kwargs):
     module = importlib.import_module('baseband_amd.' + fmt)
     if fmt == 'gsb':
         try:
+            if 'raw' not in kwargs:
+                # the timestamp file alone: what it is, what it lists, and that the raw
+                # files are needed for more (gsb/file_info.py:16-95 in the reference)
+                with module.open(name, 'rt') as fh:
+                    info = fh.info
+                if info:
+                    info.used_kwargs, info.consistent_kwargs, info.inconsistent_kwargs = {}, {}, {}
+                    info.irrelevant_kwargs = dict(kwargs)
+                    return info
+                return NoInfo("not a gsb timestamp file: {}".format(info.errors))
             with module.open(name, 'rs', **kwargs) as fh:
-                return fh.info
+                info = fh.info
+            info.used_kwargs, info.consistent_kwargs, info.inconsistent_kwargs = dict(kwargs), {}, {}
+            info.irrelevant_kwargs = {}
+            return info
+        except FileNotFoundError:
+            raise
         except Exception as exc:
             return NoInfo("opening as gsb raised {!r}".format(exc))
     file_cls = module.open.classes['rb']
     stream_cls = module.open.classes['rs']
     file_kwargs = _accepts(file_cls, kwargs)
+    kwargs_error = None
     try:
         with module.open(name, 'rb', **file_kwargs) as fh:
             info = fh.info
+    except FileNotFoundError:
+        raise
+    except (TypeError, ValueError) as exc:
+        # arguments of the wrong type or value: the format can still be told without
+        # them, and the error is reported with the info ('kwargs', as the reference
+        # files it: tests/test_file_info.py::test_info_wrong_type_args there)
+        kwargs_error = exc
+        try:
+            with module.open(name, 'rb') as fh:
+                info = fh.info
+        except Exception:
+            return NoInfo("opening as {} raised {!r}".format(fmt, exc))
     except Exception as exc:
         return NoInfo("opening as {} raised {!r}".format(fmt, exc))
     if not info:
-        return NoInfo("not a {} file: {}".format(fmt, info.errors))
+        no = NoInfo("not a {} file: {}".format(fmt, info.errors))
+        no.info = info                  # (what the format's reader made of the file: shown when only it was asked)
+        return no
+    if kwargs_error is not None:
+        info.errors['kwargs'] = kwargs_error
+        for key in file_kwargs:
+            info.missing.pop(key, None)
+        if any(k in file_kwargs for k in ('kday', 'ref_time', 'decade')):
+            for key in ('kday', 'ref_time', 'decade'):
+                info.missing.pop(key, None)
+        info.used_kwargs = dict(file_kwargs)
+        info.consistent_kwargs, info.inconsistent_kwargs = {}, {}
+        info.irrelevant_kwargs = {k: v for k, v in kwargs.items() if k not in file_kwargs}
+        return info
     used = dict(file_kwargs)
     rest = {k: v for k, v in kwargs.items() if k not in used}
-    if not info.missing:
+    if not info.missing and (getattr(info, 'frame_rate', None) is not None or 'sample_rate' in kwargs):
+        # (without a frame rate from the file or a sample rate from the caller there is
+        # no stream to open: 'frame_rate' is in the errors already, base/base.py:1453-1461)
         stream_kwargs = _accepts(stream_cls, kwargs)
+        if getattr(info, 'frame_rate', None) is not None:
+            # the file says how fast it runs: a `sample_rate` from the caller is not
+            # needed to open it and is CHECKED against the file's instead
+            # (base/base.py:1453-1461 in the reference)
+            stream_kwargs.pop('sample_rate', None)
         try:
             with module.open(name, 'rs', **stream_kwargs) as fs:
                 sinfo = fs.info
@@ -112,6 +160,8 @@ def file_info(name, format=None, **kwargs):
         if info:
             return info
         reasons.append(info.reason)
+    if len(formats) == 1 and getattr(info, 'info', None) is not None:
+        return info.info                # one format asked for: its own (falsy) info, errors and all
     return NoInfo("{} does not seem formatted as any of {}.".format(name, set(formats)))
 
 

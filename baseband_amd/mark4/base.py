@@ -37,6 +37,13 @@ class Mark4FileReader(VLBIFileReaderBase):
     def _info_extras(self, header0, offset0):
         return {'ntrack': header0.ntrack, 'offset0': offset0}
 
+    def _info_format_by_search(self):
+        # (frames are there although no header could be made of them: a decade that
+        # cannot be; mark4/file_info.py decides the format by the frames alone)
+        if self.ntrack is None:
+            self.determine_ntrack()
+        return len(self.locate_frames()) > 0
+
     def _info_number_of_frames(self, header0, offset0):
         with self.temporary_offset(-header0.frame_nbytes, 2):
             self.find_header(forward=False)
