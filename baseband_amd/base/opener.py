@@ -62,8 +62,13 @@ class FormatOpener:
         the caller gives none (DADA, GUPPI: one frame per file).
     """
     def __init__(self, fmt, classes, sequencer=sf.FileNameSequencer,
-                 default_file_size=None, adopt_header=None):
+                 default_file_size=None, adopt_header=None, header_keywords=None):
         self.fmt, self.classes = fmt, dict(classes)
+        # ``f() -> set of lower-case names`` a header of this format can be built from:
+        # keywords that only fill a file-name template are not passed on to a writer
+        # (the reference pops what `header_class.fromvalues` can have used, the template
+        # pops its own: base/base.py:1737-1779); None: any keyword may be the header's
+        self.header_keywords = header_keywords
         self.sequencer = sequencer
         self.default_file_size = default_file_size
         # ``f(header) -> this package's header``: a ``header0=`` that is the
@@ -97,6 +102,11 @@ class FormatOpener:
         if mode[0] == 'r':
             for key in values.consulted.intersection(kwargs):
                 kwargs.pop(key)
+        elif self.header_keywords is not None:
+            known = self.header_keywords()
+            for key in values.consulted.intersection(kwargs):
+                if key.lower() not in known:
+                    kwargs.pop(key)
         return fns
 
     # -- handles

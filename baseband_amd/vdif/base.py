@@ -368,6 +368,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
         return data
 
     _window = None          # kernels.VDIFWindow: argument blocks of the fused window call
+    _window_unverified = None   # ... with an empty invariant mask (verify=False)
 
     def _prepare_window_state(self, device):
         super()._prepare_window_state(device)
@@ -388,12 +389,19 @@ class VDIFStreamReader(GPUStreamReaderBase):
         if self._thread_slot is None:
             self._thread_slot = kernels.thread_slot_map(self._thread_ids,
                                                         dbuf.device)
-        w = self._window
+        # verify=False: headers are not looked at beyond what places a frame (thread,
+        # frame number) -- a damaged sync pattern does not make its frame fill, as in the
+        # reference, whose verification is what is switched off (vdif/base.py:530-534):
+        # a window whose invariant mask is empty
+        which = '_window' if self.verify else '_window_unverified'
+        w = getattr(self, which)
         if w is None:
-            w = self._window = kernels.VDIFWindow(
-                self._frame_nbytes, h0.nbytes, self._pattern, self._mask, h0['seconds'], self._frame_rate,
+            w = kernels.VDIFWindow(
+                self._frame_nbytes, h0.nbytes, self._pattern,
+                self._mask if self.verify else [0] * len(self._mask), h0['seconds'], self._frame_rate,
                 h0.payload_nbytes, self._coder, self.bps, h0.nchan * (2 if self.complex_data else 1),
                 len(self._thread_ids), self.complex_data, self.fill_value)
+            setattr(self, which, w)
         if w.fill_value != self.fill_value:
             w.set_fill(self.fill_value)
         nbad = verified = None
@@ -524,8 +532,18 @@ def _adopt_header(h):
     return new.copy()
 
 
+def _header_keywords():
+    from .header import VDIF_HEADER_CLASSES
+    names = {'edv', 'verify', 'time', 'frame_rate', 'header0', 'nthread', 'squeeze', 'file_size'}
+    for cls in VDIF_HEADER_CLASSES.values():
+        names.update(cls._properties)
+        names.update(getattr(cls, '_header_parser', {}).keys())
+    return {n.lower() for n in names}
+
+
 open = FormatOpener('VDIF', {'rb': VDIFFileReader, 'wb': VDIFFileWriter, 'rs': VDIFStreamReader,
-                             'ws': VDIFStreamWriter}, adopt_header=_adopt_header)
+                             'ws': VDIFStreamWriter}, adopt_header=_adopt_header,
+                    header_keywords=_header_keywords)
 open.__doc__ = """Open VDIF file(s): ``'rb'`` gives a `VDIFFileReader`, ``'rs'`` a
 `VDIFStreamReader`, ``'ws'`` a `VDIFStreamWriter` (vdif/base.py:810-884).
 `name` may be a file name, a file handle, a list of names or a ``{file_nr}``

@@ -508,3 +508,140 @@ def test_dada_one_frame_per_second(tmp_path):
         assert fc._frame_rate == 1
         assert abs(fc.stop_time - stop_time) < np.timedelta64(1, 'ns')
         assert bool((fc.read() == data1).all())
+
+
+# ---- more of vdif/tests/test_vdif.py: test_stream_verify, test_subset, test_template,
+# ---- test_bad_file_info, test_find_header_via_edv
+def test_vdif_stream_verify(tmp_path):
+    p = str(tmp_path / 'testverify.vdif')
+    with vdif.open(SAMPLE, 'rs') as fh:
+        data = fh.read()
+    # a file with a sync pattern error in the sixth set of frames
+    with vdif.open(SAMPLE, 'rb') as fh, vdif.open(p, 'wb') as fw:
+        fr = fh.read_frameset()
+        fr = fr.fromdata(fr.data, fr.frames[0].header)      # a mutable copy
+        for i in range(8):
+            fr['frame_nr'] = fr['frame_nr'] + 1
+            if i == 6:
+                fr.frames[2].header['sync_pattern'] = 0xabbaabba
+            fr.tofile(fw)
+    with vdif.open(p, 'rs', verify=True) as fn:
+        assert fn.verify
+        with pytest.raises((AssertionError, ValueError)):
+            fn.read()
+        fn.seek(120000)
+        fn.verify = False
+        assert not fn.verify
+        assert bool((fn.read().reshape(-1, 20000, 8) == data[:20000]).all())
+    with vdif.open(p, 'rs', verify=False) as fn:
+        assert not fn.verify
+        assert bool((fn.read().reshape(-1, 20000, 8) == data[:20000]).all())
+
+
+def test_vdif_subset(tmp_path):
+    import torch
+    with vdif.open(SAMPLE, 'rs') as fh:
+        data = fh.read()
+        sample_rate, samples_per_frame, header0, start_time = fh.sample_rate, fh.samples_per_frame, fh.header0, fh.start_time
+    with vdif.open(SAMPLE, 'rs', subset=slice(0, 8, 2)) as fhn:
+        assert fhn.sample_shape == (4,)
+        assert bool((fhn.read() == data[:, slice(0, 8, 2)]).all())
+    with vdif.open(SAMPLE, 'rs', subset=[0]) as fhn:
+        assert fhn.sample_shape == (1,)
+        check = fhn.read()
+        assert check.shape == (data.shape[0], 1) and bool((check == data[:, :1]).all())
+    test_file = str(tmp_path / 'test.vdif')
+    with vdif.open(test_file, 'ws', sample_rate=sample_rate, samples_per_frame=samples_per_frame // 8, nthread=1,
+                   nchan=8, complex_data=header0.complex_data, bps=header0.bps, edv=header0.edv,
+                   station=header0.station, time=start_time) as fw:
+        fw.write(data)
+    with vdif.open(test_file, 'rs') as fhn:
+        assert bool((fhn.read() == data).all())
+    with vdif.open(SAMPLE, 'rs', subset=np.array([3, 7])) as fhn:
+        assert fhn.sample_shape == (2,)
+        assert bool((fhn.read() == data[:, [3, 7]]).all())
+    with vdif.open(SAMPLE, 'rs', subset=[2]) as fhn:
+        assert fhn.sample_shape == (1,)
+        assert bool((fhn.read() == data[:, 2:3]).all())
+    # an 8 thread, 4 channel file
+    data4x = torch.stack([data, data.abs(), -data, -data.abs()]).permute(1, 2, 0).contiguous()
+    with vdif.open(test_file, 'ws', sample_rate=sample_rate, samples_per_frame=samples_per_frame // 4, nthread=8,
+                   nchan=4, complex_data=header0.complex_data, bps=header0.bps, edv=header0.edv,
+                   station=header0.station, time=start_time) as fw:
+        fw.write(data4x)
+    with vdif.open(test_file, 'rs') as fhn:
+        assert fhn.sample_shape == (8, 4)
+        assert bool((fhn.read() == data4x).all())
+    with vdif.open(test_file, 'rs', subset=(6, 2)) as fhn:
+        assert fhn.sample_shape == ()
+        assert bool((fhn.read() == data4x[:, 6, 2]).all())
+    with vdif.open(test_file, 'rs', subset=(3, [1, 2])) as fhn:
+        assert fhn.sample_shape == (2,)
+        assert bool((fhn.read() == data4x[:, 3, 1:3]).all())
+    subset_md = (np.array([5, 3])[:, np.newaxis], np.array([0, 2]))
+    with vdif.open(test_file, 'rs', subset=subset_md) as fhn:
+        assert fhn.sample_shape == (2, 2)
+        check = fhn.read().cpu().numpy()
+        assert np.all(check == data4x.cpu().numpy()[(slice(None),) + subset_md])
+
+
+@pytest.mark.parametrize('template,extra_args', [('f.{file_nr:03d}.vdif', {}), ('{day}.{file_nr:03d}.vdif', {'day': 'f'})])
+def test_vdif_template(tmp_path, template, extra_args):
+    import torch
+    with vdif.open(SAMPLE, 'rs') as fh:
+        header = fh.header0.copy()
+        data = fh.read()
+        dtime = fh.stop_time - fh.start_time
+    data = torch.cat((data, data, data))
+    template = str(tmp_path / template)
+    with vdif.open(template, 'ws', file_size=16 * header.frame_nbytes, nthread=8, **header, **extra_args) as fw:
+        fw.write(data)
+    ns = np.timedelta64(1, 'ns')
+    with vdif.open(template, 'rs', **extra_args) as fn:
+        assert len(fn.fh_raw.files) == 3
+        assert fn.fh_raw.files[-1] == str(tmp_path / 'f.002.vdif')
+        assert fn.header0.time == header.time
+        assert fn.stop_time - fn.start_time - 3 * dtime < ns
+        assert bool((data == fn.read()).all())
+    with vdif.open(template.format(file_nr=2, **extra_args), 'rs') as fn:
+        assert fn.header0.time - header.time - 2 * dtime < ns
+        assert bool((data[80000:] == fn.read()).all())
+    if extra_args:
+        with pytest.raises(KeyError):
+            vdif.open(template, 'rs')
+        with pytest.raises(KeyError):
+            vdif.open(template, 'ws', file_size=16 * header.frame_nbytes, nthread=8, **header)
+    with pytest.raises(TypeError):
+        vdif.open(template, 'rs', walk='silly', **extra_args)
+
+
+def test_vdif_bad_file_info(tmp_path):
+    p = str(tmp_path / 'bps32file.vdif')
+    with vdif.open(SAMPLE, 'rb') as fr, vdif.open(p, 'wb') as fw:
+        length = fr.seek(0, 2)
+        fr.seek(0)
+        while fr.tell() != length:
+            frame = fr.read_frame()
+            frame.header.mutable = True
+            frame.header.bps = 31
+            frame.payload = vdif.VDIFPayload(frame.payload.words, frame.header)
+            fw.write_frame(frame)
+    with vdif.open(p, 'rb') as fh:
+        frame = fh.read_frame()
+        with pytest.raises(KeyError):
+            frame[0]
+    with vdif.open(p, 'rb') as fh:
+        info = fh.info
+        assert info.readable is False
+        assert 'decodable' in fh.info.errors.keys()
+        assert isinstance(fh.info.errors['decodable'], KeyError)
+    with vdif.open(p, 'rs') as fh:
+        assert fh.info.readable is False
+
+
+@pytest.mark.parametrize('name,edv', [('sample.vdif', 3), ('sample_vlbi.vdif', 3), ('sample_mwa.vdif', 0),
+                                      ('sample_arochime.vdif', 0), ('sample_bps1.vdif', 0)])
+def test_vdif_find_header_via_edv(name, edv):
+    with vdif.open(golden_path('samples/' + name), 'rb') as fh:
+        header = fh.find_header()
+    assert header is not None and header.edv == edv
