@@ -396,6 +396,29 @@ class GPUStreamReaderBase:
         """Whether the stream can be read and decoded (base/base.py:1012-1018)."""
         return bool(self.info.readable)
 
+    def writable(self):
+        """A stream reader cannot be written to (base/base.py:559-567 there)."""
+        return False
+
+    def __repr__(self):
+        """The reference's layout (base/base.py:592-599)."""
+        def attr(name):
+            try:
+                return getattr(self, name)
+            except Exception:
+                return None
+        sub = 'subset={0}, '.format(self.subset) if getattr(self, 'subset', None) else ''
+        return ("<{cls} name={name} offset={offset}\n"
+                "    sample_rate={rate}, samples_per_frame={spf},\n"
+                "    sample_shape={shape}, bps={bps},\n"
+                "    {sub}start_time={start}>"
+                .format(cls=type(self).__name__, name=getattr(self.fh_raw, 'name', None), offset=attr('offset'),
+                        rate=attr('sample_rate'), spf=attr('samples_per_frame'), shape=attr('sample_shape'),
+                        bps=attr('bps'), sub=sub, start=attr('start_time')))
+
+    def seekable(self):
+        return True
+
     @property
     def info(self):
         """`StreamReaderInfo` snapshot, renewed when `verify` changes or the
@@ -522,13 +545,16 @@ class GPUStreamReaderBase:
 
     @property
     def sample_shape(self):
-        shape = self._unsliced_shape
-        if self.squeeze:
-            shape = _apply_squeeze(shape)
-        if self.subset:
-            shape = np.empty((1,) + tuple(shape), dtype=bool)[
-                (slice(None),) + self.subset].shape[1:]
-        return tuple(shape)
+        """Shape of a complete sample, squeezed and subset as the stream is: a named
+        tuple (``fh.sample_shape.nthread``) where the dimensions have names
+        (`_sample_shape_fields`), as the reference's (base/base.py:460-485,719-775)."""
+        from .utils import named_sample_shape
+        fields = self._sample_shape_fields
+        if callable(fields):
+            fields = fields(len(self._unsliced_shape))
+        return named_sample_shape(self._unsliced_shape, fields, self.squeeze, self.subset)
+
+    _sample_shape_fields = None     # names of the dimensions of a complete sample
 
     @property
     def shape(self):

@@ -133,3 +133,44 @@ class CRCStack(CRC):
         for i in range(len(stream) - ncrc):
             stream[i:i + ncrc + 1] ^= stream[i] & taps
         return stream[-ncrc:]
+
+
+def named_sample_shape(unsliced, fields, squeeze=False, subset=()):
+    """The shape of a complete sample as the reference's streams give it
+    (base/base.py:460-485,719-775 there): a named tuple ``SampleShape`` over `fields`
+    (``nthread, nchan`` for VDIF, ``npol, nchan`` for DADA / GUPPI, ``nchan`` ...), with
+    the fields of length 1 dropped when squeezed, and -- after a `subset` -- the names of
+    the dimensions that are left when indexing each dimension by itself says so; a plain
+    tuple otherwise (advanced indexing across dimensions, nothing left, no names)."""
+    from collections import namedtuple
+    import numpy as np
+    shape = tuple(int(d) for d in unsliced)
+    if not fields or len(fields) != len(shape):
+        fields = None
+    if squeeze:
+        if fields is not None:
+            fields = [f for f, d in zip(fields, shape) if d > 1]
+        shape = tuple(d for d in shape if d > 1)
+    if subset:
+        subset = tuple(subset)
+        full = np.empty((1,) + shape, dtype=bool)[(slice(None),) + subset].shape[1:]
+        if fields is None or full == () or len(subset) > len(shape):
+            return tuple(full)
+        kept, axis = [], 0
+        try:
+            for field, dim, item in zip(fields, shape, subset + (slice(None),) * (len(shape) - len(subset))):
+                left = np.empty(dim)[item].shape
+                assert len(left) <= 1                   # (no multi-dimensional indexing of one axis)
+                if len(left) == 1:
+                    assert left[0] == full[axis]
+                    kept.append(field)
+                    axis += 1
+            assert axis == len(full)
+        except Exception:
+            return tuple(full)
+        shape, fields = tuple(full), kept
+    if fields is None:
+        return tuple(shape)
+    if not fields:
+        return namedtuple('SampleShape', [])()
+    return namedtuple('SampleShape', ','.join(fields))(*shape)

@@ -94,9 +94,37 @@ class GPUStreamWriterBase:
 
     @property
     def sample_shape(self):
-        if self.squeeze:
-            return tuple(d for d in self._unsliced_shape if d > 1)
-        return self._unsliced_shape
+        from .utils import named_sample_shape
+        fields = self._sample_shape_fields
+        if callable(fields):
+            fields = fields(len(self._unsliced_shape))
+        return named_sample_shape(self._unsliced_shape, fields, self.squeeze)
+
+    _sample_shape_fields = None
+
+    def readable(self):
+        """A stream writer cannot be read from (base/base.py:559-567 in the reference)."""
+        return False
+
+    def writable(self):
+        return not self._closed
+
+    def seekable(self):
+        return False
+
+    def __repr__(self):
+        def attr(name):
+            try:
+                return getattr(self, name)
+            except Exception:
+                return None
+        return ("<{cls} name={name} offset={offset}\n"
+                "    sample_rate={rate}, samples_per_frame={spf},\n"
+                "    sample_shape={shape}, bps={bps},\n"
+                "    start_time={start}>"
+                .format(cls=type(self).__name__, name=getattr(self.fh_raw, 'name', None), offset=attr('offset'),
+                        rate=attr('sample_rate'), spf=attr('samples_per_frame'), shape=attr('sample_shape'),
+                        bps=attr('bps'), start=attr('start_time')))
 
     @property
     def start_time(self):

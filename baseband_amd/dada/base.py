@@ -77,6 +77,7 @@ class DADAFileWriter(FileBase):
 
 class DADAStreamReader(BlockStreamReader):
     """DADA stream -> device tensor (nsample, npol, nchan)."""
+    _sample_shape_fields = ('npol', 'nchan')
 
     def __init__(self, fh_raw, squeeze=True, subset=(), verify=True):
         fh_raw = DADAFileReader(fh_raw)
@@ -247,6 +248,7 @@ class DADAStreamWriter(BlockStreamWriter):
     """DADA stream writer (dada/base.py:333-362): ``header0`` describes the
     first frame; frame k gets ``OBS_OFFSET = header0's + k * payload_nbytes``
     (dada/base.py:222-225).  Without ``header0`` the keywords make one."""
+    _sample_shape_fields = ('npol', 'nchan')
 
     def __init__(self, fh_raw, header0=None, squeeze=True, **kwargs):
         if header0 is None:

@@ -89,6 +89,7 @@ class GSBFileWriter(FileBase):
 
 
 class GSBStreamReader(GPUStreamReaderBase):
+    _sample_shape_fields = staticmethod(lambda n: ('nchan',) if n == 1 else ('nthread', 'nchan'))
     def __init__(self, fh_ts, fh_raw, sample_rate=None, samples_per_frame=None,
                  payload_nbytes=None, nchan=None, bps=None, complex_data=None,
                  squeeze=True, subset=(), verify=True):
@@ -290,6 +291,7 @@ class GSBStreamWriter(GPUStreamWriterBase):
     4-bit nibbles for rawdump, int8 pairs for phased) and written to one raw
     file (rawdump) or to ``fh_raw[pol][part]`` (phased: parts are consecutive
     in time).  Arguments and defaults as for the reader."""
+    _sample_shape_fields = staticmethod(lambda n: ('nchan',) if n == 1 else ('nthread', 'nchan'))
 
     def __init__(self, fh_ts, fh_raw, header0=None, sample_rate=None,
                  samples_per_frame=None, payload_nbytes=None, nchan=None, bps=None,

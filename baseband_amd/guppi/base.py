@@ -62,6 +62,7 @@ class GUPPIFileWriter(FileBase):
 
 class GUPPIStreamReader(BlockStreamReader):
     """GUPPI stream -> device tensor (nsample, npol, nchan)."""
+    _sample_shape_fields = ('npol', 'nchan')
 
     def __init__(self, fh_raw, squeeze=True, subset=(), verify=True):
         fh_raw = GUPPIFileReader(fh_raw)
@@ -167,6 +168,7 @@ class GUPPIStreamReader(BlockStreamReader):
 class GUPPIStreamWriter(BlockStreamWriter):
     """GUPPI stream writer (guppi/base.py:281-310): no overlap; frame k gets
     ``PKTIDX = header0's + k * packets per frame`` (guppi/base.py:209-225)."""
+    _sample_shape_fields = ('npol', 'nchan')
 
     def __init__(self, fh_raw, header0=None, squeeze=True, **kwargs):
         if header0 is None:

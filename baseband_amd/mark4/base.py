@@ -139,6 +139,7 @@ class Mark4FileWriter(FileBase):
 
 class Mark4StreamReader(GPUStreamReaderBase):
     """Mark 4 stream -> device tensor (nsample, nchan)."""
+    _sample_shape_fields = ('nchan',)
 
     def __init__(self, fh_raw, sample_rate=None, ntrack=None, decade=None, ref_time=None,
                  squeeze=True, subset=(), fill_value=0., verify='fix'):
@@ -298,6 +299,7 @@ class Mark4StreamWriter(GPUStreamWriterBase):
     """Mark 4 stream writer (mark4/base.py:315-334): (n, nchan) samples are
     track-multiplexed on the GPU; the first 160*fanout samples of every frame
     are dropped because the headers occupy their place on tape."""
+    _sample_shape_fields = ('nchan',)
 
     def __init__(self, fh_raw, header0=None, sample_rate=None, squeeze=True,
                  time=None, ntrack=64, bps=2, fanout=4, **kwargs):

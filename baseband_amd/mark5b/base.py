@@ -119,6 +119,7 @@ class Mark5BFileWriter(FileBase):
 
 class Mark5BStreamReader(GPUStreamReaderBase):
     """Mark 5B stream -> device tensor (nsample, nchan)."""
+    _sample_shape_fields = ('nchan',)
 
     def __init__(self, fh_raw, sample_rate=None, kday=None, ref_time=None, nchan=None,
                  bps=2, squeeze=True, subset=(), fill_value=0., verify='fix'):
@@ -243,6 +244,7 @@ class Mark5BStreamWriter(GPUStreamWriterBase):
     """Mark 5B stream writer (mark5b/base.py:304-353): (n, nchan) samples are
     packed on the GPU into 10000-byte payloads; every frame gets a header with
     the BCD time code and its CRC."""
+    _sample_shape_fields = ('nchan',)
 
     def __init__(self, fh_raw, header0=None, sample_rate=None, nchan=1, bps=2,
                  squeeze=True, time=None, **kwargs):

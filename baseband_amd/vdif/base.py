@@ -178,6 +178,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
     Parameters are those of the reference reader (vdif/base.py:413-440);
     ``sample_rate`` is a plain number in Hz.
     """
+    _sample_shape_fields = ('nthread', 'nchan')
 
     def __init__(self, fh_raw, sample_rate=None, squeeze=True, subset=(), fill_value=0.,
                  verify='fix'):
@@ -476,6 +477,7 @@ class VDIFStreamWriter(GPUStreamWriterBase):
     """VDIF stream writer (vdif/base.py:756-807): samples of shape
     ``(n, nthread, nchan)`` are packed on the GPU; one frame per thread and
     time step is written, threads in increasing thread_id order."""
+    _sample_shape_fields = ('nthread', 'nchan')
 
     def __init__(self, fh_raw, header0=None, sample_rate=None, nthread=1,
                  squeeze=True, **kwargs):

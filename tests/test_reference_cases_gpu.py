@@ -645,3 +645,74 @@ def test_vdif_find_header_via_edv(name, edv):
     with vdif.open(golden_path('samples/' + name), 'rb') as fh:
         header = fh.find_header()
     assert header is not None and header.edv == edv
+
+
+def test_vdif_filestreamer():
+    """vdif/tests/test_vdif.py::test_filestreamer."""
+    import torch
+    with open(SAMPLE, 'rb') as fh:
+        header = vdif.VDIFHeader.fromfile(fh)
+    ns = np.timedelta64(1, 'ns')
+    with vdif.open(SAMPLE, 'rs') as fh:
+        assert fh.readable() is True and fh.writable() is False and fh.seekable() is True
+        assert fh.closed is False
+        assert repr(fh).startswith('<VDIFStreamReader')
+        assert fh.tell() == 0
+        assert header == fh.header0
+        assert fh.sample_rate == 32e6
+        assert fh.start_time == fh.header0.time
+        assert abs(fh.time - fh.start_time) < ns
+        assert fh.time == fh.tell(unit='time')
+        assert fh.dtype == np.dtype('f4')
+        record = fh.read(12)
+        assert record.dtype == torch.float32
+        assert fh.tell() == 12
+        t12 = fh.time
+        s12 = 12 / fh.sample_rate
+        assert abs(t12 - fh.start_time - np.timedelta64(int(round(s12 * 1e9)), 'ns')) < ns
+        fh.seek(10, 1)
+        assert fh.tell() == 22
+        fh.seek(t12)
+        assert fh.tell() == 12
+        fh.seek(np.timedelta64(-int(round(s12 * 1e9)), 'ns'), 1)
+        assert fh.tell() == 0
+        with pytest.raises(ValueError):
+            fh.seek(0, 3)
+        assert fh.seek(13, 0) == fh.seek(13, 'start')
+        assert fh.seek(-13, 2) == fh.seek(-13, 'end')
+        fhseek_int = fh.seek(17, 1)
+        fh.seek(-17, 'current')
+        fhseek_str = fh.seek(17, 'current')
+        assert fhseek_int == fhseek_str
+        with pytest.raises(ValueError):
+            fh.seek(0, 'last')
+        assert fh.sample_shape == (8,)
+        assert fh.shape == (40000,) + fh.sample_shape
+        assert fh.size == np.prod(fh.shape)
+        assert fh.ndim == len(fh.shape)
+        spf_ns = np.timedelta64(int(round(fh.samples_per_frame / fh.sample_rate * 1e9)), 'ns')
+        assert abs(fh.stop_time - fh._last_header.time - spf_ns) < ns
+        assert abs(fh.stop_time - fh.start_time - np.timedelta64(int(round(fh.shape[0] / fh.sample_rate * 1e9)), 'ns')) < ns
+        fh.seek(1, 'end')
+        with pytest.raises(EOFError):
+            fh.read()
+    record = record.cpu().numpy()
+    assert record.shape == (12, 8)
+    assert np.all(record.astype(int)[:, 0] == np.array([-1, -1, 3, -1, 1, -1, 3, -1, 1, 3, -1, 1]))
+    with vdif.open(SAMPLE, 'rs') as fh:
+        assert fh.sample_shape == (8,)
+        assert fh.sample_shape.nthread == 8
+        assert fh.read(1).shape == (1, 8)
+        fh.seek(0)
+        out_squeeze = np.zeros((12, 8), np.float32)
+        fh.read(out=out_squeeze)
+        assert fh.tell() == 12
+        assert np.all(out_squeeze == record)
+    with vdif.open(SAMPLE, 'rs', squeeze=False) as fh:
+        assert fh.sample_shape == (8, 1)
+        assert fh.read(1).shape == (1, 8, 1)
+        fh.seek(0)
+        out_nosqueeze = np.zeros((12, 8, 1), np.float32)
+        fh.read(out=out_nosqueeze)
+        assert fh.tell() == 12
+        assert np.all(out_nosqueeze.squeeze() == out_squeeze)
