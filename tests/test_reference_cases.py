@@ -261,3 +261,48 @@ def test_gsb_stream_wrong_payload_warning_and_last_header():
     with gsb.open(_TS_RAW, 'rs', raw=raw, payload_nbytes=2 ** 12 - 1) as fh:
         assert 'consistent' in fh.info.warnings
         assert 'non-integer' in fh.info.warnings['consistent']
+
+
+@pytest.mark.parametrize('raw, nstream', [(_PHASED, 2), (_PHASED[:1], 2), ((_PHASED[0][:1], _PHASED[1][:1]), 1),
+                                          (_PHASED[1][1], 1)])
+def test_gsb_stream_reader_defaults(raw, nstream):
+    default_frame_rate = 100e6 / 6 / 2 ** 22
+    with gsb.open(_TS_PH, 'rs', raw=raw) as fh_r:
+        assert fh_r.sample_shape[-1] == 512
+        assert fh_r.payload_nbytes == 2 ** 22
+        assert fh_r.samples_per_frame == nstream * 2 ** 12
+        assert abs(fh_r.sample_rate / (fh_r.samples_per_frame * default_frame_rate) - 1) < 2 ** -50
+
+
+def test_gsb_phased_write_one_file_and_invalid_arguments(tmp_path):
+    with gsb.open(str(tmp_path / 'test.timstamp'), 'ws', raw=str(tmp_path / 'test.raw'), header_mode='phased',
+                  time=np.datetime64('2010-10-10')) as fh_right:
+        assert fh_right.header0.mode == 'phased'
+    with gsb.open(str(tmp_path / 'test.timstamp'), 'ws', raw=str(tmp_path / 'test.raw'),
+                  time=np.datetime64('2010-10-10')) as fh_wrong:
+        assert fh_wrong.header0.mode == 'rawdump'
+    raw_dump = os.path.join(_GSB, 'sample_gsb_rawdump.dat')
+    with pytest.raises(Exception):
+        gsb.open(_TS_RAW, 'rs', raw=_PHASED, payload_nbytes=2 ** 12)
+    with pytest.raises(ValueError):
+        gsb.open('ts.dat', 's')
+    with pytest.raises(OSError):
+        gsb.open(str(tmp_path / 'ts.bla'), raw=str(tmp_path / 'raw.bla'))
+    with pytest.raises(TypeError, match="required argument 'raw'"):
+        gsb.open(_TS_PH, 'rs')
+    with pytest.raises(ValueError, match='inconsistent'):
+        gsb.open(_TS_PH, 'rs', raw=_PHASED, payload_nbytes=32, samples_per_frame=400)
+    with pytest.raises(ValueError, match='inconsistent'):
+        gsb.open(_TS_RAW, 'rs', raw=raw_dump, payload_nbytes=32, samples_per_frame=400)
+
+
+@pytest.mark.gpu
+def test_gsb_phased_stream_one_file():
+    raw = [[_PHASED[0][0]]]
+    sample_rate = (1e8 / 3) / 2 ** 23 * 2 ** 12 / 512 / 2
+    with gsb.open(_TS_PH, 'rs', raw=raw, sample_rate=sample_rate, payload_nbytes=2 ** 12) as fh:
+        ref_data = fh.read()
+    with gsb.open(_TS_PH, 'rs', raw=raw[0][0], sample_rate=sample_rate, payload_nbytes=2 ** 12) as fh_1file:
+        assert fh_1file.header0.mode == 'phased'
+        data = fh_1file.read()
+    assert bool((data == ref_data).all())
