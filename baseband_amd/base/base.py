@@ -548,11 +548,18 @@ class GPUStreamReaderBase:
         """Shape of a complete sample, squeezed and subset as the stream is: a named
         tuple (``fh.sample_shape.nthread``) where the dimensions have names
         (`_sample_shape_fields`), as the reference's (base/base.py:460-485,719-775)."""
-        from .utils import named_sample_shape
-        fields = self._sample_shape_fields
-        if callable(fields):
-            fields = fields(len(self._unsliced_shape))
-        return named_sample_shape(self._unsliced_shape, fields, self.squeeze, self.subset)
+        # (made once per squeeze / subset setting: a named tuple CLASS is made for it,
+        # which costs a hundred microseconds -- and read() asks for the shape)
+        key = (self.squeeze, id(self.subset), tuple(self._unsliced_shape))
+        cached = self.__dict__.get('_sample_shape_cached')
+        if cached is None or cached[0] != key:
+            from .utils import named_sample_shape
+            fields = self._sample_shape_fields
+            if callable(fields):
+                fields = fields(len(self._unsliced_shape))
+            cached = self._sample_shape_cached = (
+                key, named_sample_shape(self._unsliced_shape, fields, self.squeeze, self.subset), self.subset)
+        return cached[1]
 
     _sample_shape_fields = None     # names of the dimensions of a complete sample
 

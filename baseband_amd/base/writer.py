@@ -94,11 +94,15 @@ class GPUStreamWriterBase:
 
     @property
     def sample_shape(self):
-        from .utils import named_sample_shape
-        fields = self._sample_shape_fields
-        if callable(fields):
-            fields = fields(len(self._unsliced_shape))
-        return named_sample_shape(self._unsliced_shape, fields, self.squeeze)
+        key = (self.squeeze, tuple(self._unsliced_shape))
+        cached = self.__dict__.get('_sample_shape_cached')
+        if cached is None or cached[0] != key:
+            from .utils import named_sample_shape
+            fields = self._sample_shape_fields
+            if callable(fields):
+                fields = fields(len(self._unsliced_shape))
+            cached = self._sample_shape_cached = (key, named_sample_shape(self._unsliced_shape, fields, self.squeeze))
+        return cached[1]
 
     _sample_shape_fields = None
 
