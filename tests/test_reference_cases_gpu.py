@@ -1152,3 +1152,106 @@ def test_dada_filestreamer(tmp_path):
         fw.write(pdata)
     with dada.open(dada_test_squeeze, 'rs') as fhs, dada.open(dada_test_nosqueeze, 'rs') as fhns:
         assert bool((fhs.read() == fhns.read()).all())
+
+
+def test_legacy_vdif_header(tmp_path):
+    """vdif/tests/test_vdif.py::test_legacy_vdif."""
+    words = (1 << 30 | 1, 4 << 24, 1 << 29 | 1 << 24 | 507, 1 << 26 | 0x4141)
+    header = vdif.VDIFHeader(words)
+    assert header['legacy_mode'] is True and header.edv is False
+    assert abs(header.time - np.datetime64('2002-01-01T00:00:01.000000000')) < np.timedelta64(1, 'ns')
+    assert header['frame_nr'] == 0 and header['vdif_version'] == 1
+    assert header.nchan == 2 and header.sample_shape == (2,)
+    assert header.frame_nbytes == 507 * 8 and header.nbytes == 16
+    assert header.complex_data is False and header.bps == 2
+    assert header['thread_id'] == 0 and header.station == 'AA'
+    with open(str(tmp_path / 'test.vdif'), 'w+b') as s:
+        header.tofile(s)
+        s.write(np.zeros(503, dtype=np.int64).tobytes())
+        s.seek(0)
+        header2 = vdif.VDIFHeader.fromfile(s)
+    assert header2 == header
+
+
+class TestAROCHIMEPartialCopy:
+    """vdif/tests/test_vdif.py::TestAROCHIMEPartialCopy: the upper 128 channels of the
+    ARO CHIME sample copied frame by frame, frame set by frame set, through a stream
+    reader with a channel subset, and by editing the bytes (the first 128 channels)."""
+    AROCHIME = golden_path('samples/sample_arochime.vdif')
+    sample_rate = 800e6 / 2048
+    channels = slice(0, 128)
+    nchan = 128
+
+    def setup_method(self):
+        with vdif.open(self.AROCHIME, 'rs', sample_rate=self.sample_rate) as fh:
+            self.start_time = fh.start_time
+            self.data = fh.read().cpu().numpy()
+
+    def check_file(self, out_file):
+        with vdif.open(out_file, 'rs', sample_rate=self.sample_rate) as fh:
+            assert fh.header0.nchan == self.nchan
+            assert fh.header0.samples_per_frame == 1
+            assert fh.start_time == self.start_time
+            assert fh.sample_rate == self.sample_rate
+            data = fh.read().cpu().numpy()
+        assert data.shape == (5, 2, self.nchan)
+        assert np.array_equal(data, self.data[:, :, self.channels])
+
+    def test_via_frames(self, tmp_path):
+        out_file = str(tmp_path / 'upper128_wb.vdif')
+        with vdif.open(self.AROCHIME, 'rb') as fr, vdif.open(out_file, 'wb') as fw:
+            while True:
+                try:
+                    frame = fr.read_frame()
+                except EOFError:
+                    break
+                new_header = frame.header.copy()
+                new_header.nchan = self.nchan
+                new_header.samples_per_frame = 1
+                new_data = frame[:, self.channels]
+                fw.write_frame(new_data, new_header)
+        self.check_file(out_file)
+
+    def test_via_frame_sets(self, tmp_path):
+        out_file = str(tmp_path / 'upper128_wb.vdif')
+        with vdif.open(self.AROCHIME, 'rb') as fr, vdif.open(out_file, 'wb') as fw:
+            while True:
+                try:
+                    frame_set = fr.read_frameset()
+                except EOFError:
+                    break
+                new_header = frame_set.header0.copy()
+                new_header.nchan = self.nchan
+                new_header.samples_per_frame = 1
+                new_data = frame_set[:, :, self.channels]
+                fw.write_frameset(new_data, new_header, nthread=new_data.shape[1])
+        self.check_file(out_file)
+
+    def test_via_stream_reader(self, tmp_path):
+        out_file = str(tmp_path / 'upper128_ws.vdif')
+        with vdif.open(self.AROCHIME, 'rs', sample_rate=self.sample_rate,
+                       subset=(slice(None), self.channels)) as fh:
+            data1 = fh.read()
+            assert data1.shape == (5, 2, self.nchan)
+            assert np.array_equal(data1.cpu().numpy(), self.data[:, :, self.channels])
+            out_header = fh.header0.copy()
+            out_header.nchan = self.nchan
+            out_header.samples_per_frame = 1
+            with vdif.open(out_file, 'ws', sample_rate=self.sample_rate, header0=out_header, nthread=2) as fw:
+                assert fw.start_time == self.start_time and fw.sample_rate == self.sample_rate
+                assert fw.samples_per_frame == 1 and fw.sample_shape == (2, 128)
+                fw.write(data1)
+                assert fw.tell() == fh.tell()
+                assert fw.time == fh.time
+        self.check_file(out_file)
+
+    def test_via_binary_modification(self, tmp_path):
+        out_file = str(tmp_path / 'upper128_binary_mod.vdif')
+        binary = np.fromfile(self.AROCHIME, '<u4').reshape(-1, 264)     # 1024 + 32 bytes = 264 words
+        header0 = vdif.VDIFHeader(binary[0, :8]).copy()
+        header0.nchan = 128
+        header0.samples_per_frame = 1
+        assert header0.words[2] == ((32 + 128) // 8 + (7 << 24) + (1 << 29))
+        binary[:, 2] = header0.words[2]
+        binary[:, :40].tofile(out_file)                                 # header + the first 128 channels
+        self.check_file(out_file)
