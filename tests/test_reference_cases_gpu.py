@@ -1255,3 +1255,99 @@ class TestAROCHIMEPartialCopy:
         binary[:, 2] = header0.words[2]
         binary[:, :40].tofile(out_file)                                 # header + the first 128 channels
         self.check_file(out_file)
+
+
+def test_guppi_filestreamer(tmp_path):
+    """guppi/tests/test_guppi.py::test_filestreamer."""
+    from baseband_amd import guppi
+    ns = np.timedelta64(1, 'ns')
+
+    def after(n):
+        return np.timedelta64(int(round(n / 250 * 1e9)), 'ns')
+    header, header_w = _puppi_header_w()
+    with open(PUPPI, 'rb') as fh:
+        guppi.GUPPIHeader.fromfile(fh)
+        payload = guppi.GUPPIPayload.fromfile(fh, header, memmap=False)
+    pdata = payload.data
+    start_time = header.time
+    nsample = 4 * 1024 - 3 * 64
+    with guppi.open(PUPPI, 'rs') as fh:
+        assert fh.header0 == header
+        assert fh.sample_shape == (2, 4) and fh.shape == (nsample,) + fh.sample_shape
+        assert fh.size == np.prod(fh.shape) and fh.ndim == len(fh.shape)
+        assert fh.start_time == start_time and fh.sample_rate == 250.
+        record = fh.read()
+        fh.seek(0)
+        record1 = fh.read(12)
+        assert fh.tell() == 12
+        fh.seek(1523)
+        record2 = np.zeros((2, 2, 4), dtype=np.complex64)
+        record2 = fh.read(out=record2)
+        assert np.all(record2 == record[1523:1525].cpu().numpy())      # (the stream skips the overlap)
+        assert fh.tell() == 1525
+        assert fh.time == fh.tell(unit='time')
+        assert abs(fh.time - (start_time + after(1525))) < ns
+        fh.seek(fh.start_time + after(100))
+        assert fh.tell() == 100
+        assert abs(fh.stop_time - (start_time + after(nsample))) < ns
+        fh.seek(1, 'end')
+        with pytest.raises(EOFError):
+            fh.read()
+    record1n = record1.cpu().numpy()
+    assert record1n.shape == (12, 2, 4) and record1n.dtype == np.complex64
+    assert np.all(record1n[:3] == np.array(
+        [[[-7. + 12.j, -32. - 10.j, -17. + 25.j, 16. - 5.j], [14. + 21.j, -5. - 7.j, 19. - 8.j, 7. + 7.j]],
+         [[5. - 3.j, -15. - 14.j, -8. + 14.j, -6. - 18.j], [21. - 1.j, 22. + 6.j, -30. - 13.j, 12. + 23.j]],
+         [[11. + 2.j, 9. - 13.j, 9. - 15.j, -21. - 6.j], [10. - 12.j, -3. - 10.j, -12. - 8.j, 4. - 27.j]]],
+        dtype=np.complex64))
+    assert np.all(record1n == pdata[:12].squeeze().cpu().numpy())
+    assert record2.shape == (2, 2, 4)
+    filename = str(tmp_path / 'testguppi.raw')
+    spf = header.samples_per_frame - header.overlap
+    with guppi.open(filename, 'ws', header0=header_w, squeeze=False) as fw:
+        assert fw.sample_rate == 250.
+        fw.write(pdata[:spf])
+        assert fw.start_time == start_time
+        assert abs(fw.time - (start_time + after(spf))) < ns
+    with guppi.open(filename, 'rs') as fh:
+        data = fh.read()
+        assert fh.start_time == start_time
+        assert abs(fh.time - (start_time + after(spf))) < ns
+        assert fh.stop_time == fh.time and fh.sample_rate == 250.
+    assert bool((data == pdata[:spf].squeeze()).all())
+    h = header
+    filename2 = str(tmp_path / 'testguppi2.raw')
+    with guppi.open(filename2, 'ws', time=h.time, bps=h.bps, sample_rate=h.sample_rate, pktsize=h['PKTSIZE'],
+                    overlap=0, payload_nbytes=header_w.payload_nbytes // 4, nchan=2, npol=1) as fw:
+        fw.write(pdata[:spf, 0, :2])
+        assert abs(fw.start_time - start_time) < ns
+        assert abs(fw.time - (start_time + after(spf))) < ns
+    with guppi.open(filename2, 'rs') as fh:
+        data_onepol = fh.read()
+        assert abs(fh.start_time - start_time) < ns
+        assert abs(fh.stop_time - (start_time + after(spf))) < ns
+    assert bool((data_onepol == pdata[:spf, 0, :2]).all())
+    with guppi.open(PUPPI, 'rs', subset=0) as fh:
+        assert fh.sample_shape == (4,) and fh.subset == (0,)
+        assert bool((fh.read(12) == record[:12, 0, :4]).all())
+    with guppi.open(PUPPI, 'rs', subset=(1, [1, 0])) as fh:
+        assert fh.sample_shape == (2,)
+        data_sub = fh.read()
+        assert bool((data_sub[:, 1] == record[:, 1, 0]).all())
+    with guppi.open(filename2, 'rs', squeeze=False) as fh:
+        assert fh.sample_shape == (1, 2)
+        assert fh.sample_shape.npol == 1 and fh.sample_shape.nchan == 2
+        assert fh.read(1).shape == (1, 1, 2)
+        assert fh.read(10).shape == (10, 1, 2)
+        fh.seek(0)
+        out = np.zeros((12, 1, 2), dtype=np.complex64)
+        fh.read(out=out)
+        assert fh.tell() == 12
+        assert np.all(out.squeeze() == pdata[:12, 0, :2].cpu().numpy())
+    filename3 = str(tmp_path / 'testguppi3.raw')
+    with guppi.open(filename3, 'ws', time=h.time, bps=h.bps, sample_rate=h.sample_rate, pktsize=h['PKTSIZE'],
+                    overlap=0, payload_nbytes=header_w.payload_nbytes // 4, nchan=2, npol=1, squeeze=False) as fw:
+        assert fw.sample_shape == (1, 2)
+        fw.write(pdata[:spf, 0:1, :2])
+    with guppi.open(filename3, 'rs', squeeze=False) as fh:
+        assert bool((fh.read() == pdata[:spf, 0:1, :2]).all())
