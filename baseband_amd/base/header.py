@@ -19,26 +19,52 @@ class HeaderParser(dict):
     order given -- the reference's class of the same name as far as header
     DEFINITIONS use it (base/header.py:122-286; docs/tutorials/new_edv.rst):
     made from a tuple of ``(name, (word, bit, nbits[, default]))`` pairs or a
-    mapping, joined with ``|`` (or ``+``, the spelling before baseband 4.0),
-    with `defaults`.  Entries of 64 bits span two words."""
+    mapping, joined with ``|`` (or ``+``, the spelling before baseband 4.0) to
+    another `HeaderParser`, with `defaults`, and `parsers` / `setters`: functions
+    that take the field out of, or put it into, a sequence of 32-bit words.
+    Entries of 64 bits span two words."""
 
     def __init__(self, *args, **kwargs):
         super().__init__()
-        for name, spec in dict(*args, **kwargs).items():
-            spec = tuple(spec)
-            if not 3 <= len(spec) <= 4:
-                raise ValueError("header entry {!r} needs (word, bit, nbits[, default])".format(name))
+        self.update(*args, **kwargs)
+
+    @staticmethod
+    def _checked(name, spec):
+        spec = tuple(spec)
+        if not 3 <= len(spec) <= 4:
+            raise ValueError("header entry {!r} needs (word, bit, nbits[, default])".format(name))
+        word, bit, nbits = spec[:3]
+        if not (nbits == 64 and bit == 0) and (nbits < 1 or bit + nbits > 32):
+            raise ValueError("header entry {!r}: {} bits from bit {} do not fit a 32-bit word "
+                             "(64 bits: two whole words)".format(name, nbits, bit))
+        return spec
+
+    def __setitem__(self, name, spec):
+        super().__setitem__(name, self._checked(name, spec))
+
+    def update(self, *args, **kwargs):
+        try:
+            items = dict(*args, **kwargs)
+        except (TypeError, ValueError):
+            raise ValueError("a header parser is updated from pairs of (name, (word, bit, nbits[, default])) "
+                             "or a mapping") from None
+        for name, spec in items.items():
             self[name] = spec
 
     def __or__(self, other):
+        if not isinstance(other, HeaderParser):
+            raise TypeError("can only join a HeaderParser with another HeaderParser, not {}"
+                            .format(type(other).__name__))
         new = type(self)(self)
-        new.update(type(self)(other))
+        new.update(other)
         return new
 
     __add__ = __or__
 
     def __ior__(self, other):
-        self.update(type(self)(other))
+        if not isinstance(other, HeaderParser):
+            raise TypeError("can only join a HeaderParser with another HeaderParser")
+        self.update(other)
         return self
 
     def copy(self):
@@ -48,6 +74,45 @@ class HeaderParser(dict):
     def defaults(self):
         """name -> default value (None where an entry has none)."""
         return {name: (spec[3] if len(spec) > 3 else None) for name, spec in self.items()}
+
+    @staticmethod
+    def _parser(spec):
+        word, bit, nbits = spec[:3]
+        if nbits == 64:
+            return lambda words: int(words[word]) + (int(words[word + 1]) << 32)
+        mask = (1 << nbits) - 1
+        if nbits == 1:
+            return lambda words: bool((int(words[word]) >> bit) & 1)
+        return lambda words: (int(words[word]) >> bit) & mask
+
+    @staticmethod
+    def _setter(spec):
+        word, bit, nbits = spec[:3]
+        default = spec[3] if len(spec) > 3 else None
+
+        def setter(words, value):
+            if value is None and default is not None:
+                value = default
+            value = int(value)
+            if nbits == 64:
+                words[word], words[word + 1] = value & 0xffffffff, value >> 32
+            else:
+                mask = (1 << nbits) - 1
+                if value & mask != value:
+                    raise ValueError("{0} cannot be represented with {1} bits".format(value, nbits))
+                words[word] = (int(words[word]) & ~(mask << bit) & 0xffffffff) | (value << bit)
+            return words
+        return setter
+
+    @property
+    def parsers(self):
+        """name -> function(words) giving the field's value."""
+        return {name: self._parser(spec) for name, spec in self.items()}
+
+    @property
+    def setters(self):
+        """name -> function(words, value) putting the value in (None: the default)."""
+        return {name: self._setter(spec) for name, spec in self.items()}
 
     def __repr__(self):
         return "{}({})".format(type(self).__name__, tuple(self.items()))

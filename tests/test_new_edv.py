@@ -229,3 +229,43 @@ def test_vegas_and_breakthrough_listen_headers():
             want['nbytes'], want['bps'], want['complex_data'], want['npol'], want['nchan'], want['samples_per_frame'])
         assert h0.payload_nbytes == want['payload_nbytes'] and h0.sample_rate == want['sample_rate_Hz']
         assert str(fh.start_time)[:23] == want['start_time'][:23]
+
+
+def test_header_parser_as_the_reference_tests_it():
+    """base/tests/test_header_parser.py::TestHeaderParser."""
+    header_parser = HeaderParser((('x0_16_4', (0, 16, 4)), ('x0_31_1', (0, 31, 1, False)), ('x1_0_32', (1, 0, 32)),
+                                  ('x2_0_64', (2, 0, 64, 1 << 32))))
+    extra = HeaderParser((('x4_0_32', (4, 0, 32)),))
+    new = header_parser + extra
+    assert len(new.keys()) == 5 and len(header_parser.keys()) == 4
+    new = header_parser.copy()
+    assert isinstance(new, HeaderParser)
+    new.update(extra)
+    assert len(new.keys()) == 5 and new['x4_0_32'] == (4, 0, 32)
+    with pytest.raises(TypeError):
+        header_parser + {'x4_0_32': (4, 0, 32)}
+    with pytest.raises(ValueError):
+        header_parser.copy().update(('x4_0_32', (4, 0, 32)))
+    hp = header_parser.copy()
+    words = [0x12345678, 0xffff0000, 0x0, 0xffffffff]
+    hp['0_2_8'] = (0, 2, 8, 5)
+    assert '0_2_8' in hp and hp.defaults['0_2_8'] == 5
+    assert hp.parsers['0_2_8'](words) == (words[0] >> 2) & 0xff
+    hp['0_2_8'] = (0, 1, 8, 3)
+    assert hp.defaults['0_2_8'] == 3 and hp.parsers['0_2_8'](words) == (words[0] >> 1) & 0xff
+    hp.update({'0_2_8': (0, 3, 8, 1)})
+    assert hp.defaults['0_2_8'] == 1 and hp.parsers['0_2_8'](words) == (words[0] >> 3) & 0xff
+    hp2 = header_parser + HeaderParser((('0_2_8', (0, 2, 8, 4)),))
+    assert hp2.parsers['0_2_8'](words) == (words[0] >> 2) & 0xff and hp2.defaults['0_2_8'] == 4
+    with pytest.raises(TypeError):
+        hp + {'0_2_8': (0, 2, 8, 4)}
+    with pytest.raises(Exception):
+        HeaderParser((('0_2_32', (0, 2, 32, 4)),))
+    with pytest.raises(Exception):
+        HeaderParser((('0_2_64', (0, 2, 64, 4)),))
+    # the other way round: setters
+    w = [0, 0, 0, 0]
+    hp2.setters['x2_0_64'](w, None)
+    assert w[2:] == [0, 1] and hp2.parsers['x2_0_64'](w) == 1 << 32
+    hp2.setters['x0_16_4'](w, 9)
+    assert w[0] == 9 << 16 and hp2.parsers['x0_31_1'](w) is False
