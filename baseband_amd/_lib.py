@@ -102,7 +102,7 @@ class VDIFScanParams(C.Structure):
 class Mark5BScanParams(C.Structure):
     _fields_ = [('first_offset', C.c_uint64), ('ref_seconds', C.c_int32),
                 ('ref_frame_nr', C.c_int32), ('frame_rate', C.c_int32),
-                ('reserved', C.c_int32)]
+                ('by_position', C.c_int32)]
 
 
 class DecodeParams(C.Structure):
@@ -116,7 +116,7 @@ class DecodeParams(C.Structure):
 class Mark4ScanParams(C.Structure):
     _fields_ = [('first_offset', C.c_uint64), ('ntrack', C.c_int32),
                 ('ref_year', C.c_int32), ('ref_qms', C.c_int64),
-                ('frame_qms', C.c_int32), ('reserved', C.c_int32)]
+                ('frame_qms', C.c_int32), ('by_position', C.c_int32)]
 
 
 class Mark4DecodeParams(C.Structure):

@@ -142,7 +142,10 @@ void k_mark4_scan(const uint8_t *buf, uint64_t nbytes, bb_mark4_scan_params p,
             ok = false;
         }
         int64_t tidx;
-        if (p.frame_qms > 0) {
+        if (p.by_position) {
+            ok = whole;                                 // (verify=False: by where it lies, nothing checked)
+            tidx = (int64_t)frame;
+        } else if (p.frame_qms > 0) {
             const int64_t dq = q - p.ref_qms;
             tidx = (dq >= 0 ? dq + p.frame_qms / 2 : dq - p.frame_qms / 2) / p.frame_qms;
             if (tidx * p.frame_qms != dq) ok = false;   // not on the frame grid

@@ -389,7 +389,7 @@ void k_mark5b_scan(const uint8_t *buf, uint64_t nbytes, bb_mark5b_scan_params p,
         const int secs = bb_bcd_decode(w2 & 0xfffffu, 5);
         const int32_t seconds = jday * 86400 + secs;
         int64_t tidx;
-        if (p.frame_rate > 0) {
+        if (p.frame_rate > 0 && !p.by_position) {
             int64_t ds = (int64_t)seconds - p.ref_seconds;
             // jday is modulo 1000 days (mark5b/header.py:235-262): unwrap
             if (ds < -500ll * 86400) ds += 1000ll * 86400;
@@ -403,7 +403,7 @@ void k_mark5b_scan(const uint8_t *buf, uint64_t nbytes, bb_mark5b_scan_params p,
         r.payload_offset = (int64_t)(off + 16);
         r.time_index = (int32_t)tidx;
         r.thread_id = 0;
-        r.flags = (uint16_t)((sync_ok ? BB_FRAME_OK : 0u) | (all_fill ? BB_FRAME_INVALID : 0u));
+        r.flags = (uint16_t)(((p.by_position ? whole : sync_ok) ? BB_FRAME_OK : 0u) | (all_fill ? BB_FRAME_INVALID : 0u));
         *reinterpret_cast<bb_u4 *>(&recs[frame]) = *reinterpret_cast<const bb_u4 *>(&r);
     }
 }

@@ -290,6 +290,7 @@ class Mark4StreamReader(GPUStreamReaderBase):
             # waits for this verdict alone)
             nbad, verified = self._verdict_targets()
         # the look-ahead header (record n) only has to be a header
+        w.scan.by_position = 0 if self.verify else 1        # (verify=False: frames by position, nothing checked)
         w.run(dbuf, first, nframes, n, out_flat, min(n, nframes), nbad, verified, scan_stream=self._scan_side)
         if self.verify:
             self._note_checked(nframes, missing=max(0, n - nframes))

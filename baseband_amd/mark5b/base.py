@@ -234,6 +234,7 @@ class Mark5BStreamReader(GPUStreamReaderBase):
             # waits for this verdict alone)
             nbad, verified = self._verdict_targets()
         # the look-ahead header (record n) only has to be a header
+        w.scan.by_position = 0 if self.verify else 1        # (verify=False: frames by position, nothing checked)
         w.run(dbuf, self.header0['frame_nr'] + first, nframes, n, self._within, out_flat,
               min(n, nframes), nbad, verified, scan_stream=self._scan_side)
         if self.verify:

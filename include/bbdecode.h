@@ -179,7 +179,10 @@ typedef struct bb_mark5b_scan_params {
     int32_t  ref_seconds;     /* header0 BCD jday*86400+seconds, decoded */
     int32_t  ref_frame_nr;
     int32_t  frame_rate;
-    int32_t  reserved;
+    int32_t  by_position;     /* nonzero: headers are not looked at -- every whole frame counts and is placed
+                               * by where it lies (frame k of the call = time index k): a reader with
+                               * verify=False, which in the reference reads the frame at the position of an
+                               * index and checks nothing (base/base.py:1003-1010) */
 } bb_mark5b_scan_params;
 
 int bb_mark5b_scan(const void *d_buf, size_t nbytes,
@@ -392,7 +395,7 @@ typedef struct bb_mark4_scan_params {
     int32_t  ref_year;        /* full year of header0 */
     int64_t  ref_qms;         /* header0 time, quarter-ms since start of ref_year */
     int32_t  frame_qms;       /* frame duration in quarter-ms; 0: index = position */
-    int32_t  reserved;
+    int32_t  by_position;     /* nonzero: as for bb_mark5b_scan_params (verify=False) */
 } bb_mark4_scan_params;
 
 int bb_mark4_scan(const void *d_buf, size_t nbytes,
