@@ -490,6 +490,8 @@ class VDIFStreamWriter(GPUStreamWriterBase):
             if sample_rate is None:
                 sample_rate = header0.sample_rate
             if time is not None and sample_rate is not None:
+                if 'ref_epoch' not in kwargs and 'ref_time' not in kwargs:
+                    header0.ref_time = time             # (a time without an epoch brings its own)
                 header0.set_time(time, frame_rate=sample_rate / header0.samples_per_frame)
             header0.verify()
         if sample_rate is None:

@@ -199,6 +199,11 @@ class VDIFHeader(BitFieldHeader):
                  'sample_rate')
         time = kwargs.pop('time', None)
         frame_rate = kwargs.pop('frame_rate', None)
+        sample_rate = kwargs.get('sample_rate')
+        explicit_epoch = kwargs.get('ref_epoch')
+        if 'ref_time' in kwargs:
+            explicit_epoch = ref_epoch_for(kwargs.pop('ref_time'))
+            kwargs['ref_epoch'] = explicit_epoch
         for key in [k for k in kwargs if k in self._fields]:
             self[key] = kwargs.pop(key)
         for key in props + tuple(k for k in type(self)._properties if k not in props and k != 'time'):
@@ -206,7 +211,17 @@ class VDIFHeader(BitFieldHeader):
                 setattr(self, key, kwargs.pop(key))
         if kwargs:
             raise KeyError("unknown header keywords: {}".format(sorted(kwargs)))
+        if frame_rate is not None and 'sampling_rate' in self._fields and self['sampling_rate'] == 0:
+            # headers that carry the rate take it from `frame_rate` too (a property with
+            # a setter there: vdif/header.py:660-672)
+            self.sample_rate = hz(frame_rate) * self.samples_per_frame
         if time is not None:
+            if explicit_epoch is None:
+                self.ref_time = time
+            if frame_rate is None and sample_rate is not None:
+                # (headers without a rate of their own place the time with the caller's:
+                # vdif/header.py:497-518)
+                frame_rate = hz(sample_rate) / self.samples_per_frame
             self.set_time(time, frame_rate=frame_rate)
         if verify:
             self.verify()
@@ -236,7 +251,11 @@ class VDIFHeader(BitFieldHeader):
     def update(self, *, time=None, frame_rate=None, verify=True, **kwargs):
         """As the base `update`; `time` (with `frame_rate` for non-integer
         seconds) is applied last (vdif/header.py:188-236)."""
+        # (a time without an epoch brings its own: vdif/header.py:225-226)
+        ref_time = kwargs.pop('ref_time', time if 'ref_epoch' not in kwargs else None)
         super().update(verify=False, **kwargs)
+        if ref_time is not None:
+            self.ref_time = ref_time
         if time is not None:
             self.set_time(time, frame_rate=frame_rate)
         if verify:
@@ -408,6 +427,14 @@ class VDIFHeader(BitFieldHeader):
     def ref_time(self):
         return ref_epoch_time(self['ref_epoch'])
 
+    @ref_time.setter
+    def ref_time(self, ref_time):
+        """The latest reference epoch (1 January / 1 July) not after `ref_time`
+        (vdif/header.py:408-412)."""
+        epoch = ref_epoch_for(ref_time)
+        assert epoch >= 0, "VDIF reference epochs start at 2000-01-01"
+        self['ref_epoch'] = epoch
+
     @property
     def sample_shape(self):
         """(nchan,): the shape of a frame's complete sample (vdif/header.py:331-340)."""
@@ -434,8 +461,11 @@ class VDIFHeader(BitFieldHeader):
         return utc + np.timedelta64(ns, 'ns')
 
     def set_time(self, time, frame_rate=None):
+        """Seconds and frame number for `time`, counted from the header's reference
+        epoch AS IT IS (vdif/header.py:445-479: ``header.time = t`` does not move the
+        epoch; ``header.ref_time = t`` does, and `fromvalues` takes it from `time`
+        unless a ``ref_epoch`` is given)."""
         time = as_time(time)
-        self['ref_epoch'] = ref_epoch_for(time)
         dt = int((time - self.ref_time) / np.timedelta64(1, 'ns'))
         seconds, ns = divmod(dt, 1000000000)
         seconds += _leaps_between(self.ref_time, time)

@@ -306,3 +306,100 @@ def test_gsb_phased_stream_one_file():
         assert fh_1file.header0.mode == 'phased'
         data = fh_1file.read()
     assert bool((data == ref_data).all())
+
+
+def test_vdif_header_as_the_reference_tests_it(tmp_path):
+    """vdif/tests/test_vdif.py::TestVDIF::test_header."""
+    from baseband_amd import vdif
+    ns, s1 = np.timedelta64(1, 'ns'), np.timedelta64(1, 's')
+    with open(os.path.join(S, 'sample.vdif'), 'rb') as fh:
+        header = vdif.VDIFHeader.fromfile(fh)
+    assert header.nbytes == 32 and header.edv == 3
+    mjd_ns = (header.time - np.datetime64('1858-11-17', 'ns')) / np.timedelta64(1, 'D')
+    assert int(mjd_ns) == 56824 and round((mjd_ns % 1) * 86400) == 21367
+    assert header.ref_time == np.datetime64('2014-01-01')
+    assert header.payload_nbytes == 5000 and header.frame_nbytes == 5032
+    assert header['thread_id'] == 1 and header.sample_rate == 32e6
+    assert header.samples_per_frame == 20000 and header.nchan == 1 and header.sample_shape == (1,)
+    assert header.bps == 2 and not header.complex_data and not header['complex_data']
+    assert header.mutable is False
+    with open(str(tmp_path / 'test.vdif'), 'w+b') as s:
+        header.tofile(s)
+        s.seek(0)
+        header2 = vdif.VDIFHeader.fromfile(s)
+    assert header2 == header and header2.mutable is False
+    header3 = vdif.VDIFHeader.fromkeys(**header)
+    assert header3 == header and header3.mutable is True
+    with pytest.raises(KeyError):
+        vdif.VDIFHeader.fromkeys(extra=1, **header)
+    with pytest.raises(KeyError):
+        kwargs = dict(header)
+        kwargs.pop('thread_id')
+        vdif.VDIFHeader.fromkeys(**kwargs)
+    extras = dict(loif_tuning=header['loif_tuning'], dbe_unit=header['dbe_unit'], if_nr=header['if_nr'],
+                  subband=header['subband'], sideband=header['sideband'], major_rev=header['major_rev'],
+                  minor_rev=header['minor_rev'], personality=header['personality'], _7_28_4=header['_7_28_4'])
+    header4 = vdif.VDIFHeader.fromvalues(
+        edv=header.edv, ref_epoch=header['ref_epoch'], seconds=header['seconds'], frame_nr=header['frame_nr'],
+        samples_per_frame=header.samples_per_frame, bps=header.bps, complex_data=header['complex_data'],
+        thread_id=header['thread_id'], station=header.station, sampling_unit=header['sampling_unit'],
+        sampling_rate=header['sampling_rate'], **extras)
+    header4_usetime = vdif.VDIFHeader.fromvalues(
+        edv=header.edv, time=header.time, samples_per_frame=header.samples_per_frame, station=header.station,
+        frame_rate=header.frame_rate, bps=header.bps, complex_data=header['complex_data'],
+        thread_id=header['thread_id'], **extras)
+    assert header4 == header and header4.mutable is True
+    assert header4 == header4_usetime
+    header5 = header.copy()
+    assert header5 == header and header5.mutable is True
+    header5['thread_id'] = header['thread_id'] + 1
+    assert header5['thread_id'] == header['thread_id'] + 1 and header5 != header
+    with pytest.raises(TypeError):
+        header['thread_id'] = 0
+    header5.time = header.time + s1
+    frame_rate = header.sample_rate / header.samples_per_frame
+
+    def frames(x):
+        return np.timedelta64(int(round(x / frame_rate * 1e9)), 'ns')
+    assert abs(header5.time - header.time - s1) < ns
+    assert header5['frame_nr'] == header['frame_nr']
+    header5.time = header.time + s1 + frames(1.1)
+    assert abs(header5.time - header.time - s1 - frames(1)) < ns
+    assert header5['frame_nr'] == header['frame_nr'] + 1
+    header5.time = header.time + s1 - frames(0.01)          # rounding in a corner case
+    assert abs(header5.time - header.time - s1) < ns
+    assert header5['frame_nr'] == header['frame_nr']
+    header6 = vdif.header.VDIFHeader.fromvalues(edv=100)    # an EDV nothing is registered for
+    assert type(header6) is vdif.header.VDIFBaseHeader and header6['edv'] == 100
+    headerT = header.copy()
+    headerT.time = header.time + frames(1)
+    header7 = vdif.VDIFHeader.fromvalues(
+        edv=0, ref_epoch=headerT['ref_epoch'], seconds=headerT['seconds'], frame_nr=headerT['frame_nr'],
+        complex_data=headerT.complex_data, samples_per_frame=headerT.samples_per_frame, bps=headerT.bps,
+        station=headerT.station, thread_id=headerT['thread_id'])
+    assert header7['ref_epoch'] == headerT['ref_epoch'] and header7['seconds'] == headerT['seconds']
+    assert header7['frame_nr'] == headerT['frame_nr']
+    header7_usetime = vdif.VDIFHeader.fromvalues(
+        edv=0, time=headerT.time, sample_rate=headerT.sample_rate, complex_data=headerT.complex_data,
+        bps=headerT.bps, samples_per_frame=headerT.samples_per_frame, station=headerT.station,
+        thread_id=headerT['thread_id'])
+    assert header7_usetime == header7
+    header8 = vdif.VDIFHeader.fromvalues(
+        edv=0, ref_epoch=0, time=headerT.time, sample_rate=headerT.sample_rate, complex_data=headerT.complex_data,
+        bps=headerT.bps, samples_per_frame=headerT.samples_per_frame, station=headerT.station,
+        thread_id=headerT['thread_id'])
+    assert header8.ref_time == np.datetime64('2000-01-01')
+    assert abs(header8.get_time(frame_rate=headerT.frame_rate) - headerT.time) < ns
+    assert header8['frame_nr'] == headerT['frame_nr']
+    with pytest.raises(ValueError):                         # no sample rate or frame_nr: no time
+        vdif.VDIFHeader.fromvalues(edv=0, time=headerT.time, complex_data=headerT.complex_data, bps=headerT.bps,
+                                   samples_per_frame=headerT.samples_per_frame, station=headerT.station,
+                                   thread_id=headerT['thread_id'])
+    with pytest.raises(ValueError):                         # EDV 1, 3 without a sample rate
+        vdif.VDIFHeader.fromvalues(edv=1, time=headerT.time, station=headerT.station,
+                                   samples_per_frame=headerT.samples_per_frame, bps=headerT.bps,
+                                   complex_data=headerT.complex_data, thread_id=headerT['thread_id'])
+    header9 = headerT.copy()
+    time = np.datetime64('2018-01-01T00:34:07.999999999', 'ns') + np.timedelta64(1, 'ns')   # (..996 rounds up)
+    header9.time = time
+    assert header9['seconds'] == 126232450 and header9['frame_nr'] == 0
