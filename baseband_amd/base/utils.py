@@ -174,3 +174,23 @@ def named_sample_shape(unsliced, fields, squeeze=False, subset=()):
     if not fields:
         return namedtuple('SampleShape', [])()
     return namedtuple('SampleShape', ','.join(fields))(*shape)
+
+
+class fixedvalue:
+    """A value that is the same for every instance of a class, readable on the class
+    too; setting it passes when the value is that value and raises ValueError otherwise
+    (the reference's descriptor of the same name, base/utils.py:79-90: Mark 5B's
+    ``payload_nbytes = 10000``, ``complex_data = False`` ...)."""
+
+    def __init__(self, value, name=None):
+        self.value, self.name = value, name
+
+    def __set_name__(self, owner, name):
+        self.name = name
+
+    def __get__(self, instance, owner=None):
+        return self.value
+
+    def __set__(self, instance, value):
+        if value != self.value:
+            raise ValueError("'{}' can only be set to {}.".format(self.name, self.value))

@@ -2,6 +2,7 @@
 frames (mark5b/header.py:60-68,91-97,177-185,235-262).  Times are
 ``numpy.datetime64[ns]``; ``kday`` resolves the modulo-1000 day count."""
 import numpy as np
+from ..base.utils import fixedvalue
 
 from ..base.header import BitFieldHeader, four_word_struct
 from ..base.quantities import as_time, hz
@@ -61,9 +62,9 @@ class Mark5BHeader(BitFieldHeader):
     }
     _struct = four_word_struct
     _stream_invariants = {'sync_pattern', 'user'}
-    payload_nbytes = 10000
-    frame_nbytes = 10016
-    complex_data = False
+    payload_nbytes = fixedvalue(10000)
+    frame_nbytes = fixedvalue(10016)
+    complex_data = fixedvalue(False)
     kday = None
 
     def __init__(self, words=None, kday=None, ref_time=None, verify=True):

@@ -403,3 +403,86 @@ def test_vdif_header_as_the_reference_tests_it(tmp_path):
     time = np.datetime64('2018-01-01T00:34:07.999999999', 'ns') + np.timedelta64(1, 'ns')   # (..996 rounds up)
     header9.time = time
     assert header9['seconds'] == 126232450 and header9['frame_nr'] == 0
+
+
+def test_mark5b_header_as_the_reference_tests_it(tmp_path):
+    """mark5b/tests/test_mark5b.py::test_header and (the header part of) ::test_header_times."""
+    ns = np.timedelta64(1, 'ns')
+    m5 = os.path.join(S, 'sample.m5b')
+    with open(m5, 'rb') as fh:
+        header = mark5b.Mark5BHeader.fromfile(fh, kday=56000)
+    assert header.nbytes == 16 and not header.complex_data
+    assert header.kday == 56000. and header.jday == 821
+    mjd_ = (header.time - np.datetime64('1858-11-17', 'ns')) / np.timedelta64(1, 'D')
+    assert int(mjd_) == 56821 and round((mjd_ % 1) * 86400) == 19801
+    assert header.payload_nbytes == 10000 and header.frame_nbytes == 10016
+    assert header['frame_nr'] == 0
+    assert abs(header.time - np.datetime64('2014-06-13T05:30:01.000000000')) < ns
+    with open(str(tmp_path / 'test.m5b'), 'w+b') as s:
+        header.tofile(s)
+        s.seek(0)
+        header2 = mark5b.Mark5BHeader.fromfile(s, header.kday)
+    assert header2 == header
+    header3 = mark5b.Mark5BHeader.fromkeys(header.kday, **header)
+    assert header3 == header
+    header4 = mark5b.Mark5BHeader.fromvalues(time=header.time, user=header['user'],
+                                             internal_tvg=header['internal_tvg'], frame_nr=header['frame_nr'])
+    assert header4 == header
+    with open(m5, 'rb') as fh:
+        header5 = mark5b.Mark5BHeader.fromfile(fh, ref_time=mjd(57200))
+    assert header5 == header
+    header6 = mark5b.Mark5BHeader(header.words, kday=56000)
+    assert header6.time == header.time
+    header6.payload_nbytes = 10000
+    header6.frame_nbytes = 10016
+    header6.complex_data = False
+    with pytest.raises(ValueError, match="'payload_nbytes'.*set to 10000"):
+        header6.payload_nbytes = 9999
+    with pytest.raises(ValueError):
+        header6.frame_nbytes = 20
+    with pytest.raises(ValueError):
+        header6.complex_data = True
+    header7 = header.copy()
+    assert header7 == header and header7.kday == header.kday
+    header7.time = np.datetime64('2016-09-10T12:26:40.000000000')
+    assert header7.fraction == 0.
+    with pytest.raises(AssertionError):                     # an exact MJD for kday
+        mark5b.Mark5BHeader.fromkeys(56821, **header)
+    with open(m5, 'rb') as fh:
+        header8 = mark5b.Mark5BHeader.fromfile(fh, kday=None)
+        assert header8.kday is None
+        header8.kday = 56000
+        assert header8 == header
+    # ---- times
+    with mark5b.open(m5, 'rb', kday=56000, nchan=8, bps=2) as fh:
+        header0 = mark5b.Mark5BHeader.fromfile(fh, kday=56000)
+        start_time = header0.time
+        frame_rate = 32e6 / (header0.payload_nbytes * 8 // 2 // 8)
+        fh.seek(0)
+        for k in range(4):
+            h = fh.read_header()
+            fh.seek(h.payload_nbytes, 1)
+            expected = start_time + np.timedelta64(int(round(h['frame_nr'] / frame_rate * 1e9)), 'ns')
+            assert abs(h.time - expected) < ns
+    last = h
+    header = last.copy()
+    header['bcd_fraction'] = 0
+    with pytest.raises(ValueError):
+        header.time
+    assert abs(header.get_time(frame_rate) - last.time) < ns
+    frame_rate = 128e6 / 5000                               # max frame_nr is 2**15; this makes 25600
+
+    def frames(x):
+        return np.timedelta64(int(round(x / frame_rate * 1e9)), 'ns')
+    for n in (1., 3921., 25599.):
+        header.set_time(time=start_time + frames(n), frame_rate=frame_rate)
+        assert abs(header.get_time(frame_rate) - start_time - frames(n)) < ns
+        if n == 3921.:
+            assert abs(header.time - start_time - frames(n)) < np.timedelta64(100, 'us')
+    header.set_time(time=start_time + frames(25598.53), frame_rate=frame_rate)
+    assert abs(header.get_time(frame_rate) - start_time - frames(25599.)) < ns
+    # to the nearest second when less than 2 ns away, without a frame rate
+    header.set_time(time=start_time + np.timedelta64(1, 'ns'))
+    assert header.seconds == header0.seconds
+    header.set_time(time=start_time - np.timedelta64(1, 'ns'))
+    assert header.seconds == header0.seconds
