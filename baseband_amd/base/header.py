@@ -268,9 +268,17 @@ class BitFieldHeader:
                 and list(self.words) == list(other.words))
 
     def __repr__(self):
+        """Keys and values; BCD, CRC and sync-pattern fields in hex (base/header.py:497-500,661-667)."""
+        def show(key, value):
+            if key.startswith(('bcd', 'crc', 'sync_pattern')):
+                try:
+                    return hex(int(value))
+                except Exception:
+                    pass
+            return str(value)
         name = self.__class__.__name__
         return ("<{0} {1}>".format(name, (",\n  " + len(name) * " ").join(
-            ["{0}: {1}".format(k, self[k]) for k in self.keys()])))
+            ["{0}: {1}".format(k, show(k, self[k])) for k in self.keys()])))
 
 
 def strided_header_words(buf, frame_nbytes, nwords, offset=0):

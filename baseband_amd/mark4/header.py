@@ -10,6 +10,7 @@ follow mark4/header.py:540-650.  Times are ``numpy.datetime64[ns]``.
 import struct
 
 import numpy as np
+from ..base.utils import fixedvalue
 from ..base.header import BitFieldHeader
 from ..base.quantities import as_time
 
@@ -523,12 +524,7 @@ class Mark4Header:
             flags[self._track_assignment(self.ntrack, 2, self.fanout)[..., 1]] = True
         self['magnitude_bit'] = flags
 
-    complex_data = property(lambda self: False, doc="Mark 4 data are always real.")
-
-    @complex_data.setter
-    def complex_data(self, complex_data):
-        if complex_data:
-            raise ValueError("Mark 4 data are always real.")
+    complex_data = fixedvalue(False)        # (Mark 4 data are always real: "'complex_data' can only be set to False.")
 
     @property
     def nchan(self):
@@ -716,9 +712,27 @@ class Mark4Header:
                 and np.array_equal(self.words, other.words))
 
     def __repr__(self):
-        return "<Mark4Header ntrack={} fanout={} bps={} nchan={} time={}>".format(
-            self.ntrack, self.fanout, self.bps, self.nchan,
-            self.get_time() if self.decade is not None else '?')
+        """Every key with its per-track values, runs of one value folded and long lists
+        cut to their ends, BCD / CRC / sync fields in hex (mark4/header.py:797-813)."""
+        def show(key, value):
+            if key.startswith(('bcd', 'crc', 'sync_pattern')):
+                try:
+                    return hex(int(value))
+                except Exception:
+                    pass
+            return str(value)
+        name, outs = type(self).__name__, []
+        for k in self.keys():
+            v = np.atleast_1d(np.asarray(self[k]))
+            if len(v) == 1:
+                text = show(k, v[0])
+            elif np.all(v == v[0]):
+                text = '[{}]*{}'.format(show(k, v[0]), v.size)
+            else:
+                ends = (v[0], '...', v[-1]) if len(v) > 4 else tuple(v)
+                text = '[{}]'.format(', '.join(x if isinstance(x, str) else show(k, x) for x in ends))
+            outs.append('{}: {}'.format(k, text))
+        return "<{} {}>".format(name, (",\n  " + " " * len(name)).join(outs))
 
 
 def frame_header_streams(header0, times, invalid=None):

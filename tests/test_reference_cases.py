@@ -486,3 +486,86 @@ def test_mark5b_header_as_the_reference_tests_it(tmp_path):
     assert header.seconds == header0.seconds
     header.set_time(time=start_time - np.timedelta64(1, 'ns'))
     assert header.seconds == header0.seconds
+
+
+def test_mark4_header_as_the_reference_tests_it(tmp_path):
+    """mark4/tests/test_mark4.py::test_header (to the per-track time assignment)."""
+    m4 = os.path.join(S, 'sample.m4')
+    with open(m4, 'rb') as fh:
+        fh.seek(0xa88)
+        header = mark4.Mark4Header.fromfile(fh, ntrack=64, decade=2010)
+        fh.seek(-10, 2)
+        with pytest.raises(EOFError):
+            mark4.Mark4Header.fromfile(fh, ntrack=64, decade=2010)
+    assert len(header) == 64
+    assert header.track_id[0] == 2 and header.track_id[-1] == 33
+    assert header.nbytes == 160 * 64 // 8
+    assert header.fanout == 4 and header.bps == 2 and not header.complex_data
+    assert not np.all(~np.asarray(header['magnitude_bit']))
+    assert header.nchan == 8 and header.sample_shape == (8,)
+    assert str(header.time)[:10] == '2014-06-16' and str(header.time)[:25] == '2014-06-16T07:38:12.47500'
+    assert header.samples_per_frame == 20000 * 4
+    assert header.frame_nbytes == 20000 * 64 // 8
+    assert header.payload_nbytes == header.frame_nbytes - header.nbytes
+    assert header.mutable is False and header.nsb == 1
+    assert np.all(header.converters['converter'] == [0, 2, 1, 3, 4, 6, 5, 7])
+    assert np.all(header.converters['lsb'])
+    assert repr(header).startswith('<Mark4Header bcd_headstack1: [0')
+    with open(str(tmp_path / 'test.m4'), 'w+b') as s:
+        header.tofile(s)
+        s.seek(0)
+        header2 = mark4.Mark4Header.fromfile(s, header.ntrack, header.decade)
+    assert header2 == header and header2.mutable is False
+    header3 = mark4.Mark4Header.fromkeys(header.ntrack, header.decade, **header)
+    assert header3 == header and header3.mutable is True
+    header4 = mark4.Mark4Header.fromvalues(ntrack=64, samples_per_frame=80000, bps=2, nsb=1, time=header.time,
+                                           system_id=108)
+    assert header4 == header and header4.mutable is True
+    assert not header4.complex_data
+    header4.complex_data = False
+    with pytest.raises(ValueError):
+        header4.complex_data = True
+    with pytest.raises(AssertionError):                     # a year for the decade
+        mark4.Mark4Header(header.words, decade=2014)
+    with pytest.raises(ValueError):
+        mark4.Mark4Header.fromvalues(ntrack=64, samples_per_frame=80001, bps=2, nsb=1, time=header.time, system_id=108)
+    with pytest.raises(ValueError, match='can only be set to False'):
+        mark4.Mark4Header.fromvalues(ntrack=64, bps=2, complex_data=True, time=header.time)
+    with pytest.raises(ValueError, match='fanout=1, 2, or 4'):
+        mark4.Mark4Header.fromvalues(ntrack=64, bps=2, time=header.time, fanout=8)
+    with pytest.raises(ValueError, match='can only be 1 or 2'):
+        mark4.Mark4Header.fromvalues(ntrack=64, bps=2, time=header.time, nsb=3)
+    with pytest.raises(ValueError, match='track assignments only'):
+        mark4.Mark4Header.fromvalues(ntrack=8, bps=2, fanout=1)
+    with pytest.raises(ValueError, match='does not support bps=1'):
+        mark4.Mark4Header.fromvalues(ntrack=64, bps=1, fanout=1, nsb=2)
+    with open(m4, 'rb') as fh:
+        for ref in ('2010-12-17T12:00:00', '2018-04-23T16:30:00'):
+            fh.seek(0xa88)
+            assert mark4.Mark4Header.fromfile(fh, ntrack=64, ref_time=np.datetime64(ref)) == header
+    header7 = header.copy()
+    assert header7 == header and header7.mutable is True
+    header7['bcd_headstack1'] = 0x5566
+    assert np.all(np.asarray(header7['bcd_headstack1']) == 0x5566)
+    assert header7 != header
+    header7['bcd_headstack1'] = np.hstack((0x7788, np.asarray(header7['bcd_headstack1'])[1:]))
+    assert header7['bcd_headstack1'][0] == 0x7788
+    assert np.all(np.asarray(header7['bcd_headstack1'])[1:] == 0x5566)
+    with pytest.raises(TypeError):
+        header['bcd_headstack1'] = 0
+    with pytest.raises(ValueError):
+        header7.time = header.time + np.timedelta64(100, 'us')
+    header7.bps = 1
+    assert np.all(~np.asarray(header7['magnitude_bit']))
+    header7.bps = 2
+    assert not np.all(~np.asarray(header7['magnitude_bit']))
+    with pytest.raises(ValueError):
+        header7.bps = 4
+    with pytest.raises(AttributeError):
+        header7.ntrack = 51
+    with pytest.raises(AttributeError):
+        header7.frame_nbytes = header.frame_nbytes
+    with pytest.raises(AttributeError):
+        header7.payload_nbytes = header.payload_nbytes
+    header7.nchan = 16
+    assert header7.nchan == 16 and header7.bps == 1
