@@ -14,6 +14,11 @@ _FLOAT_KEYS = ('FREQ', 'BW', 'TSAMP')
 
 class DADAHeader(dict):
     def __init__(self, *args, verify=True, mutable=True, **kwargs):
+        text_layout = None
+        if len(args) == 1 and isinstance(args[0], str):
+            # the header's own text (what `repr` shows: dada/header.py:464-467)
+            comments, text_layout = {}, []
+            args = (self._fromlines(args[0].split('\n'), comments, text_layout),)
         super().__init__(*args, **kwargs)
         # what a file's header block looked like beyond KEY VALUE: trailing
         # comments per key, and the blank / comment-only lines between them,
@@ -21,9 +26,22 @@ class DADAHeader(dict):
         # (dada/header.py:117-154 keeps them as `comments` and `_<line>` keys)
         self.comments = {}
         self._layout = None
+        if text_layout is not None:
+            self.comments, self._layout = comments, text_layout
         self.mutable = mutable
         if verify and len(self):
             self.verify()
+
+    @classmethod
+    def fromkeys(cls, *args, **kwargs):
+        """A header from its keywords as they are (dada/header.py:225-236; for
+        compatibility with the other header classes)."""
+        if not args:
+            kwargs.setdefault('HEADER', 'DADA')
+        return cls(*args, **kwargs)
+
+    def __repr__(self):
+        return '{0}("""'.format(type(self).__name__) + '\n'.join(self._tolines()) + '""")'
 
     def verify(self):
         assert all(k in self for k in ('HDR_SIZE', 'NBIT', 'NDIM', 'NPOL', 'NCHAN'))
@@ -83,18 +101,29 @@ class DADAHeader(dict):
         rel = 0
         if block == b'':
             raise EOFError
-        while rel < hdr_size and block[rel:rel + 1] != b'\x00':
+        ended = False
+        while (rel < hdr_size or not ended) and block[rel:rel + 1] != b'\x00':
+            if rel >= hdr_size and rel >= len(block):
+                break
             end = block.find(b'\n', rel)
             if end < 0:
                 raise EOFError
             line = block[rel:end + 1].decode('ascii')
             rel = end + 1
             if line[0] == '#' and 'end of header' in line:
+                ended = True
                 break
             if line.startswith('HDR_SIZE'):
                 hdr_size = int(line.split()[1])
             lines.append(line)
-        fh.seek(start + hdr_size)
+        if rel > hdr_size:
+            # (the text runs beyond what HDR_SIZE says: read on to its end, as the
+            # reference does, and say so; dada/header.py:194-196)
+            import warnings
+            warnings.warn("Odd, read {0} bytes while the header size is {1}".format(start + rel, hdr_size))
+            fh.seek(start + rel)
+        else:
+            fh.seek(start + hdr_size)
         comments, layout = {}, []
         values = cls._fromlines(lines, comments, layout)
         values.setdefault('HDR_SIZE', hdr_size)
@@ -188,6 +217,10 @@ class DADAHeader(dict):
     @property
     def frame_nbytes(self):
         return self.nbytes + self.payload_nbytes
+
+    @frame_nbytes.setter
+    def frame_nbytes(self, frame_nbytes):
+        self.payload_nbytes = frame_nbytes - self.nbytes
 
     @property
     def bps(self):

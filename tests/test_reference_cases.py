@@ -569,3 +569,71 @@ def test_mark4_header_as_the_reference_tests_it(tmp_path):
         header7.payload_nbytes = header.payload_nbytes
     header7.nchan = 16
     assert header7.nchan == 16 and header7.bps == 1
+
+
+def test_dada_header_as_the_reference_tests_it(tmp_path):
+    """dada/tests/test_dada.py::test_header (without the sub-ns MJD rounding case:
+    numpy.datetime64[ns] has no 1e-15 days)."""
+    from baseband_amd.dada.header import DADAHeader           # noqa: F401  (for the repr round trip)
+    ns = np.timedelta64(1, 'ns')
+    sample = os.path.join(S, 'sample.dada')
+    with open(sample, 'rb') as fh:
+        header = dada.DADAHeader.fromfile(fh)
+        assert header.nbytes == 4096 and fh.tell() == 4096
+    assert header['NDIM'] == 2 and header['NCHAN'] == 1
+    assert header['UTC_START'] == '2013-07-02-01:37:40'
+    assert header['OBS_OFFSET'] == 6400000000              # 100 s
+    assert str(header.time)[:23] == '2013-07-02T01:39:20.000'
+    assert header.frame_nbytes == 64000 + 4096 and header.payload_nbytes == 64000
+    assert header.mutable is False
+    with pytest.raises(TypeError):
+        header['NCHAN'] = 2
+    assert header['NCHAN'] == 1
+    with pytest.raises(AttributeError):
+        header.python
+    with open(str(tmp_path / 'test.dada'), 'w+b') as s:
+        header.tofile(s)
+        assert s.tell() == header.nbytes
+        s.seek(0)
+        header2 = dada.DADAHeader.fromfile(s)
+        assert header2 == header and header2.mutable is False
+        assert s.tell() == header.nbytes
+    with open(str(tmp_path / 'test.dada'), 'w+b') as s:
+        bad_header = header.copy()
+        bad_header['HDR_SIZE'] = 1000
+        with pytest.raises(ValueError):
+            bad_header.tofile(s)
+        for line in bad_header._tolines():
+            s.write((line + '\n').encode('ascii'))
+        s.write('# end of header\n'.encode('ascii'))
+        s.seek(0)
+        with pytest.warns(UserWarning, match='Odd'):
+            dada.DADAHeader.fromfile(s)
+    with open(sample, 'rb') as fh, open(str(tmp_path / 'test2.dada'), 'w+b') as s:
+        s.write(fh.read(1000))
+        s.seek(0)
+        with pytest.raises(EOFError):
+            dada.DADAHeader.fromfile(s)
+    header3 = dada.DADAHeader.fromkeys(**header)
+    assert header3 == header and header3.mutable is True
+    half_day = np.timedelta64(12, 'h')
+    header3.start_time = header.start_time - half_day
+    assert abs(header3.start_time - (header.start_time - half_day)) < ns
+    assert abs(header3.time - (header.time - half_day)) < ns
+    header3['NCHAN'] = 2
+    assert header3['NCHAN'] == 2
+    header3.frame_nbytes = 9096
+    assert header3.payload_nbytes == 5000
+    common = dict(bps=header.bps, complex_data=header.complex_data, sample_rate=header.sample_rate,
+                  sideband=header.sideband, samples_per_frame=header.samples_per_frame,
+                  sample_shape=header.sample_shape, source=header['SOURCE'], ra=header['RA'], dec=header['DEC'],
+                  telescope=header['TELESCOPE'], instrument=header['INSTRUMENT'], receiver=header['RECEIVER'],
+                  freq=header['FREQ'], pic_version=header['PIC_VERSION'])
+    header4 = dada.DADAHeader.fromvalues(start_time=header.start_time, offset=header.time - header.start_time, **common)
+    assert header4 == header and header4.mutable is True
+    header5 = dada.DADAHeader.fromvalues(offset=header.time - header.start_time, time=header.time, **common)
+    assert header5 == header
+    header6 = dada.DADAHeader.fromvalues(time=header.time, start_time=header.start_time, **common)
+    assert header6 == header
+    header7 = eval('dada.' + repr(header))                  # the repr instantiates the header
+    assert header7 == header
