@@ -193,6 +193,8 @@ class DADAHeader(dict):
         new._layout = None if self._layout is None else list(self._layout)
         return new
 
+    __copy__ = copy             # (copy.copy(header): a mutable copy, as header.copy())
+
     def __setitem__(self, key, value):
         if not getattr(self, 'mutable', True):
             raise TypeError("immutable {0} does not support assignment."

@@ -115,6 +115,12 @@ class GUPPIHeader(dict):
         assert all(key in self for key in ('BLOCSIZE', 'PKTIDX'))
 
     @classmethod
+    def fromkeys(cls, *args, **kwargs):
+        """A header from its keywords as they are (guppi/header.py:145-152; for
+        compatibility with the other header classes)."""
+        return cls(*args, **kwargs)
+
+    @classmethod
     def fromfile(cls, fh, verify=True):
         """80-character cards up to END (guppi/header.py:105-143)."""
         start = fh.tell()
@@ -266,6 +272,8 @@ class GUPPIHeader(dict):
         new._layout = None if self._layout is None else list(self._layout)
         return new
 
+    __copy__ = copy             # (copy.copy(header): a mutable copy, as header.copy())
+
     def __setitem__(self, key, value):
         if not getattr(self, 'mutable', True):
             raise TypeError("immutable {0} does not support assignment."
@@ -333,6 +341,13 @@ class GUPPIHeader(dict):
     def sample_shape(self):
         return self.npol, self.nchan
 
+    @sample_shape.setter
+    def sample_shape(self, sample_shape):
+        # (the channels first: NPOL counts the real / imaginary components too,
+        # guppi/header.py:281-286)
+        self.nchan = sample_shape[1]
+        self.npol = sample_shape[0]
+
     @property
     def _bpcs(self):
         return int(self['OBSNCHAN']) * int(self['NPOL']) * self.bps
@@ -399,7 +414,7 @@ class GUPPIHeader(dict):
         """`offset` in seconds (float), a numpy timedelta64, a Quantity of
         time or a TimeDelta."""
         offset = seconds(offset)
-        self['PKTIDX'] = int(round(offset / float(self['TBIN']) * ((self._bpcs + 7) // 8)))
+        self['PKTIDX'] = int(round(offset / float(self['TBIN']) / int(self['PKTSIZE']) * ((self._bpcs + 7) // 8)))
 
     @property
     def start_time(self):

@@ -637,3 +637,79 @@ def test_dada_header_as_the_reference_tests_it(tmp_path):
     assert header6 == header
     header7 = eval('dada.' + repr(header))                  # the repr instantiates the header
     assert header7 == header
+
+
+def test_guppi_header_as_the_reference_tests_it(tmp_path):
+    """guppi/tests/test_guppi.py::test_header."""
+    import copy
+    ns = np.timedelta64(1, 'ns')
+    sample = os.path.join(S, 'sample_puppi.raw')
+    with open(sample, 'rb') as fh:
+        header = guppi.GUPPIHeader.fromfile(fh)
+        assert header.nbytes == 6400 and fh.tell() == 6400
+    assert header['OBSNCHAN'] == 4 and header['STT_IMJD'] == 58132 and header['STT_SMJD'] == 51093
+    assert header['STT_OFFS'] == 0 and header['PKTIDX'] == 0 and header['PKTSIZE'] == 1024
+    assert str(header.time)[:23] == '2018-01-14T14:11:33.000'
+    assert header.payload_nbytes == 16384 and header.frame_nbytes == 16384 + 6400
+    assert header.overlap == 64 and header.samples_per_frame == 1024
+    assert header.mutable is False
+    with pytest.raises(TypeError):
+        header['OBSNCHAN'] = 2
+    with open(str(tmp_path / 'testguppi1.raw'), 'w+b') as s:
+        header.tofile(s)
+        assert s.tell() == header.nbytes
+        s.seek(0)
+        header2 = guppi.GUPPIHeader.fromfile(s)
+        assert header2 == header and header2.mutable is False
+        assert s.tell() == header.nbytes
+    with open(sample, 'rb') as fh, open(str(tmp_path / 'testguppi2.raw'), 'w+b') as s:
+        s.write(fh.read(6320))                              # a short header: no "END"
+        s.seek(0)
+        with pytest.raises(EOFError):
+            guppi.GUPPIHeader.fromfile(s)
+    with open(sample, 'rb') as fh, open(str(tmp_path / 'testguppi3.raw'), 'w+b') as s:
+        s.write(fh.read(6320))                              # "END" missing, payload bytes follow
+        fh.seek(6400)
+        s.write(fh.read(10000))
+        s.seek(0)
+        with pytest.raises(UnicodeDecodeError):
+            guppi.GUPPIHeader.fromfile(s)
+    header3 = guppi.GUPPIHeader.fromkeys(**header)
+    assert header3 == header and header3.mutable is True
+    half_day = np.timedelta64(12, 'h')
+    header3.start_time = header.start_time - half_day
+    assert abs(header3.start_time - (header.start_time - half_day)) < ns
+    assert abs(header3.time - (header.time - half_day)) < ns
+    header3.frame_nbytes = 13000
+    assert header3.payload_nbytes == 6600
+    header4 = guppi.GUPPIHeader.fromkeys(**header)
+    packet_time = (header4['PKTSIZE'] * 8 // header4['OBSNCHAN'] // header4['NPOL'] // header4.bps) * header4['TBIN']
+    header4.offset += packet_time
+    assert header4['PKTIDX'] == header['PKTIDX'] + 1
+    assert abs(header4.time - (header.time + np.timedelta64(int(round(packet_time * 1e9)), 'ns'))) < ns
+    common = dict(sample_rate=header.sample_rate, samples_per_frame=header.samples_per_frame, overlap=header.overlap,
+                  sample_shape=header.sample_shape, sideband=header.sideband, bps=header.bps, pktsize=header['PKTSIZE'],
+                  obsfreq=header['OBSFREQ'], src_name=header['SRC_NAME'], observer=header['OBSERVER'],
+                  telescop=header['TELESCOP'], ra_str=header['RA_STR'], dec_str=header['DEC_STR'])
+    header5 = guppi.GUPPIHeader.fromvalues(start_time=header.start_time, stt_offs=header['STT_OFFS'],
+                                           pktidx=header['PKTIDX'], **common)
+    assert header5.mutable is True and header5.start_time == header.start_time
+    assert header5.offset == header.offset and header5.sample_rate == header.sample_rate
+    assert header5.overlap == header.overlap and header5.samples_per_frame == header.samples_per_frame
+    assert header5.sample_shape == header.sample_shape and header5.sideband == header.sideband
+    assert header5.bps == header.bps
+    for key in ('OBSFREQ', 'SRC_NAME', 'OBSERVER', 'TELESCOP', 'RA_STR', 'DEC_STR'):
+        assert header5[key] == header[key]
+    header6 = guppi.GUPPIHeader(((key, header[key]) for key in header))
+    assert header6 == header
+    header7 = header.copy()
+    assert header7 == header and header7.mutable is True
+    header8 = copy.copy(header)
+    assert header8 == header and header8.mutable is True
+    offset = 9.472
+    header9 = guppi.GUPPIHeader.fromvalues(time=header.start_time + np.timedelta64(9472, 'ms'), offset=offset, **common)
+    header10 = guppi.GUPPIHeader.fromvalues(start_time=header.start_time,
+                                            time=header.start_time + np.timedelta64(9472, 'ms'), **common)
+    assert abs(header9.offset - offset) < 1e-9
+    assert abs(header10.offset - offset) < 1e-9
+    assert header9 == header10
