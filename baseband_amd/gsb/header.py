@@ -42,67 +42,182 @@ def _format_time(time, precision, offset=_IST):
 
 
 class GSBHeader:
-    """Header = the whitespace-separated items of one timestamp line."""
+    """Header = the whitespace-separated items of one timestamp line
+    (gsb/header.py:131-361): ``header['gps']`` (and ``'pc'``, ``'seq_nr'``,
+    ``'mem_block'`` for phased data) are its keys, `time` / `gps_time` / `pc_time` its
+    instants (UTC; the file's clock is IST unless `utc_offset` says otherwise).
+    ``GSBHeader(words)`` gives the class of the words' mode."""
     _gps_precision, _pc_precision = 9, 6
+    mode = None
+    _keys = ()
+    _nwords = 0
 
+    def __new__(cls, words=None, mode=None, **kwargs):
+        if cls is GSBHeader:
+            if mode is None:
+                if words is None:
+                    raise TypeError("cannot construct an empty GSB header without knowing the mode.")
+                mode = 'rawdump' if len(words) == 7 else 'phased'
+            cls = {'rawdump': GSBRawdumpHeader, 'phased': GSBPhasedHeader}[mode]
+        return super().__new__(cls)
+
+    def __init__(self, words, mode=None, nbytes=None, utc_offset=None, verify=True):
+        if words is None:
+            self.words, self.mutable = [''] * self._nwords, True
+        else:
+            self.words, self.mutable = tuple(words), False
+        self._nbytes = nbytes
+        self._utc_offset = _offset(utc_offset)
+        if verify and words is not None:
+            self.verify()
+
+    def verify(self):
+        assert len(self.words) == self._nwords
+
+    # -- mapping protocol: dict(header), **header
+    def keys(self):
+        return self._keys
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def __contains__(self, key):
+        return key in self._keys
+
+    def _span(self, key):
+        raise KeyError(key)
+
+    def __getitem__(self, key):
+        lo, hi = self._span(key)
+        if hi - lo == 1:
+            return int(self.words[lo])
+        return ' '.join(self.words[lo:hi])
+
+    def __setitem__(self, key, value):
+        if not self.mutable:
+            raise TypeError("header is immutable; use .copy() to get a mutable one.")
+        lo, hi = self._span(key)
+        words = list(self.words)
+        if hi - lo == 1:
+            words[lo] = str(int(value))
+        else:
+            items = str(value).split()
+            if len(items) != hi - lo:
+                raise ValueError("{!r} needs {} items, got {!r}".format(key, hi - lo, value))
+            words[lo:hi] = items
+        self.words = words
+
+    # -- construction
     @classmethod
-    def fromvalues(cls, mode=None, *, time=None, gps_time=None, pc_time=None,
-                   seq_nr=0, mem_block=0, utc_offset=None, nbytes=None, **ignored):
-        """Header for `time` (UTC): rawdump = the GPS time; phased = PC time,
-        GPS time, sequence number and memory block (gsb/header.py:200-318)."""
-        if mode is None:
-            mode = 'phased' if (pc_time is not None or seq_nr or mem_block) else 'rawdump'
-        gps_time = time if gps_time is None else gps_time
-        if gps_time is None:
-            raise TypeError("a GSB header needs a time.")
-        offset = _offset(utc_offset)
-        words = _format_time(gps_time, cls._gps_precision, offset)
-        if mode == 'phased':
-            pc = _format_time(gps_time if pc_time is None else pc_time, cls._pc_precision, offset)
-            words = pc + words + [str(int(seq_nr)), str(int(mem_block))]
-        return GSBHeader(words, nbytes=nbytes, utc_offset=offset)
+    def fromfile(cls, fh, verify=True, **kwargs):
+        """One line of a timestamp file; `nbytes`, `utc_offset` as for the class
+        (gsb/header.py:202-229)."""
+        line = fh.readline()
+        if isinstance(line, bytes):
+            line = line.decode('ascii')
+        if line.strip() == '':
+            raise EOFError
+        kwargs.setdefault('nbytes', len(line))      # (the line as it is in the file: trailing blank and newline)
+        return cls(line.split(), verify=verify, **kwargs)
 
     def tofile(self, fh):
         line = ' '.join(self.words) + '\n'
         return fh.write(line if 'b' not in getattr(fh, 'mode', 't') else line.encode('ascii'))
 
-    def keys(self):
-        return ('pc', 'gps', 'seq_nr', 'mem_block') if self.mode == 'phased' else ('gps',)
-
-    mutable = True
-
-    def verify(self):
-        pass
-
-    def copy(self):
-        return GSBHeader(list(self.words), nbytes=self._nbytes, utc_offset=self._utc_offset)
+    @classmethod
+    def _mode_of(cls, mode, kwargs):
+        if mode is None:
+            mode = cls.mode
+        if mode is None:
+            if set(kwargs) & {'pc', 'pc_time', 'seq_nr', 'mem_block'}:
+                return 'phased'
+            raise TypeError("cannot construct a GSB header from values without knowing the mode.")
+        return mode
 
     @classmethod
-    def fromkeys(cls, mode=None, **kwargs):
-        """Header from the raw keys: ``gps`` (and ``pc``, ``seq_nr``,
-        ``mem_block`` for phased data), times as their seven-item strings
-        (gsb/header.py:231-238)."""
-        if mode is None:
-            mode = 'phased' if set(kwargs) & {'pc', 'seq_nr', 'mem_block'} else 'rawdump'
-        words = kwargs['gps'].split()
+    def fromkeys(cls, mode=None, *, nbytes=None, utc_offset=None, verify=True, **kwargs):
+        """Header from the raw keys: ``gps`` (and ``pc``, ``seq_nr``, ``mem_block``
+        for phased data), times as their seven-item strings; all of them and no
+        others (gsb/header.py:231-238)."""
+        if mode is None and cls.mode is None and 'gps' in kwargs and not (set(kwargs) - {'gps'}):
+            mode = 'rawdump'
+        self = GSBHeader(None, mode=cls._mode_of(mode, kwargs), nbytes=nbytes, utc_offset=utc_offset) \
+            if cls is GSBHeader else cls(None, nbytes=nbytes, utc_offset=utc_offset)
+        if set(kwargs) != set(self._keys):
+            raise KeyError("need keyword arguments for all keys in header: {}"
+                           .format(sorted(set(self._keys) ^ set(kwargs))))
+        for key, value in kwargs.items():
+            self[key] = value
+        if verify:
+            self.verify()
+        return self
+
+    @classmethod
+    def fromvalues(cls, mode=None, *, nbytes=None, utc_offset=None, verify=True, **kwargs):
+        """Header from keys and / or `time` / `gps_time` / `pc_time` (UTC), `seq_nr`,
+        `mem_block` (gsb/header.py:200-318).  The mode has to be given or to follow
+        from the keywords (any of the phased ones) or the class."""
+        mode = cls._mode_of(mode, kwargs)
+        self = GSBHeader(None, mode=mode, nbytes=nbytes, utc_offset=utc_offset) if cls is GSBHeader \
+            else cls(None, nbytes=nbytes, utc_offset=utc_offset)
+        if 'time' in kwargs:
+            t = kwargs.pop('time')
+            kwargs.setdefault('gps_time', t)
         if mode == 'phased':
-            words = (kwargs['pc'].split() + words
-                     + [str(int(kwargs.get('seq_nr', 0))), str(int(kwargs.get('mem_block', 0)))])
-        return GSBHeader(words)
+            kwargs.setdefault('seq_nr', 0)
+            kwargs.setdefault('mem_block', 0)
+            if 'pc' not in kwargs and 'pc_time' not in kwargs:
+                if 'gps_time' in kwargs:
+                    kwargs['pc_time'] = kwargs['gps_time']
+        for key in [k for k in kwargs if k in self._keys]:
+            self[key] = kwargs.pop(key)
+        for key in ('gps_time', 'pc_time'):
+            if key in kwargs:
+                setattr(self, key, kwargs.pop(key))
+        kwargs.pop('mode', None)
+        if any(w == '' for w in self.words):
+            raise TypeError("a GSB header needs a time.")
+        if verify:
+            self.verify()
+        return self
 
     def update(self, *, verify=True, **kwargs):
         """New times / counters; keyword names as for `fromvalues`."""
-        current = dict(gps_time=self.time)
-        if self.mode == 'phased':
-            current.update(pc_time=self.pc_time, seq_nr=self['seq_nr'], mem_block=self['mem_block'])
         if 'time' in kwargs:
             t = kwargs.pop('time')
             kwargs.setdefault('gps_time', t)
             if self.mode == 'phased':
                 kwargs.setdefault('pc_time', t)
-        current.update(kwargs)
-        current.setdefault('utc_offset', self._utc_offset)
-        self.words = GSBHeader.fromvalues(self.mode, **current).words
+        was, self.mutable = self.mutable, True
+        try:
+            for key in [k for k in kwargs if k in self._keys]:
+                self[key] = kwargs.pop(key)
+            for key in ('gps_time', 'pc_time'):
+                if key in kwargs:
+                    setattr(self, key, kwargs.pop(key))
+        finally:
+            self.mutable = was
+        if verify:
+            self.verify()
+
+    def copy(self):
+        new = type(self)(list(self.words), nbytes=self._nbytes, utc_offset=self._utc_offset, verify=False)
+        new.words, new.mutable = list(self.words), True
+        return new
+
+    __copy__ = copy
+
+    @property
+    def utc_offset(self):
+        """The file's clock minus UTC in seconds (5.5 h: GMRT writes IST)."""
+        return float(self._utc_offset / np.timedelta64(1, 's'))
+
+    @property
+    def nbytes(self):
+        return len(' '.join(self.words)) + 1 if self._nbytes is None else self._nbytes
 
     def seek_offset(self, n, nbytes=None):
         """Bytes to move a file pointer `n` timestamp lines on: rawdump lines
@@ -125,84 +240,48 @@ class GSBHeader:
                 ndseq -= 1
         return guess
 
-    def __new__(cls, words=None, mode=None, **kwargs):
-        if cls is GSBHeader and words is not None:
-            cls = GSBRawdumpHeader if len(words) == 7 else GSBPhasedHeader
-        return super().__new__(cls)
-
-    def __init__(self, words, mode=None, nbytes=None, utc_offset=None, verify=True):
-        self.words = tuple(words)
-        self._nbytes = nbytes
-        self._utc_offset = _offset(utc_offset)
-        if verify:
-            self.verify()
-
-    @property
-    def utc_offset(self):
-        """The file's clock minus UTC in seconds (5.5 h: GMRT writes IST)."""
-        return float(self._utc_offset / np.timedelta64(1, 's'))
-
-    @classmethod
-    def fromfile(cls, fh, verify=True, **kwargs):
-        """One line of a timestamp file; `nbytes`, `utc_offset` as for the class
-        (gsb/header.py:202-229)."""
-        line = fh.readline()
-        if isinstance(line, bytes):
-            line = line.decode('ascii')
-        if line.strip() == '':
-            raise EOFError
-        kwargs.setdefault('nbytes', len(line))      # (the line as it is in the file: trailing blank and newline)
-        return cls(line.split(), verify=verify, **kwargs)
-
-    @property
-    def nbytes(self):
-        return len(' '.join(self.words)) + 1 if self._nbytes is None else self._nbytes
-
     def __eq__(self, other):
-        return type(self) is type(other) and self.words == other.words
+        return type(self) is type(other) and tuple(self.words) == tuple(other.words)
+
+    def __repr__(self):
+        return "<{} {}>".format(type(self).__name__, ", ".join("{}: {}".format(k, self[k]) for k in self._keys))
+
+    # -- times
+    def _get_time(self, key, precision):
+        lo, hi = self._span(key)
+        return _parse_time(self.words[lo:hi], self._utc_offset)
+
+    def _set_time(self, key, precision, time):
+        self[key] = ' '.join(_format_time(time, precision, self._utc_offset))
+
+    gps_time = property(lambda self: self._get_time('gps', self._gps_precision),
+                        lambda self, t: self._set_time('gps', self._gps_precision, t))
+    time = gps_time
 
 
 class GSBRawdumpHeader(GSBHeader):
     mode = 'rawdump'
+    _keys = ('gps',)
+    _nwords = 7
 
-    def verify(self):
-        assert len(self.words) == 7
-
-    @property
-    def pc_time(self):
-        return _parse_time(self.words[:7], self._utc_offset)
-
-    time = gps_time = pc_time
-
-    def __getitem__(self, key):
+    def _span(self, key):
         if key == 'gps':
-            return ' '.join(self.words[:7])
+            return 0, 7
         raise KeyError(key)
+
+    pc_time = GSBHeader.gps_time
 
 
 class GSBPhasedHeader(GSBHeader):
     mode = 'phased'
+    _keys = ('pc', 'gps', 'seq_nr', 'mem_block')
+    _nwords = 16
 
-    def verify(self):
-        assert len(self.words) == 16
+    def _span(self, key):
+        try:
+            return {'pc': (0, 7), 'gps': (7, 14), 'seq_nr': (14, 15), 'mem_block': (15, 16)}[key]
+        except KeyError:
+            raise KeyError(key) from None
 
-    def __getitem__(self, key):
-        if key == 'seq_nr':
-            return int(self.words[14])
-        if key == 'mem_block':
-            return int(self.words[15])
-        if key == 'pc':
-            return ' '.join(self.words[:7])
-        if key == 'gps':
-            return ' '.join(self.words[7:14])
-        raise KeyError(key)
-
-    @property
-    def pc_time(self):
-        return _parse_time(self.words[:7], self._utc_offset)
-
-    @property
-    def gps_time(self):
-        return _parse_time(self.words[7:14], self._utc_offset)
-
-    time = gps_time
+    pc_time = property(lambda self: self._get_time('pc', self._pc_precision),
+                       lambda self, t: self._set_time('pc', self._pc_precision, t))

@@ -578,7 +578,9 @@ def test_gsb_header_helpers():
     h0, h5 = GSBHeader(lines[0].split()), GSBHeader(lines[5].split())
     assert [h0.seek_offset(n) for n in range(6)] == pos[:6].tolist()
     assert [h5.seek_offset(-n) for n in range(6)] == (pos[5 - np.arange(6)] - pos[5]).tolist()
-    raw = GSBHeader.fromvalues(time=t0)
+    raw = GSBHeader.fromvalues('rawdump', time=t0)
+    with pytest.raises(TypeError):           # (the mode has to be known: gsb/header.py:221-229)
+        GSBHeader.fromvalues(time=t0)
     assert raw.mode == 'rawdump' and raw.seek_offset(7) == 7 * raw.nbytes
     c = h0.copy()
     c.update(seq_nr=12, time=t0 + np.timedelta64(1, 's'))

@@ -713,3 +713,69 @@ def test_guppi_header_as_the_reference_tests_it(tmp_path):
     assert abs(header9.offset - offset) < 1e-9
     assert abs(header10.offset - offset) < 1e-9
     assert header9 == header10
+
+
+def test_gsb_headers_as_the_reference_tests_them(tmp_path):
+    """gsb/tests/test_gsb.py::test_rawdump_header and ::test_phased_header."""
+    ns = np.timedelta64(1, 'ns')
+    with open(_TS_RAW, 'rt') as fh:
+        header = gsb.GSBHeader.fromfile(fh, verify=True)
+    assert header.mode == 'rawdump'
+    assert header['gps'] == '2015 04 27 18 45 00 0.000000240'
+    assert abs(header.time - np.datetime64('2015-04-27T13:15:00.000000240')) < ns      # (the UTC offset taken off)
+    header2 = gsb.GSBHeader.fromkeys(**header)
+    assert header2 == header
+    header3 = gsb.GSBHeader.fromvalues(mode='rawdump', **header2)
+    assert header3 == header2 and header3.nbytes == header2.nbytes
+    with pytest.raises(TypeError):
+        gsb.GSBHeader.fromvalues(**header)
+    with pytest.raises(TypeError):
+        gsb.GSBHeader(None)
+    header4 = type(header).fromkeys(**header)
+    assert header4 == header
+    with pytest.raises(KeyError):
+        gsb.header.GSBPhasedHeader.fromkeys(**header)
+    assert header.copy() == header
+    # ---- phased
+    with open(_TS_PH, 'rt') as fh:
+        header = gsb.GSBHeader.fromfile(fh, verify=True)
+        fh.seek(0)
+        h_raw = fh.readline().strip()
+    assert header.mode == 'phased'
+    assert header['pc'] == h_raw[:28] and header['gps'] == h_raw[29:60]
+    assert header['seq_nr'] == 9995 and header['mem_block'] == 3
+    assert abs(header.pc_time - np.datetime64('2013-07-27T21:23:55.517535')) < ns
+    assert header.gps_time == header.time
+    assert abs(header.time - np.datetime64('2013-07-27T21:23:55.3241088')) < ns
+    assert header.mutable is False
+    with pytest.raises(TypeError):
+        header['mem_block'] = 0
+    with open(str(tmp_path / 'test.timestamp'), 'w+t') as s:
+        header.tofile(s)
+        s.seek(0)
+        assert s.readline().strip() == h_raw
+        s.seek(0)
+        header2 = gsb.GSBHeader.fromfile(s)
+        with pytest.raises(EOFError):
+            gsb.GSBHeader.fromfile(s)
+    assert header == header2 and header2.mutable is False
+    header3 = gsb.GSBHeader.fromkeys(**header)
+    assert header3 == header and header3.mutable is True
+    with pytest.raises(KeyError):
+        gsb.GSBHeader.fromkeys(extra=1, **header)
+    with pytest.raises(KeyError):
+        kwargs = dict(header)
+        kwargs.pop('seq_nr')
+        gsb.GSBHeader.fromkeys(**kwargs)
+    header4 = gsb.GSBHeader.fromvalues(time=header.time, pc_time=header.pc_time, seq_nr=header['seq_nr'],
+                                       mem_block=header['mem_block'])
+    assert header4 == header and header4.mutable is True
+    header5 = header.copy()
+    assert header5 == header and header5.mutable is True
+    header5['seq_nr'] = header['seq_nr'] + 1
+    assert header5['seq_nr'] == header['seq_nr'] + 1 and header5 != header
+    header5.time = np.datetime64('2014-01-20T05:30:00')
+    assert header5['gps'] == '2014 01 20 11 00 00 0.000000000'
+    header5['gps'] = '2014 01 20 11 00 00.000000000 0'
+    with pytest.raises(ValueError):
+        header5.time
