@@ -30,11 +30,11 @@ class VDIFPayload(PayloadBase):
             # odd widths: single channel only, padded up to the next width
             # that divides a 32-bit word
             if tuple(self.sample_shape) != (1,):
-                raise ValueError("VDIF data with several channels needs a bits "
-                                 "per sample that is a power of two.")
+                raise ValueError("multi-channel VDIF data requires bits per sample "
+                                 "that is a power of two.")      # (the reference's words: callers match on them)
             per_word = 32 // self._bpfs
             if bin(per_word).count('1') != 1:
-                raise ValueError("no sensible word packing for {} samples of {} bits"
+                raise ValueError("cannot yet sensibly handle {} data with bps={}"
                                  .format('complex' if self.complex_data else 'real', bps))
             self._bpfs = 32 // per_word
 

@@ -779,3 +779,85 @@ def test_gsb_headers_as_the_reference_tests_them(tmp_path):
     header5['gps'] = '2014 01 20 11 00 00.000000000 0'
     with pytest.raises(ValueError):
         header5.time
+
+
+def test_mark5b_locate_frames_and_find_header(tmp_path):
+    """mark5b/tests/test_mark5b.py::test_locate_frames and ::test_find_header."""
+    from baseband_amd.base.base import HeaderNotFoundError
+    m5 = os.path.join(S, 'sample.m5b')
+    with mark5b.open(m5, 'rb', kday=56000) as fh:
+        header0 = mark5b.Mark5BHeader.fromfile(fh, kday=56000)
+        fn = header0.frame_nbytes
+        fh.seek(0)
+        assert fh.locate_frames() == [0, 10016]
+        assert fh.locate_frames(forward=True) == [0, 10016]
+        assert fh.locate_frames(forward=False) == [0]
+        assert fh.tell() == 0
+        fh.seek(10000)
+        assert fh.locate_frames(forward=True) == [fn, 2 * fn]
+        assert fh.tell() == 10000
+        assert fh.locate_frames(forward=False) == [0]
+        fh.seek(-10000, 2)
+        assert fh.locate_frames(forward=False) == [3 * fn, 2 * fn]
+        fh.seek(-30, 2)
+        assert fh.locate_frames(forward=True) == []
+    m5_test = str(tmp_path / 'test.m5b')
+    with open(m5_test, 'wb') as s, open(m5, 'rb') as f:      # a corrupted file
+        s.write(f.read(10040))
+        f.seek(20000)
+        s.write(f.read())
+    shifted_pos = fn * 2 - 9960
+    with mark5b.open(m5_test, 'rb', kday=header0.kday) as fh:
+        fh.seek(0)
+        assert fh.locate_frames() == [0, shifted_pos]
+        assert fh.locate_frames(check=None) == [0, fn, shifted_pos]
+        fh.seek(10000)
+        assert fh.locate_frames(forward=True) == [shifted_pos, shifted_pos + fn]
+        assert fh.locate_frames(forward=True, check=None) == [fn, shifted_pos, shifted_pos + fn]
+    with open(m5_test, 'wb') as s, open(m5, 'rb') as f:      # a really short file
+        s.write(f.read(10018))
+    with mark5b.open(m5_test, 'rb') as fh:
+        fh.seek(10)
+        assert fh.locate_frames(forward=True) == []
+        assert fh.tell() == 10
+        assert fh.locate_frames(forward=False) == [0]
+    # ---- find_header
+    with mark5b.open(m5, 'rb', kday=56000) as fh:
+        fh.seek(0)
+        header_0 = fh.find_header()
+        assert fh.tell() == 0
+        fh.seek(10000)
+        header_10000f = fh.find_header(forward=True)
+        assert fh.tell() == fn
+        fh.seek(10000)
+        header_10000b = fh.find_header(forward=False)
+        assert fh.tell() == 0
+        fh.seek(16)
+        header_16b = fh.find_header(forward=False)
+        assert fh.tell() == 0
+        fh.seek(-10000, 2)
+        header_m10000b = fh.find_header(forward=False)
+        assert fh.tell() == 3 * fn
+        fh.seek(-30, 2)
+        with pytest.raises(HeaderNotFoundError):
+            fh.find_header(forward=True)
+    assert header_10000b == header_0 and header_16b == header_0
+    assert header_10000f['frame_nr'] == 1 and header_m10000b['frame_nr'] == 3
+    with open(m5_test, 'wb') as s, open(m5, 'rb') as f:
+        s.write(f.read(10040))
+        f.seek(20000)
+        s.write(f.read())
+    with mark5b.open(m5_test, 'rb', kday=header0.kday) as fh:
+        fh.seek(0)
+        fh.find_header()
+        assert fh.tell() == 0
+        fh.seek(10000)
+        fh.find_header(forward=True)
+        assert fh.tell() == fn * 2 - 9960
+    with open(m5_test, 'wb') as s, open(m5, 'rb') as f:
+        s.write(f.read(10018))
+    with mark5b.open(m5_test, 'rb') as fh:
+        fh.seek(10)
+        header_10 = fh.find_header(forward=False)
+        assert fh.tell() == 0
+    assert header_10 == header0

@@ -1470,3 +1470,120 @@ def test_mark5b_payload_and_frame(tmp_path):
         frame9 = mark5b.Mark5BFrame.fromfile(s, kday=56000, sample_shape=frame8.sample_shape, bps=frame8.payload.bps)
     assert frame9.valid is False and bool((frame9.data == 0.).all())
     assert np.all(np.asarray(frame9.payload.words) == 0x11223344)
+
+
+def test_vdif_payload_frame_frameset(tmp_path):
+    """vdif/tests/test_vdif.py::test_payload, ::test_invalid_payload, ::test_frame, ::test_frameset."""
+    import torch
+    first12 = np.array([1, 1, 1, -3, 1, 1, -3, -3, -3, 3, 3, -1])
+    with open(SAMPLE, 'rb') as fh:
+        header = vdif.VDIFHeader.fromfile(fh)
+        payload = vdif.VDIFPayload.fromfile(fh, header)
+    assert payload.nbytes == 5000 and payload.shape == (20000, 1) and payload.size == 20000 and payload.ndim == 2
+    assert payload.sample_shape == (1,) and payload.sample_shape.nchan == 1
+    assert payload.dtype == np.float32
+    assert np.all(payload[:12, 0].cpu().numpy().astype(int) == first12)
+    with open(str(tmp_path / 'test.vdif'), 'w+b') as s:
+        payload.tofile(s)
+        s.seek(0)
+        assert vdif.VDIFPayload.fromfile(s, header) == payload
+        with pytest.raises(EOFError):
+            s.seek(100)
+            vdif.VDIFPayload.fromfile(s, header)
+    assert vdif.VDIFPayload.fromdata(payload.data, header) == payload
+    with pytest.raises(ValueError):
+        vdif.VDIFPayload.fromdata(np.empty((payload.shape[0], 2), np.float32), header)   # wrong number of channels
+    with pytest.raises(ValueError):
+        vdif.VDIFPayload.fromdata(payload[:100], header)                                 # too few data
+    payload4 = vdif.VDIFPayload(payload.words, bps=2, complex_data=True)
+    assert payload4.complex_data is True and payload4.nbytes == 5000
+    assert payload4.shape == (10000, 1) and payload4.dtype == np.complex64
+    assert bool((payload4.data == torch.complex(payload[::2], payload[1::2])).all())
+    with pytest.raises(ValueError):
+        vdif.VDIFPayload.fromdata(payload4.data, header)
+    header5 = header.copy()
+    header5.complex_data = True
+    assert vdif.VDIFPayload.fromdata(payload4.data, header5) == payload4
+    # shapes for bps that are not powers of two (cannot be decoded)
+    assert vdif.VDIFPayload(payload.words, bps=7, complex_data=False).shape == (1250 * 4, 1)
+    assert vdif.VDIFPayload(payload.words, bps=7, complex_data=True).shape == (1250 * 2, 1)
+    assert vdif.VDIFPayload(payload.words, bps=11, complex_data=False).shape == (1250 * 2, 1)
+    assert vdif.VDIFPayload(payload.words, bps=11, complex_data=True).shape == (1250 * 1, 1)
+    with pytest.raises(ValueError, match='multi-channel'):
+        vdif.VDIFPayload(np.zeros(10, '<u4'), sample_shape=(10,), bps=5)
+    with pytest.raises(ValueError, match='cannot yet'):
+        vdif.VDIFPayload(np.zeros(10, '<u4'), bps=5)
+    # ---- frame
+    with vdif.open(SAMPLE, 'rb') as fh:
+        fh.seek(0)
+        frame = fh.read_frame()
+    assert frame.header == header and frame.payload == payload
+    assert frame.shape == payload.shape and frame.size == payload.size and frame.ndim == payload.ndim
+    assert frame == vdif.VDIFFrame(header, payload)
+    assert np.all(frame.data[:12, 0].cpu().numpy().astype(int) == first12)
+    vdif_test = str(tmp_path / 'test.vdif')
+    with open(vdif_test, 'w+b') as s:
+        frame.tofile(s)
+        s.seek(0)
+        assert vdif.VDIFFrame.fromfile(s) == frame
+    assert vdif.VDIFFrame.fromdata(payload.data, header) == frame
+    assert vdif.VDIFFrame.fromdata(payload.data, **header) == frame
+    frame5 = vdif.VDIFFrame(header.copy(), payload, valid=False)
+    assert frame5.valid is False and bool((frame5.data == 0.).all())
+    frame5.valid = True
+    assert frame5 == frame
+    with vdif.open(vdif_test, 'wb') as fw:
+        fw.write_frame(frame)
+        fw.write_frame(frame.data, header)
+    with open(vdif_test, 'rb') as s:
+        assert vdif.VDIFFrame.fromfile(s) == frame
+        assert vdif.VDIFFrame.fromfile(s) == frame
+    # ---- frame set
+    with vdif.open(SAMPLE, 'rb') as fh:
+        frameset = fh.read_frameset()
+    assert len(frameset.frames) == 8 and len(frameset) == len(frameset.frames[0])
+    assert frameset.samples_per_frame == 20000 and frameset.sample_shape == (8, 1)
+    assert frameset.shape == (20000, 8, 1) and frameset.size == 160000 and frameset.ndim == 3
+    assert frameset.nbytes == 8 * frameset.frames[0].nbytes
+    assert frameset.nchan == 1 and frameset.fill_value == 0.
+    assert 'edv' in frameset and 'edv' in frameset.keys() and frameset['edv'] == 3
+    assert bool(frameset['invalid_data']) is False
+    assert frameset.sample_rate == 32e6
+    assert frameset.time == frameset.header0.time
+    with pytest.raises(AttributeError):
+        frameset.update(1)
+    assert [fr.header['thread_id'] for fr in frameset.frames] == list(range(8))
+    first_frame = frameset.frames[header['thread_id']]
+    assert first_frame.header == header
+    assert np.all(first_frame[:12, 0].cpu().numpy().astype(int) == first12)
+    assert np.all(frameset.frames[0][:12, 0].cpu().numpy().astype(int) == np.array([-1, -1, 3, -1, 1, -1, 3, -1, 1, 3, -1, 1]))
+    assert np.all(frameset.frames[3][:12, 0].cpu().numpy().astype(int) == np.array([-1, 1, -1, 1, -3, -1, 3, -1, 3, -3, 1, 3]))
+    with vdif.open(SAMPLE, 'rb') as fh:
+        frameset2 = fh.read_frameset(thread_ids=[2, 3])
+        fh.fh_raw.seek(0)
+        frameset3 = fh.read_frameset(thread_ids=[3, 4, 1])
+    assert frameset2.shape == (20000, 2, 1)
+    assert bool((frameset2.data == frameset.data[:, 2:4]).all())
+    assert bool((frameset3.data == frameset.data[:, [3, 4, 1]]).all())
+    assert vdif.VDIFFrameSet(frameset.frames, frameset.header0) == frameset
+    frameset4 = vdif.VDIFFrameSet.fromdata(frameset.data, frameset.header0)
+    assert bool((frameset4.data == frameset.data).all()) and frameset4.time == frameset.time
+    assert vdif.VDIFFrameSet.fromdata(frameset.data, frameset4.header0) == frameset4
+    frameset6 = vdif.VDIFFrameSet.fromdata(frameset.data, **frameset4.header0)
+    assert frameset6 == frameset4
+    frameset6.frames[4].valid = False
+    frameset6.frames[6].sample_rate = frameset6.sample_rate / 2.
+    assert np.all(np.asarray(frameset6.valid) == np.array([True, True, True, True, False, True, True, True]))
+    assert np.all(np.asarray(frameset6['invalid_data']) == np.array([False, False, False, False, True, False, False, False]))
+    assert np.all(np.asarray(frameset6.sample_rate) == 32e6 * np.array([1., 1., 1., 1., 1., 1., 0.5, 1.]))
+    with vdif.open(SAMPLE, 'rb') as fh:
+        fh.seek(0)
+        frameset4 = fh.read_frameset(thread_ids=[2, 3])
+        assert frameset4.header0.time == frameset.header0.time
+        assert bool((frameset.data[:, 2:4] == frameset4.data).all())
+        fh.seek(-10064, 2)
+        with pytest.raises(EOFError):
+            fh.read_frameset(thread_ids=list(range(8)))
+        fh.seek(0)
+        with pytest.raises(OSError):
+            fh.read_frameset(thread_ids=[1, 9])
