@@ -134,6 +134,15 @@ class FrameBase:
             raise AttributeError("{} object has no attribute {}"
                                  .format(type(self).__name__, attr)) from None
 
+    def __setattr__(self, attr, value):
+        # the header's settable properties are set on the header
+        # (base/frame.py:228-234: ``frame.sample_rate = ...``, ``frame.time = ...``)
+        if attr not in ('header', 'payload', 'valid'):
+            header = self.__dict__.get('header')
+            if header is not None and attr in getattr(type(header), '_properties', ()):
+                return setattr(header, attr, value)
+        return super().__setattr__(attr, value)
+
     def __eq__(self, other):
         return (type(other) is type(self)
                 and (self.valid, self.header, self.payload)

@@ -248,8 +248,8 @@ class VDIFFrameSet:
         nthread = data.shape[1]
         if headers is None:
             kwargs.setdefault('thread_id', 0)
-            headers = VDIFHeader.fromvalues(
-                complex_data=data.is_complex(), verify=verify, **kwargs)
+            kwargs.setdefault('complex_data', data.is_complex())        # (``**header`` brings its own)
+            headers = VDIFHeader.fromvalues(verify=verify, **kwargs)
         if isinstance(headers, VDIFHeader):
             header0 = headers
             headers = []
@@ -294,7 +294,15 @@ class VDIFFrameSet:
 
     @property
     def valid(self):
-        return any(f.valid for f in self.frames)
+        """Whether the frames hold valid data: one bool when they agree, else one per
+        frame (vdif/frame.py:329-339)."""
+        valid = np.array([bool(f.valid) for f in self.frames])
+        return bool(valid[0]) if len(np.unique(valid)) == 1 else valid
+
+    @valid.setter
+    def valid(self, valid):
+        for f, v in zip(self.frames, np.broadcast_to(valid, (len(self.frames),))):
+            f.valid = bool(v)
 
     @property
     def fill_value(self):
@@ -309,10 +317,32 @@ class VDIFFrameSet:
     def keys(self):
         return self.header0.keys()
 
+    def __contains__(self, key):
+        return key in self.header0
+
+    def __eq__(self, other):
+        return (type(self) is type(other) and len(self.frames) == len(other.frames)
+                and self.header0 == other.header0
+                and all(f1 == f2 for f1, f2 in zip(self.frames, other.frames)))
+
+    __hash__ = None
+
     def __getattr__(self, attr):
-        if attr in ('frames', 'header0'):
+        """Header properties are the set's: those every VDIF header has from the first
+        header, the others (``sample_rate`` ...) from all frames -- one value when they
+        agree, else one per frame (vdif/frame.py:498-505)."""
+        if attr in ('frames', 'header0') or attr.startswith('__'):
             raise AttributeError(attr)
-        return getattr(self.header0, attr)
+        header0 = self.header0
+        if attr in type(header0)._properties:
+            from .header import VDIFBaseHeader
+            if attr in VDIFBaseHeader._properties:
+                return getattr(header0, attr)
+            values = [getattr(f.header, attr) for f in self.frames]
+            if all(v == values[0] for v in values[1:]):
+                return values[0]
+            return np.array(values)
+        raise AttributeError("{!r} object has no attribute {!r}".format(type(self).__name__, attr))
 
     def _decode_all(self):
         """All threads in one launch -> (nsample, nthread, nchan) tensor."""

@@ -227,8 +227,10 @@ class VDIFHeader(BitFieldHeader):
             self.verify()
         return self
 
-    _properties = ('frame_nbytes', 'payload_nbytes', 'bps', 'complex_data', 'nchan',
-                   'samples_per_frame', 'station', 'sample_rate')
+    # property-like keywords of every VDIF header, in the order `update` applies them
+    # (vdif/header.py:113-119); headers with a rate add theirs (VDIFSampleRateHeader)
+    _properties = ('frame_nbytes', 'payload_nbytes', 'bps', 'complex_data', 'nchan', 'sample_shape',
+                   'samples_per_frame', 'station', 'ref_time', 'time')
 
     @classmethod
     def fromkeys(cls, edv=None, *, verify=True, **kwargs):
@@ -535,6 +537,7 @@ class VDIFHeader0(VDIFBaseHeader, VDIFNoSampleRateHeader):
 class VDIFSampleRateHeader(VDIFBaseHeader):
     """EDVs that carry the sample rate (vdif/header.py:592-692)."""
     _header_parser = HeaderParser(_SAMPLE_RATE_FIELDS)
+    _properties = VDIFBaseHeader._properties[:-1] + ('sample_rate', 'frame_rate', 'time')
 
     @property
     def frame_rate(self):
