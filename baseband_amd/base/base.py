@@ -12,6 +12,7 @@ frame sets, streams the corresponding bytes to HBM in large windows
 index build -> decode.  The result is a device tensor.
 """
 import operator
+import io
 import os
 import threading
 import warnings
@@ -48,6 +49,56 @@ class FileBase:
         if attr == 'fh_raw':
             raise AttributeError(attr)
         return getattr(self.fh_raw, attr)
+
+    # A stream writer queues the frames it has packed for this handle
+    # (staging.write_device_bytes; the queue writes to `fh_raw` itself).  Whoever asks
+    # where the file stands, or writes or seeks on the side, finds the file as if
+    # every frame had been written when ``write`` returned -- as in the reference.
+    _queues_writes = True
+
+    # Pickling a file reader: what it was given, where it stands, and the NAME of the
+    # file underneath -- the handle is opened again on arrival (base/base.py:123-151 in
+    # the reference); images of the file, windows in HBM and the info are made again.
+    _unpickled_state = ('_image', '_frame_dev', '_frame_end', '_frame_run', '_frame_dev_bytes', 'info', '_info')
+
+    def __getstate__(self):
+        if self.writable():
+            raise TypeError('cannot pickle file opened for writing')
+        state = {k: v for k, v in self.__dict__.items() if k not in self._unpickled_state}
+        fh = state['fh_raw']
+        if isinstance(fh, io.IOBase):
+            del state['fh_raw']
+            state['_reopen'] = (fh.name, fh.mode, None if fh.closed else fh.tell())
+        return state
+
+    def __setstate__(self, state):
+        reopen = state.pop('_reopen', None)
+        if reopen is not None:
+            name, mode, offset = reopen
+            fh = io.open(name, mode)
+            if offset is None:
+                fh.close()
+            else:
+                fh.seek(offset)
+            state['fh_raw'] = fh
+        self.__dict__.update(state)
+
+    def _settle(self):
+        from .. import staging
+        if staging._sinks:
+            staging.finish_writes(self, close_sink=False)
+
+    def tell(self):
+        self._settle()
+        return self.fh_raw.tell()
+
+    def seek(self, *args):
+        self._settle()
+        return self.fh_raw.seek(*args)
+
+    def write(self, data):
+        self._settle()
+        return self.fh_raw.write(data)
 
     class _TemporaryOffset:
         def __init__(self, fh, offset, whence):
@@ -283,16 +334,50 @@ class VLBIFileReaderBase(FileBase):
     def _info_extras(self, header0, offset0):
         return {}
 
-    @property
-    def info(self):
-        """`FileReaderInfo` snapshot (base/file_info.py:282-415)."""
+    info = None         # (the descriptor below, set once the class exists)
+
+
+class _FileReaderInfoProperty:
+    """``reader.info``: a `FileReaderInfo` snapshot kept in the reader's ``__dict__``
+    and made again when the reader is closed or one of the arguments it was
+    constructed with is changed (``fh.nchan = 8``); it can be deleted (to have it made
+    again) but not set (base/file_info.py:282-415, and the `info_item` machinery there)."""
+
+    @staticmethod
+    def _key(reader):
+        cls = type(reader)
+        names = cls.__dict__.get('_info_key_names')
+        if names is None:
+            import inspect
+            names = tuple(n for n in inspect.signature(cls.__init__).parameters if n not in ('self', 'fh_raw'))
+            cls._info_key_names = names
+        try:
+            closed = bool(reader.fh_raw.closed)
+        except Exception:
+            closed = False
+        return (closed,) + tuple(str(getattr(reader, n, None)) for n in names)
+
+    def __get__(self, reader, cls=None):
+        if reader is None:
+            return self
         from .info import FileReaderInfo
-        cached = self.__dict__.get('_info')
-        if cached is None:
-            cached = self.__dict__['_info'] = FileReaderInfo(
-                self, self._format or type(self).__name__.replace('FileReader', '').lower(),
-                self._info_needs())
+        cached = reader.__dict__.get('info')
+        if cached is None or cached._made_for != self._key(reader):
+            cached = FileReaderInfo(
+                reader, reader._format or type(reader).__name__.replace('FileReader', '').lower(),
+                reader._info_needs())
+            cached._made_for = self._key(reader)        # (after: making it may settle e.g. Mark 4 `ntrack`)
+            reader.__dict__['info'] = cached
         return cached
+
+    def __set__(self, reader, value):
+        raise AttributeError("can't set attribute 'info'")
+
+    def __delete__(self, reader):
+        reader.__dict__.pop('info', None)
+
+
+VLBIFileReaderBase.info = _FileReaderInfoProperty()
 
 
 def _to_host_array(data, out):
@@ -761,6 +846,17 @@ class GPUStreamReaderBase:
         return part
 
     # -- the hot path
+    def _raw_follows(self):
+        """Leave the raw file pointer after the last frame (set) a read touched, where
+        the reference's frame-by-frame reads leave it (base/base.py:971-1010 there): its
+        callers interleave ``fh_raw.tell()`` / raw reads with stream reads.  (The seek of
+        the file underneath, looked up once: this runs in every small read.)"""
+        seek = self.__dict__.get('_raw_seek')
+        if seek is None:
+            raw = self.fh_raw
+            seek = self._raw_seek = getattr(raw, 'fh_raw', raw).seek
+        seek(self._file_offset0 + ((self.offset - 1) // self.samples_per_frame + 1) * self._set_nbytes)
+
     def read(self, count=None, out=None):
         """Read and decode `count` complete samples -> device tensor of shape
         ``(count,) + sample_shape`` (base/base.py:919-969)."""
@@ -785,6 +881,7 @@ class GPUStreamReaderBase:
         if ahead is not None:
             self.offset += count
             self._seq_end = self.offset
+            self._raw_follows()
             if out is None:
                 if host and isinstance(ahead, torch.Tensor):
                     from ..staging import download_new
@@ -806,6 +903,8 @@ class GPUStreamReaderBase:
             data, direct = self._fill_request(out, count)
         self.offset += count
         self._seq_end = self.offset
+        if count:
+            self._raw_follows()
         if direct:
             return out
         data = self._squeeze_and_subset(data)
@@ -1308,10 +1407,8 @@ class GPUStreamReaderBase:
         recipe = getattr(self, '_pickle_recipe', None)
         if recipe is None:
             raise TypeError("can only pickle readers opened from named files")
-        if self.closed:
-            raise TypeError("cannot pickle a closed stream reader")
         reopen, opener, source, init_args = recipe
-        return (reopen, (opener, source, init_args, self.offset))
+        return (reopen, (opener, source, init_args, self.offset, bool(self.closed)))
 
 
 # the reference's names for these roles (base/base.py)

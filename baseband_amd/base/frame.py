@@ -160,8 +160,10 @@ def block_frame_class(name, header_class, payload_class, doc):
         return cls(header, payload_class.fromfile(fh, header=header, memmap=memmap),
                    verify=verify)
 
-    def fromdata(cls, data, header, verify=True):
-        return cls(header, payload_class.fromdata(data, header=header), verify=verify)
+    def fromdata(cls, data, header=None, *, valid=None, verify=True, **kwargs):
+        if header is None:              # (header from the keywords: base/frame.py:114-134 in the reference)
+            header = header_class.fromvalues(verify=verify, **kwargs)
+        return cls(header, payload_class.fromdata(data, header=header), valid=valid, verify=verify)
 
     return type(name, (FrameBase,), dict(
         __doc__=doc, _header_class=header_class, _payload_class=payload_class,

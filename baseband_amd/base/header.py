@@ -131,8 +131,13 @@ class BitFieldHeader:
             self.words = [0] * (self._struct.size // 4)
             self._mutable = True
         else:
-            self.words = tuple(int(w) for w in words)
-            self._mutable = False
+            # as the reference's headers, which keep the caller's container: a header
+            # of a list or a writeable array can be changed, one of a tuple (what
+            # `fromfile` unpacks) or a read-only array cannot (base/header.py:337-363
+            # there).  The words are COPIED here: changes do not write through.
+            self._mutable = (isinstance(words, list)
+                             or bool(getattr(getattr(words, 'flags', None), 'writeable', False)))
+            self.words = (list if self._mutable else tuple)(int(w) for w in words)
         if verify:
             self.verify()
 

@@ -74,6 +74,9 @@ class FileReaderInfo(_Snapshot):
         self.title = type(reader).__name__.replace('Reader', '') + ' information'
         self.format = None
         self.missing = dict(needs or {})
+        if getattr(reader.fh_raw, 'closed', False):
+            self.closed, self.header0, self.readable = True, None, False    # nothing can be asked of it
+            return
         with reader.temporary_offset(0):
             header0 = self._guarded('header0', lambda: self._first_header(reader))
         self.header0 = header0
@@ -84,13 +87,19 @@ class FileReaderInfo(_Snapshot):
             find = getattr(reader, '_info_format_by_search', None)
             if find is not None:
                 with reader.temporary_offset(0):
-                    self.format = self._guarded('format', lambda: fmt if find() else None)
+                    found = self._guarded('format', find)
+                if found:
+                    self.format = fmt
+                    if isinstance(found, (list, tuple)):        # where the frames start is known all the same
+                        self.offset0 = found[0]
+                        self.attr_names = ('format', 'offset0') + type(self).attr_names[1:]
             self.readable = False
             return
         self.format = fmt
         offset0 = getattr(self, '_offset0', 0)
         extras = self._guarded('extras', lambda: reader._info_extras(header0, offset0), {}) or {}
         shape = extras.pop('_sample_shape', None)
+        self.warnings.update(extras.pop('_warnings', None) or {})
         self.attr_names = (('format',) + tuple(extras) + type(self).attr_names[1:])
         for key, value in extras.items():
             setattr(self, key, value)
@@ -174,6 +183,13 @@ class StreamReaderInfo(_Snapshot):
     attr_names = ('start_time', 'stop_time', 'sample_rate', 'shape', 'format',
                   'bps', 'complex_data', 'verify', 'readable', 'checks',
                   'errors', 'warnings')
+
+    def __call__(self):
+        """Dict of what could be determined, the raw file's under 'file_info'."""
+        out = super().__call__()
+        if getattr(self, 'file_info', None):
+            out['file_info'] = self.file_info()
+        return out
 
     def __init__(self, stream):
         super().__init__()

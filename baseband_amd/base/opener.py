@@ -38,10 +38,13 @@ def source_kind(name):
     raise ValueError("name '{}' not understood.".format(name))
 
 
-def _reopen_stream(opener, source, kwargs, offset):
-    """Unpickling: open again from the recorded source and go to `offset`."""
+def _reopen_stream(opener, source, kwargs, offset, closed=False):
+    """Unpickling: open again from the recorded source and go to `offset`; a reader
+    that was closed when pickled comes back closed."""
     reader = opener(source, 'rs', **kwargs)
     reader.offset = offset
+    if closed:
+        reader.close()
     return reader
 
 

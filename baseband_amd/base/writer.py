@@ -31,13 +31,27 @@ class LazyWriteFile:
             self._fh = open(self.name, 'w+b')
         return self._fh
 
+    # frames a stream writer has packed are queued for this handle and written behind
+    # its back (staging.write_device_bytes -- to the file itself, `fh_raw`): whoever asks
+    # where the file stands, or writes or seeks on the side, finds every frame in place
+    _queues_writes = True
+    fh_raw = property(lambda self: self._open())
+
+    def _settle(self):
+        from .. import staging
+        if staging._sinks:
+            staging.finish_writes(self, close_sink=False)
+
     def write(self, data):
+        self._settle()
         return self._open().write(data)
 
     def tell(self):
+        self._settle()
         return self._fh.tell() if self._fh is not None else 0
 
     def seek(self, offset, whence=0):
+        self._settle()
         return self._open().seek(offset, whence)
 
     def read(self, count=-1):
@@ -49,6 +63,15 @@ class LazyWriteFile:
 
     def fileno(self):
         return self._open().fileno()
+
+    def readable(self):
+        return True
+
+    def writable(self):
+        return True
+
+    def seekable(self):
+        return True
 
     @property
     def closed(self):
@@ -105,6 +128,9 @@ class GPUStreamWriterBase:
         return cached[1]
 
     _sample_shape_fields = None
+
+    def __reduce__(self):
+        raise TypeError('cannot pickle file opened for writing')
 
     def readable(self):
         """A stream writer cannot be read from (base/base.py:559-567 in the reference)."""

@@ -73,6 +73,10 @@ class GSBFileReader(FileBase):
         self.bps, self.complex_data = bps, complex_data
         super().__init__(fh_raw)
 
+    def __repr__(self):
+        return ("{name}(fh_raw={s.fh_raw}, payload_nbytes={s.payload_nbytes}, nchan={s.nchan}, bps={s.bps}, "
+                "complex_data={s.complex_data})".format(name=type(self).__name__, s=self))
+
     def read_payload(self):
         return GSBPayload.fromfile(self.fh_raw, payload_nbytes=self.payload_nbytes,
                                    sample_shape=(self.nchan,), bps=self.bps,
@@ -88,8 +92,26 @@ class GSBFileWriter(FileBase):
         return data.tofile(self.fh_raw)
 
 
+def _stream_repr(self):
+    """The reference's layout (gsb/base.py:240-254): timestamp file, data file(s), shape."""
+    raw = self.fh_raw
+    if isinstance(raw, (list, tuple)):
+        data_name = tuple(tuple(str(getattr(p, 'name', None)).split('/')[-1] for p in pol) for pol in raw)
+    else:
+        data_name = getattr(raw, 'name', None)
+    subset = getattr(self, 'subset', None)
+    return ("<{cls} header={ts} offset= {s.offset}\n    data={dn}\n"
+            "    sample_rate={s.sample_rate:.5g}, samples_per_frame={s.samples_per_frame},\n"
+            "    sample_shape={s.sample_shape}, bps={s.bps},\n"
+            "    {sub}start_time={s.start_time}>"
+            .format(cls=type(self).__name__, s=self, ts=getattr(self.fh_ts, 'name', None), dn=data_name,
+                    sub='subset={0}, '.format(subset) if subset else ''))
+
+
 class GSBStreamReader(GPUStreamReaderBase):
     _sample_shape_fields = staticmethod(lambda n: ('nchan',) if n == 1 else ('nthread', 'nchan'))
+    __repr__ = _stream_repr
+
     def __init__(self, fh_ts, fh_raw, sample_rate=None, samples_per_frame=None,
                  payload_nbytes=None, nchan=None, bps=None, complex_data=None,
                  squeeze=True, subset=(), verify=True):
@@ -218,6 +240,9 @@ class GSBStreamReader(GPUStreamReaderBase):
     # raw file, [pol][part] order, presented as one virtual image
     _file_offset0 = 0
 
+    def _raw_follows(self):
+        pass                            # (several raw files and a timestamp file: no one pointer to place)
+
     def _image(self):
         if getattr(self, '_set_image', None) is None:
             self._set_image = _BlockSetImage(self._images, self._payload_nbytes)
@@ -292,6 +317,7 @@ class GSBStreamWriter(GPUStreamWriterBase):
     file (rawdump) or to ``fh_raw[pol][part]`` (phased: parts are consecutive
     in time).  Arguments and defaults as for the reader."""
     _sample_shape_fields = staticmethod(lambda n: ('nchan',) if n == 1 else ('nthread', 'nchan'))
+    __repr__ = _stream_repr
 
     def __init__(self, fh_ts, fh_raw, header0=None, sample_rate=None,
                  samples_per_frame=None, payload_nbytes=None, nchan=None, bps=None,
@@ -375,6 +401,25 @@ class GSBStreamWriter(GPUStreamWriterBase):
             fh.close()
 
 
+def _name_of(fh):
+    """File name(s) of a handle or a nest of handles; None if any has none."""
+    if isinstance(fh, (tuple, list)):
+        names = tuple(_name_of(f) for f in fh)
+        return None if any(n is None for n in names) else names
+    name = getattr(fh, 'name', None)
+    return name if isinstance(name, str) else None
+
+
+def _reopen_stream(opener, source, kwargs, offset, closed=False):
+    """Unpickling / copying a stream reader: open the files again, go to `offset`;
+    a reader that was closed comes back closed."""
+    reader = open(source[0], 'rs', raw=source[1], **kwargs)
+    reader.offset = offset
+    if closed:
+        reader.close()
+    return reader
+
+
 def open(name, mode='rs', **kwargs):
     """Open a GSB timestamp file plus ``raw=`` data file(s) for stream reading
     (``'rs'``) or writing (``'ws'``) (gsb/base.py:460-560).  ``raw`` is one
@@ -416,7 +461,13 @@ def open(name, mode='rs', **kwargs):
             raw = (raw,)
         fh_raw = tuple(tuple(handle(f) for f in pair) for pair in raw)
     if rw == 'r':
-        return GSBStreamReader(fh_ts, fh_raw, **kwargs)
+        reader = GSBStreamReader(fh_ts, fh_raw, **kwargs)
+        # pickling / copying: the files are opened again by name on arrival
+        source = (_name_of(fh_ts), _name_of(fh_raw))
+        if source[0] is not None and source[1] is not None:
+            reader._pickle_recipe = (_reopen_stream, None, source,
+                                     dict(kwargs, header_mode=stream_mode))
+        return reader
     if 'header0' not in kwargs:
         kwargs['mode'] = stream_mode
     return GSBStreamWriter(fh_ts, fh_raw, **kwargs)

@@ -25,7 +25,12 @@ class GUPPIFileReader(VLBIFileReaderBase):
     _format = 'guppi'
 
     def _info_extras(self, header0, offset0):
-        return {'pktfmt': header0['PKTFMT'], 'overlap': header0.overlap}
+        extras = {'pktfmt': header0['PKTFMT'], 'overlap': header0.overlap}
+        if extras['pktfmt'] not in header0.supported_formats:
+            # (read as the usual layout all the same: guppi/file_info.py:28-35 in the reference)
+            extras['_warnings'] = {'pktfmt': 'Unknown pktfmt {!r}. Assuming channels are stored first.'
+                                   .format(extras['pktfmt'])}
+        return extras
 
     def read_header(self):
         return GUPPIHeader.fromfile(self.fh_raw)

@@ -91,6 +91,8 @@ class _NoSeekPastEnd:
 class GUPPIHeader(dict):
     """Dictionary of header cards with the reference's derived properties."""
 
+    supported_formats = {'1SFA', 'SIMPLE'}      # packet formats known to read correctly (guppi/header.py:69-77)
+
     # guppi/header.py:56-67
     _defaults = [('BACKEND', 'GUPPI'), ('BLOCSIZE', 0), ('STT_OFFS', 0), ('PKTIDX', 0),
                  ('OVERLAP', 0), ('SRC_NAME', 'unset'), ('TELESCOP', 'unset'),

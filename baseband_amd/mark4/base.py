@@ -42,7 +42,7 @@ class Mark4FileReader(VLBIFileReaderBase):
         # cannot be; mark4/file_info.py decides the format by the frames alone)
         if self.ntrack is None:
             self.determine_ntrack()
-        return len(self.locate_frames()) > 0
+        return self.locate_frames()
 
     def _info_number_of_frames(self, header0, offset0):
         with self.temporary_offset(-header0.frame_nbytes, 2):
@@ -54,6 +54,10 @@ class Mark4FileReader(VLBIFileReaderBase):
         self.decade = operator.index(decade) if decade is not None else None
         self.ref_time = ref_time
         super().__init__(fh_raw)
+
+    def __repr__(self):
+        return ("{name}(fh_raw={s.fh_raw}, ntrack={s.ntrack}, decade={s.decade}, ref_time={s.ref_time})"
+                .format(name=type(self).__name__, s=self))
 
     def read_header(self):
         return Mark4Header.fromfile(self.fh_raw, ntrack=self.ntrack,
@@ -83,8 +87,8 @@ class Mark4FileReader(VLBIFileReaderBase):
         # a frame is 20000 stream words of ntrack bits = 2500 bytes per track
         if frame_nbytes is not None:
             if frame_nbytes % 2500:
-                raise ValueError('Mark 4 frames hold 2500 bytes per track: '
-                                 'frame_nbytes must be a multiple of that.')
+                raise ValueError('Mark 4 frames hold 2500 bytes per track: frame_nbytes '
+                                 'must be a multiple of 2500 bytes.')
             ntrack = frame_nbytes // 2500
         else:
             ntrack = self.ntrack

@@ -52,7 +52,9 @@ class Mark4Frame(FrameBase):
         return cls(header, payload, verify=verify)
 
     @classmethod
-    def fromdata(cls, data, header, verify=True):
+    def fromdata(cls, data, header=None, verify=True, **kwargs):
+        if header is None:              # (header from the keywords: mark4/frame.py:124-146 in the reference)
+            header = Mark4Header.fromvalues(verify=verify, **kwargs)
         assert data.shape[0] == header.samples_per_frame
         start = header.nbytes * 8 // (header.ntrack // header.fanout)
         payload = Mark4Payload.fromdata(data[start:], header=header)

@@ -40,7 +40,7 @@ class Mark5BFileReader(VLBIFileReaderBase):
         return needs
 
     def _info_format_by_search(self):
-        return len(self.locate_frames()) > 0
+        return self.locate_frames()
 
     def _info_extras(self, header0, offset0):
         return {'offset0': offset0}
@@ -51,6 +51,10 @@ class Mark5BFileReader(VLBIFileReaderBase):
         self.nchan = operator.index(nchan) if nchan is not None else None
         self.bps = operator.index(bps)
         super().__init__(fh_raw)
+
+    def __repr__(self):
+        return ("{name}(fh_raw={s.fh_raw}, kday={s.kday}, ref_time={s.ref_time}, nchan={s.nchan}, bps={s.bps})"
+                .format(name=type(self).__name__, s=self))
 
     def read_header(self):
         return Mark5BHeader.fromfile(self.fh_raw, kday=self.kday,

@@ -587,6 +587,8 @@ class _FileSink:
     _NWORKER = int(os.environ.get('BB_WRITE_THREADS', 4))
 
     def __init__(self, fh, depth=None):
+        while getattr(type(fh), '_queues_writes', False):
+            fh = fh.fh_raw              # (a FileBase settles its queue before it answers: write below it)
         self.fh = fh
         self.positional = bool(_WRITE_ASYNC and getattr(fh, 'can_pwrite', False) and self._NWORKER > 1)
         nq = self._NWORKER if self.positional else 1

@@ -18,7 +18,7 @@ from baseband_amd import synth_codes as enc
 
 def test_vdif_header_fields_sample(manifest):
     case = manifest['sample_vdif']
-    h = VDIFHeader(case['header0_words'])
+    h = VDIFHeader(tuple(case['header0_words']))      # (a tuple, as `fromfile` unpacks: not to be changed)
     # sample.vdif facts (vdif/tests/test_vdif.py:44-80)
     assert h.edv == 3 and h.frame_nbytes == 5032 and h.payload_nbytes == 5000
     assert h.bps == 2 and h.nchan == 1 and not h.complex_data
@@ -30,7 +30,7 @@ def test_vdif_header_fields_sample(manifest):
     assert mask == case['stream_mask']
     assert h.same_stream(h)
     with pytest.raises(TypeError):
-        h['frame_nr'] = 3                 # immutable when read from words
+        h['frame_nr'] = 3                 # immutable when made of a tuple of words
     h2 = h.copy()
     h2['frame_nr'] = 3
     assert h2['frame_nr'] == 3 and h['frame_nr'] == 0
