@@ -8,7 +8,7 @@ import torch
 from .. import _lib, kernels
 from ..base.base import FileBase, VLBIFileReaderBase
 from ..base.blockreader import BlockStreamReader
-from ..base.opener import FormatOpener
+from ..base.opener import FormatOpener, source_kind
 from ..base.writer import BlockStreamWriter
 from ..helpers.sequentialfile import UpperCaseSequencer
 from .header import DADAHeader
@@ -269,8 +269,26 @@ class DADAStreamWriter(BlockStreamWriter):
         header['OBS_OFFSET'] = self.header0['OBS_OFFSET'] + index * self.header0.payload_nbytes
         return header
 
+    def _storage_order(self, block):
+        if self.header0.get('INSTRUMENT') != 'MKBF':
+            return block
+        # MeerKAT beamformer: heaps of 256 samples, stored (heap, pol, chan, 256, re/im)
+        # (dada/payload.py:54-89 in the reference; the reader's `bb_decode_i8_tiled` undoes it)
+        nframes, spf, npol, nchan = block.shape[:4]
+        return block.reshape(nframes, spf // 256, 256, npol, nchan, -1).movedim(2, 4)
+
 
 class _DADAOpener(FormatOpener):
+    def __call__(self, name, mode='rs', **kwargs):
+        if (self.normalize_mode(mode) == 'ws' and kwargs.get('header0') is None
+                and source_kind(name) in ('sequence', 'template')):
+            # header keywords instead of a header: make it here, so that the files of the
+            # sequence get their size (one frame each) from it (dada/base.py:411-425 there)
+            squeeze = kwargs.pop('squeeze', True)
+            extra = {k: kwargs.pop(k) for k in ('file_size',) if k in kwargs}
+            kwargs = dict(header0=DADAHeader.fromvalues(**kwargs), squeeze=squeeze, **extra)
+        return super().__call__(name, mode, **kwargs)
+
     def _sequencer_for(self, template, mode, kwargs):
         fns = super()._sequencer_for(template, mode, kwargs)
         if mode[0] == 'r' and 'obs_offset' in template.lower():

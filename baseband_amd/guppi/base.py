@@ -206,10 +206,15 @@ class GUPPIStreamWriter(BlockStreamWriter):
 class _GUPPIOpener(FormatOpener):
     def __call__(self, name, mode='rs', **kwargs):
         per_file = kwargs.pop('frames_per_file', 128)
-        if (self.normalize_mode(mode) == 'ws' and kwargs.get('header0') is not None
-                and 'file_size' not in kwargs):
-            from ..base.opener import source_kind
-            if source_kind(name) in ('sequence', 'template'):
+        from ..base.opener import source_kind
+        if self.normalize_mode(mode) == 'ws' and source_kind(name) in ('sequence', 'template'):
+            if kwargs.get('header0') is None:
+                # header keywords instead of a header: make it here, so that the files of
+                # the sequence get their size from it (guppi/base.py:351-368 in the reference)
+                squeeze = kwargs.pop('squeeze', True)
+                extra = {k: kwargs.pop(k) for k in ('file_size',) if k in kwargs}
+                kwargs = dict(header0=GUPPIHeader.fromvalues(**kwargs), squeeze=squeeze, **extra)
+            if 'file_size' not in kwargs:
                 kwargs['file_size'] = per_file * kwargs['header0'].frame_nbytes
         return super().__call__(name, mode, **kwargs)
 

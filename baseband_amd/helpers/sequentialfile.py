@@ -549,6 +549,7 @@ class SequentialFileWriter(_SequentialBase):
 
     _pw_fds = None
     _pw_lock = None
+    _pw_made = None         # files of the sequence that exist by this writer's doing
 
     def _pwrite_fd(self, nr):
         if self._pw_fds is None:
@@ -563,9 +564,16 @@ class SequentialFileWriter(_SequentialBase):
                         name = _as_name(self.files[nr])
                     except IndexError:
                         raise OSError('ran out of files.') from None
-                    # (the file this writer has open already exists -- 'w+b' made it -- and
-                    # must not be truncated under it; later ones are created here)
-                    fd = self._pw_fds[nr] = os.open(name, os.O_WRONLY | os.O_CREAT, 0o666)
+                    # (the files this writer has opened itself exist -- 'w+b' made them -- and
+                    # must not be truncated under it; later ones are created here, EMPTY the
+                    # first time: what an older, longer file of that name held must not stay)
+                    flags = os.O_WRONLY | os.O_CREAT
+                    if self._pw_made is None:
+                        self._pw_made = set(range(self.file_nr + 1))
+                    if nr not in self._pw_made and nr > self.file_nr:
+                        flags |= os.O_TRUNC
+                    self._pw_made.add(nr)
+                    fd = self._pw_fds[nr] = os.open(name, flags, 0o666)
         return fd
 
     def sync_position(self, total):

@@ -3207,3 +3207,283 @@ def test_gsb_phased_stream(tmp_path):
         gsb.open(_GSB_TS_PH, 'rs', raw=_GSB_PHASED, payload_nbytes=32, samples_per_frame=400)
     with pytest.raises(ValueError, match='inconsistent'):
         gsb.open(_GSB_TS_RAW, 'rs', raw=_GSB_RAW, payload_nbytes=32, samples_per_frame=400)
+
+
+def _dada_sample():
+    from baseband_amd import dada
+    with open(DADA, 'rb') as fh:
+        header = dada.DADAHeader.fromfile(fh)
+        payload = dada.DADAPayload.fromfile(fh, header, memmap=False)
+    return header, payload
+
+
+def test_dada_incomplete_stream_and_pickle(tmp_path):
+    """dada/tests/test_dada.py::test_incomplete_stream, ::test_pickle."""
+    import pickle
+    from baseband_amd import dada
+    header, payload = _dada_sample()
+    filename = str(tmp_path / 'a.dada')
+    with pytest.warns(UserWarning, match='partial buffer'):
+        with dada.open(filename, 'ws', header0=header, squeeze=False) as fw:
+            fw.write(payload[:10])
+    with dada.open(filename, 'rs', squeeze=False) as fwr:
+        data = fwr.read()
+        assert bool((data[:10] == payload[:10]).all()) and bool((data[10:] == fwr.fill_value).all())
+    with dada.open(DADA, 'rs', squeeze=False) as fh:
+        fh.seek(6)
+        pickled = pickle.dumps(fh)
+        fh.read(3)
+        with pickle.loads(pickled) as fh2:
+            assert fh2.tell() == 6
+            fh2.read(10)
+        assert fh.tell() == 9
+    with pickle.loads(pickled) as fh3:
+        assert fh3.tell() == 6
+        fh3.read(1)
+    closed = pickle.dumps(fh)
+    with pickle.loads(closed) as fh4:
+        assert fh4.closed
+        with pytest.raises(ValueError):
+            fh4.read(1)
+
+
+def test_dada_multiple_files_and_template_streams(tmp_path):
+    """dada/tests/test_dada.py::test_multiple_files_stream, ::test_template_stream,
+    ::test_complicated_template_stream."""
+    import pickle
+    from baseband_amd import dada
+    from baseband_amd.helpers import sequentialfile as sf
+    ns = np.timedelta64(1, 'ns')
+    at = lambda t0, n: t0 + np.timedelta64(int(round(n / 16e6 * 1e9)), 'ns')       # noqa: E731
+    header0, payload = _dada_sample()
+    data = payload.data.squeeze()
+    host = data.cpu().numpy()
+    header = header0.copy()
+    header.payload_nbytes = header0.payload_nbytes // 2
+    filenames = (str(tmp_path / 'a.dada'), str(tmp_path / 'b.dada'))
+    with dada.open(filenames, 'ws', **header) as fw:
+        start_time = fw.start_time
+        fw.write(data[:1000])
+        time1000 = fw.time
+        fw.write(data[1000:])
+        stop_time = fw.time
+    assert start_time == header.time
+    assert abs(time1000 - at(start_time, 1000)) < ns and abs(stop_time - at(start_time, 16000)) < ns
+    with dada.open(filenames[1], 'rs') as fr:
+        assert abs(fr.time - at(start_time, 8000)) < ns
+        assert np.all(fr.read().cpu().numpy() == host[8000:])
+    with dada.open(filenames, 'rs') as fr:
+        assert fr.start_time == start_time and fr.time == start_time
+        assert abs(fr.stop_time - at(start_time, 16000)) < ns
+        data2 = fr.read()
+        assert fr.time == fr.stop_time
+    assert np.all(data2.cpu().numpy() == host)
+    filenames = (str(tmp_path / 'a2.dada'), str(tmp_path / 'b2.dada'))
+    with sf.open(filenames, 'w+b', file_size=header.payload_nbytes + 4096) as fraw, \
+            dada.open(fraw, 'ws', header0=header) as fw:
+        fw.write(data)
+    with dada.open(filenames, 'rs') as fr:
+        assert np.all(fr.read().cpu().numpy() == host)
+    with dada.open(filenames, 'rs', subset=1, squeeze=False) as fr:
+        assert np.all(fr.read().cpu().numpy().squeeze() == host[:, 1])
+    with dada.open(filenames, 'rs', subset=1, squeeze=False) as fr:
+        fr.seek(10)
+        pickled = pickle.dumps(fr)
+    with pickle.loads(pickled) as fr2:
+        assert fr2.tell() == 10
+        assert np.all(fr2.read().cpu().numpy().squeeze() == host[10:, 1])
+    with pytest.raises(ValueError):
+        dada.open(filenames, 'wb')
+    # ---- {frame_nr} template
+    header = header0.copy()
+    header.payload_nbytes = header0.payload_nbytes // 4
+    template = str(tmp_path / 'a{frame_nr}.dada')
+    with dada.open(template, 'ws', header0=header) as fw:
+        fw.write(data[:1000])
+        time1000 = fw.time
+        fw.write(data[1000:])
+        stop_time = fw.time
+    assert abs(time1000 - at(header.time, 1000)) < ns and abs(stop_time - at(header.time, 16000)) < ns
+    with dada.open(template.format(frame_nr=1), 'rs') as fr:
+        data1 = fr.read()
+        assert fr.time == fr.stop_time
+        assert abs(fr.start_time - at(start_time, 4000)) < ns and abs(fr.stop_time - at(start_time, 8000)) < ns
+    assert np.all(data1.cpu().numpy() == host[4000:8000])
+    with dada.open(template, 'rs') as fr:
+        assert fr.time == start_time
+        data2 = fr.read()
+        assert fr.stop_time == fr.time and abs(fr.stop_time - at(header.time, 16000)) < ns
+    assert np.all(data2.cpu().numpy() == host)
+    # ---- the usual naming scheme, 8 files
+    header = header0.copy()
+    header.payload_nbytes = header0.payload_nbytes // 8
+    template = str(tmp_path / '{utc_start}_{obs_offset:016d}.000000.dada')
+    with dada.open(template, 'ws', header0=header) as fw:
+        fw.write(data[:7000])
+        assert fw.start_time == header.time and abs(fw.time - at(start_time, 7000)) < ns
+        fw.write(data[7000:])
+        assert abs(fw.time - at(start_time, 16000)) < ns
+    name3 = template.format(utc_start=header['UTC_START'],
+                            obs_offset=header['OBS_OFFSET'] + 3 * header.payload_nbytes)
+    with dada.open(name3, 'rs') as fr:
+        assert abs(fr.start_time - at(start_time, 6000)) < ns and abs(fr.stop_time - at(start_time, 8000)) < ns
+        data1 = fr.read()
+        assert fr.stop_time == fr.time
+    assert np.all(data1.cpu().numpy() == host[6000:8000])
+    with pytest.raises(KeyError):
+        dada.open(template, 'rs')           # UTC_START is not known
+    kwargs = dict(UTC_START=header['UTC_START'], OBS_OFFSET=header['OBS_OFFSET'] + 3 * header.payload_nbytes,
+                  FILE_SIZE=header['FILE_SIZE'])
+    with dada.open(template, 'rs', **kwargs) as fr:
+        assert abs(fr.time - at(start_time, 6000)) < ns
+        data2 = fr.read()
+        assert fr.time == fr.stop_time and abs(fr.stop_time - at(start_time, 16000)) < ns
+    assert np.all(data2.cpu().numpy() == host[6000:])
+    with pytest.raises(ValueError):
+        dada.open(name3, 's')
+    with pytest.raises(TypeError):
+        dada.open(name3, 'rs', files=(name3,))
+
+
+@pytest.mark.parametrize('nheap', [1, 3, 6])
+def test_dada_meerkat_and_mkbf(nheap, tmp_path):
+    """dada/tests/test_dada.py::test_meerkat_header, ::test_meerkat_data, ::TestMKBF."""
+    from baseband_amd import dada
+    meerkat, mkbf = golden_path('samples/sample_meerkat.dada'), golden_path('samples/sample_mkbf.dada')
+    with dada.open(meerkat, 'rb') as fh:
+        assert fh.read_header().sample_shape == (2, 1)
+    with dada.open(meerkat, 'rs') as fh:
+        assert tuple(fh.read().shape) == (16384 - 4096 // 2, 2)
+    with dada.open(mkbf, 'rb') as fh:
+        header = fh.read_header()
+    assert header.sample_shape == (2, 1024) and header["NPOL"] == 2 and header["NCHAN"] == 1024
+    assert header.start_time == np.datetime64("2023-07-19T15:24:04")
+    with dada.open(mkbf, 'rs') as fh:
+        header = fh.header0
+        dev = fh.read()
+        fh.seek(10)
+        d10 = fh.read(1)
+    data = dev.cpu().numpy()
+    assert np.array_equal(d10.cpu().numpy(), data[10:11])
+    with open(mkbf, 'rb') as fh:
+        fh.seek(4096)
+        raw_words = np.frombuffer(fh.read(-1), dtype="u1")
+    pd = raw_words.view('i1').astype('f4').view("c8").reshape(2, 1024, 256)
+    assert np.array_equal(np.moveaxis(pd, -1, 0).reshape(data.shape), data)
+    test_file = str(tmp_path / 'test_mkbf.dada')
+    other_data = data.view("f4")[..., ::-1].copy().view("c8")       # real and imaginary swapped
+    assert not np.all(other_data == data)
+    new_header = header.copy()
+    new_header.payload_nbytes *= nheap
+    with dada.open(test_file, "ws", header0=new_header) as fw:
+        fw.write(data)
+        fw.write(other_data)
+        fw.write(other_data[:200])
+        fw.write(data[200:])
+        fw.write(np.concatenate([data, other_data, data]))
+    with dada.open(test_file, "rs") as fr:
+        assert fr.header0 == new_header
+        out = fr.read().cpu().numpy()
+        assert (fr._last_header == new_header) == (nheap == 6)
+    assert out.shape == (6 * 256, 2, 1024)
+    assert np.array_equal(out[:256], data) and np.array_equal(out[256:512], other_data)
+    assert np.array_equal(out[512:712], other_data[:200]) and np.array_equal(out[712:768], data[200:])
+    assert np.array_equal(out[768:1024], data) and np.array_equal(out[1024:1280], other_data)
+    assert np.array_equal(out[1280:], data)
+
+
+def test_guppi_incomplete_pickle_template_streams(tmp_path):
+    """guppi/tests/test_guppi.py::test_incomplete_stream, ::test_pickle, ::test_template_stream,
+    ::test_stream_info, ::test_create_fake_breakthrough_listen_header."""
+    import pickle
+    from baseband_amd import guppi
+    ns = np.timedelta64(1, 'ns')
+    _, header_w = _puppi_header_w()
+    with open(PUPPI, 'rb') as fh:
+        header = guppi.GUPPIHeader.fromfile(fh)
+        payload = guppi.GUPPIPayload.fromfile(fh, header, memmap=False)
+    filename = str(tmp_path / 'testguppi.raw')
+    with pytest.warns(UserWarning, match='partial buffer'):
+        with guppi.open(filename, 'ws', header0=header_w, squeeze=False) as fw:
+            fw.write(payload[:10])
+    with guppi.open(filename, 'rs', squeeze=False) as fwr:
+        data = fwr.read()
+        assert bool((data[:10] == payload[:10]).all()) and bool((data[10:] == fwr.fill_value).all())
+    with guppi.open(PUPPI, 'rs') as fh:
+        fh.seek(6)
+        pickled = pickle.dumps(fh)
+        fh.read(3)
+        with pickle.loads(pickled) as fh2:
+            assert fh2.tell() == 6
+            fh2.read(10)
+        assert fh.tell() == 9
+    with pickle.loads(pickled) as fh3:
+        assert fh3.tell() == 6
+        fh3.read(1)
+    closed = pickle.dumps(fh)
+    with pickle.loads(closed) as fh4:
+        assert fh4.closed
+        with pytest.raises(ValueError):
+            fh4.read(1)
+    with guppi.open(PUPPI, 'rs') as fh:
+        info = fh.info
+        assert info.format == 'guppi' and info.shape == fh.shape and info.sample_rate == fh.sample_rate
+        assert info.start_time == fh.start_time and info.stop_time == fh.stop_time
+        assert info.file_info is fh.fh_raw.info
+    # ---- templates
+    start_time = header_w.time
+    with guppi.open(PUPPI, 'rs') as fh:
+        data = fh.read(3840)                # (the overlap left out)
+    host = data.cpu().numpy()
+    stop = start_time + np.timedelta64(int(round(3840 / 250 * 1e9)), 'ns')
+    template = str(tmp_path / 'guppi_{file_nr:02d}.raw')
+    with guppi.open(template, 'ws', frames_per_file=1, **header_w) as fw:
+        fw.write(data)
+    with guppi.open(template, 'rs') as fr:
+        assert len(fr.fh_raw.files) == 4 and fr.fh_raw.files[-1] == str(tmp_path / 'guppi_03.raw')
+        assert abs(fr.stop_time - stop) < ns
+        assert np.all(fr.read().cpu().numpy() == host)
+    template = str(tmp_path / 'puppi_{stt_imjd}.{file_nr:04d}.raw')
+    with guppi.open(template, 'ws', frames_per_file=1, header0=header_w) as fw:
+        fw.write(data[:1920])
+        assert fw.start_time == start_time
+        assert abs(fw.time - (start_time + np.timedelta64(int(round(1920 / 250 * 1e9)), 'ns'))) < ns
+        fw.write(data[1920:])
+        assert abs(fw.time - stop) < ns
+    with pytest.raises(KeyError):
+        guppi.open(template, 'rs')          # STT_IMJD is not known
+    kwargs = dict(STT_IMJD=header_w['STT_IMJD'])
+    with guppi.open(template, 'rs', **kwargs) as fr:
+        assert np.all(fr.read().cpu().numpy() == host)
+    with guppi.open(template, 'rs', subset=(0, [2, 3]), squeeze=False, **kwargs) as fr:
+        assert np.all(fr.read().cpu().numpy().squeeze() == host[:, 0, 2:])
+    filename = template.format(stt_imjd=header_w['STT_IMJD'], file_nr=0)
+    with pytest.raises(ValueError):
+        guppi.open(filename, 's')
+    with pytest.raises(TypeError):
+        guppi.open(filename, 'rs', files=(filename,))
+    # ---- the DIRECTIO header entry
+    with guppi.open(PUPPI, 'rs') as fh:
+        header = fh.header0.copy()
+        data = fh.read(1024)
+    header['DIRECTIO'] = 0
+    header['OVERLAP'] = 0
+    assert header.nbytes == 6480
+    filename = str(tmp_path / 'test_no_dio.raw')
+    with guppi.open(filename, 'ws', header0=header) as fw:
+        fw.write(data)
+    with guppi.open(filename, 'rs') as fr:
+        assert fr.header0.nbytes == header.nbytes and fr.header0 == header
+        assert bool((fr.read() == data).all())
+    dio_header = header.copy()
+    dio_header['DIRECTIO'] = 1
+    assert dio_header.nbytes == ((6480 + 511) // 512) * 512
+    filename = str(tmp_path / 'test_dio.raw')
+    with guppi.open(filename, 'ws', header0=dio_header) as fw:
+        fw.write(data)
+    with open(filename, 'rb') as fr:
+        check = guppi.GUPPIHeader.fromfile(fr)
+        assert check.nbytes == dio_header.nbytes and check == dio_header and fr.tell() == dio_header.nbytes
+    with guppi.open(filename, 'rs') as fr:
+        assert fr.header0.nbytes == dio_header.nbytes and fr.header0 == dio_header
+        assert bool((fr.read() == data).all())

@@ -276,3 +276,23 @@ def test_positional_writes_equal_sequential_writes(tmp_path):
     d = sf.open([str(tmp_path / 'd0.bin'), str(tmp_path / 'd1.bin')], 'w+b')
     assert not d.can_pwrite
     d.close()
+
+
+def test_positional_writes_empty_older_files_of_the_same_name(tmp_path):
+    """A sequence written over older, LONGER files of the same names: every file ends
+    where this writer's bytes end (the reference opens each with 'w+b'); files the writer
+    has opened itself are not truncated under it."""
+    from baseband_amd.helpers import sequentialfile as sf
+    names = [str(tmp_path / 'f{}.bin'.format(k)) for k in range(3)]
+    for name in names:
+        with open(name, 'wb') as fh:
+            fh.write(b'\xff' * 100)
+    with sf.open(names, 'w+b', file_size=10) as fw:
+        assert fw.can_pwrite
+        fw.pwrite_stream(bytes(range(25)), 0)           # files 0 (open already), 1 and 2
+        fw.pwrite_stream(b'\x07' * 3, 12)               # file 1 again: what is there stays
+        fw.sync_position(25)
+    got = [open(name, 'rb').read() for name in names]
+    assert got[0] == bytes(range(10))
+    assert got[1] == bytes([10, 11, 7, 7, 7, 15, 16, 17, 18, 19])
+    assert got[2] == bytes(range(20, 25))
