@@ -3487,3 +3487,39 @@ def test_guppi_incomplete_pickle_template_streams(tmp_path):
     with guppi.open(filename, 'rs') as fr:
         assert fr.header0.nbytes == dio_header.nbytes and fr.header0 == dio_header
         assert bool((fr.read() == data).all())
+
+
+def test_mark5b_sequentialfile_and_mark4_pickle(tmp_path):
+    """mark5b/tests/test_mark5b.py::test_sequentialfile, mark4/tests/test_mark4.py::test_pickle."""
+    import pickle
+    from baseband_amd import mark4, mark5b
+    with mark5b.open(M5, 'rs', sample_rate=32e6, kday=56000, nchan=8, bps=2) as fh:
+        header = fh.header0.copy()
+        data = fh.read().cpu().numpy()
+        dtime = fh.stop_time - fh.start_time
+    data = np.concatenate((data, data, data, data, data))
+    files = [str(tmp_path / 'f.{0:03d}.m5b'.format(x)) for x in range(5)]
+    with mark5b.open(files, 'ws', file_size=4 * header.frame_nbytes, sample_rate=32e6, nchan=8, kday=56000,
+                     **header) as fw:
+        fw.write(data)
+    with mark5b.open(files, 'rs', sample_rate=32e6, nchan=8, kday=56000, subset=slice(1, 5)) as fn:
+        assert len(fn.fh_raw.files) == 5
+        assert fn.header0.time == header.time
+        assert fn.stop_time - fn.start_time - 5 * dtime < np.timedelta64(1, 'ns')
+        assert np.all(data[:, 1:5] == fn.read().cpu().numpy())
+    with mark4.open(M4, 'rs', ntrack=64, decade=2010, subset=0) as fh:
+        fh.seek(6)
+        pickled = pickle.dumps(fh)
+        fh.read(3)
+        with pickle.loads(pickled) as fh2:
+            assert fh2.tell() == 6
+            fh2.read(10)
+        assert fh.tell() == 9
+    with pickle.loads(pickled) as fh3:
+        assert fh3.tell() == 6
+        fh3.read(1)
+    closed = pickle.dumps(fh)
+    with pickle.loads(closed) as fh4:
+        assert fh4.closed
+        with pytest.raises(ValueError):
+            fh4.read(1)
