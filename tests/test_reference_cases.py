@@ -861,3 +861,116 @@ def test_mark5b_locate_frames_and_find_header(tmp_path):
         header_10 = fh.find_header(forward=False)
         assert fh.tell() == 0
     assert header_10 == header0
+
+
+@pytest.mark.parametrize('edv', [0, 1, False])
+def test_vdif_header_lengths_and_bad_samples_per_frame(edv):
+    """vdif/tests/test_vdif.py::test_header_bad_samples_per_frame, ::test_header_minimal_length,
+    ::test_legacy_header_minimal_length."""
+    from baseband_amd import vdif
+    with pytest.raises(ValueError):         # samples per frame should fit nicely in a frame
+        vdif.VDIFHeader.fromvalues(samples_per_frame=78125, nchan=2, edv=0, complex_data=True)
+    nwords8 = 2 if edv is False else 4      # header length in units of 8 bytes
+    for fl in range(nwords8):
+        with pytest.raises(AssertionError):
+            vdif.VDIFHeader.fromvalues(edv=edv, frame_length=fl)
+    header = vdif.VDIFHeader.fromvalues(edv=edv, frame_length=nwords8)
+    assert header.payload_nbytes == 0
+
+
+def test_header_parser_as_the_reference_tests_it():
+    """base/tests/test_header_parser.py::TestHeaderParser (update, parsers, defaults)."""
+    from baseband_amd.base.header import HeaderParser
+    header_parser0 = HeaderParser((('x0_16_4', (0, 16, 4)), ('x0_31_1', (0, 31, 1, False)),
+                                   ('x1_0_32', (1, 0, 32)), ('x2_0_64', (2, 0, 64, 1 << 32))))
+    extra = HeaderParser((('x4_0_32', (4, 0, 32)),))
+    new = header_parser0 + extra
+    assert len(new.keys()) == 5 and len(header_parser0.keys()) == 4
+    new = header_parser0.copy()
+    assert isinstance(new, HeaderParser)
+    new.update(extra)
+    assert len(new.keys()) == 5 and tuple(new['x4_0_32'][:3]) == (4, 0, 32)
+    with pytest.raises(TypeError):
+        header_parser0 + {'x4_0_32': (4, 0, 32)}
+    with pytest.raises(ValueError):
+        header_parser0.copy().update(('x4_0_32', (4, 0, 32)))
+    header_parser = header_parser0.copy()
+    words = [0x12345678, 0xffff0000, 0x0, 0xffffffff]
+    header_parser['0_2_8'] = (0, 2, 8, 5)
+    assert '0_2_8' in header_parser and header_parser.defaults['0_2_8'] == 5
+    assert header_parser.parsers['0_2_8'](words) == (words[0] >> 2) & 0xff
+    header_parser['0_2_8'] = (0, 1, 8, 3)           # changed: the parsers follow
+    assert header_parser.defaults['0_2_8'] == 3
+    assert header_parser.parsers['0_2_8'](words) == (words[0] >> 1) & 0xff
+    header_parser.update({'0_2_8': (0, 3, 8, 1)})
+    assert header_parser.defaults['0_2_8'] == 1
+    assert header_parser.parsers['0_2_8'](words) == (words[0] >> 3) & 0xff
+    header_parser2 = header_parser0 + HeaderParser((('0_2_8', (0, 2, 8, 4)),))
+    assert header_parser2.parsers['0_2_8'](words) == (words[0] >> 2) & 0xff
+    assert header_parser2.defaults['0_2_8'] == 4
+    with pytest.raises(TypeError):
+        header_parser + {'0_2_8': (0, 2, 8, 4)}
+    # every kind of field reads and writes: a bit, a few bits, a word, two words
+    words = [0x12345678, 0xffff0000, 0x0, 0xffffffff]
+    assert header_parser0.parsers['x0_16_4'](words) == 4
+    assert header_parser0.parsers['x0_31_1'](words) is False
+    assert header_parser0.parsers['x1_0_32'](words) == 0xffff0000
+    assert header_parser0.parsers['x2_0_64'](words) == 0xffffffff00000000
+    small = [0, 0, 0, 0]
+    header_parser0.setters['x0_16_4'](small, 0xf)
+    header_parser0.setters['x0_31_1'](small, True)
+    header_parser0.setters['x2_0_64'](small, (1 << 33) + 5)
+    assert small == [0x800f0000, 0, 5, 2]
+
+
+def test_base_utils_as_the_reference_tests_them():
+    """base/tests/test_utils.py: TestBCD, TestCRC12 (the Mark 5 memo's example), test_lcm,
+    test_byte_array, test_byte_array_errors."""
+    from baseband_amd.base.utils import lcm, bcd_encode, bcd_decode, byte_array, CRC, CRCStack
+    assert bcd_decode(0x1) == 1 and bcd_decode(0x9123) == 9123
+    with pytest.raises(ValueError):
+        bcd_decode(0xf)
+    decoded = bcd_decode(np.array([0x1, 0x9123]))
+    assert isinstance(decoded, np.ndarray) and np.all(decoded == np.array([1, 9123]))
+    with pytest.raises(ValueError):
+        bcd_decode(np.array([0xf, 9123]))
+    with pytest.raises(TypeError):
+        bcd_decode([1, 2])
+    assert bcd_encode(1) == 0x1 and bcd_encode(9123) == 0x9123
+    with pytest.raises(TypeError):
+        bcd_encode('bla')
+    assert bcd_decode(bcd_encode(15)) == 15 and bcd_decode(bcd_encode(8765)) == 8765
+    a = np.array([1, 9123])
+    assert np.all(bcd_decode(bcd_encode(a)) == a)
+
+    # page 4 of haystack's Mark 5 memo 230.3
+    def hex_to_stream(string):
+        n, scalar = len(string) * 4, int(string, base=16)
+        return np.array([((scalar & (1 << bit)) != 0) for bit in range(n - 1, -1, -1)], bool)
+
+    stream_hex = ('0000 002D 0330 0000' + 'FFFF FFFF' + '4053 2143 3805 5').replace(' ', '').lower()
+    crc12, crcstack12 = CRC(0x180f), CRCStack(0x180f)
+    stream, bitstream = int(stream_hex, base=16), hex_to_stream(stream_hex)
+    crc, crcstream = 0x284, hex_to_stream('284')
+    assert np.all(crcstack12(bitstream) == crcstream)
+    assert crcstack12.check(np.hstack((bitstream, crcstream)))
+    assert crc12(stream) == crc
+    assert crc12.check((stream << len(crc12)) + crc)
+    scalar = 0x12345678
+    array = scalar * np.ones(10, dtype='u8')
+    got = crc12(array)
+    assert got.shape == array.shape and np.all(got == crc12(scalar))
+    checked = crc12.check(((scalar << len(crc12)) + crc12(scalar)) * np.ones(10, dtype='u8'))
+    assert checked.shape == array.shape and np.all(checked)
+
+    for a, b, out in ((7, 14, 14), (7853, 6199, 48680747), (0, 5, 0), (4, -12, 12), (-4, -12, 12)):
+        assert lcm(a, b) == out
+    for pattern, expected in [(b'\xa0\x55', [160, 85]), (0x55a0, [160, 85, 0, 0]),
+                              ([0x55, 0xa0], [85, 0, 0, 0, 160, 0, 0, 0]),
+                              (np.array([0xa0, 0x55], 'u1'), [160, 85]),
+                              (np.array(0x55a0, '<u4'), [160, 85, 0, 0]),
+                              (np.array(0x55a0, '<u8'), [160, 85, 0, 0, 0, 0, 0, 0]),
+                              (np.array([0x55, 0xa0], '<u4'), [85, 0, 0, 0, 160, 0, 0, 0])]:
+        assert np.array_equal(byte_array(pattern), np.array(expected, 'u1'))
+    with pytest.raises(ValueError, match='values have to fit'):
+        byte_array([-1, -1])
