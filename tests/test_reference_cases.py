@@ -974,3 +974,100 @@ def test_base_utils_as_the_reference_tests_them():
         assert np.array_equal(byte_array(pattern), np.array(expected, 'u1'))
     with pytest.raises(ValueError, match='values have to fit'):
         byte_array([-1, -1])
+
+
+def test_file_base_wrapper_offsets_pickle_deepcopy(tmp_path):
+    """base/tests/test_base.py::test_vlbi_file_base, ::test_temporary_offset, ::test_pickle,
+    ::test_deepcopy."""
+    import io
+    import pickle
+    from copy import deepcopy
+    from baseband_amd.base.base import FileBase, VLBIFileReaderBase
+    filename = str(tmp_path / 'test.dat')
+    with io.open(filename, 'wb') as fw:
+        fh = FileBase(fw)
+        assert fh.fh_raw is fw and not fh.readable() and fh.writable() and not fh.closed
+        with pytest.raises(AttributeError):
+            fh.bla
+        assert repr(fh).startswith('FileBase(fh_raw')
+        fh.write(b'abcd')
+        fh.close()
+        assert fh.closed and fh.fh_raw.closed
+    with io.open(filename, 'rb') as fr:
+        fh = FileBase(fr)
+        assert fh.fh_raw is fr and fh.readable() and not fh.writable() and not fh.closed
+        with pytest.raises(AttributeError):
+            fh.bla
+        assert fh.read() == b'abcd'
+        fh.close()
+        assert fh.closed and fh.fh_raw.closed
+    with io.open(filename, 'wb') as fw:
+        fw.write(b'abcdefghijklmnopqrstuvwxyz')
+    with io.open(filename, 'rb') as fr:
+        fh = FileBase(fr)
+        fh.seek(2)
+        assert fh.read(2) == b'cd' and fh.tell() == 4
+        with fh.temporary_offset():
+            assert fh.seek(1) == 1
+            assert fh.read(2) == b'bc' and fh.tell() == 3
+        assert fh.tell() == 4
+        with fh.temporary_offset(-2, 2):
+            assert fh.read(1) == b'y' and fh.tell() == 25
+        assert fh.tell() == 4
+    with VLBIFileReaderBase(io.open(filename, 'rb')) as fh:
+        assert fh.read(2) == b'ab'
+        pickled = pickle.dumps(fh)
+        with pickle.loads(pickled) as fh2:
+            assert fh2.tell() == 2 and fh2.read(2) == b'cd'
+            fh2.seek(-2, 2)
+            assert fh2.read(2) == b'yz'
+        with pytest.raises(ValueError):
+            fh2.read()
+        assert fh.tell() == 2 and fh.read(2) == b'cd'
+    with pickle.loads(pickled) as fh3:
+        assert fh3.read(2) == b'cd'
+    with pytest.raises(ValueError):
+        fh3.read()
+    closed = pickle.dumps(fh)
+    with pickle.loads(closed) as fh4:
+        assert fh4.closed
+        with pytest.raises(ValueError):
+            fh4.read()
+    with FileBase(io.open(filename, 'wb')) as fw:
+        with pytest.raises(TypeError):
+            pickle.dumps(fw)
+    with io.open(filename, 'wb') as fw:
+        fw.write(b'abcdefghijklmnopqrstuvwxyz')
+    with VLBIFileReaderBase(io.open(filename, 'rb')) as fh:
+        assert fh.read(2) == b'ab'
+        with deepcopy(fh) as fh2:
+            assert fh2.tell() == 2 and fh2.read(2) == b'cd'
+            fh2.seek(-2, 2)
+            assert fh2.read(2) == b'yz'
+        with pytest.raises(ValueError):
+            fh2.read()
+        assert fh.tell() == 2           # (the original neither moved nor closed)
+
+
+@pytest.mark.parametrize(
+    ('squeeze', 'subset', 'sliced_shape', 'sliced_n'),
+    [(False, (), (1, 21, 33, 1, 2), ('n0', 'n1', 'n2', 'n3', 'n4')),
+     (True, (), (21, 33, 2), ('n1', 'n2', 'n4')),
+     (False, (0,), (21, 33, 1, 2), ('n1', 'n2', 'n3', 'n4')),
+     (True, (0,), (33, 2), ('n2', 'n4')),
+     (False, (0, 13), (33, 1, 2), ('n2', 'n3', 'n4')),
+     (True, (0, 13), (2,), ('n4',)),
+     (False, (Ellipsis, 0, 1), (1, 21, 33), None),
+     (True, (Ellipsis, 0, 1), (21,), ('n1',)),
+     (False, (0, slice(1, None, 4), slice(None), 0), (5, 33, 2), ('n1', 'n2', 'n4')),
+     (True, (slice(1, None, 4), slice(None), [1]), (5, 33, 1), ('n1', 'n2', 'n4')),
+     (False, (0, 0, slice(None, 1, -4)), (8, 1, 2), ('n2', 'n3', 'n4')),
+     (True, (0, slice(None, 1, -4)), (8, 2), ('n2', 'n4')),
+     (False, (0, np.array([2, 8, 9])[:, np.newaxis], [1, 7]), (3, 2, 1, 2), None),
+     (True, (np.array([2, 8, 9])[:, np.newaxis], [1, 7], 0), (3, 2), None)])
+def test_named_sample_shape_squeeze_subset(squeeze, subset, sliced_shape, sliced_n):
+    """base/tests/test_base.py::test_squeeze_subset (the shape and the names a subset leaves)."""
+    from baseband_amd.base.utils import named_sample_shape
+    shape = named_sample_shape((1, 21, 33, 1, 2), ('n0', 'n1', 'n2', 'n3', 'n4'), squeeze, subset)
+    assert tuple(shape) == sliced_shape
+    assert getattr(shape, '_fields', None) == sliced_n
