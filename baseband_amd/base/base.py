@@ -423,6 +423,8 @@ class GPUStreamReaderBase:
         self._squeeze = bool(squeeze)
         self._subset = (() if subset is None
                         else subset if isinstance(subset, tuple) else (subset,))
+        if self._subset:
+            self.sample_shape               # (a subset that cannot index a sample is refused here, at open)
         self._fill_value = float(fill_value)
         self.verify = verify
         self.offset = 0

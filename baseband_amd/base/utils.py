@@ -153,7 +153,17 @@ def named_sample_shape(unsliced, fields, squeeze=False, subset=()):
         shape = tuple(d for d in shape if d > 1)
     if subset:
         subset = tuple(subset)
-        full = np.empty((1,) + shape, dtype=bool)[(slice(None),) + subset].shape[1:]
+        try:
+            # the subset has to pick from each sample alone: in range, something left, and
+            # no mixing of the sample axis into the rest (advanced indices that broadcast
+            # against it), as the reference checks on a dummy sample (base/base.py:727-743)
+            probe = np.empty((2,) + shape, dtype=bool)[(slice(None),) + subset]
+            assert 0 not in probe.shape and probe.shape[:1] == (2,)
+        except (IndexError, AssertionError) as exc:
+            exc.args += ("subset {} cannot be used to properly index {}samples with shape {}."
+                         .format(subset, "squeezed " if squeeze else "", shape),)
+            raise exc
+        full = probe.shape[1:]
         if fields is None or full == () or len(subset) > len(shape):
             return tuple(full)
         kept, axis = [], 0

@@ -1071,3 +1071,21 @@ def test_named_sample_shape_squeeze_subset(squeeze, subset, sliced_shape, sliced
     shape = named_sample_shape((1, 21, 33, 1, 2), ('n0', 'n1', 'n2', 'n3', 'n4'), squeeze, subset)
     assert tuple(shape) == sliced_shape
     assert getattr(shape, '_fields', None) == sliced_n
+
+
+def test_faulty_subsets_are_refused():
+    """base/tests/test_base.py::test_faulty_subset."""
+    from baseband_amd.base.utils import named_sample_shape
+    fields, unsliced = ('n0', 'n1', 'n2', 'n3', 'n4'), (1, 21, 33, 1, 2)
+    for subset in (([0], np.array([2, 8, 16])[:, np.newaxis], [1, 7]),      # dimensions change
+                   (0, 'nonsense', [1, 7]),                                  # not an index
+                   (3, 0, [2, 8])):                                          # out of bounds
+        with pytest.raises(IndexError) as excinfo:
+            named_sample_shape(unsliced, fields, True, subset)
+        assert "cannot be used to" in str(excinfo.value)
+    with pytest.raises(AssertionError) as excinfo:                           # a slice that leaves nothing
+        named_sample_shape(unsliced, fields, True, (3, 0, slice(4, 8)))
+    assert "cannot be used to" in str(excinfo.value)
+    from baseband_amd import vdif
+    with pytest.raises((IndexError, AssertionError)):
+        vdif.open(os.path.join(S, 'sample.vdif'), 'rs', subset=(0, 'nonsense'))
