@@ -182,16 +182,43 @@ def _prepare_output_memory(reader):
     """A stream whose decoded samples are 1 GiB and more: let the output arena
     start taking its memory now, in the background, instead of inside the first
     large ``read()`` (placement.prepare_output; a no-op without a GPU, with
-    BB_ARENA=0 / BB_ARENA_PREPARE=0, or when the arena has room already)."""
+    BB_ARENA=0 / BB_ARENA_PREPARE=0, or when the arena has room already).
+
+    The size comes from what ``open()`` knows WITHOUT searching the file for
+    its last header (that search, and its warnings, stay lazy: ADVICE r5): the
+    sample count if the format has set it, else the bytes of the file times
+    the expansion of one frame -- an upper bound, which is all a growth step
+    needs.  A process that opens large streams only to read small pieces sets
+    BB_ARENA_PREPARE=0 (or BB_ARENA=0): the step is taken when a reader of a
+    >= 1 GiB stream opens, not when its first large read arrives."""
     try:
-        n = 8 if reader.complex_data else 4
-        for dim in reader.shape:
-            n *= int(dim)
-        if n >= (1 << 30):
+        item = 8 if reader.complex_data else 4
+        for dim in reader.sample_shape:
+            item *= int(dim)
+        nsample = reader.__dict__.get('_nsample_found')
+        if nsample is None:
+            nsample = _nsample_bound(reader)
+        if nsample is not None and nsample * item >= (1 << 30):
             from ..placement import prepare_output
-            prepare_output(n)
+            prepare_output(int(nsample) * item)
     except Exception:
         pass
+
+
+def _nsample_bound(reader):
+    """Samples the file of `reader` can hold at most, from its size alone."""
+    raw = getattr(reader, 'fh_raw', None)
+    try:
+        set_nbytes = int(reader._set_nbytes)
+        spf = int(reader.samples_per_frame)
+        here = raw.tell()
+        size = raw.seek(0, 2)
+        raw.seek(here)
+    except Exception:
+        return None
+    if set_nbytes <= 0:
+        return None
+    return (size // set_nbytes) * spf
 
 
 class _CaseBlind(dict):

@@ -14,6 +14,7 @@ import os
 import queue
 import threading
 import time
+import weakref
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -535,7 +536,6 @@ def _pinned_result_dropped(nbytes):
 def download_new(dev):
     """A new NumPy array with the device tensor's contents (float32 or
     complex64, same shape)."""
-    import weakref
     nbytes = dev.numel() * dev.element_size()
     if nbytes < _PINNED_RESULT_MIN or not dev.is_cuda:
         return dev.cpu().numpy()
@@ -587,6 +587,13 @@ class _FileSink:
     _NWORKER = int(os.environ.get('BB_WRITE_THREADS', 4))
 
     def __init__(self, fh, depth=None):
+        # the handle the registry knows this sink by.  Its id is reused once it is freed, so a
+        # lookup checks identity; held WEAKLY so that a writer dropped without close() frees it
+        # and `_sink_for`'s finalizer then settles and closes this sink
+        try:
+            self.key = weakref.ref(fh)
+        except TypeError:               # a handle that cannot be weakly referenced is simply kept
+            self.key = lambda fh=fh: fh
         while getattr(type(fh), '_queues_writes', False):
             fh = fh.fh_raw              # (a FileBase settles its queue before it answers: write below it)
         self.fh = fh
@@ -598,6 +605,8 @@ class _FileSink:
         self.error = None
         self.stream = None
         self.pos = fh.tell() if self.positional else 0      # stream offset of the next byte queued
+        self._settled = False           # drained and nothing queued since: the handle's own position leads
+        self.closed = False
         self.threads = [threading.Thread(target=self._run, args=(q,), name='bb-file-sink', daemon=True)
                         for q in self.qs]
         for t in self.threads:
@@ -610,10 +619,18 @@ class _FileSink:
                 if item is None:
                     return
                 kind, payload, n, event, offset = item
+                if kind == 'dev':
+                    # ALWAYS, also after a file error: the buffer goes back to the shared
+                    # pinned pool below and its device-to-host copy must have landed first
+                    try:
+                        event.synchronize()
+                    except BaseException as exc:
+                        payload = None                  # state of the copy unknown: never pooled again
+                        if self.error is None:
+                            self.error = exc
                 if self.error is None:
                     try:
                         if kind == 'dev':
-                            event.synchronize()
                             data = memoryview(payload.numpy()[:n])
                         else:
                             data = payload
@@ -624,7 +641,8 @@ class _FileSink:
                     except BaseException as exc:        # kept for the caller's thread
                         self.error = exc
                 if kind == 'dev':
-                    _pinned_give(payload)
+                    if payload is not None:
+                        _pinned_give(payload)
                     self.slots.release()
             finally:
                 q.task_done()
@@ -638,6 +656,11 @@ class _FileSink:
         """(queue, stream offset or None) for the next `n` bytes."""
         if not self.positional:
             return self.qs[0], None
+        if self._settled:
+            # nothing in flight: bytes written on the handle itself since the last drain
+            # (``fw.fh_raw.write_frame(...)`` between stream writes) moved it past `pos`
+            self.pos = max(self.pos, self.fh.tell())
+            self._settled = False
         offset = self.pos
         self.pos += n
         return self.qs[(offset // self.fh.file_size) % len(self.qs)], offset
@@ -679,9 +702,13 @@ class _FileSink:
             q.join()
         if self.positional:
             self.fh.sync_position(self.pos)
+            self._settled = True
         self._check()
 
     def close(self):
+        if self.closed:
+            return
+        self.closed = True
         for q in self.qs:
             q.join()
         for q in self.qs:
@@ -693,7 +720,7 @@ class _FileSink:
         self._check()
 
 
-_sinks = {}                 # id(file handle) -> _FileSink
+_sinks = {}                 # id(file handle) -> _FileSink (which keeps the handle: `_FileSink.key`)
 _sinks_lock = threading.Lock()
 _WRITE_ASYNC = os.environ.get('BB_WRITE_ASYNC', '1') not in ('0', 'no', 'off')
 
@@ -717,9 +744,29 @@ atexit.register(_drain_all_sinks)
 def _sink_for(fh, create=True):
     with _sinks_lock:
         s = _sinks.get(id(fh))
+        if s is not None and s.key() is not fh:         # the sink of a dead handle whose id `fh` now has
+            s = None
         if s is None and create:
             s = _sinks[id(fh)] = _FileSink(fh)
+            try:
+                weakref.finalize(fh, _drop_sink, id(fh), s)
+            except TypeError:
+                pass
         return s
+
+
+def _drop_sink(key_id, sink):
+    """The handle `sink` was made for is gone without `finish_writes`: what it queued still
+    reaches the file, its thread ends and its pinned pieces go back to the pool."""
+    with _sinks_lock:
+        if _sinks.get(key_id) is sink:
+            del _sinks[key_id]
+        elif sink.closed:
+            return
+    try:
+        sink.close()
+    except BaseException:               # (a finalizer has nobody to raise to)
+        pass
 
 
 def write_host_bytes(fh, data):
@@ -748,7 +795,11 @@ def finish_writes(fh, close_sink=True):
     """Wait until everything queued for `fh` is in the file (before the handle
     is closed, flushed, or asked where it stands); raises what a write raised."""
     with _sinks_lock:
-        s = _sinks.pop(id(fh), None) if close_sink else _sinks.get(id(fh))
+        s = _sinks.get(id(fh))
+        if s is not None and s.key() is not fh:
+            s = None
+        elif s is not None and close_sink:
+            del _sinks[id(fh)]
     if s is not None:
         s.close() if close_sink else s.drain()
 

@@ -1238,3 +1238,63 @@ def test_find_header_shortcut_agrees_with_the_search(tmp_path):
                 fh.seek(here)
                 quick = fh.locate_frames(header0, forward=forward, _here_first=True)
                 assert quick == ([here] if full and full[0] == here else []), (forward, here)
+
+
+def test_file_sink_belongs_to_one_handle(tmp_path):
+    """A writer dropped without close() frees its handle and CPython hands the id to the
+    next one: the second writer's bytes must reach ITS file, the first writer's queued
+    bytes the first file, and the dead handle's sink (thread, registry entry) must go."""
+    import gc
+    from baseband_amd import staging
+    from baseband_amd.base.base import FileBase
+    a, b = str(tmp_path / 'a.bin'), str(tmp_path / 'b.bin')
+    seen_ids = set()
+    raw_a = open(a, 'wb')
+    fa = FileBase(raw_a)
+    sink_a = staging._sink_for(fa)
+    staging.write_host_bytes(fa, b'first')
+    seen_ids.add(id(fa))
+    del fa
+    gc.collect()
+    assert sink_a.closed and not any(s is sink_a for s in staging._sinks.values())
+    assert not any(t.is_alive() for t in sink_a.threads)
+    raw_a.flush()
+    # handles until one reuses the id (CPython does so at once; bounded anyway)
+    raw_b = open(b, 'wb')
+    keep = []
+    for _ in range(64):
+        fb = FileBase(raw_b)
+        if id(fb) in seen_ids:
+            break
+        keep.append(fb)
+    assert staging._sink_for(fb, create=False) is None
+    staging.write_host_bytes(fb, b'second')            # no sink: straight to the handle
+    sink_b = staging._sink_for(fb)
+    assert sink_b is not sink_a and sink_b.key() is fb
+    staging.write_host_bytes(fb, b'+queued')
+    staging.finish_writes(fb)
+    raw_a.close()
+    raw_b.close()
+    assert open(a, 'rb').read() == b'first'
+    assert open(b, 'rb').read() == b'second+queued'
+
+
+def test_file_sink_positional_resyncs_after_side_writes(tmp_path):
+    """A sequence writer's sink keeps its own stream offset; bytes written on the handle
+    itself between queued pieces (after a drain) must not be overwritten by the next piece."""
+    from baseband_amd import staging
+    from baseband_amd.helpers import sequentialfile as sf
+    names = [str(tmp_path / f'p{i}.bin') for i in range(3)]
+    with sf.open(names, 'wb', file_size=8) as fw:
+        sink = staging._sink_for(fw)
+        if not sink.positional:
+            import pytest
+            pytest.skip('positional sinks are off (BB_WRITE_ASYNC=0 or one thread)')
+        staging.write_host_bytes(fw, b'abcd')
+        staging.finish_writes(fw, close_sink=False)
+        fw.write(b'EFGHIJ')                         # on the side, across a file boundary
+        staging.write_host_bytes(fw, b'klmn')
+        staging.finish_writes(fw)
+    import pathlib
+    got = b''.join(pathlib.Path(n).read_bytes() for n in names if pathlib.Path(n).exists())
+    assert got == b'abcdEFGHIJklmn'
