@@ -162,6 +162,7 @@ def leg_cfg3(args, rank, world, device, dist, out):
         "workload": "cfg3: synthetic {:.3f} GiB per GPU 8-thread VDIF, 2-bit complex, 16 channels, "
                     "EDV 0, thread order on disk {}".format(nsets * set_nbytes / 2 ** 30, list(CFG3_ORDER)),
         "rank0_file_GiB": round(world * nsets * set_nbytes / 2 ** 30, 3),
+        "rank0_footprint_GiB": round((world * nsets * set_nbytes + nsets_world * CFG3_THREADS * 24) / 2 ** 30, 3),
         "value": round(ncomplex * world * args.steps / elapsed / 1e6, 1),
         "unit": "M complex samples/s (threads x channels counted)",
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),

@@ -159,6 +159,15 @@ def compact_line(line, detail=DETAIL_NAME):
     for k in ("dry_run", "ranks_seen", "per_rank"):
         if k in line:
             c[k] = line[k]
+    c3 = line.get("cfg3")
+    if isinstance(c3, dict) and (line.get("n_gpus") or 1) > 1:
+        # what an N > 1 run must show of the sharded leg: every rank took part in the ONE
+        # collective, and what rank 0 (which holds the whole file) had to fit
+        c["cfg3"] = {"collective": {k: _get(c3, "collective", k) for k in ("ranks_seen", "bytes", "ms", "backend")},
+                     "rank0_footprint_GiB": c3.get("rank0_footprint_GiB")}
+        for k in ("value", "ms_per_step"):
+            if c3.get(k) is not None:
+                c["cfg3"][k] = c3[k]
     c["checks_ok"] = line.get("checks_ok")
     failed = [k for k, v in (line.get("checks") or {}).items() if not v]
     if failed:

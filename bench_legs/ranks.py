@@ -51,6 +51,16 @@ def spawn_ranks(args, argv):
                 pass
 
 
+def rank0_footprint_gib(cfg3_gib, world):
+    """What rank 0 holds in the cfg3 leg beside the output buffer: the whole file (one
+    slab per rank), the scan records (16 B per frame) and the dense index (8 B per frame)
+    -- bench_legs/cfg3.py checks the same sum (+ 4 GiB of fill temporaries) against free
+    memory before it allocates.  At --gpus 8 and the default 8 GiB per rank: 64.2 GiB."""
+    set_nbytes = FRAME_NBYTES * CFG3_THREADS
+    nsets = int(cfg3_gib * 2 ** 30) // set_nbytes
+    return round((world * nsets * set_nbytes + world * nsets * CFG3_THREADS * 24) / 2 ** 30, 3)
+
+
 # ------------------------------------------------------------------ dry run
 def dry_run(args, rank, world):
     """CPU rehearsal of the multi-rank plumbing (tests/test_bench_cli.py): gloo
@@ -73,11 +83,15 @@ def dry_run(args, rank, world):
     ok = bool((src[lo * CFG3_THREADS:hi * CFG3_THREADS]
                == torch.arange(lo * CFG3_THREADS, hi * CFG3_THREADS) * FRAME_NBYTES + HEADER_NBYTES).all())
     seen = torch.ones(1)
-    elapsed = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    mine = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    elapsed = mine.clone()
+    per_rank = [mine]
     if world > 1:
         dist.barrier()
         dist.all_reduce(seen)
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, mine)             # as the real run gathers `kernel_ms_avg` of every rank
     if rank == 0:
         cpu = None
         handed = os.environ.get(CPU_JSON_ENV)
@@ -95,7 +109,9 @@ def dry_run(args, rank, world):
             "scaling": "weak", "vs_baseline": None, "dtype": "float32", "data": "synthetic",
             "dry_run": True, "ranks_seen": int(seen.item()), "slab_of_rank0": [lo, hi],
             "max_over_ranks_s": float(elapsed.item()),
-            "cfg3": {"collective": {"bytes": nsets * CFG3_THREADS * 8, "ms": round(coll_ms, 3),
+            "per_rank": {"kernel_ms_avg": [round(float(x.item()) * 1e3, 4) for x in per_rank]},
+            "cfg3": {"rank0_footprint_GiB": rank0_footprint_gib(args.cfg3_gib, world),
+                     "collective": {"bytes": nsets * CFG3_THREADS * 8, "ms": round(coll_ms, 3),
                                     "ranks_seen": int(seen.item()), "backend": "gloo"},
                      "index_ok": ok}}, args.detail)
     else:

@@ -53,7 +53,8 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line(tmp_path):
     assert line == json.loads(lines[0]) and line['detail'] in (str(detail), os.path.relpath(str(detail), ROOT))
     assert line['n_gpus'] == 2 and line['ranks_seen'] == 2
     assert line['dry_run'] is True and line['value'] is None
-    assert 'cfg3' not in line                                   # the legs are in the detail file
+    # of the legs only the sharded one shows in an N > 1 line, cut down to what proves the ranks took part
+    assert set(line['cfg3']) == {'collective', 'rank0_footprint_GiB'} and line['cfg3']['collective']['ranks_seen'] == 2
     line = json.loads(detail.read_text())
     assert line['n_gpus'] == 2 and line['ranks_seen'] == 2
     assert line['dry_run'] is True and line['value'] is None
@@ -110,6 +111,42 @@ def test_under_torch_distributed_run_like_the_driver(tmp_path):
     line = json.loads((tmp_path / 'd.json').read_text())
     assert 'N = 1' in line['roofline']['traffic_detail']['reason']
     assert line['cfg3']['collective']['ranks_seen'] == 2 and line['cfg3']['index_ok'] is True
+
+
+def test_world_8_exactly_as_the_driver_starts_it(tmp_path):
+    """No 8-GPU node has run this bench yet (SCALE records are skips): the N = 8 path is
+    rehearsed here as the driver would start it -- ``torch.distributed.run --nproc-per-node 8``
+    -- over gloo.  ONE line under 2,000 bytes; all eight ranks seen by the index broadcast;
+    one per-rank figure each; and what rank 0 must hold (the whole 64 GiB cfg3 file, its scan
+    records and the index) stated in the line."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1',
+                        '--dry-run', '--detail', str(tmp_path / 'd8.json')],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    assert len(lines[0].encode()) < 2000
+    line = _check_compact(r.stdout)
+    assert line['n_gpus'] == 8 and line['ranks_seen'] == 8 and line['scaling'] == 'weak'
+    assert line['cfg3']['collective']['ranks_seen'] == 8
+    assert line['cfg3']['collective']['bytes'] == 8 * 1000 * 8 * 8
+    assert len(line['per_rank']['kernel_ms_avg']) == 8
+    assert line['per_rank']['kernel_ms_avg'] == [float(k + 1) for k in range(8)]       # every rank's own value
+    # 8 slabs of 8 GiB (whole frame sets) + 24 B per frame of records and index
+    assert 64.0 < line['cfg3']['rank0_footprint_GiB'] < 64.5
+    detail = json.loads((tmp_path / 'd8.json').read_text())
+    assert detail['slab_of_rank0'] == [0, 1000] and detail['cfg3']['index_ok'] is True
+    assert abs(detail['max_over_ranks_s'] - 0.008) < 1e-9
 
 
 def test_a_false_self_check_fails_the_bench(tmp_path):

@@ -1,12 +1,15 @@
 """k_decode_pick (csrc/k_pick.h, round 5): folded channel subsets with one work
 item per wave and direct-to-LDS 16-byte loads.  Bit-exact against a host
-expansion from the library's level table (the table itself is pinned to the
-reference by tests/golden/levels.json) AND against k_decode_gather_select on the
+expansion from the ORACLE's level tables (`bb_oracle_np.code_levels`, pinned to the
+reference by tests/golden/levels.json -- not the table of the library under
+test) AND against k_decode_gather_select on the
 same input, for every sample width, real / complex chunks, 1-32 thread slots,
 payloads at every 4-byte alignment and at odd addresses, ragged last items,
 missing frames, offsets outside the buffer, looping workgroups, staged sizes."""
 import numpy as np
 import pytest
+
+import bb_oracle_np as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +45,7 @@ def test_pick_matches_host_expansion_and_the_gather_kernel(bps, chunk, cplx, cod
     import torch
     from baseband_amd import kernels, _lib
     rng = np.random.default_rng(bps * 1000 + chunk * 10 + nslot)
-    lev = _lib.get_levels(CODERS[coder], bps)
+    lev = orc.code_levels(coder, bps)
     nsets = 7
     try:
         for pn, hdr, lead in ((8000, 32, 0), (5000, 32, 4), (1032, 16, 8), (2000, 20, 12), (1000, 33, 1), (264, 32, 0)):
