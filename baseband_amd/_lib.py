@@ -143,7 +143,9 @@ class ArenaStats(C.Structure):
                 ('blocks', C.c_uint32), ('probes', C.c_uint32), ('last_probe_gbps', C.c_double), ('create_ms', C.c_double),
                 ('grow_ms', C.c_double), ('va_reserved', C.c_uint64), ('va_used', C.c_uint64),
                 ('va_ranges', C.c_uint32), ('va_ranges_made', C.c_uint32), ('prepares', C.c_uint32),
-                ('growing', C.c_uint32), ('prepare_ms', C.c_double), ('prepare_wait_ms', C.c_double)]
+                ('growing', C.c_uint32), ('prepare_ms', C.c_double), ('prepare_wait_ms', C.c_double),
+                ('first_probe_gbps', C.c_double), ('last_create_ms', C.c_double),
+                ('second_chances', C.c_uint32), ('second_chance_wins', C.c_uint32)]
 
 
 LAYOUT_GUPPI_CF = 0

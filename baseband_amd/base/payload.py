@@ -72,9 +72,19 @@ class RowSetMixin:
                 index = (start - lo,) + sample_index
             else:
                 index = (slice(start - lo, stop - lo, step),) + sample_index
-            block[index] = data.to(want)
+            _assign(block, index, data.to(want))
         self._store_rows(lo, hi, block)
         self._dwords = None
+
+
+def _assign(block, index, values):
+    """``block[index] = values`` with NumPy's error for shapes that do not broadcast
+    (a ValueError; torch raises RuntimeError), as callers of the reference expect."""
+    try:
+        block[index] = values
+    except RuntimeError as exc:
+        raise ValueError("could not broadcast input array from shape {} into shape {}".format(
+            tuple(values.shape), tuple(block[index].shape))) from exc
 
 
 class PayloadBase:
@@ -306,7 +316,7 @@ class PayloadBase:
                  and data.is_complex() == self.complex_data)
         if not whole:
             block = self._fresh_block(w0, w1)
-            block[index] = data.to(block.dtype)
+            _assign(block, index, data.to(block.dtype))
             data = block
         encoded = self._encode(kernels.as_device_samples(data))
         self.words[w0:w1] = encoded.reshape(-1)

@@ -738,8 +738,8 @@ class Mark4Header:
 def frame_header_streams(header0, times, invalid=None):
     """(nframes, 160) stream-word headers for frames at `times`
     (datetime64[ns] array): `header0` with each frame's time code, the
-    'communication_error' flag of every track set where `invalid` is true,
-    and the CRC-12 of every track recomputed -- what ``header0.copy();
+    the CRC-12 of every track recomputed, and then the 'communication_error'
+    flag of every track set where `invalid` is true -- what ``header0.copy();
     set_time(t); update_crc(); words2stream(words)`` gives frame by frame
     (`set_time`, `crc12_stream`, `words2stream` above), for all frames at once."""
     from ..base.utils import bcd_encode as bcd_array
@@ -769,14 +769,19 @@ def frame_header_streams(header0, times, invalid=None):
     shifts = np.arange(31, -1, -1, dtype=np.int64)
     out[:, 96:128] = ((w3[:, None] >> shifts) & 1).astype(dtype) * ones
     out[:, 128:160] = ((w4[:, None] >> shifts) & 1).astype(dtype) * ones      # (crc bits zero for now)
-    if invalid is not None:
-        pos = 32 + 31 - _FIELDS['communication_error'][1]
-        out[np.asarray(invalid, bool), pos] = ones
     # CRC-12 of the first 148 stream words of every track: polynomial division
     # without initial value is linear over GF(2), so crc bit k of every track is
     # the XOR of the stream words whose unit message has that bit in its remainder
     for k, idx in enumerate(_crc12_taps()):
         out[:, 148 + k] = np.bitwise_xor.reduce(out[:, idx], axis=1)
+    # The error flag goes in AFTER the CRC, as in files the reference writes: its
+    # writer sets a frame's time (which renews the CRC) when it starts the frame and
+    # flags it invalid when it is complete (base/base.py:1297-1323, mark4/frame.py
+    # `valid`), so the CRC of a padded last frame is that of the unflagged header
+    # (recorded case mark4:incomplete_and_headerless_streams).
+    if invalid is not None:
+        pos = 32 + 31 - _FIELDS['communication_error'][1]
+        out[np.asarray(invalid, bool), pos] = ones
     return out
 
 

@@ -59,11 +59,13 @@ class VDIFFrame(FrameBase):
         return cls(header, payload, verify=verify)
 
     @classmethod
-    def fromdata(cls, data, header=None, verify=True, **kwargs):
+    def fromdata(cls, data, header=None, *, valid=None, verify=True, **kwargs):
+        # (``valid=False`` sets the header's invalid_data bit, as the reference's
+        # FrameBase.fromdata does through the frame's ``valid``: base/frame.py:97-131)
         if header is None:
             header = VDIFHeader.fromvalues(verify=verify, **kwargs)
         payload = VDIFPayload.fromdata(data, header=header)
-        return cls(header, payload, verify=verify)
+        return cls(header, payload, valid=valid, verify=verify)
 
 
 def _from_mark5b_frame(cls, mark5b_frame, verify=True, **kwargs):

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define BB_ABI_VERSION 4   /* 4 (round 5): bb_arena_prepare, bb_arena_owns, bb_arena_stats grew (va_ranges .. prepare_wait_ms); the `reserved` words of the scan parameter blocks got meanings whose zero is the old behaviour (bb_vdif_scan_params.set_nframes, bb_mark5b_/bb_mark4_scan_params.by_position): same layout  */   /* 3 (round 4): bb_copy_frames; bb_arena_stats grew va_reserved / va_used; bb_tune knobs are thread-local */   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
+#define BB_ABI_VERSION 5   /* 5 (round 6): bb_arena_stats grew (first_probe_gbps .. second_chance_wins); bb_decode_frames_checked */   /* 4 (round 5): bb_arena_prepare, bb_arena_owns, bb_arena_stats grew (va_ranges .. prepare_wait_ms); the `reserved` words of the scan parameter blocks got meanings whose zero is the old behaviour (bb_vdif_scan_params.set_nframes, bb_mark5b_/bb_mark4_scan_params.by_position): same layout  */   /* 3 (round 4): bb_copy_frames; bb_arena_stats grew va_reserved / va_used; bb_tune knobs are thread-local */   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
 
 /* error codes (negative errno values) */
 #define BB_OK        0

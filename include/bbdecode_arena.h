@@ -26,10 +26,14 @@
  * BB_ARENA_MIN_GBPS = 6350 is held aside -- unmapped -- while the next candidate
  * is created somewhere else (none once two candidates probe within 4 % of each
  * other) and the
- * fastest stays.  The DEFAULT is ONE try (the probe then only feeds the
- * statistics): fourteen candidates on one box probed at 5.77-6.52 TB/s, and in
- * every growth the first one -- memory nothing else holds -- was the fastest or
- * tied, while a second candidate cost 0.2-1.5 s (profiles/r04h_prof_arena_grow.log).  Footprint: a
+ * fastest stays.  The DEFAULT (BB_ARENA_TRIES unset or 0; round 6) is one
+ * candidate, and ONE more when the first probes below BB_ARENA_RETRY_BELOW_GBPS
+ * = 6000 and its memory was cheap to create (under BB_ARENA_CHEAP_MS_PER_GIB = 3
+ * ms per GiB: the driver is not in the middle of wiping freed pages); the faster
+ * of the two stays (`first_probe_gbps`, `second_chances`, `second_chance_wins`
+ * in the statistics).  Fourteen candidates on one box probed at 5.77-6.52 TB/s;
+ * a second candidate cost 0.2-1.5 s (profiles/r04h_prof_arena_grow.log).  Steps
+ * grown in the background (bb_arena_prepare) follow the same rule.  Footprint: a
  * step is at most HALF of the device's free memory (behind a 4 GiB margin); at
  * most two steps exist at any moment (the best so far and the one being
  * probed: a slower candidate goes back to the device at once); another
@@ -94,6 +98,10 @@ typedef struct bb_arena_stats {
     uint32_t growing;        /* 1 while one of them is on its way */
     double   prepare_ms;     /* their wall time, total (spent on the library's thread) */
     double   prepare_wait_ms;/* time bb_arena_alloc waited for one, total */
+    double   first_probe_gbps;/* probe rate of the FIRST candidate of the last growth (= last_probe_gbps unless a second one won) */
+    double   last_create_ms; /* wall time creating that first candidate's memory took (large: the driver was wiping pages) */
+    uint32_t second_chances; /* growths that tried a second candidate because the first probed slow and was cheap */
+    uint32_t second_chance_wins; /* ... and kept the second */
 } bb_arena_stats;
 
 /* An arena that backs at most `capacity` bytes (rounded up to whole GiB) of the

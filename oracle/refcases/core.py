@@ -57,7 +57,8 @@ CASES = [
               'start_time', 'sample_rate', 'shape'),
          call('iv', 'top.file_info', S('sample.vdif'), ref_time=REF, nchan=8, decade=2000),
          gets('iv', 'format', 'used_kwargs', 'consistent_kwargs', 'inconsistent_kwargs', 'irrelevant_kwargs'),
-         call('w1', 'top.file_info', S('sample.m4'), decade='2010'), gets('w1', 'format', 'readable', 'errors'),
+         call('w1', 'top.file_info', S('sample.m4'), decade='2010'), gets('w1', 'format', 'readable'),
+         fn(None, 'truth', V('w1.errors')),
          call('w2', 'top.file_info', S('sample.m4'), decade=20100), gets('w2', 'format', 'readable'),
          call('w3', 'top.file_info', S('sample.m5b'), nchan=8, kday=5600000), gets('w3', 'format', 'readable'),
          call('m1', 'top.file_info', S('sample_mwa.vdif'), sample_rate=HZ(1.28e6)),

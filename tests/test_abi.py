@@ -33,7 +33,7 @@ def test_library_exports_all_declared_symbols():
         assert hasattr(_lib.lib, s), s
     bound = {name for name, _, _ in _lib.SIGNATURES}
     assert bound == set(syms)
-    assert _lib.lib.bb_abi_version() == 4
+    assert _lib.lib.bb_abi_version() == 5
 
 
 def test_product_library_carries_no_experiments():

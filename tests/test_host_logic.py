@@ -825,9 +825,9 @@ def test_vectorised_frame_headers_equal_the_per_frame_construction():
         for i in range(0, len(k), 11):
             h = h0.copy()
             h.set_time(times[i])
-            if invalid[i]:
-                h['communication_error'] = np.ones(ntrack, bool)
             h.update_crc()
+            if invalid[i]:          # flagged once the frame is complete: the CRC stays that of the unflagged header,
+                h['communication_error'] = np.ones(ntrack, bool)     # as in files the reference's writer pads
             assert np.array_equal(words2stream(h.words), streams[i])
     with pytest.raises(ValueError):
         frame_header_streams(h0, np.array([h0.get_time() + np.timedelta64(1, 'ms')]))
