@@ -114,7 +114,18 @@ def secondary_summary(line):
     ms = _get(line, "mid_size", "sizes")
     if ms and isinstance(ms[0], dict):
         sec["mid_2p15_arena_min"] = _get(ms[0], "arena", "frac_min")
+        sec["mid_2p15_torch_min"] = _get(ms[0], "torch_empty", "frac_min")
         sec["mid_2p15_api_read"] = _get(ms[0], "api_read", "frac")
+        # what explains a low mid-size read: where the arena's step landed (its probe, and
+        # whether a second candidate was tried / kept) and what stands around the kernel
+        sec["mid_2p15_host_ms"] = _get(ms[0], "api_read", "host_and_scan_ms")
+        sec["mid_2p15_api_kernel"] = _get(ms[0], "api_read", "kernel_frac_same_output")
+        st = _get(line, "mid_size", "arena_after") or {}
+        if st:
+            sec["arena_probe_gbps"] = round(st.get("last_probe_gbps") or 0.0, 0)
+            sec["arena_first_probe_gbps"] = round(st.get("first_probe_gbps") or 0.0, 0)
+            sec["arena_second_chances"] = [st.get("second_chances"), st.get("second_chance_wins")]
+            sec["arena_create_ms"] = round(st.get("last_create_ms") or 0.0, 1)
     for k in ("cold_minus_warm_ms", "cold_minus_warm_ms_dirty_memory"):
         v = _get(line, "cold_first_read", k)
         if v is not None:
@@ -186,6 +197,14 @@ def compact_line(line, detail=DETAIL_NAME):
             return {k: clip(v, n) for k, v in x.items()}
         return x[:n] if isinstance(x, str) else x
 
+    # (secondary figures go one at a time, the rows that repeat a sibling first: the block as a
+    # whole is what explains a low headline or mid-size read and is shed last)
+    for k in ("vdif_4bit", "vdif_1bit", "gsb_4bit", "mkbf", "guppi_tf", "enc8", "dada_i8", "vdif_8thr", "mark4",
+              "writer_sequence_GBps", "pinned_h2d_GBps", "arena_create_ms", "arena_first_probe_gbps", "enc2",
+              "guppi_tf_pick", "locate", "mid_2p15_api_kernel"):
+        if size() <= LINE_LIMIT:
+            break
+        c.get("secondary", {}).pop(k, None)
     for drop in ("secondary", "per_rank", "failed_checks"):
         if size() <= LINE_LIMIT:
             break
