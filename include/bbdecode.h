@@ -346,12 +346,12 @@ int bb_decode_frames_select_check(const bb_decode_params *params, int nwithin);
  */
 /*
  * bb_vdif_read_window for the common case -- ONE thread, frames at the fixed
- * stride of their length, no channel selection, 2- or 4-bit samples -- with the
- * DECODE LAUNCHED FIRST (round 6): on `stream`, at the fixed stride, every
- * workgroup reading its frame's own invalid-data bit (bb_decode_params.hdr_back),
- * without waiting for any scan; the scan, index and verification launches follow
- * on `scan_stream` (required, as is `verified`) exactly as in
- * bb_vdif_read_window, and `stream` is NOT made to wait for them.  When the
+ * stride of their length, no channel selection, 2- or 4-bit samples -- with a
+ * DECODE THAT DOES NOT WAIT FOR THE SCAN (round 6): the scan, index and
+ * verification launches go to `scan_stream` (required, as is `verified`) exactly
+ * as in bb_vdif_read_window, and right behind them the decode goes to `stream`,
+ * at the fixed stride, every workgroup reading its frame's own invalid-data bit
+ * (bb_decode_params.hdr_back); `stream` is NOT made to wait for `verified`.  When the
  * verdict is clean (*d_nbad stays 0: every header passed its checks and sits at
  * its place in time) the output already is what bb_vdif_read_window would have
  * written, and the decode started two launches earlier (30 us of a 0.68 ms

@@ -307,7 +307,8 @@ def test_prepare_grows_in_the_background_and_alloc_waits_for_it(monkeypatch):
         st = ar.stats()
         assert t is not None and ar.owns(t)
         assert st['steps'] == 1 and st['bytes_backed'] == 16 * GIB and st['growing'] == 0
-        assert st['probes'] == 0                    # (background steps are not probed: no NULL-stream launch from that thread)
+        # (background steps are probed too since round 6: the second-chance rule needs the figure)
+        assert st['probes'] == 1 and st['first_probe_gbps'] > 1000 and st['last_probe_gbps'] == st['first_probe_gbps']
         assert st['prepare_ms'] > 0 and dt_call < max(0.05, st['prepare_ms'] * 1e-3)
         t.fill_(3.)
         assert float(t[::65536].sum()) == 3. * t[::65536].numel()
@@ -324,6 +325,47 @@ def test_prepare_grows_in_the_background_and_alloc_waits_for_it(monkeypatch):
         ar.close()
     free_b, total_b = torch.cuda.mem_get_info()
     assert free_b > total_b - 40 * GIB
+
+
+@pytest.mark.parametrize('background', [False, True])
+def test_a_slow_cheap_first_step_gets_one_second_chance(background, monkeypatch):
+    """Round 6: a growth whose first candidate probes below BB_ARENA_RETRY_BELOW_GBPS and was
+    cheap to create tries ONE more candidate and keeps the faster; the other goes back to
+    the device.  Forced here (every rate is 'slow', every creation 'cheap'); switched off
+    again the growth takes its first candidate.  Both growth paths; the memory kept must
+    hold what is written to it."""
+    import torch
+    from baseband_amd import arena
+    monkeypatch.setenv('BB_ARENA_STEP_GIB', '12')
+    monkeypatch.setenv('BB_ARENA_RETRY_BELOW_GBPS', '8000')
+    monkeypatch.setenv('BB_ARENA_CHEAP_MS_PER_GIB', '100000')
+    free0, _ = torch.cuda.mem_get_info()
+    ar = arena.Arena(64 * GIB)
+    try:
+        if background:
+            assert ar.prepare(3 * GIB)
+        t = ar.empty((3 * GIB) // 4)
+        st = ar.stats()
+        assert st['second_chances'] == 1 and st['probes'] == 2 and st['second_chance_wins'] in (0, 1)
+        assert st['steps'] == 1 and st['bytes_backed'] == 12 * GIB          # the loser is gone
+        assert st['last_probe_gbps'] >= st['first_probe_gbps'] > 1000
+        assert (st['last_probe_gbps'] > st['first_probe_gbps']) == bool(st['second_chance_wins'])
+        free1, _ = torch.cuda.mem_get_info()
+        assert free0 - free1 < 14 * GIB
+        t.fill_(5.)
+        torch.cuda.synchronize()
+        assert float(t[::4099].min()) == 5. and float(t[-1]) == 5.
+        # the rule switched off: the next step is taken as it comes
+        monkeypatch.setenv('BB_ARENA_RETRY_BELOW_GBPS', '0')
+        u = ar.empty((11 * GIB) // 4)
+        st = ar.stats()
+        assert u is not None and st['steps'] == 2 and st['second_chances'] == 1 and st['probes'] == 3
+        u.fill_(6.)
+        torch.cuda.synchronize()
+        assert float(u[::4099].max()) == 6. and float(t[::4099].max()) == 5.
+        del t, u
+    finally:
+        ar.close()
 
 
 def test_opening_a_large_stream_prepares_the_arena(tmp_path, monkeypatch):

@@ -82,7 +82,7 @@ def test_bad_verdict_repeats_the_decode_through_the_index(damage, monkeypatch):
     fn = h0.frame_nbytes
     w = image.view('<u4').reshape(NSETS, fn // 4)
     if damage in ('sync', 'both'):
-        w[500, 6] ^= 0xffff                     # EDV 0: words 4-7 must be zero
+        w[500, 2] ^= 0x10                       # the frame length (word 2): the same in every header of a stream
     if damage in ('misplaced', 'both'):
         w[900, 1] = (w[900, 1] & 0xff000000) | ((int(w[900, 1]) & 0xffffff) + 3)      # frame_nr three too high
     outs = []
