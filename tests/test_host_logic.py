@@ -1298,3 +1298,22 @@ def test_file_sink_positional_resyncs_after_side_writes(tmp_path):
     import pathlib
     got = b''.join(pathlib.Path(n).read_bytes() for n in names if pathlib.Path(n).exists())
     assert got == b'abcdEFGHIJklmn'
+
+
+def test_a_slow_first_allocation_is_named_once(monkeypatch):
+    """Seconds spent taking output memory (the driver wiping freed pages) are reported by
+    ONE RuntimeWarning per process; fast allocations and small outputs say nothing."""
+    import warnings
+    from baseband_amd import placement
+    monkeypatch.setattr(placement, '_slow_allocation_warned', False)
+    clock = [100.0]
+    monkeypatch.setattr(placement.time, 'perf_counter', lambda: clock[0])
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        placement._note_slow_allocation(None, 1 << 20)              # small output: not timed
+        placement._note_slow_allocation(99.9, 4 << 30)              # 0.1 s
+        assert not caught
+        placement._note_slow_allocation(94.0, 4 << 30)              # 6 s
+        placement._note_slow_allocation(90.0, 4 << 30)              # again: silent
+    assert len(caught) == 1 and issubclass(caught[0].category, RuntimeWarning)
+    assert '6.0 s' in str(caught[0].message) and 'freed' in str(caught[0].message)

@@ -4,7 +4,7 @@ double-buffered download (baseband_amd.asnumpy / read(out=ndarray))."""
 import json, os, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import baseband_amd   # noqa: E402
 

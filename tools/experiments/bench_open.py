@@ -3,7 +3,7 @@
 import json, os, sys, time, io
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import vdif, mark4, mark5b, dada, guppi, synth   # noqa: E402
 import baseband_amd                                                  # noqa: E402

@@ -10,7 +10,7 @@ import sys
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import kernels, _lib, arena          # noqa: E402
 from tools.bench_formats import timeit                 # noqa: E402

@@ -3,7 +3,7 @@
 import json, os, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import vdif, gsb   # noqa: E402
 from baseband_amd.vdif.header import VDIFHeader   # noqa: E402

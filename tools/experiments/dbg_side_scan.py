@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from baseband_amd import vdif, kernels, _lib
 from baseband_amd.base import base as bbase

@@ -5,7 +5,7 @@ rocprofv3: which hardware counters differ between a launch whose output
 landed well (6.4-6.8 TB/s) and one whose output landed badly (5.3)?"""
 import json, os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import kernels, _lib
 kernels.init()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# counter passes over tools/prof_alloc.py (program directly after `--`)
+# counter passes over tools/experiments/prof_alloc.py (program directly after `--`)
 set -u
 TAG=${1:-r02af}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -7,13 +7,13 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-python3 $R/tools/prof_alloc.py > $OUT/plain0.log 2>&1      # (first process on a fresh box places differently)
-python3 $R/tools/prof_alloc.py > $OUT/plain1.log 2>&1
+python3 $R/tools/experiments/prof_alloc.py > $OUT/plain0.log 2>&1      # (first process on a fresh box places differently)
+python3 $R/tools/experiments/prof_alloc.py > $OUT/plain1.log 2>&1
 run() {
   local name=$1; shift
   rm -rf $OUT/$name
   # (bounded: a GRBM_* pass once aborted inside rocprofv3 and sat in its finaliser for 40 minutes)
-  timeout 300 rocprofv3 "$@" -d $OUT/$name -o p --output-format csv -- python3 $R/tools/prof_alloc.py > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 "$@" -d $OUT/$name -o p --output-format csv -- python3 $R/tools/experiments/prof_alloc.py > $OUT/$name.log 2>&1
   find $OUT/$name -type f ! -name '*.csv' -delete
 }
 run trace --kernel-trace
@@ -21,7 +21,7 @@ run utcl --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_
 run eawr --pmc TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_LEVEL_sum
 run tcc --pmc TCC_BUSY_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_LEVEL_sum
 run lat --pmc TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum
-python3 $R/tools/prof_alloc.py > $OUT/plain2.log 2>&1
+python3 $R/tools/experiments/prof_alloc.py > $OUT/plain2.log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob, json, collections

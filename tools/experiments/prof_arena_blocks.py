@@ -11,7 +11,7 @@ os.environ['BB_ARENA_STEP_GIB'] = '8'
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from baseband_amd import kernels, _lib, arena          # noqa: E402
 
 FRAME, PAYLOAD, HDR = 8032, 8000, 32

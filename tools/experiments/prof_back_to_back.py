@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench                                            # noqa: E402
 from baseband_amd import vdif, kernels                  # noqa: E402
 from baseband_amd.base import base as bbase             # noqa: E402

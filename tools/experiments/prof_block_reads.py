@@ -3,7 +3,7 @@
 import cProfile, io, os, pstats, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import guppi
 from baseband_amd.guppi.header import GUPPIHeader

@@ -4,7 +4,7 @@
 random input resident in HBM.  usage: prof_formats.py [gib] [reps]"""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import kernels, _lib
 from baseband_amd.mark4._bitmaps import BITMAPS

@@ -3,7 +3,7 @@ copy rate from a FRESH mapping (pages fault in) and from a populated one, by cop
     python tools/prof_munmap.py"""
 import mmap, os, sys, time, numpy as np
 from concurrent.futures import ThreadPoolExecutor
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 size = 2 << 30
 path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'bb_mm_test.bin')

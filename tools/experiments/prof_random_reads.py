@@ -3,7 +3,7 @@ frame's worth of samples (page cache -> HBM window -> scan / index / decode)."""
 import cProfile, io, os, pstats, sys, time
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import vdif, synth   # noqa: E402
 

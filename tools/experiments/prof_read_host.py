@@ -1,7 +1,7 @@
 """Host time of read() on a resident image, per function (400 reads of 2^12 frames)."""
 import cProfile, io, os, pstats, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from baseband_amd import vdif, kernels
 dev = torch.device('cuda', 0)

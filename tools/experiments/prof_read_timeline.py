@@ -7,7 +7,7 @@ synchronisation and close; the per-window sums as bench.py reports them.
 import json, os, sys, time, tempfile
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from baseband_amd import vdif, synth, staging, kernels, arena
 kernels.init()
 gib = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 import cProfile, pstats, io, json, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import vdif, synth
 tmp = os.environ.get('TMPDIR', '/tmp')

@@ -2,7 +2,7 @@
 """cProfile of the frame-at-a-time loop (host overhead of one small read)."""
 import cProfile, io, os, pstats, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import vdif, synth
 nframes = (64 << 20) // 8032

@@ -2,7 +2,7 @@
 """Where does open().read() of an 8-thread VDIF file spend its host time?"""
 import cProfile, pstats, os, sys, time, io
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import vdif, synth
 tmp = os.environ.get('TMPDIR', '/tmp')

@@ -1,7 +1,7 @@
 """cProfile of a VDIF and a Mark 4 stream writer (0.5 GiB files): where the host time goes."""
 import cProfile, io, os, pstats, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from baseband_amd import vdif, mark4
 from baseband_amd.vdif.header import VDIFHeader

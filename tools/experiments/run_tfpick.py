@@ -3,7 +3,7 @@ BB_TUNE_XPOSE_TC), 8 GiB of 64-channel 128 MiB blocks; bytes moved = blocks read
 import json, os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from baseband_amd import kernels, _lib
 kernels.init()
 dev = torch.device('cuda', 0)
