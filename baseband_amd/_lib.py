@@ -110,7 +110,7 @@ class DecodeParams(C.Structure):
                 ('nslot', C.c_int32), ('payload_nbytes', C.c_uint64),
                 ('src0', C.c_int64), ('src_stride', C.c_int64),
                 ('complex_data', C.c_int32), ('fill_re', C.c_float),
-                ('fill_im', C.c_float), ('hdr_back', C.c_int32)]
+                ('fill_im', C.c_float), ('reserved', C.c_int32)]
 
 
 class Mark4ScanParams(C.Structure):
@@ -198,8 +198,6 @@ SIGNATURES = [
                                        _vp, _vp]),
     ('bb_vdif_read_window', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _sz, _vp, _sz, C.POINTER(DecodeParams),
                                       _vp, C.c_int, _vp, _vp, _vp, _sz, C.c_uint32, _sz, _vp, _vp, _vp, _vp]),
-    ('bb_vdif_read_window_early', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _sz, _vp, _sz, C.POINTER(DecodeParams),
-                                            _vp, C.c_int, _vp, _vp, _vp, _sz, C.c_uint32, _sz, _vp, _vp, _vp, _vp]),
     ('bb_mark4_scan', C.c_int, [_vp, _sz, C.POINTER(Mark4ScanParams), _vp, _sz, _vp]),
     ('bb_mark4_locate', C.c_int, [_vp, _sz, C.c_int, _vp, _sz, _vp, _vp]),
     ('bb_mark4_header_crc', C.c_int, [_vp, _sz, C.c_int, _vp, C.c_int64, _sz, _vp, _vp]),

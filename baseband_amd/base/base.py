@@ -1127,7 +1127,6 @@ class GPUStreamReaderBase:
         `into` is an optional flat float32 device tensor to decode into."""
         kernels.require_gpu()
         self._last_scan_side = None
-        self._early_again = []
         nsets = last - first
         spf = self.samples_per_frame
         ncomp = 2 if self.complex_data else 1
@@ -1264,7 +1263,6 @@ class GPUStreamReaderBase:
         """Forget the read-ahead windows."""
         self._ahead = self._decoded = self._decoded_host = None
 
-    _early_again = ()   # windows of the current read that were decoded before their scan's verdict (callables: redo)
     _nbad = None        # device counter the verification kernel adds to
     _nmissing = 0       # frames a window should have held but the file did not
     _checked = False
@@ -1324,12 +1322,7 @@ class GPUStreamReaderBase:
                                   on_scan if on_scan is not None else self._check_stream)
             nbad = int(self._nbad_host[0]) + self._nmissing
         self._nmissing = 0
-        early, self._early_again = self._early_again, []
         if nbad:
-            # windows that were decoded ahead of their scan, frame by frame at the fixed
-            # stride: now through the index, which maps what failed to fill
-            for again in early:
-                again()
             self._zero_nbad()
             if quiet:
                 return False

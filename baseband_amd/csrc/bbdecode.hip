@@ -814,17 +814,6 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
     // an index entry is followed only if its payload lies inside the buffer
     // (fixed-stride launches were checked above)
     a.src_lim = src_limit(buf_nbytes, p->payload_nbytes);
-    a.hdr_back = 0;
-    if (p->hdr_back) {
-        // frames that mind their own invalid-data bit: fixed stride, contiguous 2- / 4-bit
-        // output -- the launches of branch 3 below that go to k_decode_flat_lds
-        if (d_src || om != BB_OUT_FLAT || !(p->bps == 2 || p->bps == 4)) return BB_ENOTSUP;
-        if (p->hdr_back < 0 || (p->hdr_back & 3) || (int64_t)p->hdr_back > p->src0) return BB_EINVAL;
-#if BB_EXP
-        if (g_tune_burst.load() != 0 || g_tune_variant.load() != 0) return BB_ENOTSUP;
-#endif
-        a.hdr_back = (uint32_t)p->hdr_back;
-    }
     a.perm = bb_perm_t{0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     const bool nt = tune_nt();
@@ -1175,59 +1164,6 @@ int bb_vdif_read_window(const void *d_buf, size_t nbytes,
     if (nwithin > 0)
         return bb_decode_frames_select(d_buf, nbytes, d_src, nsets, dec, d_within, nwithin, d_out, out_elems, stream);
     return bb_decode_frames(d_buf, nbytes, d_src, nsets, dec, d_out, out_elems, stream);
-}
-
-int bb_vdif_read_window_early(const void *d_buf, size_t nbytes,
-                              const bb_vdif_scan_params *scan, size_t nframes,
-                              const int16_t *d_thread_slot, size_t nsets,
-                              const bb_decode_params *dec,
-                              const int32_t *d_within, int nwithin,
-                              bb_frame_rec *d_recs, int64_t *d_src,
-                              float *d_out, size_t out_elems,
-                              uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad,
-                              void *verified, void *scan_stream, void *stream)
-{
-    (void)d_within;
-    if (!scan || !dec || !d_src || !d_nbad || !verified || !scan_stream) return BB_EINVAL;
-    if (dec->nslot != 1 || nwithin > 0 || recs_per_index > 1 || !(dec->bps == 2 || dec->bps == 4)) return BB_ENOTSUP;
-    if ((scan->first_offset & 3) || (scan->frame_nbytes & 3) || (scan->header_nbytes & 3)
-        || scan->header_nbytes == 0 || scan->header_nbytes >= scan->frame_nbytes
-        || dec->payload_nbytes != (uint64_t)(scan->frame_nbytes - scan->header_nbytes)) return BB_ENOTSUP;
-    // every frame of the request must lie inside the window (a file that ends early
-    // is the business of the index: bb_vdif_read_window)
-    if (nsets == 0 || scan->first_offset + (uint64_t)nsets * scan->frame_nbytes > nbytes) return BB_ENOTSUP;
-    // 1. scan, index and verification as in bb_vdif_read_window, on their own stream -- queued
-    // FIRST: launched behind the decode they would wait for its workgroups to drain (the
-    // verdict came after 0.59 instead of 0.09 ms: profiles/r06d_read_breakdown.log)
-    bb_decode_params dp = *dec;
-    dp.src0 = (int64_t)scan->first_offset + scan->header_nbytes;
-    dp.src_stride = scan->frame_nbytes;
-    dp.hdr_back = (int32_t)scan->header_nbytes;
-    {
-        // (what bb_decode_frames would refuse must be refused BEFORE anything is launched)
-        if (!d_buf || !d_out || ((uintptr_t)d_buf & 3) || ((uintptr_t)d_out & 15)) return BB_ENOTSUP;
-        if (out_elems < (uint64_t)nsets * (dec->payload_nbytes * 8 / (uint64_t)dec->bps)) return BB_ERANGE;
-        if (!coder_supported(dec->coder, dec->bps)) return BB_ENOTSUP;
-#if BB_EXP
-        if (g_tune_burst.load() != 0 || g_tune_variant.load() != 0) return BB_ENOTSUP;
-#endif
-    }
-    bb_vdif_scan_params sp = *scan;
-    sp.set_nframes = (int32_t)recs_per_index;
-    int rc = vdif_scan_impl(d_buf, nbytes, &sp, d_recs, nframes, d_src, nsets, scan_stream);
-    if (rc != BB_OK) return rc;
-    rc = index_verify(d_recs, nframes, d_thread_slot, 1, d_src, nsets, true, recs_per_index ? recs_per_index : 1,
-                      nstrict, d_nbad, scan_stream);
-    if (rc != BB_OK) return rc;
-    BB_HIP(hipEventRecord((hipEvent_t)verified, (hipStream_t)scan_stream));
-    // 2. the decode, NOT waiting for them: fixed stride, each frame minding its own invalid-data bit
-    rc = bb_decode_frames(d_buf, nbytes, nullptr, nsets, &dp, d_out, out_elems, stream);
-    if (rc == BB_ENOTSUP) {
-        // (cannot happen after the checks above; should it, the index is there: the ordinary decode)
-        BB_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)verified, 0));
-        return bb_decode_frames(d_buf, nbytes, d_src, nsets, dec, d_out, out_elems, stream);
-    }
-    return rc;
 }
 
 int bb_mark5b_read_window(const void *d_buf, size_t nbytes,

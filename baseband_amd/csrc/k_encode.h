@@ -107,7 +107,6 @@ template <int CODER, int BPS, bool DIRECT, int RUNS = 1>
 __global__ __launch_bounds__(BB_BLOCK)
 void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out, bb_perm_t perm)
 {
-    __shared__ uint32_t s_e4[(BPS == 4 && RUNS == 2) ? (BB_BLOCK / BB_WAVE) * 256 : 1];
     const int lane = bb_lane();
     const bb_f4 *in4 = reinterpret_cast<const bb_f4 *>(in);
     const uint64_t nrun = nquad >> 8;
@@ -122,34 +121,6 @@ void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out, bb_perm_t perm
           for (int j = 0; j < 4; ++j)
               vv[h][j] = (rr + h < nrun) ? __builtin_nontemporal_load(in4 + q0 + 64 * j) : bb_f4{0.f, 0.f, 0.f, 0.f};
       }
-      if (BPS == 4 && RUNS == 2) {
-        // 4-bit codes, two runs (1 KiB of output per wave and step): the 16 result bits of
-        // a quad used to leave as a 2-byte store per lane (128 bytes per instruction, byte
-        // masks all the way down).  Now neighbouring lanes pair their halves (DPP), the
-        // even lanes put dwords into a wave-private KiB of LDS in OUTPUT order, and every
-        // lane takes 16 contiguous bytes from there: ONE global_store_dwordx4 per lane,
-        // 512 bytes per run coalesced (round 6).
-        uint32_t *stage = &s_e4[(threadIdx.x >> 6) * 256];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t mine = bb_encode_quad<CODER, BPS, DIRECT>(vv[h][j]);
-                const uint32_t other = (uint32_t)__shfl_xor((int)mine, 1);
-                if (!(lane & 1)) stage[(h * 256 + 64 * j + lane) >> 1] = mine | (other << 16);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int h = lane >> 5;                                // lanes 0-31: the first run's 512 bytes
-        if (rr + h < nrun) {
-            const uint64_t r = bb_perm(perm, rr + h);
-            const bb_u4 w = *reinterpret_cast<const bb_u4 *>(stage + 4 * lane);
-            *reinterpret_cast<bb_u4 *>(out + (r << 9) + 16 * (lane & 31)) = w;
-        }
-        __builtin_amdgcn_wave_barrier();                        // the next step refills the stage
-      } else {
 #pragma unroll
       for (int h = 0; h < RUNS; ++h) {
         if (rr + h >= nrun) break;                              // (wave-uniform)
@@ -182,7 +153,6 @@ void k_encode_flat(const float *in, uint64_t nquad, uint8_t *out, bb_perm_t perm
                 if (!(lane & 1)) out[(q0 + 64 * j) >> 1] = (uint8_t)(bits[j] | (other << 4));
             }
         }
-      }
       }
     }
     // tail: fewer than 256 quads, first workgroup only (whole waves for the shuffle)

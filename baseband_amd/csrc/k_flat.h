@@ -44,8 +44,6 @@ struct bb_flat_args {
     float    fill_re, fill_im;
     int32_t  complex_data;
     uint64_t src_lim;       // offsets so with (uint64_t)so >= src_lim decode as fill (bb_src_ok)
-    uint32_t hdr_back;      // k_decode_flat_lds only: bytes from a payload back to the header word whose top
-                            // bit flags the frame invalid (VDIF word 0, bit 31); 0 = headers are not looked at
     bb_perm_t perm;         // work order (bb_common.h)
 #if BB_EXP
     int32_t  nt_loads;      // experiment: non-temporal input loads

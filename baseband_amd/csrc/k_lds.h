@@ -94,14 +94,7 @@ void k_decode_flat_lds(bb_flat_args a)
         if (a.nseg == 1) { fs = work; seg = 0; }
         else { fs = work / a.nseg; seg = work - fs * a.nseg; }
         const int64_t so = a.src ? a.src[fs] : a.src0 + (int64_t)fs * a.src_stride;
-        const bool ok = bb_src_ok(so, a.src_lim);           // the payload may be loaded
-        // The frame's own "invalid data" flag, read here instead of from an index built by a
-        // scan launch (bb_vdif_read_window_early): one dword, the same for every lane, issued
-        // BEFORE the payload's loads and waited for with them -- it decides what is STORED
-        // (fill), not what is loaded, so no load waits for another.
-        uint32_t hw = 0;
-        if (a.hdr_back && ok && (uint64_t)so >= a.hdr_back)
-            hw = *reinterpret_cast<const uint32_t *>(a.buf + (uint64_t)so - a.hdr_back);
+        const bool valid = bb_src_ok(so, a.src_lim);
         const uint64_t tile0 = seg * a.seg_tiles + (uint64_t)wave * a.tpw;
         const uint64_t seg_b_end = (seg + 1) * a.seg_tiles * 256 < pbytes ? (seg + 1) * a.seg_tiles * 256 : pbytes;
         const uint64_t b0 = tile0 * 256;                                  // first payload byte of this wave
@@ -109,13 +102,13 @@ void k_decode_flat_lds(bb_flat_args a)
         if (b0 < seg_b_end) { nb = seg_b_end - b0; if (nb > (uint64_t)a.tpw * 256) nb = (uint64_t)a.tpw * 256; }
         float *obase = a.out + bb_out_slot(a, fs) * E + b0 * (8 / BPS);
         uint32_t s = 0;
-        if (ok && nb && (reinterpret_cast<uintptr_t>(a.buf + (uint64_t)so) & 3)) {
+        if (valid && nb && (reinterpret_cast<uintptr_t>(a.buf + (uint64_t)so) & 3)) {
             // a payload at an odd address: byte loads, staged from offset 0
             const uint8_t *pp = a.buf + (uint64_t)so + b0;
             uint8_t *st8 = reinterpret_cast<uint8_t *>(&s_stage[wave][0]);
 #pragma nounroll
             for (uint32_t i = (uint32_t)lane; i < (uint32_t)nb; i += BB_WAVE) st8[i] = pp[i];
-        } else if (ok && nb) {
+        } else if (valid && nb) {
             const uint8_t *pp = a.buf + (uint64_t)so + b0;                // 4-byte aligned
             s = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 255);
             const uint8_t *base = pp - s;                                 // 256-byte aligned address
@@ -142,7 +135,6 @@ void k_decode_flat_lds(bb_flat_args a)
             }
         }
         if (GL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the direct-to-LDS loads have landed
-        const bool valid = ok && !(hw >> 31);                             // what is stored: samples or fill
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -4,7 +4,6 @@ PyTorch is used only as the device allocator / stream provider; every
 computation is a libbbdecode kernel launched on torch's current HIP stream.
 """
 import ctypes as C
-import os
 
 import numpy as np
 import torch
@@ -143,10 +142,6 @@ def _pow2(n):
     return 1 << max(0, int(n) - 1).bit_length()
 
 
-# BB_EARLY_DECODE=0: every window waits for its scan (the three launches in order), as before round 6
-_EARLY_DECODE = os.environ.get('BB_EARLY_DECODE', '1') not in ('0', 'no', 'off')
-
-
 class _FrameWindow:
     """Scratch handling shared by the window calls: the scan records and the
     index of a window.  With the scan on a SIDE stream (`scan_stream`: the
@@ -228,18 +223,12 @@ class VDIFWindow(_FrameWindow):
         self.fill_value = fill_value
 
     def run(self, dbuf, ref_frame_nr, nframes, thread_slot, nsets, within, out,
-            recs_per_index, nstrict, nbad, verified, scan_stream=None, early=False):
+            recs_per_index, nstrict, nbad, verified, scan_stream=None):
         """Launch the window on torch's current stream.  `out`: flat float32
         device tensor; `nbad`: int32[1] device counter, or None for no
         verification; `verified`: raw handle of the event to record behind the
         verification launch, or None; `scan_stream`: torch stream for the scan /
-        index / verification launches (needs `verified`; `_FrameWindow`).
-
-        `early` (needs `scan_stream`): try bb_vdif_read_window_early -- the decode
-        launched FIRST, at the frames' fixed stride, not waiting for the scan.
-        Returns None, or -- when the early form was taken -- a callable that
-        REPEATS the decode through the index the scan built; the caller calls it
-        if (and only if) the verdict turns out bad."""
+        index / verification launches (needs `verified`; `_FrameWindow`)."""
         dev = dbuf.device
         self.scan.ref_frame_nr = ref_frame_nr
         if not verified:
@@ -247,32 +236,15 @@ class VDIFWindow(_FrameWindow):
         st = self._scratch(nframes, nsets * self.dec.nslot, dev, scan_stream)
         tgt = _Target(out, out.numel(), dev)
         nsel = within.numel() if within is not None else 0
-        args = (_ptr(dbuf), dbuf.numel(), C.byref(self.scan), nframes, _ptr(thread_slot), nsets,
-                C.byref(self.dec), _ptr(within), nsel, _ptr(self.recs), _ptr(self.src),
-                _ptr(tgt.use), tgt.use.numel(), recs_per_index, nstrict, _ptr(nbad),
-                C.c_void_p(verified) if verified else C.c_void_p(0),
-                C.c_void_p(scan_stream.cuda_stream) if scan_stream is not None else C.c_void_p(0),
-                _stream(dbuf))
-        again = None
-        rc = _lib.BB_ENOTSUP
-        if early and scan_stream is not None and nsel == 0 and _EARLY_DECODE:
-            rc = lib.bb_vdif_read_window_early(*args)
-            if rc not in (_lib.BB_OK, _lib.BB_ENOTSUP):
-                check(rc, 'bb_vdif_read_window_early')
-        if rc == _lib.BB_OK:
-            src, dec, use = self.src, self.dec, tgt.use
-
-            def again():
-                # (the index is complete: the caller has the verdict, which was recorded behind it)
-                check(lib.bb_decode_frames(_ptr(dbuf), dbuf.numel(), _ptr(src), nsets, C.byref(dec),
-                                           _ptr(use), use.numel(), _stream(dbuf)), 'bb_decode_frames')
-                self._decode_queued(st, scan_stream, dev)      # the set is read until THIS decode is done
-                tgt.done()
-        else:
-            check(lib.bb_vdif_read_window(*args), 'bb_vdif_read_window')
+        check(lib.bb_vdif_read_window(
+            _ptr(dbuf), dbuf.numel(), C.byref(self.scan), nframes, _ptr(thread_slot), nsets,
+            C.byref(self.dec), _ptr(within), nsel, _ptr(self.recs), _ptr(self.src),
+            _ptr(tgt.use), tgt.use.numel(), recs_per_index, nstrict, _ptr(nbad),
+            C.c_void_p(verified) if verified else C.c_void_p(0),
+            C.c_void_p(scan_stream.cuda_stream) if scan_stream is not None else C.c_void_p(0),
+            _stream(dbuf)), 'bb_vdif_read_window')
         self._decode_queued(st, scan_stream, dev)
         tgt.done()
-        return again
 
 
 class Mark5BWindow(_FrameWindow):

@@ -410,15 +410,8 @@ class VDIFStreamReader(GPUStreamReaderBase):
             # (the verification is queued BEFORE the decode and an event recorded
             # behind it: read() waits for this verdict only -- `_resolve_checks`)
             nbad, verified = self._verdict_targets()
-        # one thread, frames at their fixed stride, the scan on its side stream: the decode
-        # goes first and does not wait for it (bb_vdif_read_window_early); should the verdict
-        # be bad, `_resolve_checks` repeats the decode through the index (`_early_again`)
-        early = bool(self.verify and nthread_file == 1 and len(self._thread_ids) == 1 and self._within is None
-                     and self._scan_side is not None and nframes >= nsets)
-        again = w.run(dbuf, h0['frame_nr'] + first_set, nframes, self._thread_slot, nsets, self._within, out_flat,
-                      nthread_file, nframes, nbad, verified, scan_stream=self._scan_side, early=early)
-        if again is not None:
-            self._early_again.append(again)
+        w.run(dbuf, h0['frame_nr'] + first_set, nframes, self._thread_slot, nsets, self._within, out_flat,
+              nthread_file, nframes, nbad, verified, scan_stream=self._scan_side)
         if self.verify:
             self._note_checked(nframes, missing=nsets * nthread_file - nframes)
 

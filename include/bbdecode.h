@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define BB_ABI_VERSION 5   /* 5 (round 6): bb_arena_stats grew (first_probe_gbps .. second_chance_wins); bb_vdif_read_window_early; bb_decode_params.reserved became hdr_back (0 = as before) */   /* 4 (round 5): bb_arena_prepare, bb_arena_owns, bb_arena_stats grew (va_ranges .. prepare_wait_ms); the `reserved` words of the scan parameter blocks got meanings whose zero is the old behaviour (bb_vdif_scan_params.set_nframes, bb_mark5b_/bb_mark4_scan_params.by_position): same layout  */   /* 3 (round 4): bb_copy_frames; bb_arena_stats grew va_reserved / va_used; bb_tune knobs are thread-local */   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
+#define BB_ABI_VERSION 5   /* 5 (round 6): bb_arena_stats grew (first_probe_gbps .. second_chance_wins) */   /* 4 (round 5): bb_arena_prepare, bb_arena_owns, bb_arena_stats grew (va_ranges .. prepare_wait_ms); the `reserved` words of the scan parameter blocks got meanings whose zero is the old behaviour (bb_vdif_scan_params.set_nframes, bb_mark5b_/bb_mark4_scan_params.by_position): same layout  */   /* 3 (round 4): bb_copy_frames; bb_arena_stats grew va_reserved / va_used; bb_tune knobs are thread-local */   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
 
 /* error codes (negative errno values) */
 #define BB_OK        0
@@ -275,11 +275,7 @@ typedef struct bb_decode_params {
     int32_t  complex_data;     /* selects (fill_re, fill_im) vs fill_re only */
     float    fill_re;
     float    fill_im;
-    int32_t  hdr_back;         /* (round 6; was `reserved`, 0 = as before) only with d_src == NULL, contiguous
-                                * 2- or 4-bit output: bytes from a payload's first byte BACK to the 32-bit header
-                                * word whose top bit says "invalid data" (VDIF: word 0, bit 31 -- the header's
-                                * length); a frame with the bit set decodes as fill, as one whose index entry
-                                * is -1 does.  A multiple of 4, at most src0.  BB_ENOTSUP for other launches. */
+    int32_t  reserved;
 } bb_decode_params;
 
 int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
@@ -344,35 +340,6 @@ int bb_decode_frames_select_check(const bb_decode_params *params, int nwithin);
  * baseband_amd/kernels.py).  d_recs (nframes records) and d_src
  * (nsets * dec->nslot entries) are scratch the caller provides.
  */
-/*
- * bb_vdif_read_window for the common case -- ONE thread, frames at the fixed
- * stride of their length, no channel selection, 2- or 4-bit samples -- with a
- * DECODE THAT DOES NOT WAIT FOR THE SCAN (round 6): the scan, index and
- * verification launches go to `scan_stream` (required, as is `verified`) exactly
- * as in bb_vdif_read_window, and right behind them the decode goes to `stream`,
- * at the fixed stride, every workgroup reading its frame's own invalid-data bit
- * (bb_decode_params.hdr_back); `stream` is NOT made to wait for `verified`.  When the
- * verdict is clean (*d_nbad stays 0: every header passed its checks and sits at
- * its place in time) the output already is what bb_vdif_read_window would have
- * written, and the decode started two launches earlier (30 us of a 0.68 ms
- * decode of 2^15 frames: profiles/r06c_read_breakdown.log).  When it is not,
- * THE CALLER repeats the decode through the index this call left in d_src
- * (bb_decode_frames with d_src on `stream`) -- the optimistic output is then
- * overwritten.  BB_ENOTSUP (nothing launched) when the window does not qualify:
- * more than one slot, nwithin > 0, recs_per_index > 1, 1- or 8-bit samples, or a
- * window that ends before its last frame does.  Reference: the per-frame header
- * check inside the read loop, base/base.py:1083-1125; vdif/header.py:158-186.
- */
-int bb_vdif_read_window_early(const void *d_buf, size_t nbytes,
-                              const bb_vdif_scan_params *scan, size_t nframes,
-                              const int16_t *d_thread_slot, size_t nsets,
-                              const bb_decode_params *dec,
-                              const int32_t *d_within, int nwithin,
-                              bb_frame_rec *d_recs, int64_t *d_src,
-                              float *d_out, size_t out_elems,
-                              uint32_t recs_per_index, size_t nstrict, uint32_t *d_nbad,
-                              void *verified, void *scan_stream, void *stream);
-
 int bb_vdif_read_window(const void *d_buf, size_t nbytes,
                         const bb_vdif_scan_params *scan, size_t nframes,
                         const int16_t *d_thread_slot, size_t nsets,
