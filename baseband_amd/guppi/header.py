@@ -5,7 +5,7 @@ guppi/header.py:216-352.  Times are ``numpy.datetime64[ns]``."""
 import operator
 
 import numpy as np
-from ..base.quantities import as_time, hz, seconds
+from ..base.quantities import as_time, hz, seconds, LeapSecondInstant, LEAP_SECOND_DAYS
 
 __all__ = ['GUPPIHeader']
 
@@ -420,16 +420,31 @@ class GUPPIHeader(dict):
 
     @property
     def start_time(self):
-        day = np.datetime64('1970-01-01', 'ns') + np.timedelta64(
-            int(self['STT_IMJD']) - _MJD_UNIX, 'D')
+        """Start of the observation: midnight of STT_IMJD plus STT_SMJD + STT_OFFS
+        ELAPSED seconds (guppi/header.py:366-370 in the reference, a Time plus a
+        TimeDelta).  A `numpy.datetime64[ns]` -- except inside an inserted leap
+        second, which only a `LeapSecondInstant` can name: the reference stores
+        2012-06-30T23:59:60.375 as the NEXT day, -1 s, 0.375 s (its setter below),
+        other writers as 86400.375 s of the day itself."""
+        day = np.datetime64('1970-01-01', 'D') + np.timedelta64(int(self['STT_IMJD']) - _MJD_UNIX, 'D')
         ns = int(round((float(self['STT_SMJD']) + float(self.get('STT_OFFS', 0))) * 1e9))
-        return day + np.timedelta64(ns, 'ns')
+        if -10 ** 9 <= ns < 0 and (day - np.timedelta64(1, 'D')) in LEAP_SECOND_DAYS:
+            return LeapSecondInstant(day - np.timedelta64(1, 'D'), ns + 10 ** 9)
+        if 86400 * 10 ** 9 <= ns < 86401 * 10 ** 9 and day in LEAP_SECOND_DAYS:
+            return LeapSecondInstant(day, ns - 86400 * 10 ** 9)
+        return day.astype('datetime64[ns]') + np.timedelta64(ns, 'ns')
 
     @start_time.setter
     def start_time(self, start_time):
         """STT_IMJD (int), STT_SMJD and STT_OFFS (floats: whole and fractional
-        seconds of the day, guppi/header.py:392-400)."""
+        seconds of the day, guppi/header.py:372-385)."""
         t = as_time(start_time)
+        if isinstance(t, LeapSecondInstant):
+            # (the reference's arithmetic: the day count is elapsed time over 86400 s, which
+            # puts the 86401st second of a day into the next one, one second before its start)
+            self['STT_IMJD'] = int((t.day + np.timedelta64(1, 'D')).astype(np.int64)) + _MJD_UNIX
+            self['STT_SMJD'], self['STT_OFFS'] = -1.0, t.ns / 1e9
+            return
         day = t.astype('datetime64[D]')
         seconds = int((t - day).astype(np.int64)) / 1e9
         self['STT_IMJD'] = int(day.astype(np.int64)) + _MJD_UNIX

@@ -51,11 +51,13 @@ def _as_Time(t):
     u, Time = _astropy()
     if Time is None or t is None:
         return t
-    t = np.datetime64(t, 'ns')
-    ns = int(t.astype(np.int64))
-    days, rest = divmod(ns, 86400 * 10 ** 9)
-    # two-part Julian date: whole days + the day fraction, exact to well below 1 ns
-    return Time(2440587.5 + days, rest / 86400e9, format='jd', scale='utc', precision=9)
+    # Through the ISO text, which astropy reads on the UTC scale as written -- a leap second's
+    # 23:59:60.f (`LeapSecondInstant`) included.  (A two-part Julian date made from POSIX-style
+    # nanoseconds came out up to a second early on days that end with a leap second: astropy's
+    # UTC day fraction is a fraction of that day's 86401 s.  ADVICE r5.)
+    from ..base.quantities import LeapSecondInstant
+    text = str(t) if isinstance(t, LeapSecondInstant) else str(np.datetime64(t, 'ns'))
+    return Time(text, format='isot', scale='utc', precision=9)
 
 
 def _as_rate(hz):

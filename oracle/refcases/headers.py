@@ -36,6 +36,24 @@ CASES = [
          call(None, 'dada.DADAHeader.fromvalues', nchan=1, npol=1, complex_data=False, bps=4, samples_per_frame=10001),
          gpu=False),
 
+    case('guppi_leap_second_start_times',
+         'a start time inside an inserted leap second, 23:59:60.375, is kept to the nanosecond: the cards '
+         'hold the next day, minus one second, plus the fraction; the times around it are ordinary '
+         '(guppi/tests/test_guppi.py, test_leap_seconds)',
+         [[call('h', 'guppi.GUPPIHeader.fromvalues', start_time=TIME(t), quiet=True), item(None, 'h', 'STT_IMJD'),
+           item(None, 'h', 'STT_SMJD'), item(None, 'h', 'STT_OFFS'), get('h.start_time'),
+           fn(None, 'sub', V('h.start_time'), TIME(t))]
+          + ([fn('later', 'add', V('h.start_time'), NS(1000000000)), fn(None, 'sub', V('later'), TIME(t))] if k < 2 else [])
+          # (a second added to 23:59:59.5 is 23:59:60.5 for the reference and the next midnight's
+          # 00:00:00.5 on numpy's scale, which this package's header times live on: not compared)
+          for k, t in enumerate(('2012-06-30T23:59:60.375000000', '2012-07-01T00:00:00.125000000',
+                                 '2012-06-30T23:59:59.500000000'))],
+         # (exactly 23:59:60: the reference's cards carry the rounding of its day arithmetic --
+         # 86399 s + 0.99999999998 -- so only the instant is compared)
+         call('h0', 'guppi.GUPPIHeader.fromvalues', start_time=TIME('2012-06-30T23:59:60.000000000'), quiet=True),
+         get('h0.start_time'),
+         gpu=False),
+
     case('file_names_from_headers',
          'name templates filled from header cards: PUPPI scan names, DADA names by frame number and by '
          'byte offset (guppi/tests/test_guppi.py, TestGUPPIFileNameSequencer; dada/tests/test_dada.py, '

@@ -99,6 +99,9 @@ class AmdUniverse(Universe):
         return os.path.join(self.sample_dir, name)
 
     def time(self, iso):
+        if 'T23:59:60' in iso:                  # inside a leap second: numpy has no label for it
+            from baseband_amd.base.quantities import LeapSecondInstant
+            return LeapSecondInstant.fromisot(iso)
         return np.datetime64(iso, 'ns')
 
     def duration_ns(self, ns):
@@ -119,6 +122,8 @@ class AmdUniverse(Universe):
     def special(self, x):
         if isinstance(x, np.datetime64):
             return {'t': str(x.astype('datetime64[ns]'))}
+        if type(x).__name__ == 'LeapSecondInstant':
+            return {'t': str(x)}
         if isinstance(x, np.timedelta64):
             return float(x.astype('timedelta64[ns]').astype(np.int64)) * 1e-9
         try:

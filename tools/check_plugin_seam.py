@@ -71,6 +71,11 @@ def describe(x):
     return {"kind": "Quantity", "repr": repr(x), "to_value": tv}
 
 
+LEAP_DAY_ISO = ('2016-12-31T00:00:00.000000001', '2016-12-31T12:00:00.123456789', '2016-12-31T23:59:59.999999999',
+                '2017-01-01T00:00:00.000000001', '2012-06-30T18:00:00.000000375')
+LEAP_ISO = ('2012-06-30T23:59:60.000000000', '2012-06-30T23:59:60.375000000', '2016-12-31T23:59:60.999999999')
+
+
 def part1(write):
     cases = []
 
@@ -97,6 +102,22 @@ def part1(write):
                        ('2020-01-01T00:00:37.000000000', 'tai'), ('2010-03-04T05:06:07.250000000', 'tt')):
         t = Time(iso, scale=scale, precision=9)
         add('as_time', t, t.utc.isot)
+    # days that end with a leap second: every instant of the day to the ns, both ways,
+    # and the instant inside the leap second itself as the small type that can name it
+    for iso in LEAP_DAY_ISO:
+        t = Time(iso, scale='utc', precision=9)
+        add('as_time', t, iso)
+    for iso in LEAP_ISO:
+        t = Time(iso, scale='utc', precision=9)
+        leap = q.as_time(t)
+        assert isinstance(leap, q.LeapSecondInstant) and str(leap) == iso, (iso, leap)
+        assert q.as_time(iso) == leap
+        y = t.utc.ymdhms
+        cases.append({"fn": "as_time", "arg": {"kind": "Time", "scale": "utc", "repr": iso, "jd1": float(t.utc.jd1),
+                                                "jd2": float(t.utc.jd2), "datetime64": None, "isot": t.utc.isot,
+                                                "ymdhms": [int(y['year']), int(y['month']), int(y['day']), int(y['hour']),
+                                                           int(y['minute']), float(y['second'])]},
+                      "expect": iso})
     add('as_time', Time(56824.247303240743, format='mjd', precision=9),
         Time(56824.247303240743, format='mjd', precision=9).utc.isot)
     # a Time without `datetime64` (older astropy): the jd1 / jd2 route, to the ns
@@ -184,6 +205,20 @@ def part2():
     # what `pip install` of this repository adds to the 'baseband.io' group (pyproject.toml)
     for name in ('vdif', 'mark5b', 'mark4', 'guppi', 'dada', 'gsb'):
         bio._entries[name + '_hip'] = EntryPoint(name + '_hip', 'baseband_amd.plugin.' + name, 'baseband.io')
+    # instants on days that end with a leap second, and inside the leap second, come back as the
+    # same Time (a Julian date made from POSIX nanoseconds was up to a second early there)
+    from baseband_amd.plugin._proxy import _as_Time
+    from baseband_amd.base import quantities as bq
+    for iso in LEAP_DAY_ISO + LEAP_ISO:
+        t = Time(iso, scale='utc', precision=9)
+        back = _as_Time(bq.as_time(t))
+        assert isinstance(back, Time) and abs((back - t).to_value(u.ns)) < 0.01 and back.isot == iso, (iso, back.isot)
+    gh = __import__('baseband_amd.guppi', fromlist=['GUPPIHeader']).GUPPIHeader.fromvalues(
+        start_time=Time('2012-06-30T23:59:60.375', precision=9))
+    import baseband.guppi
+    rh = baseband.guppi.GUPPIHeader.fromvalues(start_time=Time("2012-06-30T23:59:60.375", precision=9))
+    assert (gh['STT_IMJD'], gh['STT_SMJD']) == (rh['STT_IMJD'], rh['STT_SMJD']) and abs(gh['STT_OFFS'] - rh['STT_OFFS']) < 1e-9
+    assert abs((_as_Time(gh.start_time) - rh.start_time).to_value(u.ns)) < 0.01
     sample = os.path.join(ROOT, 'tests', 'golden', 'samples', 'sample.vdif')
     fh = baseband.open(sample, 'rs', format='vdif_hip', sample_rate=32 * u.MHz)
     ref = baseband.open(sample, 'rs', format='vdif', sample_rate=32 * u.MHz)
