@@ -145,7 +145,8 @@ class ArenaStats(C.Structure):
                 ('va_ranges', C.c_uint32), ('va_ranges_made', C.c_uint32), ('prepares', C.c_uint32),
                 ('growing', C.c_uint32), ('prepare_ms', C.c_double), ('prepare_wait_ms', C.c_double),
                 ('first_probe_gbps', C.c_double), ('last_create_ms', C.c_double),
-                ('second_chances', C.c_uint32), ('second_chance_wins', C.c_uint32)]
+                ('second_chances', C.c_uint32), ('second_chance_wins', C.c_uint32),
+                ('second_chances_no_room', C.c_uint32), ('reserved_', C.c_uint32)]
 
 
 LAYOUT_GUPPI_CF = 0

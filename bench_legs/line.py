@@ -124,7 +124,8 @@ def secondary_summary(line):
         if st:
             sec["arena_probe_gbps"] = round(st.get("last_probe_gbps") or 0.0, 0)
             sec["arena_first_probe_gbps"] = round(st.get("first_probe_gbps") or 0.0, 0)
-            sec["arena_second_chances"] = [st.get("second_chances"), st.get("second_chance_wins")]
+            sec["arena_second_chances"] = [st.get("second_chances"), st.get("second_chance_wins"),
+                                           st.get("second_chances_no_room")]     # tried, won, wanted but no room
             sec["arena_create_ms"] = round(st.get("last_create_ms") or 0.0, 1)
     for k in ("cold_minus_warm_ms", "cold_minus_warm_ms_dirty_memory"):
         v = _get(line, "cold_first_read", k)

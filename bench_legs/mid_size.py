@@ -106,11 +106,13 @@ def leg_mid_size(device, image, draws=5, launches=6):
                 # placement) from the same window: what is left of the call's time is what
                 # stands in front of and behind the kernel -- host work, the scan and index
                 # launches, the allocation, the verdict's copy
-                first = (10 * nf % (img_frames - nf))
-                win = image[first * FRAME_NBYTES:(first + nf) * FRAME_NBYTES]
                 flat = got.reshape(-1)
                 kts = []
                 for r in range(5):
+                    # (another window every time: 263 MB of input that was decoded a moment ago
+                    # would come from the 256 MiB Infinity Cache and flatter the kernel by 6 %)
+                    first = ((10 + 3 * r) * nf % (img_frames - nf))
+                    win = image[first * FRAME_NBYTES:(first + nf) * FRAME_NBYTES]
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
                     kernels.decode_frames(win, nf, PAYLOAD_NBYTES, _lib.CODER_VDIF, 2, src0=HEADER_NBYTES,

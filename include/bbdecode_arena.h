@@ -28,7 +28,7 @@
  * other) and the
  * fastest stays.  The DEFAULT (BB_ARENA_TRIES unset or 0; round 6) is one
  * candidate, and ONE more when the first probes below BB_ARENA_RETRY_BELOW_GBPS
- * = 6000 and its memory was cheap to create (under BB_ARENA_CHEAP_MS_PER_GIB = 3
+ * = 5600 and its memory was cheap to create (under BB_ARENA_CHEAP_MS_PER_GIB = 3
  * ms per GiB: the driver is not in the middle of wiping freed pages); the faster
  * of the two stays (`first_probe_gbps`, `second_chances`, `second_chance_wins`
  * in the statistics).  Fourteen candidates on one box probed at 5.77-6.52 TB/s;
@@ -102,6 +102,8 @@ typedef struct bb_arena_stats {
     double   last_create_ms; /* wall time creating that first candidate's memory took (large: the driver was wiping pages) */
     uint32_t second_chances; /* growths that tried a second candidate because the first probed slow and was cheap */
     uint32_t second_chance_wins; /* ... and kept the second */
+    uint32_t second_chances_no_room; /* growths that wanted a second candidate and had no room for it next to the first */
+    uint32_t reserved_;
 } bb_arena_stats;
 
 /* An arena that backs at most `capacity` bytes (rounded up to whole GiB) of the

@@ -650,6 +650,10 @@ def compare(steps, expected, got):
                         where, g['raises'], g.get('builtin'), w['raises'], w.get('builtin')))
                 elif st is not None and st.get('msg') and w.get('msg') != g.get('msg'):
                     diffs.append('{}: message {!r}, expected {!r}'.format(where, g.get('msg'), w.get('msg')))
+                elif st is not None and st.get('msg_has') and not (
+                        st['msg_has'] in w.get('msg', '') and st['msg_has'] in g.get('msg', '')):
+                    diffs.append('{}: message {!r} lacks {!r} (reference: {!r})'.format(
+                        where, g.get('msg'), st['msg_has'], w.get('msg')))
         elif st is not None and st.get('prefix') and isinstance(w.get('v'), str) and isinstance(g.get('v'), str):
             n = st['prefix']                            # (texts that go on to quote a library's own message)
             _same(w['v'][:n], g['v'][:n], where, diffs)
