@@ -77,6 +77,22 @@ class Universe:
         return [os.path.dirname(os.path.dirname(os.path.abspath(mod.__file__))) + os.sep]
 
 
+class _UnitOfTime:
+    """What ``fh.tell(unit)`` needs of a caller's unit object (astropy's ``u.ms``): ``to('s')``
+    and ``number * unit``.  The product is reduced to SECONDS at once -- the form durations
+    take in recorded outcomes -- instead of a Quantity."""
+    _S = {'s': 1.0, 'ms': 1e-3, 'us': 1e-6, 'ns': 1e-9, 'min': 60.0}
+
+    def __init__(self, name):
+        self.name, self.s = name, self._S[name]
+
+    def to(self, other):
+        return self.s / self._S[str(other)]
+
+    def __rmul__(self, number):
+        return float(number) * self.s
+
+
 class AmdUniverse(Universe):
     """This package: rates in Hz, instants numpy.datetime64[ns], durations
     numpy.timedelta64 or seconds, decoded samples torch tensors."""
@@ -109,6 +125,9 @@ class AmdUniverse(Universe):
 
     def rate_hz(self, hz):
         return float(hz)
+
+    def unit(self, name):
+        return name if name in ('time', 's') or name not in _UnitOfTime._S else _UnitOfTime(name)
 
     def host(self, x):
         try:
