@@ -146,7 +146,8 @@ class ArenaStats(C.Structure):
                 ('growing', C.c_uint32), ('prepare_ms', C.c_double), ('prepare_wait_ms', C.c_double),
                 ('first_probe_gbps', C.c_double), ('last_create_ms', C.c_double),
                 ('second_chances', C.c_uint32), ('second_chance_wins', C.c_uint32),
-                ('second_chances_no_room', C.c_uint32), ('reserved_', C.c_uint32)]
+                ('second_chances_no_room', C.c_uint32), ('probe_history_n', C.c_uint32),
+                ('probe_history', C.c_uint16 * 16)]
 
 
 LAYOUT_GUPPI_CF = 0

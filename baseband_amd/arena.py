@@ -211,7 +211,10 @@ class Arena:
     def stats(self):
         s = _lib.ArenaStats()
         check(lib.bb_arena_get_stats(self._handle, C.byref(s)), 'bb_arena_get_stats')
-        return {f: getattr(s, f) for f, _ in s._fields_}
+        out = {f: getattr(s, f) for f, _ in s._fields_}
+        out['probe_history'] = [int(v) for v in s.probe_history[:s.probe_history_n]]    # GB/s, oldest first
+        del out['probe_history_n']
+        return out
 
     def close(self):
         """Release the arena's memory.  Tensors still alive become invalid."""

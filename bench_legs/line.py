@@ -122,11 +122,12 @@ def secondary_summary(line):
         sec["mid_2p15_api_kernel"] = _get(ms[0], "api_read", "kernel_frac_same_output")
         st = _get(line, "mid_size", "arena_after") or {}
         if st:
-            sec["arena_probe_gbps"] = round(st.get("last_probe_gbps") or 0.0, 0)
-            sec["arena_first_probe_gbps"] = round(st.get("first_probe_gbps") or 0.0, 0)
+            sec["arena_probe_gbps"] = round(st.get("last_probe_gbps") or 0.0, 0)         # the step kept last
             sec["arena_second_chances"] = [st.get("second_chances"), st.get("second_chance_wins"),
                                            st.get("second_chances_no_room")]     # tried, won, wanted but no room
             sec["arena_create_ms"] = round(st.get("last_create_ms") or 0.0, 1)
+            if st.get("probe_history"):
+                sec["arena_probes"] = st["probe_history"][-6:]          # every candidate probed (kept or not), GB/s
     for k in ("cold_minus_warm_ms", "cold_minus_warm_ms_dirty_memory"):
         v = _get(line, "cold_first_read", k)
         if v is not None:
@@ -201,7 +202,7 @@ def compact_line(line, detail=DETAIL_NAME):
     # (secondary figures go one at a time, the rows that repeat a sibling first: the block as a
     # whole is what explains a low headline or mid-size read and is shed last)
     for k in ("vdif_4bit", "vdif_1bit", "gsb_4bit", "mkbf", "guppi_tf", "enc8", "dada_i8", "vdif_8thr", "mark4",
-              "writer_sequence_GBps", "pinned_h2d_GBps", "arena_create_ms", "arena_first_probe_gbps", "enc2",
+              "writer_sequence_GBps", "pinned_h2d_GBps", "arena_create_ms", "arena_first_probe_gbps", "arena_probe_gbps", "enc2",
               "guppi_tf_pick", "locate", "mid_2p15_api_kernel"):
         if size() <= LINE_LIMIT:
             break

@@ -27,11 +27,11 @@
  * is created somewhere else (none once two candidates probe within 4 % of each
  * other) and the
  * fastest stays.  The DEFAULT (BB_ARENA_TRIES unset or 0; round 6) is one
- * candidate, and ONE more when the first probes below BB_ARENA_RETRY_BELOW_GBPS
- * = 5600 and its memory was cheap to create (under BB_ARENA_CHEAP_MS_PER_GIB = 3
- * ms per GiB: the driver is not in the middle of wiping freed pages); the faster
- * of the two stays (`first_probe_gbps`, `second_chances`, `second_chance_wins`
- * in the statistics).  Fourteen candidates on one box probed at 5.77-6.52 TB/s;
+ * candidate, and up to BB_ARENA_MAX_CANDIDATES = 3 in all while the best so far
+ * probes below BB_ARENA_RETRY_BELOW_GBPS = 5800 and the first one's memory was
+ * cheap to create (under BB_ARENA_CHEAP_MS_PER_GIB = 3 ms per GiB: the driver is
+ * not in the middle of wiping freed pages); the fastest stays (`first_probe_gbps`,
+ * `second_chances`, `second_chance_wins`, `probe_history` in the statistics).  Fourteen candidates on one box probed at 5.77-6.52 TB/s;
  * a second candidate cost 0.2-1.5 s (profiles/r04h_prof_arena_grow.log).  Steps
  * grown in the background (bb_arena_prepare) follow the same rule.  Footprint: a
  * step is at most HALF of the device's free memory (behind a 4 GiB margin); at
@@ -102,8 +102,9 @@ typedef struct bb_arena_stats {
     double   last_create_ms; /* wall time creating that first candidate's memory took (large: the driver was wiping pages) */
     uint32_t second_chances; /* growths that tried a second candidate because the first probed slow and was cheap */
     uint32_t second_chance_wins; /* ... and kept the second */
-    uint32_t second_chances_no_room; /* growths that wanted a second candidate and had no room for it next to the first */
-    uint32_t reserved_;
+    uint32_t second_chances_no_room; /* growths that wanted another candidate and had no room for it next to the best so far */
+    uint32_t probe_history_n;        /* entries of probe_history in use */
+    uint16_t probe_history[16];      /* GB/s of every candidate probed (kept or not), oldest first; the last 16 */
 } bb_arena_stats;
 
 /* An arena that backs at most `capacity` bytes (rounded up to whole GiB) of the

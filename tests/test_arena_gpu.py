@@ -339,6 +339,7 @@ def test_a_slow_cheap_first_step_gets_one_second_chance(background, monkeypatch)
     monkeypatch.setenv('BB_ARENA_STEP_GIB', '12')
     monkeypatch.setenv('BB_ARENA_RETRY_BELOW_GBPS', '8000')
     monkeypatch.setenv('BB_ARENA_CHEAP_MS_PER_GIB', '100000')
+    monkeypatch.delenv('BB_ARENA_MAX_CANDIDATES', raising=False)
     free0, _ = torch.cuda.mem_get_info()
     ar = arena.Arena(64 * GIB)
     try:
@@ -346,10 +347,13 @@ def test_a_slow_cheap_first_step_gets_one_second_chance(background, monkeypatch)
             assert ar.prepare(3 * GIB)
         t = ar.empty((3 * GIB) // 4)
         st = ar.stats()
-        assert st['second_chances'] == 1 and st['probes'] == 2 and st['second_chance_wins'] in (0, 1)
-        assert st['steps'] == 1 and st['bytes_backed'] == 12 * GIB          # the loser is gone
+        # (every rate counts as slow here: all three candidates are looked at, the fastest stays)
+        assert st['second_chances'] == 1 and st['probes'] == 3 and st['second_chance_wins'] in (0, 1)
+        assert st['steps'] == 1 and st['bytes_backed'] == 12 * GIB          # the losers are gone
         assert st['last_probe_gbps'] >= st['first_probe_gbps'] > 1000
         assert (st['last_probe_gbps'] > st['first_probe_gbps']) == bool(st['second_chance_wins'])
+        assert len(st['probe_history']) == 3 and abs(max(st['probe_history']) - st['last_probe_gbps']) <= 1
+        assert abs(st['probe_history'][0] - st['first_probe_gbps']) <= 1
         free1, _ = torch.cuda.mem_get_info()
         assert free0 - free1 < 14 * GIB
         t.fill_(5.)
@@ -359,7 +363,8 @@ def test_a_slow_cheap_first_step_gets_one_second_chance(background, monkeypatch)
         monkeypatch.setenv('BB_ARENA_RETRY_BELOW_GBPS', '0')
         u = ar.empty((11 * GIB) // 4)
         st = ar.stats()
-        assert u is not None and st['steps'] == 2 and st['second_chances'] == 1 and st['probes'] == 3
+        assert u is not None and st['steps'] == 2 and st['second_chances'] == 1 and st['probes'] == 4
+        assert len(st['probe_history']) == 4
         u.fill_(6.)
         torch.cuda.synchronize()
         assert float(u[::4099].max()) == 6. and float(t[::4099].max()) == 5.
