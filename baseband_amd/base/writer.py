@@ -171,7 +171,12 @@ class GPUStreamWriterBase:
         ns = int(round(self.offset * 1e9 / self.sample_rate))
         if unit == 'time':
             return self._start_time + np.timedelta64(ns, 'ns')
-        raise ValueError("unit should be None or 'time'")
+        if unit == 's':
+            return self.offset / self.sample_rate
+        if hasattr(unit, 'to'):
+            # a unit object of the caller's (astropy: ``fw.tell(u.us)``), as the readers' tell does
+            return (self.offset / self.sample_rate / float(unit.to('s'))) * unit
+        raise ValueError("unit should be None, 'time', 's' or a unit of time")
 
     def write(self, data, valid=True):
         """Accept `data` of shape ``(n,) + sample_shape`` (NumPy array or torch

@@ -335,8 +335,13 @@ class Mark4StreamWriter(GPUStreamWriterBase):
         words = kernels.encode_mark4(body, h0.ntrack, maps['sign_bit'], maps['mag_bit'])
         k = np.arange(self._nframes_written, self._nframes_written + nfr)
         times = self._start_time + np.rint(k * 1e9 / self._frame_rate).astype('m8[ns]')
-        heads = frame_header_streams(h0, times, invalid=~np.asarray(valid, bool))
+        invalid = ~np.asarray(valid, bool)
+        heads = frame_header_streams(h0, times, invalid=invalid, before_invalid=self._before_invalid)
+        if nfr:
+            self._before_invalid = bool(invalid[-1])
         self._emit_frames(heads.view(np.uint8).reshape(nfr, -1), words)
+
+    _before_invalid = False     # whether the frame written last was flagged invalid (its flag is in the next CRC)
 
 
 def _adopt_header(h):

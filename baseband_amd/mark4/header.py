@@ -735,12 +735,15 @@ class Mark4Header:
         return "<{} {}>".format(name, (",\n  " + " " * len(name)).join(outs))
 
 
-def frame_header_streams(header0, times, invalid=None):
+def frame_header_streams(header0, times, invalid=None, before_invalid=False):
     """(nframes, 160) stream-word headers for frames at `times`
     (datetime64[ns] array): `header0` with each frame's time code, the
-    the CRC-12 of every track recomputed, and then the 'communication_error'
-    flag of every track set where `invalid` is true -- what ``header0.copy();
-    set_time(t); update_crc(); words2stream(words)`` gives frame by frame
+    the CRC-12 of every track recomputed -- over a header that still carries the
+    PREVIOUS frame's error flag, as the reference's writer computes it -- and then
+    the 'communication_error' flag of every track set where `invalid` is true
+    (`before_invalid`: whether the frame before the first of `times` was invalid);
+    valid frames after valid ones are what ``header0.copy(); set_time(t);
+    update_crc(); words2stream(words)`` gives frame by frame
     (`set_time`, `crc12_stream`, `words2stream` above), for all frames at once."""
     from ..base.utils import bcd_encode as bcd_array
     times = np.asarray(times, dtype='M8[ns]')
@@ -769,19 +772,28 @@ def frame_header_streams(header0, times, invalid=None):
     shifts = np.arange(31, -1, -1, dtype=np.int64)
     out[:, 96:128] = ((w3[:, None] >> shifts) & 1).astype(dtype) * ones
     out[:, 128:160] = ((w4[:, None] >> shifts) & 1).astype(dtype) * ones      # (crc bits zero for now)
+    # The error flag and the CRC, as in files the reference's writer leaves behind.  Its
+    # writer keeps ONE frame object: starting frame k it sets the time -- which renews the
+    # CRC over the header AS IT STANDS, still carrying frame k-1's error flag -- then clears
+    # the flag, and sets it again when a piece of frame k is written as invalid
+    # (base/base.py:1297-1323 `_make_frame` / `write`, mark4/frame.py `valid`; neither
+    # touches the CRC).  So the CRC of frame k covers the flag of frame k-1
+    # (`before_invalid` for the first frame of this call), and the flag itself is frame
+    # k's (recorded cases mark4:incomplete_and_headerless_streams,
+    # writers:mark5b_and_mark4_invalid_stretches).  Nothing reads the CRC back
+    # (SURVEY row M4-x); the point is byte identity of written files.
+    pos = 32 + 31 - _FIELDS['communication_error'][1]
+    inv = np.zeros(n, bool) if invalid is None else np.asarray(invalid, bool)
+    crc_flag = np.concatenate(([bool(before_invalid)], inv[:-1])) if n else inv
+    out[:, pos] = 0
+    out[crc_flag, pos] = ones
     # CRC-12 of the first 148 stream words of every track: polynomial division
     # without initial value is linear over GF(2), so crc bit k of every track is
     # the XOR of the stream words whose unit message has that bit in its remainder
     for k, idx in enumerate(_crc12_taps()):
         out[:, 148 + k] = np.bitwise_xor.reduce(out[:, idx], axis=1)
-    # The error flag goes in AFTER the CRC, as in files the reference writes: its
-    # writer sets a frame's time (which renews the CRC) when it starts the frame and
-    # flags it invalid when it is complete (base/base.py:1297-1323, mark4/frame.py
-    # `valid`), so the CRC of a padded last frame is that of the unflagged header
-    # (recorded case mark4:incomplete_and_headerless_streams).
-    if invalid is not None:
-        pos = 32 + 31 - _FIELDS['communication_error'][1]
-        out[np.asarray(invalid, bool), pos] = ones
+    out[:, pos] = 0
+    out[inv, pos] = ones
     return out
 
 

@@ -821,13 +821,15 @@ def test_vectorised_frame_headers_equal_the_per_frame_construction():
         k = np.arange(900)
         times = h0.get_time() + np.rint(k * 1e9 / 400.).astype('m8[ns]')
         invalid = rng.random(len(k)) < 0.1
-        streams = frame_header_streams(h0, times, invalid)
+        streams = frame_header_streams(h0, times, invalid, before_invalid=True)
         for i in range(0, len(k), 11):
             h = h0.copy()
             h.set_time(times[i])
+            # the CRC is renewed when a frame starts, over a header that still carries the flag of the
+            # frame before; the frame's own flag goes in when it is complete (the reference's writer)
+            h['communication_error'] = np.full(ntrack, bool(invalid[i - 1]) if i else True)
             h.update_crc()
-            if invalid[i]:          # flagged once the frame is complete: the CRC stays that of the unflagged header,
-                h['communication_error'] = np.ones(ntrack, bool)     # as in files the reference's writer pads
+            h['communication_error'] = np.full(ntrack, bool(invalid[i]))
             assert np.array_equal(words2stream(h.words), streams[i])
     with pytest.raises(ValueError):
         frame_header_streams(h0, np.array([h0.get_time() + np.timedelta64(1, 'ms')]))
