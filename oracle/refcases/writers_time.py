@@ -19,7 +19,7 @@ CASES = [
            do('fb.seek', -fnb, 2), call('hl', 'fb.read_header'), get('hl.time'), item(None, 'hl', 'seconds'),
            item(None, 'hl', 'frame_nr'), item(None, 'hl', 'thread_id'), close('fb')]
           for seed, name, nframes, spf, nthread, nchan, edv, stn, rate, t0, fnb in (
-              (1, 'sec.vdif', 6, 1000, 2, 4, 1, 'xy', 4000., '2015-06-30T23:59:59.250', 1032),
+              (1, 'sec.vdif', 6, 1000, 2, 4, 1, 'xy', 4000., '2015-05-31T23:59:59.250', 1032),
               (2, 'year.vdif', 4, 4000, 1, 1, 3, 65532, 8000., '2019-12-31T23:59:59.000', 1032),
               (3, 'epoch.vdif', 4, 320, 2, 2, 0, 'aa', 640., '2016-06-30T23:59:59.000', 192))],
          open_('fm', 'mark5b', S('sample.m5b'), 'rs', sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2),
@@ -37,9 +37,9 @@ CASES = [
          'year, 16 and 64 tracks (mark5b/tests/test_mark5b.py and mark4/tests/test_mark4.py, stream writer tests)',
          let('d5', RNG(4, (6 * 5000, 8), L2)),
          open_('fw', 'mark5b', T('day.m5b'), 'ws', sample_rate=HZ(10000.), nchan=8, bps=2,
-               time=TIME('2016-12-31T23:59:58.5'), user=0xbead, internal_tvg=True),
+               time=TIME('2017-12-31T23:59:58.5'), user=0xbead, internal_tvg=True),
          get('fw.header0'), do('fw.write', V('d5')), get('fw.time'), close('fw'), digest(T('day.m5b')),
-         open_('fb', 'mark5b', T('day.m5b'), 'rb', ref_time=TIME('2016-12-01T00:00:00'), nchan=8, bps=2),
+         open_('fb', 'mark5b', T('day.m5b'), 'rb', ref_time=TIME('2017-12-01T00:00:00'), nchan=8, bps=2),
          repeat(6, call('h', 'fb.read_header'), get('h.time'), item(None, 'h', 'frame_nr'), get('h.jday'),
                 do('fb.seek', 10000, 1)),
          close('fb'),
