@@ -239,16 +239,36 @@ inline uint64_t src_limit(size_t buf_nbytes, uint64_t span)
 }
 
 // Work order of a launch of `nwork` items writing `out_bytes` (bb_common.h,
-// bb_perm_t).  Default (knob -1): 16 stripes for outputs of 16 GiB and more,
-// 4 below; launches of fewer than 64 items per stripe keep file order.
-// Measured with every kernel family at 2^16 .. 2^20 frames
-// (profiles/r02e_exp_order.log): 33 GB outputs +12-15 % (5.5-5.6 -> 6.1-6.45
-// TB/s), 67 GB +4-6 %, 134 GB +-2 %, 8 GB: 4 stripes +0-2 %, 16 stripes -0-3 %.
-bb_perm_t make_perm(uint64_t nwork, uint64_t out_bytes)
+// bb_perm_t); launches of fewer than 64 items per stripe keep file order.
+// Rounds 2-5 dealt every launch over 16 stripes from 16 GiB of output on and over 4
+// below (profiles/r02e_exp_order.log: 33 GB outputs +12-15 % against file order, 8 GB:
+// 4 stripes +0-2 %, 16 stripes -0-3 %).  Round 6 measured the number of stripes again,
+// WITHIN one process on the same buffers (across processes the placement of the output
+// drowns it: +-15 %), for every kernel family and 1 - 137 GB of output
+// (profiles/r06o_exp_stripes_sizes.log, r06p_exp_stripes_headline.log,
+// r06r_formats_stripes_sweep.log, r06n_exp_stripes_placement.log):
+//   contiguous output (k_decode_flat_lds / _lut / int8, Mark 5B): 8 stripes +2.0-5.3 % below
+//     16 GiB (every size from 0.5 GB up, arena blocks and plain allocations; +6-7 % where
+//     the output's memory is physically contiguous and decodes slowly), +0.6-2.9 % above,
+//     +1.1-1.3 % at the headline size;
+//   GUPPI / MKBF transposes (k_decode_i8_xpose & co.): +2.6-5.6 % at every size;
+//   the LDS gather (thread interleave): +4.5 % at 1 GB, +-0.4 % from 4 GB on;
+//   k_decode_rows_pipe: 4 stripes stay best below 16 GiB (8: -0.6 .. -1.9 %), 8 above (+2.7 %);
+//   Mark 4, channel selections, copies: within +-1.2 % of the old rule: unchanged.
+enum bb_order_family { BB_ORDER_FLAT, BB_ORDER_GATHER, BB_ORDER_ROWS, BB_ORDER_TILED, BB_ORDER_OTHER };
+
+bb_perm_t make_perm(uint64_t nwork, uint64_t out_bytes, bb_order_family family = BB_ORDER_OTHER)
 {
     bb_perm_t p = {0, 0, 0};
     int lw = g_tune_order_lw.load();
-    if (lw < 0) lw = out_bytes >= (16ull << 30) ? 4 : 2;
+    if (lw < 0) {
+        const bool large = out_bytes >= (16ull << 30);
+        switch (family) {
+            case BB_ORDER_FLAT: case BB_ORDER_TILED: case BB_ORDER_GATHER: lw = 3; break;
+            case BB_ORDER_ROWS: lw = large ? 3 : 2; break;
+            default: lw = large ? 4 : 2; break;
+        }
+    }
     if (lw > 0 && (nwork >> lw) >= 64) {
         p.lw = (uint32_t)lw;
         p.stripe = nwork >> lw;
@@ -886,7 +906,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         // payload each); one workgroup per item costs 15 %, a few thousand
         // long-running ones 5-10 % (profiles/r01f_exp_gather*.log)
         uint64_t gb = (uint64_t)nframes * ga.ngroup;
-        ga.perm = make_perm(gb, out_bytes);
+        ga.perm = make_perm(gb, out_bytes, BB_ORDER_GATHER);
         const uint64_t gcap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (gb > gcap) gb = gcap;
         if (gb > 0x7fffffffull) gb = 0x7fffffffull;
@@ -908,7 +928,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.tpw = a.seg_tiles;
         const uint64_t sgroups = ((uint64_t)p->nslot + nw - 1) / nw;
         uint64_t b2 = (uint64_t)nframes * a.nseg * sgroups;
-        a.perm = make_perm(b2, out_bytes);
+        a.perm = make_perm(b2, out_bytes, BB_ORDER_ROWS);
         const uint64_t cap = tb > 0 ? (uint64_t)tb : BB_GRID_CAP;
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
@@ -1000,7 +1020,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
         a.tpw = (uint32_t)((a.seg_tiles + nwv - 1) / nwv);
         uint64_t b2 = nfs * a.nseg;
-        a.perm = make_perm(b2, out_bytes);
+        a.perm = make_perm(b2, out_bytes, BB_ORDER_FLAT);
         const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
         if (b2 > cap) b2 = cap;
         const dim3 g2((unsigned)b2);
@@ -1060,7 +1080,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
             a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
             a.tpw = (a.seg_tiles + 1) / 2;
             uint64_t b2 = nfs * a.nseg;
-            a.perm = make_perm(b2, out_bytes);
+            a.perm = make_perm(b2, out_bytes, BB_ORDER_FLAT);
             const uint64_t cap = tb > 0 ? (uint64_t)tb : (1ull << 23);
             if (b2 > cap) b2 = cap;
             const dim3 g2((unsigned)b2);
@@ -1091,7 +1111,7 @@ int bb_decode_frames(const void *d_buf, size_t buf_nbytes,
         a.seg_tiles = (uint32_t)((ntiles + a.nseg - 1) / a.nseg);
         a.tpw = (a.seg_tiles + BB_WAVES_PER_BLOCK - 1) / BB_WAVES_PER_BLOCK;
         const uint64_t nwork = nfs * a.nseg;
-        a.perm = make_perm(nwork, out_bytes);
+        a.perm = make_perm(nwork, out_bytes, BB_ORDER_FLAT);
         uint64_t blocks = nwork;
         if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
         if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
@@ -1766,7 +1786,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
             a.ntt = (uint32_t)ntt; a.nct = (uint32_t)nct;
             a.tt = (uint32_t)(rt / npd); a.tc = (uint32_t)xtc; a.tcp = 2 * ((uint32_t)xtc + 1);
             uint64_t blocks = (uint64_t)nframes * ntt * nct;
-            a.perm = make_perm(blocks, (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4);
+            a.perm = make_perm(blocks, (uint64_t)nframes * (p->t_hi - p->t_lo) * rowlen * 4, BB_ORDER_TILED);
             // one tile per workgroup: with 20 % of the traffic being reads the
             // dispatcher overlaps loads and stores of many small workgroups
             // better than a persistent pipelined grid does (16 GiB of input,
@@ -1836,7 +1856,7 @@ int bb_decode_i8_tiled(const void *d_buf, size_t buf_nbytes,
     a.nct = (uint32_t)nct;
     if (lds > 64 * 1024) return BB_ENOTSUP;
     uint64_t blocks = (uint64_t)nframes * ntt * nct;
-    a.perm = make_perm(blocks, (uint64_t)nframes * rows * rowlen * 4);
+    a.perm = make_perm(blocks, (uint64_t)nframes * rows * rowlen * 4, BB_ORDER_TILED);
     if (tb > 0 && blocks > (uint64_t)tb) blocks = (uint64_t)tb;
     if (blocks > 0x7fffffffull) blocks = 0x7fffffffull;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);

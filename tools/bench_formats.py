@@ -20,7 +20,11 @@ from baseband_amd.mark4._bitmaps import BITMAPS  # noqa: E402
 PEAK = 8000.0
 
 
-def timeit(fn, reps=7):
+_SWEEP = [int(x) for x in os.environ.get('BB_WORK_STRIPES_SWEEP', '').split(',') if x]
+_last_sweep = {}
+
+
+def _time_once(fn, reps):
     fn()
     torch.cuda.synchronize()
     ts = []
@@ -34,12 +38,28 @@ def timeit(fn, reps=7):
     return float(np.median(ts))
 
 
+def timeit(fn, reps=7):
+    """Median launch time (ms).  BB_WORK_STRIPES_SWEEP=2,3,4 (experiment build): the same
+    launch -- same buffers, same process, so the same placement -- also under each of these
+    work orders (log2 of the number of stripes); `report` attaches the times."""
+    global _last_sweep
+    _last_sweep = {}
+    for lw in _SWEEP:
+        kernels.tune(_lib.TUNE_WORK_STRIPES, lw)
+        _last_sweep[1 << lw] = _time_once(fn, reps)
+    if _SWEEP:
+        kernels.tune(_lib.TUNE_WORK_STRIPES, -1)
+    return _time_once(fn, reps)
+
+
 def report(name, ms, bytes_in, bytes_out, nvalues, **extra):
     gbs = (bytes_in + bytes_out) / ms / 1e6
     line = dict(case=name, ms=round(ms, 4), algorithmic_GBps=round(gbs, 1),
                 frac_of_8TBps=round(gbs / PEAK, 4),
                 Mvalues_per_s=round(nvalues / ms / 1e3, 1),
                 bytes_in=bytes_in, bytes_out=bytes_out, **extra)
+    if _last_sweep:
+        line['GBps_by_stripes'] = {str(k): round((bytes_in + bytes_out) / v / 1e6, 1) for k, v in _last_sweep.items()}
     print(json.dumps(line), flush=True)
 
 
@@ -48,6 +68,8 @@ def main():
     nbytes = int(gib * 2 ** 30)
     dev = torch.device('cuda')
     kernels.init()
+    if os.environ.get('BB_WORK_STRIPES_LW'):            # experiment build: the work order of every launch
+        kernels.tune(_lib.TUNE_WORK_STRIPES, int(os.environ['BB_WORK_STRIPES_LW']))
     g = torch.Generator(device=dev)
     g.manual_seed(1)
     buf = torch.randint(0, 2 ** 31 - 1, (nbytes // 4 + 1024,), generator=g, device=dev,
