@@ -252,7 +252,7 @@ inline uint64_t src_limit(size_t buf_nbytes, uint64_t span)
 //     the output's memory is physically contiguous and decodes slowly), +0.6-2.9 % above,
 //     +1.1-1.3 % at the headline size;
 //   GUPPI / MKBF transposes (k_decode_i8_xpose & co.): +2.6-5.6 % at every size;
-//   the LDS gather (thread interleave): +4.5 % at 1 GB, +-0.4 % from 4 GB on;
+//   the LDS gather (thread interleave): +4.5 % at 1 GB, +-0.4 % from 4 GB on: 8 below 16 GiB, 16 above as before;
 //   k_decode_rows_pipe: 4 stripes stay best below 16 GiB (8: -0.6 .. -1.9 %), 8 above (+2.7 %);
 //   Mark 4, channel selections, copies: within +-1.2 % of the old rule: unchanged.
 enum bb_order_family { BB_ORDER_FLAT, BB_ORDER_GATHER, BB_ORDER_ROWS, BB_ORDER_TILED, BB_ORDER_OTHER };
@@ -264,7 +264,8 @@ bb_perm_t make_perm(uint64_t nwork, uint64_t out_bytes, bb_order_family family =
     if (lw < 0) {
         const bool large = out_bytes >= (16ull << 30);
         switch (family) {
-            case BB_ORDER_FLAT: case BB_ORDER_TILED: case BB_ORDER_GATHER: lw = 3; break;
+            case BB_ORDER_FLAT: case BB_ORDER_TILED: lw = 3; break;
+            case BB_ORDER_GATHER: lw = large ? 4 : 3; break;
             case BB_ORDER_ROWS: lw = large ? 3 : 2; break;
             default: lw = large ? 4 : 2; break;
         }
