@@ -96,7 +96,7 @@ for f in files:
     m = re.match(r'r(\d\d)', f)
     rounds.setdefault(m.group(1) if m else 'zz', []).append(f)
 out = ["# profiles/ -- index", "",
-       "Every measurement file of rounds 1-5, grouped by round and kind.  `rNN<x>_` = round NN, run x (a, b, ... z, za, ...).",
+       "Every measurement file of rounds 1-6, grouped by round and kind.  `rNN<x>_` = round NN, run x (a, b, ... z, za, ...).",
        "\"cited in\" lists the documents and sources whose statements rest on the file.  Regenerate with",
        "`python tools/make_profiles_index.py`.", "",
        "Where to start: the newest `*_bench.json` (the driver-format line), the `*_kernel_stats*.csv` of the same run",
