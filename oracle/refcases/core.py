@@ -5,6 +5,17 @@ INFO_FACTS = ('format', 'readable', 'missing', 'errors', 'warnings', 'checks')
 REF = TIME('2014-01-01T00:00:00')
 
 CASES = [
+    case('older_files_of_a_sequence_are_emptied',
+         'files left over from an earlier, longer run of the same names do not keep their tails when a '
+         'sequence is written over them (round 5 found tails kept by positional writes)',
+         [[fn(None, 'write_file', T('s%d.vdif' % k), [FILL(0xee, 50000)])] for k in range(3)],
+         open_('fr', 'vdif', S('sample.vdif'), 'rs'), call('d', 'fr.read'),
+         open_('fw', 'vdif', [T('s0.vdif'), T('s1.vdif'), T('s2.vdif')], 'ws', header0=V('fr.header0'), nthread=8,
+               file_size=8 * 5032),
+         do('fw.write', V('d')), close('fw'), close('fr'),
+         digest(T('s0.vdif')), digest(T('s1.vdif')), digest(T('s2.vdif')),
+         open_('fn', 'vdif', [T('s0.vdif'), T('s1.vdif')], 'rs'), get('fn.shape'), call(None, 'fn.read', 5), close('fn')),
+
     case('open_finds_the_format',
          'open() without a format: the format is found from the bytes; arguments other formats need are '
          'dropped; squeeze and verify are passed on (baseband/tests/test_core.py, test_open / '
@@ -103,17 +114,6 @@ CASES = [
          do('fw2.write', V('d2')), close('fw2'), listdir(), digest(T('f001.vdif')),
          open_('fn2', 'top', V('seq')), get('fn2.info.format'), fn(None, 'len', V('fn2.fh_raw.files')),
          call('again2', 'fn2.read'), eq(V('again2'), V('d2')), close('fn2'), close('fv')),
-
-    case('older_files_of_a_sequence_are_emptied',
-         'files left over from an earlier, longer run of the same names do not keep their tails when a '
-         'sequence is written over them (round 5 found tails kept by positional writes)',
-         [[fn(None, 'write_file', T('s%d.vdif' % k), [FILL(0xee, 50000)])] for k in range(3)],
-         open_('fr', 'vdif', S('sample.vdif'), 'rs'), call('d', 'fr.read'),
-         open_('fw', 'vdif', [T('s0.vdif'), T('s1.vdif'), T('s2.vdif')], 'ws', header0=V('fr.header0'), nthread=8,
-               file_size=8 * 5032),
-         do('fw.write', V('d')), close('fw'), close('fr'),
-         digest(T('s0.vdif')), digest(T('s1.vdif')), digest(T('s2.vdif')),
-         open_('fn', 'vdif', [T('s0.vdif'), T('s1.vdif')], 'rs'), get('fn.shape'), call(None, 'fn.read', 5), close('fn')),
 
     case('byte_level_sequences',
          'the plain file sequences underneath: sizes, seeking across boundaries, reads that span files, '
