@@ -129,7 +129,7 @@ class Arena:
         if self._handle is None:
             return None
         # (this runs once per read(): plain Python arithmetic, no NumPy / torch helpers --
-        # 26 -> about 12 us, tools/prof_arena_empty.py)
+        # 26 -> about 12 us, tools/experiments/prof_arena_empty.py)
         shape = (int(shape),) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
         cplx = dtype == torch.complex64
         base = torch.float32 if cplx else dtype
@@ -274,7 +274,7 @@ def get_or_create(device, capacity=None):
         ar = _arenas.get(idx)
         if ar is None:
             if capacity is None:
-                # (not get_device_properties: its first call takes 107 ms, tools/prof_cold_open.py)
+                # (not get_device_properties: its first call takes 107 ms, tools/experiments/prof_cold_open.py)
                 capacity = torch.cuda.mem_get_info(idx)[1]
             ar = _arenas[idx] = Arena(capacity, device=idx)
         return ar
