@@ -15,10 +15,13 @@
  * thing in a fresh process decode at 5.3 TB/s for good
  * (profiles/r03k_exp_arena_history.log).  The arena is that: a virtual range
  * of `capacity` bytes, backed on demand in steps of at least 48 GiB (less if
- * the device has less free; BB_ARENA_STEP_GIB) by 32 MiB chunks that are DEALT
- * round robin over the step's 1 GiB "teeth" -- consecutive 32 MiB pieces of any
- * block lie a GiB apart, every block of 1.5 GiB or more spans the whole step --
- * with a first-fit allocator of 32 MiB granules on top.  A wide step is not
+ * the device has less free; BB_ARENA_STEP_GIB) by 32 MiB chunks that are mapped
+ * in a fixed pseudo-random order (round 6; rounds 3-5: dealt round robin over
+ * the step's 1 GiB "teeth") -- the pieces of any block lie scattered over the
+ * whole step, whatever order the driver created them in: a 1 GB decode into one
+ * physically contiguous gigabyte runs at 5.2 TB/s, into scattered memory at 6.4
+ * (profiles/r06l_exp_tooth_rates.log, r06t_exp_deal_orders.log) -- with a
+ * first-fit allocator of 32 MiB granules on top.  A wide step is not
  * always enough: in one process every block of a 48 GiB step decoded at 5.5
  * TB/s (profiles/r03n/bench_plain.json).  Since the rate belongs to the memory,
  * a new step is PROBED with a decode-shaped launch (2^16 frames, three
@@ -31,8 +34,9 @@
  * probes below BB_ARENA_RETRY_BELOW_GBPS = 6000 and the first one's memory was
  * cheap to create (under BB_ARENA_CHEAP_MS_PER_GIB = 3 ms per GiB: the driver is
  * not in the middle of wiping freed pages); the fastest stays (`first_probe_gbps`,
- * `second_chances`, `second_chance_wins`, `probe_history` in the statistics).  Fourteen candidates on one box probed at 5.77-6.52 TB/s;
- * a second candidate cost 0.2-1.5 s (profiles/r04h_prof_arena_grow.log).  Steps
+ * `second_chances`, `second_chance_wins`, `probe_history` in the statistics).
+ * Scattered steps probe at 6.4-6.8 TB/s (profiles/r06[s-z]_bench_line.json); a
+ * further candidate costs 0.2-1.9 s (profiles/r04h_prof_arena_grow.log).  Steps
  * grown in the background (bb_arena_prepare) follow the same rule.  Footprint: a
  * step is at most HALF of the device's free memory (behind a 4 GiB margin); at
  * most two steps exist at any moment (the best so far and the one being
