@@ -33,6 +33,11 @@ from . import _lib
 from ._lib import lib, check
 
 
+def _current_stream(device):
+    from .kernels import current_stream         # (kernels imports nothing of this module)
+    return current_stream(device)
+
+
 class _Block:
     """Owner of one arena block; torch keeps it alive through the array
     interface and drops it with the last tensor that views the block."""
@@ -150,7 +155,7 @@ class Arena:
         if rc == _lib.BB_ERANGE or not p.value:
             return None
         check(rc, 'bb_arena_alloc')
-        stream = torch.cuda.current_stream(self.device)
+        stream = _current_stream(self.device)
         nbytes = n * item
         self._order_reuse(p.value, p.value + -(-nbytes // self._granule) * self._granule, stream)
         block = _Block(self, p.value, nbytes, (n,), _TYPESTR[base], stream)

@@ -46,6 +46,28 @@ def _stream(t=None):
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_stream_objects = {}        # (device index, raw handle) -> torch.cuda.Stream
+
+
+def current_stream(device):
+    """``torch.cuda.current_stream(device)`` without its ~5 us of Python: the Stream object
+    of a raw handle is remembered (two of these per mid-size read: the arena's reuse
+    ordering and the scratch sets' events)."""
+    if _raw_stream is None:
+        return torch.cuda.current_stream(device)
+    index = device.index if isinstance(device, torch.device) else int(device)
+    if index is None:
+        index = torch.cuda.current_device()
+    raw = _raw_stream(index)
+    s = _stream_objects.get((index, raw))
+    if s is None:
+        s = _stream_objects[(index, raw)] = torch.cuda.current_stream(index)
+        if len(_stream_objects) > 64:       # (streams come and go: do not keep every one ever seen)
+            for k in list(_stream_objects)[:32]:
+                del _stream_objects[k]
+    return s
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
@@ -197,7 +219,7 @@ class _FrameWindow:
             self._rotating = True
             if st[2] is None:
                 st[2] = torch.cuda.Event()
-            st[2].record(torch.cuda.current_stream(dev))
+            st[2].record(current_stream(dev))
 
 
 class VDIFWindow(_FrameWindow):
