@@ -139,6 +139,10 @@ class GPUStreamWriterBase:
     def writable(self):
         return not self._closed
 
+    @property
+    def closed(self):
+        return self._closed
+
     def seekable(self):
         return False
 

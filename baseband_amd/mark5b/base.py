@@ -256,9 +256,17 @@ class Mark5BStreamWriter(GPUStreamWriterBase):
         if sample_rate is None:
             raise ValueError("Mark 5B stream writer needs a sample_rate.")
         spf = 10000 * 8 // bps // nchan
+        # what the reference's first (empty) frame refuses when the writer is made
+        # (mark5b/base.py:335, base/payload.py:187,321)
+        if spf * nchan * bps != 80000:
+            raise ValueError("encoded data should have length 10000")
+        if bps not in (1, 2):
+            raise ValueError("Mark5BPayload cannot encode data with {} bits".format(bps))
         frame_rate = hz(sample_rate) / spf
         if header0 is None:
             header0 = Mark5BHeader.fromvalues(time=time, frame_rate=frame_rate, **kwargs)
+        elif kwargs:
+            raise TypeError("__init__() got an unexpected keyword argument '{}'".format(sorted(kwargs)[0]))
         super().__init__(fh_raw, header0, sample_rate=sample_rate, samples_per_frame=spf,
                          unsliced_shape=(nchan,), bps=bps, complex_data=False,
                          squeeze=squeeze)

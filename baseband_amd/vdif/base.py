@@ -494,6 +494,8 @@ class VDIFStreamWriter(GPUStreamWriterBase):
                     header0.ref_time = time             # (a time without an epoch brings its own)
                 header0.set_time(time, frame_rate=sample_rate / header0.samples_per_frame)
             header0.verify()
+        elif kwargs:                    # (header keywords next to a header: the reference's TypeError)
+            raise TypeError("__init__() got an unexpected keyword argument '{}'".format(sorted(kwargs)[0]))
         if sample_rate is None:
             sample_rate = header0.sample_rate
         if sample_rate is None:

@@ -301,6 +301,9 @@ class VDIFHeader(BitFieldHeader):
             assert self['sync_pattern'] == self._fields['sync_pattern'][3]
         if self.edv == 0:
             assert all(w == 0 for w in self.words[4:])
+        elif self.edv == 2:             # (vdif/header.py:779-782)
+            assert self['frame_length'] in (629, 1004)
+            assert self.bps == 2 and not self['complex_data']
         elif self.edv == 3:
             assert self['frame_length'] in (129, 629)
         elif self.edv == 0xab:
@@ -325,6 +328,8 @@ class VDIFHeader(BitFieldHeader):
     def frame_nbytes(self, nbytes):
         units, rest = divmod(int(nbytes), 8)
         assert rest == 0, "VDIF frames are multiples of 8 bytes"
+        if self.edv == 3:               # (vdif/header.py:744-747: refused when set, not only by verify)
+            assert int(nbytes) in (1032, 5032)
         self['frame_length'] = units
 
     @property

@@ -1319,3 +1319,22 @@ def test_a_slow_first_allocation_is_named_once(monkeypatch):
         placement._note_slow_allocation(90.0, 4 << 30)              # again: silent
     assert len(caught) == 1 and issubclass(caught[0].category, RuntimeWarning)
     assert '6.0 s' in str(caught[0].message) and 'freed' in str(caught[0].message)
+
+
+def test_edv_2_and_3_headers_refuse_other_frame_lengths():
+    """EDV 3 refuses a frame length other than 1032 / 5032 bytes the moment it is set (the reference's
+    AssertionError, before the "cannot store" ValueError); EDV 2 checks its lengths and 2-bit real data in
+    verify (vdif/header.py:744-747, 779-782); EDV 1 takes any length."""
+    from baseband_amd.vdif.header import VDIFHeader
+    kw = dict(verify=False, nchan=1, bps=2, complex_data=False, station=1)
+    with pytest.raises(AssertionError):
+        VDIFHeader.fromvalues(samples_per_frame=20001, edv=3, **kw)
+    with pytest.raises(AssertionError):
+        VDIFHeader.fromvalues(samples_per_frame=20032, edv=3, **kw)
+    with pytest.raises(ValueError):
+        VDIFHeader.fromvalues(samples_per_frame=20001, edv=1, **kw)
+    assert VDIFHeader.fromvalues(samples_per_frame=20032, edv=1, **kw)['frame_length'] == 630
+    h2 = VDIFHeader.fromvalues(samples_per_frame=20032, edv=2, **kw)
+    with pytest.raises(AssertionError):
+        h2.verify()
+    VDIFHeader.fromvalues(samples_per_frame=20000, edv=2, **kw).verify()
