@@ -72,7 +72,7 @@ class RowSetMixin:
                 index = (start - lo,) + sample_index
             else:
                 index = (slice(start - lo, stop - lo, step),) + sample_index
-            _assign(block, index, data.to(want))
+            _assign(block, index, data)
         self._store_rows(lo, hi, block)
         self._dwords = None
 
@@ -80,11 +80,21 @@ class RowSetMixin:
 def _assign(block, index, values):
     """``block[index] = values`` with NumPy's error for shapes that do not broadcast
     (a ValueError; torch raises RuntimeError), as callers of the reference expect."""
+    target = tuple(block[index].shape)
+    given = tuple(values.shape)
+    while len(given) > len(target) and given[0] == 1:       # (leading axes of length 1 do not count)
+        given = given[1:]
     try:
-        block[index] = values
-    except RuntimeError as exc:
+        fits = tuple(torch.broadcast_shapes(given, target)) == target
+    except RuntimeError:
+        fits = False
+    if not fits and target == () and block.is_complex():
+        # (NumPy's wording and class for a sequence into one complex element)
+        raise TypeError("only length-1 arrays can be converted to Python scalars")
+    if not fits:            # (before any cast: NumPy complains about the shape first, and only that)
         raise ValueError("could not broadcast input array from shape {} into shape {}".format(
-            tuple(values.shape), tuple(block[index].shape))) from exc
+            tuple(values.shape), target))
+    block[index] = values.reshape(given).to(block.dtype)
 
 
 class PayloadBase:
@@ -311,12 +321,13 @@ class PayloadBase:
             data = torch.from_numpy(np.ascontiguousarray(data))
         data = data.to('cuda')
         ns = len(self.sample_shape)
-        whole = (index == (slice(None),) and data.ndim > ns
-                 and tuple(data.shape[data.ndim - ns:]) == tuple(self.sample_shape)
+        nrows = (w1 - w0) * self.words.itemsize * 8 // self._bpfs      # complete samples in those words
+        whole = (index == (slice(None),) and data.ndim == ns + 1
+                 and tuple(data.shape) == (nrows,) + tuple(self.sample_shape)
                  and data.is_complex() == self.complex_data)
         if not whole:
             block = self._fresh_block(w0, w1)
-            _assign(block, index, data.to(block.dtype))
+            _assign(block, index, data)
             data = block
         encoded = self._encode(kernels.as_device_samples(data))
         self.words[w0:w1] = encoded.reshape(-1)

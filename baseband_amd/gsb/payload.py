@@ -33,6 +33,8 @@ class GSBPayload(PayloadBase):
         per = 8 // self.bps
         import torch
         from .. import kernels
+        if byte_stop == byte_start:             # (an empty slice)
+            return torch.empty(0, dtype=torch.float32, device='cuda')
         dbuf = self._device_words()
         if hi > dbuf.numel():
             dbuf = torch.nn.functional.pad(dbuf, (0, hi - dbuf.numel()))

@@ -65,6 +65,10 @@ def ZEROS(shape, dt='f4'):
 
 
 def ARRAY(values, dt=None):
+    if dt == 'c8':                      # complex values travel as [re, im] pairs on a last axis
+        def pairs(v):
+            return [pairs(e) for e in v] if isinstance(v, (list, tuple)) else [complex(v).real, complex(v).imag]
+        values = pairs(values)
     return {'$array': values, 'dt': dt}
 
 

@@ -218,6 +218,9 @@ class Runner:
         if '$zeros' in x:
             return np.zeros(tuple(x['$zeros']), dtype=x.get('dt', 'f4'))
         if '$array' in x:
+            if x.get('dt') == 'c8':         # complex values travel as [re, im] pairs on a last axis
+                a = np.array(x['$array'], dtype='f4')
+                return np.ascontiguousarray(a).view('c8')[..., 0]
             return np.array(x['$array'], dtype=x.get('dt'))
         if '$rng' in x:
             # own generator (the same numbers under any numpy): a 64-bit LCG stepped per element
