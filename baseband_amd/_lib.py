@@ -185,6 +185,7 @@ SIGNATURES = [
     ('bb_vdif_scan_at', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_mark5b_scan', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp]),
     ('bb_mark5b_locate', C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
+    ('bb_mark5b_locate_stream', C.c_int, [_vp, _sz, C.c_uint32, C.c_uint32, _vp, _sz, _vp, _vp]),
     ('bb_mark5b_scan_at', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp, _vp]),
     ('bb_verify_records', C.c_int, [_vp, _sz, C.c_int32, C.c_uint32, _sz, _vp, _vp]),
     ('bb_build_index', C.c_int, [_vp, _sz, _vp, C.c_int, _vp, _sz, _vp]),

@@ -894,12 +894,14 @@ class GPUStreamReaderBase:
             else:
                 _to_host_array(ahead, out)
             return out
+        self._asked = (self.offset, count)
         data, direct = self._fill_request(out, count)
         if not self._resolve_checks():
             # verify='fix': frames are missing or out of place.  Build the
             # corruption-tolerant index (byte-granular header search) and
             # decode again through it.
             self._relocate()
+            self.decode_ahead = False       # (warnings belong to the read that meets a hole)
             if self.offset + count > self.shape[0]:
                 raise EOFError("cannot read from beyond end of input.")
             data, direct = self._fill_request(out, count)
@@ -1330,17 +1332,84 @@ class GPUStreamReaderBase:
                    "(bad sync/invariants or unexpected time index)".format(nbad))
             if self.verify == 'fix':
                 if self._can_relocate and not self._relocated:
-                    warnings.warn(msg + "; searching for frames byte by byte, "
-                                  "missing ones are set to fill_value.")
+                    # (no warning here: the read is done again through the index of
+                    # located frames, which names every frame it cannot supply)
                     return False
                 warnings.warn(msg + "; affected samples were set to fill_value.")
             else:
-                raise ValueError("wrong frame number. " + msg)
+                raise self._verification_error(msg)
         return True
+
+    def _verification_error(self, msg):
+        """The exception a read under ``verify=True`` ends with when headers failed their checks."""
+        return ValueError("wrong frame number. " + msg)
+
+    _asked = None               # (first sample, count) of the read() in progress
 
     _can_relocate = False
     _relocated = False
     _pending_warning = None
+
+    # After `_relocate`: which frame sets have frames missing, so that every read that
+    # meets one says so, as the reference does at each load of such a set
+    # (base/base.py:1127-1219, vdif/base.py:655-730) -- and `info`'s look at the last
+    # frame reports 'fixable gaps' with the same sentence.
+    _damage = None              # (sorted set numbers, their rows of "slot missing")
+    damage_warnings_per_read = 16
+
+    def _note_damage(self, src, nslot=1):
+        """Called at the end of `_relocate`: which sets lack frames, and by how many bytes
+        the complete ones are displaced from the fixed stride."""
+        gone = (src.reshape(-1, nslot) < 0).cpu().numpy()
+        sets = np.nonzero(gone.any(axis=1))[0]
+        self._damage = (sets, gone[sets])
+        starts = self._located_starts()
+        n = min(len(starts), len(gone))
+        whole = (starts[:n] >= 0) & ~gone[:n].any(axis=1)
+        slip = starts[:n] - self._file_offset0 - np.arange(n, dtype=np.int64) * self._set_nbytes
+        self._slips = (whole, slip, np.zeros(n, bool))
+
+    def _damage_message(self, k, missing):
+        return "problem loading frame {}. The frame seems to be missing.".format(k)
+
+    def _slip_message(self, k, nbytes):
+        return "problem loading frame {}. Stream off by {} bytes.".format(k, nbytes)
+
+    _slips = None               # (set is complete, its displacement in bytes, displacement known to the caller)
+
+    def _warn_damage(self, first, last):
+        """Warnings of one read of sets [first, last) through the index of located frames: one
+        for every set with frames missing, and -- as the reference, which learns where frames
+        lie as it meets them (base/base.py:1127-1219, the table `_raw_offsets`) -- one where a
+        complete set is not where the sets read so far put it: at the first set of the read
+        whatever the difference, further on when it is not a whole number of frames (bytes
+        went missing; whole missing frames are accounted for by the message of their set)."""
+        if self._damage is None:
+            return
+        notes = []
+        sets, rows = self._damage
+        lo, hi = np.searchsorted(sets, [first, last])
+        for j in range(lo, hi):
+            notes.append((int(sets[j]), self._damage_message(int(sets[j]), rows[j])))
+            if len(notes) > self.damage_warnings_per_read:
+                break
+        if self._slips is not None:
+            whole, slip, known = self._slips
+            ks = first + np.nonzero(whole[first:last])[0]
+            if len(ks):
+                before = np.nonzero(known[:ks[0]])[0]
+                base = slip[before[-1]] if len(before) else 0
+                step = np.diff(np.concatenate([[base], slip[ks]]))
+                frame_nbytes = getattr(self, '_frame_nbytes', None) or self._set_nbytes
+                told = (step != 0) & ((ks == first) | (step % frame_nbytes != 0)) & ~known[ks]
+                for j in np.nonzero(told)[0][:self.damage_warnings_per_read]:
+                    notes.append((int(ks[j]), self._slip_message(int(ks[j]), -int(step[j]))))     # (expected - found)
+                known[ks] = True
+        notes.sort()
+        for _, text in notes[:self.damage_warnings_per_read]:
+            warnings.warn(text)
+        if len(notes) > self.damage_warnings_per_read or hi - lo > self.damage_warnings_per_read:
+            warnings.warn("... and more frames of this read with data missing; set to invalid.")
 
     # The last header of a stream and the number of samples that follows from it are
     # looked up when first asked for, as the reference's lazy properties are
@@ -1393,6 +1462,12 @@ class GPUStreamReaderBase:
             if self._file_offset0:
                 table[0] = self._file_offset0
             return table
+        start = self._located_starts()
+        return RawOffsets.from_index(start, self._set_nbytes, known=start >= 0)
+
+    def _located_starts(self):
+        """File position of the earliest located frame of every frame (set), -1 where none was found."""
+        from .. import _lib
         offs, recs = self._located
         nsets = self._nsample // self.samples_per_frame
         when = recs[:, 2].to(torch.int64)
@@ -1401,7 +1476,8 @@ class GPUStreamReaderBase:
         start = torch.full((nsets,), none, dtype=torch.int64, device=offs.device)
         start.scatter_reduce_(0, when[ok], offs.to(torch.int64)[ok], 'amin')
         start = start.cpu().numpy()
-        return RawOffsets.from_index(start, self._set_nbytes, known=start != none)
+        start[start == none] = -1
+        return start
 
     # -- pickling: reopen by file name at the saved offset
     # (base/base.py:123-151,1020-1032); device buffers are re-creatable

@@ -737,8 +737,8 @@ int bb_mark5b_scan_at(const void *d_buf, size_t nbytes, const bb_mark5b_scan_par
     return mark5b_scan_impl(d_buf, nbytes, p, d_offsets, d_recs, nframes, stream);
 }
 
-int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets, size_t cap,
-                     unsigned long long *d_count, void *stream)
+int bb_mark5b_locate_stream(const void *d_buf, size_t nbytes, uint32_t w1_pattern, uint32_t w1_mask,
+                            int64_t *d_offsets, size_t cap, unsigned long long *d_count, void *stream)
 {
     if (!d_buf || !d_offsets || !d_count) return BB_EINVAL;
     if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
@@ -747,9 +747,15 @@ int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets, size_
     if (blocks > (g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID)) blocks = g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_mark5b_locate, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
-                       (const uint8_t *)d_buf, (uint64_t)nbytes, d_offsets, (uint64_t)cap, d_count);
+                       (const uint8_t *)d_buf, (uint64_t)nbytes, w1_pattern, w1_mask, d_offsets, (uint64_t)cap, d_count);
     BB_HIP(hipGetLastError());
     return BB_OK;
+}
+
+int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets, size_t cap,
+                     unsigned long long *d_count, void *stream)
+{
+    return bb_mark5b_locate_stream(d_buf, nbytes, 0u, 0u, d_offsets, cap, d_count, stream);
 }
 
 int bb_verify_records(const bb_frame_rec *d_recs, size_t nrecs, int32_t first_index,

@@ -433,15 +433,21 @@ __device__ __forceinline__ bool bb_mark5b_crc_ok(uint32_t w2, uint32_t w3)
 // which is what the reference's _bad_frame recovery accepts
 // (base/base.py:1127-1219).  Matches are appended unordered.
 __global__ __launch_bounds__(BB_BLOCK)
-void k_mark5b_locate(const uint8_t *buf, uint64_t nbytes, int64_t *out, uint64_t cap,
-                     unsigned long long *count)
+void k_mark5b_locate(const uint8_t *buf, uint64_t nbytes, uint32_t w1_pattern, uint32_t w1_mask,
+                     int64_t *out, uint64_t cap, unsigned long long *count)
 {
     const uint64_t q_end = nbytes - BB_M5B_FRAME + 1;       // the sync word is the probe
     bb_locate_sweep(buf, nbytes, q_end, out, cap, count,
         [&](uint32_t v) { return v ^ 0xABADDEEDu; },
         [&](uint64_t pos) -> int64_t {
+            // (word 1 under the mask: the bits that are the same in every header of ONE stream --
+            // the user word, mark5b/header.py:70-73 -- here and one frame later, where the
+            // reference's locate_frames compares the whole pattern of header0 again)
+            if (w1_mask && ((bb_load_u32_any(buf, nbytes, pos + 4) ^ w1_pattern) & w1_mask)) return -1;
             const uint64_t next = pos + BB_M5B_FRAME;
             if (next + 4 <= nbytes && bb_load_u32_any(buf, nbytes, next) != 0xABADDEEDu) return -1;
+            if (w1_mask && next + 8 <= nbytes
+                && ((bb_load_u32_any(buf, nbytes, next + 4) ^ w1_pattern) & w1_mask)) return -1;
             if (!bb_mark5b_crc_ok(bb_load_u32_any(buf, nbytes, pos + 8),
                                   bb_load_u32_any(buf, nbytes, pos + 12))) return -1;
             return (int64_t)pos;

@@ -387,11 +387,14 @@ def _collect_offsets(launch, dbuf, cap, where):
     return torch.sort(offs[:n]).values
 
 
-def mark5b_locate(dbuf, nbytes):
-    """Byte-granular Mark 5B frame search -> sorted int64 device offsets."""
+def mark5b_locate(dbuf, nbytes, w1_pattern=0, w1_mask=0):
+    """Byte-granular Mark 5B frame search -> sorted int64 device offsets.  With a mask, word 1 of
+    the headers must agree with the pattern under it (the stream's user word)."""
     return _collect_offsets(
-        lambda offs, cap, count: lib.bb_mark5b_locate(_ptr(dbuf), nbytes, offs, cap, count, _stream(dbuf)),
-        dbuf, nbytes // 10016 + 16, 'bb_mark5b_locate')
+        lambda offs, cap, count: lib.bb_mark5b_locate_stream(_ptr(dbuf), nbytes, int(w1_pattern) & 0xffffffff,
+                                                             int(w1_mask) & 0xffffffff, offs, cap, count,
+                                                             _stream(dbuf)),
+        dbuf, nbytes // 10016 + 16, 'bb_mark5b_locate_stream')
 
 
 def mark5b_scan_at(dbuf, nbytes, offsets, ref_seconds, ref_frame_nr, frame_rate):

@@ -234,6 +234,7 @@ class Mark4StreamReader(GPUStreamReaderBase):
         self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
         self._located = (offs, recs)
         self._relocated = True
+        self._note_damage(self._resident[1])
 
     def _maps(self):
         """(sign bits, magnitude bits, selected?) for the decode kernel."""
@@ -248,6 +249,7 @@ class Mark4StreamReader(GPUStreamReaderBase):
         if self._resident is None:
             return super()._read_sets(first, last, into)
         dev, src = self._resident
+        self._warn_damage(first, last)
         sign, mag, select = self._maps()
         flat = kernels.decode_mark4(
             dev, last - first, self._ntrack, 20000, sign, mag,

@@ -195,18 +195,21 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         kernels.require_gpu()
         image = self._image()
         dev, n = self._whole_file_in_hbm(), len(image)
-        offs = kernels.mark5b_locate(dev, n)
+        pattern, mask = self.header0.invariant_pattern()        # (sync word, and the user bits of word 1)
+        offs = kernels.mark5b_locate(dev, n, int(pattern[1]), int(mask[1]))
         recs = kernels.mark5b_scan_at(dev, n, offs, self._ref_seconds,
                                       self.header0['frame_nr'], self._frame_rate)
         nsets = self._nsample // self.samples_per_frame
         self._resident = (dev, kernels.build_index(recs, nsets, 1, None))
         self._located = (offs, recs)
         self._relocated = True
+        self._note_damage(self._resident[1])
 
     def _read_sets(self, first, last, into=None):
         if self._resident is None:
             return super()._read_sets(first, last, into)
         dev, src = self._resident
+        self._warn_damage(first, last)
         flat = kernels.decode_frames(
             dev, last - first, 10000, _lib.CODER_MARK5B, self.bps,
             chunk=self._unsliced_shape[0], nslot=1,

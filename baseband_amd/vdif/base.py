@@ -36,9 +36,11 @@ class VDIFFileReader(VLBIFileReaderBase):
             thread_ids = self.get_thread_ids()
         nframes = len(self.image()) / header0.frame_nbytes
         nsets = nframes / len(thread_ids)
+        notes = {} if nsets % 1 == 0 else {
+            'number_of_framesets': 'file contains non-integer number ({}) of framesets'.format(nsets)}
         return {'edv': header0.edv, 'thread_ids': thread_ids,
                 'number_of_framesets': int(nsets) if nsets % 1 == 0 else None,
-                '_sample_shape': (len(thread_ids), header0.nchan)}
+                '_sample_shape': (len(thread_ids), header0.nchan), '_warnings': notes}
 
     def read_header(self, edv=None, verify=True):
         return VDIFHeader.fromfile(self.fh_raw, edv=edv, verify=verify)
@@ -279,6 +281,76 @@ class VDIFStreamReader(GPUStreamReaderBase):
                 first = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
                 lost = (c - c[first]) > 0
                 recs[:, 3] = torch.where(lost, recs[:, 3] & ~(_lib.FRAME_OK << 16), recs[:, 3])
+        # The reference collects the frames of a set one after the other (vdif/base.py:655-712).
+        # When a frame cannot be read it searches for the next header from the end of the
+        # header before; a header found that way -- not where the next frame was due -- ends the
+        # set when its frame number is another one; frames of the set that follow it are not
+        # used.  A header that stands where it is due ends the set when it can be read as a
+        # frame of another set, and is stepped over when its seconds make no sense (its read
+        # fails, the search from there finds the header after it).
+        if offs.numel() > 2:
+            t = recs[:, 2].to(torch.int64)
+            n = t.numel()
+            o64 = offs.to(torch.int64)
+            run_start = torch.ones(n, dtype=torch.bool, device=t.device)
+            run_start[1:] = t[1:] != t[:-1]
+            run_id = torch.cumsum(run_start.to(torch.int64), 0) - 1
+            top = len(image) // self._set_nbytes + 2
+            valid = (t >= 0) & (t < top)
+            first_run = torch.full((top,), n, dtype=torch.int64, device=t.device)
+            first_run.scatter_reduce_(0, t[valid], run_id[valid], 'amin')
+            resumed = valid & (run_id > first_run[t.clamp(0, top - 1)])
+            if bool(resumed.any()):
+                starts = torch.nonzero(run_start)[:, 0]
+                ends = torch.cat([starts[1:], torch.tensor([n], device=t.device)])
+                before = (run_id - 1).clamp(min=0)
+                p_ = starts[before]                                  # first record of the run in between
+                single = (ends[before] - p_) == 1
+                due = o64[p_] == o64[(p_ - 1).clamp(min=0)] + self._frame_nbytes
+                apart = t[p_] - t
+                senseless = (apart <= -self._frame_rate) | (apart >= 2 * self._frame_rate)
+                word1 = dev[(o64 + 4)[:, None] + torch.arange(4, device=dev.device)].to(torch.int64)
+                frame_nr = (word1[:, 0] | (word1[:, 1] << 8) | (word1[:, 2] << 16))
+                same_nr = frame_nr[p_] == frame_nr
+                lost = resumed & ~(single & ((~due & same_nr) | (due & senseless)))
+                recs[:, 3] = torch.where(lost, recs[:, 3] & ~(_lib.FRAME_OK << 16), recs[:, 3])
+        # Two more of the reference's habits.  A thread that shows up twice in one set is
+        # discarded, both times (vdif/base.py:700-705).  And a damaged set is taken from the
+        # first header that has a header one frame before it (the backward search for the start
+        # of the set insists on that, vdif/base.py:576-612): frames of the set in front of it
+        # whose predecessor is gone are not used -- unless the set before was damaged as well.
+        if offs.numel() > 1:
+            t = recs[:, 2].to(torch.int64)
+            n = t.numel()
+            o64 = offs.to(torch.int64)
+            top = len(image) // self._set_nbytes + 2
+            live = (((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0) & (t >= 0) & (t < top)
+            tc = t.clamp(0, top - 1)
+            key = tc * 1024 + (recs[:, 3] & 0x3ff).to(torch.int64)
+            seen = torch.zeros(top * 1024, dtype=torch.int64, device=t.device)
+            seen.scatter_add_(0, key[live], torch.ones_like(key[live]))
+            twice = live & (seen[key] > 1)
+            per_set = torch.zeros(top, dtype=torch.int64, device=t.device)
+            per_set.scatter_add_(0, tc[live & ~twice], torch.ones_like(tc[live & ~twice]))
+            damaged = per_set[tc] < len(self._file_threads)
+            at = torch.searchsorted(o64, o64 - self._frame_nbytes).clamp(max=n - 1)
+            follows = (o64[at] == o64 - self._frame_nbytes) | (o64 < self._file_offset0 + self._frame_nbytes)
+            order = torch.argsort(tc, stable=True)
+            f_sorted = (follows & live)[order].to(torch.int64)
+            cs = torch.cumsum(f_sorted, 0)
+            g = tc[order]
+            head = torch.ones(n, dtype=torch.bool, device=t.device)
+            head[1:] = g[1:] != g[:-1]
+            base = torch.cummax(torch.where(head, cs - f_sorted, torch.zeros_like(cs)), 0).values
+            none_before = torch.empty(n, dtype=torch.bool, device=t.device)
+            none_before[order] = (cs - f_sorted - base) == 0
+            # (when the set before was damaged too, the reference arrives at this one by the
+            # header it ran into at the end of that one, and takes it from there as it is)
+            before_whole = torch.ones(top, dtype=torch.bool, device=t.device)
+            before_whole[1:] = per_set[:-1] >= len(self._file_threads)
+            front = live & damaged & before_whole[tc] & ~follows & none_before
+            lost = twice | front
+            recs[:, 3] = torch.where(lost, recs[:, 3] & ~(_lib.FRAME_OK << 16), recs[:, 3])
         ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
         same = (recs[:, 3] & 0xffff) == h0['thread_id']
         sel = recs[:, 2][ok & same]
@@ -288,11 +360,78 @@ class VDIFStreamReader(GPUStreamReaderBase):
         self._nsample = nsets * self.samples_per_frame
         self._located = (offs, recs)
         self._relocated = True
+        self._note_damage(src, len(self._thread_ids))
+
+    def _verification_error(self, msg):
+        """The reference loads one frame set at a time from the fixed stride and stops at the first
+        it cannot complete: the file ends inside the set (EOFError), the next set begins before every
+        requested thread was seen (OSError, vdif/frame.py:436-475), or a complete set sits where
+        another was expected (ValueError, vdif/base.py:640-652).  The same walk over the header
+        table says which of the three this read would have met."""
+        try:
+            kind = self._first_problem_met()
+        except Exception:               # (a table that cannot be read as headers: the general answer)
+            kind = None
+        if kind == 'end':
+            return EOFError("the file ends inside a frame set. " + msg)
+        if kind == 'header':            # (bytes went missing: what stands at a frame boundary is no header)
+            return AssertionError("a header failed verification. " + msg)
+        if kind == 'threads':
+            return OSError("could not find all requested frames. " + msg)
+        return super()._verification_error(msg)
+
+    def _first_problem_met(self):
+        if self._asked is None:
+            return None
+        spf = self.samples_per_frame
+        first = self._asked[0] // spf
+        last = -(-(self._asked[0] + self._asked[1]) // spf)
+        hw = self.fh_raw._header_table(self.header0, offset=self._file_offset0)
+        per_set, nfr = len(self._file_threads), len(hw)
+        wanted = set(int(t) for t in self._thread_ids)
+
+        def is_header(words):
+            return not any(((int(w) ^ p_) & m_) for w, p_, m_ in zip(words, self._pattern, self._mask))
+        for k in range(first, last):
+            p = k * per_set
+            if p >= nfr:
+                return 'end'
+            if not is_header(hw[p]):
+                return 'header'
+            when = (int(hw[p, 0]) & 0x3fffffff, int(hw[p, 1]) & 0xffffff)
+            seen, j = set(), p
+            while j < nfr:
+                if not is_header(hw[j]):
+                    return 'header'
+                if (int(hw[j, 0]) & 0x3fffffff, int(hw[j, 1]) & 0xffffff) != when:
+                    break
+                seen.add((int(hw[j, 3]) >> 16) & 0x3ff)
+                j += 1
+                if wanted <= seen:
+                    break
+            if not wanted <= seen:
+                return 'end' if j >= nfr else 'threads'
+            index = (when[0] - self.header0['seconds']) * self._frame_rate + when[1] - self.header0['frame_nr']
+            if index != k:
+                return 'number'
+        return None
+
+    def _damage_message(self, k, missing):
+        # (the reference's two sentences, vdif/base.py:700-730)
+        if missing.all():
+            return ("problem loading frame set {}. The frame set seems to be missing altogether. "
+                    "All threads set to invalid.".format(k))
+        ids = [int(t) for t, gone in zip(self._thread_ids, missing) if gone]
+        return "problem loading frame set {}. Thread(s) {} missing; set to invalid.".format(k, ids)
+
+    def _slip_message(self, k, nbytes):
+        return "problem loading frame set {}. Stream off by {} bytes.".format(k, nbytes)
 
     def _read_sets(self, first, last, into=None):
         if self._resident is None:
             return super()._read_sets(first, last, into)
         dev, src = self._resident
+        self._warn_damage(first, last)
         h0 = self.header0
         nslot = len(self._thread_ids)
         nsets = last - first
@@ -315,44 +454,38 @@ class VDIFStreamReader(GPUStreamReaderBase):
     def _find_last_header(self):
         """Last header of header0's thread, searching backwards from the end
         of the file (vdif/base.py:492-517); HeaderNotFoundError if the last
-        two frame sets' worth of bytes hold none."""
+        two frame sets' worth of bytes hold none.  A file whose last whole
+        frame stands on the fixed stride is looked at through the table of
+        its headers; otherwise -- bytes went missing somewhere -- the search
+        is the reference's: byte by byte backwards over two frame sets, a
+        candidate counting only with headers one frame before and after it."""
         hw = self.fh_raw._header_table(self.header0)
         nfull = len(self._image()) // self._frame_nbytes
         look = 2 * len(self._file_threads) + 1
-        for k in range(min(nfull, len(hw)) - 1, max(-1, nfull - 1 - look), -1):
-            words = hw[k]
-            if ((int(words[3]) >> 16) & 0x3ff) != self.header0['thread_id']:
-                continue
-            if any(((int(w) ^ p) & m) for w, p, m in
-                   zip(words, self._pattern, self._mask)):
-                continue
-            return VDIFHeader(words, edv=self.header0.edv, verify=False)
-        # the fixed-stride positions hold no header (bytes went missing
-        # somewhere): search the tail byte by byte, like locate_frames going
-        # backwards (base/base.py:181-335; vdif/base.py:492-517)
-        image = self._image()
-        n = len(image)
-        lo = max(0, n - look * self._frame_nbytes)
-        tail = np.asarray(image[lo:n])
-        if len(tail) >= self.header0.nbytes:
-            win = np.lib.stride_tricks.sliding_window_view(tail, 4)
-            w2 = np.ascontiguousarray(win[8:]).view('<u4')[:, 0]      # word 2 at p + 8
-            cand = np.nonzero(((w2 ^ np.uint32(self._pattern[2]))
-                               & np.uint32(self._mask[2])) == 0)[0]
-            nw = self.header0.nbytes // 4
-            for p in cand[::-1]:
-                if lo + p + self._frame_nbytes > n:
-                    continue                    # incomplete frame
-                words = np.frombuffer(tail[p:p + 4 * nw].tobytes(), '<u4')
-                if any(((int(w) ^ pt) & m) for w, pt, m in
-                       zip(words, self._pattern, self._mask)):
-                    continue
+
+        def is_header(words):
+            return not any(((int(w) ^ p) & m) for w, p, m in zip(words, self._pattern, self._mask))
+        last = min(nfull, len(hw)) - 1
+        if last >= 0 and is_header(hw[last]):
+            for k in range(last, max(-1, nfull - 1 - look), -1):
+                words = hw[k]
                 if ((int(words[3]) >> 16) & 0x3ff) != self.header0['thread_id']:
                     continue
+                if not is_header(words):
+                    continue
+                return VDIFHeader(words, edv=self.header0.edv, verify=False)
+        image = self._image()
+        nw = self.header0.nbytes // 4
+        with self.fh_raw.temporary_offset(max(0, len(image) - self._frame_nbytes)):
+            found = self.fh_raw.locate_frames(self.header0, forward=False, maximum=2 * self._set_nbytes,
+                                              check=(-1, 1))
+        for p in found:
+            words = np.frombuffer(np.asarray(image[p:p + 4 * nw]).tobytes(), '<u4')
+            if ((int(words[3]) >> 16) & 0x3ff) == self.header0['thread_id']:
                 return VDIFHeader(words, edv=self.header0.edv, verify=False)
         raise HeaderNotFoundError(
             "corrupt VDIF? No thread_id={0} frame in last {1} bytes."
-            .format(self.header0['thread_id'], look * self._frame_nbytes))
+            .format(self.header0['thread_id'], 2 * self._set_nbytes))
 
     def _squeeze_and_subset(self, data):
         # threads were already selected on read (vdif/base.py:519-528)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define BB_ABI_VERSION 5   /* 5 (round 6): bb_arena_stats grew (first_probe_gbps .. second_chance_wins) */   /* 4 (round 5): bb_arena_prepare, bb_arena_owns, bb_arena_stats grew (va_ranges .. prepare_wait_ms); the `reserved` words of the scan parameter blocks got meanings whose zero is the old behaviour (bb_vdif_scan_params.set_nframes, bb_mark5b_/bb_mark4_scan_params.by_position): same layout  */   /* 3 (round 4): bb_copy_frames; bb_arena_stats grew va_reserved / va_used; bb_tune knobs are thread-local */   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
+#define BB_ABI_VERSION 6   /* 6 (round 6): bb_mark5b_locate_stream */   /* 5 (round 6): bb_arena_stats grew (first_probe_gbps .. second_chance_wins) */   /* 4 (round 5): bb_arena_prepare, bb_arena_owns, bb_arena_stats grew (va_ranges .. prepare_wait_ms); the `reserved` words of the scan parameter blocks got meanings whose zero is the old behaviour (bb_vdif_scan_params.set_nframes, bb_mark5b_/bb_mark4_scan_params.by_position): same layout  */   /* 3 (round 4): bb_copy_frames; bb_arena_stats grew va_reserved / va_used; bb_tune knobs are thread-local */   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
 
 /* error codes (negative errno values) */
 #define BB_OK        0
@@ -204,6 +204,13 @@ int bb_mark5b_scan(const void *d_buf, size_t nbytes,
  */
 int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets,
                      size_t cap, unsigned long long *d_count, void *stream);
+/* ... for ONE stream: word 1 of the header must also agree with `w1_pattern` under
+ * `w1_mask` (the bits header0.invariant_pattern() marks in that word: the user
+ * word, mark5b/header.py:70-73), at p and -- when it still fits -- one frame
+ * later, as the stream reader's searches do, which hand header0 to locate_frames
+ * (base/base.py:1083-1219).  w1_mask = 0: bb_mark5b_locate. */
+int bb_mark5b_locate_stream(const void *d_buf, size_t nbytes, uint32_t w1_pattern, uint32_t w1_mask,
+                            int64_t *d_offsets, size_t cap, unsigned long long *d_count, void *stream);
 int bb_mark5b_scan_at(const void *d_buf, size_t nbytes,
                       const bb_mark5b_scan_params *params,
                       const int64_t *d_offsets, size_t nframes,

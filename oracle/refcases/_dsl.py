@@ -94,9 +94,11 @@ def file_(as_, path, mode='rb'):
     return {'op': 'file', 'as': as_, 'path': path, 'mode': mode, 'quiet': True}
 
 
-def call(as_, fn, *args, quiet=None, msg=None, any_warns=None, exact_exc=None, **kw):
+def call(as_, fn, *args, quiet=None, msg=None, any_warns=None, exact_exc=None, some_warns=None,
+         we_may_manage=None, **kw):
     return _opts({'op': 'call', 'as': as_, 'fn': fn, 'args': list(args), 'kw': kw},
-                 dict(quiet=quiet, msg=msg, any_warns=any_warns, exact_exc=exact_exc))
+                 dict(quiet=quiet, msg=msg, any_warns=any_warns, exact_exc=exact_exc, some_warns=some_warns,
+                      we_may_manage=we_may_manage))
 
 
 def do(fn, *args, **kw):

@@ -52,9 +52,11 @@ def test_missing_frames_and_bytes(case, tmp_path):
         s, t = divmod(idx, 8)
         want[s * 20000:(s + 1) * 20000, t] = 0.
     assert bits_equal(got, want)
-    # verify=True refuses instead of repairing
+    # verify=True refuses instead of repairing -- with the exception of the first problem the
+    # reference's set-by-set loop would meet (which one for which damage:
+    # tests/golden/refcases/damaged_streams.json)
     with vdif.open(str(p), 'rs', squeeze=False, verify=True) as fh:
-        with pytest.raises(ValueError):
+        with pytest.raises((ValueError, OSError, EOFError, AssertionError)):
             fh.read()
 
 
@@ -175,6 +177,21 @@ def test_mark5b_locate_kernel(tmp_path):
     at = torch.tensor([0, 10016, 20032, 30047], dtype=torch.int64, device='cuda')
     recs = kernels.recs_fields(kernels.mark5b_scan_at(dbuf, len(blob), at, 0, 0, 0))
     assert recs['payload_offset'].tolist() == [16, 10032, 20048, 30063]
+
+
+def test_mark5b_locate_for_one_stream():
+    """bb_mark5b_locate_stream: word 1 under the mask (the user bits) has to agree with the
+    stream's, in the frame and in the one after it -- what the reference's searches compare when
+    they are handed header0 (recorded: tests/golden/refcases/damaged_streams.json,
+    mark5b_byte_losses_swept, word 1 of a header lost)."""
+    from baseband_amd import kernels
+    blob = load_file('samples/sample.m5b').copy()
+    user = int(blob[4:8].view('<u4')[0]) & 0xffff0000
+    blob[2 * 10016 + 6] ^= 0x5a                          # user word of frame 2 changed in place
+    dbuf = kernels.to_device_bytes(np.concatenate([blob, np.zeros(8, np.uint8)]))
+    assert kernels.mark5b_locate(dbuf, len(blob)).cpu().numpy().tolist() == [0, 10016, 20032, 30048]
+    # frame 1 is followed by a header of another stream, frame 2 is one
+    assert kernels.mark5b_locate(dbuf, len(blob), user, 0xffff0000).cpu().numpy().tolist() == [0, 30048]
 
 
 def test_mark4_locate_kernel():
