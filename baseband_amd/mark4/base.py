@@ -223,6 +223,7 @@ class Mark4StreamReader(GPUStreamReaderBase):
         image = self._image()
         dev, n = self._whole_file_in_hbm(), len(image)
         offs = kernels.mark4_locate(dev, n, self._ntrack)
+        offs = self._of_this_stream(dev, n, offs)
         recs = kernels.mark4_scan_at(dev, n, offs, self._ntrack, self.header0.year,
                                      self._ref_qms, self._frame_qms)
         ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
@@ -235,6 +236,36 @@ class Mark4StreamReader(GPUStreamReaderBase):
         self._located = (offs, recs)
         self._relocated = True
         self._note_damage(self._resident[1])
+
+    def _of_this_stream(self, dev, n, offs):
+        """Of the located frames (sync pattern here and one frame later) those whose headers
+        also carry what every header of THIS stream carries -- head stacks, track roll, system id
+        (mark4/header.py:144-154) -- here and, where it fits, one frame later: the reader's
+        searches hand header0 to locate_frames (base/base.py:1127-1219), which compares all of
+        its invariant bits at the candidate and at the check positions."""
+        if not offs.numel():
+            return offs
+        pattern, mask = self.header0.invariant_pattern()
+        pb = np.ascontiguousarray(pattern).view(np.uint8)
+        mb = np.ascontiguousarray(mask).view(np.uint8)
+        used = np.nonzero(mb)[0]
+        lo, hi = int(used[0]), int(used[-1]) + 1
+        pb = torch.from_numpy(pb[lo:hi].copy()).to(dev.device)
+        mb = torch.from_numpy(mb[lo:hi].copy()).to(dev.device)
+        span = torch.arange(lo, hi, device=dev.device)
+        flat = dev.reshape(-1).view(torch.uint8)
+
+        def agrees(pos):
+            out = torch.empty(pos.numel(), dtype=torch.bool, device=dev.device)
+            for a in range(0, pos.numel(), 1 << 14):            # (bounded gathers)
+                at = pos[a:a + (1 << 14), None] + span
+                out[a:a + (1 << 14)] = (((flat[at.clamp(max=flat.numel() - 1)] ^ pb) & mb) == 0).all(dim=1)
+            return out
+        o64 = offs.to(torch.int64)
+        after = o64 + self._set_nbytes
+        fits = after + hi <= n
+        keep = agrees(o64) & (~fits | agrees(torch.where(fits, after, o64)))
+        return offs[keep]
 
     def _maps(self):
         """(sign bits, magnitude bits, selected?) for the decode kernel."""

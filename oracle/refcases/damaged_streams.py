@@ -37,6 +37,12 @@ M5B_SWEEP = ((5 * M5B, 5 * M5B + 1), (5 * M5B + 2, 5 * M5B + 4), (5 * M5B + 4, 5
              (10 * M5B + 16, 10 * M5B + 20), (11 * M5B + 500, 11 * M5B + 504), (1 * M5B + 20, 1 * M5B + 24),
              (0 * M5B + 5000, 0 * M5B + 5004))
 
+M4B = 160000
+M4_SWEEP = ((3 * M4B, 3 * M4B + 8), (3 * M4B + 500, 3 * M4B + 508), (3 * M4B + 640, 3 * M4B + 1280),
+            (3 * M4B + 5000, 3 * M4B + 5016), (3 * M4B + 159992, 3 * M4B + 160008), (3 * M4B + 80000, 4 * M4B + 80000),
+            (2 * M4B + 100, 4 * M4B + 50), (6 * M4B + 1000, 6 * M4B + 1008), (7 * M4B + 3000, 7 * M4B + 3008),
+            (1 * M4B + 768, 1 * M4B + 776))
+
 GIVES_UP = (34 * FB + 8, 34 * FB + 12)   # word 2 of a header: the reference finds no header nearby and raises
 
 VDIF_MISSING = ([5], [8], [15], [47], [7, 8], [8, 9, 10, 11, 12, 13, 14, 15], [10, 11, 30], [16, 17, 18, 19, 20, 21, 22, 23, 24],
@@ -164,6 +170,28 @@ CASES = [
            open_('f', 'mark5b', T('s%d.m5b' % k), 'rs', sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2), get('f.shape'),
            call(None, 'f.read', some_warns=True), close('f')]
           for k, (lo, hi) in enumerate(M5B_SWEEP)]),
+
+    case('mark4_frames_and_bytes_missing',
+         'eight Mark 4 frames (64 tracks, written from the two of the sample) with whole frames and bytes '
+         'taken out: gaps filled, frames found again by the sync pattern in every track '
+         '(mark4/tests/test_mark4.py, test_corrupt_stream cases, positions widened)',
+         open_('fr', 'mark4', S('sample.m4'), 'rs', sample_rate=HZ(32e6), ntrack=64, decade=2010),
+         call('d', 'fr.read'),
+         open_('fw', 'mark4', T('base.m4'), 'ws', header0=V('fr.header0'), sample_rate=HZ(32e6)),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'),
+         close('fr'), digest(T('base.m4')),
+         [without(T('base.m4'), T('m%d.m4' % k), M4B, 8, miss)
+          + [open_('f', 'mark4', T('m%d.m4' % k), 'rs', sample_rate=HZ(32e6), ntrack=64, decade=2010),
+             get('f.shape'), get('f.start_time'), get('f.stop_time'),
+             call(None, 'f.read', some_warns=True, we_may_manage=True), close('f'),
+             open_('g', 'mark4', T('m%d.m4' % k), 'rs', sample_rate=HZ(32e6), ntrack=64, decade=2010, verify=True),
+             call(None, 'g.read', any_warns=True), close('g')]
+          for k, miss in enumerate(([1], [3, 4], [7], [0], [2, 5]))],
+         [[fn('a', 'file_bytes', T('base.m4'), 0, lo, quiet=True), fn('b', 'file_bytes', T('base.m4'), hi, None, quiet=True),
+           fn(None, 'write_file', T('s%d.m4' % k), [V('a'), V('b')]),
+           open_('f', 'mark4', T('s%d.m4' % k), 'rs', sample_rate=HZ(32e6), ntrack=64, decade=2010), get('f.shape'),
+           call(None, 'f.read', some_warns=True, we_may_manage=True), close('f')]
+          for k, (lo, hi) in enumerate(M4_SWEEP)]),
 
     case('mark5b_damage_inside_frames',
          'bytes lost inside a frame (the file is shorter by less than a frame) and a sync word overwritten '
