@@ -68,3 +68,35 @@ def test_runner_reduces_results_to_plain_data(tmp_path):
     again = casekit.Runner(Plain(), tmp_path).run([{'op': 'let', 'as': 'r', 'to': {'$rng': 7, 'shape': [5], 'levels': [-1.0, 1.0]}},
                                                    {'op': 'get', 'of': 'r'}])
     assert again[1] == out[7] and set(np.unique(out[7]['v']['head'])) <= {-1.0, 1.0}      # the same numbers under any numpy
+
+
+def test_the_two_looser_comparisons_are_no_looser_than_they_say():
+    """``some_warns`` compares whether there were warnings; ``we_may_manage`` accepts a result where
+    the reference raised -- and only that: another exception, or an exception where the reference
+    had none, is still reported."""
+    warned = {'v': 1, 'warns': [['UserWarning', 'a'], ['UserWarning', 'b']]}
+    st = [{'op': 'call', 'fn': 'f.read', 'some_warns': True}]
+    assert casekit.compare(st, [warned], [{'v': 1, 'warns': [['UserWarning', 'one only']]}]) == []
+    assert len(casekit.compare(st, [warned], [{'v': 1}])) == 1
+    assert len(casekit.compare(st, [{'v': 1}], [warned])) == 1
+    gave_up = {'raises': 'AssertionError', 'builtin': 'AssertionError', 'msg': 'Cannot find header nearby.'}
+    st = [{'op': 'call', 'fn': 'f.read', 'we_may_manage': True, 'some_warns': True}]
+    assert casekit.compare(st, [gave_up], [warned]) == []
+    assert casekit.compare(st, [gave_up], [dict(gave_up)]) == []
+    assert len(casekit.compare(st, [gave_up], [{'raises': 'OSError', 'builtin': 'OSError', 'msg': ''}])) == 1
+    assert len(casekit.compare(st, [{'v': 1}], [gave_up])) == 1
+    assert len(casekit.compare(st, [{'v': 1}], [{'v': 2}])) == 1
+
+
+def test_complex_arrays_travel_as_pairs(tmp_path):
+    class Plain(casekit.Universe):
+        def module(self, name):
+            raise KeyError(name)
+
+        def package_dirs(self):
+            return []
+    r = casekit.Runner(Plain(), tmp_path)
+    out = r.run([{'op': 'let', 'as': 'c', 'to': {'$array': [[[1.0, 2.0], [3.0, -4.0]]], 'dt': 'c8'}},
+                 {'op': 'get', 'of': 'c'}])
+    r.finish()
+    assert out[1]['v']['shape'] == [1, 2] and out[1]['v']['dtype'] == 'complex64'
