@@ -392,6 +392,23 @@ class VDIFStreamReader(GPUStreamReaderBase):
 
         def is_header(words):
             return not any(((int(w) ^ p_) & m_) for w, p_, m_ in zip(words, self._pattern, self._mask))
+        # (sets that stand whole on the fixed stride are skipped in one NumPy pass: the walk
+        # below starts at the first one that does not)
+        whole = min(last, nfr // per_set) - first
+        if whole > 0:
+            block = np.asarray(hw[first * per_set:(first + whole) * per_set]).reshape(whole, per_set, -1)
+            pat = np.asarray(self._pattern, dtype=np.uint32)
+            msk = np.asarray(self._mask, dtype=np.uint32)
+            sound = (((block ^ pat) & msk) == 0).all(axis=(1, 2))
+            sec = (block[:, :, 0] & 0x3fffffff).astype(np.int64)
+            nr = (block[:, :, 1] & 0xffffff).astype(np.int64)
+            index = (sec - self.header0['seconds']) * self._frame_rate + nr - self.header0['frame_nr']
+            sound &= (index == (first + np.arange(whole))[:, None]).all(axis=1)
+            thread = (block[:, :, 3] >> 16) & 0x3ff
+            for t_ in wanted:
+                sound &= (thread == t_).any(axis=1)
+            odd = np.nonzero(~sound)[0]
+            first = first + (int(odd[0]) if len(odd) else whole)
         for k in range(first, last):
             p = k * per_set
             if p >= nfr:

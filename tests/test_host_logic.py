@@ -1338,3 +1338,37 @@ def test_edv_2_and_3_headers_refuse_other_frame_lengths():
     with pytest.raises(AssertionError):
         h2.verify()
     VDIFHeader.fromvalues(samples_per_frame=20000, edv=2, **kw).verify()
+
+
+def test_which_problem_a_strict_vdif_read_meets_first():
+    """`verify=True` ends with the exception the reference's set-by-set loop meets first; the walk
+    over the table of headers that decides it (vdif/base.py `_first_problem_met`), on a table
+    with a frame gone, a set gone, a header overwritten and the last frame cut off."""
+    import types
+    from baseband_amd.vdif.base import VDIFStreamReader
+    from baseband_amd.vdif.header import VDIFHeader
+    h0 = VDIFHeader.fromvalues(edv=0, time=np.datetime64('2015-06-07T08:09:10'), nchan=1, bps=2, complex_data=False,
+                               thread_id=0, samples_per_frame=64, station='AA', frame_nr=0)
+    nsets, nthr = 50, 4
+    table = np.zeros((nsets * nthr, 8), np.uint32)
+    for k in range(nsets):
+        for t in range(nthr):
+            h = h0.copy()
+            h['frame_nr'], h['thread_id'] = k, t
+            table[k * nthr + t] = h.words
+    pattern, mask = h0.invariant_pattern()
+
+    def met(tab, asked=(0, nsets * 64)):
+        reader = types.SimpleNamespace(
+            _asked=asked, samples_per_frame=64, header0=h0, _file_offset0=0, _frame_rate=1000,
+            fh_raw=types.SimpleNamespace(_header_table=lambda h, offset=0: tab),
+            _file_threads=list(range(nthr)), _thread_ids=list(range(nthr)), _pattern=pattern, _mask=mask)
+        return VDIFStreamReader._first_problem_met(reader)
+    assert met(table) is None
+    assert met(np.delete(table, 30 * nthr + 2, axis=0)) == 'threads'
+    assert met(np.delete(table, 30 * nthr + 2, axis=0), asked=(0, 30 * 64)) is None     # (not reached)
+    assert met(np.delete(table, np.arange(20 * nthr, 21 * nthr), axis=0)) == 'number'
+    damaged = table.copy()
+    damaged[41 * nthr + 1, 2] ^= 0xffff
+    assert met(damaged) == 'header'
+    assert met(table[:-1]) == 'end'
