@@ -1337,7 +1337,12 @@ class GPUStreamReaderBase:
                     return False
                 warnings.warn(msg + "; affected samples were set to fill_value.")
             else:
-                raise self._verification_error(msg)
+                err = self._verification_error(msg)
+                if err is None and self._can_relocate:
+                    # (headers are off the fixed stride, yet the reference's loop would find every
+                    # frame this reader asks for: read through the index of located frames)
+                    return False
+                raise err if err is not None else ValueError("wrong frame number. " + msg)
         return True
 
     def _verification_error(self, msg):
@@ -1384,7 +1389,7 @@ class GPUStreamReaderBase:
         complete set is not where the sets read so far put it: at the first set of the read
         whatever the difference, further on when it is not a whole number of frames (bytes
         went missing; whole missing frames are accounted for by the message of their set)."""
-        if self._damage is None:
+        if self._damage is None or self.verify is True:     # (a strict reader raises or is silent)
             return
         notes = []
         sets, rows = self._damage

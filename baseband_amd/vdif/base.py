@@ -371,30 +371,37 @@ class VDIFStreamReader(GPUStreamReaderBase):
         try:
             kind = self._first_problem_met()
         except Exception:               # (a table that cannot be read as headers: the general answer)
-            kind = None
+            kind = 'number'
+        return self._strict_error(kind, msg)
+
+    def _strict_error(self, kind, msg):
+        if kind is None:
+            return None
         if kind == 'end':
             return EOFError("the file ends inside a frame set. " + msg)
         if kind == 'header':            # (bytes went missing: what stands at a frame boundary is no header)
             return AssertionError("a header failed verification. " + msg)
         if kind == 'threads':
             return OSError("could not find all requested frames. " + msg)
-        return super()._verification_error(msg)
+        return ValueError("wrong frame number. " + msg)
 
-    def _first_problem_met(self):
-        if self._asked is None:
-            return None
-        spf = self.samples_per_frame
-        first = self._asked[0] // spf
-        last = -(-(self._asked[0] + self._asked[1]) // spf)
+    def _first_problem_met(self, first=None, last=None):
+        if first is None:
+            if self._asked is None:
+                return None
+            spf = self.samples_per_frame
+            first = self._asked[0] // spf
+            last = -(-(self._asked[0] + self._asked[1]) // spf)
         hw = self.fh_raw._header_table(self.header0, offset=self._file_offset0)
         per_set, nfr = len(self._file_threads), len(hw)
+        nfit = (len(self._image()) - self._file_offset0) // self._frame_nbytes    # frames that are there whole
         wanted = set(int(t) for t in self._thread_ids)
 
         def is_header(words):
             return not any(((int(w) ^ p_) & m_) for w, p_, m_ in zip(words, self._pattern, self._mask))
         # (sets that stand whole on the fixed stride are skipped in one NumPy pass: the walk
         # below starts at the first one that does not)
-        whole = min(last, nfr // per_set) - first
+        whole = min(last, nfit // per_set) - first
         if whole > 0:
             block = np.asarray(hw[first * per_set:(first + whole) * per_set]).reshape(whole, per_set, -1)
             pat = np.asarray(self._pattern, dtype=np.uint32)
@@ -422,7 +429,12 @@ class VDIFStreamReader(GPUStreamReaderBase):
                     return 'header'
                 if (int(hw[j, 0]) & 0x3fffffff, int(hw[j, 1]) & 0xffffff) != when:
                     break
-                seen.add((int(hw[j, 3]) >> 16) & 0x3ff)
+                thread = (int(hw[j, 3]) >> 16) & 0x3ff
+                if thread in wanted and thread in seen:     # (a thread again: the set is over, vdif/frame.py:209)
+                    break
+                if thread in wanted and j >= nfit:          # (its payload is cut short)
+                    return 'end'
+                seen.add(thread)
                 j += 1
                 if wanted <= seen:
                     break
@@ -448,6 +460,11 @@ class VDIFStreamReader(GPUStreamReaderBase):
         if self._resident is None:
             return super()._read_sets(first, last, into)
         dev, src = self._resident
+        if self.verify is True:         # (strict: every read answers for the sets it covers)
+            err = self._strict_error(self._first_problem_met(first, last),
+                                     "problem loading frame set in {}..{}".format(first, last - 1))
+            if err is not None:
+                raise err
         self._warn_damage(first, last)
         h0 = self.header0
         nslot = len(self._thread_ids)

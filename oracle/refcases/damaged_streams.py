@@ -71,6 +71,24 @@ CASES = [
              get('b.info.number_of_framesets'), close('b')]
           for k, miss in enumerate(VDIF_MISSING)]),
 
+    case('vdif_frames_missing_and_a_subset',
+         'a reader of some threads only meets only the holes in those: threads 1 and 5 of files that lack '
+         'thread 5 of set 0, thread 0 of set 1, a whole set; the pieces read into a caller\'s array; a strict '
+         'reader of thread 3 alone reads what is whole for it.  (Behind a hole the reference, reading some '
+         'threads only, warns "problem loading frame set k." for every other set, without saying what about; '
+         'this package names the sets that lack a thread that was asked for -- warnings not compared here) '
+         '(vdif/tests/test_vdif.py, missing frames with subset)',
+         open_('fr', 'vdif', S('sample.vdif'), 'rs'), call('d', 'fr.read'),
+         open_('fw', 'vdif', T('base.vdif'), 'ws', header0=V('fr.header0'), nthread=8),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'), close('fr'),
+         [without(T('base.vdif'), T('m%d.vdif' % k), FB, 48, miss)
+          + [open_('f', 'vdif', T('m%d.vdif' % k), 'rs', subset=[1, 5]), get('f.shape'), get('f.sample_shape'),
+             call(None, 'f.read', any_warns=True), do('f.seek', 19990), let('o', ZEROS((20, 2), 'f4')),
+             call(None, 'f.read', out=V('o'), quiet=True, any_warns=True), get('o'), close('f'),
+             open_('g', 'vdif', T('m%d.vdif' % k), 'rs', subset=TUP(3), verify=True), get('g.shape'),
+             call(None, 'g.read', any_warns=True), close('g')]
+          for k, miss in enumerate(([5], [8], [8, 9, 10, 11, 12, 13, 14, 15], [11, 21]))]),
+
     case('vdif_bytes_missing',
          'bytes lost inside a payload and inside a header, in the second half of the file (with a loss in the '
          'first three sets the reference does not open the file at all, and after one in the first word of a '

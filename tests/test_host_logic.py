@@ -1358,9 +1358,10 @@ def test_which_problem_a_strict_vdif_read_meets_first():
             table[k * nthr + t] = h.words
     pattern, mask = h0.invariant_pattern()
 
-    def met(tab, asked=(0, nsets * 64)):
+    def met(tab, asked=(0, nsets * 64), cut=0):
         reader = types.SimpleNamespace(
             _asked=asked, samples_per_frame=64, header0=h0, _file_offset0=0, _frame_rate=1000,
+            _frame_nbytes=h0.frame_nbytes, _image=lambda: np.zeros(len(tab) * h0.frame_nbytes - cut, np.uint8),
             fh_raw=types.SimpleNamespace(_header_table=lambda h, offset=0: tab),
             _file_threads=list(range(nthr)), _thread_ids=list(range(nthr)), _pattern=pattern, _mask=mask)
         return VDIFStreamReader._first_problem_met(reader)
@@ -1372,3 +1373,4 @@ def test_which_problem_a_strict_vdif_read_meets_first():
     damaged[41 * nthr + 1, 2] ^= 0xffff
     assert met(damaged) == 'header'
     assert met(table[:-1]) == 'end'
+    assert met(table, cut=1) == 'end'               # (the last payload a byte short)
