@@ -327,9 +327,10 @@ class VDIFStreamReader(GPUStreamReaderBase):
             live = (((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0) & (t >= 0) & (t < top)
             tc = t.clamp(0, top - 1)
             key = tc * 1024 + (recs[:, 3] & 0x3ff).to(torch.int64)
-            seen = torch.zeros(top * 1024, dtype=torch.int64, device=t.device)
-            seen.scatter_add_(0, key[live], torch.ones_like(key[live]))
-            twice = live & (seen[key] > 1)
+            twice = torch.zeros(n, dtype=torch.bool, device=t.device)
+            if bool(live.any()):
+                _, back, times = torch.unique(key[live], return_inverse=True, return_counts=True)
+                twice[live] = times[back] > 1
             per_set = torch.zeros(top, dtype=torch.int64, device=t.device)
             per_set.scatter_add_(0, tc[live & ~twice], torch.ones_like(tc[live & ~twice]))
             damaged = per_set[tc] < len(self._file_threads)
