@@ -350,3 +350,59 @@ def test_gather_64_threads_large():
                 continue
             raw = image[s[fset, t]:s[fset, t] + pn].cpu().numpy()
             assert np.array_equal(got_t.view(np.uint32), orc.decode_flat(raw, 'vdif', 2).view(np.uint32)), (fset, t)
+
+
+def test_damaged_gigabyte_through_the_located_frame_index():
+    """1 GiB of 8-thread VDIF (16,384 frame sets) with a frame, a whole set and forty bytes of a
+    payload taken out, opened from the device image and read with the default repair: the
+    frame-set rules of the index (tests/golden/refcases/damaged_streams.json pins them on six-set
+    files against the reference) at a size where their tensors count -- exactly the frames that
+    are gone come back as fill, frames either side of every hole decode as the oracle decodes
+    their bytes, every hole is named, and the search plus the read stay within seconds."""
+    import time
+    import warnings
+    import torch
+    import bench
+    from baseband_amd import vdif
+    dev = torch.device('cuda')
+    nthread, nsets = 8, 16384
+    fn = bench.FRAME_NBYTES
+    image, h0 = bench.make_file_image_on_device(nsets, 99, 0, dev, nthread=nthread, order=tuple(range(nthread)))
+    flat = image.view(torch.uint8).reshape(-1)
+    keep = torch.ones(flat.numel(), dtype=torch.bool, device=dev)
+    one = (5000 * nthread + 3) * fn                       # thread 3 of set 5000
+    keep[one:one + fn] = False
+    keep[9000 * nthread * fn:9001 * nthread * fn] = False  # all of set 9000
+    cut = (12000 * nthread + 5) * fn + 4000               # forty bytes inside the payload of thread 5, set 12000
+    keep[cut:cut + 40] = False
+    damaged = flat[keep].contiguous()
+    del keep
+    rate = bench.FRAME_RATE * bench.SPF
+    t0 = time.perf_counter()
+    with vdif.open(damaged, 'rs', sample_rate=rate, squeeze=False) as fh:
+        assert fh.shape[0] == nsets * bench.SPF
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            out = fh.read()
+        torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 30.
+    said = [str(c.message) for c in caught]
+    assert any('frame set 5000. Thread(s) [3] missing' in s for s in said), said
+    assert any('frame set 9000. The frame set seems to be missing altogether' in s for s in said), said
+    assert any('frame set 12000.' in s and '[5]' in s for s in said), said
+    sets = out.reshape(nsets, bench.SPF, nthread)
+    gone = {(5000, 3), (12000, 5)} | {(9000, t) for t in range(nthread)}
+    for k, t in gone:
+        assert float(sets[k, :, t].abs().max()) == 0.0, (k, t)
+    # nothing else is fill: every other (set, thread) of the damaged sets and their neighbours
+    # equals the oracle's decode of its payload in the intact image
+    frames = flat.view(nsets, nthread, fn)
+    for k in (4999, 5000, 5001, 8999, 9001, 11999, 12000, 12001, nsets - 1):
+        for t in range(nthread):
+            if (k, t) in gone:
+                continue
+            want = orc.decode_flat(frames[k, t, 32:].cpu().numpy(), 'vdif', 2)
+            got = sets[k, :, t].cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (k, t)
+    # a census over everything: exactly the eleven missing frames are zero
+    assert int((out == 0).sum().item()) == len(gone) * bench.SPF
