@@ -31,7 +31,7 @@
  * other) and the
  * fastest stays.  The DEFAULT (BB_ARENA_TRIES unset or 0; round 6) is one
  * candidate, and up to BB_ARENA_MAX_CANDIDATES = 3 in all while the best so far
- * probes below BB_ARENA_RETRY_BELOW_GBPS = 6000 and the first one's memory was
+ * probes below BB_ARENA_RETRY_BELOW_GBPS = 6300 and the first one's memory was
  * cheap to create (under BB_ARENA_CHEAP_MS_PER_GIB = 3 ms per GiB: the driver is
  * not in the middle of wiping freed pages); the fastest stays (`first_probe_gbps`,
  * `second_chances`, `second_chance_wins`, `probe_history` in the statistics).
