@@ -1374,3 +1374,44 @@ def test_which_problem_a_strict_vdif_read_meets_first():
     assert met(damaged) == 'header'
     assert met(table[:-1]) == 'end'
     assert met(table, cut=1) == 'end'               # (the last payload a byte short)
+
+
+def test_reads_through_the_index_name_their_holes_once_per_read():
+    """`_warn_damage`: every read that covers a set with frames missing says so; a complete set that is
+    not where the sets read so far put it is reported when a read STARTS there, or -- further into a
+    read -- when the difference is not a whole number of frames; what was reported is known from then
+    on; a strict reader is silent."""
+    import types
+    import warnings
+    from baseband_amd.base.base import GPUStreamReaderBase as Base
+    from baseband_amd.vdif.base import VDIFStreamReader
+    whole = np.ones(10, bool)
+    whole[[2, 6]] = False
+    slip = np.zeros(10, np.int64)
+    slip[3:] = -5032            # a frame is gone in set 2: what follows lies one frame earlier
+    slip[7:] = -5032 - 40       # forty bytes are gone in set 6
+    reader = types.SimpleNamespace(
+        _damage=(np.array([2, 6]), np.array([[False, True, False, False], [False, False, True, True]])),
+        _slips=(whole, slip, np.zeros(10, bool)), verify='fix', damage_warnings_per_read=16,
+        _frame_nbytes=5032, _set_nbytes=4 * 5032, _thread_ids=[0, 1, 2, 3])
+    reader._damage_message = lambda k, m: VDIFStreamReader._damage_message(reader, k, m)
+    reader._slip_message = lambda k, n: VDIFStreamReader._slip_message(reader, k, n)
+
+    def said(first, last):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            Base._warn_damage(reader, first, last)
+        return [str(x.message) for x in w]
+    assert said(0, 2) == []
+    # random access behind the first hole: the set is a frame early
+    assert said(4, 5) == ['problem loading frame set 4. Stream off by 5032 bytes.']
+    assert said(4, 6) == []                                         # (known now)
+    # a read over everything: both holes by name, the byte loss where it is first seen; the whole
+    # frame lost in set 2 is accounted for by that set's message
+    assert said(0, 10) == ['problem loading frame set 2. Thread(s) [1] missing; set to invalid.',
+                           'problem loading frame set 6. Thread(s) [2, 3] missing; set to invalid.',
+                           'problem loading frame set 7. Stream off by 40 bytes.']
+    assert said(0, 10) == ['problem loading frame set 2. Thread(s) [1] missing; set to invalid.',
+                           'problem loading frame set 6. Thread(s) [2, 3] missing; set to invalid.']
+    reader.verify = True
+    assert said(0, 10) == []
