@@ -85,9 +85,9 @@ def _opts(d, o):
     return d
 
 
-def open_(as_, fmt, *args, quiet=None, msg=None, msg_has=None, any_warns=None, **kw):
+def open_(as_, fmt, *args, quiet=None, msg=None, msg_has=None, any_warns=None, we_may_manage=None, **kw):
     return _opts({'op': 'open', 'as': as_, 'fmt': fmt, 'args': list(args), 'kw': kw},
-                 dict(quiet=quiet, msg=msg, msg_has=msg_has, any_warns=any_warns))
+                 dict(quiet=quiet, msg=msg, msg_has=msg_has, any_warns=any_warns, we_may_manage=we_may_manage))
 
 
 def file_(as_, path, mode='rb'):

@@ -67,5 +67,11 @@ CASES = [
          get('fy3.header0'), close('fy3'),
          open_('fq', 'mark4', T('q.m4'), 'ws', sample_rate=HZ(32e6), ntrack=48, fanout=4, nchan=8, bps=2,
                time=TIME('2014-06-16T07:38:12.4750')),
+         # (the reference has coders for five Mark 4 layouts; this package packs by bit maps and takes any)
+         open_('fq2', 'mark4', T('q2.m4'), 'ws', sample_rate=HZ(32e6), ntrack=64, fanout=2, nchan=16, bps=2,
+               time=TIME('2014-06-16T07:38:12.4750'), we_may_manage=True, quiet=True),
+         call('h16', 'vdif.VDIFHeader.fromvalues', edv=0, bps=16, nchan=2, complex_data=True, samples_per_frame=48,
+              station='aa', time=TIME('2015-01-01T00:00:00'), frame_rate=HZ(100.)),
+         call(None, 'vdif.VDIFPayload.fromdata', RNG(5, (48, 2), [-3.0, 0.0, 2.0], complex=True), V('h16')),
          close('fr')),
 ]
