@@ -43,6 +43,20 @@ M4_SWEEP = ((3 * M4B, 3 * M4B + 8), (3 * M4B + 500, 3 * M4B + 508), (3 * M4B + 6
             (2 * M4B + 100, 4 * M4B + 50), (6 * M4B + 1000, 6 * M4B + 1008), (7 * M4B + 3000, 7 * M4B + 3008),
             (1 * M4B + 768, 1 * M4B + 776))
 
+def _drawn(n, seed, nbytes=FB, first=26, span=20, nframe=48):
+    out, x = [], seed
+    for _ in range(n):
+        x = (x * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        start = first * nbytes + (x >> 20) % (span * nbytes)
+        x = (x * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        kind = (x >> 33) % 4
+        length = (1, 1 + (x >> 40) % 64, 1 + (x >> 40) % nbytes, nbytes + (x >> 40) % (3 * nbytes // 2))[kind]
+        out.append((start, min(start + length, nframe * nbytes)))
+    return tuple(out)
+
+
+RANDOM_LOSSES = _drawn(40, 20261003)
+
 GIVES_UP = (34 * FB + 8, 34 * FB + 12)   # word 2 of a header: the reference finds no header nearby and raises
 
 VDIF_MISSING = ([5], [8], [15], [47], [7, 8], [8, 9, 10, 11, 12, 13, 14, 15], [10, 11, 30], [16, 17, 18, 19, 20, 21, 22, 23, 24],
@@ -122,6 +136,44 @@ CASES = [
            call(None, 'f.read', **({'some_warns': True} if (lo, hi) != GIVES_UP else
                                    {'any_warns': True, 'we_may_manage': True})), close('f')]
           for k, (lo, hi) in enumerate(SWEEP)]),
+
+    case('vdif_losses_drawn_at_random',
+         'forty more losses in the second half of the same file, places and lengths drawn from a seeded '
+         'generator (1 byte to two and a half frames): shapes and repaired samples '
+         '(vdif/tests/test_vdif.py, TestCorruptSampleCopy, widened)',
+         open_('fr', 'vdif', S('sample.vdif'), 'rs'), call('d', 'fr.read'),
+         open_('fw', 'vdif', T('base.vdif'), 'ws', header0=V('fr.header0'), nthread=8),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'), close('fr'),
+         [[fn('a', 'file_bytes', T('base.vdif'), 0, lo, quiet=True), fn('b', 'file_bytes', T('base.vdif'), hi, None, quiet=True),
+           fn(None, 'write_file', T('r%d.vdif' % k), [V('a'), V('b')]),
+           open_('f', 'vdif', T('r%d.vdif' % k), 'rs', we_may_manage=True, quiet=True),
+           call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
+          for k, (lo, hi) in enumerate(RANDOM_LOSSES)]),
+
+    case('mark5b_and_mark4_losses_drawn_at_random',
+         'the same for twelve Mark 5B frames (forty losses) and eight Mark 4 frames (twenty): shapes and '
+         'repaired samples (the corrupt-stream tests of both formats, widened)',
+         open_('fr', 'mark5b', S('sample.m5b'), 'rs', sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2),
+         call('d', 'fr.read'),
+         open_('fw', 'mark5b', T('base.m5b'), 'ws', header0=V('fr.header0'), sample_rate=HZ(32e6), nchan=8, bps=2),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'), close('fr'),
+         [[fn('a', 'file_bytes', T('base.m5b'), 0, lo, quiet=True), fn('b', 'file_bytes', T('base.m5b'), hi, None, quiet=True),
+           fn(None, 'write_file', T('r%d.m5b' % k), [V('a'), V('b')]),
+           open_('f', 'mark5b', T('r%d.m5b' % k), 'rs', sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2,
+                 we_may_manage=True, quiet=True),
+           call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
+          for k, (lo, hi) in enumerate(_drawn(40, 77, M5B, 1, 11, 12))],
+         open_('fr', 'mark4', S('sample.m4'), 'rs', sample_rate=HZ(32e6), ntrack=64, decade=2010),
+         call('d', 'fr.read'),
+         open_('fw', 'mark4', T('base.m4'), 'ws', header0=V('fr.header0'), sample_rate=HZ(32e6)),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'),
+         close('fr'),
+         [[fn('a', 'file_bytes', T('base.m4'), 0, lo, quiet=True), fn('b', 'file_bytes', T('base.m4'), hi, None, quiet=True),
+           fn(None, 'write_file', T('r%d.m4' % k), [V('a'), V('b')]),
+           open_('f', 'mark4', T('r%d.m4' % k), 'rs', sample_rate=HZ(32e6), ntrack=64, decade=2010,
+                 we_may_manage=True, quiet=True),
+           call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
+          for k, (lo, hi) in enumerate(_drawn(20, 78, M4B, 1, 7, 8))]),
 
     case('vdif_headers_damaged_in_place',
          'no bytes lost, but a header overwritten -- the sync pattern of one frame, the frame length of another, '
