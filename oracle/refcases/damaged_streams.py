@@ -57,6 +57,19 @@ def _drawn(n, seed, nbytes=FB, first=26, span=20, nframe=48):
 
 RANDOM_LOSSES = _drawn(40, 20261003)
 
+
+def _frames_drawn(n, seed, first, stop, most=6):
+    out, x = [], seed
+    for _ in range(n):
+        x = (x * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        count = 1 + (x >> 30) % most
+        gone = set()
+        while len(gone) < count:
+            x = (x * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+            gone.add(first + (x >> 25) % (stop - first))
+        out.append(sorted(gone))
+    return out
+
 GIVES_UP = (34 * FB + 8, 34 * FB + 12)   # word 2 of a header: the reference finds no header nearby and raises
 
 VDIF_MISSING = ([5], [8], [15], [47], [7, 8], [8, 9, 10, 11, 12, 13, 14, 15], [10, 11, 30], [16, 17, 18, 19, 20, 21, 22, 23, 24],
@@ -149,6 +162,26 @@ CASES = [
            open_('f', 'vdif', T('r%d.vdif' % k), 'rs', we_may_manage=True, quiet=True),
            call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
           for k, (lo, hi) in enumerate(RANDOM_LOSSES)]),
+
+    case('frames_missing_drawn_at_random',
+         'one to six whole frames taken out of the second half of the VDIF file (thirty draws) and of the '
+         'Mark 5B file (twenty): shapes and repaired samples (the missing-frame tests of both formats, widened)',
+         open_('fr', 'vdif', S('sample.vdif'), 'rs'), call('d', 'fr.read'),
+         open_('fw', 'vdif', T('base.vdif'), 'ws', header0=V('fr.header0'), nthread=8),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'), close('fr'),
+         [without(T('base.vdif'), T('q%d.vdif' % k), FB, 48, miss)
+          + [open_('f', 'vdif', T('q%d.vdif' % k), 'rs', we_may_manage=True, quiet=True), get('f.shape'),
+             call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
+          for k, miss in enumerate(_frames_drawn(30, 5, 24, 48))],
+         open_('fr', 'mark5b', S('sample.m5b'), 'rs', sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2),
+         call('d', 'fr.read'),
+         open_('fw', 'mark5b', T('base.m5b'), 'ws', header0=V('fr.header0'), sample_rate=HZ(32e6), nchan=8, bps=2),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'), close('fr'),
+         [without(T('base.m5b'), T('q%d.m5b' % k), M5B, 12, miss)
+          + [open_('f', 'mark5b', T('q%d.m5b' % k), 'rs', sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2,
+                   we_may_manage=True, quiet=True), get('f.shape'),
+             call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
+          for k, miss in enumerate(_frames_drawn(20, 6, 1, 12, most=3))]),
 
     case('mark5b_and_mark4_losses_drawn_at_random',
          'the same for twelve Mark 5B frames (forty losses) and eight Mark 4 frames (twenty): shapes and '
