@@ -38,10 +38,28 @@ def walk(k, fmt, args, kw, length, nops=24):
     return steps
 
 
+TS_RAW, RAW = S('gsb/sample_gsb_rawdump.timestamp'), S('gsb/sample_gsb_rawdump.dat')
+TS_PH = S('gsb/sample_gsb_phased.timestamp')
+PH = [[S('gsb/sample_gsb_phased.Pol-L1.dat'), S('gsb/sample_gsb_phased.Pol-L2.dat')],
+      [S('gsb/sample_gsb_phased.Pol-R1.dat'), S('gsb/sample_gsb_phased.Pol-R2.dat')]]
+RATE_RAW = (1e8 / 3) / 2 ** 23 * 2 ** 12 * 2          # 4 bits, 4096-byte payloads
+RATE_PH = (1e8 / 3) / 2 ** 23 * 2 ** 12 / 512         # 8 bits complex, 512 channels: 8 samples per frame
+GSB_WALKS = (
+    ('gsb', [TS_RAW], dict(raw=RAW, sample_rate=HZ(RATE_RAW), samples_per_frame=8192), 81920),
+    ('gsb', [TS_PH], dict(raw=PH, sample_rate=HZ(RATE_PH), samples_per_frame=8), 80),
+    ('gsb', [TS_PH], dict(raw=PH, sample_rate=HZ(RATE_PH), samples_per_frame=8, subset=TUP(1, SL(10, 400, 7))), 80),
+    ('gsb', [TS_PH], dict(raw=PH[0], sample_rate=HZ(RATE_PH), samples_per_frame=8, squeeze=False), 80),
+)
+
 CASES = [
     case('walks_over_the_samples',
          'nineteen readers -- every sample recording, whole and with subsets of threads, channels, '
          'polarisations -- each taken through twenty-four seeks to a random place and reads of a random '
          'length, then one read of everything (the stream reader tests of every format, positions widened)',
          [walk(k, *w) for k, w in enumerate(WALKS)]),
+
+    case('walks_over_the_gsb_samples',
+         'the same for the GSB samples: the 4-bit rawdump, the phased array with both polarisations, with a '
+         'polarisation and every seventh channel, with one polarisation only (gsb/tests/test_gsb.py stream reader tests)',
+         [walk(50 + k, *w) for k, w in enumerate(GSB_WALKS)]),
 ]
