@@ -21,6 +21,8 @@ WALKS = (
     ('mark4', [S('sample_64track_fanout2_ft.m4')], dict(sample_rate=HZ(8e6), ntrack=64, decade=2010), 40000),
     ('dada', [S('sample.dada')], {}, 16000),
     ('dada', [S('sample.dada')], dict(subset=1), 16000),
+    ('dada', [S('sample_meerkat.dada')], {}, 14336),
+    ('dada', [S('sample_mkbf.dada')], {}, 256),
     ('guppi', [S('sample_puppi.raw')], {}, 3840),
     ('guppi', [S('sample_puppi.raw')], dict(subset=TUP(0, [3, 1])), 3840),
 )
@@ -53,7 +55,7 @@ GSB_WALKS = (
 
 CASES = [
     case('walks_over_the_samples',
-         'nineteen readers -- every sample recording, whole and with subsets of threads, channels, '
+         'twenty-one readers -- every sample recording, whole and with subsets of threads, channels, '
          'polarisations -- each taken through twenty-four seeks to a random place and reads of a random '
          'length, then one read of everything (the stream reader tests of every format, positions widened)',
          [walk(k, *w) for k, w in enumerate(WALKS)]),
