@@ -290,7 +290,18 @@ class _DADAOpener(FormatOpener):
         return super().__call__(name, mode, **kwargs)
 
     def _sequencer_for(self, template, mode, kwargs):
-        fns = super()._sequencer_for(template, mode, kwargs)
+        extra = {}
+        if mode[0] == 'r' and 'obs_offset' in template.lower() and kwargs.get('header0') is None:
+            # (the reference fills the template from a header made of the keywords, whose defaults
+            # put the first file at offset 0: base/base.py:1765-1779)
+            given = {k.lower() for k in kwargs}
+            extra = {k: 0 for k in ('OBS_OFFSET', 'FILE_SIZE') if k.lower() not in given}
+            kwargs.update(extra)
+        try:
+            fns = super()._sequencer_for(template, mode, kwargs)
+        finally:
+            for k in extra:
+                kwargs.pop(k, None)
         if mode[0] == 'r' and 'obs_offset' in template.lower():
             # the step of {obs_offset} is the size found in the first file
             # (dada/base.py:366-377)
