@@ -36,7 +36,8 @@ class VDIFFileReader(VLBIFileReaderBase):
             thread_ids = self.get_thread_ids()
         nframes = len(self.image()) / header0.frame_nbytes
         nsets = nframes / len(thread_ids)
-        notes = {} if nsets % 1 == 0 else {
+        # (a file that is not a whole number of FRAMES is reported as that alone: vdif/file_info.py:45-55)
+        notes = {} if nsets % 1 == 0 or nframes % 1 else {
             'number_of_framesets': 'file contains non-integer number ({}) of framesets'.format(nsets)}
         return {'edv': header0.edv, 'thread_ids': thread_ids,
                 'number_of_framesets': int(nsets) if nsets % 1 == 0 else None,

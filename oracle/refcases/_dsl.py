@@ -106,8 +106,8 @@ def do(fn, *args, **kw):
     return call(None, fn, *args, quiet=True, **kw)
 
 
-def get(of, as_=None, quiet=None):
-    return _opts({'op': 'get', 'of': of, 'as': as_}, dict(quiet=quiet))
+def get(of, as_=None, quiet=None, prefix=None):
+    return _opts({'op': 'get', 'of': of, 'as': as_}, dict(quiet=quiet, prefix=prefix))
 
 
 def gets(obj, *attrs):

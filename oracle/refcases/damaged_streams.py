@@ -183,6 +183,43 @@ CASES = [
              call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
           for k, miss in enumerate(_frames_drawn(20, 6, 1, 12, most=3))]),
 
+    case('info_of_damaged_files',
+         'what `info` says of damaged files -- readable or not, the verdict on continuity and where the '
+         'first trouble is -- for repairing and for strict readers of VDIF, Mark 5B and Mark 4 files with '
+         'frames or bytes missing (the info checks of the corrupt-file tests of the three formats)',
+         open_('fr', 'vdif', S('sample.vdif'), 'rs'), call('d', 'fr.read'),
+         open_('fw', 'vdif', T('base.vdif'), 'ws', header0=V('fr.header0'), nthread=8),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'), close('fr'),
+         [[fn('a', 'file_bytes', T('base.vdif'), 0, lo, quiet=True), fn('b', 'file_bytes', T('base.vdif'), hi, None, quiet=True),
+           fn(None, 'write_file', T('i%d.vdif' % k), [V('a'), V('b')]),
+           [[open_('f', 'vdif', T('i%d.vdif' % k), 'rs', verify=v), get('f.info.readable'), get('f.info.checks'),
+             get('f.info.errors', prefix=24), get('f.info.warnings', prefix=24), call(None, 'f.tell'), close('f')]
+            for v in ('fix', True)]]
+          for k, (lo, hi) in enumerate(((29 * FB, 30 * FB), (32 * FB, 40 * FB), (47 * FB, 48 * FB), (31 * FB + 10, 31 * FB + 20),
+                                        (37 * FB + 2000, 37 * FB + 2008), (44 * FB + 100, 45 * FB + 300)))],
+         open_('fr', 'mark5b', S('sample.m5b'), 'rs', sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2),
+         call('d', 'fr.read'),
+         open_('fw', 'mark5b', T('base.m5b'), 'ws', header0=V('fr.header0'), sample_rate=HZ(32e6), nchan=8, bps=2),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'), close('fr'),
+         [[fn('a', 'file_bytes', T('base.m5b'), 0, lo, quiet=True), fn('b', 'file_bytes', T('base.m5b'), hi, None, quiet=True),
+           fn(None, 'write_file', T('i%d.m5b' % k), [V('a'), V('b')]),
+           [[open_('f', 'mark5b', T('i%d.m5b' % k), 'rs', sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2, verify=v),
+             get('f.info.readable'), get('f.info.checks'), get('f.info.errors', prefix=24), get('f.info.warnings', prefix=24),
+             close('f')] for v in ('fix', True)]]
+          for k, (lo, hi) in enumerate(((5 * M5B, 6 * M5B), (3 * M5B, 5 * M5B), (11 * M5B, 12 * M5B), (7 * M5B + 20, 7 * M5B + 24),
+                                        (9 * M5B + 5000, 9 * M5B + 5010)))],
+         open_('fr', 'mark4', S('sample.m4'), 'rs', sample_rate=HZ(32e6), ntrack=64, decade=2010),
+         call('d', 'fr.read'),
+         open_('fw', 'mark4', T('base.m4'), 'ws', header0=V('fr.header0'), sample_rate=HZ(32e6)),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'),
+         close('fr'),
+         [[fn('a', 'file_bytes', T('base.m4'), 0, lo, quiet=True), fn('b', 'file_bytes', T('base.m4'), hi, None, quiet=True),
+           fn(None, 'write_file', T('i%d.m4' % k), [V('a'), V('b')]),
+           [[open_('f', 'mark4', T('i%d.m4' % k), 'rs', sample_rate=HZ(32e6), ntrack=64, decade=2010, verify=v),
+             get('f.info.readable'), get('f.info.checks'), get('f.info.errors', prefix=24), get('f.info.warnings', prefix=24),
+             close('f')] for v in ('fix', True)]]
+          for k, (lo, hi) in enumerate(((3 * M4B, 4 * M4B), (2 * M4B, 4 * M4B), (5 * M4B + 5000, 5 * M4B + 5016)))]),
+
     case('mark5b_and_mark4_losses_drawn_at_random',
          'the same for twelve Mark 5B frames (forty losses) and eight Mark 4 frames (twenty): shapes and '
          'repaired samples (the corrupt-stream tests of both formats, widened)',

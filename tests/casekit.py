@@ -680,9 +680,18 @@ def compare(steps, expected, got):
                         st['msg_has'] in w.get('msg', '') and st['msg_has'] in g.get('msg', '')):
                     diffs.append('{}: message {!r} lacks {!r} (reference: {!r})'.format(
                         where, g.get('msg'), st['msg_has'], w.get('msg')))
-        elif st is not None and st.get('prefix') and isinstance(w.get('v'), str) and isinstance(g.get('v'), str):
+        elif st is not None and st.get('prefix'):
             n = st['prefix']                            # (texts that go on to quote a library's own message)
-            _same(w['v'][:n], g['v'][:n], where, diffs)
+
+            def cut(x):
+                if isinstance(x, str):
+                    return x[:n]
+                if isinstance(x, dict):
+                    return {k: cut(v) for k, v in x.items()}
+                if isinstance(x, list):
+                    return [cut(v) for v in x]
+                return x
+            _same(cut(w.get('v')), cut(g.get('v')), where, diffs)
         elif not (st is not None and st.get('quiet')):
             _same(w.get('v'), g.get('v'), where, diffs)
         if 'raises' in w and 'raises' not in g and st is not None and st.get('we_may_manage'):
