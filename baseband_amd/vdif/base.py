@@ -241,32 +241,13 @@ class VDIFStreamReader(GPUStreamReaderBase):
     def _image(self):
         return self.fh_raw.image()
 
-    def _relocate(self):
-        """Corruption-tolerant index (SURVEY 8f N1): keep the file resident in
-        HBM, find every intact frame with the byte-granular header search
-        (bb_vdif_locate: pattern + a header one frame later), scan those
-        headers and place the frames by (time index, thread).  Frames that
-        are missing or damaged simply have no entry and decode to fill_value
-        -- what the reference's _bad_frame achieves frame set by frame set
-        (vdif/base.py:536-755)."""
-        from ..staging import upload
-        kernels.require_gpu()
+    def _lost_behind_holes(self, dev, offs, recs, nbytes):
+        """The reference assembles a frame set frame by frame and, when a frame
+        cannot be read, looks for the next header no further than two frames
+        on; if there is none it gives up on the REST of that set
+        (vdif/base.py:655-690).  Same here: a hole of more than three frame
+        lengths between two located frames of one set drops the later ones."""
         h0 = self.header0
-        image = self._image()
-        dev = self._whole_file_in_hbm()         # what earlier windows left in HBM is not sent again
-        n = len(image)
-        offs = kernels.vdif_locate(dev, n, self._frame_nbytes, h0.nbytes,
-                                   self._pattern, self._mask)
-        recs = kernels.vdif_scan_at(dev, n, offs, self._frame_nbytes, h0.nbytes,
-                                    self._pattern, self._mask, h0['seconds'],
-                                    h0['frame_nr'], self._frame_rate)
-        if self._thread_slot is None:
-            self._thread_slot = kernels.thread_slot_map(self._thread_ids, dev.device)
-        # The reference assembles a frame set frame by frame and, when a frame
-        # cannot be read, looks for the next header no further than two frames
-        # on; if there is none it gives up on the REST of that set
-        # (vdif/base.py:655-690).  Same here: a hole of more than three frame
-        # lengths between two located frames of one set drops the later ones.
         if offs.numel() > 1:
             t = recs[:, 2]
             same_set = t[1:] == t[:-1]
@@ -282,13 +263,17 @@ class VDIFStreamReader(GPUStreamReaderBase):
                 first = torch.cummax(torch.where(start, idx, torch.zeros_like(idx)), 0).values
                 lost = (c - c[first]) > 0
                 recs[:, 3] = torch.where(lost, recs[:, 3] & ~(_lib.FRAME_OK << 16), recs[:, 3])
-        # The reference collects the frames of a set one after the other (vdif/base.py:655-712).
-        # When a frame cannot be read it searches for the next header from the end of the
-        # header before; a header found that way -- not where the next frame was due -- ends the
-        # set when its frame number is another one; frames of the set that follow it are not
-        # used.  A header that stands where it is due ends the set when it can be read as a
-        # frame of another set, and is stepped over when its seconds make no sense (its read
-        # fails, the search from there finds the header after it).
+        return recs
+
+    def _lost_behind_foreign_headers(self, dev, offs, recs, nbytes):
+        """The reference collects the frames of a set one after the other (vdif/base.py:655-712).
+        When a frame cannot be read it searches for the next header from the end of the
+        header before; a header found that way -- not where the next frame was due -- ends the
+        set when its frame number is another one; frames of the set that follow it are not
+        used.  A header that stands where it is due ends the set when it can be read as a
+        frame of another set, and is stepped over when its seconds make no sense (its read
+        fails, the search from there finds the header after it)."""
+        h0 = self.header0
         if offs.numel() > 2:
             t = recs[:, 2].to(torch.int64)
             n = t.numel()
@@ -296,7 +281,7 @@ class VDIFStreamReader(GPUStreamReaderBase):
             run_start = torch.ones(n, dtype=torch.bool, device=t.device)
             run_start[1:] = t[1:] != t[:-1]
             run_id = torch.cumsum(run_start.to(torch.int64), 0) - 1
-            top = len(image) // self._set_nbytes + 2
+            top = nbytes // self._set_nbytes + 2
             valid = (t >= 0) & (t < top)
             first_run = torch.full((top,), n, dtype=torch.int64, device=t.device)
             first_run.scatter_reduce_(0, t[valid], run_id[valid], 'amin')
@@ -315,16 +300,20 @@ class VDIFStreamReader(GPUStreamReaderBase):
                 same_nr = frame_nr[p_] == frame_nr
                 lost = resumed & ~(single & ((~due & same_nr) | (due & senseless)))
                 recs[:, 3] = torch.where(lost, recs[:, 3] & ~(_lib.FRAME_OK << 16), recs[:, 3])
-        # Two more of the reference's habits.  A thread that shows up twice in one set is
-        # discarded, both times (vdif/base.py:700-705).  And a damaged set is taken from the
-        # first header that has a header one frame before it (the backward search for the start
-        # of the set insists on that, vdif/base.py:576-612): frames of the set in front of it
-        # whose predecessor is gone are not used -- unless the set before was damaged as well.
+        return recs
+
+    def _lost_twice_or_in_front(self, dev, offs, recs, nbytes):
+        """Two more of the reference's habits.  A thread that shows up twice in one set is
+        discarded, both times (vdif/base.py:700-705).  And a damaged set is taken from the
+        first header that has a header one frame before it (the backward search for the start
+        of the set insists on that, vdif/base.py:576-612): frames of the set in front of it
+        whose predecessor is gone are not used -- unless the set before was damaged as well."""
+        h0 = self.header0
         if offs.numel() > 1:
             t = recs[:, 2].to(torch.int64)
             n = t.numel()
             o64 = offs.to(torch.int64)
-            top = len(image) // self._set_nbytes + 2
+            top = nbytes // self._set_nbytes + 2
             live = (((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0) & (t >= 0) & (t < top)
             tc = t.clamp(0, top - 1)
             key = tc * 1024 + (recs[:, 3] & 0x3ff).to(torch.int64)
@@ -353,6 +342,33 @@ class VDIFStreamReader(GPUStreamReaderBase):
             front = live & damaged & before_whole[tc] & ~follows & none_before
             lost = twice | front
             recs[:, 3] = torch.where(lost, recs[:, 3] & ~(_lib.FRAME_OK << 16), recs[:, 3])
+        return recs
+
+    def _relocate(self):
+        """Corruption-tolerant index (SURVEY 8f N1): keep the file resident in
+        HBM, find every intact frame with the byte-granular header search
+        (bb_vdif_locate: pattern + a header one frame later), scan those
+        headers and place the frames by (time index, thread).  Frames that
+        are missing or damaged simply have no entry and decode to fill_value
+        -- what the reference's _bad_frame achieves frame set by frame set
+        (vdif/base.py:536-755)."""
+        from ..staging import upload
+        kernels.require_gpu()
+        h0 = self.header0
+        image = self._image()
+        dev = self._whole_file_in_hbm()         # what earlier windows left in HBM is not sent again
+        n = len(image)
+        offs = kernels.vdif_locate(dev, n, self._frame_nbytes, h0.nbytes,
+                                   self._pattern, self._mask)
+        recs = kernels.vdif_scan_at(dev, n, offs, self._frame_nbytes, h0.nbytes,
+                                    self._pattern, self._mask, h0['seconds'],
+                                    h0['frame_nr'], self._frame_rate)
+        if self._thread_slot is None:
+            self._thread_slot = kernels.thread_slot_map(self._thread_ids, dev.device)
+        # three rules of the reference's frame-by-frame recovery decide which located frames count
+        recs = self._lost_behind_holes(dev, offs, recs, n)
+        recs = self._lost_behind_foreign_headers(dev, offs, recs, n)
+        recs = self._lost_twice_or_in_front(dev, offs, recs, n)
         ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
         same = (recs[:, 3] & 0xffff) == h0['thread_id']
         sel = recs[:, 2][ok & same]
@@ -388,6 +404,11 @@ class VDIFStreamReader(GPUStreamReaderBase):
         return ValueError("wrong frame number. " + msg)
 
     def _first_problem_met(self, first=None, last=None):
+        """Walks the frame sets [first, last) (default: those of the read in progress) as the
+        reference's `VDIFFrameSet.fromfile` would from the fixed stride (vdif/frame.py:201-235) and
+        names the first problem: 'end' (the file ends inside a set), 'header' (bytes that are no
+        header where one is due), 'threads' (the next set begins, or a thread repeats, before all
+        threads asked for were seen), 'number' (a whole set of another time), or None."""
         if first is None:
             if self._asked is None:
                 return None
