@@ -245,6 +245,23 @@ CASES = [
            call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
           for k, (lo, hi) in enumerate(_drawn(20, 78, M4B, 1, 7, 8))]),
 
+    case('mark4_narrow_layouts_losses_drawn_at_random',
+         'the same for Mark 4 files of 32 tracks (fan-out 2) and of 16 tracks, eight frames each written from the '
+         'two of their sample, twelve losses each: the header search on 32- and 16-bit stream words '
+         '(mark4/tests/test_mark4.py corrupt-stream tests, layouts widened)',
+         [[open_('fr', 'mark4', S(sample), 'rs', sample_rate=HZ(rate), ntrack=ntrack, decade=2010), call('d', 'fr.read'),
+           open_('fw', 'mark4', T('base%d.m4' % ntrack), 'ws', header0=V('fr.header0'), sample_rate=HZ(rate)),
+           do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'),
+           close('fr'), digest(T('base%d.m4' % ntrack)),
+           [[fn('a', 'file_bytes', T('base%d.m4' % ntrack), 0, lo, quiet=True),
+             fn('b', 'file_bytes', T('base%d.m4' % ntrack), hi, None, quiet=True),
+             fn(None, 'write_file', T('r%d_%d.m4' % (ntrack, k)), [V('a'), V('b')]),
+             open_('f', 'mark4', T('r%d_%d.m4' % (ntrack, k)), 'rs', sample_rate=HZ(rate), ntrack=ntrack, decade=2010,
+                   we_may_manage=True, quiet=True),
+             call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
+            for k, (lo, hi) in enumerate(_drawn(12, 80 + ntrack, ntrack * 2500, 1, 7, 8))]]
+          for sample, ntrack, rate in (('sample_32track_fanout2.m4', 32, 16e6), ('sample_16track.m4', 16, 32e6))]),
+
     case('vdif_headers_damaged_in_place',
          'no bytes lost, but a header overwritten -- the sync pattern of one frame, the frame length of another, '
          'two headers next to each other: by default the frame (or what the search cannot reach behind '
