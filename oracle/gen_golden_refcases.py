@@ -17,6 +17,10 @@ import shutil
 import sys
 import tempfile
 
+if os.environ.get('PYTHONHASHSEED') != '0':        # (set orders show in a few messages: the same file every run)
+    os.environ['PYTHONHASHSEED'] = '0'
+    os.execv(sys.executable, [sys.executable, '-W', 'ignore'] + sys.argv)
+
 import numpy as np
 
 np.asscalar = getattr(np, 'asscalar', lambda a: a.item())
