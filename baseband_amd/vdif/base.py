@@ -8,6 +8,8 @@ window by three launches: ``bb_vdif_scan`` -> ``bb_build_index`` ->
 ``bb_decode_frames``.
 """
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -379,6 +381,58 @@ class VDIFStreamReader(GPUStreamReaderBase):
         self._located = (offs, recs)
         self._relocated = True
         self._note_damage(src, len(self._thread_ids))
+        self._note_sets_before_trouble(offs, recs)
+
+    _before_trouble = frozenset()   # whole sets whose successor cannot be read from where they end
+
+    def _note_sets_before_trouble(self, offs, recs, most=256):
+        """The reference reads one frame set AHEAD of the one it returns (base/base.py:1115-1123);
+        when that read fails, and the header it started at is not of the next set, the set being
+        returned -- whole, and where it should be -- still gets a bare "problem loading frame set
+        k." (vdif/base.py:547-562).  That is the case for the whole set in front of a run of
+        damaged ones when the frames behind it begin inside a set, or not with a header."""
+        self._before_trouble = frozenset()
+        sets = self._damage[0] if self._damage is not None else ()
+        if not len(sets) or len(self._thread_ids) != len(self._file_threads):
+            return
+        run_starts = [int(d) for i, d in enumerate(sets) if d > 0 and (i == 0 or sets[i - 1] != d - 1)][:most]
+        if not run_starts:
+            return
+        from .. import _lib
+        t = recs[:, 2].to(torch.int64)
+        ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
+        o64 = offs.to(torch.int64)
+        thread = (recs[:, 3] & 0x3ff).to(torch.int64)
+        wanted = set(int(x) for x in self._thread_ids)
+        found = set()
+        for d in run_starts:
+            k = d - 1
+            mine = torch.nonzero(ok & (t == k))[:, 0]
+            if not mine.numel():
+                continue
+            end = int(o64[mine].max()) + self._frame_nbytes
+            q = int(torch.searchsorted(o64, torch.tensor([end], device=o64.device))[0])
+            if q >= o64.numel():
+                continue                                    # (the file ends there: the last set is taken as it is)
+            if int(o64[q]) != end or not bool(ok[q]):
+                found.add(k)                                # (no header where the next set should begin)
+                continue
+            j = int(t[q])
+            if j == k + 1:
+                continue
+            stop = q
+            while stop < o64.numel() and int(t[stop]) == j and int(o64[stop]) == end + (stop - q) * self._frame_nbytes:
+                stop += 1
+            if not wanted <= set(int(x) for x in thread[q:stop].tolist()):
+                found.add(k)
+        self._before_trouble = frozenset(found)
+
+    def _warn_damage(self, first, last):
+        if self.verify is not True:
+            for k in sorted(self._before_trouble):
+                if first <= k < last:
+                    warnings.warn("problem loading frame set {}.".format(k))
+        super()._warn_damage(first, last)
 
     def _verification_error(self, msg):
         """The reference loads one frame set at a time from the fixed stride and stops at the first
