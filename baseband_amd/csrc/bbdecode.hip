@@ -681,7 +681,7 @@ int bb_vdif_locate(const void *d_buf, size_t nbytes, const bb_vdif_scan_params *
     if (p->frame_nbytes < p->header_nbytes) return BB_EINVAL;
     if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
     if (nbytes < p->frame_nbytes || p->frame_nbytes < 32) return BB_OK;
-    uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
+    uint64_t blocks = (nbytes / 16 + BB_BLOCK * BB_LOCATE_U - 1) / (BB_BLOCK * BB_LOCATE_U);   // BB_LOCATE_U x 16 bytes per lane and iteration
     // (65536 workgroups: 5.1-5.8 TB/s on the 8 GiB image, 16384: 5.0-5.2, 131072: 4.3-4.4;
     // profiles/r04l_locate.log -- the workgroups' confirm phases overlap other workgroups' sweeps)
     const uint64_t lcap = g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID;
@@ -743,7 +743,7 @@ int bb_mark5b_locate_stream(const void *d_buf, size_t nbytes, uint32_t w1_patter
     if (!d_buf || !d_offsets || !d_count) return BB_EINVAL;
     if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
     if (nbytes < BB_M5B_FRAME) return BB_OK;
-    uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
+    uint64_t blocks = (nbytes / 16 + BB_BLOCK * BB_LOCATE_U - 1) / (BB_BLOCK * BB_LOCATE_U);   // BB_LOCATE_U x 16 bytes per lane and iteration
     if (blocks > (g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID)) blocks = g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(k_mark5b_locate, dim3((unsigned)blocks), dim3(BB_BLOCK), 0, (hipStream_t)stream,
@@ -1457,7 +1457,7 @@ int bb_mark4_locate(const void *d_buf, size_t nbytes, int ntrack, int64_t *d_off
     if (ntrack != 16 && ntrack != 32 && ntrack != 64) return BB_ENOTSUP;
     if ((uintptr_t)d_buf & 15) return BB_EINVAL;           // 16-byte loads (bb_locate_sweep)
     if (nbytes < (size_t)ntrack * 2500) return BB_OK;
-    uint64_t blocks = (nbytes / 16 + BB_BLOCK - 1) / BB_BLOCK;          // 16 bytes per lane
+    uint64_t blocks = (nbytes / 16 + BB_BLOCK * BB_LOCATE_U - 1) / (BB_BLOCK * BB_LOCATE_U);   // BB_LOCATE_U x 16 bytes per lane and iteration
     if (blocks > (g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID)) blocks = g_tune_blocks.load() > 0 ? (uint64_t)g_tune_blocks.load() : BB_LOCATE_GRID;
     if (blocks == 0) blocks = 1;
     const dim3 grid((unsigned)blocks), block(BB_BLOCK);

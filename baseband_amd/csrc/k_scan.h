@@ -168,21 +168,26 @@ __device__ __forceinline__ void bb_locate_sweep(const uint8_t *buf, uint64_t nby
     // latency bound -- 32 waves x 1 KiB per CU in flight = 8 MiB on the chip, at 2
     // us per load 4.2 TB/s, which is what it measured (4.0-4.3; round 4)
     constexpr int U = BB_LOCATE_U;
-    const uint64_t stride = (uint64_t)gridDim.x * BB_BLOCK;
-    for (uint64_t j0 = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x; j0 < nchunk + (BB_WAVE - 1);
-         j0 += stride * U) {
+    // A workgroup takes U x 4 KiB in ONE piece per iteration (a lane's U chunks lie 4 KiB apart)
+    // and fetches them with nontemporal loads: a read-only sweep in that shape reaches 0.87-0.90
+    // of the peak where plain loads that lie a whole grid apart reach 0.80
+    // (tools/experiments/read_probe.cpp, profiles/r06ci_read_probe.log; round 6).
+    const uint64_t stride = BB_BLOCK;                               // between a lane's chunks
+    const uint64_t step = (uint64_t)gridDim.x * BB_BLOCK * U;       // between a workgroup's iterations
+    for (uint64_t j0 = (uint64_t)blockIdx.x * BB_BLOCK * U + threadIdx.x; j0 < nchunk + (BB_WAVE - 1);
+         j0 += step) {
         // (whole waves stay in the loop: the shuffle below needs every lane)
         bb_u4 dv[U];
         uint32_t tail[U];
         // Everything this wave touches in this iteration lies inside the buffer (all
-        // iterations but the last ones): plain loads, nothing between them.  (With the
+        // iterations but the last ones): loads with nothing between them.  (With the
         // bounds tests of the ragged end in the way the compiler waited for the first
         // chunk before it issued the second: round 5.)
         const uint64_t wave_last = (j0 - (uint64_t)lane) + (BB_WAVE - 1) + (uint64_t)(U - 1) * stride;
         if (4 * wave_last + 5 <= ndw) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                dv[u] = *reinterpret_cast<const bb_u4 *>(w + 4 * (j0 + (uint64_t)u * stride));
+                dv[u] = __builtin_nontemporal_load(reinterpret_cast<const bb_u4 *>(w + 4 * (j0 + (uint64_t)u * stride)));
             // (the dword after a lane's sixteen bytes: the next lane's first -- every lane
             // fetches its own, out of the lines the loads above bring in: no shuffle, no
             // lane that differs)
