@@ -1415,3 +1415,86 @@ def test_reads_through_the_index_name_their_holes_once_per_read():
                            'problem loading frame set 6. Thread(s) [2, 3] missing; set to invalid.']
     reader.verify = True
     assert said(0, 10) == []
+
+
+def _located_table(nsets, nthr, fb, drop=(), move=None, foreign=None):
+    """(file bytes with frame numbers in word 1, offsets, records) of `nsets` x `nthr` located frames of
+    `fb` bytes, as `bb_vdif_locate` + `bb_vdif_scan_at` would give them; `drop`: frames not located;
+    `move`: {frame: byte offset}; `foreign`: {frame: (time index, frame number)} overrides."""
+    import torch
+    from baseband_amd import _lib
+    rows, dev = [], np.zeros(nsets * nthr * fb + 64, np.uint8)
+    for f in range(nsets * nthr):
+        if f in drop:
+            continue
+        k, t = divmod(f, nthr)
+        off = (move or {}).get(f, f * fb)
+        tidx, nr = (foreign or {}).get(f, (k, k))
+        dev[off + 4:off + 8] = np.frombuffer(np.uint32(nr).tobytes(), np.uint8)
+        rows.append((off, tidx, t | (_lib.FRAME_OK << 16)))
+    rows.sort()
+    offs = torch.tensor([r[0] for r in rows], dtype=torch.int64)
+    recs = torch.zeros((len(rows), 4), dtype=torch.int32)
+    recs[:, 2] = torch.tensor([r[1] for r in rows], dtype=torch.int32)
+    recs[:, 3] = torch.tensor([r[2] for r in rows], dtype=torch.int32)
+    return torch.from_numpy(dev), offs, recs
+
+
+def test_frame_set_rules_of_the_located_frame_index():
+    """The three rules that decide which located VDIF frames count (vdif/base.py `_lost_*`; pinned
+    against the reference on damaged files by tests/golden/refcases/damaged_streams.json), on small
+    tables: frames behind a header of another frame number that was found off its place are not used;
+    a thread that occurs twice is dropped both times; a damaged set that follows a whole one starts
+    at the first frame whose predecessor is there."""
+    import types
+    from baseband_amd import _lib
+    from baseband_amd.vdif.base import VDIFStreamReader as R
+    from baseband_amd.vdif.header import VDIFHeader
+    fb, nthr, nsets = 1000, 4, 6
+    h0 = VDIFHeader.fromvalues(edv=0, time=np.datetime64('2015-06-07T08:09:10'), nchan=1, bps=2, complex_data=False,
+                               thread_id=0, samples_per_frame=64, station='AA', frame_nr=0)
+    reader = types.SimpleNamespace(header0=h0, _frame_nbytes=fb, _set_nbytes=nthr * fb, _frame_rate=100,
+                                   _file_threads=list(range(nthr)), _file_offset0=0)
+
+    def counted(offs, recs):
+        ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
+        return sorted(int(o) // fb if int(o) % fb == 0 else round(int(o) / fb, 2) for o in offs[ok])
+
+    def rules(dev, offs, recs):
+        n = dev.numel()
+        recs = R._lost_behind_holes(reader, dev, offs, recs, n)
+        recs = R._lost_behind_foreign_headers(reader, dev, offs, recs, n)
+        return R._lost_twice_or_in_front(reader, dev, offs, recs, n)
+    # nothing wrong: everything counts
+    dev, offs, recs = _located_table(nsets, nthr, fb)
+    assert counted(offs, rules(dev, offs, recs)) == list(range(24))
+    # frame 13 (set 3, thread 1) not located; what stands 40 bytes before frame 14's place carries
+    # another frame number and was found off its place: frame 15 of the same set is not used
+    dev, offs, recs = _located_table(nsets, nthr, fb, drop={13}, move={14: 14 * fb - 40, 15: 15 * fb - 40},
+                                     foreign={14: (-5000, 77)})
+    kept = counted(offs, rules(dev, offs, recs))
+    assert 15 * fb - 40 not in [int(o) for o, k in zip(offs, ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0) if k]
+    assert all(f in kept for f in list(range(12)) + [12] + list(range(16, 24)))
+    # ... with the SAME frame number there (its seconds are nonsense), the set goes on behind it
+    dev, offs, recs = _located_table(nsets, nthr, fb, drop={13}, move={14: 14 * fb - 40, 15: 15 * fb - 40},
+                                     foreign={14: (-5000, 3)})
+    recs = rules(dev, offs, recs)
+    ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
+    assert bool(ok[offs == 15 * fb - 40].all())
+    # thread 1 twice in set 2 (a spliced header): both are dropped, nothing else
+    dev, offs, recs = _located_table(nsets, nthr, fb, foreign={11: (2, 2)})
+    recs[offs == 11 * fb, 3] = 1 | (_lib.FRAME_OK << 16)
+    recs = rules(dev, offs, recs)
+    ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
+    assert [int(o) // fb for o in offs[~ok]] == [9, 11]
+    # set 4 lacks frames 16 and 17, frame 18 lies a byte early (its predecessor is gone), set 3 is
+    # whole: the set starts at frame 19
+    dev, offs, recs = _located_table(nsets, nthr, fb, drop={16, 17}, move={f: f * fb - 1 for f in range(18, 24)})
+    recs = rules(dev, offs, recs)
+    ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
+    assert [int(o) for o in offs[~ok]] == [18 * fb - 1]
+    # ... the same with set 3 damaged too: the set is taken from where the reference arrives at it
+    dev, offs, recs = _located_table(nsets, nthr, fb, drop={15, 16, 17}, move={f: f * fb - 1 for f in range(18, 24)})
+    recs = rules(dev, offs, recs)
+    ok = ((recs[:, 3] >> 16) & _lib.FRAME_OK) != 0
+    assert bool(ok.all())
