@@ -21,6 +21,10 @@ WALKS = (
     ('mark4', [S('sample_64track_fanout2_ft.m4')], dict(sample_rate=HZ(8e6), ntrack=64, decade=2010), 40000),
     ('dada', [S('sample.dada')], {}, 16000),
     ('dada', [S('sample.dada')], dict(subset=1), 16000),
+    ('vdif', [S('sample.vdif')], dict(verify=False), 40000),
+    ('vdif', [S('sample.vdif')], dict(verify=True, subset=[7, 0]), 40000),
+    ('mark5b', [S('sample.m5b')], dict(sample_rate=HZ(32e6), kday=56000, nchan=8, bps=2, verify=False), 20000),
+    ('mark4', [S('sample.m4')], dict(sample_rate=HZ(32e6), ntrack=64, decade=2010, verify=False, subset=[0, 5]), 160000),
     ('dada', [S('sample_meerkat.dada')], {}, 14336),
     ('dada', [S('sample_mkbf.dada')], {}, 256),
     ('guppi', [S('sample_puppi.raw')], {}, 3840),
@@ -55,7 +59,7 @@ GSB_WALKS = (
 
 CASES = [
     case('walks_over_the_samples',
-         'twenty-one readers -- every sample recording, whole and with subsets of threads, channels, '
+         'twenty-five readers -- every sample recording, whole and with subsets of threads, channels, '
          'polarisations -- each taken through twenty-four seeks to a random place and reads of a random '
          'length, then one read of everything (the stream reader tests of every format, positions widened)',
          [walk(k, *w) for k, w in enumerate(WALKS)]),
