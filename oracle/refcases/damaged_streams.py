@@ -183,6 +183,24 @@ CASES = [
              call(None, 'f.read', any_warns=True, we_may_manage=True), close('f')]
           for k, miss in enumerate(_frames_drawn(20, 6, 1, 12, most=3))]),
 
+    case('damage_inside_a_sequence_of_files',
+         'the six frame sets split over three files by a template; a frame, forty bytes, a whole set taken out '
+         'of the MIDDLE file: the stream is read through the template and repaired across the file boundaries '
+         '(vdif template tests and the corrupt-file tests, combined)',
+         open_('fr', 'vdif', S('sample.vdif'), 'rs'), call('d', 'fr.read'),
+         open_('fw', 'vdif', T('p{file_nr:d}.vdif'), 'ws', header0=V('fr.header0'), nthread=8, file_size=16 * FB),
+         do('fw.write', V('d')), do('fw.write', V('d')), do('fw.write', V('d')), close('fw'), close('fr'), listdir(),
+         fn('mid', 'file_bytes', T('p1.vdif'), quiet=True),
+         [[fn(None, 'write_file', T('p1.vdif'), [V('mid')]),
+           fn('a', 'file_bytes', T('p1.vdif'), 0, lo, quiet=True), fn('b', 'file_bytes', T('p1.vdif'), hi, None, quiet=True),
+           fn(None, 'write_file', T('p1.vdif'), [V('a'), V('b')]),
+           open_('f', 'vdif', T('p{file_nr:d}.vdif'), 'rs', we_may_manage=True, quiet=True), get('f.shape'),
+           call(None, 'f.read', some_warns=True, we_may_manage=True), do('f.seek', 59990),
+           call(None, 'f.read', 20, any_warns=True, we_may_manage=True), close('f'),
+           open_('g', 'vdif', [T('p0.vdif'), T('p1.vdif'), T('p2.vdif')], 'rs', verify=True),
+           call(None, 'g.read', any_warns=True), close('g')]
+          for lo, hi in ((5 * FB, 6 * FB), (9 * FB + 3000, 9 * FB + 3040), (8 * FB, 16 * FB), (15 * FB, 16 * FB))]),
+
     case('info_of_damaged_files',
          'what `info` says of damaged files -- readable or not, the verdict on continuity and where the '
          'first trouble is -- for repairing and for strict readers of VDIF, Mark 5B and Mark 4 files with '
