@@ -218,7 +218,6 @@ class Mark4StreamReader(GPUStreamReaderBase):
         reference's _bad_frame recovery (base/base.py:1127-1219).  A frame
         that shows up more than once is 'excess data', which the reference
         refuses as well."""
-        from ..staging import upload
         kernels.require_gpu()
         image = self._image()
         dev, n = self._whole_file_in_hbm(), len(image)

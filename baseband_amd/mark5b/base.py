@@ -191,7 +191,6 @@ class Mark5BStreamReader(GPUStreamReaderBase):
         (bb_mark5b_scan_at) and place the frames by their time index; frames
         without an entry decode to fill_value.  Same outcome as the
         reference's frame-by-frame _bad_frame recovery (base/base.py:1127-1219)."""
-        from ..staging import upload
         kernels.require_gpu()
         image = self._image()
         dev, n = self._whole_file_in_hbm(), len(image)

@@ -354,7 +354,6 @@ class VDIFStreamReader(GPUStreamReaderBase):
         are missing or damaged simply have no entry and decode to fill_value
         -- what the reference's _bad_frame achieves frame set by frame set
         (vdif/base.py:536-755)."""
-        from ..staging import upload
         kernels.require_gpu()
         h0 = self.header0
         image = self._image()
