@@ -58,6 +58,7 @@ TUNE_ENCODE_STRIPES = 38
 TUNE_SELECT_PICK = 39
 TUNE_PICK_BYTES = 40
 TUNE_VDIF8_LDS_GIB = 41
+TUNE_TOUCH_MIB = 42
 # include/bbdecode_exp.h (experiment build only: bb_tune answers BB_EINVAL otherwise)
 TUNE_FLAT_VARIANT = 0
 TUNE_NT_STORES = 1
@@ -184,6 +185,7 @@ SIGNATURES = [
     ('bb_vdif_locate', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_vdif_scan_at', C.c_int, [_vp, _sz, C.POINTER(VDIFScanParams), _vp, _sz, _vp, _vp]),
     ('bb_mark5b_scan', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp]),
+    ('bb_touch', C.c_int, [_vp, _sz, _vp]),
     ('bb_mark5b_locate', C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp]),
     ('bb_mark5b_locate_stream', C.c_int, [_vp, _sz, C.c_uint32, C.c_uint32, _vp, _sz, _vp, _vp]),
     ('bb_mark5b_scan_at', C.c_int, [_vp, _sz, C.POINTER(Mark5BScanParams), _vp, _sz, _vp, _vp]),

@@ -459,6 +459,19 @@ void k_mark5b_locate(const uint8_t *buf, uint64_t nbytes, uint32_t w1_pattern, u
         });
 }
 
+// A pass that only READS [buf, buf + nbytes): what it brings into the 256 MiB memory-side cache the
+// decode launch that follows finds there (bb_touch; round 6).  PLAIN loads -- nontemporal ones go
+// past that cache -- one 16-byte load per lane, which is the shape plain loads are fastest in
+// (tools/experiments/read_probe.cpp: 0.88-0.90 of the peak; four in flight: 0.81).
+__global__ __launch_bounds__(BB_BLOCK)
+void k_touch(const bb_u4 *in, uint64_t nchunk, uint32_t *sink)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * BB_BLOCK + threadIdx.x;
+    if (j >= nchunk) return;
+    const bb_u4 v = in[j];
+    if ((v.x ^ v.y ^ v.z ^ v.w) == 0x5bd1e995u && sink) sink[0] = v.x;      // (never with sink = NULL: keeps the load)
+}
+
 // Verification of a window's scan records in one launch: counts the records
 // that are not BB_FRAME_OK, or -- for the first `nstrict` of them -- whose time
 // index is not first_index + i / recs_per_index (frames out of place).  The

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define BB_ABI_VERSION 6   /* 6 (round 6): bb_mark5b_locate_stream */   /* 5 (round 6): bb_arena_stats grew (first_probe_gbps .. second_chance_wins) */   /* 4 (round 5): bb_arena_prepare, bb_arena_owns, bb_arena_stats grew (va_ranges .. prepare_wait_ms); the `reserved` words of the scan parameter blocks got meanings whose zero is the old behaviour (bb_vdif_scan_params.set_nframes, bb_mark5b_/bb_mark4_scan_params.by_position): same layout  */   /* 3 (round 4): bb_copy_frames; bb_arena_stats grew va_reserved / va_used; bb_tune knobs are thread-local */   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
+#define BB_ABI_VERSION 7   /* 7 (round 6): bb_touch; the *_read_window calls read small windows through first */   /* 6 (round 6): bb_mark5b_locate_stream */   /* 5 (round 6): bb_arena_stats grew (first_probe_gbps .. second_chance_wins) */   /* 4 (round 5): bb_arena_prepare, bb_arena_owns, bb_arena_stats grew (va_ranges .. prepare_wait_ms); the `reserved` words of the scan parameter blocks got meanings whose zero is the old behaviour (bb_vdif_scan_params.set_nframes, bb_mark5b_/bb_mark4_scan_params.by_position): same layout  */   /* 3 (round 4): bb_copy_frames; bb_arena_stats grew va_reserved / va_used; bb_tune knobs are thread-local */   /* 2: bb_tiled_params grew (npol_stored, pol_first, d_chan_map) */
 
 /* error codes (negative errno values) */
 #define BB_OK        0
@@ -202,6 +202,19 @@ int bb_mark5b_scan(const void *d_buf, size_t nbytes,
  * bb_mark5b_scan for frames at explicit, possibly odd, offsets
  * (params->first_offset is ignored).
  */
+/*
+ * Reads [d_buf, d_buf + nbytes) once, with plain loads, and keeps nothing (round 6).  What a
+ * launch reads that way stays in the device's 256 MiB memory-side cache for the launches right
+ * behind it -- the nontemporal stores of a decode do not push it out -- so a decode whose input
+ * was just read through takes it from there: the decode launch of 2^13-2^15 frames of 8 KiB runs
+ * 11-16 % faster (profiles/r06cp_exp_tiles_by_size_same_window.log against r06cq_).  The three
+ * *_read_window calls do this themselves for windows of 16-256 MiB, on the decode's stream,
+ * next to the scan on its own: a whole read() gains 4-7 % (profiles/r06cx_, r06cy_exp_touch_read.log;
+ * BB_TUNE_TOUCH_MIB, include/bbdecode_tune.h).  No reference
+ * counterpart: the reference reads a file through the page cache (base/base.py:919-969).
+ */
+int bb_touch(const void *d_buf, size_t nbytes, void *stream);
+
 int bb_mark5b_locate(const void *d_buf, size_t nbytes, int64_t *d_offsets,
                      size_t cap, unsigned long long *d_count, void *stream);
 /* ... for ONE stream: word 1 of the header must also agree with `w1_pattern` under

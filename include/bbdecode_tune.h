@@ -38,6 +38,7 @@ extern "C" {
 #define BB_TUNE_SELECT_PICK    39   /* folded channel subsets: 1 (default) = k_decode_pick (one work item per wave, direct-to-LDS 16-byte loads) for selections of up to an eighth of a thread sample where its conditions hold, 2 = wherever they hold, 0 = k_decode_gather_select always */
 #define BB_TUNE_PICK_BYTES     40   /* k_decode_pick: payload bytes of all thread slots a wave stages per work item (1024..32768, default 4096) */
 #define BB_TUNE_VDIF8_LDS_GIB   41   /* VDIF 8-bit frames with contiguous output: GiB of payload from which a launch takes k_decode_flat_lds<8,LDS,glds> (16 tiles per wave) instead of the plain kernel (default 20; 0 = always, 100000 = never) */
+#define BB_TUNE_TOUCH_MIB       42   /* the three *_read_window calls read a window of 16 MiB up to this many MiB through once, on the decode's stream, before the decode takes it (default 256 = the memory-side cache; 0 = never) */
 #define BB_TUNE_ENCODE_STRIPES 38 /* k_encode_flat: log2 of the number of stripes the 16 KiB input runs of a launch are dealt over (the decode launches' work order, applied to the read stream): 0-10; default 0 = input order */
 
 /* Sets a knob for the CALLING HOST THREAD's later launches (the knobs are

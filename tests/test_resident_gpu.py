@@ -351,3 +351,35 @@ def test_side_stream_scan_soak(monkeypatch):
         del ref
     bad = np.nonzero(sums.cpu().numpy() != want)[0]
     assert len(bad) == 0, [(int(k), plan[k]) for k in bad[:5]]
+
+
+def test_the_pre_read_of_a_window_changes_nothing_but_time():
+    """Windows of 16-256 MiB are read through once before their decode (bb_touch inside the
+    *_read_window calls, BB_TUNE_TOUCH_MIB): the samples are the same with it, without it, and with
+    a limit that leaves this window out; bb_touch itself takes any range, aligned or not."""
+    import ctypes as C
+    import torch
+    import bench
+    import bb_oracle_np as orc
+    from baseband_amd import kernels, _lib, vdif
+    dev = torch.device('cuda')
+    nframes = 8192                                          # 63 MiB of file
+    image, h0 = bench.make_file_image_on_device(nframes, 77, 0, dev)
+    rate = bench.FRAME_RATE * bench.SPF
+    got = {}
+    try:
+        for knob in (256, 0, 32):
+            kernels.tune(_lib.TUNE_TOUCH_MIB, knob)
+            with vdif.open(image, 'rs', sample_rate=rate) as fh:
+                fh.seek(5 * bench.SPF)
+                got[knob] = fh.read(6000 * bench.SPF)
+        torch.cuda.synchronize()
+    finally:
+        kernels.tune(_lib.TUNE_TOUCH_MIB, -1)
+    assert torch.equal(got[256], got[0]) and torch.equal(got[32], got[0])
+    want = orc.decode_flat(image.view(torch.uint8).reshape(nframes, bench.FRAME_NBYTES)[5 + 17, 32:].cpu().numpy(), 'vdif', 2)
+    assert bits_equal(got[256][17 * bench.SPF:18 * bench.SPF].cpu().numpy(), want)
+    flat = image.view(torch.uint8).reshape(-1)
+    for lo, n in ((0, flat.numel()), (3, 1000), (16, 16), (5, 7), (0, 0)):
+        assert _lib.lib.bb_touch(C.c_void_p(flat.data_ptr() + lo), n, None) == 0
+    torch.cuda.synchronize()
