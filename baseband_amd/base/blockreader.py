@@ -171,6 +171,8 @@ class BlockStreamReader(GPUStreamReaderBase):
         return (self._file_offset0 + frame * self._frame_nbytes,
                 self._frame_nbytes)
 
+    read_through = True     # queue a read-only pass over a request's frames in front of their decode (kernels.touch)
+
     def read(self, count=None, out=None):
         if self.closed:
             raise ValueError("I/O operation on closed stream.")
@@ -192,13 +194,23 @@ class BlockStreamReader(GPUStreamReaderBase):
         direct = (isinstance(out, torch.Tensor) and out.is_cuda and out.is_contiguous()
                   and count > 0 and (not self.subset or self._within_np is not None)
                   and out.dtype == (torch.complex64 if self.complex_data else torch.float32))
+        pieces = self._pieces(self.offset, count)
+        image = self._image()
+        resident = self._resident_bytes()
+        if resident is not None and pieces and self.read_through:
+            # The frames of this request are in HBM: a pass that only reads them is queued NOW,
+            # before the output is drawn and the launches are prepared; the decode behind it finds
+            # its input -- a fifth of an int8 decode's traffic -- in the memory-side cache and runs
+            # 20-25 % faster (profiles/r06dm_exp_cached_input_int8.log)
+            lo = self._frame_span(pieces[0][0])[0]
+            last_lo, last_n = self._frame_span(pieces[-1][0])
+            hi = min(last_lo + last_n, resident.numel())
+            if 2 * count * self._frame_nbytes >= (hi - lo) * self.samples_per_frame:    # (most of it is wanted)
+                kernels.touch(resident, lo, hi - lo)
         if direct:
             flat = (torch.view_as_real(out) if self.complex_data else out).reshape(-1)
         else:
             flat = empty_output(count * row, torch.float32)
-        pieces = self._pieces(self.offset, count)
-        image = self._image()
-        resident = self._resident_bytes()
         # merge consecutive frames that use the same row range into runs
         runs = []
         for f, a, b in pieces:

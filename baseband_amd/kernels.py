@@ -4,6 +4,7 @@ PyTorch is used only as the device allocator / stream provider; every
 computation is a libbbdecode kernel launched on torch's current HIP stream.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -525,6 +526,18 @@ def copy_frames(dbuf, nframes, nbytes_per_frame, src0=0, src_stride=0, out=None)
     check(lib.bb_copy_frames(_ptr(dbuf), dbuf.numel(), nframes, nbytes_per_frame, src0, src_stride,
                              _ptr(tgt.use), tgt.use.numel() * 4, _stream(dbuf)), 'bb_copy_frames')
     return tgt.done()
+
+
+TOUCH_MIN_BYTES = 16 << 20
+TOUCH_MAX_BYTES = max(0, int(os.environ.get('BB_TOUCH_MIB', '256') or 256)) << 20
+
+
+def touch(dbuf, lo, nbytes):
+    """Queue a pass that reads bytes [lo, lo + nbytes) of the uint8 device tensor `dbuf` once
+    and keeps nothing (bb_touch): a decode of those bytes queued right behind it finds them in
+    the device's memory-side cache.  Does nothing outside 16 MiB .. BB_TOUCH_MIB (256)."""
+    if TOUCH_MIN_BYTES <= nbytes <= TOUCH_MAX_BYTES:
+        check(lib.bb_touch(C.c_void_p(dbuf.data_ptr() + int(lo)), int(nbytes), _stream(dbuf)), 'bb_touch')
 
 
 def select_supported(bps, chunk, nslot, nwithin, payload_nbytes=None):

@@ -383,3 +383,38 @@ def test_the_pre_read_of_a_window_changes_nothing_but_time():
     for lo, n in ((0, flat.numel()), (3, 1000), (16, 16), (5, 7), (0, 0)):
         assert _lib.lib.bb_touch(C.c_void_p(flat.data_ptr() + lo), n, None) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('fmt,name', [('guppi', 'sample_puppi.raw'), ('dada', 'sample.dada')])
+def test_block_readers_queue_a_read_only_pass_that_changes_nothing(monkeypatch, fmt, name):
+    """GUPPI / DADA streams in HBM queue `kernels.touch` over the frames of a request in front of
+    their decode (base/blockreader.py `read_through`; an int8 decode whose input comes out of the
+    memory-side cache runs 20-25 % faster): the samples are the same with and without; requests that
+    want less than half of the frames they touch do not queue one."""
+    import torch
+    import baseband_amd
+    from baseband_amd import kernels
+    mod = getattr(baseband_amd, fmt)
+    raw = torch.from_numpy(np.fromfile(golden_path('samples/' + name), np.uint8)).cuda()
+    calls = []
+    real = kernels.touch
+    monkeypatch.setattr(kernels, 'TOUCH_MIN_BYTES', 0)
+    monkeypatch.setattr(kernels, 'touch', lambda dbuf, lo, n: (calls.append((int(lo), int(n))), real(dbuf, lo, n))[1])
+    got = {}
+    for on in (True, False):
+        with mod.open(raw, 'rs') as fh:
+            fh.read_through = on
+            whole = fh.read()
+            fh.seek(fh.samples_per_frame // 4)
+            part = fh.read(3 * fh.samples_per_frame // 4)
+            n_before = len(calls)
+            fh.seek(3)
+            few = fh.read(5)
+            assert len(calls) == n_before                   # (five samples of a frame: not worth a pass)
+            got[on] = (whole, part, few)
+        if on:
+            assert len(calls) >= 2 and all(n > 0 for _, n in calls)
+            n_on = len(calls)
+    assert len(calls) == n_on                               # (none with read_through off)
+    for a, b in zip(got[True], got[False]):
+        assert torch.equal(a, b)
