@@ -529,7 +529,15 @@ def copy_frames(dbuf, nframes, nbytes_per_frame, src0=0, src_stride=0, out=None)
 
 
 TOUCH_MIN_BYTES = 16 << 20
-TOUCH_MAX_BYTES = max(0, int(os.environ.get('BB_TOUCH_MIB', '256') or 256)) << 20
+def _touch_max_bytes():
+    try:                                # (as the library reads it: csrc/bbdecode.hip touch_mib_default)
+        mib = int(os.environ.get('BB_TOUCH_MIB', '') or 256)
+    except ValueError:
+        mib = 256
+    return (256 if mib < 0 else mib) << 20
+
+
+TOUCH_MAX_BYTES = _touch_max_bytes()
 
 
 def touch(dbuf, lo, nbytes):
