@@ -179,7 +179,7 @@ thread_local bb_knob g_tune_rows_tiles{8};          // tiles per work item of k_
 thread_local bb_knob g_tune_lut_tpw{0};             // tiles per wave and work item of the byte-table kernels; 0 = by kernel
 static int touch_mib_default()                      // BB_TOUCH_MIB in the environment: the default of the knob below, for whole-process A/Bs
 {
-    static const int v = [] { const char *e = getenv("BB_TOUCH_MIB"); const int x = e && *e ? atoi(e) : 256; return x < 0 ? 256 : x; }();
+    static const int v = [] { const char *e = getenv("BB_TOUCH_MIB"); char *end = nullptr; const long x = e && *e ? strtol(e, &end, 10) : 256; return (e && *e && end == e) || x < 0 || x > (1 << 20) ? 256 : (int)x; }();
     return v;
 }
 thread_local bb_knob g_tune_touch_mib{touch_mib_default()};   // a read window of at most this many MiB is read through once before its decode (0 = never)
